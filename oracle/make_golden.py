@@ -1,0 +1,226 @@
+"""TEST INFRASTRUCTURE ONLY.  Generates tests/golden/* by running the REAL reference (imported read-only
+from /root/reference, see oracle/ref_import.py) on CPU in fp32 with the deterministic synthetic weights of
+forge_amd.synth.  Run in the authoring container only:
+
+    python -m oracle.make_golden [--full]
+
+`--full` additionally runs BASELINE config 0 (SD1.5 512x512, B=1, 20-step Euler, CFG 7) end to end
+(~1-2 min) and stores its final latent + decoded uint8 image.
+The fixtures are what the GPU box checks against (the reference cannot travel there).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import forge_amd  # noqa: E402
+from forge_amd import synth  # noqa: E402
+from oracle import ref_import  # noqa: E402
+from oracle.rng import ImageRNG  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _inputs(cfg, b, hw, seed):
+    g = torch.Generator("cpu").manual_seed(seed)
+    x = torch.randn(b, cfg["in_channels"], hw, hw, generator=g)
+    ctx = torch.randn(b, 77, cfg["context_dim"], generator=g)
+    y = torch.randn(b, cfg["adm_in_channels"], generator=g) if cfg.get("adm_in_channels") else None
+    t = torch.tensor([981.0, 401.0, 37.0, 3.0][:b])
+    return x, t, ctx, y
+
+
+def gen_keys():
+    ref = ref_import.load_reference()
+    out = {}
+    for name, cfg in (("sd15", synth.SD15_UNET_CONFIG), ("sdxl", synth.SDXL_UNET_CONFIG),
+                      ("tiny_sd15", synth.TINY_SD15_UNET_CONFIG), ("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG)):
+        with torch.device("meta"):
+            net = ref_import.build_ref_unet(cfg)
+        out[name] = {k: list(v.shape) for k, v in net.state_dict().items()}
+    for name, cfg in (("vae", synth.SD15_VAE_CONFIG), ("tiny_vae", synth.TINY_VAE_CONFIG)):
+        with torch.device("meta"):
+            vae = ref_import.build_ref_vae(cfg)
+        out[name] = {k: list(v.shape) for k, v in vae.state_dict().items()
+                     if k.startswith("decoder.") or k.startswith("post_quant_conv.")}
+    with open(os.path.join(GOLD, "param_shapes.json"), "w") as f:
+        json.dump(out, f)
+    print("param_shapes.json", {k: len(v) for k, v in out.items()})
+
+
+def gen_unet(name, cfg, b=2, hw=16):
+    sd = synth.synth_unet_state_dict(cfg, seed=0)
+    net = ref_import.build_ref_unet(cfg, sd)
+    x, t, ctx, y = _inputs(cfg, b, hw, seed=11)
+    with torch.no_grad():
+        eps = net(x.clone(), t, context=ctx, y=y, transformer_options={})
+    torch.save({"x": x, "t": t, "ctx": ctx, "y": y, "eps": eps, "hw": hw}, os.path.join(GOLD, f"{name}_unet_fwd.pt"))
+    print(name, "unet fwd", tuple(eps.shape), float(eps.std()))
+    return net, sd
+
+
+def gen_vae(name, cfg, b=2, hw=8):
+    sd = synth.synth_vae_decoder_state_dict(cfg, seed=1)
+    vae = ref_import.build_ref_vae(cfg)
+    missing = vae.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys, missing.unexpected_keys
+    assert all(k.startswith(("encoder.", "quant_conv.")) for k in missing.missing_keys)
+    g = torch.Generator("cpu").manual_seed(5)
+    z = torch.randn(b, 4, hw, hw, generator=g)
+    with torch.no_grad():
+        out = vae.decode(z)
+        # decode_first_stage (diffusion_engine/sd15.py:80-84) on latents `z*0.5`
+        lat = z * 0.5
+        dec = torch.clamp((vae.decode(vae.process_out(lat)) + 1.0) / 2.0, 0.0, 1.0) * 2.0 - 1.0
+    torch.save({"z": z, "decode": out, "lat": lat, "decode_first_stage": dec}, os.path.join(GOLD, f"{name}_decode.pt"))
+    print(name, "decode", tuple(out.shape), float(out.std()))
+
+
+class _Hijack:
+    """modules/sd_samplers_common.py:214-235 TorchHijack stand-in."""
+
+    def __init__(self, rng):
+        self.rng = rng
+
+    def __getattr__(self, item):
+        if item == "randn_like":
+            return lambda x: self.rng.next()
+        return getattr(torch, item)
+
+
+def ref_sample(net, cfg, cond, uncond, seeds, hw, steps, sampler, cfg_scale=7.0, source="CPU", trace=None):
+    """Reference k-diffusion loop + reference sampling_function + reference UNet (CPU fp32)."""
+    ref = ref_import.load_reference()
+    pred = ref_import.build_ref_predictor()
+    den = ref_import.RefDenoiser(net, pred, seeds)
+    rng = ImageRNG((cfg["in_channels"], hw, hw), seeds, source)
+    x = rng.next()
+    linker = den.inner_model
+    if sampler == "DPM++ 2M":
+        sigmas = ref.kd_sampling.get_sigmas_karras(n=steps, sigma_min=linker.sigmas[0].item(),
+                                                   sigma_max=linker.sigmas[-1].item(), device="cpu")
+        fn = ref.kd_sampling.sample_dpmpp_2m
+    else:
+        sigmas = linker.get_sigmas(steps)
+        fn = ref.kd_sampling.sample_euler if sampler == "Euler" else ref.kd_sampling.sample_euler_ancestral
+    x = pred.noise_scaling(sigmas[0], x, torch.zeros_like(x), max_denoise=False)
+    ref.kd_sampling.torch = _Hijack(rng)
+    ref.sampling_function.sampling_prepare(den.patcher, x=x)
+    extra = {"cond": cond, "uncond": uncond, "cond_scale": cfg_scale, "s_min_uncond": 0.0, "image_cond": None}
+
+    def cb(d):
+        if trace is not None:
+            trace.append(d["denoised"].clone())
+    try:
+        out = fn(den, x, sigmas, extra_args=extra, callback=cb, disable=True)
+    finally:
+        ref.kd_sampling.torch = torch
+        ref.sampling_function.sampling_cleanup(den.patcher)
+    return out, sigmas
+
+
+def gen_samples(name, cfg, net, b=2, hw=16):
+    adm = cfg.get("adm_in_channels")
+    c, uc = synth.synth_conditioning(b, cfg["context_dim"], adm, seed=1234)
+    if adm:
+        c, uc = ref_import.SdxlCond(c), ref_import.SdxlCond(uc)
+    seeds = [1000 + i for i in range(b)]
+    res = {"seeds": seeds, "hw": hw}
+    for sampler, steps in (("Euler", 6), ("Euler a", 6), ("DPM++ 2M", 7)):
+        trace = []
+        lat, sigmas = ref_sample(net, cfg, c, uc, seeds, hw, steps, sampler, trace=trace)
+        res[sampler] = {"steps": steps, "latent": lat, "sigmas": sigmas, "denoised0": trace[0], "denoised_last": trace[-1]}
+        print(name, sampler, float(lat.std()))
+    # cond_scale == 1 shortcut (sampling_function.py:295-298)
+    lat, _ = ref_sample(net, cfg, c, uc, seeds, hw, 3, "Euler", cfg_scale=1.0)
+    res["Euler_cfg1"] = {"steps": 3, "latent": lat}
+    torch.save(res, os.path.join(GOLD, f"{name}_samples.pt"))
+
+
+def gen_schedules():
+    ref = ref_import.load_reference()
+    pred = ref_import.build_ref_predictor()
+    linker = ref.kd_external.ForgeScheduleLinker(pred)
+    sig = torch.tensor([14.6146, 7.3, 1.0, 0.5, 0.0292, 0.03, 100.0])
+    out = {
+        "table": pred.sigmas.clone(),
+        "linker_20": linker.get_sigmas(20), "linker_30": linker.get_sigmas(30), "linker_6": linker.get_sigmas(6),
+        "karras_30": ref.kd_sampling.get_sigmas_karras(30, pred.sigmas[0].item(), pred.sigmas[-1].item()),
+        "karras_7": ref.kd_sampling.get_sigmas_karras(7, pred.sigmas[0].item(), pred.sigmas[-1].item()),
+        "timestep_in": sig, "timestep_out": pred.timestep(sig),
+        "sigma_of_t": pred.sigma(torch.tensor([0.0, 0.5, 10.25, 998.9, 999.0])),
+        "ancestral": torch.tensor([list(map(float, ref.kd_sampling.get_ancestral_step(torch.tensor(a), torch.tensor(b))))
+                                   for a, b in ((14.6, 9.7), (1.0, 0.5), (0.1, 0.0292))]),
+        "philox_seed0_3x4": torch.from_numpy(ref.rng_philox.Generator(0).randn((3, 4))),
+    }
+    g = ref.rng_philox.Generator(12345)
+    out["philox_seed12345_a"] = torch.from_numpy(g.randn((4, 8, 8)))
+    out["philox_seed12345_b"] = torch.from_numpy(g.randn((4, 8, 8)))
+    torch.save(out, os.path.join(GOLD, "schedules.pt"))
+    print("schedules", float(pred.sigmas[0]), float(pred.sigmas[-1]))
+
+
+def gen_full_sd15():
+    """BASELINE config 0: SD1.5 random-init, 512x512, B=1, 20-step Euler, CFG 7 (reference, CPU fp32)."""
+    cfg = synth.SD15_UNET_CONFIG
+    t0 = time.time()
+    sd = synth.synth_unet_state_dict(cfg, seed=0)
+    net = ref_import.build_ref_unet(cfg, sd)
+    del sd
+    c, uc = synth.synth_conditioning(1, cfg["context_dim"], None, seed=1234)
+    x, t, ctx, _ = _inputs(cfg, 1, 64, seed=11)
+    with torch.no_grad():
+        eps = net(x.clone(), t, context=ctx, transformer_options={})
+    print("sd15 fwd", time.time() - t0, float(eps.std()))
+    t1 = time.time()
+    trace = []
+    lat, sigmas = ref_sample(net, cfg, c, uc, [42], 64, 20, "Euler", trace=trace)
+    t_sample = time.time() - t1
+    del net
+    vcfg = synth.SD15_VAE_CONFIG
+    vsd = synth.synth_vae_decoder_state_dict(vcfg, seed=1)
+    vae = ref_import.build_ref_vae(vcfg)
+    vae.load_state_dict(vsd, strict=False)
+    t2 = time.time()
+    with torch.no_grad():
+        dec = torch.clamp((vae.decode(vae.process_out(lat)) + 1.0) / 2.0, 0.0, 1.0) * 2.0 - 1.0
+    t_dec = time.time() - t2
+    img = (255.0 * torch.clamp((dec + 1.0) / 2.0, 0.0, 1.0).movedim(1, -1)).numpy().astype(np.uint8)
+    torch.save({"x": x, "t": t, "ctx": ctx, "eps": eps, "seed": 42, "latent": lat, "sigmas": sigmas,
+                "denoised0": trace[0], "image_u8": torch.from_numpy(img),
+                "cpu_seconds": {"sample20": t_sample, "decode": t_dec, "threads": torch.get_num_threads()}},
+               os.path.join(GOLD, "sd15_config0.pt"))
+    print("sd15 config0: sampler %.1fs (%.3f it/s), decode %.1fs, latent std %.3f" % (t_sample, 20 / t_sample, t_dec, float(lat.std())))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--full", action="store_true")
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    torch.manual_seed(0)
+    if a.only in ("", "keys"):
+        gen_keys()
+    if a.only in ("", "schedules"):
+        gen_schedules()
+    if a.only in ("", "tiny"):
+        net, _ = gen_unet("tiny_sd15", synth.TINY_SD15_UNET_CONFIG)
+        gen_samples("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
+        net, _ = gen_unet("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG)
+        gen_samples("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG, net)
+        gen_vae("tiny_vae", synth.TINY_VAE_CONFIG)
+    if a.full or a.only == "full":
+        gen_full_sd15()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,57 @@
+"""TEST INFRASTRUCTURE ONLY (CPU oracle).
+
+End-to-end txt2img restatement tying the pieces together the way the reference's call surface does:
+  modules/processing.py:852-1040 (seeds seed+i :894, ImageRNG :944, p.sample :990, decode :1010-1013),
+  :1342-1391 (x = rng.next(); sampler.sample), modules/sd_samplers_kdiffusion.py:81-134 (sigma choice),
+  :196-244 (x * sigma_0 via noise_scaling :207; launch the k-diffusion loop on CFGDenoiser).
+"""
+import torch
+
+from . import sampling
+from .cfg import cfg_denoise
+from .k_prediction import Predictor, apply_model
+from .rng import ImageRNG
+from .unet import unet_forward
+from .vae import decode_first_stage, to_uint8_images
+
+
+def get_sigmas(predictor, sampler_name, steps):
+    # sd_samplers_kdiffusion.py:81-134 with scheduler "Automatic": per-sampler default (:14-34)
+    _, sched = sampling.SAMPLERS[sampler_name]
+    if sched == "karras":
+        return sampling.get_sigmas_karras(steps, predictor.sigmas[0].item(), predictor.sigmas[-1].item())
+    return sampling.get_sigmas_linker(predictor, steps)
+
+
+@torch.no_grad()
+def txt2img_latents(unet_sd, unet_cfg, cond, uncond, seeds, height, width, steps, sampler_name="Euler",
+                    cfg_scale=7.0, noise_source="CPU", trace=None):
+    pred = Predictor()
+    b = len(seeds)
+    rng = ImageRNG((unet_cfg["in_channels"], height // 8, width // 8), seeds, noise_source)
+    x = rng.next()
+
+    def unet_fn(xc, t, ctx, y):
+        return unet_forward(unet_sd, unet_cfg, xc, t, ctx, y)
+
+    def denoiser(xx, sigma):
+        den, _, _ = cfg_denoise(lambda a, s, c, y: apply_model(unet_fn, pred, a, s, c, y), xx, sigma, uncond, cond, cfg_scale)
+        if trace is not None:
+            trace.append(den.clone())
+        return den
+
+    sigmas = get_sigmas(pred, sampler_name, steps)
+    x = pred.noise_scaling(sigmas[0], x, torch.zeros_like(x))
+    fn, _ = sampling.SAMPLERS[sampler_name]
+    if sampler_name == "Euler":
+        return fn(denoiser, x, sigmas, noise_fn=rng.next), sigmas
+    if sampler_name == "Euler a":
+        return fn(denoiser, x, sigmas, noise_fn=rng.next), sigmas
+    return fn(denoiser, x, sigmas), sigmas
+
+
+@torch.no_grad()
+def txt2img(unet_sd, unet_cfg, vae_sd, vae_cfg, cond, uncond, seeds, height, width, steps, **kw):
+    lat, _ = txt2img_latents(unet_sd, unet_cfg, cond, uncond, seeds, height, width, steps, **kw)
+    dec = decode_first_stage(vae_sd, lat, vae_cfg.get("scaling_factor", 0.18215), vae_cfg.get("shift_factor", 0.0) or 0.0)
+    return lat, dec, to_uint8_images(dec)

@@ -1,0 +1,130 @@
+"""Model configs of the BASELINE.json workloads and deterministic synthetic ("random-init") weights.
+
+There are no checkpoints in this environment, so every BASELINE config runs on random-init weights
+(SURVEY.md §8d).  The weights are a pure function of (parameter name, shape, seed) so that the CPU
+oracle, the real reference (when present) and the MI355X executor can be handed bit-identical fp32
+state dicts anywhere, without relying on module construction order.
+
+Init law (documented gain-scaled variant of torch's default):
+  * conv / linear weight  ~ N(0, gain^2 / fan_in),   gain = 1/sqrt(3)  (variance of torch's default
+    kaiming_uniform(a=sqrt(5)) = U(-1/sqrt(fan_in), 1/sqrt(fan_in)))
+  * conv / linear bias    ~ N(0, gain^2 / fan_in)
+  * norm weight = 1 + 0.1*N(0,1), norm bias = 0.1*N(0,1)   (so the affine path is exercised)
+numpy's PCG64 + ziggurat stream is platform-independent, unlike vectorised torch CPU randn.
+"""
+import zlib
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from .backend.nn.layout import unet_param_shapes, vae_decoder_param_shapes
+
+# LDM-style unet_config dicts (parameter counts 859.52 M / 2567.46 M verified against
+# the reference module in tests/test_oracle_vs_reference.py).
+SD15_UNET_CONFIG = dict(
+    in_channels=4, model_channels=320, out_channels=4, num_res_blocks=[2, 2, 2, 2], channel_mult=(1, 2, 4, 4),
+    num_heads=8, use_spatial_transformer=True, transformer_depth=[1, 1, 1, 1, 1, 1, 0, 0],
+    transformer_depth_middle=1, transformer_depth_output=[1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0],
+    context_dim=768, use_linear_in_transformer=False)
+
+SDXL_UNET_CONFIG = dict(
+    in_channels=4, model_channels=320, out_channels=4, num_res_blocks=[2, 2, 2], channel_mult=(1, 2, 4),
+    num_head_channels=64, use_spatial_transformer=True, transformer_depth=[0, 0, 2, 2, 10, 10],
+    transformer_depth_middle=10, transformer_depth_output=[0, 0, 0, 2, 2, 2, 10, 10, 10],
+    context_dim=2048, use_linear_in_transformer=True, adm_in_channels=2816, num_classes="sequential")
+
+# Small configs with the same block grammar (used by the parity tests; finish in seconds on CPU).
+TINY_SD15_UNET_CONFIG = dict(
+    in_channels=4, model_channels=64, out_channels=4, num_res_blocks=[1, 1, 1], channel_mult=(1, 2, 2),
+    num_heads=2, use_spatial_transformer=True, transformer_depth=[1, 1, 0],
+    transformer_depth_middle=1, transformer_depth_output=[1, 1, 1, 1, 0, 0],
+    context_dim=128, use_linear_in_transformer=False)
+# transformer_depth_output is consumed with pop() from the END (unet.py:649): listed low-res-last.
+
+TINY_SDXL_UNET_CONFIG = dict(
+    in_channels=4, model_channels=64, out_channels=4, num_res_blocks=[1, 1], channel_mult=(1, 2),
+    num_head_channels=64, use_spatial_transformer=True, transformer_depth=[0, 2],
+    transformer_depth_middle=2, transformer_depth_output=[0, 0, 2, 2],
+    context_dim=128, use_linear_in_transformer=True, adm_in_channels=192, num_classes="sequential")
+
+SD15_VAE_CONFIG = dict(in_channels=3, out_channels=3, block_out_channels=(128, 256, 512, 512), layers_per_block=2,
+                       latent_channels=4, scaling_factor=0.18215, shift_factor=0.0,
+                       use_quant_conv=True, use_post_quant_conv=True)
+SDXL_VAE_CONFIG = dict(SD15_VAE_CONFIG, scaling_factor=0.13025)
+TINY_VAE_CONFIG = dict(in_channels=3, out_channels=3, block_out_channels=(64, 128), layers_per_block=1,
+                       latent_channels=4, scaling_factor=0.18215, shift_factor=0.0,
+                       use_quant_conv=True, use_post_quant_conv=True)
+
+SCHEDULE = dict(beta_schedule="linear", linear_start=0.00085, linear_end=0.012, timesteps=1000,
+                prediction_type="epsilon")
+
+DEFAULT_GAIN = 1.0 / np.sqrt(3.0)
+
+
+def _is_norm(name, shape):
+    if len(shape) != 1:
+        return False
+    parts = name.split(".")
+    return any(p.startswith("norm") for p in parts) or parts[-2] == "0" and (
+        "in_layers" in parts or "out_layers" in parts or parts[0] == "out")
+
+
+def synth_tensor(name, shape, seed=0, gain=DEFAULT_GAIN):
+    rng = np.random.Generator(np.random.PCG64([seed, zlib.crc32(name.encode())]))
+    z = rng.standard_normal(shape, dtype=np.float32)
+    if _is_norm(name, shape):
+        if name.endswith(".weight"):
+            z = 1.0 + 0.1 * z
+        else:
+            z = 0.1 * z
+    else:
+        if name.endswith(".bias"):
+            # the sibling weight's fan_in is not known from the bias alone; callers pass it via shape hints
+            raise ValueError("bias needs fan_in; use synth_state_dict")
+        fan_in = int(np.prod(shape[1:]))
+        z *= gain / np.sqrt(fan_in)
+    return torch.from_numpy(np.ascontiguousarray(z, dtype=np.float32))
+
+
+def synth_state_dict(shapes, seed=0, gain=DEFAULT_GAIN, residual_gain=1.0):
+    """fp32 CPU state dict for `shapes` (name -> shape).  `residual_gain` scales the last projection of
+    every residual branch (documented knob to keep random-init nets well conditioned; 1.0 = off)."""
+    sd = OrderedDict()
+    branch_out = (".out_layers.3.", ".to_out.0.", ".ff.net.2.", ".proj_out.", ".conv2.")
+    for name, shape in shapes.items():
+        if _is_norm(name, shape):
+            sd[name] = synth_tensor(name, shape, seed)
+            continue
+        if name.endswith(".bias"):
+            wshape = shapes[name[:-5] + ".weight"]
+            fan_in = int(np.prod(wshape[1:]))
+            rng = np.random.Generator(np.random.PCG64([seed, zlib.crc32(name.encode())]))
+            z = rng.standard_normal(shape, dtype=np.float32) * (gain / np.sqrt(fan_in))
+            t = torch.from_numpy(z.astype(np.float32))
+        else:
+            t = synth_tensor(name, shape, seed, gain)
+        if residual_gain != 1.0 and any(b in name for b in branch_out):
+            t = t * residual_gain
+        sd[name] = t
+    return sd
+
+
+def synth_unet_state_dict(cfg, seed=0, **kw):
+    return synth_state_dict(unet_param_shapes(cfg), seed=seed, **kw)
+
+
+def synth_vae_decoder_state_dict(cfg, seed=1, **kw):
+    return synth_state_dict(vae_decoder_param_shapes(cfg), seed=seed, **kw)
+
+
+def synth_conditioning(batch, context_dim, adm_in_channels=None, tokens=77, seed=1234):
+    """cond / uncond tensors of the shapes the text encoders would produce."""
+    rng = np.random.Generator(np.random.PCG64([seed, 7]))
+    c = torch.from_numpy(rng.standard_normal((batch, tokens, context_dim), dtype=np.float32))
+    uc = torch.from_numpy(rng.standard_normal((batch, tokens, context_dim), dtype=np.float32))
+    if adm_in_channels is None:
+        return c, uc
+    y = torch.from_numpy(rng.standard_normal((batch, adm_in_channels), dtype=np.float32))
+    uy = torch.from_numpy(rng.standard_normal((batch, adm_in_channels), dtype=np.float32))
+    return {"crossattn": c, "vector": y}, {"crossattn": uc, "vector": uy}

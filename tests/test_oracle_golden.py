@@ -1,0 +1,107 @@
+"""CPU: the torch-fp32 oracle (oracle/) reproduces the fixtures generated from the REAL reference
+(tests/golden/*, made by oracle/make_golden.py).  This is what pins the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import forge_amd  # noqa: F401
+from forge_amd import synth
+from forge_amd.backend.nn.layout import unet_param_shapes, vae_decoder_param_shapes
+from oracle import pipeline, sampling
+from oracle.k_prediction import Predictor
+from oracle.rng import PhiloxGenerator
+from oracle.unet import unet_forward
+from oracle.vae import decode_first_stage, vae_decode
+
+from conftest import GOLDEN, load_golden
+
+def max_rel(a, b):
+    return float((a - b).abs().max() / b.abs().max())
+
+
+TINY = {"tiny_sd15": synth.TINY_SD15_UNET_CONFIG, "tiny_sdxl": synth.TINY_SDXL_UNET_CONFIG}
+
+
+def test_param_shapes_match_reference():
+    ref = json.load(open(os.path.join(GOLDEN, "param_shapes.json")))
+    for name, cfg in (("sd15", synth.SD15_UNET_CONFIG), ("sdxl", synth.SDXL_UNET_CONFIG), *TINY.items()):
+        ours = {k: list(v) for k, v in unet_param_shapes(cfg).items()}
+        assert ours == ref[name], name
+    for name, cfg in (("vae", synth.SD15_VAE_CONFIG), ("tiny_vae", synth.TINY_VAE_CONFIG)):
+        ours = {k: list(v) for k, v in vae_decoder_param_shapes(cfg).items()}
+        assert ours == ref[name], name
+
+
+def test_schedules_and_predictor():
+    g = load_golden("schedules.pt")
+    p = Predictor()
+    assert torch.equal(p.sigmas, g["table"])
+    for n in (20, 30, 6):
+        torch.testing.assert_close(sampling.get_sigmas_linker(p, n), g[f"linker_{n}"], rtol=0, atol=0)
+    for n in (30, 7):
+        torch.testing.assert_close(sampling.get_sigmas_karras(n, p.sigmas[0].item(), p.sigmas[-1].item()),
+                                   g[f"karras_{n}"], rtol=0, atol=0)
+    assert torch.equal(p.timestep(g["timestep_in"]), g["timestep_out"])
+    torch.testing.assert_close(p.sigma(torch.tensor([0.0, 0.5, 10.25, 998.9, 999.0])), g["sigma_of_t"], rtol=0, atol=0)
+    for (a, b), want in zip(((14.6, 9.7), (1.0, 0.5), (0.1, 0.0292)), g["ancestral"]):
+        d, u = sampling.get_ancestral_step(torch.tensor(a), torch.tensor(b))
+        assert abs(float(d) - float(want[0])) < 1e-6 and abs(float(u) - float(want[1])) < 1e-6
+
+
+def test_philox_known_answer():
+    # modules/rng_philox.py:10-15 docstring vector (the only KAT the reference ships) + reference outputs
+    g = load_golden("schedules.pt")
+    doc = np.array([[-0.92466259, -0.42534415, -2.6438457, 0.14518388],
+                    [-0.12086647, -0.57972564, -0.62285122, -0.32838709],
+                    [-1.07454231, -0.36314407, -1.67105067, 2.26550497]], dtype=np.float32)
+    out = PhiloxGenerator(0).randn((3, 4))
+    np.testing.assert_allclose(out, doc, rtol=0, atol=2e-6)
+    np.testing.assert_array_equal(out, g["philox_seed0_3x4"].numpy())
+    gen = PhiloxGenerator(12345)
+    np.testing.assert_array_equal(gen.randn((4, 8, 8)), g["philox_seed12345_a"].numpy())
+    np.testing.assert_array_equal(gen.randn((4, 8, 8)), g["philox_seed12345_b"].numpy())
+
+
+@pytest.mark.parametrize("name", list(TINY))
+def test_unet_forward(name):
+    cfg = TINY[name]
+    g = load_golden(f"{name}_unet_fwd.pt")
+    sd = synth.synth_unet_state_dict(cfg, seed=0)
+    eps = unet_forward(sd, cfg, g["x"], g["t"], g["ctx"], g["y"])
+    torch.testing.assert_close(eps, g["eps"], rtol=1e-4, atol=1e-5)
+
+
+def test_vae_decode():
+    g = load_golden("tiny_vae_decode.pt")
+    sd = synth.synth_vae_decoder_state_dict(synth.TINY_VAE_CONFIG, seed=1)
+    torch.testing.assert_close(vae_decode(sd, g["z"]), g["decode"], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(decode_first_stage(sd, g["lat"], 0.18215), g["decode_first_stage"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", list(TINY))
+@pytest.mark.parametrize("sampler", ["Euler", "Euler a", "DPM++ 2M"])
+def test_sampler_runs(name, sampler):
+    cfg = TINY[name]
+    g = load_golden(f"{name}_samples.pt")
+    sd = synth.synth_unet_state_dict(cfg, seed=0)
+    b = len(g["seeds"])
+    c, uc = synth.synth_conditioning(b, cfg["context_dim"], cfg.get("adm_in_channels"), seed=1234)
+    trace = []
+    lat, sigmas = pipeline.txt2img_latents(sd, cfg, c, uc, g["seeds"], g["hw"] * 8, g["hw"] * 8,
+                                           g[sampler]["steps"], sampler_name=sampler, trace=trace)
+    torch.testing.assert_close(sigmas, g[sampler]["sigmas"], rtol=0, atol=0)
+    # latents/denoised are O(15) (sigma_max-scaled); fp32 reassociation (SDPA vs explicit softmax) shows at ~1e-5 relative
+    assert max_rel(trace[0], g[sampler]["denoised0"]) < 5e-5
+    assert max_rel(lat, g[sampler]["latent"]) < 2e-4
+
+
+def test_cfg_scale_one_shortcut():
+    cfg = TINY["tiny_sd15"]
+    g = load_golden("tiny_sd15_samples.pt")
+    sd = synth.synth_unet_state_dict(cfg, seed=0)
+    c, uc = synth.synth_conditioning(2, cfg["context_dim"], None, seed=1234)
+    lat, _ = pipeline.txt2img_latents(sd, cfg, c, uc, g["seeds"], 128, 128, 3, sampler_name="Euler", cfg_scale=1.0)
+    assert max_rel(lat, g["Euler_cfg1"]["latent"]) < 2e-4
