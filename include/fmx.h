@@ -1,0 +1,207 @@
+/* fmx.h -- C ABI of libfmx_gfx950.so: the MI355X (gfx950 / CDNA4) kernels behind Forge's txt2img
+ * denoising hot path.  Plain pointers and sizes only; no torch types.  Every pointer is a DEVICE
+ * pointer unless a comment says "host"; `stream` is a hipStream_t passed as void*.  All entry points
+ * are asynchronous on `stream`, allocate nothing, keep no global state besides the last-error
+ * string, and return 0 on success or a non-zero code (hipError_t value, or FMX_E_* below);
+ * `fmx_last_error()` describes the last failure on the calling thread.
+ *
+ * Reference interfaces replaced (the reference has no FFI; these are the Python call sites whose
+ * arithmetic PyTorch/ATen executes today -- see INTEGRATION.md for the binding on the Forge side):
+ *   fmx_gemm_conv_f16      F.linear  backend/operations.py:153,156 ; Conv2d._conv_forward :173,176 ;
+ *                          nearest Upsample+conv backend/nn/unet.py:340-355, backend/nn/vae.py:35-57 ;
+ *                          torch.cat([h, hsp]) backend/nn/unet.py:741 (two-source A operand) ;
+ *                          GEGLU backend/nn/unet.py:104-111 ; ResBlock emb add / skip add :469-478
+ *   fmx_attention_f16      attention_function  backend/attention.py:324-339 (and :37-93)
+ *   fmx_softmax_rows_f16   sim.softmax(dim=-1) backend/attention.py:85 (materialised-score variant)
+ *   fmx_groupnorm_*        F.group_norm backend/operations.py:308 (+ SiLU backend/nn/unet.py:394-398)
+ *   fmx_layernorm_f16      F.layer_norm backend/operations.py:327
+ *   fmx_timestep_embedding timestep_embedding backend/nn/unet.py:55-67
+ *   fmx_silu_f16           nn.SiLU in time_embed / emb_layers backend/nn/unet.py:519-523,415-418
+ *   fmx_unet_pack_input    KModel.apply_model input half  backend/modules/k_model.py:25-36
+ *   fmx_cfg_combine        calculate_denoised backend/modules/k_prediction.py:81-92 + CFG combine
+ *                          backend/sampling/sampling_function.py:276-288,312
+ *   fmx_sampler_*          k_diffusion/sampling.py:120-137 (Euler), :141-159 (Euler a), :649-671 (DPM++2M)
+ *   fmx_vae_pack_latent / fmx_vae_unpack_image
+ *                          process_out backend/nn/vae.py:315 ; clamp((y+1)/2) backend/patcher/vae.py:142
+ *   fmx_philox_randn       modules/rng_philox.py:32-102 ("NV" noise source)
+ */
+#ifndef FMX_H
+#define FMX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FMX_ABI_VERSION 1
+
+#define FMX_OK 0
+#define FMX_E_BADARG 10001   /* shape / alignment / null-pointer contract violated */
+#define FMX_E_UNSUPPORTED 10002
+
+/* activation / epilogue selector for fmx_gemm_conv_f16 */
+#define FMX_ACT_NONE 0
+#define FMX_ACT_GEGLU 1 /* weight rows interleaved [16 value | 16 gate] (see fmx_geglu_interleave_rows) */
+
+int fmx_abi_version(void);
+const char* fmx_last_error(void);
+/* host out-params: number of CUs, wave size, gcn arch name (e.g. "gfx950:sramecc+:xnack-") */
+int fmx_device_info(int* cu_count, int* wave_size, char* arch, int arch_len);
+
+/* ------------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution / linear on MFMA:   OUT[M, nout] = epilogue( A (*) W^T )
+ *   A operand : NHWC fp16 activations, optionally the channel-concatenation of two tensors
+ *               (a0 with c0 channels, a1 with c1 channels; c1 = 0 for a single source).
+ *               a?_stride = element stride between consecutive pixels (0 -> dense = c?).
+ *               With kh = 1 this is a plain matrix [M = n*h*w][c0+c1] (Linear / 1x1 conv).
+ *               If up_h > 0 the input is first nearest-resized from (h, w) to (up_h, up_w)
+ *               (src = floor(dst * in / out)) -- the fused Upsample -- and the conv runs on that.
+ *   W operand : fp16 [nout][kh*kh*(c0+c1)] row-major (ldw elements per row, 0 -> dense),
+ *               K ordered (ky, kx, channel).
+ *   epilogue  : acc*alpha (+ bias[col]) (+ rowvec[row / (oh*ow)][col]) -> act -> (+ residual[row][col])
+ *               stored as fp16 (or fp32 when out_f32 != 0) at out[row*ld_out + col].
+ *               act = FMX_ACT_GEGLU: out has nout/2 columns, value*gelu_erf(gate).
+ * Requirements: (c0+c1) % 64 == 0, c0 % 64 == 0, all tensors 16-byte aligned, strides % 8 == 0.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct fmx_gemm_args {
+  const void* a0;
+  const void* a1;
+  int32_t c0, c1;
+  int32_t a0_stride, a1_stride;
+  int32_t n, h, w;
+  int32_t oh, ow;
+  int32_t kh, stride, pad;
+  int32_t up_h, up_w;
+  const void* wgt;
+  int32_t ldw;
+  int32_t nout;
+  const void* bias;
+  const void* rowvec;
+  int32_t ld_rowvec;
+  const void* residual;
+  int32_t ld_res;
+  float alpha;
+  int32_t act;
+  void* out;
+  int32_t ld_out;
+  int32_t out_f32;
+  const void* zero_page; /* >= 256 bytes of zeros (device), used for padding taps / tails */
+} fmx_gemm_args;
+
+int fmx_gemm_conv_f16(const fmx_gemm_args* args /* host */, void* stream);
+
+/* Reorders the rows of a GEGLU projection weight [2*inner][k] (and bias [2*inner]) on the DEVICE into
+ * the [16 value rows | 16 gate rows] interleave FMX_ACT_GEGLU expects.  inner % 16 == 0. */
+int fmx_geglu_interleave_rows(const void* w_in, const void* b_in, void* w_out, void* b_out,
+                              int32_t inner, int32_t k, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused multi-head attention  O = softmax(Q K^T * scale) V   (flash-style, never materialises N x N)
+ *   q  : fp16, element (b, i, h, d) at q[b*q_bs + i*q_rs + h*dpad + d]
+ *   k  : fp16, element (b, j, h, d) at k[b*k_bs + j*k_rs + h*dpad + d]
+ *   vt : fp16 V TRANSPOSED, element (b, h, d, j) at vt[b*vt_bs + h*vt_hs + d*vt_ds + j]
+ *   o  : fp16, element (b, i, h, d) at o[b*o_bs + i*o_rs + h*dpad + d]
+ *   dpad in {48, 64, 80, 160}: head dim padded to a multiple of 16 with ZERO columns (rows in vt);
+ *   nk_pad = number of key columns present per (b,h,d) row of vt / rows of k (multiple of 64),
+ *   nk = number of valid keys (<= nk_pad, keys >= nk are masked out).  nq arbitrary.
+ *   All base pointers 16-byte aligned; strides % 8 == 0.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct fmx_attn_args {
+  const void* q;
+  const void* k;
+  const void* vt;
+  void* o;
+  int64_t q_bs, q_rs;
+  int64_t k_bs, k_rs;
+  int64_t vt_bs, vt_hs, vt_ds;
+  int64_t o_bs, o_rs;
+  int32_t batch, heads, nq, nk, nk_pad, dpad;
+  float scale;
+  const void* zero_page;
+} fmx_attn_args;
+
+int fmx_attention_f16(const fmx_attn_args* args /* host */, void* stream);
+
+/* In-place row softmax over fp16 scores: x[r*ld + j], j < ncols, r < nrows (fp32 math). */
+int fmx_softmax_rows_f16(void* x, int64_t nrows, int32_t ncols, int64_t ld, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GroupNorm over NHWC fp16 (optionally the channel-concat of two tensors), fp32 statistics.
+ *   stats : partial[n][chunk][c][2] fp32 workspace, nchunks chosen by the caller (<= 256)
+ *   apply : y = (x - mean_g) * rstd_g * gamma[c] + beta[c], optional SiLU, fp16 out [n][hw][c0+c1]
+ * (c0+c1) % groups == 0, c0 % 8 == 0, c1 % 8 == 0.
+ * ---------------------------------------------------------------------------------------------- */
+int fmx_groupnorm_stats_f16(const void* x0, const void* x1, int32_t c0, int32_t c1, int32_t n, int32_t hw,
+                            float* partial, int32_t nchunks, void* stream);
+int fmx_groupnorm_apply_f16(const void* x0, const void* x1, int32_t c0, int32_t c1, int32_t n, int32_t hw,
+                            const float* partial, int32_t nchunks, int32_t groups, float eps,
+                            const void* gamma, const void* beta, int32_t silu, void* y, void* stream);
+
+/* LayerNorm over the last dim of fp16 [rows][c] (c % 8 == 0, c <= 4096), fp32 two-pass statistics. */
+int fmx_layernorm_f16(const void* x, const void* gamma, const void* beta, void* y, int64_t rows, int32_t c,
+                      float eps, void* stream);
+
+/* emb[b][0:half] = cos(t[b]*f_k), emb[b][half:] = sin(t[b]*f_k), f_k = exp(-ln(max_period)*k/half); fp32 math,
+ * fp16 out [b][dim] (dim even). */
+int fmx_timestep_embedding(const float* t, void* emb, int32_t b, int32_t dim, float max_period, void* stream);
+
+int fmx_silu_f16(const void* x, void* y, int64_t n, void* stream);
+int fmx_cast_f32_to_f16(const float* x, void* y, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Sampler-side fused elementwise (fp32 latents NCHW [b][c][h][w], as the reference keeps them)
+ * ---------------------------------------------------------------------------------------------- */
+/* UNet input pack: xc = x / sqrt(sigma^2 + sigma_data^2) (k_prediction.py:74-79) for `reps` stacked copies
+ * of the batch (reps = 2 under CFG: [uncond ; cond]), written as the 3x3 im2col matrix of the first conv:
+ * out fp16 [reps*b*h*w][64], column (ky*3+kx)*c + ch for c*9 <= 64, zero elsewhere (zero padding taps). */
+int fmx_unet_pack_input(const float* x, const float* sigma, float sigma_data, int32_t b, int32_t c, int32_t h,
+                        int32_t w, int32_t reps, void* out, void* stream);
+
+/* eps: fp16 NHWC [reps*b][h][w][ld_eps>=c] from the UNet.  denoised = x - eps*sigma (eps-prediction).
+ * reps == 2: eps holds [uncond ; cond]; out = uncond + (cond - uncond)*cond_scale; reps == 1: out = cond.
+ * Optional outputs cond_pred / uncond_pred (fp32 NCHW, may be null). */
+int fmx_cfg_combine(const void* eps, int32_t ld_eps, const float* x, const float* sigma, int32_t b, int32_t c,
+                    int32_t h, int32_t w, int32_t reps, float cond_scale, float* denoised, float* cond_pred,
+                    float* uncond_pred, void* stream);
+
+/* x_out = x + (x - denoised)/sigma * (sigma_next - sigma)   (Euler; also the deterministic part of Euler a
+ * with sigma_next := sigma_down); if noise != null: x_out += noise * noise_scale. */
+int fmx_sampler_euler_step(const float* x, const float* denoised, float sigma, float sigma_next, const float* noise,
+                           float noise_scale, float* x_out, int64_t n, void* stream);
+/* x_out = a*x + bcoef*denoised + ccoef*old_denoised (old may be null when ccoef == 0)  (DPM++ 2M update) */
+int fmx_sampler_lincomb3(const float* x, const float* denoised, const float* old_denoised, float a, float bcoef,
+                         float ccoef, float* x_out, int64_t n, void* stream);
+int fmx_scale_f32(const float* x, float s, float* y, int64_t n, void* stream);
+
+/* VAE: latent fp32 NCHW [b][c][h][w] -> (z/scaling_factor + shift) as fp16 NHWC [b*h*w][ld] (ld >= c, rest 0) */
+int fmx_vae_pack_latent(const float* z, float scaling_factor, float shift, int32_t b, int32_t c, int32_t h, int32_t w,
+                        void* out, int32_t ld, void* stream);
+/* generic 3x3 im2col for tiny channel counts: x fp16 NHWC [n][h][w][ldx] (first c channels) -> out fp16
+ * [n*h*w][64] with column (ky*3+kx)*c + ch, c*9 <= 64 */
+int fmx_im2col3x3_smallc(const void* x, int32_t ldx, int32_t n, int32_t c, int32_t h, int32_t w, void* out, void* stream);
+/* VAE output: y fp16 NHWC [b*h*w][ld] (first c channels) -> clamp((y+1)/2, 0, 1) fp32 NHWC [b][h][w][c] */
+int fmx_vae_unpack_image(const void* y, int32_t ld, int64_t npix, int32_t c, float* out, void* stream);
+
+/* Philox4x32-10 + Box-Muller ("NV" noise source, modules/rng_philox.py:32-102): out[i], i < n, for
+ * counter (offset, 0, i, 0) and key = seed.  If raw_u32 != null also stores the 4 raw words per i. */
+int fmx_philox_randn(uint64_t seed, uint32_t offset, float* out, uint32_t* raw_u32, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * HIP-graph helpers: capture everything launched on `stream` between begin/end into an executable graph.
+ * ---------------------------------------------------------------------------------------------- */
+int fmx_graph_begin(void* stream);
+int fmx_graph_end(void* stream, void** graph_exec_out /* host */);
+int fmx_graph_launch(void* graph_exec, void* stream);
+int fmx_graph_destroy(void* graph_exec);
+
+/* HIP event timing on an arbitrary stream (torch.cuda.Event only sees torch's current stream). */
+int fmx_event_create(void** ev_out /* host */);
+int fmx_event_record(void* ev, void* stream);
+int fmx_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out /* host */); /* synchronises ev_stop */
+int fmx_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FMX_H */

@@ -1,0 +1,132 @@
+"""ctypes binding of libfmx_gfx950.so (C-ABI declared in include/fmx.h).
+
+The library is built in-tree by `build()` (hipcc --offload-arch=gfx950) so that it travels with the
+repo snapshot.  There is deliberately NO fallback: if the shared object is missing or a symbol is
+absent, importing `lib()` raises -- a Forge install that selected this backend must fail loudly rather
+than silently run PyTorch eager ops.
+"""
+import ctypes as C
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfmx_gfx950.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+_lock = threading.Lock()
+_lib = None
+
+
+class FmxError(RuntimeError):
+    pass
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("a0", C.c_void_p), ("a1", C.c_void_p), ("c0", C.c_int32), ("c1", C.c_int32),
+        ("a0_stride", C.c_int32), ("a1_stride", C.c_int32),
+        ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("oh", C.c_int32), ("ow", C.c_int32),
+        ("kh", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("up_h", C.c_int32), ("up_w", C.c_int32),
+        ("wgt", C.c_void_p), ("ldw", C.c_int32), ("nout", C.c_int32),
+        ("bias", C.c_void_p), ("rowvec", C.c_void_p), ("ld_rowvec", C.c_int32),
+        ("residual", C.c_void_p), ("ld_res", C.c_int32),
+        ("alpha", C.c_float), ("act", C.c_int32),
+        ("out", C.c_void_p), ("ld_out", C.c_int32), ("out_f32", C.c_int32),
+        ("zero_page", C.c_void_p),
+    ]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("k", C.c_void_p), ("vt", C.c_void_p), ("o", C.c_void_p),
+        ("q_bs", C.c_int64), ("q_rs", C.c_int64), ("k_bs", C.c_int64), ("k_rs", C.c_int64),
+        ("vt_bs", C.c_int64), ("vt_hs", C.c_int64), ("vt_ds", C.c_int64), ("o_bs", C.c_int64), ("o_rs", C.c_int64),
+        ("batch", C.c_int32), ("heads", C.c_int32), ("nq", C.c_int32), ("nk", C.c_int32), ("nk_pad", C.c_int32),
+        ("dpad", C.c_int32), ("scale", C.c_float), ("zero_page", C.c_void_p),
+    ]
+
+
+_vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+# name -> argtypes; every function returns int (0 = ok).  Must list every symbol of include/fmx.h
+# (tests/test_capi_symbols.py parses the header and checks both directions).
+SIGNATURES = {
+    "fmx_abi_version": [],
+    "fmx_device_info": [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int],
+    "fmx_gemm_conv_f16": [C.POINTER(GemmArgs), _vp],
+    "fmx_geglu_interleave_rows": [_vp, _vp, _vp, _vp, _i32, _i32, _vp],
+    "fmx_attention_f16": [C.POINTER(AttnArgs), _vp],
+    "fmx_softmax_rows_f16": [_vp, _i64, _i32, _i64, _vp],
+    "fmx_groupnorm_stats_f16": [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
+    "fmx_groupnorm_apply_f16": [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _f32, _vp, _vp, _i32, _vp, _vp],
+    "fmx_layernorm_f16": [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp],
+    "fmx_timestep_embedding": [_vp, _vp, _i32, _i32, _f32, _vp],
+    "fmx_silu_f16": [_vp, _vp, _i64, _vp],
+    "fmx_cast_f32_to_f16": [_vp, _vp, _i64, _vp],
+    "fmx_unet_pack_input": [_vp, _vp, _f32, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
+    "fmx_cfg_combine": [_vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp],
+    "fmx_sampler_euler_step": [_vp, _vp, _f32, _f32, _vp, _f32, _vp, _i64, _vp],
+    "fmx_sampler_lincomb3": [_vp, _vp, _vp, _f32, _f32, _f32, _vp, _i64, _vp],
+    "fmx_scale_f32": [_vp, _f32, _vp, _i64, _vp],
+    "fmx_vae_pack_latent": [_vp, _f32, _f32, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
+    "fmx_im2col3x3_smallc": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
+    "fmx_vae_unpack_image": [_vp, _i32, _i64, _i32, _vp, _vp],
+    "fmx_philox_randn": [C.c_uint64, C.c_uint32, _vp, _vp, _i64, _vp],
+    "fmx_graph_begin": [_vp],
+    "fmx_graph_end": [_vp, C.POINTER(C.c_void_p)],
+    "fmx_graph_launch": [_vp, _vp],
+    "fmx_graph_destroy": [_vp],
+    "fmx_event_create": [C.POINTER(C.c_void_p)],
+    "fmx_event_record": [_vp, _vp],
+    "fmx_event_elapsed_ms": [_vp, _vp, C.POINTER(C.c_float)],
+    "fmx_event_destroy": [_vp],
+}
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/*.hip for gfx950 into libfmx_gfx950.so (make is incremental)."""
+    if force and os.path.exists(LIB_PATH):
+        os.remove(LIB_PATH)
+    cmd = ["make", "-C", CSRC, "-j8"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose:
+        print(res.stdout[-2000:])
+    if res.returncode != 0:
+        raise FmxError("building libfmx_gfx950.so failed:\n" + res.stdout[-4000:] + res.stderr[-4000:])
+    if not os.path.exists(LIB_PATH):
+        raise FmxError("build finished but %s is missing" % LIB_PATH)
+    return LIB_PATH
+
+
+def lib():
+    """Load the shared library (once) and bind every declared symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise FmxError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950).  There is no CPU/PyTorch fallback by design.")
+        handle = C.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError as e:
+                raise FmxError(f"symbol {name} missing from {LIB_PATH}") from e
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
+        handle.fmx_last_error.argtypes = []
+        handle.fmx_last_error.restype = C.c_char_p
+        if handle.fmx_abi_version() != 1:
+            raise FmxError("libfmx ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def check(code, what=""):
+    if code != 0:
+        msg = lib().fmx_last_error()
+        raise FmxError(f"{what} failed with code {code}: {msg.decode() if msg else ''}")

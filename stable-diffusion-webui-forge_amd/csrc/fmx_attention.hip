@@ -1,0 +1,284 @@
+// Fused multi-head attention (flash-style, online softmax) for gfx950 -- replaces `attention_function`
+// (backend/attention.py:324-339 SDPA / :37-93 explicit form): O = softmax(Q K^T / sqrt(d)) V per (batch, head).
+//
+// Layout trick that removes every cross-lane shuffle / LDS round trip from the softmax->PV hand-off:
+//   * scores are computed TRANSPOSED, S^T = K Q^T, with v_mfma_f32_32x32x16_f16 (A = K rows, B = Q rows):
+//     a lane then owns ONE query (column lane&31) and 16 of the tile's 32 keys in its 16 accumulators.
+//   * the order in which keys are fed to MFMA rows is free, so K rows are read through the permutation
+//     pi(i) = (i&3) | ((i>>3)&3)<<2 | ((i>>2)&1)<<4; with it, accumulator r of lane-half `hi` is key 16*hi + r,
+//     i.e. each lane holds 16 CONSECUTIVE keys -- exactly the k-slot order the next MFMA wants.
+//   * the output is accumulated TRANSPOSED too, O^T = V^T P^T (A = V^T rows = head-dim, B = P^T): the P
+//     registers are used as the B operand as they are (packed to fp16), and the O^T accumulator again has
+//     "lane = query", so the online-softmax rescale and the final 1/l are lane-local multiplies.
+//   * V is consumed as V^T [d][key]; the projection GEMM produces it directly by swapping its operands
+//     (V^T = Wv X^T is the same NT GEMM), so no transpose kernel and no ds_read_tr is needed.
+// K and V^T tiles (64 keys) are shared by the 4 waves of a workgroup (4 x 32 queries), staged by LDS-DMA,
+// double buffered, swizzled for conflict-free ds_read_b128.  Row sums stay per-lane partials (the
+// cross-half add happens once at the end); the accumulator rescale is skipped wave-uniformly when no
+// running max moved.
+#include "fmx_common.hpp"
+
+namespace {
+
+struct AttnParams {
+  const f16* q;
+  const f16* k;
+  const f16* vt;
+  f16* o;
+  long q_bs, q_rs, k_bs, k_rs, vt_bs, vt_hs, vt_ds, o_bs, o_rs;
+  int batch, heads, nq, nk, nk_pad, qtiles;
+  float scale_log2e;
+  const f16* zp;
+};
+
+constexpr int KVB = 64;  // keys per tile
+
+template <int CPR>
+__device__ __forceinline__ int k_phys_chunk(int row, int c) {
+  if (CPR == 8) return c ^ ((row >> 1) & 7);
+  if (CPR == 20) { int x = c + (row >> 2); return x >= 20 ? x - 20 : (x); }
+  return c;
+}
+template <int CPR>
+__device__ __forceinline__ int k_logical_chunk(int row, int pc) {
+  if (CPR == 8) return pc ^ ((row >> 1) & 7);
+  if (CPR == 20) { int x = pc - ((row >> 2) % 20); return x < 0 ? x + 20 : x; }
+  return pc;
+}
+
+__device__ __forceinline__ int key_perm(int i) { return (i & 3) | (((i >> 3) & 3) << 2) | (((i >> 2) & 1) << 4); }
+
+template <int DP>
+__global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int DSTEPS = DP / 16;        // QK^T MFMAs per 32-key sub-tile
+  constexpr int DVT = (DP + 31) / 32;    // 32-row tiles of O^T
+  constexpr int CPR = DP / 8;            // 16-byte chunks per K row
+  constexpr int KBYTES = KVB * DP * 2;
+  constexpr int VBYTES = DVT * 32 * 128;
+  constexpr int STAGE = KBYTES + VBYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5, li = lane & 31;
+
+  const int nwg = p.qtiles * p.heads * p.batch;
+  const int wg = xcd_remap(blockIdx.x, nwg);
+  const int qt = wg % p.qtiles;
+  const int bh = wg / p.qtiles;
+  const int h = bh % p.heads, b = bh / p.heads;
+
+  const f16* kbase = p.k + (long)b * p.k_bs + (long)h * DP;
+  const f16* vbase = p.vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
+
+  // ---- Q fragments (B operand): lane = query li, k-slots hi*8.. of each 16-wide d step -----------------------
+  const int q0 = qt * 128 + wave * 32;
+  const int qrow = min(q0 + li, p.nq - 1);
+  const f16* qp = p.q + (long)b * p.q_bs + (long)qrow * p.q_rs + (long)h * DP + hi * 8;
+  f16x8 qf[DSTEPS];
+#pragma unroll
+  for (int ds = 0; ds < DSTEPS; ++ds) qf[ds] = *reinterpret_cast<const f16x8*>(qp + ds * 16);
+
+  const f16* zp = p.zp;
+  auto stage = [&](int s, int kt) {
+    char* sk = smem + s * STAGE;
+    char* sv = sk + KBYTES;
+    const int key0 = kt * KVB;
+    // K tile: 64 rows x CPR chunks, linear chunk id q = ii*64 + lane
+#pragma unroll
+    for (int ii = wave; ii < CPR; ii += 4) {
+      const int qq = ii * 64 + lane;
+      const int row = qq / CPR, pc = qq - row * CPR;
+      const int c = k_logical_chunk<CPR>(row, pc);
+      glds16(kbase + (long)(key0 + row) * p.k_rs + c * 8, sk + ii * 1024);
+    }
+    // V^T tile: DVT*32 rows (head dim) x 8 chunks (64 keys)
+#pragma unroll
+    for (int ii = wave; ii < DVT * 4; ii += 4) {
+      const int qq = ii * 64 + lane;
+      const int row = qq >> 3, pc = qq & 7;
+      const int c = pc ^ ((row >> 1) & 7);
+      const f16* g = (row < DP) ? vbase + (long)row * p.vt_ds + key0 + c * 8 : zp + c * 8;
+      glds16(g, sv + ii * 1024);
+    }
+  };
+
+  f32x16 oacc[DVT];
+#pragma unroll
+  for (int i = 0; i < DVT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int ntiles = (p.nk + KVB - 1) / KVB;
+  stage(0, 0);
+  wait_vmcnt0();
+  __syncthreads();
+
+  const int krow = key_perm(li);
+  const float c2 = p.scale_log2e;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < ntiles) stage(cur ^ 1, kt + 1);
+    const char* sk = smem + cur * STAGE;
+    const char* sv = sk + KBYTES;
+
+    // ---- S^T = K Q^T for the two 32-key sub-tiles ---------------------------------------------------------
+    f32x16 sacc[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[s][r] = 0.f;
+      const int row = s * 32 + krow;
+#pragma unroll
+      for (int ds = 0; ds < DSTEPS; ++ds) {
+        const f16x8 kf = *reinterpret_cast<const f16x8*>(sk + row * (DP * 2) + (k_phys_chunk<CPR>(row, ds * 2 + hi) << 4));
+        sacc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ds], sacc[s], 0, 0, 0);
+      }
+    }
+    // lane now holds scores of query li against keys kt*64 + s*32 + hi*16 + r
+    if ((kt + 1) * KVB > p.nk) {  // ragged tail: mask keys >= nk (wave-uniform branch)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kt * KVB + s * 32 + hi * 16 + r >= p.nk) sacc[s][r] = -INFINITY;
+    }
+    float mx = sacc[0][0];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[s][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+    const float mc = m_new * c2;
+    float psum = 0.f;
+    f16x8 pf[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(sacc[s][r] * c2 - mc);
+        psum += e;
+        pf[s][r >> 3][r & 7] = (f16)e;
+      }
+    l_run = l_run * alpha + psum;
+    if (__any(m_new > m_run)) {
+#pragma unroll
+      for (int i = 0; i < DVT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+    }
+    m_run = m_new;
+
+    // ---- O^T += V^T P^T : A = V^T rows (head dim), B = P^T (k-slot hi*8+e <-> key s*32 + hi*16 + j*8 + e) ----
+#pragma unroll
+    for (int dt = 0; dt < DVT; ++dt) {
+      const int row = dt * 32 + li;
+      const char* rp = sv + row * 128;
+      const int sw = (row >> 1) & 7;
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const f16x8 vf = *reinterpret_cast<const f16x8*>(rp + (((s * 4 + hi * 2 + j) ^ sw) << 4));
+          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s][j], oacc[dt], 0, 0, 0);
+        }
+    }
+    wait_vmcnt0();
+    __syncthreads();
+  }
+
+  // ---- finish: 1/l, store O[b][q][h*DP + d]; lane = query, registers = 4-wide runs of d --------------------
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  const int qg = q0 + li;
+  if (qg < p.nq) {
+    f16* op = p.o + (long)b * p.o_bs + (long)qg * p.o_rs + (long)h * DP;
+#pragma unroll
+    for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = dt * 32 + g * 8 + hi * 4;
+        if (d < DP) {
+          f16x4 hv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) hv[e] = (f16)(oacc[dt][g * 4 + e] * inv);
+          *reinterpret_cast<f16x4*>(op + d) = hv;
+        }
+      }
+  }
+}
+
+template <int DP>
+int launch_attn(const AttnParams& p, hipStream_t st) {
+  constexpr int DVT = (DP + 31) / 32;
+  const int smem = 2 * (KVB * DP * 2 + DVT * 32 * 128);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<DP>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  const int grid = p.qtiles * p.heads * p.batch;
+  hipLaunchKernelGGL((attn_kernel<DP>), dim3(grid), dim3(256), smem, st, p);
+  FMX_LAUNCH_CHECK("fmx_attention_f16");
+  return FMX_OK;
+}
+
+__global__ void softmax_rows_kernel(f16* __restrict__ x, int ncols, long ld) {
+  __shared__ float red[8];
+  f16* row = x + (long)blockIdx.x * ld;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float mx = -INFINITY;
+  for (int j = tid; j < ncols; j += blockDim.x) mx = fmaxf(mx, (float)row[j]);
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = red[0];
+  for (int i = 1; i < (int)(blockDim.x >> 6); ++i) mx = fmaxf(mx, red[i]);
+  __syncthreads();
+  float sum = 0.f;
+  for (int j = tid; j < ncols; j += blockDim.x) sum += __expf((float)row[j] - mx);
+  sum = wave_sum(sum);
+  if (lane == 0) red[wave] = sum;
+  __syncthreads();
+  sum = 0.f;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) sum += red[i];
+  const float inv = 1.0f / sum;
+  for (int j = tid; j < ncols; j += blockDim.x) row[j] = (f16)(__expf((float)row[j] - mx) * inv);
+}
+
+}  // namespace
+
+extern "C" int fmx_attention_f16(const fmx_attn_args* a, void* stream) {
+  FMX_REQUIRE(a && a->q && a->k && a->vt && a->o && a->zero_page, "attention: null pointer");
+  FMX_REQUIRE(a->batch > 0 && a->heads > 0 && a->nq > 0 && a->nk > 0, "attention: bad dims");
+  FMX_REQUIRE(a->nk_pad >= a->nk && (a->nk_pad % 64) == 0, "attention: nk_pad (%d) must be a multiple of 64 >= nk (%d)", a->nk_pad, a->nk);
+  FMX_REQUIRE(fmx_aligned16(a->q) && fmx_aligned16(a->k) && fmx_aligned16(a->vt) && fmx_aligned16(a->o), "attention: 16-byte alignment");
+  FMX_REQUIRE((a->q_rs % 8) == 0 && (a->k_rs % 8) == 0 && (a->vt_ds % 8) == 0 && (a->o_rs % 4) == 0 && (a->q_bs % 8) == 0 &&
+                  (a->k_bs % 8) == 0 && (a->vt_bs % 8) == 0 && (a->vt_hs % 8) == 0, "attention: strides must be multiples of 8 elements");
+  AttnParams p;
+  p.q = (const f16*)a->q; p.k = (const f16*)a->k; p.vt = (const f16*)a->vt; p.o = (f16*)a->o;
+  p.q_bs = a->q_bs; p.q_rs = a->q_rs; p.k_bs = a->k_bs; p.k_rs = a->k_rs;
+  p.vt_bs = a->vt_bs; p.vt_hs = a->vt_hs; p.vt_ds = a->vt_ds; p.o_bs = a->o_bs; p.o_rs = a->o_rs;
+  p.batch = a->batch; p.heads = a->heads; p.nq = a->nq; p.nk = a->nk; p.nk_pad = a->nk_pad;
+  p.qtiles = (a->nq + 127) / 128;
+  p.scale_log2e = a->scale * 1.44269504088896340736f;
+  p.zp = (const f16*)a->zero_page;
+  hipStream_t st = (hipStream_t)stream;
+  switch (a->dpad) {
+    case 48: return launch_attn<48>(p, st);
+    case 64: return launch_attn<64>(p, st);
+    case 80: return launch_attn<80>(p, st);
+    case 160: return launch_attn<160>(p, st);
+    default: return fmx_set_error(FMX_E_UNSUPPORTED, "attention: dpad %d not in {48,64,80,160}", a->dpad);
+  }
+}
+
+extern "C" int fmx_softmax_rows_f16(void* x, int64_t nrows, int32_t ncols, int64_t ld, void* stream) {
+  FMX_REQUIRE(x && nrows > 0 && ncols > 0 && ld >= ncols, "softmax_rows: bad args");
+  FMX_REQUIRE(nrows < (1LL << 31), "softmax_rows: too many rows");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)nrows), dim3(256), 0, (hipStream_t)stream, (f16*)x, ncols, (long)ld);
+  FMX_LAUNCH_CHECK("fmx_softmax_rows_f16");
+  return FMX_OK;
+}

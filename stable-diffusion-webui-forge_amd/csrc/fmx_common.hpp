@@ -1,0 +1,62 @@
+// Shared helpers for the gfx950 (CDNA4, wave64) kernels of libfmx.  HIP only; no CUDA paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fmx.h"
+
+typedef _Float16 f16;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define FMX_WAVE 64
+
+int fmx_set_error(int code, const char* fmt, ...);
+
+#define FMX_REQUIRE(cond, ...)                         \
+  do {                                                 \
+    if (!(cond)) return fmx_set_error(FMX_E_BADARG, __VA_ARGS__); \
+  } while (0)
+
+#define FMX_LAUNCH_CHECK(name)                                                        \
+  do {                                                                                \
+    hipError_t _e = hipGetLastError();                                                \
+    if (_e != hipSuccess) return fmx_set_error((int)_e, "%s: %s", name, hipGetErrorString(_e)); \
+  } while (0)
+
+static inline bool fmx_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// LDS-DMA: 16 bytes per lane from a per-lane global address into LDS at (wave-uniform base + lane*16).
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ void wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// XCD-aware, bijective remap of a 1-D workgroup id: consecutive logical ids land on the same XCD
+// (hardware places workgroup b on XCD b % 8), so neighbouring tiles share that XCD's L2.
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = orig & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (orig >> 3);
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}

@@ -1,0 +1,296 @@
+// Small HBM-bound kernels around the UNet / VAE executors and the sampler loop (gfx950).
+#include "fmx_common.hpp"
+
+namespace {
+
+constexpr int TPB = 256;
+inline unsigned grid_for(long n, int per_thread = 1) {
+  long b = (n + (long)TPB * per_thread - 1) / ((long)TPB * per_thread);
+  if (b > 65535L * 16) b = 65535L * 16;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+// timestep_embedding (backend/nn/unet.py:55-67): cat([cos, sin]) of t*exp(-ln(P)*k/half), fp32 math
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, f16* __restrict__ emb, int b, int dim, float log_period) {
+  const int half = dim >> 1;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b * half) return;
+  const int bi = i / half, k = i - bi * half;
+  const float freq = expf(-log_period * (float)k / (float)half);
+  const float a = t[bi] * freq;
+  emb[(long)bi * dim + k] = (f16)cosf(a);
+  emb[(long)bi * dim + half + k] = (f16)sinf(a);
+}
+
+__global__ void silu_kernel(const f16* __restrict__ x, f16* __restrict__ y, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = (f16)silu_f((float)x[i]);
+}
+
+__global__ void cast_f32_f16_kernel(const float* __restrict__ x, f16* __restrict__ y, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = (f16)x[i];
+}
+
+// x fp32 NCHW [b][c][h][w] -> fp16 3x3-im2col rows [reps*b*h*w][64] of x / sqrt(sigma^2 + sd^2)
+// one thread per (row, tap); each writes c halfs.  Columns >= 9*c are zeroed by tap-0 threads.
+__global__ void unet_pack_input_kernel(const float* __restrict__ x, const float* __restrict__ sigma, float sd2, int b, int c,
+                                       int h, int w, int reps, f16* __restrict__ out) {
+  const long total = (long)reps * b * h * w * 9;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % 9);
+    const long row = i / 9;
+    const int px = (int)(row % w);
+    const int py = (int)((row / w) % h);
+    const int bi = (int)((row / ((long)w * h)) % b);
+    const int iy = py + tap / 3 - 1, ix = px + tap % 3 - 1;
+    const bool ok = iy >= 0 && iy < h && ix >= 0 && ix < w;
+    const float s = sigma[bi];
+    const float inv = rsqrtf(s * s + sd2);
+    f16* o = out + row * 64 + tap * c;
+    for (int ch = 0; ch < c; ++ch) o[ch] = ok ? (f16)(x[(((long)bi * c + ch) * h + iy) * w + ix] * inv) : (f16)0.f;
+    if (tap == 0)
+      for (int k = 9 * c; k < 64; ++k) out[row * 64 + k] = (f16)0.f;
+  }
+}
+
+// fp16 NHWC [n][h][w][ldx] (first c channels) -> 3x3 im2col rows [n*h*w][64]
+__global__ void im2col3x3_smallc_kernel(const f16* __restrict__ x, int ldx, int n, int c, int h, int w, f16* __restrict__ out) {
+  const long total = (long)n * h * w * 9;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % 9);
+    const long row = i / 9;
+    const int px = (int)(row % w);
+    const int py = (int)((row / w) % h);
+    const long bi = row / ((long)w * h);
+    const int iy = py + tap / 3 - 1, ix = px + tap % 3 - 1;
+    const bool ok = iy >= 0 && iy < h && ix >= 0 && ix < w;
+    f16* o = out + row * 64 + tap * c;
+    const f16* src = x + ((bi * h + iy) * w + ix) * ldx;
+    for (int ch = 0; ch < c; ++ch) o[ch] = ok ? src[ch] : (f16)0.f;
+    if (tap == 0)
+      for (int k = 9 * c; k < 64; ++k) out[row * 64 + k] = (f16)0.f;
+  }
+}
+
+// denoised = x - eps*sigma per half, then CFG combine (k_prediction.py:92, sampling_function.py:276-288,312)
+__global__ void cfg_combine_kernel(const f16* __restrict__ eps, int ld, const float* __restrict__ x, const float* __restrict__ sigma,
+                                   int b, int c, int h, int w, int reps, float cond_scale, float* __restrict__ den,
+                                   float* __restrict__ cond_pred, float* __restrict__ uncond_pred) {
+  const long total = (long)b * c * h * w;
+  const long hw = (long)h * w;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long pix = i % hw;
+    const int ch = (int)((i / hw) % c);
+    const int bi = (int)(i / (hw * c));
+    const float s = sigma[bi];
+    const float xv = x[i];
+    float result;
+    if (reps == 2) {
+      const float eu = (float)eps[((long)bi * hw + pix) * ld + ch];
+      const float ec = (float)eps[((long)(b + bi) * hw + pix) * ld + ch];
+      // accumulators 0 + out*1 divided by counts 1e-37 + 1 (sampling_function.py:155-159,284-288): exact in fp32
+      const float du = xv - eu * s;
+      const float dc = xv - ec * s;
+      result = du + (dc - du) * cond_scale;
+      if (cond_pred) cond_pred[i] = dc;
+      if (uncond_pred) uncond_pred[i] = du;
+    } else {
+      const float ec = (float)eps[((long)bi * hw + pix) * ld + ch];
+      const float dc = xv - ec * s;
+      result = 0.f + (dc - 0.f) * cond_scale;  // uncond half skipped when cond_scale == 1 (:295-298)
+      if (cond_pred) cond_pred[i] = dc;
+      if (uncond_pred) uncond_pred[i] = 0.f;
+    }
+    den[i] = result;
+  }
+}
+
+__global__ void euler_step_kernel(const float* __restrict__ x, const float* __restrict__ den, float sigma, float sigma_next,
+                                  const float* __restrict__ noise, float noise_scale, float* __restrict__ out, long n) {
+  const float dt = sigma_next - sigma;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float xv = x[i];
+    const float d = (xv - den[i]) / sigma;  // to_d (modules/sd_schedulers.py:10-12)
+    float r = xv + d * dt;
+    if (noise) r = r + noise[i] * noise_scale;
+    out[i] = r;
+  }
+}
+
+__global__ void lincomb3_kernel(const float* __restrict__ x, const float* __restrict__ d0, const float* __restrict__ d1, float a,
+                                float bc, float cc, float* __restrict__ out, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float r;
+    if (d1) {
+      // sample_dpmpp_2m (k_diffusion/sampling.py:666-669): denoised_d first, then the update
+      const float dd = bc * d0[i] + cc * d1[i];
+      r = a * x[i] + dd;
+    } else {
+      r = a * x[i] + bc * d0[i];
+    }
+    out[i] = r;
+  }
+}
+
+__global__ void scale_kernel(const float* __restrict__ x, float s, float* __restrict__ y, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = x[i] * s;
+}
+
+__global__ void vae_pack_latent_kernel(const float* __restrict__ z, float inv_scale, float shift, int b, int c, int h, int w,
+                                       f16* __restrict__ out, int ld) {
+  const long total = (long)b * h * w * ld;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % ld);
+    const long pix = i / ld;
+    const long hw = (long)h * w;
+    const long bi = pix / hw, p = pix % hw;
+    out[i] = ch < c ? (f16)(z[(bi * c + ch) * hw + p] / inv_scale + shift) : (f16)0.f;
+  }
+}
+
+__global__ void vae_unpack_image_kernel(const f16* __restrict__ y, int ld, long npix, int c, float* __restrict__ out) {
+  const long total = npix * c;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long pix = i / c;
+    const int ch = (int)(i - pix * c);
+    const float v = ((float)y[pix * ld + ch] + 1.0f) / 2.0f;
+    out[i] = fminf(fmaxf(v, 0.f), 1.f);
+  }
+}
+
+// Philox4x32-10 (modules/rng_philox.py:32-64) + Box-Muller sine branch (:67-76)
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)c[0] * 0xD2511F53ull;
+  const uint64_t p1 = (uint64_t)c[2] * 0xCD9E8D57ull;
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+  const uint32_t n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+  const uint32_t n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+__global__ void philox_randn_kernel(uint32_t seed_lo, uint32_t seed_hi, uint32_t offset, float* __restrict__ out,
+                                    uint32_t* __restrict__ raw, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    uint32_t c[4] = {offset, 0u, (uint32_t)i, 0u};
+    uint32_t k0 = seed_lo, k1 = seed_hi;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      philox_round(c, k0, k1);
+      if (r != 9) { k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+    }
+    if (raw) { raw[i * 4 + 0] = c[0]; raw[i * 4 + 1] = c[1]; raw[i * 4 + 2] = c[2]; raw[i * 4 + 3] = c[3]; }
+    const float inv = 2.3283064e-10f;
+    const float inv2pi = 2.3283064e-10f * 6.2831855f;
+    const float u = (float)c[0] * inv + inv / 2.0f;
+    const float v = (float)c[1] * inv2pi + inv2pi / 2.0f;
+    out[i] = sqrtf(-2.0f * logf(u)) * sinf(v);
+  }
+}
+
+}  // namespace
+
+extern "C" int fmx_timestep_embedding(const float* t, void* emb, int32_t b, int32_t dim, float max_period, void* stream) {
+  FMX_REQUIRE(t && emb && b > 0 && dim > 0 && (dim % 2) == 0, "timestep_embedding: bad args");
+  const int total = b * (dim / 2);
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3((total + TPB - 1) / TPB), dim3(TPB), 0, (hipStream_t)stream, t, (f16*)emb, b, dim,
+                     logf(max_period));
+  FMX_LAUNCH_CHECK("fmx_timestep_embedding");
+  return FMX_OK;
+}
+
+extern "C" int fmx_silu_f16(const void* x, void* y, int64_t n, void* stream) {
+  FMX_REQUIRE(x && y && n > 0, "silu: bad args");
+  hipLaunchKernelGGL(silu_kernel, dim3(grid_for(n, 4)), dim3(TPB), 0, (hipStream_t)stream, (const f16*)x, (f16*)y, (long)n);
+  FMX_LAUNCH_CHECK("fmx_silu_f16");
+  return FMX_OK;
+}
+
+extern "C" int fmx_cast_f32_to_f16(const float* x, void* y, int64_t n, void* stream) {
+  FMX_REQUIRE(x && y && n > 0, "cast: bad args");
+  hipLaunchKernelGGL(cast_f32_f16_kernel, dim3(grid_for(n, 4)), dim3(TPB), 0, (hipStream_t)stream, x, (f16*)y, (long)n);
+  FMX_LAUNCH_CHECK("fmx_cast_f32_to_f16");
+  return FMX_OK;
+}
+
+extern "C" int fmx_unet_pack_input(const float* x, const float* sigma, float sigma_data, int32_t b, int32_t c, int32_t h, int32_t w,
+                                   int32_t reps, void* out, void* stream) {
+  FMX_REQUIRE(x && sigma && out && b > 0 && c > 0 && c * 9 <= 64 && h > 0 && w > 0 && (reps == 1 || reps == 2), "unet_pack_input: bad args");
+  const long total = (long)reps * b * h * w * 9;
+  hipLaunchKernelGGL(unet_pack_input_kernel, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream, x, sigma, sigma_data * sigma_data,
+                     b, c, h, w, reps, (f16*)out);
+  FMX_LAUNCH_CHECK("fmx_unet_pack_input");
+  return FMX_OK;
+}
+
+extern "C" int fmx_im2col3x3_smallc(const void* x, int32_t ldx, int32_t n, int32_t c, int32_t h, int32_t w, void* out, void* stream) {
+  FMX_REQUIRE(x && out && n > 0 && c > 0 && c * 9 <= 64 && ldx >= c && h > 0 && w > 0, "im2col3x3_smallc: bad args");
+  const long total = (long)n * h * w * 9;
+  hipLaunchKernelGGL(im2col3x3_smallc_kernel, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream, (const f16*)x, ldx, n, c, h, w,
+                     (f16*)out);
+  FMX_LAUNCH_CHECK("fmx_im2col3x3_smallc");
+  return FMX_OK;
+}
+
+extern "C" int fmx_cfg_combine(const void* eps, int32_t ld_eps, const float* x, const float* sigma, int32_t b, int32_t c, int32_t h,
+                               int32_t w, int32_t reps, float cond_scale, float* denoised, float* cond_pred, float* uncond_pred,
+                               void* stream) {
+  FMX_REQUIRE(eps && x && sigma && denoised && b > 0 && c > 0 && ld_eps >= c && (reps == 1 || reps == 2), "cfg_combine: bad args");
+  const long total = (long)b * c * h * w;
+  hipLaunchKernelGGL(cfg_combine_kernel, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream, (const f16*)eps, ld_eps, x, sigma, b, c,
+                     h, w, reps, cond_scale, denoised, cond_pred, uncond_pred);
+  FMX_LAUNCH_CHECK("fmx_cfg_combine");
+  return FMX_OK;
+}
+
+extern "C" int fmx_sampler_euler_step(const float* x, const float* denoised, float sigma, float sigma_next, const float* noise,
+                                      float noise_scale, float* x_out, int64_t n, void* stream) {
+  FMX_REQUIRE(x && denoised && x_out && n > 0 && sigma != 0.f, "euler_step: bad args");
+  hipLaunchKernelGGL(euler_step_kernel, dim3(grid_for(n)), dim3(TPB), 0, (hipStream_t)stream, x, denoised, sigma, sigma_next, noise,
+                     noise_scale, x_out, (long)n);
+  FMX_LAUNCH_CHECK("fmx_sampler_euler_step");
+  return FMX_OK;
+}
+
+extern "C" int fmx_sampler_lincomb3(const float* x, const float* denoised, const float* old_denoised, float a, float bcoef, float ccoef,
+                                    float* x_out, int64_t n, void* stream) {
+  FMX_REQUIRE(x && denoised && x_out && n > 0, "lincomb3: bad args");
+  hipLaunchKernelGGL(lincomb3_kernel, dim3(grid_for(n)), dim3(TPB), 0, (hipStream_t)stream, x, denoised, old_denoised, a, bcoef, ccoef,
+                     x_out, (long)n);
+  FMX_LAUNCH_CHECK("fmx_sampler_lincomb3");
+  return FMX_OK;
+}
+
+extern "C" int fmx_scale_f32(const float* x, float s, float* y, int64_t n, void* stream) {
+  FMX_REQUIRE(x && y && n > 0, "scale: bad args");
+  hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n)), dim3(TPB), 0, (hipStream_t)stream, x, s, y, (long)n);
+  FMX_LAUNCH_CHECK("fmx_scale_f32");
+  return FMX_OK;
+}
+
+extern "C" int fmx_vae_pack_latent(const float* z, float scaling_factor, float shift, int32_t b, int32_t c, int32_t h, int32_t w, void* out,
+                                   int32_t ld, void* stream) {
+  FMX_REQUIRE(z && out && b > 0 && c > 0 && ld >= c && scaling_factor != 0.f, "vae_pack_latent: bad args");
+  const long total = (long)b * h * w * ld;
+  hipLaunchKernelGGL(vae_pack_latent_kernel, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream, z, scaling_factor, shift, b, c, h, w,
+                     (f16*)out, ld);
+  FMX_LAUNCH_CHECK("fmx_vae_pack_latent");
+  return FMX_OK;
+}
+
+extern "C" int fmx_vae_unpack_image(const void* y, int32_t ld, int64_t npix, int32_t c, float* out, void* stream) {
+  FMX_REQUIRE(y && out && npix > 0 && c > 0 && ld >= c, "vae_unpack_image: bad args");
+  hipLaunchKernelGGL(vae_unpack_image_kernel, dim3(grid_for(npix * c, 2)), dim3(TPB), 0, (hipStream_t)stream, (const f16*)y, ld, (long)npix,
+                     c, out);
+  FMX_LAUNCH_CHECK("fmx_vae_unpack_image");
+  return FMX_OK;
+}
+
+extern "C" int fmx_philox_randn(uint64_t seed, uint32_t offset, float* out, uint32_t* raw_u32, int64_t n, void* stream) {
+  FMX_REQUIRE(out && n > 0 && n <= 0xFFFFFFFFLL, "philox_randn: bad args");
+  hipLaunchKernelGGL(philox_randn_kernel, dim3(grid_for(n)), dim3(TPB), 0, (hipStream_t)stream, (uint32_t)(seed & 0xFFFFFFFFu),
+                     (uint32_t)(seed >> 32), offset, out, raw_u32, (long)n);
+  FMX_LAUNCH_CHECK("fmx_philox_randn");
+  return FMX_OK;
+}

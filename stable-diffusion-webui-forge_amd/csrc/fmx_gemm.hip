@@ -1,0 +1,380 @@
+// Implicit-GEMM convolution / linear for gfx950 (MI355X):  OUT[M, N] = epilogue(A (*) W^T), fp16 in, fp32 acc.
+//
+// Replaces F.linear / F.conv2d call sites of the reference (backend/operations.py:153-176) together with
+// the ops the reference runs around them as separate kernels: nearest Upsample (backend/nn/unet.py:340-355),
+// torch.cat of the skip tensor (:741), bias, ResBlock emb broadcast add (:469-477), residual add (:478, :240),
+// GEGLU (:104-111).
+//
+// Design (CDNA4-first, not a translation of anything):
+//  * one workgroup = 4 waves (2x2) computes a BM x BN tile with v_mfma_f32_16x16x32_f16; operands are issued
+//    swapped (W fragment as the MFMA "A", activation fragment as "B") so every lane ends up with 4
+//    CONSECUTIVE output columns of one output row -> 8-byte epilogue loads/stores instead of 2-byte ones.
+//  * both operands reach LDS by LDS-DMA (global_load_lds_dwordx4): no VGPR round trip, and -- because the
+//    per-lane SOURCE address is free -- the im2col gather (3x3 taps, stride 2, zero padding via a zero
+//    page, nearest-upsample, channel-concat of two tensors) costs address arithmetic only.
+//  * LDS rows are 64 halfs (128 B); the 16-byte chunk index is XOR-swizzled with (row>>1)&7 on the source
+//    side and on the ds_read_b128 side (same involution), which makes the fragment reads conflict-free.
+//  * double-buffered K loop (BK = 64): issue tile t+1, compute tile t, one vmcnt(0)+barrier per tile.
+//  * 1-D grid remapped so that consecutive tiles (same A rows, neighbouring W rows) share an XCD's L2.
+#include "fmx_common.hpp"
+
+namespace {
+
+struct GemmParams {
+  const f16* a0;
+  const f16* a1;
+  int c0, c1, s0, s1;  // channels and pixel strides (elements) of the two sources
+  int n, h, w, oh, ow;
+  int kh, stride, pad;
+  int up_h, up_w;
+  const f16* wgt;
+  int ldw;
+  int nout;
+  const f16* bias;
+  const f16* rowvec;
+  int ld_rowvec;
+  const f16* residual;
+  int ld_res;
+  float alpha;
+  int act;
+  void* out;
+  int ld_out;
+  int out_f32;
+  const f16* zp;
+  int M;            // n*oh*ow
+  int kt;           // number of 64-wide K tiles = kh*kh*(c0+c1)/64
+  int cpt;          // K tiles per tap = (c0+c1)/64
+  int tiles_m, tiles_n;
+};
+
+constexpr int BK = 64;
+
+// byte offset of (row, logical 16B chunk) inside a [rows][64] fp16 LDS tile
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <int BM, int BN, bool CONV>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int MI = BM / 32;  // 16-row fragments per wave along M
+  constexpr int NI = BN / 32;
+  constexpr int LA = BM / 32;  // LDS-DMA instructions per thread for the A tile
+  constexpr int LB = BN / 32;
+  constexpr int STAGE_BYTES = (BM + BN) * 128;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int wg = xcd_remap(blockIdx.x, nwg);
+  const int tm = wg / p.tiles_n;
+  const int tn = wg - tm * p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- per-thread load geometry: thread owns LDS chunk (row = j*32 + tid/8, phys chunk = tid&7) -------------
+  const int prow = tid >> 3;
+  const int kc = (tid & 7) ^ ((tid >> 4) & 7);  // logical chunk this thread must fetch (swizzle, see lds_off)
+  const int Ctot = p.c0 + p.c1;
+
+  // A rows
+  long a_pix[LA];   // CONV: (n*H + 0)*W base handled below; plain: pixel index m
+  int a_iy0[LA], a_ix0[LA];
+  bool a_ok[LA];
+#pragma unroll
+  for (int j = 0; j < LA; ++j) {
+    const int m = m0 + j * 32 + prow;
+    a_ok[j] = m < p.M;
+    if (CONV) {
+      const int per = p.oh * p.ow;
+      const int img = m / per;
+      const int rem = m - img * per;
+      const int oy = rem / p.ow;
+      const int ox = rem - oy * p.ow;
+      a_pix[j] = (long)img * p.h * p.w;
+      a_iy0[j] = oy * p.stride - p.pad;
+      a_ix0[j] = ox * p.stride - p.pad;
+    } else {
+      a_pix[j] = m;
+      a_iy0[j] = a_ix0[j] = 0;
+    }
+  }
+  // W rows
+  const f16* b_ptr[LB];
+#pragma unroll
+  for (int j = 0; j < LB; ++j) {
+    const int nn = n0 + j * 32 + prow;
+    b_ptr[j] = (nn < p.nout) ? p.wgt + (long)nn * p.ldw + kc * 8 : nullptr;
+  }
+  const f16* zp = p.zp + kc * 8;
+
+  auto stage = [&](int s, int t) {
+    char* sa = smem + s * STAGE_BYTES;
+    char* sb = sa + BM * 128;
+    // which tap / channel slice does K tile t cover?
+    int tap = 0, cc = t * BK;
+    if (CONV) {
+      tap = t / p.cpt;
+      cc = (t - tap * p.cpt) * BK;
+    }
+    const f16* src;
+    int sstride, coff;
+    if (cc < p.c0) { src = p.a0; sstride = p.s0; coff = cc; }
+    else           { src = p.a1; sstride = p.s1; coff = cc - p.c0; }
+    int ky = 0, kx = 0;
+    if (CONV) { ky = tap / p.kh; kx = tap - ky * p.kh; }
+#pragma unroll
+    for (int j = 0; j < LA; ++j) {
+      const f16* g = zp;
+      if (CONV) {
+        int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
+        bool ok = a_ok[j];
+        if (p.up_h > 0) {
+          ok = ok && iy >= 0 && iy < p.up_h && ix >= 0 && ix < p.up_w;
+          if (p.up_h == 2 * p.h && p.up_w == 2 * p.w) {  // the x2 case of every SD/SDXL/VAE Upsample
+            iy >>= 1;
+            ix >>= 1;
+          } else {  // nearest to an arbitrary skip size (odd latent sizes): src = floor(dst*in/out)
+            iy = ok ? (iy * p.h) / p.up_h : 0;
+            ix = ok ? (ix * p.w) / p.up_w : 0;
+          }
+        } else {
+          ok = ok && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
+        }
+        if (ok) g = src + (a_pix[j] + (long)iy * p.w + ix) * sstride + coff + kc * 8;
+      } else {
+        if (a_ok[j]) g = src + a_pix[j] * sstride + coff + kc * 8;
+      }
+      glds16(g, sa + (j * 256 + wave * 64) * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < LB; ++j) {
+      const f16* g = b_ptr[j] ? b_ptr[j] + (long)t * BK : zp;
+      glds16(g, sb + (j * 256 + wave * 64) * 16);
+    }
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  stage(0, 0);
+  wait_vmcnt0();
+  __syncthreads();
+
+  const int frow = lane & 15;
+  const int fk = lane >> 4;
+  for (int t = 0; t < p.kt; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < p.kt) stage(cur ^ 1, t + 1);
+    const char* sa = smem + cur * STAGE_BYTES;
+    const char* sb = sa + BM * 128;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      f16x8 af[MI], bf[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+        af[i] = *reinterpret_cast<const f16x8*>(sa + lds_off(wm * (BM / 2) + i * 16 + frow, kk * 4 + fk));
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+        bf[j] = *reinterpret_cast<const f16x8*>(sb + lds_off(wn * (BN / 2) + j * 16 + frow, kk * 4 + fk));
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    wait_vmcnt0();
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + (lane>>4)*4 + r], r = 0..3 ---------------------
+  const int per_img = p.oh * p.ow;
+  const bool geglu = p.act == FMX_ACT_GEGLU;
+  const int ncols = geglu ? (p.nout >> 1) : p.nout;
+  const bool vec_ok = ((p.ld_out & 3) == 0) && ((p.ld_res & 3) == 0) && ((p.ld_rowvec & 3) == 0);
+
+  // acc*alpha + bias[nb..nb+3] + rowvec[nb..nb+3]  (8-byte loads when the 4 columns are in range)
+  auto biased = [&](const f32x4& a, int nb, const f16* rv, float (&v)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = a[r] * p.alpha;
+    if (nb + 3 < p.nout && vec_ok) {
+      if (p.bias) {
+        const f16x4 b = *reinterpret_cast<const f16x4*>(p.bias + nb);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (float)b[r];
+      }
+      if (rv) {
+        const f16x4 b = *reinterpret_cast<const f16x4*>(rv + nb);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (float)b[r];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (nb + r < p.nout) {
+          if (p.bias) v[r] += (float)p.bias[nb + r];
+          if (rv) v[r] += (float)rv[nb + r];
+        }
+      }
+    }
+  };
+
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = m0 + wm * (BM / 2) + i * 16 + frow;
+    if (m >= p.M) continue;
+    const f16* rv = p.rowvec ? p.rowvec + (long)(m / per_img) * p.ld_rowvec : nullptr;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int nb = n0 + wn * (BN / 2) + j * 16 + fk * 4;  // first of this lane's 4 weight rows
+      float v[4];
+      int col;
+      if (geglu) {
+        // fragments come in [value | gate] pairs along j: odd j holds the gate of fragment j-1
+        if ((j & 1) == 0) continue;
+        float g[4];
+        biased(acc[i][j], nb, rv, g);
+        biased(acc[i][j - 1], nb - 16, rv, v);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_f(g[r]);
+        col = ((n0 + wn * (BN / 2)) >> 1) + (j >> 1) * 16 + fk * 4;
+      } else {
+        biased(acc[i][j], nb, rv, v);
+        col = nb;
+      }
+      if (col >= ncols) continue;
+      const long o = (long)m * p.ld_out + col;
+      const bool full = (col + 3 < ncols) && vec_ok;
+      if (p.residual) {
+        const f16* rp = p.residual + (long)m * p.ld_res + col;
+        if (full) {
+          const f16x4 rr = *reinterpret_cast<const f16x4*>(rp);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (col + r < ncols) v[r] += (float)rp[r];
+        }
+      }
+      if (p.out_f32) {
+        float* op = reinterpret_cast<float*>(p.out) + o;
+        if (full) {
+          *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (col + r < ncols) op[r] = v[r];
+        }
+      } else {
+        f16* op = reinterpret_cast<f16*>(p.out) + o;
+        if (full) {
+          f16x4 hv;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) hv[r] = (f16)v[r];
+          *reinterpret_cast<f16x4*>(op) = hv;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (col + r < ncols) op[r] = (f16)v[r];
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, bool CONV>
+int launch(const GemmParams& p, hipStream_t st) {
+  const int smem = 2 * (BM + BN) * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, CONV>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  GemmParams q = p;
+  q.tiles_m = (p.M + BM - 1) / BM;
+  q.tiles_n = (p.nout + BN - 1) / BN;
+  const int grid = q.tiles_m * q.tiles_n;
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, CONV>), dim3(grid), dim3(256), smem, st, q);
+  FMX_LAUNCH_CHECK("fmx_gemm_conv_f16");
+  return FMX_OK;
+}
+
+// interleave GEGLU rows: out row 32*q + i (i<16) = in row 16*q + i ; out row 32*q+16+i = in row inner + 16*q + i
+__global__ void geglu_interleave_kernel(const f16* __restrict__ w_in, const f16* __restrict__ b_in, f16* __restrict__ w_out,
+                                        f16* __restrict__ b_out, int inner, int k) {
+  const int orow = blockIdx.x;
+  const int q = orow >> 5, i = orow & 31;
+  const int irow = (i < 16) ? (16 * q + i) : (inner + 16 * q + (i - 16));
+  for (int c = threadIdx.x; c < k; c += blockDim.x) w_out[(long)orow * k + c] = w_in[(long)irow * k + c];
+  if (b_in && threadIdx.x == 0) b_out[orow] = b_in[irow];
+}
+
+}  // namespace
+
+extern "C" int fmx_gemm_conv_f16(const fmx_gemm_args* a, void* stream) {
+  FMX_REQUIRE(a && a->a0 && a->wgt && a->out && a->zero_page, "gemm: null pointer");
+  const int ctot = a->c0 + a->c1;
+  FMX_REQUIRE(a->c0 > 0 && a->c1 >= 0 && (a->c0 % 64) == 0 && (ctot % 64) == 0, "gemm: channels (%d,%d) must be multiples of 64", a->c0, a->c1);
+  FMX_REQUIRE(a->c1 == 0 || a->a1, "gemm: a1 missing");
+  FMX_REQUIRE(a->kh == 1 || a->kh == 3, "gemm: kh must be 1 or 3");
+  FMX_REQUIRE(a->n > 0 && a->h > 0 && a->w > 0 && a->oh > 0 && a->ow > 0 && a->nout > 0, "gemm: bad dims");
+  FMX_REQUIRE(a->act == FMX_ACT_NONE || (a->act == FMX_ACT_GEGLU && (a->nout % 32) == 0), "gemm: bad act/nout");
+  GemmParams p;
+  p.a0 = (const f16*)a->a0; p.a1 = (const f16*)a->a1;
+  p.c0 = a->c0; p.c1 = a->c1;
+  p.s0 = a->a0_stride ? a->a0_stride : a->c0;
+  p.s1 = a->a1_stride ? a->a1_stride : a->c1;
+  p.n = a->n; p.h = a->h; p.w = a->w; p.oh = a->oh; p.ow = a->ow;
+  p.kh = a->kh; p.stride = a->stride > 0 ? a->stride : 1; p.pad = a->pad;
+  p.up_h = a->up_h; p.up_w = a->up_w;
+  p.wgt = (const f16*)a->wgt;
+  p.ldw = a->ldw ? a->ldw : a->kh * a->kh * ctot;
+  p.nout = a->nout;
+  p.bias = (const f16*)a->bias; p.rowvec = (const f16*)a->rowvec; p.ld_rowvec = a->ld_rowvec;
+  p.residual = (const f16*)a->residual; p.ld_res = a->ld_res;
+  p.alpha = a->alpha; p.act = a->act;
+  p.out = a->out; p.ld_out = a->ld_out; p.out_f32 = a->out_f32;
+  p.zp = (const f16*)a->zero_page;
+  p.M = a->n * a->oh * a->ow;
+  p.cpt = ctot / 64;
+  p.kt = a->kh * a->kh * p.cpt;
+  p.tiles_m = p.tiles_n = 0;
+  FMX_REQUIRE(fmx_aligned16(p.a0) && fmx_aligned16(p.wgt) && fmx_aligned16(p.zp) && (!p.a1 || fmx_aligned16(p.a1)), "gemm: operands must be 16-byte aligned");
+  FMX_REQUIRE((p.s0 % 8) == 0 && (p.s1 % 8) == 0 && (p.ldw % 8) == 0, "gemm: strides must be multiples of 8 elements");
+  FMX_REQUIRE((long)p.M * 1 > 0 && (long)a->n * a->oh * a->ow < (1L << 31), "gemm: M overflow");
+  const bool conv = !(a->kh == 1 && p.stride == 1 && a->pad == 0 && a->up_h == 0 && a->oh == a->h && a->ow == a->w);
+  hipStream_t st = (hipStream_t)stream;
+  // tile choice: the largest tile that still gives >= 1.5 workgroups per CU (256 CUs); 64-wide N tiles
+  // for ragged N (320 = 5 x 64) so no MFMA work is spent on padding columns.
+  auto tiles = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.nout + bn - 1) / bn); };
+  const bool n128 = (p.nout % 128) == 0 || p.nout >= 2048;
+  int sel = 2;
+  if (n128 && tiles(128, 128) >= 384) sel = 0;
+  else if (tiles(128, 64) >= 384) sel = 1;
+  if (a->out_f32 < 0) sel = (-a->out_f32 - 1) % 3;  // test hook: force a tile shape (out_f32 = -1/-2/-3 -> fp16 out)
+  if (a->out_f32 < 0) p.out_f32 = 0;
+  if (conv) {
+    if (sel == 0) return launch<128, 128, true>(p, st);
+    if (sel == 1) return launch<128, 64, true>(p, st);
+    return launch<64, 64, true>(p, st);
+  } else {
+    if (sel == 0) return launch<128, 128, false>(p, st);
+    if (sel == 1) return launch<128, 64, false>(p, st);
+    return launch<64, 64, false>(p, st);
+  }
+}
+
+extern "C" int fmx_geglu_interleave_rows(const void* w_in, const void* b_in, void* w_out, void* b_out, int32_t inner,
+                                         int32_t k, void* stream) {
+  FMX_REQUIRE(w_in && w_out && inner > 0 && (inner % 16) == 0 && k > 0, "geglu_interleave: bad args");
+  FMX_REQUIRE((b_in == nullptr) == (b_out == nullptr), "geglu_interleave: bias in/out mismatch");
+  hipLaunchKernelGGL(geglu_interleave_kernel, dim3(2 * inner), dim3(256), 0, (hipStream_t)stream, (const f16*)w_in,
+                     (const f16*)b_in, (f16*)w_out, (f16*)b_out, inner, k);
+  FMX_LAUNCH_CHECK("fmx_geglu_interleave_rows");
+  return FMX_OK;
+}

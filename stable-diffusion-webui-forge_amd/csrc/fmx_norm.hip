@@ -1,0 +1,248 @@
+// GroupNorm(+SiLU) over NHWC fp16 and LayerNorm over rows, gfx950.  HBM-bound kernels: 16-byte vector
+// loads/stores, fp32 statistics, no atomics (deterministic two-level reduction).
+// Replaces F.group_norm (backend/operations.py:308; eps 1e-5 ResBlock/out, 1e-6 SpatialTransformer/VAE) fused
+// with the SiLU that follows it in ResBlock.in_layers/out_layers (backend/nn/unet.py:394-398,417-421) and the
+// torch.cat of the skip tensor in front of it (:741); and F.layer_norm (backend/operations.py:327).
+#include "fmx_common.hpp"
+
+namespace {
+
+// ---- pass 1: per-(image, chunk, channel) partial sum / sum of squares ---------------------------------------
+// grid (nchunks, n); block 256 threads; thread t owns channel octet (t % oct) and walks pixels t / oct + k*ppb.
+__global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ x0, const f16* __restrict__ x1, int c0, int c1,
+                                                        int hw, float* __restrict__ partial, int nchunks) {
+  extern __shared__ float sred[];  // [256][16] only when several pixel-lanes share an octet
+  const int C = c0 + c1;
+  const int oct = C >> 3;
+  const int img = blockIdx.y, chunk = blockIdx.x;
+  const int per = (hw + nchunks - 1) / nchunks;
+  const int p_begin = chunk * per;
+  const int p_end = min(hw, p_begin + per);
+  const int tid = threadIdx.x;
+  float* out = partial + ((long)(img * nchunks + chunk) * C) * 2;
+
+  // each "round" covers all octets with as many pixel lanes as fit in the block
+  const int lanes = max(1, 256 / oct);          // pixel lanes per octet (when oct <= 256)
+  for (int ob = 0; ob < oct; ob += 256) {       // octet blocks (oct > 256 only for C > 2048)
+    const int my_oct = ob + (oct >= 256 ? tid : tid % oct);
+    const int my_lane = oct >= 256 ? 0 : tid / oct;
+    const int nl = oct >= 256 ? 1 : lanes;
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+    const bool active = my_oct < oct && my_lane < nl;
+    if (active) {
+      const int ch = my_oct * 8;
+      const f16* src;
+      int cs, co;
+      if (ch < c0) { src = x0; cs = c0; co = ch; } else { src = x1; cs = c1; co = ch - c0; }
+      src += (long)img * hw * cs + co;
+#pragma unroll 4
+      for (int px = p_begin + my_lane; px < p_end; px += nl) {
+        const f16x8 v = *reinterpret_cast<const f16x8*>(src + (long)px * cs);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float f = (float)v[e];
+          s[e] += f;
+          q[e] += f * f;
+        }
+      }
+    }
+    if (nl == 1) {
+      if (active) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          out[(my_oct * 8 + e) * 2 + 0] = s[e];
+          out[(my_oct * 8 + e) * 2 + 1] = q[e];
+        }
+      }
+    } else {
+      // combine the pixel lanes of each octet through LDS (fixed order -> deterministic)
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        sred[tid * 16 + e] = s[e];
+        sred[tid * 16 + 8 + e] = q[e];
+      }
+      __syncthreads();
+      if (tid < oct) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float ss = 0.f, qq = 0.f;
+          for (int l = 0; l < nl; ++l) {
+            const int src_t = l * oct + tid;
+            if (src_t < 256) {
+              ss += sred[src_t * 16 + e];
+              qq += sred[src_t * 16 + 8 + e];
+            }
+          }
+          out[(tid * 8 + e) * 2 + 0] = ss;
+          out[(tid * 8 + e) * 2 + 1] = qq;
+        }
+      }
+    }
+  }
+}
+
+// ---- pass 2: normalise + affine (+ SiLU), writing the (concatenated) fp16 NHWC tensor -------------------------
+// grid (pixel tiles, n); per-channel scale/shift are built once per block in LDS.
+__global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x0, const f16* __restrict__ x1, int c0, int c1,
+                                                        int hw, const float* __restrict__ partial, int nchunks, int groups,
+                                                        float eps, const f16* __restrict__ gamma, const f16* __restrict__ beta,
+                                                        int silu, f16* __restrict__ y, int pix_per_block) {
+  extern __shared__ float ss[];  // [C] scale, [C] shift, then [groups][2]
+  const int C = c0 + c1;
+  const int cpg = C / groups;
+  const int img = blockIdx.y;
+  float* scale = ss;
+  float* shift = ss + C;
+  float* gstat = ss + 2 * C;
+  const int tid = threadIdx.x;
+  const float* pimg = partial + (long)img * nchunks * C * 2;
+  for (int g = tid; g < groups; g += 256) {
+    float s = 0.f, q = 0.f;
+    for (int ch = 0; ch < nchunks; ++ch) {
+      const float* pp = pimg + ((long)ch * C + g * cpg) * 2;
+      for (int c = 0; c < cpg; ++c) {
+        s += pp[c * 2];
+        q += pp[c * 2 + 1];
+      }
+    }
+    const float cnt = (float)cpg * (float)hw;
+    const float mean = s / cnt;
+    const float var = fmaxf(q / cnt - mean * mean, 0.f);
+    gstat[g * 2] = mean;
+    gstat[g * 2 + 1] = rsqrtf(var + eps);
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    const int g = c / cpg;
+    const float sc = gstat[g * 2 + 1] * (float)gamma[c];
+    scale[c] = sc;
+    shift[c] = (float)beta[c] - gstat[g * 2] * sc;
+  }
+  __syncthreads();
+  const int oct = C >> 3;
+  const int p0 = blockIdx.x * pix_per_block;
+  const int p1 = min(hw, p0 + pix_per_block);
+  // element i = tid + k*256 over the (pixel, octet) grid; walk (px, o) incrementally instead of dividing
+  int px = p0 + tid / oct;
+  int o = tid - (tid / oct) * oct;
+  const int dpx = 256 / oct, dov = 256 - dpx * oct;
+  while (px < p1) {
+    const int ch = o * 8;
+    const f16* src;
+    if (ch < c0) src = x0 + ((long)img * hw + px) * c0 + ch;
+    else src = x1 + ((long)img * hw + px) * c1 + (ch - c0);
+    const f16x8 v = *reinterpret_cast<const f16x8*>(src);
+    f16x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float f = (float)v[e] * scale[ch + e] + shift[ch + e];
+      if (silu) f = silu_f(f);
+      r[e] = (f16)f;
+    }
+    *reinterpret_cast<f16x8*>(y + ((long)img * hw + px) * C + ch) = r;
+    px += dpx;
+    o += dov;
+    if (o >= oct) { o -= oct; ++px; }
+  }
+}
+
+// ---- LayerNorm: one wave per row, row kept in registers, exact two-pass mean/variance in fp32 -----------------
+template <int MAXOCT>  // octets per lane
+__global__ __launch_bounds__(256) void ln_kernel(const f16* __restrict__ x, const f16* __restrict__ gamma,
+                                                  const f16* __restrict__ beta, f16* __restrict__ y, long rows, int c, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int oct = c >> 3;
+  const f16* xr = x + row * c;
+  f16x8 v[MAXOCT];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXOCT; ++j) {
+    const int o = lane + j * 64;
+    if (o < oct) {
+      v[j] = *reinterpret_cast<const f16x8*>(xr + o * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += (float)v[j][e];
+    }
+  }
+  const float mean = wave_sum(s) / (float)c;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXOCT; ++j) {
+    const int o = lane + j * 64;
+    if (o < oct) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = (float)v[j][e] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)c + eps);
+  f16* yr = y + row * c;
+#pragma unroll
+  for (int j = 0; j < MAXOCT; ++j) {
+    const int o = lane + j * 64;
+    if (o < oct) {
+      const f16x8 g = *reinterpret_cast<const f16x8*>(gamma + o * 8);
+      const f16x8 b = *reinterpret_cast<const f16x8*>(beta + o * 8);
+      f16x8 r;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r[e] = (f16)(((float)v[j][e] - mean) * rstd * (float)g[e] + (float)b[e]);
+      *reinterpret_cast<f16x8*>(yr + o * 8) = r;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int fmx_groupnorm_stats_f16(const void* x0, const void* x1, int32_t c0, int32_t c1, int32_t n, int32_t hw,
+                                       float* partial, int32_t nchunks, void* stream) {
+  FMX_REQUIRE(x0 && partial && c0 > 0 && c1 >= 0 && (c0 % 8) == 0 && (c1 % 8) == 0 && n > 0 && hw > 0, "groupnorm_stats: bad args");
+  FMX_REQUIRE(c1 == 0 || x1, "groupnorm_stats: x1 missing");
+  FMX_REQUIRE(nchunks >= 1 && nchunks <= 256, "groupnorm_stats: nchunks out of range");
+  FMX_REQUIRE(fmx_aligned16(x0) && (!x1 || fmx_aligned16(x1)), "groupnorm_stats: alignment");
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, n), dim3(256), 256 * 16 * sizeof(float), (hipStream_t)stream,
+                     (const f16*)x0, (const f16*)x1, c0, c1, hw, partial, nchunks);
+  FMX_LAUNCH_CHECK("fmx_groupnorm_stats_f16");
+  return FMX_OK;
+}
+
+extern "C" int fmx_groupnorm_apply_f16(const void* x0, const void* x1, int32_t c0, int32_t c1, int32_t n, int32_t hw,
+                                       const float* partial, int32_t nchunks, int32_t groups, float eps, const void* gamma,
+                                       const void* beta, int32_t silu, void* y, void* stream) {
+  FMX_REQUIRE(x0 && partial && gamma && beta && y, "groupnorm_apply: null pointer");
+  const int C = c0 + c1;
+  FMX_REQUIRE(c0 > 0 && c1 >= 0 && (c0 % 8) == 0 && (c1 % 8) == 0 && groups > 0 && (C % groups) == 0, "groupnorm_apply: bad channels");
+  FMX_REQUIRE(c1 == 0 || x1, "groupnorm_apply: x1 missing");
+  FMX_REQUIRE(fmx_aligned16(x0) && fmx_aligned16(y) && (!x1 || fmx_aligned16(x1)), "groupnorm_apply: alignment");
+  // ~64 KB of activations per block keeps >= 2k blocks in flight on the big tensors
+  int ppb = (32768 + C - 1) / C;
+  if (ppb < 1) ppb = 1;
+  const int tiles = (hw + ppb - 1) / ppb;
+  const size_t smem = (size_t)(2 * C + 2 * groups) * sizeof(float);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(tiles, n), dim3(256), smem, (hipStream_t)stream, (const f16*)x0, (const f16*)x1, c0, c1,
+                     hw, partial, nchunks, groups, eps, (const f16*)gamma, (const f16*)beta, silu, (f16*)y, ppb);
+  FMX_LAUNCH_CHECK("fmx_groupnorm_apply_f16");
+  return FMX_OK;
+}
+
+extern "C" int fmx_layernorm_f16(const void* x, const void* gamma, const void* beta, void* y, int64_t rows, int32_t c,
+                                 float eps, void* stream) {
+  FMX_REQUIRE(x && gamma && beta && y && rows > 0 && c > 0 && (c % 8) == 0 && c <= 4096, "layernorm: bad args");
+  FMX_REQUIRE(fmx_aligned16(x) && fmx_aligned16(y) && fmx_aligned16(gamma) && fmx_aligned16(beta), "layernorm: alignment");
+  const long blocks = (rows + 3) / 4;
+  FMX_REQUIRE(blocks < (1L << 31), "layernorm: too many rows");
+  hipStream_t st = (hipStream_t)stream;
+  const int oct = c >> 3;
+  if (oct <= 64) hipLaunchKernelGGL(ln_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, (const f16*)x, (const f16*)gamma, (const f16*)beta, (f16*)y, (long)rows, c, eps);
+  else if (oct <= 128) hipLaunchKernelGGL(ln_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, (const f16*)x, (const f16*)gamma, (const f16*)beta, (f16*)y, (long)rows, c, eps);
+  else if (oct <= 192) hipLaunchKernelGGL(ln_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, st, (const f16*)x, (const f16*)gamma, (const f16*)beta, (f16*)y, (long)rows, c, eps);
+  else hipLaunchKernelGGL(ln_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, st, (const f16*)x, (const f16*)gamma, (const f16*)beta, (f16*)y, (long)rows, c, eps);
+  FMX_LAUNCH_CHECK("fmx_layernorm_f16");
+  return FMX_OK;
+}

@@ -1,0 +1,262 @@
+"""Functional wrappers: torch tensors (device memory + streams only) -> C-ABI calls of libfmx_gfx950.so.
+
+Activations are fp16 NHWC: a feature map is a contiguous [N, H, W, C] tensor and -- for free -- the token
+matrix [N*H*W, C] the transformer blocks want (the reference pays two transposes per SpatialTransformer,
+backend/nn/unet.py:315,324).  Every function launches on torch's CURRENT stream and returns immediately.
+Temporary / output buffers come from the active `Arena` (runtime.py) when one is installed, so a whole UNet
+forward allocates nothing from HIP and can be captured into a HIP graph.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import AttnArgs, GemmArgs
+
+ACT_NONE, ACT_GEGLU = 0, 1
+
+_zero_pages = {}
+_alloc = None  # callable(shape, dtype) -> tensor ; set by runtime.Arena
+
+
+def set_allocator(fn):
+    global _alloc
+    prev = _alloc
+    _alloc = fn
+    return prev
+
+
+def empty(shape, dtype=torch.float16, device=None):
+    if _alloc is not None:
+        return _alloc(tuple(int(s) for s in shape), dtype)
+    return torch.empty(shape, dtype=dtype, device=device or torch.device("cuda", torch.cuda.current_device()))
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def zero_page(device):
+    key = (device.type, device.index)
+    zp = _zero_pages.get(key)
+    if zp is None:
+        zp = torch.zeros(4096, dtype=torch.uint8, device=device)
+        _zero_pages[key] = zp
+    return zp
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _check_f16(*ts):
+    for t in ts:
+        if t is not None and (t.dtype != torch.float16 or not t.is_cuda):
+            raise TypeError("expected fp16 device tensors, got %s on %s" % (t.dtype, t.device))
+
+
+def conv_gemm(x, wgt, nout, *, x1=None, n=None, h=None, w=None, kh=1, stride=1, pad=0, up=None, bias=None,
+              rowvec=None, residual=None, act=ACT_NONE, alpha=1.0, out=None, ld_out=None, out_dtype=torch.float16,
+              ldw=0, force_tile=0):
+    """OUT[M, ncols] = epilogue(A (*) W^T).  x: [N,H,W,C0] (or [M,C0] with kh == 1); x1: optional second source
+    concatenated along channels; wgt: [nout, kh*kh*(C0+C1)]; up=(UH, UW): nearest-resize before the conv."""
+    _check_f16(x, x1, wgt, bias, rowvec, residual)
+    if x.dim() == 2:
+        n_, h_, w_ = 1, 1, x.shape[0]
+    else:
+        n_, h_, w_ = x.shape[0], x.shape[1], x.shape[2]
+    n_, h_, w_ = (n or n_), (h or h_), (w or w_)
+    c0 = x.shape[-1]
+    c1 = x1.shape[-1] if x1 is not None else 0
+    ih, iw = (up if up is not None else (h_, w_))
+    oh = (ih + 2 * pad - kh) // stride + 1
+    ow = (iw + 2 * pad - kh) // stride + 1
+    m = n_ * oh * ow
+    ncols = nout // 2 if act == ACT_GEGLU else nout
+    if out is None:
+        out = empty((m, ncols), out_dtype, x.device)
+        ld_out = ncols
+    elif ld_out is None:
+        ld_out = out.stride(-2) if out.dim() >= 2 else ncols
+    a = GemmArgs()
+    a.a0, a.a1, a.c0, a.c1 = _p(x), _p(x1), c0, c1
+    a.a0_stride = x.stride(-2)
+    a.a1_stride = x1.stride(-2) if x1 is not None else 0
+    a.n, a.h, a.w, a.oh, a.ow = n_, h_, w_, oh, ow
+    a.kh, a.stride, a.pad = kh, stride, pad
+    a.up_h, a.up_w = (up if up is not None else (0, 0))
+    a.wgt, a.ldw, a.nout = _p(wgt), ldw or wgt.stride(0), nout
+    a.bias, a.rowvec = _p(bias), _p(rowvec)
+    a.ld_rowvec = rowvec.stride(0) if rowvec is not None else 0
+    a.residual = _p(residual)
+    a.ld_res = residual.stride(-2) if residual is not None else 0
+    a.alpha, a.act = float(alpha), act
+    a.out, a.ld_out = _p(out), ld_out
+    a.out_f32 = -force_tile if force_tile else (1 if out.dtype == torch.float32 else 0)
+    a.zero_page = _p(zero_page(x.device))
+    _lib.check(_lib.lib().fmx_gemm_conv_f16(C.byref(a), stream_ptr()), "fmx_gemm_conv_f16")
+    return out
+
+
+def linear(x, wgt, bias=None, **kw):
+    return conv_gemm(x, wgt, wgt.shape[0], bias=bias, **kw)
+
+
+def geglu_interleave(w, b):
+    inner = w.shape[0] // 2
+    wo = torch.empty_like(w)
+    bo = torch.empty_like(b) if b is not None else None
+    _lib.check(_lib.lib().fmx_geglu_interleave_rows(_p(w), _p(b), _p(wo), _p(bo), inner, w.shape[1], stream_ptr()),
+               "fmx_geglu_interleave_rows")
+    return wo, bo
+
+
+def attention(q, k, vt, *, batch, heads, nq, nk, nk_pad, dpad, scale, q_bs, q_rs, k_bs, k_rs, vt_bs, vt_hs, vt_ds,
+              out=None):
+    """q/k/vt are base tensors (views allowed: the data_ptr is the element (0,0,0,0)); strides in elements."""
+    _check_f16(q, k, vt)
+    if out is None:
+        out = empty((batch * nq, heads * dpad), torch.float16, q.device)
+    a = AttnArgs()
+    a.q, a.k, a.vt, a.o = _p(q), _p(k), _p(vt), _p(out)
+    a.q_bs, a.q_rs, a.k_bs, a.k_rs = q_bs, q_rs, k_bs, k_rs
+    a.vt_bs, a.vt_hs, a.vt_ds = vt_bs, vt_hs, vt_ds
+    a.o_bs, a.o_rs = nq * out.stride(0), out.stride(0)
+    a.batch, a.heads, a.nq, a.nk, a.nk_pad, a.dpad = batch, heads, nq, nk, nk_pad, dpad
+    a.scale = float(scale)
+    a.zero_page = _p(zero_page(q.device))
+    _lib.check(_lib.lib().fmx_attention_f16(C.byref(a), stream_ptr()), "fmx_attention_f16")
+    return out
+
+
+def softmax_rows_(x):
+    _check_f16(x)
+    _lib.check(_lib.lib().fmx_softmax_rows_f16(_p(x), x.shape[0], x.shape[1], x.stride(0), stream_ptr()), "fmx_softmax_rows_f16")
+    return x
+
+
+def _gn_chunks(n, hw):
+    want = max(1, -(-512 // n))
+    return int(max(1, min(64, want, max(1, hw // 64))))
+
+
+def groupnorm(x, gamma, beta, eps, *, x1=None, silu=False, groups=32, out=None):
+    """x: [N, H, W, C0] (x1: [N, H, W, C1] concatenated after it) -> [N, H, W, C0+C1]"""
+    _check_f16(x, x1, gamma, beta)
+    n = x.shape[0]
+    hw = x.numel() // (n * x.shape[-1])
+    c0 = x.shape[-1]
+    c1 = x1.shape[-1] if x1 is not None else 0
+    nch = _gn_chunks(n, hw)
+    partial = empty((n, nch, c0 + c1, 2), torch.float32, x.device)
+    if out is None:
+        out = empty(tuple(x.shape[:-1]) + (c0 + c1,), torch.float16, x.device)
+    L = _lib.lib()
+    _lib.check(L.fmx_groupnorm_stats_f16(_p(x), _p(x1), c0, c1, n, hw, _p(partial), nch, stream_ptr()), "fmx_groupnorm_stats_f16")
+    _lib.check(L.fmx_groupnorm_apply_f16(_p(x), _p(x1), c0, c1, n, hw, _p(partial), nch, groups, float(eps), _p(gamma), _p(beta),
+                                         1 if silu else 0, _p(out), stream_ptr()), "fmx_groupnorm_apply_f16")
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5, out=None):
+    _check_f16(x, gamma, beta)
+    c = x.shape[-1]
+    rows = x.numel() // c
+    if out is None:
+        out = empty(x.shape, torch.float16, x.device)
+    _lib.check(_lib.lib().fmx_layernorm_f16(_p(x), _p(gamma), _p(beta), _p(out), rows, c, float(eps), stream_ptr()), "fmx_layernorm_f16")
+    return out
+
+
+def timestep_embedding(t, dim, max_period=10000.0, out=None):
+    b = t.shape[0]
+    if out is None:
+        out = empty((b, dim), torch.float16, t.device)
+    _lib.check(_lib.lib().fmx_timestep_embedding(_p(t), _p(out), b, dim, float(max_period), stream_ptr()), "fmx_timestep_embedding")
+    return out
+
+
+def silu(x, out=None):
+    if out is None:
+        out = empty(x.shape, torch.float16, x.device)
+    _lib.check(_lib.lib().fmx_silu_f16(_p(x), _p(out), x.numel(), stream_ptr()), "fmx_silu_f16")
+    return out
+
+
+def cast_f16(x, out=None):
+    if out is None:
+        out = empty(x.shape, torch.float16, x.device)
+    _lib.check(_lib.lib().fmx_cast_f32_to_f16(_p(x), _p(out), x.numel(), stream_ptr()), "fmx_cast_f32_to_f16")
+    return out
+
+
+def unet_pack_input(x, sigma, reps, sigma_data=1.0, out=None):
+    b, c, h, w = x.shape
+    if out is None:
+        out = empty((reps * b * h * w, 64), torch.float16, x.device)
+    _lib.check(_lib.lib().fmx_unet_pack_input(_p(x), _p(sigma), float(sigma_data), b, c, h, w, reps, _p(out), stream_ptr()),
+               "fmx_unet_pack_input")
+    return out
+
+
+def im2col3x3_smallc(x, c, out=None):
+    n, h, w, ld = x.shape
+    if out is None:
+        out = empty((n * h * w, 64), torch.float16, x.device)
+    _lib.check(_lib.lib().fmx_im2col3x3_smallc(_p(x), ld, n, c, h, w, _p(out), stream_ptr()), "fmx_im2col3x3_smallc")
+    return out
+
+
+def cfg_combine(eps, ld_eps, x, sigma, reps, cond_scale, denoised=None, cond_pred=None, uncond_pred=None):
+    b, c, h, w = x.shape
+    if denoised is None:
+        denoised = torch.empty_like(x)
+    _lib.check(_lib.lib().fmx_cfg_combine(_p(eps), ld_eps, _p(x), _p(sigma), b, c, h, w, reps, float(cond_scale), _p(denoised),
+                                          _p(cond_pred), _p(uncond_pred), stream_ptr()), "fmx_cfg_combine")
+    return denoised
+
+
+def euler_step(x, denoised, sigma, sigma_next, noise=None, noise_scale=0.0, out=None):
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(_lib.lib().fmx_sampler_euler_step(_p(x), _p(denoised), float(sigma), float(sigma_next), _p(noise), float(noise_scale),
+                                                 _p(out), x.numel(), stream_ptr()), "fmx_sampler_euler_step")
+    return out
+
+
+def lincomb3(x, d0, d1, a, b, c, out=None):
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(_lib.lib().fmx_sampler_lincomb3(_p(x), _p(d0), _p(d1), float(a), float(b), float(c), _p(out), x.numel(), stream_ptr()),
+               "fmx_sampler_lincomb3")
+    return out
+
+
+def scale_f32(x, s, out=None):
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(_lib.lib().fmx_scale_f32(_p(x), float(s), _p(out), x.numel(), stream_ptr()), "fmx_scale_f32")
+    return out
+
+
+def vae_pack_latent(z, scaling_factor, shift, ld=8, out=None):
+    b, c, h, w = z.shape
+    if out is None:
+        out = empty((b, h, w, ld), torch.float16, z.device)
+    _lib.check(_lib.lib().fmx_vae_pack_latent(_p(z), float(scaling_factor), float(shift), b, c, h, w, _p(out), ld, stream_ptr()),
+               "fmx_vae_pack_latent")
+    return out
+
+
+def vae_unpack_image(y, ld, npix, c, out):
+    _lib.check(_lib.lib().fmx_vae_unpack_image(_p(y), ld, npix, c, _p(out), stream_ptr()), "fmx_vae_unpack_image")
+    return out
+
+
+def philox_randn(seed, offset, n, device, want_raw=False):
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    raw = torch.empty((n, 4), dtype=torch.int32, device=device) if want_raw else None
+    _lib.check(_lib.lib().fmx_philox_randn(C.c_uint64(int(seed) & (2 ** 64 - 1)), C.c_uint32(int(offset)), _p(out), _p(raw), n, stream_ptr()),
+               "fmx_philox_randn")
+    return (out, raw) if want_raw else out

@@ -1,0 +1,105 @@
+"""Micro-benchmarks of the individual HIP kernels at the SDXL / SD1.5 problem shapes.
+Prints one JSON line per case: achieved TFLOP/s or GB/s (algorithmic work / HIP-event time)."""
+import json
+import math
+import sys
+import os
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import forge_amd  # noqa
+from forge_amd import hipops as ops
+
+DEV = "cuda"
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e-3
+
+
+def rnd(*shape, scale=1.0):
+    return (torch.randn(*shape, device=DEV) * scale).half()
+
+
+def bench_linear(m, n, k, tile=0, act=0):
+    x, w, b = rnd(m, k), rnd(n, k, scale=k ** -0.5), rnd(n)
+    out = torch.empty(m, n // 2 if act else n, dtype=torch.float16, device=DEV)
+    t = timeit(lambda: ops.conv_gemm(x, w, n, bias=b, out=out, ld_out=out.shape[1], act=act, force_tile=tile))
+    print(json.dumps({"op": "linear", "m": m, "n": n, "k": k, "tile": tile, "act": act, "us": round(t * 1e6, 1), "tflops": round(2 * m * n * k / t / 1e12, 1)}), flush=True)
+
+
+def bench_conv(n, h, w, c, co, tile=0, stride=1, up=None):
+    x, wk, b = rnd(n, h, w, c), rnd(co, 9 * c, scale=(9 * c) ** -0.5), rnd(co)
+    oh, ow = (up or (h, w))
+    oh, ow = oh // stride, ow // stride
+    out = torch.empty(n * oh * ow, co, dtype=torch.float16, device=DEV)
+    t = timeit(lambda: ops.conv_gemm(x, wk, co, kh=3, pad=1, stride=stride, up=up, bias=b, out=out, ld_out=co, force_tile=tile))
+    print(json.dumps({"op": "conv3x3", "n": n, "hw": [h, w], "c": c, "co": co, "stride": stride, "up": up, "tile": tile, "us": round(t * 1e6, 1),
+                      "tflops": round(2 * n * oh * ow * co * 9 * c / t / 1e12, 1)}), flush=True)
+
+
+def bench_attn(b, h, nq, nk, d, dpad):
+    nkp = -(-nk // 64) * 64
+    q, k = rnd(b, nq, h, dpad), rnd(b, nkp, h, dpad)
+    vt = rnd(h, dpad, b, nkp)
+    out = torch.empty(b * nq, h * dpad, dtype=torch.float16, device=DEV)
+    t = timeit(lambda: ops.attention(q, k, vt, batch=b, heads=h, nq=nq, nk=nk, nk_pad=nkp, dpad=dpad, scale=d ** -0.5, q_bs=nq * h * dpad,
+                                     q_rs=h * dpad, k_bs=nkp * h * dpad, k_rs=h * dpad, vt_bs=nkp, vt_hs=dpad * b * nkp, vt_ds=b * nkp, out=out))
+    print(json.dumps({"op": "attention", "b": b, "h": h, "nq": nq, "nk": nk, "d": d, "us": round(t * 1e6, 1),
+                      "tflops": round(4 * b * h * nq * nk * d / t / 1e12, 1)}), flush=True)
+
+
+def bench_gn(n, h, w, c):
+    x, g, bb = rnd(n, h, w, c), rnd(c), rnd(c)
+    out = torch.empty_like(x)
+    t = timeit(lambda: ops.groupnorm(x, g, bb, 1e-5, silu=True, out=out))
+    by = x.numel() * 2
+    print(json.dumps({"op": "groupnorm_silu", "n": n, "hw": [h, w], "c": c, "us": round(t * 1e6, 1), "GBps_alg(1R+1W)": round(2 * by / t / 1e9, 0),
+                      "GBps_touched(2R+1W)": round(3 * by / t / 1e9, 0)}), flush=True)
+
+
+def bench_ln(rows, c):
+    x, g, bb = rnd(rows, c), rnd(c), rnd(c)
+    out = torch.empty_like(x)
+    t = timeit(lambda: ops.layernorm(x, g, bb, out=out))
+    print(json.dumps({"op": "layernorm", "rows": rows, "c": c, "us": round(t * 1e6, 1), "GBps": round(2 * x.numel() * 2 / t / 1e9, 0)}), flush=True)
+
+
+if __name__ == "__main__":
+    Bu = 16  # SDXL B=8 with CFG
+    for tile in (1, 2, 3):
+        bench_linear(Bu * 1024, 1280, 1280, tile)
+    bench_linear(Bu * 1024, 10240, 1280, 0, act=1)
+    bench_linear(Bu * 1024, 1280, 5120)
+    bench_linear(Bu * 4096, 640, 640)
+    bench_linear(Bu * 4096, 5120, 640, 0, act=1)
+    bench_linear(Bu * 4096, 640, 2560)
+    bench_linear(8192, 8192, 8192, 1)
+    for tile in (1, 2):
+        bench_conv(Bu, 128, 128, 320, 320, tile)
+    bench_conv(Bu, 64, 64, 640, 640)
+    bench_conv(Bu, 32, 32, 1280, 1280)
+    bench_conv(Bu, 32, 32, 2560, 1280)
+    bench_conv(Bu, 32, 32, 1280, 1280, up=(64, 64))
+    bench_conv(Bu, 128, 128, 320, 320, stride=2)
+    bench_attn(Bu, 10, 4096, 4096, 64, 64)
+    bench_attn(Bu, 20, 1024, 1024, 64, 64)
+    bench_attn(Bu, 20, 1024, 77, 64, 64)
+    bench_attn(8, 8, 4096, 4096, 40, 48)
+    bench_attn(8, 8, 1024, 1024, 80, 80)
+    bench_attn(8, 8, 256, 256, 160, 160)
+    bench_gn(Bu, 128, 128, 320)
+    bench_gn(Bu, 64, 64, 640)
+    bench_gn(Bu, 32, 32, 1280)
+    bench_ln(Bu * 4096, 640)
+    bench_ln(Bu * 1024, 1280)
