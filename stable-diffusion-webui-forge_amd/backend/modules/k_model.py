@@ -1,0 +1,148 @@
+"""`KModel` -- mirror of backend/modules/k_model.py:8-59 over the native UNet executor.
+
+`apply_model(x, t=sigma, c_crossattn, y, ...)` keeps the reference contract (fp32 NCHW latents in, fp32 denoised
+out) but executes `x / sqrt(sigma^2+1)` + im2col as ONE pack kernel, the UNet as a (graph-replayed) chain of gfx950
+kernels and `x - eps*sigma` as ONE kernel.  The fully fused CFG path used by the sampler is `denoise_cfg` below:
+[uncond ; cond] batch in one forward, CFG combine fused with calculate_denoised.
+"""
+import torch
+
+from ... import hipops as ops
+from ...runtime import HipGraph
+
+
+class SigmaInfo:
+    """Host knowledge about a device sigma vector (attached by our samplers to avoid a device sync per step)."""
+
+    __slots__ = ("host",)
+
+    def __init__(self, host):
+        self.host = host  # list[float], one per sample
+
+
+def host_sigmas(sigma):
+    info = getattr(sigma, "fmx_sigma", None)
+    if info is not None:
+        return info.host
+    return [float(v) for v in sigma.detach().float().cpu().tolist()]  # foreign caller: one sync
+
+
+class KModel:
+    def __init__(self, model, predictor, use_graph=True):
+        self.diffusion_model = model
+        self.predictor = predictor
+        self.storage_dtype = model.storage_dtype
+        self.computation_dtype = model.computation_dtype
+        self.device = model.device
+        self.use_graph = use_graph
+        self._graphs = {}
+        self._static = {}
+        self._stream = None
+
+    def memory_required(self, input_shape):
+        return 0  # weights and arena are resident (288 GB HBM); kept for interface parity (k_model.py:48-59)
+
+    # --------------------------------------------------------------------------------------------------------
+    def _timesteps(self, sig_host, reps):
+        t = self.predictor.timestep(torch.tensor(sig_host, dtype=torch.float32)).float()
+        return t.repeat(reps)
+
+    def _forward_static(self, key, x, sigma_dev, sig_host, reps, ctxc):
+        """pack -> UNet -> (returns eps view); static buffers per shape so the UNet can be graph-replayed."""
+        b, c, hh, ww = x.shape
+        bu = reps * b
+        st = self._static.get(key)
+        if st is None:
+            st = {"xcol": torch.empty(bu * hh * ww, 64, dtype=torch.float16, device=self.device),
+                  "t": torch.empty(bu, dtype=torch.float32, device=self.device), "eps": None, "warm": 0}
+            self._static[key] = st
+        ops.unet_pack_input(x, sigma_dev, reps, self.predictor.sigma_data, out=st["xcol"])
+        tvals = self._timesteps(sig_host, reps)
+        if len(set(tvals.tolist())) == 1:
+            st["t"].fill_(float(tvals[0]))
+        else:
+            st["t"].copy_(tvals, non_blocking=False)
+        net = self.diffusion_model
+        if not self.use_graph:
+            return net.forward_packed(st["xcol"], st["t"], ctxc, bu, hh, ww)
+        g = self._graphs.get(key)
+        if g is None:
+            # eager warm-up (sizes the arena, creates lazily-built buffers), then capture on a side stream
+            eps = net.forward_packed(st["xcol"], st["t"], ctxc, bu, hh, ww)
+            st["warm"] += 1
+            if st["warm"] < 2:
+                return eps
+            cur = torch.cuda.current_stream(self.device)
+            if self._stream is None:
+                self._stream = torch.cuda.Stream(self.device)
+            s = self._stream
+            s.wait_stream(cur)
+            g = HipGraph()
+            with torch.cuda.stream(s):
+                st["eps"] = g.capture(s, lambda: net.forward_packed(st["xcol"], st["t"], ctxc, bu, hh, ww))
+                g.launch(s)
+            cur.wait_stream(s)
+            self._graphs[key] = g
+            st["ctx_key"] = ctxc.key
+            return st["eps"]
+        if st.get("ctx_key") != ctxc.key:
+            # new conditioning re-uses the same cached K/V buffers only if shapes match; simplest safe policy: recapture
+            g.destroy()
+            del self._graphs[key]
+            st["warm"] = 1
+            return self._forward_static(key, x, sigma_dev, sig_host, reps, ctxc)
+        cur = torch.cuda.current_stream(self.device)
+        s = self._stream
+        s.wait_stream(cur)
+        g.launch(s)
+        cur.wait_stream(s)
+        return st["eps"]
+
+    def denoise_cfg(self, x, sigma, uncond_ctx, cond_ctx, cond_scale, want_parts=False):
+        """Fused path: returns CFG-combined denoised (fp32 NCHW) [+ cond_pred, uncond_pred].
+        `uncond_ctx`/`cond_ctx`: (context [B,T,Dc], y or None); uncond_ctx None => cond_scale == 1 shortcut."""
+        b, c, hh, ww = x.shape
+        reps = 1 if uncond_ctx is None else 2
+        sig_host = host_sigmas(sigma)
+        if reps == 2:
+            ctx = self._stack_ctx(uncond_ctx, cond_ctx)
+        else:
+            ctx = cond_ctx
+        ctxc = self.diffusion_model.prepare_context(ctx[0], ctx[1])
+        key = (b, c, hh, ww, reps)
+        eps = self._forward_static(key, x, sigma, sig_host, reps, ctxc)
+        cond_pred = torch.empty_like(x) if want_parts else None
+        uncond_pred = torch.empty_like(x) if want_parts else None
+        den = ops.cfg_combine(eps, eps.shape[-1], x, sigma, reps, cond_scale, None, cond_pred, uncond_pred)
+        return (den, cond_pred, uncond_pred) if want_parts else den
+
+    def _stack_ctx(self, uc, c):
+        """[uncond ; cond] along batch (sampling_function.py:187-236 order); cached on the identity of the parts."""
+        key = (uc[0].data_ptr(), c[0].data_ptr(), uc[0]._version, c[0]._version, tuple(uc[0].shape), tuple(c[0].shape))
+        cached = getattr(self, "_stacked", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        tu, tc = uc[0].shape[1], c[0].shape[1]
+        cu, cc = uc[0], c[0]
+        if tu != tc:  # ConditionCrossAttn.concat (condition.py:56-70): repeat to the lcm of the token counts
+            import math
+            l = tu * tc // math.gcd(tu, tc)
+            cu, cc = cu.repeat(1, l // tu, 1), cc.repeat(1, l // tc, 1)
+        ctx = torch.cat([cu, cc]).contiguous()
+        y = None if c[1] is None else torch.cat([uc[1], c[1]]).contiguous()
+        self._stacked = (key, (ctx, y), (uc, c))
+        return ctx, y
+
+    def apply_model(self, x, t, c_concat=None, c_crossattn=None, control=None, transformer_options=None, y=None, **kwargs):
+        """Reference signature (k_model.py:25): x fp32 [Bu,C,H,W], t = sigma [Bu] -> denoised fp32."""
+        if c_concat is not None or control is not None:
+            raise NotImplementedError("c_concat / control are outside the txt2img hot path")
+        to = transformer_options or {}
+        if to.get("patches") or to.get("patches_replace") or to.get("block_modifiers"):
+            raise NotImplementedError("transformer patches are not supported by the native executor")
+        x = x.to(device=self.device, dtype=torch.float32).contiguous()
+        sigma = t.to(device=self.device, dtype=torch.float32).contiguous()
+        ctxc = self.diffusion_model.prepare_context(c_crossattn, y)
+        b, c, hh, ww = x.shape
+        eps = self._forward_static((b, c, hh, ww, 1, "apply"), x, sigma, host_sigmas(t), 1, ctxc)
+        return ops.cfg_combine(eps, eps.shape[-1], x, sigma, 1, 1.0)

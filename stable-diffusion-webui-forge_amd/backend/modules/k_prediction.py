@@ -1,0 +1,67 @@
+"""Sigma schedule / prediction algebra of the path -- host-side mirror of backend/modules/k_prediction.py.
+
+`Prediction` keeps the reference's names and semantics (:113-159): 1000-entry scaled-linear sigma table computed
+in float64 and stored fp32, nearest-index `timestep()`, log-linear `sigma()`.  The table lives on the HOST: it is
+1000 floats consulted once per step, while the tensor-sized arithmetic (`calculate_input`, `calculate_denoised`,
+`noise_scaling`, :74-104) runs in the fused HIP kernels (fmx_unet_pack_input / fmx_cfg_combine / fmx_scale_f32).
+"""
+import torch
+
+from ... import hipops as ops
+
+
+class AbstractPrediction:
+    def __init__(self, sigma_data=1.0, prediction_type="epsilon"):
+        if prediction_type != "epsilon":
+            raise NotImplementedError("only epsilon prediction is on the SD1.x/SDXL path (k_prediction.py:81-92)")
+        self.sigma_data = sigma_data
+        self.prediction_type = prediction_type
+
+    def noise_scaling(self, sigma, noise, latent_image=None, max_denoise=False):
+        """k_prediction.py:94-104; `sigma` is a host scalar (sigmas[0]).  latent_image None == zeros (txt2img)."""
+        s = float(sigma)
+        f = (1.0 + s ** 2.0) ** 0.5 if max_denoise else s
+        out = ops.scale_f32(noise, f)
+        if latent_image is not None:
+            out += latent_image
+        return out
+
+
+class Prediction(AbstractPrediction):
+    def __init__(self, sigma_data=1.0, prediction_type="epsilon", beta_schedule="linear", linear_start=0.00085,
+                 linear_end=0.012, timesteps=1000):
+        super().__init__(sigma_data, prediction_type)
+        if beta_schedule != "linear":
+            raise NotImplementedError(beta_schedule)
+        betas = torch.linspace(linear_start ** 0.5, linear_end ** 0.5, timesteps, dtype=torch.float64) ** 2
+        alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        sigmas = ((1 - alphas_cumprod) / alphas_cumprod) ** 0.5
+        self.alphas_cumprod = alphas_cumprod.float()
+        self.sigmas = sigmas.float()
+        self.log_sigmas = sigmas.log().float()
+
+    @property
+    def sigma_min(self):
+        return self.sigmas[0]
+
+    @property
+    def sigma_max(self):
+        return self.sigmas[-1]
+
+    def timestep(self, sigma):
+        """Nearest table index (argmin in log space), :148-151.  `sigma`: host tensor [B] (or python floats)."""
+        sigma = torch.as_tensor(sigma, dtype=torch.float32).reshape(-1).cpu()
+        dists = sigma.log()[None, :] - self.log_sigmas[:, None]
+        return dists.abs().argmin(dim=0)
+
+    def sigma(self, timestep):
+        t = torch.clamp(torch.as_tensor(timestep).float().cpu(), min=0, max=len(self.sigmas) - 1)
+        lo, hi, w = t.floor().long(), t.ceil().long(), t.frac()
+        return ((1 - w) * self.log_sigmas[lo] + w * self.log_sigmas[hi]).exp()
+
+    def percent_to_sigma(self, percent):
+        if percent <= 0.0:
+            return 999999999.9
+        if percent >= 1.0:
+            return 0.0
+        return self.sigma(torch.tensor(1000.0 * (1.0 - percent))).item()

@@ -1,0 +1,200 @@
+"""MI355X-native AutoencoderKL *decoder* (the VAE half on the txt2img path).
+
+Drop-in for `IntegratedAutoencoderKL.decode / process_out` (reference: backend/nn/vae.py:305-316, Decoder.forward
+:248-271) plus the `VAE.decode_inner` post-processing (backend/patcher/vae.py:128-148): fp16 NHWC activations, all
+3x3 convs on the MFMA implicit-GEMM kernel with the nearest-x2 Upsample (vae.py:35-57) fused into the conv's
+loader, GroupNorm(eps 1e-6)+SiLU fused, residual adds in the conv epilogue.  The single-head mid-block attention
+(C = 512, N up to 16 384; attention.py:412-422) runs as S = QK^T (GEMM) -> row softmax -> PV (GEMM): with 288 GB
+of HBM the N x N score matrix of one image (512 MB at 1024^2) is affordable and keeps the MFMA GEMM as the only
+heavy kernel; V's bias is added after PV (softmax rows sum to 1).
+The reference decodes in fp32 on AMD (backend/memory_management.py:190-205); this path is fp16 storage with fp32
+accumulation everywhere (GEMM, norm statistics, softmax).
+"""
+import torch
+
+from ... import hipops as ops
+from ...runtime import Arena, ArenaOverflow
+from .layout import vae_decoder_layout
+from .unet import _conv_w
+
+
+class IntegratedAutoencoderKL:
+    def __init__(self, config, state_dict, device="cuda"):
+        self.config = dict(config)
+        self.layout = vae_decoder_layout(config)
+        self.device = torch.device(device)
+        self.scaling_factor = self.layout.scaling_factor
+        self.shift_factor = self.layout.shift_factor
+        self.latent_channels = self.layout.latent_channels
+        self._arena = None
+        self.up_factor = 2 ** (len(self.layout.levels) - 1)
+        self._load(state_dict)
+
+    def _load(self, sd):
+        dev = self.device
+
+        def T(k):
+            return sd[k].to(device=dev, dtype=torch.float16).contiguous()
+
+        def conv(k):
+            return (_conv_w(sd[k + ".weight"].to(dev, torch.float16)), T(k + ".bias"))
+
+        def norm(k):
+            return (T(k + ".weight"), T(k + ".bias"))
+
+        w = {}
+        lay = self.layout
+        lc = lay.latent_channels
+        # post_quant_conv (1x1, lc->lc) folded into conv_in's im2col GEMM is not exact at the borders (zero padding
+        # happens after the 1x1 conv + bias), so it runs as its own tiny GEMM on a 64-wide zero-padded latent.
+        if lay.use_post_quant_conv:
+            pw = sd["post_quant_conv.weight"].to(dev, torch.float16).reshape(lc, lc)
+            wp = pw.new_zeros(8, 64)
+            wp[:lc, :lc] = pw
+            bp = pw.new_zeros(8)
+            bp[:lc] = T("post_quant_conv.bias")
+            w["pq"] = (wp.contiguous(), bp.contiguous())
+        cw = _conv_w(sd["decoder.conv_in.weight"].to(dev, torch.float16))
+        wp = cw.new_zeros(cw.shape[0], 64)
+        wp[:, :cw.shape[1]] = cw
+        w["conv_in"] = (wp.contiguous(), T("decoder.conv_in.bias"))
+
+        def res(k, cin, cout):
+            w[k + ".n1"], w[k + ".c1"] = norm(k + ".norm1"), conv(k + ".conv1")
+            w[k + ".n2"], w[k + ".c2"] = norm(k + ".norm2"), conv(k + ".conv2")
+            if cin != cout:
+                w[k + ".sc"] = conv(k + ".nin_shortcut")
+
+        bi = lay.block_in
+        res("decoder.mid.block_1", bi, bi)
+        res("decoder.mid.block_2", bi, bi)
+        a = "decoder.mid.attn_1"
+        w[a + ".norm"] = norm(a + ".norm")
+        qw, qb = conv(a + ".q")
+        kw, kb = conv(a + ".k")
+        w[a + ".qk"] = (torch.cat([qw, kw], 0).contiguous(), torch.cat([qb, kb], 0).contiguous())
+        w[a + ".v"] = conv(a + ".v")
+        w[a + ".proj_out"] = conv(a + ".proj_out")
+        for _, blocks, up in lay.levels:
+            for key, cin, cout in blocks:
+                res(key, cin, cout)
+            if up is not None:
+                w[up] = conv(up + ".conv")
+        w["norm_out"] = norm("decoder.norm_out")
+        w["conv_out"] = conv("decoder.conv_out")
+        self.w = w
+        torch.cuda.synchronize(dev)
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _res(self, k, x, cin, cout, arena):
+        b, hh, ww, _ = x.shape
+        out = ops.empty((b, hh, ww, cout))
+        m = arena.mark()
+        g1 = ops.groupnorm(x, *self.w[k + ".n1"], 1e-6, silu=True)
+        h = ops.conv_gemm(g1, self.w[k + ".c1"][0], cout, kh=3, pad=1, bias=self.w[k + ".c1"][1]).view(b, hh, ww, cout)
+        g2 = ops.groupnorm(h, *self.w[k + ".n2"], 1e-6, silu=True)
+        sk = ops.conv_gemm(x, self.w[k + ".sc"][0], cout, bias=self.w[k + ".sc"][1]) if cin != cout else x.view(-1, cout)
+        ops.conv_gemm(g2, self.w[k + ".c2"][0], cout, kh=3, pad=1, bias=self.w[k + ".c2"][1], residual=sk, out=out.view(-1, cout), ld_out=cout)
+        arena.release(m)
+        return out
+
+    def _attn(self, x, arena):
+        a = "decoder.mid.attn_1"
+        b, hh, ww, c = x.shape
+        n = hh * ww
+        out = ops.empty((b, hh, ww, c))
+        m = arena.mark()
+        g = ops.groupnorm(x, *self.w[a + ".norm"], 1e-6).view(-1, c)
+        qk = ops.linear(g, *self.w[a + ".qk"])                                  # [B*N, 2C]
+        o = ops.empty((b * n, c))
+        npad = -(-n // 64) * 64
+        scale = c ** -0.5
+        for bi in range(b):
+            mk = arena.mark()
+            gb = g[bi * n:(bi + 1) * n]
+            q = qk[bi * n:(bi + 1) * n, :c]
+            kk = qk[bi * n:(bi + 1) * n, c:]
+            s = ops.empty((n, npad))
+            if npad != n:
+                s.zero_()  # padded key columns must hold finite values for the PV GEMM (their P is never produced)
+            ops.conv_gemm(q, kk, n, alpha=scale, out=s, ld_out=npad)             # S = scale * Q K^T
+            ops.softmax_rows_(s[:, :n])
+            if npad != n:
+                s[:, n:].zero_()
+            vt = ops.empty((c, npad))
+            if npad != n:
+                vt.zero_()
+            ops.conv_gemm(self.w[a + ".v"][0], gb, n, out=vt, ld_out=npad)        # V^T (bias deferred)
+            ops.conv_gemm(s, vt, c, bias=self.w[a + ".v"][1], out=o[bi * n:(bi + 1) * n], ld_out=c)  # P V + b_v
+            arena.release(mk)
+        ops.linear(o, *self.w[a + ".proj_out"], residual=x.view(-1, c), out=out.view(-1, c), ld_out=c)
+        arena.release(m)
+        return out
+
+    def _decode_impl(self, z, arena):
+        """z fp32 NCHW [B, lc, h, w] (already process_out'ed) -> fp16 [B*8h*8w, 4] (first out_channels valid)"""
+        lay = self.layout
+        b, lc, hh, ww = z.shape
+        zl = ops.vae_pack_latent(z, 1.0, 0.0, ld=64)                              # [B,h,w,64] zero padded
+        if lay.use_post_quant_conv:
+            zq = ops.conv_gemm(zl.view(-1, 64), self.w["pq"][0], 8, bias=self.w["pq"][1]).view(b, hh, ww, 8)
+        else:
+            zq = zl
+        col = ops.im2col3x3_smallc(zq, lc)
+        h = ops.linear(col, *self.w["conv_in"]).view(b, hh, ww, lay.block_in)
+        bi = lay.block_in
+        h = self._res("decoder.mid.block_1", h, bi, bi, arena)
+        h = self._attn(h, arena)
+        h = self._res("decoder.mid.block_2", h, bi, bi, arena)
+        for _, blocks, up in lay.levels:
+            for key, cin, cout in blocks:
+                h = self._res(key, h, cin, cout, arena)
+            if up is not None:
+                bb, h2, w2, c = h.shape
+                h = ops.conv_gemm(h, self.w[up][0], c, kh=3, pad=1, up=(2 * h2, 2 * w2), bias=self.w[up][1]).view(bb, 2 * h2, 2 * w2, c)
+        g = ops.groupnorm(h, *self.w["norm_out"], 1e-6, silu=True)
+        y = ops.conv_gemm(g, self.w["conv_out"][0], lay.out_channels, kh=3, pad=1, bias=self.w["conv_out"][1],
+                          out=ops.empty((g.shape[0] * g.shape[1] * g.shape[2], 4)), ld_out=4)
+        return y
+
+    def _run(self, z):
+        b, lc, hh, ww = z.shape
+        f = self.up_factor
+        need = max(1 << 28, int(b * hh * ww * f * f * self.layout.final_ch * 2 * 14) + 2 * (hh * ww) ** 2 * 2)
+        while True:
+            if self._arena is None or self._arena.capacity < need:
+                self._arena = None
+                self._arena = Arena(need, self.device)
+            arena = self._arena
+            arena.reset()
+            try:
+                with arena:
+                    return self._decode_impl(z, arena)
+            except ArenaOverflow:
+                torch.cuda.synchronize(self.device)
+                need = arena.capacity * 2
+                self._arena = None
+
+    # ---- reference surface ---------------------------------------------------------------------------------------
+    def process_out(self, latent):
+        return (latent / self.scaling_factor) + self.shift_factor  # vae.py:315
+
+    def decode(self, z):
+        """vae.py:305-311: z [B, lc, h, w] -> [B, 3, 8h, 8w] (same dtype as z)."""
+        zf = z.to(device=self.device, dtype=torch.float32).contiguous()
+        y = self._run(zf)
+        b, _, hh, ww = z.shape
+        oc = self.layout.out_channels
+        f = self.up_factor
+        return y.view(b, f * hh, f * ww, 4)[..., :oc].permute(0, 3, 1, 2).to(z.dtype)
+
+    def decode_inner(self, samples_in):
+        """patcher/vae.py:128-148: -> fp32 [B, 8h, 8w, 3] in [0, 1] (clamp((y+1)/2) fused into the unpack kernel)."""
+        zf = samples_in.to(device=self.device, dtype=torch.float32).contiguous()
+        y = self._run(zf)
+        b, _, hh, ww = samples_in.shape
+        oc = self.layout.out_channels
+        f = self.up_factor
+        out = torch.empty(b, f * hh, f * ww, oc, dtype=torch.float32, device=self.device)
+        ops.vae_unpack_image(y, 4, b * f * f * hh * ww, oc, out)
+        return out

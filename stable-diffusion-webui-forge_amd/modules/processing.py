@@ -1,0 +1,118 @@
+"""txt2img job orchestration -- mirror of modules/processing.py for the hot path:
+`StableDiffusionProcessingTxt2Img` (dataclass fields :123-216 that the path reads), `.sample` (:1342-1391),
+`process_images` / `process_images_inner` (:815-1158: seeds seed+i :894, ImageRNG :944, p.sample :990,
+decode_latent_batch :1010, clamp + *255 + uint8 truncation :1012-1040), `decode_latent_batch` (:628).
+Prompts are replaced by ready conditioning tensors (`p.c`, `p.uc`): the text encoders are out of scope.
+"""
+from dataclasses import dataclass, field
+from typing import Any, List, Optional
+
+import numpy as np
+import torch
+
+from . import rng, sd_samplers, shared
+
+
+@dataclass
+class Processed:
+    images: List[Any]
+    latents: torch.Tensor
+    seeds: List[int]
+    decoded: Optional[torch.Tensor] = None
+
+
+def decode_first_stage(model, x):
+    return model.decode_first_stage(x)
+
+
+def decode_latent_batch(model, batch, target_device=None, check_for_nans=False):
+    samples = decode_first_stage(model, batch)
+    if target_device is not None:
+        samples = samples.to(target_device)
+    return [x for x in samples]
+
+
+@dataclass
+class StableDiffusionProcessingTxt2Img:
+    sd_model: Any = None
+    c: Any = None                 # cond:   tensor [B,T,D] or {"crossattn","vector"} (prompt_parser.DictWithShape)
+    uc: Any = None                # uncond: same
+    seed: int = -1
+    sampler_name: str = "Euler"
+    scheduler: Optional[str] = None
+    batch_size: int = 1
+    n_iter: int = 1
+    steps: int = 20
+    cfg_scale: float = 7.0
+    width: int = 512
+    height: int = 512
+    eta: Optional[float] = None
+    s_min_uncond: float = 0.0
+    s_churn: float = 0.0
+    s_tmin: float = 0.0
+    s_tmax: float = float("inf")
+    s_noise: float = 1.0
+    is_hr_pass: bool = False
+    enable_hr: bool = False
+    do_decode: bool = True
+    disable_progress: bool = True
+    sampler_noise_scheduler_override: Any = None
+    scripts: Any = None
+    extra_generation_params: dict = field(default_factory=dict)
+    # filled while running
+    seeds: List[int] = field(default_factory=list)
+    all_seeds: List[int] = field(default_factory=list)
+    rng: Any = None
+    sampler: Any = None
+    iteration: int = 0
+
+    def txt2img_image_conditioning(self, x, width=None, height=None):
+        # processing.py:362-371 -- non-inpaint models get a dummy 1x1 zero conditioning
+        return x.new_zeros(x.shape[0], 5, 1, 1)
+
+    def sample(self, conditioning, unconditional_conditioning, seeds, subseeds=None, subseed_strength=0.0, prompts=None):
+        self.sampler = sd_samplers.create_sampler(self.sampler_name, self.sd_model)
+        x = self.rng.next()
+        self.sd_model.forge_objects = self.sd_model.forge_objects_after_applying_lora.shallow_copy()
+        samples = self.sampler.sample(self, x, conditioning, unconditional_conditioning,
+                                      image_conditioning=self.txt2img_image_conditioning(x))
+        return samples
+
+
+def _slice_cond(c, a, b):
+    if isinstance(c, dict):
+        return type(c)({k: v[a:b] for k, v in c.items()})
+    return c[a:b]
+
+
+def process_images(p) -> Processed:
+    return process_images_inner(p)
+
+
+@torch.inference_mode()
+def process_images_inner(p) -> Processed:
+    seed = int(p.seed) if p.seed is not None and int(p.seed) != -1 else int(np.random.randint(0, 2 ** 31 - 1))
+    total = p.batch_size * p.n_iter
+    p.all_seeds = [seed + i for i in range(total)]  # :894 (no subseed strength)
+    dev = p.sd_model.device
+    lc = p.sd_model.forge_objects.vae.latent_channels if p.sd_model.forge_objects.vae is not None else 4
+    images, lat_all, dec_all = [], [], []
+    shared.state.interrupted = False
+    for n in range(p.n_iter):
+        p.iteration = n
+        lo, hi = n * p.batch_size, (n + 1) * p.batch_size
+        p.seeds = p.all_seeds[lo:hi]
+        p.rng = rng.ImageRNG((lc, p.height // 8, p.width // 8), p.seeds, device=dev)
+        c, uc = _slice_cond(p.c, lo, hi), _slice_cond(p.uc, lo, hi)
+        samples = p.sample(conditioning=c, unconditional_conditioning=uc, seeds=p.seeds)
+        lat_all.append(samples)
+        if not p.do_decode or p.sd_model.forge_objects.vae is None:
+            continue
+        x = torch.stack(decode_latent_batch(p.sd_model, samples, target_device=None)).float()
+        dec_all.append(x)
+        x = torch.clamp((x + 1.0) / 2.0, min=0.0, max=1.0)
+        for xs in x:
+            arr = 255.0 * np.moveaxis(xs.cpu().numpy(), 0, 2)
+            images.append(arr.astype(np.uint8))  # truncation, as the reference (:1039-1040)
+    return Processed(images=images, latents=torch.cat(lat_all), seeds=p.all_seeds,
+                     decoded=torch.cat(dec_all) if dec_all else None)

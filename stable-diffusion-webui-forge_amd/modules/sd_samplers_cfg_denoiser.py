@@ -1,0 +1,63 @@
+"""`CFGDenoiser` -- mirror of modules/sd_samplers_cfg_denoiser.py:33-228 (forward(x, sigma, uncond, cond, cond_scale,
+s_min_uncond, image_cond)).  Per step: interrupt check, prompt-schedule reconstruction, NGMS / skip-early-cond rules,
+`sampling_function`, last-latent bookkeeping.  inpaint masks (:178-181,204-213) are rejected (img2img is a "next" row)."""
+import torch
+
+from . import prompt_parser, sd_samplers_common, shared
+from ..backend.sampling.sampling_function import sampling_function
+
+
+class CFGDenoiserParams:
+    def __init__(self, x, image_cond, sigma, sampling_step, total_sampling_steps, text_cond, text_uncond, denoiser=None):
+        self.x, self.image_cond, self.sigma = x, image_cond, sigma
+        self.sampling_step, self.total_sampling_steps = sampling_step, total_sampling_steps
+        self.text_cond, self.text_uncond, self.denoiser = text_cond, text_uncond, denoiser
+
+
+class CFGDenoiser:
+    def __init__(self, sampler):
+        self.model_wrap = None
+        self.mask = None
+        self.nmask = None
+        self.init_latent = None
+        self.steps = None
+        self.total_steps = None
+        self.step = 0
+        self.image_cfg_scale = None
+        self.padded_cond_uncond = False
+        self.padded_cond_uncond_v0 = False
+        self.sampler = sampler
+        self.p = None
+        self.need_last_noise_uncond = False
+        self.last_noise_uncond = None
+
+    @property
+    def inner_model(self):
+        raise NotImplementedError()
+
+    def forward(self, x, sigma, uncond, cond, cond_scale, s_min_uncond, image_cond):
+        state, opts = shared.state, shared.opts
+        if state.interrupted or state.skipped:
+            raise sd_samplers_common.InterruptedException
+        if self.mask is not None:
+            raise NotImplementedError("inpaint mask blending is outside the txt2img hot path")
+        cond_composition, cond = prompt_parser.reconstruct_multicond_batch(cond, self.step)
+        uncond = prompt_parser.reconstruct_cond_batch(uncond, self.step) if uncond is not None else None
+        denoiser_params = CFGDenoiserParams(x, image_cond, sigma, state.sampling_step, state.sampling_steps, cond, uncond, self)
+        if getattr(self.p, "is_hr_pass", False):
+            cond_scale = self.p.hr_cfg
+        sig0 = sigma.fmx_sigma.host[0] if hasattr(sigma, "fmx_sigma") else float(sigma[0])
+        if opts.skip_early_cond > 0 and self.step / self.total_steps <= opts.skip_early_cond:
+            cond_scale = 1.0
+        elif (self.step % 2 or opts.s_min_uncond_all) and s_min_uncond > 0 and sig0 < s_min_uncond:
+            cond_scale = 1.0
+        denoised, cond_pred, uncond_pred = sampling_function(self, denoiser_params=denoiser_params, cond_scale=cond_scale,
+                                                             cond_composition=cond_composition)
+        if self.need_last_noise_uncond:
+            self.last_noise_uncond = (x - uncond_pred) / sigma[:, None, None, None]
+        self.sampler.last_latent = denoised
+        state.current_latent = denoised
+        self.step += 1
+        return denoised
+
+    __call__ = forward

@@ -1,0 +1,94 @@
+"""Mirror of modules/sd_samplers_common.py for the path: `SamplerData` (:13-31), `InterruptedException` (:186),
+`TorchHijack` (:214-235), `Sampler` base (:238-364: callback_state, launch_sampling, initialize)."""
+import inspect
+from collections import namedtuple
+
+import torch
+
+from . import shared
+from .. import k_diffusion  # noqa: F401
+from ..k_diffusion import sampling as kd_sampling
+
+
+class SamplerData(namedtuple("SamplerData", ["name", "constructor", "aliases", "options"])):
+    def total_steps(self, steps):
+        if self.options.get("second_order", False):
+            steps = steps * 2
+        return steps
+
+
+class InterruptedException(BaseException):
+    pass
+
+
+class TorchHijack:
+    """Replaces `torch` inside k_diffusion.sampling so that randn_like draws from the per-image generators (p.rng):
+    images generated in a batch equal images generated individually (and independent of multi-GPU sharding)."""
+
+    def __init__(self, p):
+        self.rng = p.rng
+
+    def __getattr__(self, item):
+        if item == "randn_like":
+            return self.randn_like
+        if hasattr(torch, item):
+            return getattr(torch, item)
+        raise AttributeError(f"'{type(self).__name__}' object has no attribute '{item}'")
+
+    def randn_like(self, x):
+        return self.rng.next()
+
+
+class Sampler:
+    def __init__(self, funcname):
+        self.funcname = funcname
+        self.func = funcname
+        self.extra_params = []
+        self.stop_at = None
+        self.eta = None
+        self.config = None
+        self.last_latent = None
+        self.s_min_uncond = None
+        self.s_churn, self.s_tmin, self.s_tmax, self.s_noise = 0.0, 0.0, float("inf"), 1.0
+        self.eta_option_field = "eta_ancestral"
+        self.eta_default = 1.0
+        self.p = None
+        self.model_wrap_cfg = None
+        self.sampler_extra_args = None
+        self.options = {}
+
+    def callback_state(self, d):
+        step = d["i"]
+        if self.stop_at is not None and step > self.stop_at:
+            raise InterruptedException
+        shared.state.sampling_step = step
+
+    def launch_sampling(self, steps, func):
+        self.model_wrap_cfg.steps = steps
+        self.model_wrap_cfg.total_steps = self.config.total_steps(steps)
+        shared.state.sampling_steps = steps
+        shared.state.sampling_step = 0
+        try:
+            return func()
+        except RecursionError:
+            return self.last_latent
+        except InterruptedException:
+            return self.last_latent
+
+    def initialize(self, p):
+        self.p = p
+        self.model_wrap_cfg.p = p
+        self.model_wrap_cfg.mask = getattr(p, "mask", None)
+        self.model_wrap_cfg.nmask = getattr(p, "nmask", None)
+        self.model_wrap_cfg.step = 0
+        self.eta = p.eta if getattr(p, "eta", None) is not None else getattr(shared.opts, self.eta_option_field, 0.0)
+        self.s_min_uncond = getattr(p, "s_min_uncond", 0.0)
+        kd_sampling.torch = TorchHijack(p)
+        extra = {}
+        params = inspect.signature(self.func).parameters
+        for name in self.extra_params:
+            if hasattr(p, name) and name in params:
+                extra[name] = getattr(p, name)
+        if "eta" in params:
+            extra["eta"] = self.eta
+        return extra

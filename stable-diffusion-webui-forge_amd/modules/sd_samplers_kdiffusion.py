@@ -1,0 +1,102 @@
+"""`KDiffusionSampler` -- mirror of modules/sd_samplers_kdiffusion.py (sampler table :14-34, `get_sigmas` :81-134,
+`sample` :196-244) over the native denoiser.  Samplers that need torchsde / second-order model calls are listed in the
+reference's table but not built here (same denoiser underneath, elementwise-only differences)."""
+import inspect
+
+import torch
+
+from . import sd_samplers_common, shared
+from .sd_samplers_cfg_denoiser import CFGDenoiser
+from ..backend.sampling.sampling_function import sampling_cleanup, sampling_prepare
+from ..k_diffusion import external as kd_external
+from ..k_diffusion import sampling as kd_sampling
+
+samplers_k_diffusion = [
+    ("DPM++ 2M", "sample_dpmpp_2m", ["k_dpmpp_2m"], {"scheduler": "karras"}),
+    ("Euler a", "sample_euler_ancestral", ["k_euler_a", "k_euler_ancestral"], {"uses_ensd": True}),
+    ("Euler", "sample_euler", ["k_euler"], {}),
+]
+
+sampler_extra_params = {"sample_euler": ["s_churn", "s_tmin", "s_tmax", "s_noise"]}
+
+# modules/sd_schedulers.py:211-228 (the two schedules the table above uses; "Automatic" -> sampler default)
+k_diffusion_scheduler = {"karras": kd_sampling.get_sigmas_karras, "exponential": kd_sampling.get_sigmas_exponential}
+
+samplers_data_k_diffusion = [
+    sd_samplers_common.SamplerData(label, lambda model, funcname=funcname: KDiffusionSampler(funcname, model), aliases, options)
+    for label, funcname, aliases, options in samplers_k_diffusion
+]
+k_diffusion_samplers_map = {x.name: x for x in samplers_data_k_diffusion}
+
+
+class CFGDenoiserKDiffusion(CFGDenoiser):
+    def __init__(self, sampler, sd_model):
+        super().__init__(sampler)
+        self._sd_model = sd_model
+
+    @property
+    def inner_model(self):
+        if self.model_wrap is None:
+            self.model_wrap = kd_external.ForgeScheduleLinker(self._sd_model.forge_objects.unet.model.predictor)
+            self.model_wrap.inner_model = self._sd_model
+        return self.model_wrap
+
+
+class KDiffusionSampler(sd_samplers_common.Sampler):
+    def __init__(self, funcname, sd_model, options=None):
+        super().__init__(funcname)
+        self.extra_params = sampler_extra_params.get(funcname, [])
+        self.options = options or {}
+        self.func = funcname if callable(funcname) else getattr(kd_sampling, self.funcname)
+        self.model_wrap_cfg = CFGDenoiserKDiffusion(self, sd_model)
+        self.model_wrap = self.model_wrap_cfg.inner_model
+
+    def get_sigmas(self, p, steps):
+        opts = shared.opts
+        discard = self.config is not None and self.config.options.get("discard_next_to_last_sigma", False)
+        if opts.always_discard_next_to_last_sigma and not discard:
+            discard = True
+        steps += 1 if discard else 0
+        scheduler_name = (getattr(p, "scheduler", None)) or "Automatic"
+        if scheduler_name == "Automatic":
+            scheduler_name = self.config.options.get("scheduler", None)
+        fn = k_diffusion_scheduler.get((scheduler_name or "").lower()) if scheduler_name else None
+        m_min, m_max = self.model_wrap.sigmas[0].item(), self.model_wrap.sigmas[-1].item()
+        sigma_min, sigma_max = (0.1, 10) if opts.use_old_karras_scheduler_sigmas else (m_min, m_max)
+        if getattr(p, "sampler_noise_scheduler_override", None):
+            sigmas = p.sampler_noise_scheduler_override(steps)
+        elif fn is None:
+            sigmas = self.model_wrap.get_sigmas(steps)
+        else:
+            kw = {"sigma_min": sigma_min, "sigma_max": sigma_max}
+            if opts.sigma_min != 0 and opts.sigma_min != m_min:
+                kw["sigma_min"] = opts.sigma_min
+            if opts.sigma_max != 0 and opts.sigma_max != m_max:
+                kw["sigma_max"] = opts.sigma_max
+            if fn is kd_sampling.get_sigmas_karras and opts.rho != 0 and opts.rho != 7.0:
+                kw["rho"] = opts.rho
+            sigmas = fn(n=steps, **kw, device="cpu")
+        if discard:
+            sigmas = torch.cat([sigmas[:-2], sigmas[-1:]])
+        return sigmas.cpu()
+
+    def sample(self, p, x, conditioning, unconditional_conditioning, steps=None, image_conditioning=None):
+        unet_patcher = self.model_wrap.inner_model.forge_objects.unet
+        sampling_prepare(unet_patcher, x=x)
+        steps = steps or p.steps
+        sigmas = self.get_sigmas(p, steps)  # stays on the host: the native loops read it as python floats
+        x = self.model_wrap.predictor.noise_scaling(sigmas[0], x, None, max_denoise=shared.opts.sgm_noise_multiplier)
+        extra_params_kwargs = self.initialize(p)
+        parameters = inspect.signature(self.func).parameters
+        if "n" in parameters:
+            extra_params_kwargs["n"] = steps
+        if "sigmas" in parameters:
+            extra_params_kwargs["sigmas"] = sigmas
+        self.last_latent = x
+        self.sampler_extra_args = {"cond": conditioning, "image_cond": image_conditioning, "uncond": unconditional_conditioning,
+                                   "cond_scale": p.cfg_scale, "s_min_uncond": self.s_min_uncond}
+        samples = self.launch_sampling(steps, lambda: self.func(self.model_wrap_cfg, x, extra_args=self.sampler_extra_args,
+                                                                disable=getattr(p, "disable_progress", True),
+                                                                callback=self.callback_state, **extra_params_kwargs))
+        sampling_cleanup(unet_patcher)
+        return samples
