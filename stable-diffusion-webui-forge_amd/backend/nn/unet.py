@@ -132,6 +132,8 @@ class IntegratedUNet2DConditionModel:
                 H, d = L.heads, L.dim_head
                 dp = _dpad(d)
                 inner = H * d
+                if (H * dp) % 64 != 0:
+                    raise NotImplementedError(f"heads*padded_dim = {H}*{dp} must be a multiple of 64 (GEMM K tile)")
                 w[k + ".norm"] = (T(k + ".norm.weight"), T(k + ".norm.bias"))
                 pin_w = sd[k + ".proj_in.weight"].to(dev, torch.float16).reshape(inner, L.ch).contiguous()
                 pout_w = sd[k + ".proj_out.weight"].to(dev, torch.float16).reshape(L.ch, inner).contiguous()

@@ -37,7 +37,7 @@ SDXL_UNET_CONFIG = dict(
 # Small configs with the same block grammar (used by the parity tests; finish in seconds on CPU).
 TINY_SD15_UNET_CONFIG = dict(
     in_channels=4, model_channels=64, out_channels=4, num_res_blocks=[1, 1, 1], channel_mult=(1, 2, 2),
-    num_heads=2, use_spatial_transformer=True, transformer_depth=[1, 1, 0],
+    num_heads=4, use_spatial_transformer=True, transformer_depth=[1, 1, 0],
     transformer_depth_middle=1, transformer_depth_output=[1, 1, 1, 1, 0, 0],
     context_dim=128, use_linear_in_transformer=False)
 # transformer_depth_output is consumed with pop() from the END (unet.py:649): listed low-res-last.
