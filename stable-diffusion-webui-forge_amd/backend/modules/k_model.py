@@ -20,6 +20,15 @@ class SigmaInfo:
         self.host = host  # list[float], one per sample
 
 
+def tensor_version(t):
+    """`_version` is unavailable on inference-mode tensors (processing runs under torch.inference_mode, as the reference
+    does, processing.py:911); identity (data_ptr, shape) is then the cache key."""
+    try:
+        return t._version
+    except RuntimeError:
+        return -1
+
+
 def host_sigmas(sigma):
     info = getattr(sigma, "fmx_sigma", None)
     if info is not None:
@@ -118,7 +127,7 @@ class KModel:
 
     def _stack_ctx(self, uc, c):
         """[uncond ; cond] along batch (sampling_function.py:187-236 order); cached on the identity of the parts."""
-        key = (uc[0].data_ptr(), c[0].data_ptr(), uc[0]._version, c[0]._version, tuple(uc[0].shape), tuple(c[0].shape))
+        key = (uc[0].data_ptr(), c[0].data_ptr(), tensor_version(uc[0]), tensor_version(c[0]), tuple(uc[0].shape), tuple(c[0].shape))
         cached = getattr(self, "_stacked", None)
         if cached is not None and cached[0] == key:
             return cached[1]

@@ -171,8 +171,13 @@ class IntegratedUNet2DConditionModel:
     # ------------------------------------------------------------------------------------------------------------
     def prepare_context(self, context, y=None):
         """context [Bu, T, Dc] (any float dtype, device), y [Bu, adm] or None.  Cached on tensor identity+version."""
-        key = (context.data_ptr(), tuple(context.shape), context._version,
-               None if y is None else (y.data_ptr(), tuple(y.shape), y._version))
+        def ver(t):
+            try:
+                return t._version
+            except RuntimeError:  # inference-mode tensors carry no version counter
+                return -1
+        key = (context.data_ptr(), tuple(context.shape), ver(context),
+               None if y is None else (y.data_ptr(), tuple(y.shape), ver(y)))
         c = self._ctx
         if c.key == key:
             return c
@@ -233,13 +238,26 @@ class IntegratedUNet2DConditionModel:
         mk = arena.mark()
         # self attention
         n1 = ops.layernorm(h, *self.w[b + ".norm1"])
-        qk = ops.linear(n1, self.w[b + ".attn1.qk"])                       # [M, 2*H*dp]
-        vt = ops.conv_gemm(self.w[b + ".attn1.v"], n1, m_tok)              # [H*dp, M] = V^T
-        npad = -(-n // 64) * 64
-        if npad != n:
-            raise NotImplementedError("token count per image must be a multiple of 64 (latent H*W)")
-        o = ops.attention(qk, qk[:, hd:], vt, batch=bu, heads=H, nq=n, nk=n, nk_pad=n, dpad=dp, scale=d ** -0.5,
-                          q_bs=n * 2 * hd, q_rs=2 * hd, k_bs=n * 2 * hd, k_rs=2 * hd, vt_bs=n, vt_hs=dp * m_tok, vt_ds=m_tok)
+        if n % 64 == 0:
+            qk = ops.linear(n1, self.w[b + ".attn1.qk"])                   # [M, 2*H*dp] = [Q | K]
+            vt = ops.conv_gemm(self.w[b + ".attn1.v"], n1, m_tok)          # [H*dp, M] = V^T (operand swap)
+            o = ops.attention(qk, qk[:, hd:], vt, batch=bu, heads=H, nq=n, nk=n, nk_pad=n, dpad=dp, scale=d ** -0.5,
+                              q_bs=n * 2 * hd, q_rs=2 * hd, k_bs=n * 2 * hd, k_rs=2 * hd, vt_bs=n, vt_hs=dp * m_tok, vt_ds=m_tok)
+        else:
+            # ragged token count (latent H*W not a multiple of the 64-key tile): per-image projections into zero-padded
+            # K / V^T buffers so that every key tile the kernel touches is real, finite memory
+            npad = -(-n // 64) * 64
+            qk = ops.empty((bu, npad, 2 * hd))
+            vt = ops.empty((hd, bu * npad))
+            qk.zero_()
+            vt.zero_()
+            n1v = n1.view(bu, n, -1)
+            for bi in range(bu):
+                ops.linear(n1v[bi], self.w[b + ".attn1.qk"], out=qk[bi, :n], ld_out=2 * hd)
+                ops.conv_gemm(self.w[b + ".attn1.v"], n1v[bi], n, out=vt[:, bi * npad:bi * npad + n], ld_out=bu * npad)
+            o = ops.attention(qk, qk[:, :, hd:], vt, batch=bu, heads=H, nq=n, nk=n, nk_pad=npad, dpad=dp, scale=d ** -0.5,
+                              q_bs=npad * 2 * hd, q_rs=2 * hd, k_bs=npad * 2 * hd, k_rs=2 * hd, vt_bs=npad,
+                              vt_hs=dp * bu * npad, vt_ds=bu * npad)
         ops.linear(o, *self.w[b + ".attn1.out"], residual=h, out=h, ld_out=h.shape[1])
         arena.release(mk)
         # cross attention against the cached text K / V^T

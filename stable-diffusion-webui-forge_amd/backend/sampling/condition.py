@@ -67,8 +67,15 @@ def compile_weighted_conditions(cond, weights):
         for i, w in cond_pre:
             idx.append(i)
             weight = w
-        feed = cond.advanced_indexing(idx) if hasattr(cond, "advanced_indexing") else (
-            {k: v[idx] for k, v in cond.items()} if isinstance(cond, dict) else cond[idx])
+        nb = (cond["crossattn"] if isinstance(cond, dict) else cond).shape[0]
+        if idx == list(range(nb)):
+            # plain prompts: the composition selects every image once, in order.  The reference still gathers
+            # (`cond[current_indices]`, condition.py:133-136), which only copies; keeping the tensor itself keeps its
+            # identity stable across steps, which is what the per-conditioning K/V cache and the HIP graph key on.
+            feed = cond
+        else:
+            feed = cond.advanced_indexing(idx) if hasattr(cond, "advanced_indexing") else (
+                {k: v[idx] for k, v in cond.items()} if isinstance(cond, dict) else cond[idx])
         h = compile_conditions(feed)
         h[0]["strength"] = weight
         results += h

@@ -1,0 +1,80 @@
+"""Multi-GPU batch sharding for the sampling path: one process per GPU, `torch.distributed` (backend "nccl" == RCCL over
+xGMI on ROCm; "gloo" in the CPU tests).  The reference is single-process single-GPU; images in a batch
+are independent (no cross-sample op anywhere on the path), so the only communication per JOB is
+  1. broadcast of the conditioning from rank 0 (text-cond [B,77,Dc] (+ pooled vector) for cond and uncond), and
+  2. gather of the final latents (or decoded images) on rank 0;
+nothing is exchanged inside the step loop.  Seeds are seed + global image index, so results do not depend on the sharding.
+"""
+import torch
+import torch.distributed as dist
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_range(total, rank, world_size):
+    """Contiguous shard [lo, hi) of `total` images for `rank`; earlier ranks take the remainder."""
+    base, rem = divmod(total, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def _flatten(cond):
+    if isinstance(cond, dict):
+        keys = sorted(cond.keys())
+        return keys, [cond[k] for k in keys]
+    return None, [cond]
+
+
+def broadcast_conditioning(cond, uncond, device, src=0, spec=None):
+    """Rank `src` holds (cond, uncond) for the GLOBAL batch; every rank returns them (same structure).  `spec` (needed on
+    non-src ranks) = {"keys": [...] or None, "shapes": [[...], ...], "dtype": torch.dtype} for cond; uncond mirrors it."""
+    rank, ws = world()
+    if ws == 1:
+        return cond, uncond
+    meta = [None]
+    if rank == src:
+        keys, tensors = _flatten(cond)
+        meta = [{"keys": keys, "shapes": [list(t.shape) for t in tensors], "dtype": tensors[0].dtype}]
+    dist.broadcast_object_list(meta, src=src)
+    m = meta[0]
+    out = []
+    for which in (cond, uncond):
+        if rank == src:
+            _, tensors = _flatten(which)
+            tensors = [t.to(device).contiguous() for t in tensors]
+        else:
+            tensors = [torch.empty(s, dtype=m["dtype"], device=device) for s in m["shapes"]]
+        for t in tensors:
+            dist.broadcast(t, src=src)
+        out.append(dict(zip(m["keys"], tensors)) if m["keys"] is not None else tensors[0])
+    return out[0], out[1]
+
+
+def slice_conditioning(cond, lo, hi):
+    if isinstance(cond, dict):
+        return type(cond)({k: v[lo:hi].contiguous() for k, v in cond.items()})
+    return cond[lo:hi].contiguous()
+
+
+def gather_latents(local, total, dst=0):
+    """All ranks pass their [b_local, ...] tensor; rank `dst` gets the [total, ...] batch in global order (others None).
+    Uses all_gather on equal-size padded shards (RCCL has no native gatherv)."""
+    rank, ws = world()
+    if ws == 1:
+        return local
+    per = -(-total // ws)
+    pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    bufs = [torch.empty_like(pad) for _ in range(ws)]
+    dist.all_gather(bufs, pad)
+    if rank != dst:
+        return None
+    parts = []
+    for r in range(ws):
+        lo, hi = shard_range(total, r, ws)
+        parts.append(bufs[r][:hi - lo])
+    return torch.cat(parts)

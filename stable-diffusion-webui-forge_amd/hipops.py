@@ -18,6 +18,55 @@ ACT_NONE, ACT_GEGLU = 0, 1
 
 _zero_pages = {}
 _alloc = None  # callable(shape, dtype) -> tensor ; set by runtime.Arena
+_profiler = None  # KernelProfiler while bench.py measures per-launch kernel time
+
+
+class KernelProfiler:
+    """Brackets every launch of the two MFMA kernels with HIP events recorded on the launch stream (fmx_event_*), so
+    bench.py can report algorithmic FLOP / measured kernel time per kernel family (roofline.achieved)."""
+
+    def __init__(self):
+        self.records = []  # (kind, flops, ev_start, ev_stop)
+
+    def __enter__(self):
+        global _profiler
+        self._prev, _profiler = _profiler, self
+        return self
+
+    def __exit__(self, *exc):
+        global _profiler
+        _profiler = self._prev
+        return False
+
+    def _event(self):
+        ev = C.c_void_p()
+        _lib.check(_lib.lib().fmx_event_create(C.byref(ev)), "fmx_event_create")
+        return ev
+
+    def launch(self, kind, flops, fn):
+        L = _lib.lib()
+        a, b = self._event(), self._event()
+        sp = stream_ptr()
+        _lib.check(L.fmx_event_record(a, sp), "fmx_event_record")
+        fn()
+        _lib.check(L.fmx_event_record(b, sp), "fmx_event_record")
+        self.records.append((kind, flops, a, b))
+
+    def summary(self):
+        """-> {kind: {"launches", "flops", "seconds"}} ; synchronises."""
+        L = _lib.lib()
+        out = {}
+        for kind, flops, a, b in self.records:
+            ms = C.c_float()
+            _lib.check(L.fmx_event_elapsed_ms(a, b, C.byref(ms)), "fmx_event_elapsed_ms")
+            d = out.setdefault(kind, {"launches": 0, "flops": 0.0, "seconds": 0.0})
+            d["launches"] += 1
+            d["flops"] += flops
+            d["seconds"] += ms.value * 1e-3
+            L.fmx_event_destroy(a)
+            L.fmx_event_destroy(b)
+        self.records = []
+        return out
 
 
 def set_allocator(fn):
@@ -95,6 +144,10 @@ def conv_gemm(x, wgt, nout, *, x1=None, n=None, h=None, w=None, kh=1, stride=1, 
     a.out, a.ld_out = _p(out), ld_out
     a.out_f32 = -force_tile if force_tile else (1 if out.dtype == torch.float32 else 0)
     a.zero_page = _p(zero_page(x.device))
+    if _profiler is not None:
+        flops = 2.0 * m * nout * kh * kh * (c0 + c1)
+        _profiler.launch("gemm_conv", flops, lambda: _lib.check(_lib.lib().fmx_gemm_conv_f16(C.byref(a), stream_ptr()), "fmx_gemm_conv_f16"))
+        return out
     _lib.check(_lib.lib().fmx_gemm_conv_f16(C.byref(a), stream_ptr()), "fmx_gemm_conv_f16")
     return out
 
@@ -126,6 +179,11 @@ def attention(q, k, vt, *, batch, heads, nq, nk, nk_pad, dpad, scale, q_bs, q_rs
     a.batch, a.heads, a.nq, a.nk, a.nk_pad, a.dpad = batch, heads, nq, nk, nk_pad, dpad
     a.scale = float(scale)
     a.zero_page = _p(zero_page(q.device))
+    if _profiler is not None:
+        d_true = int(round(float(scale) ** -2))
+        flops = 4.0 * batch * heads * nq * nk * d_true
+        _profiler.launch("attention", flops, lambda: _lib.check(_lib.lib().fmx_attention_f16(C.byref(a), stream_ptr()), "fmx_attention_f16"))
+        return out
     _lib.check(_lib.lib().fmx_attention_f16(C.byref(a), stream_ptr()), "fmx_attention_f16")
     return out
 

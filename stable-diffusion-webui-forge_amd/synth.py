@@ -128,3 +128,19 @@ def synth_conditioning(batch, context_dim, adm_in_channels=None, tokens=77, seed
     y = torch.from_numpy(rng.standard_normal((batch, adm_in_channels), dtype=np.float32))
     uy = torch.from_numpy(rng.standard_normal((batch, adm_in_channels), dtype=np.float32))
     return {"crossattn": c, "vector": y}, {"crossattn": uc, "vector": uy}
+
+
+def synth_state_dict_device(shapes, seed, device, dtype=torch.float16, gain=DEFAULT_GAIN):
+    """Same init law as `synth_state_dict`, drawn directly on the device (bench.py: 2.6 G parameters in seconds).
+    Values differ from the numpy stream, so this is for throughput runs, not for parity fixtures."""
+    g = torch.Generator(device=device).manual_seed(int(seed))
+    sd = OrderedDict()
+    for name, shape in shapes.items():
+        z = torch.randn(shape, generator=g, device=device, dtype=torch.float32)
+        if _is_norm(name, shape):
+            z = 1.0 + 0.1 * z if name.endswith(".weight") else 0.1 * z
+        else:
+            wshape = shapes[name[:-5] + ".weight"] if name.endswith(".bias") else shape
+            z = z * (gain / float(np.sqrt(int(np.prod(wshape[1:])))))
+        sd[name] = z.to(dtype)
+    return sd
