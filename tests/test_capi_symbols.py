@@ -1,0 +1,76 @@
+"""CPU: the C-ABI shared library loads without a GPU and exports exactly the symbols include/fmx.h declares; the ctypes
+binding (forge_amd/_lib.py) lists the same set.  No compute call is made here."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+import forge_amd  # noqa: F401
+from forge_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "fmx.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fmx_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    return _lib.build()
+
+
+def test_header_declares_something():
+    syms = declared_symbols()
+    assert "fmx_gemm_conv_f16" in syms and "fmx_attention_f16" in syms and len(syms) >= 25
+
+
+def test_library_exports_every_declared_symbol(built):
+    handle = ctypes.CDLL(built)
+    for s in declared_symbols():
+        assert hasattr(handle, s), f"{s} declared in include/fmx.h but not exported by {built}"
+
+
+def test_no_undeclared_fmx_exports(built):
+    out = subprocess.run(["nm", "-D", "--defined-only", built], capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if re.search(r" T fmx_", ln)})
+    declared = set(declared_symbols())
+    extra = [s for s in exported if s not in declared and s != "fmx_set_error"]
+    assert not extra, f"exported but not declared in include/fmx.h: {extra}"
+
+
+def test_ctypes_binding_matches_header(built):
+    declared = set(declared_symbols())
+    bound = set(_lib.SIGNATURES) | {"fmx_last_error"}
+    assert declared == bound, (sorted(declared - bound), sorted(bound - declared))
+    L = _lib.lib()
+    assert L.fmx_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    """field order / count of the two argument structs (a mismatch would silently corrupt every launch)"""
+    src = open(HEADER).read()
+    for cname, cls in (("fmx_gemm_args", _lib.GemmArgs), ("fmx_attn_args", _lib.AttnArgs)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), src, flags=re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            first, *rest = decl.split(",")
+            names.append(re.findall(r"(\w+)$", first.strip())[0])
+            names += [r.strip().lstrip("*") for r in rest]
+        assert names == [f[0] for f in cls._fields_], cname
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.FmxError):
+        _lib.lib()

@@ -1,0 +1,20 @@
+#!/bin/bash
+# One GPU-box visit: parity tests, headline bench, rocprofv3 kernel-trace stats of the same bench command.
+# usage (from repo root, through gpurun): bash tools/gpu_round.sh <tag> [tests|bench|prof ...]
+TAG=${1:-r1}; shift
+WHAT=${@:-tests bench prof}
+R=${GRAFT_REPO_ROOT:-$PWD}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd $R
+for w in $WHAT; do
+  case $w in
+    tests) timeout 1500 python -m pytest tests -m gpu -x -q -s 2>&1 | tail -150 > $O/pytest_gpu.log; tail -5 $O/pytest_gpu.log;;
+    smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -3 $O/smoke.log;;
+    bench) timeout 1200 python bench.py > $O/bench.json 2> $O/bench.err; cat $O/bench.json; tail -3 $O/bench.err;;
+    prof) (cd /tmp && export TMPDIR=/tmp && timeout 1200 rocprofv3 --kernel-trace --stats -f csv -d $O/prof -o kt -- \
+            python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/prof_bench.log 2>&1); tail -2 $O/prof_bench.log;
+          find $O/prof -name '*kernel_trace.csv' -size +20M -delete; ls -la $O/prof/* | head;;
+    kbench) timeout 900 python tools/bench_kernels.py > $O/kbench.log 2>&1; tail -60 $O/kbench.log;;
+  esac
+done
