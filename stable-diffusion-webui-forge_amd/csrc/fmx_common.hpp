@@ -48,7 +48,20 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// exact-erf GELU (backend/nn/unet.py:111 F.gelu default).  erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far
+// below the fp16 rounding of the result): branch-free, one rcp + one exp -- libm's erff is ~60 instructions with
+// divergent branches, which made the GEGLU epilogue a measurable fraction of the ff1 GEMM.
+__device__ __forceinline__ float erf_as(float x) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  float pl = fmaf(1.061405429f, t, -1.453152027f);
+  pl = fmaf(pl, t, 1.421413741f);
+  pl = fmaf(pl, t, -0.284496736f);
+  pl = fmaf(pl, t, 0.254829592f);
+  const float y = 1.0f - pl * t * __expf(-ax * ax);
+  return copysignf(y, x);
+}
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -16,38 +16,12 @@
 //    side and on the ds_read_b128 side (same involution), which makes the fragment reads conflict-free.
 //  * double-buffered K loop (BK = 64): issue tile t+1, compute tile t, one vmcnt(0)+barrier per tile.
 //  * 1-D grid remapped so that consecutive tiles (same A rows, neighbouring W rows) share an XCD's L2.
-#include "fmx_common.hpp"
+#include "fmx_gemm_common.hpp"
 
 namespace {
 
-struct GemmParams {
-  const f16* a0;
-  const f16* a1;
-  int c0, c1, s0, s1;  // channels and pixel strides (elements) of the two sources
-  int n, h, w, oh, ow;
-  int kh, stride, pad;
-  int up_h, up_w;
-  const f16* wgt;
-  int ldw;
-  int nout;
-  const f16* bias;
-  const f16* rowvec;
-  int ld_rowvec;
-  const f16* residual;
-  int ld_res;
-  float alpha;
-  int act;
-  void* out;
-  int ld_out;
-  int out_f32;
-  const f16* zp;
-  int M;            // n*oh*ow
-  int kt;           // number of 64-wide K tiles = kh*kh*(c0+c1)/64
-  int cpt;          // K tiles per tap = (c0+c1)/64
-  int tiles_m, tiles_n;
-};
 
-constexpr int BK = 64;
+constexpr int BK = FMX_BK;
 
 // byte offset of (row, logical 16B chunk) inside a [rows][64] fp16 LDS tile
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -191,97 +165,87 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   }
 
   // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + (lane>>4)*4 + r], r = 0..3 ---------------------
-  const int per_img = p.oh * p.ow;
-  const bool geglu = p.act == FMX_ACT_GEGLU;
-  const int ncols = geglu ? (p.nout >> 1) : p.nout;
-  const bool vec_ok = ((p.ld_out & 3) == 0) && ((p.ld_res & 3) == 0) && ((p.ld_rowvec & 3) == 0);
-
-  // acc*alpha + bias[nb..nb+3] + rowvec[nb..nb+3]  (8-byte loads when the 4 columns are in range)
-  auto biased = [&](const f32x4& a, int nb, const f16* rv, float (&v)[4]) {
+  if (FastEpilogue::eligible(p)) {  // uniform; straight-line loads (see FastEpilogue)
+    const FastEpilogue fe(p);
+    const bool gg = p.act == FMX_ACT_GEGLU;
+    int nbs[NI];
+    bool nok[NI];
+    f16x4 bb[NI];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = a[r] * p.alpha;
-    if (nb + 3 < p.nout && vec_ok) {
-      if (p.bias) {
-        const f16x4 b = *reinterpret_cast<const f16x4*>(p.bias + nb);
+    for (int j = 0; j < NI; ++j) {
+      const int nb = n0 + wn * (BN / 2) + j * 16 + fk * 4;
+      nok[j] = nb < fe.nout;
+      nbs[j] = nok[j] ? nb : 0;
+      bb[j] = fe.bias4(nbs[j]);
+    }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += (float)b[r];
-      }
-      if (rv) {
-        const f16x4 b = *reinterpret_cast<const f16x4*>(rv + nb);
+    for (int i = 0; i < MI; ++i) {
+      const int m = m0 + wm * (BM / 2) + i * 16 + frow;
+      const bool mok = m < p.M;
+      const int mc = mok ? m : p.M - 1;
+      const int img = mc / fe.per_img;
+      if (!gg) {
+        f16x4 rv[NI], rs[NI];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += (float)b[r];
-      }
-    } else {
+        for (int j = 0; j < NI; ++j) {
+          rv[j] = fe.rv4(img, nbs[j]);
+          rs[j] = fe.res4(mc, nbs[j]);
+        }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (nb + r < p.nout) {
-          if (p.bias) v[r] += (float)p.bias[nb + r];
-          if (rv) v[r] += (float)rv[nb + r];
+        for (int j = 0; j < NI; ++j) {
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * fe.alpha + (float)bb[j][r] + (float)rv[j][r] + (float)rs[j][r];
+          if (mok && nok[j]) fe.store4(m, nbs[j], v);
+        }
+      } else {
+        // fragments come in [value | gate] pairs along j: odd j holds the gate of fragment j-1
+#pragma unroll
+        for (int j = 1; j < NI; j += 2) {
+          const int col = ((n0 + wn * (BN / 2)) >> 1) + (j >> 1) * 16 + fk * 4;
+          const int colc = nok[j] ? col : 0;
+          const f16x4 rvv = fe.rv4(img, nbs[j - 1]), rvg = fe.rv4(img, nbs[j]), rs = fe.res4(mc, colc);
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float val = acc[i][j - 1][r] * fe.alpha + (float)bb[j - 1][r] + (float)rvv[r];
+            const float gate = acc[i][j][r] * fe.alpha + (float)bb[j][r] + (float)rvg[r];
+            v[r] = val * gelu_erf_f(gate) + (float)rs[r];
+          }
+          if (mok && nok[j]) fe.store4(m, col, v);
         }
       }
     }
-  };
-
+    return;
+  }
+  const GemmEpilogue ep(p);
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const int m = m0 + wm * (BM / 2) + i * 16 + frow;
     if (m >= p.M) continue;
-    const f16* rv = p.rowvec ? p.rowvec + (long)(m / per_img) * p.ld_rowvec : nullptr;
+    const f16* rv = ep.rowvec_of(m);
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       const int nb = n0 + wn * (BN / 2) + j * 16 + fk * 4;  // first of this lane's 4 weight rows
       float v[4];
       int col;
-      if (geglu) {
+      if (ep.geglu) {
         // fragments come in [value | gate] pairs along j: odd j holds the gate of fragment j-1
         if ((j & 1) == 0) continue;
         float g[4];
-        biased(acc[i][j], nb, rv, g);
-        biased(acc[i][j - 1], nb - 16, rv, v);
+        const float ag[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        const float av[4] = {acc[i][j - 1][0], acc[i][j - 1][1], acc[i][j - 1][2], acc[i][j - 1][3]};
+        ep.biased(ag, nb, rv, g);
+        ep.biased(av, nb - 16, rv, v);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_f(g[r]);
         col = ((n0 + wn * (BN / 2)) >> 1) + (j >> 1) * 16 + fk * 4;
       } else {
-        biased(acc[i][j], nb, rv, v);
+        const float av[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        ep.biased(av, nb, rv, v);
         col = nb;
       }
-      if (col >= ncols) continue;
-      const long o = (long)m * p.ld_out + col;
-      const bool full = (col + 3 < ncols) && vec_ok;
-      if (p.residual) {
-        const f16* rp = p.residual + (long)m * p.ld_res + col;
-        if (full) {
-          const f16x4 rr = *reinterpret_cast<const f16x4*>(rp);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (col + r < ncols) v[r] += (float)rp[r];
-        }
-      }
-      if (p.out_f32) {
-        float* op = reinterpret_cast<float*>(p.out) + o;
-        if (full) {
-          *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (col + r < ncols) op[r] = v[r];
-        }
-      } else {
-        f16* op = reinterpret_cast<f16*>(p.out) + o;
-        if (full) {
-          f16x4 hv;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) hv[r] = (f16)v[r];
-          *reinterpret_cast<f16x4*>(op) = hv;
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (col + r < ncols) op[r] = (f16)v[r];
-        }
-      }
+      ep.store(m, col, v);
     }
   }
 }
@@ -356,8 +320,25 @@ extern "C" int fmx_gemm_conv_f16(const fmx_gemm_args* a, void* stream) {
   int sel = 2;
   if (n128 && tiles(128, 128) >= 384) sel = 0;
   else if (tiles(128, 64) >= 384) sel = 1;
-  if (a->out_f32 < 0) sel = (-a->out_f32 - 1) % 3;  // test hook: force a tile shape (out_f32 = -1/-2/-3 -> fp16 out)
+  // 256x256 ping-pong kernel: needs the branch-free epilogue; wins (measured, profiles/r01c_gemm_sweep.jsonl) when its
+  // tiles fill the 256 CUs in whole rounds and K is deep enough to amortise its longer prologue
+  {
+    const long t256 = tiles(256, 256);
+    const long rounds = (t256 + 255) / 256;
+    const double util = (double)p.M * (double)p.nout / ((double)rounds * 256.0 * 65536.0);
+    if (FastEpilogue::eligible(p) && p.nout >= 256 && p.M >= 256 && util >= 0.8 && p.kt >= 8) sel = 3;
+  }
+  // the 256x256 kernel addresses both operands with 32-bit element offsets
+  const double a_span = (double)a->n * a->h * a->w * (double)(p.s0 > p.s1 ? p.s0 : p.s1);
+  const double w_span = (double)p.nout * p.ldw;
+  const bool fits32 = a_span < 4.0e9 && w_span < 4.0e9;
+  if (!fits32 && sel == 3) sel = n128 ? 0 : 1;
+  if (a->out_f32 < 0) sel = (-a->out_f32 - 1) % 4;  // test hook: force a tile shape (out_f32 = -1..-4 -> fp16 out)
   if (a->out_f32 < 0) p.out_f32 = 0;
+  if (sel == 3) {
+    FMX_REQUIRE(FastEpilogue::eligible(p) && fits32, "gemm: 256x256 kernel needs fp16 output, leading dimensions / nout multiples of 4 / 8, operands < 2^32 elements");
+    return fmx_launch_gemm256(p, conv, st);
+  }
   if (conv) {
     if (sel == 0) return launch<128, 128, true>(p, st);
     if (sel == 1) return launch<128, 64, true>(p, st);

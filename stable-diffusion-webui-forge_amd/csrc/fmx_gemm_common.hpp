@@ -1,0 +1,165 @@
+// Shared pieces of the MFMA implicit-GEMM kernels (fmx_gemm.hip: 128x128 / 128x64 / 64x64 tiles, 4 waves;
+// fmx_gemm256.hip: 256x256 tile, 8 waves, ping-pong schedule): launch parameters and the fused epilogue.
+#pragma once
+#include "fmx_common.hpp"
+
+struct GemmParams {
+  const f16* a0;
+  const f16* a1;
+  int c0, c1, s0, s1;  // channels and pixel strides (elements) of the two sources
+  int n, h, w, oh, ow;
+  int kh, stride, pad;
+  int up_h, up_w;
+  const f16* wgt;
+  int ldw;
+  int nout;
+  const f16* bias;
+  const f16* rowvec;
+  int ld_rowvec;
+  const f16* residual;
+  int ld_res;
+  float alpha;
+  int act;
+  void* out;
+  int ld_out;
+  int out_f32;
+  const f16* zp;
+  int M;            // n*oh*ow
+  int kt;           // number of 64-wide K tiles = kh*kh*(c0+c1)/64
+  int cpt;          // K tiles per tap = (c0+c1)/64
+  int tiles_m, tiles_n;
+};
+
+// K-tile depth of every GEMM kernel: 64 halfs = one 128-byte LDS row.
+constexpr int FMX_BK = 64;
+
+// Epilogue for one lane-owned run of 4 CONSECUTIVE output columns of output row m (the MFMA operands are issued
+// swapped so that this is what a lane holds):  acc*alpha (+bias) (+rowvec[image]) -> (GEGLU) -> (+residual) -> store.
+//   v   : the 4 accumulators (value half when geglu), g : the 4 gate accumulators (geglu only)
+//   nb  : first weight row (GEMM column before GEGLU halving) of v; nbg : same for g
+//   col : first output column
+struct GemmEpilogue {
+  const GemmParams& p;
+  int per_img, ncols;
+  bool geglu, vec_ok;
+  __device__ __forceinline__ explicit GemmEpilogue(const GemmParams& q) : p(q) {
+    per_img = p.oh * p.ow;
+    geglu = p.act == FMX_ACT_GEGLU;
+    ncols = geglu ? (p.nout >> 1) : p.nout;
+    vec_ok = ((p.ld_out & 3) == 0) && ((p.ld_res & 3) == 0) && ((p.ld_rowvec & 3) == 0);
+  }
+  __device__ __forceinline__ const f16* rowvec_of(int m) const {
+    return p.rowvec ? p.rowvec + (long)(m / per_img) * p.ld_rowvec : nullptr;
+  }
+  __device__ __forceinline__ void biased(const float (&a)[4], int nb, const f16* rv, float (&v)[4]) const {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = a[r] * p.alpha;
+    if (nb + 3 < p.nout && vec_ok) {
+      if (p.bias) {
+        const f16x4 b = *reinterpret_cast<const f16x4*>(p.bias + nb);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (float)b[r];
+      }
+      if (rv) {
+        const f16x4 b = *reinterpret_cast<const f16x4*>(rv + nb);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (float)b[r];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (nb + r < p.nout) {
+          if (p.bias) v[r] += (float)p.bias[nb + r];
+          if (rv) v[r] += (float)rv[nb + r];
+        }
+      }
+    }
+  }
+  // v already biased (and GEGLU-combined); adds the residual and stores 4 columns starting at `col` of row m
+  __device__ __forceinline__ void store(int m, int col, float (&v)[4]) const {
+    if (col >= ncols) return;
+    const long o = (long)m * p.ld_out + col;
+    const bool full = (col + 3 < ncols) && vec_ok;
+    if (p.residual) {
+      const f16* rp = p.residual + (long)m * p.ld_res + col;
+      if (full) {
+        const f16x4 rr = *reinterpret_cast<const f16x4*>(rp);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (col + r < ncols) v[r] += (float)rp[r];
+      }
+    }
+    if (p.out_f32) {
+      float* op = reinterpret_cast<float*>(p.out) + o;
+      if (full) {
+        *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (col + r < ncols) op[r] = v[r];
+      }
+    } else {
+      f16* op = reinterpret_cast<f16*>(p.out) + o;
+      if (full) {
+        f16x4 hv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hv[r] = (f16)v[r];
+        *reinterpret_cast<f16x4*>(op) = hv;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (col + r < ncols) op[r] = (f16)v[r];
+      }
+    }
+  }
+};
+
+// Branch-free epilogue for the common case (fp16 output, every leading dimension and nout a multiple of 4): absent
+// operands (bias / rowvec / residual) are redirected to the zero page with index multiplier 0, so the code below is
+// straight-line -- the compiler can put all of a row's loads in flight before the first use instead of one
+// s_waitcnt vmcnt(0) per 4 columns.
+struct FastEpilogue {
+  const f16* bias;
+  const f16* rowvec;
+  const f16* res;
+  f16* out;
+  long ld_rv, ld_res, ld_out;
+  int mb, mrv, mres;  // 1 when the operand exists, else 0
+  int per_img, nout, ncols;
+  float alpha;
+  __device__ __forceinline__ explicit FastEpilogue(const GemmParams& p) {
+    mb = p.bias ? 1 : 0;
+    mrv = p.rowvec ? 1 : 0;
+    mres = p.residual ? 1 : 0;
+    bias = p.bias ? p.bias : p.zp;
+    rowvec = p.rowvec ? p.rowvec : p.zp;
+    res = p.residual ? p.residual : p.zp;
+    out = reinterpret_cast<f16*>(p.out);
+    ld_rv = (long)p.ld_rowvec * mrv;
+    ld_res = (long)p.ld_res * mres;
+    ld_out = p.ld_out;
+    per_img = p.oh * p.ow;
+    nout = p.nout;
+    ncols = p.act == FMX_ACT_GEGLU ? (p.nout >> 1) : p.nout;
+    alpha = p.alpha;
+  }
+  static __host__ __device__ __forceinline__ bool eligible(const GemmParams& p) {
+    return !p.out_f32 && (p.ld_out & 3) == 0 && (p.ld_res & 3) == 0 && (p.ld_rowvec & 3) == 0 && (p.nout & 7) == 0;
+  }
+  // nb / col are multiples of 4; callers clamp them into range for the loads and predicate the store
+  __device__ __forceinline__ f16x4 bias4(int nb) const { return *reinterpret_cast<const f16x4*>(bias + nb * mb); }
+  __device__ __forceinline__ f16x4 rv4(int img, int nb) const { return *reinterpret_cast<const f16x4*>(rowvec + img * ld_rv + nb * mrv); }
+  __device__ __forceinline__ f16x4 res4(int m, int col) const { return *reinterpret_cast<const f16x4*>(res + m * ld_res + col * mres); }
+  __device__ __forceinline__ void store4(int m, int col, const float (&v)[4]) const {
+    f16x4 hv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hv[r] = (f16)v[r];
+    *reinterpret_cast<f16x4*>(out + m * ld_out + col) = hv;
+  }
+};
+
+// 256x256-tile kernel (fmx_gemm256.hip)
+int fmx_launch_gemm256(const GemmParams& p, bool conv, hipStream_t st);

@@ -75,7 +75,27 @@ def bench_ln(rows, c):
     print(json.dumps({"op": "layernorm", "rows": rows, "c": c, "us": round(t * 1e6, 1), "GBps": round(2 * x.numel() * 2 / t / 1e9, 0)}), flush=True)
 
 
+def gemm_sweep():
+    """every GEMM-shaped problem of one SDXL 1024^2 B=8 (Bu=16) UNet forward, old tiles (1,2,3) vs 256x256 (4) vs auto (0)"""
+    Bu = 16
+    lin = [(Bu * 1024, 1280, 1280, 0), (Bu * 1024, 2560, 1280, 0), (1280, Bu * 1024, 1280, 0), (Bu * 1024, 10240, 1280, 1), (Bu * 1024, 1280, 5120, 0),
+           (Bu * 4096, 640, 640, 0), (Bu * 4096, 1280, 640, 0), (640, Bu * 4096, 640, 0), (Bu * 4096, 5120, 640, 1), (Bu * 4096, 640, 2560, 0),
+           (8192, 8192, 8192, 0), (4096, 4096, 4096, 0)]
+    for m, n, k, act in lin:
+        for tile in (1, 4, 0):
+            bench_linear(m, n, k, tile, act=act)
+    conv = [(Bu, 32, 32, 1280, 1280, 1, None), (Bu, 32, 32, 2560, 1280, 1, None), (Bu, 64, 64, 640, 640, 1, None), (Bu, 64, 64, 1920, 640, 1, None),
+            (Bu, 128, 128, 320, 320, 1, None), (Bu, 128, 128, 960, 320, 1, None), (Bu, 32, 32, 1280, 1280, 1, (64, 64)), (Bu, 64, 64, 640, 640, 1, (128, 128)),
+            (Bu, 128, 128, 320, 320, 2, None), (Bu, 64, 64, 640, 640, 2, None), (8, 256, 256, 512, 512, 1, None), (8, 512, 512, 256, 256, 1, None)]
+    for n, h, w, c, co, stride, up in conv:
+        for tile in ((1, 2, 4, 0) if co == 320 else (1, 4, 0)):
+            bench_conv(n, h, w, c, co, tile, stride=stride, up=up)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "gemm":
+        gemm_sweep()
+        sys.exit(0)
     Bu = 16  # SDXL B=8 with CFG
     for tile in (1, 2, 3):
         bench_linear(Bu * 1024, 1280, 1280, tile)

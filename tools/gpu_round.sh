@@ -16,5 +16,8 @@ for w in $WHAT; do
             python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/prof_bench.log 2>&1); tail -2 $O/prof_bench.log;
           find $O/prof -name '*kernel_trace.csv' -size +20M -delete; ls -la $O/prof/* | head;;
     kbench) timeout 900 python tools/bench_kernels.py > $O/kbench.log 2>&1; tail -60 $O/kbench.log;;
+    gemmbench) timeout 900 python tools/bench_kernels.py gemm > $O/gemmbench.log 2>&1; tail -100 $O/gemmbench.log;;
+    ktests) timeout -s KILL 240 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "gemm256_identity" > $O/ktests_quick.log 2>&1 || { tail -30 $O/ktests_quick.log; echo "QUICK TEST FAILED -- stopping"; exit 1; }
+            timeout -s KILL 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q 2>&1 | tail -60 > $O/ktests.log; tail -25 $O/ktests.log;;
   esac
 done
