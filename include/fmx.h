@@ -128,14 +128,15 @@ int fmx_softmax_rows_f16(void* x, int64_t nrows, int32_t ncols, int64_t ld, void
 
 /* ------------------------------------------------------------------------------------------------
  * GroupNorm over NHWC fp16 (optionally the channel-concat of two tensors), fp32 statistics.
- *   stats : partial[n][chunk][c][2] fp32 workspace, nchunks chosen by the caller (<= 256)
+ *   stats : partial[n][chunk][c][2] fp32 workspace, nchunks chosen by the caller (<= 256); CONSUMED by apply
+ *           (apply first folds the chunks into per-channel scale/shift in place, deterministically)
  *   apply : y = (x - mean_g) * rstd_g * gamma[c] + beta[c], optional SiLU, fp16 out [n][hw][c0+c1]
  * (c0+c1) % groups == 0, c0 % 8 == 0, c1 % 8 == 0.
  * ---------------------------------------------------------------------------------------------- */
 int fmx_groupnorm_stats_f16(const void* x0, const void* x1, int32_t c0, int32_t c1, int32_t n, int32_t hw,
                             float* partial, int32_t nchunks, void* stream);
 int fmx_groupnorm_apply_f16(const void* x0, const void* x1, int32_t c0, int32_t c1, int32_t n, int32_t hw,
-                            const float* partial, int32_t nchunks, int32_t groups, float eps,
+                            float* partial, int32_t nchunks, int32_t groups, float eps,
                             const void* gamma, const void* beta, int32_t silu, void* y, void* stream);
 
 /* LayerNorm over the last dim of fp16 [rows][c] (c % 8 == 0, c <= 4096), fp32 two-pass statistics. */

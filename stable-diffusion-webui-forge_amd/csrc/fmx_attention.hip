@@ -210,6 +210,196 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
   }
 }
 
+// ---- d_head 64, 64 queries per wave ------------------------------------------------------------------------------
+// Same algorithm and LDS image as attn_kernel<64>, but a wave owns TWO 32-query fragments: every K / V^T fragment read
+// from LDS feeds 2 MFMAs and a workgroup (4 waves) covers 256 queries per K/V tile, which halves the LDS reads and the
+// LDS-DMA instructions per MFMA -- on MI355X both cost matrix-pipe time (a DMA instruction does not issue while the
+// SIMD's other wave streams MFMAs, see fmx_gemm256.hip).  ~215 VGPRs -> 2 waves per SIMD, softmax VALU of one wave
+// under the MFMAs of the other.
+__global__ __launch_bounds__(256, 2) void attn_q64_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int DP = 64, DSTEPS = 4, DVT = 2, CPR = 8;
+  constexpr int KBYTES = KVB * DP * 2;
+  constexpr int VBYTES = DVT * 32 * 128;
+  constexpr int STAGE = KBYTES + VBYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, li = lane & 31;
+
+  const int nwg = p.qtiles * p.heads * p.batch;
+  const int wg = xcd_remap(blockIdx.x, nwg);
+  const int qt = wg % p.qtiles;
+  const int bh = wg / p.qtiles;
+  const int h = bh % p.heads, b = bh / p.heads;
+
+  const f16* kbase = p.k + (long)b * p.k_bs + (long)h * DP;
+  const f16* vbase = p.vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
+
+  const int q0 = qt * 256 + wave * 64;
+  f16x8 qf[2][DSTEPS];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int qrow = min(q0 + a * 32 + li, p.nq - 1);
+    const f16* qp = p.q + (long)b * p.q_bs + (long)qrow * p.q_rs + (long)h * DP + hi * 8;
+#pragma unroll
+    for (int ds = 0; ds < DSTEPS; ++ds) qf[a][ds] = *reinterpret_cast<const f16x8*>(qp + ds * 16);
+  }
+
+  // staging: K tile 64 rows x 8 chunks and V^T tile 64 rows x 8 chunks = 2 x 8 KiB, 2 + 2 DMA instructions per wave
+  const int srow = lane >> 3, spc = lane & 7;
+  auto stage = [&](int s, int kt) {
+    char* sk = smem + s * STAGE;
+    char* sv = sk + KBYTES;
+    const int key0 = kt * KVB;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int row = (e * 4 + wave) * 8 + srow;
+      const int c = spc ^ ((row >> 1) & 7);
+      glds16(kbase + (long)(key0 + row) * p.k_rs + c * 8, sk + (e * 4 + wave) * 1024);
+      glds16(vbase + (long)row * p.vt_ds + key0 + c * 8, sv + (e * 4 + wave) * 1024);
+    }
+  };
+
+  f32x16 oacc[DVT][2];
+#pragma unroll
+  for (int i = 0; i < DVT; ++i)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[i][a][r] = 0.f;
+  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+
+  const int ntiles = (p.nk + KVB - 1) / KVB;
+  stage(0, 0);
+  wait_vmcnt0();
+  __syncthreads();
+
+  const int krow = key_perm(li);
+  const float c2 = p.scale_log2e;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < ntiles) stage(cur ^ 1, kt + 1);
+    const char* sk = smem + cur * STAGE;
+    const char* sv = sk + KBYTES;
+
+    f32x16 sacc[2][2];  // [32-key sub-tile][query fragment]
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[s][a][r] = 0.f;
+      const int row = s * 32 + krow;
+#pragma unroll
+      for (int ds = 0; ds < DSTEPS; ++ds) {
+        const f16x8 kf = *reinterpret_cast<const f16x8*>(sk + row * 128 + (k_phys_chunk<CPR>(row, ds * 2 + hi) << 4));
+#pragma unroll
+        for (int a = 0; a < 2; ++a) sacc[s][a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[a][ds], sacc[s][a], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if ((kt + 1) * KVB > p.nk) {  // ragged tail: mask keys >= nk (wave-uniform branch)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (kt * KVB + s * 32 + hi * 16 + r >= p.nk) sacc[s][a][r] = -INFINITY;
+    }
+    f16x8 pf[2][2][2];  // [query fragment][sub-tile][8-key half]
+    bool grew = false;
+    float alpha[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      float mx = sacc[0][a][0];
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[s][a][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run[a], mx);
+      alpha[a] = __builtin_amdgcn_exp2f((m_run[a] - m_new) * c2);
+      const float mc = m_new * c2;
+      float psum = 0.f;
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = __builtin_amdgcn_exp2f(sacc[s][a][r] * c2 - mc);
+          psum += e;
+          pf[a][s][r >> 3][r & 7] = (f16)e;
+        }
+      l_run[a] = l_run[a] * alpha[a] + psum;
+      grew = grew || (m_new > m_run[a]);
+      m_run[a] = m_new;
+    }
+    if (__any(grew)) {
+#pragma unroll
+      for (int i = 0; i < DVT; ++i)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[i][a][r] *= alpha[a];
+    }
+
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int dt = 0; dt < DVT; ++dt) {
+      const int row = dt * 32 + li;
+      const char* rp = sv + row * 128;
+      const int sw = (row >> 1) & 7;
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const f16x8 vf = *reinterpret_cast<const f16x8*>(rp + (((s * 4 + hi * 2 + j) ^ sw) << 4));
+#pragma unroll
+          for (int a = 0; a < 2; ++a) oacc[dt][a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[a][s][j], oacc[dt][a], 0, 0, 0);
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    wait_vmcnt0();
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const float l_tot = l_run[a] + __shfl_xor(l_run[a], 32);
+    const float inv = 1.0f / l_tot;
+    const int qg = q0 + a * 32 + li;
+    if (qg < p.nq) {
+      f16* op = p.o + (long)b * p.o_bs + (long)qg * p.o_rs + (long)h * DP;
+#pragma unroll
+      for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int d = dt * 32 + g4 * 8 + hi * 4;
+          f16x4 hv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) hv[e] = (f16)(oacc[dt][a][g4 * 4 + e] * inv);
+          *reinterpret_cast<f16x4*>(op + d) = hv;
+        }
+    }
+  }
+}
+
+int launch_attn_q64(AttnParams p, hipStream_t st) {
+  const int smem = 2 * (KVB * 64 * 2 + 2 * 32 * 128);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_q64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  p.qtiles = (p.nq + 255) / 256;
+  const int grid = p.qtiles * p.heads * p.batch;
+  hipLaunchKernelGGL(attn_q64_kernel, dim3(grid), dim3(256), smem, st, p);
+  FMX_LAUNCH_CHECK("fmx_attention_f16 (q64)");
+  return FMX_OK;
+}
+
 template <int DP>
 int launch_attn(const AttnParams& p, hipStream_t st) {
   constexpr int DVT = (DP + 31) / 32;
@@ -263,12 +453,17 @@ extern "C" int fmx_attention_f16(const fmx_attn_args* a, void* stream) {
   p.vt_bs = a->vt_bs; p.vt_hs = a->vt_hs; p.vt_ds = a->vt_ds; p.o_bs = a->o_bs; p.o_rs = a->o_rs;
   p.batch = a->batch; p.heads = a->heads; p.nq = a->nq; p.nk = a->nk; p.nk_pad = a->nk_pad;
   p.qtiles = (a->nq + 127) / 128;
-  p.scale_log2e = a->scale * 1.44269504088896340736f;
+  const bool force32 = a->scale < 0.f;
+  p.scale_log2e = fabsf(a->scale) * 1.44269504088896340736f;
   p.zp = (const f16*)a->zero_page;
   hipStream_t st = (hipStream_t)stream;
   switch (a->dpad) {
     case 48: return launch_attn<48>(p, st);
-    case 64: return launch_attn<64>(p, st);
+    case 64:
+      // 64-query-per-wave variant when there are enough queries to fill 256-query workgroups (test hook: scale < 0 forces
+      // the 32-query kernel)
+      if (a->nq >= 256 && !force32) return launch_attn_q64(p, st);
+      return launch_attn<64>(p, st);
     case 80: return launch_attn<80>(p, st);
     case 160: return launch_attn<160>(p, st);
     default: return fmx_set_error(FMX_E_UNSUPPORTED, "attention: dpad %d not in {48,64,80,160}", a->dpad);

@@ -166,7 +166,7 @@ def geglu_interleave(w, b):
 
 
 def attention(q, k, vt, *, batch, heads, nq, nk, nk_pad, dpad, scale, q_bs, q_rs, k_bs, k_rs, vt_bs, vt_hs, vt_ds,
-              out=None):
+              out=None, force32=False):
     """q/k/vt are base tensors (views allowed: the data_ptr is the element (0,0,0,0)); strides in elements."""
     _check_f16(q, k, vt)
     if out is None:
@@ -177,7 +177,7 @@ def attention(q, k, vt, *, batch, heads, nq, nk, nk_pad, dpad, scale, q_bs, q_rs
     a.vt_bs, a.vt_hs, a.vt_ds = vt_bs, vt_hs, vt_ds
     a.o_bs, a.o_rs = nq * out.stride(0), out.stride(0)
     a.batch, a.heads, a.nq, a.nk, a.nk_pad, a.dpad = batch, heads, nq, nk, nk_pad, dpad
-    a.scale = float(scale)
+    a.scale = -float(scale) if force32 else float(scale)  # test hook: negative scale selects the 32-query-per-wave kernel
     a.zero_page = _p(zero_page(q.device))
     if _profiler is not None:
         d_true = int(round(float(scale) ** -2))

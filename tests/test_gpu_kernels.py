@@ -196,9 +196,13 @@ def _attn_ref(q, k, v, scale):
 
 @pytest.mark.parametrize("b,h,nq,nk,d,dpad", [
     (2, 2, 128, 128, 64, 64), (1, 3, 256, 192, 64, 64), (2, 2, 200, 77, 64, 64), (1, 10, 1024, 1024, 64, 64),
+    (2, 3, 300, 200, 64, 64), (1, 2, 4096, 4096, 64, 64), (2, 2, 1000, 77, 64, 64),
     (2, 2, 64, 64, 40, 48), (1, 2, 160, 128, 80, 80), (1, 2, 96, 77, 160, 160), (1, 8, 4096, 4096, 40, 48),
 ])
-def test_attention(b, h, nq, nk, d, dpad):
+@pytest.mark.parametrize("force32", [False, True])
+def test_attention(b, h, nq, nk, d, dpad, force32):
+    if force32 and not (dpad == 64 and nq >= 256):
+        pytest.skip("only d_head 64 with >= 256 queries has two kernels")
     nk_pad = -(-nk // 64) * 64
     q = torch.zeros(b, nq, h, dpad, dtype=torch.float16, device=DEV)
     k = torch.zeros(b, nk_pad, h, dpad, dtype=torch.float16, device=DEV)
@@ -212,21 +216,22 @@ def test_attention(b, h, nq, nk, d, dpad):
     scale = d ** -0.5
     out = ops.attention(q, k, vt, batch=b, heads=h, nq=nq, nk=nk, nk_pad=nk_pad, dpad=dpad, scale=scale,
                         q_bs=nq * h * dpad, q_rs=h * dpad, k_bs=nk_pad * h * dpad, k_rs=h * dpad,
-                        vt_bs=nk_pad, vt_hs=dpad * b * nk_pad, vt_ds=b * nk_pad)
+                        vt_bs=nk_pad, vt_hs=dpad * b * nk_pad, vt_ds=b * nk_pad, force32=force32)
     ref = _attn_ref(q.permute(0, 2, 1, 3)[..., :d], k.permute(0, 2, 1, 3)[:, :, :nk, :d], v.permute(0, 2, 1, 3)[:, :, :nk, :d], scale)
     got = out.reshape(b, nq, h, dpad).permute(0, 2, 1, 3)
     close(got[..., :d], ref, 2e-3, 2e-3, "attention")
     assert float(got[..., d:].abs().max()) == 0.0 if dpad > d else True
 
 
-def test_attention_spiked_max():
+@pytest.mark.parametrize("force32", [False, True])
+def test_attention_spiked_max(force32):
     # one key dominates late in the sequence: forces the online-softmax rescale branch
     b, h, n, d = 1, 1, 512, 64
     q, k, v = rnd(b, n, h, d, seed=50), rnd(b, n, h, d, seed=51), rnd(b, n, h, d, seed=52)
     k[0, 400, 0] = q[0, 17, 0] * 6
     vt = v.permute(2, 3, 0, 1).contiguous()
     out = ops.attention(q, k, vt, batch=b, heads=h, nq=n, nk=n, nk_pad=n, dpad=d, scale=d ** -0.5, q_bs=n * d, q_rs=d,
-                        k_bs=n * d, k_rs=d, vt_bs=n, vt_hs=d * n, vt_ds=n)
+                        k_bs=n * d, k_rs=d, vt_bs=n, vt_hs=d * n, vt_ds=n, force32=force32)
     ref = _attn_ref(q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3), d ** -0.5)
     close(out.reshape(b, n, h, d).permute(0, 2, 1, 3), ref, 2e-3, 2e-3, "attention spike")
 

@@ -48,14 +48,14 @@ def bench_conv(n, h, w, c, co, tile=0, stride=1, up=None):
                       "tflops": round(2 * n * oh * ow * co * 9 * c / t / 1e12, 1)}), flush=True)
 
 
-def bench_attn(b, h, nq, nk, d, dpad):
+def bench_attn(b, h, nq, nk, d, dpad, force32=False):
     nkp = -(-nk // 64) * 64
     q, k = rnd(b, nq, h, dpad), rnd(b, nkp, h, dpad)
     vt = rnd(h, dpad, b, nkp)
     out = torch.empty(b * nq, h * dpad, dtype=torch.float16, device=DEV)
     t = timeit(lambda: ops.attention(q, k, vt, batch=b, heads=h, nq=nq, nk=nk, nk_pad=nkp, dpad=dpad, scale=d ** -0.5, q_bs=nq * h * dpad,
-                                     q_rs=h * dpad, k_bs=nkp * h * dpad, k_rs=h * dpad, vt_bs=nkp, vt_hs=dpad * b * nkp, vt_ds=b * nkp, out=out))
-    print(json.dumps({"op": "attention", "b": b, "h": h, "nq": nq, "nk": nk, "d": d, "us": round(t * 1e6, 1),
+                                     q_rs=h * dpad, k_bs=nkp * h * dpad, k_rs=h * dpad, vt_bs=nkp, vt_hs=dpad * b * nkp, vt_ds=b * nkp, out=out, force32=force32))
+    print(json.dumps({"op": "attention", "b": b, "h": h, "nq": nq, "nk": nk, "d": d, "force32": force32, "us": round(t * 1e6, 1),
                       "tflops": round(4 * b * h * nq * nk * d / t / 1e12, 1)}), flush=True)
 
 
@@ -93,6 +93,14 @@ def gemm_sweep():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "attn":
+        for f32 in (True, False):
+            bench_attn(16, 10, 4096, 4096, 64, 64, f32)
+            bench_attn(16, 20, 1024, 1024, 64, 64, f32)
+            bench_attn(16, 20, 1024, 77, 64, 64, f32)
+            bench_attn(16, 10, 4096, 77, 64, 64, f32)
+            bench_attn(2, 10, 4096, 4096, 64, 64, f32)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "gemm":
         gemm_sweep()
         sys.exit(0)
