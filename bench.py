@@ -79,6 +79,26 @@ def cpu_baseline(model, cfg, latent):
     return dt, nthreads, t_init
 
 
+def pmc_traffic_per_launch():
+    """HBM bytes per launch of the GEMM kernels from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE
+    runs of this same workload, tools/gpu_round.sh pmc -> profiles/*_pmc_fetch_write_summary.json; FETCH_SIZE doubled per
+    MI355X_MICROARCH.md).  bench.py cannot run the profiler on itself, so this is the last committed measurement or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_fetch_write_summary.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        n = b = 0.0
+        for fam in ("gemm", "gemm256"):
+            if fam in d:
+                n += d[fam]["launches_FETCH_SIZE"]
+                b += d[fam]["hbm_bytes_per_launch"] * d[fam]["launches_FETCH_SIZE"]
+        return {"hbm_bytes_per_launch_avg": round(b / n), "source": os.path.basename(files[-1])} if n else None
+    except Exception:
+        return None
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -167,7 +187,7 @@ def main():
         # ---- VAE decode (per-job, outside the step loop) and latent gather -------------------------------------
         vae_ms = None
         if not a.no_vae:
-            eng.decode_first_stage(lat[:1])
+            eng.decode_first_stage(lat)          # untimed: sizes the VAE arena for this batch
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             img = eng.decode_first_stage(lat)
@@ -198,16 +218,17 @@ def main():
             g = summ.get("gemm_conv")
             if g:
                 ach = g["flops"] / g["seconds"]
-                roof = {"kernel": "gemm_kernel (fmx_gemm_conv_f16: MFMA implicit-GEMM conv3x3/1x1 + linear, fused epilogues)",
+                traffic = pmc_traffic_per_launch()
+                roof = {"kernel": "gemm256_kernel + gemm_kernel (fmx_gemm_conv_f16: MFMA implicit-GEMM conv3x3/1x1 + linear, fused epilogues)",
                         "bound": "mfma", "achieved": round(ach / 1e12, 1), "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s",
-                        "frac": round(ach / MFMA_PEAK, 4), "traffic": None, "launches_per_forward": g["launches"],
+                        "frac": round(ach / MFMA_PEAK, 4), "traffic": traffic, "launches_per_forward": g["launches"],
                         "flop_per_launch_avg": round(g["flops"] / g["launches"] / 1e9, 2), "flop_unit": "GFLOP",
                         "us_per_launch_avg": round(g["seconds"] / g["launches"] * 1e6, 1),
                         "kernel_time_per_forward_ms": round(g["seconds"] * 1e3, 2)}
             at = summ.get("attention")
             if at:
                 ach = at["flops"] / at["seconds"]
-                attn_roof = {"kernel": "attn_kernel (fmx_attention_f16: fused QK^T-softmax-PV)", "bound": "mfma",
+                attn_roof = {"kernel": "attn_q64_kernel (fmx_attention_f16: fused QK^T-softmax-PV)", "bound": "mfma",
                              "achieved": round(ach / 1e12, 1), "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK, 4),
                              "launches_per_forward": at["launches"], "kernel_time_per_forward_ms": round(at["seconds"] * 1e3, 2)}
 

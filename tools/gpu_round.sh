@@ -15,6 +15,9 @@ for w in $WHAT; do
     prof) (cd /tmp && export TMPDIR=/tmp && timeout 1200 rocprofv3 --kernel-trace --stats -f csv -d $O/prof -o kt -- \
             python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/prof_bench.log 2>&1); tail -2 $O/prof_bench.log;
           find $O/prof -name '*kernel_trace.csv' -size +20M -delete; ls -la $O/prof/* | head;;
+    pmc) for C in FETCH_SIZE WRITE_SIZE; do (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --pmc $C -f csv -d $O/pmc_$C -o pmc -- \
+            python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vae --no-roofline --no-graph > $O/pmc_$C.log 2>&1); tail -1 $O/pmc_$C.log; done;
+          python $R/tools/pmc_summary.py $O > $O/pmc_summary.json; cat $O/pmc_summary.json; find $O -name '*counter_collection.csv' -size +30M -delete; find $O -name '*kernel_trace.csv' -delete;;
     kbench) timeout 900 python tools/bench_kernels.py > $O/kbench.log 2>&1; tail -60 $O/kbench.log;;
     gemmbench) timeout 900 python tools/bench_kernels.py gemm > $O/gemmbench.log 2>&1; tail -100 $O/gemmbench.log;;
     ktests) timeout -s KILL 240 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "gemm256_identity" > $O/ktests_quick.log 2>&1 || { tail -30 $O/ktests_quick.log; echo "QUICK TEST FAILED -- stopping"; exit 1; }
