@@ -15,7 +15,9 @@
  *   fmx_softmax_rows_f16   sim.softmax(dim=-1) backend/attention.py:85 (materialised-score variant)
  *   fmx_groupnorm_*        F.group_norm backend/operations.py:308 (+ SiLU backend/nn/unet.py:394-398)
  *   fmx_layernorm_f16      F.layer_norm backend/operations.py:327
- *   fmx_timestep_embedding timestep_embedding backend/nn/unet.py:55-67
+ *   fmx_timestep_embedding timestep_embedding backend/nn/unet.py:55-67 (and backend/nn/flux.py:52-73 with t*1000)
+ *   fmx_layernorm_mod_f16  LayerNorm(no affine) + adaLN modulate backend/nn/flux.py:209-210,228-229,255,260,286,326
+ *   fmx_flux_qk_norm_rope_f16  QKNorm (RMSNorm) + apply_rope + [B,H,L,D] permute backend/nn/flux.py:43-49,115-139,217-247
  *   fmx_silu_f16           nn.SiLU in time_embed / emb_layers backend/nn/unet.py:519-523,415-418
  *   fmx_unet_pack_input    KModel.apply_model input half  backend/modules/k_model.py:25-36
  *   fmx_cfg_combine        calculate_denoised backend/modules/k_prediction.py:81-92 + CFG combine
@@ -34,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FMX_ABI_VERSION 1
+#define FMX_ABI_VERSION 2
 
 #define FMX_OK 0
 #define FMX_E_BADARG 10001   /* shape / alignment / null-pointer contract violated */
@@ -43,6 +45,7 @@ extern "C" {
 /* activation / epilogue selector for fmx_gemm_conv_f16 */
 #define FMX_ACT_NONE 0
 #define FMX_ACT_GEGLU 1 /* weight rows interleaved [16 value | 16 gate] (see fmx_geglu_interleave_rows) */
+#define FMX_ACT_GELU_TANH 2 /* nn.GELU(approximate="tanh") of the Flux MLPs (backend/nn/flux.py:193,280) */
 
 int fmx_abi_version(void);
 const char* fmx_last_error(void);
@@ -59,7 +62,8 @@ int fmx_device_info(int* cu_count, int* wave_size, char* arch, int arch_len);
  *               (src = floor(dst * in / out)) -- the fused Upsample -- and the conv runs on that.
  *   W operand : fp16 [nout][kh*kh*(c0+c1)] row-major (ldw elements per row, 0 -> dense),
  *               K ordered (ky, kx, channel).
- *   epilogue  : acc*alpha (+ bias[col]) (+ rowvec[row / (oh*ow)][col]) -> act -> (+ residual[row][col])
+ *   epilogue  : acc*alpha (+ bias[col]) (+ rowvec[row / (oh*ow)][col]) -> act -> (* gate[row / (oh*ow)][col])
+ *               -> (+ residual[row][col])    (gate: the adaLN gates of Flux, backend/nn/flux.py:254-262,301)
  *               stored as fp16 (or fp32 when out_f32 != 0) at out[row*ld_out + col].
  *               act = FMX_ACT_GEGLU: out has nout/2 columns, value*gelu_erf(gate).
  * Requirements: (c0+c1) % 64 == 0, c0 % 64 == 0, all tensors 16-byte aligned, strides % 8 == 0.
@@ -87,6 +91,8 @@ typedef struct fmx_gemm_args {
   int32_t ld_out;
   int32_t out_f32;
   const void* zero_page; /* >= 256 bytes of zeros (device), used for padding taps / tails */
+  const void* gate;      /* optional fp16 [n][ld_gate] per-image column scale applied after act (fp16-output fast epilogue only) */
+  int32_t ld_gate;
 } fmx_gemm_args;
 
 int fmx_gemm_conv_f16(const fmx_gemm_args* args /* host */, void* stream);
@@ -102,7 +108,7 @@ int fmx_geglu_interleave_rows(const void* w_in, const void* b_in, void* w_out, v
  *   k  : fp16, element (b, j, h, d) at k[b*k_bs + j*k_rs + h*dpad + d]
  *   vt : fp16 V TRANSPOSED, element (b, h, d, j) at vt[b*vt_bs + h*vt_hs + d*vt_ds + j]
  *   o  : fp16, element (b, i, h, d) at o[b*o_bs + i*o_rs + h*dpad + d]
- *   dpad in {48, 64, 80, 160}: head dim padded to a multiple of 16 with ZERO columns (rows in vt);
+ *   dpad in {48, 64, 80, 128, 160}: head dim padded to a multiple of 16 with ZERO columns (rows in vt);
  *   nk_pad = number of key columns present per (b,h,d) row of vt / rows of k (multiple of 64),
  *   nk = number of valid keys (<= nk_pad, keys >= nk are masked out).  nq arbitrary.
  *   All base pointers 16-byte aligned; strides % 8 == 0.
@@ -142,6 +148,19 @@ int fmx_groupnorm_apply_f16(const void* x0, const void* x1, int32_t c0, int32_t 
 /* LayerNorm over the last dim of fp16 [rows][c] (c % 8 == 0, c <= 4096), fp32 two-pass statistics. */
 int fmx_layernorm_f16(const void* x, const void* gamma, const void* beta, void* y, int64_t rows, int32_t c,
                       float eps, void* stream);
+
+/* Flux adaLN: y = (1 + scale[b]) * LayerNorm_noaffine(x) + shift[b]; x, y fp16 [rows][c], b = row / rows_per_batch;
+ * scale / shift fp16 vectors of batch element b at scale + b*ld_mod, shift + b*ld_mod (views into the Modulation output). */
+int fmx_layernorm_mod_f16(const void* x, const void* scale, const void* shift, int64_t ld_mod, int64_t rows_per_batch, void* y,
+                          int64_t rows, int32_t c, float eps, void* stream);
+
+/* Flux attention front end for one stream (txt or img) of `tokens` rows per batch element:
+ *   qkv [batch*tokens][ld_qkv] fp16 = [q | k | v], each [heads][128]  ->  per-head RMSNorm(q)*q_scale, RMSNorm(k)*k_scale (eps),
+ *   rotary embedding with pe[(row_off + t)][64][2] = (cos, sin) fp32, written to q_out / k_out [batch][l_pad][heads*128] at rows
+ *   row_off + t, and v transposed to vt_out [heads*128][batch*l_pad] at columns b*l_pad + row_off + t. */
+int fmx_flux_qk_norm_rope_f16(const void* qkv, int64_t ld_qkv, const void* q_scale, const void* k_scale, const float* pe, void* q_out,
+                              void* k_out, void* vt_out, int32_t batch, int32_t tokens, int32_t heads, int32_t head_dim,
+                              int32_t row_off, int32_t l_pad, float eps, void* stream);
 
 /* emb[b][0:half] = cos(t[b]*f_k), emb[b][half:] = sin(t[b]*f_k), f_k = exp(-ln(max_period)*k/half); fp32 math,
  * fp16 out [b][dim] (dim even). */

@@ -201,6 +201,50 @@ def gen_full_sd15():
     print("sd15 config0: sampler %.1fs (%.3f it/s), decode %.1fs, latent std %.3f" % (t_sample, 20 / t_sample, t_dec, float(lat.std())))
 
 
+def gen_flux(name="tiny_flux", cfg=None, b=2, h=16, w=24, ltxt=40):
+    """Flux DiT: one forward of the REAL reference and a 4-step Euler flow-sampling run through the reference's KModel +
+    PredictionFlux + k_diffusion.sample_euler ('simple' sigmas: modules/sd_schedulers.py:81-87, restated because that module
+    imports gradio)."""
+    cfg = cfg or synth.TINY_FLUX_CONFIG
+    ref = ref_import.load_reference()
+    sd = synth.synth_flux_state_dict(cfg, seed=2)
+    net = ref_import.build_ref_flux(cfg, sd)
+    g = torch.Generator("cpu").manual_seed(21)
+    x = torch.randn(b, cfg["in_channels"], h, w, generator=g)
+    ctx = torch.randn(b, ltxt, cfg["context_in_dim"], generator=g)
+    y = torch.randn(b, cfg["vec_in_dim"], generator=g)
+    t = torch.tensor([0.93, 0.41][:b])
+    guid = torch.full((b,), 3.5)
+    with torch.no_grad():
+        out = net(x.clone(), t, context=ctx, y=y, guidance=guid)
+    pred = ref.k_prediction.PredictionFlux(seq_len=(h // 2) * (w // 2))
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        km = ref.k_model.KModel(net, None, k_predictor=pred)
+    n = 4
+    ss = len(pred.sigmas) / n
+    sigmas = torch.FloatTensor([float(pred.sigmas[-(1 + int(i * ss))]) for i in range(n)] + [0.0])
+    x0 = torch.randn(b, cfg["in_channels"], h, w, generator=g)
+    xs = pred.noise_scaling(sigmas[0], x0.clone(), torch.zeros_like(x0))
+
+    def model_fn(xx, sigma, **kw):
+        return km.apply_model(xx, sigma, c_crossattn=ctx, y=y, guidance=guid)
+
+    with torch.no_grad():
+        lat = ref.kd_sampling.sample_euler(model_fn, xs, sigmas, disable=True)
+    torch.save({"x": x, "t": t, "ctx": ctx, "y": y, "guidance": guid, "out": out, "sigma_table": pred.sigmas.clone(), "mu": float(pred.mu),
+                "sigmas": sigmas, "noise": x0, "latent": lat, "hw": (h, w)}, os.path.join(GOLD, f"{name}_fwd.pt"))
+    keys = {k: list(v.shape) for k, v in net.state_dict().items()}
+    with torch.device("meta"):
+        big = ref_import.build_ref_flux(synth.FLUX_DEV_CONFIG)
+    shapes = json.load(open(os.path.join(GOLD, "param_shapes.json")))
+    shapes["tiny_flux"] = keys
+    shapes["flux_dev"] = {k: list(v.shape) for k, v in big.state_dict().items()}
+    json.dump(shapes, open(os.path.join(GOLD, "param_shapes.json"), "w"))
+    print(name, "fwd", tuple(out.shape), float(out.std()), "latent std", float(lat.std()), "params flux_dev",
+          sum(int(np.prod(v)) for v in shapes["flux_dev"].values()) / 1e9, "B")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
@@ -218,6 +262,8 @@ def main():
         net, _ = gen_unet("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG)
         gen_samples("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG, net)
         gen_vae("tiny_vae", synth.TINY_VAE_CONFIG)
+    if a.only in ("", "flux"):
+        gen_flux()
     if a.full or a.only == "full":
         gen_full_sd15()
 

@@ -83,6 +83,7 @@ def load_reference():
         import backend.attention as attention
         import backend.nn.unet as nn_unet
         import backend.nn.vae as nn_vae
+        import backend.nn.flux as nn_flux
         import backend.modules.k_prediction as k_prediction
         import backend.modules.k_model as k_model
         import backend.sampling.sampling_function as sampling_function
@@ -104,7 +105,7 @@ def load_reference():
         return (x - denoised) / sigma
     kd_sampling.to_d = to_d
 
-    _loaded = SimpleNamespace(attention=attention, nn_unet=nn_unet, nn_vae=nn_vae,
+    _loaded = SimpleNamespace(attention=attention, nn_unet=nn_unet, nn_vae=nn_vae, nn_flux=nn_flux,
                               k_prediction=k_prediction, k_model=k_model,
                               sampling_function=sampling_function, condition=condition,
                               patcher_unet=patcher_unet, kd_sampling=kd_sampling,
@@ -183,3 +184,15 @@ class SdxlCond(dict):
 
     def advanced_indexing(self, item):
         return SdxlCond({k: v[item] for k, v in self.items()})
+
+
+def build_ref_flux(flux_config, state_dict=None):
+    """Reference IntegratedFluxTransformer2DModel (backend/nn/flux.py:310) on CPU fp32 with the attributes loader.py:169-173 sets."""
+    import torch
+    ref = load_reference()
+    net = ref.nn_flux.IntegratedFluxTransformer2DModel(**flux_config)
+    if state_dict is not None:
+        net.load_state_dict(state_dict, strict=True)
+    net.storage_dtype = net.computation_dtype = torch.float32
+    net.load_device = net.offload_device = net.initial_device = torch.device("cpu")
+    return net.eval()

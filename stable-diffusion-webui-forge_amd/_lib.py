@@ -33,7 +33,7 @@ class GemmArgs(C.Structure):
         ("residual", C.c_void_p), ("ld_res", C.c_int32),
         ("alpha", C.c_float), ("act", C.c_int32),
         ("out", C.c_void_p), ("ld_out", C.c_int32), ("out_f32", C.c_int32),
-        ("zero_page", C.c_void_p),
+        ("zero_page", C.c_void_p), ("gate", C.c_void_p), ("ld_gate", C.c_int32),
     ]
 
 
@@ -61,6 +61,8 @@ SIGNATURES = {
     "fmx_groupnorm_stats_f16": [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
     "fmx_groupnorm_apply_f16": [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _f32, _vp, _vp, _i32, _vp, _vp],
     "fmx_layernorm_f16": [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp],
+    "fmx_layernorm_mod_f16": [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i32, _f32, _vp],
+    "fmx_flux_qk_norm_rope_f16": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
     "fmx_timestep_embedding": [_vp, _vp, _i32, _i32, _f32, _vp],
     "fmx_silu_f16": [_vp, _vp, _i64, _vp],
     "fmx_cast_f32_to_f16": [_vp, _vp, _i64, _vp],
@@ -120,7 +122,7 @@ def lib():
             fn.restype = C.c_int
         handle.fmx_last_error.argtypes = []
         handle.fmx_last_error.restype = C.c_char_p
-        if handle.fmx_abi_version() != 1:
+        if handle.fmx_abi_version() != 2:
             raise FmxError("libfmx ABI version mismatch")
         _lib = handle
     return _lib

@@ -46,3 +46,28 @@ def build_engine(unet_config, unet_state_dict, vae_config=None, vae_state_dict=N
     unet = IntegratedUNet2DConditionModel(unet_config, unet_state_dict, device=device)
     vae = IntegratedAutoencoderKL(vae_config, vae_state_dict, device=device) if vae_config is not None else None
     return ForgeDiffusionEngine(unet, vae, is_sdxl=unet_config.get("adm_in_channels") is not None)
+
+
+class FluxEngine:
+    """Object protocol of backend/diffusion_engine/flux.py:27-120 that the call surface touches (transformer only: text encoders
+    and the 16-channel VAE are outside this round's scope)."""
+
+    def __init__(self, transformer, seq_len):
+        from ..modules.k_model import KModelFlux
+        from ..modules.k_prediction import PredictionFlux
+        from ..patcher.unet import UnetPatcher
+        patcher = UnetPatcher(KModelFlux(transformer, PredictionFlux(seq_len=seq_len)), transformer.device, transformer.device)
+        self.forge_objects = ForgeObjects(unet=patcher, clip=None, vae=None)
+        self.forge_objects_original = self.forge_objects.shallow_copy()
+        self.forge_objects_after_applying_lora = self.forge_objects.shallow_copy()
+        self.is_sdxl = self.is_sd1 = self.is_inpaint = False
+        self.is_flux = True
+        self.use_distilled_cfg_scale = True
+        self.latent_channels = transformer.in_channels // 4
+        self.device = transformer.device
+
+
+def build_flux_engine(flux_config, state_dict, width, height, device="cuda"):
+    from ..nn.flux import IntegratedFluxTransformer2DModel
+    net = IntegratedFluxTransformer2DModel(flux_config, state_dict, device=device)
+    return FluxEngine(net, seq_len=(height // 16) * (width // 16))

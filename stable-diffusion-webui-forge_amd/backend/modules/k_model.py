@@ -155,3 +155,37 @@ class KModel:
         b, c, hh, ww = x.shape
         eps = self._forward_static((b, c, hh, ww, 1, "apply"), x, sigma, host_sigmas(t), 1, ctxc)
         return ops.cfg_combine(eps, eps.shape[-1], x, sigma, 1, 1.0)
+
+
+class KModelFlux:
+    """`KModel` over the Flux executor (k_model.py:25-46 with prediction_type 'const': input = x, timestep = sigma, denoised =
+    x - out * sigma).  Flux-dev is guidance-distilled: cond_scale == 1, no uncond batch (diffusion_engine/flux.py:88-93)."""
+
+    def __init__(self, model, predictor):
+        self.diffusion_model = model
+        self.predictor = predictor
+        self.storage_dtype = model.storage_dtype
+        self.computation_dtype = model.computation_dtype
+        self.device = model.device
+        self.use_graph = False
+
+    def memory_required(self, input_shape):
+        return 0
+
+    def apply_model(self, x, t, c_concat=None, c_crossattn=None, control=None, transformer_options=None, y=None, guidance=None, **kwargs):
+        if c_concat is not None or control is not None:
+            raise NotImplementedError("c_concat / control are outside the txt2img hot path")
+        x = x.to(device=self.device, dtype=torch.float32).contiguous()
+        sigma = t.to(device=self.device, dtype=torch.float32).contiguous()
+        out = self.diffusion_model.forward(x, sigma, c_crossattn, y, guidance).float()
+        sig_host = host_sigmas(t)
+        if len(set(sig_host)) == 1:
+            return ops.lincomb3(x, out, None, 1.0, -float(sig_host[0]), 0.0)   # x - out * sigma in one kernel
+        return x - out * sigma.view(-1, 1, 1, 1)
+
+    def denoise_cfg(self, x, sigma, uncond_ctx, cond_ctx, cond_scale, want_parts=False):
+        if uncond_ctx is not None:
+            raise NotImplementedError("Flux-dev runs at cfg scale 1 with distilled guidance (one model call per step)")
+        ctx, y, guidance = cond_ctx
+        den = self.apply_model(x, sigma, c_crossattn=ctx, y=y, guidance=guidance)
+        return (den, den, None) if want_parts else den

@@ -12,14 +12,19 @@ from ... import hipops as ops
 
 class AbstractPrediction:
     def __init__(self, sigma_data=1.0, prediction_type="epsilon"):
-        if prediction_type != "epsilon":
-            raise NotImplementedError("only epsilon prediction is on the SD1.x/SDXL path (k_prediction.py:81-92)")
+        if prediction_type not in ("epsilon", "const"):
+            raise NotImplementedError("epsilon (SD1.x/SDXL) and const (Flux flow matching) are on the path (k_prediction.py:74-92)")
         self.sigma_data = sigma_data
         self.prediction_type = prediction_type
 
     def noise_scaling(self, sigma, noise, latent_image=None, max_denoise=False):
         """k_prediction.py:94-104; `sigma` is a host scalar (sigmas[0]).  latent_image None == zeros (txt2img)."""
         s = float(sigma)
+        if self.prediction_type == "const":  # :95-96  sigma * noise + (1 - sigma) * latent
+            out = ops.scale_f32(noise, s)
+            if latent_image is not None:
+                out += (1.0 - s) * latent_image
+            return out
         f = (1.0 + s ** 2.0) ** 0.5 if max_denoise else s
         out = ops.scale_f32(noise, f)
         if latent_image is not None:
@@ -65,3 +70,35 @@ class Prediction(AbstractPrediction):
         if percent >= 1.0:
             return 0.0
         return self.sigma(torch.tensor(1000.0 * (1.0 - percent))).item()
+
+
+class PredictionFlux(AbstractPrediction):
+    """k_prediction.py:280-324: flow-matching 'const' prediction; sigma table = time-shifted linspace(1/N..1), mu from the
+    image sequence length (diffusers calculate_shift, restated); timestep(sigma) = sigma."""
+
+    def __init__(self, seq_len=4096, base_seq_len=256, max_seq_len=4096, base_shift=0.5, max_shift=1.15, pseudo_timestep_range=10000, mu=None):
+        super().__init__(sigma_data=1.0, prediction_type="const")
+        import math
+        if mu is None:
+            m = (max_shift - base_shift) / (max_seq_len - base_seq_len)
+            mu = seq_len * m + (base_shift - m * base_seq_len)
+        self.mu = mu
+        t = torch.arange(1, pseudo_timestep_range + 1, 1) / pseudo_timestep_range
+        self.sigmas = (math.exp(mu) / (math.exp(mu) + (1 / t - 1) ** 1.0)).float()
+
+    @property
+    def sigma_min(self):
+        return self.sigmas[0]
+
+    @property
+    def sigma_max(self):
+        return self.sigmas[-1]
+
+    def timestep(self, sigma):
+        return sigma
+
+    def sigma(self, timestep):
+        return timestep
+
+    def percent_to_sigma(self, percent):
+        return 1.0 if percent <= 0.0 else 0.0 if percent >= 1.0 else 1.0 - percent

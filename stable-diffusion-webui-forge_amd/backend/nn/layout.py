@@ -292,3 +292,50 @@ def vae_decoder_param_shapes(cfg):
     norm("decoder.norm_out", lay.final_ch)
     conv("decoder.conv_out", lay.final_ch, lay.out_channels, 3)
     return s
+
+
+# ---- Flux (MMDiT) ---------------------------------------------------------------------------------------------------
+def flux_param_shapes(cfg):
+    """State-dict keys / shapes of IntegratedFluxTransformer2DModel (backend/nn/flux.py:310-367) for a config dict with the
+    reference ctor's keys (in_channels, vec_in_dim, context_in_dim, hidden_size, mlp_ratio, num_heads, depth,
+    depth_single_blocks, axes_dim, theta, qkv_bias, guidance_embed)."""
+    hs, nh = cfg["hidden_size"], cfg["num_heads"]
+    hd = hs // nh
+    mlp = int(hs * cfg["mlp_ratio"])
+    inc = cfg["in_channels"] * 4
+    out = OrderedDict()
+
+    def lin(k, nin, nout, bias=True):
+        out[k + ".weight"] = (nout, nin)
+        if bias:
+            out[k + ".bias"] = (nout,)
+
+    lin("img_in", inc, hs)
+    lin("time_in.in_layer", 256, hs)
+    lin("time_in.out_layer", hs, hs)
+    lin("vector_in.in_layer", cfg["vec_in_dim"], hs)
+    lin("vector_in.out_layer", hs, hs)
+    if cfg["guidance_embed"]:
+        lin("guidance_in.in_layer", 256, hs)
+        lin("guidance_in.out_layer", hs, hs)
+    lin("txt_in", cfg["context_in_dim"], hs)
+    for i in range(cfg["depth"]):
+        b = f"double_blocks.{i}"
+        for st in ("img", "txt"):
+            lin(f"{b}.{st}_mod.lin", hs, 6 * hs)
+            lin(f"{b}.{st}_attn.qkv", hs, 3 * hs, bias=cfg["qkv_bias"])
+            out[f"{b}.{st}_attn.norm.query_norm.scale"] = (hd,)
+            out[f"{b}.{st}_attn.norm.key_norm.scale"] = (hd,)
+            lin(f"{b}.{st}_attn.proj", hs, hs)
+            lin(f"{b}.{st}_mlp.0", hs, mlp)
+            lin(f"{b}.{st}_mlp.2", mlp, hs)
+    for i in range(cfg["depth_single_blocks"]):
+        b = f"single_blocks.{i}"
+        lin(f"{b}.linear1", hs, 3 * hs + mlp)
+        lin(f"{b}.linear2", hs + mlp, hs)
+        out[f"{b}.norm.query_norm.scale"] = (hd,)
+        out[f"{b}.norm.key_norm.scale"] = (hd,)
+        lin(f"{b}.modulation.lin", hs, 3 * hs)
+    lin("final_layer.linear", hs, inc)
+    lin("final_layer.adaLN_modulation.1", hs, 2 * hs)
+    return out

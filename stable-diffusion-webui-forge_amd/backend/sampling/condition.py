@@ -55,8 +55,10 @@ def compile_conditions(cond):
     if isinstance(cond, torch.Tensor):
         return [dict(cross_attn=cond, model_conds=dict(c_crossattn=ConditionCrossAttn(cond)))]
     cross_attn, pooled = cond["crossattn"], cond["vector"]
-    return [dict(cross_attn=cross_attn, pooled_output=pooled,
-                 model_conds=dict(c_crossattn=ConditionCrossAttn(cross_attn), y=Condition(pooled)))]
+    mc = dict(c_crossattn=ConditionCrossAttn(cross_attn), y=Condition(pooled))
+    if "guidance" in cond:  # Flux distilled guidance (condition.py:104-119 with diffusion_engine/flux.py:92)
+        mc["guidance"] = Condition(cond["guidance"])
+    return [dict(cross_attn=cross_attn, pooled_output=pooled, model_conds=mc)]
 
 
 def compile_weighted_conditions(cond, weights):

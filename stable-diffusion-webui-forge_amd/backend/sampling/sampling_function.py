@@ -28,7 +28,7 @@ def _single(conds, what):
     if not math.isclose(c.get("strength", 1.0), 1.0):
         raise NotImplementedError("prompt weights != 1 change the CFG formula (edit_strength); not on the native path")
     mc = c["model_conds"]
-    return mc["c_crossattn"].cond, (mc["y"].cond if "y" in mc else None)
+    return mc["c_crossattn"].cond, (mc["y"].cond if "y" in mc else None), (mc["guidance"].cond if "guidance" in mc else None)
 
 
 def calc_cond_uncond_batch(model, cond, uncond, x_in, timestep, model_options, cond_scale=1.0):

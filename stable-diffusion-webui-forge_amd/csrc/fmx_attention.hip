@@ -36,12 +36,14 @@ constexpr int KVB = 64;  // keys per tile
 template <int CPR>
 __device__ __forceinline__ int k_phys_chunk(int row, int c) {
   if (CPR == 8) return c ^ ((row >> 1) & 7);
+  if (CPR == 16) return c ^ (row & 15);
   if (CPR == 20) { int x = c + (row >> 2); return x >= 20 ? x - 20 : (x); }
   return c;
 }
 template <int CPR>
 __device__ __forceinline__ int k_logical_chunk(int row, int pc) {
   if (CPR == 8) return pc ^ ((row >> 1) & 7);
+  if (CPR == 16) return pc ^ (row & 15);
   if (CPR == 20) { int x = pc - ((row >> 2) % 20); return x < 0 ? x + 20 : x; }
   return pc;
 }
@@ -465,8 +467,9 @@ extern "C" int fmx_attention_f16(const fmx_attn_args* a, void* stream) {
       if (a->nq >= 256 && !force32) return launch_attn_q64(p, st);
       return launch_attn<64>(p, st);
     case 80: return launch_attn<80>(p, st);
+    case 128: return launch_attn<128>(p, st);
     case 160: return launch_attn<160>(p, st);
-    default: return fmx_set_error(FMX_E_UNSUPPORTED, "attention: dpad %d not in {48,64,80,160}", a->dpad);
+    default: return fmx_set_error(FMX_E_UNSUPPORTED, "attention: dpad %d not in {48,64,80,128,160}", a->dpad);
   }
 }
 

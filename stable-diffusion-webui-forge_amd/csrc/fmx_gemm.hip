@@ -185,17 +185,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
       const int mc = mok ? m : p.M - 1;
       const int img = mc / fe.per_img;
       if (!gg) {
-        f16x4 rv[NI], rs[NI];
+        f16x4 rv[NI], rs[NI], gt[NI];
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
           rv[j] = fe.rv4(img, nbs[j]);
           rs[j] = fe.res4(mc, nbs[j]);
+          gt[j] = fe.gate4(img, nbs[j]);
         }
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
           float v[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * fe.alpha + (float)bb[j][r] + (float)rv[j][r] + (float)rs[j][r];
+          for (int r = 0; r < 4; ++r)
+            v[r] = fe.act_gate(acc[i][j][r] * fe.alpha + (float)bb[j][r] + (float)rv[j][r], (float)gt[j][r]) + (float)rs[j][r];
           if (mok && nok[j]) fe.store4(m, nbs[j], v);
         }
       } else {
@@ -287,7 +289,7 @@ extern "C" int fmx_gemm_conv_f16(const fmx_gemm_args* a, void* stream) {
   FMX_REQUIRE(a->c1 == 0 || a->a1, "gemm: a1 missing");
   FMX_REQUIRE(a->kh == 1 || a->kh == 3, "gemm: kh must be 1 or 3");
   FMX_REQUIRE(a->n > 0 && a->h > 0 && a->w > 0 && a->oh > 0 && a->ow > 0 && a->nout > 0, "gemm: bad dims");
-  FMX_REQUIRE(a->act == FMX_ACT_NONE || (a->act == FMX_ACT_GEGLU && (a->nout % 32) == 0), "gemm: bad act/nout");
+  FMX_REQUIRE(a->act == FMX_ACT_NONE || a->act == FMX_ACT_GELU_TANH || (a->act == FMX_ACT_GEGLU && (a->nout % 32) == 0), "gemm: bad act/nout");
   GemmParams p;
   p.a0 = (const f16*)a->a0; p.a1 = (const f16*)a->a1;
   p.c0 = a->c0; p.c1 = a->c1;
@@ -304,6 +306,7 @@ extern "C" int fmx_gemm_conv_f16(const fmx_gemm_args* a, void* stream) {
   p.alpha = a->alpha; p.act = a->act;
   p.out = a->out; p.ld_out = a->ld_out; p.out_f32 = a->out_f32;
   p.zp = (const f16*)a->zero_page;
+  p.gate = (const f16*)a->gate; p.ld_gate = a->ld_gate;
   p.M = a->n * a->oh * a->ow;
   p.cpt = ctot / 64;
   p.kt = a->kh * a->kh * p.cpt;
@@ -311,6 +314,8 @@ extern "C" int fmx_gemm_conv_f16(const fmx_gemm_args* a, void* stream) {
   FMX_REQUIRE(fmx_aligned16(p.a0) && fmx_aligned16(p.wgt) && fmx_aligned16(p.zp) && (!p.a1 || fmx_aligned16(p.a1)), "gemm: operands must be 16-byte aligned");
   FMX_REQUIRE((p.s0 % 8) == 0 && (p.s1 % 8) == 0 && (p.ldw % 8) == 0, "gemm: strides must be multiples of 8 elements");
   FMX_REQUIRE((long)p.M * 1 > 0 && (long)a->n * a->oh * a->ow < (1L << 31), "gemm: M overflow");
+  FMX_REQUIRE((!a->gate && a->act != FMX_ACT_GELU_TANH) || FastEpilogue::eligible(p) || a->out_f32 < 0,
+              "gemm: gate / GELU-tanh need fp16 output and leading dimensions / nout multiples of 4 / 8");
   const bool conv = !(a->kh == 1 && p.stride == 1 && a->pad == 0 && a->up_h == 0 && a->oh == a->h && a->ow == a->w);
   hipStream_t st = (hipStream_t)stream;
   // tile choice: the largest tile that still gives >= 1.5 workgroups per CU (256 CUs); 64-wide N tiles

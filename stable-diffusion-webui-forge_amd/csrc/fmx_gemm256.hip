@@ -344,13 +344,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
         const bool mok = m < p.M;
         const int mc = mok ? m : p.M - 1;
         const int img = mc / ep.per_img;
-        f16x4 rv[2][4], rs[2][4];
+        f16x4 rv[2][4], rs[2][4], gt[2][4];
 #pragma unroll
         for (int qj = 0; qj < 2; ++qj)
 #pragma unroll
           for (int q4 = 0; q4 < 4; ++q4) {
             rv[qj][q4] = ep.rv4(img, nbs[qj][q4]);
             rs[qj][q4] = ep.res4(mc, nbs[qj][q4]);
+            gt[qj][q4] = ep.gate4(img, nbs[qj][q4]);
           }
 #pragma unroll
         for (int qj = 0; qj < 2; ++qj)
@@ -359,7 +360,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              v[r] = acc[qi][qj][f][q4 * 4 + r] * ep.alpha + (float)bb[qj][q4][r] + (float)rv[qj][q4][r] + (float)rs[qj][q4][r];
+              v[r] = ep.act_gate(acc[qi][qj][f][q4 * 4 + r] * ep.alpha + (float)bb[qj][q4][r] + (float)rv[qj][q4][r], (float)gt[qj][q4][r]) +
+                     (float)rs[qj][q4][r];
             if (mok && nok[qj][q4]) ep.store4(m, nbs[qj][q4], v);
           }
       }

@@ -24,6 +24,8 @@ struct GemmParams {
   int ld_out;
   int out_f32;
   const f16* zp;
+  const f16* gate;
+  int ld_gate;
   int M;            // n*oh*ow
   int kt;           // number of 64-wide K tiles = kh*kh*(c0+c1)/64
   int cpt;          // K tiles per tap = (c0+c1)/64
@@ -127,13 +129,20 @@ struct FastEpilogue {
   const f16* res;
   f16* out;
   long ld_rv, ld_res, ld_out;
-  int mb, mrv, mres;  // 1 when the operand exists, else 0
+  const f16* gate;
+  long ld_gt;
+  int mb, mrv, mres, mgt;  // 1 when the operand exists, else 0
+  bool gelu_tanh;
   int per_img, nout, ncols;
   float alpha;
   __device__ __forceinline__ explicit FastEpilogue(const GemmParams& p) {
     mb = p.bias ? 1 : 0;
     mrv = p.rowvec ? 1 : 0;
     mres = p.residual ? 1 : 0;
+    mgt = p.gate ? 1 : 0;
+    gate = p.gate ? p.gate : p.zp;
+    ld_gt = (long)p.ld_gate * mgt;
+    gelu_tanh = p.act == FMX_ACT_GELU_TANH;
     bias = p.bias ? p.bias : p.zp;
     rowvec = p.rowvec ? p.rowvec : p.zp;
     res = p.residual ? p.residual : p.zp;
@@ -147,11 +156,17 @@ struct FastEpilogue {
     alpha = p.alpha;
   }
   static __host__ __device__ __forceinline__ bool eligible(const GemmParams& p) {
-    return !p.out_f32 && (p.ld_out & 3) == 0 && (p.ld_res & 3) == 0 && (p.ld_rowvec & 3) == 0 && (p.nout & 7) == 0;
+    return !p.out_f32 && (p.ld_out & 3) == 0 && (p.ld_res & 3) == 0 && (p.ld_rowvec & 3) == 0 && (p.ld_gate & 3) == 0 && (p.nout & 7) == 0;
   }
   // nb / col are multiples of 4; callers clamp them into range for the loads and predicate the store
   __device__ __forceinline__ f16x4 bias4(int nb) const { return *reinterpret_cast<const f16x4*>(bias + nb * mb); }
   __device__ __forceinline__ f16x4 rv4(int img, int nb) const { return *reinterpret_cast<const f16x4*>(rowvec + img * ld_rv + nb * mrv); }
+  __device__ __forceinline__ f16x4 gate4(int img, int nb) const { return *reinterpret_cast<const f16x4*>(gate + img * ld_gt + nb * mgt); }
+  // act (GELU-tanh when selected) then the optional gate: absent gate reads zeros -> factor 1
+  __device__ __forceinline__ float act_gate(float v, float gt) const {
+    if (gelu_tanh) v = gelu_tanh_f(v);
+    return v * fmaf((float)mgt, gt - 1.0f, 1.0f);
+  }
   __device__ __forceinline__ f16x4 res4(int m, int col) const { return *reinterpret_cast<const f16x4*>(res + m * ld_res + col * mres); }
   __device__ __forceinline__ void store4(int m, int col, const float (&v)[4]) const {
     f16x4 hv;

@@ -184,9 +184,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
 }
 
 // ---- LayerNorm: one wave per row, row kept in registers, exact two-pass mean/variance in fp32 -----------------
-template <int MAXOCT>  // octets per lane
+// MOD = false: y = LN(x) * gamma + beta.   MOD = true (Flux adaLN, backend/nn/flux.py:209-210,286,326): LN has no affine and
+// y = (1 + scale[b]) * LN(x) + shift[b] with per-batch vectors gamma := scale + b*ld_mod, beta := shift + b*ld_mod, b = row / rows_per_b.
+template <int MAXOCT, bool MOD>  // octets per lane
 __global__ __launch_bounds__(256) void ln_kernel(const f16* __restrict__ x, const f16* __restrict__ gamma,
-                                                  const f16* __restrict__ beta, f16* __restrict__ y, long rows, int c, float eps) {
+                                                  const f16* __restrict__ beta, f16* __restrict__ y, long rows, int c, float eps,
+                                                  long rows_per_b, long ld_mod) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -218,15 +221,16 @@ __global__ __launch_bounds__(256) void ln_kernel(const f16* __restrict__ x, cons
   }
   const float rstd = rsqrtf(wave_sum(q) / (float)c + eps);
   f16* yr = y + row * c;
+  const long moff = MOD ? (row / rows_per_b) * ld_mod : 0;
 #pragma unroll
   for (int j = 0; j < MAXOCT; ++j) {
     const int o = lane + j * 64;
     if (o < oct) {
-      const f16x8 g = *reinterpret_cast<const f16x8*>(gamma + o * 8);
-      const f16x8 b = *reinterpret_cast<const f16x8*>(beta + o * 8);
+      const f16x8 g = *reinterpret_cast<const f16x8*>(gamma + moff + o * 8);
+      const f16x8 b = *reinterpret_cast<const f16x8*>(beta + moff + o * 8);
       f16x8 r;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) r[e] = (f16)(((float)v[j][e] - mean) * rstd * (float)g[e] + (float)b[e]);
+      for (int e = 0; e < 8; ++e) r[e] = (f16)(((float)v[j][e] - mean) * rstd * ((MOD ? 1.0f : 0.0f) + (float)g[e]) + (float)b[e]);
       *reinterpret_cast<f16x8*>(yr + o * 8) = r;
     }
   }
@@ -266,18 +270,35 @@ extern "C" int fmx_groupnorm_apply_f16(const void* x0, const void* x1, int32_t c
   return FMX_OK;
 }
 
+template <bool MOD>
+static int launch_ln(const void* x, const void* gamma, const void* beta, void* y, int64_t rows, int32_t c, float eps, long rows_per_b,
+                     long ld_mod, void* stream, const char* name) {
+  const long blocks = (rows + 3) / 4;
+  if (blocks >= (1L << 31)) return fmx_set_error(FMX_E_BADARG, "%s: too many rows", name);
+  hipStream_t st = (hipStream_t)stream;
+  const int oct = c >> 3;
+#define FMX_LN(MO)                                                                                                              \
+  hipLaunchKernelGGL((ln_kernel<MO, MOD>), dim3((unsigned)blocks), dim3(256), 0, st, (const f16*)x, (const f16*)gamma, (const f16*)beta, \
+                     (f16*)y, (long)rows, c, eps, rows_per_b, ld_mod)
+  if (oct <= 64) FMX_LN(1);
+  else if (oct <= 128) FMX_LN(2);
+  else if (oct <= 192) FMX_LN(3);
+  else FMX_LN(8);
+#undef FMX_LN
+  FMX_LAUNCH_CHECK(name);
+  return FMX_OK;
+}
+
 extern "C" int fmx_layernorm_f16(const void* x, const void* gamma, const void* beta, void* y, int64_t rows, int32_t c,
                                  float eps, void* stream) {
   FMX_REQUIRE(x && gamma && beta && y && rows > 0 && c > 0 && (c % 8) == 0 && c <= 4096, "layernorm: bad args");
   FMX_REQUIRE(fmx_aligned16(x) && fmx_aligned16(y) && fmx_aligned16(gamma) && fmx_aligned16(beta), "layernorm: alignment");
-  const long blocks = (rows + 3) / 4;
-  FMX_REQUIRE(blocks < (1L << 31), "layernorm: too many rows");
-  hipStream_t st = (hipStream_t)stream;
-  const int oct = c >> 3;
-  if (oct <= 64) hipLaunchKernelGGL(ln_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, (const f16*)x, (const f16*)gamma, (const f16*)beta, (f16*)y, (long)rows, c, eps);
-  else if (oct <= 128) hipLaunchKernelGGL(ln_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, (const f16*)x, (const f16*)gamma, (const f16*)beta, (f16*)y, (long)rows, c, eps);
-  else if (oct <= 192) hipLaunchKernelGGL(ln_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, st, (const f16*)x, (const f16*)gamma, (const f16*)beta, (f16*)y, (long)rows, c, eps);
-  else hipLaunchKernelGGL(ln_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, st, (const f16*)x, (const f16*)gamma, (const f16*)beta, (f16*)y, (long)rows, c, eps);
-  FMX_LAUNCH_CHECK("fmx_layernorm_f16");
-  return FMX_OK;
+  return launch_ln<false>(x, gamma, beta, y, rows, c, eps, 1, 0, stream, "fmx_layernorm_f16");
+}
+
+extern "C" int fmx_layernorm_mod_f16(const void* x, const void* scale, const void* shift, int64_t ld_mod, int64_t rows_per_batch,
+                                     void* y, int64_t rows, int32_t c, float eps, void* stream) {
+  FMX_REQUIRE(x && scale && shift && y && rows > 0 && rows_per_batch > 0 && c > 0 && (c % 8) == 0 && c <= 4096, "layernorm_mod: bad args");
+  FMX_REQUIRE(fmx_aligned16(x) && fmx_aligned16(y) && fmx_aligned16(scale) && fmx_aligned16(shift) && (ld_mod % 8) == 0, "layernorm_mod: alignment");
+  return launch_ln<true>(x, scale, shift, y, rows, c, eps, rows_per_batch, ld_mod, stream, "fmx_layernorm_mod_f16");
 }

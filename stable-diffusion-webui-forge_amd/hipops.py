@@ -14,7 +14,7 @@ import torch
 from . import _lib
 from ._lib import AttnArgs, GemmArgs
 
-ACT_NONE, ACT_GEGLU = 0, 1
+ACT_NONE, ACT_GEGLU, ACT_GELU_TANH = 0, 1, 2
 
 _zero_pages = {}
 _alloc = None  # callable(shape, dtype) -> tensor ; set by runtime.Arena
@@ -107,10 +107,10 @@ def _check_f16(*ts):
 
 def conv_gemm(x, wgt, nout, *, x1=None, n=None, h=None, w=None, kh=1, stride=1, pad=0, up=None, bias=None,
               rowvec=None, residual=None, act=ACT_NONE, alpha=1.0, out=None, ld_out=None, out_dtype=torch.float16,
-              ldw=0, force_tile=0):
+              ldw=0, force_tile=0, gate=None):
     """OUT[M, ncols] = epilogue(A (*) W^T).  x: [N,H,W,C0] (or [M,C0] with kh == 1); x1: optional second source
     concatenated along channels; wgt: [nout, kh*kh*(C0+C1)]; up=(UH, UW): nearest-resize before the conv."""
-    _check_f16(x, x1, wgt, bias, rowvec, residual)
+    _check_f16(x, x1, wgt, bias, rowvec, residual, gate)
     if x.dim() == 2:
         n_, h_, w_ = 1, 1, x.shape[0]
     else:
@@ -144,6 +144,8 @@ def conv_gemm(x, wgt, nout, *, x1=None, n=None, h=None, w=None, kh=1, stride=1, 
     a.out, a.ld_out = _p(out), ld_out
     a.out_f32 = -force_tile if force_tile else (1 if out.dtype == torch.float32 else 0)
     a.zero_page = _p(zero_page(x.device))
+    a.gate = _p(gate)
+    a.ld_gate = gate.stride(0) if gate is not None else 0
     if _profiler is not None:
         flops = 2.0 * m * nout * kh * kh * (c0 + c1)
         _profiler.launch("gemm_conv", flops, lambda: _lib.check(_lib.lib().fmx_gemm_conv_f16(C.byref(a), stream_ptr()), "fmx_gemm_conv_f16"))
@@ -225,6 +227,28 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None):
         out = empty(x.shape, torch.float16, x.device)
     _lib.check(_lib.lib().fmx_layernorm_f16(_p(x), _p(gamma), _p(beta), _p(out), rows, c, float(eps), stream_ptr()), "fmx_layernorm_f16")
     return out
+
+
+def layernorm_mod(x, scale, shift, rows_per_batch, eps=1e-6, out=None):
+    """Flux adaLN: (1 + scale[b]) * LayerNorm(x, no affine) + shift[b]; scale/shift: [B, c] views with a common row stride."""
+    _check_f16(x, scale, shift)
+    c = x.shape[-1]
+    rows = x.numel() // c
+    assert scale.stride(0) == shift.stride(0) and scale.stride(-1) == 1 and shift.stride(-1) == 1
+    if out is None:
+        out = empty(x.shape, torch.float16, x.device)
+    _lib.check(_lib.lib().fmx_layernorm_mod_f16(_p(x), _p(scale), _p(shift), scale.stride(0), rows_per_batch, _p(out), rows, c, float(eps),
+                                                stream_ptr()), "fmx_layernorm_mod_f16")
+    return out
+
+
+def flux_qk_norm_rope(qkv, q_scale, k_scale, pe, q_out, k_out, vt_out, *, batch, tokens, heads, head_dim, row_off, l_pad, eps=1e-6):
+    """qkv: [batch*tokens, >= 3*heads*head_dim] (row stride = qkv.stride(0)); pe: fp32 [L_total, head_dim/2, 2] (cos, sin)."""
+    _check_f16(qkv, q_scale, k_scale, q_out, k_out, vt_out)
+    assert pe.dtype == torch.float32 and pe.is_contiguous()
+    _lib.check(_lib.lib().fmx_flux_qk_norm_rope_f16(_p(qkv), qkv.stride(0), _p(q_scale), _p(k_scale), _p(pe), _p(q_out), _p(k_out), _p(vt_out),
+                                                    batch, tokens, heads, head_dim, row_off, l_pad, float(eps), stream_ptr()),
+               "fmx_flux_qk_norm_rope_f16")
 
 
 def timestep_embedding(t, dim, max_period=10000.0, out=None):

@@ -95,7 +95,7 @@ def process_images_inner(p) -> Processed:
     total = p.batch_size * p.n_iter
     p.all_seeds = [seed + i for i in range(total)]  # :894 (no subseed strength)
     dev = p.sd_model.device
-    lc = p.sd_model.forge_objects.vae.latent_channels if p.sd_model.forge_objects.vae is not None else 4
+    lc = p.sd_model.forge_objects.vae.latent_channels if p.sd_model.forge_objects.vae is not None else getattr(p.sd_model, "latent_channels", 4)
     images, lat_all, dec_all = [], [], []
     shared.state.interrupted = False
     for n in range(p.n_iter):

@@ -22,6 +22,13 @@ sampler_extra_params = {"sample_euler": ["s_churn", "s_tmin", "s_tmax", "s_noise
 # modules/sd_schedulers.py:211-228 (the two schedules the table above uses; "Automatic" -> sampler default)
 k_diffusion_scheduler = {"karras": kd_sampling.get_sigmas_karras, "exponential": kd_sampling.get_sigmas_exponential}
 
+
+def simple_scheduler(n, sigma_min, sigma_max, inner_model, device):
+    """modules/sd_schedulers.py:81-87 ('Simple', the schedule Forge pairs with Flux)."""
+    ss = len(inner_model.sigmas) / n
+    sigs = [float(inner_model.sigmas[-(1 + int(x * ss))]) for x in range(n)] + [0.0]
+    return torch.FloatTensor(sigs).to(device)
+
 samplers_data_k_diffusion = [
     sd_samplers_common.SamplerData(label, lambda model, funcname=funcname: KDiffusionSampler(funcname, model), aliases, options)
     for label, funcname, aliases, options in samplers_k_diffusion
@@ -65,6 +72,8 @@ class KDiffusionSampler(sd_samplers_common.Sampler):
         sigma_min, sigma_max = (0.1, 10) if opts.use_old_karras_scheduler_sigmas else (m_min, m_max)
         if getattr(p, "sampler_noise_scheduler_override", None):
             sigmas = p.sampler_noise_scheduler_override(steps)
+        elif (scheduler_name or "").lower() == "simple":
+            sigmas = simple_scheduler(steps, sigma_min, sigma_max, self.model_wrap, "cpu")
         elif fn is None:
             sigmas = self.model_wrap.get_sigmas(steps)
         else:

@@ -18,7 +18,7 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
-from .backend.nn.layout import unet_param_shapes, vae_decoder_param_shapes
+from .backend.nn.layout import flux_param_shapes, unet_param_shapes, vae_decoder_param_shapes
 
 # LDM-style unet_config dicts (parameter counts 859.52 M / 2567.46 M verified against
 # the reference module in tests/test_oracle_vs_reference.py).
@@ -56,6 +56,13 @@ TINY_VAE_CONFIG = dict(in_channels=3, out_channels=3, block_out_channels=(64, 12
                        latent_channels=4, scaling_factor=0.18215, shift_factor=0.0,
                        use_quant_conv=True, use_post_quant_conv=True)
 
+# Flux.1-dev (backend/huggingface/black-forest-labs/FLUX.1-dev/transformer/config.json) and a tiny twin with the
+# same head_dim 128 / axes_dim split (the RoPE table and attention tile shapes are the real ones)
+FLUX_DEV_CONFIG = dict(in_channels=16, vec_in_dim=768, context_in_dim=4096, hidden_size=3072, mlp_ratio=4.0, num_heads=24, depth=19,
+                       depth_single_blocks=38, axes_dim=[16, 56, 56], theta=10000, qkv_bias=True, guidance_embed=True)
+TINY_FLUX_CONFIG = dict(in_channels=16, vec_in_dim=64, context_in_dim=128, hidden_size=256, mlp_ratio=4.0, num_heads=2, depth=2,
+                        depth_single_blocks=2, axes_dim=[16, 56, 56], theta=10000, qkv_bias=True, guidance_embed=True)
+
 SCHEDULE = dict(beta_schedule="linear", linear_start=0.00085, linear_end=0.012, timesteps=1000,
                 prediction_type="epsilon")
 
@@ -74,7 +81,7 @@ def synth_tensor(name, shape, seed=0, gain=DEFAULT_GAIN):
     rng = np.random.Generator(np.random.PCG64([seed, zlib.crc32(name.encode())]))
     z = rng.standard_normal(shape, dtype=np.float32)
     if _is_norm(name, shape):
-        if name.endswith(".weight"):
+        if name.endswith((".weight", ".scale")):
             z = 1.0 + 0.1 * z
         else:
             z = 0.1 * z
@@ -114,6 +121,10 @@ def synth_unet_state_dict(cfg, seed=0, **kw):
     return synth_state_dict(unet_param_shapes(cfg), seed=seed, **kw)
 
 
+def synth_flux_state_dict(cfg, seed=2, **kw):
+    return synth_state_dict(flux_param_shapes(cfg), seed=seed, **kw)
+
+
 def synth_vae_decoder_state_dict(cfg, seed=1, **kw):
     return synth_state_dict(vae_decoder_param_shapes(cfg), seed=seed, **kw)
 
@@ -138,7 +149,7 @@ def synth_state_dict_device(shapes, seed, device, dtype=torch.float16, gain=DEFA
     for name, shape in shapes.items():
         z = torch.randn(shape, generator=g, device=device, dtype=torch.float32)
         if _is_norm(name, shape):
-            z = 1.0 + 0.1 * z if name.endswith(".weight") else 0.1 * z
+            z = 1.0 + 0.1 * z if name.endswith((".weight", ".scale")) else 0.1 * z
         else:
             wshape = shapes[name[:-5] + ".weight"] if name.endswith(".bias") else shape
             z = z * (gain / float(np.sqrt(int(np.prod(wshape[1:])))))

@@ -9,7 +9,7 @@ import torch
 
 import forge_amd  # noqa: F401
 from forge_amd import synth
-from forge_amd.backend.nn.layout import unet_param_shapes, vae_decoder_param_shapes
+from forge_amd.backend.nn.layout import flux_param_shapes, unet_param_shapes, vae_decoder_param_shapes
 from oracle import pipeline, sampling
 from oracle.k_prediction import Predictor
 from oracle.rng import PhiloxGenerator
@@ -105,3 +105,28 @@ def test_cfg_scale_one_shortcut():
     c, uc = synth.synth_conditioning(2, cfg["context_dim"], None, seed=1234)
     lat, _ = pipeline.txt2img_latents(sd, cfg, c, uc, g["seeds"], 128, 128, 3, sampler_name="Euler", cfg_scale=1.0)
     assert max_rel(lat, g["Euler_cfg1"]["latent"]) < 2e-4
+
+
+# ---- Flux ---------------------------------------------------------------------------------------
+def test_flux_param_shapes_match_reference():
+    ref = json.load(open(os.path.join(GOLDEN, "param_shapes.json")))
+    for name, cfg in (("tiny_flux", synth.TINY_FLUX_CONFIG), ("flux_dev", synth.FLUX_DEV_CONFIG)):
+        ours = {k: list(v) for k, v in flux_param_shapes(cfg).items()}
+        assert ours == ref[name], name
+
+
+def test_flux_forward_and_sampler_restated():
+    from oracle import flux as oflux
+    g = load_golden("tiny_flux_fwd.pt")
+    cfg = synth.TINY_FLUX_CONFIG
+    sd = synth.synth_flux_state_dict(cfg, seed=2)
+    out = oflux.flux_forward(sd, cfg, g["x"], g["t"], g["ctx"], g["y"], g["guidance"])
+    torch.testing.assert_close(out, g["out"], rtol=1e-4, atol=1e-5)
+    h, w = g["hw"]
+    table = oflux.flux_sigma_table(seq_len=(h // 2) * (w // 2))
+    torch.testing.assert_close(table.float(), g["sigma_table"], rtol=1e-6, atol=1e-7)
+    sigmas = oflux.flux_sigmas_simple(4, g["sigma_table"])
+    torch.testing.assert_close(sigmas, g["sigmas"], rtol=0, atol=0)
+    xs = sigmas[0] * g["noise"]  # noise_scaling for 'const' with a zero latent (k_prediction.py:94-96)
+    lat = oflux.flux_sample_euler(sd, cfg, xs, sigmas, g["ctx"], g["y"], g["guidance"])
+    assert max_rel(lat, g["latent"]) < 2e-4
