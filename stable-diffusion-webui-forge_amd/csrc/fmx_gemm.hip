@@ -331,19 +331,29 @@ extern "C" int fmx_gemm_conv_f16(const fmx_gemm_args* a, void* stream) {
     const long t256 = tiles(256, 256);
     const long rounds = (t256 + 255) / 256;
     const double util = (double)p.M * (double)p.nout / ((double)rounds * 256.0 * 65536.0);
-    if (FastEpilogue::eligible(p) && p.nout >= 256 && p.M >= 256 && util >= 0.8 && p.kt >= 8) sel = 3;
+    if (FastEpilogue::eligible8(p) && p.nout >= 256 && p.M >= 256 && util >= 0.8 && p.kt >= 8) sel = 3;
   }
   // the 256x256 kernel addresses both operands with 32-bit element offsets
   const double a_span = (double)a->n * a->h * a->w * (double)(p.s0 > p.s1 ? p.s0 : p.s1);
   const double w_span = (double)p.nout * p.ldw;
   const bool fits32 = a_span < 4.0e9 && w_span < 4.0e9;
   if (!fits32 && sel == 3) sel = n128 ? 0 : 1;
-  if (a->out_f32 < 0) sel = (-a->out_f32 - 1) % 4;  // test hook: force a tile shape (out_f32 = -1..-4 -> fp16 out)
+  // 128x160 tiles: SD-family channel counts are multiples of 320, so N = 320 k splits into 160-wide tiles with no padding
+  // columns, and (M, N) = (16384, 1280) / (65536, 640) become exactly 2 / 4 rounds of the 512 resident workgroups
+  // (128x128: 2.5 / 5 rounds).  Odd fragment count per wave along N -> not for GEGLU (value | gate fragment pairs).
+  if (sel != 3 && a->act != FMX_ACT_GEGLU && (p.nout % 160) == 0 && p.M >= 128) {
+    auto rounds = [&](int bm, int bn, int slots) { return (double)((tiles(bm, bn) + slots - 1) / slots) * bm * bn; };
+    const double c160 = rounds(128, 160, 512) / 1.0, c128 = rounds(128, 128, 512) / 1.0;
+    if (sel == 0 ? c160 < c128 : (p.nout % 128) != 0 && tiles(128, 160) >= 256) sel = 4;
+  }
+  if (a->out_f32 < 0) sel = (-a->out_f32 - 1) % 5;  // test hook: force a tile shape (out_f32 = -1..-5 -> fp16 out)
+  FMX_REQUIRE(sel != 4 || a->act != FMX_ACT_GEGLU, "gemm: the 128x160 tile does not support GEGLU");
   if (a->out_f32 < 0) p.out_f32 = 0;
   if (sel == 3) {
-    FMX_REQUIRE(FastEpilogue::eligible(p) && fits32, "gemm: 256x256 kernel needs fp16 output, leading dimensions / nout multiples of 4 / 8, operands < 2^32 elements");
+    FMX_REQUIRE(FastEpilogue::eligible8(p) && fits32, "gemm: 256x256 kernel needs fp16 output, 16-byte aligned epilogue operands, leading dimensions / nout multiples of 8, operands < 2^32 elements");
     return fmx_launch_gemm256(p, conv, st);
   }
+  if (sel == 4) return conv ? launch<128, 160, true>(p, st) : launch<128, 160, false>(p, st);
   if (conv) {
     if (sel == 0) return launch<128, 128, true>(p, st);
     if (sel == 1) return launch<128, 64, true>(p, st);

@@ -318,23 +318,42 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     }
     return;
   }
-  // ---- epilogue: lane = pixel (li), registers = 4 runs of 4 consecutive channels per 32x32 fragment.  Only the
-  //      branch-free FastEpilogue form is implemented here (the dispatcher checks FastEpilogue::eligible). -----------------
+  // ---- epilogue.  The MFMA leaves lane (li, hi) with 4 runs (q4) of 4 consecutive channels  q4*8 + hi*4 + [0,4)  of
+  //      pixel li.  One v_permlane32_swap per accumulator pair (q4 even <-> q4 odd) turns that into 2 runs of 8
+  //      consecutive channels  (2*pp + hi)*8 + [0,8)  per fragment, so every epilogue load / store is 16 bytes per lane:
+  //      half the memory instructions of the 8-byte form (the tile's store tail is issue-bound: 12 us per round of
+  //      256 tiles at 32 dwordx2 stores per lane, measured with the mainloop ablated).  Only the branch-free
+  //      FastEpilogue form is implemented here (the dispatcher checks FastEpilogue::eligible8). ---------------------------
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float x = acc[a][b][f][pp * 8 + r], y = acc[a][b][f][pp * 8 + 4 + r];
+            swap_halfwaves(x, y);
+            acc[a][b][f][pp * 8 + r] = x;
+            acc[a][b][f][pp * 8 + 4 + r] = y;
+          }
   const FastEpilogue ep(p);
   const bool geglu = p.act == FMX_ACT_GEGLU;
   if (!geglu) {
-    // bias for this lane's 8 column groups, loaded once
-    int nbs[2][4];
-    bool nok[2][4];
-    f16x4 bb[2][4];
+    // bias for this lane's 4 column groups, loaded once
+    int nbs[2][2];
+    bool nok[2][2];
+    f16x8 bb[2][2];
 #pragma unroll
     for (int qj = 0; qj < 2; ++qj)
 #pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        const int nb = n0 + qj * 128 + wc * 32 + q4 * 8 + hi * 4;
-        nok[qj][q4] = nb < ep.nout;
-        nbs[qj][q4] = nok[qj][q4] ? nb : 0;
-        bb[qj][q4] = ep.bias4(nbs[qj][q4]);
+      for (int pp = 0; pp < 2; ++pp) {
+        const int nb = n0 + qj * 128 + wc * 32 + (2 * pp + hi) * 8;
+        nok[qj][pp] = nb < ep.nout;
+        nbs[qj][pp] = nok[qj][pp] ? nb : 0;
+        bb[qj][pp] = ep.bias8(nbs[qj][pp]);
       }
 #pragma unroll
     for (int qi = 0; qi < 2; ++qi)
@@ -344,42 +363,41 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
         const bool mok = m < p.M;
         const int mc = mok ? m : p.M - 1;
         const int img = mc / ep.per_img;
-        f16x4 rv[2][4], rs[2][4], gt[2][4];
+        f16x8 rv[2][2], rs[2][2], gt[2][2];
 #pragma unroll
         for (int qj = 0; qj < 2; ++qj)
 #pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) {
-            rv[qj][q4] = ep.rv4(img, nbs[qj][q4]);
-            rs[qj][q4] = ep.res4(mc, nbs[qj][q4]);
-            gt[qj][q4] = ep.gate4(img, nbs[qj][q4]);
+          for (int pp = 0; pp < 2; ++pp) {
+            rv[qj][pp] = ep.rv8(img, nbs[qj][pp]);
+            rs[qj][pp] = ep.res8(mc, nbs[qj][pp]);
+            gt[qj][pp] = ep.gate8(img, nbs[qj][pp]);
           }
 #pragma unroll
         for (int qj = 0; qj < 2; ++qj)
 #pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) {
-            float v[4];
+          for (int pp = 0; pp < 2; ++pp) {
+            float v[8];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-              v[r] = ep.act_gate(acc[qi][qj][f][q4 * 4 + r] * ep.alpha + (float)bb[qj][q4][r] + (float)rv[qj][q4][r], (float)gt[qj][q4][r]) +
-                     (float)rs[qj][q4][r];
-            if (mok && nok[qj][q4]) ep.store4(m, nbs[qj][q4], v);
+            for (int r = 0; r < 8; ++r)
+              v[r] = ep.act_gate(acc[qi][qj][f][pp * 8 + r] * ep.alpha + (float)bb[qj][pp][r] + (float)rv[qj][pp][r], (float)gt[qj][pp][r]) +
+                     (float)rs[qj][pp][r];
+            if (mok && nok[qj][pp]) ep.store8(m, nbs[qj][pp], v);
           }
       }
   } else {
-    // weight rows are interleaved [16 value | 16 gate]: register groups 0,1 of a fragment are values, 2,3 their gates
-    int nbs[2][2];
-    bool nok[2][2];
-    f16x4 bv[2][2], bg[2][2];
+    // weight rows are interleaved [16 value | 16 gate]: after the swap, registers 0..7 of a fragment are the values of
+    // columns hi*8 + [0,8) and registers 8..15 their gates
+    int nbs[2];
+    bool nok[2];
+    f16x8 bv[2], bg[2];
 #pragma unroll
-    for (int qj = 0; qj < 2; ++qj)
-#pragma unroll
-      for (int q4 = 0; q4 < 2; ++q4) {
-        const int nb = n0 + qj * 128 + wc * 32 + q4 * 8 + hi * 4;
-        nok[qj][q4] = nb < ep.nout;
-        nbs[qj][q4] = nok[qj][q4] ? nb : 0;
-        bv[qj][q4] = ep.bias4(nbs[qj][q4]);
-        bg[qj][q4] = ep.bias4(nbs[qj][q4] + 16);
-      }
+    for (int qj = 0; qj < 2; ++qj) {
+      const int nb = n0 + qj * 128 + wc * 32 + hi * 8;
+      nok[qj] = nb < ep.nout;
+      nbs[qj] = nok[qj] ? nb : 0;
+      bv[qj] = ep.bias8(nbs[qj]);
+      bg[qj] = ep.bias8(nbs[qj] + 16);
+    }
 #pragma unroll
     for (int qi = 0; qi < 2; ++qi)
 #pragma unroll
@@ -389,22 +407,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
         const int mc = mok ? m : p.M - 1;
         const int img = mc / ep.per_img;
 #pragma unroll
-        for (int qj = 0; qj < 2; ++qj)
+        for (int qj = 0; qj < 2; ++qj) {
+          const int nb = nbs[qj];
+          const int col = ((n0 + qj * 128 + wc * 32) >> 1) + hi * 8;
+          const int colc = nok[qj] ? col : 0;
+          const f16x8 rvv = ep.rv8(img, nb), rvg = ep.rv8(img, nb + 16), rs = ep.res8(mc, colc);
+          float v[8];
 #pragma unroll
-          for (int q4 = 0; q4 < 2; ++q4) {
-            const int nb = nbs[qj][q4];
-            const int col = ((n0 + qj * 128 + wc * 32) >> 1) + q4 * 8 + hi * 4;
-            const int colc = nok[qj][q4] ? col : 0;
-            const f16x4 rvv = ep.rv4(img, nb), rvg = ep.rv4(img, nb + 16), rs = ep.res4(mc, colc);
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float val = acc[qi][qj][f][q4 * 4 + r] * ep.alpha + (float)bv[qj][q4][r] + (float)rvv[r];
-              const float gate = acc[qi][qj][f][q4 * 4 + 8 + r] * ep.alpha + (float)bg[qj][q4][r] + (float)rvg[r];
-              v[r] = val * gelu_erf_f(gate) + (float)rs[r];
-            }
-            if (mok && nok[qj][q4]) ep.store4(m, col, v);
+          for (int r = 0; r < 8; ++r) {
+            const float val = acc[qi][qj][f][r] * ep.alpha + (float)bv[qj][r] + (float)rvv[r];
+            const float gate = acc[qi][qj][f][8 + r] * ep.alpha + (float)bg[qj][r] + (float)rvg[r];
+            v[r] = val * gelu_erf_f(gate) + (float)rs[r];
           }
+          if (mok && nok[qj]) ep.store8(m, col, v);
+        }
       }
   }
 }

@@ -174,7 +174,33 @@ struct FastEpilogue {
     for (int r = 0; r < 4; ++r) hv[r] = (f16)v[r];
     *reinterpret_cast<f16x4*>(out + m * ld_out + col) = hv;
   }
+  // 8-wide (16-byte) forms for kernels whose lanes own 8 consecutive columns (after a v_permlane32_swap of the MFMA
+  // accumulators): half the store / load instructions of the 4-wide forms -- the epilogue of a 256x256 tile is
+  // store-ISSUE-bound, not bandwidth-bound.  Need eligible8(): every leading dimension a multiple of 8, 16-byte bases.
+  static inline bool eligible8(const GemmParams& p) {
+    return eligible(p) && (p.ld_out & 7) == 0 && (p.ld_res & 7) == 0 && (p.ld_rowvec & 7) == 0 && (p.ld_gate & 7) == 0 &&
+           fmx_aligned16(p.out) && fmx_aligned16(p.bias) && fmx_aligned16(p.rowvec) && fmx_aligned16(p.residual) && fmx_aligned16(p.gate);
+  }
+  __device__ __forceinline__ f16x8 bias8(int nb) const { return *reinterpret_cast<const f16x8*>(bias + nb * mb); }
+  __device__ __forceinline__ f16x8 rv8(int img, int nb) const { return *reinterpret_cast<const f16x8*>(rowvec + img * ld_rv + nb * mrv); }
+  __device__ __forceinline__ f16x8 gate8(int img, int nb) const { return *reinterpret_cast<const f16x8*>(gate + img * ld_gt + nb * mgt); }
+  __device__ __forceinline__ f16x8 res8(int m, int col) const { return *reinterpret_cast<const f16x8*>(res + m * ld_res + col * mres); }
+  __device__ __forceinline__ void store8(int m, int col, const float (&v)[8]) const {
+    f16x8 hv;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) hv[r] = (f16)v[r];
+    *reinterpret_cast<f16x8*>(out + m * ld_out + col) = hv;
+  }
 };
+
+// v_permlane32_swap on a pair of fp32 registers: afterwards lanes 0-31 hold {a.lo, a.hi} and lanes 32-63 {b.lo, b.hi}
+// in (a, b), i.e. the upper half-wave of `a` and the lower half-wave of `b` trade places.
+__device__ __forceinline__ void swap_halfwaves(float& a, float& b) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
 
 // 256x256-tile kernel (fmx_gemm256.hip)
 int fmx_launch_gemm256(const GemmParams& p, bool conv, hipStream_t st);

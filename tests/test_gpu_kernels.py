@@ -31,7 +31,7 @@ def close(got, want, rtol, atol, what=""):
 
 # ----------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("m,n,k", [(256, 256, 128), (384, 320, 320), (77 * 2, 640, 768), (1000, 132, 64), (4096, 1280, 1280), (130, 4, 2880)])
-@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])
 def test_linear_plain(m, n, k, tile):
     if tile == 4 and n % 8:
         pytest.skip("256x256 kernel needs nout % 8 == 0 (dispatcher never selects it otherwise)")
@@ -100,7 +100,7 @@ def test_linear_two_source_and_vt():
     dict(n=2, h=16, w=16, c=128, co=4, kh=3, stride=1, pad=1),
     dict(n=2, h=12, w=12, c=64, co=128, kh=1, stride=1, pad=0),
 ])
-@pytest.mark.parametrize("tile", [0, 3, 4])
+@pytest.mark.parametrize("tile", [0, 3, 4, 5])
 def test_conv(cfg, tile):
     if tile == 4 and cfg["co"] % 8:
         pytest.skip("256x256 kernel needs nout % 8 == 0")
