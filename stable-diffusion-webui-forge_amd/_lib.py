@@ -11,7 +11,8 @@ import subprocess
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfmx_gfx950.so")
+# FMX_LIB: developer hook for tools/ (timing-ablation builds of the same library); the product path never sets it
+LIB_PATH = os.environ.get("FMX_LIB") or os.path.join(_HERE, "libfmx_gfx950.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 _lock = threading.Lock()

@@ -333,10 +333,15 @@ extern "C" int fmx_gemm_conv_f16(const fmx_gemm_args* a, void* stream) {
     const double util = (double)p.M * (double)p.nout / ((double)rounds * 256.0 * 65536.0);
     if (FastEpilogue::eligible8(p) && p.nout >= 256 && p.M >= 256 && util >= 0.8 && p.kt >= 8) sel = 3;
   }
-  // the 256x256 kernel addresses both operands with 32-bit element offsets
-  const double a_span = (double)a->n * a->h * a->w * (double)(p.s0 > p.s1 ? p.s0 : p.s1);
-  const double w_span = (double)p.nout * p.ldw;
-  const bool fits32 = a_span < 4.0e9 && w_span < 4.0e9;
+  // the 256x256 kernel addresses its operands through buffer descriptors with 32-bit byte offsets; offsets >= 0xC0000000
+  // are its "load zeros" marker, so every operand must span less than that
+  const double npix = (double)a->n * a->h * a->w;
+  const double a0_span = ((npix - 1) * p.s0 + p.c0) * 2.0, a1_span = p.c1 ? ((npix - 1) * p.s1 + p.c1) * 2.0 : 16.0;
+  const double w_span = ((double)(p.nout - 1) * p.ldw + (double)a->kh * a->kh * ctot) * 2.0;
+  const bool fits32 = a0_span < 3.0e9 && a1_span < 3.0e9 && w_span < 3.0e9;
+  p.a0_bytes = fits32 ? (unsigned)a0_span : 0;
+  p.a1_bytes = fits32 ? (unsigned)a1_span : 0;
+  p.w_bytes = fits32 ? (unsigned)w_span : 0;
   if (!fits32 && sel == 3) sel = n128 ? 0 : 1;
   // 128x160 tiles: SD-family channel counts are multiples of 320, so N = 320 k splits into 160-wide tiles with no padding
   // columns, and (M, N) = (16384, 1280) / (65536, 640) become exactly 2 / 4 rounds of the 512 resident workgroups

@@ -52,6 +52,11 @@ struct Cursor {  // K-tile being staged
   int t, ky, kx, cc;
 };
 
+struct Piece {  // one DMA instruction: per-lane byte offset, uniform byte offset, which descriptor (0 = a0, 1 = a1, 2 = weights)
+  unsigned voff, soff;
+  int which;
+};
+
 // ABL: timing-ablation bits for tools/ablate_gemm.py / stamp_gemm.py (results are garbage when != 0; only reachable when
 // built with -DFMX_ABLATE):  1 = no vmcnt wait, 2 = no LDS-DMA, 4 = no ds_read, 8 = no MFMA, 128 = s_memtime stamps
 // SCHED (A/B of the DMA issue points): 0 = piece 0 at the start of the LOAD slot + piece 1 inside the MFMA burst,
@@ -87,8 +92,18 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   //      lane -> row (e*8 + wave)*8 + lane/8 of the half-tile, physical chunk lane&7 -------------------------------------
   const int r8 = lane >> 3;
   const int kc = (lane & 7) ^ ((((wave & 1) << 2) + (lane >> 4)) & 7);  // logical chunk (source side of the swizzle)
+  const unsigned kcb = (unsigned)kc * 16u;                               // its byte offset inside the 128-B K row
+  // Every DMA is a buffer_load_dwordx4 ... lds: wave-uniform descriptor + 32-bit per-lane byte offset (+ uniform soffset).
+  // Measured (tools/ubench/dma_rate.hip): beside MFMA streams on the sibling waves a 64-bit-vaddr global_load_lds costs
+  // 35 cycles per 1-KiB piece per CU, the 32-bit-offset forms 20 (= their rate with no MFMA at all).  Lanes with nothing
+  // to load (conv zero padding, rows >= M / >= nout, the pipeline tail) use an offset beyond num_records: the hardware
+  // bounds check writes zeros into LDS (tools/ubench/oob_probe.hip) -- no zero page, no 64-bit select.
+  constexpr unsigned OOB = 0xC0000000u;  // the dispatcher guarantees every operand spans < OOB bytes
+  const __amdgpu_buffer_rsrc_t rs_a0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(p.a0), 0, p.a0_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(p.a1 ? p.a1 : p.a0), 0, p.a1_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(p.wgt), 0, p.w_bytes, 0x00020000);
   int a_pix[4], a_yx[4];  // [q*2+e]: first pixel of the image (or pixel index for plain GEMM; -1 = none), packed (iy0, ix0)
-  unsigned b_off[4];      // weight row offset in halfs (incl. the chunk), or 0xffffffff
+  unsigned b_off[4];      // byte offset of (weight row, chunk), or OOB
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const int row = (s >> 1) * 128 + ((s & 1) * 8 + wave) * 8 + r8;
@@ -109,17 +124,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
       a_yx[s] = 0;
     }
     const int nn = n0 + row;
-    b_off[s] = (nn < p.nout) ? (unsigned)nn * (unsigned)p.ldw + kc * 8 : 0xffffffffu;
+    b_off[s] = (nn < p.nout) ? (unsigned)nn * (unsigned)p.ldw * 2u + kcb : OOB;
   }
-  const f16* zp = p.zp + kc * 8;
 
-  // source address of DMA piece (half q, e) of the A operand for K-tile `c`: 32-bit element offsets from a uniform base
-  // (the host guarantees M * max(stride) < 2^32)
-  auto a_src = [&](int s, const Cursor& c) -> const f16* {
-    const f16* src;
-    unsigned sstride, coff;
-    if (c.cc < p.c0) { src = p.a0; sstride = p.s0; coff = c.cc; }
-    else             { src = p.a1; sstride = p.s1; coff = c.cc - p.c0; }
+  // A-operand piece (half q, e) for K-tile `c`
+  auto a_piece = [&](int s, const Cursor& c) -> Piece {
+    const bool second = c.cc >= p.c0;  // uniform
+    const unsigned sstride = second ? (unsigned)p.s1 : (unsigned)p.s0;
+    const unsigned coff = second ? (unsigned)(c.cc - p.c0) : (unsigned)c.cc;
     bool ok;
     unsigned pix;
     if (CONV) {
@@ -138,12 +150,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
       pix = (unsigned)a_pix[s];
     }
     ok = ok && c.t < p.kt;
-    const unsigned el = pix * sstride + coff + kc * 8;
-    return ok ? src + el : zp;
+    return Piece{ok ? pix * sstride * 2u + kcb : OOB, coff * 2u, second ? 1 : 0};
   };
-  auto b_src = [&](int s, const Cursor& c) -> const f16* {
-    const bool ok = b_off[s] != 0xffffffffu && c.t < p.kt;
-    return ok ? p.wgt + (b_off[s] + (unsigned)c.t * BK) : zp;
+  auto b_piece = [&](int s, const Cursor& c) -> Piece {
+    return Piece{c.t < p.kt ? b_off[s] : OOB, (unsigned)c.t * (BK * 2u), 2};
   };
   auto advance = [&](Cursor& c) {
     c.t++;
@@ -154,13 +164,21 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     }
   };
   // half-tile ids inside a stage: 0 = A_0, 1 = A_1, 2 = B_0, 3 = B_1;  HT = half-tile id, E = which of the wave's 2 pieces
-  auto src_of = [&](auto HT, auto E, const Cursor& c) -> const f16* {
+  auto src_of = [&](auto HT, auto E, const Cursor& c) -> Piece {
     constexpr int ht = decltype(HT)::value, e = decltype(E)::value;
-    return ht < 2 ? a_src(ht * 2 + e, c) : b_src((ht - 2) * 2 + e, c);
+    if constexpr (ht < 2) return a_piece(ht * 2 + e, c);
+    else return b_piece((ht - 2) * 2 + e, c);
   };
-  auto dma = [&](const f16* src, int buf, auto HT, auto E) {
+  auto dma = [&](const Piece& pc, int buf, auto HT, auto E) {
     constexpr int ht = decltype(HT)::value, e = decltype(E)::value;
-    if (!(ABL & 2)) glds16(src, smem + buf * STAGE_BYTES + ht * HALF_BYTES + (e * 8 + wave) * 1024);
+    if (ABL & 2) return;
+    auto* dst = (__attribute__((address_space(3))) void*)(smem + buf * STAGE_BYTES + ht * HALF_BYTES + (e * 8 + wave) * 1024);
+    if constexpr (ht >= 2) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, dst, 16, pc.voff, pc.soff, 0, 0);
+    } else {
+      if (pc.which) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a1, dst, 16, pc.voff, pc.soff, 0, 0);  // uniform branch
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a0, dst, 16, pc.voff, pc.soff, 0, 0);
+    }
   };
 
   f32x16 acc[2][2][2];  // [qi][qj][f]
@@ -203,7 +221,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
       wf[qj][ks] = *reinterpret_cast<const f16x8*>(base + lds_off(wc * 32 + li, ks * 2 + hi));
   };
   // 8 MFMAs of quadrant (qi, qj); this wave's second DMA piece of the phase goes out after MFMA 2*wc
-  auto mma = [&](auto QI, auto QJ, const f16* src1, int buf, auto HT) {
+  auto mma = [&](auto QI, auto QJ, const Piece& src1, int buf, auto HT) {
     constexpr int qi = decltype(QI)::value, qj = decltype(QJ)::value;
     if (ABL & 8) {  // keep the fragments alive so the ds_reads are not dead code
 #pragma unroll
@@ -247,7 +265,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   advance(c1);            // c1 = tile 1
   dma(src_of(IC<0>{}, IC<0>{}, c1), 1, IC<0>{}, IC<0>{});
   dma(src_of(IC<0>{}, IC<1>{}, c1), 1, IC<0>{}, IC<1>{});
-  const f16* src0 = src_of(IC<2>{}, IC<0>{}, c1);  // first piece of P1's half-tile B_0(1)
+  Piece src0 = src_of(IC<2>{}, IC<0>{}, c1);  // first piece of P1's half-tile B_0(1)
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (g == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one slot behind group 0
@@ -280,7 +298,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     __builtin_amdgcn_sched_barrier(0);                                         \
     stamp(IC<PH * 6 + 3>{});                                                   \
     {                                                                          \
-      const f16* src1 = src_of(IC<HT>{}, IC<1>{}, CUR);                        \
+      const Piece src1 = src_of(IC<HT>{}, IC<1>{}, CUR);                       \
       mma(IC<QI>{}, IC<QJ>{}, src1, SBUF, IC<HT>{});                           \
       if (SCHED == 3) {                                                        \
         dma(src0, SBUF, IC<HT>{}, IC<0>{});                                    \

@@ -30,6 +30,7 @@ struct GemmParams {
   int kt;           // number of 64-wide K tiles = kh*kh*(c0+c1)/64
   int cpt;          // K tiles per tap = (c0+c1)/64
   int tiles_m, tiles_n;
+  unsigned a0_bytes, a1_bytes, w_bytes;  // operand extents for the buffer descriptors of the 256x256 kernel
 };
 
 // K-tile depth of every GEMM kernel: 64 halfs = one 128-byte LDS row.
