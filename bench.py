@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-vae", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--breakdown", default="", help="write the per-shape kernel-time table of one UNet forward to this file")
     return ap.parse_args()
 
 
@@ -214,6 +215,12 @@ def main():
                 km.denoise_cfg(x, sig, uctx, cctx, a.cfg)
                 torch.cuda.synchronize()
                 summ = prof.summary()
+            if a.breakdown:
+                rows = sorted(prof.by_tag.items(), key=lambda kv: -kv[1]["seconds"])
+                with open(a.breakdown, "w") as f:
+                    for (kind, tag), d in rows:
+                        f.write(json.dumps({"kind": kind, "shape": tag, "launches": d["launches"], "ms": round(d["seconds"] * 1e3, 3),
+                                            "tflops": round(d["flops"] / d["seconds"] / 1e12, 1)}) + "\n")
             km.use_graph = not a.no_graph
             g = summ.get("gemm_conv")
             if g:

@@ -26,7 +26,9 @@ constexpr int BK = FMX_BK;
 // byte offset of (row, logical 16B chunk) inside a [rows][64] fp16 LDS tile
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-template <int BM, int BN, bool CONV>
+// BUF: LDS-DMA through buffer descriptors (32-bit byte offsets, hardware zero fill for out-of-range lanes) -- needs every
+// operand to span < 0xC0000000 bytes (dispatcher: fits32); BUF = false keeps 64-bit global addresses + the zero page.
+template <int BM, int BN, bool CONV, bool BUF>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int MI = BM / 32;  // 16-row fragments per wave along M
@@ -75,12 +77,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   }
   // W rows
   const f16* b_ptr[LB];
+  unsigned b_voff[LB];
+  constexpr unsigned OOB = 0xC0000000u;
+  const unsigned kcb = (unsigned)kc * 16u;
 #pragma unroll
   for (int j = 0; j < LB; ++j) {
     const int nn = n0 + j * 32 + prow;
     b_ptr[j] = (nn < p.nout) ? p.wgt + (long)nn * p.ldw + kc * 8 : nullptr;
+    b_voff[j] = (nn < p.nout) ? (unsigned)nn * (unsigned)p.ldw * 2u + kcb : OOB;
   }
   const f16* zp = p.zp + kc * 8;
+  const __amdgpu_buffer_rsrc_t rs_a0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(p.a0), 0, p.a0_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(p.a1 ? p.a1 : p.a0), 0, p.a1_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(p.wgt), 0, p.w_bytes, 0x00020000);
 
   auto stage = [&](int s, int t) {
     char* sa = smem + s * STAGE_BYTES;
@@ -91,18 +100,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
       tap = t / p.cpt;
       cc = (t - tap * p.cpt) * BK;
     }
-    const f16* src;
-    int sstride, coff;
-    if (cc < p.c0) { src = p.a0; sstride = p.s0; coff = cc; }
-    else           { src = p.a1; sstride = p.s1; coff = cc - p.c0; }
+    const bool second = cc >= p.c0;  // uniform
+    const f16* src = second ? p.a1 : p.a0;
+    const int sstride = second ? p.s1 : p.s0;
+    const int coff = second ? cc - p.c0 : cc;
     int ky = 0, kx = 0;
     if (CONV) { ky = tap / p.kh; kx = tap - ky * p.kh; }
+    const __amdgpu_buffer_rsrc_t rs_a = second ? rs_a1 : rs_a0;  // uniform select
+    const __amdgpu_buffer_rsrc_t rs_w = rs_b;  // local copy: passing the captured descriptor straight to the builtin makes the host pass drop the kernel stub
 #pragma unroll
     for (int j = 0; j < LA; ++j) {
-      const f16* g = zp;
+      bool ok = a_ok[j];
+      long pix = a_pix[j];
       if (CONV) {
         int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
-        bool ok = a_ok[j];
         if (p.up_h > 0) {
           ok = ok && iy >= 0 && iy < p.up_h && ix >= 0 && ix < p.up_w;
           if (p.up_h == 2 * p.h && p.up_w == 2 * p.w) {  // the x2 case of every SD/SDXL/VAE Upsample
@@ -115,16 +126,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
         } else {
           ok = ok && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
         }
-        if (ok) g = src + (a_pix[j] + (long)iy * p.w + ix) * sstride + coff + kc * 8;
-      } else {
-        if (a_ok[j]) g = src + a_pix[j] * sstride + coff + kc * 8;
+        pix += (long)iy * p.w + ix;
       }
-      glds16(g, sa + (j * 256 + wave * 64) * 16);
+      char* dst = sa + (j * 256 + wave * 64) * 16;
+      if (BUF) {
+        const unsigned voff = ok ? (unsigned)pix * (unsigned)sstride * 2u + kcb : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)dst, 16, voff, (unsigned)coff * 2u, 0, 0);
+      } else {
+        glds16(ok ? src + pix * sstride + coff + kc * 8 : zp, dst);
+      }
     }
 #pragma unroll
     for (int j = 0; j < LB; ++j) {
-      const f16* g = b_ptr[j] ? b_ptr[j] + (long)t * BK : zp;
-      glds16(g, sb + (j * 256 + wave * 64) * 16);
+      char* dst = sb + (j * 256 + wave * 64) * 16;
+      if (BUF) {
+        const unsigned bv = b_voff[j];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)dst, 16, bv, (unsigned)t * (BK * 2u), 0, 0);
+      } else {
+        glds16(b_ptr[j] ? b_ptr[j] + (long)t * BK : zp, dst);
+      }
     }
   };
 
@@ -252,12 +272,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   }
 }
 
-template <int BM, int BN, bool CONV>
-int launch(const GemmParams& p, hipStream_t st) {
+template <int BM, int BN, bool CONV, bool BUF>
+int launch_impl(const GemmParams& p, hipStream_t st) {
   const int smem = 2 * (BM + BN) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, CONV>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, CONV, BUF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
@@ -265,9 +285,14 @@ int launch(const GemmParams& p, hipStream_t st) {
   q.tiles_m = (p.M + BM - 1) / BM;
   q.tiles_n = (p.nout + BN - 1) / BN;
   const int grid = q.tiles_m * q.tiles_n;
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, CONV>), dim3(grid), dim3(256), smem, st, q);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, CONV, BUF>), dim3(grid), dim3(256), smem, st, q);
   FMX_LAUNCH_CHECK("fmx_gemm_conv_f16");
   return FMX_OK;
+}
+
+template <int BM, int BN, bool CONV>
+int launch(const GemmParams& p, hipStream_t st) {
+  return p.a0_bytes ? launch_impl<BM, BN, CONV, true>(p, st) : launch_impl<BM, BN, CONV, false>(p, st);
 }
 
 // interleave GEGLU rows: out row 32*q + i (i<16) = in row 16*q + i ; out row 32*q+16+i = in row inner + 16*q + i
@@ -351,12 +376,13 @@ extern "C" int fmx_gemm_conv_f16(const fmx_gemm_args* a, void* stream) {
     const double c160 = rounds(128, 160, 512) / 1.0, c128 = rounds(128, 128, 512) / 1.0;
     if (sel == 0 ? c160 < c128 : (p.nout % 128) != 0 && tiles(128, 160) >= 256) sel = 4;
   }
-  if (a->out_f32 < 0) sel = (-a->out_f32 - 1) % 5;  // test hook: force a tile shape (out_f32 = -1..-5 -> fp16 out)
+  if (sel == 3) sel = 5;  // production 256x256 kernel: the software-pipelined one (fmx_gemm256p.hip); 3 = ping-pong, test hook only
+  if (a->out_f32 < 0) sel = (-a->out_f32 - 1) % 6;  // test hook: force a tile shape (out_f32 = -1..-6 -> fp16 out)
   FMX_REQUIRE(sel != 4 || a->act != FMX_ACT_GEGLU, "gemm: the 128x160 tile does not support GEGLU");
   if (a->out_f32 < 0) p.out_f32 = 0;
-  if (sel == 3) {
+  if (sel == 3 || sel == 5) {
     FMX_REQUIRE(FastEpilogue::eligible8(p) && fits32, "gemm: 256x256 kernel needs fp16 output, 16-byte aligned epilogue operands, leading dimensions / nout multiples of 8, operands < 2^32 elements");
-    return fmx_launch_gemm256(p, conv, st);
+    return sel == 5 ? fmx_launch_gemm256p(p, conv, st) : fmx_launch_gemm256(p, conv, st);
   }
   if (sel == 4) return conv ? launch<128, 160, true>(p, st) : launch<128, 160, false>(p, st);
   if (conv) {

@@ -270,6 +270,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   __builtin_amdgcn_s_barrier();
   if (g == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one slot behind group 0
 
+  unsigned long long clk0 = 0, rt0 = 0;
+  if (ABL & 128) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
   for (int t = 0; t < p.kt; ++t) {
     const int buf = t & 1;
     Cursor c2 = c1;
@@ -333,6 +335,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
       unsigned* dbg = reinterpret_cast<unsigned*>(p.out);
 #pragma unroll
       for (int i = 0; i < 24; ++i) dbg[wave * 24 + i] = stamps[i];
+      if (wave == 0) {  // whole K loop: shader cycles (s_memtime) and 100 MHz ticks (s_memrealtime) -> effective clock
+        dbg[192] = (unsigned)(__builtin_amdgcn_s_memtime() - clk0);
+        dbg[193] = (unsigned)(__builtin_amdgcn_s_memrealtime() - rt0);
+        dbg[194] = (unsigned)p.kt;
+      }
     }
     return;
   }

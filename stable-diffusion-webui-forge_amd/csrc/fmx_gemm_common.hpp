@@ -205,3 +205,5 @@ __device__ __forceinline__ void swap_halfwaves(float& a, float& b) {
 
 // 256x256-tile kernel (fmx_gemm256.hip)
 int fmx_launch_gemm256(const GemmParams& p, bool conv, hipStream_t st);
+// same tile, software-pipelined single-barrier schedule (fmx_gemm256p.hip)
+int fmx_launch_gemm256p(const GemmParams& p, bool conv, hipStream_t st);

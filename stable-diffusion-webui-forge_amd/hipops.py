@@ -27,6 +27,8 @@ class KernelProfiler:
 
     def __init__(self):
         self.records = []  # (kind, flops, ev_start, ev_stop)
+        self.tags = []     # problem shape per record (bench.py --breakdown)
+        self.by_tag = {}
 
     def __enter__(self):
         global _profiler
@@ -43,7 +45,7 @@ class KernelProfiler:
         _lib.check(_lib.lib().fmx_event_create(C.byref(ev)), "fmx_event_create")
         return ev
 
-    def launch(self, kind, flops, fn):
+    def launch(self, kind, flops, fn, tag=None):
         L = _lib.lib()
         a, b = self._event(), self._event()
         sp = stream_ptr()
@@ -51,21 +53,26 @@ class KernelProfiler:
         fn()
         _lib.check(L.fmx_event_record(b, sp), "fmx_event_record")
         self.records.append((kind, flops, a, b))
+        self.tags.append(tag)
 
     def summary(self):
         """-> {kind: {"launches", "flops", "seconds"}} ; synchronises."""
         L = _lib.lib()
         out = {}
-        for kind, flops, a, b in self.records:
+        for (kind, flops, a, b), tag in zip(self.records, self.tags):
             ms = C.c_float()
             _lib.check(L.fmx_event_elapsed_ms(a, b, C.byref(ms)), "fmx_event_elapsed_ms")
             d = out.setdefault(kind, {"launches": 0, "flops": 0.0, "seconds": 0.0})
             d["launches"] += 1
             d["flops"] += flops
             d["seconds"] += ms.value * 1e-3
+            t = self.by_tag.setdefault((kind, tag), {"launches": 0, "flops": 0.0, "seconds": 0.0})
+            t["launches"] += 1
+            t["flops"] += flops
+            t["seconds"] += ms.value * 1e-3
             L.fmx_event_destroy(a)
             L.fmx_event_destroy(b)
-        self.records = []
+        self.records, self.tags = [], []
         return out
 
 
@@ -148,7 +155,8 @@ def conv_gemm(x, wgt, nout, *, x1=None, n=None, h=None, w=None, kh=1, stride=1, 
     a.ld_gate = gate.stride(0) if gate is not None else 0
     if _profiler is not None:
         flops = 2.0 * m * nout * kh * kh * (c0 + c1)
-        _profiler.launch("gemm_conv", flops, lambda: _lib.check(_lib.lib().fmx_gemm_conv_f16(C.byref(a), stream_ptr()), "fmx_gemm_conv_f16"))
+        _profiler.launch("gemm_conv", flops, lambda: _lib.check(_lib.lib().fmx_gemm_conv_f16(C.byref(a), stream_ptr()), "fmx_gemm_conv_f16"),
+                         tag=f"M={m} N={nout} K={kh * kh * (c0 + c1)} kh={kh} s={stride}{' up' if up else ''}{' geglu' if act == ACT_GEGLU else ''}")
         return out
     _lib.check(_lib.lib().fmx_gemm_conv_f16(C.byref(a), stream_ptr()), "fmx_gemm_conv_f16")
     return out
@@ -184,7 +192,8 @@ def attention(q, k, vt, *, batch, heads, nq, nk, nk_pad, dpad, scale, q_bs, q_rs
     if _profiler is not None:
         d_true = int(round(float(scale) ** -2))
         flops = 4.0 * batch * heads * nq * nk * d_true
-        _profiler.launch("attention", flops, lambda: _lib.check(_lib.lib().fmx_attention_f16(C.byref(a), stream_ptr()), "fmx_attention_f16"))
+        _profiler.launch("attention", flops, lambda: _lib.check(_lib.lib().fmx_attention_f16(C.byref(a), stream_ptr()), "fmx_attention_f16"),
+                         tag=f"B={batch} H={heads} Nq={nq} Nk={nk} d={dpad}")
         return out
     _lib.check(_lib.lib().fmx_attention_f16(C.byref(a), stream_ptr()), "fmx_attention_f16")
     return out

@@ -20,7 +20,7 @@ for w in $WHAT; do
           python $R/tools/pmc_summary.py $O > $O/pmc_summary.json; cat $O/pmc_summary.json; find $O -name '*counter_collection.csv' -size +30M -delete; find $O -name '*kernel_trace.csv' -delete;;
     kbench) timeout 900 python tools/bench_kernels.py > $O/kbench.log 2>&1; tail -60 $O/kbench.log;;
     gemmbench) timeout 900 python tools/bench_kernels.py gemm > $O/gemmbench.log 2>&1; tail -100 $O/gemmbench.log;;
-    ktests) timeout -s KILL 240 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "gemm256_identity" > $O/ktests_quick.log 2>&1 || { tail -30 $O/ktests_quick.log; echo "QUICK TEST FAILED -- stopping"; exit 1; }
+    ktests) timeout -s KILL 240 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "gemm256_identity or gemm256_epilogues" > $O/ktests_quick.log 2>&1 || { tail -30 $O/ktests_quick.log; echo "QUICK TEST FAILED -- stopping"; exit 1; }
             timeout -s KILL 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q 2>&1 | tail -60 > $O/ktests.log; tail -25 $O/ktests.log;;
   esac
 done

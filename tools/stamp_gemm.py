@@ -15,7 +15,11 @@ out = torch.zeros(m, n, dtype=torch.float16, device="cuda")
 for _ in range(3):
     ops.conv_gemm(x, w, n, out=out, ld_out=n, force_tile=4)
 torch.cuda.synchronize()
-st = out.view(-1)[:8 * 24 * 2].view(torch.int32).cpu().numpy().astype("int64").reshape(8, 24) & 0xffffffff
+raw = out.view(-1)[:200 * 2].view(torch.int32).cpu().numpy().astype("int64") & 0xffffffff
+st = raw[:192].reshape(8, 24)
+cyc, rt, kt = int(raw[192]), int(raw[193]), int(raw[194])
+print(f"K loop of block 8: {cyc} shader cycles, {rt} realtime ticks (100 MHz) over {kt} K-tiles -> {cyc / max(kt, 1):.0f} cycles per K-tile, "
+      f"effective clock {cyc / max(rt, 1) * 0.1:.3f} GHz")
 t0 = st[:, 0].min()
 names = ["start", "dma0_issued", "ds_issued", "barrier1_passed", "mfma+dma1_issued", "barrier2_passed"]
 print("wave  phase | " + " ".join(f"{n_:>15s}" for n_ in names))
