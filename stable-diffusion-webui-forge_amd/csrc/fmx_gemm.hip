@@ -16,6 +16,8 @@
 //    side and on the ds_read_b128 side (same involution), which makes the fragment reads conflict-free.
 //  * double-buffered K loop (BK = 64): issue tile t+1, compute tile t, one vmcnt(0)+barrier per tile.
 //  * 1-D grid remapped so that consecutive tiles (same A rows, neighbouring W rows) share an XCD's L2.
+#include <math.h>
+
 #include "fmx_gemm_common.hpp"
 
 namespace {
@@ -343,23 +345,8 @@ extern "C" int fmx_gemm_conv_f16(const fmx_gemm_args* a, void* stream) {
               "gemm: gate / GELU-tanh need fp16 output and leading dimensions / nout multiples of 4 / 8");
   const bool conv = !(a->kh == 1 && p.stride == 1 && a->pad == 0 && a->up_h == 0 && a->oh == a->h && a->ow == a->w);
   hipStream_t st = (hipStream_t)stream;
-  // tile choice: the largest tile that still gives >= 1.5 workgroups per CU (256 CUs); 64-wide N tiles
-  // for ragged N (320 = 5 x 64) so no MFMA work is spent on padding columns.
-  auto tiles = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.nout + bn - 1) / bn); };
-  const bool n128 = (p.nout % 128) == 0 || p.nout >= 2048;
-  int sel = 2;
-  if (n128 && tiles(128, 128) >= 384) sel = 0;
-  else if (tiles(128, 64) >= 384) sel = 1;
-  // 256x256 ping-pong kernel: needs the branch-free epilogue; wins (measured, profiles/r01c_gemm_sweep.jsonl) when its
-  // tiles fill the 256 CUs in whole rounds and K is deep enough to amortise its longer prologue
-  {
-    const long t256 = tiles(256, 256);
-    const long rounds = (t256 + 255) / 256;
-    const double util = (double)p.M * (double)p.nout / ((double)rounds * 256.0 * 65536.0);
-    if (FastEpilogue::eligible8(p) && p.nout >= 256 && p.M >= 256 && util >= 0.8 && p.kt >= 8) sel = 3;
-  }
-  // the 256x256 kernel addresses its operands through buffer descriptors with 32-bit byte offsets; offsets >= 0xC0000000
-  // are its "load zeros" marker, so every operand must span less than that
+  // the 8-wave kernels (and the buffer-descriptor path of the 4-wave ones) address their operands with 32-bit byte offsets;
+  // offsets >= 0xC0000000 are the "load zeros" marker, so every operand must span less than that
   const double npix = (double)a->n * a->h * a->w;
   const double a0_span = ((npix - 1) * p.s0 + p.c0) * 2.0, a1_span = p.c1 ? ((npix - 1) * p.s1 + p.c1) * 2.0 : 16.0;
   const double w_span = ((double)(p.nout - 1) * p.ldw + (double)a->kh * a->kh * ctot) * 2.0;
@@ -367,22 +354,38 @@ extern "C" int fmx_gemm_conv_f16(const fmx_gemm_args* a, void* stream) {
   p.a0_bytes = fits32 ? (unsigned)a0_span : 0;
   p.a1_bytes = fits32 ? (unsigned)a1_span : 0;
   p.w_bytes = fits32 ? (unsigned)w_span : 0;
-  if (!fits32 && sel == 3) sel = n128 ? 0 : 1;
-  // 128x160 tiles: SD-family channel counts are multiples of 320, so N = 320 k splits into 160-wide tiles with no padding
-  // columns, and (M, N) = (16384, 1280) / (65536, 640) become exactly 2 / 4 rounds of the 512 resident workgroups
-  // (128x128: 2.5 / 5 rounds).  Odd fragment count per wave along N -> not for GEGLU (value | gate fragment pairs).
-  if (sel != 3 && a->act != FMX_ACT_GEGLU && (p.nout % 160) == 0 && p.M >= 128) {
-    auto rounds = [&](int bm, int bn, int slots) { return (double)((tiles(bm, bn) + slots - 1) / slots) * bm * bn; };
-    const double c160 = rounds(128, 160, 512) / 1.0, c128 = rounds(128, 128, 512) / 1.0;
-    if (sel == 0 ? c160 < c128 : (p.nout % 128) != 0 && tiles(128, 160) >= 256) sel = 4;
-  }
-  if (sel == 3) sel = 5;  // production 256x256 kernel: the software-pipelined one (fmx_gemm256p.hip); 3 = ping-pong, test hook only
-  if (a->out_f32 < 0) sel = (-a->out_f32 - 1) % 6;  // test hook: force a tile shape (out_f32 = -1..-6 -> fp16 out)
+  // Tile choice by a cost model calibrated on tools/bench_kernels.py sweeps (profiles/*_gemm_sweep.jsonl):
+  //   time ~ rounds x tile area x (workgroups per CU) / efficiency,   rounds = ceil(tiles / (256 CUs x workgroups per CU)),
+  // efficiency = the kernel's steady-state rate relative to the 256x320 kernel, times kt / (kt + overhead in K-tiles): the
+  // 8-wave kernels own a CU alone, so their prologue + epilogue (~6 K-tiles' worth) is exposed once per tile; the 4-wave
+  // kernels run 2-4 workgroups per CU and hide most of it.  Padding rows / columns are counted through the tile area.
+  // sel: 0 = 128x128, 1 = 128x64, 2 = 64x64, 4 = 128x160, 5 = 256x256 pipelined, 6 = 256x320 pipelined (3 = ping-pong, test hook)
+  auto tiles = [&](int bm, int bn) { return (double)((p.M + bm - 1) / bm) * (double)((p.nout + bn - 1) / bn); };
+  const double kt = p.kt;
+  auto cost = [&](int bm, int bn, int wpc, double eff, double ovh) {
+    const double rounds = ceil(tiles(bm, bn) / (256.0 * wpc));
+    return rounds * bm * bn * wpc / (eff * kt / (kt + ovh));
+  };
+  const bool big_ok = FastEpilogue::eligible8(p) && fits32;
+  const bool geglu = a->act == FMX_ACT_GEGLU;
+  // (efficiency, overhead) fitted to profiles/r02o_gemm_sweep.jsonl: steady-state TF/s / 1200 and the K-tiles' worth of
+  // exposed prologue + epilogue per tile; the GEGLU epilogue (erf) costs the 4-wave kernels about 3 K-tiles more
+  const double g4 = geglu ? 3.0 : 0.0;
+  int sel = 2;
+  double best = cost(64, 64, 5, 0.45, 3.0 + g4);
+  auto consider = [&](int id, double c) { if (c < best) { best = c; sel = id; } };
+  consider(1, cost(128, 64, 3, 0.62, 4.0 + g4));
+  consider(0, cost(128, 128, 2, 0.76, 4.5 + g4));
+  if (!geglu && (p.nout % 160) == 0) consider(4, cost(128, 160, 2, 0.87, 5.5));
+  if (big_ok) consider(5, cost(256, 256, 1, 0.96, 4.5));
+  if (big_ok && (!geglu || (p.nout % 32) == 0)) consider(6, cost(256, 320, 1, 1.0, 7.0));
+  if (a->out_f32 < 0) sel = (-a->out_f32 - 1) % 7;  // test hook: force a tile shape (out_f32 = -1..-7 -> fp16 out)
   FMX_REQUIRE(sel != 4 || a->act != FMX_ACT_GEGLU, "gemm: the 128x160 tile does not support GEGLU");
   if (a->out_f32 < 0) p.out_f32 = 0;
-  if (sel == 3 || sel == 5) {
+  if (sel == 3 || sel == 5 || sel == 6) {
     FMX_REQUIRE(FastEpilogue::eligible8(p) && fits32, "gemm: 256x256 kernel needs fp16 output, 16-byte aligned epilogue operands, leading dimensions / nout multiples of 8, operands < 2^32 elements");
-    return sel == 5 ? fmx_launch_gemm256p(p, conv, st) : fmx_launch_gemm256(p, conv, st);
+    if (sel == 6) FMX_REQUIRE(a->act != FMX_ACT_GEGLU || (p.nout % 32) == 0, "gemm: GEGLU needs nout % 32 == 0");
+    return sel == 3 ? fmx_launch_gemm256(p, conv, st) : fmx_launch_gemm256p(p, conv, sel == 6 ? 320 : 256, st);
   }
   if (sel == 4) return conv ? launch<128, 160, true>(p, st) : launch<128, 160, false>(p, st);
   if (conv) {

@@ -1,30 +1,32 @@
-// 256x256-tile implicit-GEMM convolution / linear for gfx950, software-pipelined variant ("gemm256p").
+// 256 x BN-tile implicit-GEMM convolution / linear for gfx950, software-pipelined ("gemm256p"), BN = 256 or 320.
 //
-// Same tile, LDS image, swizzle and LDS-DMA pieces as fmx_gemm256.hip; what differs is the schedule.  fmx_gemm256.hip
-// alternates two wave groups through 8 barrier-separated slots per K-tile (one group loads while the other owns the
-// matrix pipe); its s_memtime stamps (profiles/r02d_*) show every slot costing max(load, 8 MFMA) + barrier skew, 3000+
-// cycles per K-tile against 2048 cycles of MFMA.  Here every wave runs ONE in-order stream with ONE barrier per K-tile:
+// Same LDS image, swizzle and LDS-DMA pieces as fmx_gemm256.hip; what differs is the schedule.  fmx_gemm256.hip alternates
+// two wave groups through 8 barrier-separated slots per K-tile (one group loads while the other owns the matrix pipe);
+// its s_memtime stamps (profiles/r02d_*) show every slot costing max(load, 8 MFMA) + barrier skew, 3000+ cycles per
+// K-tile against 2048 cycles of MFMA.  Here every wave runs ONE in-order stream with ONE barrier per K-tile:
 //
-//   wave (wm, wn), wm = wave / 4, wn = wave % 4, owns rows m0 + wm*128 + [0,128) x cols n0 + wn*64 + [0,64):
-//   4 x 2 accumulator blocks of 32 x 32 (v_mfma_f32_32x32x16_f16, weights as MFMA-A, activations as MFMA-B).
-//   A K-tile (BK = 64) is 4 k-steps of 8 MFMAs; the 6 fragments of k-step s+1 are read from LDS into the other half of a
-//   register double buffer BEFORE the MFMAs of k-step s issue, so LDS latency hides behind 256 cycles of matrix work, and
-//   the second wave of the SIMD fills whatever gaps remain (both waves want the pipe all the time: no role split).
+//   BN = 256: waves 2 (M) x 4 (N), wave tile 128 x 64  = 4 x 2 accumulator blocks of 32 x 32,  8 MFMA / 6 ds_read per k-step
+//   BN = 320: waves 4 (M) x 2 (N), wave tile  64 x 160 = 2 x 5 blocks,                        10 MFMA / 7 ds_read per k-step
+//   (v_mfma_f32_32x32x16_f16, weights as MFMA-A, activations as MFMA-B).  320 is the native width of the SD family: every
+//   channel count is 320 k, so N = 320 / 640 / 1280 tile with no padding columns and (M, N) = (16384, 1280) is exactly
+//   256 tiles = one round of the 256 CUs (256-wide tiles: 320 tiles = 1.25 rounds), with 10 % fewer LDS-DMA bytes per FLOP.
 //
-//   k-step 3 of K-tile t:   s_waitcnt lgkmcnt(0) vmcnt(0) | s_barrier | DMA tile t+2 -> stage t&1 (8 pieces per wave)
-//                           | ds_read fragments (t+1, 0) from stage (t+1)&1 | 8 MFMA (t, 3)
-//   Why one barrier is enough: at that point every wave has finished its LAST reads of stage t&1 (the fragments of
-//   k-step 3 were read during k-step 2 and lgkmcnt(0) has retired them), so the stage may be overwritten (WAR); and every
-//   wave has waited for its own pieces of tile t+1 (issued one whole K-tile earlier), so after the barrier all of tile
-//   t+1 is visible in LDS (RAW).  The DMA of tile t+2 then has three k-steps (~1500 cycles) to land.
+//   A K-tile (BK = 64) is 4 k-steps; the fragments of k-step s+1 are read from LDS into the other half of a register
+//   double buffer while the MFMAs of k-step s issue, interleaved one load per MFMA (sched_group_barrier): a lone load
+//   issues in the 32-cycle shadow of the running MFMA, the same loads issued back to back starve the matrix pipe
+//   (tools/ubench/lds_mix.hip).  The second wave of the SIMD fills whatever gaps remain.
+//
+//   k-step 3 of K-tile t:   s_waitcnt lgkmcnt(0) vmcnt(0) | s_barrier | ds_read fragments (t+1, 0) from stage (t+1)&1
+//                           | MFMAs (t, 3) | first 3 pieces of tile t+2 -> stage t&1
+//   Why one barrier is enough: at that point every wave has finished its LAST reads of stage t&1 (the fragments of k-step 3
+//   were read during k-step 2 and lgkmcnt(0) has retired them), so the stage may be overwritten (WAR); and every wave has
+//   waited for its own pieces of tile t+1 (issued during k-steps (t-1,3), (t,0), (t,1)), so after the barrier all of tile
+//   t+1 is visible in LDS (RAW).
 #include "fmx_gemm_common.hpp"
 
 namespace {
 
-constexpr int BM = 256, BN = 256, BK = FMX_BK;
-constexpr int HALF_BYTES = 128 * 128;        // one half-tile: 128 rows x 128 B
-constexpr int STAGE_BYTES = 4 * HALF_BYTES;  // A_0 A_1 B_0 B_1
-constexpr int LDS_BYTES = 2 * STAGE_BYTES;   // 128 KiB
+constexpr int BM = 256, BK = FMX_BK;
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
@@ -40,8 +42,24 @@ struct Piece {  // one DMA instruction: per-lane byte offset, uniform byte offse
   bool second;
 };
 
-template <bool CONV>
+template <int BN>
+struct Geo {
+  static constexpr int WN = BN == 256 ? 4 : 2;          // waves along N
+  static constexpr int WM = 8 / WN;                     // waves along M
+  static constexpr int MI = BM / (WM * 32);             // 32-row blocks per wave along M
+  static constexpr int NJ = BN / (WN * 32);             // 32-col blocks per wave along N
+  static constexpr int NPA = BM / 64, NPB = BN / 64;    // LDS-DMA pieces per wave per K-tile (8 rows x 128 B each)
+  static constexpr int NP = NPA + NPB;
+  static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
+  static constexpr int WAVE_EPI_BYTES = BN == 256 ? 16384 : 20480;  // per-wave transpose buffer of the epilogue
+  static constexpr int LDS_BYTES = 2 * STAGE_BYTES > 8 * WAVE_EPI_BYTES ? 2 * STAGE_BYTES : 8 * WAVE_EPI_BYTES;  // 128 / 160 KiB
+};
+
+template <bool CONV, int BN>
 __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
+  using G = Geo<BN>;
+  constexpr int MI = G::MI, NJ = G::NJ, NPA = G::NPA, NPB = G::NPB, NP = G::NP;
+  constexpr int STAGE_BYTES = G::STAGE_BYTES, A_BYTES = G::A_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef FMX_ABLATE
   const unsigned long long rt_entry = __builtin_amdgcn_s_memrealtime();
@@ -49,7 +67,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wm = wave / G::WN, wn = wave % G::WN;
   const int hi = lane >> 5, li = lane & 31;
 
   // ---- tile id: XCD remap, then 8-row groups of tiles so that an XCD's 32 concurrent tiles form an 8 x 4 patch ----
@@ -69,8 +87,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   const int m0 = tm * BM, n0 = tn * BN;
   const int Ctot = p.c0 + p.c1;
 
-  // ---- staging geometry: a wave issues 4 A pieces and 4 B pieces per K-tile; piece s covers the 8 rows
-  //      (s>>1)*128 + ((s&1)*8 + wave)*8 + [0,8) of its operand, lane -> row lane/8, physical chunk lane&7 ------------------
+  // ---- staging geometry: piece s of a wave covers the 8 rows  s*64 + wave*8 + [0,8)  of its operand (A: s < NPA,
+  //      B: s < NPB), lane -> row lane/8, physical 16-byte chunk lane&7; LDS destination (s*8 + wave) * 1 KiB ---------------
   const int r8 = lane >> 3;
   const int kc = (lane & 7) ^ ((((wave & 1) << 2) + (lane >> 4)) & 7);  // logical chunk (source side of the swizzle)
   const unsigned kcb = (unsigned)kc * 16u;
@@ -79,12 +97,11 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   const __amdgpu_buffer_rsrc_t rs_a0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(p.a0), 0, p.a0_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(p.a1 ? p.a1 : p.a0), 0, p.a1_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(p.wgt), 0, p.w_bytes, 0x00020000);
-  int a_pix[4], a_yx[4];
-  unsigned b_off[4];
+  int a_pix[NPA], a_yx[NPA];
+  unsigned b_off[NPB];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const int row = (s >> 1) * 128 + ((s & 1) * 8 + wave) * 8 + r8;
-    const int m = m0 + row;
+  for (int s = 0; s < NPA; ++s) {
+    const int m = m0 + s * 64 + wave * 8 + r8;
     if (CONV) {
       const int per = p.oh * p.ow;
       const int mm = min(m, p.M - 1);
@@ -100,7 +117,10 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
       a_pix[s] = (m < p.M) ? m : -1;
       a_yx[s] = 0;
     }
-    const int nn = n0 + row;
+  }
+#pragma unroll
+  for (int s = 0; s < NPB; ++s) {
+    const int nn = n0 + s * 64 + wave * 8 + r8;
     b_off[s] = (nn < p.nout) ? (unsigned)nn * (unsigned)p.ldw * 2u + kcb : OOB;
   }
 
@@ -135,84 +155,82 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
       if (++c.kx == p.kh) { c.kx = 0; ++c.ky; }
     }
   };
-  // piece IDX (0-3: A pieces, 4-7: B pieces) of K-tile `c` into stage `buf`; tiles past the end load zeros (no traffic)
+  // piece IDX (0 .. NPA-1: A pieces, NPA .. NP-1: B pieces) of K-tile `c` into stage `buf`; tiles past the end are zero
+  // fills (no traffic), IDX >= NP is a no-op
   auto issue_piece = [&](auto IDX, const Cursor& c, int buf) {
     constexpr int idx = decltype(IDX)::value;
-    constexpr int s = idx & 3;
-    char* sbase = smem + buf * STAGE_BYTES + wave * 1024;
-    const bool live = c.t < p.kt;  // uniform
-    if constexpr (idx < 4) {
-      const Piece pc = a_piece(s, c);
-      auto* dst = (__attribute__((address_space(3))) void*)(sbase + (s >> 1) * HALF_BYTES + (s & 1) * 8192);
-      const __amdgpu_buffer_rsrc_t rs = pc.second ? rs_a1 : rs_a0;  // uniform select (s_cselect), no branch
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, live ? pc.voff : OOB, pc.soff, 0, 0);
-    } else {
-      auto* dst = (__attribute__((address_space(3))) void*)(sbase + (2 + (s >> 1)) * HALF_BYTES + (s & 1) * 8192);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, dst, 16, live ? b_off[s] : OOB, (unsigned)c.t * (BK * 2u), 0, 0);
+    if constexpr (idx < NP) {
+      char* sbase = smem + buf * STAGE_BYTES + wave * 1024;
+      const bool live = c.t < p.kt;  // uniform
+      if constexpr (idx < NPA) {
+        constexpr int s = idx;
+        const Piece pc = a_piece(s, c);
+        auto* dst = (__attribute__((address_space(3))) void*)(sbase + s * 8192);
+        const __amdgpu_buffer_rsrc_t rs = pc.second ? rs_a1 : rs_a0;  // uniform select (s_cselect), no branch
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, live ? pc.voff : OOB, pc.soff, 0, 0);
+      } else {
+        constexpr int s = idx - NPA;
+        auto* dst = (__attribute__((address_space(3))) void*)(sbase + A_BYTES + s * 8192);
+        const unsigned bo = b_off[s];  // (local copy: hipcc's host pass silently drops the kernel stub when a captured array
+        const unsigned voff = live ? bo : OOB;  //  element is handed straight to the buffer builtin)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, dst, 16, voff, (unsigned)c.t * (BK * 2u), 0, 0);
+      }
     }
   };
 
-  f32x16 acc[4][2];  // [mi][nj]
+  f32x16 acc[MI][NJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  f16x8 af[2][4];  // [buffer][mi]  activation fragments (MFMA "B" operand)
-  f16x8 wf[2][2];  // [buffer][nj]  weight fragments     (MFMA "A" operand)
+  f16x8 af[2][MI];  // [buffer][mi]  activation fragments (MFMA "B" operand)
+  f16x8 wf[2][NJ];  // [buffer][nj]  weight fragments     (MFMA "A" operand)
 
-  // LDS byte offsets of this lane's fragment rows (k-step 0, hi folded in); k-step s adds the swizzled chunk below
-  // activation rows wm*128 + mi*32 + li live in half-tile wm; weight rows wn*64 + nj*32 + li in half-tile 2 + wn/2
   auto read_frags = [&](int buf, int ks, int fb) {
-    const char* sa = smem + buf * STAGE_BYTES + wm * HALF_BYTES;
-    const char* sb = smem + buf * STAGE_BYTES + (2 + (wn >> 1)) * HALF_BYTES;
+    const char* sa = smem + buf * STAGE_BYTES;
+    const char* sb = sa + A_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) af[fb][i] = *reinterpret_cast<const f16x8*>(sa + lds_off(i * 32 + li, ks * 2 + hi));
+    for (int i = 0; i < MI; ++i) af[fb][i] = *reinterpret_cast<const f16x8*>(sa + lds_off(wm * (MI * 32) + i * 32 + li, ks * 2 + hi));
 #pragma unroll
-    for (int j = 0; j < 2; ++j) wf[fb][j] = *reinterpret_cast<const f16x8*>(sb + lds_off((wn & 1) * 64 + j * 32 + li, ks * 2 + hi));
+    for (int j = 0; j < NJ; ++j) wf[fb][j] = *reinterpret_cast<const f16x8*>(sb + lds_off(wn * (NJ * 32) + j * 32 + li, ks * 2 + hi));
   };
   auto mma = [&](int fb) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[fb][j], af[fb][i], acc[i][j], 0, 0, 0);
+      for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[fb][j], af[fb][i], acc[i][j], 0, 0, 0);
   };
 
-  // MFMA / DS-read / VMEM interleave of one k-step (8 MFMA, 6 ds_read_b128, NV LDS-DMA pieces): a lone load between two
-  // MFMAs issues in the 32-cycle shadow of the running MFMA; the same loads issued back to back starve the matrix pipe
-  // (tools/ubench/lds_mix.hip: 6 reads + 2 pieces ahead of 8 MFMAs cost a lone wave 396 cycles per k-step instead of 260).
-#define FMX_INTERLEAVE(NV)                                                            \
-  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                 \
-  __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                 \
-  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                 \
-  __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                 \
-  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                 \
-  __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                 \
-  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                 \
-  __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                 \
-  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                 \
-  __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                 \
-  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                 \
-  __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                 \
-  if (NV > 0) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);                     \
-  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                 \
-  if (NV > 1) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);                     \
-  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                 \
-  if (NV > 2) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+  // MFMA / DS-read / VMEM interleave of one k-step: (MFMA, ds_read) x (MI + NJ), then the remaining MFMAs each preceded by
+  // one LDS-DMA piece, any left-over pieces last
+#define FMX_INTERLEAVE(NV)                                                                        \
+  {                                                                                               \
+    _Pragma("unroll") for (int q = 0; q < MI + NJ; ++q) {                                         \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                          \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                          \
+    }                                                                                             \
+    _Pragma("unroll") for (int q = 0; q < MI * NJ - MI - NJ; ++q) {                               \
+      if (q < (NV)) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);                            \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                          \
+    }                                                                                             \
+    _Pragma("unroll") for (int q = MI * NJ - MI - NJ; q < (NV); ++q) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0); \
+  }
 
   // ---- prologue: tile 0 complete, pieces 0-2 of tile 1 in flight ----------------------------------------------------------
   Cursor c1{0, 0, 0, 0};
   issue_piece(IC<0>{}, c1, 0); issue_piece(IC<1>{}, c1, 0); issue_piece(IC<2>{}, c1, 0); issue_piece(IC<3>{}, c1, 0);
   issue_piece(IC<4>{}, c1, 0); issue_piece(IC<5>{}, c1, 0); issue_piece(IC<6>{}, c1, 0); issue_piece(IC<7>{}, c1, 0);
+  issue_piece(IC<8>{}, c1, 0);
   advance(c1);  // c1 = tile 1
   issue_piece(IC<0>{}, c1, 1); issue_piece(IC<1>{}, c1, 1); issue_piece(IC<2>{}, c1, 1);
   asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   read_frags(0, 0, 0);
 
-  // iteration t:  k-step 0: + pieces 3-5 of tile t+1   k-step 1: + pieces 6-7 of tile t+1   k-step 2: nothing
+  // iteration t:  k-step 0: + pieces 3-5 of tile t+1   k-step 1: + pieces 6.. of tile t+1   k-step 2: nothing
   //               wait + barrier                          k-step 3: + pieces 0-2 of tile t+2 (into the stage just released)
 #ifdef FMX_ABLATE
   const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
@@ -229,8 +247,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
     __builtin_amdgcn_sched_barrier(0);
     read_frags(buf, 2, 0);
     mma(1);
-    issue_piece(IC<6>{}, c1, buf ^ 1); issue_piece(IC<7>{}, c1, buf ^ 1);
-    FMX_INTERLEAVE(2)
+    issue_piece(IC<6>{}, c1, buf ^ 1); issue_piece(IC<7>{}, c1, buf ^ 1); issue_piece(IC<8>{}, c1, buf ^ 1);
+    FMX_INTERLEAVE(NP - 6)
     __builtin_amdgcn_sched_barrier(0);
     read_frags(buf, 3, 1);
     mma(0);
@@ -257,41 +275,43 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   //      ONE pixel; stored as they are (even widened to 16 B by a half-wave swap, as fmx_gemm256.hip does) every store
   //      instruction scatters 32-byte pieces over 32 cache lines, and the tile's store tail measured 9.4 us per workgroup
   //      (tools/clock_gemm.py; 20 % of a K = 1280 tile, 35 % of a K = 640 tile) -- transaction-bound, not bandwidth-bound.
-  //      Here each wave transposes its 128 x 64 sub-tile through its private 16 KiB of the (now idle) staging LDS in fp32
-  //      (two passes of 64 rows; GEGLU: one pass of 128 rows x 32 outputs) and 8 (GEGLU: 4) lanes then own one output row:
-  //      residual loads and stores are whole 128-byte (64-byte) line segments.  16-byte chunks are XOR-swizzled by row on
-  //      both sides; the arithmetic (fp32, one rounding) is unchanged.
+  //      Here each wave transposes its sub-tile through a private slice of the (now idle) LDS in fp32, one 32-row block
+  //      row at a time (GEGLU: the whole sub-tile at once, it is half as wide), and NJ*4 (GEGLU: NJ*2) lanes then own one
+  //      output row: residual loads and stores are contiguous runs of NJ*64 (NJ*32) bytes.  16-byte chunks are
+  //      XOR-swizzled by row on both sides; the arithmetic (fp32, one rounding) is unchanged.
   __builtin_amdgcn_s_barrier();  // every wave is done reading the last stage: the LDS is free
-  char* my = smem + wave * 16384;
+  char* my = smem + wave * G::WAVE_EPI_BYTES;
   const FastEpilogue ep(p);
   const bool geglu = p.act == FMX_ACT_GEGLU;
   if (!geglu) {
-    const int cg = lane & 7, rsub = lane >> 3;
-    const int nb = n0 + wn * 64 + cg * 8;
-    const bool nok = nb < ep.nout;
-    const int nbc = nok ? nb : 0;
+    constexpr int RB = NJ * 128;       // staged row: NJ*32 fp32
+    constexpr int LPR = NJ * 4;        // lanes per output row (8 columns each)
+    constexpr int RPI = 64 / LPR;      // rows per wave instruction
+    constexpr int ITERS = (32 + RPI - 1) / RPI;
+    const int cg = lane % LPR, rsub = lane / LPR;
+    const int nb = n0 + wn * (NJ * 32) + cg * 8;
+    const bool nok = nb < ep.nout && rsub < RPI;
+    const int nbc = nb < ep.nout ? nb : 0;
     const f16x8 bb = ep.bias8(nbc);
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int i = 0; i < MI; ++i) {
 #pragma unroll
-      for (int i2 = 0; i2 < 2; ++i2)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) {
-            const int row = i2 * 32 + li, chunk = j * 8 + q4 * 2 + hi;
-            const f32x16& a = acc[pass * 2 + i2][j];
-            *reinterpret_cast<f32x4*>(my + row * 256 + ((chunk ^ (row & 15)) << 4)) = f32x4{a[q4 * 4], a[q4 * 4 + 1], a[q4 * 4 + 2], a[q4 * 4 + 3]};
-          }
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const int chunk = j * 8 + q4 * 2 + hi;
+          const f32x16& a = acc[i][j];
+          *reinterpret_cast<f32x4*>(my + li * RB + ((chunk ^ (li & 7)) << 4)) = f32x4{a[q4 * 4], a[q4 * 4 + 1], a[q4 * 4 + 2], a[q4 * 4 + 3]};
+        }
       // same wave wrote and reads: LDS operations of one wave execute in order, no barrier needed
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int row = it * 8 + rsub;
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(my + row * 256 + (((2 * cg) ^ (row & 15)) << 4));
-        const f32x4 hi4 = *reinterpret_cast<const f32x4*>(my + row * 256 + (((2 * cg + 1) ^ (row & 15)) << 4));
-        const int m = m0 + wm * 128 + pass * 64 + row;
-        const bool mok = m < p.M;
-        const int mc = mok ? m : p.M - 1;
+      for (int it = 0; it < ITERS; ++it) {
+        const int row = min(it * RPI + rsub, 31);
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(my + row * RB + (((2 * cg) ^ (row & 7)) << 4));
+        const f32x4 hi4 = *reinterpret_cast<const f32x4*>(my + row * RB + (((2 * cg + 1) ^ (row & 7)) << 4));
+        const int m = m0 + wm * (MI * 32) + i * 32 + row;
+        const bool mok = m < p.M && it * RPI + rsub < 32;
+        const int mc = m < p.M ? m : p.M - 1;
         const int img = mc / ep.per_img;
         const f16x8 rv = ep.rv8(img, nbc), rs = ep.res8(mc, nbc), gt = ep.gate8(img, nbc);
         float v[8];
@@ -305,25 +325,30 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
     }
   } else {
     // weight rows are interleaved [16 value | 16 gate] per 32-row block: registers q4 = 0,1 of a block are the values of
-    // output columns q4*8 + hi*4 + [0,4), registers q4 = 2,3 their gates (same lane).  Staged row = 32 outputs = 128 B.
-    int nbs[2][2];
-    f16x4 bv[2][2], bg[2][2];
+    // output columns q4*8 + hi*4 + [0,4), registers q4 = 2,3 their gates (same lane).  Staged row = NJ*16 outputs.
+    constexpr int RB = NJ * 64;
+    constexpr int LPR = NJ * 2;
+    constexpr int RPI = 64 / LPR;
+    constexpr int ROWS = MI * 32;
+    constexpr int ITERS = (ROWS + RPI - 1) / RPI;
+    int nbs[NJ][2];
+    f16x4 bv[NJ][2], bg[NJ][2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int q4 = 0; q4 < 2; ++q4) {
-        const int nb = n0 + wn * 64 + j * 32 + q4 * 8 + hi * 4;
+        const int nb = n0 + wn * (NJ * 32) + j * 32 + q4 * 8 + hi * 4;
         nbs[j][q4] = nb < ep.nout ? nb : 0;
         bv[j][q4] = ep.bias4(nbs[j][q4]);
         bg[j][q4] = ep.bias4(nbs[j][q4] + 16);
       }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int mrow = m0 + wm * 128 + i * 32 + li;
+    for (int i = 0; i < MI; ++i) {
+      const int mrow = m0 + wm * (MI * 32) + i * 32 + li;
       const int mc = mrow < p.M ? mrow : p.M - 1;
       const int img = mc / ep.per_img;
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int q4 = 0; q4 < 2; ++q4) {
           const f16x4 rvv = ep.rv4(img, nbs[j][q4]), rvg = ep.rv4(img, nbs[j][q4] + 16);
@@ -335,21 +360,21 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
             o[r] = val * gelu_erf_f(gate);
           }
           const int row = i * 32 + li, chunk = j * 4 + q4 * 2 + hi;
-          *reinterpret_cast<f32x4*>(my + row * 128 + ((chunk ^ (row & 7)) << 4)) = o;
+          *reinterpret_cast<f32x4*>(my + row * RB + ((chunk ^ (row & 3)) << 4)) = o;  // NJ*4 chunks per row: XOR of the low 2 bits stays inside
         }
     }
-    const int cg = lane & 3, rsub = lane >> 2;
-    const int col = ((n0 + wn * 64) >> 1) + cg * 8;
-    const bool nok = col < ep.ncols;
-    const int colc = nok ? col : 0;
+    const int cg = lane % LPR, rsub = lane / LPR;
+    const int col = ((n0 + wn * (NJ * 32)) >> 1) + cg * 8;
+    const bool nok = col < ep.ncols && rsub < RPI;
+    const int colc = col < ep.ncols ? col : 0;
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int row = it * 16 + rsub;
-      const f32x4 lo = *reinterpret_cast<const f32x4*>(my + row * 128 + (((2 * cg) ^ (row & 7)) << 4));
-      const f32x4 hi4 = *reinterpret_cast<const f32x4*>(my + row * 128 + (((2 * cg + 1) ^ (row & 7)) << 4));
-      const int m = m0 + wm * 128 + row;
-      const bool mok = m < p.M;
-      const int mc = mok ? m : p.M - 1;
+    for (int it = 0; it < ITERS; ++it) {
+      const int row = min(it * RPI + rsub, ROWS - 1);
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(my + row * RB + (((2 * cg) ^ (row & 3)) << 4));
+      const f32x4 hi4 = *reinterpret_cast<const f32x4*>(my + row * RB + (((2 * cg + 1) ^ (row & 3)) << 4));
+      const int m = m0 + wm * (MI * 32) + row;
+      const bool mok = m < p.M && it * RPI + rsub < ROWS;
+      const int mc = m < p.M ? m : p.M - 1;
       const f16x8 rs = ep.res8(mc, colc);
       float v[8];
 #pragma unroll
@@ -372,21 +397,27 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
 #endif
 }
 
-}  // namespace
-
-int fmx_launch_gemm256p(const GemmParams& p, bool conv, hipStream_t st) {
+template <int BN>
+int launch_bn(const GemmParams& p, bool conv, hipStream_t st) {
+  using G = Geo<BN>;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<true, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<false, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     attr_set = true;
   }
   GemmParams q = p;
   q.tiles_m = (p.M + BM - 1) / BM;
   q.tiles_n = (p.nout + BN - 1) / BN;
   const int grid = q.tiles_m * q.tiles_n;
-  if (conv) hipLaunchKernelGGL(gemm256p_kernel<true>, dim3(grid), dim3(512), LDS_BYTES, st, q);
-  else hipLaunchKernelGGL(gemm256p_kernel<false>, dim3(grid), dim3(512), LDS_BYTES, st, q);
-  FMX_LAUNCH_CHECK("fmx_gemm_conv_f16 (256x256 pipelined)");
+  if (conv) hipLaunchKernelGGL((gemm256p_kernel<true, BN>), dim3(grid), dim3(512), G::LDS_BYTES, st, q);
+  else hipLaunchKernelGGL((gemm256p_kernel<false, BN>), dim3(grid), dim3(512), G::LDS_BYTES, st, q);
+  FMX_LAUNCH_CHECK("fmx_gemm_conv_f16 (256-row pipelined)");
   return FMX_OK;
+}
+
+}  // namespace
+
+int fmx_launch_gemm256p(const GemmParams& p, bool conv, int bn, hipStream_t st) {
+  return bn == 320 ? launch_bn<320>(p, conv, st) : launch_bn<256>(p, conv, st);
 }

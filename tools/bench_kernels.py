@@ -82,13 +82,13 @@ def gemm_sweep():
            (Bu * 4096, 640, 640, 0), (Bu * 4096, 1280, 640, 0), (640, Bu * 4096, 640, 0), (Bu * 4096, 5120, 640, 1), (Bu * 4096, 640, 2560, 0),
            (8192, 8192, 8192, 0), (4096, 4096, 4096, 0)]
     for m, n, k, act in lin:
-        for tile in ((1, 6, 0) if act or n % 160 else (1, 5, 6, 0)):
+        for tile in ((6, 7, 0) if act else (5, 6, 7, 0) if n % 320 == 0 else (1, 6, 7, 0)):
             bench_linear(m, n, k, tile, act=act)
     conv = [(Bu, 32, 32, 1280, 1280, 1, None), (Bu, 32, 32, 2560, 1280, 1, None), (Bu, 64, 64, 640, 640, 1, None), (Bu, 64, 64, 1920, 640, 1, None),
             (Bu, 128, 128, 320, 320, 1, None), (Bu, 128, 128, 960, 320, 1, None), (Bu, 32, 32, 1280, 1280, 1, (64, 64)), (Bu, 64, 64, 640, 640, 1, (128, 128)),
             (Bu, 128, 128, 320, 320, 2, None), (Bu, 64, 64, 640, 640, 2, None), (8, 256, 256, 512, 512, 1, None), (8, 512, 512, 256, 256, 1, None)]
     for n, h, w, c, co, stride, up in conv:
-        for tile in ((1, 5, 6, 0) if co % 160 == 0 else (1, 6, 0)):
+        for tile in ((5, 6, 7, 0) if co % 160 == 0 else (1, 6, 7, 0)):
             bench_conv(n, h, w, c, co, tile, stride=stride, up=up)
 
 
