@@ -354,38 +354,39 @@ extern "C" int fmx_gemm_conv_f16(const fmx_gemm_args* a, void* stream) {
   p.a0_bytes = fits32 ? (unsigned)a0_span : 0;
   p.a1_bytes = fits32 ? (unsigned)a1_span : 0;
   p.w_bytes = fits32 ? (unsigned)w_span : 0;
-  // Tile choice by a cost model calibrated on tools/bench_kernels.py sweeps (profiles/*_gemm_sweep.jsonl):
-  //   time ~ rounds x tile area x (workgroups per CU) / efficiency,   rounds = ceil(tiles / (256 CUs x workgroups per CU)),
-  // efficiency = the kernel's steady-state rate relative to the 256x320 kernel, times kt / (kt + overhead in K-tiles): the
-  // 8-wave kernels own a CU alone, so their prologue + epilogue (~6 K-tiles' worth) is exposed once per tile; the 4-wave
-  // kernels run 2-4 workgroups per CU and hide most of it.  Padding rows / columns are counted through the tile area.
-  // sel: 0 = 128x128, 1 = 128x64, 2 = 64x64, 4 = 128x160, 5 = 256x256 pipelined, 6 = 256x320 pipelined (3 = ping-pong, test hook)
+  // Tile choice by a cost model fitted to tools/bench_kernels.py sweeps (profiles/r02o_gemm_sweep.jsonl).  In units of
+  // "one output element x one K-tile at the 256x320 kernel's steady-state rate":
+  //   time = rounds x wpc x ( area x (kt + e) / eff + F ),    rounds = ceil(tiles / (256 CUs x wpc)),
+  // wpc = resident workgroups per CU, eff = steady-state rate relative to the 256x320 kernel, e = epilogue cost per output
+  // element in K-tiles (it scales with the tile area), F = per-tile fixed latency (prologue + first loads, ~1.5 K-tiles of a
+  // 256x256 tile; half of it hides behind the CU's other workgroup for the 4-wave kernels).  Padding rows / columns are
+  // counted through the tile area.
+  // sel: 0 = 128x128, 1 = 128x64, 2 = 64x64, 4 = 128x160, 5 / 6 / 7 = 256x256 / 256x320 / 320x256 pipelined (3 = ping-pong, test hook)
   auto tiles = [&](int bm, int bn) { return (double)((p.M + bm - 1) / bm) * (double)((p.nout + bn - 1) / bn); };
   const double kt = p.kt;
-  auto cost = [&](int bm, int bn, int wpc, double eff, double ovh) {
+  const bool geglu = a->act == FMX_ACT_GEGLU;
+  auto cost = [&](int bm, int bn, int wpc, double eff, double e, double fixed) {
     const double rounds = ceil(tiles(bm, bn) / (256.0 * wpc));
-    return rounds * bm * bn * wpc / (eff * kt / (kt + ovh));
+    return rounds * wpc * ((double)bm * bn * (kt + e) / eff + fixed);
   };
   const bool big_ok = FastEpilogue::eligible8(p) && fits32;
-  const bool geglu = a->act == FMX_ACT_GEGLU;
-  // (efficiency, overhead) fitted to profiles/r02o_gemm_sweep.jsonl: steady-state TF/s / 1200 and the K-tiles' worth of
-  // exposed prologue + epilogue per tile; the GEGLU epilogue (erf) costs the 4-wave kernels about 3 K-tiles more
-  const double g4 = geglu ? 3.0 : 0.0;
+  const double e4 = geglu ? 5.0 : 2.0, F4 = 49152.0, e8 = 4.0, F8 = 98304.0;
   int sel = 2;
-  double best = cost(64, 64, 5, 0.45, 3.0 + g4);
+  double best = cost(64, 64, 5, 0.42, e4, F4);
   auto consider = [&](int id, double c) { if (c < best) { best = c; sel = id; } };
-  consider(1, cost(128, 64, 3, 0.62, 4.0 + g4));
-  consider(0, cost(128, 128, 2, 0.76, 4.5 + g4));
-  if (!geglu && (p.nout % 160) == 0) consider(4, cost(128, 160, 2, 0.87, 5.5));
-  if (big_ok) consider(5, cost(256, 256, 1, 0.96, 4.5));
-  if (big_ok && (!geglu || (p.nout % 32) == 0)) consider(6, cost(256, 320, 1, 1.0, 7.0));
-  if (a->out_f32 < 0) sel = (-a->out_f32 - 1) % 7;  // test hook: force a tile shape (out_f32 = -1..-7 -> fp16 out)
+  consider(1, cost(128, 64, 3, 0.58, e4, F4));
+  consider(0, cost(128, 128, 2, 0.70, e4, F4));
+  if (!geglu && (p.nout % 160) == 0) consider(4, cost(128, 160, 2, 0.80, e4, F4));
+  if (big_ok) consider(5, cost(256, 256, 1, 0.97, e8, F8));
+  if (big_ok && (!geglu || (p.nout % 32) == 0)) consider(6, cost(256, 320, 1, 1.0, e8, F8));
+  if (big_ok && !geglu) consider(7, cost(320, 256, 1, 1.0, e8, F8));
+  if (a->out_f32 < 0) sel = (-a->out_f32 - 1) % 8;  // test hook: force a tile shape (out_f32 = -1..-8 -> fp16 out)
   FMX_REQUIRE(sel != 4 || a->act != FMX_ACT_GEGLU, "gemm: the 128x160 tile does not support GEGLU");
   if (a->out_f32 < 0) p.out_f32 = 0;
-  if (sel == 3 || sel == 5 || sel == 6) {
+  if (sel == 3 || sel >= 5) {
     FMX_REQUIRE(FastEpilogue::eligible8(p) && fits32, "gemm: 256x256 kernel needs fp16 output, 16-byte aligned epilogue operands, leading dimensions / nout multiples of 8, operands < 2^32 elements");
     if (sel == 6) FMX_REQUIRE(a->act != FMX_ACT_GEGLU || (p.nout % 32) == 0, "gemm: GEGLU needs nout % 32 == 0");
-    return sel == 3 ? fmx_launch_gemm256(p, conv, st) : fmx_launch_gemm256p(p, conv, sel == 6 ? 320 : 256, st);
+    return sel == 3 ? fmx_launch_gemm256(p, conv, st) : fmx_launch_gemm256p(p, conv, sel == 7 ? 320 : 256, sel == 6 ? 320 : 256, st);
   }
   if (sel == 4) return conv ? launch<128, 160, true>(p, st) : launch<128, 160, false>(p, st);
   if (conv) {

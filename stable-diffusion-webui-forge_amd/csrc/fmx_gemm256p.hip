@@ -7,6 +7,7 @@
 //
 //   BN = 256: waves 2 (M) x 4 (N), wave tile 128 x 64  = 4 x 2 accumulator blocks of 32 x 32,  8 MFMA / 6 ds_read per k-step
 //   BN = 320: waves 4 (M) x 2 (N), wave tile  64 x 160 = 2 x 5 blocks,                        10 MFMA / 7 ds_read per k-step
+//   BM = 320 (x 256): waves 2 x 4, wave tile 160 x 64 = 5 x 2 blocks -- the same thing for the operand-swapped V^T GEMM
 //   (v_mfma_f32_32x32x16_f16, weights as MFMA-A, activations as MFMA-B).  320 is the native width of the SD family: every
 //   channel count is 320 k, so N = 320 / 640 / 1280 tile with no padding columns and (M, N) = (16384, 1280) is exactly
 //   256 tiles = one round of the 256 CUs (256-wide tiles: 320 tiles = 1.25 rounds), with 10 % fewer LDS-DMA bytes per FLOP.
@@ -26,7 +27,7 @@
 
 namespace {
 
-constexpr int BM = 256, BK = FMX_BK;
+constexpr int BK = FMX_BK;
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
@@ -42,22 +43,22 @@ struct Piece {  // one DMA instruction: per-lane byte offset, uniform byte offse
   bool second;
 };
 
-template <int BN>
+template <int BM, int BN>
 struct Geo {
-  static constexpr int WN = BN == 256 ? 4 : 2;          // waves along N
+  static constexpr int WN = BN == 320 ? 2 : 4;          // waves along N
   static constexpr int WM = 8 / WN;                     // waves along M
   static constexpr int MI = BM / (WM * 32);             // 32-row blocks per wave along M
   static constexpr int NJ = BN / (WN * 32);             // 32-col blocks per wave along N
   static constexpr int NPA = BM / 64, NPB = BN / 64;    // LDS-DMA pieces per wave per K-tile (8 rows x 128 B each)
   static constexpr int NP = NPA + NPB;
   static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
-  static constexpr int WAVE_EPI_BYTES = BN == 256 ? 16384 : 20480;  // per-wave transpose buffer of the epilogue
+  static constexpr int WAVE_EPI_BYTES = (BM == 256 && BN == 256) ? 16384 : 20480;  // per-wave transpose buffer of the epilogue
   static constexpr int LDS_BYTES = 2 * STAGE_BYTES > 8 * WAVE_EPI_BYTES ? 2 * STAGE_BYTES : 8 * WAVE_EPI_BYTES;  // 128 / 160 KiB
 };
 
-template <bool CONV, int BN>
+template <bool CONV, int BM, int BN>
 __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
-  using G = Geo<BN>;
+  using G = Geo<BM, BN>;
   constexpr int MI = G::MI, NJ = G::NJ, NPA = G::NPA, NPB = G::NPB, NP = G::NP;
   constexpr int STAGE_BYTES = G::STAGE_BYTES, A_BYTES = G::A_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -397,27 +398,28 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
 #endif
 }
 
-template <int BN>
+template <int BM, int BN>
 int launch_bn(const GemmParams& p, bool conv, hipStream_t st) {
-  using G = Geo<BN>;
+  using G = Geo<BM, BN>;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<true, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<false, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<true, BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<false, BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     attr_set = true;
   }
   GemmParams q = p;
   q.tiles_m = (p.M + BM - 1) / BM;
   q.tiles_n = (p.nout + BN - 1) / BN;
   const int grid = q.tiles_m * q.tiles_n;
-  if (conv) hipLaunchKernelGGL((gemm256p_kernel<true, BN>), dim3(grid), dim3(512), G::LDS_BYTES, st, q);
-  else hipLaunchKernelGGL((gemm256p_kernel<false, BN>), dim3(grid), dim3(512), G::LDS_BYTES, st, q);
+  if (conv) hipLaunchKernelGGL((gemm256p_kernel<true, BM, BN>), dim3(grid), dim3(512), G::LDS_BYTES, st, q);
+  else hipLaunchKernelGGL((gemm256p_kernel<false, BM, BN>), dim3(grid), dim3(512), G::LDS_BYTES, st, q);
   FMX_LAUNCH_CHECK("fmx_gemm_conv_f16 (256-row pipelined)");
   return FMX_OK;
 }
 
 }  // namespace
 
-int fmx_launch_gemm256p(const GemmParams& p, bool conv, int bn, hipStream_t st) {
-  return bn == 320 ? launch_bn<320>(p, conv, st) : launch_bn<256>(p, conv, st);
+int fmx_launch_gemm256p(const GemmParams& p, bool conv, int bm, int bn, hipStream_t st) {
+  if (bm == 320) return launch_bn<320, 256>(p, conv, st);
+  return bn == 320 ? launch_bn<256, 320>(p, conv, st) : launch_bn<256, 256>(p, conv, st);
 }

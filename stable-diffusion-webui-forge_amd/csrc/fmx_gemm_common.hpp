@@ -206,4 +206,4 @@ __device__ __forceinline__ void swap_halfwaves(float& a, float& b) {
 // 256x256-tile kernel (fmx_gemm256.hip)
 int fmx_launch_gemm256(const GemmParams& p, bool conv, hipStream_t st);
 // same tile, software-pipelined single-barrier schedule (fmx_gemm256p.hip)
-int fmx_launch_gemm256p(const GemmParams& p, bool conv, int bn, hipStream_t st);  // bn = 256 or 320
+int fmx_launch_gemm256p(const GemmParams& p, bool conv, int bm, int bn, hipStream_t st);  // (bm, bn) = (256,256) (256,320) (320,256)

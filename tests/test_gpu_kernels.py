@@ -31,9 +31,9 @@ def close(got, want, rtol, atol, what=""):
 
 # ----------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("m,n,k", [(256, 256, 128), (384, 320, 320), (77 * 2, 640, 768), (1000, 132, 64), (4096, 1280, 1280), (130, 4, 2880)])
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_linear_plain(m, n, k, tile):
-    if tile in (4, 6, 7) and n % 8:
+    if tile in (4, 6, 7, 8) and n % 8:
         pytest.skip("256x256 kernel needs nout % 8 == 0 (dispatcher never selects it otherwise)")
     x = rnd(m, k, seed=1)
     w = rnd(n, k, scale=1 / math.sqrt(k), seed=2)
@@ -100,9 +100,9 @@ def test_linear_two_source_and_vt():
     dict(n=2, h=16, w=16, c=128, co=4, kh=3, stride=1, pad=1),
     dict(n=2, h=12, w=12, c=64, co=128, kh=1, stride=1, pad=0),
 ])
-@pytest.mark.parametrize("tile", [0, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("tile", [0, 3, 4, 5, 6, 7, 8])
 def test_conv(cfg, tile):
-    if tile in (4, 6, 7) and cfg["co"] % 8:
+    if tile in (4, 6, 7, 8) and cfg["co"] % 8:
         pytest.skip("256x256 kernel needs nout % 8 == 0")
     n, h, w, c, co, kh = cfg["n"], cfg["h"], cfg["w"], cfg["c"], cfg["co"], cfg["kh"]
     x = rnd(n, h, w, c, seed=20)
@@ -124,7 +124,7 @@ def test_conv(cfg, tile):
 
 # ---- 256x256 kernels (force_tile=t256: ping-pong schedule, 6: software-pipelined single-barrier schedule): epilogues, GEGLU, two sources, ragged M / N, long K, tail handling ----
 @pytest.mark.parametrize("m,n,k", [(256, 256, 64), (512, 512, 128), (300, 264, 192), (1000, 1280, 1280), (4096, 640, 2560), (2048, 320, 320)])
-@pytest.mark.parametrize("t256", [4, 6, 7])
+@pytest.mark.parametrize("t256", [4, 6, 7, 8])
 def test_gemm256_epilogues(m, n, k, t256):
     x, w, b = rnd(m, k, seed=100), rnd(n, k, scale=1 / math.sqrt(k), seed=101), rnd(n, seed=102)
     res = rnd(m, n, seed=103)
@@ -135,7 +135,7 @@ def test_gemm256_epilogues(m, n, k, t256):
     close(r2, x.float() @ w.float().t() + res.float(), 2e-3, 2e-3, "gemm256 in-place residual")
 
 
-@pytest.mark.parametrize("t256", [4, 6, 7])
+@pytest.mark.parametrize("t256", [4, 6, 7, 8])
 def test_gemm256_identity_asymmetric(t256):
     m = n = k = 512
     x = torch.eye(m, dtype=torch.float16, device=DEV)
@@ -145,7 +145,7 @@ def test_gemm256_identity_asymmetric(t256):
 
 
 @pytest.mark.parametrize("m,k,inner", [(512, 320, 1280), (300, 640, 2560 + 16)])
-@pytest.mark.parametrize("t256", [4, 6, 7])
+@pytest.mark.parametrize("t256", [4, 6, 7, 8])
 def test_gemm256_geglu(m, k, inner, t256):
     x = rnd(m, k, seed=110)
     w = rnd(2 * inner, k, scale=1 / math.sqrt(k), seed=111)
@@ -157,7 +157,7 @@ def test_gemm256_geglu(m, k, inner, t256):
     close(out, a * F.gelu(g), 3e-3, 3e-3, "gemm256 geglu")
 
 
-@pytest.mark.parametrize("t256", [4, 6, 7])
+@pytest.mark.parametrize("t256", [4, 6, 7, 8])
 def test_gemm256_two_source_conv_and_swapped(t256):
     n, h, w, c0, c1, co = 2, 24, 24, 128, 64, 256
     x0, x1 = rnd(n, h, w, c0, seed=120), rnd(n, h, w, c1, seed=121)
@@ -173,7 +173,7 @@ def test_gemm256_two_source_conv_and_swapped(t256):
     close(vt, wv.float() @ xa.float().t(), 2e-3, 2e-3, "gemm256 swapped operands")
 
 
-@pytest.mark.parametrize("t256", [4, 6, 7])
+@pytest.mark.parametrize("t256", [4, 6, 7, 8])
 def test_gemm256_matches_small_tile_bitwise_class(t256):
     # same K order and fp32 accumulation in both kernels: results agree to fp16 rounding of the same fp32 sums
     m, n, k = 768, 512, 1280
