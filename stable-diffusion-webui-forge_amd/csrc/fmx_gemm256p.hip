@@ -56,6 +56,60 @@ struct Geo {
   static constexpr int LDS_BYTES = 2 * STAGE_BYTES > 8 * WAVE_EPI_BYTES ? 2 * STAGE_BYTES : 8 * WAVE_EPI_BYTES;  // 128 / 160 KiB
 };
 
+// Row pass of the epilogue: RB-byte fp32 rows staged in this wave's LDS slice -> 8 output columns per lane, LPR lanes per
+// row.  v = act(a * alpha + bias + rowvec[image]) * gate + residual, fp16 store.  The pointers are __restrict__ PARAMETERS
+// on purpose: the output may be the residual itself (in-place `x += f(x)`), and without the no-alias promise the compiler
+// makes every later global load wait (s_waitcnt vmcnt(0)) for every earlier store to COMPLETE -- one full store round trip
+// per iteration, 9-15 us of epilogue per tile (tools/clock_gemm.py).  The promise is safe here: an element is read and
+// written by the same lane only, and its store depends on its load through registers.
+// MODE 0: bias + rowvec + gate + residual;  1: bias + residual;  2: bias only (the absent operands cost a load each otherwise)
+template <int RB, int LPR, int ROWS, int SWZ, bool TANH, int MODE>
+__device__ __forceinline__ void epi_rows(const char* my, int lane, int mbase, int M, int /*col*/, bool nok, int per_img, float alpha, float has_gate,
+                                         const f16* __restrict__ bias, const f16* __restrict__ rowvec, long ld_rv, const f16* __restrict__ gate, long ld_gt,
+                                         const f16* __restrict__ res, long ld_res, f16* __restrict__ out, long ld_out) {
+  constexpr int RPI = 64 / LPR;  // rows per wave instruction
+  constexpr int ITERS = (ROWS + RPI - 1) / RPI;
+  // opaque copy: keeps the compiler from hoisting the ITERS x 2 LDS offsets of EVERY call of this function above the whole
+  // epilogue (they are loop-invariant across the block rows) -- 35 spilled registers in the 160-accumulator tile otherwise
+  asm volatile("" : "+v"(lane));
+  const int cg = lane % LPR, rsub = lane / LPR;
+  const f16x8 bb = *reinterpret_cast<const f16x8*>(bias);
+  // vmcnt retires in order, loads and stores alike: an iteration that loads its operands AFTER the previous iteration's
+  // store waits for that store to complete.  So the operands of iteration it+1 are requested before iteration it stores.
+  f16x8 rv[2], gt[2], rs[2];
+  auto fetch = [&](int it, int slot) {
+    const int row = min(it * RPI + rsub, ROWS - 1);
+    const int m = mbase + row;
+    const int mc = m < M ? m : M - 1;
+    const int img = mc / per_img;
+    if (MODE == 0) rv[slot] = *reinterpret_cast<const f16x8*>(rowvec + img * ld_rv);
+    if (MODE == 0) gt[slot] = *reinterpret_cast<const f16x8*>(gate + img * ld_gt);
+    if (MODE <= 1) rs[slot] = *reinterpret_cast<const f16x8*>(res + mc * ld_res);
+  };
+  fetch(0, 0);
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int cur = it & 1;
+    if (it + 1 < ITERS) fetch(it + 1, cur ^ 1);
+    const int row = min(it * RPI + rsub, ROWS - 1);
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(my + row * RB + (((2 * cg) ^ (row & SWZ)) << 4));
+    const f32x4 hi4 = *reinterpret_cast<const f32x4*>(my + row * RB + (((2 * cg + 1) ^ (row & SWZ)) << 4));
+    const int m = mbase + row;
+    const bool ok = nok && m < M && rsub < RPI && it * RPI + rsub < ROWS;
+    f16x8 hv;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      float v = (r < 4 ? lo[r & 3] : hi4[r & 3]) * alpha + (float)bb[r];
+      if (MODE == 0) v += (float)rv[cur][r];
+      if (TANH) v = gelu_tanh_f(v);
+      if (MODE == 0) v *= fmaf(has_gate, (float)gt[cur][r] - 1.0f, 1.0f);
+      if (MODE <= 1) v += (float)rs[cur][r];
+      hv[r] = (f16)v;
+    }
+    if (ok) *reinterpret_cast<f16x8*>(out + m * ld_out) = hv;
+  }
+}
+
 template <bool CONV, int BM, int BN>
 __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   using G = Geo<BM, BN>;
@@ -274,12 +328,11 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
 
   // ---- epilogue: through LDS, so that every global access is row-contiguous.  The MFMA leaves a lane with 4-channel runs of
   //      ONE pixel; stored as they are (even widened to 16 B by a half-wave swap, as fmx_gemm256.hip does) every store
-  //      instruction scatters 32-byte pieces over 32 cache lines, and the tile's store tail measured 9.4 us per workgroup
-  //      (tools/clock_gemm.py; 20 % of a K = 1280 tile, 35 % of a K = 640 tile) -- transaction-bound, not bandwidth-bound.
-  //      Here each wave transposes its sub-tile through a private slice of the (now idle) LDS in fp32, one 32-row block
-  //      row at a time (GEGLU: the whole sub-tile at once, it is half as wide), and NJ*4 (GEGLU: NJ*2) lanes then own one
-  //      output row: residual loads and stores are contiguous runs of NJ*64 (NJ*32) bytes.  16-byte chunks are
-  //      XOR-swizzled by row on both sides; the arithmetic (fp32, one rounding) is unchanged.
+  //      instruction scatters 32-byte pieces over 32 cache lines (transaction-bound, not bandwidth-bound).  Here each wave
+  //      transposes its sub-tile through a private slice of the (now idle) LDS in fp32, one 32-row block row at a time
+  //      (GEGLU: the whole sub-tile at once, it is half as wide), and NJ*4 (GEGLU: NJ*2) lanes then own one output row:
+  //      residual loads and stores are contiguous runs of NJ*64 (NJ*32) bytes.  16-byte chunks are XOR-swizzled by row on
+  //      both sides; the arithmetic (fp32, one rounding) is unchanged.  The row pass itself lives in epi_rows() below.
   __builtin_amdgcn_s_barrier();  // every wave is done reading the last stage: the LDS is free
   char* my = smem + wave * G::WAVE_EPI_BYTES;
   const FastEpilogue ep(p);
@@ -287,13 +340,10 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   if (!geglu) {
     constexpr int RB = NJ * 128;       // staged row: NJ*32 fp32
     constexpr int LPR = NJ * 4;        // lanes per output row (8 columns each)
-    constexpr int RPI = 64 / LPR;      // rows per wave instruction
-    constexpr int ITERS = (32 + RPI - 1) / RPI;
-    const int cg = lane % LPR, rsub = lane / LPR;
+    const int cg = lane % LPR;
     const int nb = n0 + wn * (NJ * 32) + cg * 8;
-    const bool nok = nb < ep.nout && rsub < RPI;
-    const int nbc = nb < ep.nout ? nb : 0;
-    const f16x8 bb = ep.bias8(nbc);
+    const bool nok = nb < ep.nout;
+    const int nbc = nok ? nb : 0;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -305,83 +355,58 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
           *reinterpret_cast<f32x4*>(my + li * RB + ((chunk ^ (li & 7)) << 4)) = f32x4{a[q4 * 4], a[q4 * 4 + 1], a[q4 * 4 + 2], a[q4 * 4 + 3]};
         }
       // same wave wrote and reads: LDS operations of one wave execute in order, no barrier needed
-#pragma unroll
-      for (int it = 0; it < ITERS; ++it) {
-        const int row = min(it * RPI + rsub, 31);
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(my + row * RB + (((2 * cg) ^ (row & 7)) << 4));
-        const f32x4 hi4 = *reinterpret_cast<const f32x4*>(my + row * RB + (((2 * cg + 1) ^ (row & 7)) << 4));
-        const int m = m0 + wm * (MI * 32) + i * 32 + row;
-        const bool mok = m < p.M && it * RPI + rsub < 32;
-        const int mc = m < p.M ? m : p.M - 1;
-        const int img = mc / ep.per_img;
-        const f16x8 rv = ep.rv8(img, nbc), rs = ep.res8(mc, nbc), gt = ep.gate8(img, nbc);
-        float v[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          const float a = r < 4 ? lo[r & 3] : hi4[r & 3];
-          v[r] = ep.act_gate(a * ep.alpha + (float)bb[r] + (float)rv[r], (float)gt[r]) + (float)rs[r];
-        }
-        if (mok && nok) ep.store8(m, nbc, v);
-      }
+      const int mbase = m0 + wm * (MI * 32) + i * 32;
+#define FMX_EPI_ARGS my, lane, mbase, p.M, nbc, nok, ep.per_img, ep.alpha, (float)ep.mgt, ep.bias + nbc * ep.mb, ep.rowvec + nbc * ep.mrv, ep.ld_rv, \
+                     ep.gate + nbc * ep.mgt, ep.ld_gt, ep.res + nbc * ep.mres, ep.ld_res, ep.out + nbc, ep.ld_out
+      if (ep.gelu_tanh) epi_rows<RB, LPR, 32, 7, true, 0>(FMX_EPI_ARGS);       // uniform branches
+      else if (ep.mrv | ep.mgt) epi_rows<RB, LPR, 32, 7, false, 0>(FMX_EPI_ARGS);
+      else if (ep.mres) epi_rows<RB, LPR, 32, 7, false, 1>(FMX_EPI_ARGS);
+      else epi_rows<RB, LPR, 32, 7, false, 2>(FMX_EPI_ARGS);
+#undef FMX_EPI_ARGS
     }
   } else {
     // weight rows are interleaved [16 value | 16 gate] per 32-row block: registers q4 = 0,1 of a block are the values of
     // output columns q4*8 + hi*4 + [0,4), registers q4 = 2,3 their gates (same lane).  Staged row = NJ*16 outputs.
     constexpr int RB = NJ * 64;
     constexpr int LPR = NJ * 2;
-    constexpr int RPI = 64 / LPR;
     constexpr int ROWS = MI * 32;
-    constexpr int ITERS = (ROWS + RPI - 1) / RPI;
-    int nbs[NJ][2];
-    f16x4 bv[NJ][2], bg[NJ][2];
+    int mcs[MI], imgs[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int mrow = m0 + wm * (MI * 32) + i * 32 + li;
+      mcs[i] = mrow < p.M ? mrow : p.M - 1;
+      imgs[i] = mcs[i] / ep.per_img;
+    }
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int q4 = 0; q4 < 2; ++q4) {
         const int nb = n0 + wn * (NJ * 32) + j * 32 + q4 * 8 + hi * 4;
-        nbs[j][q4] = nb < ep.nout ? nb : 0;
-        bv[j][q4] = ep.bias4(nbs[j][q4]);
-        bg[j][q4] = ep.bias4(nbs[j][q4] + 16);
-      }
+        const int nbc = nb < ep.nout ? nb : 0;
+        const f16x4 bv = ep.bias4(nbc), bg = ep.bias4(nbc + 16);  // few live registers: the 160-accumulator tile has none to spare
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int mrow = m0 + wm * (MI * 32) + i * 32 + li;
-      const int mc = mrow < p.M ? mrow : p.M - 1;
-      const int img = mc / ep.per_img;
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int q4 = 0; q4 < 2; ++q4) {
-          const f16x4 rvv = ep.rv4(img, nbs[j][q4]), rvg = ep.rv4(img, nbs[j][q4] + 16);
+        for (int i = 0; i < MI; ++i) {
+          const f16x4 rvv = ep.rv4(imgs[i], nbc), rvg = ep.rv4(imgs[i], nbc + 16);
           f32x4 o;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float val = acc[i][j][q4 * 4 + r] * ep.alpha + (float)bv[j][q4][r] + (float)rvv[r];
-            const float gate = acc[i][j][8 + q4 * 4 + r] * ep.alpha + (float)bg[j][q4][r] + (float)rvg[r];
+            const float val = acc[i][j][q4 * 4 + r] * ep.alpha + (float)bv[r] + (float)rvv[r];
+            const float gate = acc[i][j][8 + q4 * 4 + r] * ep.alpha + (float)bg[r] + (float)rvg[r];
             o[r] = val * gelu_erf_f(gate);
           }
           const int row = i * 32 + li, chunk = j * 4 + q4 * 2 + hi;
           *reinterpret_cast<f32x4*>(my + row * RB + ((chunk ^ (row & 3)) << 4)) = o;  // NJ*4 chunks per row: XOR of the low 2 bits stays inside
         }
-    }
-    const int cg = lane % LPR, rsub = lane / LPR;
+      }
+    const int cg = lane % LPR;
     const int col = ((n0 + wn * (NJ * 32)) >> 1) + cg * 8;
-    const bool nok = col < ep.ncols && rsub < RPI;
-    const int colc = col < ep.ncols ? col : 0;
-#pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-      const int row = min(it * RPI + rsub, ROWS - 1);
-      const f32x4 lo = *reinterpret_cast<const f32x4*>(my + row * RB + (((2 * cg) ^ (row & 3)) << 4));
-      const f32x4 hi4 = *reinterpret_cast<const f32x4*>(my + row * RB + (((2 * cg + 1) ^ (row & 3)) << 4));
-      const int m = m0 + wm * (MI * 32) + row;
-      const bool mok = m < p.M && it * RPI + rsub < ROWS;
-      const int mc = m < p.M ? m : p.M - 1;
-      const f16x8 rs = ep.res8(mc, colc);
-      float v[8];
-#pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] = (r < 4 ? lo[r & 3] : hi4[r & 3]) + (float)rs[r];
-      if (mok && nok) ep.store8(m, colc, v);
-    }
+    const bool nok = col < ep.ncols;
+    const int colc = nok ? col : 0;
+    // bias / rowvec / act were applied above: the row pass only adds the residual (alpha = 1, every other operand -> zero page)
+    if (ep.mres) epi_rows<RB, LPR, ROWS, 3, false, 1>(my, lane, m0 + wm * (MI * 32), p.M, colc, nok, ep.per_img, 1.0f, 0.0f, p.zp, p.zp, 0L, p.zp, 0L,
+                                                       ep.res + colc, ep.ld_res, ep.out + colc, ep.ld_out);
+    else epi_rows<RB, LPR, ROWS, 3, false, 2>(my, lane, m0 + wm * (MI * 32), p.M, colc, nok, ep.per_img, 1.0f, 0.0f, p.zp, p.zp, 0L, p.zp, 0L, p.zp, 0L,
+                                               ep.out + colc, ep.ld_out);
   }
 #ifdef FMX_ABLATE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

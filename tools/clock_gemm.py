@@ -8,17 +8,19 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import forge_amd  # noqa
 from forge_amd import hipops as ops
 
-for (m, n, k, reps, act) in [(4096, 4096, 4096, 200, 0), (16384, 10240, 1280, 60, 0), (16384, 10240, 1280, 60, 1), (65536, 5120, 640, 60, 1), (16384, 2560, 1280, 100, 0)]:
+TILE = int(os.environ.get("FMX_TILE", "6"))
+BN = 320 if TILE == 7 else 256
+for (m, n, k, reps, act) in [(16384, 1280, 1280, 200, 0), (16384, 10240, 1280, 60, 1), (65536, 640, 640, 200, 0), (16384, 1280, 5120, 100, 0)]:
     for data in ("randn",):
         x = (torch.randn(m, k, device="cuda") if data == "randn" else torch.zeros(m, k, device="cuda")).half()
         w = (torch.randn(n, k, device="cuda") * k ** -0.5 if data == "randn" else torch.zeros(n, k, device="cuda")).half()
         out = torch.zeros(m, n // 2 if act else n, dtype=torch.float16, device="cuda")
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(3):
-            ops.conv_gemm(x, w, n, out=out, ld_out=out.shape[1], act=act, force_tile=6)
+            ops.conv_gemm(x, w, n, out=out, ld_out=out.shape[1], act=act, force_tile=TILE)
         s.record()
         for _ in range(reps):
-            ops.conv_gemm(x, w, n, out=out, ld_out=out.shape[1], act=act, force_tile=6)
+            ops.conv_gemm(x, w, n, out=out, ld_out=out.shape[1], act=act, force_tile=TILE)
         e.record()
         torch.cuda.synchronize()
         t = s.elapsed_time(e) / reps * 1e-3
@@ -30,7 +32,7 @@ for (m, n, k, reps, act) in [(4096, 4096, 4096, 200, 0), (16384, 10240, 1280, 60
         i = int(idx[0]) - 3
         cyc, rt, kt = [int(v) & 0xffffffff for v in words[i:i + 3].tolist()]
         pro, epi = [int(v) & 0xffffffff for v in words[i + 4:i + 6].tolist()]
-        tiles = -(-m // 256) * -(-n // 256)
+        tiles = -(-m // 256) * -(-n // BN)
         rounds = -(-tiles // 256)
         print(f"   per workgroup: prologue {pro * 10} ns, K loop {rt * 10} ns, epilogue+store drain {epi * 10} ns; kernel wall {t * 1e6:.1f} us over {rounds} round(s) "
               f"-> {t * 1e6 / rounds:.1f} us per round vs {(pro + rt + epi) * 0.01:.1f} us inside the workgroup")
