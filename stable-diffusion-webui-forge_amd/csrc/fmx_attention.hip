@@ -16,6 +16,8 @@
 // double buffered, swizzled for conflict-free ds_read_b128.  Row sums stay per-lane partials (the
 // cross-half add happens once at the end); the accumulator rescale is skipped wave-uniformly when no
 // running max moved.
+#include <stdlib.h>
+
 #include "fmx_common.hpp"
 
 namespace {
@@ -218,6 +220,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 // LDS-DMA instructions per MFMA -- on MI355X both cost matrix-pipe time (a DMA instruction does not issue while the
 // SIMD's other wave streams MFMAs, see fmx_gemm256.hip).  ~215 VGPRs -> 2 waves per SIMD, softmax VALU of one wave
 // under the MFMAs of the other.
+template <int PRIO>
 __global__ __launch_bounds__(256, 2) void attn_q64_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int DP = 64, DSTEPS = 4, DVT = 2, CPR = 8;
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void attn_q64_kernel(const AttnParams p) {
     const char* sv = sk + KBYTES;
 
     f32x16 sacc[2][2];  // [32-key sub-tile][query fragment]
-    __builtin_amdgcn_s_setprio(1);
+    if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
 #pragma unroll
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void attn_q64_kernel(const AttnParams p) {
         for (int a = 0; a < 2; ++a) sacc[s][a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[a][ds], sacc[s][a], 0, 0, 0);
       }
     }
-    __builtin_amdgcn_s_setprio(0);
+    if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
     if ((kt + 1) * KVB > p.nk) {  // ragged tail: mask keys >= nk (wave-uniform branch)
 #pragma unroll
       for (int s = 0; s < 2; ++s)
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void attn_q64_kernel(const AttnParams p) {
           for (int r = 0; r < 16; ++r) oacc[i][a][r] *= alpha[a];
     }
 
-    __builtin_amdgcn_s_setprio(1);
+    if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int dt = 0; dt < DVT; ++dt) {
       const int row = dt * 32 + li;
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void attn_q64_kernel(const AttnParams p) {
           for (int a = 0; a < 2; ++a) oacc[dt][a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[a][s][j], oacc[dt][a], 0, 0, 0);
         }
     }
-    __builtin_amdgcn_s_setprio(0);
+    if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
     wait_vmcnt0();
     __syncthreads();
   }
@@ -390,14 +393,19 @@ __global__ __launch_bounds__(256, 2) void attn_q64_kernel(const AttnParams p) {
 
 int launch_attn_q64(AttnParams p, hipStream_t st) {
   const int smem = 2 * (KVB * 64 * 2 + 2 * 32 * 128);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_q64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
+  static int prio = -1;
+  if (prio < 0) {
+    // A/B knob (tools/bench_kernels.py attn): s_setprio flips around the MFMA bursts.  Measured on MI355X: without them
+    // 811 vs 793 TF/s at N = 4096 -- the partner wave's softmax VALU starves behind a prioritised MFMA stream -- so default off.
+    const char* e = getenv("FMX_ATTN_PRIO");
+    prio = e ? atoi(e) : 0;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_q64_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_q64_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   }
   p.qtiles = (p.nq + 255) / 256;
   const int grid = p.qtiles * p.heads * p.batch;
-  hipLaunchKernelGGL(attn_q64_kernel, dim3(grid), dim3(256), smem, st, p);
+  if (prio == 1) hipLaunchKernelGGL(attn_q64_kernel<1>, dim3(grid), dim3(256), smem, st, p);
+  else hipLaunchKernelGGL(attn_q64_kernel<0>, dim3(grid), dim3(256), smem, st, p);
   FMX_LAUNCH_CHECK("fmx_attention_f16 (q64)");
   return FMX_OK;
 }
