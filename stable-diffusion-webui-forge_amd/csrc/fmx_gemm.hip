@@ -379,7 +379,7 @@ extern "C" int fmx_gemm_conv_f16(const fmx_gemm_args* a, void* stream) {
   if (!geglu && (p.nout % 160) == 0) consider(4, cost(128, 160, 2, 0.80, e4, F4));
   if (big_ok) consider(5, cost(256, 256, 1, 0.97, e8, F8));
   if (big_ok && (!geglu || (p.nout % 32) == 0)) consider(6, cost(256, 320, 1, 1.0, e8, F8));
-  if (big_ok && !geglu) consider(7, cost(320, 256, 1, 1.0, e8, F8));
+  if (big_ok && !geglu) consider(7, cost(320, 256, 1, 0.97, e8, F8));  // only where its row quantisation wins (M = 320 k: the V^T GEMM)
   if (a->out_f32 < 0) sel = (-a->out_f32 - 1) % 8;  // test hook: force a tile shape (out_f32 = -1..-8 -> fp16 out)
   FMX_REQUIRE(sel != 4 || a->act != FMX_ACT_GEGLU, "gemm: the 128x160 tile does not support GEGLU");
   if (a->out_f32 < 0) p.out_f32 = 0;
