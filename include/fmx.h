@@ -203,6 +203,13 @@ int fmx_im2col3x3_smallc(const void* x, int32_t ldx, int32_t n, int32_t c, int32
 /* VAE output: y fp16 NHWC [b*h*w][ld] (first c channels) -> clamp((y+1)/2, 0, 1) fp32 NHWC [b][h][w][c] */
 int fmx_vae_unpack_image(const void* y, int32_t ld, int64_t npix, int32_t c, float* out, void* stream);
 
+/* Posterior sample of the VAE encoder (backend/nn/vae.py:16-29 DiagonalGaussianDistribution.sample, :312-313 process_in):
+ *   out[b][c][p] = (mean + exp(0.5 * clamp(logvar, -30, 20)) * noise[b][c][p] - shift) * scale
+ * moments: fp16 [B*npix][ld], channels 0..lc-1 = mean, lc..2lc-1 = logvar (the quant_conv output, NHWC);
+ * noise / out: fp32 NCHW [B][lc][npix].  scale = 1, shift = 0 gives the raw sample. */
+int fmx_vae_sample_posterior(const void* moments, int32_t ld, const float* noise, int32_t b, int32_t lc, int64_t npix, float scale, float shift,
+                             float* out, void* stream);
+
 /* Philox4x32-10 + Box-Muller ("NV" noise source, modules/rng_philox.py:32-102): out[i], i < n, for
  * counter (offset, 0, i, 0) and key = seed.  If raw_u32 != null also stores the 4 raw words per i. */
 int fmx_philox_randn(uint64_t seed, uint32_t offset, float* out, uint32_t* raw_u32, int64_t n, void* stream);

@@ -84,6 +84,26 @@ def gen_vae(name, cfg, b=2, hw=8):
     print(name, "decode", tuple(out.shape), float(out.std()))
 
 
+def gen_vae_encode(name, cfg, b=2, h=32, w=48):
+    """Encoder + quant_conv of the real reference (vae.py:183-200, :296-298) on a seeded image in [-1, 1]; the posterior sample
+    with an explicit noise tensor (the reference draws torch.randn on the CPU default generator, vae.py:28)."""
+    sd = synth.synth_vae_state_dict(cfg, seed=1)
+    vae = ref_import.build_ref_vae(cfg)
+    missing = vae.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys and not missing.missing_keys, missing
+    g = torch.Generator("cpu").manual_seed(9)
+    x = torch.rand(b, 3, h, w, generator=g) * 2 - 1
+    with torch.no_grad():
+        moments = vae.quant_conv(vae.encoder(x))
+        torch.manual_seed(123)
+        sample = vae.encode(x)          # mean + std * torch.randn(shape) under seed 123
+        torch.manual_seed(123)
+        noise = torch.randn(sample.shape)
+        latent = vae.process_in(sample)
+    torch.save({"x": x, "moments": moments, "noise": noise, "sample": sample, "process_in": latent}, os.path.join(GOLD, f"{name}_encode.pt"))
+    print(name, "encode", tuple(moments.shape), float(moments.std()))
+
+
 class _Hijack:
     """modules/sd_samplers_common.py:214-235 TorchHijack stand-in."""
 
@@ -262,6 +282,7 @@ def main():
         net, _ = gen_unet("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG)
         gen_samples("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG, net)
         gen_vae("tiny_vae", synth.TINY_VAE_CONFIG)
+        gen_vae_encode("tiny_vae", synth.TINY_VAE_CONFIG)
     if a.only in ("", "flux"):
         gen_flux()
     if a.full or a.only == "full":

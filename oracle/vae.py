@@ -61,6 +61,44 @@ def vae_decode(sd, z):
     return h
 
 
+@torch.no_grad()
+def vae_encode_moments(sd, x):
+    """Encoder.forward (vae.py:183-200) + quant_conv (:297-298): x [B,3,H,W] in [-1,1] -> moments [B, 2*lc, H/f, W/f]."""
+    h = _conv(sd, "encoder.conv_in", x)
+    nlev = 0
+    while f"encoder.down.{nlev}.block.0.norm1.weight" in sd:
+        nlev += 1
+    for lev in range(nlev):
+        i = 0
+        while f"encoder.down.{lev}.block.{i}.norm1.weight" in sd:
+            h = _resnet(sd, f"encoder.down.{lev}.block.{i}", h)
+            i += 1
+        if lev != nlev - 1:
+            h = F.pad(h, (0, 1, 0, 1), mode="constant", value=0)  # Downsample (vae.py:67-70): pad right/bottom, stride 2
+            h = F.conv2d(h, sd[f"encoder.down.{lev}.downsample.conv.weight"], sd[f"encoder.down.{lev}.downsample.conv.bias"], stride=2)
+    h = _resnet(sd, "encoder.mid.block_1", h)
+    h = _attn(sd, "encoder.mid.attn_1", h)
+    h = _resnet(sd, "encoder.mid.block_2", h)
+    h = _conv(sd, "encoder.conv_out", F.silu(_gn(sd, "encoder.norm_out", h)))
+    if "quant_conv.weight" in sd:
+        h = _conv(sd, "quant_conv", h, 0)
+    return h
+
+
+def posterior_sample(moments, noise):
+    """DiagonalGaussianDistribution (vae.py:16-29): mean + exp(0.5 * clamp(logvar, -30, 20)) * noise."""
+    mean, logvar = torch.chunk(moments, 2, dim=1)
+    return mean + torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0)) * noise
+
+
+def encode_first_stage(sd, x, scaling_factor, shift_factor=0.0, noise=None):
+    """diffusion_engine/sd15.py:75-78 + patcher/vae.py:172-174: x [B,3,H,W] in [-1,1] -> process_in(sample)."""
+    m = vae_encode_moments(sd, x.float())
+    if noise is None:
+        noise = torch.randn(m.shape[0], m.shape[1] // 2, m.shape[2], m.shape[3])  # vae.py:28: CPU default generator
+    return (posterior_sample(m, noise) - shift_factor) * scaling_factor  # process_in (vae.py:312-313)
+
+
 def process_out(latent, scaling_factor, shift_factor=0.0):
     return latent / scaling_factor + shift_factor  # vae.py:315
 

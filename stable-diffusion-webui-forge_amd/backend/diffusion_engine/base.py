@@ -38,6 +38,14 @@ class ForgeDiffusionEngine:
         sample = vae.decode(sample).movedim(-1, 1) * 2.0 - 1.0
         return sample.to(x)
 
+    @torch.inference_mode()
+    def encode_first_stage(self, x):
+        """sd15.py:75-78: x NCHW in [-1, 1] -> process_in(vae.encode(NHWC in [0, 1]))."""
+        vae = self.forge_objects.vae
+        sample = vae.encode(x.movedim(1, -1) * 0.5 + 0.5)
+        sample = vae.first_stage_model.process_in(sample)
+        return sample.to(x)
+
     def get_learned_conditioning(self, prompt):
         raise NotImplementedError("text encoders are out of scope (SURVEY.md §2.2): pass cond tensors to the processing object")
 

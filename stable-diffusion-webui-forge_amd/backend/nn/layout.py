@@ -294,6 +294,82 @@ def vae_decoder_param_shapes(cfg):
     return s
 
 
+# ------------------------------------------------------------------------------------------------
+# AutoencoderKL encoder (vae.py:140-200, Downsample :60-74, quant_conv :287, encode :296-303) -- img2img / hires path
+# ------------------------------------------------------------------------------------------------
+
+@dataclass
+class VaeEncoderLayout:
+    in_channels: int
+    latent_channels: int
+    ch: int
+    block_in: int
+    use_quant_conv: bool
+    # list over execution order: (i_level, [(key, cin, cout)...], downsample_key or None)
+    levels: list = field(default_factory=list)
+
+
+def vae_encoder_layout(cfg) -> VaeEncoderLayout:
+    boc = list(cfg["block_out_channels"])
+    ch = boc[0]
+    ch_mult = [c // ch for c in boc]
+    nres = cfg["layers_per_block"]
+    nlev = len(ch_mult)
+    lay = VaeEncoderLayout(in_channels=cfg.get("in_channels", 3), latent_channels=cfg.get("latent_channels", 4), ch=ch,
+                           block_in=ch * ch_mult[-1], use_quant_conv=cfg.get("use_quant_conv", True))
+    in_ch_mult = [1] + ch_mult
+    for i_level in range(nlev):
+        cin = ch * in_ch_mult[i_level]
+        cout = ch * ch_mult[i_level]
+        blocks = []
+        for i_block in range(nres):
+            blocks.append((f"encoder.down.{i_level}.block.{i_block}", cin, cout))
+            cin = cout
+        down = f"encoder.down.{i_level}.downsample" if i_level != nlev - 1 else None
+        lay.levels.append((i_level, blocks, down))
+    return lay
+
+
+def vae_encoder_param_shapes(cfg):
+    lay = vae_encoder_layout(cfg)
+    s = OrderedDict()
+
+    def conv(key, i, o, k):
+        s[key + ".weight"] = (o, i, k, k)
+        s[key + ".bias"] = (o,)
+
+    def norm(key, c):
+        s[key + ".weight"] = (c,)
+        s[key + ".bias"] = (c,)
+
+    def res(key, i, o):
+        norm(key + ".norm1", i)
+        conv(key + ".conv1", i, o, 3)
+        norm(key + ".norm2", o)
+        conv(key + ".conv2", o, o, 3)
+        if i != o:
+            conv(key + ".nin_shortcut", i, o, 1)
+
+    conv("encoder.conv_in", lay.in_channels, lay.ch, 3)
+    for _, blocks, down in lay.levels:
+        for key, i, o in blocks:
+            res(key, i, o)
+        if down is not None:
+            c = blocks[-1][2]
+            conv(down + ".conv", c, c, 3)
+    bi = lay.block_in
+    res("encoder.mid.block_1", bi, bi)
+    norm("encoder.mid.attn_1.norm", bi)
+    for n in ("q", "k", "v", "proj_out"):
+        conv(f"encoder.mid.attn_1.{n}", bi, bi, 1)
+    res("encoder.mid.block_2", bi, bi)
+    norm("encoder.norm_out", bi)
+    conv("encoder.conv_out", bi, 2 * lay.latent_channels, 3)
+    if lay.use_quant_conv:
+        conv("quant_conv", 2 * lay.latent_channels, 2 * lay.latent_channels, 1)
+    return s
+
+
 # ---- Flux (MMDiT) ---------------------------------------------------------------------------------------------------
 def flux_param_shapes(cfg):
     """State-dict keys / shapes of IntegratedFluxTransformer2DModel (backend/nn/flux.py:310-367) for a config dict with the

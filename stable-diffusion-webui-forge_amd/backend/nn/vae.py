@@ -1,4 +1,4 @@
-"""MI355X-native AutoencoderKL *decoder* (the VAE half on the txt2img path).
+"""MI355X-native AutoencoderKL: the decoder (txt2img path) and the encoder (img2img / hires path).
 
 Drop-in for `IntegratedAutoencoderKL.decode / process_out` (reference: backend/nn/vae.py:305-316, Decoder.forward
 :248-271) plus the `VAE.decode_inner` post-processing (backend/patcher/vae.py:128-148): fp16 NHWC activations, all
@@ -9,12 +9,17 @@ of HBM the N x N score matrix of one image (512 MB at 1024^2) is affordable and 
 heavy kernel; V's bias is added after PV (softmax rows sum to 1).
 The reference decodes in fp32 on AMD (backend/memory_management.py:190-205); this path is fp16 storage with fp32
 accumulation everywhere (GEMM, norm statistics, softmax).
+
+Encoder (`encode`, reference Encoder.forward vae.py:183-200, Downsample :60-74, quant_conv + DiagonalGaussianDistribution
+:16-29, :296-303): same kernels; the Downsample's right/bottom-only zero padding costs nothing -- the conv loader's bounds
+check already returns zeros for taps past the input, so only the output extent is passed (pad = 0, stride 2).  Present only
+when the state dict carries `encoder.*` keys.
 """
 import torch
 
 from ... import hipops as ops
 from ...runtime import Arena, ArenaOverflow
-from .layout import vae_decoder_layout
+from .layout import vae_decoder_layout, vae_encoder_layout
 from .unet import _conv_w
 
 
@@ -28,6 +33,8 @@ class IntegratedAutoencoderKL:
         self.latent_channels = self.layout.latent_channels
         self._arena = None
         self.up_factor = 2 ** (len(self.layout.levels) - 1)
+        self.has_encoder = "encoder.conv_in.weight" in state_dict
+        self.enc_layout = vae_encoder_layout(config) if self.has_encoder else None
         self._load(state_dict)
 
     def _load(self, sd):
@@ -82,6 +89,36 @@ class IntegratedAutoencoderKL:
                 w[up] = conv(up + ".conv")
         w["norm_out"] = norm("decoder.norm_out")
         w["conv_out"] = conv("decoder.conv_out")
+        if self.has_encoder:
+            el = self.enc_layout
+            cw = _conv_w(sd["encoder.conv_in.weight"].to(dev, torch.float16))   # [ch, 9*in_channels]
+            if cw.shape[1] > 64:
+                raise NotImplementedError("encoder in_channels*9 must be <= 64 (im2col'ed first conv)")
+            wp = cw.new_zeros(cw.shape[0], 64)
+            wp[:, :cw.shape[1]] = cw
+            w["e.conv_in"] = (wp.contiguous(), T("encoder.conv_in.bias"))
+            for _, blocks, down in el.levels:
+                for key, cin, cout in blocks:
+                    res(key, cin, cout)
+                if down is not None:
+                    w[down] = conv(down + ".conv")
+            ebi = el.block_in
+            res("encoder.mid.block_1", ebi, ebi)
+            res("encoder.mid.block_2", ebi, ebi)
+            a = "encoder.mid.attn_1"
+            w[a + ".norm"] = norm(a + ".norm")
+            qw, qb = conv(a + ".q")
+            kw, kb = conv(a + ".k")
+            w[a + ".qk"] = (torch.cat([qw, kw], 0).contiguous(), torch.cat([qb, kb], 0).contiguous())
+            w[a + ".v"] = conv(a + ".v")
+            w[a + ".proj_out"] = conv(a + ".proj_out")
+            w["e.norm_out"] = norm("encoder.norm_out")
+            w["e.conv_out"] = conv("encoder.conv_out")
+            if el.use_quant_conv:
+                qc = sd["quant_conv.weight"].to(dev, torch.float16).reshape(2 * lc, 2 * lc)
+                qp = qc.new_zeros(2 * lc, 64)  # the moments travel in a 64-wide zero-padded NHWC buffer (GEMM K tile)
+                qp[:, :2 * lc] = qc
+                w["e.quant"] = (qp.contiguous(), T("quant_conv.bias"))
         self.w = w
         torch.cuda.synchronize(dev)
 
@@ -98,8 +135,7 @@ class IntegratedAutoencoderKL:
         arena.release(m)
         return out
 
-    def _attn(self, x, arena):
-        a = "decoder.mid.attn_1"
+    def _attn(self, x, arena, a="decoder.mid.attn_1"):
         b, hh, ww, c = x.shape
         n = hh * ww
         out = ops.empty((b, hh, ww, c))
@@ -175,7 +211,87 @@ class IntegratedAutoencoderKL:
                 need = arena.capacity * 2
                 self._arena = None
 
+    # ---- encoder -----------------------------------------------------------------------------------------------------
+    def _encode_impl(self, x, arena):
+        """x fp32 NCHW [B, 3, H, W] in [-1, 1] -> moments fp16 [B*h*w, 64] (first 2*lc columns valid: mean | logvar)"""
+        el = self.enc_layout
+        b, c, hh, ww = x.shape
+        xl = ops.vae_pack_latent(x, 1.0, 0.0, ld=8)                               # NHWC fp16, zero padded to 8 channels
+        col = ops.im2col3x3_smallc(xl, c)
+        h = ops.linear(col, *self.w["e.conv_in"]).view(b, hh, ww, el.ch)
+        for _, blocks, down in el.levels:
+            for key, cin, cout in blocks:
+                h = self._res(key, h, cin, cout, arena)
+            if down is not None:
+                bb, h2, w2, cc = h.shape
+                oh, ow = (h2 + 1 - 3) // 2 + 1, (w2 + 1 - 3) // 2 + 1            # F.pad (0,1,0,1) then 3x3 stride 2 (vae.py:67-70)
+                h = ops.conv_gemm(h, self.w[down][0], cc, kh=3, stride=2, pad=0, out_hw=(oh, ow), bias=self.w[down][1]).view(bb, oh, ow, cc)
+        ebi = el.block_in
+        h = self._res("encoder.mid.block_1", h, ebi, ebi, arena)
+        h = self._attn(h, arena, "encoder.mid.attn_1")
+        h = self._res("encoder.mid.block_2", h, ebi, ebi, arena)
+        g = ops.groupnorm(h, *self.w["e.norm_out"], 1e-6, silu=True)
+        npix = g.shape[0] * g.shape[1] * g.shape[2]
+        lc2 = 2 * el.latent_channels
+        mo = ops.empty((npix, 64))
+        mo.zero_()
+        ops.conv_gemm(g, self.w["e.conv_out"][0], lc2, kh=3, pad=1, bias=self.w["e.conv_out"][1], out=mo, ld_out=64)
+        if el.use_quant_conv:
+            mq = ops.empty((npix, 64))
+            mq.zero_()
+            ops.conv_gemm(mo, self.w["e.quant"][0], lc2, bias=self.w["e.quant"][1], out=mq, ld_out=64)
+            mo = mq
+        return mo
+
+    def _run_encode(self, x):
+        b, c, hh, ww = x.shape
+        need = max(1 << 28, int(b * hh * ww * self.enc_layout.ch * 2 * 14) + 2 * ((hh // self.up_factor) * (ww // self.up_factor)) ** 2 * 2)
+        while True:
+            if self._arena is None or self._arena.capacity < need:
+                self._arena = None
+                self._arena = Arena(need, self.device)
+            arena = self._arena
+            arena.reset()
+            try:
+                with arena:
+                    return self._encode_impl(x, arena)
+            except ArenaOverflow:
+                torch.cuda.synchronize(self.device)
+                need = arena.capacity * 2
+                self._arena = None
+
+    def encode_moments(self, x):
+        """-> fp32 NCHW [B, 2*lc, h, w] (mean | logvar): quant_conv(encoder(x)), vae.py:296-298."""
+        if not self.has_encoder:
+            raise RuntimeError("this AutoencoderKL was built without encoder weights")
+        xf = x.to(device=self.device, dtype=torch.float32).contiguous()
+        mo = self._run_encode(xf)
+        b, _, hh, ww = x.shape
+        f = self.up_factor
+        lc2 = 2 * self.latent_channels
+        return mo.view(b, hh // f, ww // f, 64)[..., :lc2].permute(0, 3, 1, 2).float()
+
+    def encode(self, x, regulation=None, noise=None):
+        """vae.py:296-303: posterior sample = mean + std * noise.  The reference draws torch.randn(shape) on the CPU default
+        generator (vae.py:28); same here unless `noise` is given, so a seeded torch.manual_seed reproduces it."""
+        if regulation is not None:
+            raise NotImplementedError("model_vae_regulation hooks are not supported by the native MI355X executor")
+        if not self.has_encoder:
+            raise RuntimeError("this AutoencoderKL was built without encoder weights")
+        xf = x.to(device=self.device, dtype=torch.float32).contiguous()
+        b, _, hh, ww = x.shape
+        f = self.up_factor
+        lc = self.latent_channels
+        if noise is None:
+            noise = torch.randn(b, lc, hh // f, ww // f)
+        noise = noise.to(device=self.device, dtype=torch.float32).contiguous()
+        mo = self._run_encode(xf)
+        return ops.vae_sample_posterior(mo, 64, noise, lc).to(x.dtype)
+
     # ---- reference surface ---------------------------------------------------------------------------------------
+    def process_in(self, latent):
+        return (latent - self.shift_factor) * self.scaling_factor  # vae.py:312-313
+
     def process_out(self, latent):
         return (latent / self.scaling_factor) + self.shift_factor  # vae.py:315
 

@@ -159,6 +159,21 @@ __global__ void vae_unpack_image_kernel(const f16* __restrict__ y, int ld, long 
   }
 }
 
+__global__ void vae_sample_posterior_kernel(const f16* __restrict__ mo, int ld, const float* __restrict__ noise, int b, int lc, long npix, float scale,
+                                            float shift, float* __restrict__ out) {
+  const long total = (long)b * lc * npix;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long p = i % npix;
+    const long bc = i / npix;
+    const int c = (int)(bc % lc);
+    const long bi = bc / lc;
+    const f16* row = mo + (bi * npix + p) * ld;
+    const float mean = (float)row[c];
+    const float logvar = fminf(fmaxf((float)row[lc + c], -30.0f), 20.0f);
+    out[i] = (mean + __expf(0.5f * logvar) * noise[i] - shift) * scale;
+  }
+}
+
 // Philox4x32-10 (modules/rng_philox.py:32-64) + Box-Muller sine branch (:67-76)
 __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
   const uint64_t p0 = (uint64_t)c[0] * 0xD2511F53ull;
@@ -284,6 +299,15 @@ extern "C" int fmx_vae_unpack_image(const void* y, int32_t ld, int64_t npix, int
   hipLaunchKernelGGL(vae_unpack_image_kernel, dim3(grid_for(npix * c, 2)), dim3(TPB), 0, (hipStream_t)stream, (const f16*)y, ld, (long)npix,
                      c, out);
   FMX_LAUNCH_CHECK("fmx_vae_unpack_image");
+  return FMX_OK;
+}
+
+extern "C" int fmx_vae_sample_posterior(const void* moments, int32_t ld, const float* noise, int32_t b, int32_t lc, int64_t npix, float scale, float shift,
+                                        float* out, void* stream) {
+  FMX_REQUIRE(moments && noise && out && b > 0 && lc > 0 && npix > 0 && ld >= 2 * lc, "vae_sample_posterior: bad args");
+  hipLaunchKernelGGL(vae_sample_posterior_kernel, dim3(grid_for((long)b * lc * npix)), dim3(TPB), 0, (hipStream_t)stream, (const f16*)moments, ld,
+                     noise, b, lc, (long)npix, scale, shift, out);
+  FMX_LAUNCH_CHECK("fmx_vae_sample_posterior");
   return FMX_OK;
 }
 

@@ -114,7 +114,7 @@ def _check_f16(*ts):
 
 def conv_gemm(x, wgt, nout, *, x1=None, n=None, h=None, w=None, kh=1, stride=1, pad=0, up=None, bias=None,
               rowvec=None, residual=None, act=ACT_NONE, alpha=1.0, out=None, ld_out=None, out_dtype=torch.float16,
-              ldw=0, force_tile=0, gate=None):
+              ldw=0, force_tile=0, gate=None, out_hw=None):
     """OUT[M, ncols] = epilogue(A (*) W^T).  x: [N,H,W,C0] (or [M,C0] with kh == 1); x1: optional second source
     concatenated along channels; wgt: [nout, kh*kh*(C0+C1)]; up=(UH, UW): nearest-resize before the conv."""
     _check_f16(x, x1, wgt, bias, rowvec, residual, gate)
@@ -128,6 +128,8 @@ def conv_gemm(x, wgt, nout, *, x1=None, n=None, h=None, w=None, kh=1, stride=1, 
     ih, iw = (up if up is not None else (h_, w_))
     oh = (ih + 2 * pad - kh) // stride + 1
     ow = (iw + 2 * pad - kh) // stride + 1
+    if out_hw is not None:  # asymmetric padding (VAE Downsample pads right / bottom only, vae.py:67-70): taps beyond the
+        oh, ow = out_hw     # input are bounds-checked zeros, so only the output extent changes
     m = n_ * oh * ow
     ncols = nout // 2 if act == ACT_GEGLU else nout
     if out is None:
@@ -337,6 +339,16 @@ def vae_pack_latent(z, scaling_factor, shift, ld=8, out=None):
         out = empty((b, h, w, ld), torch.float16, z.device)
     _lib.check(_lib.lib().fmx_vae_pack_latent(_p(z), float(scaling_factor), float(shift), b, c, h, w, _p(out), ld, stream_ptr()),
                "fmx_vae_pack_latent")
+    return out
+
+
+def vae_sample_posterior(moments, ld, noise, lc, scale=1.0, shift=0.0, out=None):
+    """moments fp16 [B*npix, ld] (mean | logvar), noise fp32 [B, lc, h, w] -> fp32 [B, lc, h, w] = (sample - shift) * scale."""
+    b, _, hh, ww = noise.shape
+    if out is None:
+        out = torch.empty_like(noise)
+    _lib.check(_lib.lib().fmx_vae_sample_posterior(_p(moments), ld, _p(noise), b, lc, hh * ww, float(scale), float(shift), _p(out), stream_ptr()),
+               "fmx_vae_sample_posterior")
     return out
 
 

@@ -18,7 +18,7 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
-from .backend.nn.layout import flux_param_shapes, unet_param_shapes, vae_decoder_param_shapes
+from .backend.nn.layout import flux_param_shapes, unet_param_shapes, vae_decoder_param_shapes, vae_encoder_param_shapes
 
 # LDM-style unet_config dicts (parameter counts 859.52 M / 2567.46 M verified against
 # the reference module in tests/test_oracle_vs_reference.py).
@@ -127,6 +127,13 @@ def synth_flux_state_dict(cfg, seed=2, **kw):
 
 def synth_vae_decoder_state_dict(cfg, seed=1, **kw):
     return synth_state_dict(vae_decoder_param_shapes(cfg), seed=seed, **kw)
+
+
+def synth_vae_state_dict(cfg, seed=1, **kw):
+    """decoder + encoder + quant convs; the decoder tensors equal synth_vae_decoder_state_dict's (pure function of the name)"""
+    shapes = OrderedDict(vae_decoder_param_shapes(cfg))
+    shapes.update(vae_encoder_param_shapes(cfg))
+    return synth_state_dict(shapes, seed=seed, **kw)
 
 
 def synth_conditioning(batch, context_dim, adm_in_channels=None, tokens=77, seed=1234):

@@ -42,7 +42,7 @@ def engines():
     out = {}
     for name, cfg in TINY.items():
         sd = synth.synth_unet_state_dict(cfg, seed=0)
-        vsd = synth.synth_vae_decoder_state_dict(synth.TINY_VAE_CONFIG, seed=1)
+        vsd = synth.synth_vae_state_dict(synth.TINY_VAE_CONFIG, seed=1)  # decoder + encoder (the decoder half is unchanged)
         out[name] = build_engine(cfg, sd, synth.TINY_VAE_CONFIG, vsd, device=DEV)
     return out
 
@@ -63,6 +63,25 @@ def test_vae_decode_vs_reference_fixture(engines):
     report("tiny vae decode vs reference", max_rel(out, g["decode"]), 3e-3)
     dec = engines["tiny_sd15"].decode_first_stage(g["lat"].to(DEV))
     report("decode_first_stage vs reference", max_rel(dec, g["decode_first_stage"]), 3e-3)
+
+
+def test_vae_encode_vs_reference_fixture(engines):
+    """Encoder + quant_conv + posterior sample + process_in (img2img entry) against the real reference's outputs."""
+    g = load_golden("tiny_vae_encode.pt")
+    eng = engines["tiny_sd15"]
+    vae = eng.forge_objects.vae.first_stage_model
+    mo = vae.encode_moments(g["x"].to(DEV))
+    report("tiny vae encoder moments vs reference", max_rel(mo, g["moments"]), 3e-3)
+    smp = vae.encode(g["x"].to(DEV), noise=g["noise"])
+    report("tiny vae posterior sample vs reference", max_rel(smp, g["sample"]), 3e-3)
+    torch.manual_seed(123)  # the reference draws the posterior noise with torch.randn on the CPU default generator (vae.py:28)
+    lat = eng.encode_first_stage(g["x"].to(DEV))
+    report("encode_first_stage vs reference", max_rel(lat, g["process_in"]), 3e-3)
+    # odd image sizes: the right / bottom zero padding of the Downsample (vae.py:67-70) vs the oracle on CPU
+    from oracle.vae import vae_encode_moments
+    x = torch.rand(1, 3, 26, 34, generator=torch.Generator("cpu").manual_seed(4)) * 2 - 1
+    sd = synth.synth_vae_state_dict(synth.TINY_VAE_CONFIG, seed=1)
+    report("tiny vae encoder (26x34) vs oracle", max_rel(vae.encode_moments(x.to(DEV)), vae_encode_moments(sd, x)), 3e-3)
 
 
 def _conds(cfg, b):

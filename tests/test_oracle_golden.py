@@ -9,12 +9,12 @@ import torch
 
 import forge_amd  # noqa: F401
 from forge_amd import synth
-from forge_amd.backend.nn.layout import flux_param_shapes, unet_param_shapes, vae_decoder_param_shapes
+from forge_amd.backend.nn.layout import flux_param_shapes, unet_param_shapes, vae_decoder_param_shapes, vae_encoder_param_shapes
 from oracle import pipeline, sampling
 from oracle.k_prediction import Predictor
 from oracle.rng import PhiloxGenerator
 from oracle.unet import unet_forward
-from oracle.vae import decode_first_stage, vae_decode
+from oracle.vae import decode_first_stage, encode_first_stage, posterior_sample, vae_decode, vae_encode_moments
 
 from conftest import GOLDEN, load_golden
 
@@ -130,3 +130,19 @@ def test_flux_forward_and_sampler_restated():
     xs = sigmas[0] * g["noise"]  # noise_scaling for 'const' with a zero latent (k_prediction.py:94-96)
     lat = oflux.flux_sample_euler(sd, cfg, xs, sigmas, g["ctx"], g["y"], g["guidance"])
     assert max_rel(lat, g["latent"]) < 2e-4
+
+
+def test_vae_encoder_oracle_vs_reference_fixture():
+    """Encoder + quant_conv + posterior sample + process_in of the real reference (backend/nn/vae.py:183-200, :296-303, :16-29)."""
+    g = load_golden("tiny_vae_encode.pt")
+    cfg = synth.TINY_VAE_CONFIG
+    sd = synth.synth_vae_state_dict(cfg, seed=1)
+    assert set(vae_encoder_param_shapes(cfg)) <= set(sd)
+    m = vae_encode_moments(sd, g["x"])
+    assert max_rel(m, g["moments"]) < 1e-4
+    assert max_rel(posterior_sample(m, g["noise"]), g["sample"]) < 1e-4
+    lat = encode_first_stage(sd, g["x"], cfg["scaling_factor"], cfg["shift_factor"], noise=g["noise"])
+    assert max_rel(lat, g["process_in"]) < 1e-4
+    # the decoder half of the joint state dict is the decoder-only one (weights are a pure function of the name)
+    dec = synth.synth_vae_decoder_state_dict(cfg, seed=1)
+    assert all(torch.equal(sd[k], v) for k, v in dec.items())
