@@ -193,6 +193,9 @@ int fmx_sampler_euler_step(const float* x, const float* denoised, float sigma, f
 int fmx_sampler_lincomb3(const float* x, const float* denoised, const float* old_denoised, float a, float bcoef,
                          float ccoef, float* x_out, int64_t n, void* stream);
 int fmx_scale_f32(const float* x, float s, float* y, int64_t n, void* stream);
+/* out = a * a_mask + b * b_mask, fp32, elementwise over n (inpaint latent blending: modules/sd_samplers_cfg_denoiser.py:181,205
+ * `x * nmask + noisy_init * mask`, `denoised * nmask + init_latent * mask`; processing.py:1866).  out may alias a or b. */
+int fmx_blend_masked(const float* a, const float* a_mask, const float* b, const float* b_mask, float* out, int64_t n, void* stream);
 
 /* VAE: latent fp32 NCHW [b][c][h][w] -> (z/scaling_factor + shift) as fp16 NHWC [b*h*w][ld] (ld >= c, rest 0) */
 int fmx_vae_pack_latent(const float* z, float scaling_factor, float shift, int32_t b, int32_t c, int32_t h, int32_t w,

@@ -147,6 +147,85 @@ def ref_sample(net, cfg, cond, uncond, seeds, hw, steps, sampler, cfg_scale=7.0,
     return out, sigmas
 
 
+def mask_noise_fn(shape):
+    """deterministic stand-in for the torch.randn_like of sd_samplers_cfg_denoiser.py:180 (device RNG in the reference)"""
+    def fn(step):
+        return torch.randn(shape, generator=torch.Generator("cpu").manual_seed(7000 + step))
+    return fn
+
+
+def ref_sample_img2img(net, cfg, cond, uncond, seeds, init_latent, steps, strength, sampler, cfg_scale=7.0, mask=None, nmask=None):
+    """Reference k-diffusion loop + sampling_function + UNet driven the way sample_img2img does
+    (modules/sd_samplers_kdiffusion.py:136-194; mask blending of sd_samplers_cfg_denoiser.py:178-181,204-213 and
+    processing.py:1865-1866 restated around the reference denoiser)."""
+    ref = ref_import.load_reference()
+    pred = ref_import.build_ref_predictor()
+    den = ref_import.RefDenoiser(net, pred, seeds)
+    rng = ImageRNG(tuple(init_latent.shape[1:]), seeds, "CPU")
+    noise = rng.next()
+    linker = den.inner_model
+    t_enc = int(min(strength, 0.999) * steps)                       # sd_samplers_common.py:30-31
+    if sampler == "DPM++ 2M":
+        sigmas = ref.kd_sampling.get_sigmas_karras(n=steps, sigma_min=linker.sigmas[0].item(), sigma_max=linker.sigmas[-1].item(), device="cpu")
+        fn = ref.kd_sampling.sample_dpmpp_2m
+    else:
+        sigmas = linker.get_sigmas(steps)
+        fn = ref.kd_sampling.sample_euler if sampler == "Euler" else ref.kd_sampling.sample_euler_ancestral
+    sigma_sched = sigmas[steps - t_enc - 1:]
+    xi = pred.noise_scaling(sigma_sched[0], noise, init_latent, max_denoise=False)
+    mnoise = mask_noise_fn(tuple(init_latent.shape))
+    step = [0]
+
+    class Model:  # the k-diffusion loops read model.inner_model.predictor (sampling.py:143)
+        inner_model = den.inner_model
+
+        def __call__(self, x, sigma, **extra):
+            if mask is not None:
+                noisy = pred.noise_scaling(sigma[:, None, None, None], mnoise(step[0]), init_latent, max_denoise=False)
+                x = x * nmask + noisy * mask
+            d = den(x, sigma, **extra)
+            if mask is not None:
+                d = d * nmask + init_latent * mask
+            step[0] += 1
+            return d
+
+    model = Model()
+
+    ref.kd_sampling.torch = _Hijack(rng)
+    ref.sampling_function.sampling_prepare(den.patcher, x=xi)
+    extra = {"cond": cond, "uncond": uncond, "cond_scale": cfg_scale, "s_min_uncond": 0.0, "image_cond": None}
+    try:
+        out = fn(model, xi, sigma_sched, extra_args=extra, disable=True)
+    finally:
+        ref.kd_sampling.torch = torch
+        ref.sampling_function.sampling_cleanup(den.patcher)
+    if mask is not None:
+        out = out * nmask + init_latent * mask
+    return out, sigma_sched
+
+
+def gen_img2img(name, cfg, net, b=2, hw=16):
+    adm = cfg.get("adm_in_channels")
+    c, uc = synth.synth_conditioning(b, cfg["context_dim"], adm, seed=1234)
+    if adm:
+        c, uc = ref_import.SdxlCond(c), ref_import.SdxlCond(uc)
+    seeds = [2000 + i for i in range(b)]
+    init = torch.randn(b, cfg["in_channels"], hw, hw, generator=torch.Generator("cpu").manual_seed(31)) * 0.8
+    res = {"seeds": seeds, "hw": hw, "init_latent": init}
+    for sampler, steps, strength in (("Euler", 8, 0.6), ("Euler a", 8, 0.5), ("DPM++ 2M", 9, 0.75)):
+        lat, sched = ref_sample_img2img(net, cfg, c, uc, seeds, init, steps, strength, sampler)
+        res[sampler] = {"steps": steps, "denoising_strength": strength, "latent": lat, "sigma_sched": sched}
+        print(name, "img2img", sampler, float(lat.std()))
+    # inpaint-style latent mask: keep the left half (mask = 1 where the original is kept, nmask = 1 - mask)
+    nmask = torch.zeros(b, cfg["in_channels"], hw, hw)
+    nmask[..., hw // 2:] = 1.0
+    nmask[0, :, : hw // 4] = 0.5  # soft values as a blurred mask would give
+    mask = 1.0 - nmask
+    lat, sched = ref_sample_img2img(net, cfg, c, uc, seeds, init, 8, 0.6, "Euler", mask=mask, nmask=nmask)
+    res["Euler_masked"] = {"steps": 8, "denoising_strength": 0.6, "latent": lat, "mask": mask, "nmask": nmask}
+    torch.save(res, os.path.join(GOLD, f"{name}_img2img.pt"))
+
+
 def gen_samples(name, cfg, net, b=2, hw=16):
     adm = cfg.get("adm_in_channels")
     c, uc = synth.synth_conditioning(b, cfg["context_dim"], adm, seed=1234)
@@ -279,6 +358,7 @@ def main():
     if a.only in ("", "tiny"):
         net, _ = gen_unet("tiny_sd15", synth.TINY_SD15_UNET_CONFIG)
         gen_samples("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
+        gen_img2img("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
         net, _ = gen_unet("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG)
         gen_samples("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG, net)
         gen_vae("tiny_vae", synth.TINY_VAE_CONFIG)

@@ -55,3 +55,52 @@ def txt2img(unet_sd, unet_cfg, vae_sd, vae_cfg, cond, uncond, seeds, height, wid
     lat, _ = txt2img_latents(unet_sd, unet_cfg, cond, uncond, seeds, height, width, steps, **kw)
     dec = decode_first_stage(vae_sd, lat, vae_cfg.get("scaling_factor", 0.18215), vae_cfg.get("shift_factor", 0.0) or 0.0)
     return lat, dec, to_uint8_images(dec)
+
+
+def setup_img2img_steps(steps, denoising_strength, fix_steps=False):
+    """modules/sd_samplers_common.py:24-33 (opts.img2img_fix_steps False by default)."""
+    if fix_steps:
+        requested = steps
+        steps = int(requested / min(denoising_strength, 0.999)) if denoising_strength > 0 else 0
+        return steps, requested - 1
+    return steps, int(min(denoising_strength, 0.999) * steps)
+
+
+@torch.no_grad()
+def img2img_latents(unet_sd, unet_cfg, cond, uncond, seeds, init_latent, steps, denoising_strength, sampler_name="Euler",
+                    cfg_scale=7.0, noise_source="CPU", mask=None, nmask=None, mask_noise=None):
+    """modules/processing.py:1843-1875 (Img2Img.sample) + modules/sd_samplers_kdiffusion.py:136-194 (sample_img2img:
+    t_enc, sigma_sched = sigmas[steps - t_enc - 1:], xi = init + noise * sigma_sched[0], loop over sigma_sched) +
+    modules/sd_samplers_cfg_denoiser.py:178-181, 204-213 (inpaint mask: noised original under the mask before the model,
+    original under the mask after it).  `mask_noise(step)` stands for the torch.randn_like of :180."""
+    pred = Predictor()
+    rng = ImageRNG(tuple(init_latent.shape[1:]), seeds, noise_source)
+    noise = rng.next()
+    steps, t_enc = setup_img2img_steps(steps, denoising_strength)
+    sigmas = get_sigmas(pred, sampler_name, steps)
+    sigma_sched = sigmas[steps - t_enc - 1:]
+    xi = pred.noise_scaling(sigma_sched[0], noise, init_latent)
+
+    def unet_fn(xc, t, ctx, y):
+        return unet_forward(unet_sd, unet_cfg, xc, t, ctx, y)
+
+    step = [0]
+
+    def denoiser(xx, sigma):
+        if mask is not None:
+            noisy = pred.noise_scaling(sigma[:, None, None, None], mask_noise(step[0]), init_latent)
+            xx = xx * nmask + noisy * mask
+        den, _, _ = cfg_denoise(lambda a, s, c, y: apply_model(unet_fn, pred, a, s, c, y), xx, sigma, uncond, cond, cfg_scale)
+        if mask is not None:
+            den = den * nmask + init_latent * mask
+        step[0] += 1
+        return den
+
+    fn, _ = sampling.SAMPLERS[sampler_name]
+    if sampler_name in ("Euler", "Euler a"):
+        out = fn(denoiser, xi, sigma_sched, noise_fn=rng.next)
+    else:
+        out = fn(denoiser, xi, sigma_sched)
+    if mask is not None:
+        out = out * nmask + init_latent * mask  # processing.py:1865-1866
+    return out, sigma_sched

@@ -75,6 +75,7 @@ SIGNATURES = {
     "fmx_vae_pack_latent": [_vp, _f32, _f32, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
     "fmx_im2col3x3_smallc": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "fmx_vae_unpack_image": [_vp, _i32, _i64, _i32, _vp, _vp],
+    "fmx_blend_masked": [_vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "fmx_vae_sample_posterior": [_vp, _i32, _vp, _i32, _i32, _i64, _f32, _f32, _vp, _vp],
     "fmx_philox_randn": [C.c_uint64, C.c_uint32, _vp, _vp, _i64, _vp],
     "fmx_graph_begin": [_vp],

@@ -159,6 +159,10 @@ __global__ void vae_unpack_image_kernel(const f16* __restrict__ y, int ld, long 
   }
 }
 
+__global__ void blend_masked_kernel(const float* a, const float* am, const float* b, const float* bm, float* out, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = a[i] * am[i] + b[i] * bm[i];
+}
+
 __global__ void vae_sample_posterior_kernel(const f16* __restrict__ mo, int ld, const float* __restrict__ noise, int b, int lc, long npix, float scale,
                                             float shift, float* __restrict__ out) {
   const long total = (long)b * lc * npix;
@@ -299,6 +303,13 @@ extern "C" int fmx_vae_unpack_image(const void* y, int32_t ld, int64_t npix, int
   hipLaunchKernelGGL(vae_unpack_image_kernel, dim3(grid_for(npix * c, 2)), dim3(TPB), 0, (hipStream_t)stream, (const f16*)y, ld, (long)npix,
                      c, out);
   FMX_LAUNCH_CHECK("fmx_vae_unpack_image");
+  return FMX_OK;
+}
+
+extern "C" int fmx_blend_masked(const float* a, const float* a_mask, const float* b, const float* b_mask, float* out, int64_t n, void* stream) {
+  FMX_REQUIRE(a && a_mask && b && b_mask && out && n > 0, "blend_masked: bad args");
+  hipLaunchKernelGGL(blend_masked_kernel, dim3(grid_for(n)), dim3(TPB), 0, (hipStream_t)stream, a, a_mask, b, b_mask, out, (long)n);
+  FMX_LAUNCH_CHECK("fmx_blend_masked");
   return FMX_OK;
 }
 

@@ -333,6 +333,17 @@ def scale_f32(x, s, out=None):
     return out
 
 
+def blend_masked(a, a_mask, b, b_mask, out=None):
+    """out = a * a_mask + b * b_mask (fp32, same shapes); out may alias a or b."""
+    for t in (a, a_mask, b, b_mask):
+        if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous() or t.shape != a.shape:
+            raise TypeError("blend_masked expects contiguous fp32 device tensors of one shape")
+    if out is None:
+        out = torch.empty_like(a)
+    _lib.check(_lib.lib().fmx_blend_masked(_p(a), _p(a_mask), _p(b), _p(b_mask), _p(out), a.numel(), stream_ptr()), "fmx_blend_masked")
+    return out
+
+
 def vae_pack_latent(z, scaling_factor, shift, ld=8, out=None):
     b, c, h, w = z.shape
     if out is None:

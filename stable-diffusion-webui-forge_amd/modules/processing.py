@@ -1,7 +1,10 @@
-"""txt2img job orchestration -- mirror of modules/processing.py for the hot path:
+"""txt2img / img2img job orchestration -- mirror of modules/processing.py for the hot path:
 `StableDiffusionProcessingTxt2Img` (dataclass fields :123-216 that the path reads), `.sample` (:1342-1391),
 `process_images` / `process_images_inner` (:815-1158: seeds seed+i :894, ImageRNG :944, p.sample :990,
 decode_latent_batch :1010, clamp + *255 + uint8 truncation :1012-1040), `decode_latent_batch` (:628).
+`StableDiffusionProcessingImg2Img` (:1637-1875): init images -> VAE encode -> `sample_img2img` on the tail of the sigma
+schedule, optional latent inpaint mask (`mask` keeps the original, `nmask` = 1 - mask is repainted; :1822-1832, :1865-1866).
+The PIL / cv2 mask preparation of the UI (:1692-1745) is outside the path: the latent-resolution mask tensor is an input.
 Prompts are replaced by ready conditioning tensors (`p.c`, `p.uc`): the text encoders are out of scope.
 """
 from dataclasses import dataclass, field
@@ -79,6 +82,60 @@ class StableDiffusionProcessingTxt2Img:
         return samples
 
 
+@dataclass
+class StableDiffusionProcessingImg2Img(StableDiffusionProcessingTxt2Img):
+    init_images: Any = None            # tensor [B, 3, H, W] in [0, 1] (the reference converts PIL images to this, :1772-1777)
+    init_latent: Any = None            # or an already encoded latent [B, lc, H/8, W/8]
+    denoising_strength: float = 0.75
+    latent_mask: Any = None            # [B or 1, 1 or lc, H/8, W/8] in [0, 1]: 1 = repaint (the reference's `latmask`, :1823-1831)
+    inpainting_fill: int = 1           # 1 = original (:1834-1841); latent noise / nothing are UI conveniences not mirrored
+    initial_noise_multiplier: float = 1.0
+    mask: Any = None
+    nmask: Any = None
+    image_conditioning: Any = None
+    mask_noise_source: Any = None      # test hook, see CFGDenoiser.mask_noise_source
+
+    def init(self, all_seeds=None):
+        """:1684-1842 for tensor inputs: VAE-encode the init images, build mask / nmask at latent resolution."""
+        from .sd_samplers_common import images_tensor_to_samples
+        dev = self.sd_model.device
+        if self.init_latent is None:
+            if self.init_images is None:
+                raise ValueError("img2img needs init_images or init_latent")
+            self.init_latent = images_tensor_to_samples(self.init_images, None, self.sd_model)
+        self.init_latent = self.init_latent.to(device=dev, dtype=torch.float32).contiguous()
+        if self.latent_mask is not None:
+            latmask = self.latent_mask.to(device=dev, dtype=torch.float32)
+            if latmask.dim() == 3:
+                latmask = latmask[:, None]
+            latmask = latmask.expand(self.init_latent.shape[0], self.init_latent.shape[1], -1, -1).contiguous()
+            self.mask = 1.0 - latmask       # :1830
+            self.nmask = latmask            # :1831
+            if self.inpainting_fill != 1:
+                raise NotImplementedError("only inpainting_fill == 1 (original) is mirrored")
+        self.image_conditioning = self.init_latent.new_zeros(self.init_latent.shape[0], 5, 1, 1)  # non-inpaint models (:404-406)
+
+    def sample(self, conditioning, unconditional_conditioning, seeds, subseeds=None, subseed_strength=0.0, prompts=None):
+        from .. import hipops as ops
+        self.sampler = sd_samplers.create_sampler(self.sampler_name, self.sd_model)
+        x = self.rng.next()
+        if self.initial_noise_multiplier != 1.0:
+            x = x * self.initial_noise_multiplier
+        self.sd_model.forge_objects = self.sd_model.forge_objects_after_applying_lora.shallow_copy()
+        lo = self.iteration * self.batch_size
+        init = self.init_latent[lo:lo + self.batch_size] if self.init_latent.shape[0] > self.batch_size else self.init_latent
+        full_mask, full_nmask = self.mask, self.nmask
+        if self.mask is not None and self.mask.shape[0] > self.batch_size:
+            self.mask, self.nmask = full_mask[lo:lo + self.batch_size].contiguous(), full_nmask[lo:lo + self.batch_size].contiguous()
+        try:
+            samples = self.sampler.sample_img2img(self, init, x, conditioning, unconditional_conditioning, image_conditioning=self.image_conditioning)
+            if self.mask is not None:
+                samples = ops.blend_masked(samples.contiguous(), self.nmask, init.contiguous(), self.mask)  # :1865-1866
+        finally:
+            self.mask, self.nmask = full_mask, full_nmask
+        return samples
+
+
 def _slice_cond(c, a, b):
     if isinstance(c, dict):
         return type(c)({k: v[a:b] for k, v in c.items()})
@@ -98,6 +155,8 @@ def process_images_inner(p) -> Processed:
     lc = p.sd_model.forge_objects.vae.latent_channels if p.sd_model.forge_objects.vae is not None else getattr(p.sd_model, "latent_channels", 4)
     images, lat_all, dec_all = [], [], []
     shared.state.interrupted = False
+    if isinstance(p, StableDiffusionProcessingImg2Img):
+        p.init(p.all_seeds)
     for n in range(p.n_iter):
         p.iteration = n
         lo, hi = n * p.batch_size, (n + 1) * p.batch_size

@@ -1,9 +1,10 @@
 """`CFGDenoiser` -- mirror of modules/sd_samplers_cfg_denoiser.py:33-228 (forward(x, sigma, uncond, cond, cond_scale,
 s_min_uncond, image_cond)).  Per step: interrupt check, prompt-schedule reconstruction, NGMS / skip-early-cond rules,
-`sampling_function`, last-latent bookkeeping.  inpaint masks (:178-181,204-213) are rejected (img2img is a "next" row)."""
+`sampling_function`, last-latent bookkeeping, inpaint latent-mask blending (:178-181 before the model, :204-213 after)."""
 import torch
 
 from . import prompt_parser, sd_samplers_common, shared
+from .. import hipops as ops
 from ..backend.sampling.sampling_function import sampling_function
 
 
@@ -30,6 +31,9 @@ class CFGDenoiser:
         self.p = None
         self.need_last_noise_uncond = False
         self.last_noise_uncond = None
+        # test hook: callable(step, like) replacing the torch.randn_like of :180 (device RNG in the reference, so fixtures
+        # made on CPU can only be matched with an injected noise source)
+        self.mask_noise_source = None
 
     @property
     def inner_model(self):
@@ -39,14 +43,18 @@ class CFGDenoiser:
         state, opts = shared.state, shared.opts
         if state.interrupted or state.skipped:
             raise sd_samplers_common.InterruptedException
+        sig0 = sigma.fmx_sigma.host[0] if hasattr(sigma, "fmx_sigma") else float(sigma[0])
         if self.mask is not None:
-            raise NotImplementedError("inpaint mask blending is outside the txt2img hot path")
+            # :178-181  x = x * nmask + noise_scaling(sigma, randn_like(init_latent), init_latent) * mask
+            noise = self.mask_noise_source(self.step, self.init_latent) if self.mask_noise_source is not None else torch.randn_like(self.init_latent)
+            predictor = self.inner_model.inner_model.forge_objects.unet.model.predictor
+            noisy_initial_latent = predictor.noise_scaling(sig0, noise.to(self.init_latent), self.init_latent, max_denoise=False)
+            x = ops.blend_masked(x, self._nmask32(x), noisy_initial_latent, self._mask32(x))
         cond_composition, cond = prompt_parser.reconstruct_multicond_batch(cond, self.step)
         uncond = prompt_parser.reconstruct_cond_batch(uncond, self.step) if uncond is not None else None
         denoiser_params = CFGDenoiserParams(x, image_cond, sigma, state.sampling_step, state.sampling_steps, cond, uncond, self)
         if getattr(self.p, "is_hr_pass", False):
             cond_scale = self.p.hr_cfg
-        sig0 = sigma.fmx_sigma.host[0] if hasattr(sigma, "fmx_sigma") else float(sigma[0])
         if opts.skip_early_cond > 0 and self.step / self.total_steps <= opts.skip_early_cond:
             cond_scale = 1.0
         elif (self.step % 2 or opts.s_min_uncond_all) and s_min_uncond > 0 and sig0 < s_min_uncond:
@@ -55,9 +63,23 @@ class CFGDenoiser:
                                                              cond_composition=cond_composition)
         if self.need_last_noise_uncond:
             self.last_noise_uncond = (x - uncond_pred) / sigma[:, None, None, None]
+        if self.mask is not None:
+            denoised = ops.blend_masked(denoised, self._nmask32(x), self.init_latent, self._mask32(x))  # :204-213
         self.sampler.last_latent = denoised
         state.current_latent = denoised
         self.step += 1
         return denoised
+
+    def _mask32(self, like):
+        if getattr(self, "_m32_src", None) is not self.mask:
+            self._m32_src = self.mask
+            self._m32 = self.mask.to(device=like.device, dtype=torch.float32).expand_as(like).contiguous()
+        return self._m32
+
+    def _nmask32(self, like):
+        if getattr(self, "_n32_src", None) is not self.nmask:
+            self._n32_src = self.nmask
+            self._n32 = self.nmask.to(device=like.device, dtype=torch.float32).expand_as(like).contiguous()
+        return self._n32
 
     __call__ = forward

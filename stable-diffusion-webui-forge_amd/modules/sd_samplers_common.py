@@ -21,6 +21,28 @@ class InterruptedException(BaseException):
     pass
 
 
+def setup_img2img_steps(p, steps=None):
+    """sd_samplers_common.py:24-33."""
+    if getattr(shared.opts, "img2img_fix_steps", False) or steps is not None:
+        requested_steps = (steps or p.steps)
+        steps = int(requested_steps / min(p.denoising_strength, 0.999)) if p.denoising_strength > 0 else 0
+        t_enc = requested_steps - 1
+    else:
+        steps = p.steps
+        t_enc = int(min(p.denoising_strength, 0.999) * steps)
+    return steps, t_enc
+
+
+def images_tensor_to_samples(image, approximation=None, model=None):
+    """sd_samplers_common.py:96-120 ("Full" VAE encode only): image [B,3,H,W] in [0, 1] -> latent, one image at a time as the
+    reference does (each draws its own posterior noise from the CPU default generator, nn/vae.py:28)."""
+    model = model if model is not None else shared.sd_model
+    image = image.to(model.device, dtype=torch.float32) * 2 - 1
+    if len(image) > 1:
+        return torch.stack([model.encode_first_stage(torch.unsqueeze(img, 0))[0] for img in image])
+    return model.encode_first_stage(image)
+
+
 class TorchHijack:
     """Replaces `torch` inside k_diffusion.sampling so that randn_like draws from the per-image generators (p.rng):
     images generated in a batch equal images generated individually (and independent of multi-GPU sharding)."""
@@ -80,6 +102,7 @@ class Sampler:
         self.model_wrap_cfg.p = p
         self.model_wrap_cfg.mask = getattr(p, "mask", None)
         self.model_wrap_cfg.nmask = getattr(p, "nmask", None)
+        self.model_wrap_cfg.mask_noise_source = getattr(p, "mask_noise_source", None)
         self.model_wrap_cfg.step = 0
         self.eta = p.eta if getattr(p, "eta", None) is not None else getattr(shared.opts, self.eta_option_field, 0.0)
         self.s_min_uncond = getattr(p, "s_min_uncond", 0.0)

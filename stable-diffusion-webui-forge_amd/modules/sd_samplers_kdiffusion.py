@@ -89,6 +89,40 @@ class KDiffusionSampler(sd_samplers_common.Sampler):
             sigmas = torch.cat([sigmas[:-2], sigmas[-1:]])
         return sigmas.cpu()
 
+    def sample_img2img(self, p, x, noise, conditioning, unconditional_conditioning, steps=None, image_conditioning=None):
+        """sd_samplers_kdiffusion.py:136-194: x = init latent, noise = p.rng.next(); runs the last t_enc + 1 sigmas."""
+        unet_patcher = self.model_wrap.inner_model.forge_objects.unet
+        sampling_prepare(unet_patcher, x=x)
+        steps, t_enc = sd_samplers_common.setup_img2img_steps(p, steps)
+        sigmas = self.get_sigmas(p, steps)
+        sigma_sched = sigmas[steps - t_enc - 1:]
+        x = x.to(noise)
+        xi = self.model_wrap.predictor.noise_scaling(sigma_sched[0], noise, x, max_denoise=False)
+        extra_noise = getattr(shared.opts, "img2img_extra_noise", 0.0)
+        if extra_noise > 0:
+            xi += noise * extra_noise
+        extra_params_kwargs = self.initialize(p)
+        parameters = inspect.signature(self.func).parameters
+        if "sigma_min" in parameters:
+            extra_params_kwargs["sigma_min"] = sigma_sched[-2]
+        if "sigma_max" in parameters:
+            extra_params_kwargs["sigma_max"] = sigma_sched[0]
+        if "n" in parameters:
+            extra_params_kwargs["n"] = len(sigma_sched) - 1
+        if "sigma_sched" in parameters:
+            extra_params_kwargs["sigma_sched"] = sigma_sched
+        if "sigmas" in parameters:
+            extra_params_kwargs["sigmas"] = sigma_sched
+        self.model_wrap_cfg.init_latent = x
+        self.last_latent = x
+        self.sampler_extra_args = {"cond": conditioning, "image_cond": image_conditioning, "uncond": unconditional_conditioning,
+                                   "cond_scale": p.cfg_scale, "s_min_uncond": self.s_min_uncond}
+        samples = self.launch_sampling(t_enc + 1, lambda: self.func(self.model_wrap_cfg, xi, extra_args=self.sampler_extra_args,
+                                                                    disable=getattr(p, "disable_progress", True),
+                                                                    callback=self.callback_state, **extra_params_kwargs))
+        sampling_cleanup(unet_patcher)
+        return samples
+
     def sample(self, p, x, conditioning, unconditional_conditioning, steps=None, image_conditioning=None):
         unet_patcher = self.model_wrap.inner_model.forge_objects.unet
         sampling_prepare(unet_patcher, x=x)

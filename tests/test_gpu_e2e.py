@@ -106,6 +106,62 @@ def test_sampler_vs_reference_fixture(name, sampler, engines):
     report(f"{name} {sampler} {g[sampler]['steps']} steps vs reference", max_rel(res.latents, g[sampler]["latent"]), 1e-2)
 
 
+@pytest.mark.parametrize("sampler", ["Euler", "Euler a", "DPM++ 2M"])
+def test_img2img_vs_reference_fixture(sampler, engines):
+    """StableDiffusionProcessingImg2Img -> sample_img2img on the tail of the sigma schedule, vs the reference's loops driven
+    the same way (tests/golden/tiny_sd15_img2img.pt)."""
+    g = load_golden("tiny_sd15_img2img.pt")
+    cfg = TINY["tiny_sd15"]
+    c, uc = _conds(cfg, len(g["seeds"]))
+    r = g[sampler]
+    p = processing.StableDiffusionProcessingImg2Img(sd_model=engines["tiny_sd15"], c=c, uc=uc, seed=g["seeds"][0], sampler_name=sampler,
+                                                    batch_size=len(g["seeds"]), steps=r["steps"], cfg_scale=7.0, width=g["hw"] * 8, height=g["hw"] * 8,
+                                                    init_latent=g["init_latent"].clone(), denoising_strength=r["denoising_strength"], do_decode=False)
+    res = processing.process_images(p)
+    report(f"tiny_sd15 img2img {sampler} (strength {r['denoising_strength']}) vs reference", max_rel(res.latents, r["latent"]), 1e-2)
+
+
+def test_img2img_inpaint_mask_vs_reference_fixture(engines):
+    """latent inpaint mask: noised original under the mask before every model call, original restored after it and at the end
+    (sd_samplers_cfg_denoiser.py:178-181,204-213; processing.py:1865-1866).  The per-step noise of :180 is injected (the
+    reference draws it from the device RNG)."""
+    from oracle.make_golden import mask_noise_fn
+    g = load_golden("tiny_sd15_img2img.pt")
+    cfg = TINY["tiny_sd15"]
+    c, uc = _conds(cfg, len(g["seeds"]))
+    r = g["Euler_masked"]
+    mn = mask_noise_fn(tuple(g["init_latent"].shape))
+    p = processing.StableDiffusionProcessingImg2Img(sd_model=engines["tiny_sd15"], c=c, uc=uc, seed=g["seeds"][0], sampler_name="Euler",
+                                                    batch_size=len(g["seeds"]), steps=r["steps"], cfg_scale=7.0, width=g["hw"] * 8, height=g["hw"] * 8,
+                                                    init_latent=g["init_latent"].clone(), denoising_strength=r["denoising_strength"], do_decode=False,
+                                                    latent_mask=r["nmask"], mask_noise_source=lambda step, like: mn(step).to(like))
+    res = processing.process_images(p)
+    report("tiny_sd15 img2img with latent mask vs reference", max_rel(res.latents, r["latent"]), 1e-2)
+    keep = (r["mask"] == 1.0)
+    assert torch.equal(res.latents.cpu()[keep], g["init_latent"][keep]), "kept region must be the original latent exactly"
+
+
+def test_img2img_from_images(engines):
+    """init_images path: VAE encode (one image at a time, posterior noise from the CPU default generator) -> img2img, vs the
+    CPU oracle fed the same encoder output."""
+    from oracle import pipeline
+    from oracle.vae import encode_first_stage
+    cfg, vcfg = TINY["tiny_sd15"], synth.TINY_VAE_CONFIG
+    sd, vsd = synth.synth_unet_state_dict(cfg, seed=0), synth.synth_vae_state_dict(vcfg, seed=1)
+    c, uc = _conds(cfg, 2)
+    # the tiny VAE downsamples by 2 (two levels), the call surface assumes latent = size / 8: a 32x32 image <-> "128x128" job
+    img = torch.rand(2, 3, 32, 32, generator=torch.Generator("cpu").manual_seed(77))
+    torch.manual_seed(5)
+    p = processing.StableDiffusionProcessingImg2Img(sd_model=engines["tiny_sd15"], c=c, uc=uc, seed=41, sampler_name="Euler", batch_size=2, steps=6,
+                                                    cfg_scale=7.0, width=128, height=128, init_images=img, denoising_strength=0.5, do_decode=False)
+    res = processing.process_images(p)
+    torch.manual_seed(5)
+    init = torch.stack([encode_first_stage(vsd, (img[i:i + 1] * 2 - 1), vcfg["scaling_factor"], 0.0)[0] for i in range(2)])
+    report("init latent (VAE encode of images) vs oracle", max_rel(p.init_latent, init), 3e-3)
+    lat, _ = pipeline.img2img_latents(sd, cfg, c.cpu(), uc.cpu(), [41, 42], init, 6, 0.5, sampler_name="Euler")
+    report("img2img from images vs oracle", max_rel(res.latents, lat), 1e-2)
+
+
 def test_cfg_scale_one_shortcut(engines):
     g = load_golden("tiny_sd15_samples.pt")
     cfg = TINY["tiny_sd15"]

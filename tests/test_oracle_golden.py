@@ -146,3 +146,25 @@ def test_vae_encoder_oracle_vs_reference_fixture():
     # the decoder half of the joint state dict is the decoder-only one (weights are a pure function of the name)
     dec = synth.synth_vae_decoder_state_dict(cfg, seed=1)
     assert all(torch.equal(sd[k], v) for k, v in dec.items())
+
+
+def test_img2img_oracle_vs_reference_fixture():
+    """sample_img2img (modules/sd_samplers_kdiffusion.py:136-194) + inpaint mask blending (sd_samplers_cfg_denoiser.py:178-213,
+    processing.py:1865-1866) restated in oracle/pipeline.py vs the reference's own loops / sampling_function / UNet."""
+    from oracle.make_golden import mask_noise_fn
+    g = load_golden("tiny_sd15_img2img.pt")
+    cfg = synth.TINY_SD15_UNET_CONFIG
+    sd = synth.synth_unet_state_dict(cfg, seed=0)
+    c, uc = synth.synth_conditioning(len(g["seeds"]), cfg["context_dim"], None, seed=1234)
+    for sampler in ("Euler", "Euler a", "DPM++ 2M"):
+        r = g[sampler]
+        lat, sched = pipeline.img2img_latents(sd, cfg, c, uc, g["seeds"], g["init_latent"], r["steps"], r["denoising_strength"], sampler_name=sampler)
+        assert torch.equal(sched, r["sigma_sched"]), sampler
+        assert max_rel(lat, r["latent"]) < 2e-4, (sampler, max_rel(lat, r["latent"]))
+    r = g["Euler_masked"]
+    lat, _ = pipeline.img2img_latents(sd, cfg, c, uc, g["seeds"], g["init_latent"], r["steps"], r["denoising_strength"], sampler_name="Euler",
+                                      mask=r["mask"], nmask=r["nmask"], mask_noise=mask_noise_fn(tuple(g["init_latent"].shape)))
+    assert max_rel(lat, r["latent"]) < 2e-4
+    # the kept region is exactly the original (processing.py:1865-1866)
+    keep = r["mask"] == 1.0
+    assert torch.equal(lat[keep], g["init_latent"][keep])
