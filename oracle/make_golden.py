@@ -226,6 +226,77 @@ def gen_img2img(name, cfg, net, b=2, hw=16):
     torch.save(res, os.path.join(GOLD, f"{name}_img2img.pt"))
 
 
+def synth_lora(cfg, seed=3, rank=8):
+    """A synthetic LoRA file for the tiny SD1.5-style UNet in the naming styles found in the wild: kohya/diffusers names
+    (lora_unet_down_blocks_..), LDM names (lora_unet_input_blocks_..), a LoCon conv with a Tucker mid tensor, a rank that is
+    not a multiple of 8, a `.diff` / `.diff_b` pair, a `.set_weight`, plus text-encoder keys that must be ignored."""
+    from forge_amd.backend.nn.layout import unet_param_shapes
+    shapes = unet_param_shapes(cfg)
+    g = torch.Generator("cpu").manual_seed(seed)
+
+    def rn(*shape, scale=0.05):
+        return (torch.randn(*shape, generator=g) * scale).half()
+
+    sd = {}
+
+    def lora(name, key, r, alpha=None, conv_mid=False):
+        o, i = shapes[key][0], shapes[key][1]
+        if len(shapes[key]) == 4 and conv_mid:
+            sd[name + ".lora_up.weight"] = rn(o, r, 1, 1)
+            sd[name + ".lora_mid.weight"] = rn(r, r, shapes[key][2], shapes[key][3])
+            sd[name + ".lora_down.weight"] = rn(r, i, 1, 1)
+        elif len(shapes[key]) == 4:
+            sd[name + ".lora_up.weight"] = rn(o, r, 1, 1)
+            sd[name + ".lora_down.weight"] = rn(r, i, shapes[key][2], shapes[key][3])
+        else:
+            sd[name + ".lora_up.weight"] = rn(o, r)
+            sd[name + ".lora_down.weight"] = rn(r, i)
+        if alpha is not None:
+            sd[name + ".alpha"] = torch.tensor(float(alpha))
+
+    lora("lora_unet_down_blocks_0_attentions_0_transformer_blocks_0_attn1_to_q", "input_blocks.1.1.transformer_blocks.0.attn1.to_q.weight", rank, alpha=4)
+    lora("lora_unet_down_blocks_0_attentions_0_transformer_blocks_0_attn2_to_k", "input_blocks.1.1.transformer_blocks.0.attn2.to_k.weight", rank, alpha=rank)
+    lora("lora_unet_down_blocks_0_attentions_0_transformer_blocks_0_ff_net_0_proj", "input_blocks.1.1.transformer_blocks.0.ff.net.0.proj.weight", 5)
+    lora("lora_unet_mid_block_attentions_0_proj_in", "middle_block.1.proj_in.weight", rank, alpha=2)
+    lora("lora_unet_input_blocks_1_0_in_layers_2", "input_blocks.1.0.in_layers.2.weight", rank, alpha=8)            # LDM naming
+    lora("lora_unet_up_blocks_2_resnets_1_conv1", "output_blocks.5.0.in_layers.2.weight", 4, alpha=1, conv_mid=True)
+    lora("lora_unet_output_blocks_4_0_out_layers_3", "output_blocks.4.0.out_layers.3.weight", 12, alpha=6)
+    k = "output_blocks.5.0.emb_layers.1"
+    sd["diffusion_model." + k + ".diff"] = rn(*shapes[k + ".weight"], scale=0.02)
+    sd["diffusion_model." + k + ".diff_b"] = rn(*shapes[k + ".bias"], scale=0.02)
+    sd["diffusion_model.out.2.set_weight"] = rn(*shapes["out.2.weight"], scale=0.1)
+    sd["lora_te_text_model_encoder_layers_0_mlp_fc1.lora_up.weight"] = rn(16, 4)
+    sd["lora_te_text_model_encoder_layers_0_mlp_fc1.lora_down.weight"] = rn(4, 16)
+    return sd
+
+
+def gen_lora(name="tiny_sd15", cfg=None):
+    """The REAL reference's key map, patch parser and merge (backend/patcher/lora.py:43,19,85; comfyui_lora_collection/lora.py)
+    on a synthetic LoRA for the tiny UNet: merged weights of every patched parameter (fp16 weights, fp32 computation)."""
+    import importlib
+    from types import SimpleNamespace
+    cfg = cfg or synth.TINY_SD15_UNET_CONFIG
+    ref_import.load_reference()
+    rl = importlib.import_module("backend.patcher.lora")
+    sd = {k: v.half() for k, v in synth.synth_unet_state_dict(cfg, seed=0).items()}
+    keys = {"diffusion_model." + k: None for k in sd}
+    rcfg = {k: (list(v) if isinstance(v, (list, tuple)) else v) for k, v in cfg.items()}
+    model = SimpleNamespace(state_dict=lambda: keys, diffusion_model=SimpleNamespace(config=rcfg), config=SimpleNamespace(huggingface_repo="sd15"))
+    key_map = rl.model_lora_keys_unet(model, {})
+    lora_sd = synth_lora(cfg)
+    patch_dict, remaining = rl.load_lora(lora_sd, key_map)
+    strength = 0.8
+    merged = {}
+    for mk, pv in patch_dict.items():
+        k = mk[len("diffusion_model."):]
+        merged[k] = rl.merge_lora_to_weight([(strength, pv, 1.0, None, None)], sd[k].clone(), key=k, computation_dtype=torch.float32)
+    import hashlib
+    km = "\n".join(f"{a}\t{b}" for a, b in sorted(key_map.items()))
+    torch.save({"strength": strength, "merged": merged, "remaining": sorted(remaining), "key_map_sha256": hashlib.sha256(km.encode()).hexdigest(),
+                "key_map_len": len(key_map)}, os.path.join(GOLD, f"{name}_lora_merge.pt"))
+    print(name, "lora merge:", len(merged), "patched,", len(remaining), "unused keys, key map", len(key_map))
+
+
 def gen_samples(name, cfg, net, b=2, hw=16):
     adm = cfg.get("adm_in_channels")
     c, uc = synth.synth_conditioning(b, cfg["context_dim"], adm, seed=1234)
@@ -359,6 +430,7 @@ def main():
         net, _ = gen_unet("tiny_sd15", synth.TINY_SD15_UNET_CONFIG)
         gen_samples("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
         gen_img2img("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
+        gen_lora("tiny_sd15", synth.TINY_SD15_UNET_CONFIG)
         net, _ = gen_unet("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG)
         gen_samples("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG, net)
         gen_vae("tiny_vae", synth.TINY_VAE_CONFIG)

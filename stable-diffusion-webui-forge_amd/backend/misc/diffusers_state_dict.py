@@ -1,0 +1,93 @@
+"""diffusers <-> LDM parameter names of the UNet -- counterpart of backend/misc/diffusers_state_dict.py:70
+(`unet_to_diffusers`, also packages_3rdparty/comfyui_lora_collection/utils.py:189), which LoRA files in the diffusers /
+kohya naming need (`lora_unet_down_blocks_0_attentions_0_transformer_blocks_0_attn1_to_q`, ...).
+
+Built from the executor's own flat layout (`layout.unet_layout`) rather than from the config lists: every layer object
+already knows its LDM key, so the diffusers name only needs the (level, index-within-level) bookkeeping of diffusers'
+down_blocks / mid_block / up_blocks.  tests/test_loader_lora.py checks the result against the reference's map."""
+from ..nn.layout import ConvIn, Down, Res, SpatialT, Up, unet_layout, unet_param_shapes
+
+_RES = {  # LDM ResBlock sub-key -> diffusers ResnetBlock2D sub-key
+    "in_layers.0": "norm1", "in_layers.2": "conv1", "emb_layers.1": "time_emb_proj",
+    "out_layers.0": "norm2", "out_layers.3": "conv2", "skip_connection": "conv_shortcut",
+}
+_BASIC = {  # diffusers -> LDM (both embedding names of diffusers map to label_emb)
+    "class_embedding.linear_1": "label_emb.0.0", "class_embedding.linear_2": "label_emb.0.2",
+    "add_embedding.linear_1": "label_emb.0.0", "add_embedding.linear_2": "label_emb.0.2",
+    "conv_in": "input_blocks.0.0", "conv_norm_out": "out.0", "conv_out": "out.2",
+    "time_embedding.linear_1": "time_embed.0", "time_embedding.linear_2": "time_embed.2",
+}
+
+
+def unet_to_diffusers(unet_config):
+    """-> {diffusers parameter name: LDM parameter name} for every parameter both namings have."""
+    if "num_res_blocks" not in unet_config:
+        return {}
+    lay = unet_layout(unet_config)
+    have = set(unet_param_shapes(unet_config))
+    out = {}
+
+    def put(dname, lname):
+        for suf in (".weight", ".bias"):
+            # the reference's table lists the skip / embedding entries unconditionally; keep them all (harmless extra keys)
+            out[dname + suf] = lname + suf
+
+    def res(dprefix, L):
+        for lk, dk in _RES.items():
+            put(f"{dprefix}.{dk}", f"{L.key}.{lk}")
+
+    def attn(dprefix, L):
+        for n in ("proj_in", "proj_out", "norm"):
+            put(f"{dprefix}.{n}", f"{L.key}.{n}")
+        for t in range(L.depth):
+            for sub in ("norm1", "norm2", "norm3", "attn1.to_out.0", "attn2.to_out.0", "ff.net.0.proj", "ff.net.2"):
+                put(f"{dprefix}.transformer_blocks.{t}.{sub}", f"{L.key}.transformer_blocks.{t}.{sub}")
+            for a in ("attn1", "attn2"):
+                for q in ("to_q", "to_k", "to_v"):
+                    out[f"{dprefix}.transformer_blocks.{t}.{a}.{q}.weight"] = f"{L.key}.transformer_blocks.{t}.{a}.{q}.weight"
+
+    # down path: diffusers level x = number of Downsample layers seen so far, i = index of the ResBlock inside the level
+    level, i = 0, 0
+    for blk in lay.input_blocks[1:]:
+        if isinstance(blk[0], Down):
+            put(f"down_blocks.{level}.downsamplers.0.conv", blk[0].key + ".op")
+            level, i = level + 1, 0
+            continue
+        for L in blk:
+            if isinstance(L, Res):
+                res(f"down_blocks.{level}.resnets.{i}", L)
+            elif isinstance(L, SpatialT):
+                attn(f"down_blocks.{level}.attentions.{i}", L)
+        i += 1
+    # the reference emits a downsampler entry for the last level too (it does not exist in the model; harmless)
+    nrb = unet_config["num_res_blocks"]
+    nrb = [nrb] * len(unet_config.get("channel_mult", (1, 2, 4, 8))) if isinstance(nrb, int) else list(nrb)
+    n_last = sum(r + 1 for r in nrb)  # = 1 + blocks of the earlier levels + the last level's ResBlocks
+    put(f"down_blocks.{len(nrb) - 1}.downsamplers.0.conv", f"input_blocks.{n_last}.0.op")
+    # middle
+    ri = 0
+    for L in lay.middle:
+        if isinstance(L, Res):
+            res(f"mid_block.resnets.{ri}", L)
+            ri += 1
+        else:
+            attn("mid_block.attentions.0", L)
+    # up path
+    level, i = 0, 0
+    for blk in lay.output_blocks:
+        for L in blk:
+            if isinstance(L, Res):
+                res(f"up_blocks.{level}.resnets.{i}", L)
+            elif isinstance(L, SpatialT):
+                attn(f"up_blocks.{level}.attentions.{i}", L)
+            elif isinstance(L, Up):
+                put(f"up_blocks.{level}.upsamplers.0.conv", L.key + ".conv")
+        i += 1
+        if i == nrb[::-1][level] + 1:
+            if not any(isinstance(L, Up) for L in blk):  # last level: the reference still lists an upsampler slot
+                c = 1 + sum(isinstance(L, SpatialT) for L in blk)
+                put(f"up_blocks.{level}.upsamplers.0.conv", f"{blk[0].key[:-2]}.{c}.conv")
+            level, i = level + 1, 0
+    for dk, lk in _BASIC.items():
+        put(dk, lk)
+    return out

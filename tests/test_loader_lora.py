@@ -1,0 +1,87 @@
+"""CPU: checkpoint splitting / model-family detection / LoRA key maps and patch parsing of forge_amd.backend.{loader,patcher.lora}
+against fixtures produced by the REAL reference (oracle/make_golden.py gen_lora) and, when /root/reference is present, against
+the reference's own functions."""
+import hashlib
+
+import pytest
+import torch
+
+import forge_amd  # noqa: F401
+from forge_amd import synth
+from forge_amd.backend import loader
+from forge_amd.backend.misc.diffusers_state_dict import unet_to_diffusers
+from forge_amd.backend.nn.layout import unet_param_shapes, vae_decoder_param_shapes, vae_encoder_param_shapes
+from forge_amd.backend.patcher import lora as nlora
+from oracle import ref_import
+
+from conftest import load_golden
+
+
+def _meta_sd(shapes, prefix=""):
+    return {prefix + k: torch.empty(v, device="meta") for k, v in shapes.items()}
+
+
+@pytest.mark.parametrize("name,cfg", [("sd15", synth.SD15_UNET_CONFIG), ("sdxl", synth.SDXL_UNET_CONFIG)])
+def test_detect_unet_config_from_shapes(name, cfg):
+    det = loader.detect_unet_config(_meta_sd(unet_param_shapes(cfg), loader.UNET_PREFIX))
+    assert unet_param_shapes(det) == unet_param_shapes(cfg)
+    for k in ("num_heads", "num_head_channels", "context_dim", "use_linear_in_transformer", "adm_in_channels"):
+        assert det.get(k) == cfg.get(k), k
+
+
+def test_split_state_dict_single_file_layout():
+    cfg = synth.SDXL_UNET_CONFIG
+    sd = _meta_sd(unet_param_shapes(cfg), loader.UNET_PREFIX)
+    vshapes = dict(vae_decoder_param_shapes(synth.SDXL_VAE_CONFIG))
+    vshapes.update(vae_encoder_param_shapes(synth.SDXL_VAE_CONFIG))
+    sd.update(_meta_sd(vshapes, loader.VAE_PREFIX))
+    sd["conditioner.embedders.0.transformer.text_model.embeddings.position_ids"] = torch.empty(1, 77, device="meta")
+    sd["first_stage_model.loss.logvar"] = torch.empty(1, device="meta")
+    parts, guess = loader.split_state_dict(sd)
+    assert set(parts["unet"]) == set(unet_param_shapes(cfg))
+    assert set(parts["vae"]) == set(vshapes)
+    assert guess["is_sdxl"] and guess["vae_config"]["scaling_factor"] == 0.13025 and guess["ignored"] == ["conditioner"]
+    # a bare UNet state dict gets the checkpoint prefix (loader.py:442-446)
+    bare = loader.preprocess_state_dict(_meta_sd(unet_param_shapes(synth.SD15_UNET_CONFIG)))
+    assert all(k.startswith(loader.UNET_PREFIX) for k in bare)
+
+
+def _key_map(cfg):
+    return nlora.model_lora_keys_unet(list(unet_param_shapes(cfg)), cfg)
+
+
+def test_lora_key_map_matches_reference_fixture():
+    g = load_golden("tiny_sd15_lora_merge.pt")
+    km = _key_map(synth.TINY_SD15_UNET_CONFIG)
+    txt = "\n".join(f"{a}\t{b}" for a, b in sorted(km.items()))
+    assert len(km) == g["key_map_len"]
+    assert hashlib.sha256(txt.encode()).hexdigest() == g["key_map_sha256"]
+
+
+@pytest.mark.skipif(not ref_import.reference_available(), reason="needs /root/reference")
+@pytest.mark.parametrize("cfg", [synth.SD15_UNET_CONFIG, synth.SDXL_UNET_CONFIG, synth.TINY_SDXL_UNET_CONFIG])
+def test_lora_key_map_and_diffusers_names_vs_reference(cfg):
+    import importlib
+    from types import SimpleNamespace
+    ref_import.load_reference()
+    rl = importlib.import_module("backend.patcher.lora")
+    cu = importlib.import_module("packages_3rdparty.comfyui_lora_collection.utils")
+    rcfg = {k: (list(v) if isinstance(v, (list, tuple)) else v) for k, v in cfg.items()}
+    assert cu.unet_to_diffusers(dict(rcfg)) == unet_to_diffusers(cfg)
+    keys = {"diffusion_model." + k: None for k in unet_param_shapes(cfg)}
+    model = SimpleNamespace(state_dict=lambda: keys, diffusion_model=SimpleNamespace(config=rcfg), config=SimpleNamespace(huggingface_repo="sd"))
+    assert rl.model_lora_keys_unet(model, {}) == _key_map(cfg)
+
+
+def test_load_lora_patch_parsing():
+    from oracle.make_golden import synth_lora
+    g = load_golden("tiny_sd15_lora_merge.pt")
+    cfg = synth.TINY_SD15_UNET_CONFIG
+    patch_dict, remaining = nlora.load_lora(synth_lora(cfg), _key_map(cfg))
+    assert sorted(remaining) == g["remaining"]
+    assert {k[len("diffusion_model."):] for k in patch_dict} == set(g["merged"])
+    kinds = {k: v[0] for k, v in patch_dict.items()}
+    assert kinds["diffusion_model.out.2.weight"] == "set" and kinds["diffusion_model.output_blocks.5.0.emb_layers.1.bias"] == "diff"
+    assert patch_dict["diffusion_model.output_blocks.5.0.in_layers.2.weight"][1][3] is not None  # Tucker mid tensor kept
+    with pytest.raises(NotImplementedError):
+        nlora.load_lora({"lora_unet_time_embed_0.hada_w1_a": torch.zeros(1)}, {"lora_unet_time_embed_0": "diffusion_model.time_embed.0.weight"})
