@@ -167,6 +167,9 @@ int fmx_flux_qk_norm_rope_f16(const void* qkv, int64_t ld_qkv, const void* q_sca
 int fmx_timestep_embedding(const float* t, void* emb, int32_t b, int32_t dim, float max_period, void* stream);
 
 int fmx_silu_f16(const void* x, void* y, int64_t n, void* stream);
+/* h[p][c] += ctrl[b][c][p'] : ControlNet residual injection (backend/nn/unet.py:44-52 `h += ctrl`).  h: fp16 NHWC [B*npix][C]
+ * (the executor's activation layout), ctrl: fp32 NCHW [B][C][npix] as the ControlNet produces it. */
+int fmx_add_control_nchw(void* h, const float* ctrl, int32_t b, int32_t c, int64_t npix, void* stream);
 int fmx_cast_f32_to_f16(const float* x, void* y, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

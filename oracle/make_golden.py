@@ -67,6 +67,36 @@ def gen_unet(name, cfg, b=2, hw=16):
     return net, sd
 
 
+def synth_control(cfg, b, hw, seed=21):
+    """ControlNet-style residuals for every injection point of the UNet (unet.py:714,732,739): 'input' after each input block,
+    'middle', 'output' on every skip; lists are consumed from the END, so they are stored in pop() order reversed."""
+    from forge_amd.backend.nn.layout import Down, unet_layout
+    lay = unet_layout(cfg)
+    g = torch.Generator("cpu").manual_seed(seed)
+    shapes = []
+    ch, res = cfg["model_channels"], hw
+    for blk in lay.input_blocks:
+        for L in blk:
+            if isinstance(L, Down):
+                res = (res + 2 - 3) // 2 + 1
+            ch = getattr(L, "cout", getattr(L, "ch", ch))
+        shapes.append((b, ch, res, res))
+    inp = [torch.randn(s, generator=g) * 0.3 for s in shapes]
+    inp[2] = None                                             # a None entry is skipped (unet.py:47)
+    mid = [torch.randn(shapes[-1], generator=g) * 0.3]
+    outp = [torch.randn(s, generator=g) * 0.3 for s in shapes]  # skips are popped last-in-first-out, lists too
+    return {"input": inp[::-1], "middle": mid, "output": outp}
+
+
+def gen_unet_control(name, cfg, net, b=2, hw=16):
+    x, t, ctx, y = _inputs(cfg, b, hw, seed=11)
+    control = synth_control(cfg, b, hw)
+    with torch.no_grad():
+        eps = net(x.clone(), t, context=ctx, y=y, control={k: list(v) for k, v in control.items()}, transformer_options={})
+    torch.save({"eps": eps, "hw": hw}, os.path.join(GOLD, f"{name}_unet_ctrl.pt"))
+    print(name, "unet fwd with control", float(eps.std()))
+
+
 def gen_vae(name, cfg, b=2, hw=8):
     sd = synth.synth_vae_decoder_state_dict(cfg, seed=1)
     vae = ref_import.build_ref_vae(cfg)
@@ -431,6 +461,7 @@ def main():
         gen_samples("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
         gen_img2img("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
         gen_lora("tiny_sd15", synth.TINY_SD15_UNET_CONFIG)
+        gen_unet_control("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
         net, _ = gen_unet("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG)
         gen_samples("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG, net)
         gen_vae("tiny_vae", synth.TINY_VAE_CONFIG)

@@ -129,9 +129,21 @@ def _run_block(sd, cfg, prefix, h, emb, context, output_shape=None):
     return h
 
 
+def _apply_control(h, control, name):
+    """unet.py:44-52: pop the LAST tensor of control[name] and add it (None entries are skipped)."""
+    if control is not None and name in control and len(control[name]) > 0:
+        ctrl = control[name].pop()
+        if ctrl is not None:
+            h = h + ctrl
+    return h
+
+
 @torch.no_grad()
-def unet_forward(sd, cfg, x, timesteps, context, y=None):
-    """x [B,C,H,W] fp32, timesteps [B] (table index as float), context [B,T,D], y [B,adm] or None -> eps."""
+def unet_forward(sd, cfg, x, timesteps, context, y=None, control=None):
+    """x [B,C,H,W] fp32, timesteps [B] (table index as float), context [B,T,D], y [B,adm] or None -> eps.
+    control: {'input': [...], 'middle': [...], 'output': [...]} ControlNet residual lists (consumed from the end, unet.py:714,732,739)."""
+    if control is not None:
+        control = {k: list(v) for k, v in control.items()}
     mc = cfg["model_channels"]
     emb = _lin(sd, "time_embed.2", F.silu(_lin(sd, "time_embed.0", timestep_embedding(timesteps, mc))))
     if "label_emb.0.0.weight" in sd:
@@ -143,12 +155,15 @@ def unet_forward(sd, cfg, x, timesteps, context, y=None):
     while f"input_blocks.{i}.0.weight" in sd or any(
             f"input_blocks.{i}.0.{s}" in sd for s in ("in_layers.0.weight", "op.weight")):
         h = _run_block(sd, cfg, f"input_blocks.{i}", h, emb, context)
+        h = _apply_control(h, control, "input")
         hs.append(h)
         i += 1
     h = _run_block(sd, cfg, "middle_block", h, emb, context)
+    h = _apply_control(h, control, "middle")
     i = 0
     while f"output_blocks.{i}.0.in_layers.0.weight" in sd:
-        h = torch.cat([h, hs.pop()], dim=1)  # current first (unet.py:741)
+        hsp = _apply_control(hs.pop(), control, "output")
+        h = torch.cat([h, hsp], dim=1)  # current first (unet.py:741)
         out_shape = hs[-1].shape if hs else None
         h = _run_block(sd, cfg, f"output_blocks.{i}", h, emb, context, out_shape)
         i += 1

@@ -56,7 +56,7 @@ class KModel:
         t = self.predictor.timestep(torch.tensor(sig_host, dtype=torch.float32)).float()
         return t.repeat(reps)
 
-    def _forward_static(self, key, x, sigma_dev, sig_host, reps, ctxc):
+    def _forward_static(self, key, x, sigma_dev, sig_host, reps, ctxc, control=None):
         """pack -> UNet -> (returns eps view); static buffers per shape so the UNet can be graph-replayed."""
         b, c, hh, ww = x.shape
         bu = reps * b
@@ -72,8 +72,8 @@ class KModel:
         else:
             st["t"].copy_(tvals, non_blocking=False)
         net = self.diffusion_model
-        if not self.use_graph:
-            return net.forward_packed(st["xcol"], st["t"], ctxc, bu, hh, ww)
+        if not self.use_graph or control is not None:  # ControlNet residuals change every step: eager, not graph replay
+            return net.forward_packed(st["xcol"], st["t"], ctxc, bu, hh, ww, control)
         g = self._graphs.get(key)
         if g is None:
             # eager warm-up (sizes the arena, creates lazily-built buffers), then capture on a side stream
@@ -144,8 +144,8 @@ class KModel:
 
     def apply_model(self, x, t, c_concat=None, c_crossattn=None, control=None, transformer_options=None, y=None, **kwargs):
         """Reference signature (k_model.py:25): x fp32 [Bu,C,H,W], t = sigma [Bu] -> denoised fp32."""
-        if c_concat is not None or control is not None:
-            raise NotImplementedError("c_concat / control are outside the txt2img hot path")
+        if c_concat is not None:
+            raise NotImplementedError("c_concat (inpaint-model conditioning) is outside the built path")
         to = transformer_options or {}
         if to.get("patches") or to.get("patches_replace") or to.get("block_modifiers"):
             raise NotImplementedError("transformer patches are not supported by the native executor")
@@ -153,7 +153,7 @@ class KModel:
         sigma = t.to(device=self.device, dtype=torch.float32).contiguous()
         ctxc = self.diffusion_model.prepare_context(c_crossattn, y)
         b, c, hh, ww = x.shape
-        eps = self._forward_static((b, c, hh, ww, 1, "apply"), x, sigma, host_sigmas(t), 1, ctxc)
+        eps = self._forward_static((b, c, hh, ww, 1, "apply"), x, sigma, host_sigmas(t), 1, ctxc, control)
         return ops.cfg_combine(eps, eps.shape[-1], x, sigma, 1, 1.0)
 
 

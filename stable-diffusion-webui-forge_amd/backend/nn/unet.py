@@ -15,8 +15,10 @@ Differences from the reference that are design, not omissions:
   * cross-attention K / V^T of the text context and the SDXL label embedding depend only on the conditioning,
     so they are computed once per job and cached (`prepare_context`), not once per step (unet.py:145-155, :707);
   * all ResBlock `emb_layers` projections run as ONE GEMM per step.
-Hooks that need per-block Python callbacks on NCHW tensors (transformer patches, block modifiers, ControlNet
-residuals) are rejected explicitly -- callers that need them must use the PyTorch module path.
+ControlNet residuals (`control={'input': [...], 'middle': [...], 'output': [...]}`, unet.py:44-52,714,732,739) are injected
+natively (fp32 NCHW residual -> fp16 NHWC activation, one transposing add kernel each); such forwards run eagerly, not from
+the captured graph, since the residuals change every step.  Hooks that need per-block Python callbacks on NCHW tensors
+(transformer patches, block modifiers, group_norm_wrapper) are rejected explicitly.
 """
 import math
 
@@ -311,8 +313,19 @@ class IntegratedUNet2DConditionModel:
         return h
 
     # ------------------------------------------------------------------------------------------------------------
-    def _forward_impl(self, xcol, t, ctxc, bu, hh, ww, arena):
+    @staticmethod
+    def _apply_control(h, control, name):
+        """unet.py:44-52: pop the last residual of control[name]; None entries are skipped."""
+        if control is not None and name in control and len(control[name]) > 0:
+            ctrl = control[name].pop()
+            if ctrl is not None:
+                ops.add_control_(h, ctrl)
+        return h
+
+    def _forward_impl(self, xcol, t, ctxc, bu, hh, ww, arena, control=None):
         """xcol: [Bu*H*W, 64] im2col of the (scaled) input; t: [Bu] fp32 table indices.  -> eps [Bu*H*W, out_ch]"""
+        if control is not None:
+            control = {k: list(v) for k, v in control.items()}
         lay = self.layout
         te = lay.time_embed_dim
         t_emb = ops.timestep_embedding(t, lay.model_channels)
@@ -329,10 +342,12 @@ class IntegratedUNet2DConditionModel:
                 h = ops.linear(xcol, cw, cb).view(bu, hh, ww, lay.model_channels)
             else:
                 h = self._run_block(blk, h, None, emb_all, ctxc, arena)
+            h = self._apply_control(h, control, "input")
             hs.append(h)
         h = self._run_block(lay.middle, h, None, emb_all, ctxc, arena)
+        h = self._apply_control(h, control, "middle")
         for blk in lay.output_blocks:
-            skip = hs.pop()
+            skip = self._apply_control(hs.pop(), control, "output")
             up_to = (hs[-1].shape[1], hs[-1].shape[2]) if hs else None
             h = self._run_block(blk, h, skip, emb_all, ctxc, arena, up_to)
         g = ops.groupnorm(h, *self.w["out.gn"], 1e-5, silu=True)
@@ -346,7 +361,7 @@ class IntegratedUNet2DConditionModel:
             self._arena = Arena(need, self.device)
         return self._arena
 
-    def forward_packed(self, xcol, t, ctxc, bu, hh, ww):
+    def forward_packed(self, xcol, t, ctxc, bu, hh, ww, control=None):
         """Hot-path entry (no layout conversion): returns eps as fp16 [Bu*H*W, out_channels] living in the arena
         (valid until the next forward)."""
         while True:
@@ -354,7 +369,7 @@ class IntegratedUNet2DConditionModel:
             arena.reset()
             try:
                 with arena:
-                    return self._forward_impl(xcol, t, ctxc, bu, hh, ww, arena)
+                    return self._forward_impl(xcol, t, ctxc, bu, hh, ww, arena, control)
             except ArenaOverflow:
                 torch.cuda.synchronize(self.device)
                 self._arena_bytes = arena.capacity * 2
@@ -363,16 +378,16 @@ class IntegratedUNet2DConditionModel:
     # reference-compatible signature (backend/nn/unet.py:696): NCHW in, NCHW out
     def forward(self, x, timesteps=None, context=None, y=None, control=None, transformer_options=None, **kwargs):
         to = transformer_options or {}
-        if control is not None or to.get("patches") or to.get("patches_replace") or to.get("block_modifiers") \
+        if to.get("patches") or to.get("patches_replace") or to.get("block_modifiers") \
                 or to.get("block_inner_modifiers") or "group_norm_wrapper" in to:
-            raise NotImplementedError("per-block Python hooks / ControlNet residuals are not supported by the native "
-                                      "MI355X executor; run those jobs through the PyTorch module path")
+            raise NotImplementedError("per-block Python hooks are not supported by the native MI355X executor; run those jobs "
+                                      "through the PyTorch module path")
         assert (y is not None) == (self.num_classes is not None)
         bu, c, hh, ww = x.shape
         ctxc = self.prepare_context(context, y)
         ones = torch.zeros(bu, dtype=torch.float32, device=self.device)  # sigma = 0 -> scale 1/sqrt(0 + 1) = 1
         xcol = ops.unet_pack_input(x.to(device=self.device, dtype=torch.float32).contiguous(), ones, 1, 1.0)
-        eps = self.forward_packed(xcol, timesteps.to(device=self.device, dtype=torch.float32).contiguous(), ctxc, bu, hh, ww)
+        eps = self.forward_packed(xcol, timesteps.to(device=self.device, dtype=torch.float32).contiguous(), ctxc, bu, hh, ww, control)
         return eps.view(bu, hh, ww, -1).permute(0, 3, 1, 2).to(x.dtype)
 
     __call__ = forward

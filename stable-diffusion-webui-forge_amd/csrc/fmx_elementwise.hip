@@ -28,6 +28,29 @@ __global__ void silu_kernel(const f16* __restrict__ x, f16* __restrict__ y, long
     y[i] = (f16)silu_f((float)x[i]);
 }
 
+// h NHWC fp16 += ctrl NCHW fp32.  One block handles a 64-pixel x 64-channel patch through LDS so both sides are coalesced.
+__global__ void add_control_nchw_kernel(f16* __restrict__ h, const float* __restrict__ ctrl, int c, long npix) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.z;
+  const long p0 = (long)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 256 threads: 4 rows of 64
+  for (int r = ty; r < 64; r += 4) {                        // r = channel within the patch, tx = pixel
+    const int ch = c0 + r;
+    const long p = p0 + tx;
+    tile[r][tx] = (ch < c && p < npix) ? ctrl[((long)b * c + ch) * npix + p] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {                        // r = pixel within the patch, tx = channel
+    const long p = p0 + r;
+    const int ch = c0 + tx;
+    if (p < npix && ch < c) {
+      f16* q = h + ((long)b * npix + p) * c + ch;
+      *q = (f16)((float)*q + tile[tx][r]);
+    }
+  }
+}
+
 __global__ void cast_f32_f16_kernel(const float* __restrict__ x, f16* __restrict__ y, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = (f16)x[i];
 }
@@ -223,6 +246,14 @@ extern "C" int fmx_silu_f16(const void* x, void* y, int64_t n, void* stream) {
   FMX_REQUIRE(x && y && n > 0, "silu: bad args");
   hipLaunchKernelGGL(silu_kernel, dim3(grid_for(n, 4)), dim3(TPB), 0, (hipStream_t)stream, (const f16*)x, (f16*)y, (long)n);
   FMX_LAUNCH_CHECK("fmx_silu_f16");
+  return FMX_OK;
+}
+
+extern "C" int fmx_add_control_nchw(void* h, const float* ctrl, int32_t b, int32_t c, int64_t npix, void* stream) {
+  FMX_REQUIRE(h && ctrl && b > 0 && c > 0 && npix > 0, "add_control: bad args");
+  hipLaunchKernelGGL(add_control_nchw_kernel, dim3((unsigned)((npix + 63) / 64), (unsigned)((c + 63) / 64), (unsigned)b), dim3(256), 0,
+                     (hipStream_t)stream, (f16*)h, ctrl, c, (long)npix);
+  FMX_LAUNCH_CHECK("fmx_add_control_nchw");
   return FMX_OK;
 }
 

@@ -277,6 +277,16 @@ def silu(x, out=None):
     return out
 
 
+def add_control_(h, ctrl):
+    """h [B,H,W,C] fp16 NHWC += ctrl [B,C,H,W] fp32 NCHW (ControlNet residual, unet.py:44-52), in place."""
+    b, hh, ww, c = h.shape
+    if tuple(ctrl.shape) != (b, c, hh, ww):
+        raise ValueError(f"control residual {tuple(ctrl.shape)} does not match activation {(b, c, hh, ww)}")
+    ctrl = ctrl.to(device=h.device, dtype=torch.float32).contiguous()
+    _lib.check(_lib.lib().fmx_add_control_nchw(_p(h), _p(ctrl), b, c, hh * ww, stream_ptr()), "fmx_add_control_nchw")
+    return h
+
+
 def cast_f16(x, out=None):
     if out is None:
         out = empty(x.shape, torch.float16, x.device)

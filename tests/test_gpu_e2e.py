@@ -56,6 +56,22 @@ def test_unet_forward_vs_reference_fixture(name, engines):
     report(f"{name} unet forward vs reference", max_rel(eps, g["eps"]), 3e-3)
 
 
+def test_unet_forward_with_controlnet_residuals(engines):
+    """ControlNet residual injection (unet.py:44-52: after every input block, after the middle block, on every skip) against the
+    real reference UNet fed the same residual lists (tests/golden/tiny_sd15_unet_ctrl.pt); also through KModel.apply_model."""
+    from oracle.make_golden import synth_control
+    g, fx = load_golden("tiny_sd15_unet_ctrl.pt"), load_golden("tiny_sd15_unet_fwd.pt")
+    cfg = TINY["tiny_sd15"]
+    net = engines["tiny_sd15"].forge_objects.unet.model.diffusion_model
+    control = synth_control(cfg, fx["x"].shape[0], g["hw"])
+    dev_control = {k: [None if t is None else t.to(DEV) for t in v] for k, v in control.items()}
+    eps = net.forward(fx["x"].to(DEV), fx["t"].to(DEV), context=fx["ctx"].to(DEV), y=None, control=dev_control)
+    report("tiny_sd15 unet forward with control residuals vs reference", max_rel(eps, g["eps"]), 3e-3)
+    assert all(len(v) == len(control[k]) for k, v in dev_control.items()), "the caller's lists must not be consumed"
+    plain = net.forward(fx["x"].to(DEV), fx["t"].to(DEV), context=fx["ctx"].to(DEV), y=None)
+    assert max_rel(plain, fx["eps"]) < 3e-3 and max_rel(eps, plain) > 0.1
+
+
 def test_vae_decode_vs_reference_fixture(engines):
     g = load_golden("tiny_vae_decode.pt")
     vae = engines["tiny_sd15"].forge_objects.vae.first_stage_model

@@ -168,3 +168,13 @@ def test_img2img_oracle_vs_reference_fixture():
     # the kept region is exactly the original (processing.py:1865-1866)
     keep = r["mask"] == 1.0
     assert torch.equal(lat[keep], g["init_latent"][keep])
+
+
+def test_unet_control_residuals_oracle_vs_reference_fixture():
+    """apply_control (backend/nn/unet.py:44-52) at the three injection points: oracle vs the real reference UNet."""
+    from oracle.make_golden import synth_control
+    g, fx = load_golden("tiny_sd15_unet_ctrl.pt"), load_golden("tiny_sd15_unet_fwd.pt")
+    cfg = synth.TINY_SD15_UNET_CONFIG
+    sd = synth.synth_unet_state_dict(cfg, seed=0)
+    out = unet_forward(sd, cfg, fx["x"], fx["t"], fx["ctx"], None, control=synth_control(cfg, fx["x"].shape[0], g["hw"]))
+    assert max_rel(out, g["eps"]) < 1e-4
