@@ -124,6 +124,7 @@ typedef struct fmx_attn_args {
   int64_t o_bs, o_rs;
   int32_t batch, heads, nq, nk, nk_pad, dpad;
   float scale;
+  int32_t causal; /* 1: key j attends only for j <= query i (CLIP text encoder, transformers causal mask); occupies former padding */
   const void* zero_page;
 } fmx_attn_args;
 
@@ -171,6 +172,11 @@ int fmx_silu_f16(const void* x, void* y, int64_t n, void* stream);
  * (the executor's activation layout), ctrl: fp32 NCHW [B][C][npix] as the ControlNet produces it. */
 int fmx_add_control_nchw(void* h, const float* ctrl, int32_t b, int32_t c, int64_t npix, void* stream);
 int fmx_cast_f32_to_f16(const float* x, void* y, int64_t n, void* stream);
+/* y = act(x), fp16, kind 0 = quick_gelu x*sigmoid(1.702x) (CLIP-L), 1 = exact erf GELU (CLIP-G) */
+int fmx_act_f16(const void* x, void* y, int64_t n, int32_t kind, void* stream);
+/* CLIP text embeddings (transformers CLIPTextEmbeddings): out[b*T + t][:] = tok_emb[ids[b*T + t]][:] + pos_emb[t][:], fp16, c % 8 == 0 */
+int fmx_embed_tokens(const int32_t* ids, const void* tok_emb, const void* pos_emb, void* out, int32_t batch, int32_t tokens, int32_t c,
+                     int32_t vocab, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Sampler-side fused elementwise (fp32 latents NCHW [b][c][h][w], as the reference keeps them)

@@ -97,6 +97,40 @@ def gen_unet_control(name, cfg, net, b=2, hw=16):
     print(name, "unet fwd with control", float(eps.std()))
 
 
+def clip_test_tokens(cfg, b=2, seed=1):
+    """token ids shaped like a tokenised prompt batch: BOS, words, EOS (= largest id), padding with EOS (classic_engine.py:76-83)"""
+    g = torch.Generator("cpu").manual_seed(seed)
+    v = cfg["vocab_size"]
+    ids = torch.randint(3, v - 2, (b, 77), generator=g)
+    ids[:, 0] = v - 2
+    for i, n in enumerate((10, 76)[:b]):
+        ids[i, n:] = v - 1
+    return ids
+
+
+def gen_clip(name, cfg):
+    """transformers.CLIPTextModel (the package that executes the reference's text-encoder arithmetic, backend/nn/clip.py:4-12)
+    with the synthetic weights: every hidden state the classic engine can select, final LayerNorm, pooled (+ projection)."""
+    from transformers import CLIPTextConfig, CLIPTextModel
+    sd = synth.synth_clip_state_dict(cfg)
+    hc = CLIPTextConfig(vocab_size=cfg["vocab_size"], hidden_size=cfg["hidden_size"], intermediate_size=cfg["intermediate_size"],
+                        num_hidden_layers=cfg["num_hidden_layers"], num_attention_heads=cfg["num_attention_heads"], max_position_embeddings=77,
+                        hidden_act=cfg["hidden_act"], eos_token_id=2, bos_token_id=0, pad_token_id=1, projection_dim=cfg["hidden_size"])
+    m = CLIPTextModel(hc).eval()
+    pref = "text_model." if any(k.startswith("text_model.") for k in m.state_dict()) else ""
+    miss = m.load_state_dict({pref + k[len("transformer.text_model."):]: v for k, v in sd.items() if k.startswith("transformer.text_model.")}, strict=True)
+    ids = clip_test_tokens(cfg)
+    with torch.no_grad():
+        out = m(ids, output_hidden_states=True)
+        fin = m.text_model.final_layer_norm if hasattr(m, "text_model") else m.final_layer_norm
+        res = {"ids": ids, "hidden_last": out.hidden_states[-1], "hidden_penultimate": out.hidden_states[-2], "last_hidden_state": out.last_hidden_state,
+               "penultimate_final_ln": fin(out.hidden_states[-2]), "pooled": out.pooler_output}
+        if "transformer.text_projection.weight" in sd:
+            res["pooled_projected"] = torch.nn.functional.linear(out.pooler_output, sd["transformer.text_projection.weight"])
+    torch.save(res, os.path.join(GOLD, f"{name}.pt"))
+    print(name, tuple(out.last_hidden_state.shape), float(out.last_hidden_state.std()))
+
+
 def gen_vae(name, cfg, b=2, hw=8):
     sd = synth.synth_vae_decoder_state_dict(cfg, seed=1)
     vae = ref_import.build_ref_vae(cfg)
@@ -466,6 +500,9 @@ def main():
         gen_samples("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG, net)
         gen_vae("tiny_vae", synth.TINY_VAE_CONFIG)
         gen_vae_encode("tiny_vae", synth.TINY_VAE_CONFIG)
+    if a.only in ("", "clip"):
+        gen_clip("tiny_clip_l", synth.TINY_CLIP_L_CONFIG)
+        gen_clip("tiny_clip_g", synth.TINY_CLIP_G_CONFIG)
     if a.only in ("", "flux"):
         gen_flux()
     if a.full or a.only == "full":

@@ -44,7 +44,7 @@ class AttnArgs(C.Structure):
         ("q_bs", C.c_int64), ("q_rs", C.c_int64), ("k_bs", C.c_int64), ("k_rs", C.c_int64),
         ("vt_bs", C.c_int64), ("vt_hs", C.c_int64), ("vt_ds", C.c_int64), ("o_bs", C.c_int64), ("o_rs", C.c_int64),
         ("batch", C.c_int32), ("heads", C.c_int32), ("nq", C.c_int32), ("nk", C.c_int32), ("nk_pad", C.c_int32),
-        ("dpad", C.c_int32), ("scale", C.c_float), ("zero_page", C.c_void_p),
+        ("dpad", C.c_int32), ("scale", C.c_float), ("causal", C.c_int32), ("zero_page", C.c_void_p),
     ]
 
 
@@ -66,6 +66,8 @@ SIGNATURES = {
     "fmx_flux_qk_norm_rope_f16": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
     "fmx_timestep_embedding": [_vp, _vp, _i32, _i32, _f32, _vp],
     "fmx_silu_f16": [_vp, _vp, _i64, _vp],
+    "fmx_act_f16": [_vp, _vp, _i64, _i32, _vp],
+    "fmx_embed_tokens": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "fmx_add_control_nchw": [_vp, _vp, _i32, _i32, _i64, _vp],
     "fmx_cast_f32_to_f16": [_vp, _vp, _i64, _vp],
     "fmx_unet_pack_input": [_vp, _vp, _f32, _i32, _i32, _i32, _i32, _i32, _vp, _vp],

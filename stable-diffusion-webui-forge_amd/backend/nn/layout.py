@@ -370,6 +370,37 @@ def vae_encoder_param_shapes(cfg):
     return s
 
 
+# ------------------------------------------------------------------------------------------------
+# CLIP text encoder (backend/nn/clip.py IntegratedCLIP over transformers' CLIPTextModel; key names as in Forge checkpoints)
+# ------------------------------------------------------------------------------------------------
+
+def clip_param_shapes(cfg):
+    """cfg: hidden_size, intermediate_size, num_hidden_layers, num_attention_heads, vocab_size, max_position_embeddings,
+    hidden_act ('quick_gelu' | 'gelu'), optional add_text_projection"""
+    c, f = cfg["hidden_size"], cfg["intermediate_size"]
+    s = OrderedDict()
+    p = "transformer.text_model."
+    s[p + "embeddings.token_embedding.weight"] = (cfg["vocab_size"], c)
+    s[p + "embeddings.position_embedding.weight"] = (cfg["max_position_embeddings"], c)
+    for i in range(cfg["num_hidden_layers"]):
+        b = f"{p}encoder.layers.{i}."
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            s[b + f"self_attn.{n}.weight"] = (c, c)
+            s[b + f"self_attn.{n}.bias"] = (c,)
+        for n in ("layer_norm1", "layer_norm2"):
+            s[b + n + ".weight"] = (c,)
+            s[b + n + ".bias"] = (c,)
+        s[b + "mlp.fc1.weight"] = (f, c)
+        s[b + "mlp.fc1.bias"] = (f,)
+        s[b + "mlp.fc2.weight"] = (c, f)
+        s[b + "mlp.fc2.bias"] = (c,)
+    s[p + "final_layer_norm.weight"] = (c,)
+    s[p + "final_layer_norm.bias"] = (c,)
+    if cfg.get("add_text_projection"):
+        s["transformer.text_projection.weight"] = (c, c)
+    return s
+
+
 # ---- Flux (MMDiT) ---------------------------------------------------------------------------------------------------
 def flux_param_shapes(cfg):
     """State-dict keys / shapes of IntegratedFluxTransformer2DModel (backend/nn/flux.py:310-367) for a config dict with the

@@ -30,6 +30,7 @@ struct AttnParams {
   long q_bs, q_rs, k_bs, k_rs, vt_bs, vt_hs, vt_ds, o_bs, o_rs;
   int batch, heads, nq, nk, nk_pad, qtiles;
   float scale_log2e;
+  int causal;
   const f16* zp;
 };
 
@@ -146,6 +147,14 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           if (kt * KVB + s * 32 + hi * 16 + r >= p.nk) sacc[s][r] = -INFINITY;
+    }
+    if (p.causal && (kt + 1) * KVB - 1 > q0) {  // causal mask (CLIP text encoder): key j > query i never attends; the first key
+      const int qi = q0 + li;                   // tile always holds key 0 <= i, so the running max is finite from tile 0 on
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kt * KVB + s * 32 + hi * 16 + r > qi) sacc[s][r] = -INFINITY;
     }
     float mx = sacc[0][0];
 #pragma unroll
@@ -466,13 +475,15 @@ extern "C" int fmx_attention_f16(const fmx_attn_args* a, void* stream) {
   const bool force32 = a->scale < 0.f;
   p.scale_log2e = fabsf(a->scale) * 1.44269504088896340736f;
   p.zp = (const f16*)a->zero_page;
+  p.causal = a->causal ? 1 : 0;
+  FMX_REQUIRE(!p.causal || a->nq == a->nk, "attention: the causal mask is defined for self-attention (nq == nk)");
   hipStream_t st = (hipStream_t)stream;
   switch (a->dpad) {
     case 48: return launch_attn<48>(p, st);
     case 64:
       // 64-query-per-wave variant when there are enough queries to fill 256-query workgroups (test hook: scale < 0 forces
       // the 32-query kernel)
-      if (a->nq >= 256 && !force32) return launch_attn_q64(p, st);
+      if (a->nq >= 256 && !force32 && !p.causal) return launch_attn_q64(p, st);
       return launch_attn<64>(p, st);
     case 80: return launch_attn<80>(p, st);
     case 128: return launch_attn<128>(p, st);

@@ -51,6 +51,28 @@ __global__ void add_control_nchw_kernel(f16* __restrict__ h, const float* __rest
   }
 }
 
+__global__ void act_kernel(const f16* __restrict__ x, f16* __restrict__ y, long n, int kind) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = (float)x[i];
+    y[i] = (f16)(kind == 0 ? v / (1.0f + __expf(-1.702f * v)) : gelu_erf_f(v));
+  }
+}
+
+__global__ void embed_tokens_kernel(const int* __restrict__ ids, const f16* __restrict__ tok, const f16* __restrict__ pos, f16* __restrict__ out,
+                                    int tokens, int c, int vocab) {
+  const int row = blockIdx.x;                      // b * tokens + t
+  const int t = row % tokens;
+  const int id = min(max(ids[row], 0), vocab - 1);
+  for (int j = threadIdx.x * 8; j < c; j += blockDim.x * 8) {
+    const f16x8 a = *reinterpret_cast<const f16x8*>(tok + (long)id * c + j);
+    const f16x8 b = *reinterpret_cast<const f16x8*>(pos + (long)t * c + j);
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (f16)((float)a[e] + (float)b[e]);
+    *reinterpret_cast<f16x8*>(out + (long)row * c + j) = o;
+  }
+}
+
 __global__ void cast_f32_f16_kernel(const float* __restrict__ x, f16* __restrict__ y, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = (f16)x[i];
 }
@@ -254,6 +276,22 @@ extern "C" int fmx_add_control_nchw(void* h, const float* ctrl, int32_t b, int32
   hipLaunchKernelGGL(add_control_nchw_kernel, dim3((unsigned)((npix + 63) / 64), (unsigned)((c + 63) / 64), (unsigned)b), dim3(256), 0,
                      (hipStream_t)stream, (f16*)h, ctrl, c, (long)npix);
   FMX_LAUNCH_CHECK("fmx_add_control_nchw");
+  return FMX_OK;
+}
+
+extern "C" int fmx_act_f16(const void* x, void* y, int64_t n, int32_t kind, void* stream) {
+  FMX_REQUIRE(x && y && n > 0 && (kind == 0 || kind == 1), "act: bad args");
+  hipLaunchKernelGGL(act_kernel, dim3(grid_for(n, 4)), dim3(TPB), 0, (hipStream_t)stream, (const f16*)x, (f16*)y, (long)n, kind);
+  FMX_LAUNCH_CHECK("fmx_act_f16");
+  return FMX_OK;
+}
+
+extern "C" int fmx_embed_tokens(const int32_t* ids, const void* tok_emb, const void* pos_emb, void* out, int32_t batch, int32_t tokens, int32_t c,
+                                int32_t vocab, void* stream) {
+  FMX_REQUIRE(ids && tok_emb && pos_emb && out && batch > 0 && tokens > 0 && c > 0 && (c % 8) == 0 && vocab > 0, "embed_tokens: bad args");
+  hipLaunchKernelGGL(embed_tokens_kernel, dim3(batch * tokens), dim3(128), 0, (hipStream_t)stream, ids, (const f16*)tok_emb, (const f16*)pos_emb,
+                     (f16*)out, tokens, c, vocab);
+  FMX_LAUNCH_CHECK("fmx_embed_tokens");
   return FMX_OK;
 }
 

@@ -178,7 +178,7 @@ def geglu_interleave(w, b):
 
 
 def attention(q, k, vt, *, batch, heads, nq, nk, nk_pad, dpad, scale, q_bs, q_rs, k_bs, k_rs, vt_bs, vt_hs, vt_ds,
-              out=None, force32=False):
+              out=None, force32=False, causal=False):
     """q/k/vt are base tensors (views allowed: the data_ptr is the element (0,0,0,0)); strides in elements."""
     _check_f16(q, k, vt)
     if out is None:
@@ -191,6 +191,7 @@ def attention(q, k, vt, *, batch, heads, nq, nk, nk_pad, dpad, scale, q_bs, q_rs
     a.batch, a.heads, a.nq, a.nk, a.nk_pad, a.dpad = batch, heads, nq, nk, nk_pad, dpad
     a.scale = -float(scale) if force32 else float(scale)  # test hook: negative scale selects the 32-query-per-wave kernel
     a.zero_page = _p(zero_page(q.device))
+    a.causal = 1 if causal else 0
     if _profiler is not None:
         d_true = int(round(float(scale) ** -2))
         flops = 4.0 * batch * heads * nq * nk * d_true
@@ -285,6 +286,26 @@ def add_control_(h, ctrl):
     ctrl = ctrl.to(device=h.device, dtype=torch.float32).contiguous()
     _lib.check(_lib.lib().fmx_add_control_nchw(_p(h), _p(ctrl), b, c, hh * ww, stream_ptr()), "fmx_add_control_nchw")
     return h
+
+
+ACT_QUICK_GELU, ACT_GELU_ERF = 0, 1
+
+
+def act(x, kind, out=None):
+    if out is None:
+        out = empty(x.shape, torch.float16, x.device)
+    _lib.check(_lib.lib().fmx_act_f16(_p(x), _p(out), x.numel(), int(kind), stream_ptr()), "fmx_act_f16")
+    return out
+
+
+def embed_tokens(ids, tok_emb, pos_emb, out=None):
+    """ids int32 [B, T] -> fp16 [B*T, C] = tok_emb[ids] + pos_emb[t]"""
+    b, t = ids.shape
+    c = tok_emb.shape[1]
+    if out is None:
+        out = empty((b * t, c), torch.float16, ids.device)
+    _lib.check(_lib.lib().fmx_embed_tokens(_p(ids), _p(tok_emb), _p(pos_emb), _p(out), b, t, c, tok_emb.shape[0], stream_ptr()), "fmx_embed_tokens")
+    return out
 
 
 def cast_f16(x, out=None):

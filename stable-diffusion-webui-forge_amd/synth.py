@@ -18,7 +18,7 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
-from .backend.nn.layout import flux_param_shapes, unet_param_shapes, vae_decoder_param_shapes, vae_encoder_param_shapes
+from .backend.nn.layout import clip_param_shapes, flux_param_shapes, unet_param_shapes, vae_decoder_param_shapes, vae_encoder_param_shapes
 
 # LDM-style unet_config dicts (parameter counts 859.52 M / 2567.46 M verified against
 # the reference module in tests/test_oracle_vs_reference.py).
@@ -134,6 +134,22 @@ def synth_vae_state_dict(cfg, seed=1, **kw):
     shapes = OrderedDict(vae_decoder_param_shapes(cfg))
     shapes.update(vae_encoder_param_shapes(cfg))
     return synth_state_dict(shapes, seed=seed, **kw)
+
+
+# CLIP-L (SD1.x / SDXL first encoder) and OpenCLIP bigG (SDXL second encoder) text-model configs, and tiny twins with the
+# real head width (64) for the parity tests
+CLIP_L_CONFIG = dict(hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12, vocab_size=49408,
+                     max_position_embeddings=77, hidden_act="quick_gelu")
+CLIP_G_CONFIG = dict(hidden_size=1280, intermediate_size=5120, num_hidden_layers=32, num_attention_heads=20, vocab_size=49408,
+                     max_position_embeddings=77, hidden_act="gelu", add_text_projection=True)
+TINY_CLIP_L_CONFIG = dict(hidden_size=128, intermediate_size=256, num_hidden_layers=3, num_attention_heads=2, vocab_size=1000,
+                          max_position_embeddings=77, hidden_act="quick_gelu")
+TINY_CLIP_G_CONFIG = dict(hidden_size=192, intermediate_size=320, num_hidden_layers=4, num_attention_heads=3, vocab_size=1000,
+                          max_position_embeddings=77, hidden_act="gelu", add_text_projection=True)
+
+
+def synth_clip_state_dict(cfg, seed=4, **kw):
+    return synth_state_dict(clip_param_shapes(cfg), seed=seed, **kw)
 
 
 def synth_conditioning(batch, context_dim, adm_in_channels=None, tokens=77, seed=1234):

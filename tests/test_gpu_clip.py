@@ -1,0 +1,62 @@
+"""GPU (MI355X): native CLIP text encoder vs fixtures produced by transformers' CLIPTextModel (the package that executes the
+reference's text-encoder arithmetic, backend/nn/clip.py) with the same synthetic weights, and the classic engine's emphasis
+path vs the CPU oracle."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import forge_amd  # noqa: E402
+from forge_amd import synth  # noqa: E402
+from forge_amd.backend.nn.clip import IntegratedCLIP  # noqa: E402
+from forge_amd.backend.text_processing.classic_engine import ClassicTextProcessingEngine  # noqa: E402
+from oracle import clip as oclip  # noqa: E402
+
+from conftest import load_golden  # noqa: E402
+
+DEV = "cuda"
+
+
+def max_rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / b.abs().max())
+
+
+def report(name, val, tol):
+    print(f"[parity] {name}: max_rel={val:.3e} (tol {tol:.0e})")
+    assert val < tol, f"{name}: {val} >= {tol}"
+
+
+@pytest.mark.parametrize("name,cfg", [("tiny_clip_l", synth.TINY_CLIP_L_CONFIG), ("tiny_clip_g", synth.TINY_CLIP_G_CONFIG)])
+def test_clip_text_encoder_vs_transformers_fixture(name, cfg):
+    g = load_golden(name + ".pt")
+    net = IntegratedCLIP(cfg, synth.synth_clip_state_dict(cfg), device=DEV)
+    z, pooled = net.encode(g["ids"], clip_skip=1, final_layer_norm=True, return_pooled=True)
+    report(f"{name} last_hidden_state (causal attention, {cfg['hidden_act']})", max_rel(z, g["last_hidden_state"]), 3e-3)
+    report(f"{name} pooled (EOS position)", max_rel(pooled, g["pooled"]), 3e-3)
+    z2, _ = net.encode(g["ids"], clip_skip=2, final_layer_norm=False)
+    report(f"{name} penultimate hidden state (SDXL clip skip)", max_rel(z2, g["hidden_penultimate"]), 3e-3)
+    z3, _ = net.encode(g["ids"], clip_skip=2, final_layer_norm=True)
+    report(f"{name} penultimate + final LayerNorm (SD1.x clip skip 2)", max_rel(z3, g["penultimate_final_ln"]), 3e-3)
+    if "pooled_projected" in g:
+        _, pp = net.encode(g["ids"], return_pooled=True, project_pooled=True)
+        report(f"{name} pooled x text_projection", max_rel(pp, g["pooled_projected"]), 3e-3)
+
+
+def test_classic_engine_emphasis_and_chunks():
+    cfg = synth.TINY_CLIP_L_CONFIG
+    sd = synth.synth_clip_state_dict(cfg)
+    g = load_golden("tiny_clip_l.pt")
+    eng = ClassicTextProcessingEngine(IntegratedCLIP(cfg, sd, device=DEV), embedding_key="clip_l", return_pooled=True, clip_skip=2, final_layer_norm=True)
+    ids = g["ids"]
+    mult = torch.ones(ids.shape)
+    mult[0, 3:6] = 1.3
+    mult[1, 10:20] = 0.7
+    ids2 = torch.flip(ids, dims=[0])
+    out = eng([ids.tolist(), ids2.tolist()], [mult.tolist(), mult.tolist()])
+    assert out.shape == (2, 154, cfg["hidden_size"]) and out.pooled.shape == (2, cfg["hidden_size"])
+    want = []
+    for t in (ids, ids2):
+        z, pooled = oclip.encode_with_transformers(sd, cfg, t, clip_skip=2, final_layer_norm=True, return_pooled=True)
+        want.append(oclip.apply_emphasis_original(z, mult))
+    report("classic engine: 2 chunks, emphasis Original, clip skip 2", max_rel(out, torch.hstack(want)), 3e-3)

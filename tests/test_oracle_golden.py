@@ -178,3 +178,20 @@ def test_unet_control_residuals_oracle_vs_reference_fixture():
     sd = synth.synth_unet_state_dict(cfg, seed=0)
     out = unet_forward(sd, cfg, fx["x"], fx["t"], fx["ctx"], None, control=synth_control(cfg, fx["x"].shape[0], g["hw"]))
     assert max_rel(out, g["eps"]) < 1e-4
+
+
+@pytest.mark.parametrize("name,cfg", [("tiny_clip_l", synth.TINY_CLIP_L_CONFIG), ("tiny_clip_g", synth.TINY_CLIP_G_CONFIG)])
+def test_clip_oracle_vs_transformers_fixture(name, cfg):
+    """oracle/clip.py vs transformers.CLIPTextModel outputs (tests/golden/tiny_clip_*.pt)."""
+    from oracle import clip as oclip
+    g = load_golden(name + ".pt")
+    sd = synth.synth_clip_state_dict(cfg)
+    hs = oclip.clip_hidden_states(sd, cfg, g["ids"])
+    assert max_rel(hs[-1], g["hidden_last"]) < 1e-5 and max_rel(hs[-2], g["hidden_penultimate"]) < 1e-5
+    z, pooled = oclip.encode_with_transformers(sd, cfg, g["ids"], return_pooled=True, is_clip_l=True)
+    assert max_rel(z, g["last_hidden_state"]) < 1e-5 and max_rel(pooled, g["pooled"]) < 1e-5
+    z2, _ = oclip.encode_with_transformers(sd, cfg, g["ids"], clip_skip=2)
+    assert max_rel(z2, g["penultimate_final_ln"]) < 1e-5
+    if "pooled_projected" in g:
+        _, pp = oclip.encode_with_transformers(sd, cfg, g["ids"], return_pooled=True, is_clip_l=False)
+        assert max_rel(pp, g["pooled_projected"]) < 1e-5
