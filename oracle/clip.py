@@ -72,3 +72,20 @@ def apply_emphasis_original(z, multipliers):
     z = z * multipliers.reshape(multipliers.shape + (1,)).expand(z.shape)
     new_mean = z.mean()
     return z * (original_mean / new_mean)
+
+
+def timestep_embedder_256(v):
+    """backend/nn/unet.py:55-67 at dim 256 (diffusion_engine/sdxl.py:72 `Timestep(256)`): [cos | sin] of v * exp(-ln 1e4 * k / 128)."""
+    half = 128
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+    a = torch.tensor([float(v)])[:, None] * freqs[None]
+    return torch.cat([torch.cos(a), torch.sin(a)], dim=-1)
+
+
+@torch.no_grad()
+def sdxl_conditioning(sd_l, cfg_l, sd_g, cfg_g, ids_l, ids_g, width, height, crop_left=0, crop_top=0):
+    """diffusion_engine/sdxl.py:76-117 for one 77-token chunk per prompt without emphasis."""
+    cond_l, _ = encode_with_transformers(sd_l, cfg_l, ids_l, clip_skip=2, final_layer_norm=False)
+    cond_g, pooled = encode_with_transformers(sd_g, cfg_g, ids_g, clip_skip=2, final_layer_norm=False, return_pooled=True, is_clip_l=False)
+    flat = torch.cat([timestep_embedder_256(v) for v in (height, width, crop_top, crop_left, height, width)]).flatten()[None].repeat(pooled.shape[0], 1)
+    return {"crossattn": torch.cat([cond_l, cond_g], dim=2), "vector": torch.cat([pooled, flat], dim=1)}

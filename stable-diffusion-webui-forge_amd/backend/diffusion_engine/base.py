@@ -1,6 +1,6 @@
 """`ForgeObjects` / engine object protocol -- mirror of backend/diffusion_engine/base.py:7-20 and the attributes of
 sd15.py:19-84 / sdxl.py:22-138 the call surface touches: forge_objects{,_original,_after_applying_lora}, is_sdxl,
-decode_first_stage, get_learned_conditioning (absent: text encoders are out of scope -> cond tensors are supplied)."""
+decode_first_stage, encode_first_stage, get_learned_conditioning (from token batches; cond tensors may also be supplied directly)."""
 import torch
 
 from ..modules.k_prediction import Prediction
@@ -46,8 +46,57 @@ class ForgeDiffusionEngine:
         sample = vae.first_stage_model.process_in(sample)
         return sample.to(x)
 
+    # ---- text conditioning (sd15.py:19-73, sdxl.py:22-120), from TOKEN batches: tokenisation is host-side string work ----------
+    def attach_text_encoders(self, clip_l, clip_g=None):
+        """clip_l / clip_g: forge_amd.backend.nn.clip.IntegratedCLIP.  Engine options as the reference constructs them."""
+        from ..text_processing.classic_engine import ClassicTextProcessingEngine
+        if self.is_sdxl:
+            if clip_g is None:
+                raise ValueError("SDXL needs both text encoders")
+            self.text_processing_engine_l = ClassicTextProcessingEngine(clip_l, embedding_key="clip_l", text_projection=False, minimal_clip_skip=2,
+                                                                        clip_skip=2, return_pooled=False, final_layer_norm=False)
+            self.text_processing_engine_g = ClassicTextProcessingEngine(clip_g, embedding_key="clip_g", text_projection=True, minimal_clip_skip=2,
+                                                                        clip_skip=2, return_pooled=True, final_layer_norm=False)
+        else:
+            self.text_processing_engine = ClassicTextProcessingEngine(clip_l, embedding_key="clip_l", text_projection=False, minimal_clip_skip=1,
+                                                                      clip_skip=1, return_pooled=False, final_layer_norm=True)
+
+    def set_clip_skip(self, clip_skip):
+        for name in ("text_processing_engine", "text_processing_engine_l", "text_processing_engine_g"):
+            if hasattr(self, name):
+                getattr(self, name).clip_skip = clip_skip
+
+    @torch.inference_mode()
     def get_learned_conditioning(self, prompt):
-        raise NotImplementedError("text encoders are out of scope (SURVEY.md §2.2): pass cond tensors to the processing object")
+        """`prompt`: TokenizedPrompts (below).  SD1.x -> tensor [B, 77 n, 768]; SDXL -> {'crossattn': [B, 77 n, 2048], 'vector': [B, 2816]}
+        (sdxl.py:76-117: penultimate CLIP-L | CLIP-G states, pooled-projected CLIP-G + six 256-wide size / crop embeddings)."""
+        from ... import hipops as ops
+        if not self.is_sdxl:
+            if not hasattr(self, "text_processing_engine"):
+                raise RuntimeError("no text encoder attached: attach_text_encoders() or pass cond tensors to the processing object")
+            return self.text_processing_engine(prompt.tokens_l, prompt.multipliers_l)
+        cond_l = self.text_processing_engine_l(prompt.tokens_l, prompt.multipliers_l)
+        cond_g = self.text_processing_engine_g(prompt.tokens_g, prompt.multipliers_g)
+        clip_pooled = cond_g.pooled
+        vals = [prompt.height, prompt.width, prompt.crop_top, prompt.crop_left, prompt.height, prompt.width]  # sdxl.py:93-96
+        t = torch.tensor([float(v) for v in vals], dtype=torch.float32, device=self.device)
+        flat = ops.timestep_embedding(t, 256).float().flatten().unsqueeze(0).repeat(clip_pooled.shape[0], 1)
+        if prompt.is_negative_prompt and prompt.all_empty:  # :100-105
+            clip_pooled, cond_l, cond_g = torch.zeros_like(clip_pooled), torch.zeros_like(cond_l), torch.zeros_like(cond_g)
+        from ...modules.prompt_parser import DictWithShape
+        return DictWithShape({"crossattn": torch.cat([cond_l, cond_g], dim=2), "vector": torch.cat([clip_pooled, flat], dim=1)})
+
+
+class TokenizedPrompts:
+    """What the tokenizer side hands over for one batch of prompts: per text encoder [n_chunks][B][77] token ids and emphasis
+    multipliers (classic_engine.py:150-261), plus the SDXL size conditioning inputs (sdxl.py:81-91)."""
+
+    def __init__(self, tokens_l, multipliers_l, tokens_g=None, multipliers_g=None, width=1024, height=1024, crop_left=0, crop_top=0,
+                 is_negative_prompt=False, all_empty=False):
+        self.tokens_l, self.multipliers_l = tokens_l, multipliers_l
+        self.tokens_g, self.multipliers_g = tokens_g, multipliers_g
+        self.width, self.height, self.crop_left, self.crop_top = width, height, crop_left, crop_top
+        self.is_negative_prompt, self.all_empty = is_negative_prompt, all_empty
 
 
 def build_engine(unet_config, unet_state_dict, vae_config=None, vae_state_dict=None, device="cuda"):

@@ -60,3 +60,26 @@ def test_classic_engine_emphasis_and_chunks():
         z, pooled = oclip.encode_with_transformers(sd, cfg, t, clip_skip=2, final_layer_norm=True, return_pooled=True)
         want.append(oclip.apply_emphasis_original(z, mult))
     report("classic engine: 2 chunks, emphasis Original, clip skip 2", max_rel(out, torch.hstack(want)), 3e-3)
+
+
+def test_sdxl_conditioning_assembly():
+    """engine.get_learned_conditioning for SDXL (sdxl.py:76-117): [CLIP-L | CLIP-G] penultimate states, pooled-projected CLIP-G +
+    six Timestep(256) embeddings of (height, width, crop_top, crop_left, target_height, target_width)."""
+    from forge_amd.backend.diffusion_engine.base import ForgeDiffusionEngine, TokenizedPrompts
+    from types import SimpleNamespace
+    cl, cg = synth.TINY_CLIP_L_CONFIG, synth.TINY_CLIP_G_CONFIG
+    sl, sg = synth.synth_clip_state_dict(cl), synth.synth_clip_state_dict(cg, seed=5)
+    eng = ForgeDiffusionEngine.__new__(ForgeDiffusionEngine)  # conditioning only: no UNet needed
+    eng.is_sdxl, eng.device = True, torch.device(DEV)
+    eng.attach_text_encoders(IntegratedCLIP(cl, sl, device=DEV), IntegratedCLIP(cg, sg, device=DEV))
+    ids = load_golden("tiny_clip_l.pt")["ids"]
+    ones = torch.ones(ids.shape).tolist()
+    tp = TokenizedPrompts([ids.tolist()], [ones], [ids.tolist()], [ones], width=832, height=1216, crop_left=8, crop_top=16)
+    cond = eng.get_learned_conditioning(tp)
+    want = oclip.sdxl_conditioning(sl, cl, sg, cg, ids, ids, 832, 1216, 8, 16)
+    assert cond["crossattn"].shape == (2, 77, cl["hidden_size"] + cg["hidden_size"]) and cond["vector"].shape == (2, cg["hidden_size"] + 1536)
+    report("SDXL crossattn [clip_l | clip_g]", max_rel(cond["crossattn"], want["crossattn"]), 3e-3)
+    report("SDXL vector [pooled | size embeddings]", max_rel(cond["vector"], want["vector"]), 3e-3)
+    neg = TokenizedPrompts([ids.tolist()], [ones], [ids.tolist()], [ones], is_negative_prompt=True, all_empty=True)
+    z = eng.get_learned_conditioning(neg)
+    assert float(z["crossattn"].abs().max()) == 0.0 and float(z["vector"][:, :cg["hidden_size"]].abs().max()) == 0.0
