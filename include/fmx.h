@@ -201,6 +201,11 @@ int fmx_sampler_euler_step(const float* x, const float* denoised, float sigma, f
 /* x_out = a*x + bcoef*denoised + ccoef*old_denoised (old may be null when ccoef == 0)  (DPM++ 2M update) */
 int fmx_sampler_lincomb3(const float* x, const float* denoised, const float* old_denoised, float a, float bcoef,
                          float ccoef, float* x_out, int64_t n, void* stream);
+/* x_out = sum_{k < n_terms} coefs[k] * srcs[k]  (1 <= n_terms <= 8; `srcs` / `coefs` are HOST arrays of device pointers / scalars;
+ * x_out may alias a source).  The update of every multi-stage / multistep k-diffusion sampler with host-side coefficients:
+ * Heun, DPM2(a), DPM++ 2S a, LMS, HeunPP2, IPNDM(_V), DEIS, Restart (k_diffusion/sampling.py:189-341, 573-603, 771-981,
+ * modules/sd_samplers_extra.py:7-74). */
+int fmx_sampler_lincomb(const float* const* srcs, const float* coefs, int32_t n_terms, float* x_out, int64_t n, void* stream);
 int fmx_scale_f32(const float* x, float s, float* y, int64_t n, void* stream);
 /* out = a * a_mask + b * b_mask, fp32, elementwise over n (inpaint latent blending: modules/sd_samplers_cfg_denoiser.py:181,205
  * `x * nmask + noisy_init * mask`, `denoised * nmask + init_latent * mask`; processing.py:1866).  out may alias a or b. */

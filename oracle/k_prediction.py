@@ -27,7 +27,7 @@ class Predictor:
 
     def timestep(self, sigma):
         # :148-151 nearest table entry in log space -> integer index
-        d = sigma.log()[None, :] - self.log_sigmas[:, None]
+        d = sigma.log().reshape(1, -1) - self.log_sigmas[:, None]
         return d.abs().argmin(dim=0).view(sigma.shape)
 
     def sigma(self, t):

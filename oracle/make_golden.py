@@ -379,6 +379,162 @@ def gen_samples(name, cfg, net, b=2, hw=16):
     torch.save(res, os.path.join(GOLD, f"{name}_samples.pt"))
 
 
+REF_SAMPLER_FN = {"Heun": "sample_heun", "DPM2": "sample_dpm_2", "DPM2 a": "sample_dpm_2_ancestral", "DPM++ 2S a": "sample_dpmpp_2s_ancestral",
+                  "LMS": "sample_lms", "HeunPP2": "sample_heunpp2", "IPNDM": "sample_ipndm", "IPNDM_V": "sample_ipndm_v", "DEIS": "sample_deis",
+                  "Restart": None}
+
+
+def _ref_restart():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_ref_samplers_extra", os.path.join(ref_import.REFERENCE_ROOT, "modules", "sd_samplers_extra.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)  # imports only torch, tqdm, k_diffusion.sampling
+    return mod.restart_sampler
+
+
+def ref_sampler_sigmas(ref, linker, name, steps):
+    """modules/sd_samplers_kdiffusion.py:81-134 for scheduler 'Automatic' with the per-sampler options of :14-34."""
+    from oracle.sampling import SAMPLERS_EXTRA
+    _, sched, _, _, discard = SAMPLERS_EXTRA[name]
+    n = steps + (1 if discard else 0)
+    if sched == "karras":
+        sig = ref.kd_sampling.get_sigmas_karras(n=n, sigma_min=linker.sigmas[0].item(), sigma_max=linker.sigmas[-1].item(), device="cpu")
+    else:
+        sig = linker.get_sigmas(n)
+    return torch.cat([sig[:-2], sig[-1:]]) if discard else sig
+
+
+def toy_denoiser(x, sigma, **kw):
+    """closed-form stand-in for CFGDenoiser (nonlinear in x and sigma so that solver order and stage placement matter)"""
+    s = sigma.view(-1, 1, 1, 1)
+    return x / (1 + s * s) + 0.3 * torch.tanh(x) * s / (1 + s)
+
+
+def toy_inputs():
+    g = torch.Generator().manual_seed(77)
+    x0 = torch.randn(2, 4, 8, 8, generator=g)
+    return x0, [torch.randn(2, 4, 8, 8, generator=g) for _ in range(64)]
+
+
+def gen_samplers_toy():
+    """The reference's sampler FUNCTIONS on the toy denoiser: pins oracle/sampling.py's restatements on CPU (no UNet in the way)."""
+    ref = ref_import.load_reference()
+    pred = ref_import.build_ref_predictor()
+    linker = ref.kd_external.ForgeScheduleLinker(pred)
+    restart = _ref_restart()
+    x0, noises = toy_inputs()
+
+    class Toy:
+        inner_model = SimpleNamespace(predictor=pred)  # sample_dpm_2_ancestral checks for PredictionFlux (sampling.py:251)
+
+        def __call__(self, x, sigma, **kw):
+            return toy_denoiser(x, sigma)
+
+    class Seq:
+        def __init__(self):
+            self.i = 0
+
+        def __getattr__(self, item):
+            if item == "randn_like":
+                def f(x):
+                    self.i += 1
+                    return noises[self.i - 1]
+                return f
+            return getattr(torch, item)
+    out = {}
+    for name, fn_name in REF_SAMPLER_FN.items():
+        for steps in (5, 12, 24, 40):
+            sig = ref_sampler_sigmas(ref, linker, name, steps)
+            h = Seq()
+            ref.kd_sampling.torch = h
+            try:
+                fn = restart if fn_name is None else getattr(ref.kd_sampling, fn_name)
+                lat = fn(Toy(), x0 * sig[0], sig, disable=True)
+            finally:
+                ref.kd_sampling.torch = torch
+            out[(name, steps)] = {"sigmas": sig, "latent": lat, "draws": h.i}
+    sig = linker.get_sigmas(12)
+    from k_diffusion import deis
+    out["deis_tab_3"] = [[float(c) for c in row] for row in deis.get_deis_coeff_list(sig, 3, deis_mode="tab")]
+    out["deis_tab_4"] = [[float(c) for c in row] for row in deis.get_deis_coeff_list(sig, 4, deis_mode="tab")]
+    out["deis_rhoab_3"] = [[float(c) for c in row] for row in deis.get_deis_coeff_list(sig, 3, deis_mode="rhoab")]
+    out["deis_sigmas"] = sig
+    torch.save(out, os.path.join(GOLD, "samplers_toy.pt"))
+    print("samplers_toy", len(out))
+
+
+def gen_schedulers():
+    """modules/sd_schedulers.py's table, imported from the reference with a two-attribute stand-in for modules.shared."""
+    import importlib.util
+    import types
+    ref = ref_import.load_reference()
+    shared = types.ModuleType("modules.shared")
+    shared.opts = SimpleNamespace(beta_dist_alpha=0.6, beta_dist_beta=0.6)
+    shared.sd_model = SimpleNamespace(is_sdxl=False)
+    pkg = types.ModuleType("modules")
+    pkg.shared, pkg.__path__ = shared, []
+    saved = {k: sys.modules.get(k) for k in ("modules", "modules.shared")}
+    sys.modules["modules"], sys.modules["modules.shared"] = pkg, shared
+    try:
+        spec = importlib.util.spec_from_file_location("_ref_sd_schedulers", os.path.join(ref_import.REFERENCE_ROOT, "modules", "sd_schedulers.py"))
+        rs = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(rs)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    pred = ref_import.build_ref_predictor()
+    linker = ref.kd_external.ForgeScheduleLinker(pred)
+    linker.inner_model = SimpleNamespace(forge_objects=SimpleNamespace(unet=SimpleNamespace(model=SimpleNamespace(predictor=pred))))
+    out = {}
+    for sdxl in (False, True):
+        shared.sd_model.is_sdxl = sdxl
+        for sch in rs.schedulers:
+            if sch.function is None:
+                continue
+            for n in (1, 4, 11, 20, 31, 32):
+                kw = {"sigma_min": pred.sigmas[0].item(), "sigma_max": pred.sigmas[-1].item()}
+                if sch.need_inner_model:
+                    kw["inner_model"] = linker
+                out[(sch.name, n, sdxl)] = sch.function(n=n, **kw, device="cpu").float()
+    out["labels"] = {s.name: s.label for s in rs.schedulers}
+    out["rho"] = {"karras_5": rs.schedulers_map["karras"].function(n=10, sigma_min=0.03, sigma_max=14.0, rho=5.0, device="cpu"),
+                  "polyexponential_2": rs.schedulers_map["polyexponential"].function(n=10, sigma_min=0.03, sigma_max=14.0, rho=2.0, device="cpu")}
+    torch.save(out, os.path.join(GOLD, "schedulers.pt"))
+    print("schedulers", len(out))
+
+
+def gen_samples_extra(name, cfg, net, b=2, hw=16):
+    """The rest of the sampler table through the real reference stack (reference UNet + sampling_function + sampler function)."""
+    ref = ref_import.load_reference()
+    pred = ref_import.build_ref_predictor()
+    restart = _ref_restart()
+    c, uc = synth.synth_conditioning(b, cfg["context_dim"], cfg.get("adm_in_channels"), seed=1234)
+    seeds = [1000 + i for i in range(b)]
+    res = {"seeds": seeds, "hw": hw}
+    for sampler, fn_name in REF_SAMPLER_FN.items():
+        steps = 21 if sampler == "Restart" else 6
+        den = ref_import.RefDenoiser(net, pred, seeds)
+        rng = ImageRNG((cfg["in_channels"], hw, hw), seeds, "CPU")
+        x = rng.next()
+        sigmas = ref_sampler_sigmas(ref, den.inner_model, sampler, steps)
+        x = pred.noise_scaling(sigmas[0], x, torch.zeros_like(x), max_denoise=False)
+        ref.kd_sampling.torch = _Hijack(rng)
+        ref.sampling_function.sampling_prepare(den.patcher, x=x)
+        extra = {"cond": c, "uncond": uc, "cond_scale": 7.0, "s_min_uncond": 0.0, "image_cond": None}
+        try:
+            fn = restart if fn_name is None else getattr(ref.kd_sampling, fn_name)
+            lat = fn(den, x, sigmas, extra_args=extra, disable=True)
+        finally:
+            ref.kd_sampling.torch = torch
+            ref.sampling_function.sampling_cleanup(den.patcher)
+        res[sampler] = {"steps": steps, "latent": lat, "sigmas": sigmas}
+        print(name, sampler, float(lat.std()))
+    torch.save(res, os.path.join(GOLD, f"{name}_samples_extra.pt"))
+
+
 def gen_schedules():
     ref = ref_import.load_reference()
     pred = ref_import.build_ref_predictor()
@@ -493,6 +649,7 @@ def main():
     if a.only in ("", "tiny"):
         net, _ = gen_unet("tiny_sd15", synth.TINY_SD15_UNET_CONFIG)
         gen_samples("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
+        gen_samples_extra("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
         gen_img2img("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
         gen_lora("tiny_sd15", synth.TINY_SD15_UNET_CONFIG)
         gen_unet_control("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
@@ -500,6 +657,12 @@ def main():
         gen_samples("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG, net)
         gen_vae("tiny_vae", synth.TINY_VAE_CONFIG)
         gen_vae_encode("tiny_vae", synth.TINY_VAE_CONFIG)
+    if a.only == "samplers":
+        net, _ = gen_unet("tiny_sd15", synth.TINY_SD15_UNET_CONFIG)
+        gen_samples_extra("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
+    if a.only in ("", "samplers"):
+        gen_samplers_toy()
+        gen_schedulers()
     if a.only in ("", "clip"):
         gen_clip("tiny_clip_l", synth.TINY_CLIP_L_CONFIG)
         gen_clip("tiny_clip_g", synth.TINY_CLIP_G_CONFIG)

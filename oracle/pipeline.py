@@ -16,16 +16,28 @@ from .vae import decode_first_stage, to_uint8_images
 
 
 def get_sigmas(predictor, sampler_name, steps):
-    # sd_samplers_kdiffusion.py:81-134 with scheduler "Automatic": per-sampler default (:14-34)
-    _, sched = sampling.SAMPLERS[sampler_name]
+    # sd_samplers_kdiffusion.py:81-134 with scheduler "Automatic": per-sampler default and discard_next_to_last_sigma (:14-34)
+    if sampler_name in sampling.SAMPLERS:
+        (_, sched), discard = sampling.SAMPLERS[sampler_name], False
+    else:
+        _, sched, _, _, discard = sampling.SAMPLERS_EXTRA[sampler_name]
+    n = steps + (1 if discard else 0)
     if sched == "karras":
-        return sampling.get_sigmas_karras(steps, predictor.sigmas[0].item(), predictor.sigmas[-1].item())
-    return sampling.get_sigmas_linker(predictor, steps)
+        sig = sampling.get_sigmas_karras(n, predictor.sigmas[0].item(), predictor.sigmas[-1].item())
+    else:
+        sig = sampling.get_sigmas_linker(predictor, n)
+    return torch.cat([sig[:-2], sig[-1:]]) if discard else sig
+
+
+@torch.no_grad()
+def txt2img_latents_on_schedule(unet_sd, unet_cfg, cond, uncond, seeds, height, width, sigmas, sampler_name="Euler", cfg_scale=7.0):
+    """txt2img_latents with an explicit sigma schedule (p.scheduler != Automatic, sd_samplers_kdiffusion.py:88-127)."""
+    return txt2img_latents(unet_sd, unet_cfg, cond, uncond, seeds, height, width, len(sigmas) - 1, sampler_name, cfg_scale, sigmas=sigmas)[0]
 
 
 @torch.no_grad()
 def txt2img_latents(unet_sd, unet_cfg, cond, uncond, seeds, height, width, steps, sampler_name="Euler",
-                    cfg_scale=7.0, noise_source="CPU", trace=None):
+                    cfg_scale=7.0, noise_source="CPU", trace=None, sigmas=None):
     pred = Predictor()
     b = len(seeds)
     rng = ImageRNG((unet_cfg["in_channels"], height // 8, width // 8), seeds, noise_source)
@@ -40,12 +52,13 @@ def txt2img_latents(unet_sd, unet_cfg, cond, uncond, seeds, height, width, steps
             trace.append(den.clone())
         return den
 
-    sigmas = get_sigmas(pred, sampler_name, steps)
+    sigmas = get_sigmas(pred, sampler_name, steps) if sigmas is None else sigmas
     x = pred.noise_scaling(sigmas[0], x, torch.zeros_like(x))
+    if sampler_name in sampling.SAMPLERS_EXTRA:
+        fn, _, draws, ancestral, _ = sampling.SAMPLERS_EXTRA[sampler_name]
+        return (fn(denoiser, x, sigmas, noise_fn=rng.next) if (draws or ancestral) else fn(denoiser, x, sigmas)), sigmas
     fn, _ = sampling.SAMPLERS[sampler_name]
-    if sampler_name == "Euler":
-        return fn(denoiser, x, sigmas, noise_fn=rng.next), sigmas
-    if sampler_name == "Euler a":
+    if sampler_name in ("Euler", "Euler a"):
         return fn(denoiser, x, sigmas, noise_fn=rng.next), sigmas
     return fn(denoiser, x, sigmas), sigmas
 

@@ -85,3 +85,327 @@ def sample_dpmpp_2m(model, x, sigmas, callback=None):
 
 SAMPLERS = {"Euler": (sample_euler, None), "Euler a": (sample_euler_ancestral, None),
             "DPM++ 2M": (sample_dpmpp_2m, "karras")}  # sd_samplers_kdiffusion.py:14-34 default schedulers
+
+
+# ---- the rest of the k-diffusion table ("remaining samplers"; the torchsde-driven SDE family is excluded) -------
+def _to_d(x, sigma, denoised):
+    return (x - denoised) / sigma  # modules/sd_schedulers.py:10-12
+
+
+def _cb(callback, x, i, sigma, sigma_hat, denoised):
+    if callback is not None:
+        callback({"x": x, "i": i, "sigma": sigma, "sigma_hat": sigma_hat, "denoised": denoised})
+
+
+def sample_heun(model, x, sigmas, noise_fn=None, callback=None):
+    """k_diffusion/sampling.py:189-214 with s_churn = 0 (gamma = 0): one randn_like per step is still drawn (:196)."""
+    s_in = x.new_ones([x.shape[0]])
+    for i in range(len(sigmas) - 1):
+        if noise_fn is not None:
+            noise_fn()
+        denoised = model(x, sigmas[i] * s_in)
+        d = _to_d(x, sigmas[i], denoised)
+        _cb(callback, x, i, sigmas[i], sigmas[i], denoised)
+        dt = sigmas[i + 1] - sigmas[i]
+        if sigmas[i + 1] == 0:
+            x = x + d * dt
+        else:
+            x_2 = x + d * dt
+            d_2 = _to_d(x_2, sigmas[i + 1], model(x_2, sigmas[i + 1] * s_in))
+            x = x + (d + d_2) / 2 * dt
+    return x
+
+
+def sample_dpm_2(model, x, sigmas, noise_fn=None, callback=None):
+    """k_diffusion/sampling.py:218-246, gamma = 0."""
+    s_in = x.new_ones([x.shape[0]])
+    for i in range(len(sigmas) - 1):
+        if noise_fn is not None:
+            noise_fn()
+        denoised = model(x, sigmas[i] * s_in)
+        d = _to_d(x, sigmas[i], denoised)
+        _cb(callback, x, i, sigmas[i], sigmas[i], denoised)
+        if sigmas[i + 1] == 0:
+            x = x + d * (sigmas[i + 1] - sigmas[i])
+        else:
+            sigma_mid = sigmas[i].log().lerp(sigmas[i + 1].log(), 0.5).exp()
+            x_2 = x + d * (sigma_mid - sigmas[i])
+            d_2 = _to_d(x_2, sigma_mid, model(x_2, sigma_mid * s_in))
+            x = x + d_2 * (sigmas[i + 1] - sigmas[i])
+    return x
+
+
+def sample_dpm_2_ancestral(model, x, sigmas, noise_fn, eta=1.0, s_noise=1.0, callback=None):
+    """k_diffusion/sampling.py:249-276."""
+    s_in = x.new_ones([x.shape[0]])
+    for i in range(len(sigmas) - 1):
+        denoised = model(x, sigmas[i] * s_in)
+        sigma_down, sigma_up = get_ancestral_step(sigmas[i], sigmas[i + 1], eta)
+        _cb(callback, x, i, sigmas[i], sigmas[i], denoised)
+        d = _to_d(x, sigmas[i], denoised)
+        if sigma_down == 0:
+            x = x + d * (sigma_down - sigmas[i])
+        else:
+            sigma_mid = sigmas[i].log().lerp(sigma_down.log(), 0.5).exp()
+            x_2 = x + d * (sigma_mid - sigmas[i])
+            d_2 = _to_d(x_2, sigma_mid, model(x_2, sigma_mid * s_in))
+            x = x + d_2 * (sigma_down - sigmas[i])
+            x = x + noise_fn() * s_noise * sigma_up
+    return x
+
+
+def sample_dpmpp_2s_ancestral(model, x, sigmas, noise_fn, eta=1.0, s_noise=1.0, callback=None):
+    """k_diffusion/sampling.py:573-603."""
+    s_in = x.new_ones([x.shape[0]])
+    t_fn = lambda s: s.log().neg()
+    sigma_fn = lambda t: t.neg().exp()
+    for i in range(len(sigmas) - 1):
+        denoised = model(x, sigmas[i] * s_in)
+        sigma_down, sigma_up = get_ancestral_step(sigmas[i], sigmas[i + 1], eta)
+        _cb(callback, x, i, sigmas[i], sigmas[i], denoised)
+        if sigma_down == 0:
+            x = x + _to_d(x, sigmas[i], denoised) * (sigma_down - sigmas[i])
+        else:
+            t, t_next = t_fn(sigmas[i]), t_fn(sigma_down)
+            h = t_next - t
+            s = t + 0.5 * h
+            x_2 = (sigma_fn(s) / sigma_fn(t)) * x - (-h * 0.5).expm1() * denoised
+            denoised_2 = model(x_2, sigma_fn(s) * s_in)
+            x = (sigma_fn(t_next) / sigma_fn(t)) * x - (-h).expm1() * denoised_2
+        if sigmas[i + 1] > 0:
+            x = x + noise_fn() * s_noise * sigma_up
+    return x
+
+
+def linear_multistep_coeff(order, t, i, j):
+    """k_diffusion/sampling.py:311-321: integral over [t_i, t_i+1] of the j-th Lagrange basis on the last `order` nodes."""
+    from scipy import integrate
+    if order - 1 > i:
+        raise ValueError(f"Order {order} too high for step {i}")
+
+    def basis(tau):
+        p = 1.0
+        for k in range(order):
+            if k != j:
+                p *= (tau - t[i - k]) / (t[i - j] - t[i - k])
+        return p
+    return integrate.quad(basis, t[i], t[i + 1], epsrel=1e-4)[0]
+
+
+def sample_lms(model, x, sigmas, order=4, callback=None):
+    """k_diffusion/sampling.py:325-341."""
+    s_in = x.new_ones([x.shape[0]])
+    nodes = sigmas.detach().cpu().numpy()
+    ds = []
+    for i in range(len(sigmas) - 1):
+        denoised = model(x, sigmas[i] * s_in)
+        ds.append(_to_d(x, sigmas[i], denoised))
+        if len(ds) > order:
+            ds.pop(0)
+        _cb(callback, x, i, sigmas[i], sigmas[i], denoised)
+        cur = min(i + 1, order)
+        coeffs = [linear_multistep_coeff(cur, nodes, i, j) for j in range(cur)]
+        x = x + sum(c * d for c, d in zip(coeffs, reversed(ds)))
+    return x
+
+
+def sample_heunpp2(model, x, sigmas, noise_fn=None, callback=None):
+    """k_diffusion/sampling.py:771-823, gamma = 0."""
+    s_in = x.new_ones([x.shape[0]])
+    s_end = sigmas[-1]
+    for i in range(len(sigmas) - 1):
+        if noise_fn is not None:
+            noise_fn()
+        denoised = model(x, sigmas[i] * s_in)
+        d = _to_d(x, sigmas[i], denoised)
+        _cb(callback, x, i, sigmas[i], sigmas[i], denoised)
+        dt = sigmas[i + 1] - sigmas[i]
+        if sigmas[i + 1] == s_end:
+            x = x + d * dt
+            continue
+        x_2 = x + d * dt
+        d_2 = _to_d(x_2, sigmas[i + 1], model(x_2, sigmas[i + 1] * s_in))
+        if sigmas[i + 2] == s_end:
+            w2 = sigmas[i + 1] / (2 * sigmas[0])
+            x = x + (d * (1 - w2) + d_2 * w2) * dt
+        else:
+            x_3 = x_2 + d_2 * (sigmas[i + 2] - sigmas[i + 1])
+            d_3 = _to_d(x_3, sigmas[i + 2], model(x_3, sigmas[i + 2] * s_in))
+            w = 3 * sigmas[0]
+            w2, w3 = sigmas[i + 1] / w, sigmas[i + 2] / w
+            x = x + ((1 - w2 - w3) * d + w2 * d_2 + w3 * d_3) * dt
+    return x
+
+
+_AB = {1: (1.0,), 2: (3 / 2, -1 / 2), 3: (23 / 12, -16 / 12, 5 / 12), 4: (55 / 24, -59 / 24, 37 / 24, -9 / 24)}
+
+
+def sample_ipndm(model, x, sigmas, max_order=4, callback=None):
+    """k_diffusion/sampling.py:829-865: Adams-Bashforth on d with fixed coefficients; history of max_order - 1 derivatives."""
+    s_in = x.new_ones([x.shape[0]])
+    hist = []
+    for i in range(len(sigmas) - 1):
+        denoised = model(x, sigmas[i] * s_in)
+        _cb(callback, x, i, sigmas[i], sigmas[i], denoised)
+        d = (x - denoised) / sigmas[i]
+        order = min(max_order, i + 1)
+        c = _AB[order]
+        comb = c[0] * d
+        for k in range(1, order):
+            comb = comb + c[k] * hist[-k]
+        x = x + (sigmas[i + 1] - sigmas[i]) * comb
+        hist.append(d)
+        hist = hist[-(max_order - 1):]
+    return x
+
+
+def ipndm_v_coeffs(t, i, order):
+    """k_diffusion/sampling.py:891-921: variable-step Adams-Bashforth weights for nodes t[i], t[i-1], ..."""
+    h_n = t[i + 1] - t[i]
+    if order == 1:
+        return [1.0]
+    h_1 = t[i] - t[i - 1]
+    if order == 2:
+        return [(2 + h_n / h_1) / 2, -(h_n / h_1) / 2]
+    h_2 = t[i - 1] - t[i - 2]
+    temp1 = (1 - h_n / (3 * (h_n + h_1)) * (h_n * (h_n + h_1)) / (h_1 * (h_1 + h_2))) / 2
+    if order == 3:
+        return [(2 + h_n / h_1) / 2 + temp1, -(h_n / h_1) / 2 - (1 + h_1 / h_2) * temp1, temp1 * h_1 / h_2]
+    h_3 = t[i - 2] - t[i - 3]
+    temp2 = ((1 - h_n / (3 * (h_n + h_1))) / 2 + (1 - h_n / (2 * (h_n + h_1))) * h_n / (6 * (h_n + h_1 + h_2))) \
+        * (h_n * (h_n + h_1) * (h_n + h_1 + h_2)) / (h_1 * (h_1 + h_2) * (h_1 + h_2 + h_3))
+    q = h_1 * (h_1 + h_2) / (h_2 * (h_2 + h_3))
+    return [(2 + h_n / h_1) / 2 + temp1 + temp2,
+            -(h_n / h_1) / 2 - (1 + h_1 / h_2) * temp1 - (1 + h_1 / h_2 + q) * temp2,
+            temp1 * h_1 / h_2 + (h_1 / h_2 + q * (1 + h_2 / h_3)) * temp2,
+            -temp2 * q * h_1 / h_2]
+
+
+def sample_ipndm_v(model, x, sigmas, max_order=4, callback=None):
+    """k_diffusion/sampling.py:869-929."""
+    s_in = x.new_ones([x.shape[0]])
+    hist = []
+    for i in range(len(sigmas) - 1):
+        denoised = model(x, sigmas[i] * s_in)
+        _cb(callback, x, i, sigmas[i], sigmas[i], denoised)
+        d = (x - denoised) / sigmas[i]
+        order = min(max_order, i + 1)
+        c = ipndm_v_coeffs(sigmas, i, order)
+        comb = c[0] * d
+        for k in range(1, order):
+            comb = comb + c[k] * hist[-k]
+        x = x + (sigmas[i + 1] - sigmas[i]) * comb
+        hist.append(d)
+        hist = hist[-(max_order - 1):]
+    return x
+
+
+def deis_coeff_list(sigmas, max_order, n=10000):
+    """k_diffusion/deis.py:13-21,59-88 ('tab' mode): sigma -> VP time t (beta_d, beta_min fitted to sigma_min 0.002, sigma_max 80,
+    eps_s 1e-3), then per step the integral over [t_i, t_i+1] of  -1/2 dlog(alpha)/dtau / sqrt(alpha (1 - alpha))  times each Lagrange
+    basis on the last `order` nodes, by an n-point Riemann sum.  dlog(alpha)/dtau = -tau (b1 - b0) - b0 in closed form (the
+    reference differentiates it with autograd, deis.py:43-56)."""
+    import numpy as np
+    eps_s, s_min, s_max = 1e-3, torch.tensor(0.002), torch.tensor(80.0)
+    beta_d = 2 * (np.log(s_min ** 2 + 1) / eps_s - np.log(s_max ** 2 + 1)) / (eps_s - 1)
+    beta_min = np.log(s_max ** 2 + 1) - 0.5 * beta_d
+    t = ((beta_min ** 2 + 2 * beta_d * (sigmas.clone().cpu() ** 2 + 1).log()).sqrt() - beta_min) / beta_d
+    b0, b1 = beta_min, beta_d + beta_min
+    out = []
+    for i in range(len(t) - 1):
+        order = min(i + 1, max_order)
+        if order == 1:
+            out.append([])
+            continue
+        taus = torch.linspace(t[i], t[i + 1], n)
+        dtau = (t[i + 1] - t[i]) / n
+        prev = t[[i - k for k in range(order)]]
+        alpha = torch.exp(-0.5 * taus ** 2 * (b1 - b0) - taus * b0)
+        integrand = -0.5 * (-taus * (b1 - b0) - b0) / torch.sqrt(alpha * (1 - alpha))
+        cs = []
+        for j in range(order):
+            poly = 1
+            for k in range(order):
+                if k != j:
+                    poly = poly * (taus - prev[k]) / (prev[j] - prev[k])
+            cs.append(torch.sum(integrand * poly) * dtau)
+        out.append(cs)
+    return out
+
+
+def sample_deis(model, x, sigmas, max_order=3, callback=None):
+    """k_diffusion/sampling.py:933-981."""
+    s_in = x.new_ones([x.shape[0]])
+    coeffs = deis_coeff_list(sigmas, max_order)
+    hist = []
+    for i in range(len(sigmas) - 1):
+        denoised = model(x, sigmas[i] * s_in)
+        _cb(callback, x, i, sigmas[i], sigmas[i], denoised)
+        d = (x - denoised) / sigmas[i]
+        order = 1 if sigmas[i + 1] <= 0 else min(max_order, i + 1)
+        if order == 1:
+            x = x + (sigmas[i + 1] - sigmas[i]) * d
+        else:
+            c = coeffs[i]
+            upd = c[0] * d
+            for k in range(1, order):
+                upd = upd + c[k] * hist[-k]
+            x = x + upd
+        hist.append(d)
+        hist = hist[-(max_order - 1):]
+    return x
+
+
+def restart_step_list(sigmas):
+    """modules/sd_samplers_extra.py:39-67: (possibly re-made Karras) schedule + the (old, new) sigma pairs incl. restart segments."""
+    steps = sigmas.shape[0] - 1
+    restart_list = {}
+    if steps >= 20:
+        restart_steps, restart_times = 9, 1
+        if steps >= 36:
+            restart_steps, restart_times = steps // 4, 2
+        sigmas = get_sigmas_karras(steps - restart_steps * restart_times, sigmas[-2].item(), sigmas[0].item())
+        restart_list = {0.1: [restart_steps + 1, restart_times, 2]}
+    restart_list = {int(torch.argmin(abs(sigmas - k), dim=0)): v for k, v in restart_list.items()}
+    pairs = []
+    for i in range(len(sigmas) - 1):
+        pairs.append((sigmas[i], sigmas[i + 1]))
+        if i + 1 in restart_list:
+            r_steps, r_times, r_max = restart_list[i + 1]
+            min_idx, max_idx = i + 1, int(torch.argmin(abs(sigmas - r_max), dim=0))
+            if max_idx < min_idx:
+                seg = get_sigmas_karras(r_steps, sigmas[min_idx].item(), sigmas[max_idx].item())[:-1]
+                for _ in range(r_times):
+                    pairs.extend(zip(seg[:-1], seg[1:]))
+    return pairs
+
+
+def sample_restart(model, x, sigmas, noise_fn, s_noise=1.0, callback=None):
+    """modules/sd_samplers_extra.py:7-74: Heun steps over restart_step_list, re-noising when the next pair starts higher."""
+    s_in = x.new_ones([x.shape[0]])
+    last = None
+    for step_id, (old, new) in enumerate(restart_step_list(sigmas)):
+        if last is not None and last < old:
+            x = x + noise_fn() * s_noise * (old ** 2 - last ** 2) ** 0.5
+        denoised = model(x, old * s_in)
+        d = _to_d(x, old, denoised)
+        _cb(callback, x, step_id, new, old, denoised)
+        dt = new - old
+        if new == 0:
+            x = x + d * dt
+        else:
+            x_2 = x + d * dt
+            d_2 = _to_d(x_2, new, model(x_2, new * s_in))
+            x = x + (d + d_2) / 2 * dt
+        last = new
+    return x
+
+
+# name -> (function, default scheduler, draws randn_like each step, ancestral noise, discard_next_to_last_sigma)
+SAMPLERS_EXTRA = {
+    "Heun": (sample_heun, None, True, False, False), "DPM2": (sample_dpm_2, "karras", True, False, True),
+    "DPM2 a": (sample_dpm_2_ancestral, "karras", False, True, True), "DPM++ 2S a": (sample_dpmpp_2s_ancestral, "karras", False, True, False),
+    "LMS": (sample_lms, None, False, False, False), "HeunPP2": (sample_heunpp2, None, True, False, False),
+    "IPNDM": (sample_ipndm, None, False, False, False), "IPNDM_V": (sample_ipndm_v, None, False, False, False),
+    "DEIS": (sample_deis, None, False, False, False), "Restart": (sample_restart, "karras", False, True, False),
+}

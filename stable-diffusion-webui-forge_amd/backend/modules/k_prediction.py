@@ -55,9 +55,9 @@ class Prediction(AbstractPrediction):
 
     def timestep(self, sigma):
         """Nearest table index (argmin in log space), :148-151.  `sigma`: host tensor [B] (or python floats)."""
-        sigma = torch.as_tensor(sigma, dtype=torch.float32).reshape(-1).cpu()
-        dists = sigma.log()[None, :] - self.log_sigmas[:, None]
-        return dists.abs().argmin(dim=0)
+        sigma = torch.as_tensor(sigma, dtype=torch.float32).cpu()
+        dists = sigma.log().reshape(1, -1) - self.log_sigmas[:, None]
+        return dists.abs().argmin(dim=0).view(sigma.shape)  # keeps a 0-dim input 0-dim (sd_schedulers.py:33-34 feeds it to linspace)
 
     def sigma(self, timestep):
         t = torch.clamp(torch.as_tensor(timestep).float().cpu(), min=0, max=len(self.sigmas) - 1)

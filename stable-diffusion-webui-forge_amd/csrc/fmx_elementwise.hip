@@ -178,6 +178,35 @@ __global__ void lincomb3_kernel(const float* __restrict__ x, const float* __rest
   }
 }
 
+struct LincombArgs {
+  const float* src[8];
+  float coef[8];
+};
+
+// out = sum_k coef[k] * src[k], accumulated left to right (host-side scalar coefficients of the multistep / multi-stage samplers)
+template <int N>
+__global__ void lincomb_kernel(LincombArgs a, float* __restrict__ out, long n) {
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long)gridDim.x * blockDim.x * 4) {
+    if (i + 4 <= n) {
+      float4 r = *reinterpret_cast<const float4*>(a.src[0] + i);
+      r.x *= a.coef[0], r.y *= a.coef[0], r.z *= a.coef[0], r.w *= a.coef[0];
+#pragma unroll
+      for (int k = 1; k < N; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(a.src[k] + i);
+        r.x += a.coef[k] * v.x, r.y += a.coef[k] * v.y, r.z += a.coef[k] * v.z, r.w += a.coef[k] * v.w;
+      }
+      *reinterpret_cast<float4*>(out + i) = r;
+    } else {
+      for (long j = i; j < n; ++j) {
+        float r = a.coef[0] * a.src[0][j];
+#pragma unroll
+        for (int k = 1; k < N; ++k) r += a.coef[k] * a.src[k][j];
+        out[j] = r;
+      }
+    }
+  }
+}
+
 __global__ void scale_kernel(const float* __restrict__ x, float s, float* __restrict__ y, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = x[i] * s;
 }
@@ -338,6 +367,35 @@ extern "C" int fmx_sampler_euler_step(const float* x, const float* denoised, flo
   hipLaunchKernelGGL(euler_step_kernel, dim3(grid_for(n)), dim3(TPB), 0, (hipStream_t)stream, x, denoised, sigma, sigma_next, noise,
                      noise_scale, x_out, (long)n);
   FMX_LAUNCH_CHECK("fmx_sampler_euler_step");
+  return FMX_OK;
+}
+
+template <int N>
+static void launch_lincomb(const LincombArgs& a, float* out, long n, hipStream_t st) {
+  hipLaunchKernelGGL(lincomb_kernel<N>, dim3(grid_for((n + 3) / 4)), dim3(TPB), 0, st, a, out, n);
+}
+
+extern "C" int fmx_sampler_lincomb(const float* const* srcs, const float* coefs, int32_t n_terms, float* x_out, int64_t n, void* stream) {
+  FMX_REQUIRE(srcs && coefs && x_out && n > 0 && n_terms >= 1 && n_terms <= 8, "lincomb: 1..8 terms");
+  LincombArgs a;
+  for (int k = 0; k < 8; ++k) {
+    a.src[k] = k < n_terms ? srcs[k] : nullptr;
+    a.coef[k] = k < n_terms ? coefs[k] : 0.f;
+    FMX_REQUIRE(k >= n_terms || (srcs[k] && (reinterpret_cast<uintptr_t>(srcs[k]) & 15) == 0), "lincomb: null / unaligned source");
+  }
+  FMX_REQUIRE((reinterpret_cast<uintptr_t>(x_out) & 15) == 0, "lincomb: unaligned output");
+  hipStream_t st = (hipStream_t)stream;
+  switch (n_terms) {
+    case 1: launch_lincomb<1>(a, x_out, (long)n, st); break;
+    case 2: launch_lincomb<2>(a, x_out, (long)n, st); break;
+    case 3: launch_lincomb<3>(a, x_out, (long)n, st); break;
+    case 4: launch_lincomb<4>(a, x_out, (long)n, st); break;
+    case 5: launch_lincomb<5>(a, x_out, (long)n, st); break;
+    case 6: launch_lincomb<6>(a, x_out, (long)n, st); break;
+    case 7: launch_lincomb<7>(a, x_out, (long)n, st); break;
+    default: launch_lincomb<8>(a, x_out, (long)n, st); break;
+  }
+  FMX_LAUNCH_CHECK("fmx_sampler_lincomb");
   return FMX_OK;
 }
 

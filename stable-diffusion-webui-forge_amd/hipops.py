@@ -357,6 +357,23 @@ def lincomb3(x, d0, d1, a, b, c, out=None):
     return out
 
 
+def lincomb(srcs, coefs, out=None):
+    """out = sum_k coefs[k] * srcs[k] over fp32 tensors of one shape (1..8 terms), one fused pass."""
+    import ctypes
+    n = len(srcs)
+    assert 1 <= n <= 8 and n == len(coefs)
+    x = srcs[0]
+    for t in srcs:
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.shape == x.shape and t.device == x.device
+    if out is None:
+        out = torch.empty_like(x)
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in srcs])
+    cf = (ctypes.c_float * n)(*[float(c) for c in coefs])
+    _lib.check(_lib.lib().fmx_sampler_lincomb(ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(cf, ctypes.c_void_p), n, _p(out), x.numel(),
+                                              stream_ptr()), "fmx_sampler_lincomb")
+    return out
+
+
 def scale_f32(x, s, out=None):
     if out is None:
         out = torch.empty_like(x)

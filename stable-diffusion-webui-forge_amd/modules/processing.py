@@ -143,6 +143,7 @@ def _slice_cond(c, a, b):
 
 
 def process_images(p) -> Processed:
+    shared.sd_model = p.sd_model  # the reference's p.sd_model IS shared.sd_model (processing.py:252-258); schedulers read is_sdxl from it
     return process_images_inner(p)
 
 

@@ -1,11 +1,11 @@
 """`KDiffusionSampler` -- mirror of modules/sd_samplers_kdiffusion.py (sampler table :14-34, `get_sigmas` :81-134,
-`sample` :196-244) over the native denoiser.  Samplers that need torchsde / second-order model calls are listed in the
-reference's table but not built here (same denoiser underneath, elementwise-only differences)."""
+`sample` :196-244) over the native denoiser.  The torchsde-driven SDE family and DPM fast / adaptive are listed in the
+reference's table but not built here."""
 import inspect
 
 import torch
 
-from . import sd_samplers_common, shared
+from . import sd_samplers_common, sd_samplers_extra, sd_schedulers, shared
 from .sd_samplers_cfg_denoiser import CFGDenoiser
 from ..backend.sampling.sampling_function import sampling_cleanup, sampling_prepare
 from ..k_diffusion import external as kd_external
@@ -13,21 +13,27 @@ from ..k_diffusion import sampling as kd_sampling
 
 samplers_k_diffusion = [
     ("DPM++ 2M", "sample_dpmpp_2m", ["k_dpmpp_2m"], {"scheduler": "karras"}),
+    ("DPM++ 2S a", "sample_dpmpp_2s_ancestral", ["k_dpmpp_2s_a"], {"scheduler": "karras", "uses_ensd": True, "second_order": True}),
     ("Euler a", "sample_euler_ancestral", ["k_euler_a", "k_euler_ancestral"], {"uses_ensd": True}),
     ("Euler", "sample_euler", ["k_euler"], {}),
+    ("LMS", "sample_lms", ["k_lms"], {}),
+    ("Heun", "sample_heun", ["k_heun"], {"second_order": True}),
+    ("DPM2", "sample_dpm_2", ["k_dpm_2"], {"scheduler": "karras", "discard_next_to_last_sigma": True, "second_order": True}),
+    ("DPM2 a", "sample_dpm_2_ancestral", ["k_dpm_2_a"], {"scheduler": "karras", "discard_next_to_last_sigma": True, "uses_ensd": True,
+                                                         "second_order": True}),
+    ("Restart", sd_samplers_extra.restart_sampler, ["restart"], {"scheduler": "karras", "second_order": True}),
+    ("HeunPP2", "sample_heunpp2", ["heunpp2"], {}),
+    ("IPNDM", "sample_ipndm", ["ipndm"], {}),
+    ("IPNDM_V", "sample_ipndm_v", ["ipndm_v"], {}),
+    ("DEIS", "sample_deis", ["deis"], {}),
 ]
+# not built: the torchsde-driven family (DPM++ SDE, DPM++ 2M SDE (Heun), DPM++ 3M SDE) and DPM fast / adaptive (DPMSolver class)
 
-sampler_extra_params = {"sample_euler": ["s_churn", "s_tmin", "s_tmax", "s_noise"]}
-
-# modules/sd_schedulers.py:211-228 (the two schedules the table above uses; "Automatic" -> sampler default)
-k_diffusion_scheduler = {"karras": kd_sampling.get_sigmas_karras, "exponential": kd_sampling.get_sigmas_exponential}
-
-
-def simple_scheduler(n, sigma_min, sigma_max, inner_model, device):
-    """modules/sd_schedulers.py:81-87 ('Simple', the schedule Forge pairs with Flux)."""
-    ss = len(inner_model.sigmas) / n
-    sigs = [float(inner_model.sigmas[-(1 + int(x * ss))]) for x in range(n)] + [0.0]
-    return torch.FloatTensor(sigs).to(device)
+sampler_extra_params = {
+    "sample_euler": ["s_churn", "s_tmin", "s_tmax", "s_noise"], "sample_heun": ["s_churn", "s_tmin", "s_tmax", "s_noise"],
+    "sample_dpm_2": ["s_churn", "s_tmin", "s_tmax", "s_noise"], "sample_dpm_2_ancestral": ["s_noise"],
+    "sample_dpmpp_2s_ancestral": ["s_noise"],
+}
 
 samplers_data_k_diffusion = [
     sd_samplers_common.SamplerData(label, lambda model, funcname=funcname: KDiffusionSampler(funcname, model), aliases, options)
@@ -64,17 +70,15 @@ class KDiffusionSampler(sd_samplers_common.Sampler):
         if opts.always_discard_next_to_last_sigma and not discard:
             discard = True
         steps += 1 if discard else 0
-        scheduler_name = (getattr(p, "scheduler", None)) or "Automatic"
+        scheduler_name = (getattr(p, "hr_scheduler", None) if getattr(p, "is_hr_pass", False) else getattr(p, "scheduler", None)) or "Automatic"
         if scheduler_name == "Automatic":
             scheduler_name = self.config.options.get("scheduler", None)
-        fn = k_diffusion_scheduler.get((scheduler_name or "").lower()) if scheduler_name else None
+        scheduler = sd_schedulers.schedulers_map.get(scheduler_name)
         m_min, m_max = self.model_wrap.sigmas[0].item(), self.model_wrap.sigmas[-1].item()
         sigma_min, sigma_max = (0.1, 10) if opts.use_old_karras_scheduler_sigmas else (m_min, m_max)
         if getattr(p, "sampler_noise_scheduler_override", None):
             sigmas = p.sampler_noise_scheduler_override(steps)
-        elif (scheduler_name or "").lower() == "simple":
-            sigmas = simple_scheduler(steps, sigma_min, sigma_max, self.model_wrap, "cpu")
-        elif fn is None:
+        elif scheduler is None or scheduler.function is None:
             sigmas = self.model_wrap.get_sigmas(steps)
         else:
             kw = {"sigma_min": sigma_min, "sigma_max": sigma_max}
@@ -82,9 +86,11 @@ class KDiffusionSampler(sd_samplers_common.Sampler):
                 kw["sigma_min"] = opts.sigma_min
             if opts.sigma_max != 0 and opts.sigma_max != m_max:
                 kw["sigma_max"] = opts.sigma_max
-            if fn is kd_sampling.get_sigmas_karras and opts.rho != 0 and opts.rho != 7.0:
+            if scheduler.default_rho != -1 and opts.rho != 0 and opts.rho != scheduler.default_rho:
                 kw["rho"] = opts.rho
-            sigmas = fn(n=steps, **kw, device="cpu")
+            if scheduler.need_inner_model:
+                kw["inner_model"] = self.model_wrap
+            sigmas = scheduler.function(n=steps, **kw, device="cpu")
         if discard:
             sigmas = torch.cat([sigmas[:-2], sigmas[-1:]])
         return sigmas.cpu()

@@ -122,6 +122,48 @@ def test_sampler_vs_reference_fixture(name, sampler, engines):
     report(f"{name} {sampler} {g[sampler]['steps']} steps vs reference", max_rel(res.latents, g[sampler]["latent"]), 1e-2)
 
 
+EXTRA_SAMPLERS = ["Heun", "DPM2", "DPM2 a", "DPM++ 2S a", "LMS", "HeunPP2", "IPNDM", "IPNDM_V", "DEIS", "Restart"]
+
+
+@pytest.mark.parametrize("sampler", EXTRA_SAMPLERS)
+def test_extra_sampler_vs_reference_fixture(sampler, engines):
+    """The rest of the k-diffusion table (sd_samplers_kdiffusion.py:14-34 minus the torchsde family) against the reference's sampler
+    functions run through the reference UNet + sampling_function on CPU fp32 (tests/golden/tiny_sd15_samples_extra.pt); schedule,
+    discard_next_to_last_sigma and RNG consumption come from the product's own sampler table / get_sigmas."""
+    cfg = TINY["tiny_sd15"]
+    g = load_golden("tiny_sd15_samples_extra.pt")
+    shared.opts.randn_source = "CPU"
+    c, uc = _conds(cfg, len(g["seeds"]))
+    p = processing.StableDiffusionProcessingTxt2Img(sd_model=engines["tiny_sd15"], c=c, uc=uc, seed=g["seeds"][0], sampler_name=sampler,
+                                                    batch_size=len(g["seeds"]), steps=g[sampler]["steps"], cfg_scale=7.0,
+                                                    width=g["hw"] * 8, height=g["hw"] * 8, do_decode=False)
+    res = processing.process_images(p)
+    report(f"tiny_sd15 {sampler} {g[sampler]['steps']} steps vs reference", max_rel(res.latents, g[sampler]["latent"]), 1e-2)
+
+
+@pytest.mark.parametrize("scheduler", ["Uniform", "Karras", "Exponential", "Polyexponential", "SGM Uniform", "KL Optimal", "Align Your Steps",
+                                       "Simple", "Normal", "DDIM", "Beta", "Turbo", "Align Your Steps GITS", "Align Your Steps 32"])
+def test_scheduler_choice_reaches_the_sampler(scheduler, engines):
+    """p.scheduler selects the sigma schedule exactly as modules/sd_samplers_kdiffusion.py:81-134; the Euler result must equal the
+    oracle's Euler loop on that schedule."""
+    from oracle import pipeline, sampling as osamp, schedulers as osched
+    from oracle.k_prediction import Predictor
+    cfg = TINY["tiny_sd15"]
+    g = load_golden("schedulers.pt")
+    key = {v: k for k, v in g["labels"].items()}[scheduler]
+    steps = 4
+    c, uc = _conds(cfg, 2)
+    shared.opts.randn_source = "CPU"
+    shared.sd_model = engines["tiny_sd15"]
+    p = processing.StableDiffusionProcessingTxt2Img(sd_model=engines["tiny_sd15"], c=c, uc=uc, seed=5, sampler_name="Euler", scheduler=scheduler,
+                                                    batch_size=2, steps=steps, cfg_scale=7.0, width=128, height=128, do_decode=False)
+    res = processing.process_images(p)
+    sig = g[(key, steps, False)]
+    sd = synth.synth_unet_state_dict(cfg, seed=0)
+    want = pipeline.txt2img_latents_on_schedule(sd, cfg, c.cpu(), uc.cpu(), [5, 6], 128, 128, sig, "Euler")
+    report(f"Euler on the {scheduler} schedule vs oracle", max_rel(res.latents, want), 1e-2)
+
+
 @pytest.mark.parametrize("sampler", ["Euler", "Euler a", "DPM++ 2M"])
 def test_img2img_vs_reference_fixture(sampler, engines):
     """StableDiffusionProcessingImg2Img -> sample_img2img on the tail of the sigma schedule, vs the reference's loops driven

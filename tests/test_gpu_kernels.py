@@ -308,6 +308,16 @@ def test_pack_cfg_sampler_kernels():
     torch.testing.assert_close(out, x + (x - den) / 14.6 * (9.7 - 14.6) + nz * 0.3, rtol=1e-6, atol=1e-5)
     out = ops.lincomb3(x, den, den1, 0.7, 0.2, -0.1)
     torch.testing.assert_close(out, 0.7 * x + (0.2 * den - 0.1 * den1), rtol=1e-6, atol=1e-5)
+    # generic 1..8-term linear combination (multi-stage / multistep samplers); sizes with and without a 4-element tail, in place
+    for shape in ((2, 4, 8, 8), (1, 4, 5, 7), (3,)):
+        srcs = [torch.randn(*shape, generator=g).to(DEV) for _ in range(8)]
+        coefs = [0.7, -1.3, 0.25, 2.0, -0.5, 0.125, 1.5, -0.75]
+        for n in range(1, 9):
+            want = sum(c * t.double() for c, t in zip(coefs[:n], srcs[:n])).float()
+            torch.testing.assert_close(ops.lincomb(srcs[:n], coefs[:n]), want, rtol=1e-6, atol=1e-5)
+        acc = srcs[0].clone()
+        ops.lincomb([acc, srcs[1]], [1.0, 2.0], out=acc)
+        torch.testing.assert_close(acc, srcs[0] + 2.0 * srcs[1], rtol=1e-6, atol=1e-5)
 
 
 def test_vae_pack_unpack_and_im2col():

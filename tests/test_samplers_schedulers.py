@@ -1,0 +1,119 @@
+"""CPU: the rest of the sampler / scheduler tables.
+  * oracle/sampling.py restatements vs the REFERENCE's sampler functions on a closed-form denoiser (tests/golden/samplers_toy.pt)
+    and through the reference UNet + sampling_function (tests/golden/tiny_sd15_samples_extra.pt);
+  * oracle/schedulers.py AND the product's host-side modules/sd_schedulers.py, k_diffusion/deis.py vs the reference's
+    (tests/golden/schedulers.pt, samplers_toy.pt) -- bit-exact: it is the same fp32 / numpy host arithmetic."""
+import pytest
+import torch
+
+from forge_amd import synth
+from oracle import pipeline, sampling as osamp, schedulers as osched
+from oracle.k_prediction import Predictor
+from oracle.make_golden import toy_denoiser, toy_inputs
+
+from conftest import load_golden
+
+EXTRA = list(osamp.SAMPLERS_EXTRA)
+
+
+def max_rel(a, b):
+    return float((a - b).abs().max() / b.abs().max())
+
+
+@pytest.mark.parametrize("name", EXTRA)
+def test_oracle_sampler_restatements_vs_reference_functions(name):
+    g = load_golden("samplers_toy.pt")
+    x0, noises = toy_inputs()
+    fn, _, draws, ancestral, _ = osamp.SAMPLERS_EXTRA[name]
+    for steps in (5, 12, 24, 40):
+        ref = g[(name, steps)]
+        it = iter(noises)
+        kw = {"noise_fn": lambda: next(it)} if (draws or ancestral) else {}
+        got = fn(toy_denoiser, x0 * ref["sigmas"][0], ref["sigmas"], **kw)
+        assert max_rel(got, ref["latent"]) < 5e-6, (name, steps)
+        used = 64 - len(list(it))
+        assert used == ref["draws"], (name, steps, used, ref["draws"])  # the RNG stream advances exactly as in the reference
+
+
+@pytest.mark.parametrize("name", EXTRA)
+def test_oracle_pipeline_extra_samplers_vs_reference_stack(name):
+    g = load_golden("tiny_sd15_samples_extra.pt")
+    cfg = synth.TINY_SD15_UNET_CONFIG
+    sd = synth.synth_unet_state_dict(cfg, seed=0)
+    c, uc = synth.synth_conditioning(len(g["seeds"]), cfg["context_dim"], None, seed=1234)
+    lat, sigmas = pipeline.txt2img_latents(sd, cfg, c, uc, g["seeds"], g["hw"] * 8, g["hw"] * 8, g[name]["steps"], sampler_name=name)
+    torch.testing.assert_close(sigmas, g[name]["sigmas"], rtol=0, atol=0)
+    assert max_rel(lat, g[name]["latent"]) < 5e-4
+
+
+def test_oracle_schedulers_bit_exact():
+    g = load_golden("schedulers.pt")
+    linker = osched.Linker(Predictor())
+    for name in osched.ALL:
+        for sdxl in (False, True):
+            for n in (1, 4, 11, 20, 31, 32):
+                want = g[(name, n, sdxl)]
+                got = osched.get_sigmas(name, n, linker, is_sdxl=sdxl).float()
+                assert want.shape == got.shape and torch.equal(want, got), (name, n, sdxl)
+
+
+def test_product_schedulers_bit_exact():
+    """modules/sd_schedulers.py of the product (host arithmetic, no GPU involved) against the reference's table."""
+    from types import SimpleNamespace
+    from forge_amd.backend.modules.k_prediction import Prediction
+    from forge_amd.k_diffusion.external import ForgeScheduleLinker
+    from forge_amd.modules import sd_schedulers, shared
+    g = load_golden("schedulers.pt")
+    pred = Prediction(prediction_type="epsilon", beta_schedule="linear", linear_start=0.00085, linear_end=0.012, timesteps=1000)
+    linker = ForgeScheduleLinker(pred)
+    linker.inner_model = SimpleNamespace(forge_objects=SimpleNamespace(unet=SimpleNamespace(model=SimpleNamespace(predictor=pred))))
+    assert {s.name: s.label for s in sd_schedulers.schedulers} == g["labels"]
+    saved = shared.sd_model
+    try:
+        for sdxl in (False, True):
+            shared.sd_model = SimpleNamespace(is_sdxl=sdxl)
+            for sch in sd_schedulers.schedulers:
+                if sch.function is None:
+                    continue
+                for n in (1, 4, 11, 20, 31, 32):
+                    kw = {"sigma_min": pred.sigmas[0].item(), "sigma_max": pred.sigmas[-1].item()}
+                    if sch.need_inner_model:
+                        kw["inner_model"] = linker
+                    got = sch.function(n=n, **kw, device="cpu").float()
+                    want = g[(sch.name, n, sdxl)]
+                    assert want.shape == got.shape and torch.equal(want, got), (sch.name, n, sdxl)
+    finally:
+        shared.sd_model = saved
+    assert torch.equal(sd_schedulers.schedulers_map["Karras"].function(n=10, sigma_min=0.03, sigma_max=14.0, rho=5.0, device="cpu"), g["rho"]["karras_5"])
+    assert torch.equal(sd_schedulers.schedulers_map["polyexponential"].function(n=10, sigma_min=0.03, sigma_max=14.0, rho=2.0, device="cpu"),
+                       g["rho"]["polyexponential_2"])
+
+
+def test_deis_coefficient_tables():
+    from forge_amd.k_diffusion import deis
+    g = load_golden("samplers_toy.pt")
+    sig = g["deis_sigmas"]
+    for key, order, mode in (("deis_tab_3", 3, "tab"), ("deis_tab_4", 4, "tab"), ("deis_rhoab_3", 3, "rhoab")):
+        got = deis.get_deis_coeff_list(sig, order, deis_mode=mode)
+        assert len(got) == len(g[key])
+        for i, (a, b) in enumerate(zip(got, g[key])):
+            assert len(a) == len(b), (key, i)
+            if i == len(got) - 1 and mode == "tab":
+                continue  # the last interval ends at sigma = 0 where the VP integrand is singular; sample_deis never reads it
+            for x, y in zip(a, b):
+                assert abs(float(x) - y) <= 2e-5 * max(abs(y), 1e-3), (key, i, float(x), y)
+    ours = osamp.deis_coeff_list(sig, 3)
+    for a, b in zip(ours[:-1], g["deis_tab_3"][:-1]):
+        for x, y in zip(a, b):
+            assert abs(float(x) - y) <= 2e-5 * max(abs(y), 1e-3)
+
+
+def test_sampler_table_matches_reference_names_and_options():
+    from forge_amd.modules import sd_samplers, sd_samplers_kdiffusion as kd
+    names = {x.name: x for x in sd_samplers.all_samplers}
+    for name in ["DPM++ 2M", "Euler a", "Euler"] + EXTRA:
+        assert name in names, name
+    assert names["DPM2"].options == {"scheduler": "karras", "discard_next_to_last_sigma": True, "second_order": True}
+    assert names["DPM++ 2S a"].options["scheduler"] == "karras" and names["Restart"].options["scheduler"] == "karras"
+    assert sd_samplers.find_sampler_config("k_dpm_2_a").name == "DPM2 a"
+    assert set(kd.sampler_extra_params["sample_heun"]) == {"s_churn", "s_tmin", "s_tmax", "s_noise"}
