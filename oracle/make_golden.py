@@ -463,6 +463,184 @@ def gen_samplers_toy():
     print("samplers_toy", len(out))
 
 
+def _ref_timesteps_impl():
+    """modules/sd_samplers_timesteps_impl.py imported from the reference; its `modules.*` imports are satisfied by the real
+    uni_pc.py / torch_utils.py files and a bare stand-in for modules.shared."""
+    import importlib.util
+    import types
+
+    def load(name, *parts):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(ref_import.REFERENCE_ROOT, *parts))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    ref_import.load_reference()
+    names = ["modules", "modules.shared", "modules.models", "modules.models.diffusion", "modules.models.diffusion.uni_pc", "modules.torch_utils"]
+    saved = {k: sys.modules.get(k) for k in names}
+    try:
+        for n in names[:5]:
+            sys.modules[n] = types.ModuleType(n)
+            sys.modules[n].__path__ = []
+        sys.modules["modules.shared"].opts = SimpleNamespace(uni_pc_variant="bh1", uni_pc_skip_type="time_uniform", uni_pc_order=3,
+                                                             uni_pc_lower_order_final=True)
+        sys.modules["modules"].shared = sys.modules["modules.shared"]
+        sys.modules["modules.models.diffusion.uni_pc"].uni_pc = load("_ref_uni_pc", "modules", "models", "diffusion", "uni_pc", "uni_pc.py")
+        sys.modules["modules.torch_utils"] = load("_ref_torch_utils", "modules", "torch_utils.py")
+        return load("_ref_timesteps_impl", "modules", "sd_samplers_timesteps_impl.py")
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+class RefEpsDenoiser:
+    """CFGDenoiser in classic_ddim_eps_estimation mode (modules/sd_samplers_cfg_denoiser.py:163-169, 201-202, 224-226 restated -- that
+    module needs gradio) around `inner(x, sigma, **extra)` -> denoised [, cond_pred, uncond_pred in inner.last]."""
+
+    def __init__(self, inner, alphas_cumprod):
+        self.inner = inner
+        self.inner_model = SimpleNamespace(inner_model=SimpleNamespace(alphas_cumprod=alphas_cumprod))
+        self.need_last_noise_uncond, self.last_noise_uncond = False, None
+
+    def __call__(self, x, t, **extra):
+        acd = self.inner_model.inner_model.alphas_cumprod
+        fake_sigmas = ((1 - acd) / acd) ** 0.5
+        sigma = fake_sigmas[t.round().long().clip(0, int(fake_sigmas.shape[0]))]
+        x = x * ((sigma ** 2.0 + 1.0) ** 0.5)[:, None, None, None]
+        denoised = self.inner(x, sigma, **extra)
+        if self.need_last_noise_uncond:
+            self.last_noise_uncond = (x - self.inner.last[2]) / sigma[:, None, None, None]
+        return (x - denoised) / sigma[:, None, None, None]
+
+
+def _ref_lcm_schedule(ref, pred):
+    """LCMCompVisDenoiser's schedule methods (modules/sd_samplers_lcm.py:10-49): that module imports modules.shared, so the class
+    body is re-assembled here from the reference's own DiscreteEpsDDPMDenoiser (k_diffusion/external.py:76-133)."""
+    base = ref.kd_external.DiscreteEpsDDPMDenoiser
+    skip = 1000 // 50
+    acd = 1.0 / (pred.sigmas ** 2.0 + 1.0)
+    valid = torch.zeros(50, dtype=torch.float32)
+    for x in range(50):
+        valid[50 - 1 - x] = acd[1000 - 1 - x * skip]
+    sched = base(None, valid, quantize=None)
+
+    def sigma_to_t(sigma):
+        d = sigma.log() - sched.log_sigmas[:, None]
+        return d.abs().argmin(dim=0).view(sigma.shape) * skip + (skip - 1)
+
+    def t_to_sigma(timestep):
+        t = torch.clamp(((timestep - (skip - 1)) / skip).float(), min=0, max=(len(sched.sigmas) - 1))
+        return base.t_to_sigma(sched, t)
+
+    def get_sigmas(n):
+        t = torch.linspace(sigma_to_t(sched.sigma_max), sigma_to_t(sched.sigma_min), n)
+        return ref.kd_sampling.append_zero(t_to_sigma(t))
+    return sched, get_sigmas
+
+
+def gen_samples_more(name, cfg, net, b=2, hw=16):
+    """DDIM / DDIM CFG++ / PLMS (reference functions, eps-mode denoiser), LCM and DDPM (reference loop functions) through the
+    reference UNet + sampling_function; plus the same on the toy denoiser for the CPU pin of oracle/sampling.py."""
+    import importlib.util
+    ref = ref_import.load_reference()
+    impl = _ref_timesteps_impl()
+    spec = importlib.util.spec_from_file_location("_ref_kd_extra", os.path.join(ref_import.REFERENCE_ROOT, "backend", "modules", "k_diffusion_extra.py"))
+    kd_extra = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kd_extra)
+    pred = ref_import.build_ref_predictor()
+    acd = 1.0 / (pred.sigmas ** 2.0 + 1.0)
+    lcm_sched, lcm_get_sigmas = _ref_lcm_schedule(ref, pred)
+
+    def ref_sample_lcm(model, x, sigmas, extra_args=None, noise_sampler=None):  # sd_samplers_lcm.py:69-83 needs modules.shared to import
+        s_in = x.new_ones([x.shape[0]])
+        for i in range(len(sigmas) - 1):
+            denoised = model(x, sigmas[i] * s_in, **(extra_args or {}))
+            x = denoised
+            if sigmas[i + 1] > 0:
+                x = x + sigmas[i + 1] * ref.kd_sampling.torch.randn_like(x)
+        return x
+
+    c, uc = synth.synth_conditioning(b, cfg["context_dim"], cfg.get("adm_in_channels"), seed=1234)
+    seeds = [1000 + i for i in range(b)]
+    extra = {"cond": c, "uncond": uc, "cond_scale": 7.0, "s_min_uncond": 0.0, "image_cond": None}
+    x0, noises = toy_inputs()
+    res = {"seeds": seeds, "hw": hw, "lcm_sigmas_table": lcm_sched.sigmas.clone(),
+           "lcm_get_sigmas": {n: lcm_get_sigmas(n) for n in (1, 4, 8, 50)}}
+    steps = 6
+
+    class Seq:
+        def __init__(self):
+            self.i = 0
+
+        def __getattr__(self, item):
+            if item == "randn_like":
+                def f(x):
+                    self.i += 1
+                    return noises[self.i - 1]
+                return f
+            return getattr(torch, item)
+
+    class ToyInner:
+        last = None
+
+        def __call__(self, x, sigma, **kw):
+            d = toy_denoiser(x, sigma)
+            self.last = (d, d, toy_denoiser(0.5 * x, sigma))
+            return d
+    timesteps = torch.clip(torch.asarray(list(range(0, 1000, 1000 // steps))) + 1, 0, 999)
+    cases = {"DDIM": (impl.ddim, {"eta": 0.0}), "DDIM eta": (impl.ddim, {"eta": 0.7}), "DDIM CFG++": (impl.ddim_cfgpp, {"eta": 0.0}),
+             "PLMS": (impl.plms, {})}
+    for label, (fn, kw) in cases.items():
+        # toy
+        h = Seq()
+        impl.k_diffusion.sampling.torch = h
+        try:
+            toy = fn(RefEpsDenoiser(ToyInner(), acd), x0.clone(), timesteps, disable=True, **kw)
+        finally:
+            impl.k_diffusion.sampling.torch = torch
+        # real stack
+        den = ref_import.RefDenoiser(net, pred, seeds)
+        rng = ImageRNG((cfg["in_channels"], hw, hw), seeds, "CPU")
+        x = rng.next()
+        impl.k_diffusion.sampling.torch = _Hijack(rng)
+        ref.sampling_function.sampling_prepare(den.patcher, x=x)
+        try:
+            lat = fn(RefEpsDenoiser(den, acd), x, timesteps, extra_args=extra, disable=True, **kw)
+        finally:
+            impl.k_diffusion.sampling.torch = torch
+            ref.sampling_function.sampling_cleanup(den.patcher)
+        res[label] = {"steps": steps, "timesteps": timesteps, "latent": lat, "toy": toy, "toy_draws": h.i, **kw}
+        print(name, label, float(lat.std()), float(toy.std()))
+    for label, fn, sig in (("LCM", ref_sample_lcm, lcm_get_sigmas(steps)),
+                           ("DDPM", kd_extra.sample_ddpm, ref.kd_external.ForgeScheduleLinker(pred).get_sigmas(steps))):
+        h = Seq()
+        ref.kd_sampling.torch = h
+        kd_extra.torch = h
+        try:
+            toy = fn(lambda x, s, **kw: toy_denoiser(x, s), x0 * sig[0], sig)
+        finally:
+            ref.kd_sampling.torch = torch
+            kd_extra.torch = torch
+        den = ref_import.RefDenoiser(net, pred, seeds)
+        rng = ImageRNG((cfg["in_channels"], hw, hw), seeds, "CPU")
+        x = pred.noise_scaling(sig[0], rng.next(), torch.zeros(b, cfg["in_channels"], hw, hw), max_denoise=False)
+        hj = _Hijack(rng)
+        ref.kd_sampling.torch = hj
+        kd_extra.torch = hj
+        ref.sampling_function.sampling_prepare(den.patcher, x=x)
+        try:
+            lat = fn(den, x, sig, extra_args=extra)
+        finally:
+            ref.kd_sampling.torch = torch
+            kd_extra.torch = torch
+            ref.sampling_function.sampling_cleanup(den.patcher)
+        res[label] = {"steps": steps, "sigmas": sig, "latent": lat, "toy": toy, "toy_draws": h.i}
+        print(name, label, float(lat.std()), float(toy.std()))
+    torch.save(res, os.path.join(GOLD, f"{name}_samples_more.pt"))
+
+
 def gen_schedulers():
     """modules/sd_schedulers.py's table, imported from the reference with a two-attribute stand-in for modules.shared."""
     import importlib.util
@@ -650,6 +828,7 @@ def main():
         net, _ = gen_unet("tiny_sd15", synth.TINY_SD15_UNET_CONFIG)
         gen_samples("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
         gen_samples_extra("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
+        gen_samples_more("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
         gen_img2img("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
         gen_lora("tiny_sd15", synth.TINY_SD15_UNET_CONFIG)
         gen_unet_control("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
@@ -660,6 +839,10 @@ def main():
     if a.only == "samplers":
         net, _ = gen_unet("tiny_sd15", synth.TINY_SD15_UNET_CONFIG)
         gen_samples_extra("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
+        gen_samples_more("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
+    if a.only == "samplers_more":
+        net, _ = gen_unet("tiny_sd15", synth.TINY_SD15_UNET_CONFIG)
+        gen_samples_more("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
     if a.only in ("", "samplers"):
         gen_samplers_toy()
         gen_schedulers()

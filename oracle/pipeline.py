@@ -64,6 +64,36 @@ def txt2img_latents(unet_sd, unet_cfg, cond, uncond, seeds, height, width, steps
 
 
 @torch.no_grad()
+def txt2img_latents_more(unet_sd, unet_cfg, cond, uncond, seeds, height, width, steps, sampler_name, cfg_scale=7.0, eta=0.0):
+    """DDIM / DDIM CFG++ / PLMS (modules/sd_samplers_timesteps.py:121-149: x = noise, timesteps :62), LCM (sd_samplers_lcm.py) and DDPM
+    (modules_forge/alter_samplers.py) with the same denoiser underneath."""
+    pred = Predictor()
+    rng = ImageRNG((unet_cfg["in_channels"], height // 8, width // 8), seeds, "CPU")
+    x = rng.next()
+
+    def unet_fn(xc, t, ctx, y):
+        return unet_forward(unet_sd, unet_cfg, xc, t, ctx, y)
+
+    def denoiser_full(xx, sigma):
+        return cfg_denoise(lambda a, s, c, y: apply_model(unet_fn, pred, a, s, c, y), xx, sigma, uncond, cond, cfg_scale)
+
+    if sampler_name in ("DDIM", "DDIM CFG++", "PLMS"):
+        eps_model = sampling.EpsFromDenoiser(denoiser_full, 1.0 / (pred.sigmas ** 2.0 + 1.0))
+        ts = sampling.timesteps_for(steps)
+        if sampler_name == "PLMS":
+            return sampling.sample_plms(eps_model, x, ts)
+        return sampling.sample_ddim(eps_model, x, ts, rng.next, eta=eta, cfgpp=sampler_name == "DDIM CFG++")
+    if sampler_name == "LCM":
+        sigmas = sampling.LcmSchedule(pred).get_sigmas(steps)
+        fn = sampling.sample_lcm
+    else:
+        sigmas = sampling.get_sigmas_linker(pred, steps)
+        fn = sampling.sample_ddpm
+    x = pred.noise_scaling(sigmas[0], x, torch.zeros_like(x))
+    return fn(lambda xx, s: denoiser_full(xx, s)[0], x, sigmas, rng.next)
+
+
+@torch.no_grad()
 def txt2img(unet_sd, unet_cfg, vae_sd, vae_cfg, cond, uncond, seeds, height, width, steps, **kw):
     lat, _ = txt2img_latents(unet_sd, unet_cfg, cond, uncond, seeds, height, width, steps, **kw)
     dec = decode_first_stage(vae_sd, lat, vae_cfg.get("scaling_factor", 0.18215), vae_cfg.get("shift_factor", 0.0) or 0.0)

@@ -409,3 +409,136 @@ SAMPLERS_EXTRA = {
     "IPNDM": (sample_ipndm, None, False, False, False), "IPNDM_V": (sample_ipndm_v, None, False, False, False),
     "DEIS": (sample_deis, None, False, False, False), "Restart": (sample_restart, "karras", False, True, False),
 }
+
+
+# ---- timestep-space samplers (modules/sd_samplers_timesteps_impl.py) and the classic_ddim_eps_estimation wrapper ----------------------
+def timesteps_for(steps):
+    return torch.clip(torch.asarray(list(range(0, 1000, 1000 // steps))) + 1, 0, 999)  # sd_samplers_timesteps.py:62
+
+
+class EpsFromDenoiser:
+    """modules/sd_samplers_cfg_denoiser.py:163-169, 201-202, 224-226: model(x_vp, t) -> eps via the sigma-space denoiser.
+    `denoiser(x, sigma_vec)` returns denoised, or (denoised, cond_pred, uncond_pred)."""
+
+    def __init__(self, denoiser, alphas_cumprod):
+        self.denoiser, self.acd = denoiser, alphas_cumprod
+        self.need_last_noise_uncond, self.last_noise_uncond = False, None
+
+    def __call__(self, x, t):
+        fake_sigmas = ((1 - self.acd) / self.acd) ** 0.5
+        sigma = fake_sigmas[t.round().long().clip(0, int(fake_sigmas.shape[0]))]
+        x = x * ((sigma ** 2.0 + 1.0) ** 0.5)[:, None, None, None]
+        out = self.denoiser(x, sigma)
+        denoised, uncond_pred = (out[0], out[2]) if isinstance(out, tuple) else (out, None)
+        if self.need_last_noise_uncond:
+            self.last_noise_uncond = (x - uncond_pred) / sigma[:, None, None, None]
+        return (x - denoised) / sigma[:, None, None, None]
+
+
+def _ddim_tables(acd, timesteps, eta):
+    import numpy as np
+    alphas = acd[timesteps]
+    alphas_prev = acd[torch.nn.functional.pad(timesteps[:-1], pad=(1, 0))].to(torch.float64)
+    sigmas = eta * np.sqrt((1 - alphas_prev.numpy()) / (1 - alphas) * (1 - alphas / alphas_prev.numpy()))
+    return alphas, alphas_prev, torch.sqrt(1 - alphas), sigmas
+
+
+def sample_ddim(eps_model, x, timesteps, noise_fn, eta=0.0, cfgpp=False):
+    """sd_samplers_timesteps_impl.py:11-42 (ddim) / :45-83 (ddim_cfgpp: direction from the unconditional eps)."""
+    alphas, alphas_prev, s1m, sigmas = _ddim_tables(eps_model.acd, timesteps, eta)
+    eps_model.need_last_noise_uncond = cfgpp
+    s_in, s_x = x.new_ones((x.shape[0])), x.new_ones((x.shape[0], 1, 1, 1))
+    for i in range(len(timesteps) - 1):
+        index = len(timesteps) - 1 - i
+        e_t = eps_model(x, timesteps[index].item() * s_in)
+        a_t, a_prev = alphas[index].item() * s_x, alphas_prev[index].item() * s_x
+        sigma_t, sqrt_one_minus_at = sigmas[index].item() * s_x, s1m[index].item() * s_x
+        pred_x0 = (x - sqrt_one_minus_at * e_t) / a_t.sqrt()
+        dir_xt = (1.0 - a_prev - sigma_t ** 2).sqrt() * (eps_model.last_noise_uncond if cfgpp else e_t)
+        x = a_prev.sqrt() * pred_x0 + dir_xt + sigma_t * noise_fn()
+    return x
+
+
+def sample_plms(eps_model, x, timesteps):
+    """sd_samplers_timesteps_impl.py:86-142."""
+    alphas, alphas_prev, s1m, _ = _ddim_tables(eps_model.acd, timesteps, 0.0)
+    s_in, s_x = x.new_ones([x.shape[0]]), x.new_ones((x.shape[0], 1, 1, 1))
+    old = []
+
+    def x_prev_of(e, index):
+        a_t, a_prev = alphas[index].item() * s_x, alphas_prev[index].item() * s_x
+        pred_x0 = (x - s1m[index].item() * s_x * e) / a_t.sqrt()
+        return a_prev.sqrt() * pred_x0 + (1.0 - a_prev).sqrt() * e
+
+    for i in range(len(timesteps) - 1):
+        index = len(timesteps) - 1 - i
+        e_t = eps_model(x, timesteps[index].item() * s_in)
+        if len(old) == 0:
+            e_next = eps_model(x_prev_of(e_t, index), timesteps[max(index - 1, 0)].item() * s_in)
+            e_prime = (e_t + e_next) / 2
+        elif len(old) == 1:
+            e_prime = (3 * e_t - old[-1]) / 2
+        elif len(old) == 2:
+            e_prime = (23 * e_t - 16 * old[-1] + 5 * old[-2]) / 12
+        else:
+            e_prime = (55 * e_t - 59 * old[-1] + 37 * old[-2] - 9 * old[-3]) / 24
+        x_new = x_prev_of(e_prime, index)
+        old = (old + [e_t])[-3:]
+        x = x_new
+    return x
+
+
+# ---- LCM (modules/sd_samplers_lcm.py) and DDPM (backend/modules/k_diffusion_extra.py) -------------------------------------------------
+class LcmSchedule:
+    """sd_samplers_lcm.py:10-49 + k_diffusion/external.py:76-120: the 50 training timesteps of LCM (every 20th of 1000)."""
+
+    def __init__(self, predictor, timesteps=1000, original_timesteps=50):
+        self.skip = timesteps // original_timesteps
+        acd = 1.0 / (predictor.sigmas ** 2.0 + 1.0)
+        valid = torch.zeros(original_timesteps)
+        for x in range(original_timesteps):
+            valid[original_timesteps - 1 - x] = acd[timesteps - 1 - x * self.skip]
+        self.sigmas = ((1 - valid) / valid) ** 0.5
+        self.log_sigmas = self.sigmas.log()
+
+    def sigma_to_t(self, sigma):
+        d = sigma.log() - self.log_sigmas[:, None]
+        return d.abs().argmin(dim=0).view(sigma.shape) * self.skip + (self.skip - 1)
+
+    def t_to_sigma(self, timestep):
+        t = torch.clamp(((timestep - (self.skip - 1)) / self.skip).float(), min=0, max=len(self.sigmas) - 1)
+        lo, hi, w = t.floor().long(), t.ceil().long(), t.frac()
+        return ((1 - w) * self.log_sigmas[lo] + w * self.log_sigmas[hi]).exp()
+
+    def get_sigmas(self, n):
+        start, end = self.sigma_to_t(self.sigmas[-1]), self.sigma_to_t(self.sigmas[0])
+        return append_zero(self.t_to_sigma(torch.linspace(start, end, n)))
+
+
+def sample_lcm(model, x, sigmas, noise_fn, callback=None):
+    """sd_samplers_lcm.py:69-83."""
+    s_in = x.new_ones([x.shape[0]])
+    for i in range(len(sigmas) - 1):
+        denoised = model(x, sigmas[i] * s_in)
+        _cb(callback, x, i, sigmas[i], sigmas[i], denoised)
+        x = denoised
+        if sigmas[i + 1] > 0:
+            x = x + sigmas[i + 1] * noise_fn()
+    return x
+
+
+def sample_ddpm(model, x, sigmas, noise_fn, callback=None):
+    """backend/modules/k_diffusion_extra.py:12-42."""
+    s_in = x.new_ones([x.shape[0]])
+    for i in range(len(sigmas) - 1):
+        denoised = model(x, sigmas[i] * s_in)
+        _cb(callback, x, i, sigmas[i], sigmas[i], denoised)
+        sigma, sigma_prev = sigmas[i], sigmas[i + 1]
+        xv, noise = x / torch.sqrt(1.0 + sigma ** 2.0), (x - denoised) / sigma
+        alpha_cumprod, alpha_cumprod_prev = 1 / (sigma * sigma + 1), 1 / (sigma_prev * sigma_prev + 1)
+        alpha = alpha_cumprod / alpha_cumprod_prev
+        mu = (1.0 / alpha).sqrt() * (xv - (1 - alpha) * noise / (1 - alpha_cumprod).sqrt())
+        if sigma_prev > 0:
+            mu = mu + ((1 - alpha) * (1.0 - alpha_cumprod_prev) / (1.0 - alpha_cumprod)).sqrt() * noise_fn()
+        x = mu * torch.sqrt(1.0 + sigma_prev ** 2.0) if sigma_prev != 0 else mu
+    return x

@@ -1,7 +1,9 @@
 """`create_sampler` / `add_sampler` -- mirror of modules/sd_samplers.py:34-70."""
-from . import sd_samplers_kdiffusion
+from . import sd_samplers_kdiffusion, sd_samplers_lcm, sd_samplers_timesteps
+from ..modules_forge import alter_samplers
 
-all_samplers = [*sd_samplers_kdiffusion.samplers_data_k_diffusion]
+all_samplers = [*sd_samplers_kdiffusion.samplers_data_k_diffusion, *sd_samplers_timesteps.samplers_data_timesteps,
+                *sd_samplers_lcm.samplers_data_lcm, *alter_samplers.samplers_data_alter]
 all_samplers_map = {x.name: x for x in all_samplers}
 
 

@@ -5,6 +5,7 @@ import torch
 
 from . import prompt_parser, sd_samplers_common, shared
 from .. import hipops as ops
+from ..backend.modules.k_model import SigmaInfo
 from ..backend.sampling.sampling_function import sampling_function
 
 
@@ -31,6 +32,7 @@ class CFGDenoiser:
         self.p = None
         self.need_last_noise_uncond = False
         self.last_noise_uncond = None
+        self.classic_ddim_eps_estimation = False
         # test hook: callable(step, like) replacing the torch.randn_like of :180 (device RNG in the reference, so fixtures
         # made on CPU can only be matched with an injected noise source)
         self.mask_noise_source = None
@@ -44,6 +46,15 @@ class CFGDenoiser:
         if state.interrupted or state.skipped:
             raise sd_samplers_common.InterruptedException
         sig0 = sigma.fmx_sigma.host[0] if hasattr(sigma, "fmx_sigma") else float(sigma[0])
+        if self.classic_ddim_eps_estimation:
+            # :163-169  `sigma` holds a timestep and x the variance-preserving latent: look the real sigma up and rescale x to the
+            # variance-exploding latent the denoiser works on
+            acd = self.inner_model.inner_model.alphas_cumprod
+            fake_sigmas = ((1 - acd) / acd) ** 0.5
+            sig0 = float(fake_sigmas[min(max(int(round(sig0)), 0), int(fake_sigmas.shape[0]) - 1)])
+            x = ops.scale_f32(x, (sig0 ** 2.0 + 1.0) ** 0.5)
+            sigma = torch.full_like(sigma, sig0)
+            sigma.fmx_sigma = SigmaInfo([sig0] * x.shape[0])
         if self.mask is not None:
             # :178-181  x = x * nmask + noise_scaling(sigma, randn_like(init_latent), init_latent) * mask
             noise = self.mask_noise_source(self.step, self.init_latent) if self.mask_noise_source is not None else torch.randn_like(self.init_latent)
@@ -62,12 +73,14 @@ class CFGDenoiser:
         denoised, cond_pred, uncond_pred = sampling_function(self, denoiser_params=denoiser_params, cond_scale=cond_scale,
                                                              cond_composition=cond_composition)
         if self.need_last_noise_uncond:
-            self.last_noise_uncond = (x - uncond_pred) / sigma[:, None, None, None]
+            self.last_noise_uncond = ops.lincomb([x, uncond_pred], [1.0 / sig0, -1.0 / sig0])  # :201-202
         if self.mask is not None:
             denoised = ops.blend_masked(denoised, self._nmask32(x), self.init_latent, self._mask32(x))  # :204-213
         self.sampler.last_latent = denoised
         state.current_latent = denoised
         self.step += 1
+        if self.classic_ddim_eps_estimation:
+            return ops.lincomb([x, denoised], [1.0 / sig0, -1.0 / sig0])  # :224-226 eps = (x - denoised) / sigma
         return denoised
 
     def _mask32(self, like):

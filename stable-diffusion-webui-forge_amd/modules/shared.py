@@ -8,7 +8,7 @@ opts = SimpleNamespace(
     randn_source="CPU",  # reference default is "GPU"; "CPU"/"NV" are the device-independent sources (modules/rng.py:6-33)
     eta_noise_seed_delta=0, always_discard_next_to_last_sigma=False, sgm_noise_multiplier=False,
     use_old_karras_scheduler_sigmas=False, s_min_uncond=0.0, s_min_uncond_all=False, skip_early_cond=0.0,
-    eta_ancestral=1.0, sigma_min=0.0, sigma_max=0.0, rho=0.0, s_churn=0.0, s_tmin=0.0, s_tmax=0.0, s_noise=1.0,
+    eta_ancestral=1.0, eta_ddim=0.0, sigma_min=0.0, sigma_max=0.0, rho=0.0, s_churn=0.0, s_tmin=0.0, s_tmax=0.0, s_noise=1.0,
     beta_dist_alpha=0.6, beta_dist_beta=0.6, forge_try_reproduce="None", sd_vae_decode_method="Full",
 )
 

@@ -141,6 +141,22 @@ def test_extra_sampler_vs_reference_fixture(sampler, engines):
     report(f"tiny_sd15 {sampler} {g[sampler]['steps']} steps vs reference", max_rel(res.latents, g[sampler]["latent"]), 1e-2)
 
 
+@pytest.mark.parametrize("label,sampler,eta", [("DDIM", "DDIM", None), ("DDIM eta", "DDIM", 0.7), ("DDIM CFG++", "DDIM CFG++", None), ("PLMS", "PLMS", None),
+                                               ("LCM", "LCM", None), ("DDPM", "DDPM", None)])
+def test_timestep_lcm_ddpm_samplers_vs_reference_fixture(label, sampler, eta, engines):
+    """modules/sd_samplers_timesteps.py (DDIM, DDIM CFG++, PLMS through the CFGDenoiser's classic_ddim_eps_estimation mode),
+    sd_samplers_lcm.py and the DDPM alter-sampler against the reference's functions on the reference UNet."""
+    cfg = TINY["tiny_sd15"]
+    g = load_golden("tiny_sd15_samples_more.pt")
+    shared.opts.randn_source = "CPU"
+    c, uc = _conds(cfg, len(g["seeds"]))
+    p = processing.StableDiffusionProcessingTxt2Img(sd_model=engines["tiny_sd15"], c=c, uc=uc, seed=g["seeds"][0], sampler_name=sampler,
+                                                    batch_size=len(g["seeds"]), steps=g[label]["steps"], cfg_scale=7.0, eta=eta,
+                                                    width=g["hw"] * 8, height=g["hw"] * 8, do_decode=False)
+    res = processing.process_images(p)
+    report(f"tiny_sd15 {label} {g[label]['steps']} steps vs reference", max_rel(res.latents, g[label]["latent"]), 1e-2)
+
+
 @pytest.mark.parametrize("scheduler", ["Uniform", "Karras", "Exponential", "Polyexponential", "SGM Uniform", "KL Optimal", "Align Your Steps",
                                        "Simple", "Normal", "DDIM", "Beta", "Turbo", "Align Your Steps GITS", "Align Your Steps 32"])
 def test_scheduler_choice_reaches_the_sampler(scheduler, engines):

@@ -117,3 +117,64 @@ def test_sampler_table_matches_reference_names_and_options():
     assert names["DPM++ 2S a"].options["scheduler"] == "karras" and names["Restart"].options["scheduler"] == "karras"
     assert sd_samplers.find_sampler_config("k_dpm_2_a").name == "DPM2 a"
     assert set(kd.sampler_extra_params["sample_heun"]) == {"s_churn", "s_tmin", "s_tmax", "s_noise"}
+
+
+MORE = [("DDIM", {}), ("DDIM eta", {"eta": 0.7}), ("DDIM CFG++", {}), ("PLMS", {}), ("LCM", {}), ("DDPM", {})]
+
+
+def _toy_full(x, sigma):
+    d = toy_denoiser(x, sigma)
+    return d, d, toy_denoiser(0.5 * x, sigma)  # (denoised, cond_pred, stand-in uncond_pred), as oracle/make_golden.py ToyInner
+
+
+@pytest.mark.parametrize("label,kw", MORE)
+def test_oracle_timestep_lcm_ddpm_restatements_vs_reference_functions(label, kw):
+    g = load_golden("tiny_sd15_samples_more.pt")[label]
+    x0, noises = toy_inputs()
+    it = iter(noises)
+    nf = lambda: next(it)
+    acd = 1.0 / (Predictor().sigmas ** 2.0 + 1.0)
+    if label.startswith("DDIM"):
+        got = osamp.sample_ddim(osamp.EpsFromDenoiser(_toy_full, acd), x0.clone(), g["timesteps"], nf, eta=kw.get("eta", 0.0), cfgpp=label == "DDIM CFG++")
+    elif label == "PLMS":
+        got = osamp.sample_plms(osamp.EpsFromDenoiser(_toy_full, acd), x0.clone(), g["timesteps"])
+    else:
+        fn = osamp.sample_lcm if label == "LCM" else osamp.sample_ddpm
+        got = fn(toy_denoiser, x0 * g["sigmas"][0], g["sigmas"], nf)
+    assert max_rel(got, g["toy"]) < 5e-6
+    assert 64 - len(list(it)) == g["toy_draws"]
+
+
+@pytest.mark.parametrize("label,kw", MORE)
+def test_oracle_pipeline_more_samplers_vs_reference_stack(label, kw):
+    g = load_golden("tiny_sd15_samples_more.pt")
+    cfg = synth.TINY_SD15_UNET_CONFIG
+    sd = synth.synth_unet_state_dict(cfg, seed=0)
+    c, uc = synth.synth_conditioning(len(g["seeds"]), cfg["context_dim"], None, seed=1234)
+    name = "DDIM" if label == "DDIM eta" else label
+    lat = pipeline.txt2img_latents_more(sd, cfg, c, uc, g["seeds"], g["hw"] * 8, g["hw"] * 8, g[label]["steps"], name, eta=kw.get("eta", 0.0))
+    assert max_rel(lat, g[label]["latent"]) < 5e-4
+
+
+def test_lcm_schedule_bit_exact():
+    """oracle AND product LCM schedules (50 training timesteps, sigma <-> t maps) vs the reference's DiscreteEpsDDPMDenoiser-based one."""
+    from types import SimpleNamespace
+    from forge_amd.backend.modules.k_prediction import Prediction
+    from forge_amd.modules.sd_samplers_lcm import LCMCompVisDenoiser
+    g = load_golden("tiny_sd15_samples_more.pt")
+    pred = Prediction(prediction_type="epsilon", beta_schedule="linear", linear_start=0.00085, linear_end=0.012, timesteps=1000)
+    prod = LCMCompVisDenoiser(SimpleNamespace(forge_objects=SimpleNamespace(unet=SimpleNamespace(model=SimpleNamespace(predictor=pred)))))
+    orc = osamp.LcmSchedule(Predictor())
+    assert torch.equal(prod.sigmas, g["lcm_sigmas_table"]) and torch.equal(orc.sigmas, g["lcm_sigmas_table"])
+    for n, want in g["lcm_get_sigmas"].items():
+        assert torch.equal(prod.get_sigmas(n), want) and torch.equal(orc.get_sigmas(n), want), n
+
+
+def test_ddpm_step_coefficients_match_the_written_out_step():
+    from forge_amd.backend.modules.k_diffusion_extra import ddpm_step_coefficients
+    x, den, nz = torch.randn(3, 4), torch.randn(3, 4), torch.randn(3, 4)
+    for s, sp in ((14.6, 9.7), (1.0, 0.4), (0.1, 0.0)):
+        sig = torch.tensor([s, sp])
+        want = osamp.sample_ddpm(lambda xx, ss: den, x, sig, lambda: nz)
+        cx, cd, cn = ddpm_step_coefficients(sig[0], sig[1])
+        torch.testing.assert_close(cx * x + cd * den + cn * nz, want, rtol=1e-5, atol=1e-5)
