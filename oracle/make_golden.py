@@ -486,7 +486,8 @@ def _ref_timesteps_impl():
         sys.modules["modules"].shared = sys.modules["modules.shared"]
         sys.modules["modules.models.diffusion.uni_pc"].uni_pc = load("_ref_uni_pc", "modules", "models", "diffusion", "uni_pc", "uni_pc.py")
         sys.modules["modules.torch_utils"] = load("_ref_torch_utils", "modules", "torch_utils.py")
-        return load("_ref_timesteps_impl", "modules", "sd_samplers_timesteps_impl.py")
+        impl = load("_ref_timesteps_impl", "modules", "sd_samplers_timesteps_impl.py")
+        return impl
     finally:
         for k, v in saved.items():
             if v is None:
@@ -639,6 +640,50 @@ def gen_samples_more(name, cfg, net, b=2, hw=16):
         res[label] = {"steps": steps, "sigmas": sig, "latent": lat, "toy": toy, "toy_draws": h.i}
         print(name, label, float(lat.std()), float(toy.std()))
     torch.save(res, os.path.join(GOLD, f"{name}_samples_more.pt"))
+
+
+def gen_unipc(name, cfg, net, b=2, hw=16):
+    """The reference's `unipc()` wrapper + UniPC / NoiseScheduleVP classes, on the toy denoiser (all variants / skip types / orders)
+    and through the reference UNet + sampling_function (default options)."""
+    ref = ref_import.load_reference()
+    impl = _ref_timesteps_impl()
+    pred = ref_import.build_ref_predictor()
+    acd = 1.0 / (pred.sigmas ** 2.0 + 1.0)
+    x0, _ = toy_inputs()
+
+    class ToyInner:
+        last = None
+
+        def __call__(self, x, sigma, **kw):
+            return toy_denoiser(x, sigma)
+    res = {"seeds": [1000 + i for i in range(b)], "hw": hw, "toy": {}}
+    shared_opts = impl.shared.opts
+    for variant in ("bh1", "bh2", "vary_coeff"):
+        for skip in ("time_uniform", "time_quadratic", "logSNR"):
+            for order, lof, steps in ((3, True, 8), (2, True, 5), (1, True, 4), (3, False, 8), (2, False, 6), (6, True, 9)):  # order 4 without lower_order_final is unstable in fp32 (3e-4 vs fp64 in the reference itself)
+                shared_opts.uni_pc_variant, shared_opts.uni_pc_skip_type = variant, skip
+                shared_opts.uni_pc_order, shared_opts.uni_pc_lower_order_final = order, lof
+                xin = x0[:1].clone() if variant == "vary_coeff" else x0.clone()  # the reference's vary_coeff path only runs at batch 1
+                ts = torch.clip(torch.asarray(list(range(0, 1000, 1000 // steps))) + 1, 0, 999)
+                out = impl.unipc(RefEpsDenoiser(ToyInner(), acd), xin, ts, extra_args={}, callback=lambda d: None, disable=True)
+                res["toy"][(variant, skip, order, lof, steps)] = out
+    shared_opts.uni_pc_variant, shared_opts.uni_pc_skip_type, shared_opts.uni_pc_order, shared_opts.uni_pc_lower_order_final = "bh1", "time_uniform", 3, True
+    ts = torch.clip(torch.asarray(list(range(0, 1000, 1000 // 6))) + 1, 0, 999)
+    res["toy_img2img"] = impl.unipc(RefEpsDenoiser(ToyInner(), acd), x0.clone(), ts[:4], extra_args={}, callback=lambda d: None, disable=True, is_img2img=True)
+    c, uc = synth.synth_conditioning(b, cfg["context_dim"], cfg.get("adm_in_channels"), seed=1234)
+    extra = {"cond": c, "uncond": uc, "cond_scale": 7.0, "s_min_uncond": 0.0, "image_cond": None}
+    for steps in (6, 9):
+        den = ref_import.RefDenoiser(net, pred, res["seeds"])
+        x = ImageRNG((cfg["in_channels"], hw, hw), res["seeds"], "CPU").next()
+        ts = torch.clip(torch.asarray(list(range(0, 1000, 1000 // steps))) + 1, 0, 999)
+        ref.sampling_function.sampling_prepare(den.patcher, x=x)
+        try:
+            lat = impl.unipc(RefEpsDenoiser(den, acd), x, ts, extra_args=extra, callback=lambda d: None, disable=True)
+        finally:
+            ref.sampling_function.sampling_cleanup(den.patcher)
+        res[steps] = {"latent": lat, "timesteps": ts}
+        print(name, "UniPC", steps, float(lat.std()))
+    torch.save(res, os.path.join(GOLD, f"{name}_samples_unipc.pt"))
 
 
 def gen_schedulers():
@@ -829,6 +874,7 @@ def main():
         gen_samples("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
         gen_samples_extra("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
         gen_samples_more("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
+        gen_unipc("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
         gen_img2img("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
         gen_lora("tiny_sd15", synth.TINY_SD15_UNET_CONFIG)
         gen_unet_control("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
@@ -840,6 +886,9 @@ def main():
         net, _ = gen_unet("tiny_sd15", synth.TINY_SD15_UNET_CONFIG)
         gen_samples_extra("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
         gen_samples_more("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
+    if a.only == "unipc":
+        net, _ = gen_unet("tiny_sd15", synth.TINY_SD15_UNET_CONFIG)
+        gen_unipc("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
     if a.only == "samplers_more":
         net, _ = gen_unet("tiny_sd15", synth.TINY_SD15_UNET_CONFIG)
         gen_samples_more("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)

@@ -77,9 +77,12 @@ def txt2img_latents_more(unet_sd, unet_cfg, cond, uncond, seeds, height, width, 
     def denoiser_full(xx, sigma):
         return cfg_denoise(lambda a, s, c, y: apply_model(unet_fn, pred, a, s, c, y), xx, sigma, uncond, cond, cfg_scale)
 
-    if sampler_name in ("DDIM", "DDIM CFG++", "PLMS"):
+    if sampler_name in ("DDIM", "DDIM CFG++", "PLMS", "UniPC"):
         eps_model = sampling.EpsFromDenoiser(denoiser_full, 1.0 / (pred.sigmas ** 2.0 + 1.0))
         ts = sampling.timesteps_for(steps)
+        if sampler_name == "UniPC":
+            from . import unipc
+            return unipc.sample_unipc(eps_model, x, len(ts), eps_model.acd)
         if sampler_name == "PLMS":
             return sampling.sample_plms(eps_model, x, ts)
         return sampling.sample_ddim(eps_model, x, ts, rng.next, eta=eta, cfgpp=sampler_name == "DDIM CFG++")

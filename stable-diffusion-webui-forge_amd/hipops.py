@@ -358,10 +358,15 @@ def lincomb3(x, d0, d1, a, b, c, out=None):
 
 
 def lincomb(srcs, coefs, out=None):
-    """out = sum_k coefs[k] * srcs[k] over fp32 tensors of one shape (1..8 terms), one fused pass."""
+    """out = sum_k coefs[k] * srcs[k] over fp32 tensors of one shape; one fused pass per 8 terms."""
     import ctypes
     n = len(srcs)
-    assert 1 <= n <= 8 and n == len(coefs)
+    assert n >= 1 and n == len(coefs)
+    if n > 8:  # more terms than one launch takes (UniPC at order > 5): accumulate in groups, the partial sum riding along as term 0
+        acc = lincomb(srcs[:8], coefs[:8], out=out)
+        for i in range(8, n, 7):
+            acc = lincomb([acc] + list(srcs[i:i + 7]), [1.0] + list(coefs[i:i + 7]), out=acc)
+        return acc
     x = srcs[0]
     for t in srcs:
         assert t.dtype == torch.float32 and t.is_contiguous() and t.shape == x.shape and t.device == x.device

@@ -13,7 +13,8 @@ samplers_timesteps = [
     ("DDIM", sd_samplers_timesteps_impl.ddim, ["ddim"], {}),
     ("DDIM CFG++", sd_samplers_timesteps_impl.ddim_cfgpp, ["ddim_cfgpp"], {}),
     ("PLMS", sd_samplers_timesteps_impl.plms, ["plms"], {}),
-]  # not built: UniPC (modules/models/diffusion/uni_pc)
+    ("UniPC", sd_samplers_timesteps_impl.unipc, ["unipc"], {}),
+]
 
 samplers_data_timesteps = [
     sd_samplers_common.SamplerData(label, lambda model, funcname=funcname: CompVisSampler(funcname, model), aliases, options)

@@ -1,10 +1,12 @@
-"""DDIM / DDIM CFG++ / PLMS over discrete timesteps -- mirror of modules/sd_samplers_timesteps_impl.py (`ddim` :11-42,
-`ddim_cfgpp` :45-83, `plms` :86-142).  `model(x, t)` is a CFGDenoiser in classic_ddim_eps_estimation mode: x is the
+"""DDIM / DDIM CFG++ / PLMS / UniPC over discrete timesteps -- mirror of modules/sd_samplers_timesteps_impl.py (`ddim` :11-42,
+`ddim_cfgpp` :45-83, `plms` :86-142, `UniPCCFG` :145-170, `unipc` :173-181).  `model(x, t)` is a CFGDenoiser in classic_ddim_eps_estimation mode: x is the
 variance-preserving latent, the return value is eps.  Every update is linear in (x, eps, eps history, noise) with coefficients
 from the alphas_cumprod table, so it is one fused pass (fmx_sampler_lincomb) per step."""
 import torch
 import tqdm
 
+from . import shared
+from .models.diffusion.uni_pc import uni_pc
 from .. import hipops as ops
 from ..k_diffusion import sampling as kd_sampling
 from ..backend.modules.k_model import SigmaInfo
@@ -103,3 +105,35 @@ def plms(model, x, timesteps, extra_args=None, callback=None, disable=None):
         if callback is not None:
             callback({"x": x, "i": i, "sigma": 0, "sigma_hat": 0, "denoised": pred_x0})
     return x
+
+
+class UniPCCFG(uni_pc.UniPC):
+    def __init__(self, cfg_model, extra_args, callback, *args, **kwargs):
+        super().__init__(None, *args, **kwargs)
+
+        def after_update(x, model_x):
+            if callback is not None:
+                callback({"x": x, "i": self.index, "sigma": 0, "sigma_hat": 0, "denoised": model_x})
+            self.index += 1
+        self.cfg_model = cfg_model
+        self.extra_args = {} if extra_args is None else extra_args
+        self.callback = callback
+        self.index = 0
+        self.after_update = after_update
+
+    def get_model_input_time(self, t_continuous):
+        return (t_continuous - 1.0 / self.noise_schedule.total_N) * 1000.0
+
+    def model(self, x, t):
+        return self.cfg_model(x, _tvec(x, float(self.get_model_input_time(t))), **self.extra_args)
+
+
+@torch.no_grad()
+def unipc(model, x, timesteps, extra_args=None, callback=None, disable=None, is_img2img=False):
+    alphas_cumprod = model.inner_model.inner_model.alphas_cumprod
+    ns = uni_pc.NoiseScheduleVP("discrete", alphas_cumprod=alphas_cumprod)
+    t_start = float(timesteps[-1]) / 1000 + 1 / 1000 if is_img2img else None
+    opts = shared.opts
+    sampler = UniPCCFG(model, extra_args, callback, ns, predict_x0=True, thresholding=False, variant=opts.uni_pc_variant)
+    return sampler.sample(x, steps=len(timesteps), t_start=t_start, skip_type=opts.uni_pc_skip_type, method="multistep", order=opts.uni_pc_order,
+                          lower_order_final=opts.uni_pc_lower_order_final, disable=True if disable is None else disable)

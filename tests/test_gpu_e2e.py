@@ -157,6 +157,20 @@ def test_timestep_lcm_ddpm_samplers_vs_reference_fixture(label, sampler, eta, en
     report(f"tiny_sd15 {label} {g[label]['steps']} steps vs reference", max_rel(res.latents, g[label]["latent"]), 1e-2)
 
 
+@pytest.mark.parametrize("steps", [6, 9])
+def test_unipc_vs_reference_fixture(steps, engines):
+    """UniPC (bh1, time_uniform, order 3, lower_order_final: the reference's defaults) against the reference's own UniPC classes."""
+    cfg = TINY["tiny_sd15"]
+    g = load_golden("tiny_sd15_samples_unipc.pt")
+    shared.opts.randn_source = "CPU"
+    c, uc = _conds(cfg, len(g["seeds"]))
+    p = processing.StableDiffusionProcessingTxt2Img(sd_model=engines["tiny_sd15"], c=c, uc=uc, seed=g["seeds"][0], sampler_name="UniPC",
+                                                    batch_size=len(g["seeds"]), steps=steps, cfg_scale=7.0, width=g["hw"] * 8, height=g["hw"] * 8,
+                                                    do_decode=False)
+    res = processing.process_images(p)
+    report(f"tiny_sd15 UniPC {steps} steps vs reference", max_rel(res.latents, g[steps]["latent"]), 1e-2)
+
+
 @pytest.mark.parametrize("scheduler", ["Uniform", "Karras", "Exponential", "Polyexponential", "SGM Uniform", "KL Optimal", "Align Your Steps",
                                        "Simple", "Normal", "DDIM", "Beta", "Turbo", "Align Your Steps GITS", "Align Your Steps 32"])
 def test_scheduler_choice_reaches_the_sampler(scheduler, engines):

@@ -178,3 +178,26 @@ def test_ddpm_step_coefficients_match_the_written_out_step():
         want = osamp.sample_ddpm(lambda xx, ss: den, x, sig, lambda: nz)
         cx, cd, cn = ddpm_step_coefficients(sig[0], sig[1])
         torch.testing.assert_close(cx * x + cd * den + cn * nz, want, rtol=1e-5, atol=1e-5)
+
+
+def test_oracle_unipc_vs_reference_classes():
+    """oracle/unipc.py vs the reference's unipc() / UniPC / NoiseScheduleVP: every variant x skip type x (order, lower_order_final) on the
+    toy denoiser, the img2img start time, and the default configuration through the reference UNet stack."""
+    from oracle import unipc as ou
+    g = load_golden("tiny_sd15_samples_unipc.pt")
+    x0, _ = toy_inputs()
+    acd = 1.0 / (Predictor().sigmas ** 2.0 + 1.0)
+    for (variant, skip, order, lof, steps), want in g["toy"].items():
+        n = len(osamp.timesteps_for(steps))
+        xin = x0[:1].clone() if variant == "vary_coeff" else x0.clone()
+        got = ou.sample_unipc(osamp.EpsFromDenoiser(_toy_full, acd), xin, n, acd, variant, skip, order, lof)
+        assert max_rel(got, want) < 3e-5, (variant, skip, order, lof, steps, max_rel(got, want))
+    ts = osamp.timesteps_for(6)[:4]
+    got = ou.sample_unipc(osamp.EpsFromDenoiser(_toy_full, acd), x0.clone(), len(ts), acd, t_start=ts[-1] / 1000 + 1 / 1000)
+    assert max_rel(got, g["toy_img2img"]) < 3e-5
+    cfg = synth.TINY_SD15_UNET_CONFIG
+    sd = synth.synth_unet_state_dict(cfg, seed=0)
+    c, uc = synth.synth_conditioning(len(g["seeds"]), cfg["context_dim"], None, seed=1234)
+    for steps in (6, 9):
+        lat = pipeline.txt2img_latents_more(sd, cfg, c, uc, g["seeds"], g["hw"] * 8, g["hw"] * 8, steps, "UniPC")
+        assert max_rel(lat, g[steps]["latent"]) < 5e-4, steps
