@@ -206,6 +206,10 @@ int fmx_sampler_lincomb3(const float* x, const float* denoised, const float* old
  * Heun, DPM2(a), DPM++ 2S a, LMS, HeunPP2, IPNDM(_V), DEIS, Restart (k_diffusion/sampling.py:189-341, 573-603, 771-981,
  * modules/sd_samplers_extra.py:7-74). */
 int fmx_sampler_lincomb(const float* const* srcs, const float* coefs, int32_t n_terms, float* x_out, int64_t n, void* stream);
+/* out[0] = || (x_low - x_high) / max(atol, rtol * max(|x_low|, |x_prev|)) ||_2 / sqrt(n)   -- the local error estimate of the adaptive
+ * DPM-Solver (k_diffusion/sampling.py:531-532).  workspace: >= 256 floats of device memory.  Deterministic summation order. */
+int fmx_sampler_error_norm(const float* x_low, const float* x_high, const float* x_prev, float atol, float rtol, float* workspace,
+                           float* out, int64_t n, void* stream);
 int fmx_scale_f32(const float* x, float s, float* y, int64_t n, void* stream);
 /* out = a * a_mask + b * b_mask, fp32, elementwise over n (inpaint latent blending: modules/sd_samplers_cfg_denoiser.py:181,205
  * `x * nmask + noisy_init * mask`, `denoised * nmask + init_latent * mask`; processing.py:1866).  out may alias a or b. */

@@ -686,6 +686,121 @@ def gen_unipc(name, cfg, net, b=2, hw=16):
     torch.save(res, os.path.join(GOLD, f"{name}_samples_unipc.pt"))
 
 
+class ListNoiseSampler:
+    """noise_sampler(sigma, sigma_next) stand-in for BrownianTreeNoiseSampler: hands out a fixed list (torchsde is not in this image, and
+    its stream could not be reproduced natively anyway); records the (sigma, sigma_next) it was asked for."""
+
+    def __init__(self, noises):
+        self.noises, self.i, self.asked = noises, 0, []
+
+    def __call__(self, sigma, sigma_next):
+        self.asked.append((float(sigma), float(sigma_next)))
+        self.i += 1
+        return self.noises[self.i - 1]
+
+
+def gen_samplers_sde():
+    """DPM++ SDE / 2M SDE (midpoint, heun) / 3M SDE with an injected noise sampler, DPM fast and DPM adaptive: the reference's functions
+    on the toy denoiser (CPU pin of oracle + product host algebra) and through the reference UNet + sampling_function."""
+    ref = ref_import.load_reference()
+    kd = ref.kd_sampling
+    pred = ref_import.build_ref_predictor()
+    linker = ref.kd_external.ForgeScheduleLinker(pred)
+    x0, noises = toy_inputs()
+    smin, smax = pred.sigmas[0].item(), pred.sigmas[-1].item()
+
+    class Toy:
+        inner_model = SimpleNamespace(predictor=pred)
+
+        def __call__(self, x, sigma, **kw):
+            return toy_denoiser(x, sigma)
+
+    class Seq:
+        def __init__(self):
+            self.i = 0
+
+        def __getattr__(self, item):
+            if item == "randn_like":
+                def f(x):
+                    self.i += 1
+                    return noises[self.i - 1]
+                return f
+            return getattr(torch, item)
+    out = {}
+    karras = lambda n: kd.get_sigmas_karras(n, smin, smax)
+    expo = lambda n: kd.get_sigmas_exponential(n, smin, smax)
+    disc = lambda sig: torch.cat([sig[:-2], sig[-1:]])
+    cases = {"DPM++ SDE": (kd.sample_dpmpp_sde, karras, {}), "DPM++ SDE eta0.5": (kd.sample_dpmpp_sde, karras, {"eta": 0.5, "s_noise": 0.9}),
+             "DPM++ 2M SDE": (kd.sample_dpmpp_2m_sde, expo, {}), "DPM++ 2M SDE Heun": (kd.sample_dpmpp_2m_sde, expo, {"solver_type": "heun"}),
+             "DPM++ 2M SDE eta0": (kd.sample_dpmpp_2m_sde, expo, {"eta": 0.0}),
+             "DPM++ 3M SDE": (kd.sample_dpmpp_3m_sde, lambda n: disc(expo(n + 1)), {}), "DPM++ 3M SDE eta0": (kd.sample_dpmpp_3m_sde, lambda n: disc(expo(n + 1)), {"eta": 0.0})}
+    for label, (fn, sched, kw) in cases.items():
+        for steps in (5, 12):
+            sig = sched(steps)
+            ns = ListNoiseSampler(noises)
+            lat = fn(Toy(), x0 * sig[0], sig, noise_sampler=ns, disable=True, **kw)
+            out[(label, steps)] = {"sigmas": sig, "latent": lat, "asked": ns.asked, "kw": kw}
+    for n in (5, 6, 7, 12):
+        for eta in (0.0, 0.6):
+            h = Seq()
+            kd.torch = h
+            try:
+                lat = kd.sample_dpm_fast(Toy(), x0 * smax, smin, smax, n, disable=True, eta=eta)
+            finally:
+                kd.torch = torch
+            out[("DPM fast", n, eta)] = {"latent": lat, "draws": h.i}
+    for order in (2, 3):
+        for eta in (0.0, 0.6):
+            h = Seq()
+            kd.torch = h
+            try:
+                lat, info = kd.sample_dpm_adaptive(Toy(), x0 * smax, smin, smax, disable=True, order=order, eta=eta, return_info=True)
+            finally:
+                kd.torch = torch
+            out[("DPM adaptive", order, eta)] = {"latent": lat, "draws": h.i, "info": info}
+            print("DPM adaptive", order, eta, info)
+    # through the reference UNet stack (tiny_sd15): DPM fast 7 evaluations, DPM adaptive order 3 with a loose tolerance (few steps)
+    cfg = synth.TINY_SD15_UNET_CONFIG
+    net = ref_import.build_ref_unet(cfg, synth.synth_unet_state_dict(cfg, seed=0))
+    b, hw = 2, 16
+    c, uc = synth.synth_conditioning(b, cfg["context_dim"], None, seed=1234)
+    seeds = [1000 + i for i in range(b)]
+    extra = {"cond": c, "uncond": uc, "cond_scale": 7.0, "s_min_uncond": 0.0, "image_cond": None}
+    stack = {"seeds": seeds, "hw": hw}
+
+    def run(fn, *a, noise_list=None, **kw):
+        den = ref_import.RefDenoiser(net, pred, seeds)
+        rng = ImageRNG((cfg["in_channels"], hw, hw), seeds, "CPU")
+        x = pred.noise_scaling(torch.tensor(smax), rng.next(), torch.zeros(b, cfg["in_channels"], hw, hw), max_denoise=False)
+        kd.torch = _Hijack(rng)
+        ref.sampling_function.sampling_prepare(den.patcher, x=x)
+        try:
+            return fn(den, x, *a, extra_args=extra, disable=True, **kw)
+        finally:
+            kd.torch = torch
+            ref.sampling_function.sampling_cleanup(den.patcher)
+    stack["DPM fast"] = {"n": 7, "latent": run(kd.sample_dpm_fast, smin, smax, 7)}
+    lat, info = run(kd.sample_dpm_adaptive, smin, smax, rtol=0.5, atol=0.5, return_info=True)
+    stack["DPM adaptive"] = {"rtol": 0.5, "atol": 0.5, "latent": lat, "info": info}
+    print("stack DPM adaptive", info)
+    g = torch.Generator().manual_seed(99)
+    nz = [torch.randn(b, cfg["in_channels"], hw, hw, generator=g) for _ in range(16)]
+    stack["noises_seed"] = 99
+    for label, fn, sig, kw in (("DPM++ SDE", kd.sample_dpmpp_sde, karras(5), {}), ("DPM++ 2M SDE", kd.sample_dpmpp_2m_sde, expo(6), {}),
+                               ("DPM++ 3M SDE", kd.sample_dpmpp_3m_sde, disc(expo(7)), {})):
+        den = ref_import.RefDenoiser(net, pred, seeds)
+        x = pred.noise_scaling(sig[0], ImageRNG((cfg["in_channels"], hw, hw), seeds, "CPU").next(), torch.zeros(b, cfg["in_channels"], hw, hw), max_denoise=False)
+        ref.sampling_function.sampling_prepare(den.patcher, x=x)
+        try:
+            lat = fn(den, x, sig, extra_args=extra, disable=True, noise_sampler=ListNoiseSampler(nz), **kw)
+        finally:
+            ref.sampling_function.sampling_cleanup(den.patcher)
+        stack[label] = {"sigmas": sig, "latent": lat}
+        print("stack", label, float(lat.std()))
+    out["stack"] = stack
+    torch.save(out, os.path.join(GOLD, "samplers_sde_dpm.pt"))
+
+
 def gen_schedulers():
     """modules/sd_schedulers.py's table, imported from the reference with a two-attribute stand-in for modules.shared."""
     import importlib.util
@@ -892,6 +1007,8 @@ def main():
     if a.only == "samplers_more":
         net, _ = gen_unet("tiny_sd15", synth.TINY_SD15_UNET_CONFIG)
         gen_samples_more("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
+    if a.only in ("", "samplers", "sde"):
+        gen_samplers_sde()
     if a.only in ("", "samplers"):
         gen_samplers_toy()
         gen_schedulers()

@@ -542,3 +542,177 @@ def sample_ddpm(model, x, sigmas, noise_fn, callback=None):
             mu = mu + ((1 - alpha) * (1.0 - alpha_cumprod_prev) / (1.0 - alpha_cumprod)).sqrt() * noise_fn()
         x = mu * torch.sqrt(1.0 + sigma_prev ** 2.0) if sigma_prev != 0 else mu
     return x
+
+
+# ---- SDE family (noise_sampler injected: the reference's default is torchsde's BrownianTree) and DPM-Solver fast / adaptive ----------
+def sample_dpmpp_sde(model, x, sigmas, noise_sampler, eta=1.0, s_noise=1.0, r=0.5):
+    """k_diffusion/sampling.py:607-645."""
+    s_in = x.new_ones([x.shape[0]])
+    sigma_fn = lambda t: t.neg().exp()
+    t_fn = lambda s: s.log().neg()
+    for i in range(len(sigmas) - 1):
+        denoised = model(x, sigmas[i] * s_in)
+        if sigmas[i + 1] == 0:
+            x = x + _to_d(x, sigmas[i], denoised) * (sigmas[i + 1] - sigmas[i])
+            continue
+        t, t_next = t_fn(sigmas[i]), t_fn(sigmas[i + 1])
+        h = t_next - t
+        s = t + h * r
+        fac = 1 / (2 * r)
+        sd, su = get_ancestral_step(sigma_fn(t), sigma_fn(s), eta)
+        s_ = t_fn(sd)
+        x_2 = (sigma_fn(s_) / sigma_fn(t)) * x - (t - s_).expm1() * denoised
+        x_2 = x_2 + noise_sampler(sigma_fn(t), sigma_fn(s)) * s_noise * su
+        denoised_2 = model(x_2, sigma_fn(s) * s_in)
+        sd, su = get_ancestral_step(sigma_fn(t), sigma_fn(t_next), eta)
+        t_next_ = t_fn(sd)
+        denoised_d = (1 - fac) * denoised + fac * denoised_2
+        x = (sigma_fn(t_next_) / sigma_fn(t)) * x - (t - t_next_).expm1() * denoised_d
+        x = x + noise_sampler(sigma_fn(t), sigma_fn(t_next)) * s_noise * su
+    return x
+
+
+def sample_dpmpp_2m_sde(model, x, sigmas, noise_sampler, eta=1.0, s_noise=1.0, solver_type="midpoint"):
+    """k_diffusion/sampling.py:675-717."""
+    s_in = x.new_ones([x.shape[0]])
+    old, h_last = None, None
+    for i in range(len(sigmas) - 1):
+        denoised = model(x, sigmas[i] * s_in)
+        if sigmas[i + 1] == 0:
+            x = denoised
+        else:
+            t, s = -sigmas[i].log(), -sigmas[i + 1].log()
+            h = s - t
+            eta_h = eta * h
+            x = sigmas[i + 1] / sigmas[i] * (-eta_h).exp() * x + (-h - eta_h).expm1().neg() * denoised
+            if old is not None:
+                r = h_last / h
+                if solver_type == "heun":
+                    x = x + ((-h - eta_h).expm1().neg() / (-h - eta_h) + 1) * (1 / r) * (denoised - old)
+                else:
+                    x = x + 0.5 * (-h - eta_h).expm1().neg() * (1 / r) * (denoised - old)
+            if eta:
+                x = x + noise_sampler(sigmas[i], sigmas[i + 1]) * sigmas[i + 1] * (-2 * eta_h).expm1().neg().sqrt() * s_noise
+            h_last = h
+        old = denoised
+    return x
+
+
+def sample_dpmpp_3m_sde(model, x, sigmas, noise_sampler, eta=1.0, s_noise=1.0):
+    """k_diffusion/sampling.py:721-768."""
+    s_in = x.new_ones([x.shape[0]])
+    den_1, den_2, h_1, h_2 = None, None, None, None
+    for i in range(len(sigmas) - 1):
+        denoised = model(x, sigmas[i] * s_in)
+        if sigmas[i + 1] == 0:
+            x = denoised
+        else:
+            t, s = -sigmas[i].log(), -sigmas[i + 1].log()
+            h = s - t
+            h_eta = h * (eta + 1)
+            x = torch.exp(-h_eta) * x + (-h_eta).expm1().neg() * denoised
+            if h_2 is not None:
+                r0, r1 = h_1 / h, h_2 / h
+                d1_0, d1_1 = (denoised - den_1) / r0, (den_1 - den_2) / r1
+                d1 = d1_0 + (d1_0 - d1_1) * r0 / (r0 + r1)
+                d2 = (d1_0 - d1_1) / (r0 + r1)
+                phi_2 = h_eta.neg().expm1() / h_eta + 1
+                phi_3 = phi_2 / h_eta - 0.5
+                x = x + phi_2 * d1 - phi_3 * d2
+            elif h_1 is not None:
+                x = x + (h_eta.neg().expm1() / h_eta + 1) * ((denoised - den_1) / (h_1 / h))
+            if eta:
+                x = x + noise_sampler(sigmas[i], sigmas[i + 1]) * sigmas[i + 1] * (-2 * h * eta).expm1().neg().sqrt() * s_noise
+            h_1, h_2 = h, h_1
+        den_1, den_2 = denoised, den_1
+    return x
+
+
+class DpmSolver:
+    """k_diffusion/sampling.py:397-463 (the eps cache is made explicit: a stage eps is passed in when an earlier solver step already has it)."""
+
+    def __init__(self, model):
+        self.model = model
+
+    @staticmethod
+    def sigma(t):
+        return t.neg().exp()
+
+    def eps(self, x, t):
+        return (x - self.model(x, self.sigma(t) * x.new_ones([x.shape[0]]))) / self.sigma(t)
+
+    def step1(self, x, t, t_next, eps):
+        return x - self.sigma(t_next) * (t_next - t).expm1() * eps
+
+    def step2(self, x, t, t_next, eps, r1=0.5):
+        h = t_next - t
+        s1 = t + r1 * h
+        e1 = self.eps(x - self.sigma(s1) * (r1 * h).expm1() * eps, s1)
+        return x - self.sigma(t_next) * h.expm1() * eps - self.sigma(t_next) / (2 * r1) * h.expm1() * (e1 - eps), e1
+
+    def step3(self, x, t, t_next, eps, e1=None, r1=1 / 3, r2=2 / 3):
+        h = t_next - t
+        s1, s2 = t + r1 * h, t + r2 * h
+        if e1 is None:
+            e1 = self.eps(x - self.sigma(s1) * (r1 * h).expm1() * eps, s1)
+        u2 = x - self.sigma(s2) * (r2 * h).expm1() * eps - self.sigma(s2) * (r2 / r1) * ((r2 * h).expm1() / (r2 * h) - 1) * (e1 - eps)
+        e2 = self.eps(u2, s2)
+        return x - self.sigma(t_next) * h.expm1() * eps - self.sigma(t_next) / r2 * (h.expm1() / h - 1) * (e2 - eps)
+
+    def target(self, t, t_next, t_end, eta):
+        if not eta:
+            return t_next, 0.0
+        sd, su = get_ancestral_step(self.sigma(t), self.sigma(t_next), eta)
+        t_ = torch.minimum(t_end, -sd.log())
+        return t_, (self.sigma(t_next) ** 2 - self.sigma(t_) ** 2) ** 0.5
+
+
+def sample_dpm_fast(model, x, sigma_min, sigma_max, n, noise_fn, eta=0.0, s_noise=1.0):
+    """k_diffusion/sampling.py:465-499, 546-555."""
+    import math
+    sol = DpmSolver(model)
+    t_start, t_end = -torch.tensor(sigma_max).log(), -torch.tensor(sigma_min).log()
+    m = math.floor(n / 3) + 1
+    ts = torch.linspace(t_start, t_end, m + 1)
+    orders = [3] * (m - 2) + [2, 1] if n % 3 == 0 else [3] * (m - 1) + [n % 3]
+    for i, order in enumerate(orders):
+        t, t_next = ts[i], ts[i + 1]
+        t_, su = sol.target(t, t_next, t_end, eta)
+        eps = sol.eps(x, t)
+        x = sol.step1(x, t, t_, eps) if order == 1 else sol.step2(x, t, t_, eps)[0] if order == 2 else sol.step3(x, t, t_, eps)
+        x = x + su * s_noise * noise_fn()
+    return x
+
+
+def sample_dpm_adaptive(model, x, sigma_min, sigma_max, noise_fn, order=3, rtol=0.05, atol=0.0078, h_init=0.05, eta=0.0, s_noise=1.0,
+                        accept_safety=0.81):
+    """k_diffusion/sampling.py:501-543, 558-569 with the PID controller (:368-394) at pcoeff 0, icoeff 1, dcoeff 0."""
+    import math
+    sol = DpmSolver(model)
+    t_start, t_end = -torch.tensor(sigma_max).log(), -torch.tensor(sigma_min).log()
+    s, x_prev, h = t_start, x, abs(h_init)
+    b1 = 1.0 / (1.5 if eta else order)
+    info = {"steps": 0, "n_accept": 0, "n_reject": 0}
+    while s < t_end - 1e-5:
+        t = torch.minimum(t_end, s + h)
+        t_, su = sol.target(s, t, t_end, eta)
+        eps = sol.eps(x, s)
+        if order == 2:
+            x_low = sol.step1(x, s, t_, eps)
+            x_high, _ = sol.step2(x, s, t_, eps)
+        else:
+            x_low, e1 = sol.step2(x, s, t_, eps, r1=1 / 3)
+            x_high = sol.step3(x, s, t_, eps, e1=e1)  # dpm_solver_3_step reuses the cached eps_r1 of the r1 = 1/3 two-stage step (:527-528)
+        delta = torch.maximum(torch.tensor(atol), torch.tensor(rtol) * torch.maximum(x_low.abs(), x_prev.abs()))
+        error = torch.linalg.norm((x_low - x_high) / delta) / x.numel() ** 0.5
+        factor = 1 + math.atan((1 / (float(error) + 1e-8)) ** b1 - 1)
+        if factor >= accept_safety:
+            x_prev = x_low
+            x = x_high + su * s_noise * noise_fn()
+            s = t
+            info["n_accept"] += 1
+        else:
+            info["n_reject"] += 1
+        h *= factor
+        info["steps"] += 1
+    return x, info

@@ -207,6 +207,40 @@ __global__ void lincomb_kernel(LincombArgs a, float* __restrict__ out, long n) {
   }
 }
 
+// DPM-Solver adaptive step-size control (k_diffusion/sampling.py:531-532): sum over the latent of ((x_low - x_high) / delta)^2 with
+// delta = max(atol, rtol * max(|x_low|, |x_prev|)).  Stage 1: one fp32 partial per block (fixed grid, fixed summation order inside the
+// block: strided per-thread sums, wave shuffle tree, LDS across the 4 waves); stage 2: a single block adds the partials in order.
+// Same bits on every run for a given size.
+constexpr int ERRNORM_BLOCKS = 256;
+
+__global__ void error_norm_partial_kernel(const float* __restrict__ x_low, const float* __restrict__ x_high, const float* __restrict__ x_prev,
+                                          float atol, float rtol, float* __restrict__ partial, long n) {
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float lo = x_low[i];
+    const float delta = fmaxf(atol, rtol * fmaxf(fabsf(lo), fabsf(x_prev[i])));
+    const float r = (lo - x_high[i]) / delta;
+    acc += r * r;
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  __shared__ float wave_sum[TPB / 64];
+  if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < TPB / 64; ++w) t += wave_sum[w];
+    partial[blockIdx.x] = t;
+  }
+}
+
+__global__ void error_norm_final_kernel(const float* __restrict__ partial, int nblocks, float inv_numel, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float t = 0.f;
+    for (int b = 0; b < nblocks; ++b) t += partial[b];
+    out[0] = sqrtf(t) * sqrtf(inv_numel);  // ||.||_2 / sqrt(numel)
+  }
+}
+
 __global__ void scale_kernel(const float* __restrict__ x, float s, float* __restrict__ y, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = x[i] * s;
 }
@@ -367,6 +401,17 @@ extern "C" int fmx_sampler_euler_step(const float* x, const float* denoised, flo
   hipLaunchKernelGGL(euler_step_kernel, dim3(grid_for(n)), dim3(TPB), 0, (hipStream_t)stream, x, denoised, sigma, sigma_next, noise,
                      noise_scale, x_out, (long)n);
   FMX_LAUNCH_CHECK("fmx_sampler_euler_step");
+  return FMX_OK;
+}
+
+extern "C" int fmx_sampler_error_norm(const float* x_low, const float* x_high, const float* x_prev, float atol, float rtol, float* workspace,
+                                      float* out, int64_t n, void* stream) {
+  FMX_REQUIRE(x_low && x_high && x_prev && workspace && out && n > 0 && atol > 0.f, "error_norm: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(error_norm_partial_kernel, dim3(ERRNORM_BLOCKS), dim3(TPB), 0, st, x_low, x_high, x_prev, atol, rtol, workspace, (long)n);
+  FMX_LAUNCH_CHECK("fmx_sampler_error_norm (partial)");
+  hipLaunchKernelGGL(error_norm_final_kernel, dim3(1), dim3(64), 0, st, workspace, ERRNORM_BLOCKS, 1.0f / (float)n, out);
+  FMX_LAUNCH_CHECK("fmx_sampler_error_norm (final)");
   return FMX_OK;
 }
 

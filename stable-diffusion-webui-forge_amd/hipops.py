@@ -379,6 +379,15 @@ def lincomb(srcs, coefs, out=None):
     return out
 
 
+def error_norm(x_low, x_high, x_prev, atol, rtol):
+    """-> python float: ||(x_low - x_high) / max(atol, rtol * max(|x_low|, |x_prev|))|| / sqrt(numel) (one device sync: the adaptive
+    step-size controller needs the value on the host to accept / reject the step)."""
+    ws = torch.empty(257, dtype=torch.float32, device=x_low.device)
+    _lib.check(_lib.lib().fmx_sampler_error_norm(_p(x_low), _p(x_high), _p(x_prev), float(atol), float(rtol), _p(ws), ws[256:].data_ptr(),
+                                                 x_low.numel(), stream_ptr()), "fmx_sampler_error_norm")
+    return float(ws[256])
+
+
 def scale_f32(x, s, out=None):
     if out is None:
         out = torch.empty_like(x)

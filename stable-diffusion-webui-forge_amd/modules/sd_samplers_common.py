@@ -97,6 +97,15 @@ class Sampler:
         except InterruptedException:
             return self.last_latent
 
+    def create_noise_sampler(self, x, sigmas, p):
+        """sd_samplers_common.py:343-351: one Brownian path per image, seeded by the image's seed, so results do not depend on batch size."""
+        if getattr(shared.opts, "no_dpmpp_sde_batch_determinism", False):
+            return None
+        sigma_min, sigma_max = sigmas[sigmas > 0].min(), sigmas.max()
+        it = getattr(p, "iteration", 0)
+        current_iter_seeds = p.all_seeds[it * p.batch_size:(it + 1) * p.batch_size]
+        return kd_sampling.BrownianTreeNoiseSampler(x, sigma_min, sigma_max, seed=current_iter_seeds)
+
     def initialize(self, p):
         self.p = p
         self.model_wrap_cfg.p = p

@@ -1,6 +1,5 @@
 """`KDiffusionSampler` -- mirror of modules/sd_samplers_kdiffusion.py (sampler table :14-34, `get_sigmas` :81-134,
-`sample` :196-244) over the native denoiser.  The torchsde-driven SDE family and DPM fast / adaptive are listed in the
-reference's table but not built here."""
+`sample` :196-244) over the native denoiser.  The whole table is built; the SDE family uses a native Brownian path instead of torchsde's."""
 import inspect
 
 import torch
@@ -13,7 +12,12 @@ from ..k_diffusion import sampling as kd_sampling
 
 samplers_k_diffusion = [
     ("DPM++ 2M", "sample_dpmpp_2m", ["k_dpmpp_2m"], {"scheduler": "karras"}),
+    ("DPM++ SDE", "sample_dpmpp_sde", ["k_dpmpp_sde"], {"scheduler": "karras", "second_order": True, "brownian_noise": True}),
+    ("DPM++ 2M SDE", "sample_dpmpp_2m_sde", ["k_dpmpp_2m_sde"], {"scheduler": "exponential", "brownian_noise": True}),
+    ("DPM++ 2M SDE Heun", "sample_dpmpp_2m_sde", ["k_dpmpp_2m_sde_heun"], {"scheduler": "exponential", "brownian_noise": True, "solver_type": "heun"}),
     ("DPM++ 2S a", "sample_dpmpp_2s_ancestral", ["k_dpmpp_2s_a"], {"scheduler": "karras", "uses_ensd": True, "second_order": True}),
+    ("DPM++ 3M SDE", "sample_dpmpp_3m_sde", ["k_dpmpp_3m_sde"], {"scheduler": "exponential", "discard_next_to_last_sigma": True,
+                                                                  "brownian_noise": True}),
     ("Euler a", "sample_euler_ancestral", ["k_euler_a", "k_euler_ancestral"], {"uses_ensd": True}),
     ("Euler", "sample_euler", ["k_euler"], {}),
     ("LMS", "sample_lms", ["k_lms"], {}),
@@ -21,18 +25,22 @@ samplers_k_diffusion = [
     ("DPM2", "sample_dpm_2", ["k_dpm_2"], {"scheduler": "karras", "discard_next_to_last_sigma": True, "second_order": True}),
     ("DPM2 a", "sample_dpm_2_ancestral", ["k_dpm_2_a"], {"scheduler": "karras", "discard_next_to_last_sigma": True, "uses_ensd": True,
                                                          "second_order": True}),
+    ("DPM fast", "sample_dpm_fast", ["k_dpm_fast"], {"uses_ensd": True}),
+    ("DPM adaptive", "sample_dpm_adaptive", ["k_dpm_ad"], {"uses_ensd": True}),
     ("Restart", sd_samplers_extra.restart_sampler, ["restart"], {"scheduler": "karras", "second_order": True}),
     ("HeunPP2", "sample_heunpp2", ["heunpp2"], {}),
     ("IPNDM", "sample_ipndm", ["ipndm"], {}),
     ("IPNDM_V", "sample_ipndm_v", ["ipndm_v"], {}),
     ("DEIS", "sample_deis", ["deis"], {}),
 ]
-# not built: the torchsde-driven family (DPM++ SDE, DPM++ 2M SDE (Heun), DPM++ 3M SDE) and DPM fast / adaptive (DPMSolver class)
+# the SDE family draws its noise from a native Brownian path (k_diffusion/sampling.py BatchedBrownianTree): the reference's comes from
+# torchsde.BrownianTree, whose value stream is torchsde's own, so those four match the reference in distribution, not bit for bit
 
 sampler_extra_params = {
     "sample_euler": ["s_churn", "s_tmin", "s_tmax", "s_noise"], "sample_heun": ["s_churn", "s_tmin", "s_tmax", "s_noise"],
-    "sample_dpm_2": ["s_churn", "s_tmin", "s_tmax", "s_noise"], "sample_dpm_2_ancestral": ["s_noise"],
-    "sample_dpmpp_2s_ancestral": ["s_noise"],
+    "sample_dpm_2": ["s_churn", "s_tmin", "s_tmax", "s_noise"], "sample_dpm_fast": ["s_noise"], "sample_dpm_2_ancestral": ["s_noise"],
+    "sample_dpmpp_2s_ancestral": ["s_noise"], "sample_dpmpp_sde": ["s_noise"], "sample_dpmpp_2m_sde": ["s_noise"],
+    "sample_dpmpp_3m_sde": ["s_noise"],
 }
 
 samplers_data_k_diffusion = [
@@ -119,6 +127,10 @@ class KDiffusionSampler(sd_samplers_common.Sampler):
             extra_params_kwargs["sigma_sched"] = sigma_sched
         if "sigmas" in parameters:
             extra_params_kwargs["sigmas"] = sigma_sched
+        if self.config.options.get("brownian_noise", False):
+            extra_params_kwargs["noise_sampler"] = self.create_noise_sampler(x, sigmas, p)
+        if self.config.options.get("solver_type", None) == "heun":
+            extra_params_kwargs["solver_type"] = "heun"
         self.model_wrap_cfg.init_latent = x
         self.last_latent = x
         self.sampler_extra_args = {"cond": conditioning, "image_cond": image_conditioning, "uncond": unconditional_conditioning,
@@ -139,8 +151,15 @@ class KDiffusionSampler(sd_samplers_common.Sampler):
         parameters = inspect.signature(self.func).parameters
         if "n" in parameters:
             extra_params_kwargs["n"] = steps
+        if "sigma_min" in parameters:
+            extra_params_kwargs["sigma_min"] = self.model_wrap.sigmas[0].item()
+            extra_params_kwargs["sigma_max"] = self.model_wrap.sigmas[-1].item()
         if "sigmas" in parameters:
             extra_params_kwargs["sigmas"] = sigmas
+        if self.config.options.get("brownian_noise", False):
+            extra_params_kwargs["noise_sampler"] = self.create_noise_sampler(x, sigmas, p)
+        if self.config.options.get("solver_type", None) == "heun":
+            extra_params_kwargs["solver_type"] = "heun"
         self.last_latent = x
         self.sampler_extra_args = {"cond": conditioning, "image_cond": image_conditioning, "uncond": unconditional_conditioning,
                                    "cond_scale": p.cfg_scale, "s_min_uncond": self.s_min_uncond}

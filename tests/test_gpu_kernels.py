@@ -315,6 +315,15 @@ def test_pack_cfg_sampler_kernels():
         for n in range(1, 9):
             want = sum(c * t.double() for c, t in zip(coefs[:n], srcs[:n])).float()
             torch.testing.assert_close(ops.lincomb(srcs[:n], coefs[:n]), want, rtol=1e-6, atol=1e-5)
+        if len(shape) == 4:
+            many = [torch.randn(*shape, generator=g).to(DEV) for _ in range(19)]
+            cf = [((-1) ** k) * (0.1 + 0.07 * k) for k in range(19)]
+            torch.testing.assert_close(ops.lincomb(many, cf), sum(c * t.double() for c, t in zip(cf, many)).float(), rtol=1e-5, atol=1e-5)
+            lo, hi, pv = srcs[0], srcs[0] + 0.01 * srcs[1], srcs[2]
+            delta = torch.maximum(torch.tensor(0.0078, device=DEV), 0.05 * torch.maximum(lo.abs(), pv.abs()))
+            want = float(torch.linalg.norm(((lo - hi) / delta).double()) / lo.numel() ** 0.5)
+            got = ops.error_norm(lo, hi, pv, 0.0078, 0.05)
+            assert abs(got - want) < 1e-5 * want and got == ops.error_norm(lo, hi, pv, 0.0078, 0.05)  # deterministic reduction
         acc = srcs[0].clone()
         ops.lincomb([acc, srcs[1]], [1.0, 2.0], out=acc)
         torch.testing.assert_close(acc, srcs[0] + 2.0 * srcs[1], rtol=1e-6, atol=1e-5)

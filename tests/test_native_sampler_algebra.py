@@ -33,6 +33,11 @@ def torch_kernels(monkeypatch):
     monkeypatch.setattr(hipops, "lincomb3", lincomb3)
     monkeypatch.setattr(hipops, "scale_f32", lambda x, s, out=None: x * s)
 
+    def error_norm(x_low, x_high, x_prev, atol, rtol):
+        delta = torch.maximum(torch.tensor(atol), torch.tensor(rtol) * torch.maximum(x_low.abs(), x_prev.abs()))
+        return float(torch.linalg.norm((x_low - x_high) / delta) / x_low.numel() ** 0.5)
+    monkeypatch.setattr(hipops, "error_norm", error_norm)
+
 
 def max_rel(a, b):
     return float((a - b).abs().max() / b.abs().max())
@@ -130,3 +135,46 @@ def test_unipc_host_algebra_all_variants(monkeypatch):
     finally:
         for k, v in saved.items():
             setattr(shared.opts, k, v)
+
+
+SDE_NATIVE = {"DPM++ SDE": kd.sample_dpmpp_sde, "DPM++ SDE eta0.5": kd.sample_dpmpp_sde, "DPM++ 2M SDE": kd.sample_dpmpp_2m_sde,
+              "DPM++ 2M SDE Heun": kd.sample_dpmpp_2m_sde, "DPM++ 2M SDE eta0": kd.sample_dpmpp_2m_sde, "DPM++ 3M SDE": kd.sample_dpmpp_3m_sde,
+              "DPM++ 3M SDE eta0": kd.sample_dpmpp_3m_sde}
+
+
+@pytest.mark.parametrize("label", list(SDE_NATIVE))
+def test_sde_family_host_algebra(label):
+    from oracle.make_golden import ListNoiseSampler
+    g = load_golden("samplers_sde_dpm.pt")
+    x0, noises = toy_inputs()
+    for steps in (5, 12):
+        ref = g[(label, steps)]
+        ns = ListNoiseSampler(noises)
+        got = SDE_NATIVE[label](toy_denoiser, x0 * ref["sigmas"][0], ref["sigmas"], noise_sampler=ns, disable=True, **ref["kw"])
+        assert max_rel(got, ref["latent"]) < 2e-5, (label, steps, max_rel(got, ref["latent"]))
+        assert len(ns.asked) == len(ref["asked"]) and all(abs(a[0] - b[0]) < 1e-4 * b[0] and abs(a[1] - b[1]) < 1e-4 * b[1]
+                                                          for a, b in zip(ns.asked, ref["asked"]))
+
+
+def test_dpm_solver_fast_and_adaptive_host_algebra(monkeypatch):
+    g = load_golden("samplers_sde_dpm.pt")
+    x0, noises = toy_inputs()
+    p = Predictor()
+    smin, smax = p.sigmas[0].item(), p.sigmas[-1].item()
+    for n in (5, 6, 7, 12):
+        for eta in (0.0, 0.6):
+            h = Seq(noises)
+            monkeypatch.setattr(kd, "torch", h)
+            got = kd.sample_dpm_fast(toy_denoiser, x0 * smax, smin, smax, n, disable=True, eta=eta)
+            monkeypatch.setattr(kd, "torch", torch)
+            ref = g[("DPM fast", n, eta)]
+            assert max_rel(got, ref["latent"]) < 2e-5 and h.i == ref["draws"], (n, eta)
+    for order in (2, 3):
+        for eta in (0.0, 0.6):
+            h = Seq(noises)
+            monkeypatch.setattr(kd, "torch", h)
+            got, info = kd.sample_dpm_adaptive(toy_denoiser, x0 * smax, smin, smax, disable=True, order=order, eta=eta, return_info=True)
+            monkeypatch.setattr(kd, "torch", torch)
+            ref = g[("DPM adaptive", order, eta)]
+            assert info == ref["info"], (order, eta, info, ref["info"])
+            assert max_rel(got, ref["latent"]) < 5e-5 and h.i == ref["draws"], (order, eta)

@@ -201,3 +201,43 @@ def test_oracle_unipc_vs_reference_classes():
     for steps in (6, 9):
         lat = pipeline.txt2img_latents_more(sd, cfg, c, uc, g["seeds"], g["hw"] * 8, g["hw"] * 8, steps, "UniPC")
         assert max_rel(lat, g[steps]["latent"]) < 5e-4, steps
+
+
+SDE_CASES = {"DPM++ SDE": osamp.sample_dpmpp_sde, "DPM++ SDE eta0.5": osamp.sample_dpmpp_sde, "DPM++ 2M SDE": osamp.sample_dpmpp_2m_sde,
+             "DPM++ 2M SDE Heun": osamp.sample_dpmpp_2m_sde, "DPM++ 2M SDE eta0": osamp.sample_dpmpp_2m_sde,
+             "DPM++ 3M SDE": osamp.sample_dpmpp_3m_sde, "DPM++ 3M SDE eta0": osamp.sample_dpmpp_3m_sde}
+
+
+@pytest.mark.parametrize("label", list(SDE_CASES))
+def test_oracle_sde_family_vs_reference_functions(label):
+    from oracle.make_golden import ListNoiseSampler
+    g = load_golden("samplers_sde_dpm.pt")
+    x0, noises = toy_inputs()
+    for steps in (5, 12):
+        ref = g[(label, steps)]
+        ns = ListNoiseSampler(noises)
+        got = SDE_CASES[label](toy_denoiser, x0 * ref["sigmas"][0], ref["sigmas"], ns, **ref["kw"])
+        assert max_rel(got, ref["latent"]) < 5e-6, (label, steps)
+        assert len(ns.asked) == len(ref["asked"]) and all(abs(a[0] - b[0]) < 1e-4 * b[0] and abs(a[1] - b[1]) < 1e-4 * b[1]
+                                                          for a, b in zip(ns.asked, ref["asked"])), (label, steps)
+
+
+def test_oracle_dpm_solver_fast_and_adaptive_vs_reference_functions():
+    g = load_golden("samplers_sde_dpm.pt")
+    x0, noises = toy_inputs()
+    p = Predictor()
+    smin, smax = p.sigmas[0].item(), p.sigmas[-1].item()
+    for n in (5, 6, 7, 12):
+        for eta in (0.0, 0.6):
+            it = iter(noises)
+            got = osamp.sample_dpm_fast(toy_denoiser, x0 * smax, smin, smax, n, lambda: next(it), eta=eta)
+            ref = g[("DPM fast", n, eta)]
+            assert max_rel(got, ref["latent"]) < 5e-6, (n, eta)
+            assert 64 - len(list(it)) == ref["draws"]
+    for order in (2, 3):
+        for eta in (0.0, 0.6):
+            it = iter(noises)
+            got, info = osamp.sample_dpm_adaptive(toy_denoiser, x0 * smax, smin, smax, lambda: next(it), order=order, eta=eta)
+            ref = g[("DPM adaptive", order, eta)]
+            assert {k: info[k] for k in ("steps", "n_accept", "n_reject")} == {k: ref["info"][k] for k in ("steps", "n_accept", "n_reject")}
+            assert max_rel(got, ref["latent"]) < 2e-5, (order, eta)
