@@ -210,6 +210,13 @@ int fmx_sampler_lincomb(const float* const* srcs, const float* coefs, int32_t n_
  * DPM-Solver (k_diffusion/sampling.py:531-532).  workspace: >= 256 floats of device memory.  Deterministic summation order. */
 int fmx_sampler_error_norm(const float* x_low, const float* x_high, const float* x_prev, float atol, float rtol, float* workspace,
                            float* out, int64_t n, void* stream);
+/* Separable linear resize of fp32 planes [planes][h][w] -> [planes][oh][ow]:
+ *   out[p][oy][ox] = sum_{a<ky} sum_{b<kx} yweights[oy][a] * xweights[ox][b] * in[p][ystart[oy] + a][xstart[ox] + b]
+ * (tables in device memory; ystart[oy] + ky <= h and xstart[ox] + kx <= w).  The hires-fix latent upscale, i.e. what
+ * torch.nn.functional.interpolate does at modules/processing.py:1459 for bilinear / bicubic / nearest(-exact), antialiased or not. */
+int fmx_resize_separable_f32(const float* in, float* out, const int32_t* ystart, const float* yweights, const int32_t* xstart,
+                             const float* xweights, int32_t planes, int32_t h, int32_t w, int32_t oh, int32_t ow, int32_t ky, int32_t kx,
+                             void* stream);
 int fmx_scale_f32(const float* x, float s, float* y, int64_t n, void* stream);
 /* out = a * a_mask + b * b_mask, fp32, elementwise over n (inpaint latent blending: modules/sd_samplers_cfg_denoiser.py:181,205
  * `x * nmask + noisy_init * mask`, `denoised * nmask + init_latent * mask`; processing.py:1866).  out may alias a or b. */

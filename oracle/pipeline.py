@@ -114,7 +114,7 @@ def setup_img2img_steps(steps, denoising_strength, fix_steps=False):
 
 @torch.no_grad()
 def img2img_latents(unet_sd, unet_cfg, cond, uncond, seeds, init_latent, steps, denoising_strength, sampler_name="Euler",
-                    cfg_scale=7.0, noise_source="CPU", mask=None, nmask=None, mask_noise=None):
+                    cfg_scale=7.0, noise_source="CPU", mask=None, nmask=None, mask_noise=None, fix_steps=False):
     """modules/processing.py:1843-1875 (Img2Img.sample) + modules/sd_samplers_kdiffusion.py:136-194 (sample_img2img:
     t_enc, sigma_sched = sigmas[steps - t_enc - 1:], xi = init + noise * sigma_sched[0], loop over sigma_sched) +
     modules/sd_samplers_cfg_denoiser.py:178-181, 204-213 (inpaint mask: noised original under the mask before the model,
@@ -122,7 +122,7 @@ def img2img_latents(unet_sd, unet_cfg, cond, uncond, seeds, init_latent, steps, 
     pred = Predictor()
     rng = ImageRNG(tuple(init_latent.shape[1:]), seeds, noise_source)
     noise = rng.next()
-    steps, t_enc = setup_img2img_steps(steps, denoising_strength)
+    steps, t_enc = setup_img2img_steps(steps, denoising_strength, fix_steps)
     sigmas = get_sigmas(pred, sampler_name, steps)
     sigma_sched = sigmas[steps - t_enc - 1:]
     xi = pred.noise_scaling(sigma_sched[0], noise, init_latent)
@@ -150,3 +150,19 @@ def img2img_latents(unet_sd, unet_cfg, cond, uncond, seeds, init_latent, steps, 
     if mask is not None:
         out = out * nmask + init_latent * mask  # processing.py:1865-1866
     return out, sigma_sched
+
+
+@torch.no_grad()
+def hires_latents(unet_sd, unet_cfg, cond, uncond, seeds, height, width, steps, hr_scale=2.0, mode="bilinear", antialias=False,
+                  denoising_strength=0.75, hr_second_pass_steps=0, hr_cfg=1.0, sampler_name="Euler", cfg_scale=7.0, hr_sampler_name=None):
+    """modules/processing.py:1342-1391 + :1430-1536 for a latent upscaler: first pass -> F.interpolate (:1459) -> noise from a NEW ImageRNG
+    with the same seeds (:1498-1499) -> sample_img2img with explicit steps (the `steps is not None` branch of setup_img2img_steps,
+    sd_samplers_common.py:25-29) at cond_scale = hr_cfg (sd_samplers_cfg_denoiser.py:189-190)."""
+    import torch.nn.functional as F
+    first, _ = txt2img_latents(unet_sd, unet_cfg, cond, uncond, seeds, height, width, steps, sampler_name=sampler_name, cfg_scale=cfg_scale)
+    size = (int(height * hr_scale) // 8, int(width * hr_scale) // 8)
+    kw = {"antialias": antialias} if mode in ("bilinear", "bicubic") else {}
+    up = F.interpolate(first, size=size, mode=mode, **kw)
+    out, _ = img2img_latents(unet_sd, unet_cfg, cond, uncond, seeds, up, hr_second_pass_steps or steps, denoising_strength,
+                             sampler_name=hr_sampler_name or sampler_name, cfg_scale=hr_cfg, fix_steps=True)
+    return first, up, out

@@ -241,6 +241,29 @@ __global__ void error_norm_final_kernel(const float* __restrict__ partial, int n
   }
 }
 
+// out[b][c][oy][ox] = sum_ky sum_kx yw[oy][ky] * xw[ox][kx] * in[b][c][ys[oy] + ky][xs[ox] + kx]  (hires-fix latent resize: every
+// interpolate mode of modules/shared.py:56-63 is separable with <= a handful of taps per axis when upscaling)
+__global__ void resize_separable_kernel(const float* __restrict__ in, float* __restrict__ out, const int* __restrict__ ys,
+                                        const float* __restrict__ yw, const int* __restrict__ xs, const float* __restrict__ xw, int planes,
+                                        int h, int w, int oh, int ow, int ky, int kx) {
+  const long total = (long)planes * oh * ow;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % ow);
+    const int oy = (int)((i / ow) % oh);
+    const long p = i / ((long)ow * oh);
+    const float* src = in + p * (long)h * w + (long)ys[oy] * w + xs[ox];
+    const float* wy = yw + (long)oy * ky;
+    const float* wx = xw + (long)ox * kx;
+    float acc = 0.f;
+    for (int a = 0; a < ky; ++a) {
+      float row = 0.f;
+      for (int b = 0; b < kx; ++b) row += wx[b] * src[(long)a * w + b];
+      acc += wy[a] * row;
+    }
+    out[i] = acc;
+  }
+}
+
 __global__ void scale_kernel(const float* __restrict__ x, float s, float* __restrict__ y, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = x[i] * s;
 }
@@ -412,6 +435,19 @@ extern "C" int fmx_sampler_error_norm(const float* x_low, const float* x_high, c
   FMX_LAUNCH_CHECK("fmx_sampler_error_norm (partial)");
   hipLaunchKernelGGL(error_norm_final_kernel, dim3(1), dim3(64), 0, st, workspace, ERRNORM_BLOCKS, 1.0f / (float)n, out);
   FMX_LAUNCH_CHECK("fmx_sampler_error_norm (final)");
+  return FMX_OK;
+}
+
+extern "C" int fmx_resize_separable_f32(const float* in, float* out, const int32_t* ystart, const float* yweights, const int32_t* xstart,
+                                        const float* xweights, int32_t planes, int32_t h, int32_t w, int32_t oh, int32_t ow, int32_t ky, int32_t kx,
+                                        void* stream) {
+  FMX_REQUIRE(in && out && ystart && yweights && xstart && xweights && planes > 0 && h > 0 && w > 0 && oh > 0 && ow > 0 && ky > 0 && kx > 0 &&
+                  ky <= h && kx <= w,
+              "resize_separable: bad args");
+  const long total = (long)planes * oh * ow;
+  hipLaunchKernelGGL(resize_separable_kernel, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream, in, out, ystart, yweights, xstart,
+                     xweights, planes, h, w, oh, ow, ky, kx);
+  FMX_LAUNCH_CHECK("fmx_resize_separable_f32");
   return FMX_OK;
 }
 

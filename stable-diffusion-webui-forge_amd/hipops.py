@@ -388,6 +388,22 @@ def error_norm(x_low, x_high, x_prev, atol, rtol):
     return float(ws[256])
 
 
+def resize_separable(x, ystart, yweights, xstart, xweights):
+    """x fp32 [..., H, W] -> [..., OH, OW] with per-axis (start, weights) tables (host or device tensors), see fmx.h."""
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    h, w = x.shape[-2:]
+    oh, ky = yweights.shape
+    ow, kx = xweights.shape
+    dev = x.device
+    ys, yw = ystart.to(device=dev, dtype=torch.int32).contiguous(), yweights.to(device=dev, dtype=torch.float32).contiguous()
+    xs, xw = xstart.to(device=dev, dtype=torch.int32).contiguous(), xweights.to(device=dev, dtype=torch.float32).contiguous()
+    out = torch.empty(x.shape[:-2] + (oh, ow), dtype=torch.float32, device=dev)
+    planes = x.numel() // (h * w)
+    _lib.check(_lib.lib().fmx_resize_separable_f32(_p(x), _p(out), _p(ys), _p(yw), _p(xs), _p(xw), planes, h, w, oh, ow, ky, kx, stream_ptr()),
+               "fmx_resize_separable_f32")
+    return out
+
+
 def scale_f32(x, s, out=None):
     if out is None:
         out = torch.empty_like(x)

@@ -56,7 +56,25 @@ class StableDiffusionProcessingTxt2Img:
     s_tmax: float = float("inf")
     s_noise: float = 1.0
     is_hr_pass: bool = False
+    # hires fix (processing.py:1187-1204); only the latent upscalers of shared.latent_upscale_modes are built (image-space upscalers are
+    # separate networks outside the path)
     enable_hr: bool = False
+    denoising_strength: float = 0.75
+    hr_scale: float = 2.0
+    hr_upscaler: Optional[str] = None
+    hr_second_pass_steps: int = 0
+    hr_resize_x: int = 0
+    hr_resize_y: int = 0
+    hr_sampler_name: Optional[str] = None
+    hr_scheduler: Optional[str] = None
+    hr_cfg: float = 1.0
+    hr_c: Any = None              # hires-pass conditioning (defaults to c / uc: `hr_prompt == ''` -> the first-pass prompt, :1554-1558)
+    hr_uc: Any = None
+    hr_upscale_to_x: int = 0
+    hr_upscale_to_y: int = 0
+    truncate_x: int = 0
+    truncate_y: int = 0
+    latent_scale_mode: Any = None
     do_decode: bool = True
     disable_progress: bool = True
     sampler_noise_scheduler_override: Any = None
@@ -73,13 +91,71 @@ class StableDiffusionProcessingTxt2Img:
         # processing.py:362-371 -- non-inpaint models get a dummy 1x1 zero conditioning
         return x.new_zeros(x.shape[0], 5, 1, 1)
 
+    def calculate_target_resolution(self):
+        """processing.py:1246-1273."""
+        if self.hr_resize_x == 0 and self.hr_resize_y == 0:
+            self.hr_upscale_to_x, self.hr_upscale_to_y = int(self.width * self.hr_scale), int(self.height * self.hr_scale)
+        elif self.hr_resize_y == 0:
+            self.hr_upscale_to_x, self.hr_upscale_to_y = self.hr_resize_x, self.hr_resize_x * self.height // self.width
+        elif self.hr_resize_x == 0:
+            self.hr_upscale_to_x, self.hr_upscale_to_y = self.hr_resize_y * self.width // self.height, self.hr_resize_y
+        else:
+            target_w, target_h = self.hr_resize_x, self.hr_resize_y
+            if self.width / self.height < self.hr_resize_x / self.hr_resize_y:
+                self.hr_upscale_to_x, self.hr_upscale_to_y = self.hr_resize_x, self.hr_resize_x * self.height // self.width
+            else:
+                self.hr_upscale_to_x, self.hr_upscale_to_y = self.hr_resize_y * self.width // self.height, self.hr_resize_y
+            self.truncate_x = (self.hr_upscale_to_x - target_w) // 8
+            self.truncate_y = (self.hr_upscale_to_y - target_h) // 8
+
+    def init_hr(self):
+        """processing.py:1275-1341, the part that decides anything: scheduler default, upscaler -> latent mode, target size."""
+        from . import latent_upscale
+        if self.hr_scheduler is None:
+            self.hr_scheduler = self.scheduler
+        modes = latent_upscale.latent_upscale_modes
+        self.latent_scale_mode = modes.get(self.hr_upscaler, None) if self.hr_upscaler is not None else modes[latent_upscale.latent_upscale_default_mode]
+        if self.latent_scale_mode is None:
+            raise NotImplementedError(f"hires upscaler '{self.hr_upscaler}': only the latent upscalers {list(modes)} are on the native path")
+        self.calculate_target_resolution()
+
     def sample(self, conditioning, unconditional_conditioning, seeds, subseeds=None, subseed_strength=0.0, prompts=None):
         self.sampler = sd_samplers.create_sampler(self.sampler_name, self.sd_model)
         x = self.rng.next()
         self.sd_model.forge_objects = self.sd_model.forge_objects_after_applying_lora.shallow_copy()
         samples = self.sampler.sample(self, x, conditioning, unconditional_conditioning,
                                       image_conditioning=self.txt2img_image_conditioning(x))
-        return samples
+        if not self.enable_hr:
+            return samples
+        return self.sample_hr_pass(samples, None, seeds, subseeds, subseed_strength, prompts)
+
+    def sample_hr_pass(self, samples, decoded_samples, seeds, subseeds=None, subseed_strength=0.0, prompts=None):
+        """processing.py:1430-1536 for the latent upscalers: resize the first-pass latent, fresh noise from a new ImageRNG with the same
+        seeds, img2img pass with the hires sampler / scheduler / CFG / conds.  Returns the hires LATENT (the reference returns it decoded,
+        :1531; here process_images_inner decodes it like any other sample)."""
+        from . import latent_upscale
+        if shared.state.interrupted:
+            return samples
+        self.is_hr_pass = True
+        try:
+            self.sampler = sd_samplers.create_sampler(self.hr_sampler_name or self.sampler_name, self.sd_model)
+            samples = latent_upscale.interpolate(samples.contiguous(), (self.hr_upscale_to_y // 8, self.hr_upscale_to_x // 8),
+                                                 mode=self.latent_scale_mode["mode"], antialias=self.latent_scale_mode["antialias"])
+            image_conditioning = self.txt2img_image_conditioning(samples)
+            ty, tx = self.truncate_y, self.truncate_x
+            samples = samples[:, :, ty // 2:samples.shape[2] - (ty + 1) // 2, tx // 2:samples.shape[3] - (tx + 1) // 2].contiguous()
+            self.rng = rng.ImageRNG(tuple(samples.shape[1:]), self.seeds, device=samples.device)
+            noise = self.rng.next()
+            lo = self.iteration * self.batch_size
+            hr_c = _slice_cond(self.hr_c, lo, lo + self.batch_size) if self.hr_c is not None else self._first_pass_conds[0]
+            hr_uc = _slice_cond(self.hr_uc, lo, lo + self.batch_size) if self.hr_uc is not None else self._first_pass_conds[1]
+            if self.hr_cfg == 1:
+                hr_uc = None  # :1586-1588
+            self.sd_model.forge_objects = self.sd_model.forge_objects_after_applying_lora.shallow_copy()
+            return self.sampler.sample_img2img(self, samples, noise, hr_c, hr_uc, steps=self.hr_second_pass_steps or self.steps,
+                                               image_conditioning=image_conditioning)
+        finally:
+            self.is_hr_pass = False
 
 
 @dataclass
@@ -158,12 +234,15 @@ def process_images_inner(p) -> Processed:
     shared.state.interrupted = False
     if isinstance(p, StableDiffusionProcessingImg2Img):
         p.init(p.all_seeds)
+    elif getattr(p, "enable_hr", False):
+        p.init_hr()
     for n in range(p.n_iter):
         p.iteration = n
         lo, hi = n * p.batch_size, (n + 1) * p.batch_size
         p.seeds = p.all_seeds[lo:hi]
         p.rng = rng.ImageRNG((lc, p.height // 8, p.width // 8), p.seeds, device=dev)
         c, uc = _slice_cond(p.c, lo, hi), _slice_cond(p.uc, lo, hi)
+        p._first_pass_conds = (c, uc)
         samples = p.sample(conditioning=c, unconditional_conditioning=uc, seeds=p.seeds)
         lat_all.append(samples)
         if not p.do_decode or p.sd_model.forge_objects.vae is None:

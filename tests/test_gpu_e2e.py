@@ -265,6 +265,42 @@ def test_sde_samplers_run_with_native_brownian_noise(sampler, engines):
     assert bool(torch.isfinite(a).all()) and float(a.std()) > 0.1
 
 
+def test_latent_resize_kernel_vs_torch_interpolate():
+    import torch.nn.functional as F
+    from forge_amd.modules import latent_upscale
+    torch.manual_seed(0)
+    for (h, w), out in (((16, 16), (32, 32)), ((13, 7), (29, 9)), ((64, 64), (96, 128)), ((32, 32), (24, 16)), ((128, 128), (256, 256))):
+        x = torch.randn(2, 4, h, w)
+        for name, m in latent_upscale.latent_upscale_modes.items():
+            kw = {"antialias": m["antialias"]} if m["mode"] in ("bilinear", "bicubic") else {}
+            want = F.interpolate(x, size=out, mode=m["mode"], **kw)
+            got = latent_upscale.interpolate(x.to(DEV), out, mode=m["mode"], antialias=m["antialias"])
+            torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("upscaler,hr_sampler,hr_cfg", [(None, None, 1.0), ("Latent (bicubic)", "DPM++ 2M", 5.0), ("Latent (nearest-exact)", None, 7.0),
+                                                        ("Latent (antialiased)", "Euler a", 3.0)])
+def test_hires_fix_latent_pass_vs_oracle(upscaler, hr_sampler, hr_cfg, engines):
+    """txt2img with enable_hr (processing.py:1342-1536, latent upscalers): first pass, latent resize kernel, fresh noise, img2img pass with
+    the hires sampler / steps / CFG -- against the oracle's restatement built from F.interpolate and the pinned sampler loops."""
+    from forge_amd.modules import latent_upscale
+    from oracle import pipeline
+    cfg = TINY["tiny_sd15"]
+    sd = synth.synth_unet_state_dict(cfg, seed=0)
+    c, uc = _conds(cfg, 2)
+    shared.opts.randn_source = "CPU"
+    p = processing.StableDiffusionProcessingTxt2Img(sd_model=engines["tiny_sd15"], c=c, uc=uc, seed=31, sampler_name="Euler", batch_size=2, steps=5,
+                                                    cfg_scale=7.0, width=96, height=128, do_decode=False, enable_hr=True, hr_scale=1.5,
+                                                    hr_upscaler=upscaler, hr_second_pass_steps=4, denoising_strength=0.6, hr_sampler_name=hr_sampler,
+                                                    hr_cfg=hr_cfg)
+    res = processing.process_images(p)
+    m = latent_upscale.latent_upscale_modes[upscaler or "Latent"]
+    _, _, want = pipeline.hires_latents(sd, cfg, c.cpu(), uc.cpu(), [31, 32], 128, 96, 5, hr_scale=1.5, mode=m["mode"], antialias=m["antialias"],
+                                        denoising_strength=0.6, hr_second_pass_steps=4, hr_cfg=hr_cfg, hr_sampler_name=hr_sampler)
+    assert tuple(res.latents.shape) == (2, 4, 24, 18)
+    report(f"hires fix ({upscaler or 'Latent'}, {hr_sampler or 'same sampler'}, hr_cfg {hr_cfg}) vs oracle", max_rel(res.latents, want), 1e-2)
+
+
 @pytest.mark.parametrize("scheduler", ["Uniform", "Karras", "Exponential", "Polyexponential", "SGM Uniform", "KL Optimal", "Align Your Steps",
                                        "Simple", "Normal", "DDIM", "Beta", "Turbo", "Align Your Steps GITS", "Align Your Steps 32"])
 def test_scheduler_choice_reaches_the_sampler(scheduler, engines):

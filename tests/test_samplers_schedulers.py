@@ -241,3 +241,43 @@ def test_oracle_dpm_solver_fast_and_adaptive_vs_reference_functions():
             ref = g[("DPM adaptive", order, eta)]
             assert {k: info[k] for k in ("steps", "n_accept", "n_reject")} == {k: ref["info"][k] for k in ("steps", "n_accept", "n_reject")}
             assert max_rel(got, ref["latent"]) < 2e-5, (order, eta)
+
+
+def test_latent_resize_tables_match_torch_interpolate():
+    """modules/latent_upscale.axis_table (host side of the hires-fix latent resize) applied as dense matrices == F.interpolate for every
+    mode of shared.latent_upscale_modes, up- and down-scaling, odd sizes (the tie-breaking of nearest-exact needs fp32 index arithmetic)."""
+    import torch.nn.functional as F
+    from forge_amd.modules.latent_upscale import axis_table, latent_upscale_modes
+
+    def apply(x, size, mode, aa):
+        mats = []
+        for n_in, n_out in ((x.shape[-2], size[0]), (x.shape[-1], size[1])):
+            st, wt = axis_table(n_in, n_out, mode, aa)
+            m = torch.zeros(n_out, n_in)
+            for o in range(n_out):
+                for k in range(wt.shape[1]):
+                    m[o, int(st[o]) + k] += wt[o, k]
+            mats.append(m)
+        return torch.einsum("oh,bchw,pw->bcop", mats[0], x, mats[1])
+    torch.manual_seed(0)
+    sizes = (((16, 16), (32, 32)), ((8, 12), (20, 18)), ((64, 64), (96, 128)), ((16, 24), (24, 36)), ((13, 7), (29, 9)), ((32, 32), (24, 16)),
+             ((20, 30), (7, 11)), ((16, 16), (16, 16)))
+    for (h, w), out in sizes:
+        x = torch.randn(2, 4, h, w)
+        for m in latent_upscale_modes.values():
+            kw = {"antialias": m["antialias"]} if m["mode"] in ("bilinear", "bicubic") else {}
+            want = F.interpolate(x, size=out, mode=m["mode"], **kw)
+            torch.testing.assert_close(apply(x, out, m["mode"], m["antialias"]), want, rtol=1e-5, atol=2e-5)
+
+
+def test_hires_target_resolution_rules():
+    from forge_amd.modules.processing import StableDiffusionProcessingTxt2Img as P
+    def res(**kw):
+        p = P(width=512, height=768, **kw)
+        p.calculate_target_resolution()
+        return p.hr_upscale_to_x, p.hr_upscale_to_y, p.truncate_x, p.truncate_y
+    assert res(hr_scale=1.5) == (768, 1152, 0, 0)
+    assert res(hr_resize_x=1024) == (1024, 1536, 0, 0)
+    assert res(hr_resize_y=1024) == (682, 1024, 0, 0)
+    assert res(hr_resize_x=1024, hr_resize_y=1024) == (1024, 1536, 0, 64)   # crop the long side: (1536 - 1024) // 8
+    assert res(hr_resize_x=640, hr_resize_y=1280) == (853, 1280, 26, 0)
