@@ -801,6 +801,43 @@ def gen_samplers_sde():
     torch.save(out, os.path.join(GOLD, "samplers_sde_dpm.pt"))
 
 
+def gen_unet_hooks(name, cfg, net, b=2, hw=16):
+    """Reference UNet forward with the hook set of oracle/hooks_fixture.py (direct call), and a 3-step Euler run through the reference
+    sampling_function with the same hooks installed on the patcher's model_options (exercises the per-call transformer_options keys)."""
+    from oracle.hooks_fixture import build_hooks
+    fx = torch.load(os.path.join(GOLD, f"{name}_unet_fwd.pt"))
+    to, log = build_hooks()
+    with torch.no_grad():
+        eps = net(fx["x"], fx["t"], context=fx["ctx"], y=fx["y"], transformer_options=to)
+    res = {"eps": eps, "log": list(log)}
+    ref = ref_import.load_reference()
+    pred = ref_import.build_ref_predictor()
+    adm = cfg.get("adm_in_channels")
+    c, uc = synth.synth_conditioning(b, cfg["context_dim"], adm, seed=1234)
+    if adm:
+        c, uc = ref_import.SdxlCond(c), ref_import.SdxlCond(uc)
+    seeds = [1000 + i for i in range(b)]
+    den = ref_import.RefDenoiser(net, pred, seeds)
+    to2, log2 = build_hooks(use_call_keys=True)
+    den.patcher.model_options["transformer_options"] = to2
+    rng = ImageRNG((cfg["in_channels"], hw, hw), seeds, "CPU")
+    x = rng.next()
+    sigmas = den.inner_model.get_sigmas(3)
+    x = pred.noise_scaling(sigmas[0], x, torch.zeros_like(x), max_denoise=False)
+    ref.kd_sampling.torch = _Hijack(rng)
+    ref.sampling_function.sampling_prepare(den.patcher, x=x)
+    try:
+        lat = ref.kd_sampling.sample_euler(den, x, sigmas, extra_args={"cond": c, "uncond": uc, "cond_scale": 7.0, "s_min_uncond": 0.0, "image_cond": None},
+                                           disable=True)
+    finally:
+        ref.kd_sampling.torch = torch
+        ref.sampling_function.sampling_cleanup(den.patcher)
+    res["euler3"] = {"latent": lat, "seeds": seeds, "hw": hw}
+    res["log_first_forward_of_run"] = log2[:len(log)]
+    torch.save(res, os.path.join(GOLD, f"{name}_unet_hooks.pt"))
+    print(name, "hooks:", len(log), "hook calls per forward; eps std", float(eps.std()), "euler3 std", float(lat.std()))
+
+
 def gen_schedulers():
     """modules/sd_schedulers.py's table, imported from the reference with a two-attribute stand-in for modules.shared."""
     import importlib.util
@@ -993,14 +1030,20 @@ def main():
         gen_img2img("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
         gen_lora("tiny_sd15", synth.TINY_SD15_UNET_CONFIG)
         gen_unet_control("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
+        gen_unet_hooks("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
         net, _ = gen_unet("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG)
         gen_samples("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG, net)
+        gen_unet_hooks("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG, net)
         gen_vae("tiny_vae", synth.TINY_VAE_CONFIG)
         gen_vae_encode("tiny_vae", synth.TINY_VAE_CONFIG)
     if a.only == "samplers":
         net, _ = gen_unet("tiny_sd15", synth.TINY_SD15_UNET_CONFIG)
         gen_samples_extra("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
         gen_samples_more("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
+    if a.only == "hooks":
+        for nm, cf in (("tiny_sd15", synth.TINY_SD15_UNET_CONFIG), ("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG)):
+            net, _ = gen_unet(nm, cf)
+            gen_unet_hooks(nm, cf, net)
     if a.only == "unipc":
         net, _ = gen_unet("tiny_sd15", synth.TINY_SD15_UNET_CONFIG)
         gen_unipc("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)

@@ -56,7 +56,7 @@ class KModel:
         t = self.predictor.timestep(torch.tensor(sig_host, dtype=torch.float32)).float()
         return t.repeat(reps)
 
-    def _forward_static(self, key, x, sigma_dev, sig_host, reps, ctxc, control=None):
+    def _forward_static(self, key, x, sigma_dev, sig_host, reps, ctxc, control=None, transformer_options=None):
         """pack -> UNet -> (returns eps view); static buffers per shape so the UNet can be graph-replayed."""
         b, c, hh, ww = x.shape
         bu = reps * b
@@ -72,8 +72,10 @@ class KModel:
         else:
             st["t"].copy_(tvals, non_blocking=False)
         net = self.diffusion_model
-        if not self.use_graph or control is not None:  # ControlNet residuals change every step: eager, not graph replay
-            return net.forward_packed(st["xcol"], st["t"], ctxc, bu, hh, ww, control)
+        hooks = net._hooks(transformer_options)
+        if not self.use_graph or control is not None or hooks is not None:
+            # ControlNet residuals change every step and Python hooks cannot be captured: eager, not graph replay
+            return net.forward_packed(st["xcol"], st["t"], ctxc, bu, hh, ww, control, hooks)
         g = self._graphs.get(key)
         if g is None:
             # eager warm-up (sizes the arena, creates lazily-built buffers), then capture on a side stream
@@ -107,11 +109,23 @@ class KModel:
         cur.wait_stream(s)
         return st["eps"]
 
-    def denoise_cfg(self, x, sigma, uncond_ctx, cond_ctx, cond_scale, want_parts=False):
+    def denoise_cfg(self, x, sigma, uncond_ctx, cond_ctx, cond_scale, want_parts=False, transformer_options=None):
         """Fused path: returns CFG-combined denoised (fp32 NCHW) [+ cond_pred, uncond_pred].
-        `uncond_ctx`/`cond_ctx`: (context [B,T,Dc], y or None); uncond_ctx None => cond_scale == 1 shortcut."""
+        `uncond_ctx`/`cond_ctx`: (context [B,T,Dc], y or None); uncond_ctx None => cond_scale == 1 shortcut.
+        `transformer_options` with Python hooks: completed with the per-call keys of sampling_function.py:253-257 and run eagerly."""
         b, c, hh, ww = x.shape
         reps = 1 if uncond_ctx is None else 2
+        if self.diffusion_model._hooks(transformer_options) is not None:
+            to = transformer_options.copy()
+            cond_or_uncond = [1, 0] if reps == 2 else [0]          # batch order [uncond ; cond] (sampling_function.py:187-229)
+            to["cond_or_uncond"] = cond_or_uncond[:]
+            to["sigmas"] = sigma
+            to["cond_mark"] = torch.tensor([float(cx) for cx in cond_or_uncond for _ in range(b)], dtype=sigma.dtype, device=sigma.device)
+            to["cond_indices"] = [i * b + j for i, cx in enumerate(cond_or_uncond) if cx == 0 for j in range(b)]
+            to["uncond_indices"] = [i * b + j for i, cx in enumerate(cond_or_uncond) if cx != 0 for j in range(b)]
+            transformer_options = to
+        else:
+            transformer_options = None
         sig_host = host_sigmas(sigma)
         if reps == 2:
             ctx = self._stack_ctx(uncond_ctx, cond_ctx)
@@ -119,7 +133,7 @@ class KModel:
             ctx = cond_ctx
         ctxc = self.diffusion_model.prepare_context(ctx[0], ctx[1])
         key = (b, c, hh, ww, reps)
-        eps = self._forward_static(key, x, sigma, sig_host, reps, ctxc)
+        eps = self._forward_static(key, x, sigma, sig_host, reps, ctxc, transformer_options=transformer_options)
         cond_pred = torch.empty_like(x) if want_parts else None
         uncond_pred = torch.empty_like(x) if want_parts else None
         den = ops.cfg_combine(eps, eps.shape[-1], x, sigma, reps, cond_scale, None, cond_pred, uncond_pred)
@@ -146,14 +160,11 @@ class KModel:
         """Reference signature (k_model.py:25): x fp32 [Bu,C,H,W], t = sigma [Bu] -> denoised fp32."""
         if c_concat is not None:
             raise NotImplementedError("c_concat (inpaint-model conditioning) is outside the built path")
-        to = transformer_options or {}
-        if to.get("patches") or to.get("patches_replace") or to.get("block_modifiers"):
-            raise NotImplementedError("transformer patches are not supported by the native executor")
         x = x.to(device=self.device, dtype=torch.float32).contiguous()
         sigma = t.to(device=self.device, dtype=torch.float32).contiguous()
         ctxc = self.diffusion_model.prepare_context(c_crossattn, y)
         b, c, hh, ww = x.shape
-        eps = self._forward_static((b, c, hh, ww, 1, "apply"), x, sigma, host_sigmas(t), 1, ctxc, control)
+        eps = self._forward_static((b, c, hh, ww, 1, "apply"), x, sigma, host_sigmas(t), 1, ctxc, control, transformer_options)
         return ops.cfg_combine(eps, eps.shape[-1], x, sigma, 1, 1.0)
 
 

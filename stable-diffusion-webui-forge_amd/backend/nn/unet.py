@@ -18,7 +18,7 @@ Differences from the reference that are design, not omissions:
 ControlNet residuals (`control={'input': [...], 'middle': [...], 'output': [...]}`, unet.py:44-52,714,732,739) are injected
 natively (fp32 NCHW residual -> fp16 NHWC activation, one transposing add kernel each); such forwards run eagerly, not from
 the captured graph, since the residuals change every step.  Hooks that need per-block Python callbacks on NCHW tensors
-(transformer patches, block modifiers, group_norm_wrapper) are rejected explicitly.
+(`patches`, `patches_replace`, `block_modifiers`) are called eagerly on [B, N, C] / NCHW views; module-typed hooks are rejected.
 """
 import math
 
@@ -207,6 +207,7 @@ class IntegratedUNet2DConditionModel:
             h1 = ops.silu(h1, out=h1)
             c.label = ops.linear(h1, *self.w["le2"], out=torch.empty(bu, self.layout.time_embed_dim, dtype=torch.float16, device=self.device))
         c.key, c.bu, c.tokens, c.tpad = key, bu, t, tp
+        c.ctx = ctx[:, :t]  # fp16 [Bu, T, Dc]: the `context` a transformer hook sees
         self._ctx_keepalive = (context, y)
         return c
 
@@ -278,7 +279,103 @@ class IntegratedUNet2DConditionModel:
         ops.linear(g, *self.w[b + ".ff2"], residual=h, out=h, ld_out=h.shape[1])
         arena.release(mk)
 
-    def _spatial_transformer(self, L, x, ctxc, arena):
+    # ---- per-block Python hooks (unet.py:186-279 `patches` / `patches_replace`): eager, general-shape path ----------------------------
+    def _attend(self, wq, wk, wv, H, d, xq, xk, xv):
+        """Attention with arbitrary query / key / value sources (what attn{1,2}_patch may hand back): xq [B, Nq, Cq], xk / xv [B, Nk, Ck]
+        fp16 -> [B*Nq, H*dp].  Keys / values are projected per image into zero-padded 64-key tiles, as the ragged self-attention path does."""
+        dp = _dpad(d)
+        hd = H * dp
+        B, nq = xq.shape[0], xq.shape[1]
+        nk = xk.shape[1]
+        nkp = -(-nk // 64) * 64
+        q = ops.linear(xq.reshape(B * nq, -1).to(torch.float16).contiguous(), wq)
+        kbuf = torch.zeros(B, nkp, hd, dtype=torch.float16, device=self.device)
+        vt = torch.zeros(hd, B * nkp, dtype=torch.float16, device=self.device)
+        for bi in range(B):
+            ops.linear(xk[bi].to(torch.float16).contiguous(), wk, out=kbuf[bi, :nk], ld_out=hd)
+            ops.conv_gemm(wv, xv[bi].to(torch.float16).contiguous(), nk, out=vt[:, bi * nkp:bi * nkp + nk], ld_out=B * nkp)
+        return ops.attention(q, kbuf, vt, batch=B, heads=H, nq=nq, nk=nk, nk_pad=nkp, dpad=dp, scale=d ** -0.5, q_bs=nq * hd, q_rs=hd,
+                             k_bs=nkp * hd, k_rs=hd, vt_bs=nkp, vt_hs=dp * B * nkp, vt_ds=B * nkp)
+
+    @staticmethod
+    def _unpad_heads(t2d, B, n, H, d, dp):
+        """[B*n, H*dp] (heads padded to the MFMA-friendly width) -> [B, n, H*d], the layout a replace-hook expects."""
+        return t2d.view(B, n, H, dp)[..., :d].reshape(B, n, H * d)
+
+    @staticmethod
+    def _pad_heads(t, H, d, dp):
+        B, n, _ = t.shape
+        out = torch.zeros(B, n, H, dp, dtype=torch.float16, device=t.device)
+        out[..., :d] = t.reshape(B, n, H, d).to(torch.float16)
+        return out.view(B * n, H * dp)
+
+    def _attn_block_hooked(self, b, L, h, bu, n, ctxc, arena, to):
+        """BasicTransformerBlock._forward (unet.py:183-279) with its hook points, on [Bu, N, C] fp16 tensors (h is updated in place)."""
+        H, d = L.heads, L.dim_head
+        dp = _dpad(d)
+        hd = H * dp
+        C_ = h.shape[1]
+        patches, replace = to.get("patches", {}), to.get("patches_replace", {})
+        extra = {k: v for k, v in to.items() if k not in ("patches", "patches_replace")}
+        extra["n_heads"], extra["dim_head"] = H, d
+        block, block_index = to.get("block", None), to.get("block_index", 0)
+        transformer_block = (block[0], block[1], block_index) if block is not None else None
+        wqk = self.w[b + ".attn1.qk"]
+
+        def sublayer(which, nrm, ctx_default, wq, wk, wv, wout):
+            context, value = ctx_default, None
+            if which + "_patch" in patches:
+                if context is None:
+                    context = nrm
+                value = context
+                for p in patches[which + "_patch"]:
+                    nrm, context, value = p(nrm, context, value, extra)
+            rep = replace.get(which, {})
+            key = transformer_block if transformer_block in rep else block
+            if context is None:
+                context = nrm
+            if value is None:
+                value = context
+            if key in rep:
+                B_, nq, nk = nrm.shape[0], nrm.shape[1], context.shape[1]
+                q = self._unpad_heads(ops.linear(nrm.reshape(B_ * nq, -1).to(torch.float16).contiguous(), wq), B_, nq, H, d, dp)
+                k = self._unpad_heads(ops.linear(context.reshape(B_ * nk, -1).to(torch.float16).contiguous(), wk), B_, nk, H, d, dp)
+                # the V weight is stored for the operand-swapped V^T GEMM; the same rows serve as a plain Linear weight
+                v = self._unpad_heads(ops.linear(value.reshape(B_ * nk, -1).to(torch.float16).contiguous(), wv), B_, nk, H, d, dp)
+                o = self._pad_heads(rep[key](q, k, v, extra), H, d, dp)
+            else:
+                o = self._attend(wq, wk, wv, H, d, nrm, context, value)
+            out = ops.linear(o, *wout).view(bu, -1, C_)
+            for p in patches.get(which + "_output_patch", []):
+                out = p(out, extra)
+            return out
+
+        hv = h.view(bu, n, C_)
+        n1 = ops.layernorm(h, *self.w[b + ".norm1"]).view(bu, n, C_)
+        hv += sublayer("attn1", n1, None, wqk[:hd], wqk[hd:], self.w[b + ".attn1.v"], self.w[b + ".attn1.out"]).to(torch.float16)
+        for p in patches.get("middle_patch", []):
+            r = p(hv, extra)
+            if r is not hv:
+                hv.copy_(r)
+        n2 = ops.layernorm(h, *self.w[b + ".norm2"]).view(bu, n, C_)
+        hv += sublayer("attn2", n2, ctxc.ctx, self.w[b + ".attn2.q"], self.w[b + ".attn2.k"], self.w[b + ".attn2.v"],
+                       self.w[b + ".attn2.out"]).to(torch.float16)
+        n3 = ops.layernorm(h, *self.w[b + ".norm3"])
+        fw, fb = self.w[b + ".ff1"]
+        g = ops.conv_gemm(n3, fw, fw.shape[0], bias=fb, act=ops.ACT_GEGLU)
+        ops.linear(g, *self.w[b + ".ff2"], residual=h, out=h, ld_out=h.shape[1])
+
+    @staticmethod
+    def _call_nchw(fn, h, *args):
+        """Run a UNet-level hook that expects NCHW on an NHWC fp16 activation: it gets a permuted VIEW (in-place edits land in h);
+        a new tensor coming back is converted to NHWC fp16."""
+        v = h.permute(0, 3, 1, 2)
+        r = fn(v, *args)
+        if r is v or (r.data_ptr() == h.data_ptr() and r.shape == v.shape and r.stride() == v.stride()):
+            return h
+        return r.permute(0, 2, 3, 1).to(torch.float16).contiguous()
+
+    def _spatial_transformer(self, L, x, ctxc, arena, to=None):
         k = L.key
         bu, hh, ww, c = x.shape
         n = hh * ww
@@ -287,19 +384,26 @@ class IntegratedUNet2DConditionModel:
         mk = arena.mark()
         g = ops.groupnorm(x, *self.w[k + ".norm"], 1e-6)
         h = ops.linear(g.view(-1, c), *self.w[k + ".proj_in"])  # 1x1 conv == Linear in NHWC
+        hooked = to is not None and (to.get("patches") or to.get("patches_replace"))
         for di in range(L.depth):
-            self._attn_block(f"{k}.transformer_blocks.{di}", L, h, bu, n, ctxc, arena)
+            if hooked:
+                to["block_index"] = di
+                self._attn_block_hooked(f"{k}.transformer_blocks.{di}", L, h, bu, n, ctxc, arena, to)
+            else:
+                self._attn_block(f"{k}.transformer_blocks.{di}", L, h, bu, n, ctxc, arena)
         ops.linear(h, *self.w[k + ".proj_out"], residual=x.view(-1, c), out=out.view(-1, c), ld_out=c)
         arena.release(mk)
         return out
 
-    def _run_block(self, blk, h, skip, emb_all, ctxc, arena, up_to=None):
+    def _run_block(self, blk, h, skip, emb_all, ctxc, arena, up_to=None, to=None):
         for L in blk:
             if isinstance(L, Res):
                 h = self._res(L, h, skip, emb_all, arena)
                 skip = None
             elif isinstance(L, SpatialT):
-                h = self._spatial_transformer(L, h, ctxc, arena)
+                h = self._spatial_transformer(L, h, ctxc, arena, to)
+                if to is not None and "transformer_index" in to:
+                    to["transformer_index"] += 1  # unet.py:82-84
             elif isinstance(L, Down):
                 bu, hh, ww, c = h.shape
                 h = ops.conv_gemm(h, self.w[L.key][0], c, kh=3, stride=2, pad=1, bias=self.w[L.key][1])
@@ -322,12 +426,22 @@ class IntegratedUNet2DConditionModel:
                 ops.add_control_(h, ctrl)
         return h
 
-    def _forward_impl(self, xcol, t, ctxc, bu, hh, ww, arena, control=None):
-        """xcol: [Bu*H*W, 64] im2col of the (scaled) input; t: [Bu] fp32 table indices.  -> eps [Bu*H*W, out_ch]"""
+    def _forward_impl(self, xcol, t, ctxc, bu, hh, ww, arena, control=None, to=None):
+        """xcol: [Bu*H*W, 64] im2col of the (scaled) input; t: [Bu] fp32 table indices.  -> eps [Bu*H*W, out_ch].
+        `to`: transformer_options with Python hooks (unet.py:696-763 hook points), or None on the fast path."""
         if control is not None:
             control = {k: list(v) for k, v in control.items()}
         lay = self.layout
-        te = lay.time_embed_dim
+        patches = to.get("patches", {}) if to is not None else {}
+        modifiers = to.get("block_modifiers", []) if to is not None else []
+        if to is not None:
+            to["original_shape"] = [bu, lay.in_channels, hh, ww]
+            to["transformer_index"] = 0
+
+        def modify(h, when):
+            for m in modifiers:
+                h = self._call_nchw(m, h, when, to)
+            return h
         t_emb = ops.timestep_embedding(t, lay.model_channels)
         e1 = ops.linear(t_emb, *self.w["te0"])
         e1 = ops.silu(e1, out=e1)
@@ -337,22 +451,59 @@ class IntegratedUNet2DConditionModel:
         hs = []
         h = None
         for bi, blk in enumerate(lay.input_blocks):
+            if to is not None:
+                to["block"] = ("input", bi)
             if bi == 0:
+                if modifiers:
+                    # the 'before' hook of block 0 sees the network input: the centre tap of the im2col rows (already fp16); re-packed after
+                    ci = lay.in_channels
+                    x_mod = modify(xcol.view(bu, hh, ww, -1)[..., 4 * ci:5 * ci].contiguous(), "before")
+                    xcol = ops.unet_pack_input(x_mod.permute(0, 3, 1, 2).float().contiguous(), torch.zeros(bu, dtype=torch.float32, device=self.device),
+                                               1, 1.0)
                 cw, cb = self.w[blk[0].key]
                 h = ops.linear(xcol, cw, cb).view(bu, hh, ww, lay.model_channels)
             else:
-                h = self._run_block(blk, h, None, emb_all, ctxc, arena)
+                h = modify(h, "before")
+                h = self._run_block(blk, h, None, emb_all, ctxc, arena, to=to)
             h = self._apply_control(h, control, "input")
+            h = modify(h, "after")
+            for p in patches.get("input_block_patch", []):
+                h = self._call_nchw(p, h, to)
             hs.append(h)
-        h = self._run_block(lay.middle, h, None, emb_all, ctxc, arena)
+            for p in patches.get("input_block_patch_after_skip", []):
+                h = self._call_nchw(p, h, to)
+        if to is not None:
+            to["block"] = ("middle", 0)
+        h = modify(h, "before")
+        h = self._run_block(lay.middle, h, None, emb_all, ctxc, arena, to=to)
         h = self._apply_control(h, control, "middle")
-        for blk in lay.output_blocks:
+        h = modify(h, "after")
+        for bi, blk in enumerate(lay.output_blocks):
+            if to is not None:
+                to["block"] = ("output", bi)
             skip = self._apply_control(hs.pop(), control, "output")
+            for p in patches.get("output_block_patch", []):
+                hv, sv = h.permute(0, 3, 1, 2), skip.permute(0, 3, 1, 2)
+                rh, rs = p(hv, sv, to)
+                h = h if rh is hv else rh.permute(0, 2, 3, 1).to(torch.float16).contiguous()
+                skip = skip if rs is sv else rs.permute(0, 2, 3, 1).to(torch.float16).contiguous()
             up_to = (hs[-1].shape[1], hs[-1].shape[2]) if hs else None
-            h = self._run_block(blk, h, skip, emb_all, ctxc, arena, up_to)
+            if modifiers:
+                # the reference hands block modifiers the CONCATENATED [h, skip] tensor (unet.py:741-748); the executor keeps the two
+                # halves separate (dual-input GroupNorm / conv), so it is materialised only when a modifier wants to see it
+                cat = modify(torch.cat([h, skip], dim=-1), "before")
+                h, skip = cat[..., :h.shape[-1]].contiguous(), cat[..., h.shape[-1]:].contiguous()
+            h = self._run_block(blk, h, skip, emb_all, ctxc, arena, up_to, to=to)
+            h = modify(h, "after")
+        if to is not None:
+            to["block"] = ("last", 0)
+        h = modify(h, "before")
         g = ops.groupnorm(h, *self.w["out.gn"], 1e-5, silu=True)
         oc = lay.out_channels
-        return ops.conv_gemm(g, self.w["out.conv"][0], oc, kh=3, pad=1, bias=self.w["out.conv"][1])
+        out = ops.conv_gemm(g, self.w["out.conv"][0], oc, kh=3, pad=1, bias=self.w["out.conv"][1])
+        if modifiers:
+            out = modify(out.view(bu, hh, ww, -1)[..., :oc].contiguous(), "after").reshape(bu * hh * ww, oc)
+        return out
 
     def _get_arena(self, bu, hh, ww):
         need = self._arena_bytes or max(1 << 28, 40 * bu * hh * ww * self.layout.model_channels * 2)
@@ -361,7 +512,7 @@ class IntegratedUNet2DConditionModel:
             self._arena = Arena(need, self.device)
         return self._arena
 
-    def forward_packed(self, xcol, t, ctxc, bu, hh, ww, control=None):
+    def forward_packed(self, xcol, t, ctxc, bu, hh, ww, control=None, transformer_options=None):
         """Hot-path entry (no layout conversion): returns eps as fp16 [Bu*H*W, out_channels] living in the arena
         (valid until the next forward)."""
         while True:
@@ -369,25 +520,35 @@ class IntegratedUNet2DConditionModel:
             arena.reset()
             try:
                 with arena:
-                    return self._forward_impl(xcol, t, ctxc, bu, hh, ww, arena, control)
+                    return self._forward_impl(xcol, t, ctxc, bu, hh, ww, arena, control, self._hooks(transformer_options))
             except ArenaOverflow:
                 torch.cuda.synchronize(self.device)
                 self._arena_bytes = arena.capacity * 2
                 self._arena = None
 
+    @staticmethod
+    def _hooks(transformer_options):
+        """-> the options dict if it carries Python hooks the executor has to call, else None (fast path).  Hooks whose contract is a
+        torch.nn.Module (block_inner_modifiers get `layer`, group_norm_wrapper gets the GroupNorm module) have no counterpart here."""
+        to = transformer_options
+        if not to:
+            return None
+        if to.get("block_inner_modifiers") or "group_norm_wrapper" in to:
+            raise NotImplementedError("block_inner_modifiers / group_norm_wrapper take torch.nn.Module arguments; the native executor has no "
+                                      "modules to hand them")
+        if to.get("patches") or to.get("patches_replace") or to.get("block_modifiers"):
+            return to
+        return None
+
     # reference-compatible signature (backend/nn/unet.py:696): NCHW in, NCHW out
     def forward(self, x, timesteps=None, context=None, y=None, control=None, transformer_options=None, **kwargs):
-        to = transformer_options or {}
-        if to.get("patches") or to.get("patches_replace") or to.get("block_modifiers") \
-                or to.get("block_inner_modifiers") or "group_norm_wrapper" in to:
-            raise NotImplementedError("per-block Python hooks are not supported by the native MI355X executor; run those jobs "
-                                      "through the PyTorch module path")
         assert (y is not None) == (self.num_classes is not None)
         bu, c, hh, ww = x.shape
         ctxc = self.prepare_context(context, y)
         ones = torch.zeros(bu, dtype=torch.float32, device=self.device)  # sigma = 0 -> scale 1/sqrt(0 + 1) = 1
         xcol = ops.unet_pack_input(x.to(device=self.device, dtype=torch.float32).contiguous(), ones, 1, 1.0)
-        eps = self.forward_packed(xcol, timesteps.to(device=self.device, dtype=torch.float32).contiguous(), ctxc, bu, hh, ww, control)
+        eps = self.forward_packed(xcol, timesteps.to(device=self.device, dtype=torch.float32).contiguous(), ctxc, bu, hh, ww, control,
+                                  transformer_options)
         return eps.view(bu, hh, ww, -1).permute(0, 3, 1, 2).to(x.dtype)
 
     __call__ = forward

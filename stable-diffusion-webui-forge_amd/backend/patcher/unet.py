@@ -24,7 +24,8 @@ class UnetPatcher:
 
     def clone(self):
         n = UnetPatcher(self.model, self.load_device, self.offload_device)
-        n.model_options = copy.deepcopy(self.model_options)
+        n.model_options = copy.copy(self.model_options)  # shallow, like ModelPatcher.clone (base.py:64-66): hooks are shared objects
+        n.model_options["transformer_options"] = dict(self.model_options.get("transformer_options", {}))
         return n
 
     def has_online_lora(self):
@@ -35,6 +36,68 @@ class UnetPatcher:
 
     def memory_required(self, input_shape):
         return self.model.memory_required(input_shape)
+
+    # ---- hook setters (backend/patcher/base.py:146-200, backend/patcher/unet.py:91-172) ------------------------------------------------
+    def append_transformer_option(self, k, v, ensure_uniqueness=False):
+        to = self.model_options.setdefault("transformer_options", {})
+        if k not in to:
+            to[k] = []
+        if ensure_uniqueness and v in to[k]:
+            return
+        to[k].append(v)
+
+    def set_transformer_option(self, k, v):
+        self.model_options.setdefault("transformer_options", {})[k] = v
+
+    def set_model_patch(self, patch, name):
+        to = self.model_options["transformer_options"]
+        if "patches" not in to:
+            to["patches"] = {}
+        to["patches"][name] = to["patches"].get(name, []) + [patch]
+
+    def set_model_patch_replace(self, patch, name, block_name, number, transformer_index=None):
+        to = self.model_options["transformer_options"].copy()
+        to["patches_replace"] = dict(to.get("patches_replace", {}))
+        to["patches_replace"][name] = dict(to["patches_replace"].get(name, {}))
+        block = (block_name, number, transformer_index) if transformer_index is not None else (block_name, number)
+        to["patches_replace"][name][block] = patch
+        self.model_options["transformer_options"] = to
+
+    def set_model_attn1_patch(self, patch):
+        self.set_model_patch(patch, "attn1_patch")
+
+    def set_model_attn2_patch(self, patch):
+        self.set_model_patch(patch, "attn2_patch")
+
+    def set_model_attn1_replace(self, patch, block_name, number, transformer_index=None):
+        self.set_model_patch_replace(patch, "attn1", block_name, number, transformer_index)
+
+    def set_model_attn2_replace(self, patch, block_name, number, transformer_index=None):
+        self.set_model_patch_replace(patch, "attn2", block_name, number, transformer_index)
+
+    def set_model_attn1_output_patch(self, patch):
+        self.set_model_patch(patch, "attn1_output_patch")
+
+    def set_model_attn2_output_patch(self, patch):
+        self.set_model_patch(patch, "attn2_output_patch")
+
+    def set_model_input_block_patch(self, patch):
+        self.set_model_patch(patch, "input_block_patch")
+
+    def set_model_input_block_patch_after_skip(self, patch):
+        self.set_model_patch(patch, "input_block_patch_after_skip")
+
+    def set_model_output_block_patch(self, patch):
+        self.set_model_patch(patch, "output_block_patch")
+
+    def add_block_modifier(self, modifier, ensure_uniqueness=False):
+        self.append_transformer_option("block_modifiers", modifier, ensure_uniqueness)
+
+    def set_model_replace_all(self, patch, target="attn1"):
+        for block_name in ["input", "middle", "output"]:
+            for number in range(16):
+                for transformer_index in range(16):
+                    self.set_model_patch_replace(patch, target, block_name, number, transformer_index)
 
     def set_model_unet_function_wrapper(self, wrapper):
         self.model_options["model_function_wrapper"] = wrapper  # rejected at sampling time (sampling_function.py)

@@ -5,8 +5,9 @@ The reference decides per step, from a free-memory query, whether cond and uncon
 on a 288 GB part they always do, so the batch is always [uncond ; cond] (the order the reference produces, :187-229)
 and the whole step -- input scaling, UNet, `x - eps*sigma`, area-weighted average (weights 1 over counts 1+1e-37) and
 `uncond + (cond - uncond) * cond_scale` -- runs as: one pack kernel, one UNet graph, one combine kernel.
-Features that would need several UNet calls per step (regional `area` conds, masks, per-cond timestep ranges,
-ControlNet, c_concat) are rejected explicitly.
+Python hooks in model_options['transformer_options'] (`patches`, `patches_replace`, `block_modifiers`) are handed to the UNet
+executor, which then runs eagerly.  Features that would need several UNet calls per step (regional `area` conds, masks, per-cond
+timestep ranges, c_concat) are rejected explicitly.
 """
 import math
 
@@ -36,16 +37,13 @@ def calc_cond_uncond_batch(model, cond, uncond, x_in, timestep, model_options, c
     per-half outputs only exist inside the combine kernel; both halves are still returned."""
     cctx = _single(cond, "cond")
     uctx = _single(uncond, "uncond") if uncond is not None else None
-    return model.denoise_cfg(x_in, timestep, uctx, cctx, cond_scale, want_parts=True)
+    return model.denoise_cfg(x_in, timestep, uctx, cctx, cond_scale, want_parts=True, transformer_options=model_options.get("transformer_options"))
 
 
 def sampling_function_inner(model, x, timestep, uncond, cond, cond_scale, model_options={}, seed=None, return_full=False):
     for k in _UNSUPPORTED_OPTS:
         if model_options.get(k):
             raise NotImplementedError(f"model_options['{k}'] is not supported by the native path")
-    to = model_options.get("transformer_options", {})
-    if to.get("patches") or to.get("patches_replace") or to.get("block_modifiers"):
-        raise NotImplementedError("transformer patches are not supported by the native path")
     if math.isclose(cond_scale, 1.0) and not model_options.get("disable_cfg1_optimization", False):
         uncond_ = None  # :295-298
     else:
