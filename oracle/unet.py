@@ -66,17 +66,52 @@ def cross_attention(sd, key, x, context, heads):
     return _lin(sd, key + ".to_out.0", attention(q, k, v, heads))
 
 
-def transformer_block(sd, key, x, context, heads):
-    # unet.py:183-279 without patches: three pre-LN residual sub-layers
-    x = x + cross_attention(sd, key + ".attn1", _ln(sd, key + ".norm1", x), None, heads)
-    x = x + cross_attention(sd, key + ".attn2", _ln(sd, key + ".norm2", x), context, heads)
+def _hooked_attention(sd, key, which, n, context, to, heads):
+    """One attention sub-layer with the hook points of unet.py:205-238 (attn1) / :244-274 (attn2): `<which>_patch` may replace
+    (query source, context, value source); `patches_replace[<which>]` keyed (block, id, block_index) or (block, id) takes over the
+    attention itself between the projections; `<which>_output_patch` post-processes."""
+    patches, replace = to.get("patches", {}), to.get("patches_replace", {})
+    extra = {k: v for k, v in to.items() if k not in ("patches", "patches_replace")}
+    extra["n_heads"], extra["dim_head"] = heads, n.shape[-1] // heads
+    value = None
+    if which + "_patch" in patches:
+        if context is None:
+            context = n
+        value = context
+        for p in patches[which + "_patch"]:
+            n, context, value = p(n, context, value, extra)
+    block = to.get("block")
+    tb = (block[0], block[1], to.get("block_index", 0)) if block is not None else None
+    rep = replace.get(which, {})
+    k_ = tb if tb in rep else block
+    context = n if context is None else context
+    value = context if value is None else value
+    q, k, v = _lin(sd, key + ".to_q", n), _lin(sd, key + ".to_k", context), _lin(sd, key + ".to_v", value)
+    o = rep[k_](q, k, v, extra) if k_ in rep else attention(q, k, v, heads)
+    n = _lin(sd, key + ".to_out.0", o)
+    for p in patches.get(which + "_output_patch", []):
+        n = p(n, extra)
+    return n
+
+
+def transformer_block(sd, key, x, context, heads, to=None):
+    # unet.py:183-279: three pre-LN residual sub-layers (+ the patch hooks when transformer_options carries any)
+    if to is not None and (to.get("patches") or to.get("patches_replace")):
+        x = x + _hooked_attention(sd, key + ".attn1", "attn1", _ln(sd, key + ".norm1", x), None, to, heads)
+        extra = {k: v for k, v in to.items() if k not in ("patches", "patches_replace")}
+        for p in to.get("patches", {}).get("middle_patch", []):
+            x = p(x, extra)
+        x = x + _hooked_attention(sd, key + ".attn2", "attn2", _ln(sd, key + ".norm2", x), context, to, heads)
+    else:
+        x = x + cross_attention(sd, key + ".attn1", _ln(sd, key + ".norm1", x), None, heads)
+        x = x + cross_attention(sd, key + ".attn2", _ln(sd, key + ".norm2", x), context, heads)
     h = _lin(sd, key + ".ff.net.0.proj", _ln(sd, key + ".norm3", x))
     a, gate = h.chunk(2, dim=-1)
     h = a * F.gelu(gate)  # exact erf GELU (unet.py:111)
     return x + _lin(sd, key + ".ff.net.2", h)
 
 
-def spatial_transformer(sd, key, x, context, heads):
+def spatial_transformer(sd, key, x, context, heads, to=None):
     # unet.py:308-327
     b, c, hh, ww = x.shape
     x_in = x
@@ -89,7 +124,9 @@ def spatial_transformer(sd, key, x, context, heads):
         x = _lin(sd, key + ".proj_in", x)
     d = 0
     while f"{key}.transformer_blocks.{d}.norm1.weight" in sd:
-        x = transformer_block(sd, f"{key}.transformer_blocks.{d}", x, context, heads)
+        if to is not None:
+            to["block_index"] = d
+        x = transformer_block(sd, f"{key}.transformer_blocks.{d}", x, context, heads, to)
         d += 1
     if use_linear:
         x = _lin(sd, key + ".proj_out", x)
@@ -104,7 +141,7 @@ def _heads_for(cfg, ch):
     return cfg["num_heads"] if nhc == -1 else ch // nhc
 
 
-def _run_block(sd, cfg, prefix, h, emb, context, output_shape=None):
+def _run_block(sd, cfg, prefix, h, emb, context, output_shape=None, to=None):
     """One TimestepEmbedSequential (unet.py:74-93): sub-layers prefix.0, prefix.1, ..."""
     j = 0
     while True:
@@ -112,7 +149,9 @@ def _run_block(sd, cfg, prefix, h, emb, context, output_shape=None):
         if key + ".in_layers.0.weight" in sd:
             h = resblock(sd, key, h, emb)
         elif key + ".norm.weight" in sd:
-            h = spatial_transformer(sd, key, h, context, _heads_for(cfg, h.shape[1]))
+            h = spatial_transformer(sd, key, h, context, _heads_for(cfg, h.shape[1]), to)
+            if to is not None and "transformer_index" in to:
+                to["transformer_index"] += 1
         elif key + ".op.weight" in sd:
             h = _conv(sd, key + ".op", h, stride=2)  # Downsample: conv3x3 stride 2 pad 1 (unet.py:367)
         elif key + ".conv.weight" in sd:
@@ -139,11 +178,27 @@ def _apply_control(h, control, name):
 
 
 @torch.no_grad()
-def unet_forward(sd, cfg, x, timesteps, context, y=None, control=None):
+def unet_forward(sd, cfg, x, timesteps, context, y=None, control=None, transformer_options=None):
     """x [B,C,H,W] fp32, timesteps [B] (table index as float), context [B,T,D], y [B,adm] or None -> eps.
-    control: {'input': [...], 'middle': [...], 'output': [...]} ControlNet residual lists (consumed from the end, unet.py:714,732,739)."""
+    control: {'input': [...], 'middle': [...], 'output': [...]} ControlNet residual lists (consumed from the end, unet.py:714,732,739).
+    transformer_options: the hook points of unet.py:696-763 (`block_modifiers`, `patches`: input_block_patch(_after_skip),
+    output_block_patch; the per-transformer-block ones are in transformer_block above)."""
     if control is not None:
         control = {k: list(v) for k, v in control.items()}
+    to = transformer_options
+    patches = to.get("patches", {}) if to else {}
+    mods = to.get("block_modifiers", []) if to else []
+    if to is not None:
+        to["original_shape"], to["transformer_index"] = list(x.shape), 0
+
+    def modify(h, when):
+        for m in mods:
+            h = m(h, when, to)
+        return h
+
+    def at(block):
+        if to is not None:
+            to["block"] = block
     mc = cfg["model_channels"]
     emb = _lin(sd, "time_embed.2", F.silu(_lin(sd, "time_embed.0", timestep_embedding(timesteps, mc))))
     if "label_emb.0.0.weight" in sd:
@@ -154,18 +209,35 @@ def unet_forward(sd, cfg, x, timesteps, context, y=None, control=None):
     i = 0
     while f"input_blocks.{i}.0.weight" in sd or any(
             f"input_blocks.{i}.0.{s}" in sd for s in ("in_layers.0.weight", "op.weight")):
-        h = _run_block(sd, cfg, f"input_blocks.{i}", h, emb, context)
+        at(("input", i))
+        h = modify(h, "before")
+        h = _run_block(sd, cfg, f"input_blocks.{i}", h, emb, context, to=to)
         h = _apply_control(h, control, "input")
+        h = modify(h, "after")
+        for p in patches.get("input_block_patch", []):
+            h = p(h, to)
         hs.append(h)
+        for p in patches.get("input_block_patch_after_skip", []):
+            h = p(h, to)
         i += 1
-    h = _run_block(sd, cfg, "middle_block", h, emb, context)
+    at(("middle", 0))
+    h = modify(h, "before")
+    h = _run_block(sd, cfg, "middle_block", h, emb, context, to=to)
     h = _apply_control(h, control, "middle")
+    h = modify(h, "after")
     i = 0
     while f"output_blocks.{i}.0.in_layers.0.weight" in sd:
+        at(("output", i))
         hsp = _apply_control(hs.pop(), control, "output")
+        for p in patches.get("output_block_patch", []):
+            h, hsp = p(h, hsp, to)
         h = torch.cat([h, hsp], dim=1)  # current first (unet.py:741)
         out_shape = hs[-1].shape if hs else None
-        h = _run_block(sd, cfg, f"output_blocks.{i}", h, emb, context, out_shape)
+        h = modify(h, "before")
+        h = _run_block(sd, cfg, f"output_blocks.{i}", h, emb, context, out_shape, to=to)
+        h = modify(h, "after")
         i += 1
+    at(("last", 0))
+    h = modify(h, "before")
     h = _conv(sd, "out.2", F.silu(_gn(sd, "out.0", h, 1e-5)))
-    return h
+    return modify(h, "after")

@@ -195,3 +195,17 @@ def test_clip_oracle_vs_transformers_fixture(name, cfg):
     if "pooled_projected" in g:
         _, pp = oclip.encode_with_transformers(sd, cfg, g["ids"], return_pooled=True, is_clip_l=False)
         assert max_rel(pp, g["pooled_projected"]) < 1e-5
+
+
+@pytest.mark.parametrize("name", list(TINY))
+def test_unet_hooks_restated(name):
+    """oracle/unet.py's hook points vs the reference UNet running the same hook functions (oracle/hooks_fixture.py): identical call
+    sequence (hook, block, block_index, transformer_index) and output."""
+    from oracle.hooks_fixture import build_hooks
+    cfg = TINY[name]
+    g, fx = load_golden(f"{name}_unet_hooks.pt"), load_golden(f"{name}_unet_fwd.pt")
+    sd = synth.synth_unet_state_dict(cfg, seed=0)
+    to, log = build_hooks()
+    eps = unet_forward(sd, cfg, fx["x"], fx["t"], fx["ctx"], fx["y"], transformer_options=to)
+    assert log == g["log"]
+    torch.testing.assert_close(eps, g["eps"], rtol=1e-4, atol=1e-5)
