@@ -171,6 +171,10 @@ int fmx_silu_f16(const void* x, void* y, int64_t n, void* stream);
 /* h[p][c] += ctrl[b][c][p'] : ControlNet residual injection (backend/nn/unet.py:44-52 `h += ctrl`).  h: fp16 NHWC [B*npix][C]
  * (the executor's activation layout), ctrl: fp32 NCHW [B][C][npix] as the ControlNet produces it. */
 int fmx_add_control_nchw(void* h, const float* ctrl, int32_t b, int32_t c, int64_t npix, void* stream);
+/* h[i] += alpha * c[i], h fp16, c fp16 (c_is_f32 == 0) or fp32, both contiguous in the SAME layout: ControlNet residuals that are already
+ * channels-last (the native ControlNet's outputs; `h += ctrl` of backend/nn/unet.py:44-52 with the `x *= strength` of
+ * patcher/controlnet.py:236 folded into alpha). */
+int fmx_add_scaled_f16(void* h, const void* c, int32_t c_is_f32, float alpha, int64_t n, void* stream);
 int fmx_cast_f32_to_f16(const float* x, void* y, int64_t n, void* stream);
 /* y = act(x), fp16, kind 0 = quick_gelu x*sigmoid(1.702x) (CLIP-L), 1 = exact erf GELU (CLIP-G) */
 int fmx_act_f16(const void* x, void* y, int64_t n, int32_t kind, void* stream);

@@ -1,0 +1,106 @@
+"""TEST INFRASTRUCTURE ONLY (CPU oracle).
+
+Restates the ControlNet side of the path in plain torch fp32:
+  backend/nn/cnets/cldm.py:229-254 `ControlNet.forward` (hint block -> trunk = UNet encoder with the hint added after the first conv ->
+  zero convs) on the LDM-keyed state dict, with oracle/unet.py's block walker;
+  backend/patcher/controlnet.py:79-146 compute_controlnet_weighting, :149-168 broadcast_image_to, :223-272 control_merge, :284-338 get_control
+  (previous-ControlNet chain, sigma range gate, hint resize 'nearest-exact' + centre crop, strength, global average pooling).
+Pinned against the reference's own classes in tests/golden/*_controlnet.pt (oracle/make_golden.py gen_controlnet)."""
+import torch
+import torch.nn.functional as F
+
+from .unet import _conv, _lin, _run_block, timestep_embedding
+
+
+@torch.no_grad()
+def controlnet_forward(sd, cfg, x, hint, timesteps, context, y=None):
+    mc = cfg["model_channels"]
+    emb = _lin(sd, "time_embed.2", F.silu(_lin(sd, "time_embed.0", timestep_embedding(timesteps, mc))))
+    g = hint
+    for i, stride in enumerate((1, 1, 2, 1, 2, 1, 2, 1)):  # cldm.py:109-125: conv, SiLU, conv, ... (no SiLU after the last)
+        g = _conv(sd, f"input_hint_block.{2 * i}", g if i == 0 else F.silu(g), stride=stride)
+    if "label_emb.0.0.weight" in sd:
+        emb = emb + _lin(sd, "label_emb.0.2", F.silu(_lin(sd, "label_emb.0.0", y)))
+    outs, h, i = [], x, 0
+    while f"zero_convs.{i}.0.weight" in sd:
+        h = _run_block(sd, cfg, f"input_blocks.{i}", h, emb, context)
+        if i == 0:
+            h = h + g
+        outs.append(_conv(sd, f"zero_convs.{i}.0", h, padding=0))
+        i += 1
+    h = _run_block(sd, cfg, "middle_block", h, emb, context)
+    outs.append(_conv(sd, "middle_block_out.0", h, padding=0))
+    return outs
+
+
+def adaptive_resize_nearest_exact_center(samples, width, height):
+    ow, oh = samples.shape[3], samples.shape[2]
+    oa, na = ow / oh, width / height
+    x = y = 0
+    if oa > na:
+        x = round((ow - ow * (na / oa)) / 2)
+    elif oa < na:
+        y = round((oh - oh * (oa / na)) / 2)
+    return F.interpolate(samples[:, :, y:oh - y, x:ow - x], size=(height, width), mode="nearest-exact")
+
+
+def broadcast_image_to(t, target, batched_number):
+    if t.shape[0] == 1:
+        return t
+    per = target // batched_number
+    t = t[:per]
+    if per > t.shape[0]:
+        t = torch.cat([t] * (per // t.shape[0]) + [t[:(per % t.shape[0])]], dim=0)
+    return t if t.shape[0] == target else torch.cat([t] * batched_number, dim=0)
+
+
+class Control:
+    """One link of the ControlNet chain (patcher/controlnet.py ControlNet + ControlBase state)."""
+
+    def __init__(self, sd, cfg, hint, strength=1.0, percent_range=(0.0, 1.0), global_average_pooling=False, previous=None, weighting=None):
+        self.sd, self.cfg, self.hint, self.strength, self.percent_range = sd, cfg, hint, strength, percent_range
+        self.gap, self.previous, self.weighting = global_average_pooling, previous, weighting or {}
+
+    def get_control(self, predictor, x_noisy, t, context, y, batched_number, to):
+        prev = self.previous.get_control(predictor, x_noisy, t, context, y, batched_number, to) if self.previous is not None else None
+        lo, hi = predictor.percent_to_sigma(self.percent_range[0]), predictor.percent_to_sigma(self.percent_range[1])
+        if t[0] > lo or t[0] < hi:
+            return prev
+        hint = adaptive_resize_nearest_exact_center(self.hint, x_noisy.shape[3] * 8, x_noisy.shape[2] * 8)
+        if hint.shape[0] != x_noisy.shape[0]:
+            hint = broadcast_image_to(hint, x_noisy.shape[0], batched_number)
+        outs = controlnet_forward(self.sd, self.cfg, predictor.calculate_input(t, x_noisy), hint, predictor.timestep(t).float(), context, y)
+        out = {"input": [], "middle": [], "output": []}
+        for i, x in enumerate(outs):
+            if self.gap:
+                x = torch.mean(x, dim=(2, 3), keepdim=True).repeat(1, 1, x.shape[2], x.shape[3])
+            out["middle" if i == len(outs) - 1 else "output"].append(x * self.strength)
+        out = self._weight(out, to)
+        if prev is not None:
+            for k in out:
+                for i, pv in enumerate(prev[k]):
+                    if i >= len(out[k]):
+                        out[k].append(pv)
+                    elif pv is not None:
+                        out[k][i] = pv if out[k][i] is None else out[k][i] + pv
+        return out
+
+    def _weight(self, control, to):
+        w = self.weighting
+        if not w:
+            return control
+        reps, sigmas, cond_mark = len(to["cond_or_uncond"]), to["sigmas"], to["cond_mark"]
+        frame = torch.tensor(list(w["frame"]) * reps).to(sigmas) if "frame" in w else 1.0
+        sig = torch.cat([w["sigma"](sigmas)] * reps) if "sigma" in w else 1.0
+        for k, v in control.items():
+            for i, s in enumerate(v):
+                pw = (w.get("positive", {}).get(k, []) + [1.0] * 99)[i] if "positive" in w else 1.0
+                nw = (w.get("negative", {}).get(k, []) + [1.0] * 99)[i] if "negative" in w else 1.0
+                final = (pw * (1.0 - cond_mark) + nw * cond_mark) * sig * frame
+                if "mask" in w:
+                    m = w["mask"]
+                    if m.shape[0] != 1 and s.shape[0] % m.shape[0] == 0:
+                        m = m.repeat(s.shape[0] // m.shape[0], 1, 1, 1)
+                    s = s * F.interpolate(m.to(s), size=s.shape[2:], mode="bilinear")
+                control[k][i] = s * final[:, None, None, None]
+        return control

@@ -36,6 +36,14 @@ class Predictor:
         lo, hi, w = t.floor().long(), t.ceil().long(), t.frac()
         return ((1 - w) * self.log_sigmas[lo] + w * self.log_sigmas[hi]).exp()
 
+    def percent_to_sigma(self, percent):
+        # k_prediction.py:161-167
+        if percent <= 0.0:
+            return 999999999.9
+        if percent >= 1.0:
+            return 0.0
+        return self.sigma(torch.tensor(1000.0 * (1.0 - percent))).item()
+
     def calculate_input(self, sigma, x):
         s = sigma.view(-1, *([1] * (x.ndim - 1)))
         return x / (s ** 2 + self.sigma_data ** 2) ** 0.5

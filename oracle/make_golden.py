@@ -838,6 +838,74 @@ def gen_unet_hooks(name, cfg, net, b=2, hw=16):
     print(name, "hooks:", len(log), "hook calls per forward; eps std", float(eps.std()), "euler3 std", float(lat.std()))
 
 
+def controlnet_case(cfg, b=2, hw=16):
+    """Deterministic ControlNet inputs shared by the generator and the tests: hint images (one at the exact 8x size, one that needs the
+    nearest-exact resize + centre crop), a mask, per-frame weights."""
+    g = torch.Generator().manual_seed(2024)
+    return {"hint_a": torch.rand(b, 3, hw * 8, hw * 8, generator=g), "hint_b": torch.rand(1, 3, hw * 6, hw * 10, generator=g),
+            "mask": torch.rand(b, 1, 24, 24, generator=g), "frame": [0.6, 1.3][:b],
+            "positive": {"output": [1.0, 0.9, 0.8, 1.1], "middle": [0.7]}, "negative": {"output": [0.5, 1.2], "middle": [1.4]}}
+
+
+def sigma_weight(s):
+    return (s / 14.6146) ** 0.5
+
+
+def gen_controlnet(name, cfg, net, b=2, hw=16):
+    """cldm.ControlNet forward (model level) and a 3-step Euler run through the reference sampling_function with a CHAIN of two reference
+    patcher-level ControlNets (strength, start / end percent, global average pooling, all five advanced weightings)."""
+    import importlib
+    ref = ref_import.load_reference()
+    cldm = importlib.import_module("backend.nn.cnets.cldm")
+    pc = importlib.import_module("backend.patcher.controlnet")
+    fx = torch.load(os.path.join(GOLD, f"{name}_unet_fwd.pt"))
+    case = controlnet_case(cfg, b, hw)
+    kw = {k: v for k, v in cfg.items() if k not in ("out_channels", "transformer_depth_output")}
+    kw["transformer_depth"] = list(kw["transformer_depth"])
+    models = []
+    for seed in (6, 9):
+        m = cldm.ControlNet(hint_channels=3, dtype=torch.float32, **kw)
+        sd = synth.synth_controlnet_state_dict(cfg, seed=seed)
+        missing, unexpected = m.load_state_dict(sd, strict=True), None
+        m.eval()
+        models.append(m)
+    with torch.no_grad():
+        outs = models[0](x=fx["x"], hint=case["hint_a"], timesteps=fx["t"], context=fx["ctx"], y=fx["y"])
+    res = {"outs_every_4th_channel": [o[:, ::4].clone() for o in outs], "hw": hw}  # all residuals, a quarter of the channels (fixture size)
+    pred = ref_import.build_ref_predictor()
+    adm = cfg.get("adm_in_channels")
+    c, uc = synth.synth_conditioning(b, cfg["context_dim"], adm, seed=1234)
+    if adm:
+        c, uc = ref_import.SdxlCond(c), ref_import.SdxlCond(uc)
+    seeds = [1000 + i for i in range(b)]
+    den = ref_import.RefDenoiser(net, pred, seeds)
+    cn_a = pc.ControlNet(models[0], load_device=torch.device("cpu"))
+    cn_b = pc.ControlNet(models[1], global_average_pooling=True, load_device=torch.device("cpu"))
+    unet = pc.apply_controlnet_advanced(den.patcher, cn_a, case["hint_a"], 0.8, 0.0, 0.7, positive_advanced_weighting=case["positive"],
+                                        negative_advanced_weighting=case["negative"], advanced_frame_weighting=case["frame"],
+                                        advanced_sigma_weighting=sigma_weight, advanced_mask_weighting=case["mask"])
+    unet = pc.apply_controlnet_advanced(unet, cn_b, case["hint_b"], 0.5, 0.2, 1.0)
+    den.patcher = unet
+    den.inner_model.inner_model.forge_objects.unet = unet
+    rng = ImageRNG((cfg["in_channels"], hw, hw), seeds, "CPU")
+    x = rng.next()
+    sigmas = den.inner_model.get_sigmas(4)
+    x = pred.noise_scaling(sigmas[0], x, torch.zeros_like(x), max_denoise=False)
+    ref.kd_sampling.torch = _Hijack(rng)
+    ref.sampling_function.sampling_prepare(unet, x=x)
+    try:
+        lat = ref.kd_sampling.sample_euler(den, x, sigmas, extra_args={"cond": c, "uncond": uc, "cond_scale": 7.0, "s_min_uncond": 0.0, "image_cond": None},
+                                           disable=True)
+    finally:
+        ref.kd_sampling.torch = torch
+        ref.sampling_function.sampling_cleanup(unet)
+    res["euler4"] = {"latent": lat, "seeds": seeds, "sigmas": sigmas}
+    # the same run without ControlNets, to show the chain matters
+    res["euler4_plain_std"] = float(lat.std())
+    torch.save(res, os.path.join(GOLD, f"{name}_controlnet.pt"))
+    print(name, "controlnet:", len(outs), "residuals; euler4 std", float(lat.std()))
+
+
 def gen_schedulers():
     """modules/sd_schedulers.py's table, imported from the reference with a two-attribute stand-in for modules.shared."""
     import importlib.util
@@ -1031,15 +1099,21 @@ def main():
         gen_lora("tiny_sd15", synth.TINY_SD15_UNET_CONFIG)
         gen_unet_control("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
         gen_unet_hooks("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
+        gen_controlnet("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
         net, _ = gen_unet("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG)
         gen_samples("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG, net)
         gen_unet_hooks("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG, net)
+        gen_controlnet("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG, net)
         gen_vae("tiny_vae", synth.TINY_VAE_CONFIG)
         gen_vae_encode("tiny_vae", synth.TINY_VAE_CONFIG)
     if a.only == "samplers":
         net, _ = gen_unet("tiny_sd15", synth.TINY_SD15_UNET_CONFIG)
         gen_samples_extra("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
         gen_samples_more("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
+    if a.only == "controlnet":
+        for nm, cf in (("tiny_sd15", synth.TINY_SD15_UNET_CONFIG), ("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG)):
+            net, _ = gen_unet(nm, cf)
+            gen_controlnet(nm, cf, net)
     if a.only == "hooks":
         for nm, cf in (("tiny_sd15", synth.TINY_SD15_UNET_CONFIG), ("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG)):
             net, _ = gen_unet(nm, cf)

@@ -166,3 +166,26 @@ def hires_latents(unet_sd, unet_cfg, cond, uncond, seeds, height, width, steps, 
     out, _ = img2img_latents(unet_sd, unet_cfg, cond, uncond, seeds, up, hr_second_pass_steps or steps, denoising_strength,
                              sampler_name=hr_sampler_name or sampler_name, cfg_scale=hr_cfg, fix_steps=True)
     return first, up, out
+
+
+@torch.no_grad()
+def txt2img_latents_controlnet(unet_sd, unet_cfg, cond, uncond, seeds, height, width, steps, chain, cfg_scale=7.0):
+    """Euler txt2img with a ControlNet chain (oracle.controlnet.Control) in the loop, as backend/sampling/sampling_function.py:220-268 wires it:
+    per call the stacked [uncond ; cond] batch goes through get_control, the residuals into the UNet forward."""
+    from .cfg import _cat, _ctx_y
+    pred = Predictor()
+    b = len(seeds)
+    rng = ImageRNG((unet_cfg["in_channels"], height // 8, width // 8), seeds, "CPU")
+    x = rng.next()
+    ctx, y = _ctx_y(_cat(uncond, cond))
+
+    def denoiser(xx, sigma):
+        x2, s2 = torch.cat([xx, xx]), torch.cat([sigma, sigma])
+        to = {"cond_or_uncond": [1, 0], "sigmas": sigma, "cond_mark": torch.tensor([1.0] * b + [0.0] * b)}
+        control = chain.get_control(pred, x2, s2, ctx, y, 2, to)
+        out = apply_model(lambda xc, t, c, yy: unet_forward(unet_sd, unet_cfg, xc, t, c, yy, control=control), pred, x2, s2, ctx, y)
+        un, co = out[:b], out[b:]
+        return un + (co - un) * cfg_scale
+    sigmas = get_sigmas(pred, "Euler", steps)
+    x = pred.noise_scaling(sigmas[0], x, torch.zeros_like(x))
+    return sampling.sample_euler(denoiser, x, sigmas, noise_fn=rng.next)

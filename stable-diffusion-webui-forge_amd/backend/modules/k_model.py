@@ -109,14 +109,14 @@ class KModel:
         cur.wait_stream(s)
         return st["eps"]
 
-    def denoise_cfg(self, x, sigma, uncond_ctx, cond_ctx, cond_scale, want_parts=False, transformer_options=None):
+    def denoise_cfg(self, x, sigma, uncond_ctx, cond_ctx, cond_scale, want_parts=False, transformer_options=None, control_model=None):
         """Fused path: returns CFG-combined denoised (fp32 NCHW) [+ cond_pred, uncond_pred].
         `uncond_ctx`/`cond_ctx`: (context [B,T,Dc], y or None); uncond_ctx None => cond_scale == 1 shortcut.
         `transformer_options` with Python hooks: completed with the per-call keys of sampling_function.py:253-257 and run eagerly."""
         b, c, hh, ww = x.shape
         reps = 1 if uncond_ctx is None else 2
-        if self.diffusion_model._hooks(transformer_options) is not None:
-            to = transformer_options.copy()
+        if self.diffusion_model._hooks(transformer_options) is not None or control_model is not None:
+            to = dict(transformer_options or {})
             cond_or_uncond = [1, 0] if reps == 2 else [0]          # batch order [uncond ; cond] (sampling_function.py:187-229)
             to["cond_or_uncond"] = cond_or_uncond[:]
             to["sigmas"] = sigma
@@ -126,6 +126,7 @@ class KModel:
             transformer_options = to
         else:
             transformer_options = None
+        per_call_options = transformer_options
         sig_host = host_sigmas(sigma)
         if reps == 2:
             ctx = self._stack_ctx(uncond_ctx, cond_ctx)
@@ -133,7 +134,17 @@ class KModel:
             ctx = cond_ctx
         ctxc = self.diffusion_model.prepare_context(ctx[0], ctx[1])
         key = (b, c, hh, ww, reps)
-        eps = self._forward_static(key, x, sigma, sig_host, reps, ctxc, transformer_options=transformer_options)
+        control = None
+        if control_model is not None:
+            # sampling_function.py:261-268: every ControlNet of the chain sees the per-call options, then one get_control on the stacked batch
+            p = control_model
+            while p is not None:
+                p.transformer_options = per_call_options
+                p = p.previous_controlnet
+            t_all = torch.cat([sigma] * reps)
+            t_all.fmx_sigma = SigmaInfo(list(sig_host) * reps)
+            control = control_model.get_control(torch.cat([x] * reps), t_all, {"c_crossattn": ctx[0], "y": ctx[1]}, reps)
+        eps = self._forward_static(key, x, sigma, sig_host, reps, ctxc, control=control, transformer_options=transformer_options)
         cond_pred = torch.empty_like(x) if want_parts else None
         uncond_pred = torch.empty_like(x) if want_parts else None
         den = ops.cfg_combine(eps, eps.shape[-1], x, sigma, reps, cond_scale, None, cond_pred, uncond_pred)

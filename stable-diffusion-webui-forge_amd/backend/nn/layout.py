@@ -79,14 +79,15 @@ def _heads(ch, num_heads, num_head_channels):
     return ch // num_head_channels, num_head_channels
 
 
-def unet_layout(cfg) -> UNetLayout:
-    """Enumerate blocks exactly as IntegratedUNet2DConditionModel.__init__ does (unet.py:540-694)."""
+def unet_layout(cfg, encoder_only=False) -> UNetLayout:
+    """Enumerate blocks exactly as IntegratedUNet2DConditionModel.__init__ does (unet.py:540-694).  encoder_only: input blocks +
+    middle block, the trunk of cldm.ControlNet (backend/nn/cnets/cldm.py:101-204: same enumeration, no decoder)."""
     mc = cfg["model_channels"]
     channel_mult = tuple(cfg.get("channel_mult", (1, 2, 4, 8)))
     nrb = cfg["num_res_blocks"]
     nrb = [nrb] * len(channel_mult) if isinstance(nrb, int) else list(nrb)
     td = list(cfg["transformer_depth"])
-    td_out = list(cfg["transformer_depth_output"])
+    td_out = list(cfg.get("transformer_depth_output") or []) if encoder_only else list(cfg["transformer_depth_output"])
     td_mid = cfg["transformer_depth_middle"]
     num_heads = cfg.get("num_heads", -1)
     nhc = cfg.get("num_head_channels", -1)
@@ -99,7 +100,7 @@ def unet_layout(cfg) -> UNetLayout:
     if num_classes not in (None, "sequential"):
         raise NotImplementedError("only num_classes None / 'sequential' (unet.py:524-538)")
 
-    lay = UNetLayout(in_channels=cfg["in_channels"], model_channels=mc, out_channels=cfg["out_channels"],
+    lay = UNetLayout(in_channels=cfg["in_channels"], model_channels=mc, out_channels=cfg.get("out_channels", cfg["in_channels"]),
                      time_embed_dim=mc * 4,
                      adm_in_channels=cfg.get("adm_in_channels") if num_classes == "sequential" else None,
                      context_dim=ctx)
@@ -127,6 +128,10 @@ def unet_layout(cfg) -> UNetLayout:
     if td_mid >= 0:
         lay.middle += [SpatialT("middle_block.1", ch, h, d, td_mid, ctx, use_linear),
                        Res("middle_block.2", ch, ch)]
+    lay.out_ch = ch
+    if encoder_only:
+        lay.zero_conv_channels = chans  # one zero conv per input block (cldm.py:108,166,190), + middle_block_out on `ch`
+        return lay
     idx = 0
     for level, mult in list(enumerate(channel_mult))[::-1]:
         for i in range(nrb[level] + 1):
@@ -147,8 +152,25 @@ def unet_layout(cfg) -> UNetLayout:
     return lay
 
 
-def unet_param_shapes(cfg) -> "OrderedDict[str, Tuple[int, ...]]":
-    lay = unet_layout(cfg)
+HINT_BLOCK = ((16, 1), (16, 1), (32, 2), (32, 1), (96, 2), (96, 1), (256, 2))  # (out channels, stride) of cldm.py:109-125, then -> model_channels
+
+
+def controlnet_param_shapes(cfg, hint_channels=3):
+    """cldm.ControlNet (backend/nn/cnets/cldm.py:74-207): the UNet encoder's keys + input_hint_block + zero_convs + middle_block_out."""
+    s = unet_param_shapes(cfg, encoder_only=True)
+    lay = unet_layout(cfg, encoder_only=True)
+    cin = hint_channels
+    for i, (cout, _) in enumerate(HINT_BLOCK + ((lay.model_channels, 1),)):
+        s[f"input_hint_block.{2 * i}.weight"], s[f"input_hint_block.{2 * i}.bias"] = (cout, cin, 3, 3), (cout,)
+        cin = cout
+    for i, c in enumerate(lay.zero_conv_channels):
+        s[f"zero_convs.{i}.0.weight"], s[f"zero_convs.{i}.0.bias"] = (c, c, 1, 1), (c,)
+    s["middle_block_out.0.weight"], s["middle_block_out.0.bias"] = (lay.out_ch, lay.out_ch, 1, 1), (lay.out_ch,)
+    return s
+
+
+def unet_param_shapes(cfg, encoder_only=False) -> "OrderedDict[str, Tuple[int, ...]]":
+    lay = unet_layout(cfg, encoder_only)
     s = OrderedDict()
     te = lay.time_embed_dim
 
@@ -207,6 +229,8 @@ def unet_param_shapes(cfg) -> "OrderedDict[str, Tuple[int, ...]]":
             conv(L.key + ".op", L.ch, L.ch, 3)
         elif isinstance(L, Up):
             conv(L.key + ".conv", L.ch, L.ch, 3)
+    if encoder_only:
+        return s
     norm("out.0", lay.out_ch)
     conv("out.2", lay.model_channels, lay.out_channels, 3)
     return s

@@ -76,9 +76,11 @@ class ContextCache:
 
 
 class IntegratedUNet2DConditionModel:
+    encoder_only = False  # cnets/cldm.py's ControlNet re-uses this executor for its trunk (input blocks + middle block)
+
     def __init__(self, config, state_dict, device="cuda", arena_bytes=None):
         self.config = dict(config)
-        self.layout = unet_layout(config)
+        self.layout = unet_layout(config, self.encoder_only)
         self.device = torch.device(device)
         self.dtype = torch.float16
         self.storage_dtype = self.computation_dtype = torch.float16
@@ -163,10 +165,15 @@ class IntegratedUNet2DConditionModel:
         w["emb_all"] = (torch.cat(emb_w, 0).contiguous(), torch.cat(emb_b, 0).contiguous())
         self._emb_off = emb_off
         self._emb_total = off
-        w["out.gn"] = (T("out.0.weight"), T("out.0.bias"))
-        w["out.conv"] = (_conv_w(sd["out.2.weight"].to(dev, torch.float16)), T("out.2.bias"))
+        if not self.encoder_only:
+            w["out.gn"] = (T("out.0.weight"), T("out.0.bias"))
+            w["out.conv"] = (_conv_w(sd["out.2.weight"].to(dev, torch.float16)), T("out.2.bias"))
         self.w = w
+        self._load_extra(sd, w)
         torch.cuda.synchronize(dev)
+
+    def _load_extra(self, sd, w):
+        pass
 
     # ------------------------------------------------------------------------------------------------------------
     # conditioning-only work (once per job)

@@ -1,0 +1,221 @@
+"""ControlNet at the patcher level -- mirror of backend/patcher/controlnet.py: `apply_controlnet_advanced` (:11-76),
+`compute_controlnet_weighting` (:79-146), `broadcast_image_to` (:149-168), `ControlBase` (:175-272: strength, start / end percent ->
+sigma range, linked list of previous ControlNets, `control_merge`), `ControlNet.get_control` (:275-338).  The control model underneath is
+the native backend/nn/cnets/cldm.ControlNet; T2I-Adapter and ControlLoRA (:341-586) are other networks, not built.
+
+Residuals stay fp16 and channels-last from the ControlNet's zero convs to the UNet's `h += ctrl` (the reference casts them to the
+latent's fp32, :238-239; the native UNet consumes fp16, so the cast would only be undone)."""
+import torch
+
+from ..misc import image_resize
+
+
+def apply_controlnet_advanced(unet, controlnet, image_bchw, strength, start_percent, end_percent, positive_advanced_weighting=None,
+                              negative_advanced_weighting=None, advanced_frame_weighting=None, advanced_sigma_weighting=None,
+                              advanced_mask_weighting=None):
+    """-> a clone of `unet` (UnetPatcher) with the ControlNet appended to its linked list.  Weighting arguments as in the reference:
+    per-injection-point weights for the cond / uncond halves, per-frame weights, a sigma -> weight function, a [B, 1, H, W] mask."""
+    cnet = controlnet.copy().set_cond_hint(image_bchw, strength, (start_percent, end_percent))
+    cnet.positive_advanced_weighting = positive_advanced_weighting
+    cnet.negative_advanced_weighting = negative_advanced_weighting
+    cnet.advanced_frame_weighting = advanced_frame_weighting
+    cnet.advanced_sigma_weighting = advanced_sigma_weighting
+    if advanced_mask_weighting is not None:
+        assert isinstance(advanced_mask_weighting, torch.Tensor)
+        B, C, H, W = advanced_mask_weighting.shape
+        assert B > 0 and C == 1 and H > 0 and W > 0
+    cnet.advanced_mask_weighting = advanced_mask_weighting
+    m = unet.clone()
+    m.add_patched_controlnet(cnet)
+    return m
+
+
+def get_at(array, index, default=None):
+    return array[index] if 0 <= index < len(array) else default
+
+
+def compute_controlnet_weighting(control, cnet):
+    pos = getattr(cnet, "positive_advanced_weighting", None)
+    neg = getattr(cnet, "negative_advanced_weighting", None)
+    frame = getattr(cnet, "advanced_frame_weighting", None)
+    sigma_fn = getattr(cnet, "advanced_sigma_weighting", None)
+    mask = getattr(cnet, "advanced_mask_weighting", None)
+    if pos is None and neg is None and frame is None and sigma_fn is None and mask is None:
+        return control
+    to = cnet.transformer_options
+    cond_or_uncond, sigmas, cond_mark = to["cond_or_uncond"], to["sigmas"], to["cond_mark"]
+    if frame is not None:
+        frame = torch.Tensor(frame * len(cond_or_uncond)).to(sigmas)
+        assert frame.shape[0] == cond_mark.shape[0], "Frame weighting list length is different from batch size!"
+    sigma_w = torch.cat([sigma_fn(sigmas)] * len(cond_or_uncond)) if sigma_fn is not None else None
+    for k, v in control.items():
+        for i in range(len(v)):
+            signal = control[k][i]
+            if not isinstance(signal, torch.Tensor):
+                continue
+            B, C, H, W = signal.shape
+            pw = get_at(pos.get(k, []), i, 1.0) if pos is not None else 1.0
+            nw = get_at(neg.get(k, []), i, 1.0) if neg is not None else 1.0
+            final = pw * (1.0 - cond_mark) + nw * cond_mark  # cond_mark is 1 on the uncond half
+            if sigma_w is not None:
+                final = final * sigma_w
+            if frame is not None:
+                final = final * frame
+            if isinstance(mask, torch.Tensor):
+                if mask.shape[0] != 1:
+                    k_ = int(signal.shape[0] // mask.shape[0])
+                    if signal.shape[0] == k_ * mask.shape[0]:
+                        mask = mask.repeat(k_, 1, 1, 1)
+                signal = signal * torch.nn.functional.interpolate(mask.to(signal), size=(H, W), mode="bilinear")
+            control[k][i] = signal * final.to(signal)[:, None, None, None]
+    return control
+
+
+def broadcast_image_to(tensor, target_batch_size, batched_number):
+    current = tensor.shape[0]
+    if current == 1:
+        return tensor
+    per_batch = target_batch_size // batched_number
+    tensor = tensor[:per_batch]
+    if per_batch > tensor.shape[0]:
+        tensor = torch.cat([tensor] * (per_batch // tensor.shape[0]) + [tensor[:(per_batch % tensor.shape[0])]], dim=0)
+    if tensor.shape[0] == target_batch_size:
+        return tensor
+    return torch.cat([tensor] * batched_number, dim=0)
+
+
+class ControlBase:
+    def __init__(self, device=None):
+        self.cond_hint_original = None
+        self.cond_hint = None
+        self.strength = 1.0
+        self.timestep_percent_range = (0.0, 1.0)
+        self.global_average_pooling = False
+        self.timestep_range = None
+        self.transformer_options = {}
+        self.device = device
+        self.previous_controlnet = None
+
+    def set_cond_hint(self, cond_hint, strength=1.0, timestep_percent_range=(0.0, 1.0)):
+        self.cond_hint_original = cond_hint
+        self.strength = strength
+        self.timestep_percent_range = timestep_percent_range
+        return self
+
+    def pre_run(self, model, percent_to_timestep_function):
+        self.timestep_range = (percent_to_timestep_function(self.timestep_percent_range[0]),
+                               percent_to_timestep_function(self.timestep_percent_range[1]))
+        if self.previous_controlnet is not None:
+            self.previous_controlnet.pre_run(model, percent_to_timestep_function)
+
+    def set_previous_controlnet(self, controlnet):
+        self.previous_controlnet = controlnet
+        return self
+
+    def cleanup(self):
+        if self.previous_controlnet is not None:
+            self.previous_controlnet.cleanup()
+        self.cond_hint = None
+        self.timestep_range = None
+
+    def get_models(self):
+        return self.previous_controlnet.get_models() if self.previous_controlnet is not None else []
+
+    def copy_to(self, c):
+        c.cond_hint_original = self.cond_hint_original
+        c.strength = self.strength
+        c.timestep_percent_range = self.timestep_percent_range
+        c.global_average_pooling = self.global_average_pooling
+
+    def inference_memory_requirements(self, dtype):
+        return self.previous_controlnet.inference_memory_requirements(dtype) if self.previous_controlnet is not None else 0
+
+    def control_merge(self, control_input, control_output, control_prev, output_dtype):
+        out = {"input": [], "middle": [], "output": []}
+        if control_input is not None:
+            for x in control_input:
+                if x is not None and self.strength != 1.0:
+                    x *= self.strength
+                out["input"].insert(0, x)
+        if control_output is not None:
+            for i, x in enumerate(control_output):
+                key = "middle" if i == len(control_output) - 1 else "output"
+                if x is not None:
+                    if self.global_average_pooling:
+                        x = torch.mean(x, dim=(2, 3), keepdim=True).repeat(1, 1, x.shape[2], x.shape[3])
+                    if self.strength != 1.0:
+                        x *= self.strength
+                out[key].append(x)
+        out = compute_controlnet_weighting(out, self)
+        if control_prev is not None:
+            for name in ["input", "middle", "output"]:
+                o = out[name]
+                for i, prev_val in enumerate(control_prev[name]):
+                    if i >= len(o):
+                        o.append(prev_val)
+                    elif prev_val is not None:
+                        if o[i] is None:
+                            o[i] = prev_val
+                        elif o[i].shape[0] < prev_val.shape[0]:
+                            o[i] = prev_val + o[i]
+                        else:
+                            o[i] += prev_val
+        return out
+
+
+class ControlNet(ControlBase):
+    def __init__(self, control_model, global_average_pooling=False, device=None, load_device=None, manual_cast_dtype=None):
+        super().__init__(device if device is not None else getattr(control_model, "device", None))
+        self.control_model = control_model
+        self.load_device = load_device
+        self.global_average_pooling = global_average_pooling
+        self.model_sampling_current = None
+        self.manual_cast_dtype = manual_cast_dtype
+
+    def get_control(self, x_noisy, t, cond, batched_number):
+        """x_noisy fp32 [Bu, C, h, w] (NOT yet input-scaled), t = sigma [Bu], cond {'c_crossattn', 'y'} -> {'input', 'middle', 'output'}."""
+        to = self.transformer_options
+        for modifier in to.get("controlnet_conditioning_modifiers", []):
+            x_noisy, t, cond, batched_number = modifier(self, x_noisy, t, cond, batched_number)
+        control_prev = None
+        if self.previous_controlnet is not None:
+            control_prev = self.previous_controlnet.get_control(x_noisy, t, cond, batched_number)
+        t0 = t.fmx_sigma.host[0] if hasattr(t, "fmx_sigma") else float(t[0])
+        if self.timestep_range is not None:
+            if t0 > self.timestep_range[0] or t0 < self.timestep_range[1]:
+                return control_prev
+        if self.cond_hint is None or x_noisy.shape[2] * 8 != self.cond_hint.shape[2] or x_noisy.shape[3] * 8 != self.cond_hint.shape[3]:
+            self.cond_hint = image_resize.adaptive_resize(self.cond_hint_original.to(x_noisy.device), x_noisy.shape[3] * 8, x_noisy.shape[2] * 8,
+                                                          "nearest-exact", "center")
+        if x_noisy.shape[0] != self.cond_hint.shape[0]:
+            self.cond_hint = broadcast_image_to(self.cond_hint, x_noisy.shape[0], batched_number)
+        context, y = cond["c_crossattn"], cond.get("y", None)
+        predictor = self.model_sampling_current
+        sig = t.fmx_sigma.host if hasattr(t, "fmx_sigma") else t.detach().float().cpu().tolist()
+        sig = list(sig) * (x_noisy.shape[0] // len(sig))
+        timestep = predictor.timestep(torch.tensor(sig, dtype=torch.float32)).float()
+        scale = torch.tensor([1.0 / (s ** 2 + predictor.sigma_data ** 2) ** 0.5 for s in sig], dtype=torch.float32, device=x_noisy.device)
+        x_in = x_noisy * scale[:, None, None, None]  # predictor.calculate_input (k_prediction.py:78-79)
+        wrapper = to.get("controlnet_model_function_wrapper", None)
+        if wrapper is not None:
+            control = wrapper(x=x_in, hint=self.cond_hint, timesteps=timestep, context=context, y=y, model=self, inner_model=self.control_model)
+        else:
+            control = self.control_model(x=x_in, hint=self.cond_hint, timesteps=timestep, context=context, y=y)
+        return self.control_merge(None, control, control_prev, x_noisy.dtype)
+
+    def copy(self):
+        c = ControlNet(self.control_model, global_average_pooling=self.global_average_pooling, load_device=self.load_device,
+                       manual_cast_dtype=self.manual_cast_dtype)
+        self.copy_to(c)
+        return c
+
+    def get_models(self):
+        return super().get_models() + [self.control_model]
+
+    def pre_run(self, model, percent_to_timestep_function):
+        super().pre_run(model, percent_to_timestep_function)
+        self.model_sampling_current = model.predictor
+
+    def cleanup(self):
+        self.model_sampling_current = None
+        super().cleanup()

@@ -26,13 +26,23 @@ class UnetPatcher:
         n = UnetPatcher(self.model, self.load_device, self.offload_device)
         n.model_options = copy.copy(self.model_options)  # shallow, like ModelPatcher.clone (base.py:64-66): hooks are shared objects
         n.model_options["transformer_options"] = dict(self.model_options.get("transformer_options", {}))
+        n.controlnet_linked_list = self.controlnet_linked_list
+        n.extra_concat_condition = self.extra_concat_condition
         return n
 
     def has_online_lora(self):
         return False
 
+    def add_patched_controlnet(self, cnet):
+        cnet.set_previous_controlnet(self.controlnet_linked_list)  # patcher/unet.py:68-71
+        self.controlnet_linked_list = cnet
+
     def list_controlnets(self):
-        return []
+        results, pointer = [], self.controlnet_linked_list
+        while pointer is not None:
+            results.append(pointer)
+            pointer = pointer.previous_controlnet
+        return results
 
     def memory_required(self, input_shape):
         return self.model.memory_required(input_shape)

@@ -23,7 +23,7 @@ def _single(conds, what):
     if len(conds) != 1:
         raise NotImplementedError(f"{what}: composable / AND prompts need several UNet passes per step; not on the native path")
     c = conds[0]
-    for k in ("area", "mask", "timestep_start", "timestep_end", "control"):
+    for k in ("area", "mask", "timestep_start", "timestep_end"):
         if k in c:
             raise NotImplementedError(f"{what}: '{k}' conditioning is not supported by the native path")
     if not math.isclose(c.get("strength", 1.0), 1.0):
@@ -37,7 +37,8 @@ def calc_cond_uncond_batch(model, cond, uncond, x_in, timestep, model_options, c
     per-half outputs only exist inside the combine kernel; both halves are still returned."""
     cctx = _single(cond, "cond")
     uctx = _single(uncond, "uncond") if uncond is not None else None
-    return model.denoise_cfg(x_in, timestep, uctx, cctx, cond_scale, want_parts=True, transformer_options=model_options.get("transformer_options"))
+    return model.denoise_cfg(x_in, timestep, uctx, cctx, cond_scale, want_parts=True, transformer_options=model_options.get("transformer_options"),
+                             control_model=cond[0].get("control"))
 
 
 def sampling_function_inner(model, x, timestep, uncond, cond, cond_scale, model_options={}, seed=None, return_full=False):
@@ -58,22 +59,33 @@ def sampling_function(self, denoiser_params, cond_scale, cond_composition):
     """Same signature as the reference (:325): `self` is the CFGDenoiser."""
     unet_patcher = self.inner_model.inner_model.forge_objects.unet
     model = unet_patcher.model
-    if unet_patcher.controlnet_linked_list is not None or unet_patcher.extra_concat_condition is not None:
-        raise NotImplementedError("ControlNet / concat conditioning are outside the native hot path")
+    control = unet_patcher.controlnet_linked_list
+    if unet_patcher.extra_concat_condition is not None:
+        raise NotImplementedError("concat conditioning is outside the native hot path")
     if isinstance(denoiser_params.image_cond, torch.Tensor) and denoiser_params.image_cond.shape[1:] == denoiser_params.x.shape[1:] \
             and float(denoiser_params.image_cond.abs().max()) != 0.0:
         raise NotImplementedError("inpainting-model image conditioning is outside the native hot path")
     x, timestep = denoiser_params.x, denoiser_params.sigma
     uncond = compile_conditions(denoiser_params.text_uncond)
     cond = compile_weighted_conditions(denoiser_params.text_cond, cond_composition)
+    if control is not None:  # :352-357
+        for h in cond:
+            h["control"] = control
+        if uncond is not None:
+            for h in uncond:
+                h["control"] = control
     return sampling_function_inner(model, x, timestep, uncond, cond, cond_scale, unet_patcher.model_options,
                                    self.p.seeds[0], return_full=True)
 
 
 def sampling_prepare(unet, x):
-    """:366-399 is VRAM juggling (load_models_gpu); weights are resident here.  Kept for call-surface parity."""
-    return
+    """:366-399: the VRAM juggling (load_models_gpu) has nothing to do here -- weights are resident; what remains is handing every
+    ControlNet the predictor and its sigma range (:393-397)."""
+    real_model = unet.model
+    for cnet in unet.list_controlnets():
+        cnet.pre_run(real_model, lambda p: real_model.predictor.percent_to_sigma(p))
 
 
 def sampling_cleanup(unet):
-    return
+    for cnet in unet.list_controlnets():
+        cnet.cleanup()

@@ -264,6 +264,29 @@ __global__ void resize_separable_kernel(const float* __restrict__ in, float* __r
   }
 }
 
+// h += alpha * c, same (NHWC) layout: ControlNet residuals that already live channels-last (the native ControlNet's outputs)
+template <typename T>
+__global__ void add_scaled_kernel(f16* __restrict__ h, const T* __restrict__ c, float alpha, long n) {
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += (long)gridDim.x * blockDim.x * 8) {
+    if (i + 8 <= n) {
+      f16 hv[8];
+      *reinterpret_cast<uint4*>(hv) = *reinterpret_cast<const uint4*>(h + i);
+      T cv[8];
+      if constexpr (sizeof(T) == 2) {
+        *reinterpret_cast<uint4*>(cv) = *reinterpret_cast<const uint4*>(c + i);
+      } else {
+        *reinterpret_cast<uint4*>(cv) = *reinterpret_cast<const uint4*>(c + i);
+        *reinterpret_cast<uint4*>(cv + 4) = *reinterpret_cast<const uint4*>(c + i + 4);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) hv[k] = (f16)((float)hv[k] + alpha * (float)cv[k]);
+      *reinterpret_cast<uint4*>(h + i) = *reinterpret_cast<const uint4*>(hv);
+    } else {
+      for (long j = i; j < n; ++j) h[j] = (f16)((float)h[j] + alpha * (float)c[j]);
+    }
+  }
+}
+
 __global__ void scale_kernel(const float* __restrict__ x, float s, float* __restrict__ y, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = x[i] * s;
 }
@@ -448,6 +471,17 @@ extern "C" int fmx_resize_separable_f32(const float* in, float* out, const int32
   hipLaunchKernelGGL(resize_separable_kernel, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream, in, out, ystart, yweights, xstart,
                      xweights, planes, h, w, oh, ow, ky, kx);
   FMX_LAUNCH_CHECK("fmx_resize_separable_f32");
+  return FMX_OK;
+}
+
+extern "C" int fmx_add_scaled_f16(void* h, const void* c, int32_t c_is_f32, float alpha, int64_t n, void* stream) {
+  FMX_REQUIRE(h && c && n > 0 && (reinterpret_cast<uintptr_t>(h) & 15) == 0 && (reinterpret_cast<uintptr_t>(c) & 15) == 0, "add_scaled: bad args");
+  const long groups = (n + 7) / 8;
+  if (c_is_f32)
+    hipLaunchKernelGGL(add_scaled_kernel<float>, dim3(grid_for(groups)), dim3(TPB), 0, (hipStream_t)stream, (f16*)h, (const float*)c, alpha, (long)n);
+  else
+    hipLaunchKernelGGL(add_scaled_kernel<f16>, dim3(grid_for(groups)), dim3(TPB), 0, (hipStream_t)stream, (f16*)h, (const f16*)c, alpha, (long)n);
+  FMX_LAUNCH_CHECK("fmx_add_scaled_f16");
   return FMX_OK;
 }
 

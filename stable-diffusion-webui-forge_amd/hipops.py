@@ -278,11 +278,20 @@ def silu(x, out=None):
     return out
 
 
-def add_control_(h, ctrl):
-    """h [B,H,W,C] fp16 NHWC += ctrl [B,C,H,W] fp32 NCHW (ControlNet residual, unet.py:44-52), in place."""
+def add_control_(h, ctrl, alpha=1.0):
+    """h [B,H,W,C] fp16 NHWC += alpha * ctrl [B,C,H,W] (ControlNet residual, unet.py:44-52), in place.  A residual whose MEMORY is already
+    channels-last (the native ControlNet hands out NCHW views of NHWC buffers) is added elementwise; an NCHW-contiguous one goes through
+    the transposing kernel."""
     b, hh, ww, c = h.shape
     if tuple(ctrl.shape) != (b, c, hh, ww):
         raise ValueError(f"control residual {tuple(ctrl.shape)} does not match activation {(b, c, hh, ww)}")
+    nhwc = ctrl.permute(0, 2, 3, 1)
+    if ctrl.device == h.device and nhwc.is_contiguous() and ctrl.dtype in (torch.float16, torch.float32) and not (c == 1 or hh * ww == 1):
+        _lib.check(_lib.lib().fmx_add_scaled_f16(_p(h), _p(nhwc), 1 if ctrl.dtype == torch.float32 else 0, float(alpha), h.numel(), stream_ptr()),
+                   "fmx_add_scaled_f16")
+        return h
+    if alpha != 1.0:
+        ctrl = ctrl * alpha
     ctrl = ctrl.to(device=h.device, dtype=torch.float32).contiguous()
     _lib.check(_lib.lib().fmx_add_control_nchw(_p(h), _p(ctrl), b, c, hh * ww, stream_ptr()), "fmx_add_control_nchw")
     return h

@@ -121,6 +121,13 @@ def synth_unet_state_dict(cfg, seed=0, **kw):
     return synth_state_dict(unet_param_shapes(cfg), seed=seed, **kw)
 
 
+def synth_controlnet_state_dict(cfg, hint_channels=3, seed=6, zero_conv_gain=1.0, **kw):
+    """cldm.ControlNet weights.  Real checkpoints start from ZERO 1x1 output convs; random ones (same init as every other conv) make the
+    residuals non-trivial for parity tests."""
+    from .backend.nn.layout import controlnet_param_shapes
+    return synth_state_dict(controlnet_param_shapes(cfg, hint_channels), seed=seed, **kw)
+
+
 def synth_flux_state_dict(cfg, seed=2, **kw):
     return synth_state_dict(flux_param_shapes(cfg), seed=seed, **kw)
 

@@ -1,0 +1,86 @@
+"""GPU: the native ControlNet (backend/nn/cnets/cldm.py on the UNet executor's kernels) and its patcher-level wiring
+(backend/patcher/controlnet.py, sampling_function) against the REAL reference classes (tests/golden/*_controlnet.pt, made on CPU fp32 by
+oracle/make_golden.py gen_controlnet with cldm.ControlNet, patcher.controlnet.ControlNet / apply_controlnet_advanced, sampling_function)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import forge_amd  # noqa: E402
+from forge_amd import synth  # noqa: E402
+from forge_amd.backend.diffusion_engine.base import build_engine  # noqa: E402
+from forge_amd.backend.nn.cnets import cldm  # noqa: E402
+from forge_amd.backend.patcher import controlnet as pc  # noqa: E402
+from forge_amd.modules import processing, shared  # noqa: E402
+from forge_amd.modules.prompt_parser import DictWithShape  # noqa: E402
+from oracle.make_golden import controlnet_case, sigma_weight  # noqa: E402
+
+from conftest import load_golden  # noqa: E402
+
+DEV = "cuda"
+TINY = {"tiny_sd15": synth.TINY_SD15_UNET_CONFIG, "tiny_sdxl": synth.TINY_SDXL_UNET_CONFIG}
+
+
+def max_rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / b.abs().max())
+
+
+@pytest.fixture(scope="module")
+def engines():
+    return {n: build_engine(cfg, synth.synth_unet_state_dict(cfg, seed=0), None, None, device=DEV) for n, cfg in TINY.items()}
+
+
+@pytest.mark.parametrize("name", list(TINY))
+def test_controlnet_forward_vs_reference(name):
+    cfg = TINY[name]
+    g, fx = load_golden(f"{name}_controlnet.pt"), load_golden(f"{name}_unet_fwd.pt")
+    case = controlnet_case(cfg)
+    net = cldm.ControlNet(cfg, synth.synth_controlnet_state_dict(cfg, seed=6), device=DEV)
+    y = fx["y"].to(DEV) if fx["y"] is not None else None
+    outs = net(x=fx["x"].to(DEV), hint=case["hint_a"].to(DEV), timesteps=fx["t"].to(DEV), context=fx["ctx"].to(DEV), y=y)
+    assert len(outs) == len(g["outs_every_4th_channel"])
+    worst = 0.0
+    for o, want in zip(outs, g["outs_every_4th_channel"]):
+        assert o.dtype == torch.float16 and o.permute(0, 2, 3, 1).is_contiguous()   # NCHW view of channels-last memory
+        worst = max(worst, max_rel(o[:, ::4], want))
+    print(f"[parity] {name} ControlNet forward, {len(outs)} residuals vs reference cldm.ControlNet: worst max_rel={worst:.3e} (tol 3e-03)")
+    assert worst < 3e-3
+    hint2 = case["hint_a"].to(DEV)
+    a = net.guided_hint(hint2)
+    assert net.guided_hint(hint2) is a  # cached per hint tensor: the hint block runs once per job, not once per step
+
+
+@pytest.mark.parametrize("name", list(TINY))
+def test_sampling_with_a_controlnet_chain_vs_reference(name, engines):
+    cfg = TINY[name]
+    g = load_golden(f"{name}_controlnet.pt")
+    case = controlnet_case(cfg)
+    eng = engines[name]
+    cn_a = pc.ControlNet(cldm.ControlNet(cfg, synth.synth_controlnet_state_dict(cfg, seed=6), device=DEV))
+    cn_b = pc.ControlNet(cldm.ControlNet(cfg, synth.synth_controlnet_state_dict(cfg, seed=9), device=DEV), global_average_pooling=True)
+    unet = pc.apply_controlnet_advanced(eng.forge_objects.unet, cn_a, case["hint_a"].to(DEV), 0.8, 0.0, 0.7, positive_advanced_weighting=case["positive"],
+                                        negative_advanced_weighting=case["negative"], advanced_frame_weighting=case["frame"],
+                                        advanced_sigma_weighting=sigma_weight, advanced_mask_weighting=case["mask"].to(DEV))
+    unet = pc.apply_controlnet_advanced(unet, cn_b, case["hint_b"].to(DEV), 0.5, 0.2, 1.0)
+    assert [type(c).__name__ for c in unet.list_controlnets()] == ["ControlNet", "ControlNet"] and eng.forge_objects.unet.controlnet_linked_list is None
+    saved = eng.forge_objects_after_applying_lora
+    eng.forge_objects_after_applying_lora = saved.shallow_copy()
+    eng.forge_objects_after_applying_lora.unet = unet
+    try:
+        b = len(g["euler4"]["seeds"])
+        c, uc = synth.synth_conditioning(b, cfg["context_dim"], cfg.get("adm_in_channels"), seed=1234)
+        if isinstance(c, dict):
+            c, uc = DictWithShape({k: v.to(DEV) for k, v in c.items()}), DictWithShape({k: v.to(DEV) for k, v in uc.items()})
+        else:
+            c, uc = c.to(DEV), uc.to(DEV)
+        shared.opts.randn_source = "CPU"
+        p = processing.StableDiffusionProcessingTxt2Img(sd_model=eng, c=c, uc=uc, seed=g["euler4"]["seeds"][0], sampler_name="Euler", batch_size=b,
+                                                        steps=4, cfg_scale=7.0, width=g["hw"] * 8, height=g["hw"] * 8, do_decode=False)
+        lat = processing.process_images(p).latents
+    finally:
+        eng.forge_objects_after_applying_lora = saved
+        eng.forge_objects = saved.shallow_copy()
+    err = max_rel(lat, g["euler4"]["latent"])
+    print(f"[parity] {name} 4-step Euler with a 2-ControlNet chain (ranges, pooling, weightings) vs reference: max_rel={err:.3e} (tol 1e-02)")
+    assert err < 1e-2

@@ -209,3 +209,27 @@ def test_unet_hooks_restated(name):
     eps = unet_forward(sd, cfg, fx["x"], fx["t"], fx["ctx"], fx["y"], transformer_options=to)
     assert log == g["log"]
     torch.testing.assert_close(eps, g["eps"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", list(TINY))
+def test_controlnet_restated(name):
+    """oracle/controlnet.py vs the reference's cldm.ControlNet (model level) and a 4-step Euler run through the reference's
+    sampling_function with a chain of two patcher-level ControlNets (strength, percent ranges, global average pooling, all advanced
+    weightings, hint resize + centre crop + batch broadcast)."""
+    from oracle import controlnet as ocn
+    from oracle.make_golden import controlnet_case, sigma_weight
+    cfg = TINY[name]
+    g, fx = load_golden(f"{name}_controlnet.pt"), load_golden(f"{name}_unet_fwd.pt")
+    case = controlnet_case(cfg)
+    sd_a, sd_b = synth.synth_controlnet_state_dict(cfg, seed=6), synth.synth_controlnet_state_dict(cfg, seed=9)
+    outs = ocn.controlnet_forward(sd_a, cfg, fx["x"], case["hint_a"], fx["t"], fx["ctx"], fx["y"])
+    assert len(outs) == len(g["outs_every_4th_channel"])
+    for o, want in zip(outs, g["outs_every_4th_channel"]):
+        torch.testing.assert_close(o[:, ::4], want, rtol=1e-4, atol=1e-5)
+    first = ocn.Control(sd_a, cfg, case["hint_a"], 0.8, (0.0, 0.7), weighting={"positive": case["positive"], "negative": case["negative"],
+                                                                                "frame": case["frame"], "sigma": sigma_weight, "mask": case["mask"]})
+    chain = ocn.Control(sd_b, cfg, case["hint_b"], 0.5, (0.2, 1.0), global_average_pooling=True, previous=first)
+    sd = synth.synth_unet_state_dict(cfg, seed=0)
+    c, uc = synth.synth_conditioning(2, cfg["context_dim"], cfg.get("adm_in_channels"), seed=1234)
+    lat = pipeline.txt2img_latents_controlnet(sd, cfg, c, uc, g["euler4"]["seeds"], g["hw"] * 8, g["hw"] * 8, 4, chain)
+    assert max_rel(lat, g["euler4"]["latent"]) < 2e-4
