@@ -205,7 +205,10 @@ class KModelFlux:
             return ops.lincomb3(x, out, None, 1.0, -float(sig_host[0]), 0.0)   # x - out * sigma in one kernel
         return x - out * sigma.view(-1, 1, 1, 1)
 
-    def denoise_cfg(self, x, sigma, uncond_ctx, cond_ctx, cond_scale, want_parts=False):
+    def denoise_cfg(self, x, sigma, uncond_ctx, cond_ctx, cond_scale, want_parts=False, transformer_options=None, control_model=None):
+        to = transformer_options or {}
+        if control_model is not None or to.get("patches") or to.get("patches_replace") or to.get("block_modifiers"):
+            raise NotImplementedError("ControlNet / per-block hooks are built for the LDM UNet executor, not for the Flux transformer")
         if uncond_ctx is not None:
             raise NotImplementedError("Flux-dev runs at cfg scale 1 with distilled guidance (one model call per step)")
         ctx, y, guidance = cond_ctx
