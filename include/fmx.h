@@ -191,12 +191,15 @@ int fmx_embed_tokens(const int32_t* ids, const void* tok_emb, const void* pos_em
 int fmx_unet_pack_input(const float* x, const float* sigma, float sigma_data, int32_t b, int32_t c, int32_t h,
                         int32_t w, int32_t reps, void* out, void* stream);
 
-/* eps: fp16 NHWC [reps*b][h][w][ld_eps>=c] from the UNet.  denoised = x - eps*sigma (eps-prediction).
+/* eps: fp16 NHWC [reps*b][h][w][ld_eps>=c], the model output.  Per half, calculate_denoised (k_prediction.py:81-92):
+ *   prediction_type 0 (epsilon; also Flux 'const'): x - out*sigma
+ *   prediction_type 1 (v_prediction): x*sd^2/(sigma^2+sd^2) - out*sigma*sd/sqrt(sigma^2+sd^2)      (sd = sigma_data)
+ *   prediction_type 2 (edm):          x*sd^2/(sigma^2+sd^2) + out*sigma*sd/sqrt(sigma^2+sd^2)
  * reps == 2: eps holds [uncond ; cond]; out = uncond + (cond - uncond)*cond_scale; reps == 1: out = cond.
  * Optional outputs cond_pred / uncond_pred (fp32 NCHW, may be null). */
 int fmx_cfg_combine(const void* eps, int32_t ld_eps, const float* x, const float* sigma, int32_t b, int32_t c,
                     int32_t h, int32_t w, int32_t reps, float cond_scale, float* denoised, float* cond_pred,
-                    float* uncond_pred, void* stream);
+                    float* uncond_pred, int32_t prediction_type, float sigma_data, void* stream);
 
 /* x_out = x + (x - denoised)/sigma * (sigma_next - sigma)   (Euler; also the deterministic part of Euler a
  * with sigma_next := sigma_down); if noise != null: x_out += noise * noise_scale. */

@@ -7,15 +7,41 @@ epsilon prediction), :113-159 (scaled-linear beta schedule -> 1000-entry sigma t
 import torch
 
 
+def beta_schedule(schedule, n, linear_start, linear_end, cosine_s=8e-3):
+    """k_prediction.py:18-39 (float64)."""
+    import math
+    if schedule == "linear":
+        return torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n, dtype=torch.float64) ** 2
+    if schedule == "cosine":
+        t = torch.arange(n + 1, dtype=torch.float64) / n + cosine_s
+        a = torch.cos(t / (1 + cosine_s) * math.pi / 2).pow(2)
+        a = a / a[0]
+        return torch.clamp(1 - a[1:] / a[:-1], min=0, max=0.999)
+    if schedule == "sqrt_linear":
+        return torch.linspace(linear_start, linear_end, n, dtype=torch.float64)
+    return torch.linspace(linear_start, linear_end, n, dtype=torch.float64) ** 0.5  # "sqrt"
+
+
+def rescale_zero_terminal_snr_sigmas(sigmas):
+    """k_prediction.py:48-63."""
+    abs_ = (1 / ((sigmas * sigmas) + 1)).sqrt()
+    a0, at = abs_[0].clone(), abs_[-1].clone()
+    abs_ = (abs_ - at) * (a0 / (a0 - at))
+    ab = abs_ ** 2
+    ab[-1] = 4.8973451890853435e-08
+    return ((1 - ab) / ab) ** 0.5
+
+
 class Predictor:
-    def __init__(self, linear_start=0.00085, linear_end=0.012, timesteps=1000, sigma_data=1.0):
+    def __init__(self, linear_start=0.00085, linear_end=0.012, timesteps=1000, sigma_data=1.0, prediction_type="epsilon", schedule="linear"):
         # k_prediction.py:20-22: float64 linspace of sqrt(beta), squared; :127-133 cumprod -> sigmas, stored fp32
-        betas = torch.linspace(linear_start ** 0.5, linear_end ** 0.5, timesteps, dtype=torch.float64) ** 2
+        betas = beta_schedule(schedule, timesteps, linear_start, linear_end)
         alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
         sig = ((1 - alphas_cumprod) / alphas_cumprod) ** 0.5
         self.sigmas = sig.float()
         self.log_sigmas = sig.log().float()
         self.sigma_data = sigma_data
+        self.prediction_type = prediction_type
 
     @property
     def sigma_min(self):
@@ -42,7 +68,7 @@ class Predictor:
             return 999999999.9
         if percent >= 1.0:
             return 0.0
-        return self.sigma(torch.tensor(1000.0 * (1.0 - percent))).item()
+        return self.sigma(torch.tensor((1.0 - percent) * 999.0)).item()
 
     def calculate_input(self, sigma, x):
         s = sigma.view(-1, *([1] * (x.ndim - 1)))
@@ -50,6 +76,11 @@ class Predictor:
 
     def calculate_denoised(self, sigma, model_output, model_input):
         s = sigma.view(-1, *([1] * (model_output.ndim - 1)))
+        sd = self.sigma_data
+        if self.prediction_type == "v_prediction":  # :83-86
+            return model_input * sd ** 2 / (s ** 2 + sd ** 2) - model_output * s * sd / (s ** 2 + sd ** 2) ** 0.5
+        if self.prediction_type == "edm":  # :87-90
+            return model_input * sd ** 2 / (s ** 2 + sd ** 2) + model_output * s * sd / (s ** 2 + sd ** 2) ** 0.5
         return model_input - model_output * s
 
     def noise_scaling(self, sigma, noise, latent_image, max_denoise=False):

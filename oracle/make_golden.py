@@ -906,6 +906,43 @@ def gen_controlnet(name, cfg, net, b=2, hw=16):
     print(name, "controlnet:", len(outs), "residuals; euler4 std", float(lat.std()))
 
 
+def gen_prediction_types(name, cfg, net, b=2, hw=16):
+    """Prediction(prediction_type='v_prediction' | 'edm') and the non-default beta schedules / zero-terminal-SNR rescale of
+    backend/modules/k_prediction.py: sigma tables, calculate_denoised, and a 4-step Euler run through the reference stack per type."""
+    ref = ref_import.load_reference()
+    kp = ref.k_prediction
+    out = {"hw": hw, "seeds": [1000 + i for i in range(b)]}
+    for sched, (ls, le) in (("linear", (0.00085, 0.012)), ("cosine", (0.00085, 0.012)), ("sqrt_linear", (0.0001, 0.02)), ("sqrt", (0.0001, 0.0004))):
+        p = kp.Prediction(prediction_type="epsilon", beta_schedule=sched, linear_start=ls, linear_end=le, timesteps=1000)
+        out[("sigmas", sched)] = p.sigmas.clone()
+    base = kp.Prediction(prediction_type="v_prediction", beta_schedule="linear", linear_start=0.00085, linear_end=0.012, timesteps=1000)
+    out["ztsnr_sigmas"] = kp.rescale_zero_terminal_snr_sigmas(base.sigmas.clone())
+    out["percent_to_sigma"] = {pc: base.percent_to_sigma(pc) for pc in (0.0, 0.1, 0.37, 0.7, 1.0)}
+    g = torch.Generator().manual_seed(5)
+    x, mo, sg = torch.randn(3, 4, 8, 8, generator=g), torch.randn(3, 4, 8, 8, generator=g), torch.tensor([14.6, 1.3, 0.05])
+    c, uc = synth.synth_conditioning(b, cfg["context_dim"], cfg.get("adm_in_channels"), seed=1234)
+    for ptype in ("v_prediction", "edm"):
+        pred = kp.Prediction(prediction_type=ptype, beta_schedule="linear", linear_start=0.00085, linear_end=0.012, timesteps=1000)
+        out[("denoised", ptype)] = pred.calculate_denoised(sg, mo, x)
+        den = ref_import.RefDenoiser(net, pred, out["seeds"])
+        rng = ImageRNG((cfg["in_channels"], hw, hw), out["seeds"], "CPU")
+        xx = rng.next()
+        sigmas = den.inner_model.get_sigmas(4)
+        xx = pred.noise_scaling(sigmas[0], xx, torch.zeros_like(xx), max_denoise=False)
+        ref.kd_sampling.torch = _Hijack(rng)
+        ref.sampling_function.sampling_prepare(den.patcher, x=xx)
+        try:
+            lat = ref.kd_sampling.sample_euler(den, xx, sigmas, extra_args={"cond": c, "uncond": uc, "cond_scale": 7.0, "s_min_uncond": 0.0,
+                                                                              "image_cond": None}, disable=True)
+        finally:
+            ref.kd_sampling.torch = torch
+            ref.sampling_function.sampling_cleanup(den.patcher)
+        out[("euler4", ptype)] = lat
+        print(name, ptype, float(lat.std()))
+    out["kat"] = {"x": x, "model_output": mo, "sigma": sg}
+    torch.save(out, os.path.join(GOLD, f"{name}_prediction_types.pt"))
+
+
 def gen_schedulers():
     """modules/sd_schedulers.py's table, imported from the reference with a two-attribute stand-in for modules.shared."""
     import importlib.util
@@ -1100,6 +1137,7 @@ def main():
         gen_unet_control("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
         gen_unet_hooks("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
         gen_controlnet("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
+        gen_prediction_types("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
         net, _ = gen_unet("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG)
         gen_samples("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG, net)
         gen_unet_hooks("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG, net)
@@ -1110,6 +1148,9 @@ def main():
         net, _ = gen_unet("tiny_sd15", synth.TINY_SD15_UNET_CONFIG)
         gen_samples_extra("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
         gen_samples_more("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
+    if a.only == "prediction":
+        net, _ = gen_unet("tiny_sd15", synth.TINY_SD15_UNET_CONFIG)
+        gen_prediction_types("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
     if a.only == "controlnet":
         for nm, cf in (("tiny_sd15", synth.TINY_SD15_UNET_CONFIG), ("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG)):
             net, _ = gen_unet(nm, cf)

@@ -37,8 +37,8 @@ def txt2img_latents_on_schedule(unet_sd, unet_cfg, cond, uncond, seeds, height, 
 
 @torch.no_grad()
 def txt2img_latents(unet_sd, unet_cfg, cond, uncond, seeds, height, width, steps, sampler_name="Euler",
-                    cfg_scale=7.0, noise_source="CPU", trace=None, sigmas=None):
-    pred = Predictor()
+                    cfg_scale=7.0, noise_source="CPU", trace=None, sigmas=None, predictor=None):
+    pred = predictor if predictor is not None else Predictor()
     b = len(seeds)
     rng = ImageRNG((unet_cfg["in_channels"], height // 8, width // 8), seeds, noise_source)
     x = rng.next()

@@ -71,7 +71,7 @@ SIGNATURES = {
     "fmx_add_control_nchw": [_vp, _vp, _i32, _i32, _i64, _vp],
     "fmx_cast_f32_to_f16": [_vp, _vp, _i64, _vp],
     "fmx_unet_pack_input": [_vp, _vp, _f32, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
-    "fmx_cfg_combine": [_vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp],
+    "fmx_cfg_combine": [_vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _i32, _f32, _vp],
     "fmx_sampler_euler_step": [_vp, _vp, _f32, _f32, _vp, _f32, _vp, _i64, _vp],
     "fmx_sampler_lincomb": [_vp, _vp, _i32, _vp, _i64, _vp],
     "fmx_sampler_error_norm": [_vp, _vp, _vp, _f32, _f32, _vp, _vp, _i64, _vp],

@@ -147,7 +147,8 @@ class KModel:
         eps = self._forward_static(key, x, sigma, sig_host, reps, ctxc, control=control, transformer_options=transformer_options)
         cond_pred = torch.empty_like(x) if want_parts else None
         uncond_pred = torch.empty_like(x) if want_parts else None
-        den = ops.cfg_combine(eps, eps.shape[-1], x, sigma, reps, cond_scale, None, cond_pred, uncond_pred)
+        den = ops.cfg_combine(eps, eps.shape[-1], x, sigma, reps, cond_scale, None, cond_pred, uncond_pred,
+                              prediction_type=self.predictor.prediction_type, sigma_data=self.predictor.sigma_data)
         return (den, cond_pred, uncond_pred) if want_parts else den
 
     def _stack_ctx(self, uc, c):
@@ -176,7 +177,8 @@ class KModel:
         ctxc = self.diffusion_model.prepare_context(c_crossattn, y)
         b, c, hh, ww = x.shape
         eps = self._forward_static((b, c, hh, ww, 1, "apply"), x, sigma, host_sigmas(t), 1, ctxc, control, transformer_options)
-        return ops.cfg_combine(eps, eps.shape[-1], x, sigma, 1, 1.0)
+        return ops.cfg_combine(eps, eps.shape[-1], x, sigma, 1, 1.0, prediction_type=self.predictor.prediction_type,
+                               sigma_data=self.predictor.sigma_data)
 
 
 class KModelFlux:

@@ -10,10 +10,36 @@ import torch
 from ... import hipops as ops
 
 
+def make_beta_schedule(schedule, n_timestep, linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3):
+    """k_prediction.py:18-39, float64."""
+    if schedule == "linear":
+        return torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=torch.float64) ** 2
+    if schedule == "cosine":
+        import math
+        ts = torch.arange(n_timestep + 1, dtype=torch.float64) / n_timestep + cosine_s
+        alphas = torch.cos(ts / (1 + cosine_s) * math.pi / 2).pow(2)
+        alphas = alphas / alphas[0]
+        return torch.clamp(1 - alphas[1:] / alphas[:-1], min=0, max=0.999)
+    if schedule == "sqrt_linear":
+        return torch.linspace(linear_start, linear_end, n_timestep, dtype=torch.float64)
+    if schedule == "sqrt":
+        return torch.linspace(linear_start, linear_end, n_timestep, dtype=torch.float64) ** 0.5
+    raise ValueError(f"schedule '{schedule}' unknown.")
+
+
+def rescale_zero_terminal_snr_sigmas(sigmas):
+    """k_prediction.py:48-63: shift / rescale sqrt(alpha_bar) so that the last timestep has zero SNR (then clamp it to a finite sigma)."""
+    alphas_bar_sqrt = (1 / ((sigmas * sigmas) + 1)).sqrt()
+    first, last = alphas_bar_sqrt[0].clone(), alphas_bar_sqrt[-1].clone()
+    alphas_bar_sqrt = (alphas_bar_sqrt - last) * (first / (first - last))
+    alphas_bar = alphas_bar_sqrt ** 2
+    alphas_bar[-1] = 4.8973451890853435e-08
+    return ((1 - alphas_bar) / alphas_bar) ** 0.5
+
+
 class AbstractPrediction:
     def __init__(self, sigma_data=1.0, prediction_type="epsilon"):
-        if prediction_type not in ("epsilon", "const"):
-            raise NotImplementedError("epsilon (SD1.x/SDXL) and const (Flux flow matching) are on the path (k_prediction.py:74-92)")
+        assert prediction_type in ("epsilon", "const", "v_prediction", "edm")  # k_prediction.py:71
         self.sigma_data = sigma_data
         self.prediction_type = prediction_type
 
@@ -36,12 +62,14 @@ class Prediction(AbstractPrediction):
     def __init__(self, sigma_data=1.0, prediction_type="epsilon", beta_schedule="linear", linear_start=0.00085,
                  linear_end=0.012, timesteps=1000):
         super().__init__(sigma_data, prediction_type)
-        if beta_schedule != "linear":
-            raise NotImplementedError(beta_schedule)
-        betas = torch.linspace(linear_start ** 0.5, linear_end ** 0.5, timesteps, dtype=torch.float64) ** 2
+        betas = make_beta_schedule(beta_schedule, timesteps, linear_start=linear_start, linear_end=linear_end)
         alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
         sigmas = ((1 - alphas_cumprod) / alphas_cumprod) ** 0.5
         self.alphas_cumprod = alphas_cumprod.float()
+        self.set_sigmas(sigmas)
+
+    def set_sigmas(self, sigmas):
+        """(also the hook a zero-terminal-SNR checkpoint uses: set_sigmas(rescale_zero_terminal_snr_sigmas(self.sigmas)))"""
         self.sigmas = sigmas.float()
         self.log_sigmas = sigmas.log().float()
 
@@ -69,7 +97,7 @@ class Prediction(AbstractPrediction):
             return 999999999.9
         if percent >= 1.0:
             return 0.0
-        return self.sigma(torch.tensor(1000.0 * (1.0 - percent))).item()
+        return self.sigma(torch.tensor((1.0 - percent) * 999.0)).item()  # :166-167
 
 
 class PredictionFlux(AbstractPrediction):

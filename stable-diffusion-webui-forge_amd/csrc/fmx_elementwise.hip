@@ -118,10 +118,12 @@ __global__ void im2col3x3_smallc_kernel(const f16* __restrict__ x, int ldx, int 
   }
 }
 
-// denoised = x - eps*sigma per half, then CFG combine (k_prediction.py:92, sampling_function.py:276-288,312)
+// calculate_denoised per half (k_prediction.py:81-92: denoised = A(sigma) * x + B(sigma) * model_output with
+//   epsilon / const: A = 1, B = -sigma;   v_prediction: A = sd^2 / (sigma^2 + sd^2), B = -sigma sd / sqrt(sigma^2 + sd^2);   edm: same A, +B)
+// then the CFG combine (sampling_function.py:276-288,312)
 __global__ void cfg_combine_kernel(const f16* __restrict__ eps, int ld, const float* __restrict__ x, const float* __restrict__ sigma,
                                    int b, int c, int h, int w, int reps, float cond_scale, float* __restrict__ den,
-                                   float* __restrict__ cond_pred, float* __restrict__ uncond_pred) {
+                                   float* __restrict__ cond_pred, float* __restrict__ uncond_pred, int pred_type, float sigma_data) {
   const long total = (long)b * c * h * w;
   const long hw = (long)h * w;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -129,20 +131,26 @@ __global__ void cfg_combine_kernel(const f16* __restrict__ eps, int ld, const fl
     const int ch = (int)((i / hw) % c);
     const int bi = (int)(i / (hw * c));
     const float s = sigma[bi];
+    float ca = 1.f, cb = -s;
+    if (pred_type != 0) {
+      const float v = s * s + sigma_data * sigma_data;
+      ca = sigma_data * sigma_data / v;
+      cb = (pred_type == 1 ? -1.f : 1.f) * s * sigma_data / sqrtf(v);
+    }
     const float xv = x[i];
     float result;
     if (reps == 2) {
       const float eu = (float)eps[((long)bi * hw + pix) * ld + ch];
       const float ec = (float)eps[((long)(b + bi) * hw + pix) * ld + ch];
       // accumulators 0 + out*1 divided by counts 1e-37 + 1 (sampling_function.py:155-159,284-288): exact in fp32
-      const float du = xv - eu * s;
-      const float dc = xv - ec * s;
+      const float du = pred_type == 0 ? xv - eu * s : xv * ca + eu * cb;
+      const float dc = pred_type == 0 ? xv - ec * s : xv * ca + ec * cb;
       result = du + (dc - du) * cond_scale;
       if (cond_pred) cond_pred[i] = dc;
       if (uncond_pred) uncond_pred[i] = du;
     } else {
       const float ec = (float)eps[((long)bi * hw + pix) * ld + ch];
-      const float dc = xv - ec * s;
+      const float dc = pred_type == 0 ? xv - ec * s : xv * ca + ec * cb;
       result = 0.f + (dc - 0.f) * cond_scale;  // uncond half skipped when cond_scale == 1 (:295-298)
       if (cond_pred) cond_pred[i] = dc;
       if (uncond_pred) uncond_pred[i] = 0.f;
@@ -432,11 +440,13 @@ extern "C" int fmx_im2col3x3_smallc(const void* x, int32_t ldx, int32_t n, int32
 
 extern "C" int fmx_cfg_combine(const void* eps, int32_t ld_eps, const float* x, const float* sigma, int32_t b, int32_t c, int32_t h,
                                int32_t w, int32_t reps, float cond_scale, float* denoised, float* cond_pred, float* uncond_pred,
-                               void* stream) {
-  FMX_REQUIRE(eps && x && sigma && denoised && b > 0 && c > 0 && ld_eps >= c && (reps == 1 || reps == 2), "cfg_combine: bad args");
+                               int32_t prediction_type, float sigma_data, void* stream) {
+  FMX_REQUIRE(eps && x && sigma && denoised && b > 0 && c > 0 && ld_eps >= c && (reps == 1 || reps == 2) && prediction_type >= 0 &&
+                  prediction_type <= 2 && sigma_data > 0.f,
+              "cfg_combine: bad args");
   const long total = (long)b * c * h * w;
   hipLaunchKernelGGL(cfg_combine_kernel, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream, (const f16*)eps, ld_eps, x, sigma, b, c,
-                     h, w, reps, cond_scale, denoised, cond_pred, uncond_pred);
+                     h, w, reps, cond_scale, denoised, cond_pred, uncond_pred, prediction_type, sigma_data);
   FMX_LAUNCH_CHECK("fmx_cfg_combine");
   return FMX_OK;
 }

@@ -341,12 +341,17 @@ def im2col3x3_smallc(x, c, out=None):
     return out
 
 
-def cfg_combine(eps, ld_eps, x, sigma, reps, cond_scale, denoised=None, cond_pred=None, uncond_pred=None):
+PREDICTION_TYPES = {"epsilon": 0, "const": 0, "v_prediction": 1, "edm": 2}
+
+
+def cfg_combine(eps, ld_eps, x, sigma, reps, cond_scale, denoised=None, cond_pred=None, uncond_pred=None, prediction_type="epsilon",
+                sigma_data=1.0):
     b, c, h, w = x.shape
     if denoised is None:
         denoised = torch.empty_like(x)
     _lib.check(_lib.lib().fmx_cfg_combine(_p(eps), ld_eps, _p(x), _p(sigma), b, c, h, w, reps, float(cond_scale), _p(denoised),
-                                          _p(cond_pred), _p(uncond_pred), stream_ptr()), "fmx_cfg_combine")
+                                          _p(cond_pred), _p(uncond_pred), PREDICTION_TYPES[prediction_type], float(sigma_data), stream_ptr()),
+               "fmx_cfg_combine")
     return denoised
 
 

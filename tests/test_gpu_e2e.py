@@ -265,6 +265,33 @@ def test_sde_samplers_run_with_native_brownian_noise(sampler, engines):
     assert bool(torch.isfinite(a).all()) and float(a.std()) > 0.1
 
 
+@pytest.mark.parametrize("ptype", ["v_prediction", "edm"])
+def test_prediction_types_vs_reference_fixture(ptype):
+    """v-prediction (SD2.x, v-pred SDXL finetunes) and EDM parameterisations: calculate_denoised inside the fused CFG-combine kernel
+    (k_prediction.py:81-92) against the reference's Prediction class, kernel-level and through a 4-step Euler run."""
+    from forge_amd import hipops as ops
+    from forge_amd.backend.diffusion_engine.base import ForgeDiffusionEngine
+    from forge_amd.backend.modules.k_prediction import Prediction
+    from forge_amd.backend.patcher.unet import UnetPatcher
+    g = load_golden("tiny_sd15_prediction_types.pt")
+    k = g["kat"]
+    x, mo, sg = k["x"].to(DEV), k["model_output"].to(DEV), k["sigma"].to(DEV)
+    eps = mo.permute(0, 2, 3, 1).contiguous().half()
+    den = ops.cfg_combine(eps, 4, x, sg, 1, 1.0, prediction_type=ptype, sigma_data=1.0)
+    report(f"calculate_denoised {ptype} (kernel) vs reference", max_rel(den, g[("denoised", ptype)]), 2e-3)  # fp16 model output
+    cfg = TINY["tiny_sd15"]
+    eng = build_engine(cfg, synth.synth_unet_state_dict(cfg, seed=0), None, None, device=DEV)
+    pred = Prediction(prediction_type=ptype)
+    eng.forge_objects.unet = UnetPatcher.from_model(eng.forge_objects.unet.model.diffusion_model, k_predictor=pred)
+    eng.forge_objects_original = eng.forge_objects.shallow_copy()
+    eng.forge_objects_after_applying_lora = eng.forge_objects.shallow_copy()
+    shared.opts.randn_source = "CPU"
+    c, uc = _conds(cfg, 2)
+    p = processing.StableDiffusionProcessingTxt2Img(sd_model=eng, c=c, uc=uc, seed=g["seeds"][0], sampler_name="Euler", batch_size=2, steps=4,
+                                                    cfg_scale=7.0, width=g["hw"] * 8, height=g["hw"] * 8, do_decode=False)
+    report(f"tiny_sd15 {ptype} 4-step Euler vs reference", max_rel(processing.process_images(p).latents, g[("euler4", ptype)]), 1e-2)
+
+
 def test_latent_resize_kernel_vs_torch_interpolate():
     import torch.nn.functional as F
     from forge_amd.modules import latent_upscale

@@ -281,3 +281,30 @@ def test_hires_target_resolution_rules():
     assert res(hr_resize_y=1024) == (682, 1024, 0, 0)
     assert res(hr_resize_x=1024, hr_resize_y=1024) == (1024, 1536, 0, 64)   # crop the long side: (1536 - 1024) // 8
     assert res(hr_resize_x=640, hr_resize_y=1280) == (853, 1280, 26, 0)
+
+
+def test_prediction_types_and_beta_schedules():
+    """backend/modules/k_prediction.py: all four beta schedules, zero-terminal-SNR rescale, percent_to_sigma, and calculate_denoised for
+    v_prediction / edm -- oracle AND product (host tables) against the reference's Prediction class; the oracle's Euler run per prediction
+    type against the reference stack."""
+    from forge_amd.backend.modules import k_prediction as prod
+    from oracle import k_prediction as okp
+    g = load_golden("tiny_sd15_prediction_types.pt")
+    for sched, (ls, le) in (("linear", (0.00085, 0.012)), ("cosine", (0.00085, 0.012)), ("sqrt_linear", (0.0001, 0.02)), ("sqrt", (0.0001, 0.0004))):
+        want = g[("sigmas", sched)]
+        assert torch.equal(okp.Predictor(ls, le, schedule=sched).sigmas, want), sched
+        assert torch.equal(prod.Prediction(beta_schedule=sched, linear_start=ls, linear_end=le).sigmas, want), sched
+    base = prod.Prediction(prediction_type="v_prediction")
+    assert torch.equal(prod.rescale_zero_terminal_snr_sigmas(base.sigmas.clone()), g["ztsnr_sigmas"])
+    assert torch.equal(okp.rescale_zero_terminal_snr_sigmas(okp.Predictor().sigmas.clone()), g["ztsnr_sigmas"])
+    for pc, want in g["percent_to_sigma"].items():
+        assert base.percent_to_sigma(pc) == want and okp.Predictor().percent_to_sigma(pc) == want, pc
+    cfg = synth.TINY_SD15_UNET_CONFIG
+    sd = synth.synth_unet_state_dict(cfg, seed=0)
+    c, uc = synth.synth_conditioning(2, cfg["context_dim"], None, seed=1234)
+    k = g["kat"]
+    for ptype in ("v_prediction", "edm"):
+        pred = okp.Predictor(prediction_type=ptype)
+        torch.testing.assert_close(pred.calculate_denoised(k["sigma"], k["model_output"], k["x"]), g[("denoised", ptype)], rtol=1e-6, atol=1e-6)
+        lat, _ = pipeline.txt2img_latents(sd, cfg, c, uc, g["seeds"], g["hw"] * 8, g["hw"] * 8, 4, sampler_name="Euler", predictor=pred)
+        assert max_rel(lat, g[("euler4", ptype)]) < 2e-4, ptype
