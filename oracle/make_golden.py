@@ -943,6 +943,78 @@ def gen_prediction_types(name, cfg, net, b=2, hw=16):
     torch.save(out, os.path.join(GOLD, f"{name}_prediction_types.pt"))
 
 
+def cfg_hooks_fixture():
+    """Deterministic model_options hooks shared by the generator (reference sampling_function) and the tests (native sampling_function)."""
+    def sampler_cfg_function(args):  # a 'rescale'-style cfg function: returns the noise prediction (x - denoised)
+        return args["uncond"] + (args["cond"] - args["uncond"]) * args["cond_scale"] * 0.9
+
+    def post_cfg(args):
+        return args["denoised"] * 0.99 + 0.01 * args["cond_denoised"]
+
+    def pre_cfg(model, cond, uncond, x, timestep, model_options):
+        return model, cond, uncond, x * 1.0, timestep, model_options
+
+    def wrapper(apply_model, params):
+        assert params["cond_or_uncond"][0] == 1 and params["input"].shape[0] == params["timestep"].shape[0]
+        return apply_model(params["input"], params["timestep"], **params["c"]) * 1.01
+    return {"sampler_cfg_function": sampler_cfg_function, "sampler_post_cfg_function": [post_cfg], "sampler_pre_cfg_function": [pre_cfg],
+            "model_function_wrapper": wrapper}
+
+
+def multicond_case(cfg, b=2, seed=77):
+    """AND-composed prompts as tensors: image i has parts (2i, w=1.0) and (2i+1, w=0.6); plus a per-image prompt-editing schedule."""
+    adm = cfg.get("adm_in_channels")
+    c4, uc = synth.synth_conditioning(2 * b, cfg["context_dim"], adm, seed=seed)
+    comp = [[(2 * i, 1.0), (2 * i + 1, 0.6)] for i in range(b)]
+    take = lambda t, n: ({k: v[:n] for k, v in t.items()} if isinstance(t, dict) else t[:n])
+    return c4, take(uc, b), comp
+
+
+def gen_cfg_paths(name, cfg, net, b=2, hw=16):
+    """sampling_function's general paths through the reference: (1) AND-composed prompts (two weighted conds per image -> edit strength
+    1.6), (2) sampler_pre_cfg / sampler_cfg / sampler_post_cfg functions, (3) model_function_wrapper; 3 Euler steps each."""
+    ref = ref_import.load_reference()
+    pred = ref_import.build_ref_predictor()
+    seeds = [1000 + i for i in range(b)]
+    c4, uc, comp = multicond_case(cfg, b)
+    c1, _ = synth.synth_conditioning(b, cfg["context_dim"], cfg.get("adm_in_channels"), seed=1234)
+    wrap = (lambda t: ref_import.SdxlCond(t)) if cfg.get("adm_in_channels") else (lambda t: t)
+    hooks = cfg_hooks_fixture()
+    res = {"seeds": seeds, "hw": hw}
+
+    class Den(ref_import.RefDenoiser):
+        composition = None
+
+        def __call__(self, x, sigma, uncond, cond, cond_scale, s_min_uncond=0.0, image_cond=None):
+            params = SimpleNamespace(x=x, sigma=sigma, text_cond=cond, text_uncond=uncond, image_cond=image_cond)
+            comp_ = self.composition or [[(i, 1.0)] for i in range(x.shape[0])]
+            return ref.sampling_function.sampling_function(self, denoiser_params=params, cond_scale=cond_scale, cond_composition=comp_)[0]
+
+    def run(cond, composition, options):
+        den = Den(net, pred, seeds)
+        den.composition = composition
+        den.patcher.model_options.update(options)
+        rng = ImageRNG((cfg["in_channels"], hw, hw), seeds, "CPU")
+        x = rng.next()
+        sigmas = den.inner_model.get_sigmas(3)
+        x = pred.noise_scaling(sigmas[0], x, torch.zeros_like(x), max_denoise=False)
+        ref.kd_sampling.torch = _Hijack(rng)
+        ref.sampling_function.sampling_prepare(den.patcher, x=x)
+        try:
+            return ref.kd_sampling.sample_euler(den, x, sigmas, extra_args={"cond": wrap(cond), "uncond": wrap(uc), "cond_scale": 5.0, "s_min_uncond": 0.0,
+                                                                            "image_cond": None}, disable=True)
+        finally:
+            ref.kd_sampling.torch = torch
+            ref.sampling_function.sampling_cleanup(den.patcher)
+    res["and_composed"] = run(c4, comp, {})
+    res["cfg_functions"] = run(c1, None, {k: hooks[k] for k in ("sampler_cfg_function", "sampler_post_cfg_function", "sampler_pre_cfg_function")})
+    res["model_function_wrapper"] = run(c1, None, {"model_function_wrapper": hooks["model_function_wrapper"]})
+    res["plain"] = run(c1, None, {})
+    for k in ("and_composed", "cfg_functions", "model_function_wrapper", "plain"):
+        print(name, k, float(res[k].std()))
+    torch.save(res, os.path.join(GOLD, f"{name}_cfg_paths.pt"))
+
+
 def gen_schedulers():
     """modules/sd_schedulers.py's table, imported from the reference with a two-attribute stand-in for modules.shared."""
     import importlib.util
@@ -1138,16 +1210,22 @@ def main():
         gen_unet_hooks("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
         gen_controlnet("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
         gen_prediction_types("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
+        gen_cfg_paths("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
         net, _ = gen_unet("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG)
         gen_samples("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG, net)
         gen_unet_hooks("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG, net)
         gen_controlnet("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG, net)
+        gen_cfg_paths("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG, net)
         gen_vae("tiny_vae", synth.TINY_VAE_CONFIG)
         gen_vae_encode("tiny_vae", synth.TINY_VAE_CONFIG)
     if a.only == "samplers":
         net, _ = gen_unet("tiny_sd15", synth.TINY_SD15_UNET_CONFIG)
         gen_samples_extra("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
         gen_samples_more("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
+    if a.only == "cfgpaths":
+        for nm, cf in (("tiny_sd15", synth.TINY_SD15_UNET_CONFIG), ("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG)):
+            net, _ = gen_unet(nm, cf)
+            gen_cfg_paths(nm, cf, net)
     if a.only == "prediction":
         net, _ = gen_unet("tiny_sd15", synth.TINY_SD15_UNET_CONFIG)
         gen_prediction_types("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)

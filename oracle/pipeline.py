@@ -189,3 +189,19 @@ def txt2img_latents_controlnet(unet_sd, unet_cfg, cond, uncond, seeds, height, w
     sigmas = get_sigmas(pred, "Euler", steps)
     x = pred.noise_scaling(sigmas[0], x, torch.zeros_like(x))
     return sampling.sample_euler(denoiser, x, sigmas, noise_fn=rng.next)
+
+
+@torch.no_grad()
+def txt2img_latents_general_cfg(unet_sd, unet_cfg, cond, uncond, composition, seeds, height, width, steps, cfg_scale, options=None):
+    """Euler txt2img through cfg_denoise_general (AND-composed prompts, cfg function hooks, model_function_wrapper)."""
+    from .cfg import cfg_denoise_general
+    pred = Predictor()
+    rng = ImageRNG((unet_cfg["in_channels"], height // 8, width // 8), seeds, "CPU")
+    x = rng.next()
+    comp = composition or [[(i, 1.0)] for i in range(len(seeds))]
+
+    def model_fn(xx, ss, ctx, y):
+        return apply_model(lambda xc, t, c, yy: unet_forward(unet_sd, unet_cfg, xc, t, c, yy), pred, xx, ss, ctx, y)
+    sigmas = get_sigmas(pred, "Euler", steps)
+    x = pred.noise_scaling(sigmas[0], x, torch.zeros_like(x))
+    return sampling.sample_euler(lambda xx, s: cfg_denoise_general(model_fn, xx, s, uncond, cond, comp, cfg_scale, options), x, sigmas, noise_fn=rng.next)

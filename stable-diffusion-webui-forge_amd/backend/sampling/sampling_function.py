@@ -5,7 +5,9 @@ The reference decides per step, from a free-memory query, whether cond and uncon
 on a 288 GB part they always do, so the batch is always [uncond ; cond] (the order the reference produces, :187-229)
 and the whole step -- input scaling, UNet, `x - eps*sigma`, area-weighted average (weights 1 over counts 1+1e-37) and
 `uncond + (cond - uncond) * cond_scale` -- runs as: one pack kernel, one UNet graph, one combine kernel.
-Python hooks in model_options['transformer_options'] (`patches`, `patches_replace`, `block_modifiers`) are handed to the UNet
+One cond at strength 1 takes that fused path; AND-composed prompts (several conds with strengths), `model_function_wrapper` and the
+sampler_pre_cfg / sampler_cfg / sampler_post_cfg / conditioning_modifiers hooks take the general path below (one stacked model call,
+weighted averaging, the reference's CFG formula with edit strength).  Python hooks in model_options['transformer_options'] (`patches`, `patches_replace`, `block_modifiers`) are handed to the UNet
 executor, which then runs eagerly.  Features that would need several UNet calls per step (regional `area` conds, masks, per-cond
 timestep ranges, c_concat) are rejected explicitly.
 """
@@ -15,41 +17,125 @@ import torch
 
 from .condition import compile_conditions, compile_weighted_conditions
 
-_UNSUPPORTED_OPTS = ("model_function_wrapper", "sampler_cfg_function", "sampler_pre_cfg_function",
-                     "sampler_post_cfg_function", "conditioning_modifiers")
-
-
 def _single(conds, what):
-    if len(conds) != 1:
-        raise NotImplementedError(f"{what}: composable / AND prompts need several UNet passes per step; not on the native path")
     c = conds[0]
-    for k in ("area", "mask", "timestep_start", "timestep_end"):
-        if k in c:
-            raise NotImplementedError(f"{what}: '{k}' conditioning is not supported by the native path")
-    if not math.isclose(c.get("strength", 1.0), 1.0):
-        raise NotImplementedError("prompt weights != 1 change the CFG formula (edit_strength); not on the native path")
     mc = c["model_conds"]
     return mc["c_crossattn"].cond, (mc["y"].cond if "y" in mc else None), (mc["guidance"].cond if "guidance" in mc else None)
 
 
-def calc_cond_uncond_batch(model, cond, uncond, x_in, timestep, model_options, cond_scale=1.0):
-    """-> (cfg_result, cond_pred, uncond_pred).  Unlike the reference (:154) the CFG combine is fused in, because the
-    per-half outputs only exist inside the combine kernel; both halves are still returned."""
-    cctx = _single(cond, "cond")
-    uctx = _single(uncond, "uncond") if uncond is not None else None
-    return model.denoise_cfg(x_in, timestep, uctx, cctx, cond_scale, want_parts=True, transformer_options=model_options.get("transformer_options"),
-                             control_model=cond[0].get("control"))
+def _check_supported(conds, what):
+    for c in conds:
+        for k in ("area", "mask", "timestep_start", "timestep_end"):
+            if k in c:
+                raise NotImplementedError(f"{what}: regional / time-ranged conditioning ('{k}') is not on the native path")
+        if "c_concat" in c["model_conds"]:
+            raise NotImplementedError("c_concat (inpainting-model conditioning) is not on the native path")
+
+
+def _fused_ok(model, cond, uncond, model_options):
+    """One cond at strength 1 (+ at most one uncond), nothing wrapping the model call: the fused pack -> UNet graph -> combine path."""
+    return (len(cond) == 1 and math.isclose(cond[0].get("strength", 1.0), 1.0) and (uncond is None or len(uncond) == 1)
+            and "model_function_wrapper" not in model_options and hasattr(model, "denoise_cfg"))
+
+
+def _general_cond_uncond_batch(model, cond, uncond, x_in, timestep, model_options):
+    """calc_cond_uncond_batch (sampling_function.py:154-288) for any number of conds / unconds with strengths (AND-composed prompts) and for
+    `model_function_wrapper`: every entry covers the whole batch, all of them go through ONE model call stacked in the reference's order
+    ([uncond..., cond_K-1, ..., cond_0], :187-229), outputs are averaged with weights = strengths (the accumulators of :155-159)."""
+    from ...k_diffusion.sampling import _sigma_vec  # noqa: F401  (SigmaInfo carrier)
+    from ..modules.k_model import SigmaInfo, host_sigmas
+    entries = [(c, 0) for c in cond] + [(u, 1) for u in (uncond or [])]
+    entries.reverse()
+    n = len(entries)
+    crossattn = [e["model_conds"]["c_crossattn"] for e, _ in entries]
+    ctx = crossattn[0].concat(crossattn[1:])
+    ys = [e["model_conds"]["y"].cond for e, _ in entries if "y" in e["model_conds"]]
+    y = torch.cat(ys) if ys else None
+    cond_or_uncond = [cu for _, cu in entries]
+    b = x_in.shape[0]
+    input_x = torch.cat([x_in] * n)
+    timestep_ = torch.cat([timestep] * n)
+    timestep_.fmx_sigma = SigmaInfo(list(host_sigmas(timestep)) * n)
+    to = dict(model_options.get("transformer_options", {}))
+    to["cond_or_uncond"] = cond_or_uncond[:]
+    to["sigmas"] = timestep
+    to["cond_mark"] = torch.tensor([float(cu) for cu in cond_or_uncond for _ in range(b)], dtype=timestep.dtype, device=timestep.device)
+    to["cond_indices"] = [i * b + j for i, cu in enumerate(cond_or_uncond) if cu == 0 for j in range(b)]
+    to["uncond_indices"] = [i * b + j for i, cu in enumerate(cond_or_uncond) if cu != 0 for j in range(b)]
+    c = {"c_crossattn": ctx, "transformer_options": to}
+    if y is not None:
+        c["y"] = y
+    control = entries[0][0].get("control")
+    if control is not None:
+        p = control
+        while p is not None:
+            p.transformer_options = to
+            p = p.previous_controlnet
+        c["control"] = control.get_control(input_x, timestep_, dict(c), n)
+        c["control_model"] = control
+    if "model_function_wrapper" in model_options:
+        output = model_options["model_function_wrapper"](model.apply_model, {"input": input_x, "timestep": timestep_, "c": c,
+                                                                            "cond_or_uncond": cond_or_uncond})
+    else:
+        output = model.apply_model(input_x, timestep_, **c)
+    chunks = output.chunk(n)
+    outs = {0: [], 1: []}
+    for (e, cu), o in zip(entries, chunks):
+        outs[cu].append((float(e.get("strength", 1.0)), o))
+
+    def average(items):
+        if not items:
+            return torch.zeros_like(x_in) / 1e-37  # zero accumulator over the 1e-37 count (:155-159, 284-288)
+        total = sum(w for w, _ in items) + 1e-37
+        return ops_lincomb([o.contiguous() for _, o in items], [w / total for w, _ in items])
+    return average(outs[0]), average(outs[1])
+
+
+def ops_lincomb(srcs, coefs):
+    from ... import hipops as ops
+    return ops.lincomb(srcs, coefs)
+
+
+def calc_cond_uncond_batch(model, cond, uncond, x_in, timestep, model_options, cond_scale=None):
+    """-> (cond_pred, uncond_pred) as the reference (:154); on the fused path the CFG combine happens in the same kernel and the combined
+    result is returned as a third value when `cond_scale` is given."""
+    _check_supported(cond, "cond")
+    if uncond is not None:
+        _check_supported(uncond, "uncond")
+    if cond_scale is not None and _fused_ok(model, cond, uncond, model_options):
+        cctx = _single(cond, "cond")
+        uctx = _single(uncond, "uncond") if uncond is not None else None
+        return model.denoise_cfg(x_in, timestep, uctx, cctx, cond_scale, want_parts=True, transformer_options=model_options.get("transformer_options"),
+                                 control_model=cond[0].get("control"))
+    cond_pred, uncond_pred = _general_cond_uncond_batch(model, cond, uncond, x_in, timestep, model_options)
+    return None, cond_pred, uncond_pred
 
 
 def sampling_function_inner(model, x, timestep, uncond, cond, cond_scale, model_options={}, seed=None, return_full=False):
-    for k in _UNSUPPORTED_OPTS:
-        if model_options.get(k):
-            raise NotImplementedError(f"model_options['{k}'] is not supported by the native path")
+    """:292-322, including the sampler_pre_cfg / sampler_cfg / sampler_post_cfg function hooks and the edit-strength form of the CFG
+    formula for AND-composed prompts."""
+    from ... import hipops as ops
+    edit_strength = sum((item["strength"] if "strength" in item else 1) for item in cond)
     if math.isclose(cond_scale, 1.0) and not model_options.get("disable_cfg1_optimization", False):
         uncond_ = None  # :295-298
     else:
         uncond_ = uncond
-    cfg_result, cond_pred, uncond_pred = calc_cond_uncond_batch(model, cond, uncond_, x, timestep, model_options, cond_scale)
+    for fn in model_options.get("sampler_pre_cfg_function", []):
+        model, cond, uncond_, x, timestep, model_options = fn(model, cond, uncond_, x, timestep, model_options)
+    custom_cfg = "sampler_cfg_function" in model_options
+    fused_scale = None if (custom_cfg or not math.isclose(edit_strength, 1.0)) else cond_scale
+    cfg_result, cond_pred, uncond_pred = calc_cond_uncond_batch(model, cond, uncond_, x, timestep, model_options, fused_scale)
+    if custom_cfg:
+        args = {"cond": x - cond_pred, "uncond": x - uncond_pred, "cond_scale": cond_scale, "timestep": timestep, "input": x, "sigma": timestep,
+                "cond_denoised": cond_pred, "uncond_denoised": uncond_pred, "model": model, "model_options": model_options}
+        cfg_result = x - model_options["sampler_cfg_function"](args)
+    elif cfg_result is None:
+        k = cond_scale * edit_strength if not math.isclose(edit_strength, 1.0) else cond_scale
+        cfg_result = ops.lincomb([uncond_pred.contiguous(), cond_pred.contiguous()], [1.0 - k, k])  # uncond + (cond - uncond) * k
+    for fn in model_options.get("sampler_post_cfg_function", []):
+        args = {"denoised": cfg_result, "cond": cond, "uncond": uncond, "model": model, "uncond_denoised": uncond_pred, "cond_denoised": cond_pred,
+                "sigma": timestep, "model_options": model_options, "input": x}
+        cfg_result = fn(args)
     if return_full:
         return cfg_result, cond_pred, uncond_pred
     return cfg_result
@@ -74,8 +160,10 @@ def sampling_function(self, denoiser_params, cond_scale, cond_composition):
         if uncond is not None:
             for h in uncond:
                 h["control"] = control
-    return sampling_function_inner(model, x, timestep, uncond, cond, cond_scale, unet_patcher.model_options,
-                                   self.p.seeds[0], return_full=True)
+    model_options, seed = unet_patcher.model_options, self.p.seeds[0]
+    for modifier in model_options.get("conditioning_modifiers", []):  # :359-360
+        model, x, timestep, uncond, cond, cond_scale, model_options, seed = modifier(model, x, timestep, uncond, cond, cond_scale, model_options, seed)
+    return sampling_function_inner(model, x, timestep, uncond, cond, cond_scale, model_options, seed, return_full=True)
 
 
 def sampling_prepare(unet, x):

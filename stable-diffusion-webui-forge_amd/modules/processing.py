@@ -213,9 +213,12 @@ class StableDiffusionProcessingImg2Img(StableDiffusionProcessingTxt2Img):
 
 
 def _slice_cond(c, a, b):
+    from .prompt_parser import MulticondLearnedConditioning
     if isinstance(c, dict):
         return type(c)({k: v[a:b] for k, v in c.items()})
-    return c[a:b]
+    if isinstance(c, MulticondLearnedConditioning):
+        return MulticondLearnedConditioning((b - a,), c.batch[a:b])
+    return c[a:b]  # tensor, or list of per-image schedules
 
 
 def process_images(p) -> Processed:

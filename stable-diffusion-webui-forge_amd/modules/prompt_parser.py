@@ -1,7 +1,11 @@
-"""The conditioning object shapes of modules/prompt_parser.py that the denoiser consumes (:271-365), for prompts
-without scheduling: `reconstruct_cond_batch` / `reconstruct_multicond_batch` accept either ready tensors
-(`[B,T,D]` or `DictWithShape{crossattn, vector}`) or the reference's scheduled lists, whose schedule is resolved per
-step.  Text encoding itself is out of scope; BASELINE configs use synthetic cond tensors."""
+"""The conditioning objects of modules/prompt_parser.py that the denoiser consumes (:129-147, :233-242, :271-365):
+`ScheduledPromptConditioning` lists (prompt editing: the cond changes at given steps), `MulticondLearnedConditioning` (AND-composed
+prompts: several weighted conds per image) and their per-step resolution `reconstruct_cond_batch` / `reconstruct_multicond_batch` /
+`stack_conds`.  Ready tensors (`[B,T,D]` or `DictWithShape{crossattn, vector}`) are accepted wherever a schedule is, standing for plain
+prompts.  The string side (the `[from:to:when]` / `AND` / `(emphasis:1.2)` grammars, :26-127, :205-230) is host text processing outside
+the path: schedules and weights arrive here already parsed."""
+from collections import namedtuple
+
 import torch
 
 
@@ -26,21 +30,127 @@ class DictWithShape(dict):
         return DictWithShape({k: v[item] for k, v in self.items()})
 
 
+ScheduledPromptConditioning = namedtuple("ScheduledPromptConditioning", ["end_at_step", "cond"])  # prompt_parser.py:129
+
+
+class ComposableScheduledPromptConditioning:
+    """One AND-part of a prompt: its schedule and its weight (:233-236)."""
+
+    def __init__(self, schedules, weight=1.0):
+        self.schedules = schedules
+        self.weight = weight
+
+
+class MulticondLearnedConditioning:
+    """:239-242; `shape` lets the object stand where a tensor is expected (DDIM / PLMS look at it)."""
+
+    def __init__(self, shape, batch):
+        self.shape = shape
+        self.batch = batch
+
+
+class SdConditioning(list):
+    """:132-147: prompts (or token batches) + the side information SDXL's conditioner needs."""
+
+    def __init__(self, prompts, is_negative_prompt=False, width=None, height=None, copy_from=None, distilled_cfg_scale=None):
+        super().__init__()
+        self.extend(prompts)
+        if copy_from is None:
+            copy_from = prompts
+        self.is_negative_prompt = is_negative_prompt or getattr(copy_from, "is_negative_prompt", False)
+        self.width = width or getattr(copy_from, "width", None)
+        self.height = height or getattr(copy_from, "height", None)
+        self.distilled_cfg_scale = distilled_cfg_scale or getattr(copy_from, "distilled_cfg_scale", None)
+
+
 def _as_cond(c):
     if isinstance(c, dict) and not isinstance(c, DictWithShape):
         return DictWithShape(c)
     return c
 
 
+def _pick(schedule, current_step):
+    """index of the first entry whose end_at_step has not passed (:305-309, :346-350); 0 when all have."""
+    for current, entry in enumerate(schedule):
+        if current_step <= entry.end_at_step:
+            return current
+    return 0
+
+
+_memo = {}  # id(schedule object) -> (object, chosen indices, result): the SAME tensors are handed out while the choice is unchanged, so the
+            # executor's per-conditioning K/V cache and captured graph (keyed on tensor identity) survive between schedule switches
+
+
+def _memoised(obj, chosen, build):
+    hit = _memo.get(id(obj))
+    if hit is not None and hit[0] is obj and hit[1] == chosen:
+        return hit[2]
+    if len(_memo) > 16:
+        _memo.clear()
+    res = build()
+    _memo[id(obj)] = (obj, chosen, res)
+    return res
+
+
 def reconstruct_cond_batch(c, current_step):
-    """:294-318 -- for plain (unscheduled) conds the tensor itself."""
+    """:294-318.  Ready tensors / dicts (no schedule) pass through; a list of per-image schedules is resolved for `current_step`."""
     if isinstance(c, (torch.Tensor, dict)):
         return _as_cond(c)
-    raise NotImplementedError("scheduled prompt lists need the text encoders (out of scope); pass cond tensors")
+    chosen = tuple(_pick(sched, current_step) for sched in c)
+    return _memoised(c, chosen, lambda: _reconstruct_cond_batch(c, current_step))
+
+
+def _reconstruct_cond_batch(c, current_step):
+    param = c[0][0].cond
+    if isinstance(param, dict):
+        res = DictWithShape({k: torch.zeros((len(c),) + v.shape, device=v.device, dtype=v.dtype) for k, v in param.items()})
+    else:
+        res = torch.zeros((len(c),) + param.shape, device=param.device, dtype=param.dtype)
+    for i, cond_schedule in enumerate(c):
+        chosen = cond_schedule[_pick(cond_schedule, current_step)].cond
+        if isinstance(param, dict):
+            for k, v in chosen.items():
+                res[k][i] = v
+        else:
+            res[i] = chosen
+    return res
+
+
+def stack_conds(tensors):
+    """:321-334: prompts of different chunk counts are padded by repeating their last token vector."""
+    tensors = list(tensors)
+    token_count = max(x.shape[0] for x in tensors)
+    for i in range(len(tensors)):
+        if tensors[i].shape[0] != token_count:
+            last_vector = tensors[i][-1:]
+            tensors[i] = torch.vstack([tensors[i], last_vector.repeat([token_count - tensors[i].shape[0], 1])])
+    return torch.stack(tensors)
 
 
 def reconstruct_multicond_batch(c, current_step):
-    """:337-365 -- returns (conds_list, cond): one (index, weight=1.0) entry per image for plain prompts."""
-    cond = reconstruct_cond_batch(c, current_step)
-    b = cond["crossattn"].shape[0] if isinstance(cond, dict) else cond.shape[0]
-    return [[(i, 1.0)] for i in range(b)], cond
+    """:337-365 -> (conds_list, stacked conds).  conds_list[i] = [(row of the stacked tensor, weight), ...] for image i: one entry per
+    AND-part.  Ready tensors / dicts stand for plain prompts: one (i, 1.0) entry per image."""
+    if isinstance(c, (torch.Tensor, dict)):
+        cond = _as_cond(c)
+        b = cond["crossattn"].shape[0] if isinstance(cond, dict) else cond.shape[0]
+        return [[(i, 1.0)] for i in range(b)], cond
+    if isinstance(c, list):  # a plain list of per-image schedules (what the reference builds for the NEGATIVE prompt): one part per image
+        return [[(i, 1.0)] for i in range(len(c))], reconstruct_cond_batch(c, current_step)
+    chosen = tuple(_pick(part.schedules, current_step) for parts in c.batch for part in parts)
+    return _memoised(c, chosen, lambda: _reconstruct_multicond_batch(c, current_step))
+
+
+def _reconstruct_multicond_batch(c, current_step):
+    param = c.batch[0][0].schedules[0].cond
+    tensors, conds_list = [], []
+    for composable_prompts in c.batch:
+        conds_for_batch = []
+        for part in composable_prompts:
+            conds_for_batch.append((len(tensors), part.weight))
+            tensors.append(part.schedules[_pick(part.schedules, current_step)].cond)
+        conds_list.append(conds_for_batch)
+    if isinstance(tensors[0], dict):
+        stacked = DictWithShape({k: stack_conds([x[k] for x in tensors]) for k in tensors[0].keys()})
+    else:
+        stacked = stack_conds(tensors).to(device=param.device, dtype=param.dtype)
+    return conds_list, stacked

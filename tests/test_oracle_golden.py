@@ -233,3 +233,23 @@ def test_controlnet_restated(name):
     c, uc = synth.synth_conditioning(2, cfg["context_dim"], cfg.get("adm_in_channels"), seed=1234)
     lat = pipeline.txt2img_latents_controlnet(sd, cfg, c, uc, g["euler4"]["seeds"], g["hw"] * 8, g["hw"] * 8, 4, chain)
     assert max_rel(lat, g["euler4"]["latent"]) < 2e-4
+
+
+@pytest.mark.parametrize("name", list(TINY))
+def test_general_cfg_paths_restated(name):
+    """oracle/cfg.py cfg_denoise_general vs the reference's sampling_function: AND-composed prompts (edit strength), the three cfg
+    function hooks, model_function_wrapper."""
+    from oracle.make_golden import cfg_hooks_fixture, multicond_case
+    cfg = TINY[name]
+    g = load_golden(f"{name}_cfg_paths.pt")
+    sd = synth.synth_unet_state_dict(cfg, seed=0)
+    c4, uc, comp = multicond_case(cfg)
+    c1, _ = synth.synth_conditioning(2, cfg["context_dim"], cfg.get("adm_in_channels"), seed=1234)
+    hooks = cfg_hooks_fixture()
+    size = g["hw"] * 8
+    cases = {"and_composed": (c4, comp, None), "plain": (c1, None, None),
+             "cfg_functions": (c1, None, {k: hooks[k] for k in ("sampler_cfg_function", "sampler_post_cfg_function", "sampler_pre_cfg_function")}),
+             "model_function_wrapper": (c1, None, {"model_function_wrapper": hooks["model_function_wrapper"]})}
+    for key, (cond, composition, options) in cases.items():
+        lat = pipeline.txt2img_latents_general_cfg(sd, cfg, cond, uc, composition, g["seeds"], size, size, 3, 5.0, options)
+        assert max_rel(lat, g[key]) < 2e-4, key
