@@ -77,6 +77,13 @@ class KModel:
             # ControlNet residuals change every step and Python hooks cannot be captured: eager, not graph replay
             return net.forward_packed(st["xcol"], st["t"], ctxc, bu, hh, ww, control, hooks)
         g = self._graphs.get(key)
+        if g is not None and st.get("arena_epoch") != net.arena_epoch:
+            # the executor re-allocated its arena since this graph was captured (a larger shape came through, e.g. the hires pass):
+            # the graph's kernels point into freed memory -- drop it and capture again on the current arena
+            g.destroy()
+            del self._graphs[key]
+            st["warm"] = 0
+            g = None
         if g is None:
             # eager warm-up (sizes the arena, creates lazily-built buffers), then capture on a side stream
             eps = net.forward_packed(st["xcol"], st["t"], ctxc, bu, hh, ww)
@@ -95,6 +102,7 @@ class KModel:
             cur.wait_stream(s)
             self._graphs[key] = g
             st["ctx_key"] = ctxc.key
+            st["arena_epoch"] = net.arena_epoch
             return st["eps"]
         if st.get("ctx_key") != ctxc.key:
             # new conditioning re-uses the same cached K/V buffers only if shapes match; simplest safe policy: recapture

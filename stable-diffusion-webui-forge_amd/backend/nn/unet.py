@@ -89,6 +89,7 @@ class IntegratedUNet2DConditionModel:
         self.out_channels = self.layout.out_channels
         self.num_classes = config.get("num_classes")
         self._arena = None
+        self.arena_epoch = 0  # bumped whenever the arena is re-allocated: graphs captured on the old one hold dangling pointers
         self._arena_bytes = arena_bytes
         self._ctx = ContextCache()
         self._load(state_dict)
@@ -515,8 +516,10 @@ class IntegratedUNet2DConditionModel:
     def _get_arena(self, bu, hh, ww):
         need = self._arena_bytes or max(1 << 28, 40 * bu * hh * ww * self.layout.model_channels * 2)
         if self._arena is None or self._arena.capacity < need:
+            torch.cuda.synchronize(self.device)  # nothing may still be running out of the arena that is about to be freed
             self._arena = None
             self._arena = Arena(need, self.device)
+            self.arena_epoch += 1
         return self._arena
 
     def forward_packed(self, xcol, t, ctxc, bu, hh, ww, control=None, transformer_options=None):
@@ -532,6 +535,7 @@ class IntegratedUNet2DConditionModel:
                 torch.cuda.synchronize(self.device)
                 self._arena_bytes = arena.capacity * 2
                 self._arena = None
+                self.arena_epoch += 1
 
     @staticmethod
     def _hooks(transformer_options):

@@ -61,6 +61,24 @@ def compile_conditions(cond):
     return [dict(cross_attn=cross_attn, pooled_output=pooled, model_conds=mc)]
 
 
+_gather_cache = {}  # (crossattn data_ptr, shape, rows) -> gathered cond: AND-composed prompts gather the same rows every step; handing out the
+                    # SAME tensors keeps the executor's per-conditioning K/V cache and captured graph valid from step to step
+
+
+def _gather(cond, idx):
+    ca = cond["crossattn"] if isinstance(cond, dict) else cond
+    key = (ca.data_ptr(), tuple(ca.shape), tuple(idx))
+    hit = _gather_cache.get(key)
+    if hit is not None and hit[0] is ca:
+        return hit[1]
+    if len(_gather_cache) > 32:
+        _gather_cache.clear()
+    feed = cond.advanced_indexing(idx) if hasattr(cond, "advanced_indexing") else (
+        {k: v[idx] for k, v in cond.items()} if isinstance(cond, dict) else cond[idx])
+    _gather_cache[key] = (ca, feed)
+    return feed
+
+
 def compile_weighted_conditions(cond, weights):
     transposed = list(map(list, zip(*weights)))
     results = []
@@ -76,8 +94,7 @@ def compile_weighted_conditions(cond, weights):
             # identity stable across steps, which is what the per-conditioning K/V cache and the HIP graph key on.
             feed = cond
         else:
-            feed = cond.advanced_indexing(idx) if hasattr(cond, "advanced_indexing") else (
-                {k: v[idx] for k, v in cond.items()} if isinstance(cond, dict) else cond[idx])
+            feed = _gather(cond, idx)
         h = compile_conditions(feed)
         h[0]["strength"] = weight
         results += h

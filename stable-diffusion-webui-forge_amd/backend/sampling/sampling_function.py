@@ -48,9 +48,17 @@ def _general_cond_uncond_batch(model, cond, uncond, x_in, timestep, model_option
     entries.reverse()
     n = len(entries)
     crossattn = [e["model_conds"]["c_crossattn"] for e, _ in entries]
-    ctx = crossattn[0].concat(crossattn[1:])
     ys = [e["model_conds"]["y"].cond for e, _ in entries if "y" in e["model_conds"]]
-    y = torch.cat(ys) if ys else None
+    # the stacked conditioning is the same tensor as long as its parts are (their identity is stable across steps, see condition._gather /
+    # prompt_parser._memoised), so the UNet's context cache and the captured graph of this batch size stay valid
+    key = tuple((c.cond.data_ptr(), tuple(c.cond.shape)) for c in crossattn) + tuple((t.data_ptr(), tuple(t.shape)) for t in ys)
+    cached = getattr(model, "_general_ctx", None)
+    if cached is not None and cached[0] == key:
+        ctx, y = cached[1], cached[2]
+    else:
+        ctx = crossattn[0].concat(crossattn[1:])
+        y = torch.cat(ys) if ys else None
+        model._general_ctx = (key, ctx, y, crossattn, ys)
     cond_or_uncond = [cu for _, cu in entries]
     b = x_in.shape[0]
     input_x = torch.cat([x_in] * n)

@@ -292,6 +292,30 @@ def test_prediction_types_vs_reference_fixture(ptype):
     report(f"tiny_sd15 {ptype} 4-step Euler vs reference", max_rel(processing.process_images(p).latents, g[("euler4", ptype)]), 1e-2)
 
 
+def test_graph_survives_arena_reallocation():
+    """A captured UNet graph points into the executor's activation arena.  When a larger shape comes through later (hires second pass, a
+    bigger batch) the arena is re-allocated; the old graph must be dropped and re-captured, not replayed on freed memory."""
+    cfg = TINY["tiny_sd15"]
+    eng = build_engine(cfg, synth.synth_unet_state_dict(cfg, seed=0), None, None, device=DEV)
+    net = eng.forge_objects.unet.model.diffusion_model
+    net._arena_bytes = 6 << 20   # small on purpose: the 16x16-latent job fits, the 48x48 one overflows and forces a re-allocation
+    shared.opts.randn_source = "CPU"
+    c, uc = _conds(cfg, 2)
+
+    def run(size, steps=5):
+        p = processing.StableDiffusionProcessingTxt2Img(sd_model=eng, c=c, uc=uc, seed=3, sampler_name="Euler", batch_size=2, steps=steps, cfg_scale=7.0,
+                                                        width=size, height=size, do_decode=False)
+        return processing.process_images(p).latents.clone()
+    first = run(128)            # warm-up, capture, replay on the small arena
+    epoch = net.arena_epoch
+    big = run(384)
+    assert net.arena_epoch > epoch, "the larger job was expected to outgrow the arena"
+    junk = [torch.randn(1 << 22, device=DEV) for _ in range(8)]  # recycle whatever the old arena's memory became
+    again = run(128)
+    del junk
+    assert torch.isfinite(big).all() and torch.equal(first, again)
+
+
 def test_latent_resize_kernel_vs_torch_interpolate():
     import torch.nn.functional as F
     from forge_amd.modules import latent_upscale
