@@ -88,9 +88,12 @@ class Predictor:
         return noise + latent_image
 
 
-def apply_model(unet_fn, predictor, x, sigma, context, y=None):
-    """k_model.py:25-46 with fp32 computation dtype: eps-net call wrapped in input/denoised algebra."""
+def apply_model(unet_fn, predictor, x, sigma, context, y=None, c_concat=None):
+    """k_model.py:25-46 with fp32 computation dtype: eps-net call wrapped in input/denoised algebra.  c_concat (inpainting / edit
+    models, :38-39) is concatenated AFTER the input scaling, i.e. unscaled."""
     xc = predictor.calculate_input(sigma, x)
+    if c_concat is not None:
+        xc = torch.cat([xc, c_concat], dim=1)
     t = predictor.timestep(sigma).float()
     eps = unet_fn(xc, t, context, y).float()
     return predictor.calculate_denoised(sigma, eps, x)

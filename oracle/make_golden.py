@@ -1015,6 +1015,42 @@ def gen_cfg_paths(name, cfg, net, b=2, hw=16):
     torch.save(res, os.path.join(GOLD, f"{name}_cfg_paths.pt"))
 
 
+def inpaint_case(b=2, hw=16, seed=31):
+    g = torch.Generator().manual_seed(seed)
+    mask = (torch.rand(b, 1, hw, hw, generator=g) > 0.5).float()
+    return torch.cat([mask, torch.randn(b, 4, hw, hw, generator=g)], dim=1)  # [mask | masked-image latent]
+
+
+def gen_inpaint_model(b=2, hw=16):
+    """Inpainting UNet (in_channels 9) in the reference: forward on the concatenated input, KModel-level c_concat via sampling_function's
+    image_cond, 3 Euler steps."""
+    ref = ref_import.load_reference()
+    cfg = synth.TINY_SD15_INPAINT_UNET_CONFIG
+    net = ref_import.build_ref_unet(cfg, synth.synth_unet_state_dict(cfg, seed=0))
+    fx = torch.load(os.path.join(GOLD, "tiny_sd15_unet_fwd.pt"))
+    ic = inpaint_case(b, hw)
+    with torch.no_grad():
+        eps = net(torch.cat([fx["x"], ic], dim=1), fx["t"], context=fx["ctx"], y=None)
+    pred = ref_import.build_ref_predictor()
+    c, uc = synth.synth_conditioning(b, cfg["context_dim"], None, seed=1234)
+    seeds = [1000 + i for i in range(b)]
+    den = ref_import.RefDenoiser(net, pred, seeds)
+    rng = ImageRNG((4, hw, hw), seeds, "CPU")
+    x = rng.next()
+    sigmas = den.inner_model.get_sigmas(3)
+    x = pred.noise_scaling(sigmas[0], x, torch.zeros_like(x), max_denoise=False)
+    ref.kd_sampling.torch = _Hijack(rng)
+    ref.sampling_function.sampling_prepare(den.patcher, x=x)
+    try:
+        lat = ref.kd_sampling.sample_euler(den, x, sigmas, extra_args={"cond": c, "uncond": uc, "cond_scale": 7.0, "s_min_uncond": 0.0, "image_cond": ic},
+                                           disable=True)
+    finally:
+        ref.kd_sampling.torch = torch
+        ref.sampling_function.sampling_cleanup(den.patcher)
+    torch.save({"eps": eps, "euler3": lat, "seeds": seeds, "hw": hw}, os.path.join(GOLD, "tiny_sd15_inpaint_model.pt"))
+    print("inpaint model: eps std", float(eps.std()), "euler3 std", float(lat.std()))
+
+
 def gen_schedulers():
     """modules/sd_schedulers.py's table, imported from the reference with a two-attribute stand-in for modules.shared."""
     import importlib.util
@@ -1222,6 +1258,8 @@ def main():
         net, _ = gen_unet("tiny_sd15", synth.TINY_SD15_UNET_CONFIG)
         gen_samples_extra("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
         gen_samples_more("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
+    if a.only in ("", "tiny", "inpaint"):
+        gen_inpaint_model()
     if a.only == "cfgpaths":
         for nm, cf in (("tiny_sd15", synth.TINY_SD15_UNET_CONFIG), ("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG)):
             net, _ = gen_unet(nm, cf)

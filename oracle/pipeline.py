@@ -205,3 +205,20 @@ def txt2img_latents_general_cfg(unet_sd, unet_cfg, cond, uncond, composition, se
     sigmas = get_sigmas(pred, "Euler", steps)
     x = pred.noise_scaling(sigmas[0], x, torch.zeros_like(x))
     return sampling.sample_euler(lambda xx, s: cfg_denoise_general(model_fn, xx, s, uncond, cond, comp, cfg_scale, options), x, sigmas, noise_fn=rng.next)
+
+
+@torch.no_grad()
+def txt2img_latents_inpaint_model(unet_sd, unet_cfg, cond, uncond, seeds, height, width, steps, image_cond, cfg_scale=7.0):
+    """Euler txt2img on an inpainting UNet (in_channels 9): image_cond [B, 5, h, w] goes to BOTH CFG halves as c_concat
+    (sampling_function.py:342-350) and is concatenated to the scaled latent inside apply_model (k_model.py:38-39)."""
+    pred = Predictor()
+    b = len(seeds)
+    rng = ImageRNG((4, height // 8, width // 8), seeds, "CPU")
+    x = rng.next()
+
+    def model(a, s, c, y):
+        return apply_model(lambda xc, t, cc, yy: unet_forward(unet_sd, unet_cfg, xc, t, cc, yy), pred, a, s, c, y,
+                           c_concat=torch.cat([image_cond] * (a.shape[0] // b)))
+    sigmas = get_sigmas(pred, "Euler", steps)
+    x = pred.noise_scaling(sigmas[0], x, torch.zeros_like(x))
+    return sampling.sample_euler(lambda xx, s: cfg_denoise(model, xx, s, uncond, cond, cfg_scale)[0], x, sigmas, noise_fn=rng.next)

@@ -27,7 +27,7 @@ class ForgeDiffusionEngine:
         self.forge_objects_after_applying_lora = self.forge_objects.shallow_copy()
         self.is_sdxl = is_sdxl
         self.is_sd1 = not is_sdxl
-        self.is_inpaint = False
+        self.is_inpaint = getattr(unet, "concat_channels", 0) == 5  # huggingface_guess `inpaint_model()`: in_channels 9 (base.py:28)
         self.device = unet.device
 
     @torch.inference_mode()

@@ -56,7 +56,7 @@ class KModel:
         t = self.predictor.timestep(torch.tensor(sig_host, dtype=torch.float32)).float()
         return t.repeat(reps)
 
-    def _forward_static(self, key, x, sigma_dev, sig_host, reps, ctxc, control=None, transformer_options=None):
+    def _forward_static(self, key, x, sigma_dev, sig_host, reps, ctxc, control=None, transformer_options=None, c_concat=None):
         """pack -> UNet -> (returns eps view); static buffers per shape so the UNet can be graph-replayed."""
         b, c, hh, ww = x.shape
         bu = reps * b
@@ -73,9 +73,13 @@ class KModel:
             st["t"].copy_(tvals, non_blocking=False)
         net = self.diffusion_model
         hooks = net._hooks(transformer_options)
+        concat_term = net.prepare_concat(c_concat, bu) if c_concat is not None else None  # cached per c_concat tensor: once per job
         if not self.use_graph or control is not None or hooks is not None:
             # ControlNet residuals change every step and Python hooks cannot be captured: eager, not graph replay
-            return net.forward_packed(st["xcol"], st["t"], ctxc, bu, hh, ww, control, hooks)
+            return net.forward_packed(st["xcol"], st["t"], ctxc, bu, hh, ww, control, hooks, concat_term)
+        if st.get("concat_ptr") != (None if concat_term is None else concat_term.data_ptr()) and key in self._graphs:
+            self._graphs.pop(key).destroy()  # the captured graph reads the previous job's concat term
+            st["warm"] = 1
         g = self._graphs.get(key)
         if g is not None and st.get("arena_epoch") != net.arena_epoch:
             # the executor re-allocated its arena since this graph was captured (a larger shape came through, e.g. the hires pass):
@@ -86,7 +90,8 @@ class KModel:
             g = None
         if g is None:
             # eager warm-up (sizes the arena, creates lazily-built buffers), then capture on a side stream
-            eps = net.forward_packed(st["xcol"], st["t"], ctxc, bu, hh, ww)
+            eps = net.forward_packed(st["xcol"], st["t"], ctxc, bu, hh, ww, concat_term=concat_term)
+            st["concat_ptr"] = None if concat_term is None else concat_term.data_ptr()
             st["warm"] += 1
             if st["warm"] < 2:
                 return eps
@@ -97,7 +102,7 @@ class KModel:
             s.wait_stream(cur)
             g = HipGraph()
             with torch.cuda.stream(s):
-                st["eps"] = g.capture(s, lambda: net.forward_packed(st["xcol"], st["t"], ctxc, bu, hh, ww))
+                st["eps"] = g.capture(s, lambda: net.forward_packed(st["xcol"], st["t"], ctxc, bu, hh, ww, concat_term=concat_term))
                 g.launch(s)
             cur.wait_stream(s)
             self._graphs[key] = g
@@ -109,7 +114,7 @@ class KModel:
             g.destroy()
             del self._graphs[key]
             st["warm"] = 1
-            return self._forward_static(key, x, sigma_dev, sig_host, reps, ctxc)
+            return self._forward_static(key, x, sigma_dev, sig_host, reps, ctxc, c_concat=c_concat)
         cur = torch.cuda.current_stream(self.device)
         s = self._stream
         s.wait_stream(cur)
@@ -117,7 +122,8 @@ class KModel:
         cur.wait_stream(s)
         return st["eps"]
 
-    def denoise_cfg(self, x, sigma, uncond_ctx, cond_ctx, cond_scale, want_parts=False, transformer_options=None, control_model=None):
+    def denoise_cfg(self, x, sigma, uncond_ctx, cond_ctx, cond_scale, want_parts=False, transformer_options=None, control_model=None,
+                    c_concat=None):
         """Fused path: returns CFG-combined denoised (fp32 NCHW) [+ cond_pred, uncond_pred].
         `uncond_ctx`/`cond_ctx`: (context [B,T,Dc], y or None); uncond_ctx None => cond_scale == 1 shortcut.
         `transformer_options` with Python hooks: completed with the per-call keys of sampling_function.py:253-257 and run eagerly."""
@@ -152,7 +158,7 @@ class KModel:
             t_all = torch.cat([sigma] * reps)
             t_all.fmx_sigma = SigmaInfo(list(sig_host) * reps)
             control = control_model.get_control(torch.cat([x] * reps), t_all, {"c_crossattn": ctx[0], "y": ctx[1]}, reps)
-        eps = self._forward_static(key, x, sigma, sig_host, reps, ctxc, control=control, transformer_options=transformer_options)
+        eps = self._forward_static(key, x, sigma, sig_host, reps, ctxc, control=control, transformer_options=transformer_options, c_concat=c_concat)
         cond_pred = torch.empty_like(x) if want_parts else None
         uncond_pred = torch.empty_like(x) if want_parts else None
         den = ops.cfg_combine(eps, eps.shape[-1], x, sigma, reps, cond_scale, None, cond_pred, uncond_pred,
@@ -178,13 +184,11 @@ class KModel:
 
     def apply_model(self, x, t, c_concat=None, c_crossattn=None, control=None, transformer_options=None, y=None, **kwargs):
         """Reference signature (k_model.py:25): x fp32 [Bu,C,H,W], t = sigma [Bu] -> denoised fp32."""
-        if c_concat is not None:
-            raise NotImplementedError("c_concat (inpaint-model conditioning) is outside the built path")
         x = x.to(device=self.device, dtype=torch.float32).contiguous()
         sigma = t.to(device=self.device, dtype=torch.float32).contiguous()
         ctxc = self.diffusion_model.prepare_context(c_crossattn, y)
         b, c, hh, ww = x.shape
-        eps = self._forward_static((b, c, hh, ww, 1, "apply"), x, sigma, host_sigmas(t), 1, ctxc, control, transformer_options)
+        eps = self._forward_static((b, c, hh, ww, 1, "apply"), x, sigma, host_sigmas(t), 1, ctxc, control, transformer_options, c_concat)
         return ops.cfg_combine(eps, eps.shape[-1], x, sigma, 1, 1.0, prediction_type=self.predictor.prediction_type,
                                sigma_data=self.predictor.sigma_data)
 

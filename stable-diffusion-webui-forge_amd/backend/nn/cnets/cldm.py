@@ -82,7 +82,7 @@ class ControlNet(IntegratedUNet2DConditionModel):
         return self._guided_hint
 
     # ---- per step ------------------------------------------------------------------------------------------------------------------
-    def _forward_impl(self, xcol, t, ctxc, bu, hh, ww, arena, guided_hint):
+    def _forward_impl(self, xcol, t, ctxc, bu, hh, ww, arena, guided_hint):  # noqa: the ControlNet trunk has its own walk
         lay = self.layout
         t_emb = ops.timestep_embedding(t, lay.model_channels)
         e1 = ops.linear(t_emb, *self.w["te0"])

@@ -116,12 +116,24 @@ class IntegratedUNet2DConditionModel:
         for L in lay.all_layers():
             k = L.key
             if isinstance(L, ConvIn):
-                cw = _conv_w(sd[k + ".weight"].to(dev, torch.float16))  # [mc, 9*cin]
-                if cw.shape[1] > 64:
-                    raise NotImplementedError("in_channels*9 must be <= 64 (im2col'ed first conv)")
-                wp = cw.new_zeros(cw.shape[0], 64)
-                wp[:, :cw.shape[1]] = cw
-                w[k] = (wp.contiguous(), T(k + ".bias"))
+                full = sd[k + ".weight"].to(dev, torch.float16)            # [mc, cin, 3, 3]
+                lc = min(lay.out_channels, L.cin) if L.cin * 9 > 64 else L.cin
+                # inpainting / edit models (in_channels 9 / 8 = latent + c_concat, k_model.py:38-39): the conv is linear in its input
+                # channels, so it is split into the per-step part on the noisy latent and a per-JOB part on the concat conditioning
+                # (prepare_concat), which rides into the first GEMM as its residual operand
+                parts = []
+                for lo, hi in ((0, lc), (lc, L.cin)):
+                    if hi > lo:
+                        cw = _conv_w(full[:, lo:hi].contiguous())               # [mc, 9*(hi-lo)]
+                        if cw.shape[1] > 64:
+                            raise NotImplementedError("each half of the first conv must have 9*channels <= 64 (im2col'ed)")
+                        wp = cw.new_zeros(cw.shape[0], 64)
+                        wp[:, :cw.shape[1]] = cw
+                        parts.append(wp.contiguous())
+                w[k] = (parts[0], T(k + ".bias"))
+                self.latent_channels, self.concat_channels = lc, L.cin - lc
+                if len(parts) > 1:
+                    w[k + ".concat"] = parts[1]
             elif isinstance(L, Res):
                 w[k + ".gn1"] = (T(k + ".in_layers.0.weight"), T(k + ".in_layers.0.bias"))
                 w[k + ".conv1"] = (_conv_w(sd[k + ".in_layers.2.weight"].to(dev, torch.float16)), T(k + ".in_layers.2.bias"))
@@ -434,7 +446,24 @@ class IntegratedUNet2DConditionModel:
                 ops.add_control_(h, ctrl)
         return h
 
-    def _forward_impl(self, xcol, t, ctxc, bu, hh, ww, arena, control=None, to=None):
+    def prepare_concat(self, c_concat, bu):
+        """c_concat [B or Bu, concat_channels, h, w] (mask + masked-image latent of an inpainting model; NOT input-scaled, k_model.py:38-39)
+        -> conv_in's contribution of those channels, fp16 [Bu*h*w, model_channels].  Cached on the tensor's identity: once per job."""
+        key = (c_concat.data_ptr(), tuple(c_concat.shape), bu)
+        hit = getattr(self, "_concat_cache", None)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        if self.concat_channels == 0 or c_concat.shape[1] != self.concat_channels:
+            raise ValueError(f"this UNet takes {self.concat_channels} concat channels, got {tuple(c_concat.shape)}")
+        cc = c_concat.to(device=self.device, dtype=torch.float32)
+        if cc.shape[0] != bu:
+            cc = cc.repeat(bu // cc.shape[0], 1, 1, 1)
+        xl = ops.vae_pack_latent(cc.contiguous(), 1.0, 0.0, ld=8)        # NCHW fp32 -> NHWC fp16 (8-channel rows)
+        term = ops.linear(ops.im2col3x3_smallc(xl, self.concat_channels), self.w[self.layout.input_blocks[0][0].key + ".concat"]).clone()
+        self._concat_cache = (key, term, c_concat)
+        return term
+
+    def _forward_impl(self, xcol, t, ctxc, bu, hh, ww, arena, control=None, to=None, concat_term=None):
         """xcol: [Bu*H*W, 64] im2col of the (scaled) input; t: [Bu] fp32 table indices.  -> eps [Bu*H*W, out_ch].
         `to`: transformer_options with Python hooks (unet.py:696-763 hook points), or None on the fast path."""
         if control is not None:
@@ -464,12 +493,16 @@ class IntegratedUNet2DConditionModel:
             if bi == 0:
                 if modifiers:
                     # the 'before' hook of block 0 sees the network input: the centre tap of the im2col rows (already fp16); re-packed after
+                    if self.concat_channels:
+                        raise NotImplementedError("block modifiers on the input of an inpainting UNet")
                     ci = lay.in_channels
                     x_mod = modify(xcol.view(bu, hh, ww, -1)[..., 4 * ci:5 * ci].contiguous(), "before")
                     xcol = ops.unet_pack_input(x_mod.permute(0, 3, 1, 2).float().contiguous(), torch.zeros(bu, dtype=torch.float32, device=self.device),
                                                1, 1.0)
                 cw, cb = self.w[blk[0].key]
-                h = ops.linear(xcol, cw, cb).view(bu, hh, ww, lay.model_channels)
+                if (concat_term is None) != (self.concat_channels == 0):
+                    raise ValueError("an inpainting / edit UNet needs c_concat (and only such a UNet takes one)")
+                h = ops.linear(xcol, cw, cb, residual=concat_term).view(bu, hh, ww, lay.model_channels)
             else:
                 h = modify(h, "before")
                 h = self._run_block(blk, h, None, emb_all, ctxc, arena, to=to)
@@ -522,7 +555,7 @@ class IntegratedUNet2DConditionModel:
             self.arena_epoch += 1
         return self._arena
 
-    def forward_packed(self, xcol, t, ctxc, bu, hh, ww, control=None, transformer_options=None):
+    def forward_packed(self, xcol, t, ctxc, bu, hh, ww, control=None, transformer_options=None, concat_term=None):
         """Hot-path entry (no layout conversion): returns eps as fp16 [Bu*H*W, out_channels] living in the arena
         (valid until the next forward)."""
         while True:
@@ -530,7 +563,7 @@ class IntegratedUNet2DConditionModel:
             arena.reset()
             try:
                 with arena:
-                    return self._forward_impl(xcol, t, ctxc, bu, hh, ww, arena, control, self._hooks(transformer_options))
+                    return self._forward_impl(xcol, t, ctxc, bu, hh, ww, arena, control, self._hooks(transformer_options), concat_term)
             except ArenaOverflow:
                 torch.cuda.synchronize(self.device)
                 self._arena_bytes = arena.capacity * 2
@@ -557,9 +590,14 @@ class IntegratedUNet2DConditionModel:
         bu, c, hh, ww = x.shape
         ctxc = self.prepare_context(context, y)
         ones = torch.zeros(bu, dtype=torch.float32, device=self.device)  # sigma = 0 -> scale 1/sqrt(0 + 1) = 1
-        xcol = ops.unet_pack_input(x.to(device=self.device, dtype=torch.float32).contiguous(), ones, 1, 1.0)
+        x = x.to(device=self.device, dtype=torch.float32)
+        concat_term = None
+        if self.concat_channels:  # the reference's forward gets latent and concat channels already concatenated
+            concat_term = self.prepare_concat(x[:, self.latent_channels:].contiguous(), bu)
+            x = x[:, :self.latent_channels]
+        xcol = ops.unet_pack_input(x.contiguous(), ones, 1, 1.0)
         eps = self.forward_packed(xcol, timesteps.to(device=self.device, dtype=torch.float32).contiguous(), ctxc, bu, hh, ww, control,
-                                  transformer_options)
+                                  transformer_options, concat_term)
         return eps.view(bu, hh, ww, -1).permute(0, 3, 1, 2).to(x.dtype)
 
     __call__ = forward

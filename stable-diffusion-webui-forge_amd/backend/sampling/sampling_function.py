@@ -9,13 +9,13 @@ One cond at strength 1 takes that fused path; AND-composed prompts (several cond
 sampler_pre_cfg / sampler_cfg / sampler_post_cfg / conditioning_modifiers hooks take the general path below (one stacked model call,
 weighted averaging, the reference's CFG formula with edit strength).  Python hooks in model_options['transformer_options'] (`patches`, `patches_replace`, `block_modifiers`) are handed to the UNet
 executor, which then runs eagerly.  Features that would need several UNet calls per step (regional `area` conds, masks, per-cond
-timestep ranges, c_concat) are rejected explicitly.
+timestep ranges) are rejected explicitly; inpainting-model `c_concat` is carried to the executor, which folds it into the first conv once per job.
 """
 import math
 
 import torch
 
-from .condition import compile_conditions, compile_weighted_conditions
+from .condition import Condition, compile_conditions, compile_weighted_conditions
 
 def _single(conds, what):
     c = conds[0]
@@ -28,8 +28,6 @@ def _check_supported(conds, what):
         for k in ("area", "mask", "timestep_start", "timestep_end"):
             if k in c:
                 raise NotImplementedError(f"{what}: regional / time-ranged conditioning ('{k}') is not on the native path")
-        if "c_concat" in c["model_conds"]:
-            raise NotImplementedError("c_concat (inpainting-model conditioning) is not on the native path")
 
 
 def _fused_ok(model, cond, uncond, model_options):
@@ -73,6 +71,9 @@ def _general_cond_uncond_batch(model, cond, uncond, x_in, timestep, model_option
     c = {"c_crossattn": ctx, "transformer_options": to}
     if y is not None:
         c["y"] = y
+    cc = entries[0][0]["model_conds"].get("c_concat")
+    if cc is not None:
+        c["c_concat"] = cc.cond  # identical for every entry (sampling_function.py:344-350); the executor repeats it over the stacked batch
     control = entries[0][0].get("control")
     if control is not None:
         p = control
@@ -113,8 +114,9 @@ def calc_cond_uncond_batch(model, cond, uncond, x_in, timestep, model_options, c
     if cond_scale is not None and _fused_ok(model, cond, uncond, model_options):
         cctx = _single(cond, "cond")
         uctx = _single(uncond, "uncond") if uncond is not None else None
+        cc = cond[0]["model_conds"].get("c_concat")
         return model.denoise_cfg(x_in, timestep, uctx, cctx, cond_scale, want_parts=True, transformer_options=model_options.get("transformer_options"),
-                                 control_model=cond[0].get("control"))
+                                 control_model=cond[0].get("control"), **({"c_concat": cc.cond} if cc is not None else {}))
     cond_pred, uncond_pred = _general_cond_uncond_batch(model, cond, uncond, x_in, timestep, model_options)
     return None, cond_pred, uncond_pred
 
@@ -154,14 +156,13 @@ def sampling_function(self, denoiser_params, cond_scale, cond_composition):
     unet_patcher = self.inner_model.inner_model.forge_objects.unet
     model = unet_patcher.model
     control = unet_patcher.controlnet_linked_list
-    if unet_patcher.extra_concat_condition is not None:
-        raise NotImplementedError("concat conditioning is outside the native hot path")
-    if isinstance(denoiser_params.image_cond, torch.Tensor) and denoiser_params.image_cond.shape[1:] == denoiser_params.x.shape[1:] \
-            and float(denoiser_params.image_cond.abs().max()) != 0.0:
-        raise NotImplementedError("inpainting-model image conditioning is outside the native hot path")
     x, timestep = denoiser_params.x, denoiser_params.sigma
     uncond = compile_conditions(denoiser_params.text_uncond)
     cond = compile_weighted_conditions(denoiser_params.text_cond, cond_composition)
+    image_cond_in = unet_patcher.extra_concat_condition if unet_patcher.extra_concat_condition is not None else denoiser_params.image_cond
+    if isinstance(image_cond_in, torch.Tensor) and image_cond_in.shape[0] == x.shape[0] and image_cond_in.shape[2:] == x.shape[2:]:
+        for h in (uncond or []) + cond:  # :342-350: inpainting / edit models get the image conditioning as c_concat on both halves
+            h["model_conds"]["c_concat"] = Condition(image_cond_in)
     if control is not None:  # :352-357
         for h in cond:
             h["control"] = control

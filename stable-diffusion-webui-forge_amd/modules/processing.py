@@ -88,8 +88,30 @@ class StableDiffusionProcessingTxt2Img:
     iteration: int = 0
 
     def txt2img_image_conditioning(self, x, width=None, height=None):
-        # processing.py:362-371 -- non-inpaint models get a dummy 1x1 zero conditioning
+        """processing.py:103-119: inpainting models get [all-ones mask | latent of an all-0.5 image]; others a dummy 1x1 zero tensor."""
+        if getattr(self.sd_model, "is_inpaint", False):
+            from .sd_samplers_common import images_tensor_to_samples
+            gray = torch.ones(x.shape[0], 3, height or self.height, width or self.width, device=x.device) * 0.5
+            lat = images_tensor_to_samples(gray, None, self.sd_model)
+            return torch.nn.functional.pad(lat, (0, 0, 0, 0, 1, 0), value=1.0).to(x.dtype).contiguous()
         return x.new_zeros(x.shape[0], 5, 1, 1)
+
+    def inpainting_image_conditioning(self, source_image, latent_image, image_mask=None, round_image_mask=True, inpainting_mask_weight=1.0):
+        """processing.py:320-358: source_image [B, 3, H, W] in [-1, 1], image_mask tensor [1 or B, 1, H, W] in [0, 1] (1 = repaint) ->
+        [mask at latent resolution | latent of the masked image] = the 5 concat channels of an inpainting UNet."""
+        mask = image_mask if image_mask is not None else source_image.new_ones(1, 1, *source_image.shape[-2:])
+        mask = mask.to(device=source_image.device, dtype=source_image.dtype)
+        if round_image_mask and image_mask is not None:
+            mask = torch.round(mask)
+        cond_image = torch.lerp(source_image, source_image * (1.0 - mask), inpainting_mask_weight)
+        cond_image = self.sd_model.encode_first_stage(cond_image)
+        mask = torch.nn.functional.interpolate(mask, size=latent_image.shape[-2:]).expand(cond_image.shape[0], -1, -1, -1)
+        return torch.cat([mask, cond_image], dim=1).contiguous()
+
+    def img2img_image_conditioning(self, source_image, latent_image, image_mask=None, round_image_mask=True):
+        if getattr(self.sd_model, "is_inpaint", False):  # processing.py:360-378
+            return self.inpainting_image_conditioning(source_image.float(), latent_image, image_mask=image_mask, round_image_mask=round_image_mask)
+        return latent_image.new_zeros(latent_image.shape[0], 5, 1, 1)
 
     def calculate_target_resolution(self):
         """processing.py:1246-1273."""
@@ -170,6 +192,7 @@ class StableDiffusionProcessingImg2Img(StableDiffusionProcessingTxt2Img):
     nmask: Any = None
     image_conditioning: Any = None
     mask_noise_source: Any = None      # test hook, see CFGDenoiser.mask_noise_source
+    image_mask: Any = None             # pixel-space mask tensor [1 or B, 1, H, W] for inpainting MODELS (their c_concat), 1 = repaint
 
     def init(self, all_seeds=None):
         """:1684-1842 for tensor inputs: VAE-encode the init images, build mask / nmask at latent resolution."""
@@ -189,7 +212,13 @@ class StableDiffusionProcessingImg2Img(StableDiffusionProcessingTxt2Img):
             self.nmask = latmask            # :1831
             if self.inpainting_fill != 1:
                 raise NotImplementedError("only inpainting_fill == 1 (original) is mirrored")
-        self.image_conditioning = self.init_latent.new_zeros(self.init_latent.shape[0], 5, 1, 1)  # non-inpaint models (:404-406)
+        if getattr(self.sd_model, "is_inpaint", False):  # :1842: conditioning from the (pixel-space) source image and mask
+            if self.init_images is None:
+                raise ValueError("an inpainting model needs init_images (the masked image is VAE-encoded for its conditioning)")
+            self.image_conditioning = self.img2img_image_conditioning(self.init_images.to(dev).float() * 2.0 - 1.0, self.init_latent,
+                                                                      getattr(self, "image_mask", None))
+        else:
+            self.image_conditioning = self.init_latent.new_zeros(self.init_latent.shape[0], 5, 1, 1)  # non-inpaint models (:376-378)
 
     def sample(self, conditioning, unconditional_conditioning, seeds, subseeds=None, subseed_strength=0.0, prompts=None):
         from .. import hipops as ops

@@ -42,6 +42,8 @@ TINY_SD15_UNET_CONFIG = dict(
     context_dim=128, use_linear_in_transformer=False)
 # transformer_depth_output is consumed with pop() from the END (unet.py:649): listed low-res-last.
 
+TINY_SD15_INPAINT_UNET_CONFIG = dict(TINY_SD15_UNET_CONFIG, in_channels=9)  # 4 latent + 1 mask + 4 masked-image latent (sd-v1-5-inpainting)
+
 TINY_SDXL_UNET_CONFIG = dict(
     in_channels=4, model_channels=64, out_channels=4, num_res_blocks=[1, 1], channel_mult=(1, 2),
     num_head_channels=64, use_spatial_transformer=True, transformer_depth=[0, 2],

@@ -292,6 +292,46 @@ def test_prediction_types_vs_reference_fixture(ptype):
     report(f"tiny_sd15 {ptype} 4-step Euler vs reference", max_rel(processing.process_images(p).latents, g[("euler4", ptype)]), 1e-2)
 
 
+def test_inpainting_model_c_concat_vs_reference_fixture():
+    """Inpainting UNet (in_channels 9 = latent + mask + masked-image latent): the conv_in is split into a per-step part on the noisy latent
+    and a per-job part on c_concat (prepare_concat, cached); c_concat reaches both CFG halves via sampling_function's image_cond.  Against
+    the reference UNet fed the concatenated input and the reference sampling_function; then processing's own conditioning builders."""
+    from oracle.make_golden import inpaint_case
+    cfg = synth.TINY_SD15_INPAINT_UNET_CONFIG
+    g, fx = load_golden("tiny_sd15_inpaint_model.pt"), load_golden("tiny_sd15_unet_fwd.pt")
+    vsd = synth.synth_vae_state_dict(synth.TINY_VAE_CONFIG, seed=1)
+    eng = build_engine(cfg, synth.synth_unet_state_dict(cfg, seed=0), synth.TINY_VAE_CONFIG, vsd, device=DEV)
+    assert eng.is_inpaint
+    net = eng.forge_objects.unet.model.diffusion_model
+    ic = inpaint_case().to(DEV)
+    eps = net.forward(torch.cat([fx["x"].to(DEV), ic], dim=1), fx["t"].to(DEV), context=fx["ctx"].to(DEV), y=None)
+    report("inpainting UNet forward (9 input channels) vs reference", max_rel(eps, g["eps"]), 3e-3)
+    shared.opts.randn_source = "CPU"
+    c, uc = _conds(cfg, 2)
+
+    class P(processing.StableDiffusionProcessingTxt2Img):
+        def txt2img_image_conditioning(self, x, width=None, height=None):
+            return ic
+    p = P(sd_model=eng, c=c, uc=uc, seed=g["seeds"][0], sampler_name="Euler", batch_size=2, steps=3, cfg_scale=7.0, width=g["hw"] * 8,
+          height=g["hw"] * 8, do_decode=False)
+    report("inpainting model 3-step Euler (c_concat through sampling_function) vs reference", max_rel(processing.process_images(p).latents, g["euler3"]), 1e-2)
+    # the stock builders: txt2img on an inpainting model conditions on [ones | latent of a 0.5-gray image] (processing.py:103-114)
+    p2 = processing.StableDiffusionProcessingTxt2Img(sd_model=eng, c=c, uc=uc, seed=1, sampler_name="Euler", batch_size=2, steps=2, cfg_scale=7.0, width=32,
+                                                     height=32, do_decode=False)
+    x = torch.zeros(2, 4, 16, 16, device=DEV)  # the tiny VAE downsamples x2: a 32x32 image is a 16x16 latent
+    cond_t2i = p2.txt2img_image_conditioning(x, 32, 32)
+    assert tuple(cond_t2i.shape) == (2, 5, 16, 16) and float(cond_t2i[:, 0].min()) == 1.0
+    src = torch.rand(2, 3, 32, 32, device=DEV) * 2 - 1
+    msk = (torch.rand(1, 1, 32, 32, device=DEV) > 0.5).float()
+    torch.manual_seed(123)  # the VAE encoder samples its posterior from the default CPU generator (nn/vae.py:28)
+    cond_i2i = p2.inpainting_image_conditioning(src, x, image_mask=msk)
+    torch.manual_seed(123)
+    want_lat = eng.encode_first_stage(src * (1.0 - msk))
+    assert tuple(cond_i2i.shape) == (2, 5, 16, 16)
+    assert torch.equal(cond_i2i[:, :1], torch.nn.functional.interpolate(msk, size=(16, 16)).expand(2, -1, -1, -1))
+    assert max_rel(cond_i2i[:, 1:], want_lat) < 1e-5
+
+
 def test_graph_survives_arena_reallocation():
     """A captured UNet graph points into the executor's activation arena.  When a larger shape comes through later (hires second pass, a
     bigger batch) the arena is re-allocated; the old graph must be dropped and re-captured, not replayed on freed memory."""

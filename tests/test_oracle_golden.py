@@ -253,3 +253,16 @@ def test_general_cfg_paths_restated(name):
     for key, (cond, composition, options) in cases.items():
         lat = pipeline.txt2img_latents_general_cfg(sd, cfg, cond, uc, composition, g["seeds"], size, size, 3, 5.0, options)
         assert max_rel(lat, g[key]) < 2e-4, key
+
+
+def test_inpainting_model_restated():
+    """in_channels-9 UNet + c_concat (k_model.py:38-39, sampling_function.py:342-350) vs the reference UNet / sampling_function."""
+    from oracle.make_golden import inpaint_case
+    cfg = synth.TINY_SD15_INPAINT_UNET_CONFIG
+    g, fx = load_golden("tiny_sd15_inpaint_model.pt"), load_golden("tiny_sd15_unet_fwd.pt")
+    sd = synth.synth_unet_state_dict(cfg, seed=0)
+    ic = inpaint_case()
+    torch.testing.assert_close(unet_forward(sd, cfg, torch.cat([fx["x"], ic], dim=1), fx["t"], fx["ctx"], None), g["eps"], rtol=1e-4, atol=1e-5)
+    c, uc = synth.synth_conditioning(2, cfg["context_dim"], None, seed=1234)
+    lat = pipeline.txt2img_latents_inpaint_model(sd, cfg, c, uc, g["seeds"], g["hw"] * 8, g["hw"] * 8, 3, ic)
+    assert max_rel(lat, g["euler3"]) < 2e-4
