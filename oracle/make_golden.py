@@ -334,6 +334,55 @@ def synth_lora(cfg, seed=3, rank=8):
     return sd
 
 
+def synth_lycoris(cfg, seed=8):
+    """A synthetic LyCORIS file for the tiny UNet: LoHa (linear; conv through Tucker cores), LoKr (full x low-rank; conv with a 4-d w2; low-rank
+    w1 with Tucker w2), GLoRA (square and non-square targets), DoRA scales on a plain LoRA / a LoHa / a LoKr (output- and input-axis), and a
+    w_norm / b_norm pair."""
+    from forge_amd.backend.nn.layout import unet_param_shapes
+    shapes = unet_param_shapes(cfg)
+    g = torch.Generator("cpu").manual_seed(seed)
+    rn = lambda *shape, scale=0.1: (torch.randn(*shape, generator=g) * scale).half()
+    sd = {}
+    name = lambda key: "lora_unet_" + key[:-len(".weight")].replace(".", "_")
+    r = 4
+    # LoHa, linear
+    k = "input_blocks.1.1.transformer_blocks.0.attn1.to_v.weight"
+    o, i = shapes[k]
+    sd.update({name(k) + ".hada_w1_a": rn(o, r), name(k) + ".hada_w1_b": rn(r, i), name(k) + ".hada_w2_a": rn(o, r), name(k) + ".hada_w2_b": rn(r, i),
+               name(k) + ".alpha": torch.tensor(2.0)})
+    # LoHa, conv 3x3 with Tucker cores, + DoRA
+    k = "input_blocks.1.0.out_layers.3.weight"
+    o, i, kh, kw = shapes[k]
+    sd.update({name(k) + ".hada_t1": rn(r, r, kh, kw), name(k) + ".hada_w1_a": rn(r, o), name(k) + ".hada_w1_b": rn(r, i),
+               name(k) + ".hada_t2": rn(r, r, kh, kw), name(k) + ".hada_w2_a": rn(r, o), name(k) + ".hada_w2_b": rn(r, i),
+               name(k) + ".alpha": torch.tensor(4.0), name(k) + ".dora_scale": (torch.rand(o, 1, 1, 1, generator=g) + 0.5).half()})
+    # LoKr, linear: full w1 x low-rank w2
+    k = "middle_block.1.transformer_blocks.0.attn2.to_q.weight"
+    o, i = shapes[k]
+    sd.update({name(k) + ".lokr_w1": rn(4, 4, scale=0.3), name(k) + ".lokr_w2_a": rn(o // 4, r), name(k) + ".lokr_w2_b": rn(r, i // 4), name(k) + ".alpha": torch.tensor(2.0)})
+    # LoKr, conv: low-rank w1, full 4-d w2, + DoRA on the input axis
+    k = "output_blocks.4.0.in_layers.2.weight"
+    o, i, kh, kw = shapes[k]
+    sd.update({name(k) + ".lokr_w1_a": rn(8, 2, scale=0.3), name(k) + ".lokr_w1_b": rn(2, 8, scale=0.3), name(k) + ".lokr_w2": rn(o // 8, i // 8, kh, kw),
+               name(k) + ".alpha": torch.tensor(1.0), name(k) + ".dora_scale": (torch.rand(1, i, 1, 1, generator=g) + 0.5).half()})
+    # (LoKr with a Tucker-decomposed w2 is left out: torch.kron rejects the einsum's non-contiguous result in the reference itself, torch 2.10)
+    # GLoRA: square and non-square linear
+    for k in ("input_blocks.3.1.transformer_blocks.0.attn1.to_out.0.weight", "input_blocks.3.1.transformer_blocks.0.attn2.to_k.weight"):
+        o, i = shapes[k]
+        sd.update({name(k) + ".a1.weight": rn(i, r), name(k) + ".a2.weight": rn(r, i), name(k) + ".b1.weight": rn(o, r), name(k) + ".b2.weight": rn(r, i),
+                   name(k) + ".alpha": torch.tensor(2.0)})
+    # DoRA on a plain LoRA
+    k = "output_blocks.2.1.transformer_blocks.0.ff.net.2.weight"
+    o, i = shapes[k]
+    sd.update({name(k) + ".lora_up.weight": rn(o, r), name(k) + ".lora_down.weight": rn(r, i), name(k) + ".alpha": torch.tensor(2.0),
+               name(k) + ".dora_scale": (torch.rand(o, 1, generator=g) + 0.5).half()})
+    # w_norm / b_norm
+    k = "out.0"
+    sd["diffusion_model." + k + ".w_norm"] = rn(*shapes[k + ".weight"], scale=0.02)
+    sd["diffusion_model." + k + ".b_norm"] = rn(*shapes[k + ".bias"], scale=0.02)
+    return sd
+
+
 def gen_lora(name="tiny_sd15", cfg=None):
     """The REAL reference's key map, patch parser and merge (backend/patcher/lora.py:43,19,85; comfyui_lora_collection/lora.py)
     on a synthetic LoRA for the tiny UNet: merged weights of every patched parameter (fp16 weights, fp32 computation)."""
@@ -354,6 +403,15 @@ def gen_lora(name="tiny_sd15", cfg=None):
     for mk, pv in patch_dict.items():
         k = mk[len("diffusion_model."):]
         merged[k] = rl.merge_lora_to_weight([(strength, pv, 1.0, None, None)], sd[k].clone(), key=k, computation_dtype=torch.float32)
+    ly_dict, ly_remaining = rl.load_lora(synth_lycoris(cfg), key_map)
+    ly_merged, ly_kinds = {}, {}
+    for mk, pv in ly_dict.items():
+        k = mk[len("diffusion_model."):]
+        ly_kinds[k] = pv[0]
+        ly_merged[k] = rl.merge_lora_to_weight([(0.7, pv, 1.0, None, None)], sd[k].clone(), key=k, computation_dtype=torch.float32)
+    torch.save({"strength": 0.7, "merged_every_5th": {k: v.flatten()[::5].clone() for k, v in ly_merged.items()}, "kinds": ly_kinds,
+                "remaining": sorted(ly_remaining)}, os.path.join(GOLD, f"{name}_lycoris_merge.pt"))  # a fifth of every merged weight (fixture size)
+    print(name, "lycoris merge:", ly_kinds)
     import hashlib
     km = "\n".join(f"{a}\t{b}" for a, b in sorted(key_map.items()))
     torch.save({"strength": strength, "merged": merged, "remaining": sorted(remaining), "key_map_sha256": hashlib.sha256(km.encode()).hexdigest(),
@@ -1258,6 +1316,8 @@ def main():
         net, _ = gen_unet("tiny_sd15", synth.TINY_SD15_UNET_CONFIG)
         gen_samples_extra("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
         gen_samples_more("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
+    if a.only == "lora":
+        gen_lora("tiny_sd15", synth.TINY_SD15_UNET_CONFIG)
     if a.only in ("", "tiny", "inpaint"):
         gen_inpaint_model()
     if a.only == "cfgpaths":

@@ -9,14 +9,15 @@ through the same C-ABI GEMM as everything else:   W' = W * strength_model + (str
 = fmx_gemm_conv_f16(A = up [out, rank pad 64], W = down^T [in*kh*kw, rank pad 64], alpha, residual = W): fp16 operands, fp32
 accumulation, one rounding -- the arithmetic of the reference with computation_dtype fp32 and fp16 LoRA tensors.
 
-Patch types built: "lora" (regular / diffusers / transformers key styles, optional conv `lora_mid`), "diff", "set".
-LoHa / LoKr / GLoRA / DoRA files are recognised and rejected explicitly."""
+Patch types built: "lora" (regular / diffusers / transformers key styles, optional conv `lora_mid`), "diff" (incl. w_norm / b_norm),
+"set", and the LyCORIS family "loha", "lokr", "glora", each optionally with a DoRA `dora_scale` (`weight_decompose`, :35-78).  The
+LyCORIS deltas are built from small factor products (Hadamard, Kronecker, Tucker cores) in fp32 on the device at load time -- the same
+computation_dtype the reference uses -- and added to the weight once."""
 import torch
 
 from ... import hipops as ops
 from ..misc.diffusers_state_dict import unet_to_diffusers
 
-UNSUPPORTED_SUFFIXES = (".hada_w1_a", ".lokr_w1", ".lokr_w1_a", ".a1.weight", ".dora_scale")
 
 
 def model_lora_keys_unet(unet_keys, unet_config, key_map=None):
@@ -51,13 +52,22 @@ def load_lora(lora, to_load):
     the patch types listed in the module docstring."""
     patch_dict, loaded = {}, set()
     for x, target in to_load.items():
-        for suf in UNSUPPORTED_SUFFIXES:
-            if x + suf in lora:
-                raise NotImplementedError(f"LoRA entry {x}{suf}: LoHa / LoKr / GLoRA / DoRA patches are not supported by the native merge")
         alpha = None
         if x + ".alpha" in lora:
             alpha = float(lora[x + ".alpha"].item())
             loaded.add(x + ".alpha")
+        dora_scale = lora.get(x + ".dora_scale")
+        if dora_scale is not None:
+            loaded.add(x + ".dora_scale")
+
+        def take(*names):
+            out = []
+            for n in names:
+                t = lora.get(x + n)
+                if t is not None:
+                    loaded.add(x + n)
+                out.append(t)
+            return out
         for up, down, mid in ((".lora_up.weight", ".lora_down.weight", ".lora_mid.weight"), ("_lora.up.weight", "_lora.down.weight", None),
                               (".lora_B.weight", ".lora_A.weight", None), (".lora.up.weight", ".lora.down.weight", None),
                               (".lora_linear_layer.up.weight", ".lora_linear_layer.down.weight", None)):
@@ -66,9 +76,24 @@ def load_lora(lora, to_load):
                 if mid is not None and x + mid in lora:
                     m = lora[x + mid]
                     loaded.add(x + mid)
-                patch_dict[target] = ("lora", (lora[x + up], lora[x + down], alpha, m, None))
+                patch_dict[target] = ("lora", (lora[x + up], lora[x + down], alpha, m, dora_scale))
                 loaded.update((x + up, x + down))
                 break
+        if x + ".hada_w1_a" in lora:  # LoHa (comfyui_lora_collection/lora.py:97-118)
+            w1a, w1b, w2a, w2b, t1, t2 = take(".hada_w1_a", ".hada_w1_b", ".hada_w2_a", ".hada_w2_b", ".hada_t1", ".hada_t2")
+            patch_dict[target] = ("loha", (w1a, w1b, alpha, w2a, w2b, t1, t2, dora_scale))
+        lokr = take(".lokr_w1", ".lokr_w2", ".lokr_w1_a", ".lokr_w1_b", ".lokr_w2_a", ".lokr_w2_b", ".lokr_t2")
+        if lokr[0] is not None or lokr[1] is not None or lokr[2] is not None or lokr[4] is not None:  # LoKr (:120-160)
+            w1, w2, w1_a, w1_b, w2_a, w2_b, t2 = lokr
+            patch_dict[target] = ("lokr", (w1, w2, alpha, w1_a, w1_b, w2_a, w2_b, t2, dora_scale))
+        if x + ".a1.weight" in lora:  # GLoRA (:162-171)
+            a1, a2, b1, b2 = take(".a1.weight", ".a2.weight", ".b1.weight", ".b2.weight")
+            patch_dict[target] = ("glora", (a1, a2, b1, b2, alpha, dora_scale))
+        if x + ".w_norm" in lora:  # :173-182
+            w_norm, b_norm = take(".w_norm", ".b_norm")
+            patch_dict[target] = ("diff", (w_norm,))
+            if b_norm is not None:
+                patch_dict[target[:-len(".weight")] + ".bias"] = ("diff", (b_norm,))
         if x + ".diff" in lora:
             patch_dict[target] = ("diff", (lora[x + ".diff"],))
             loaded.add(x + ".diff")
@@ -119,8 +144,14 @@ def merge_lora_to_weight(patches, weight, key="online_lora", computation_dtype=t
             w = v[0].to(device=device, dtype=torch.float16).reshape(shape).contiguous()
         elif ptype == "lora":
             up, down, alpha, mid, dora = v
-            if dora is not None:
-                raise NotImplementedError("DoRA scale")
+            if dora is not None:  # the decomposition needs the delta itself, not only W + delta: fp32 on the device, as the reference
+                dn = down.to(device=device, dtype=torch.float32)
+                if mid is not None:
+                    m = mid.to(device=device, dtype=torch.float32)
+                    dn = torch.mm(dn.transpose(0, 1).flatten(1), m.transpose(0, 1).flatten(1)).reshape(dn.shape[1], dn.shape[0], m.shape[2], m.shape[3]).transpose(0, 1)
+                diff = torch.mm(up.to(device=device, dtype=torch.float32).flatten(1), dn.flatten(1)).reshape(shape)
+                w = _weight_decompose(dora, w, diff, (alpha / down.shape[0]) if alpha is not None else 1.0, strength, device)
+                continue
             rank = down.shape[0]
             scale = strength * ((alpha / rank) if alpha is not None else 1.0)
             up2 = up.to(device=device, dtype=torch.float16).flatten(1)                        # [out, rank]
@@ -139,9 +170,75 @@ def merge_lora_to_weight(patches, weight, key="online_lora", computation_dtype=t
             out = torch.empty_like(w2)
             ops.conv_gemm(a, b, w2.shape[1], alpha=scale, residual=w2, out=out, ld_out=w2.shape[1])
             w = out.reshape(shape)
+        elif ptype in ("loha", "lokr", "glora"):
+            f32 = lambda t: t.to(device=device, dtype=torch.float32)
+            if ptype == "loha":  # patcher/lora.py:230-266: (w1a w1b) * (w2a w2b), optionally through Tucker cores t1 / t2
+                w1a, w1b, alpha, w2a, w2b, t1, t2, dora = v
+                scale = (alpha / w1b.shape[0]) if alpha is not None else 1.0
+                if t1 is not None:
+                    m1 = torch.einsum("i j k l, j r, i p -> p r k l", f32(t1), f32(w1b), f32(w1a))
+                    m2 = torch.einsum("i j k l, j r, i p -> p r k l", f32(t2), f32(w2b), f32(w2a))
+                else:
+                    m1, m2 = torch.mm(f32(w1a), f32(w1b)), torch.mm(f32(w2a), f32(w2b))
+                diff = (m1 * m2).reshape(shape)
+            elif ptype == "lokr":  # :180-228: kron(w1, w2), each either given or a low-rank product
+                w1, w2, alpha, w1_a, w1_b, w2_a, w2_b, t2, dora = v
+                dim = None
+                if w1 is None:
+                    dim = w1_b.shape[0]
+                    w1 = torch.mm(f32(w1_a), f32(w1_b))
+                else:
+                    w1 = f32(w1)
+                if w2 is None:
+                    dim = w2_b.shape[0]
+                    w2 = torch.mm(f32(w2_a), f32(w2_b)) if t2 is None else torch.einsum("i j k l, j r, i p -> p r k l", f32(t2), f32(w2_b), f32(w2_a))
+                else:
+                    w2 = f32(w2)
+                if w2.dim() == 4:
+                    w1 = w1.unsqueeze(2).unsqueeze(2)
+                scale = (alpha / dim) if (alpha is not None and dim is not None) else 1.0
+                diff = torch.kron(w1.contiguous(), w2.contiguous()).reshape(shape)
+            else:  # glora :268-306: W a1 a2 + b1 b2 (new layout) or b2 b1 + W a2 a1 (old LyCORIS layout)
+                a1, a2, b1, b2, alpha, dora = v
+                old = b2.shape[1] == b1.shape[0] == a1.shape[0] == a2.shape[1]
+                if b2.shape[0] == b1.shape[1] == a1.shape[1] == a2.shape[0]:
+                    if not (old and a2.shape[0] == shape[0] and shape[0] == shape[1]):
+                        old = False
+                A1, A2, B1, B2 = (f32(t.flatten(1)) for t in (a1, a2, b1, b2))
+                scale = 1.0 if alpha is None else (alpha / a1.shape[0] if old else alpha / a2.shape[0])
+                wf = w.float()
+                if old:
+                    diff = (torch.mm(B2, B1) + torch.mm(torch.mm(wf.flatten(1), A2), A1)).reshape(shape)
+                else:
+                    if wf.dim() > 2:
+                        diff = torch.einsum("o i ..., i j -> o j ...", torch.einsum("o i ..., i j -> o j ...", wf, A1), A2).reshape(shape)
+                    else:
+                        diff = torch.mm(torch.mm(wf, A1), A2).reshape(shape)
+                    diff = diff + torch.mm(B1, B2).reshape(shape)
+            if dora is not None:
+                w = _weight_decompose(dora, w, diff, scale, strength, device)
+            else:
+                w = (w.float() + (strength * scale) * diff).half()
         else:
             raise NotImplementedError(f"patch type {ptype}")
     return w
+
+
+def _weight_decompose(dora_scale, weight, lora_diff, alpha, strength, device):
+    """DoRA (patcher/lora.py:35-78): re-normalise every output (or input) slice of W + alpha * delta to the learned magnitude `dora_scale`,
+    then blend towards it by `strength`.  fp32 on the device; returns fp16."""
+    ds = dora_scale.to(device=device, dtype=torch.float32)
+    wf = weight.float()
+    calc = wf + alpha * lora_diff
+    if ds.shape[0] == calc.shape[0]:
+        # output-axis decomposition: the reference normalises by the norm of the ORIGINAL weight here (:58-63), not of W + delta
+        norm = wf.reshape(wf.shape[0], -1).norm(dim=1, keepdim=True).reshape(wf.shape[0], *[1] * (wf.dim() - 1))
+    else:
+        norm = calc.transpose(0, 1).reshape(calc.shape[1], -1).norm(dim=1, keepdim=True).reshape(calc.shape[1], *[1] * (calc.dim() - 1)).transpose(0, 1)
+    norm = norm + torch.finfo(torch.float32).eps  # eps of the computation dtype the weight was cast to (:74)
+    calc = calc * (ds / norm)
+    out = calc if strength == 1.0 else wf + strength * (calc - wf)
+    return out.half()
 
 
 def merge_loras_into_state_dict(unet_sd, unet_config, loras, device="cuda"):

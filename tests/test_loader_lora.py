@@ -83,5 +83,23 @@ def test_load_lora_patch_parsing():
     kinds = {k: v[0] for k, v in patch_dict.items()}
     assert kinds["diffusion_model.out.2.weight"] == "set" and kinds["diffusion_model.output_blocks.5.0.emb_layers.1.bias"] == "diff"
     assert patch_dict["diffusion_model.output_blocks.5.0.in_layers.2.weight"][1][3] is not None  # Tucker mid tensor kept
-    with pytest.raises(NotImplementedError):
-        nlora.load_lora({"lora_unet_time_embed_0.hada_w1_a": torch.zeros(1)}, {"lora_unet_time_embed_0": "diffusion_model.time_embed.0.weight"})
+
+
+def test_lycoris_and_dora_merge_vs_reference():
+    """LoHa (linear / Tucker conv), LoKr (full x low-rank, low-rank x 4-d), GLoRA (square / non-square), DoRA on LoRA / LoHa / LoKr (output- and
+    input-axis norms), w_norm / b_norm: the native parser + merge against the reference's load_lora + merge_lora_to_weight (fp16 weights, fp32
+    computation).  These branches are load-time weight algebra in torch, so they run on the CPU here as they do on the device."""
+    from oracle.make_golden import synth_lycoris
+    g = load_golden("tiny_sd15_lycoris_merge.pt")
+    cfg = synth.TINY_SD15_UNET_CONFIG
+    sd = {k: v.half() for k, v in synth.synth_unet_state_dict(cfg, seed=0).items()}
+    patch_dict, remaining = nlora.load_lora(synth_lycoris(cfg), _key_map(cfg))
+    assert sorted(remaining) == g["remaining"]
+    assert {k[len("diffusion_model."):]: v[0] for k, v in patch_dict.items()} == g["kinds"]
+    for mk, pv in patch_dict.items():
+        k = mk[len("diffusion_model."):]
+        got = nlora.merge_lora_to_weight([(g["strength"], pv, 1.0, None, None)], sd[k].clone(), key=k, device="cpu")
+        want = g["merged_every_5th"][k]
+        assert got.dtype == torch.float16
+        err = (got.flatten()[::5].float() - want.float()).abs().max() / want.float().abs().max()
+        assert err < 2e-3, (k, pv[0], float(err))  # one fp16 rounding of the result; the reference rounds W + delta the same way
