@@ -175,8 +175,10 @@ int fmx_add_control_nchw(void* h, const float* ctrl, int32_t b, int32_t c, int64
  * channels-last (the native ControlNet's outputs; `h += ctrl` of backend/nn/unet.py:44-52 with the `x *= strength` of
  * patcher/controlnet.py:236 folded into alpha). */
 int fmx_add_scaled_f16(void* h, const void* c, int32_t c_is_f32, float alpha, int64_t n, void* stream);
+/* 2x2 / stride-2 average pooling on fp16 NHWC [n][h][w][c] (h, w even): the conv-less Downsample of backend/nn/cnets/t2i_adapter.py:42-62 */
+int fmx_avgpool2x2_nhwc_f16(const void* x, void* y, int32_t n, int32_t h, int32_t w, int32_t c, void* stream);
 int fmx_cast_f32_to_f16(const float* x, void* y, int64_t n, void* stream);
-/* y = act(x), fp16, kind 0 = quick_gelu x*sigmoid(1.702x) (CLIP-L), 1 = exact erf GELU (CLIP-G) */
+/* y = act(x), fp16, kind 0 = quick_gelu x*sigmoid(1.702x) (CLIP-L), 1 = exact erf GELU (CLIP-G), 2 = ReLU (T2I-Adapter ResnetBlock) */
 int fmx_act_f16(const void* x, void* y, int64_t n, int32_t kind, void* stream);
 /* CLIP text embeddings (transformers CLIPTextEmbeddings): out[b*T + t][:] = tok_emb[ids[b*T + t]][:] + pos_emb[t][:], fp16, c % 8 == 0 */
 int fmx_embed_tokens(const int32_t* ids, const void* tok_emb, const void* pos_emb, void* out, int32_t batch, int32_t tokens, int32_t c,

@@ -104,3 +104,71 @@ class Control:
                     s = s * F.interpolate(m.to(s), size=s.shape[2:], mode="bilinear")
                 control[k][i] = s * final[:, None, None, None]
         return control
+
+
+# ---- T2I-Adapter (backend/nn/cnets/t2i_adapter.py:64-164, patcher/controlnet.py:477-545) ------------------------------------------------------
+@torch.no_grad()
+def adapter_forward(sd, x, channels, nums_rb=2, ksize=1, use_conv=False, xl=False):
+    """Adapter.forward: pixel-unshuffle -> conv_in -> ResnetBlocks (sk=True layout: in_conv only where the width changes, identity skip) -> feature
+    list with the None placeholders that align features with UNet input blocks."""
+    r = 16 if xl else 8
+    down_at = (2,) if xl else (3, 2, 1)
+    pad = ksize // 2
+    conv = lambda k, t, stride=1, p=1: F.conv2d(t, sd[k + ".weight"], sd[k + ".bias"], stride=stride, padding=p)
+    h = conv("conv_in", F.pixel_unshuffle(x, r))
+    feats = []
+    for i in range(len(channels)):
+        for j in range(nums_rb):
+            k = f"body.{i * nums_rb + j}"
+            if j == 0 and i in down_at:
+                h = conv(k + ".down_opt.op", h, stride=2) if use_conv else F.avg_pool2d(h, 2, 2)
+            if k + ".in_conv.weight" in sd:
+                h = conv(k + ".in_conv", h, p=pad)
+            y = conv(k + ".block2", F.relu(conv(k + ".block1", h)), p=pad)
+            h = y + (conv(k + ".skep", h, p=pad) if k + ".skep.weight" in sd else h)
+        if xl:
+            feats.append(None)
+            if i == 0:
+                feats += [None, None]
+            if i == 2:
+                feats.append(None)
+        else:
+            feats += [None, None]
+        feats.append(h)
+    return feats
+
+
+class AdapterControl:
+    """T2IAdapter.get_control + ControlBase.control_merge for the 'input' residual list (reversed: control_merge inserts at the front)."""
+
+    def __init__(self, sd, hint, strength=1.0, percent_range=(0.0, 1.0), previous=None, **adapter_kw):
+        self.sd, self.hint, self.strength, self.percent_range, self.previous, self.kw = sd, hint, strength, percent_range, previous, adapter_kw
+        self.features = None
+
+    def get_control(self, predictor, x_noisy, t, context, y, batched_number, to):
+        prev = self.previous.get_control(predictor, x_noisy, t, context, y, batched_number, to) if self.previous is not None else None
+        lo, hi = predictor.percent_to_sigma(self.percent_range[0]), predictor.percent_to_sigma(self.percent_range[1])
+        if t[0] > lo or t[0] < hi:
+            return prev
+        if self.features is None:
+            hint = adaptive_resize_nearest_exact_center(self.hint, x_noisy.shape[3] * 8, x_noisy.shape[2] * 8).float()
+            if hint.shape[0] != x_noisy.shape[0]:
+                hint = broadcast_image_to(hint, x_noisy.shape[0], batched_number)
+            self.features = adapter_forward(self.sd, hint, **self.kw)
+        feats = [None if f is None else f.clone() for f in self.features]
+        mid = None
+        if self.kw.get("xl"):
+            mid, feats = feats[-1:], feats[:-1]
+        out = {"input": [], "middle": [], "output": []}
+        for f in feats:
+            out["input"].insert(0, None if f is None else f * self.strength)
+        for f in (mid or []):
+            out["middle"].append(f * self.strength)
+        if prev is not None:
+            for k in out:
+                for i, pv in enumerate(prev[k]):
+                    if i >= len(out[k]):
+                        out[k].append(pv)
+                    elif pv is not None:
+                        out[k][i] = pv if out[k][i] is None else out[k][i] + pv
+        return out

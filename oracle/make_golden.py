@@ -1109,6 +1109,70 @@ def gen_inpaint_model(b=2, hw=16):
     print("inpaint model: eps std", float(eps.std()), "euler3 std", float(lat.std()))
 
 
+ADAPTER_VARIANTS = {  # name -> Adapter kwargs (cin = 3 or 1 image channels x unshuffle^2)
+    "sd15_k1_pool": dict(channels=[64, 128, 256, 256], nums_rb=2, cin=192, ksize=1, sk=True, use_conv=False, xl=False),
+    "sd15_k3_conv": dict(channels=[64, 128, 256, 256], nums_rb=2, cin=64, ksize=3, sk=True, use_conv=True, xl=False),
+    "sdxl": dict(channels=[64, 128, 256, 256], nums_rb=2, cin=768, ksize=1, sk=True, use_conv=False, xl=True),
+}
+
+
+def adapter_hint(vname, b=2, hw=16):
+    """The hint image of a variant, regenerated from its seed (not stored: 400 KB each)."""
+    kw = ADAPTER_VARIANTS[vname]
+    g = torch.Generator().manual_seed(55 + list(ADAPTER_VARIANTS).index(vname))
+    return torch.rand(b, kw["cin"] // ((16 if kw["xl"] else 8) ** 2), hw * 8, hw * 8, generator=g)
+
+
+def gen_t2i_adapter(b=2, hw=16):
+    """The reference's Adapter (three checkpoint layouts) and a 3-step Euler run of an SD1.5-shaped UNet through the reference sampling_function
+    with the reference's patcher-level T2IAdapter attached (strength 0.9, active for the first 60 % of the schedule)."""
+    import importlib
+    ref = ref_import.load_reference()
+    t2i = importlib.import_module("backend.nn.cnets.t2i_adapter")
+    pc = importlib.import_module("backend.patcher.controlnet")
+    g = torch.Generator().manual_seed(55)
+    res = {"hw": hw, "seeds": [1000 + i for i in range(b)], "features": {}}
+    models = {}
+    for vname, kw in ADAPTER_VARIANTS.items():
+        m = t2i.Adapter(**kw)
+        sd = synth.synth_t2i_adapter_state_dict(**kw)
+        assert set(sd) == set(m.state_dict()) and all(tuple(sd[k].shape) == tuple(v.shape) for k, v in m.state_dict().items()), vname
+        m.load_state_dict(sd)
+        m.eval()
+        models[vname] = m
+        hint = adapter_hint(vname, b, hw)
+        with torch.no_grad():
+            feats = m(hint)
+        res["features"][vname] = {"layout": [None if f is None else tuple(f.shape) for f in feats],
+                                  "values_every_4th_channel": [f[:, ::4].clone() for f in feats if f is not None]}
+    cfg = synth.MINI_SD15_UNET_CONFIG
+    net = ref_import.build_ref_unet(cfg, synth.synth_unet_state_dict(cfg, seed=0))
+    pred = ref_import.build_ref_predictor()
+    c, uc = synth.synth_conditioning(b, cfg["context_dim"], None, seed=1234)
+    den = ref_import.RefDenoiser(net, pred, res["seeds"])
+    ad = pc.T2IAdapter(models["sd15_k1_pool"], 3, device=torch.device("cpu"))
+    hint = adapter_hint("sd15_k1_pool", b, hw)
+    unet = den.patcher.clone()
+    unet.add_patched_controlnet(ad.copy().set_cond_hint(hint, 0.9, (0.0, 0.6)))
+    den.patcher = unet
+    den.inner_model.inner_model.forge_objects.unet = unet
+    rng = ImageRNG((4, hw, hw), res["seeds"], "CPU")
+    x = rng.next()
+    sigmas = den.inner_model.get_sigmas(3)
+    x = pred.noise_scaling(sigmas[0], x, torch.zeros_like(x), max_denoise=False)
+    ref.kd_sampling.torch = _Hijack(rng)
+    ref.sampling_function.sampling_prepare(unet, x=x)
+    try:
+        lat = ref.kd_sampling.sample_euler(den, x, sigmas, extra_args={"cond": c, "uncond": uc, "cond_scale": 7.0, "s_min_uncond": 0.0, "image_cond": None},
+                                           disable=True)
+    finally:
+        ref.kd_sampling.torch = torch
+        ref.sampling_function.sampling_cleanup(unet)
+    res["euler3"] = lat
+    torch.save(res, os.path.join(GOLD, "mini_sd15_t2i_adapter.pt"))
+    print("t2i adapter:", {k: len(v["values_every_4th_channel"]) for k, v in res["features"].items()}, "euler3 std", float(lat.std()))
+
+
 def gen_schedulers():
     """modules/sd_schedulers.py's table, imported from the reference with a two-attribute stand-in for modules.shared."""
     import importlib.util
@@ -1316,6 +1380,8 @@ def main():
         net, _ = gen_unet("tiny_sd15", synth.TINY_SD15_UNET_CONFIG)
         gen_samples_extra("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
         gen_samples_more("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
+    if a.only in ("", "t2i"):
+        gen_t2i_adapter()
     if a.only == "lora":
         gen_lora("tiny_sd15", synth.TINY_SD15_UNET_CONFIG)
     if a.only in ("", "tiny", "inpaint"):

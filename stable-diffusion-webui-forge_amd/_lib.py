@@ -76,6 +76,7 @@ SIGNATURES = {
     "fmx_sampler_lincomb": [_vp, _vp, _i32, _vp, _i64, _vp],
     "fmx_sampler_error_norm": [_vp, _vp, _vp, _f32, _f32, _vp, _vp, _i64, _vp],
     "fmx_resize_separable_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "fmx_avgpool2x2_nhwc_f16": [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "fmx_add_scaled_f16": [_vp, _vp, _i32, _f32, _i64, _vp],
     "fmx_sampler_lincomb3": [_vp, _vp, _vp, _f32, _f32, _f32, _vp, _i64, _vp],
     "fmx_scale_f32": [_vp, _f32, _vp, _i64, _vp],

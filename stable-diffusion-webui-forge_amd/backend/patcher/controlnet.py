@@ -1,7 +1,8 @@
 """ControlNet at the patcher level -- mirror of backend/patcher/controlnet.py: `apply_controlnet_advanced` (:11-76),
 `compute_controlnet_weighting` (:79-146), `broadcast_image_to` (:149-168), `ControlBase` (:175-272: strength, start / end percent ->
 sigma range, linked list of previous ControlNets, `control_merge`), `ControlNet.get_control` (:275-338).  The control model underneath is
-the native backend/nn/cnets/cldm.ControlNet; T2I-Adapter and ControlLoRA (:341-586) are other networks, not built.
+the native backend/nn/cnets/cldm.ControlNet; `T2IAdapter` / `load_t2i_adapter` (:477-586) over the native backend/nn/cnets/t2i_adapter.Adapter.
+ControlLoRA (:341-474) is not built.
 
 Residuals stay fp16 and channels-last from the ControlNet's zero convs to the UNet's `h += ctrl` (the reference casts them to the
 latent's fp32, :238-239; the native UNet consumes fp16, so the cast would only be undone)."""
@@ -219,3 +220,90 @@ class ControlNet(ControlBase):
     def cleanup(self):
         self.model_sampling_current = None
         super().cleanup()
+
+
+class T2IAdapter(ControlBase):
+    """patcher/controlnet.py:477-545: the adapter's features depend on the hint only -> computed once and cached (`control_input`), then
+    injected as 'input' residuals (and, for SDXL adapters, the last one as 'middle') every step."""
+
+    def __init__(self, t2i_model, channels_in, device=None):
+        super().__init__(device if device is not None else getattr(t2i_model, "device", None))
+        self.t2i_model = t2i_model
+        self.channels_in = channels_in
+        self.control_input = None
+
+    def scale_image_to(self, width, height):
+        import math
+        r = self.t2i_model.unshuffle_amount
+        return math.ceil(width / r) * r, math.ceil(height / r) * r
+
+    def get_control(self, x_noisy, t, cond, batched_number):
+        to = self.transformer_options
+        for modifier in to.get("controlnet_conditioning_modifiers", []):
+            x_noisy, t, cond, batched_number = modifier(self, x_noisy, t, cond, batched_number)
+        control_prev = None
+        if self.previous_controlnet is not None:
+            control_prev = self.previous_controlnet.get_control(x_noisy, t, cond, batched_number)
+        t0 = t.fmx_sigma.host[0] if hasattr(t, "fmx_sigma") else float(t[0])
+        if self.timestep_range is not None:
+            if t0 > self.timestep_range[0] or t0 < self.timestep_range[1]:
+                return control_prev
+        if self.cond_hint is None or x_noisy.shape[2] * 8 != self.cond_hint.shape[2] or x_noisy.shape[3] * 8 != self.cond_hint.shape[3]:
+            self.control_input = None
+            width, height = self.scale_image_to(x_noisy.shape[3] * 8, x_noisy.shape[2] * 8)
+            self.cond_hint = image_resize.adaptive_resize(self.cond_hint_original.to(x_noisy.device), width, height, "nearest-exact", "center").float()
+            if self.channels_in == 1 and self.cond_hint.shape[1] > 1:
+                self.cond_hint = torch.mean(self.cond_hint, 1, keepdim=True)
+        if x_noisy.shape[0] != self.cond_hint.shape[0]:
+            self.cond_hint = broadcast_image_to(self.cond_hint, x_noisy.shape[0], batched_number)
+            self.control_input = None
+        if self.control_input is None:
+            wrapper = to.get("controlnet_model_function_wrapper", None)
+            if wrapper is not None:
+                self.control_input = wrapper(hint=self.cond_hint, model=self, inner_model=self.t2i_model, inner_t2i_model=self.t2i_model)
+            else:
+                self.control_input = self.t2i_model(self.cond_hint)
+        control_input = [None if a is None else a.clone() for a in self.control_input]  # control_merge scales in place
+        mid = None
+        if self.t2i_model.xl:
+            mid, control_input = control_input[-1:], control_input[:-1]
+        return self.control_merge(control_input, mid, control_prev, x_noisy.dtype)
+
+    def copy(self):
+        c = T2IAdapter(self.t2i_model, self.channels_in)
+        self.copy_to(c)
+        return c
+
+
+def load_t2i_adapter(t2i_data, device="cuda"):
+    """patcher/controlnet.py:548-586 for the `Adapter` family (TencentARC and diffusers key layouts)."""
+    from ..nn.cnets import t2i_adapter
+    if "adapter" in t2i_data:
+        t2i_data = t2i_data["adapter"]
+    if "adapter.body.0.resnets.0.block1.weight" in t2i_data:  # diffusers format
+        repl = {}
+        for i in range(4):
+            for j in range(2):
+                repl[f"adapter.body.{i}.resnets.{j}."] = f"body.{i * 2 + j}."
+            repl[f"adapter.body.{i}."] = f"body.{i * 2}."
+        repl["adapter."] = ""
+        out = {}
+        for k, v in t2i_data.items():
+            for old in sorted(repl, key=len, reverse=True):
+                if k.startswith(old):
+                    k = repl[old] + k[len(old):]
+                    break
+            out[k] = v
+        t2i_data = out
+    keys = t2i_data.keys()
+    if "body.0.in_conv.weight" in keys:
+        raise NotImplementedError("Adapter_light checkpoints are not built")
+    if "conv_in.weight" not in keys:
+        return None
+    cin, channel = t2i_data["conv_in.weight"].shape[1], t2i_data["conv_in.weight"].shape[0]
+    ksize = t2i_data["body.0.block2.weight"].shape[2]
+    use_conv = any(k.endswith("down_opt.op.weight") for k in keys)
+    xl = cin in (256, 768)
+    model = t2i_adapter.Adapter(t2i_data, channels=[channel, channel * 2, channel * 4, channel * 4], nums_rb=2, cin=cin, ksize=ksize, sk=True,
+                                use_conv=use_conv, xl=xl, device=device)
+    return T2IAdapter(model, model.input_channels)

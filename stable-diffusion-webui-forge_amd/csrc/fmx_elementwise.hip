@@ -54,7 +54,22 @@ __global__ void add_control_nchw_kernel(f16* __restrict__ h, const float* __rest
 __global__ void act_kernel(const f16* __restrict__ x, f16* __restrict__ y, long n, int kind) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const float v = (float)x[i];
-    y[i] = (f16)(kind == 0 ? v / (1.0f + __expf(-1.702f * v)) : gelu_erf_f(v));
+    y[i] = (f16)(kind == 0 ? v / (1.0f + __expf(-1.702f * v)) : kind == 1 ? gelu_erf_f(v) : fmaxf(v, 0.f));
+  }
+}
+
+// 2x2 average pooling, stride 2, fp16 NHWC [n][h][w][c] -> [n][h/2][w/2][c] (h, w even): T2I-Adapter's conv-less Downsample (t2i_adapter.py:42-62)
+__global__ void avgpool2x2_kernel(const f16* __restrict__ x, f16* __restrict__ y, int n, int h, int w, int c) {
+  const int oh = h / 2, ow = w / 2;
+  const long total = (long)n * oh * ow * c;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % c);
+    const int ox = (int)((i / c) % ow);
+    const int oy = (int)((i / ((long)c * ow)) % oh);
+    const long b = i / ((long)c * ow * oh);
+    const f16* p = x + ((b * h + 2 * oy) * w + 2 * ox) * (long)c + ch;
+    const float v = (float)p[0] + (float)p[c] + (float)p[(long)w * c] + (float)p[(long)w * c + c];
+    y[i] = (f16)(0.25f * v);
   }
 }
 
@@ -397,7 +412,7 @@ extern "C" int fmx_add_control_nchw(void* h, const float* ctrl, int32_t b, int32
 }
 
 extern "C" int fmx_act_f16(const void* x, void* y, int64_t n, int32_t kind, void* stream) {
-  FMX_REQUIRE(x && y && n > 0 && (kind == 0 || kind == 1), "act: bad args");
+  FMX_REQUIRE(x && y && n > 0 && kind >= 0 && kind <= 2, "act: bad args");
   hipLaunchKernelGGL(act_kernel, dim3(grid_for(n, 4)), dim3(TPB), 0, (hipStream_t)stream, (const f16*)x, (f16*)y, (long)n, kind);
   FMX_LAUNCH_CHECK("fmx_act_f16");
   return FMX_OK;
@@ -481,6 +496,14 @@ extern "C" int fmx_resize_separable_f32(const float* in, float* out, const int32
   hipLaunchKernelGGL(resize_separable_kernel, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream, in, out, ystart, yweights, xstart,
                      xweights, planes, h, w, oh, ow, ky, kx);
   FMX_LAUNCH_CHECK("fmx_resize_separable_f32");
+  return FMX_OK;
+}
+
+extern "C" int fmx_avgpool2x2_nhwc_f16(const void* x, void* y, int32_t n, int32_t h, int32_t w, int32_t c, void* stream) {
+  FMX_REQUIRE(x && y && n > 0 && c > 0 && h > 0 && w > 0 && (h % 2) == 0 && (w % 2) == 0, "avgpool2x2: even H / W only");
+  const long total = (long)n * (h / 2) * (w / 2) * c;
+  hipLaunchKernelGGL(avgpool2x2_kernel, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream, (const f16*)x, (f16*)y, n, h, w, c);
+  FMX_LAUNCH_CHECK("fmx_avgpool2x2_nhwc_f16");
   return FMX_OK;
 }
 

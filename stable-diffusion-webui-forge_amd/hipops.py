@@ -297,7 +297,15 @@ def add_control_(h, ctrl, alpha=1.0):
     return h
 
 
-ACT_QUICK_GELU, ACT_GELU_ERF = 0, 1
+ACT_QUICK_GELU, ACT_GELU_ERF, ACT_RELU = 0, 1, 2
+
+
+def avgpool2x2(x):
+    """fp16 NHWC [N, H, W, C] -> [N, H/2, W/2, C]"""
+    n, h, w, c = x.shape
+    out = empty((n, h // 2, w // 2, c), torch.float16, x.device)
+    _lib.check(_lib.lib().fmx_avgpool2x2_nhwc_f16(_p(x), _p(out), n, h, w, c, stream_ptr()), "fmx_avgpool2x2_nhwc_f16")
+    return out
 
 
 def act(x, kind, out=None):

@@ -130,6 +130,19 @@ def synth_controlnet_state_dict(cfg, hint_channels=3, seed=6, zero_conv_gain=1.0
     return synth_state_dict(controlnet_param_shapes(cfg, hint_channels), seed=seed, **kw)
 
 
+# an SD1.5-SHAPED small UNet (4 levels x 2 ResBlocks = 12 input blocks): T2I-Adapter features are placed by input-block index, so its tests
+# need the real block grammar; channels 64 / 128 / 256 / 256
+MINI_SD15_UNET_CONFIG = dict(
+    in_channels=4, model_channels=64, out_channels=4, num_res_blocks=[2, 2, 2, 2], channel_mult=(1, 2, 4, 4), num_heads=4,
+    use_spatial_transformer=True, transformer_depth=[1, 1, 1, 1, 1, 1, 0, 0], transformer_depth_middle=1,
+    transformer_depth_output=[1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0], context_dim=128, use_linear_in_transformer=False)
+
+
+def synth_t2i_adapter_state_dict(seed=11, **adapter_kw):
+    from .backend.nn.cnets.t2i_adapter import adapter_param_shapes
+    return synth_state_dict(OrderedDict(adapter_param_shapes(**adapter_kw)), seed=seed)
+
+
 def synth_flux_state_dict(cfg, seed=2, **kw):
     return synth_state_dict(flux_param_shapes(cfg), seed=seed, **kw)
 

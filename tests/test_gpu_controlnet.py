@@ -84,3 +84,37 @@ def test_sampling_with_a_controlnet_chain_vs_reference(name, engines):
     err = max_rel(lat, g["euler4"]["latent"])
     print(f"[parity] {name} 4-step Euler with a 2-ControlNet chain (ranges, pooling, weightings) vs reference: max_rel={err:.3e} (tol 1e-02)")
     assert err < 1e-2
+
+
+def test_t2i_adapter_vs_reference():
+    """The native T2I-Adapter (three checkpoint layouts) against the reference's Adapter, and a 3-step Euler run of an SD1.5-shaped UNet with the
+    adapter attached through the patcher-level T2IAdapter (features computed once, injected as 'input' residuals) against the reference's."""
+    from forge_amd.backend.nn.cnets import t2i_adapter
+    from oracle.make_golden import ADAPTER_VARIANTS, adapter_hint
+    g = load_golden("mini_sd15_t2i_adapter.pt")
+    worst = 0.0
+    for vname, kw in ADAPTER_VARIANTS.items():
+        net = t2i_adapter.Adapter(synth.synth_t2i_adapter_state_dict(**kw), device=DEV, **kw)
+        feats = net(adapter_hint(vname).to(DEV))
+        want = g["features"][vname]
+        assert [None if f is None else tuple(f.shape) for f in feats] == want["layout"], vname
+        for f, w in zip([f for f in feats if f is not None], want["values_every_4th_channel"]):
+            worst = max(worst, max_rel(f[:, ::4], w))
+    print(f"[parity] T2I-Adapter features (3 checkpoint layouts) vs reference Adapter: worst max_rel={worst:.3e} (tol 3e-03)")
+    assert worst < 3e-3
+    cfg = synth.MINI_SD15_UNET_CONFIG
+    eng = build_engine(cfg, synth.synth_unet_state_dict(cfg, seed=0), None, None, device=DEV)
+    kw = ADAPTER_VARIANTS["sd15_k1_pool"]
+    ad = pc.load_t2i_adapter(synth.synth_t2i_adapter_state_dict(**kw), device=DEV)
+    assert ad.t2i_model.ksize == 1 and not ad.t2i_model.use_conv and not ad.t2i_model.xl and ad.channels_in == 3
+    unet = eng.forge_objects.unet.clone()
+    unet.add_patched_controlnet(ad.copy().set_cond_hint(adapter_hint("sd15_k1_pool").to(DEV), 0.9, (0.0, 0.6)))
+    eng.forge_objects_after_applying_lora = eng.forge_objects_after_applying_lora.shallow_copy()
+    eng.forge_objects_after_applying_lora.unet = unet
+    c, uc = synth.synth_conditioning(2, cfg["context_dim"], None, seed=1234)
+    shared.opts.randn_source = "CPU"
+    p = processing.StableDiffusionProcessingTxt2Img(sd_model=eng, c=c.to(DEV), uc=uc.to(DEV), seed=g["seeds"][0], sampler_name="Euler", batch_size=2, steps=3,
+                                                    cfg_scale=7.0, width=g["hw"] * 8, height=g["hw"] * 8, do_decode=False)
+    err = max_rel(processing.process_images(p).latents, g["euler3"])
+    print(f"[parity] SD1.5-shaped UNet + T2I-Adapter, 3-step Euler vs reference: max_rel={err:.3e} (tol 1e-02)")
+    assert err < 1e-2

@@ -266,3 +266,27 @@ def test_inpainting_model_restated():
     c, uc = synth.synth_conditioning(2, cfg["context_dim"], None, seed=1234)
     lat = pipeline.txt2img_latents_inpaint_model(sd, cfg, c, uc, g["seeds"], g["hw"] * 8, g["hw"] * 8, 3, ic)
     assert max_rel(lat, g["euler3"]) < 2e-4
+
+
+def test_t2i_adapter_restated():
+    """oracle/controlnet.py adapter_forward / AdapterControl vs the reference's Adapter (three checkpoint layouts: 1x1 + avg-pool, 3x3 + strided
+    conv, SDXL x16 unshuffle) and vs a 3-step Euler run through the reference sampling_function with the reference T2IAdapter attached; also
+    pins the product's adapter_param_shapes to the reference module's state dict (checked at fixture time)."""
+    from oracle import controlnet as ocn
+    from oracle.make_golden import ADAPTER_VARIANTS, adapter_hint
+    g = load_golden("mini_sd15_t2i_adapter.pt")
+    for vname, kw in ADAPTER_VARIANTS.items():
+        sd = synth.synth_t2i_adapter_state_dict(**kw)
+        feats = ocn.adapter_forward(sd, adapter_hint(vname), kw["channels"], kw["nums_rb"], kw["ksize"], kw["use_conv"], kw["xl"])
+        want = g["features"][vname]
+        assert [None if f is None else tuple(f.shape) for f in feats] == want["layout"], vname
+        for f, w in zip([f for f in feats if f is not None], want["values_every_4th_channel"]):
+            torch.testing.assert_close(f[:, ::4], w, rtol=1e-4, atol=1e-5)
+    cfg = synth.MINI_SD15_UNET_CONFIG
+    kw = ADAPTER_VARIANTS["sd15_k1_pool"]
+    chain = ocn.AdapterControl(synth.synth_t2i_adapter_state_dict(**kw), adapter_hint("sd15_k1_pool"), 0.9, (0.0, 0.6), channels=kw["channels"],
+                               nums_rb=kw["nums_rb"], ksize=kw["ksize"], use_conv=kw["use_conv"], xl=kw["xl"])
+    sd = synth.synth_unet_state_dict(cfg, seed=0)
+    c, uc = synth.synth_conditioning(2, cfg["context_dim"], None, seed=1234)
+    lat = pipeline.txt2img_latents_controlnet(sd, cfg, c, uc, g["seeds"], g["hw"] * 8, g["hw"] * 8, 3, chain)
+    assert max_rel(lat, g["euler3"]) < 2e-4
