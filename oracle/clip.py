@@ -27,12 +27,23 @@ def _lin(sd, key, x):
 
 
 @torch.no_grad()
-def clip_hidden_states(sd, cfg, ids):
-    """-> list of hidden states (embeddings, after layer 1, ..., after layer N), all pre-final-LN (HF `hidden_states`)."""
+def clip_hidden_states(sd, cfg, ids, fixes=None):
+    """-> list of hidden states (embeddings, after layer 1, ..., after layer N), all pre-final-LN (HF `hidden_states`).
+    fixes: per prompt a list of (offset, vectors [n, C]) textual-inversion embeddings that REPLACE the token embeddings of positions
+    offset+1 ... (classic_engine.py:20-50 CLIPEmbeddingForTextualInversion), before the position embedding is added."""
     b, t = ids.shape
     c, heads = cfg["hidden_size"], cfg["num_attention_heads"]
     d = c // heads
-    x = sd[P + "embeddings.token_embedding.weight"][ids] + sd[P + "embeddings.position_embedding.weight"][:t][None]
+    tok = sd[P + "embeddings.token_embedding.weight"][ids]
+    if fixes is not None:
+        rows = []
+        for fx, tensor in zip(fixes, tok):
+            for offset, emb in fx:
+                n = min(tensor.shape[0] - offset - 1, emb.shape[0])
+                tensor = torch.cat([tensor[0:offset + 1], emb[0:n].to(tensor), tensor[offset + 1 + n:]])
+            rows.append(tensor)
+        tok = torch.stack(rows)
+    x = tok + sd[P + "embeddings.position_embedding.weight"][:t][None]
     mask = torch.full((t, t), float("-inf")).triu(1)
     hs = [x]
     for i in range(cfg["num_hidden_layers"]):
@@ -51,9 +62,9 @@ def clip_hidden_states(sd, cfg, ids):
 
 
 @torch.no_grad()
-def encode_with_transformers(sd, cfg, ids, clip_skip=1, final_layer_norm=True, return_pooled=False, is_clip_l=True):
+def encode_with_transformers(sd, cfg, ids, clip_skip=1, final_layer_norm=True, return_pooled=False, is_clip_l=True, fixes=None):
     """classic_engine.py:124-148 -> (z [B,T,C], pooled [B,C] or None)"""
-    hs = clip_hidden_states(sd, cfg, ids)
+    hs = clip_hidden_states(sd, cfg, ids, fixes)
     z = hs[-clip_skip]
     if final_layer_norm:
         z = _ln(sd, P + "final_layer_norm", z)

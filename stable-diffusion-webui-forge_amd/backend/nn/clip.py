@@ -55,15 +55,23 @@ class IntegratedCLIP:
         torch.cuda.synchronize(dev)
 
     @torch.inference_mode()
-    def hidden_states(self, ids):
+    def hidden_states(self, ids, fixes=None):
         """ids [B, T] (any integer dtype) -> list of fp16 [B*T, C]: embeddings, after layer 1, ..., after layer N (pre final LN),
-        i.e. transformers' `output_hidden_states`."""
+        i.e. transformers' `output_hidden_states`.  fixes: per prompt [(offset, vectors [n, C]), ...] textual-inversion embeddings that
+        replace the TOKEN embeddings at positions offset+1... (classic_engine.py:20-50); the position embedding still applies."""
         b, t = ids.shape
         if t > self.w["pos"].shape[0]:
             raise ValueError(f"{t} tokens > max_position_embeddings {self.w['pos'].shape[0]}")
         c, H, d = self.hidden, self.heads, self.d
         ids32 = ids.to(device=self.device, dtype=torch.int32).contiguous()
         x = ops.embed_tokens(ids32, self.w["tok"], self.w["pos"])
+        if fixes is not None:
+            xv = x.view(b, t, c)
+            for bi, fx in enumerate(fixes):
+                for offset, emb in fx:
+                    n = min(t - offset - 1, emb.shape[0])
+                    if n > 0:
+                        xv[bi, offset + 1:offset + 1 + n] = emb[:n].to(device=self.device, dtype=torch.float16) + self.w["pos"][offset + 1:offset + 1 + n]
         tp = -(-t // 64) * 64  # keys padded to the attention tile; the padding rows/columns are zeros and masked by nk
         hs = [x]
         for i in range(self.layers):
@@ -87,10 +95,10 @@ class IntegratedCLIP:
         return ops.layernorm(x.contiguous(), *self.w["final"])
 
     @torch.inference_mode()
-    def encode(self, ids, clip_skip=1, final_layer_norm=True, return_pooled=False, project_pooled=False):
+    def encode(self, ids, clip_skip=1, final_layer_norm=True, return_pooled=False, project_pooled=False, fixes=None):
         """classic_engine.py:124-148 -> (z fp32 [B, T, C], pooled fp32 [B, C] or None)"""
         b, t = ids.shape
-        hs = self.hidden_states(ids)
+        hs = self.hidden_states(ids, fixes)
         z = hs[-clip_skip]
         if final_layer_norm:
             z = self.final_layer_norm(z)

@@ -83,3 +83,28 @@ def test_sdxl_conditioning_assembly():
     neg = TokenizedPrompts([ids.tolist()], [ones], [ids.tolist()], [ones], is_negative_prompt=True, all_empty=True)
     z = eng.get_learned_conditioning(neg)
     assert float(z["crossattn"].abs().max()) == 0.0 and float(z["vector"][:, :cg["hidden_size"]].abs().max()) == 0.0
+
+
+def test_textual_inversion_fixes_and_emphasis_modes():
+    """Textual-inversion vectors spliced over token embeddings (classic_engine.py:20-50) and the four emphasis modes (emphasis.py:19-59) vs oracle."""
+    cfg = synth.TINY_CLIP_L_CONFIG
+    sd = synth.synth_clip_state_dict(cfg)
+    net = IntegratedCLIP(cfg, sd, device=DEV)
+    ids = load_golden("tiny_clip_l.pt")["ids"]
+    g = torch.Generator().manual_seed(3)
+    c = cfg["hidden_size"]
+    fixes = [[(3, torch.randn(2, c, generator=g) * 0.02), (40, torch.randn(5, c, generator=g) * 0.02)], [(74, torch.randn(4, c, generator=g) * 0.02)]]
+    z, _ = net.encode(ids, clip_skip=1, final_layer_norm=True, fixes=fixes)
+    want, _ = oclip.encode_with_transformers(sd, cfg, ids, clip_skip=1, final_layer_norm=True, fixes=fixes)
+    report("CLIP-L with textual-inversion fixes", max_rel(z, want), 3e-3)
+    plain, _ = oclip.encode_with_transformers(sd, cfg, ids, clip_skip=1, final_layer_norm=True)
+    assert max_rel(want, plain) > 1e-2
+    mult = torch.ones(ids.shape)
+    mult[0, 5:9], mult[1, 20:30] = 1.21, 0.8
+    for mode in ("Original", "No norm", "Ignore", "None"):
+        eng = ClassicTextProcessingEngine(net, emphasis_name=mode)
+        got = eng([ids.tolist()], [mult.tolist()], [fixes])
+        ref = want * mult[..., None] if mode in ("Original", "No norm") else want
+        if mode == "Original":
+            ref = ref * (want.mean() / ref.mean())
+        report(f"emphasis mode {mode}", max_rel(got, ref), 4e-3)
