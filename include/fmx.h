@@ -150,6 +150,12 @@ int fmx_groupnorm_apply_f16(const void* x0, const void* x1, int32_t c0, int32_t 
 int fmx_layernorm_f16(const void* x, const void* gamma, const void* beta, void* y, int64_t rows, int32_t c,
                       float eps, void* stream);
 
+/* Same, with the output rows of every image re-spaced: input row i of image b (b = r / rows_per_image) goes to output row
+ * b * out_rows_per_image + i.  Used when the token count per image is not a multiple of the attention key tile (64): the rows in between
+ * stay whatever the caller left there (zeros), so ONE batched Q|K / V^T projection serves all images. */
+int fmx_layernorm_padded_f16(const void* x, const void* gamma, const void* beta, void* y, int64_t rows, int32_t c, float eps,
+                             int64_t rows_per_image, int64_t out_rows_per_image, void* stream);
+
 /* Flux adaLN: y = (1 + scale[b]) * LayerNorm_noaffine(x) + shift[b]; x, y fp16 [rows][c], b = row / rows_per_batch;
  * scale / shift fp16 vectors of batch element b at scale + b*ld_mod, shift + b*ld_mod (views into the Modulation output). */
 int fmx_layernorm_mod_f16(const void* x, const void* scale, const void* shift, int64_t ld_mod, int64_t rows_per_batch, void* y,

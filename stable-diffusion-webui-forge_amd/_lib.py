@@ -62,6 +62,7 @@ SIGNATURES = {
     "fmx_groupnorm_stats_f16": [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
     "fmx_groupnorm_apply_f16": [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _f32, _vp, _vp, _i32, _vp, _vp],
     "fmx_layernorm_f16": [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp],
+    "fmx_layernorm_padded_f16": [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _i64, _i64, _vp],
     "fmx_layernorm_mod_f16": [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i32, _f32, _vp],
     "fmx_flux_qk_norm_rope_f16": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
     "fmx_timestep_embedding": [_vp, _vp, _i32, _i32, _f32, _vp],

@@ -88,6 +88,7 @@ class IntegratedUNet2DConditionModel:
         self.model_channels = self.layout.model_channels
         self.out_channels = self.layout.out_channels
         self.num_classes = config.get("num_classes")
+        self._pad_bufs = {}  # (Bu, n_pad, C) -> persistent zero-padded LayerNorm output for ragged token counts (see _attn_block)
         self._arena = None
         self.arena_epoch = 0  # bumped whenever the arena is re-allocated: graphs captured on the old one hold dangling pointers
         self._arena_bytes = arena_bytes
@@ -260,25 +261,26 @@ class IntegratedUNet2DConditionModel:
         m_tok = bu * n
         mk = arena.mark()
         # self attention
-        n1 = ops.layernorm(h, *self.w[b + ".norm1"])
         if n % 64 == 0:
+            n1 = ops.layernorm(h, *self.w[b + ".norm1"])
             qk = ops.linear(n1, self.w[b + ".attn1.qk"])                   # [M, 2*H*dp] = [Q | K]
             vt = ops.conv_gemm(self.w[b + ".attn1.v"], n1, m_tok)          # [H*dp, M] = V^T (operand swap)
             o = ops.attention(qk, qk[:, hd:], vt, batch=bu, heads=H, nq=n, nk=n, nk_pad=n, dpad=dp, scale=d ** -0.5,
                               q_bs=n * 2 * hd, q_rs=2 * hd, k_bs=n * 2 * hd, k_rs=2 * hd, vt_bs=n, vt_hs=dp * m_tok, vt_ds=m_tok)
         else:
-            # ragged token count (latent H*W not a multiple of the 64-key tile): per-image projections into zero-padded
-            # K / V^T buffers so that every key tile the kernel touches is real, finite memory
+            # ragged token count (latent H*W not a multiple of the 64-key tile, e.g. SDXL at 832x1216): LayerNorm writes each image's tokens
+            # at a padded stride into a persistent zero-filled buffer, so Q|K and V^T are still ONE batched GEMM each over [Bu * n_pad]
+            # rows; the pad rows are zeros in, zeros out (no bias on q / k / v) and masked by nk in the attention kernel
             npad = -(-n // 64) * 64
-            qk = ops.empty((bu, npad, 2 * hd))
-            vt = ops.empty((hd, bu * npad))
-            qk.zero_()
-            vt.zero_()
-            n1v = n1.view(bu, n, -1)
-            for bi in range(bu):
-                ops.linear(n1v[bi], self.w[b + ".attn1.qk"], out=qk[bi, :n], ld_out=2 * hd)
-                ops.conv_gemm(self.w[b + ".attn1.v"], n1v[bi], n, out=vt[:, bi * npad:bi * npad + n], ld_out=bu * npad)
-            o = ops.attention(qk, qk[:, :, hd:], vt, batch=bu, heads=H, nq=n, nk=n, nk_pad=npad, dpad=dp, scale=d ** -0.5,
+            key = (bu, npad, h.shape[1])
+            padbuf = self._pad_bufs.get(key)
+            if padbuf is None:
+                padbuf = self._pad_bufs[key] = torch.zeros(bu, npad, h.shape[1], dtype=torch.float16, device=self.device)
+            ops.layernorm_padded(h, *self.w[b + ".norm1"], out=padbuf, rows_per_image=n)
+            p2d = padbuf.view(bu * npad, -1)
+            qk = ops.linear(p2d, self.w[b + ".attn1.qk"])                  # [Bu*n_pad, 2*H*dp]
+            vt = ops.conv_gemm(self.w[b + ".attn1.v"], p2d, bu * npad)     # [H*dp, Bu*n_pad]
+            o = ops.attention(qk, qk[:, hd:], vt, batch=bu, heads=H, nq=n, nk=n, nk_pad=npad, dpad=dp, scale=d ** -0.5,
                               q_bs=npad * 2 * hd, q_rs=2 * hd, k_bs=npad * 2 * hd, k_rs=2 * hd, vt_bs=npad,
                               vt_hs=dp * bu * npad, vt_ds=bu * npad)
         ops.linear(o, *self.w[b + ".attn1.out"], residual=h, out=h, ld_out=h.shape[1])

@@ -184,7 +184,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
 }
 
 // ---- LayerNorm: one wave per row, row kept in registers, exact two-pass mean/variance in fp32 -----------------
-// MOD = false: y = LN(x) * gamma + beta.   MOD = true (Flux adaLN, backend/nn/flux.py:209-210,286,326): LN has no affine and
+// MOD = false: y = LN(x) * gamma + beta, row r written to output row (r / rows_per_b) * ld_mod + r % rows_per_b (token rows re-spaced
+// to a padded per-image stride for the attention key tiles; identity when rows_per_b == ld_mod).   MOD = true (Flux adaLN, backend/nn/flux.py:209-210,286,326): LN has no affine and
 // y = (1 + scale[b]) * LN(x) + shift[b] with per-batch vectors gamma := scale + b*ld_mod, beta := shift + b*ld_mod, b = row / rows_per_b.
 template <int MAXOCT, bool MOD>  // octets per lane
 __global__ __launch_bounds__(256) void ln_kernel(const f16* __restrict__ x, const f16* __restrict__ gamma,
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const f16* __restrict__ x, cons
     }
   }
   const float rstd = rsqrtf(wave_sum(q) / (float)c + eps);
-  f16* yr = y + row * c;
+  f16* yr = y + (MOD ? row : (row / rows_per_b) * ld_mod + row % rows_per_b) * c;
   const long moff = MOD ? (row / rows_per_b) * ld_mod : 0;
 #pragma unroll
   for (int j = 0; j < MAXOCT; ++j) {
@@ -293,7 +294,15 @@ extern "C" int fmx_layernorm_f16(const void* x, const void* gamma, const void* b
                                  float eps, void* stream) {
   FMX_REQUIRE(x && gamma && beta && y && rows > 0 && c > 0 && (c % 8) == 0 && c <= 4096, "layernorm: bad args");
   FMX_REQUIRE(fmx_aligned16(x) && fmx_aligned16(y) && fmx_aligned16(gamma) && fmx_aligned16(beta), "layernorm: alignment");
-  return launch_ln<false>(x, gamma, beta, y, rows, c, eps, 1, 0, stream, "fmx_layernorm_f16");
+  return launch_ln<false>(x, gamma, beta, y, rows, c, eps, rows, rows, stream, "fmx_layernorm_f16");
+}
+
+extern "C" int fmx_layernorm_padded_f16(const void* x, const void* gamma, const void* beta, void* y, int64_t rows, int32_t c, float eps,
+                                        int64_t rows_per_image, int64_t out_rows_per_image, void* stream) {
+  FMX_REQUIRE(x && gamma && beta && y && rows > 0 && c > 0 && (c % 8) == 0 && c <= 4096, "layernorm_padded: bad args");
+  FMX_REQUIRE(rows_per_image > 0 && out_rows_per_image >= rows_per_image && rows % rows_per_image == 0, "layernorm_padded: bad row geometry");
+  FMX_REQUIRE(fmx_aligned16(x) && fmx_aligned16(y) && fmx_aligned16(gamma) && fmx_aligned16(beta), "layernorm_padded: alignment");
+  return launch_ln<false>(x, gamma, beta, y, rows, c, eps, rows_per_image, out_rows_per_image, stream, "fmx_layernorm_padded_f16");
 }
 
 extern "C" int fmx_layernorm_mod_f16(const void* x, const void* scale, const void* shift, int64_t ld_mod, int64_t rows_per_batch,

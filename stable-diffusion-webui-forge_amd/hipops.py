@@ -241,6 +241,17 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None):
     return out
 
 
+def layernorm_padded(x, gamma, beta, out, rows_per_image, eps=1e-5):
+    """LayerNorm of x [B*n, C] written into out [B, n_pad, C] (rows n..n_pad of every image are left untouched)."""
+    _check_f16(x, gamma, beta, out)
+    c = x.shape[-1]
+    rows = x.numel() // c
+    assert out.is_contiguous() and out.shape[-1] == c and out.shape[0] * rows_per_image == rows and out.shape[1] >= rows_per_image
+    _lib.check(_lib.lib().fmx_layernorm_padded_f16(_p(x), _p(gamma), _p(beta), _p(out), rows, c, float(eps), rows_per_image, out.shape[1],
+                                                   stream_ptr()), "fmx_layernorm_padded_f16")
+    return out
+
+
 def layernorm_mod(x, scale, shift, rows_per_batch, eps=1e-6, out=None):
     """Flux adaLN: (1 + scale[b]) * LayerNorm(x, no affine) + shift[b]; scale/shift: [B, c] views with a common row stride."""
     _check_f16(x, scale, shift)

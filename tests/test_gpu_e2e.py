@@ -332,6 +332,24 @@ def test_inpainting_model_c_concat_vs_reference_fixture():
     assert max_rel(cond_i2i[:, 1:], want_lat) < 1e-5
 
 
+@pytest.mark.parametrize("name,hw", [("tiny_sd15", (13, 10)), ("tiny_sdxl", (9, 14)), ("tiny_sd15", (26, 19))])
+def test_unet_forward_ragged_token_counts_vs_oracle(name, hw, engines):
+    """Latent sizes whose token counts are not multiples of the 64-key attention tile at any level (e.g. 832x1216 SDXL): LayerNorm writes
+    at a padded per-image stride and the Q|K / V^T projections stay one batched GEMM each."""
+    from oracle.unet import unet_forward
+    cfg = TINY[name]
+    sd = synth.synth_unet_state_dict(cfg, seed=0)
+    g = torch.Generator().manual_seed(9)
+    b = 3
+    x = torch.randn(b, 4, *hw, generator=g)
+    t = torch.tensor([900.0, 500.0, 20.0])
+    ctx = torch.randn(b, 77, cfg["context_dim"], generator=g)
+    y = torch.randn(b, cfg["adm_in_channels"], generator=g) if cfg.get("adm_in_channels") else None
+    net = engines[name].forge_objects.unet.model.diffusion_model
+    eps = net.forward(x.to(DEV), t.to(DEV), context=ctx.to(DEV), y=None if y is None else y.to(DEV))
+    report(f"{name} unet forward at latent {hw[0]}x{hw[1]} (ragged tokens) vs oracle", max_rel(eps, unet_forward(sd, cfg, x, t, ctx, y)), 3e-3)
+
+
 def test_graph_survives_arena_reallocation():
     """A captured UNet graph points into the executor's activation arena.  When a larger shape comes through later (hires second pass, a
     bigger batch) the arena is re-allocated; the old graph must be dropped and re-captured, not replayed on freed memory."""

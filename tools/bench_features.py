@@ -30,9 +30,12 @@ def main():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--res", type=int, default=1024)
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--only", default="samplers,controlnet,hooks,and,hires")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
+    width, height = a.width or a.res, a.height or a.res
     cfg = synth.SDXL_UNET_CONFIG
     eng = build_engine(cfg, synth.synth_state_dict_device(unet_param_shapes(cfg), 0, dev), None, None, device=dev)
     b = a.batch
@@ -50,7 +53,7 @@ def main():
         try:
             def once(n):
                 p = processing.StableDiffusionProcessingTxt2Img(sd_model=eng, c=cond if cond is not None else c1, uc=u1, seed=1, sampler_name=sampler,
-                                                                batch_size=b, steps=n, cfg_scale=7.0, width=a.res, height=a.res, do_decode=False, **kw)
+                                                                batch_size=b, steps=n, cfg_scale=7.0, width=width, height=height, do_decode=False, **kw)
                 return processing.process_images(p).latents
             once(max(3, min(steps, 4)))  # priming (arena, caches, graph)
             torch.cuda.synchronize()
@@ -65,6 +68,8 @@ def main():
         print(json.dumps({"case": label, "sampler": sampler, "steps": steps, "ms_per_step": round(dt / steps * 1e3, 2),
                           "ms_total": round(dt * 1e3, 1), "finite": ok, "shape": list(lat.shape)}), flush=True)
 
+    if "one" in what:
+        run(f"{width}x{height}", sampler="Euler")
     if "samplers" in what:
         for s in ("Euler", "Euler a", "DPM++ 2M", "Heun", "DPM2 a", "DPM++ 2S a", "LMS", "IPNDM_V", "DEIS", "DPM++ SDE", "DPM++ 2M SDE", "DPM++ 3M SDE",
                   "DPM fast", "DDIM", "PLMS", "UniPC", "LCM", "DDPM"):
@@ -84,7 +89,7 @@ def main():
         from forge_amd.backend.nn.cnets import cldm
         from forge_amd.backend.patcher import controlnet as pc
         cn = cldm.ControlNet(cfg, synth.synth_state_dict_device(controlnet_param_shapes(cfg), 6, dev), device=dev)
-        hint = torch.rand(1, 3, a.res, a.res, device=dev)
+        hint = torch.rand(1, 3, height, width, device=dev)
         unet = pc.apply_controlnet_advanced(eng.forge_objects.unet, pc.ControlNet(cn), hint, 0.8, 0.0, 1.0)
         run("ControlNet (SDXL-size control model, strength 0.8)", unet=unet)
     if "hires" in what:
