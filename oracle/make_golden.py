@@ -1173,6 +1173,106 @@ def gen_t2i_adapter(b=2, hw=16):
     print("t2i adapter:", {k: len(v["values_every_4th_channel"]) for k, v in res["features"].items()}, "euler3 std", float(lat.std()))
 
 
+TOKENIZE_PROMPTS = [
+    "a photo of a cat", "", "a (cat:1.3) and a [dog], ((very)) detailed \\(literal\\)", "first part BREAK second part, (emphasised BREAK third:1.2)",
+    "masterpiece, best quality, " + ", ".join(f"tag number {i}" for i in range(40)),                       # > 75 tokens: comma backtracking
+    " ".join(["word"] * 80) + ", tail after a comma",                                                      # no comma within reach: hard cut
+    ", ".join(["a"] * 74) + ", boundary, case",
+    "an embedding myemb in the middle, and again myemb, (myemb:1.4)", " ".join(["filler"] * 73) + " myemb end",
+    "unbalanced (bracket [here", "colon: in text (weight : 0.5 ) x",
+]
+
+
+class ReplayTokenizer:
+    """tokenizer(texts)["input_ids"] from a recorded {text: ids} table (the CLIP vocabulary is 1.5 MB and does not travel); the ids of the
+    special tokens and of ',</w>' are recorded too."""
+
+    def __init__(self, rec):
+        self.table = rec["table"]
+        self.bos_token_id, self.eos_token_id, self.pad_token_id = rec["bos"], rec["eos"], rec["pad"]
+        self._comma = rec["comma"]
+
+    def get_vocab(self):
+        return {",</w>": self._comma}
+
+    def __call__(self, texts, truncation=False, add_special_tokens=False):
+        return {"input_ids": [list(self.table[t]) for t in texts]}
+
+
+class FakeEmbeddingDb:
+    """Textual-inversion database stand-in: the token sequence of 'myemb' maps to a 3-vector embedding."""
+
+    def __init__(self, ids, vectors=3):
+        self.ids = list(ids)
+        self.emb = SimpleNamespace(name="myemb", vectors=vectors, vec=torch.arange(vectors * 8, dtype=torch.float32).reshape(vectors, 8))
+        self.fixes = None
+
+    def find_embedding_at_position(self, tokens, offset):
+        if self.ids and tokens[offset:offset + len(self.ids)] == self.ids:
+            return self.emb, len(self.ids)
+        return None, None
+
+
+def gen_tokenize():
+    """The reference's parse_prompt_attention / ClassicTextProcessingEngine.tokenize_line / get_multicond_prompt_list on a prompt set, with the
+    real CLIP tokenizer (backend/huggingface/runwayml/stable-diffusion-v1-5/tokenizer); every tokenizer call is recorded for replay."""
+    import importlib
+    import types
+    from transformers import CLIPTokenizer  # before the reference's stub modules are installed
+    tok = CLIPTokenizer.from_pretrained(os.path.join(ref_import.REFERENCE_ROOT, "backend", "huggingface", "runwayml", "stable-diffusion-v1-5", "tokenizer"))
+    ref_import.load_reference()
+    saved = {k: sys.modules.get(k) for k in ("PIL", "PIL.Image", "modules", "modules.shared", "lark")}
+    try:
+        for n in ("PIL", "PIL.Image", "modules", "modules.shared", "lark"):
+            sys.modules[n] = types.ModuleType(n)
+        sys.modules["PIL"].Image = sys.modules["PIL.Image"]
+        sys.modules["modules"].__path__ = []
+        sys.modules["modules"].shared = sys.modules["modules.shared"]
+        sys.modules["modules.shared"].opts = SimpleNamespace(emphasis="Original")
+        sys.modules["lark"].Lark = lambda *a, **k: None   # the schedule grammar is not exercised here
+        ce = importlib.import_module("backend.text_processing.classic_engine")
+        parsing = importlib.import_module("backend.text_processing.parsing")
+        spec = importlib.util.spec_from_file_location("_ref_prompt_parser", os.path.join(ref_import.REFERENCE_ROOT, "modules", "prompt_parser.py"))
+        rpp = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(rpp)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    table = {}
+
+    class Recording:
+        bos_token_id, eos_token_id, pad_token_id = tok.bos_token_id, tok.eos_token_id, tok.pad_token_id
+
+        def get_vocab(self):
+            return tok.get_vocab()
+
+        def __call__(self, texts, **kw):
+            out = tok(texts, **kw)
+            for t, ids in zip(texts, out["input_ids"]):
+                table[t] = list(ids)
+            return out
+    enc = SimpleNamespace(transformer=SimpleNamespace(text_model=SimpleNamespace(embeddings=SimpleNamespace(token_embedding=SimpleNamespace(weight=None)))))
+    eng = ce.ClassicTextProcessingEngine(enc, Recording(), emphasis_name="Original")
+    emb_ids = tok(["myemb"], truncation=False, add_special_tokens=False)["input_ids"][0]
+    eng.embeddings = FakeEmbeddingDb(emb_ids)
+    res = {"prompts": TOKENIZE_PROMPTS, "emb_ids": emb_ids, "lines": [], "parsed": []}
+    for pr in TOKENIZE_PROMPTS:
+        chunks, count = eng.tokenize_line(pr)
+        res["lines"].append({"count": count, "chunks": [{"tokens": c.tokens, "multipliers": c.multipliers, "fixes": [f.offset for f in c.fixes]} for c in chunks]})
+        res["parsed"].append(parsing.parse_prompt_attention(pr, "Original"))
+    batch_chunks, token_count = eng.process_texts(TOKENIZE_PROMPTS[:4])
+    res["process_texts"] = {"token_count": token_count, "n_chunks": [len(c) for c in batch_chunks]}
+    and_prompts = ["a cat AND a dog :1.5 AND a bird: 0.25", "plain", "x AND x", "sandy AND candy:2"]
+    idx, flat, pidx = rpp.get_multicond_prompt_list(and_prompts)
+    res["multicond"] = {"prompts": and_prompts, "indexes": idx, "flat": list(flat), "prompt_indexes": pidx}
+    res["tokenizer"] = {"table": table, "bos": tok.bos_token_id, "eos": tok.eos_token_id, "pad": tok.pad_token_id, "comma": tok.get_vocab().get(",</w>")}
+    torch.save(res, os.path.join(GOLD, "tokenize_clip_l.pt"))
+    print("tokenize:", [(l["count"], len(l["chunks"])) for l in res["lines"]], res["multicond"]["indexes"])
+
+
 def gen_schedulers():
     """modules/sd_schedulers.py's table, imported from the reference with a two-attribute stand-in for modules.shared."""
     import importlib.util
@@ -1380,6 +1480,8 @@ def main():
         net, _ = gen_unet("tiny_sd15", synth.TINY_SD15_UNET_CONFIG)
         gen_samples_extra("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
         gen_samples_more("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
+    if a.only in ("", "tokenize"):
+        gen_tokenize()
     if a.only in ("", "t2i"):
         gen_t2i_adapter()
     if a.only == "lora":

@@ -47,19 +47,22 @@ class ForgeDiffusionEngine:
         return sample.to(x)
 
     # ---- text conditioning (sd15.py:19-73, sdxl.py:22-120), from TOKEN batches: tokenisation is host-side string work ----------
-    def attach_text_encoders(self, clip_l, clip_g=None):
-        """clip_l / clip_g: forge_amd.backend.nn.clip.IntegratedCLIP.  Engine options as the reference constructs them."""
-        from ..text_processing.classic_engine import ClassicTextProcessingEngine
+    def attach_text_encoders(self, clip_l, clip_g=None, tokenizer_l=None, tokenizer_g=None, embeddings_l=None, embeddings_g=None):
+        """clip_l / clip_g: forge_amd.backend.nn.clip.IntegratedCLIP.  Engine options as the reference constructs them.  With tokenizers
+        (CLIPTokenizer objects of the user's install) `get_learned_conditioning` also takes prompt STRINGS (`SdConditioning([...])`)."""
+        from functools import partial
+        from ..text_processing.classic_engine import ClassicTextProcessingEngine as _Engine
+        tl, tg = dict(tokenizer=tokenizer_l, embeddings=embeddings_l), dict(tokenizer=tokenizer_g, embeddings=embeddings_g)
         if self.is_sdxl:
             if clip_g is None:
                 raise ValueError("SDXL needs both text encoders")
-            self.text_processing_engine_l = ClassicTextProcessingEngine(clip_l, embedding_key="clip_l", text_projection=False, minimal_clip_skip=2,
-                                                                        clip_skip=2, return_pooled=False, final_layer_norm=False)
-            self.text_processing_engine_g = ClassicTextProcessingEngine(clip_g, embedding_key="clip_g", text_projection=True, minimal_clip_skip=2,
-                                                                        clip_skip=2, return_pooled=True, final_layer_norm=False)
+            self.text_processing_engine_l = _Engine(clip_l, embedding_key="clip_l", text_projection=False, minimal_clip_skip=2, clip_skip=2,
+                                                    return_pooled=False, final_layer_norm=False, **tl)
+            self.text_processing_engine_g = _Engine(clip_g, embedding_key="clip_g", text_projection=True, minimal_clip_skip=2, clip_skip=2,
+                                                    return_pooled=True, final_layer_norm=False, **tg)
         else:
-            self.text_processing_engine = ClassicTextProcessingEngine(clip_l, embedding_key="clip_l", text_projection=False, minimal_clip_skip=1,
-                                                                      clip_skip=1, return_pooled=False, final_layer_norm=True)
+            self.text_processing_engine = _Engine(clip_l, embedding_key="clip_l", text_projection=False, minimal_clip_skip=1, clip_skip=1,
+                                                  return_pooled=False, final_layer_norm=True, **tl)
 
     def set_clip_skip(self, clip_skip):
         for name in ("text_processing_engine", "text_processing_engine_l", "text_processing_engine_g"):
@@ -71,12 +74,23 @@ class ForgeDiffusionEngine:
         """`prompt`: TokenizedPrompts (below).  SD1.x -> tensor [B, 77 n, 768]; SDXL -> {'crossattn': [B, 77 n, 2048], 'vector': [B, 2816]}
         (sdxl.py:76-117: penultimate CLIP-L | CLIP-G states, pooled-projected CLIP-G + six 256-wide size / crop embeddings)."""
         from ... import hipops as ops
-        if not self.is_sdxl:
+        if not isinstance(prompt, TokenizedPrompts):
+            # prompt strings (modules/prompt_parser.SdConditioning or a plain list), as Forge calls it (sd15.py:62-73, sdxl.py:76-117)
+            texts = list(prompt)
+            side = {"width": getattr(prompt, "width", None) or 1024, "height": getattr(prompt, "height", None) or 1024,
+                    "is_negative_prompt": getattr(prompt, "is_negative_prompt", False), "all_empty": all(x == "" for x in texts)}
+            if not self.is_sdxl:
+                return self.text_processing_engine.encode_texts(texts)
+            cond_l = self.text_processing_engine_l.encode_texts(texts)
+            cond_g = self.text_processing_engine_g.encode_texts(texts)
+            prompt = TokenizedPrompts(None, None, **side)
+        elif not self.is_sdxl:
             if not hasattr(self, "text_processing_engine"):
                 raise RuntimeError("no text encoder attached: attach_text_encoders() or pass cond tensors to the processing object")
             return self.text_processing_engine(prompt.tokens_l, prompt.multipliers_l)
-        cond_l = self.text_processing_engine_l(prompt.tokens_l, prompt.multipliers_l)
-        cond_g = self.text_processing_engine_g(prompt.tokens_g, prompt.multipliers_g)
+        else:
+            cond_l = self.text_processing_engine_l(prompt.tokens_l, prompt.multipliers_l)
+            cond_g = self.text_processing_engine_g(prompt.tokens_g, prompt.multipliers_g)
         clip_pooled = cond_g.pooled
         vals = [prompt.height, prompt.width, prompt.crop_top, prompt.crop_left, prompt.height, prompt.width]  # sdxl.py:93-96
         t = torch.tensor([float(v) for v in vals], dtype=torch.float32, device=self.device)

@@ -2,8 +2,10 @@
 `ScheduledPromptConditioning` lists (prompt editing: the cond changes at given steps), `MulticondLearnedConditioning` (AND-composed
 prompts: several weighted conds per image) and their per-step resolution `reconstruct_cond_batch` / `reconstruct_multicond_batch` /
 `stack_conds`.  Ready tensors (`[B,T,D]` or `DictWithShape{crossattn, vector}`) are accepted wherever a schedule is, standing for plain
-prompts.  The string side (the `[from:to:when]` / `AND` / `(emphasis:1.2)` grammars, :26-127, :205-230) is host text processing outside
-the path: schedules and weights arrive here already parsed."""
+prompts.  `get_multicond_prompt_list` (the AND / `:weight` splitting, :205-230) and `get_learned_conditioning` / `get_multicond_learned_conditioning`
+(:150-202, :245-268) are here too; the `[from:to:when]` prompt-editing grammar (a lark Earley grammar, :26-127) is not -- its result (the per-prompt
+schedule list) is an input."""
+import re
 from collections import namedtuple
 
 import torch
@@ -61,6 +63,58 @@ class SdConditioning(list):
         self.width = width or getattr(copy_from, "width", None)
         self.height = height or getattr(copy_from, "height", None)
         self.distilled_cfg_scale = distilled_cfg_scale or getattr(copy_from, "distilled_cfg_scale", None)
+
+
+_AND = re.compile(r"\bAND\b")
+_WEIGHT = re.compile(r"^((?:\s|.)*?)(?:\s*:\s*([-+]?(?:\d+\.?|\d*\.\d+)))?\s*$")
+
+
+def get_multicond_prompt_list(prompts):
+    """:208-230: split every prompt at the AND keyword, read an optional trailing `:weight` off each part, de-duplicate identical part texts.
+    -> (per prompt [(index into flat list, weight), ...], flat SdConditioning of part texts, {text: index})."""
+    res_indexes, prompt_indexes = [], {}
+    flat = SdConditioning(prompts)
+    flat.clear()
+    for prompt in prompts:
+        indexes = []
+        for sub in _AND.split(prompt):
+            m = _WEIGHT.search(sub)
+            text, weight = m.groups() if m is not None else (sub, 1.0)
+            weight = float(weight) if weight is not None else 1.0
+            if text not in prompt_indexes:
+                prompt_indexes[text] = len(flat)
+                flat.append(text)
+            indexes.append((prompt_indexes[text], weight))
+        res_indexes.append(indexes)
+    return res_indexes, flat, prompt_indexes
+
+
+def get_learned_conditioning(model, prompts, steps, hires_steps=None, use_old_scheduling=False, schedules=None):
+    """:150-202 with the prompt-editing grammar factored out: `schedules[i]` = [[end_at_step, text], ...] for prompt i (what
+    get_learned_conditioning_prompt_schedules returns; default: the whole prompt for all `steps`).  Every distinct text is encoded once by
+    `model.get_learned_conditioning(SdConditioning(texts))` -> list of per-prompt [ScheduledPromptConditioning, ...]."""
+    if schedules is None:
+        schedules = [[[steps, p]] for p in prompts]
+    res, cache = [], {}
+    for prompt, sched in zip(prompts, schedules):
+        if prompt in cache:
+            res.append(cache[prompt])
+            continue
+        conds = model.get_learned_conditioning(SdConditioning([text for _, text in sched], copy_from=prompts))
+        out = []
+        for i, (end_at_step, _) in enumerate(sched):
+            out.append(ScheduledPromptConditioning(end_at_step, {k: v[i] for k, v in conds.items()} if isinstance(conds, dict) else conds[i]))
+        cache[prompt] = out
+        res.append(out)
+    return res
+
+
+def get_multicond_learned_conditioning(model, prompts, steps, hires_steps=None, use_old_scheduling=False, schedules_for=None):
+    """:245-268: AND-composed prompts -> MulticondLearnedConditioning.  schedules_for(flat_texts) may supply prompt-editing schedules."""
+    res_indexes, flat, _ = get_multicond_prompt_list(prompts)
+    learned = get_learned_conditioning(model, flat, steps, hires_steps, use_old_scheduling, None if schedules_for is None else schedules_for(flat))
+    return MulticondLearnedConditioning((len(prompts),), [[ComposableScheduledPromptConditioning(learned[i], w) for i, w in indexes]
+                                                         for indexes in res_indexes])
 
 
 def _as_cond(c):

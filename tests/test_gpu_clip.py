@@ -108,3 +108,28 @@ def test_textual_inversion_fixes_and_emphasis_modes():
         if mode == "Original":
             ref = ref * (want.mean() / ref.mean())
         report(f"emphasis mode {mode}", max_rel(got, ref), 4e-3)
+
+
+def test_prompt_strings_end_to_end():
+    """Strings -> emphasis parsing -> chunking (replayed CLIP tokenizer) -> native CLIP -> conditioning, equal to feeding the same token
+    batches; the vocabulary of the tiny test encoder is smaller than CLIP's, so ids are folded into it on both sides."""
+    from forge_amd.backend.diffusion_engine.base import ForgeDiffusionEngine
+    from oracle.make_golden import ReplayTokenizer
+    g = load_golden("tokenize_clip_l.pt")
+    cfg = synth.TINY_CLIP_L_CONFIG
+    rec = dict(g["tokenizer"])
+    fold = lambda i: int(i) % (cfg["vocab_size"] - 3) if i not in (rec["bos"], rec["eos"]) else (cfg["vocab_size"] - 2 if i == rec["bos"] else cfg["vocab_size"] - 1)
+    rec = {"table": {t: [fold(i) for i in ids] for t, ids in rec["table"].items()}, "bos": cfg["vocab_size"] - 2, "eos": cfg["vocab_size"] - 1,
+           "pad": cfg["vocab_size"] - 1, "comma": fold(rec["comma"])}
+    eng = ForgeDiffusionEngine.__new__(ForgeDiffusionEngine)
+    eng.is_sdxl, eng.device = False, torch.device(DEV)
+    eng.attach_text_encoders(IntegratedCLIP(cfg, synth.synth_clip_state_dict(cfg), device=DEV), tokenizer_l=ReplayTokenizer(rec))
+    prompts = [g["prompts"][2], g["prompts"][3], g["prompts"][0]]
+    cond = eng.get_learned_conditioning(prompts)
+    assert tuple(cond.shape) == (3, 2 * 77, cfg["hidden_size"])   # the BREAK prompt has two chunks; shorter prompts get an empty second chunk
+    te = eng.text_processing_engine
+    chunks = [te.tokenize_line(p)[0] for p in prompts]
+    toks = [[(c[i] if i < len(c) else te.empty_chunk()).tokens for c in chunks] for i in range(2)]
+    mult = [[(c[i] if i < len(c) else te.empty_chunk()).multipliers for c in chunks] for i in range(2)]
+    assert torch.equal(cond, te(toks, mult))
+    assert float((cond[0, :77] - cond[2, :77]).abs().max()) > 1e-3

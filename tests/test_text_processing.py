@@ -1,0 +1,50 @@
+"""CPU: the string side of the text path -- prompt-attention syntax, 75-token chunking with comma backtracking / BREAK / textual-inversion
+placeholders, AND-composition lists -- against the REFERENCE's parse_prompt_attention, ClassicTextProcessingEngine.tokenize_line (run with the
+real CLIP tokenizer; every tokenizer call recorded and replayed here) and get_multicond_prompt_list (tests/golden/tokenize_clip_l.pt)."""
+import torch
+
+from forge_amd.backend.text_processing.classic_engine import ClassicTextProcessingEngine
+from forge_amd.backend.text_processing.parsing import parse_prompt_attention
+from forge_amd.modules import prompt_parser as pp
+from oracle.make_golden import FakeEmbeddingDb, ReplayTokenizer
+
+from conftest import load_golden
+
+
+def test_parse_prompt_attention_vs_reference():
+    g = load_golden("tokenize_clip_l.pt")
+    for prompt, want in zip(g["prompts"], g["parsed"]):
+        assert parse_prompt_attention(prompt, "Original") == want, prompt
+    assert parse_prompt_attention("(a:1.2) [b]", "None") == [["(a:1.2) [b]", 1.0]]
+
+
+def test_tokenize_line_chunking_vs_reference():
+    g = load_golden("tokenize_clip_l.pt")
+    eng = ClassicTextProcessingEngine(None, tokenizer=ReplayTokenizer(g["tokenizer"]), embeddings=FakeEmbeddingDb(g["emb_ids"]))
+    for prompt, want in zip(g["prompts"], g["lines"]):
+        chunks, count = eng.tokenize_line(prompt)
+        assert count == want["count"] and len(chunks) == len(want["chunks"]), prompt
+        for c, w in zip(chunks, want["chunks"]):
+            assert c.tokens == w["tokens"] and c.multipliers == w["multipliers"] and [f.offset for f in c.fixes] == w["fixes"], prompt
+            assert len(c.tokens) == 77
+    batch_chunks, token_count = eng.process_texts(g["prompts"][:4])
+    assert token_count == g["process_texts"]["token_count"] and [len(c) for c in batch_chunks] == g["process_texts"]["n_chunks"]
+    assert eng.get_target_prompt_token_count(76) == 150 and eng.empty_chunk().tokens[:2] == [g["tokenizer"]["bos"], g["tokenizer"]["eos"]]
+
+
+def test_multicond_prompt_list_and_objects():
+    g = load_golden("tokenize_clip_l.pt")["multicond"]
+    idx, flat, pidx = pp.get_multicond_prompt_list(g["prompts"])
+    assert idx == g["indexes"] and list(flat) == g["flat"] and pidx == g["prompt_indexes"]
+
+    class Model:  # encodes a text as a [2, 4] tensor filled with its length
+        def get_learned_conditioning(self, texts):
+            return torch.stack([torch.full((2, 4), float(len(t))) for t in texts])
+    mc = pp.get_multicond_learned_conditioning(Model(), g["prompts"], steps=20)
+    assert mc.shape == (len(g["prompts"]),) and [[part.weight for part in parts] for parts in mc.batch] == [[w for _, w in i] for i in idx]
+    conds_list, stacked = pp.reconstruct_multicond_batch(mc, 3)
+    assert conds_list[0] == [(0, 1.0), (1, 1.5), (2, 0.25)] and stacked.shape[0] == sum(len(i) for i in idx)
+    # prompt editing: explicit schedules, resolved per step
+    sched = pp.get_learned_conditioning(Model(), ["ab", "c"], 10, schedules=[[[4, "a"], [10, "abc"]], [[10, "c"]]])
+    assert [e.end_at_step for e in sched[0]] == [4, 10]
+    assert float(pp.reconstruct_cond_batch(sched, 4)[0, 0, 0]) == 1.0 and float(pp.reconstruct_cond_batch(sched, 5)[0, 0, 0]) == 3.0

@@ -101,6 +101,16 @@ if __name__ == "__main__":
             bench_attn(16, 10, 4096, 77, 64, 64, f32)
             bench_attn(2, 10, 4096, 4096, 64, 64, f32)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "smallm":
+        # batch-1 shapes (UNet batch 2): which tile is fastest, and what does the dispatcher (tile 0) pick?
+        for m, n, k in ((2048, 1280, 1280), (2048, 1280, 5120), (2048, 2560, 1280), (1280, 2048, 1280), (8192, 640, 640), (8192, 1280, 640),
+                        (4096, 1280, 1280), (4096, 1280, 5120)):
+            for tile in (0, 1, 2, 3, 5, 6, 7, 8):
+                try:
+                    bench_linear(m, n, k, tile)
+                except Exception as e:
+                    print(json.dumps({"m": m, "n": n, "k": k, "tile": tile, "error": str(e)[:80]}), flush=True)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "gemm":
         gemm_sweep()
         sys.exit(0)
