@@ -38,8 +38,10 @@ def decode_latent_batch(model, batch, target_device=None, check_for_nans=False):
 @dataclass
 class StableDiffusionProcessingTxt2Img:
     sd_model: Any = None
-    c: Any = None                 # cond:   tensor [B,T,D] or {"crossattn","vector"} (prompt_parser.DictWithShape)
+    c: Any = None                 # cond:   tensor [B,T,D] or {"crossattn","vector"} (prompt_parser.DictWithShape), or schedule objects
     uc: Any = None                # uncond: same
+    prompt: Any = None            # or prompt strings (str, or a list of n_iter * batch_size strings): encoded by setup_conds through the
+    negative_prompt: Any = ""     #   engine's text encoders (needs attach_text_encoders(..., tokenizer_l=...))
     seed: int = -1
     sampler_name: str = "Euler"
     scheduler: Optional[str] = None
@@ -112,6 +114,23 @@ class StableDiffusionProcessingTxt2Img:
         if getattr(self.sd_model, "is_inpaint", False):  # processing.py:360-378
             return self.inpainting_image_conditioning(source_image.float(), latent_image, image_mask=image_mask, round_image_mask=round_image_mask)
         return latent_image.new_zeros(latent_image.shape[0], 5, 1, 1)
+
+    def setup_conds(self):
+        """processing.py:489-506: prompts -> p.c (MulticondLearnedConditioning: AND parts, prompt-editing schedules) and p.uc (schedules; None
+        at cfg_scale == 1).  Only when no ready conditioning was supplied."""
+        from . import prompt_parser
+        if self.c is not None or self.prompt is None:
+            return
+        total = self.batch_size * self.n_iter
+        prompts = list(self.prompt) if isinstance(self.prompt, (list, tuple)) else [self.prompt] * total
+        negs = list(self.negative_prompt) if isinstance(self.negative_prompt, (list, tuple)) else [self.negative_prompt] * len(prompts)
+        if len(prompts) != len(negs):
+            raise RuntimeError(f"Received a different number of prompts ({len(prompts)}) and negative prompts ({len(negs)})")
+        config = sd_samplers.find_sampler_config(self.sampler_name)
+        total_steps = config.total_steps(self.steps) if config else self.steps
+        mk = lambda texts, neg: prompt_parser.SdConditioning(texts, width=self.width, height=self.height, is_negative_prompt=neg)
+        self.uc = None if self.cfg_scale == 1 else prompt_parser.get_learned_conditioning(self.sd_model, mk(negs, True), total_steps)
+        self.c = prompt_parser.get_multicond_learned_conditioning(self.sd_model, mk(prompts, False), total_steps)
 
     def calculate_target_resolution(self):
         """processing.py:1246-1273."""
@@ -251,6 +270,8 @@ def _slice_cond(c, a, b):
 
 
 def process_images(p) -> Processed:
+    if hasattr(p, "setup_conds"):
+        p.setup_conds()
     shared.sd_model = p.sd_model  # the reference's p.sd_model IS shared.sd_model (processing.py:252-258); schedulers read is_sdxl from it
     return process_images_inner(p)
 

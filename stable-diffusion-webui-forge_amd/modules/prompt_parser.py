@@ -3,8 +3,8 @@
 prompts: several weighted conds per image) and their per-step resolution `reconstruct_cond_batch` / `reconstruct_multicond_batch` /
 `stack_conds`.  Ready tensors (`[B,T,D]` or `DictWithShape{crossattn, vector}`) are accepted wherever a schedule is, standing for plain
 prompts.  `get_multicond_prompt_list` (the AND / `:weight` splitting, :205-230) and `get_learned_conditioning` / `get_multicond_learned_conditioning`
-(:150-202, :245-268) are here too; the `[from:to:when]` prompt-editing grammar (a lark Earley grammar, :26-127) is not -- its result (the per-prompt
-schedule list) is an input."""
+(:150-202, :245-268) and the `[from:to:when]` / `[a|b]` prompt-editing grammar (:7-127; a lark Earley grammar in the reference, an ordered-choice
+recursive-descent parser here, checked against the reference's own doctests) are host text processing that feeds them."""
 import re
 from collections import namedtuple
 
@@ -65,6 +65,186 @@ class SdConditioning(list):
         self.distilled_cfg_scale = distilled_cfg_scale or getattr(copy_from, "distilled_cfg_scale", None)
 
 
+# ---- prompt editing: "[from:to:when]", "[to:when]", "[from::when]", "[a|b|c]" (prompt_parser.py:7-127) ---------------------------------------
+# The reference parses this with a lark Earley grammar (:18-29).  The language is small enough for ordered-choice recursive descent: inside a
+# prompt, "[" opens (in this order) a scheduled, an alternate or an emphasised group, "(" an emphasised group; a bracket that opens none of them
+# ends the enclosing prompt, and at the top level the six punctuation characters "[]():" (not "|") may also stand alone as literal text.
+class _NoParse(Exception):
+    pass
+
+
+_PLAIN = re.compile(r"(?:[^\\\[\]():|]|\\.)+", re.S)
+_WS = re.compile(r"\s+")
+_NUMBER = re.compile(r"[+-]?(?:\d+\.\d*|\.\d+|\d+)(?:[eE][+-]?\d+)?")
+
+
+def _parse_prompt(s, i):
+    """prompt: (emphasized | scheduled | alternate | plain | WHITESPACE)*  ->  (nodes, next index)."""
+    nodes = []
+    while i < len(s):
+        ch = s[i]
+        m = _PLAIN.match(s, i)
+        if m:
+            nodes.append(m.group(0))
+            i = m.end()
+        elif ch == "[":
+            for rule in (_parse_scheduled, _parse_alternate, _parse_square):
+                try:
+                    node, i = rule(s, i)
+                    break
+                except _NoParse:
+                    continue
+            else:
+                return nodes, i
+            nodes.append(node)
+        elif ch == "(":
+            try:
+                node, i = _parse_round(s, i)
+            except _NoParse:
+                return nodes, i
+            nodes.append(node)
+        else:
+            return nodes, i
+    return nodes, i
+
+
+def _expect(s, i, ch):
+    if i >= len(s) or s[i] != ch:
+        raise _NoParse
+    return i + 1
+
+
+def _parse_scheduled(s, i):
+    """"[" [prompt ":"] prompt ":" [WS] NUMBER [WS] "]" """
+    i = _expect(s, i, "[")
+    first, i = _parse_prompt(s, i)
+    i = _expect(s, i, ":")
+
+    def tail(j):
+        m = _WS.match(s, j)
+        j = m.end() if m else j
+        num = _NUMBER.match(s, j)
+        if not num:
+            raise _NoParse
+        j = num.end()
+        m = _WS.match(s, j)
+        j = m.end() if m else j
+        return num.group(0), _expect(s, j, "]")
+    try:  # two-part form first: "[" prompt ":" prompt ":" NUMBER "]"
+        second, j = _parse_prompt(s, i)
+        j = _expect(s, j, ":")
+        when, j = tail(j)
+        return ("scheduled", first, second, when), j
+    except _NoParse:
+        when, j = tail(i)
+        return ("scheduled", None, first, when), j
+
+
+def _parse_alternate(s, i):
+    """"[" prompt ("|" [prompt])+ "]" """
+    i = _expect(s, i, "[")
+    first, i = _parse_prompt(s, i)
+    options = [first]
+    i = _expect(s, i, "|")
+    while True:
+        opt, i = _parse_prompt(s, i)
+        options.append(opt)
+        if i < len(s) and s[i] == "|":
+            i += 1
+            continue
+        return ("alternate", options), _expect(s, i, "]")
+
+
+def _parse_square(s, i):
+    i = _expect(s, i, "[")
+    inner, i = _parse_prompt(s, i)
+    return ("group", "[", inner, "]"), _expect(s, i, "]")
+
+
+def _parse_round(s, i):
+    """"(" prompt ")" | "(" prompt ":" prompt ")" """
+    i = _expect(s, i, "(")
+    inner, i = _parse_prompt(s, i)
+    if i < len(s) and s[i] == ":":
+        second, j = _parse_prompt(s, i + 1)
+        return ("group", "(", inner + [":"] + second, ")"), _expect(s, j, ")")
+    return ("group", "(", inner, ")"), _expect(s, i, ")")
+
+
+def _parse_schedule_tree(s):
+    """start: (prompt | /[][():]/+)*"""
+    nodes, i = [], 0
+    while i < len(s):
+        part, j = _parse_prompt(s, i)
+        nodes += part
+        if j < len(s):
+            if s[j] not in "[]():":
+                raise _NoParse  # e.g. a top-level "|": no parse, the prompt is used as is (:119-124)
+            nodes.append(s[j])
+            j += 1
+        i = j
+    return nodes
+
+
+def get_learned_conditioning_prompt_schedules(prompts, base_steps, hires_steps=None, use_old_scheduling=False):
+    """:31-127 -> per prompt [[end_at_step, text], ...].  `when` with a decimal point is a fraction of the steps, otherwise a step number;
+    in a hires pass (hires_steps given) integers count on from base_steps and fractions from 1.0 (:49-57)."""
+    if hires_steps is None or use_old_scheduling:
+        int_offset, flt_offset, steps = 0, 0, base_steps
+    else:
+        int_offset, flt_offset, steps = base_steps, 1.0, hires_steps
+
+    def when_of(token):
+        v = float(token)
+        if use_old_scheduling:
+            v = v * steps if v < 1 else v
+        elif "." in token:
+            v = (v - flt_offset) * steps
+        else:
+            v = v - int_offset
+        return min(steps, int(v))
+
+    def collect(nodes, out):
+        for n in nodes:
+            if isinstance(n, tuple):
+                if n[0] == "scheduled":
+                    w = when_of(n[3])
+                    if w >= 1:
+                        out.add(w)
+                    collect(n[1] or [], out)
+                    collect(n[2], out)
+                elif n[0] == "alternate":
+                    out.update(range(1, steps + 1))
+                    for o in n[1]:
+                        collect(o, out)
+                else:
+                    collect(n[2], out)
+
+    def render(nodes, step):
+        parts = []
+        for n in nodes:
+            if isinstance(n, str):
+                parts.append(n)
+            elif n[0] == "scheduled":
+                parts.append(render(n[1] or [], step) if step <= when_of(n[3]) else render(n[2], step))
+            elif n[0] == "alternate":
+                parts.append(render(n[1][(step - 1) % len(n[1])], step))
+            else:
+                parts.append(n[1] + render(n[2], step) + n[3])
+        return "".join(parts)
+
+    def schedule(prompt):
+        try:
+            tree = _parse_schedule_tree(prompt)
+        except _NoParse:
+            return [[steps, prompt]]
+        marks = {steps}
+        collect(tree, marks)
+        return [[t, render(tree, t)] for t in sorted(marks)]
+    cache = {p: schedule(p) for p in set(prompts)}
+    return [cache[p] for p in prompts]
+
+
 _AND = re.compile(r"\bAND\b")
 _WEIGHT = re.compile(r"^((?:\s|.)*?)(?:\s*:\s*([-+]?(?:\d+\.?|\d*\.\d+)))?\s*$")
 
@@ -94,7 +274,7 @@ def get_learned_conditioning(model, prompts, steps, hires_steps=None, use_old_sc
     get_learned_conditioning_prompt_schedules returns; default: the whole prompt for all `steps`).  Every distinct text is encoded once by
     `model.get_learned_conditioning(SdConditioning(texts))` -> list of per-prompt [ScheduledPromptConditioning, ...]."""
     if schedules is None:
-        schedules = [[[steps, p]] for p in prompts]
+        schedules = get_learned_conditioning_prompt_schedules(prompts, steps, hires_steps, use_old_scheduling)
     res, cache = [], {}
     for prompt, sched in zip(prompts, schedules):
         if prompt in cache:

@@ -133,3 +133,50 @@ def test_prompt_strings_end_to_end():
     mult = [[(c[i] if i < len(c) else te.empty_chunk()).multipliers for c in chunks] for i in range(2)]
     assert torch.equal(cond, te(toks, mult))
     assert float((cond[0, :77] - cond[2, :77]).abs().max()) > 1e-3
+
+
+class WordHashTokenizer:
+    """Any-prompt stand-in for CLIPTokenizer in wiring tests: words and punctuation -> crc32 % vocab (the real vocabulary does not travel)."""
+
+    def __init__(self, vocab):
+        self.vocab = vocab
+        self.bos_token_id, self.eos_token_id, self.pad_token_id = vocab - 2, vocab - 1, vocab - 1
+
+    def _id(self, w):
+        import zlib
+        return zlib.crc32(w.encode()) % (self.vocab - 3)
+
+    def get_vocab(self):
+        return {",</w>": self._id(",")}
+
+    def __call__(self, texts, truncation=False, add_special_tokens=False):
+        import re
+        return {"input_ids": [[self._id(w) for w in re.findall(r"[A-Za-z0-9]+|[^\sA-Za-z0-9]", t)] for t in texts]}
+
+
+def test_processing_from_prompt_strings_with_and_and_editing():
+    """processing.setup_conds (processing.py:489-506): prompt strings -> AND parts with weights + prompt-editing schedules + emphasis -> native CLIP
+    -> MulticondLearnedConditioning / scheduled uncond -> sampling.  Checked against the same job assembled by hand from the pieces."""
+    from forge_amd.backend.diffusion_engine.base import build_engine
+    from forge_amd.modules import processing, prompt_parser as pp, shared
+    ucfg, ccfg = synth.TINY_SD15_UNET_CONFIG, synth.TINY_CLIP_L_CONFIG
+    eng = build_engine(ucfg, synth.synth_unet_state_dict(ucfg, seed=0), None, None, device=DEV)
+    eng.attach_text_encoders(IntegratedCLIP(ccfg, synth.synth_clip_state_dict(ccfg), device=DEV), tokenizer_l=WordHashTokenizer(ccfg["vocab_size"]))
+    shared.opts.randn_source = "CPU"
+    prompts = ["a (red:1.3) [fox:wolf:2] in snow AND misty forest :0.6", "a castle, [day|night] sky AND storm clouds :0.6"]
+    kw = dict(sd_model=eng, seed=21, sampler_name="Euler", batch_size=2, steps=4, cfg_scale=6.0, width=128, height=128, do_decode=False)
+    got = processing.process_images(processing.StableDiffusionProcessingTxt2Img(prompt=prompts, negative_prompt="blurry, [low:high:0.5] quality", **kw))
+    # by hand: schedules from the grammar, every text encoded once, objects built explicitly
+    enc = lambda texts: eng.get_learned_conditioning(pp.SdConditioning(texts, width=128, height=128))
+    idx, flat, _ = pp.get_multicond_prompt_list(prompts)
+    scheds = pp.get_learned_conditioning_prompt_schedules(list(flat), 4)
+    assert scheds[0] == [[2, "a (red:1.3) fox in snow"], [4, "a (red:1.3) wolf in snow"]] and len(scheds[2]) == 4
+    # (all texts of one schedule are encoded in ONE batch, as prompt_parser.py:186-187 does: "Original" emphasis renormalises by the batch mean)
+    parts = [[pp.ScheduledPromptConditioning(t, cnd) for (t, _), cnd in zip(s, enc([text for _, text in s]))] for s in scheds]
+    c = pp.MulticondLearnedConditioning((2,), [[pp.ComposableScheduledPromptConditioning(parts[i], w) for i, w in ix] for ix in idx])
+    nsched = pp.get_learned_conditioning_prompt_schedules(["blurry, [low:high:0.5] quality"], 4)[0]
+    uc = [[pp.ScheduledPromptConditioning(t, cnd) for (t, _), cnd in zip(nsched, enc([text for _, text in nsched]))]] * 2
+    want = processing.process_images(processing.StableDiffusionProcessingTxt2Img(c=c, uc=uc, **kw))
+    assert torch.equal(got.latents, want.latents) and bool(torch.isfinite(got.latents).all())
+    plain = processing.process_images(processing.StableDiffusionProcessingTxt2Img(prompt="a red fox in snow", negative_prompt="", **kw))
+    assert float((plain.latents - got.latents).abs().max()) > 1e-2

@@ -48,3 +48,33 @@ def test_multicond_prompt_list_and_objects():
     sched = pp.get_learned_conditioning(Model(), ["ab", "c"], 10, schedules=[[[4, "a"], [10, "abc"]], [[10, "c"]]])
     assert [e.end_at_step for e in sched[0]] == [4, 10]
     assert float(pp.reconstruct_cond_batch(sched, 4)[0, 0, 0]) == 1.0 and float(pp.reconstruct_cond_batch(sched, 5)[0, 0, 0]) == 3.0
+
+
+def test_prompt_editing_schedules_match_the_reference_doctests():
+    """Known answers: the doctest block of get_learned_conditioning_prompt_schedules (modules/prompt_parser.py:32-71; lark is not installed here,
+    so the reference parser itself cannot run) and the worked example in the comment at its top (:7-13).  One doctest is left out: the reference
+    marks `[{b|d{:.5]` as "not handling this right now" and its stated answer contradicts the grammar ('|' is not a plain character)."""
+    g = lambda p, base=10, hires=None: pp.get_learned_conditioning_prompt_schedules([p], base, hires)[0]
+    assert g("test") == [[10, "test"]]
+    assert g("a [b:3]") == [[3, "a "], [10, "a b"]]
+    assert g("a [b: 3]") == [[3, "a "], [10, "a b"]]
+    assert g("a [[[b]]:2]") == [[2, "a "], [10, "a [[b]]"]]
+    assert g("[(a:2):3]") == [[3, ""], [10, "(a:2)"]]
+    assert g("a [b : c : 1] d") == [[1, "a b  d"], [10, "a  c  d"]]
+    assert g("a[b:[c:d:2]:1]e") == [[1, "abe"], [2, "ace"], [10, "ade"]]
+    assert g("a [unbalanced") == [[10, "a [unbalanced"]]
+    assert g("a [b:.5] c") == [[5, "a  c"], [10, "a b c"]]
+    assert g("((a][:b:c [d:3]") == [[3, "((a][:b:c "], [10, "((a][:b:c d"]]
+    assert g("[a|(b:1.1)]") == [[i, "a" if i % 2 else "(b:1.1)"] for i in range(1, 11)]
+    assert g("[fe|]male") == [[i, "female" if i % 2 else "male"] for i in range(1, 11)]
+    assert g("[fe|||]male") == [[i, "female" if i % 4 == 1 else "male"] for i in range(1, 11)]
+    assert g("a [b:.5] c", 10, 10) == [[10, "a b c"]]
+    assert g("a [b:1.5] c", 10, 10) == [[5, "a  c"], [10, "a b c"]]
+    big = "fantasy landscape with a [mountain:lake:0.25] and [an oak:a christmas tree:0.75][ in foreground::0.6][: in background:0.25] [shoddy:masterful:0.5]"
+    assert g(big, 100) == [[25, "fantasy landscape with a mountain and an oak in foreground shoddy"],
+                           [50, "fantasy landscape with a lake and an oak in foreground in background shoddy"],
+                           [60, "fantasy landscape with a lake and an oak in foreground in background masterful"],
+                           [75, "fantasy landscape with a lake and an oak in background masterful"],
+                           [100, "fantasy landscape with a lake and a christmas tree in background masterful"]]
+    assert g("a | b [c:3]") == [[10, "a | b [c:3]"]]   # a top-level '|' has no parse: used as is
+    assert g("\\\\[not:3\\\\] (x:1.2)") == [[10, "\\\\[not:3\\\\] (x:1.2)"]]
