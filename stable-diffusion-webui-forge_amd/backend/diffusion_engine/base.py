@@ -50,7 +50,6 @@ class ForgeDiffusionEngine:
     def attach_text_encoders(self, clip_l, clip_g=None, tokenizer_l=None, tokenizer_g=None, embeddings_l=None, embeddings_g=None):
         """clip_l / clip_g: forge_amd.backend.nn.clip.IntegratedCLIP.  Engine options as the reference constructs them.  With tokenizers
         (CLIPTokenizer objects of the user's install) `get_learned_conditioning` also takes prompt STRINGS (`SdConditioning([...])`)."""
-        from functools import partial
         from ..text_processing.classic_engine import ClassicTextProcessingEngine as _Engine
         tl, tg = dict(tokenizer=tokenizer_l, embeddings=embeddings_l), dict(tokenizer=tokenizer_g, embeddings=embeddings_g)
         if self.is_sdxl:

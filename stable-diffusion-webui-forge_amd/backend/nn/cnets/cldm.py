@@ -13,7 +13,7 @@ residuals with a plain elementwise kernel."""
 import torch
 
 from .... import hipops as ops
-from ..layout import HINT_BLOCK, ConvIn
+from ..layout import HINT_BLOCK
 from ..unet import IntegratedUNet2DConditionModel, _conv_w
 
 

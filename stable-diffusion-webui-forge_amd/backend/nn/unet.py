@@ -20,7 +20,6 @@ natively (fp32 NCHW residual -> fp16 NHWC activation, one transposing add kernel
 the captured graph, since the residuals change every step.  Hooks that need per-block Python callbacks on NCHW tensors
 (`patches`, `patches_replace`, `block_modifiers`) are called eagerly on [B, N, C] / NCHW views; module-typed hooks are rejected.
 """
-import math
 
 import torch
 

@@ -7,7 +7,6 @@ Temporary / output buffers come from the active `Arena` (runtime.py) when one is
 forward allocates nothing from HIP and can be captured into a HIP graph.
 """
 import ctypes as C
-import math
 
 import torch
 

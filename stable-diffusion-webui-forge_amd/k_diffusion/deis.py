@@ -1,7 +1,5 @@
 """DEIS coefficient tables -- mirror of k_diffusion/deis.py (`edm2t` :13-21, `get_deis_coeff_list` :59-121).  Host-side, O(steps * N)
 scalar work done once per sampling run; the latent-sized updates it feeds are in sampling.py (`sample_deis`)."""
-import math
-
 import torch
 
 _EPS_S, _SIGMA_MIN, _SIGMA_MAX = 1e-3, 0.002, 80.0

@@ -66,7 +66,6 @@ def test_sdxl_conditioning_assembly():
     """engine.get_learned_conditioning for SDXL (sdxl.py:76-117): [CLIP-L | CLIP-G] penultimate states, pooled-projected CLIP-G +
     six Timestep(256) embeddings of (height, width, crop_top, crop_left, target_height, target_width)."""
     from forge_amd.backend.diffusion_engine.base import ForgeDiffusionEngine, TokenizedPrompts
-    from types import SimpleNamespace
     cl, cg = synth.TINY_CLIP_L_CONFIG, synth.TINY_CLIP_G_CONFIG
     sl, sg = synth.synth_clip_state_dict(cl), synth.synth_clip_state_dict(cg, seed=5)
     eng = ForgeDiffusionEngine.__new__(ForgeDiffusionEngine)  # conditioning only: no UNet needed

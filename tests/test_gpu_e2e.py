@@ -270,7 +270,6 @@ def test_prediction_types_vs_reference_fixture(ptype):
     """v-prediction (SD2.x, v-pred SDXL finetunes) and EDM parameterisations: calculate_denoised inside the fused CFG-combine kernel
     (k_prediction.py:81-92) against the reference's Prediction class, kernel-level and through a 4-step Euler run."""
     from forge_amd import hipops as ops
-    from forge_amd.backend.diffusion_engine.base import ForgeDiffusionEngine
     from forge_amd.backend.modules.k_prediction import Prediction
     from forge_amd.backend.patcher.unet import UnetPatcher
     g = load_golden("tiny_sd15_prediction_types.pt")
@@ -415,8 +414,7 @@ def test_hires_fix_latent_pass_vs_oracle(upscaler, hr_sampler, hr_cfg, engines):
 def test_scheduler_choice_reaches_the_sampler(scheduler, engines):
     """p.scheduler selects the sigma schedule exactly as modules/sd_samplers_kdiffusion.py:81-134; the Euler result must equal the
     oracle's Euler loop on that schedule."""
-    from oracle import pipeline, sampling as osamp, schedulers as osched
-    from oracle.k_prediction import Predictor
+    from oracle import pipeline
     cfg = TINY["tiny_sd15"]
     g = load_golden("schedulers.pt")
     key = {v: k for k, v in g["labels"].items()}[scheduler]
