@@ -19,8 +19,11 @@ class ForgeObjects:
 
 
 class ForgeDiffusionEngine:
-    def __init__(self, unet, vae, is_sdxl=False):
-        predictor = Prediction(prediction_type="epsilon", beta_schedule="linear", linear_start=0.00085, linear_end=0.012, timesteps=1000)
+    def __init__(self, unet, vae, is_sdxl=False, prediction_type="epsilon", ztsnr=False):
+        predictor = Prediction(prediction_type=prediction_type, beta_schedule="linear", linear_start=0.00085, linear_end=0.012, timesteps=1000)
+        if ztsnr:  # zero-terminal-SNR checkpoints carry a 'ztsnr' key (loader.py:462); their sigma table is rescaled (k_prediction.py:48-63)
+            from ..modules.k_prediction import rescale_zero_terminal_snr_sigmas
+            predictor.set_sigmas(rescale_zero_terminal_snr_sigmas(predictor.sigmas))
         self.forge_objects = ForgeObjects(unet=UnetPatcher.from_model(unet, k_predictor=predictor), clip=None,
                                           vae=VAE(vae) if vae is not None else None)
         self.forge_objects_original = self.forge_objects.shallow_copy()
@@ -112,10 +115,10 @@ class TokenizedPrompts:
         self.is_negative_prompt, self.all_empty = is_negative_prompt, all_empty
 
 
-def build_engine(unet_config, unet_state_dict, vae_config=None, vae_state_dict=None, device="cuda"):
+def build_engine(unet_config, unet_state_dict, vae_config=None, vae_state_dict=None, device="cuda", prediction_type="epsilon", ztsnr=False):
     unet = IntegratedUNet2DConditionModel(unet_config, unet_state_dict, device=device)
     vae = IntegratedAutoencoderKL(vae_config, vae_state_dict, device=device) if vae_config is not None else None
-    return ForgeDiffusionEngine(unet, vae, is_sdxl=unet_config.get("adm_in_channels") is not None)
+    return ForgeDiffusionEngine(unet, vae, is_sdxl=unet_config.get("adm_in_channels") is not None, prediction_type=prediction_type, ztsnr=ztsnr)
 
 
 class FluxEngine:

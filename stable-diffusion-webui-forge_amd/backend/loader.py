@@ -109,24 +109,28 @@ def split_state_dict(sd):
     unet_config = detect_unet_config(sd)
     is_sdxl = unet_config.get("adm_in_channels") is not None
     vae_config = dict(SD_VAE_CONFIG, scaling_factor=0.13025 if is_sdxl else 0.18215) if vae else None
-    pred = "v_prediction" if (unet_config["context_dim"] == 1024 and unet_config.get("use_linear_in_transformer") and "v_pred" in sd) else "epsilon"
-    guess = {"unet_config": unet_config, "vae_config": vae_config, "is_sdxl": is_sdxl, "prediction_type": pred,
+    # the prediction type is not in the tensor shapes: checkpoints mark it with a 'v_pred' key (and 'ztsnr' for a zero-terminal-SNR schedule,
+    # loader.py:462); a yaml next to the file or the caller decides otherwise (loader.py:543-567) -> forge_loader(prediction_type=...)
+    pred = "v_prediction" if "v_pred" in sd else "epsilon"
+    guess = {"unet_config": unet_config, "vae_config": vae_config, "is_sdxl": is_sdxl, "prediction_type": pred, "ztsnr": "ztsnr" in sd,
              "ignored": sorted({k.split(".")[0] for k in sd if not k.startswith((UNET_PREFIX, VAE_PREFIX))})}
     return {"unet": unet, "vae": vae}, guess
 
 
 @torch.inference_mode()
-def forge_loader(sd, loras=None, device="cuda"):
-    """checkpoint path / state dict (+ optional [(lora_sd, strength)]) -> ForgeDiffusionEngine on the native executors."""
+def forge_loader(sd, loras=None, device="cuda", prediction_type=None):
+    """checkpoint path / state dict (+ optional [(lora_sd, strength)]) -> ForgeDiffusionEngine on the native executors.
+    prediction_type: 'epsilon' | 'v_prediction' | 'edm' to override what the checkpoint's marker keys say (SD2.x-768, v-pred SDXL finetunes)."""
     from .patcher.lora import merge_loras_into_state_dict
     parts, guess = split_state_dict(sd)
-    if guess["prediction_type"] != "epsilon":
-        raise NotImplementedError("v-prediction checkpoints: the predictor exists (k_prediction.py) but is not wired into this loader yet")
+    if prediction_type is not None:
+        guess["prediction_type"] = prediction_type
     unet_sd = parts["unet"]
     report = None
     if loras:
         unet_sd, report = merge_loras_into_state_dict(unet_sd, guess["unet_config"], [(load_torch_file(l), s) for l, s in loras], device=device)
-    engine = build_engine(guess["unet_config"], unet_sd, guess["vae_config"], parts["vae"] or None, device=device)
+    engine = build_engine(guess["unet_config"], unet_sd, guess["vae_config"], parts["vae"] or None, device=device,
+                          prediction_type=guess["prediction_type"], ztsnr=guess["ztsnr"])
     engine.lora_report = report
     engine.model_guess = guess
     return engine

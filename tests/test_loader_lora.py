@@ -21,7 +21,17 @@ def _meta_sd(shapes, prefix=""):
     return {prefix + k: torch.empty(v, device="meta") for k, v in shapes.items()}
 
 
-@pytest.mark.parametrize("name,cfg", [("sd15", synth.SD15_UNET_CONFIG), ("sdxl", synth.SDXL_UNET_CONFIG)])
+SD21_UNET_CONFIG = dict(in_channels=4, model_channels=320, out_channels=4, num_res_blocks=[2, 2, 2, 2], channel_mult=(1, 2, 4, 4), num_head_channels=64,
+                        use_spatial_transformer=True, transformer_depth=[1, 1, 1, 1, 1, 1, 0, 0], transformer_depth_middle=1,
+                        transformer_depth_output=[1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0], context_dim=1024, use_linear_in_transformer=True)
+SDXL_REFINER_UNET_CONFIG = dict(in_channels=4, model_channels=384, out_channels=4, num_res_blocks=[2, 2, 2, 2], channel_mult=(1, 2, 4, 4), num_head_channels=64,
+                                use_spatial_transformer=True, transformer_depth=[0, 0, 4, 4, 4, 4, 0, 0], transformer_depth_middle=4,
+                                transformer_depth_output=[0, 0, 0, 4, 4, 4, 4, 4, 4, 0, 0, 0], context_dim=1280, use_linear_in_transformer=True,
+                                adm_in_channels=2560, num_classes="sequential")
+
+
+@pytest.mark.parametrize("name,cfg", [("sd15", synth.SD15_UNET_CONFIG), ("sdxl", synth.SDXL_UNET_CONFIG), ("sd21", SD21_UNET_CONFIG),
+                                      ("sdxl_refiner", SDXL_REFINER_UNET_CONFIG), ("sd15_inpaint", dict(synth.SD15_UNET_CONFIG, in_channels=9))])
 def test_detect_unet_config_from_shapes(name, cfg):
     det = loader.detect_unet_config(_meta_sd(unet_param_shapes(cfg), loader.UNET_PREFIX))
     assert unet_param_shapes(det) == unet_param_shapes(cfg)
@@ -41,6 +51,10 @@ def test_split_state_dict_single_file_layout():
     assert set(parts["unet"]) == set(unet_param_shapes(cfg))
     assert set(parts["vae"]) == set(vshapes)
     assert guess["is_sdxl"] and guess["vae_config"]["scaling_factor"] == 0.13025 and guess["ignored"] == ["conditioner"]
+    assert guess["prediction_type"] == "epsilon" and not guess["ztsnr"]
+    sd["v_pred"], sd["ztsnr"] = torch.empty(0, device="meta"), torch.empty(0, device="meta")   # marker keys of v-prediction / zero-terminal-SNR checkpoints
+    _, guess_v = loader.split_state_dict(sd)
+    assert guess_v["prediction_type"] == "v_prediction" and guess_v["ztsnr"]
     # a bare UNet state dict gets the checkpoint prefix (loader.py:442-446)
     bare = loader.preprocess_state_dict(_meta_sd(unet_param_shapes(synth.SD15_UNET_CONFIG)))
     assert all(k.startswith(loader.UNET_PREFIX) for k in bare)
