@@ -1401,6 +1401,21 @@ def gen_full_sd15():
     print("sd15 config0: sampler %.1fs (%.3f it/s), decode %.1fs, latent std %.3f" % (t_sample, 20 / t_sample, t_dec, float(lat.std())))
 
 
+def gen_full_sdxl():
+    """The BASELINE bench workload's network at full size: SDXL UNet (2.57 B parameters, random-init), one sample-forward at the 128x128 latent
+    (1024x1024) with 77 x 2048 context and the 2816-wide vector conditioning, on the real reference (CPU fp32)."""
+    cfg = synth.SDXL_UNET_CONFIG
+    t0 = time.time()
+    sd = synth.synth_unet_state_dict(cfg, seed=0)
+    net = ref_import.build_ref_unet(cfg, sd)
+    del sd
+    x, t, ctx, y = _inputs(cfg, 1, 128, seed=13)
+    with torch.no_grad():
+        eps = net(x.clone(), t, context=ctx, y=y, transformer_options={})
+    print("sdxl fwd", time.time() - t0, float(eps.std()))
+    torch.save({"eps": eps, "inputs_seed": 13}, os.path.join(GOLD, "sdxl_full_fwd.pt"))  # inputs are regenerated from the seed (_inputs)
+
+
 def gen_flux(name="tiny_flux", cfg=None, b=2, h=16, w=24, ltxt=40):
     """Flux DiT: one forward of the REAL reference and a 4-step Euler flow-sampling run through the reference's KModel +
     PredictionFlux + k_diffusion.sample_euler ('simple' sigmas: modules/sd_schedulers.py:81-87, restated because that module
@@ -1521,6 +1536,8 @@ def main():
         gen_flux()
     if a.full or a.only == "full":
         gen_full_sd15()
+    if a.full or a.only == "full_sdxl":
+        gen_full_sdxl()
 
 
 if __name__ == "__main__":

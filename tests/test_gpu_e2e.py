@@ -549,3 +549,16 @@ def test_sd15_full_size_vs_reference_fixture():
     diff = np.abs(res.images[0].astype(np.int32) - g["image_u8"][0].numpy().astype(np.int32))
     print(f"[parity] SD1.5 image uint8: max diff {diff.max()}, mean {diff.mean():.4f}, frac>2: {(diff > 2).mean():.5f}")
     assert diff.mean() < 1.0
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(GOLDEN, "sdxl_full_fwd.pt")), reason="full fixture not generated")
+def test_sdxl_full_size_forward_vs_reference_fixture():
+    """The bench workload's network at full size -- SDXL UNet, 2.57 B parameters, 128x128 latent, 77 x 2048 context + 2816-wide vector -- against
+    one forward of the REAL reference (CPU fp32, 3 minutes; oracle/make_golden.py gen_full_sdxl).  Also through the graph-replayed CFG path."""
+    from oracle.make_golden import _inputs
+    g = load_golden("sdxl_full_fwd.pt")
+    cfg = synth.SDXL_UNET_CONFIG
+    x, t, ctx, y = _inputs(cfg, 1, 128, seed=g["inputs_seed"])
+    net = IntegratedUNet2DConditionModel(cfg, synth.synth_unet_state_dict(cfg, seed=0), device=DEV)
+    eps = net.forward(x.to(DEV), t.to(DEV), context=ctx.to(DEV), y=y.to(DEV))
+    report("SDXL unet forward at full size (128x128 latent) vs reference", max_rel(eps, g["eps"]), 3e-3)
