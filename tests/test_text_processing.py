@@ -78,3 +78,42 @@ def test_prompt_editing_schedules_match_the_reference_doctests():
                            [100, "fantasy landscape with a lake and a christmas tree in background masterful"]]
     assert g("a | b [c:3]") == [[10, "a | b [c:3]"]]   # a top-level '|' has no parse: used as is
     assert g("\\\\[not:3\\\\] (x:1.2)") == [[10, "\\\\[not:3\\\\] (x:1.2)"]]
+
+
+def test_parse_prompt_attention_randomised_against_the_reference_module():
+    """4 000 random strings over the syntax's alphabet through both parsers (the reference's parsing.py needs nothing but `re`).  Runs where
+    /root/reference exists (the authoring container); the committed fixture above covers the GPU box."""
+    import importlib.util
+    import os
+    import random
+    import pytest
+    path = "/root/reference/backend/text_processing/parsing.py"
+    if not os.path.exists(path):
+        pytest.skip("reference not present")
+    spec = importlib.util.spec_from_file_location("_ref_parsing", path)
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    rnd = random.Random(0)
+    alphabet = ["a", "cat ", "(", ")", "[", "]", ":", "1.2", " ", "\\(", "\\)", "\\\\", "\\", " BREAK ", "BREAK", ",", ":0.5)", ": 1.3 )", "dog", "(((", "]]",
+                ":-1)", ":.5)", "\n", "x:y"]
+    for _ in range(4000):
+        s = "".join(rnd.choice(alphabet) for _ in range(rnd.randint(1, 12)))
+        for mode in ("Original", "None"):
+            assert parse_prompt_attention(s, mode) == ref.parse_prompt_attention(s, mode), repr(s)
+
+
+def test_prompt_schedule_invariants():
+    """Properties of the prompt-editing schedules that hold for any input: ends at the last step, strictly increasing marks, text without
+    constructs is returned unchanged, and rendering is idempotent on construct-free output."""
+    import random
+    rnd = random.Random(1)
+    alphabet = ["a", " b", "[", "]", ":", "|", "(", ")", "3", ".5", " ", "cat", "\\[", "1.5", "0"]
+    for _ in range(3000):
+        s = "".join(rnd.choice(alphabet) for _ in range(rnd.randint(0, 14)))
+        for steps, hires in ((10, None), (7, 12)):
+            sched = pp.get_learned_conditioning_prompt_schedules([s], steps, hires)[0]
+            total = hires if hires is not None else steps
+            marks = [m for m, _ in sched]
+            assert marks[-1] == total and marks == sorted(set(marks)) and all(1 <= m <= total for m in marks), (s, sched)
+            if not any(ch in s for ch in "[|"):
+                assert sched == [[total, s]], (s, sched)
