@@ -136,9 +136,9 @@ def gen_vae(name, cfg, b=2, hw=8):
     vae = ref_import.build_ref_vae(cfg)
     missing = vae.load_state_dict(sd, strict=False)
     assert not missing.unexpected_keys, missing.unexpected_keys
-    assert all(k.startswith(("encoder.", "quant_conv.")) for k in missing.missing_keys)
+    assert all(k.startswith(("encoder.", "quant_conv.")) for k in missing.missing_keys), missing.missing_keys
     g = torch.Generator("cpu").manual_seed(5)
-    z = torch.randn(b, 4, hw, hw, generator=g)
+    z = torch.randn(b, cfg["latent_channels"], hw, hw, generator=g)
     with torch.no_grad():
         out = vae.decode(z)
         # decode_first_stage (diffusion_engine/sd15.py:80-84) on latents `z*0.5`
@@ -1499,6 +1499,8 @@ def main():
         gen_tokenize()
     if a.only in ("", "t2i"):
         gen_t2i_adapter()
+    if a.only in ("", "tiny", "fluxvae"):
+        gen_vae("tiny_flux_vae", synth.TINY_FLUX_VAE_CONFIG)
     if a.only == "lora":
         gen_lora("tiny_sd15", synth.TINY_SD15_UNET_CONFIG)
     if a.only in ("", "tiny", "inpaint"):

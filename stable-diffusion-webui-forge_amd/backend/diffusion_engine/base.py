@@ -122,15 +122,16 @@ def build_engine(unet_config, unet_state_dict, vae_config=None, vae_state_dict=N
 
 
 class FluxEngine:
-    """Object protocol of backend/diffusion_engine/flux.py:27-120 that the call surface touches (transformer only: text encoders
-    and the 16-channel VAE are outside this round's scope)."""
+    """Object protocol of backend/diffusion_engine/flux.py:27-120 that the call surface touches: the transformer and, optionally, the
+    16-channel VAE (decode_first_stage / encode_first_stage as flux.py:107-120); the T5 / CLIP text encoders are not built -- conditioning
+    tensors are supplied."""
 
-    def __init__(self, transformer, seq_len):
+    def __init__(self, transformer, seq_len, vae=None):
         from ..modules.k_model import KModelFlux
         from ..modules.k_prediction import PredictionFlux
         from ..patcher.unet import UnetPatcher
         patcher = UnetPatcher(KModelFlux(transformer, PredictionFlux(seq_len=seq_len)), transformer.device, transformer.device)
-        self.forge_objects = ForgeObjects(unet=patcher, clip=None, vae=None)
+        self.forge_objects = ForgeObjects(unet=patcher, clip=None, vae=VAE(vae) if vae is not None else None)
         self.forge_objects_original = self.forge_objects.shallow_copy()
         self.forge_objects_after_applying_lora = self.forge_objects.shallow_copy()
         self.is_sdxl = self.is_sd1 = self.is_inpaint = False
@@ -139,8 +140,12 @@ class FluxEngine:
         self.latent_channels = transformer.in_channels // 4
         self.device = transformer.device
 
+    decode_first_stage = ForgeDiffusionEngine.decode_first_stage   # flux.py:113-117: same process_out -> decode -> [-1, 1] as sd15.py:80-84
+    encode_first_stage = ForgeDiffusionEngine.encode_first_stage
 
-def build_flux_engine(flux_config, state_dict, width, height, device="cuda"):
+
+def build_flux_engine(flux_config, state_dict, width, height, device="cuda", vae_config=None, vae_state_dict=None):
     from ..nn.flux import IntegratedFluxTransformer2DModel
     net = IntegratedFluxTransformer2DModel(flux_config, state_dict, device=device)
-    return FluxEngine(net, seq_len=(height // 16) * (width // 16))
+    vae = IntegratedAutoencoderKL(vae_config, vae_state_dict, device=device) if vae_config is not None else None
+    return FluxEngine(net, seq_len=(height // 16) * (width // 16), vae=vae)

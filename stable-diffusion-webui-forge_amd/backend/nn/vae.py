@@ -61,9 +61,18 @@ class IntegratedAutoencoderKL:
             bp = pw.new_zeros(8)
             bp[:lc] = T("post_quant_conv.bias")
             w["pq"] = (wp.contiguous(), bp.contiguous())
-        cw = _conv_w(sd["decoder.conv_in.weight"].to(dev, torch.float16))
-        wp = cw.new_zeros(cw.shape[0], 64)
-        wp[:, :cw.shape[1]] = cw
+        full = sd["decoder.conv_in.weight"].to(dev, torch.float16)               # [block_in, lc, 3, 3]
+        if lc * 9 <= 64:
+            cw = _conv_w(full)
+            wp = cw.new_zeros(cw.shape[0], 64)
+            wp[:, :cw.shape[1]] = cw
+        else:
+            # 16-channel latents (Flux / SD3 VAE): the 3x3 conv runs as the regular implicit GEMM on the 64-wide zero-padded latent
+            if lay.use_post_quant_conv:
+                raise NotImplementedError("post_quant_conv with more than 7 latent channels")
+            padded = full.new_zeros(full.shape[0], 64, 3, 3)
+            padded[:, :lc] = full
+            wp = _conv_w(padded)
         w["conv_in"] = (wp.contiguous(), T("decoder.conv_in.bias"))
 
         def res(k, cin, cout):
@@ -176,8 +185,10 @@ class IntegratedAutoencoderKL:
             zq = ops.conv_gemm(zl.view(-1, 64), self.w["pq"][0], 8, bias=self.w["pq"][1]).view(b, hh, ww, 8)
         else:
             zq = zl
-        col = ops.im2col3x3_smallc(zq, lc)
-        h = ops.linear(col, *self.w["conv_in"]).view(b, hh, ww, lay.block_in)
+        if lc * 9 <= 64:
+            h = ops.linear(ops.im2col3x3_smallc(zq, lc), *self.w["conv_in"]).view(b, hh, ww, lay.block_in)
+        else:
+            h = ops.conv_gemm(zq, self.w["conv_in"][0], lay.block_in, kh=3, pad=1, bias=self.w["conv_in"][1]).view(b, hh, ww, lay.block_in)
         bi = lay.block_in
         h = self._res("decoder.mid.block_1", h, bi, bi, arena)
         h = self._attn(h, arena)

@@ -58,6 +58,12 @@ TINY_VAE_CONFIG = dict(in_channels=3, out_channels=3, block_out_channels=(64, 12
                        latent_channels=4, scaling_factor=0.18215, shift_factor=0.0,
                        use_quant_conv=True, use_post_quant_conv=True)
 
+# Flux.1-dev VAE (backend/huggingface/black-forest-labs/FLUX.1-dev/vae/config.json): 16 latent channels, no quant convs, shift factor
+FLUX_VAE_CONFIG = dict(in_channels=3, out_channels=3, block_out_channels=(128, 256, 512, 512), layers_per_block=2, latent_channels=16,
+                       scaling_factor=0.3611, shift_factor=0.1159, use_quant_conv=False, use_post_quant_conv=False)
+TINY_FLUX_VAE_CONFIG = dict(TINY_VAE_CONFIG, latent_channels=16, scaling_factor=0.3611, shift_factor=0.1159, use_quant_conv=False,
+                            use_post_quant_conv=False)
+
 # Flux.1-dev (backend/huggingface/black-forest-labs/FLUX.1-dev/transformer/config.json) and a tiny twin with the
 # same head_dim 128 / axes_dim split (the RoPE table and attention tile shapes are the real ones)
 FLUX_DEV_CONFIG = dict(in_channels=16, vec_in_dim=768, context_in_dim=4096, hidden_size=3072, mlp_ratio=4.0, num_heads=24, depth=19,

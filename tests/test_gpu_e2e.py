@@ -81,6 +81,17 @@ def test_vae_decode_vs_reference_fixture(engines):
     report("decode_first_stage vs reference", max_rel(dec, g["decode_first_stage"]), 3e-3)
 
 
+def test_flux_vae_decode_16_channels_vs_reference_fixture():
+    """16 latent channels, no quant convs, shift factor 0.1159 (Flux / SD3 VAE, backend/huggingface/black-forest-labs/FLUX.1-dev/vae): conv_in runs
+    as the implicit GEMM on the 64-wide zero-padded latent instead of the small-channel im2col."""
+    g, cfg = load_golden("tiny_flux_vae_decode.pt"), synth.TINY_FLUX_VAE_CONFIG
+    vae = IntegratedAutoencoderKL(cfg, synth.synth_vae_decoder_state_dict(cfg, seed=1), device=DEV)
+    report("16-channel vae decode vs reference", max_rel(vae.decode(g["z"].to(DEV)), g["decode"]), 3e-3)
+    dec = vae.decode(vae.process_out(g["lat"].to(DEV)))
+    want = (g["decode_first_stage"] + 1.0) / 2.0   # the fixture holds the clamped [0,1] image mapped back to [-1,1]
+    report("16-channel process_out + decode vs reference", max_rel(torch.clamp((dec + 1.0) / 2.0, 0.0, 1.0), want), 3e-3)
+
+
 def test_vae_encode_vs_reference_fixture(engines):
     """Encoder + quant_conv + posterior sample + process_in (img2img entry) against the real reference's outputs."""
     g = load_golden("tiny_vae_encode.pt")

@@ -79,6 +79,11 @@ def test_vae_decode():
     sd = synth.synth_vae_decoder_state_dict(synth.TINY_VAE_CONFIG, seed=1)
     torch.testing.assert_close(vae_decode(sd, g["z"]), g["decode"], rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(decode_first_stage(sd, g["lat"], 0.18215), g["decode_first_stage"], rtol=1e-4, atol=1e-5)
+    # 16-channel latents, no quant convs, shift factor (Flux / SD3 VAE)
+    g, cfg = load_golden("tiny_flux_vae_decode.pt"), synth.TINY_FLUX_VAE_CONFIG
+    sd = synth.synth_vae_decoder_state_dict(cfg, seed=1)
+    torch.testing.assert_close(vae_decode(sd, g["z"]), g["decode"], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(decode_first_stage(sd, g["lat"], cfg["scaling_factor"], cfg["shift_factor"]), g["decode_first_stage"], rtol=1e-4, atol=1e-5)
 
 
 @pytest.mark.parametrize("name", list(TINY))
