@@ -37,6 +37,8 @@ def host_sigmas(sigma):
 
 
 class KModel:
+    MAX_CACHED_SHAPES = 16  # captured graphs + their static input buffers, one set per (batch, channels, h, w, CFG halves)
+
     def __init__(self, model, predictor, use_graph=True):
         self.diffusion_model = model
         self.predictor = predictor
@@ -62,6 +64,14 @@ class KModel:
         bu = reps * b
         st = self._static.get(key)
         if st is None:
+            if len(self._static) >= self.MAX_CACHED_SHAPES:
+                # a long-lived server sees many (batch, resolution) shapes: drop every cached graph and its static buffers rather than
+                # grow without bound (the next call of each shape warms up and captures again)
+                torch.cuda.synchronize(self.device)
+                for g in self._graphs.values():
+                    g.destroy()
+                self._graphs.clear()
+                self._static.clear()
             st = {"xcol": torch.empty(bu * hh * ww, 64, dtype=torch.float16, device=self.device),
                   "t": torch.empty(bu, dtype=torch.float32, device=self.device), "eps": None, "warm": 0}
             self._static[key] = st

@@ -274,6 +274,10 @@ class IntegratedUNet2DConditionModel:
             key = (bu, npad, h.shape[1])
             padbuf = self._pad_bufs.get(key)
             if padbuf is None:
+                if len(self._pad_bufs) >= 24:   # bounded; captured graphs that point at the dropped buffers are invalidated via the epoch
+                    torch.cuda.synchronize(self.device)
+                    self._pad_bufs.clear()
+                    self.arena_epoch += 1
                 padbuf = self._pad_bufs[key] = torch.zeros(bu, npad, h.shape[1], dtype=torch.float16, device=self.device)
             ops.layernorm_padded(h, *self.w[b + ".norm1"], out=padbuf, rows_per_image=n)
             p2d = padbuf.view(bu * npad, -1)

@@ -384,6 +384,32 @@ def test_graph_survives_arena_reallocation():
     assert torch.isfinite(big).all() and torch.equal(first, again)
 
 
+def test_graph_cache_is_bounded(engines):
+    """More distinct (batch, resolution) shapes than MAX_CACHED_SHAPES: the graph / static-buffer caches are dropped and rebuilt, results stay
+    the same as on first sight."""
+    from forge_amd.backend.modules.k_model import KModel
+    cfg = TINY["tiny_sd15"]
+    eng = build_engine(cfg, synth.synth_unet_state_dict(cfg, seed=0), None, None, device=DEV)
+    km = eng.forge_objects.unet.model
+    shared.opts.randn_source = "CPU"
+    c, uc = _conds(cfg, 1)
+
+    def run(size):
+        p = processing.StableDiffusionProcessingTxt2Img(sd_model=eng, c=c, uc=uc, seed=3, sampler_name="Euler", batch_size=1, steps=4, cfg_scale=7.0,
+                                                        width=size, height=size, do_decode=False)
+        return processing.process_images(p).latents.clone()
+    first = run(128)
+    old = KModel.MAX_CACHED_SHAPES
+    KModel.MAX_CACHED_SHAPES = 3
+    try:
+        for size in (64, 192, 256, 320, 104):   # 104 -> 13x13 latent: ragged tokens, padded LayerNorm buffers
+            assert torch.isfinite(run(size)).all()
+        assert len(km._static) <= 3 and len(km._graphs) <= 3
+        assert torch.equal(run(128), first)
+    finally:
+        KModel.MAX_CACHED_SHAPES = old
+
+
 def test_latent_resize_kernel_vs_torch_interpolate():
     import torch.nn.functional as F
     from forge_amd.modules import latent_upscale
