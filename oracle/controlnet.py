@@ -5,7 +5,9 @@ Restates the ControlNet side of the path in plain torch fp32:
   zero convs) on the LDM-keyed state dict, with oracle/unet.py's block walker;
   backend/patcher/controlnet.py:79-146 compute_controlnet_weighting, :149-168 broadcast_image_to, :223-272 control_merge, :284-338 get_control
   (previous-ControlNet chain, sigma range gate, hint resize 'nearest-exact' + centre crop, strength, global average pooling).
-Pinned against the reference's own classes in tests/golden/*_controlnet.pt (oracle/make_golden.py gen_controlnet)."""
+  backend/patcher/controlnet.py:360-457 Control-LoRA weight assembly (`control_lora_weights`).
+Pinned against the reference's own classes in tests/golden/*_controlnet.pt, *_control_lora.pt (oracle/make_golden.py gen_controlnet,
+gen_control_lora)."""
 import torch
 import torch.nn.functional as F
 
@@ -31,6 +33,25 @@ def controlnet_forward(sd, cfg, x, hint, timesteps, context, y=None):
     h = _run_block(sd, cfg, "middle_block", h, emb, context)
     outs.append(_conv(sd, "middle_block_out.0", h, padding=0))
     return outs
+
+
+def control_lora_weights(unet_sd, control_weights):
+    """patcher/controlnet.py:445-457 (+ ControlLoraOps.forward :371-417): the control model starts from the UNet's tensors (keys the ControlNet
+    does not have are dropped by the try / except), the file's plain tensors replace them, and a module with `up` / `down` computes with
+    weight + (up.flatten(1) @ down.flatten(1)).reshape(weight.shape).  Returned as an ordinary ControlNet state dict for `controlnet_forward`."""
+    sd = {k: v.float() for k, v in unet_sd.items() if k.startswith(("input_blocks.", "middle_block.", "time_embed.", "label_emb."))}
+    pairs = {}
+    for k, v in control_weights.items():
+        if k == "lora_controlnet":
+            continue
+        if k.endswith(".up") or k.endswith(".down"):
+            pairs.setdefault(k.rsplit(".", 1)[0], {})[k.rsplit(".", 1)[1]] = v.float()
+        else:
+            sd[k] = v.float()
+    for base, ud in pairs.items():
+        w = sd[base + ".weight"]
+        sd[base + ".weight"] = w + (ud["up"].flatten(1) @ ud["down"].flatten(1)).reshape(w.shape)
+    return sd
 
 
 def adaptive_resize_nearest_exact_center(samples, width, height):
@@ -135,6 +156,24 @@ def adapter_forward(sd, x, channels, nums_rb=2, ksize=1, use_conv=False, xl=Fals
         else:
             feats += [None, None]
         feats.append(h)
+    return feats
+
+
+@torch.no_grad()
+def adapter_light_forward(sd, x, channels, nums_rb=4):
+    """t2i_adapter.py:226-293 `Adapter_light`: pixel-unshuffle x8; per stage [2x2 average pool from the second stage on] -> 1x1 in_conv -> nums_rb x
+    (3x3, ReLU, 3x3, + input) -> 1x1 out_conv; the feature list has two None placeholders before every stage's map."""
+    h = F.pixel_unshuffle(x, 8)
+    feats = []
+    for i in range(len(channels)):
+        if i > 0:
+            h = F.avg_pool2d(h, kernel_size=2, stride=2)
+        h = _conv(sd, f"body.{i}.in_conv", h, padding=0)
+        for j in range(nums_rb):
+            t = F.relu(_conv(sd, f"body.{i}.body.{j}.block1", h))
+            h = _conv(sd, f"body.{i}.body.{j}.block2", t) + h
+        h = _conv(sd, f"body.{i}.out_conv", h, padding=0)
+        feats += [None, None, h]
     return feats
 
 

@@ -964,6 +964,48 @@ def gen_controlnet(name, cfg, net, b=2, hw=16):
     print(name, "controlnet:", len(outs), "residuals; euler4 std", float(lat.std()))
 
 
+def gen_control_lora(name, cfg, b=2, hw=16):
+    """patcher.controlnet.ControlLora (:420-474): the control model is built in pre_run from the UNet's own weights plus the file's low-rank
+    pairs.  Fixture: the residuals of one model call (a quarter of the channels) and a 4-step Euler run through the reference stack."""
+    import importlib
+    ref = ref_import.load_reference()
+    pc = importlib.import_module("backend.patcher.controlnet")
+    net = ref_import.build_ref_unet(cfg, synth.synth_unet_state_dict(cfg, seed=0))
+    # diffusers' ConfigMixin (a stub here) records the constructor arguments as `.config`; pre_run reads them back (:428)
+    net.config = {k: (list(v) if isinstance(v, (list, tuple)) else v) for k, v in cfg.items()}
+    fx = torch.load(os.path.join(GOLD, f"{name}_unet_fwd.pt"))
+    case = controlnet_case(cfg, b, hw)
+    pred = ref_import.build_ref_predictor()
+    adm = cfg.get("adm_in_channels")
+    c, uc = synth.synth_conditioning(b, cfg["context_dim"], adm, seed=1234)
+    if adm:
+        c, uc = ref_import.SdxlCond(c), ref_import.SdxlCond(uc)
+    seeds = [1000 + i for i in range(b)]
+    den = ref_import.RefDenoiser(net, pred, seeds)
+    cl = pc.ControlLora(synth.synth_control_lora_state_dict(cfg))
+    unet = pc.apply_controlnet_advanced(den.patcher, cl, case["hint_a"], 0.9, 0.0, 1.0)
+    den.patcher = unet
+    den.inner_model.inner_model.forge_objects.unet = unet
+    rng = ImageRNG((cfg["in_channels"], hw, hw), seeds, "CPU")
+    x = rng.next()
+    sigmas = den.inner_model.get_sigmas(4)
+    x = pred.noise_scaling(sigmas[0], x, torch.zeros_like(x), max_denoise=False)
+    ref.kd_sampling.torch = _Hijack(rng)
+    ref.sampling_function.sampling_prepare(unet, x=x)
+    try:
+        linked = unet.controlnet_linked_list
+        with torch.no_grad():
+            outs = linked.control_model(x=fx["x"], hint=case["hint_a"], timesteps=fx["t"], context=fx["ctx"], y=fx["y"])
+        lat = ref.kd_sampling.sample_euler(den, x, sigmas, extra_args={"cond": c, "uncond": uc, "cond_scale": 7.0, "s_min_uncond": 0.0, "image_cond": None},
+                                           disable=True)
+    finally:
+        ref.kd_sampling.torch = torch
+        ref.sampling_function.sampling_cleanup(unet)
+    res = {"outs_every_8th_channel": [o[:, ::8].clone() for o in outs], "hw": hw, "euler4": {"latent": lat, "seeds": seeds, "sigmas": sigmas}}
+    torch.save(res, os.path.join(GOLD, f"{name}_control_lora.pt"))
+    print(name, "control-lora:", len(outs), "residuals, std", float(outs[3].std()), "; euler4 std", float(lat.std()))
+
+
 def gen_prediction_types(name, cfg, net, b=2, hw=16):
     """Prediction(prediction_type='v_prediction' | 'edm') and the non-default beta schedules / zero-terminal-SNR rescale of
     backend/modules/k_prediction.py: sigma tables, calculate_denoised, and a 4-step Euler run through the reference stack per type."""
@@ -1171,6 +1213,31 @@ def gen_t2i_adapter(b=2, hw=16):
     res["euler3"] = lat
     torch.save(res, os.path.join(GOLD, "mini_sd15_t2i_adapter.pt"))
     print("t2i adapter:", {k: len(v["values_every_4th_channel"]) for k, v in res["features"].items()}, "euler3 std", float(lat.std()))
+
+
+ADAPTER_LIGHT_KW = dict(channels=[64, 128, 256, 256], nums_rb=2, cin=192)   # quarter widths 16 / 32 / 64 / 64: below the GEMM granule
+
+
+def adapter_light_hint(b=2, hw=16):
+    return torch.rand(b, 3, hw * 8, hw * 8, generator=torch.Generator().manual_seed(77))
+
+
+def gen_adapter_light():
+    """The reference's Adapter_light (the colour adapter's network) on synthetic weights: feature maps, every 4th channel."""
+    import importlib
+    ref_import.load_reference()
+    t2i = importlib.import_module("backend.nn.cnets.t2i_adapter")
+    m = t2i.Adapter_light(**ADAPTER_LIGHT_KW)
+    sd = synth.synth_t2i_adapter_light_state_dict(**ADAPTER_LIGHT_KW)
+    assert set(sd) == set(m.state_dict()) and all(tuple(sd[k].shape) == tuple(v.shape) for k, v in m.state_dict().items())
+    m.load_state_dict(sd)
+    m.eval()
+    with torch.no_grad():
+        feats = m(adapter_light_hint())
+    res = {"layout": [None if f is None else tuple(f.shape) for f in feats], "values_every_4th_channel": [f[:, ::4].clone() for f in feats if f is not None],
+           "input_channels": m.input_channels, "unshuffle_amount": m.unshuffle_amount}
+    torch.save(res, os.path.join(GOLD, "mini_adapter_light.pt"))
+    print("adapter_light:", res["layout"], [float(f.std()) for f in res["values_every_4th_channel"]])
 
 
 TOKENIZE_PROMPTS = [
@@ -1499,6 +1566,8 @@ def main():
         gen_tokenize()
     if a.only in ("", "t2i"):
         gen_t2i_adapter()
+    if a.only in ("", "t2i", "adapterlight"):
+        gen_adapter_light()
     if a.only in ("", "tiny", "fluxvae"):
         gen_vae("tiny_flux_vae", synth.TINY_FLUX_VAE_CONFIG)
     if a.only == "lora":
@@ -1516,6 +1585,9 @@ def main():
         for nm, cf in (("tiny_sd15", synth.TINY_SD15_UNET_CONFIG), ("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG)):
             net, _ = gen_unet(nm, cf)
             gen_controlnet(nm, cf, net)
+    if a.only in ("", "tiny", "controllora"):
+        gen_control_lora("tiny_sd15", synth.TINY_SD15_UNET_CONFIG)
+        gen_control_lora("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG)
     if a.only == "hooks":
         for nm, cf in (("tiny_sd15", synth.TINY_SD15_UNET_CONFIG), ("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG)):
             net, _ = gen_unet(nm, cf)

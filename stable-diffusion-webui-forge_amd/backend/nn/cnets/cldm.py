@@ -23,6 +23,7 @@ def _pad64(c):
 
 class ControlNet(IntegratedUNet2DConditionModel):
     encoder_only = True
+    TRUNK_PREFIXES = ()  # nothing builds a Control-LoRA on top of a ControlNet: do not keep its source tensors alive
 
     def __init__(self, config, state_dict, device="cuda", hint_channels=3, arena_bytes=None):
         self.hint_channels = hint_channels

@@ -76,6 +76,7 @@ class ContextCache:
 
 class IntegratedUNet2DConditionModel:
     encoder_only = False  # cnets/cldm.py's ControlNet re-uses this executor for its trunk (input blocks + middle block)
+    TRUNK_PREFIXES = ("input_blocks.", "middle_block.", "time_embed.", "label_emb.")
 
     def __init__(self, config, state_dict, device="cuda", arena_bytes=None):
         self.config = dict(config)
@@ -92,6 +93,10 @@ class IntegratedUNet2DConditionModel:
         self.arena_epoch = 0  # bumped whenever the arena is re-allocated: graphs captured on the old one hold dangling pointers
         self._arena_bytes = arena_bytes
         self._ctx = ContextCache()
+        # Control-LoRA builds its control model from the UNet's own trunk weights (patcher/controlnet.py:445-453 reads
+        # `diffusion_model.state_dict()`); the kernel layouts below are not invertible in general (fused / padded / transposed), so the source
+        # tensors of the trunk are kept by reference (no copy) under their LDM keys
+        self._trunk_sd = {k: v for k, v in state_dict.items() if k.startswith(self.TRUNK_PREFIXES)}
         self._load(state_dict)
 
     # ------------------------------------------------------------------------------------------------------------
@@ -574,6 +579,10 @@ class IntegratedUNet2DConditionModel:
                 self._arena_bytes = arena.capacity * 2
                 self._arena = None
                 self.arena_epoch += 1
+
+    def state_dict(self):
+        """LDM-keyed source tensors of the encoder trunk (the part a ControlNet shares with the UNet); see __init__."""
+        return dict(self._trunk_sd)
 
     @staticmethod
     def _hooks(transformer_options):

@@ -222,6 +222,85 @@ class ControlNet(ControlBase):
         super().cleanup()
 
 
+def control_lora_state_dict(unet_sd, control_weights, device=None):
+    """The weights ControlLora.pre_run assembles (patcher/controlnet.py:445-457 with ControlLoraOps :371-417): every trunk tensor of the UNet,
+    overridden by the file's direct tensors; a module that carries an `up` / `down` pair computes with `weight + (up.flatten(1) @
+    down.flatten(1)).reshape(weight.shape)`, where `weight` is the UNet's.  The sum is formed once here, in fp32 (the reference re-forms it in
+    the storage dtype on every forward), so the control model is an ordinary ControlNet afterwards."""
+    merged = dict(unet_sd)
+    for k, v in control_weights.items():
+        if k == "lora_controlnet" or k.endswith((".up", ".down")):
+            continue
+        merged[k] = v
+    for k, up in control_weights.items():
+        if not k.endswith(".up"):
+            continue
+        base = k[:-3]
+        w = merged[base + ".weight"]
+        dev = device if device is not None else w.device
+        delta = torch.mm(up.to(dev, torch.float32).flatten(start_dim=1), control_weights[base + ".down"].to(dev, torch.float32).flatten(start_dim=1))
+        merged[base + ".weight"] = w.to(dev, torch.float32) + delta.reshape(w.shape)
+    return merged
+
+
+class ControlLora(ControlNet):
+    """patcher/controlnet.py:420-474: a ControlNet stored as low-rank differences to the UNet it is used with.  The control model exists only
+    between pre_run and cleanup (it depends on the UNet, LoRAs included)."""
+
+    def __init__(self, control_weights, global_average_pooling=False, device=None):
+        ControlBase.__init__(self, device)
+        self.control_weights = control_weights
+        self.global_average_pooling = global_average_pooling
+        self.control_model = None
+        self.load_device = None
+        self.model_sampling_current = None
+        self.manual_cast_dtype = None
+
+    def pre_run(self, model, percent_to_timestep_function):
+        super().pre_run(model, percent_to_timestep_function)
+        if self.control_model is not None:
+            return  # sampling_prepare walks the chain AND every link recurses into its predecessors: build once per job (cleanup drops it)
+        from ..nn.cnets import cldm
+        net = model.diffusion_model
+        config = dict(net.config)
+        config.pop("out_channels", None)
+        hint_channels = int(self.control_weights["input_hint_block.0.weight"].shape[1])
+        self.device = net.device
+        self.manual_cast_dtype = model.computation_dtype
+        self.control_model = cldm.ControlNet(config, control_lora_state_dict(net.state_dict(), self.control_weights, device=net.device),
+                                             device=net.device, hint_channels=hint_channels)
+
+    def copy(self):
+        c = ControlLora(self.control_weights, global_average_pooling=self.global_average_pooling)
+        self.copy_to(c)
+        return c
+
+    def cleanup(self):
+        self.control_model = None
+        super().cleanup()
+
+    def get_models(self):
+        return ControlBase.get_models(self)
+
+    def inference_memory_requirements(self, dtype):
+        n = sum(int(v.numel()) for v in self.control_weights.values())
+        return n * torch.empty(0, dtype=dtype).element_size() + ControlBase.inference_memory_requirements(self, dtype)
+
+
+def load_controlnet(controlnet_data, unet_config=None, device="cuda"):
+    """State dict -> patcher-level control object.  Control-LoRA files carry the `lora_controlnet` marker and need no config (it is the UNet's);
+    a full ControlNet (LDM keys) is built on `unet_config`, the configuration of the UNet family it was trained for."""
+    if "lora_controlnet" in controlnet_data:
+        return ControlLora(controlnet_data, device=device)
+    if "zero_convs.0.0.weight" not in controlnet_data:
+        raise ValueError("not an LDM-keyed ControlNet state dict (diffusers-format files are converted by the loader of the host application)")
+    if unet_config is None:
+        raise ValueError("a full ControlNet needs the UNet configuration it belongs to")
+    from ..nn.cnets import cldm
+    config = {k: v for k, v in dict(unet_config).items() if k != "out_channels"}
+    return ControlNet(cldm.ControlNet(config, controlnet_data, device=device, hint_channels=int(controlnet_data["input_hint_block.0.weight"].shape[1])))
+
+
 class T2IAdapter(ControlBase):
     """patcher/controlnet.py:477-545: the adapter's features depend on the hint only -> computed once and cached (`control_input`), then
     injected as 'input' residuals (and, for SDXL adapters, the last one as 'middle') every step."""
@@ -297,7 +376,13 @@ def load_t2i_adapter(t2i_data, device="cuda"):
         t2i_data = out
     keys = t2i_data.keys()
     if "body.0.in_conv.weight" in keys:
-        raise NotImplementedError("Adapter_light checkpoints are not built")
+        # :561-563 hard-codes channels [320, 640, 1280, 1280] and nums_rb 4 -- what every Adapter_light checkpoint has; read off the tensors
+        # here, which gives the same values for those files
+        cin = t2i_data["body.0.in_conv.weight"].shape[1]
+        channels = [t2i_data[f"body.{i}.out_conv.weight"].shape[0] for i in range(4)]
+        nums_rb = sum(1 for k in keys if k.startswith("body.0.body.") and k.endswith(".block1.weight"))
+        model = t2i_adapter.Adapter_light(t2i_data, channels=channels, nums_rb=nums_rb, cin=cin, device=device)
+        return T2IAdapter(model, model.input_channels)
     if "conv_in.weight" not in keys:
         return None
     cin, channel = t2i_data["conv_in.weight"].shape[1], t2i_data["conv_in.weight"].shape[0]

@@ -136,6 +136,30 @@ def synth_controlnet_state_dict(cfg, hint_channels=3, seed=6, zero_conv_gain=1.0
     return synth_state_dict(controlnet_param_shapes(cfg, hint_channels), seed=seed, **kw)
 
 
+def synth_control_lora_state_dict(cfg, hint_channels=3, rank=4, seed=13, delta_gain=0.5, skip_prefixes=("time_embed.",)):
+    """A Control-LoRA file (patcher/controlnet.py:360-457): for the trunk's conv / linear weights a low-rank pair `<module>.up` / `<module>.down`
+    that is ADDED to the UNet's own weight, everything else (norms, biases, hint block, zero convs) stored directly, plus the `lora_controlnet`
+    marker.  Modules under `skip_prefixes` get no entry at all: they run on the UNet's weights unchanged."""
+    from .backend.nn.layout import controlnet_param_shapes
+    shapes = controlnet_param_shapes(cfg, hint_channels)
+    direct = synth_state_dict(shapes, seed=seed)
+    trunk = ("input_blocks.", "middle_block.", "time_embed.", "label_emb.")
+    sd = OrderedDict()
+    for name, shape in shapes.items():
+        if name.startswith(skip_prefixes):
+            continue
+        if name.startswith(trunk) and name.endswith(".weight") and len(shape) >= 2:
+            base = name[:-7]
+            up_shape = (shape[0], rank) + (1,) * (len(shape) - 2)
+            # up ~ N(0, 1/rank), down ~ N(0, (delta_gain * gain)^2 / fan_in)  =>  std(up @ down) = delta_gain * std(a synthetic weight)
+            sd[base + ".up"] = synth_tensor(base + ".up", up_shape, seed, 1.0)
+            sd[base + ".down"] = synth_tensor(base + ".down", (rank,) + tuple(shape[1:]), seed, delta_gain * DEFAULT_GAIN)
+        else:
+            sd[name] = direct[name]
+    sd["lora_controlnet"] = torch.zeros(1)
+    return sd
+
+
 # an SD1.5-SHAPED small UNet (4 levels x 2 ResBlocks = 12 input blocks): T2I-Adapter features are placed by input-block index, so its tests
 # need the real block grammar; channels 64 / 128 / 256 / 256
 MINI_SD15_UNET_CONFIG = dict(
@@ -147,6 +171,11 @@ MINI_SD15_UNET_CONFIG = dict(
 def synth_t2i_adapter_state_dict(seed=11, **adapter_kw):
     from .backend.nn.cnets.t2i_adapter import adapter_param_shapes
     return synth_state_dict(OrderedDict(adapter_param_shapes(**adapter_kw)), seed=seed)
+
+
+def synth_t2i_adapter_light_state_dict(seed=12, **adapter_kw):
+    from .backend.nn.cnets.t2i_adapter import adapter_light_param_shapes
+    return synth_state_dict(OrderedDict(adapter_light_param_shapes(**adapter_kw)), seed=seed)
 
 
 def synth_flux_state_dict(cfg, seed=2, **kw):

@@ -86,6 +86,49 @@ def test_sampling_with_a_controlnet_chain_vs_reference(name, engines):
     assert err < 1e-2
 
 
+@pytest.mark.parametrize("name", list(TINY))
+def test_control_lora_vs_reference(name, engines):
+    """Control-LoRA (patcher/controlnet.py:420-474): control model assembled in pre_run from the UNet's trunk + the file's low-rank pairs, against
+    the reference's ControlLora -- residuals of one call and a 4-step Euler run."""
+    cfg = TINY[name]
+    g, fx = load_golden(f"{name}_control_lora.pt"), load_golden(f"{name}_unet_fwd.pt")
+    case = controlnet_case(cfg)
+    eng = engines[name]
+    cl = pc.load_controlnet(synth.synth_control_lora_state_dict(cfg), device=DEV)
+    assert type(cl).__name__ == "ControlLora" and cl.control_model is None
+    unet = pc.apply_controlnet_advanced(eng.forge_objects.unet, cl, case["hint_a"].to(DEV), 0.9, 0.0, 1.0)
+    link = unet.controlnet_linked_list
+    from forge_amd.backend.sampling.sampling_function import sampling_cleanup, sampling_prepare
+    sampling_prepare(unet, None)
+    y = fx["y"].to(DEV) if fx["y"] is not None else None
+    outs = link.control_model(x=fx["x"].to(DEV), hint=case["hint_a"].to(DEV), timesteps=fx["t"].to(DEV), context=fx["ctx"].to(DEV), y=y)
+    worst = max(max_rel(o[:, ::8], want) for o, want in zip(outs, g["outs_every_8th_channel"]))
+    sampling_cleanup(unet)
+    assert link.control_model is None and len(outs) == len(g["outs_every_8th_channel"])
+    print(f"[parity] {name} Control-LoRA residuals vs reference ControlLora: worst max_rel={worst:.3e} (tol 3e-03)")
+    assert worst < 3e-3
+    saved = eng.forge_objects_after_applying_lora
+    eng.forge_objects_after_applying_lora = saved.shallow_copy()
+    eng.forge_objects_after_applying_lora.unet = unet
+    try:
+        b = len(g["euler4"]["seeds"])
+        c, uc = synth.synth_conditioning(b, cfg["context_dim"], cfg.get("adm_in_channels"), seed=1234)
+        if isinstance(c, dict):
+            c, uc = DictWithShape({k: v.to(DEV) for k, v in c.items()}), DictWithShape({k: v.to(DEV) for k, v in uc.items()})
+        else:
+            c, uc = c.to(DEV), uc.to(DEV)
+        shared.opts.randn_source = "CPU"
+        p = processing.StableDiffusionProcessingTxt2Img(sd_model=eng, c=c, uc=uc, seed=g["euler4"]["seeds"][0], sampler_name="Euler", batch_size=b,
+                                                        steps=4, cfg_scale=7.0, width=g["hw"] * 8, height=g["hw"] * 8, do_decode=False)
+        lat = processing.process_images(p).latents
+    finally:
+        eng.forge_objects_after_applying_lora = saved
+        eng.forge_objects = saved.shallow_copy()
+    err = max_rel(lat, g["euler4"]["latent"])
+    print(f"[parity] {name} 4-step Euler with a Control-LoRA vs reference: max_rel={err:.3e} (tol 1e-02)")
+    assert err < 1e-2 and link.control_model is None   # built in sampling_prepare, dropped in sampling_cleanup
+
+
 def test_t2i_adapter_vs_reference():
     """The native T2I-Adapter (three checkpoint layouts) against the reference's Adapter, and a 3-step Euler run of an SD1.5-shaped UNet with the
     adapter attached through the patcher-level T2IAdapter (features computed once, injected as 'input' residuals) against the reference's."""
@@ -118,3 +161,19 @@ def test_t2i_adapter_vs_reference():
     err = max_rel(processing.process_images(p).latents, g["euler3"])
     print(f"[parity] SD1.5-shaped UNet + T2I-Adapter, 3-step Euler vs reference: max_rel={err:.3e} (tol 1e-02)")
     assert err < 1e-2
+
+
+def test_adapter_light_vs_reference():
+    """`Adapter_light` (the colour adapter's network; quarter widths zero-padded to the GEMM granule) against the reference's, through the
+    checkpoint loader (layout detected from the keys)."""
+    from oracle.make_golden import ADAPTER_LIGHT_KW, adapter_light_hint
+    g = load_golden("mini_adapter_light.pt")
+    ad = pc.load_t2i_adapter(synth.synth_t2i_adapter_light_state_dict(**ADAPTER_LIGHT_KW), device=DEV)
+    net = ad.t2i_model
+    assert type(net).__name__ == "Adapter_light" and net.channels == ADAPTER_LIGHT_KW["channels"] and net.nums_rb == ADAPTER_LIGHT_KW["nums_rb"]
+    assert (ad.channels_in, net.unshuffle_amount, net.xl) == (g["input_channels"], g["unshuffle_amount"], False)
+    feats = net(adapter_light_hint().to(DEV))
+    assert [None if f is None else tuple(f.shape) for f in feats] == g["layout"]
+    worst = max(max_rel(f[:, ::4], w) for f, w in zip([f for f in feats if f is not None], g["values_every_4th_channel"]))
+    print(f"[parity] Adapter_light features vs reference: worst max_rel={worst:.3e} (tol 3e-03)")
+    assert worst < 3e-3

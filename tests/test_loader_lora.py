@@ -117,3 +117,22 @@ def test_lycoris_and_dora_merge_vs_reference():
         assert got.dtype == torch.float16
         err = (got.flatten()[::5].float() - want.float()).abs().max() / want.float().abs().max()
         assert err < 2e-3, (k, pv[0], float(err))  # one fp16 rounding of the result; the reference rounds W + delta the same way
+
+
+def test_control_lora_weight_assembly_matches_the_oracle():
+    """Host side of Control-LoRA (backend/patcher/controlnet.py control_lora_state_dict / load_controlnet) against oracle/controlnet.py, which is
+    pinned to the reference's ControlLora (tests/golden/*_control_lora.pt)."""
+    from forge_amd.backend.patcher import controlnet as pc
+    from oracle import controlnet as ocn
+    cfg = synth.TINY_SDXL_UNET_CONFIG
+    unet_sd = synth.synth_unet_state_dict(cfg, seed=0)
+    cl = synth.synth_control_lora_state_dict(cfg)
+    trunk = {k: v for k, v in unet_sd.items() if k.startswith(("input_blocks.", "middle_block.", "time_embed.", "label_emb."))}
+    got, want = pc.control_lora_state_dict(trunk, cl), ocn.control_lora_weights(unet_sd, cl)
+    assert set(got) == set(want)
+    for k in want:
+        torch.testing.assert_close(got[k].float(), want[k], rtol=1e-6, atol=1e-7)
+    obj = pc.load_controlnet(cl, device="cpu")
+    assert isinstance(obj, pc.ControlLora) and obj.copy().control_weights is cl
+    with pytest.raises(ValueError):
+        pc.load_controlnet({"foo": torch.zeros(1)})

@@ -241,6 +241,30 @@ def test_controlnet_restated(name):
 
 
 @pytest.mark.parametrize("name", list(TINY))
+def test_control_lora_restated(name):
+    """oracle/controlnet.py control_lora_weights (UNet trunk + direct tensors + up @ down pairs) vs the reference's ControlLora: the residuals of
+    one control-model call and a 4-step Euler run through the reference's sampling stack."""
+    from oracle import controlnet as ocn
+    from oracle.make_golden import controlnet_case
+    cfg = TINY[name]
+    g, fx = load_golden(f"{name}_control_lora.pt"), load_golden(f"{name}_unet_fwd.pt")
+    case = controlnet_case(cfg)
+    sd = synth.synth_unet_state_dict(cfg, seed=0)
+    cl = synth.synth_control_lora_state_dict(cfg)
+    assert "lora_controlnet" in cl and not any(k.startswith("time_embed.") for k in cl)   # time_embed runs on the UNet's own weights
+    merged = ocn.control_lora_weights(sd, cl)
+    assert not torch.equal(merged["input_blocks.1.0.in_layers.2.weight"], sd["input_blocks.1.0.in_layers.2.weight"])
+    outs = ocn.controlnet_forward(merged, cfg, fx["x"], case["hint_a"], fx["t"], fx["ctx"], fx["y"])
+    assert len(outs) == len(g["outs_every_8th_channel"])
+    for o, want in zip(outs, g["outs_every_8th_channel"]):
+        torch.testing.assert_close(o[:, ::8], want, rtol=1e-4, atol=1e-5)
+    c, uc = synth.synth_conditioning(2, cfg["context_dim"], cfg.get("adm_in_channels"), seed=1234)
+    chain = ocn.Control(merged, cfg, case["hint_a"], 0.9, (0.0, 1.0))
+    lat = pipeline.txt2img_latents_controlnet(sd, cfg, c, uc, g["euler4"]["seeds"], g["hw"] * 8, g["hw"] * 8, 4, chain)
+    assert max_rel(lat, g["euler4"]["latent"]) < 2e-4
+
+
+@pytest.mark.parametrize("name", list(TINY))
 def test_general_cfg_paths_restated(name):
     """oracle/cfg.py cfg_denoise_general vs the reference's sampling_function: AND-composed prompts (edit strength), the three cfg
     function hooks, model_function_wrapper."""
@@ -271,6 +295,19 @@ def test_inpainting_model_restated():
     c, uc = synth.synth_conditioning(2, cfg["context_dim"], None, seed=1234)
     lat = pipeline.txt2img_latents_inpaint_model(sd, cfg, c, uc, g["seeds"], g["hw"] * 8, g["hw"] * 8, 3, ic)
     assert max_rel(lat, g["euler3"]) < 2e-4
+
+
+def test_adapter_light_restated():
+    """oracle/controlnet.py adapter_light_forward vs the reference's Adapter_light; also pins the product's adapter_light_param_shapes to the
+    reference module's state dict (asserted at fixture time)."""
+    from oracle import controlnet as ocn
+    from oracle.make_golden import ADAPTER_LIGHT_KW, adapter_light_hint
+    g = load_golden("mini_adapter_light.pt")
+    feats = ocn.adapter_light_forward(synth.synth_t2i_adapter_light_state_dict(**ADAPTER_LIGHT_KW), adapter_light_hint(), ADAPTER_LIGHT_KW["channels"],
+                                      ADAPTER_LIGHT_KW["nums_rb"])
+    assert [None if f is None else tuple(f.shape) for f in feats] == g["layout"]
+    for f, w in zip([f for f in feats if f is not None], g["values_every_4th_channel"]):
+        torch.testing.assert_close(f[:, ::4], w, rtol=1e-4, atol=1e-5)
 
 
 def test_t2i_adapter_restated():
