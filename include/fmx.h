@@ -258,6 +258,31 @@ int fmx_vae_sample_posterior(const void* moments, int32_t ld, const float* noise
 int fmx_philox_randn(uint64_t seed, uint32_t offset, float* out, uint32_t* raw_u32, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * bfloat16 build of the Flux path.  The reference computes Flux in bf16 (backend/loader.py picks the storage dtype of the checkpoint,
+ * bf16 for Flux.1; fp16 overflows in the late single-stream blocks of trained weights).  These entry points are the SAME kernels as
+ * their _f16 counterparts compiled with bfloat16 elements (storage, MFMA operands; fp32 accumulation, softmax and epilogue math as
+ * before): identical argument contracts, every "fp16" in the descriptions above reads "bf16".  fmx_groupnorm_* / fmx_layernorm_padded /
+ * fmx_softmax_rows come along with their files; the Flux executor uses the other seven.
+ * ---------------------------------------------------------------------------------------------- */
+int fmx_gemm_conv_bf16(const fmx_gemm_args* args /* host */, void* stream);
+int fmx_attention_bf16(const fmx_attn_args* args /* host */, void* stream);
+int fmx_softmax_rows_bf16(void* x, int64_t nrows, int32_t ncols, int64_t ld, void* stream);
+int fmx_groupnorm_stats_bf16(const void* x0, const void* x1, int32_t c0, int32_t c1, int32_t n, int32_t hw, float* partial, int32_t nchunks,
+                             void* stream);
+int fmx_groupnorm_apply_bf16(const void* x0, const void* x1, int32_t c0, int32_t c1, int32_t n, int32_t hw, float* partial, int32_t nchunks,
+                             int32_t groups, float eps, const void* gamma, const void* beta, int32_t silu, void* y, void* stream);
+int fmx_layernorm_bf16(const void* x, const void* gamma, const void* beta, void* y, int64_t rows, int32_t c, float eps, void* stream);
+int fmx_layernorm_padded_bf16(const void* x, const void* gamma, const void* beta, void* y, int64_t rows, int32_t c, float eps,
+                              int64_t rows_per_image, int64_t out_rows_per_image, void* stream);
+int fmx_layernorm_mod_bf16(const void* x, const void* scale, const void* shift, int64_t ld_mod, int64_t rows_per_batch, void* y,
+                           int64_t rows, int32_t c, float eps, void* stream);
+int fmx_flux_qk_norm_rope_bf16(const void* qkv, int64_t ld_qkv, const void* q_scale, const void* k_scale, const float* pe, void* q_out,
+                               void* k_out, void* vt_out, int32_t batch, int32_t tokens, int32_t heads, int32_t head_dim,
+                               int32_t row_off, int32_t l_pad, float eps, void* stream);
+int fmx_timestep_embedding_bf16(const float* t, void* emb, int32_t b, int32_t dim, float max_period, void* stream);
+int fmx_silu_bf16(const void* x, void* y, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * HIP-graph helpers: capture everything launched on `stream` between begin/end into an executable graph.
  * ---------------------------------------------------------------------------------------------- */
 int fmx_graph_begin(void* stream);

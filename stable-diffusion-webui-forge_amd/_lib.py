@@ -98,6 +98,13 @@ SIGNATURES = {
 }
 
 
+# bfloat16 build of the Flux path's kernels: same signatures as the _f16 entries (include/fmx.h, last section)
+for _n in ("fmx_gemm_conv", "fmx_attention", "fmx_softmax_rows", "fmx_groupnorm_stats", "fmx_groupnorm_apply", "fmx_layernorm", "fmx_layernorm_padded",
+           "fmx_layernorm_mod", "fmx_flux_qk_norm_rope", "fmx_silu"):
+    SIGNATURES[_n + "_bf16"] = SIGNATURES[_n + "_f16"]
+SIGNATURES["fmx_timestep_embedding_bf16"] = SIGNATURES["fmx_timestep_embedding"]
+
+
 def build(force=False, verbose=False):
     """Compile csrc/*.hip for gfx950 into libfmx_gfx950.so (make is incremental)."""
     if force and os.path.exists(LIB_PATH):

@@ -144,8 +144,8 @@ class FluxEngine:
     encode_first_stage = ForgeDiffusionEngine.encode_first_stage
 
 
-def build_flux_engine(flux_config, state_dict, width, height, device="cuda", vae_config=None, vae_state_dict=None):
+def build_flux_engine(flux_config, state_dict, width, height, device="cuda", vae_config=None, vae_state_dict=None, dtype=torch.float16):
     from ..nn.flux import IntegratedFluxTransformer2DModel
-    net = IntegratedFluxTransformer2DModel(flux_config, state_dict, device=device)
+    net = IntegratedFluxTransformer2DModel(flux_config, state_dict, device=device, dtype=dtype)
     vae = IntegratedAutoencoderKL(vae_config, vae_state_dict, device=device) if vae_config is not None else None
     return FluxEngine(net, seq_len=(height // 16) * (width // 16), vae=vae)

@@ -14,8 +14,8 @@ kernels (include/fmx.h) instead of an nn.Module graph:
   * all 19*2 + 38 + 1 adaLN modulation Linears depend only on `vec`: ONE GEMM per forward (the reference runs 77).
 The rotary table depends only on the latent size and text length: built once on the host in float64 exactly as
 `rope()` (:21-40) and cached.
-fp16 storage / fp32 accumulation like the rest of the path (the reference computes Flux in bf16; bf16 kernel variants
-are the planned follow-up -- DESIGN.md).
+fp16 or bf16 storage / MFMA operands with fp32 accumulation (`dtype`; the reference computes Flux in bf16): the bf16 entry points are the
+same kernels compiled a second time with bfloat16 elements (csrc/fmx_common.hpp).
 """
 import math
 
@@ -36,10 +36,15 @@ def _rope_table(ids, axes_dim, theta):
 
 
 class IntegratedFluxTransformer2DModel:
-    def __init__(self, config, state_dict, device="cuda"):
+    def __init__(self, config, state_dict, device="cuda", dtype=torch.float16):
+        """`dtype`: torch.float16 or torch.bfloat16 -- storage and MFMA operand type of the whole forward (accumulation, softmax, norms and
+        epilogue math are fp32 either way).  bf16 is what the reference runs Flux.1 in; trained Flux weights overflow fp16 in the late
+        single-stream blocks, so real checkpoints want bf16, while fp16 has 3 more mantissa bits for well-scaled activations."""
+        if dtype not in (torch.float16, torch.bfloat16):
+            raise ValueError("the Flux executor computes in fp16 or bf16")
         self.config = dict(config)
         self.device = torch.device(device)
-        self.dtype = self.storage_dtype = self.computation_dtype = torch.float16
+        self.dtype = self.storage_dtype = self.computation_dtype = dtype
         self.hidden = config["hidden_size"]
         self.heads = config["num_heads"]
         self.head_dim = self.hidden // self.heads
@@ -59,7 +64,7 @@ class IntegratedFluxTransformer2DModel:
         dev = self.device
 
         def T(k):
-            return sd[k].to(device=dev, dtype=torch.float16).contiguous()
+            return sd[k].to(device=dev, dtype=self.dtype).contiguous()
 
         def lin(k):
             return T(k + ".weight"), (T(k + ".bias") if (k + ".bias") in sd else None)
@@ -142,13 +147,13 @@ class IntegratedFluxTransformer2DModel:
         dev, hs, H, D = self.device, self.hidden, self.heads, self.head_dim
         bsz, c, h, w = x.shape
         pad_h, pad_w = (2 - h % 2) % 2, (2 - w % 2) % 2
-        xf = x.to(device=dev, dtype=torch.float16)
+        xf = x.to(device=dev, dtype=self.dtype)
         if pad_h or pad_w:
             xf = torch.nn.functional.pad(xf, (0, pad_w, 0, pad_h), mode="circular")
         h_len, w_len = xf.shape[-2] // 2, xf.shape[-1] // 2
         L = h_len * w_len
         img_tok = xf.view(bsz, c, h_len, 2, w_len, 2).permute(0, 2, 4, 1, 3, 5).reshape(bsz * L, c * 4).contiguous()  # flux.py:406
-        ctx = context.to(device=dev, dtype=torch.float16).contiguous()
+        ctx = context.to(device=dev, dtype=self.dtype).contiguous()
         lt = ctx.shape[1]
         ltot = lt + L
         lpad = -(-ltot // 64) * 64
@@ -156,22 +161,22 @@ class IntegratedFluxTransformer2DModel:
 
         # ---- vec (flux.py:375-381) and every adaLN modulation of the network in one GEMM -------------------------
         t32 = timestep.to(device=dev, dtype=torch.float32).reshape(-1)
-        vec = self._mlp_embed(ops.timestep_embedding(t32 * 1000.0, 256), "time_in")
+        vec = self._mlp_embed(ops.timestep_embedding(t32 * 1000.0, 256, dtype=self.dtype), "time_in")
         if self.guidance_embed:
             if guidance is None:
                 raise ValueError("Didn't get guidance strength for guidance distilled model.")
             g32 = guidance.to(device=dev, dtype=torch.float32).reshape(-1)
-            vec = ops.linear(ops.silu(ops.linear(ops.timestep_embedding(g32 * 1000.0, 256), *self.w["guidance_in.in_layer"])),
+            vec = ops.linear(ops.silu(ops.linear(ops.timestep_embedding(g32 * 1000.0, 256, dtype=self.dtype), *self.w["guidance_in.in_layer"])),
                              *self.w["guidance_in.out_layer"], residual=vec)
-        yv = y.to(device=dev, dtype=torch.float16).contiguous()
+        yv = y.to(device=dev, dtype=self.dtype).contiguous()
         vec = ops.linear(ops.silu(ops.linear(yv, *self.w["vector_in.in_layer"])), *self.w["vector_in.out_layer"], residual=vec)
         mods = ops.linear(ops.silu(vec), *self.w["mods"])                       # [B, total]
 
         img = ops.linear(img_tok, *self.w["img_in"])                            # [B*L, hs]
         txt = ops.linear(ctx.view(bsz * lt, -1), *self.w["txt_in"])             # [B*Lt, hs]
-        qj = torch.zeros(bsz, lpad, hs, dtype=torch.float16, device=dev)        # joint txt||img q, k (pad rows stay 0)
-        kj = torch.zeros(bsz, lpad, hs, dtype=torch.float16, device=dev)
-        vtj = torch.zeros(hs, bsz * lpad, dtype=torch.float16, device=dev)      # V^T
+        qj = torch.zeros(bsz, lpad, hs, dtype=self.dtype, device=dev)           # joint txt||img q, k (pad rows stay 0)
+        kj = torch.zeros(bsz, lpad, hs, dtype=self.dtype, device=dev)
+        vtj = torch.zeros(hs, bsz * lpad, dtype=self.dtype, device=dev)         # V^T
 
         # ---- double-stream blocks (flux.py:206-264) ----------------------------------------------------------------
         streams = (("img", L, lt), ("txt", lt, 0))

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 #pragma unroll
       for (int ds = 0; ds < DSTEPS; ++ds) {
         const f16x8 kf = *reinterpret_cast<const f16x8*>(sk + row * (DP * 2) + (k_phys_chunk<CPR>(row, ds * 2 + hi) << 4));
-        sacc[s] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ds], sacc[s], 0, 0, 0);
+        sacc[s] = FMX_MFMA_32x32x16(kf, qf[ds], sacc[s]);
       }
     }
     // lane now holds scores of query li against keys kt*64 + s*32 + hi*16 + r
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const f16x8 vf = *reinterpret_cast<const f16x8*>(rp + (((s * 4 + hi * 2 + j) ^ sw) << 4));
-          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s][j], oacc[dt], 0, 0, 0);
+          oacc[dt] = FMX_MFMA_32x32x16(vf, pf[s][j], oacc[dt]);
         }
     }
     wait_vmcnt0();
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void attn_q64_kernel(const AttnParams p) {
       for (int ds = 0; ds < DSTEPS; ++ds) {
         const f16x8 kf = *reinterpret_cast<const f16x8*>(sk + row * 128 + (k_phys_chunk<CPR>(row, ds * 2 + hi) << 4));
 #pragma unroll
-        for (int a = 0; a < 2; ++a) sacc[s][a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[a][ds], sacc[s][a], 0, 0, 0);
+        for (int a = 0; a < 2; ++a) sacc[s][a] = FMX_MFMA_32x32x16(kf, qf[a][ds], sacc[s][a]);
       }
     }
     if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void attn_q64_kernel(const AttnParams p) {
         for (int j = 0; j < 2; ++j) {
           const f16x8 vf = *reinterpret_cast<const f16x8*>(rp + (((s * 4 + hi * 2 + j) ^ sw) << 4));
 #pragma unroll
-          for (int a = 0; a < 2; ++a) oacc[dt][a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[a][s][j], oacc[dt][a], 0, 0, 0);
+          for (int a = 0; a < 2; ++a) oacc[dt][a] = FMX_MFMA_32x32x16(vf, pf[a][s][j], oacc[dt][a]);
         }
     }
     if (PRIO == 1) __builtin_amdgcn_s_setprio(0);

@@ -3,12 +3,31 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// The 16-bit kernels are written once against the element type `f16` of their translation unit.  The default build is IEEE half
+// (the SD / SDXL path).  The files the Flux transformer needs (GEMMs, attention, LayerNorm, q/k-norm + RoPE) are compiled a second
+// time with -DFMX_ELEM_BF16: same code with bfloat16 storage and bf16 MFMA operands (the reference computes Flux in bf16), every
+// entry point exported under a _bf16 name (fmx_bf16_names.hpp).
+#ifdef FMX_ELEM_BF16
+#include "fmx_bf16_names.hpp"
+#endif
+
 #include "fmx.h"
 
+#ifdef FMX_ELEM_BF16
+typedef __bf16 f16;
+typedef __bf16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 f16x8 __attribute__((ext_vector_type(8)));
+#define FMX_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#define FMX_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#else
 typedef _Float16 f16;
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#define FMX_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define FMX_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

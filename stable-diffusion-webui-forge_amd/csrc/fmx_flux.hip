@@ -83,3 +83,44 @@ extern "C" int fmx_flux_qk_norm_rope_f16(const void* qkv, int64_t ld_qkv, const 
   FMX_LAUNCH_CHECK("fmx_flux_qk_norm_rope_f16");
   return FMX_OK;
 }
+
+#ifdef FMX_ELEM_BF16
+// The two small elementwise ops on the Flux `vec` path (timestep / guidance embedding -> MLPEmbedder, SiLU; backend/nn/flux.py:52-73,
+// 142-153).  Their fp16 forms live in fmx_elementwise.hip next to the UNet's other elementwise kernels; the bfloat16 build needs only
+// these two, so they are here rather than in a second build of that whole file.
+namespace {
+
+__global__ void timestep_embedding_bf16_kernel(const float* __restrict__ t, f16* __restrict__ emb, int b, int dim, float log_period) {
+  const int half = dim >> 1;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b * half) return;
+  const int bi = i / half, k = i - bi * half;
+  const float a = t[bi] * expf(-log_period * (float)k / (float)half);
+  emb[(long)bi * dim + k] = (f16)cosf(a);
+  emb[(long)bi * dim + half + k] = (f16)sinf(a);
+}
+
+__global__ void silu_bf16_kernel(const f16* __restrict__ x, f16* __restrict__ y, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = (f16)silu_f((float)x[i]);
+}
+
+}  // namespace
+
+extern "C" int fmx_timestep_embedding_bf16(const float* t, void* emb, int32_t b, int32_t dim, float max_period, void* stream) {
+  FMX_REQUIRE(t && emb && b > 0 && dim > 0 && (dim % 2) == 0 && max_period > 1.0f, "timestep_embedding_bf16: bad args");
+  const int total = b * (dim / 2);
+  hipLaunchKernelGGL(timestep_embedding_bf16_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, (f16*)emb, b, dim,
+                     logf(max_period));
+  FMX_LAUNCH_CHECK("fmx_timestep_embedding_bf16");
+  return FMX_OK;
+}
+
+extern "C" int fmx_silu_bf16(const void* x, void* y, int64_t n, void* stream) {
+  FMX_REQUIRE(x && y && n > 0, "silu_bf16: bad args");
+  const long blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(silu_bf16_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream, (const f16*)x,
+                     (f16*)y, (long)n);
+  FMX_LAUNCH_CHECK("fmx_silu_bf16");
+  return FMX_OK;
+}
+#endif

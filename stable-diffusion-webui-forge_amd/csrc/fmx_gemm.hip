@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = FMX_MFMA_16x16x32(bf[j], af[i], acc[i][j]);
     }
     wait_vmcnt0();
     __syncthreads();
@@ -400,6 +400,7 @@ extern "C" int fmx_gemm_conv_f16(const fmx_gemm_args* a, void* stream) {
   }
 }
 
+#ifndef FMX_ELEM_BF16  // a 16-bit row shuffle: one copy serves both element types
 extern "C" int fmx_geglu_interleave_rows(const void* w_in, const void* b_in, void* w_out, void* b_out, int32_t inner,
                                          int32_t k, void* stream) {
   FMX_REQUIRE(w_in && w_out && inner > 0 && (inner % 16) == 0 && k > 0, "geglu_interleave: bad args");
@@ -409,3 +410,4 @@ extern "C" int fmx_geglu_interleave_rows(const void* w_in, const void* b_in, voi
   FMX_LAUNCH_CHECK("fmx_geglu_interleave_rows");
   return FMX_OK;
 }
+#endif

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
       for (int f = 0; f < 2; ++f)
-        acc[qi][qj][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[qj][ks], af[f][ks], acc[qi][qj][f], 0, 0, 0);
+        acc[qi][qj][f] = FMX_MFMA_32x32x16(wf[qj][ks], af[f][ks], acc[qi][qj][f]);
       if (SCHED == 0 && wc == ks) dma(src1, buf, HT, IC<1>{});
     }
     __builtin_amdgcn_s_setprio(0);

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
-      for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[fb][j], af[fb][i], acc[i][j], 0, 0, 0);
+      for (int i = 0; i < MI; ++i) acc[i][j] = FMX_MFMA_32x32x16(wf[fb][j], af[fb][i], acc[i][j]);
   };
 
   // MFMA / DS-read / VMEM interleave of one k-step: (MFMA, ds_read) x (MI + NJ), then the remaining MFMAs each preceded by

@@ -111,12 +111,31 @@ def _check_f16(*ts):
             raise TypeError("expected fp16 device tensors, got %s on %s" % (t.dtype, t.device))
 
 
+def _elem(*ts):
+    """-> (symbol suffix, torch dtype) of a 16-bit kernel call: all tensors fp16 (the SD / SDXL path and the default everywhere) or all
+    bfloat16 (the Flux executor's optional compute type; only the entry points with a _bf16 build accept it)."""
+    dt = None
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda or t.dtype not in (torch.float16, torch.bfloat16):
+            raise TypeError("expected fp16 / bf16 device tensors, got %s on %s" % (t.dtype, t.device))
+        if dt is None:
+            dt = t.dtype
+        elif t.dtype != dt:
+            raise TypeError("mixed fp16 / bf16 operands in one kernel call")
+    return ("_bf16", torch.bfloat16) if dt == torch.bfloat16 else ("_f16", torch.float16)
+
+
 def conv_gemm(x, wgt, nout, *, x1=None, n=None, h=None, w=None, kh=1, stride=1, pad=0, up=None, bias=None,
-              rowvec=None, residual=None, act=ACT_NONE, alpha=1.0, out=None, ld_out=None, out_dtype=torch.float16,
+              rowvec=None, residual=None, act=ACT_NONE, alpha=1.0, out=None, ld_out=None, out_dtype=None,
               ldw=0, force_tile=0, gate=None, out_hw=None):
     """OUT[M, ncols] = epilogue(A (*) W^T).  x: [N,H,W,C0] (or [M,C0] with kh == 1); x1: optional second source
     concatenated along channels; wgt: [nout, kh*kh*(C0+C1)]; up=(UH, UW): nearest-resize before the conv."""
-    _check_f16(x, x1, wgt, bias, rowvec, residual, gate)
+    sfx, elem = _elem(x, x1, wgt, bias, rowvec, residual, gate)
+    fn_name = "fmx_gemm_conv" + sfx
+    if out_dtype is None:
+        out_dtype = elem
     if x.dim() == 2:
         n_, h_, w_ = 1, 1, x.shape[0]
     else:
@@ -156,10 +175,10 @@ def conv_gemm(x, wgt, nout, *, x1=None, n=None, h=None, w=None, kh=1, stride=1, 
     a.ld_gate = gate.stride(0) if gate is not None else 0
     if _profiler is not None:
         flops = 2.0 * m * nout * kh * kh * (c0 + c1)
-        _profiler.launch("gemm_conv", flops, lambda: _lib.check(_lib.lib().fmx_gemm_conv_f16(C.byref(a), stream_ptr()), "fmx_gemm_conv_f16"),
+        _profiler.launch("gemm_conv", flops, lambda: _lib.check(getattr(_lib.lib(), fn_name)(C.byref(a), stream_ptr()), fn_name),
                          tag=f"M={m} N={nout} K={kh * kh * (c0 + c1)} kh={kh} s={stride}{' up' if up else ''}{' geglu' if act == ACT_GEGLU else ''}")
         return out
-    _lib.check(_lib.lib().fmx_gemm_conv_f16(C.byref(a), stream_ptr()), "fmx_gemm_conv_f16")
+    _lib.check(getattr(_lib.lib(), fn_name)(C.byref(a), stream_ptr()), fn_name)
     return out
 
 
@@ -179,9 +198,10 @@ def geglu_interleave(w, b):
 def attention(q, k, vt, *, batch, heads, nq, nk, nk_pad, dpad, scale, q_bs, q_rs, k_bs, k_rs, vt_bs, vt_hs, vt_ds,
               out=None, force32=False, causal=False):
     """q/k/vt are base tensors (views allowed: the data_ptr is the element (0,0,0,0)); strides in elements."""
-    _check_f16(q, k, vt)
+    sfx, elem = _elem(q, k, vt, out)
+    fn_name = "fmx_attention" + sfx
     if out is None:
-        out = empty((batch * nq, heads * dpad), torch.float16, q.device)
+        out = empty((batch * nq, heads * dpad), elem, q.device)
     a = AttnArgs()
     a.q, a.k, a.vt, a.o = _p(q), _p(k), _p(vt), _p(out)
     a.q_bs, a.q_rs, a.k_bs, a.k_rs = q_bs, q_rs, k_bs, k_rs
@@ -194,10 +214,10 @@ def attention(q, k, vt, *, batch, heads, nq, nk, nk_pad, dpad, scale, q_bs, q_rs
     if _profiler is not None:
         d_true = int(round(float(scale) ** -2))
         flops = 4.0 * batch * heads * nq * nk * d_true
-        _profiler.launch("attention", flops, lambda: _lib.check(_lib.lib().fmx_attention_f16(C.byref(a), stream_ptr()), "fmx_attention_f16"),
+        _profiler.launch("attention", flops, lambda: _lib.check(getattr(_lib.lib(), fn_name)(C.byref(a), stream_ptr()), fn_name),
                          tag=f"B={batch} H={heads} Nq={nq} Nk={nk} d={dpad}")
         return out
-    _lib.check(_lib.lib().fmx_attention_f16(C.byref(a), stream_ptr()), "fmx_attention_f16")
+    _lib.check(getattr(_lib.lib(), fn_name)(C.byref(a), stream_ptr()), fn_name)
     return out
 
 
@@ -253,38 +273,40 @@ def layernorm_padded(x, gamma, beta, out, rows_per_image, eps=1e-5):
 
 def layernorm_mod(x, scale, shift, rows_per_batch, eps=1e-6, out=None):
     """Flux adaLN: (1 + scale[b]) * LayerNorm(x, no affine) + shift[b]; scale/shift: [B, c] views with a common row stride."""
-    _check_f16(x, scale, shift)
+    sfx, elem = _elem(x, scale, shift, out)
     c = x.shape[-1]
     rows = x.numel() // c
     assert scale.stride(0) == shift.stride(0) and scale.stride(-1) == 1 and shift.stride(-1) == 1
     if out is None:
-        out = empty(x.shape, torch.float16, x.device)
-    _lib.check(_lib.lib().fmx_layernorm_mod_f16(_p(x), _p(scale), _p(shift), scale.stride(0), rows_per_batch, _p(out), rows, c, float(eps),
-                                                stream_ptr()), "fmx_layernorm_mod_f16")
+        out = empty(x.shape, elem, x.device)
+    _lib.check(getattr(_lib.lib(), "fmx_layernorm_mod" + sfx)(_p(x), _p(scale), _p(shift), scale.stride(0), rows_per_batch, _p(out), rows, c,
+                                                              float(eps), stream_ptr()), "fmx_layernorm_mod" + sfx)
     return out
 
 
 def flux_qk_norm_rope(qkv, q_scale, k_scale, pe, q_out, k_out, vt_out, *, batch, tokens, heads, head_dim, row_off, l_pad, eps=1e-6):
     """qkv: [batch*tokens, >= 3*heads*head_dim] (row stride = qkv.stride(0)); pe: fp32 [L_total, head_dim/2, 2] (cos, sin)."""
-    _check_f16(qkv, q_scale, k_scale, q_out, k_out, vt_out)
+    sfx, _ = _elem(qkv, q_scale, k_scale, q_out, k_out, vt_out)
     assert pe.dtype == torch.float32 and pe.is_contiguous()
-    _lib.check(_lib.lib().fmx_flux_qk_norm_rope_f16(_p(qkv), qkv.stride(0), _p(q_scale), _p(k_scale), _p(pe), _p(q_out), _p(k_out), _p(vt_out),
-                                                    batch, tokens, heads, head_dim, row_off, l_pad, float(eps), stream_ptr()),
-               "fmx_flux_qk_norm_rope_f16")
+    _lib.check(getattr(_lib.lib(), "fmx_flux_qk_norm_rope" + sfx)(_p(qkv), qkv.stride(0), _p(q_scale), _p(k_scale), _p(pe), _p(q_out), _p(k_out),
+                                                                  _p(vt_out), batch, tokens, heads, head_dim, row_off, l_pad, float(eps),
+                                                                  stream_ptr()), "fmx_flux_qk_norm_rope" + sfx)
 
 
-def timestep_embedding(t, dim, max_period=10000.0, out=None):
+def timestep_embedding(t, dim, max_period=10000.0, out=None, dtype=torch.float16):
     b = t.shape[0]
     if out is None:
-        out = empty((b, dim), torch.float16, t.device)
-    _lib.check(_lib.lib().fmx_timestep_embedding(_p(t), _p(out), b, dim, float(max_period), stream_ptr()), "fmx_timestep_embedding")
+        out = empty((b, dim), dtype, t.device)
+    name = "fmx_timestep_embedding_bf16" if out.dtype == torch.bfloat16 else "fmx_timestep_embedding"
+    _lib.check(getattr(_lib.lib(), name)(_p(t), _p(out), b, dim, float(max_period), stream_ptr()), name)
     return out
 
 
 def silu(x, out=None):
+    sfx, elem = _elem(x, out)
     if out is None:
-        out = empty(x.shape, torch.float16, x.device)
-    _lib.check(_lib.lib().fmx_silu_f16(_p(x), _p(out), x.numel(), stream_ptr()), "fmx_silu_f16")
+        out = empty(x.shape, elem, x.device)
+    _lib.check(getattr(_lib.lib(), "fmx_silu" + sfx)(_p(x), _p(out), x.numel(), stream_ptr()), "fmx_silu" + sfx)
     return out
 
 

@@ -140,3 +140,109 @@ def test_flux_euler_sampling_vs_reference_fixture():
     v = max_rel(res.latents, g["latent"])
     print(f"[parity] tiny flux 4-step Euler (simple sigmas) vs reference: max_rel={v:.3e} (tol 1e-02)")
     assert v < 1e-2
+
+
+# ---- bfloat16 build of the Flux path (the reference's Flux compute type): the same kernels compiled with bf16 elements ---------------------------
+# Tolerances: a bf16 result carries a rounding error of up to 2^-8 = 3.9e-3 relative (8 significand bits) where fp16 has 4.9e-4, and the
+# attention probabilities are rounded to bf16 before P.V; kernels are checked at 1e-2, the multi-block forward and the 4-step run at 2e-2 (measured 6.1e-3 / 2.0e-3, printed).
+BF = torch.bfloat16
+
+
+def test_bf16_gemm_epilogues_all_tile_families():
+    bsz, l, k, n = 2, 640, 256, 1280
+    x, w, bias = rnd(bsz * l, k, seed=320).to(BF), rnd(n, k, scale=1 / math.sqrt(k), seed=321).to(BF), rnd(n, scale=0.2, seed=322).to(BF)
+    gate = rnd(bsz, 3 * n, scale=0.7, seed=323).to(BF)[:, n:2 * n]
+    res = rnd(bsz * l, n, seed=324).to(BF)
+    lin = x.float() @ w.float().t() + bias.float()
+    ref_gate = lin.view(bsz, l, n) * gate.float()[:, None] + res.float().view(bsz, l, n)
+    # 0 = the dispatcher's choice; forced: 4-wave 128x128 / 128x64 / 64x64, ping-pong 256x256, 128x160, pipelined 256x256 / 256x320 / 320x256
+    for tile in (0, 1, 2, 3, 4, 5, 6, 7, 8):
+        out = ops.conv_gemm(x, w, n, n=bsz, h=1, w=l, bias=bias, gate=gate, residual=res, force_tile=tile)
+        assert out.dtype == BF
+        close(out.view(bsz, l, n), ref_gate, 1e-2, 1e-2, f"bf16 gate epilogue, tile {tile}")
+        out = ops.conv_gemm(x, w, n, bias=bias, act=ops.ACT_GELU_TANH, force_tile=tile)
+        close(out, F.gelu(lin, approximate="tanh"), 1e-2, 1e-2, f"bf16 gelu-tanh epilogue, tile {tile}")
+    close(ops.linear(x, w, bias), lin, 1e-2, 1e-2, "bf16 linear (dispatcher's choice)")
+    with pytest.raises(TypeError):
+        ops.linear(x, w.half(), bias)   # mixed element types are rejected, not converted
+
+
+@pytest.mark.parametrize("b,h,nq,nk", [(1, 2, 300, 300), (2, 3, 128, 77), (1, 24, 1280, 1280)])
+def test_bf16_attention_d128(b, h, nq, nk):
+    from test_gpu_kernels import _attn_ref
+    d = 128
+    nk_pad = -(-nk // 64) * 64
+    q = rnd(b, nq, h, d, seed=330).to(BF)
+    k = torch.zeros(b, nk_pad, h, d, dtype=BF, device=DEV)
+    v = torch.zeros_like(k)
+    k[:, :nk], v[:, :nk] = rnd(b, nk, h, d, seed=331).to(BF), rnd(b, nk, h, d, seed=332).to(BF)
+    k[:, nk:] = 5.0
+    vt = v.permute(2, 3, 0, 1).contiguous()
+    out = ops.attention(q, k, vt, batch=b, heads=h, nq=nq, nk=nk, nk_pad=nk_pad, dpad=d, scale=d ** -0.5, q_bs=nq * h * d, q_rs=h * d,
+                        k_bs=nk_pad * h * d, k_rs=h * d, vt_bs=nk_pad, vt_hs=d * b * nk_pad, vt_ds=b * nk_pad)
+    assert out.dtype == BF
+    ref = _attn_ref(q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3)[:, :, :nk], v.permute(0, 2, 1, 3)[:, :, :nk], d ** -0.5)
+    close(out.reshape(b, nq, h, d).permute(0, 2, 1, 3), ref, 1e-2, 1e-2, "bf16 attention d128")
+
+
+def test_bf16_layernorm_mod_and_qk_norm_rope():
+    b, l, c = 3, 50, 3072
+    x = (rnd(b * l, c, scale=2, seed=340) + 0.3).to(BF)
+    mods = rnd(b, 4 * c, scale=0.5, seed=341).to(BF)
+    scale, shift = mods[:, c:2 * c], mods[:, 0:c]
+    out = ops.layernorm_mod(x, scale, shift, l)
+    ref = F.layer_norm(x.float().view(b, l, c), (c,), eps=1e-6) * (1 + scale.float()[:, None]) + shift.float()[:, None]
+    assert out.dtype == BF
+    close(out.view(b, l, c), ref, 1e-2, 1e-2, "bf16 layernorm_mod")
+    b, l, h, row_off, d = 2, 100, 2, 40, 128
+    hd, ltot = h * d, row_off + l
+    lpad = -(-ltot // 64) * 64
+    qkv = rnd(b * l, 3 * hd, seed=342).to(BF)
+    qs, ks = (1 + 0.1 * rnd(d, seed=343)).to(BF), (1 + 0.1 * rnd(d, seed=344)).to(BF)
+    ids = torch.zeros(ltot, 3)
+    ids[:, 1], ids[:, 2] = torch.arange(ltot) // 7, torch.arange(ltot) % 7
+    pe = _rope_table(ids, [16, 56, 56], 10000).to(DEV)
+    qo = torch.zeros(b, lpad, hd, dtype=BF, device=DEV)
+    ko, vt = torch.zeros_like(qo), torch.zeros(hd, b * lpad, dtype=BF, device=DEV)
+    ops.flux_qk_norm_rope(qkv, qs, ks, pe, qo, ko, vt, batch=b, tokens=l, heads=h, head_dim=d, row_off=row_off, l_pad=lpad)
+    q, k, v = qkv.float().view(b, l, 3, h, d).permute(2, 0, 1, 3, 4)
+    rms = lambda t, s: t * torch.rsqrt((t * t).mean(-1, keepdim=True) + 1e-6) * s.float()
+
+    def rot(t):
+        cs = pe[row_off:row_off + l].float()[None, :, None]
+        tp = t.reshape(b, l, h, d // 2, 2)
+        return torch.stack([cs[..., 0] * tp[..., 0] - cs[..., 1] * tp[..., 1], cs[..., 1] * tp[..., 0] + cs[..., 0] * tp[..., 1]], -1).reshape(b, l, h, d)
+    close(qo[:, row_off:ltot].view(b, l, h, d), rot(rms(q, qs)), 1e-2, 1e-2, "bf16 q norm+rope")
+    close(ko[:, row_off:ltot].view(b, l, h, d), rot(rms(k, ks)), 1e-2, 1e-2, "bf16 k norm+rope")
+    torch.testing.assert_close(vt.view(h, d, b, lpad)[:, :, :, row_off:ltot].permute(2, 3, 0, 1).float(), v, rtol=0, atol=0)
+
+
+def test_bf16_flux_forward_and_sampling_vs_reference_fixture():
+    """The Flux executor with dtype=bfloat16 against the fp32 reference fixture (forward and the 4-step Euler run)."""
+    g = load_golden("tiny_flux_fwd.pt")
+    cfg = synth.TINY_FLUX_CONFIG
+    net = IntegratedFluxTransformer2DModel(cfg, synth.synth_flux_state_dict(cfg, seed=2), device=DEV, dtype=BF)
+    assert net.w["img_in"][0].dtype == BF and net.computation_dtype == BF
+    out = net.forward(g["x"].to(DEV), g["t"].to(DEV), g["ctx"].to(DEV), g["y"].to(DEV), g["guidance"].to(DEV))
+    v = max_rel(out, g["out"])
+    print(f"[parity] tiny flux forward, bf16 build vs reference (fp32): max_rel={v:.3e} (tol 2e-02)")
+    assert v < 2e-2
+    h, w = g["hw"]
+    eng = build_flux_engine(cfg, synth.synth_flux_state_dict(cfg, seed=2), width=w * 8, height=h * 8, device=DEV, dtype=BF)
+    cond = DictWithShape({"crossattn": g["ctx"].to(DEV), "vector": g["y"].to(DEV), "guidance": g["guidance"].to(DEV)})
+    p = processing.StableDiffusionProcessingTxt2Img(sd_model=eng, c=cond, uc=cond, seed=0, sampler_name="Euler", scheduler="simple",
+                                                    batch_size=2, steps=4, cfg_scale=1.0, width=w * 8, height=h * 8, do_decode=False)
+
+    class FixedNoise:
+        def next(self_inner):
+            return g["noise"].to(DEV)
+    import forge_amd.modules.rng as rng_mod
+    orig = rng_mod.ImageRNG
+    rng_mod.ImageRNG = lambda *a, **k: FixedNoise()
+    try:
+        res = processing.process_images(p)
+    finally:
+        rng_mod.ImageRNG = orig
+    v = max_rel(res.latents, g["latent"])
+    print(f"[parity] tiny flux 4-step Euler, bf16 build vs reference (fp32): max_rel={v:.3e} (tol 2e-02)")
+    assert v < 2e-2
