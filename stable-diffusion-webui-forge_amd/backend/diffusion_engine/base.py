@@ -126,17 +126,25 @@ class FluxEngine:
     16-channel VAE (decode_first_stage / encode_first_stage as flux.py:107-120); the T5 / CLIP text encoders are not built -- conditioning
     tensors are supplied."""
 
-    def __init__(self, transformer, seq_len, vae=None):
+    def __init__(self, transformer, seq_len=4096, vae=None, schnell=None):
+        """The predictor is chosen as flux.py:36-47 does: Flux-schnell gets mu = 1.0; everything else the time shift of a 4096-token image
+        (mu = 1.15) -- a CONSTANT in the reference, whatever the resolution (its k_prediction.py:293 leaves binding the latent size to the
+        sigmas as a TODO); `seq_len` is the hook for callers that want that binding.  The reference tells schnell from the repository name;
+        here it is the model without a guidance embedding (the architectural difference between the two)."""
         from ..modules.k_model import KModelFlux
         from ..modules.k_prediction import PredictionFlux
         from ..patcher.unet import UnetPatcher
-        patcher = UnetPatcher(KModelFlux(transformer, PredictionFlux(seq_len=seq_len)), transformer.device, transformer.device)
+        if schnell is None:
+            schnell = not transformer.guidance_embed
+        predictor = PredictionFlux(mu=1.0) if schnell else PredictionFlux(seq_len=seq_len, base_seq_len=256, max_seq_len=4096, base_shift=0.5,
+                                                                         max_shift=1.15)
+        patcher = UnetPatcher(KModelFlux(transformer, predictor), transformer.device, transformer.device)
         self.forge_objects = ForgeObjects(unet=patcher, clip=None, vae=VAE(vae) if vae is not None else None)
         self.forge_objects_original = self.forge_objects.shallow_copy()
         self.forge_objects_after_applying_lora = self.forge_objects.shallow_copy()
         self.is_sdxl = self.is_sd1 = self.is_inpaint = False
         self.is_flux = True
-        self.use_distilled_cfg_scale = True
+        self.use_distilled_cfg_scale = not schnell   # flux.py:47
         self.latent_channels = transformer.in_channels // 4
         self.device = transformer.device
 
@@ -144,8 +152,8 @@ class FluxEngine:
     encode_first_stage = ForgeDiffusionEngine.encode_first_stage
 
 
-def build_flux_engine(flux_config, state_dict, width, height, device="cuda", vae_config=None, vae_state_dict=None, dtype=torch.float16):
+def build_flux_engine(flux_config, state_dict, device="cuda", vae_config=None, vae_state_dict=None, dtype=torch.float16, seq_len=4096, schnell=None):
     from ..nn.flux import IntegratedFluxTransformer2DModel
     net = IntegratedFluxTransformer2DModel(flux_config, state_dict, device=device, dtype=dtype)
     vae = IntegratedAutoencoderKL(vae_config, vae_state_dict, device=device) if vae_config is not None else None
-    return FluxEngine(net, seq_len=(height // 16) * (width // 16), vae=vae)
+    return FluxEngine(net, seq_len=seq_len, vae=vae, schnell=schnell)

@@ -14,8 +14,6 @@ from .diffusion_engine.base import build_engine
 
 UNET_PREFIX = "model.diffusion_model."
 VAE_PREFIX = "first_stage_model."
-SD_VAE_CONFIG = dict(in_channels=3, out_channels=3, block_out_channels=(128, 256, 512, 512), layers_per_block=2, latent_channels=4,
-                     shift_factor=0.0, use_quant_conv=True, use_post_quant_conv=True)
 
 
 def load_torch_file(path, device="cpu"):
@@ -100,15 +98,78 @@ def detect_unet_config(sd, prefix=UNET_PREFIX):
     return cfg
 
 
+def detect_vae_config(vae_sd, **constants):
+    """AutoencoderKL structure from an LDM-keyed VAE state dict (widths per level, ResBlocks per level, latent channels, quant convs); what no
+    tensor carries (scaling / shift factor) comes in as `constants`."""
+    n = _count(vae_sd, "decoder.up.{}.block.0.conv1.weight")
+    return dict(in_channels=vae_sd["encoder.conv_in.weight"].shape[1] if "encoder.conv_in.weight" in vae_sd else 3,
+                out_channels=vae_sd["decoder.conv_out.weight"].shape[0],
+                block_out_channels=tuple(vae_sd[f"decoder.up.{l}.block.0.conv1.weight"].shape[0] for l in range(n)),
+                layers_per_block=_count(vae_sd, "decoder.up.0.block.{}.conv1.weight") - 1, latent_channels=vae_sd["decoder.conv_in.weight"].shape[1],
+                use_quant_conv="quant_conv.weight" in vae_sd, use_post_quant_conv="post_quant_conv.weight" in vae_sd, **constants)
+
+
+def flux_prefix(sd):
+    """-> key prefix of a Flux transformer inside `sd` ('model.diffusion_model.' in full checkpoints, '' in transformer-only files), or None."""
+    for prefix in (UNET_PREFIX, ""):
+        if prefix + "double_blocks.0.img_attn.norm.key_norm.scale" in sd:
+            return prefix
+    return None
+
+
+def detect_flux_config(sd, prefix=UNET_PREFIX):
+    """Flux hyper-parameters.  huggingface_guess (absent here) keys the family on `double_blocks.0.img_attn.norm.key_norm.scale`, counts the
+    double / single blocks, reads `guidance_embed` off the presence of `guidance_in.in_layer.weight` and fills every other field with the
+    Flux.1 constants; here the widths are read off the tensors instead (identical for Flux.1 files, and it keeps reduced-size twins
+    loadable), head_dim is the norm scale's length, and the rotary split / theta -- which no tensor carries -- are Flux.1's."""
+    g = lambda k: sd[prefix + k]  # noqa: E731
+    hidden = g("img_in.weight").shape[0]
+    head_dim = g("double_blocks.0.img_attn.norm.key_norm.scale").shape[0]
+    if head_dim != 128:
+        raise NotImplementedError(f"Flux head_dim {head_dim}: the rotary split [16, 56, 56] is defined for 128")
+    return dict(in_channels=g("img_in.weight").shape[1] // 4, vec_in_dim=g("vector_in.in_layer.weight").shape[1],
+                context_in_dim=g("txt_in.weight").shape[1], hidden_size=hidden, mlp_ratio=g("double_blocks.0.img_mlp.0.weight").shape[0] / hidden,
+                num_heads=hidden // head_dim, depth=_count(sd, prefix + "double_blocks.{}.img_attn.qkv.weight"),
+                depth_single_blocks=_count(sd, prefix + "single_blocks.{}.linear1.weight"), axes_dim=[16, 56, 56], theta=10000,
+                qkv_bias=(prefix + "double_blocks.0.img_attn.qkv.bias") in sd, guidance_embed=(prefix + "guidance_in.in_layer.weight") in sd)
+
+
+FLUX_VAE_PREFIXES = ("vae.", VAE_PREFIX)  # Forge's own Flux checkpoints store the VAE under 'vae.', converted LDM ones under 'first_stage_model.'
+
+
+def split_flux_state_dict(sd):
+    """Flux counterpart of split_state_dict: -> ({'transformer', 'vae'}, guess).  The compute type follows the stored tensors as the reference's
+    loader does (bf16 files -> bf16, fp16 files -> fp16; fp32 files run in bf16, the reference's first choice for Flux); quantised storage
+    (fp8 / nf4 / gguf) is outside the native path."""
+    prefix = flux_prefix(sd)
+    tr = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix) and not k.startswith(FLUX_VAE_PREFIXES + ("text_encoders.",))}
+    vae = {}
+    from .misc.diffusers_state_dict import vae_from_diffusers
+    for vp in FLUX_VAE_PREFIXES:
+        vae = {k[len(vp):]: v for k, v in sd.items() if k.startswith(vp)}
+        if vae:
+            vae = vae_from_diffusers(vae)
+            break
+    stored = tr["img_in.weight"].dtype
+    if stored not in (torch.float16, torch.bfloat16, torch.float32):
+        raise NotImplementedError(f"Flux checkpoint stored as {stored}: quantised formats are not on the native path")
+    guess = {"flux_config": detect_flux_config(sd, prefix), "vae_config": detect_vae_config(vae, scaling_factor=0.3611, shift_factor=0.1159) if vae else None, "is_flux": True,
+             "dtype": torch.float16 if stored == torch.float16 else torch.bfloat16,
+             "ignored": sorted({k.split(".")[0] for k in sd if not k.startswith((prefix,) + FLUX_VAE_PREFIXES)} if prefix else set())}
+    return {"transformer": tr, "vae": vae}, guess
+
+
 def split_state_dict(sd):
     """loader.py:449-486 without the text encoders: -> ({'unet': ..., 'vae': ...}, guess dict)."""
     sd = preprocess_state_dict(load_torch_file(sd))
     unet = {k[len(UNET_PREFIX):]: v for k, v in sd.items() if k.startswith(UNET_PREFIX)}
     vae = {k[len(VAE_PREFIX):]: v for k, v in sd.items() if k.startswith(VAE_PREFIX)}
     vae = {k: v for k, v in vae.items() if not k.startswith(("loss.", "model_ema."))}
+    from .misc.diffusers_state_dict import vae_from_diffusers
+    vae = vae_from_diffusers(vae)   # loader.py:58-59
     unet_config = detect_unet_config(sd)
     is_sdxl = unet_config.get("adm_in_channels") is not None
-    vae_config = dict(SD_VAE_CONFIG, scaling_factor=0.13025 if is_sdxl else 0.18215) if vae else None
+    vae_config = detect_vae_config(vae, scaling_factor=0.13025 if is_sdxl else 0.18215, shift_factor=0.0) if vae else None
     # the prediction type is not in the tensor shapes: checkpoints mark it with a 'v_pred' key (and 'ztsnr' for a zero-terminal-SNR schedule,
     # loader.py:462); a yaml next to the file or the caller decides otherwise (loader.py:543-567) -> forge_loader(prediction_type=...)
     pred = "v_prediction" if "v_pred" in sd else "epsilon"
@@ -122,6 +183,16 @@ def forge_loader(sd, loras=None, device="cuda", prediction_type=None):
     """checkpoint path / state dict (+ optional [(lora_sd, strength)]) -> ForgeDiffusionEngine on the native executors.
     prediction_type: 'epsilon' | 'v_prediction' | 'edm' to override what the checkpoint's marker keys say (SD2.x-768, v-pred SDXL finetunes)."""
     from .patcher.lora import merge_loras_into_state_dict
+    sd = load_torch_file(sd)
+    if flux_prefix(sd) is not None:
+        if loras:
+            raise NotImplementedError("LoRA merging is built for the LDM UNet key maps, not for Flux")
+        from .diffusion_engine.base import build_flux_engine
+        parts, guess = split_flux_state_dict(sd)
+        engine = build_flux_engine(guess["flux_config"], parts["transformer"], device=device, vae_config=guess["vae_config"],
+                                   vae_state_dict=parts["vae"] or None, dtype=guess["dtype"])
+        engine.model_guess = guess
+        return engine
     parts, guess = split_state_dict(sd)
     if prediction_type is not None:
         guess["prediction_type"] = prediction_type

@@ -91,3 +91,44 @@ def unet_to_diffusers(unet_config):
     for dk, lk in _BASIC.items():
         put(dk, lk)
     return out
+
+
+def vae_from_diffusers(sd):
+    """diffusers `AutoencoderKL` parameter names -> the LDM names the native VAE loads (the reference calls
+    huggingface_guess.diffusers_convert.convert_vae_state_dict for this, backend/loader.py:58-59; that package is not vendored, the mapping
+    is the published one of diffusers' own conversion script):
+      {en,de}coder.{down,up}_blocks.i.resnets.j -> encoder.down.i.block.j / decoder.up.(n-1-i).block.j   (the decoder counts levels backwards)
+      downsamplers.0.conv -> downsample.conv, upsamplers.0.conv -> upsample.conv, mid_block.resnets.j -> mid.block_(j+1),
+      mid_block.attentions.0.{group_norm, to_q, to_k, to_v, to_out.0} -> mid.attn_1.{norm, q, k, v, proj_out} (Linear [C, C] -> 1x1 conv),
+      conv_shortcut -> nin_shortcut, conv_norm_out -> norm_out.
+    A dict that is already LDM-keyed is returned unchanged."""
+    import re
+    if not any(".up_blocks." in k or ".down_blocks." in k or ".mid_block." in k for k in sd):
+        return sd
+    n_up = 1 + max(int(m.group(1)) for m in (re.match(r"decoder\.up_blocks\.(\d+)\.", k) for k in sd) if m)
+    attn = {"group_norm": "norm", "to_q": "q", "to_k": "k", "to_v": "v", "to_out.0": "proj_out",
+            "query": "q", "key": "k", "value": "v", "proj_attn": "proj_out"}   # second row: names of diffusers < 0.15
+    out = {}
+    for k, v in sd.items():
+        m = re.match(r"(encoder|decoder)\.(down_blocks|up_blocks)\.(\d+)\.(resnets\.(\d+)|downsamplers\.0\.conv|upsamplers\.0\.conv)\.(.+)", k)
+        if m:
+            side, kind, i, what, j, rest = m.group(1), m.group(2), int(m.group(3)), m.group(4), m.group(5), m.group(6)
+            level = i if kind == "down_blocks" else n_up - 1 - i
+            stem = f"{side}.{'down' if kind == 'down_blocks' else 'up'}.{level}"
+            if what.startswith("resnets"):
+                k = f"{stem}.block.{j}.{rest}"
+            else:
+                k = f"{stem}.{'downsample' if what.startswith('down') else 'upsample'}.conv.{rest}"
+        else:
+            m = re.match(r"(encoder|decoder)\.mid_block\.resnets\.(\d+)\.(.+)", k)
+            if m:
+                k = f"{m.group(1)}.mid.block_{int(m.group(2)) + 1}.{m.group(3)}"
+            else:
+                m = re.match(r"(encoder|decoder)\.mid_block\.attentions\.0\.(.+)\.(weight|bias)", k)
+                if m:
+                    k = f"{m.group(1)}.mid.attn_1.{attn[m.group(2)]}.{m.group(3)}"
+                    if m.group(3) == "weight" and v.dim() == 2:
+                        v = v.reshape(v.shape[0], v.shape[1], 1, 1)
+        k = k.replace(".conv_shortcut.", ".nin_shortcut.").replace(".conv_norm_out.", ".norm_out.")
+        out[k] = v
+    return out

@@ -120,7 +120,7 @@ def test_flux_euler_sampling_vs_reference_fixture():
     g = load_golden("tiny_flux_fwd.pt")
     cfg = synth.TINY_FLUX_CONFIG
     h, w = g["hw"]
-    eng = build_flux_engine(cfg, synth.synth_flux_state_dict(cfg, seed=2), width=w * 8, height=h * 8, device=DEV)
+    eng = build_flux_engine(cfg, synth.synth_flux_state_dict(cfg, seed=2), device=DEV, seq_len=(h // 2) * (w // 2))
     pred = eng.forge_objects.unet.model.predictor
     torch.testing.assert_close(pred.sigmas, g["sigma_table"], rtol=1e-6, atol=1e-7)
     cond = DictWithShape({"crossattn": g["ctx"].to(DEV), "vector": g["y"].to(DEV), "guidance": g["guidance"].to(DEV)})
@@ -228,7 +228,7 @@ def test_bf16_flux_forward_and_sampling_vs_reference_fixture():
     print(f"[parity] tiny flux forward, bf16 build vs reference (fp32): max_rel={v:.3e} (tol 2e-02)")
     assert v < 2e-2
     h, w = g["hw"]
-    eng = build_flux_engine(cfg, synth.synth_flux_state_dict(cfg, seed=2), width=w * 8, height=h * 8, device=DEV, dtype=BF)
+    eng = build_flux_engine(cfg, synth.synth_flux_state_dict(cfg, seed=2), device=DEV, dtype=BF, seq_len=(h // 2) * (w // 2))
     cond = DictWithShape({"crossattn": g["ctx"].to(DEV), "vector": g["y"].to(DEV), "guidance": g["guidance"].to(DEV)})
     p = processing.StableDiffusionProcessingTxt2Img(sd_model=eng, c=cond, uc=cond, seed=0, sampler_name="Euler", scheduler="simple",
                                                     batch_size=2, steps=4, cfg_scale=1.0, width=w * 8, height=h * 8, do_decode=False)
@@ -246,3 +246,29 @@ def test_bf16_flux_forward_and_sampling_vs_reference_fixture():
     v = max_rel(res.latents, g["latent"])
     print(f"[parity] tiny flux 4-step Euler, bf16 build vs reference (fp32): max_rel={v:.3e} (tol 2e-02)")
     assert v < 2e-2
+
+
+def test_forge_loader_builds_a_flux_engine_from_a_checkpoint():
+    """forge_loader on a Flux checkpoint (prefixed transformer stored in bf16 + a diffusers-keyed 16-channel VAE under 'vae.'): family and
+    configuration detected, compute type bf16 as stored, predictor as backend/diffusion_engine/flux.py:36-47 (constant mu = 1.15 for the
+    guidance-distilled model, mu = 1.0 for schnell), forward identical to the directly built executor, VAE decodes."""
+    from forge_amd.backend import loader
+    from test_loader_lora import _vae_ldm_to_diffusers_names
+    cfg, vcfg = synth.TINY_FLUX_CONFIG, synth.TINY_FLUX_VAE_CONFIG
+    tr = {k: v.to(BF) for k, v in synth.synth_flux_state_dict(cfg, seed=2).items()}
+    ck = {"model.diffusion_model." + k: v for k, v in tr.items()}
+    ck.update({"vae." + k: v for k, v in _vae_ldm_to_diffusers_names(synth.synth_vae_state_dict(vcfg, seed=1), len(vcfg["block_out_channels"])).items()})
+    eng = loader.forge_loader(ck, device=DEV)
+    net = eng.forge_objects.unet.model.diffusion_model
+    assert eng.is_flux and net.dtype == BF and eng.model_guess["flux_config"] == cfg and eng.use_distilled_cfg_scale
+    pred = eng.forge_objects.unet.model.predictor
+    assert abs(pred.mu - 1.15) < 1e-6
+    g = load_golden("tiny_flux_fwd.pt")
+    args = (g["x"].to(DEV), g["t"].to(DEV), g["ctx"].to(DEV), g["y"].to(DEV), g["guidance"].to(DEV))
+    direct = IntegratedFluxTransformer2DModel(cfg, tr, device=DEV, dtype=BF)
+    assert torch.equal(net.forward(*args), direct.forward(*args))
+    img = eng.decode_first_stage(torch.randn(1, 16, 8, 8, device=DEV))
+    up = 2 ** (len(vcfg["block_out_channels"]) - 1)   # the tiny twin has two levels: x2 (the real Flux VAE: four levels, x8)
+    assert tuple(img.shape) == (1, 3, 8 * up, 8 * up) and torch.isfinite(img).all()
+    schnell = loader.forge_loader({k: v for k, v in tr.items() if not k.startswith("guidance_in.")}, device=DEV)
+    assert abs(schnell.forge_objects.unet.model.predictor.mu - 1.0) < 1e-12 and not schnell.use_distilled_cfg_scale and schnell.forge_objects.vae is None

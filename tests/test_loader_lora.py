@@ -136,3 +136,72 @@ def test_control_lora_weight_assembly_matches_the_oracle():
     assert isinstance(obj, pc.ControlLora) and obj.copy().control_weights is cl
     with pytest.raises(ValueError):
         pc.load_controlnet({"foo": torch.zeros(1)})
+
+
+def _vae_ldm_to_diffusers_names(sd, n_levels):
+    """Test-side inverse of vae_from_diffusers, written from the module structure of diffusers' AutoencoderKL (Encoder / Decoder with
+    DownEncoderBlock2D / UpDecoderBlock2D / UNetMidBlock2D + Attention), not from the product's rules."""
+    out = {}
+    for k, v in sd.items():
+        parts = k.split(".")
+        if parts[1] in ("down", "up"):
+            side, level = parts[0], int(parts[2])
+            blk = f"{side}.{'down_blocks' if parts[1] == 'down' else 'up_blocks'}.{level if parts[1] == 'down' else n_levels - 1 - level}"
+            if parts[3] == "block":
+                tail = ".".join(parts[5:]).replace("nin_shortcut", "conv_shortcut")
+                k2 = f"{blk}.resnets.{parts[4]}.{tail}"
+            else:
+                k2 = f"{blk}.{'downsamplers' if parts[3] == 'downsample' else 'upsamplers'}.0.conv.{parts[-1]}"
+        elif parts[1] == "mid" and parts[2].startswith("block_"):
+            k2 = f"{parts[0]}.mid_block.resnets.{int(parts[2][6:]) - 1}." + ".".join(parts[3:])
+        elif parts[1] == "mid":
+            name = {"norm": "group_norm", "q": "to_q", "k": "to_k", "v": "to_v", "proj_out": "to_out.0"}[parts[3]]
+            k2 = f"{parts[0]}.mid_block.attentions.0.{name}.{parts[4]}"
+            if parts[4] == "weight" and v.dim() == 4:
+                v = v.reshape(v.shape[0], v.shape[1])   # diffusers' Attention uses Linear layers
+        elif parts[1] == "norm_out":
+            k2 = f"{parts[0]}.conv_norm_out.{parts[2]}"
+        else:
+            k2 = k
+        out[k2] = v
+    return out
+
+
+def test_vae_keys_from_diffusers_round_trip():
+    from forge_amd.backend.misc.diffusers_state_dict import vae_from_diffusers
+    for cfg in (synth.TINY_VAE_CONFIG, synth.TINY_FLUX_VAE_CONFIG):
+        ldm = synth.synth_vae_state_dict(cfg, seed=1)
+        dif = _vae_ldm_to_diffusers_names(ldm, len(cfg["block_out_channels"]))
+        assert "decoder.up_blocks.0.resnets.0.norm1.weight" in dif and "encoder.mid_block.attentions.0.to_q.weight" in dif   # loader.py:58 marker
+        assert dif["decoder.mid_block.attentions.0.to_out.0.weight"].dim() == 2 and not any(".up." in k or ".down." in k for k in dif)
+        back = vae_from_diffusers(dif)
+        assert set(back) == set(ldm)
+        for k in ldm:
+            assert back[k].shape == ldm[k].shape and torch.equal(back[k], ldm[k]), k
+        assert vae_from_diffusers(ldm) is ldm   # already LDM-keyed: untouched
+
+
+def test_flux_checkpoint_detection_and_split():
+    """loader: Flux transformer recognised by its marker key (with and without the checkpoint prefix), configuration read off the tensors,
+    VAE found under 'vae.' (diffusers names converted), compute type following the stored tensors."""
+    cfg = synth.TINY_FLUX_CONFIG
+    tr = {k: v.to(torch.bfloat16) for k, v in synth.synth_flux_state_dict(cfg, seed=2).items()}
+    vae = synth.synth_vae_state_dict(synth.TINY_FLUX_VAE_CONFIG, seed=1)
+    ck = {"model.diffusion_model." + k: v for k, v in tr.items()}
+    ck.update({"vae." + k: v for k, v in _vae_ldm_to_diffusers_names(vae, len(synth.TINY_FLUX_VAE_CONFIG["block_out_channels"])).items()})
+    ck["text_encoders.clip_l.transformer.text_model.embeddings.position_embedding.weight"] = torch.zeros(77, 8)
+    assert loader.flux_prefix(ck) == "model.diffusion_model." and loader.flux_prefix(tr) == "" and loader.flux_prefix(vae) is None
+    parts, guess = loader.split_flux_state_dict(ck)
+    assert guess["flux_config"] == cfg and guess["dtype"] == torch.bfloat16 and guess["ignored"] == ["text_encoders"]
+    assert set(parts["transformer"]) == set(tr) and set(parts["vae"]) == set(vae)
+    assert guess["vae_config"] == {**synth.TINY_FLUX_VAE_CONFIG, "block_out_channels": tuple(synth.TINY_FLUX_VAE_CONFIG["block_out_channels"])}
+    full = loader.detect_vae_config({k: torch.empty(s, device="meta") for k, s in {**vae_decoder_param_shapes(synth.FLUX_VAE_CONFIG),
+                                                                                  **vae_encoder_param_shapes(synth.FLUX_VAE_CONFIG)}.items()},
+                                    scaling_factor=0.3611, shift_factor=0.1159)
+    assert full == synth.FLUX_VAE_CONFIG
+    parts2, guess2 = loader.split_flux_state_dict({k: v.half() for k, v in tr.items()})     # transformer-only file, fp16
+    assert guess2["flux_config"] == cfg and guess2["dtype"] == torch.float16 and not parts2["vae"] and guess2["vae_config"] is None
+    schnell = {k: v for k, v in tr.items() if not k.startswith("guidance_in.")}
+    assert loader.detect_flux_config(schnell, "")["guidance_embed"] is False
+    with pytest.raises(NotImplementedError):
+        loader.split_flux_state_dict({k: v.to(torch.float8_e4m3fn) for k, v in tr.items()})
