@@ -1240,6 +1240,50 @@ def gen_adapter_light():
     print("adapter_light:", res["layout"], [float(f.std()) for f in res["values_every_4th_channel"]])
 
 
+RNG_VARIATION_CASES = {   # name -> ImageRNG kwargs (modules/rng.py:113-177); latent shape (4, 6, 8), three images
+    "subseed": dict(subseeds=[100, 101], subseed_strength=0.35),                                    # fewer subseeds than images: the rest use 0 (:136)
+    "resize_grow": dict(seed_resize_from_h=32, seed_resize_from_w=48),                              # 4 x 6 noise pasted into the centre of 6 x 8
+    "resize_crop": dict(seed_resize_from_h=80, seed_resize_from_w=48),                              # taller source: cropped rows, pasted columns
+    "both": dict(subseeds=[5, 6, 7], subseed_strength=0.8, seed_resize_from_h=32, seed_resize_from_w=104),
+}
+
+
+def gen_rng_variations():
+    """The reference's ImageRNG (modules/rng.py) with variation seeds and seed resize, for the two device-independent noise sources; two draws
+    each (the second one comes from the per-image generators, re-seeded with eta_noise_seed_delta)."""
+    import importlib.util, sys, types
+    ref_import.load_reference()
+    opts = SimpleNamespace(randn_source="CPU", forge_try_reproduce="None", eta_noise_seed_delta=31337)
+    mods = {"modules": types.ModuleType("modules"), "modules.devices": types.ModuleType("modules.devices"), "modules.shared": types.ModuleType("modules.shared")}
+    mods["modules.devices"].device = mods["modules.devices"].cpu = torch.device("cpu")
+    mods["modules.shared"].opts, mods["modules.shared"].device = opts, torch.device("cpu")
+    saved = {k: sys.modules.get(k) for k in list(mods) + ["modules.rng_philox", "modules.rng"]}
+    try:
+        sys.modules.update(mods)
+        for name in ("rng_philox", "rng"):
+            spec = importlib.util.spec_from_file_location(f"modules.{name}", os.path.join(ref_import.REFERENCE_ROOT, "modules", f"{name}.py"))
+            m = importlib.util.module_from_spec(spec)
+            sys.modules[f"modules.{name}"] = m
+            setattr(mods["modules"], name, m)
+            spec.loader.exec_module(m)
+        mods["modules"].devices, mods["modules"].shared = mods["modules.devices"], mods["modules.shared"]
+        rng_ref = sys.modules["modules.rng"]
+        out = {"shape": (4, 6, 8), "seeds": [7, 8, 9], "eta_noise_seed_delta": 31337}
+        for source in ("CPU", "NV"):
+            opts.randn_source = source
+            for cname, kw in RNG_VARIATION_CASES.items():
+                g = rng_ref.ImageRNG(out["shape"], out["seeds"], **kw)
+                out[(source, cname)] = [g.next().clone(), g.next().clone()]
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    torch.save(out, os.path.join(GOLD, "rng_variations.pt"))
+    print("rng variations:", {k: float(v[0].std()) for k, v in out.items() if isinstance(k, tuple)})
+
+
 TOKENIZE_PROMPTS = [
     "a photo of a cat", "", "a (cat:1.3) and a [dog], ((very)) detailed \\(literal\\)", "first part BREAK second part, (emphasised BREAK third:1.2)",
     "masterpiece, best quality, " + ", ".join(f"tag number {i}" for i in range(40)),                       # > 75 tokens: comma backtracking
@@ -1564,6 +1608,8 @@ def main():
         gen_samples_more("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)
     if a.only in ("", "tokenize"):
         gen_tokenize()
+    if a.only in ("", "rng"):
+        gen_rng_variations()
     if a.only in ("", "t2i"):
         gen_t2i_adapter()
     if a.only in ("", "t2i", "adapterlight"):

@@ -56,16 +56,65 @@ class PhiloxGenerator:
         return out
 
 
+def slerp(val, low, high):
+    """modules/rng.py:100-110, applied by ImageRNG to ONE image's [C, H, W] noise: `dim=1` is therefore the H axis (the function was written
+    for [B, D] batches; the reference's behaviour is what is restated, quirk included)."""
+    low_n = low / torch.norm(low, dim=1, keepdim=True)
+    high_n = high / torch.norm(high, dim=1, keepdim=True)
+    dot = (low_n * high_n).sum(1)
+    if dot.mean() > 0.9995:
+        return low * val + high * (1 - val)
+    omega = torch.acos(dot)
+    so = torch.sin(omega)
+    return (torch.sin((1.0 - val) * omega) / so).unsqueeze(1) * low + (torch.sin(val * omega) / so).unsqueeze(1) * high
+
+
 class ImageRNG:
-    def __init__(self, shape, seeds, source="CPU"):
+    """modules/rng.py:113-177 incl. variation seeds (subseeds + slerp, :133-146) and seed resize (:131, :148-160: the noise of the ORIGINAL
+    size is centred into noise of the new size).  A tensor drawn "with seed s" and no generator (rng.py:13-33) is the first tensor of a fresh
+    generator seeded s; with a generator it is the generator's next tensor."""
+
+    def __init__(self, shape, seeds, source="CPU", subseeds=None, subseed_strength=0.0, seed_resize_from_h=0, seed_resize_from_w=0, eta_noise_seed_delta=0):
         self.shape = tuple(int(s) for s in shape)
-        self.source = source
-        if source == "NV":
-            self.generators = [PhiloxGenerator(s) for s in seeds]
-        else:
-            self.generators = [torch.Generator("cpu").manual_seed(int(s)) for s in seeds]
+        self.source, self.seeds = source, [int(s) for s in seeds]
+        self.subseeds, self.strength = subseeds, subseed_strength
+        self.rh, self.rw, self.delta = seed_resize_from_h, seed_resize_from_w, eta_noise_seed_delta
+        self.generators = [self._gen(s) for s in self.seeds]
+        self.is_first = True
+
+    def _gen(self, seed):
+        return PhiloxGenerator(seed) if self.source == "NV" else torch.Generator("cpu").manual_seed(int(seed))
+
+    def _draw(self, g, shape):
+        return torch.from_numpy(g.randn(shape)) if self.source == "NV" else torch.randn(shape, generator=g)
+
+    def first(self):
+        shape = self.shape
+        nshape = shape if self.rh <= 0 or self.rw <= 0 else (shape[0], int(self.rh) // 8, int(self.rw // 8))
+        xs = []
+        for i, (seed, g) in enumerate(zip(self.seeds, self.generators)):
+            sub = None
+            if self.subseeds is not None and self.strength != 0:
+                sub = self._draw(self._gen(0 if i >= len(self.subseeds) else self.subseeds[i]), nshape)
+            noise = self._draw(self._gen(seed), nshape) if nshape != shape else self._draw(g, shape)
+            if sub is not None:
+                noise = slerp(self.strength, noise, sub)
+            if nshape != shape:
+                x = self._draw(g, shape)
+                dx, dy = (shape[2] - nshape[2]) // 2, (shape[1] - nshape[1]) // 2
+                w = nshape[2] if dx >= 0 else nshape[2] + 2 * dx
+                h = nshape[1] if dy >= 0 else nshape[1] + 2 * dy
+                tx, ty = max(dx, 0), max(dy, 0)
+                dx, dy = max(-dx, 0), max(-dy, 0)
+                x[:, ty:ty + h, tx:tx + w] = noise[:, dy:dy + h, dx:dx + w]
+                noise = x
+            xs.append(noise)
+        if self.delta:
+            self.generators = [self._gen(s + self.delta) for s in self.seeds]
+        return torch.stack(xs)
 
     def next(self):
-        if self.source == "NV":
-            return torch.stack([torch.from_numpy(g.randn(self.shape)) for g in self.generators])
-        return torch.stack([torch.randn(self.shape, generator=g) for g in self.generators])
+        if self.is_first:
+            self.is_first = False
+            return self.first()
+        return torch.stack([self._draw(g, self.shape) for g in self.generators])

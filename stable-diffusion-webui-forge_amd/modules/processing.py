@@ -43,6 +43,10 @@ class StableDiffusionProcessingTxt2Img:
     prompt: Any = None            # or prompt strings (str, or a list of n_iter * batch_size strings): encoded by setup_conds through the
     negative_prompt: Any = ""     #   engine's text encoders (needs attach_text_encoders(..., tokenizer_l=...))
     seed: int = -1
+    subseed: int = -1             # variation seed (processing.py:132-135, rng.py:133-146): noise = slerp(subseed_strength, noise(seed), noise(subseed))
+    subseed_strength: float = 0.0
+    seed_resize_from_h: int = -1  # seed resize (rng.py:131,148-160): the noise of this (pixel) size is centred into the noise of the image size
+    seed_resize_from_w: int = -1
     sampler_name: str = "Euler"
     scheduler: Optional[str] = None
     batch_size: int = 1
@@ -185,7 +189,8 @@ class StableDiffusionProcessingTxt2Img:
             image_conditioning = self.txt2img_image_conditioning(samples)
             ty, tx = self.truncate_y, self.truncate_x
             samples = samples[:, :, ty // 2:samples.shape[2] - (ty + 1) // 2, tx // 2:samples.shape[3] - (tx + 1) // 2].contiguous()
-            self.rng = rng.ImageRNG(tuple(samples.shape[1:]), self.seeds, device=samples.device)
+            self.rng = rng.ImageRNG(tuple(samples.shape[1:]), self.seeds, subseeds=getattr(self, "subseeds", None), subseed_strength=self.subseed_strength,
+                                    seed_resize_from_h=self.seed_resize_from_h, seed_resize_from_w=self.seed_resize_from_w, device=samples.device)   # :1495
             noise = self.rng.next()
             lo = self.iteration * self.batch_size
             hr_c = _slice_cond(self.hr_c, lo, lo + self.batch_size) if self.hr_c is not None else self._first_pass_conds[0]
@@ -280,7 +285,9 @@ def process_images(p) -> Processed:
 def process_images_inner(p) -> Processed:
     seed = int(p.seed) if p.seed is not None and int(p.seed) != -1 else int(np.random.randint(0, 2 ** 31 - 1))
     total = p.batch_size * p.n_iter
-    p.all_seeds = [seed + i for i in range(total)]  # :894 (no subseed strength)
+    p.all_seeds = [seed + (i if p.subseed_strength == 0 else 0) for i in range(total)]  # :894: a variation batch shares ONE seed ...
+    subseed = int(p.subseed) if p.subseed is not None and int(p.subseed) != -1 else int(np.random.randint(0, 2 ** 31 - 1))
+    p.all_subseeds = [subseed + i for i in range(total)]                                 # ... and varies the subseed (:896-899)
     dev = p.sd_model.device
     lc = p.sd_model.forge_objects.vae.latent_channels if p.sd_model.forge_objects.vae is not None else getattr(p.sd_model, "latent_channels", 4)
     images, lat_all, dec_all = [], [], []
@@ -293,7 +300,9 @@ def process_images_inner(p) -> Processed:
         p.iteration = n
         lo, hi = n * p.batch_size, (n + 1) * p.batch_size
         p.seeds = p.all_seeds[lo:hi]
-        p.rng = rng.ImageRNG((lc, p.height // 8, p.width // 8), p.seeds, device=dev)
+        p.subseeds = p.all_subseeds[lo:hi]
+        p.rng = rng.ImageRNG((lc, p.height // 8, p.width // 8), p.seeds, subseeds=p.subseeds, subseed_strength=p.subseed_strength,
+                             seed_resize_from_h=p.seed_resize_from_h, seed_resize_from_w=p.seed_resize_from_w, device=dev)   # :944
         c, uc = _slice_cond(p.c, lo, hi), _slice_cond(p.uc, lo, hi)
         p._first_pass_conds = (c, uc)
         samples = p.sample(conditioning=c, unconditional_conditioning=uc, seeds=p.seeds)

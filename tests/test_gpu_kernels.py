@@ -344,6 +344,28 @@ def test_vae_pack_unpack_and_im2col():
     torch.testing.assert_close(out.reshape(-1, 3), torch.clamp((y[:, :3].float() + 1) / 2, 0, 1))
 
 
+def test_image_rng_variations_on_device():
+    """modules/rng.py ImageRNG with variation seeds / seed resize on the device against the reference's values (made on the CPU): the CPU source's
+    draws are bit-identical but the slerp (norm, acos, sin, a division by sin(omega)) then runs in the device's libm; the Philox source adds the
+    2e-6 of the device Box-Muller per draw.  Tolerances 5e-5 / 2e-4 on N(0, 1) values."""
+    from forge_amd.modules import rng as prod_rng, shared
+    from oracle.make_golden import RNG_VARIATION_CASES
+    from conftest import load_golden
+    g = load_golden("rng_variations.pt")
+    saved = shared.opts.randn_source, shared.opts.eta_noise_seed_delta
+    try:
+        shared.opts.eta_noise_seed_delta = g["eta_noise_seed_delta"]
+        for source, tol in (("CPU", 5e-5), ("NV", 2e-4)):
+            shared.opts.randn_source = source
+            for cname, kw in RNG_VARIATION_CASES.items():
+                r = prod_rng.ImageRNG(g["shape"], g["seeds"], device=DEV, **kw)
+                for want in g[(source, cname)]:
+                    got = r.next()
+                    assert got.is_cuda and float((got.cpu() - want).abs().max()) <= tol, (source, cname)
+    finally:
+        shared.opts.randn_source, shared.opts.eta_noise_seed_delta = saved
+
+
 def test_philox_bit_exact():
     from oracle.rng import philox4x32_10, philox_randn
     n = 4 * 64 * 64

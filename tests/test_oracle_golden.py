@@ -332,3 +332,33 @@ def test_t2i_adapter_restated():
     c, uc = synth.synth_conditioning(2, cfg["context_dim"], None, seed=1234)
     lat = pipeline.txt2img_latents_controlnet(sd, cfg, c, uc, g["seeds"], g["hw"] * 8, g["hw"] * 8, 3, chain)
     assert max_rel(lat, g["euler3"]) < 2e-4
+
+
+def test_image_rng_variation_seeds_and_seed_resize():
+    """oracle/rng.py ImageRNG and the product's modules/rng.py ImageRNG (run here on the CPU: the "CPU" noise source is torch-only host
+    logic) against the reference's modules/rng.py ImageRNG: variation seeds (slerp), seed resize (centre paste / crop), both, and the second
+    draw after the eta_noise_seed_delta re-seed.  Bit-exact for the CPU source; the Philox ("NV") source is checked for the oracle."""
+    from oracle.make_golden import RNG_VARIATION_CASES
+    from oracle.rng import ImageRNG as OracleRNG
+    from forge_amd.modules import rng as prod_rng, shared
+    g = load_golden("rng_variations.pt")
+    for source in ("CPU", "NV"):
+        for cname, kw in RNG_VARIATION_CASES.items():
+            o = OracleRNG(g["shape"], g["seeds"], source, eta_noise_seed_delta=g["eta_noise_seed_delta"], **kw)
+            for want in g[(source, cname)]:
+                got = o.next()
+                if source == "CPU":
+                    assert torch.equal(got, want), (source, cname)
+                else:
+                    torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-6)
+    saved = shared.opts.randn_source, shared.opts.eta_noise_seed_delta
+    shared.opts.randn_source, shared.opts.eta_noise_seed_delta = "CPU", g["eta_noise_seed_delta"]
+    try:
+        for cname, kw in RNG_VARIATION_CASES.items():
+            r = prod_rng.ImageRNG(g["shape"], g["seeds"], device="cpu", **kw)
+            for want in g[("CPU", cname)]:
+                assert torch.equal(r.next(), want), cname
+        plain = prod_rng.ImageRNG(g["shape"], g["seeds"], device="cpu")   # no variation: the per-image generators' first tensors, as before
+        assert torch.equal(plain.next()[1], torch.randn(g["shape"], generator=torch.Generator("cpu").manual_seed(8)))
+    finally:
+        shared.opts.randn_source, shared.opts.eta_noise_seed_delta = saved
