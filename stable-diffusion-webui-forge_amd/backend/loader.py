@@ -1,5 +1,5 @@
 """Single-file checkpoint -> native engine: counterpart of backend/loader.py (`preprocess_state_dict` :442,
-`split_state_dict` :449, `forge_loader` :498) for the SD1.x / SD2.x / SDXL-base LDM layouts.
+`split_state_dict` :449, `forge_loader` :498) for the SD1.x / SD2.x / SDXL-base LDM layouts and Flux.1 (dev / schnell) transformers.
 
 The reference delegates model-family detection to the `huggingface_guess` package (git lllyasviel/huggingface_guess@84826248,
 `launch_utils.py:397-404`; absent here): `guess(sd)` reads the UNet hyper-parameters off the tensor shapes
@@ -7,7 +7,11 @@ The reference delegates model-family detection to the `huggingface_guess` packag
 `detect_unet_config` below restates that published shape-reading algorithm for the LDM UNet; the head layout, which shapes
 cannot reveal, follows the model list (context 768 -> SD1.x: 8 heads; 1024 -> SD2.x, 2048 / 1280 -> SDXL: 64 channels per head).
 The native executor binds LDM parameter names directly, so no key conversion is needed for the UNet or the (LDM-layout) VAE of
-a single-file checkpoint."""
+a single-file checkpoint; a diffusers-keyed VAE goes through `misc.diffusers_state_dict.vae_from_diffusers` (the reference calls
+`huggingface_guess.diffusers_convert.convert_vae_state_dict`, loader.py:58-59).  `detect_flux_config` restates the same package's Flux
+branch.  Parity of these three restatements is UNPINNED against the package itself (it is not in the image): they are anchored on the
+reference's call sites, on its engines' use of the resulting configuration (diffusion_engine/flux.py:36-47) and on round trips through
+the native parameter-shape tables (tests/test_loader_lora.py)."""
 import torch
 
 from .diffusion_engine.base import build_engine
