@@ -34,6 +34,7 @@ from forge_amd import distributed as fdist  # noqa: E402
 from forge_amd import hipops, synth  # noqa: E402
 from forge_amd.backend.diffusion_engine.base import build_engine  # noqa: E402
 from forge_amd.backend.nn.layout import unet_param_shapes, vae_decoder_param_shapes  # noqa: E402
+from forge_amd.backend.nn.unet import IntegratedUNet2DConditionModel  # noqa: E402
 from forge_amd.modules import processing, rng, sd_samplers, shared  # noqa: E402
 from forge_amd.modules.prompt_parser import DictWithShape  # noqa: E402
 
@@ -121,6 +122,7 @@ def main():
     t0 = time.time()
     usd = synth.synth_state_dict_device(unet_param_shapes(ucfg), 0, dev)
     vsd = None if a.no_vae else synth.synth_state_dict_device(vae_decoder_param_shapes(vcfg), 1, dev)
+    IntegratedUNet2DConditionModel.RETAIN_TRUNK_WEIGHTS = False  # no Control-LoRA in this run: do not keep a second copy of the encoder weights
     eng = build_engine(ucfg, usd, None if a.no_vae else vcfg, vsd, device=dev)
     del usd, vsd
     eng.forge_objects.unet.model.use_graph = not a.no_graph

@@ -77,6 +77,7 @@ class ContextCache:
 class IntegratedUNet2DConditionModel:
     encoder_only = False  # cnets/cldm.py's ControlNet re-uses this executor for its trunk (input blocks + middle block)
     TRUNK_PREFIXES = ("input_blocks.", "middle_block.", "time_embed.", "label_emb.")
+    RETAIN_TRUNK_WEIGHTS = True
 
     def __init__(self, config, state_dict, device="cuda", arena_bytes=None):
         self.config = dict(config)
@@ -96,7 +97,8 @@ class IntegratedUNet2DConditionModel:
         # Control-LoRA builds its control model from the UNet's own trunk weights (patcher/controlnet.py:445-453 reads
         # `diffusion_model.state_dict()`); the kernel layouts below are not invertible in general (fused / padded / transposed), so the source
         # tensors of the trunk are kept by reference (no copy) under their LDM keys
-        self._trunk_sd = {k: v for k, v in state_dict.items() if k.startswith(self.TRUNK_PREFIXES)}
+        # (RETAIN_TRUNK_WEIGHTS = False drops them: a throughput run that never attaches a Control-LoRA saves the duplicate)
+        self._trunk_sd = {k: v for k, v in state_dict.items() if k.startswith(self.TRUNK_PREFIXES)} if self.RETAIN_TRUNK_WEIGHTS else None
         self._load(state_dict)
 
     # ------------------------------------------------------------------------------------------------------------
@@ -582,6 +584,8 @@ class IntegratedUNet2DConditionModel:
 
     def state_dict(self):
         """LDM-keyed source tensors of the encoder trunk (the part a ControlNet shares with the UNet); see __init__."""
+        if self._trunk_sd is None:
+            raise RuntimeError("this executor was built with RETAIN_TRUNK_WEIGHTS = False: its source tensors were not kept")
         return dict(self._trunk_sd)
 
     @staticmethod
