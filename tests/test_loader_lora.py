@@ -51,6 +51,7 @@ def test_split_state_dict_single_file_layout():
     assert set(parts["unet"]) == set(unet_param_shapes(cfg))
     assert set(parts["vae"]) == set(vshapes)
     assert guess["is_sdxl"] and guess["vae_config"]["scaling_factor"] == 0.13025 and guess["ignored"] == ["conditioner"]
+    assert guess["vae_config"] == synth.SDXL_VAE_CONFIG      # structure read off the tensors + the family's scaling constant
     assert guess["prediction_type"] == "epsilon" and not guess["ztsnr"]
     sd["v_pred"], sd["ztsnr"] = torch.empty(0, device="meta"), torch.empty(0, device="meta")   # marker keys of v-prediction / zero-terminal-SNR checkpoints
     _, guess_v = loader.split_state_dict(sd)
