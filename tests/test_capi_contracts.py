@@ -1,0 +1,92 @@
+"""Argument contracts of the C-ABI (include/fmx.h): every entry point validates on the HOST before it launches anything, returns
+FMX_E_BADARG (10001) and leaves a message in fmx_last_error().  No GPU is needed to check that -- nothing here gets as far as a launch."""
+import ctypes as C
+
+import pytest
+
+import forge_amd  # noqa: F401
+from forge_amd import _lib
+from forge_amd._lib import AttnArgs, GemmArgs
+
+BADARG, UNSUPPORTED = 10001, 10002
+# entry points whose first act is a HIP runtime call (device query, graph / event objects): not exercised without a device
+RUNTIME = {"fmx_abi_version", "fmx_device_info", "fmx_graph_begin", "fmx_graph_end", "fmx_graph_launch", "fmx_graph_destroy", "fmx_event_create",
+           "fmx_event_record", "fmx_event_elapsed_ms", "fmx_event_destroy"}
+FAKE = 0x7F0000001000  # a 16-byte aligned non-null "device pointer": validation never dereferences it
+
+
+@pytest.fixture(scope="module")
+def lib():
+    try:
+        return _lib.lib()
+    except _lib.FmxError as e:
+        pytest.skip(f"libfmx not built: {e}")
+
+
+def _zero_args(argtypes):
+    out = []
+    for t in argtypes:
+        if t in (C.c_void_p, C.c_char_p) or (hasattr(t, "_type_") and not isinstance(t._type_, str)):
+            out.append(None)
+        elif t in (C.c_float, C.c_double):
+            out.append(0.0)
+        else:
+            out.append(0)
+    return out
+
+
+def test_every_entry_point_rejects_null_pointers_and_zero_sizes(lib):
+    checked = 0
+    for name, argtypes in _lib.SIGNATURES.items():
+        if name in RUNTIME:
+            continue
+        rc = getattr(lib, name)(*_zero_args(argtypes))
+        assert rc == BADARG, (name, rc)
+        assert lib.fmx_last_error().decode().strip(), name
+        checked += 1
+    assert checked >= 40
+
+
+def _gemm(**kw):
+    a = GemmArgs()
+    a.a0 = a.wgt = a.out = a.zero_page = FAKE
+    a.c0, a.c1, a.n, a.h, a.w, a.oh, a.ow, a.kh, a.stride, a.pad, a.nout = 64, 0, 1, 1, 128, 1, 128, 1, 1, 0, 64
+    a.alpha = 1.0
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+@pytest.mark.parametrize("suffix", ["_f16", "_bf16"])
+@pytest.mark.parametrize("kw,msg", [
+    (dict(c0=48), "multiples of 64"),                       # K granule of every GEMM kernel
+    (dict(c1=64), "a1 missing"),                            # second source announced but not given
+    (dict(kh=5), "kh must be 1 or 3"),
+    (dict(act=1, nout=48), "bad act/nout"),                 # GEGLU interleave granule
+    (dict(a0=FAKE + 8), "16-byte aligned"),
+    (dict(a0_stride=68), "multiples of 8"),
+    (dict(nout=0), "bad dims"),
+])
+def test_gemm_contract_violations(lib, suffix, kw, msg):
+    rc = getattr(lib, "fmx_gemm_conv" + suffix)(C.byref(_gemm(**kw)), None)
+    assert rc == BADARG and msg in lib.fmx_last_error().decode()
+
+
+def test_other_contract_violations(lib):
+    err = lambda: lib.fmx_last_error().decode()  # noqa: E731
+    p = C.c_void_p(FAKE)
+    assert lib.fmx_layernorm_f16(p, p, p, p, 4, 4104, 1e-5, None) == BADARG                      # c > 4096
+    assert lib.fmx_layernorm_f16(p, p, p, p, 4, 100, 1e-5, None) == BADARG                       # c % 8
+    assert lib.fmx_layernorm_padded_f16(p, p, p, p, 10, 64, 1e-5, 4, 8, None) == BADARG and "row geometry" in err()   # rows % rows_per_image
+    assert lib.fmx_layernorm_padded_f16(p, p, p, p, 8, 64, 1e-5, 4, 2, None) == BADARG                                # out stride < rows per image
+    assert lib.fmx_flux_qk_norm_rope_f16(p, 384, p, p, p, p, p, p, 1, 8, 1, 64, 0, 64, 1e-6, None) == BADARG and "128" in err()
+    assert lib.fmx_flux_qk_norm_rope_bf16(p, 384, p, p, p, p, p, p, 1, 80, 1, 128, 0, 64, 1e-6, None) == BADARG       # l_pad < row_off + tokens
+    assert lib.fmx_sampler_lincomb(p, p, 9, p, 16, None) == BADARG and "1..8" in err()
+    assert lib.fmx_avgpool2x2_nhwc_f16(p, p, 1, 5, 4, 64, None) == BADARG and "even" in err()
+    assert lib.fmx_act_f16(p, p, 16, 7, None) == BADARG                                          # unknown activation kind
+    a = AttnArgs()
+    a.q = a.k = a.vt = a.o = a.zero_page = FAKE
+    a.batch, a.heads, a.nq, a.nk, a.nk_pad, a.dpad, a.scale = 1, 1, 64, 64, 64, 200, 0.1
+    assert lib.fmx_attention_f16(C.byref(a), None) == UNSUPPORTED                                # head dim the kernels are not built for
+    a.dpad, a.nk_pad = 64, 60
+    assert lib.fmx_attention_f16(C.byref(a), None) == BADARG                                     # key padding granule
