@@ -362,3 +362,33 @@ def test_image_rng_variation_seeds_and_seed_resize():
         assert torch.equal(plain.next()[1], torch.randn(g["shape"], generator=torch.Generator("cpu").manual_seed(8)))
     finally:
         shared.opts.randn_source, shared.opts.eta_noise_seed_delta = saved
+
+
+def test_processing_wires_variation_seeds_into_the_noise():
+    """process_images_inner (processing.py:863-944): with a subseed strength every image of the job shares the seed and the subseed counts up,
+    batch n of n_iter takes its slice, and the ImageRNG it builds draws the reference's values (the sampler is replaced by `rng.next()`)."""
+    from types import SimpleNamespace
+    from forge_amd.modules import processing, shared
+    g = load_golden("rng_variations.pt")
+    c, h, w = g["shape"]
+
+    class NoiseOnly(processing.StableDiffusionProcessingTxt2Img):
+        def sample(self, conditioning, unconditional_conditioning, seeds, subseeds=None, subseed_strength=0.0, prompts=None):
+            return self.rng.next()
+    model = SimpleNamespace(device=torch.device("cpu"), forge_objects=SimpleNamespace(vae=None), latent_channels=c)
+    saved = shared.opts.randn_source, shared.opts.eta_noise_seed_delta, getattr(shared, "sd_model", None)
+    shared.opts.randn_source, shared.opts.eta_noise_seed_delta = "CPU", 0
+    try:
+        p = NoiseOnly(sd_model=model, c=torch.zeros(4, 1, 1), uc=torch.zeros(4, 1, 1), seed=7, subseed=100, subseed_strength=0.35, batch_size=2,
+                      n_iter=2, width=w * 8, height=h * 8, do_decode=False)
+        res = processing.process_images_inner(p)
+        assert p.all_seeds == [7, 7, 7, 7] and p.all_subseeds == [100, 101, 102, 103] and p.subseeds == [102, 103]
+        want = g[("CPU", "subseed")][0][0]   # fixture image 0: seed 7, subseed 100, strength 0.35
+        assert torch.equal(res.latents[0], want)
+        assert not torch.equal(res.latents[1], res.latents[0])   # same seed, next subseed
+        p2 = NoiseOnly(sd_model=model, c=torch.zeros(2, 1, 1), uc=torch.zeros(2, 1, 1), seed=7, batch_size=2, width=w * 8, height=h * 8, do_decode=False)
+        res2 = processing.process_images_inner(p2)
+        assert p2.all_seeds == [7, 8] and torch.equal(res2.latents[1], torch.randn(g["shape"], generator=torch.Generator("cpu").manual_seed(8)))
+    finally:
+        shared.opts.randn_source, shared.opts.eta_noise_seed_delta = saved[0], saved[1]
+        shared.sd_model = saved[2]
