@@ -5,7 +5,7 @@ kohya naming need (`lora_unet_down_blocks_0_attentions_0_transformer_blocks_0_at
 Built from the executor's own flat layout (`layout.unet_layout`) rather than from the config lists: every layer object
 already knows its LDM key, so the diffusers name only needs the (level, index-within-level) bookkeeping of diffusers'
 down_blocks / mid_block / up_blocks.  tests/test_loader_lora.py checks the result against the reference's map."""
-from ..nn.layout import ConvIn, Down, Res, SpatialT, Up, unet_layout, unet_param_shapes
+from ..nn.layout import Down, Res, SpatialT, Up, unet_layout, unet_param_shapes
 
 _RES = {  # LDM ResBlock sub-key -> diffusers ResnetBlock2D sub-key
     "in_layers.0": "norm1", "in_layers.2": "conv1", "emb_layers.1": "time_emb_proj",

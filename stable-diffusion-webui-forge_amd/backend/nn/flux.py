@@ -17,8 +17,6 @@ The rotary table depends only on the latent size and text length: built once on 
 fp16 or bf16 storage / MFMA operands with fp32 accumulation (`dtype`; the reference computes Flux in bf16): the bf16 entry points are the
 same kernels compiled a second time with bfloat16 elements (csrc/fmx_common.hpp).
 """
-import math
-
 import torch
 
 from ... import hipops as ops
