@@ -90,3 +90,16 @@ def test_other_contract_violations(lib):
     assert lib.fmx_attention_f16(C.byref(a), None) == UNSUPPORTED                                # head dim the kernels are not built for
     a.dpad, a.nk_pad = 64, 60
     assert lib.fmx_attention_f16(C.byref(a), None) == BADARG                                     # key padding granule
+
+
+def test_host_tensors_and_mixed_element_types_are_rejected_not_converted():
+    """hipops never falls back to a torch implementation: host tensors, fp32 activations or a mix of fp16 and bf16 operands raise."""
+    import torch
+    from forge_amd import hipops as ops
+    x, w = torch.zeros(64, 64, dtype=torch.float16), torch.zeros(64, 64, dtype=torch.float16)
+    with pytest.raises(TypeError):
+        ops.linear(x, w)                                   # host memory
+    with pytest.raises(TypeError):
+        ops.silu(torch.zeros(8))                           # fp32 on the host
+    with pytest.raises(TypeError):
+        ops.layernorm_mod(x, w.bfloat16(), w, 64)
