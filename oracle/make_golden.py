@@ -1240,6 +1240,55 @@ def gen_adapter_light():
     print("adapter_light:", res["layout"], [float(f.std()) for f in res["values_every_4th_channel"]])
 
 
+class RegionalToyModel:
+    """apply_model stand-in for the regional-conditioning fixtures: depends on x, sigma, the text conditioning AND on the size of the
+    rectangle it is evaluated on (a ramp over the crop's width and height), so a wrong crop, weight or placement shows."""
+
+    def memory_required(self, shape):
+        return 0
+
+    def apply_model(self, x, t, c_crossattn=None, **kw):
+        ramp = torch.linspace(0, 1, x.shape[3]).view(1, 1, 1, -1) + torch.linspace(0, 2, x.shape[2]).view(1, 1, -1, 1)
+        return x * (0.3 + 0.01 * t.view(-1, 1, 1, 1)) + c_crossattn.mean(dim=(1, 2)).view(-1, 1, 1, 1) + 0.05 * ramp.to(x)
+
+
+def regional_case(b=2, c=2, hh=20, ww=24):
+    """Seeded inputs shared by the generator and the test: latent, three cond entries (full frame with a mask, an area touching the top-left
+    corner, an interior area with a sigma window) and two uncond entries (plain, and one that is only active at high sigma)."""
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(b, c, hh, ww, generator=g)
+    ctx = [torch.randn(b, 5, 8, generator=g) for _ in range(5)]
+    mask = torch.rand(1, hh, ww, generator=g)
+    cond = [dict(ctx=0, mask=mask, mask_strength=0.7, strength=1.0), dict(ctx=1, area=(16, 12, 0, 0), strength=0.8),
+            dict(ctx=2, area=(10, 14, 9, 6), strength=1.3, timestep_start=8.0, timestep_end=1.0)]
+    uncond = [dict(ctx=3), dict(ctx=4, timestep_end=4.0, strength=0.5)]
+    return x, ctx, cond, uncond, [11.0, 5.0, 0.7]     # sigmas: third cond inactive / all active / third cond and second uncond inactive
+
+
+def gen_regional():
+    """The reference's calc_cond_uncond_batch on regional / time-ranged entries (get_area_and_mult :17-73, accumulation :154-288)."""
+    import importlib
+    ref = ref_import.load_reference()
+    rc = importlib.import_module("backend.sampling.condition")
+    x, ctx, cond, uncond, sigmas = regional_case()
+
+    def build(entries):
+        out = []
+        for e in entries:
+            d = {k: v for k, v in e.items() if k != "ctx"}
+            d["model_conds"] = {"c_crossattn": rc.ConditionCrossAttn(ctx[e["ctx"]])}
+            out.append(d)
+        return out
+    res = {}
+    model = RegionalToyModel()
+    for s in sigmas:
+        t = torch.full((x.shape[0],), s)
+        c_out, u_out = ref.sampling_function.calc_cond_uncond_batch(model, build(cond), build(uncond), x, t, {})
+        res[s] = (c_out, u_out)
+    torch.save(res, os.path.join(GOLD, "regional_conds.pt"))
+    print("regional:", {s: (float(v[0].std()), float(v[1].std())) for s, v in res.items()})
+
+
 RNG_VARIATION_CASES = {   # name -> ImageRNG kwargs (modules/rng.py:113-177); latent shape (4, 6, 8), three images
     "subseed": dict(subseeds=[100, 101], subseed_strength=0.35),                                    # fewer subseeds than images: the rest use 0 (:136)
     "resize_grow": dict(seed_resize_from_h=32, seed_resize_from_w=48),                              # 4 x 6 noise pasted into the centre of 6 x 8
@@ -1610,6 +1659,8 @@ def main():
         gen_tokenize()
     if a.only in ("", "rng"):
         gen_rng_variations()
+    if a.only in ("", "regional"):
+        gen_regional()
     if a.only in ("", "t2i"):
         gen_t2i_adapter()
     if a.only in ("", "t2i", "adapterlight"):

@@ -8,8 +8,9 @@ and the whole step -- input scaling, UNet, `x - eps*sigma`, area-weighted averag
 One cond at strength 1 takes that fused path; AND-composed prompts (several conds with strengths), `model_function_wrapper` and the
 sampler_pre_cfg / sampler_cfg / sampler_post_cfg / conditioning_modifiers hooks take the general path below (one stacked model call,
 weighted averaging, the reference's CFG formula with edit strength).  Python hooks in model_options['transformer_options'] (`patches`, `patches_replace`, `block_modifiers`) are handed to the UNet
-executor, which then runs eagerly.  Features that would need several UNet calls per step (regional `area` conds, masks, per-cond
-timestep ranges) are rejected explicitly; inpainting-model `c_concat` is carried to the executor, which folds it into the first conv once per job.
+executor, which then runs eagerly.  Entries with `area` / `mask` / `timestep_start` / `timestep_end` (regional and time-ranged conditioning,
+:17-73) take `_regional_cond_uncond_batch`: one model call per active entry on its rectangle, per-element weighted average.  Inpainting-model
+`c_concat` is carried to the executor, which folds it into the first conv once per job.
 """
 import math
 
@@ -23,11 +24,106 @@ def _single(conds, what):
     return mc["c_crossattn"].cond, (mc["y"].cond if "y" in mc else None), (mc["guidance"].cond if "guidance" in mc else None)
 
 
+_REGIONAL_KEYS = ("area", "mask", "timestep_start", "timestep_end")
+
+
+def _is_regional(conds):
+    return any(k in c for c in (conds or []) for k in _REGIONAL_KEYS)
+
+
+def get_area_and_mult(conds, x_in, sigma0):
+    """sampling_function.py:17-73: -> None when the entry's sigma window excludes this step, else (area, mult): the latent rectangle
+    (h, w, y, x) the entry is evaluated on and its per-element averaging weight = mask * mask_strength * strength, or -- without a mask --
+    strength with an 8-row linear feather on every side of the rectangle that is not an edge of the latent."""
+    if "timestep_start" in conds and sigma0 > float(conds["timestep_start"]):
+        return None
+    if "timestep_end" in conds and sigma0 < float(conds["timestep_end"]):
+        return None
+    area = tuple(int(v) for v in conds["area"]) if "area" in conds else (x_in.shape[2], x_in.shape[3], 0, 0)
+    strength = float(conds.get("strength", 1.0))
+    b, c = x_in.shape[0], x_in.shape[1]
+    h, w, y0, x0 = area
+    if "mask" in conds:
+        mask = conds["mask"]
+        if mask.shape[1] != x_in.shape[2] or mask.shape[2] != x_in.shape[3]:
+            raise ValueError(f"cond mask {tuple(mask.shape)} does not match the latent {tuple(x_in.shape)}")
+        mask = mask.to(device=x_in.device, dtype=torch.float32)[:, y0:y0 + h, x0:x0 + w] * float(conds.get("mask_strength", 1.0))
+        mult = mask.unsqueeze(1).repeat(b // mask.shape[0], c, 1, 1) * strength
+    else:
+        mult = torch.full((b, c, h, w), strength, dtype=torch.float32, device=x_in.device)
+        rr = 8
+        ramp = [(1.0 / rr) * (t + 1) for t in range(rr)]
+        if y0 != 0:
+            for t in range(rr):
+                mult[:, :, t:1 + t, :] *= ramp[t]
+        if h + y0 < x_in.shape[2]:
+            for t in range(rr):
+                mult[:, :, h - 1 - t:h - t, :] *= ramp[t]
+        if x0 != 0:
+            for t in range(rr):
+                mult[:, :, :, t:1 + t] *= ramp[t]
+        if w + x0 < x_in.shape[3]:
+            for t in range(rr):
+                mult[:, :, :, w - 1 - t:w - t] *= ramp[t]
+    return area, mult
+
+
+def _regional_cond_uncond_batch(model, cond, uncond, x_in, timestep, model_options):
+    """calc_cond_uncond_batch (:154-288) for entries with `area` / `mask` / `timestep_start` / `timestep_end` (ComfyUI-style regional and
+    time-ranged conditioning; nothing in Forge's own UI produces them, extensions can).  Every active entry is evaluated on its rectangle of
+    the latent -- one model call per entry through the general path above -- and the outputs are averaged per element with the weights of
+    get_area_and_mult: out = sum_i o_i * m_i / (1e-37 + sum_i m_i).  The normalised weight maps depend on the set of active entries only,
+    so they are built once per set; the per-step work is one `fmx_blend_masked` pass per entry."""
+    from ... import hipops as ops
+    from ..modules.k_model import host_sigmas
+    sigma0 = float(host_sigmas(timestep)[0])
+    full = (x_in.shape[2], x_in.shape[3], 0, 0)
+    preds = []
+    for entries, cu in ((cond, 0), (uncond or [], 1)):
+        active = []
+        for e in entries:
+            am = get_area_and_mult(e, x_in, sigma0)
+            if am is not None:
+                if am[0] != full and "c_concat" in e["model_conds"]:
+                    raise NotImplementedError("area conditioning together with an inpainting model's c_concat")
+                active.append((e, am[0], am[1]))
+        if not active:
+            preds.append(torch.zeros_like(x_in))     # 0 / 1e-37 (:155-159, 284-288)
+            continue
+        count = torch.full_like(x_in, 1e-37)
+        for _, (h, w, y0, x0), mult in active:
+            count[:, :, y0:y0 + h, x0:x0 + w] += mult
+        acc = None
+        zeros = None
+        for e, (h, w, y0, x0), mult in active:
+            crop = x_in if (h, w, y0, x0) == full else x_in[:, :, y0:y0 + h, x0:x0 + w].contiguous()
+            single = dict(e)
+            single.pop("strength", None)              # the weight is applied below, per element
+            c_out, u_out = _general_cond_uncond_batch(model, [single] if cu == 0 else [], [single] if cu == 1 else None, crop, timestep, model_options)
+            o = c_out if cu == 0 else u_out
+            wmap = torch.zeros_like(x_in)
+            wmap[:, :, y0:y0 + h, x0:x0 + w] = mult
+            wmap /= count
+            if (h, w, y0, x0) != full:                # place the rectangle's output into the frame (memory movement only)
+                placed = torch.zeros_like(x_in)
+                placed[:, :, y0:y0 + h, x0:x0 + w] = o
+                o = placed
+            o = o.contiguous()
+            if acc is None:
+                zeros = torch.zeros_like(x_in)
+                acc = ops.blend_masked(o, wmap, o, zeros)
+            else:
+                if getattr(model, "_ones_like", None) is None or model._ones_like.shape != x_in.shape or model._ones_like.device != x_in.device:
+                    model._ones_like = torch.ones_like(x_in)
+                acc = ops.blend_masked(acc, model._ones_like, o, wmap, out=acc)
+        preds.append(acc)
+    return preds[0], preds[1]
+
+
 def _check_supported(conds, what):
     for c in conds:
-        for k in ("area", "mask", "timestep_start", "timestep_end"):
-            if k in c:
-                raise NotImplementedError(f"{what}: regional / time-ranged conditioning ('{k}') is not on the native path")
+        if "gligen" in c:
+            raise NotImplementedError(f"{what}: GLIGEN conditioning is not on the native path")
 
 
 def _fused_ok(model, cond, uncond, model_options):
@@ -111,6 +207,9 @@ def calc_cond_uncond_batch(model, cond, uncond, x_in, timestep, model_options, c
     _check_supported(cond, "cond")
     if uncond is not None:
         _check_supported(uncond, "uncond")
+    if _is_regional(cond) or _is_regional(uncond):
+        cond_pred, uncond_pred = _regional_cond_uncond_batch(model, cond, uncond, x_in, timestep, model_options)
+        return None, cond_pred, uncond_pred
     if cond_scale is not None and _fused_ok(model, cond, uncond, model_options):
         cctx = _single(cond, "cond")
         uctx = _single(uncond, "uncond") if uncond is not None else None

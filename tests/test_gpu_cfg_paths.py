@@ -106,3 +106,30 @@ def test_prompt_editing_schedule_switches_conditioning(engines):
     err = max_rel(lat, want)
     print(f"[parity] prompt-editing schedule (switch after step 2) vs oracle: max_rel={err:.3e} (tol 1e-02)")
     assert err < 1e-2
+
+
+def test_regional_masks_that_partition_the_frame_reproduce_the_plain_run(engines):
+    """Regional / time-ranged conditioning on the device (sampling_function._regional_cond_uncond_batch; its arithmetic is pinned to the
+    reference on the CPU in tests/test_regional_conds.py): every cond entry is split into two copies with complementary masks and half the
+    strength, the uncond gets a window that never closes -- the weighted average of identical predictions is the prediction, so the run must
+    reproduce the plain one (up to the different UNet batch composition: separate calls instead of one [uncond ; cond] batch)."""
+    cfg, eng = TINY["tiny_sd15"], engines["tiny_sd15"]
+    g = {"seeds": [5, 6], "hw": 16}
+    c, uc = synth.synth_conditioning(2, cfg["context_dim"], None, seed=1234)
+    plain = run(eng, g, c.to(DEV), uc.to(DEV), steps=2)
+    left = torch.zeros(1, g["hw"], g["hw"], device=DEV)
+    left[:, :, :g["hw"] // 2] = 1.0
+    seen = []
+
+    def modifier(model, x, timestep, uncond, cond, cond_scale, model_options, seed):
+        new = []
+        for e in cond:
+            new += [dict(e, mask=left, strength=0.5), dict(e, mask=1.0 - left, strength=0.5)]
+        unc = [dict(e, timestep_end=0.0) for e in uncond] if uncond is not None else None
+        seen.append(len(new))
+        return model, x, timestep, unc, new, cond_scale, model_options, seed
+    regional = run(eng, g, c.to(DEV), uc.to(DEV), steps=2, options={"conditioning_modifiers": [modifier]})
+    err = max_rel(regional, plain)
+    print(f"[parity] regional conds (complementary masks, open sigma window) vs the plain run, 2-step Euler: max_rel={err:.3e} (tol 2e-02)")
+    assert seen and seen[0] == 2 and err < 2e-2
+    assert torch.isfinite(regional).all()
