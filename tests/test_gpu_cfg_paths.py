@@ -108,6 +108,8 @@ def test_prompt_editing_schedule_switches_conditioning(engines):
     assert err < 1e-2
 
 
+@pytest.mark.xfail(strict=False, reason="written after the round-1 GPU budget was spent: not yet run on hardware (DESIGN.md, end of section 8); "
+                                       "an XPASS here means it can lose this marker")
 def test_regional_masks_that_partition_the_frame_reproduce_the_plain_run(engines):
     """Regional / time-ranged conditioning on the device (sampling_function._regional_cond_uncond_batch; its arithmetic is pinned to the
     reference on the CPU in tests/test_regional_conds.py): every cond entry is split into two copies with complementary masks and half the
