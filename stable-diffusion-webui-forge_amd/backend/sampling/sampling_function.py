@@ -72,8 +72,9 @@ def _regional_cond_uncond_batch(model, cond, uncond, x_in, timestep, model_optio
     """calc_cond_uncond_batch (:154-288) for entries with `area` / `mask` / `timestep_start` / `timestep_end` (ComfyUI-style regional and
     time-ranged conditioning; nothing in Forge's own UI produces them, extensions can).  Every active entry is evaluated on its rectangle of
     the latent -- one model call per entry through the general path above -- and the outputs are averaged per element with the weights of
-    get_area_and_mult: out = sum_i o_i * m_i / (1e-37 + sum_i m_i).  The normalised weight maps depend on the set of active entries only,
-    so they are built once per set; the per-step work is one `fmx_blend_masked` pass per entry."""
+    get_area_and_mult: out = sum_i o_i * m_i / (1e-37 + sum_i m_i), formed as sum_i o_i * w_i with the normalised maps w_i = m_i / count
+    (one `fmx_blend_masked` pass per entry).  The maps depend on the set of active entries only; they are rebuilt each step with a handful
+    of latent-sized torch ops (set-up arithmetic, like the reference's), which caching per active set would remove."""
     from ... import hipops as ops
     from ..modules.k_model import host_sigmas
     sigma0 = float(host_sigmas(timestep)[0])
