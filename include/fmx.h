@@ -26,6 +26,20 @@
  *   fmx_vae_pack_latent / fmx_vae_unpack_image
  *                          process_out backend/nn/vae.py:315 ; clamp((y+1)/2) backend/patcher/vae.py:142
  *   fmx_philox_randn       modules/rng_philox.py:32-102 ("NV" noise source)
+ *   fmx_sampler_lincomb / fmx_sampler_error_norm
+ *                          every other update of k_diffusion/sampling.py, modules/sd_samplers_timesteps_impl.py, uni_pc.py (a linear
+ *                          combination of latent-sized tensors with host-computed coefficients); DPM adaptive's error norm :507-560
+ *   fmx_layernorm_padded_f16  F.layer_norm writing at a padded per-image row stride (ragged token counts, backend/nn/unet.py:183-279)
+ *   fmx_resize_separable_f32  F.interpolate of the hires pass modules/processing.py:1430-1480 (all latent upscale modes)
+ *   fmx_blend_masked       inpaint latent blending modules/sd_samplers_cfg_denoiser.py:178-213 ; regional cond averaging
+ *                          backend/sampling/sampling_function.py:276-288
+ *   fmx_add_control_nchw / fmx_add_scaled_f16
+ *                          ControlNet / T2I-Adapter residual injection backend/nn/unet.py:44-52
+ *   fmx_avgpool2x2_nhwc_f16 / fmx_act_f16
+ *                          T2I-Adapter Downsample + ReLU backend/nn/cnets/t2i_adapter.py:42-62,76-101 ; CLIP quick-GELU / GELU
+ *   fmx_embed_tokens       CLIP token + position embedding (transformers CLIPTextEmbeddings, called from backend/nn/clip.py)
+ *   fmx_vae_sample_posterior  DiagonalGaussianDistribution.sample + process_in backend/nn/vae.py:16-29,312-313
+ *   fmx_*_bf16             the bfloat16 build of the Flux path's kernels (last section)
  */
 #ifndef FMX_H
 #define FMX_H
