@@ -206,3 +206,29 @@ def test_flux_checkpoint_detection_and_split():
     assert loader.detect_flux_config(schnell, "")["guidance_embed"] is False
     with pytest.raises(NotImplementedError):
         loader.split_flux_state_dict({k: v.to(torch.float8_e4m3fn) for k, v in tr.items()})
+
+
+@pytest.mark.skipif(not ref_import.reference_available(), reason="needs /root/reference")
+def test_flux_and_vae_detection_agree_with_the_configuration_files_the_reference_ships():
+    """The reference builds Flux from backend/huggingface/black-forest-labs/FLUX.1-{dev,schnell}/{transformer,vae}/config.json (diffusers field
+    names); what the loader reads off a full-size state dict must describe the same networks."""
+    import json
+    import os
+    from forge_amd.backend.nn.layout import flux_param_shapes
+    root = os.path.join(ref_import.REFERENCE_ROOT, "backend", "huggingface", "black-forest-labs")
+    for repo, guidance in (("FLUX.1-dev", True), ("FLUX.1-schnell", False)):
+        want = json.load(open(os.path.join(root, repo, "transformer", "config.json")))
+        cfg = dict(synth.FLUX_DEV_CONFIG, guidance_embed=guidance)
+        sd = {k: torch.empty(s, device="meta") for k, s in flux_param_shapes(cfg).items()}
+        got = loader.detect_flux_config(sd, "")
+        assert got == cfg
+        assert (got["hidden_size"] // got["num_heads"], got["num_heads"], got["depth"], got["depth_single_blocks"]) == (
+            want["attention_head_dim"], want["num_attention_heads"], want["num_layers"], want["num_single_layers"])
+        assert (got["in_channels"] * 4, got["context_in_dim"], got["vec_in_dim"], got["guidance_embed"]) == (
+            want["in_channels"], want["joint_attention_dim"], want["pooled_projection_dim"], want["guidance_embeds"])
+        vwant = json.load(open(os.path.join(root, repo, "vae", "config.json")))
+        vshapes = {**vae_decoder_param_shapes(synth.FLUX_VAE_CONFIG), **vae_encoder_param_shapes(synth.FLUX_VAE_CONFIG)}
+        vgot = loader.detect_vae_config({k: torch.empty(s, device="meta") for k, s in vshapes.items()}, scaling_factor=0.3611, shift_factor=0.1159)
+        for k in ("block_out_channels", "layers_per_block", "latent_channels", "in_channels", "out_channels", "scaling_factor", "shift_factor",
+                  "use_quant_conv", "use_post_quant_conv"):
+            assert (tuple(vgot[k]) if k == "block_out_channels" else vgot[k]) == (tuple(vwant[k]) if k == "block_out_channels" else vwant[k]), k
