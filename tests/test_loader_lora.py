@@ -232,3 +232,39 @@ def test_flux_and_vae_detection_agree_with_the_configuration_files_the_reference
         for k in ("block_out_channels", "layers_per_block", "latent_channels", "in_channels", "out_channels", "scaling_factor", "shift_factor",
                   "use_quant_conv", "use_post_quant_conv"):
             assert (tuple(vgot[k]) if k == "block_out_channels" else vgot[k]) == (tuple(vwant[k]) if k == "block_out_channels" else vwant[k]), k
+
+
+@pytest.mark.skipif(not ref_import.reference_available(), reason="needs /root/reference")
+@pytest.mark.parametrize("repo,base,override", [
+    ("runwayml/stable-diffusion-v1-5", "SD15_UNET_CONFIG", {}),
+    ("runwayml/stable-diffusion-inpainting", "SD15_UNET_CONFIG", {"in_channels": 9}),
+    ("stabilityai/stable-diffusion-xl-base-1.0", "SDXL_UNET_CONFIG", {}),
+])
+def test_unet_detection_agrees_with_the_configuration_files_the_reference_ships(repo, base, override):
+    """detect_unet_config on a full-size (meta) state dict vs backend/huggingface/<repo>/unet/config.json (diffusers field names: widths per
+    level, ResBlocks per level, transformer depth per level, heads, context / label widths, linear vs conv projections)."""
+    import json
+    import os
+    want = json.load(open(os.path.join(ref_import.REFERENCE_ROOT, "backend", "huggingface", repo, "unet", "config.json")))
+    cfg = dict(getattr(synth, base), **override)
+    got = loader.detect_unet_config(_meta_sd(unet_param_shapes(cfg), loader.UNET_PREFIX))
+    mc = got["model_channels"]
+    widths = [mc * m for m in got["channel_mult"]]
+    assert widths == want["block_out_channels"] and got["in_channels"] == want["in_channels"] and got["out_channels"] == want["out_channels"]
+    nres = got["num_res_blocks"]
+    assert set(nres) == {want["layers_per_block"]} and len(nres) == len(widths)
+    assert got["context_dim"] == want["cross_attention_dim"] and got["use_linear_in_transformer"] == bool(want.get("use_linear_projection", False))
+    assert got.get("adm_in_channels") == want.get("projection_class_embeddings_input_dim")
+    # transformer depth of each level's first ResBlock position (0 where the diffusers block type has no cross-attention)
+    depth_per_level = [got["transformer_depth"][sum(nres[:i])] for i in range(len(widths))]
+    tl = want.get("transformer_layers_per_block", 1)
+    tl = tl if isinstance(tl, list) else [tl] * len(widths)
+    want_depth = [tl[i] if "CrossAttn" in t else 0 for i, t in enumerate(want["down_block_types"])]
+    assert depth_per_level == want_depth
+    # heads: diffusers' (misnamed) attention_head_dim holds the head COUNT per level
+    heads = want["attention_head_dim"]
+    heads = heads if isinstance(heads, list) else [heads] * len(widths)
+    if "num_heads" in got:
+        assert all(h == got["num_heads"] for h in heads)
+    else:
+        assert [w // got["num_head_channels"] for w in widths] == heads
