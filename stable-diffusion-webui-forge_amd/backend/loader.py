@@ -9,9 +9,10 @@ cannot reveal, follows the model list (context 768 -> SD1.x: 8 heads; 1024 -> SD
 The native executor binds LDM parameter names directly, so no key conversion is needed for the UNet or the (LDM-layout) VAE of
 a single-file checkpoint; a diffusers-keyed VAE goes through `misc.diffusers_state_dict.vae_from_diffusers` (the reference calls
 `huggingface_guess.diffusers_convert.convert_vae_state_dict`, loader.py:58-59).  `detect_flux_config` restates the same package's Flux
-branch.  Parity of these three restatements is UNPINNED against the package itself (it is not in the image): they are anchored on the
-reference's call sites, on its engines' use of the resulting configuration (diffusion_engine/flux.py:36-47) and on round trips through
-the native parameter-shape tables (tests/test_loader_lora.py)."""
+branch.  Parity of these restatements is UNPINNED against the package itself (it is not in the image): they are anchored on the reference's
+call sites, on its engines' use of the resulting configuration (diffusion_engine/flux.py:36-47), on the per-family configuration files
+the reference ships under backend/huggingface/ (SD1.5, SD-inpainting, SDXL-base UNets; FLUX.1-dev / -schnell transformers and VAE) and
+on round trips through the native parameter-shape tables (tests/test_loader_lora.py)."""
 import torch
 
 from .diffusion_engine.base import build_engine
