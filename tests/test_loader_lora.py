@@ -268,3 +268,37 @@ def test_unet_detection_agrees_with_the_configuration_files_the_reference_ships(
         assert all(h == got["num_heads"] for h in heads)
     else:
         assert [w // got["num_head_channels"] for w in widths] == heads
+
+
+def _ldm_config_from_diffusers(want):
+    """Test-side mapping diffusers UNet2DConditionModel config -> the LDM constructor arguments (what huggingface_guess's model list encodes)."""
+    widths, lpb = want["block_out_channels"], want["layers_per_block"]
+    mc, n = widths[0], len(widths)
+    tl = want.get("transformer_layers_per_block") or 1
+    tl = tl if isinstance(tl, list) else [tl] * n
+    per_level = [tl[i] if "CrossAttn" in t else 0 for i, t in enumerate(want["down_block_types"])]
+    cfg = dict(in_channels=want["in_channels"], model_channels=mc, out_channels=want["out_channels"], num_res_blocks=[lpb] * n,
+               channel_mult=tuple(w // mc for w in widths), use_spatial_transformer=True,
+               transformer_depth=[d for d in per_level for _ in range(lpb)], transformer_depth_middle=tl[-1],
+               transformer_depth_output=[d for d in per_level for _ in range(lpb + 1)], context_dim=want["cross_attention_dim"],
+               use_linear_in_transformer=bool(want.get("use_linear_projection", False)), num_head_channels=64)
+    if want.get("projection_class_embeddings_input_dim"):
+        cfg.update(adm_in_channels=want["projection_class_embeddings_input_dim"], num_classes="sequential")
+    return cfg
+
+
+@pytest.mark.skipif(not ref_import.reference_available(), reason="needs /root/reference")
+@pytest.mark.parametrize("repo", ["stabilityai/stable-diffusion-2-1", "stabilityai/stable-diffusion-xl-refiner-1.0", "stabilityai/stable-diffusion-xl-base-1.0"])
+def test_unet_detection_round_trips_the_sd2_and_refiner_structures(repo):
+    """SD2.1 (context 1024, linear projections, 64 channels per head, last level without attention) and the SDXL refiner (384-wide, four levels,
+    attention only in the two middle ones, 2560-wide label input): shipped config -> LDM arguments -> parameter shapes -> detection."""
+    import json
+    import os
+    want = json.load(open(os.path.join(ref_import.REFERENCE_ROOT, "backend", "huggingface", repo, "unet", "config.json")))
+    cfg = _ldm_config_from_diffusers(want)
+    got = loader.detect_unet_config(_meta_sd(unet_param_shapes(cfg), loader.UNET_PREFIX))
+    for k, v in cfg.items():
+        assert got[k] == v, (k, got[k], v)
+    assert [w // got["num_head_channels"] for w in want["block_out_channels"]] == want["attention_head_dim"]
+    if "xl-base" in repo:
+        assert {k: got[k] for k in synth.SDXL_UNET_CONFIG} == synth.SDXL_UNET_CONFIG
