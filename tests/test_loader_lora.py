@@ -302,3 +302,29 @@ def test_unet_detection_round_trips_the_sd2_and_refiner_structures(repo):
     assert [w // got["num_head_channels"] for w in want["block_out_channels"]] == want["attention_head_dim"]
     if "xl-base" in repo:
         assert {k: got[k] for k in synth.SDXL_UNET_CONFIG} == synth.SDXL_UNET_CONFIG
+
+
+@pytest.mark.skipif(not ref_import.reference_available(), reason="needs /root/reference")
+def test_family_constants_match_the_shipped_scheduler_and_vae_configs():
+    """The constants no tensor carries -- noise schedule, VAE scaling / shift factors, the Flux time-shift parameters -- against the scheduler and
+    VAE configuration files under backend/huggingface/."""
+    import inspect
+    import json
+    import os
+    from forge_amd.backend.modules.k_prediction import PredictionFlux
+    hub = os.path.join(ref_import.REFERENCE_ROOT, "backend", "huggingface")
+    load = lambda *p: json.load(open(os.path.join(hub, *p)))  # noqa: E731
+    for repo in ("runwayml/stable-diffusion-v1-5", "stabilityai/stable-diffusion-xl-base-1.0"):
+        sch = load(repo, "scheduler", "scheduler_config.json")
+        # diffusers' "scaled_linear" is the LDM "linear" schedule (linspace of sqrt(beta)), k_prediction.py:20-25
+        assert sch["beta_schedule"] == "scaled_linear" and synth.SCHEDULE["beta_schedule"] == "linear"
+        assert (sch["beta_start"], sch["beta_end"], sch["num_train_timesteps"]) == (synth.SCHEDULE["linear_start"], synth.SCHEDULE["linear_end"],
+                                                                                     synth.SCHEDULE["timesteps"])
+    # the SD1.5 file predates the field: AutoencoderKL's default 0.18215 applies (backend/nn/vae.py:278)
+    assert load("runwayml/stable-diffusion-v1-5", "vae", "config.json").get("scaling_factor", 0.18215) == synth.SD15_VAE_CONFIG["scaling_factor"] == 0.18215
+    assert load("stabilityai/stable-diffusion-xl-base-1.0", "vae", "config.json")["scaling_factor"] == synth.SDXL_VAE_CONFIG["scaling_factor"]
+    fl = load("black-forest-labs/FLUX.1-dev", "scheduler", "scheduler_config.json")
+    d = {k: v.default for k, v in inspect.signature(PredictionFlux.__init__).parameters.items() if v.default is not inspect.Parameter.empty}
+    assert (d["base_seq_len"], d["max_seq_len"], d["base_shift"], d["max_shift"]) == (fl["base_image_seq_len"], fl["max_image_seq_len"],
+                                                                                      fl["base_shift"], fl["max_shift"])
+    assert abs(PredictionFlux().mu - fl["max_shift"]) < 1e-12      # the engine's constant 4096-token image sits at the top of the shift range
