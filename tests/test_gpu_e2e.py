@@ -1,10 +1,11 @@
 """GPU (MI355X) end-to-end parity of the native path (C-ABI kernels behind the Forge call surface) against
   (1) committed golden fixtures produced by the REAL reference on CPU fp32 (tests/golden, oracle/make_golden.py), and
   (2) the torch-fp32 oracle (oracle/) run on this box's CPU on the same seeded inputs.
-Tolerance: the north star asks for 1e-3 relative (fp16) on latents.  Errors are reported as max|diff| / max|ref| per
-tensor ("max_rel"); single UNet forward and VAE decode are held to 3e-3, multi-step sampler runs to 1e-2 (random-init
-weights make the sampler a chaotic map: per-step fp16 rounding of ~1e-3 compounds over the steps); the measured values
-are printed so the judge can see the actual margins."""
+Tolerance (tests/parity.py): the north star asks for 1e-3 relative (fp16) per pixel.  Every comparison prints max_rel, the per-pixel
+pp_rel and rms_rel, and is held to max(1e-3, 1.5 x floor) (rms: 1.25 x floor), where the floor is what the REAL reference's own fp16 run
+loses against its own fp32 run on the same fixture (tests/golden/fp16_floor.json, oracle/make_floor.py) -- e.g. 1.8e-3 for one tiny
+UNet forward, 1.2e-3 for the SD1.5 20-step latents, 2.0e-3 ... 5.4e-3 for 6-step runs of the random-init tiny networks (a chaotic map).
+Comparisons against the CPU oracle that have no fixture of their own are bracketed by the floor of the nearest fixture family."""
 import os
 
 import numpy as np
@@ -27,14 +28,7 @@ DEV = "cuda"
 TINY = {"tiny_sd15": synth.TINY_SD15_UNET_CONFIG, "tiny_sdxl": synth.TINY_SDXL_UNET_CONFIG}
 
 
-def max_rel(a, b):
-    a, b = a.detach().float().cpu(), b.detach().float().cpu()
-    return float((a - b).abs().max() / b.abs().max())
-
-
-def report(name, val, tol):
-    print(f"[parity] {name}: max_rel={val:.3e} (tol {tol:.0e})")
-    assert val < tol, f"{name}: {val} >= {tol}"
+from parity import check, max_rel  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -53,7 +47,7 @@ def test_unet_forward_vs_reference_fixture(name, engines):
     net = engines[name].forge_objects.unet.model.diffusion_model
     y = g["y"].to(DEV) if g["y"] is not None else None
     eps = net.forward(g["x"].to(DEV), g["t"].to(DEV), context=g["ctx"].to(DEV), y=y)
-    report(f"{name} unet forward vs reference", max_rel(eps, g["eps"]), 3e-3)
+    check(f"{name} unet forward vs reference", eps, g["eps"], floor=f"{name}_unet_fwd.pt:eps")
 
 
 def test_unet_forward_with_controlnet_residuals(engines):
@@ -66,7 +60,7 @@ def test_unet_forward_with_controlnet_residuals(engines):
     control = synth_control(cfg, fx["x"].shape[0], g["hw"])
     dev_control = {k: [None if t is None else t.to(DEV) for t in v] for k, v in control.items()}
     eps = net.forward(fx["x"].to(DEV), fx["t"].to(DEV), context=fx["ctx"].to(DEV), y=None, control=dev_control)
-    report("tiny_sd15 unet forward with control residuals vs reference", max_rel(eps, g["eps"]), 3e-3)
+    check("tiny_sd15 unet forward with control residuals vs reference", eps, g["eps"], floor="tiny_sd15_unet_ctrl.pt:eps")
     assert all(len(v) == len(control[k]) for k, v in dev_control.items()), "the caller's lists must not be consumed"
     plain = net.forward(fx["x"].to(DEV), fx["t"].to(DEV), context=fx["ctx"].to(DEV), y=None)
     assert max_rel(plain, fx["eps"]) < 3e-3 and max_rel(eps, plain) > 0.1
@@ -76,9 +70,9 @@ def test_vae_decode_vs_reference_fixture(engines):
     g = load_golden("tiny_vae_decode.pt")
     vae = engines["tiny_sd15"].forge_objects.vae.first_stage_model
     out = vae.decode(g["z"].to(DEV))
-    report("tiny vae decode vs reference", max_rel(out, g["decode"]), 3e-3)
+    check("tiny vae decode vs reference", out, g["decode"], floor="tiny_vae_decode.pt:decode")
     dec = engines["tiny_sd15"].decode_first_stage(g["lat"].to(DEV))
-    report("decode_first_stage vs reference", max_rel(dec, g["decode_first_stage"]), 3e-3)
+    check("decode_first_stage vs reference", dec, g["decode_first_stage"], floor="tiny_vae_decode.pt:decode_first_stage")
 
 
 def test_flux_vae_decode_16_channels_vs_reference_fixture():
@@ -86,10 +80,10 @@ def test_flux_vae_decode_16_channels_vs_reference_fixture():
     as the implicit GEMM on the 64-wide zero-padded latent instead of the small-channel im2col."""
     g, cfg = load_golden("tiny_flux_vae_decode.pt"), synth.TINY_FLUX_VAE_CONFIG
     vae = IntegratedAutoencoderKL(cfg, synth.synth_vae_decoder_state_dict(cfg, seed=1), device=DEV)
-    report("16-channel vae decode vs reference", max_rel(vae.decode(g["z"].to(DEV)), g["decode"]), 3e-3)
+    check("16-channel vae decode vs reference", vae.decode(g["z"].to(DEV)), g["decode"], floor="tiny_flux_vae_decode.pt:decode")
     dec = vae.decode(vae.process_out(g["lat"].to(DEV)))
     want = (g["decode_first_stage"] + 1.0) / 2.0   # the fixture holds the clamped [0,1] image mapped back to [-1,1]
-    report("16-channel process_out + decode vs reference", max_rel(torch.clamp((dec + 1.0) / 2.0, 0.0, 1.0), want), 3e-3)
+    check("16-channel process_out + decode vs reference", torch.clamp((dec + 1.0) / 2.0, 0.0, 1.0), want, floor="tiny_flux_vae_decode.pt:decode_first_stage")
 
 
 def test_vae_encode_vs_reference_fixture(engines):
@@ -98,17 +92,17 @@ def test_vae_encode_vs_reference_fixture(engines):
     eng = engines["tiny_sd15"]
     vae = eng.forge_objects.vae.first_stage_model
     mo = vae.encode_moments(g["x"].to(DEV))
-    report("tiny vae encoder moments vs reference", max_rel(mo, g["moments"]), 3e-3)
+    check("tiny vae encoder moments vs reference", mo, g["moments"], floor="tiny_vae_encode.pt:moments")
     smp = vae.encode(g["x"].to(DEV), noise=g["noise"])
-    report("tiny vae posterior sample vs reference", max_rel(smp, g["sample"]), 3e-3)
+    check("tiny vae posterior sample vs reference", smp, g["sample"], floor="tiny_vae_encode.pt:sample")
     torch.manual_seed(123)  # the reference draws the posterior noise with torch.randn on the CPU default generator (vae.py:28)
     lat = eng.encode_first_stage(g["x"].to(DEV))
-    report("encode_first_stage vs reference", max_rel(lat, g["process_in"]), 3e-3)
+    check("encode_first_stage vs reference", lat, g["process_in"], floor="tiny_vae_encode.pt:sample")
     # odd image sizes: the right / bottom zero padding of the Downsample (vae.py:67-70) vs the oracle on CPU
     from oracle.vae import vae_encode_moments
     x = torch.rand(1, 3, 26, 34, generator=torch.Generator("cpu").manual_seed(4)) * 2 - 1
     sd = synth.synth_vae_state_dict(synth.TINY_VAE_CONFIG, seed=1)
-    report("tiny vae encoder (26x34) vs oracle", max_rel(vae.encode_moments(x.to(DEV)), vae_encode_moments(sd, x)), 3e-3)
+    check("tiny vae encoder (26x34) vs oracle", vae.encode_moments(x.to(DEV)), vae_encode_moments(sd, x), floor="tiny_vae_encode.pt:moments")
 
 
 def _conds(cfg, b):
@@ -130,7 +124,7 @@ def test_sampler_vs_reference_fixture(name, sampler, engines):
                                                     width=g["hw"] * 8, height=g["hw"] * 8, do_decode=False)
     res = processing.process_images(p)
     assert res.seeds == g["seeds"]
-    report(f"{name} {sampler} {g[sampler]['steps']} steps vs reference", max_rel(res.latents, g[sampler]["latent"]), 1e-2)
+    check(f"{name} {sampler} {g[sampler]['steps']} steps vs reference", res.latents, g[sampler]["latent"], floor=f"{name}_samples.pt:{sampler}/latent")
 
 
 EXTRA_SAMPLERS = ["Heun", "DPM2", "DPM2 a", "DPM++ 2S a", "LMS", "HeunPP2", "IPNDM", "IPNDM_V", "DEIS", "Restart"]
@@ -149,7 +143,7 @@ def test_extra_sampler_vs_reference_fixture(sampler, engines):
                                                     batch_size=len(g["seeds"]), steps=g[sampler]["steps"], cfg_scale=7.0,
                                                     width=g["hw"] * 8, height=g["hw"] * 8, do_decode=False)
     res = processing.process_images(p)
-    report(f"tiny_sd15 {sampler} {g[sampler]['steps']} steps vs reference", max_rel(res.latents, g[sampler]["latent"]), 1e-2)
+    check(f"tiny_sd15 {sampler} {g[sampler]['steps']} steps vs reference", res.latents, g[sampler]["latent"], floor=f"tiny_sd15_samples_extra.pt:{sampler}/latent")
 
 
 @pytest.mark.parametrize("label,sampler,eta", [("DDIM", "DDIM", None), ("DDIM eta", "DDIM", 0.7), ("DDIM CFG++", "DDIM CFG++", None), ("PLMS", "PLMS", None),
@@ -165,7 +159,7 @@ def test_timestep_lcm_ddpm_samplers_vs_reference_fixture(label, sampler, eta, en
                                                     batch_size=len(g["seeds"]), steps=g[label]["steps"], cfg_scale=7.0, eta=eta,
                                                     width=g["hw"] * 8, height=g["hw"] * 8, do_decode=False)
     res = processing.process_images(p)
-    report(f"tiny_sd15 {label} {g[label]['steps']} steps vs reference", max_rel(res.latents, g[label]["latent"]), 1e-2)
+    check(f"tiny_sd15 {label} {g[label]['steps']} steps vs reference", res.latents, g[label]["latent"], floor=f"tiny_sd15_samples_more.pt:{label}/latent")
 
 
 @pytest.mark.parametrize("steps", [6, 9])
@@ -179,7 +173,7 @@ def test_unipc_vs_reference_fixture(steps, engines):
                                                     batch_size=len(g["seeds"]), steps=steps, cfg_scale=7.0, width=g["hw"] * 8, height=g["hw"] * 8,
                                                     do_decode=False)
     res = processing.process_images(p)
-    report(f"tiny_sd15 UniPC {steps} steps vs reference", max_rel(res.latents, g[steps]["latent"]), 1e-2)
+    check(f"tiny_sd15 UniPC {steps} steps vs reference", res.latents, g[steps]["latent"], floor=f"tiny_sd15_samples_unipc.pt:{steps}/latent")
 
 
 def _run_with_tweaked_sampler(monkeypatch, engine, cfg, g, sampler_name, steps, tweak, scheduler=None, eta=None):
@@ -213,7 +207,7 @@ def test_sde_family_with_injected_noise_vs_reference_fixture(label, steps, engin
     def tweak(smp):
         smp.create_noise_sampler = lambda x, sigmas, p: ListNoiseSampler(nz)
     lat = _run_with_tweaked_sampler(monkeypatch, engines["tiny_sd15"], cfg, g, label, steps, tweak)
-    report(f"tiny_sd15 {label} {steps} steps (injected noise) vs reference", max_rel(lat, g[label]["latent"]), 1e-2)
+    check(f"tiny_sd15 {label} {steps} steps (injected noise) vs reference", lat, g[label]["latent"], floor=f"samplers_sde_dpm.pt:stack/{label}/latent")
 
 
 def test_dpm_fast_and_adaptive_vs_reference_fixture(engines, monkeypatch):
@@ -222,7 +216,7 @@ def test_dpm_fast_and_adaptive_vs_reference_fixture(engines, monkeypatch):
     g = load_golden("samplers_sde_dpm.pt")["stack"]
     cfg = TINY["tiny_sd15"]
     lat = _run_with_tweaked_sampler(monkeypatch, engines["tiny_sd15"], cfg, g, "DPM fast", g["DPM fast"]["n"], lambda smp: None, eta=0.0)  # the fixture ran the reference function at its eta = 0 default
-    report("tiny_sd15 DPM fast 7 evaluations vs reference", max_rel(lat, g["DPM fast"]["latent"]), 1e-2)
+    check("tiny_sd15 DPM fast 7 evaluations vs reference", lat, g["DPM fast"]["latent"], floor="samplers_sde_dpm.pt:stack/DPM fast/latent")
     infos = []
 
     def tweak(smp):
@@ -233,7 +227,7 @@ def test_dpm_fast_and_adaptive_vs_reference_fixture(engines, monkeypatch):
         smp.func = functools.wraps(kd.sample_dpm_adaptive)(fn)
     lat = _run_with_tweaked_sampler(monkeypatch, engines["tiny_sd15"], cfg, g, "DPM adaptive", 20, tweak, eta=0.0)
     assert infos[0] == g["DPM adaptive"]["info"], (infos[0], g["DPM adaptive"]["info"])  # same accept / reject decisions
-    report("tiny_sd15 DPM adaptive (rtol = atol = 0.5) vs reference", max_rel(lat, g["DPM adaptive"]["latent"]), 1e-2)
+    check("tiny_sd15 DPM adaptive (rtol = atol = 0.5) vs reference", lat, g["DPM adaptive"]["latent"], floor="samplers_sde_dpm.pt:stack/DPM adaptive/latent")
 
 
 def test_brownian_path_is_one_consistent_path_per_image():
@@ -288,7 +282,7 @@ def test_prediction_types_vs_reference_fixture(ptype):
     x, mo, sg = k["x"].to(DEV), k["model_output"].to(DEV), k["sigma"].to(DEV)
     eps = mo.permute(0, 2, 3, 1).contiguous().half()
     den = ops.cfg_combine(eps, 4, x, sg, 1, 1.0, prediction_type=ptype, sigma_data=1.0)
-    report(f"calculate_denoised {ptype} (kernel) vs reference", max_rel(den, g[("denoised", ptype)]), 2e-3)  # fp16 model output
+    check(f"calculate_denoised {ptype} (kernel) vs reference", den, g[("denoised", ptype)], tol=1e-3)  # the model output enters as fp16
     cfg = TINY["tiny_sd15"]
     eng = build_engine(cfg, synth.synth_unet_state_dict(cfg, seed=0), None, None, device=DEV)
     pred = Prediction(prediction_type=ptype)
@@ -299,7 +293,8 @@ def test_prediction_types_vs_reference_fixture(ptype):
     c, uc = _conds(cfg, 2)
     p = processing.StableDiffusionProcessingTxt2Img(sd_model=eng, c=c, uc=uc, seed=g["seeds"][0], sampler_name="Euler", batch_size=2, steps=4,
                                                     cfg_scale=7.0, width=g["hw"] * 8, height=g["hw"] * 8, do_decode=False)
-    report(f"tiny_sd15 {ptype} 4-step Euler vs reference", max_rel(processing.process_images(p).latents, g[("euler4", ptype)]), 1e-2)
+    check(f"tiny_sd15 {ptype} 4-step Euler vs reference", processing.process_images(p).latents, g[("euler4", ptype)],
+          floor=f"tiny_sd15_prediction_types.pt:('euler4', '{ptype}')")
 
 
 def test_inpainting_model_c_concat_vs_reference_fixture():
@@ -315,7 +310,7 @@ def test_inpainting_model_c_concat_vs_reference_fixture():
     net = eng.forge_objects.unet.model.diffusion_model
     ic = inpaint_case().to(DEV)
     eps = net.forward(torch.cat([fx["x"].to(DEV), ic], dim=1), fx["t"].to(DEV), context=fx["ctx"].to(DEV), y=None)
-    report("inpainting UNet forward (9 input channels) vs reference", max_rel(eps, g["eps"]), 3e-3)
+    check("inpainting UNet forward (9 input channels) vs reference", eps, g["eps"], floor="tiny_sd15_inpaint_model.pt:eps")
     shared.opts.randn_source = "CPU"
     c, uc = _conds(cfg, 2)
 
@@ -324,7 +319,8 @@ def test_inpainting_model_c_concat_vs_reference_fixture():
             return ic
     p = P(sd_model=eng, c=c, uc=uc, seed=g["seeds"][0], sampler_name="Euler", batch_size=2, steps=3, cfg_scale=7.0, width=g["hw"] * 8,
           height=g["hw"] * 8, do_decode=False)
-    report("inpainting model 3-step Euler (c_concat through sampling_function) vs reference", max_rel(processing.process_images(p).latents, g["euler3"]), 1e-2)
+    check("inpainting model 3-step Euler (c_concat through sampling_function) vs reference", processing.process_images(p).latents, g["euler3"],
+          floor="tiny_sd15_inpaint_model.pt:euler3")
     # the stock builders: txt2img on an inpainting model conditions on [ones | latent of a 0.5-gray image] (processing.py:103-114)
     p2 = processing.StableDiffusionProcessingTxt2Img(sd_model=eng, c=c, uc=uc, seed=1, sampler_name="Euler", batch_size=2, steps=2, cfg_scale=7.0, width=32,
                                                      height=32, do_decode=False)
@@ -357,7 +353,7 @@ def test_unet_forward_ragged_token_counts_vs_oracle(name, hw, engines):
     y = torch.randn(b, cfg["adm_in_channels"], generator=g) if cfg.get("adm_in_channels") else None
     net = engines[name].forge_objects.unet.model.diffusion_model
     eps = net.forward(x.to(DEV), t.to(DEV), context=ctx.to(DEV), y=None if y is None else y.to(DEV))
-    report(f"{name} unet forward at latent {hw[0]}x{hw[1]} (ragged tokens) vs oracle", max_rel(eps, unet_forward(sd, cfg, x, t, ctx, y)), 3e-3)
+    check(f"{name} unet forward at latent {hw[0]}x{hw[1]} (ragged tokens) vs oracle", eps, unet_forward(sd, cfg, x, t, ctx, y), floor=f"{name}_unet_fwd.pt:eps")
 
 
 def test_graph_survives_arena_reallocation():
@@ -443,7 +439,8 @@ def test_hires_fix_latent_pass_vs_oracle(upscaler, hr_sampler, hr_cfg, engines):
     _, _, want = pipeline.hires_latents(sd, cfg, c.cpu(), uc.cpu(), [31, 32], 128, 96, 5, hr_scale=1.5, mode=m["mode"], antialias=m["antialias"],
                                         denoising_strength=0.6, hr_second_pass_steps=4, hr_cfg=hr_cfg, hr_sampler_name=hr_sampler)
     assert tuple(res.latents.shape) == (2, 4, 24, 18)
-    report(f"hires fix ({upscaler or 'Latent'}, {hr_sampler or 'same sampler'}, hr_cfg {hr_cfg}) vs oracle", max_rel(res.latents, want), 1e-2)
+    check(f"hires fix ({upscaler or 'Latent'}, {hr_sampler or 'same sampler'}, hr_cfg {hr_cfg}) vs oracle", res.latents, want,
+          floor=[f"tiny_sd15_img2img.pt:{hr_sampler or 'Euler'}/latent", "tiny_sd15_samples.pt:Euler/latent"])  # a 5-step run feeding a 4-step img2img run
 
 
 @pytest.mark.parametrize("scheduler", ["Uniform", "Karras", "Exponential", "Polyexponential", "SGM Uniform", "KL Optimal", "Align Your Steps",
@@ -465,7 +462,7 @@ def test_scheduler_choice_reaches_the_sampler(scheduler, engines):
     sig = g[(key, steps, False)]
     sd = synth.synth_unet_state_dict(cfg, seed=0)
     want = pipeline.txt2img_latents_on_schedule(sd, cfg, c.cpu(), uc.cpu(), [5, 6], 128, 128, sig, "Euler")
-    report(f"Euler on the {scheduler} schedule vs oracle", max_rel(res.latents, want), 1e-2)
+    check(f"Euler on the {scheduler} schedule vs oracle", res.latents, want, floor="tiny_sd15_samples.pt:Euler/latent")  # 4 of the fixture's 6 steps
 
 
 @pytest.mark.parametrize("sampler", ["Euler", "Euler a", "DPM++ 2M"])
@@ -480,7 +477,7 @@ def test_img2img_vs_reference_fixture(sampler, engines):
                                                     batch_size=len(g["seeds"]), steps=r["steps"], cfg_scale=7.0, width=g["hw"] * 8, height=g["hw"] * 8,
                                                     init_latent=g["init_latent"].clone(), denoising_strength=r["denoising_strength"], do_decode=False)
     res = processing.process_images(p)
-    report(f"tiny_sd15 img2img {sampler} (strength {r['denoising_strength']}) vs reference", max_rel(res.latents, r["latent"]), 1e-2)
+    check(f"tiny_sd15 img2img {sampler} (strength {r['denoising_strength']}) vs reference", res.latents, r["latent"], floor=f"tiny_sd15_img2img.pt:{sampler}/latent")
 
 
 def test_img2img_inpaint_mask_vs_reference_fixture(engines):
@@ -498,7 +495,7 @@ def test_img2img_inpaint_mask_vs_reference_fixture(engines):
                                                     init_latent=g["init_latent"].clone(), denoising_strength=r["denoising_strength"], do_decode=False,
                                                     latent_mask=r["nmask"], mask_noise_source=lambda step, like: mn(step).to(like))
     res = processing.process_images(p)
-    report("tiny_sd15 img2img with latent mask vs reference", max_rel(res.latents, r["latent"]), 1e-2)
+    check("tiny_sd15 img2img with latent mask vs reference", res.latents, r["latent"], floor="tiny_sd15_img2img.pt:Euler_masked/latent")
     keep = (r["mask"] == 1.0)
     assert torch.equal(res.latents.cpu()[keep], g["init_latent"][keep]), "kept region must be the original latent exactly"
 
@@ -519,9 +516,9 @@ def test_img2img_from_images(engines):
     res = processing.process_images(p)
     torch.manual_seed(5)
     init = torch.stack([encode_first_stage(vsd, (img[i:i + 1] * 2 - 1), vcfg["scaling_factor"], 0.0)[0] for i in range(2)])
-    report("init latent (VAE encode of images) vs oracle", max_rel(p.init_latent, init), 3e-3)
+    check("init latent (VAE encode of images) vs oracle", p.init_latent, init, floor="tiny_vae_encode.pt:sample")
     lat, _ = pipeline.img2img_latents(sd, cfg, c.cpu(), uc.cpu(), [41, 42], init, 6, 0.5, sampler_name="Euler")
-    report("img2img from images vs oracle", max_rel(res.latents, lat), 1e-2)
+    check("img2img from images vs oracle", res.latents, lat, floor="tiny_sd15_img2img.pt:Euler/latent")
 
 
 def test_cfg_scale_one_shortcut(engines):
@@ -531,7 +528,7 @@ def test_cfg_scale_one_shortcut(engines):
     p = processing.StableDiffusionProcessingTxt2Img(sd_model=engines["tiny_sd15"], c=c, uc=uc, seed=g["seeds"][0], sampler_name="Euler",
                                                     batch_size=2, steps=3, cfg_scale=1.0, width=128, height=128, do_decode=False)
     res = processing.process_images(p)
-    report("cfg_scale=1 shortcut vs reference", max_rel(res.latents, g["Euler_cfg1"]["latent"]), 1e-2)
+    check("cfg_scale=1 shortcut vs reference", res.latents, g["Euler_cfg1"]["latent"], floor="tiny_sd15_samples.pt:Euler_cfg1/latent")
 
 
 def test_graph_replay_matches_eager(engines):
@@ -559,43 +556,109 @@ def test_txt2img_images_vs_oracle(engines):
     p = processing.StableDiffusionProcessingTxt2Img(sd_model=engines["tiny_sd15"], c=c_cpu.to(DEV), uc=uc_cpu.to(DEV), seed=11,
                                                     sampler_name="Euler a", batch_size=2, steps=4, width=128, height=128)
     res = processing.process_images(p)
-    report("txt2img latents vs oracle", max_rel(res.latents, lat), 1e-2)
-    report("txt2img decoded vs oracle", max_rel(res.decoded, dec), 1e-2)
+    check("txt2img latents vs oracle", res.latents, lat, floor="pipeline:txt2img_eulera4/latent")
+    check("txt2img decoded vs oracle", res.decoded, dec, floor="pipeline:txt2img_eulera4/decoded")
     got = np.stack(res.images).astype(np.int32)
     diff = np.abs(got - img.astype(np.int32))
     print(f"[parity] uint8 images: max diff {diff.max()}, mean {diff.mean():.4f}")
     assert diff.max() <= 3
 
 
-@pytest.mark.skipif(not os.path.exists(os.path.join(GOLDEN, "sd15_config0.pt")), reason="full fixture not generated")
-def test_sd15_full_size_vs_reference_fixture():
+def _have(*names):
+    return all(os.path.exists(os.path.join(GOLDEN, n)) for n in names)
+
+
+@pytest.fixture(scope="module")
+def sd15_engine():
+    cfg = synth.SD15_UNET_CONFIG
+    return build_engine(cfg, synth.synth_unet_state_dict(cfg, seed=0), synth.SD15_VAE_CONFIG,
+                        synth.synth_vae_decoder_state_dict(synth.SD15_VAE_CONFIG, seed=1), device=DEV)
+
+
+@pytest.fixture(scope="module")
+def sdxl_engine():
+    cfg = synth.SDXL_UNET_CONFIG
+    return build_engine(cfg, synth.synth_unet_state_dict(cfg, seed=0), synth.SDXL_VAE_CONFIG,
+                        synth.synth_vae_decoder_state_dict(synth.SDXL_VAE_CONFIG, seed=1), device=DEV)
+
+
+@pytest.mark.skipif(not _have("sd15_config0.pt"), reason="full fixture not generated")
+def test_sd15_full_size_vs_reference_fixture(sd15_engine):
     """BASELINE config 0 at full size: one UNet forward and the 20-step Euler run of the real reference (CPU fp32)."""
     g = load_golden("sd15_config0.pt")
     cfg = synth.SD15_UNET_CONFIG
-    eng = build_engine(cfg, synth.synth_unet_state_dict(cfg, seed=0), synth.SD15_VAE_CONFIG,
-                       synth.synth_vae_decoder_state_dict(synth.SD15_VAE_CONFIG, seed=1), device=DEV)
+    eng = sd15_engine
     net = eng.forge_objects.unet.model.diffusion_model
     eps = net.forward(g["x"].to(DEV), g["t"].to(DEV), context=g["ctx"].to(DEV))
-    report("SD1.5 unet forward (64x64) vs reference", max_rel(eps, g["eps"]), 3e-3)
+    check("SD1.5 unet forward (64x64) vs reference", eps, g["eps"], floor="sd15_config0.pt:eps")
     c, uc = synth.synth_conditioning(1, cfg["context_dim"], None, seed=1234)
     shared.opts.randn_source = "CPU"
     p = processing.StableDiffusionProcessingTxt2Img(sd_model=eng, c=c.to(DEV), uc=uc.to(DEV), seed=g["seed"], sampler_name="Euler",
                                                     batch_size=1, steps=20, cfg_scale=7.0, width=512, height=512)
     res = processing.process_images(p)
-    report("SD1.5 512x512 20-step Euler latents vs reference", max_rel(res.latents, g["latent"]), 2e-2)
+    check("SD1.5 512x512 20-step Euler latents vs reference", res.latents, g["latent"], floor="sd15_config0.pt:latent")
+    # the decoder on the REFERENCE's latent (decoder error alone), then the image the whole job produced
+    vae = eng.forge_objects.vae.first_stage_model
+    from oracle.vae import vae_decode  # CPU fp32 restatement, pinned to the reference decoder (tests/test_oracle_golden.py)
+    want = vae_decode(synth.synth_vae_decoder_state_dict(synth.SD15_VAE_CONFIG, seed=1), g["latent"] / synth.SD15_VAE_CONFIG["scaling_factor"])
+    check("SD1.5 VAE decode 512x512 of the reference latent vs oracle", vae.decode(vae.process_out(g["latent"].to(DEV))), want, floor="sd15_config0.pt:decoded")
     diff = np.abs(res.images[0].astype(np.int32) - g["image_u8"][0].numpy().astype(np.int32))
     print(f"[parity] SD1.5 image uint8: max diff {diff.max()}, mean {diff.mean():.4f}, frac>2: {(diff > 2).mean():.5f}")
-    assert diff.mean() < 1.0
+    assert diff.max() <= 2 and diff.mean() < 0.25
 
 
-@pytest.mark.skipif(not os.path.exists(os.path.join(GOLDEN, "sdxl_full_fwd.pt")), reason="full fixture not generated")
-def test_sdxl_full_size_forward_vs_reference_fixture():
+@pytest.mark.skipif(not _have("sd15_config2.pt"), reason="full fixture not generated")
+def test_sd15_config2_batch4_euler_a_vs_reference_fixture(sd15_engine):
+    """BASELINE config 2 at full size: SD1.5 512x512, batch 4, 20-step Euler a, CFG 7 -- the real reference's run (CPU fp32, 160 UNet
+    sample-forwards, oracle/make_floor.py gen_config2); ancestral noise from the per-image CPU generators, as the reference draws it."""
+    g = load_golden("sd15_config2.pt")
+    cfg = synth.SD15_UNET_CONFIG
+    c, uc = synth.synth_conditioning(4, cfg["context_dim"], None, seed=1234)
+    shared.opts.randn_source = "CPU"
+    p = processing.StableDiffusionProcessingTxt2Img(sd_model=sd15_engine, c=c.to(DEV), uc=uc.to(DEV), seed=g["seeds"][0], sampler_name=g["sampler"],
+                                                    batch_size=4, steps=g["steps"], cfg_scale=7.0, width=512, height=512, do_decode=False)
+    res = processing.process_images(p)
+    assert res.seeds == g["seeds"]
+    check("SD1.5 512x512 batch 4, 20-step Euler a latents vs reference", res.latents, g["latent"], floor="sd15_config2.pt:latent")
+
+
+@pytest.mark.skipif(not _have("sdxl_full_fwd.pt"), reason="full fixture not generated")
+def test_sdxl_full_size_forward_vs_reference_fixture(sdxl_engine):
     """The bench workload's network at full size -- SDXL UNet, 2.57 B parameters, 128x128 latent, 77 x 2048 context + 2816-wide vector -- against
-    one forward of the REAL reference (CPU fp32, 3 minutes; oracle/make_golden.py gen_full_sdxl).  Also through the graph-replayed CFG path."""
+    one forward of the REAL reference (CPU fp32, 3 minutes; oracle/make_golden.py gen_full_sdxl)."""
     from oracle.make_golden import _inputs
     g = load_golden("sdxl_full_fwd.pt")
     cfg = synth.SDXL_UNET_CONFIG
     x, t, ctx, y = _inputs(cfg, 1, 128, seed=g["inputs_seed"])
-    net = IntegratedUNet2DConditionModel(cfg, synth.synth_unet_state_dict(cfg, seed=0), device=DEV)
+    net = sdxl_engine.forge_objects.unet.model.diffusion_model
     eps = net.forward(x.to(DEV), t.to(DEV), context=ctx.to(DEV), y=y.to(DEV))
-    report("SDXL unet forward at full size (128x128 latent) vs reference", max_rel(eps, g["eps"]), 3e-3)
+    check("SDXL unet forward at full size (128x128 latent) vs reference", eps, g["eps"], floor="sdxl_full_fwd.pt:eps")
+
+
+@pytest.mark.skipif(not _have("sdxl_config3.pt"), reason="full fixture not generated")
+def test_sdxl_config3_dpmpp2m_vs_reference_fixture(sdxl_engine):
+    """BASELINE config 3's sampler at full size: SDXL 1024x1024, DPM++ 2M on the Karras schedule, CFG 7, 5 steps of one image (10 sample-forwards
+    of the real reference on CPU fp32 take 25 minutes; oracle/make_floor.py gen_config3)."""
+    g = load_golden("sdxl_config3.pt")
+    cfg = synth.SDXL_UNET_CONFIG
+    c, uc = _conds(cfg, 1)
+    shared.opts.randn_source = "CPU"
+    p = processing.StableDiffusionProcessingTxt2Img(sd_model=sdxl_engine, c=c, uc=uc, seed=g["seeds"][0], sampler_name=g["sampler"], batch_size=1,
+                                                    steps=g["steps"], cfg_scale=7.0, width=1024, height=1024, do_decode=False)
+    res = processing.process_images(p)
+    check(f"SDXL 1024x1024 {g['steps']}-step DPM++ 2M latents vs reference", res.latents, g["latent"], floor="sdxl_config3.pt:latent")
+
+
+@pytest.mark.parametrize("fixture", ["sdxl_vae1024.pt", "sdxl_config3_decode.pt"])
+def test_sdxl_vae_decode_1024_vs_reference_fixture(fixture, sdxl_engine):
+    """The 1024x1024 VAE decode incl. the mid-block attention over 16 384 tokens (backend/nn/vae.py:118-137, attention.py:412-422) against the
+    real reference decoder (CPU fp32).  The fixtures keep every 4th pixel in both directions and one whole 128x128 crop of the 12 MB image."""
+    if not _have(fixture):
+        pytest.skip("full fixture not generated")
+    g = load_golden(fixture)
+    vae = sdxl_engine.forge_objects.vae.first_stage_model
+    dec = vae.decode(vae.process_out(g["latent"].to(DEV)))
+    assert tuple(dec.shape) == (1, 3, 1024, 1024)
+    fl = f"{fixture}:decoded"
+    check(f"SDXL VAE decode 1024x1024 ({fixture}) every 4th pixel vs reference", dec[:, :, ::4, ::4], g["decoded_s4"], floor=fl)
+    check(f"SDXL VAE decode 1024x1024 ({fixture}) centre crop vs reference", dec[:, :, 448:576, 448:576], g["decoded_crop"], floor=fl)
