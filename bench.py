@@ -1,84 +1,136 @@
 #!/usr/bin/env python
 """Headline benchmark: sampler it/s of the txt2img hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W [--config NAME]
 
-Workload (config.workload): SDXL UNet, 1024x1024 (latent 128x128), batch 8 images per GPU, fp16, Euler sampler, CFG 7
-(UNet batch 16 = [uncond ; cond]), random-init weights and synthetic conditioning (no checkpoints / datasets here).
-A "step" is one sampler iteration through the Forge call surface: CFGDenoiser.forward -> sampling_function ->
-KModel (pack, UNet forward, x - eps*sigma, CFG combine) -> sampler update.  W warm-up steps, then EXACTLY K steps timed
-between barrier + torch.cuda.synchronize(); max over ranks; `value` = (N * K) / T = batch-steps per second over the job
-(weak scaling: 8 images per GPU).  ms/image (20 sampler steps + VAE decode) is reported alongside.
+N > 1: one rank per GPU over RCCL.  Either the caller launches the ranks (`python -m torch.distributed.run --nproc-per-node N ... bench.py
+--gpus N`, what the driver does: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment) or, when WORLD_SIZE is not set,
+bench.py re-executes ITSELF under torch.distributed.run with N ranks on 127.0.0.1.  Either way every rank asserts that the process group it
+joined has exactly N members and rank 0 prints the number of ranks an all-reduce actually saw (`ranks_in_collective`); a mismatch is fatal.
+
+Workloads (--config; `config.workload` names the one that ran; BASELINE.json `configs`):
+  sdxl-b8-euler20        (default) SDXL UNet 1024x1024 (latent 128x128), batch 8 / GPU, fp16, Euler, CFG 7 (UNet batch 16) -- the
+                         configuration BASELINE.json's metric is quoted on (SDXL 1024^2 20-step Euler, 1/2/4/8 GPU)
+  sd15-b4-eulera         configs[1]: SD1.5 512x512, batch 4, fp16, Euler a
+  sdxl-b8-dpmpp2m30-vae  configs[2]: SDXL 1024x1024, batch 8, fp16, DPM++ 2M (Karras), 30 nominal steps, VAE decode in ms/image
+  flux-b2-bf16           configs[4] per-GPU shard (16 images / 8 GPUs): Flux-dev DiT 1024x1024 (4096 + 256 tokens), batch 2, bf16, Euler on
+                         the flow schedule, distilled guidance (no CFG batch)
+Random-init weights and synthetic conditioning (no checkpoints / datasets here).  A "step" is one sampler iteration through the Forge
+call surface: CFGDenoiser.forward -> sampling_function -> KModel (pack, network forward, prediction -> denoised, CFG combine) -> sampler
+update.  W warm-up steps, then EXACTLY K steps timed between barrier + torch.cuda.synchronize(); max over ranks; `value` = (N * K) / T =
+batch-steps per second over the job (weak scaling: the per-GPU batch is fixed).  ms/image (nominal steps + VAE decode) is reported alongside.
 
 Extra objects on the JSON line:
-  roofline      dominant kernel (MFMA implicit-GEMM conv/linear, 88 % of the step's FLOPs): algorithmic FLOP of all its
-                launches in one UNet forward / their summed HIP-event time (events recorded on the launch stream), vs the
-                2.5 PFLOP/s dense fp16 MFMA peak.  `attention` carries the same for the fused attention kernel.
-  cpu_baseline  the CPU oracle (oracle/, a restatement of the reference's torch code; kind "port") timed on this box's
-                host cores on a bounded sample: ONE SDXL UNet sample-forward at 128x128 latent (6.76 TFLOP); a step of
-                this workload is 16 such forwards, so it/s = 1 / (16 * t).
+  roofline      dominant kernel (MFMA implicit-GEMM conv/linear, 88 % of the step's FLOPs): algorithmic FLOP of all its launches in one
+                network forward / their summed HIP-event time (events recorded on the launch stream), vs the 2.5 PFLOP/s dense fp16/bf16
+                MFMA peak.  `roofline_attention` carries the same for the fused attention kernel, `roofline_groupnorm` the HBM-side one for
+                GroupNorm(+SiLU) (algorithmic bytes = 1 read + 1 write of the tensor, vs 8 TB/s).
+  cpu_baseline  the CPU oracle (oracle/, a restatement of the reference's torch code pinned to the real reference; kind "port") timed on
+                this box's host cores on a bounded sample: ONE sample-forward of the workload's network (B = 1; Flux: 2 + 2 blocks of the
+                57, extrapolated by block count); a step is 2 * batch (CFG) such forwards.  `reference_on_authoring_box` repeats the figure
+                BASELINE.md measured with the reference's own modules (8 vCPU), for scale.
+
+Test hook (tests/test_bench_launcher.py): `--stub-engine` replaces the workload by a few CPU flops over the gloo backend so that the launcher,
+rank accounting and JSON contract can be exercised at world_size 2 without a GPU; its line says `"data": "stub"` and is not a measurement.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import forge_amd  # noqa: E402
-from forge_amd import distributed as fdist  # noqa: E402
-from forge_amd import hipops, synth  # noqa: E402
-from forge_amd.backend.diffusion_engine.base import build_engine  # noqa: E402
-from forge_amd.backend.nn.layout import unet_param_shapes, vae_decoder_param_shapes  # noqa: E402
-from forge_amd.backend.nn.unet import IntegratedUNet2DConditionModel  # noqa: E402
-from forge_amd.modules import processing, rng, sd_samplers, shared  # noqa: E402
-from forge_amd.modules.prompt_parser import DictWithShape  # noqa: E402
-
-# algorithmic FLOP per UNet sample-forward (FlopCounterMode on the reference modules)
-FLOPS_PER_SAMPLE_FWD = {"sdxl": 6.7612e12, "sd15": 0.8033e12}
-VAE_FLOPS_PER_IMAGE = {1024: 10.4704e12, 512: 2.5145e12}
+# algorithmic FLOP per sample-forward (FlopCounterMode on the reference modules)
+FLOPS_PER_SAMPLE_FWD = {"sdxl": 6.7612e12, "sd15": 0.8033e12, "flux": 69.47e12}
 MFMA_PEAK = 2.5e15
+HBM_PEAK = 8.0e12
+
+CONFIGS = {
+    "sdxl-b8-euler20": dict(model="sdxl", res=1024, batch=8, sampler="Euler", scheduler=None, nominal_steps=20, cfg=7.0, dtype="f16",
+                            baseline="metric config: SDXL 1024^2 20-step Euler"),
+    "sd15-b4-eulera": dict(model="sd15", res=512, batch=4, sampler="Euler a", scheduler=None, nominal_steps=20, cfg=7.0, dtype="f16",
+                           baseline="configs[1]: SD1.5 512x512 batch=4 fp16, 20-step Euler-a"),
+    "sdxl-b8-dpmpp2m30-vae": dict(model="sdxl", res=1024, batch=8, sampler="DPM++ 2M", scheduler=None, nominal_steps=30, cfg=7.0, dtype="f16",
+                                  baseline="configs[2]: SDXL 1024x1024 batch=8 fp16, 30-step DPM++ 2M, VAE decode"),
+    "flux-b2-bf16": dict(model="flux", res=1024, batch=2, sampler="Euler", scheduler="simple", nominal_steps=20, cfg=1.0, dtype="bf16",
+                         baseline="configs[4] per-GPU shard: Flux.1-dev DiT 1024x1024 batch=16 over 8 GPUs, bf16"),
+}
+# reference modules timed on the authoring box (8 vCPU Xeon 2.1 GHz, fp32, torch 2.10): it/s of one UNet step at B = 1 with CFG
+REFERENCE_CPU_AUTHORING_BOX = {"sd15": {"it_per_s_b1_cfg": 0.468, "cores": 8, "source": "BASELINE.md section 2 (reference modules, SD1.5 512^2 B=1 20-step Euler)"}}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--model", default="sdxl", choices=["sdxl", "sd15"])
-    ap.add_argument("--res", type=int, default=0, help="image size (default 1024 for sdxl, 512 for sd15)")
-    ap.add_argument("--batch", type=int, default=0, help="images per GPU (default 8 for sdxl, 4 for sd15)")
-    ap.add_argument("--sampler", default="Euler")
-    ap.add_argument("--cfg", type=float, default=7.0)
+    ap.add_argument("--config", default="sdxl-b8-euler20", choices=sorted(CONFIGS))
+    ap.add_argument("--model", default=None, choices=["sdxl", "sd15", "flux"], help="override the workload's network")
+    ap.add_argument("--res", type=int, default=0, help="override the image size")
+    ap.add_argument("--batch", type=int, default=0, help="override images per GPU")
+    ap.add_argument("--sampler", default=None)
+    ap.add_argument("--cfg", type=float, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-vae", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--breakdown", default="", help="write the per-shape kernel-time table of one UNet forward to this file")
-    return ap.parse_args()
+    ap.add_argument("--breakdown", default="", help="write the per-shape kernel-time table of one network forward to this file")
+    ap.add_argument("--stub-engine", action="store_true", help="launcher self-test without a GPU (gloo, no kernels); not a measurement")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(a):
+    """--gpus N > 1 without a launcher: become `torch.distributed.run --nproc-per-node N bench.py <same flags>` on 127.0.0.1."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this host driver
+    env["FMX_BENCH_SELF_LAUNCHED"] = "1"
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def cpu_baseline(model, cfg, latent):
-    """Oracle timed on host cores (test-infrastructure import allowed for this leg only)."""
-    from oracle.unet import unet_forward
+    """Oracle timed on host cores (test-infrastructure import allowed for this leg only).  -> (seconds per sample-forward, threads, note)"""
+    import torch
+    from forge_amd.backend.nn.layout import unet_param_shapes
     nthreads = torch.get_num_threads()
-    t0 = time.time()
-    sd = {}
     g = torch.Generator().manual_seed(0)
-    for name, shape in unet_param_shapes(cfg).items():
-        sd[name] = torch.empty(shape).normal_(0, 0.02, generator=g)
-    t_init = time.time() - t0
+    if model == "flux":
+        from forge_amd.backend.nn.layout import flux_param_shapes
+        from oracle.flux import flux_forward
+        small = dict(cfg, depth=2, depth_single_blocks=2)
+        sd = {name: torch.empty(shape).normal_(0, 0.02, generator=g) for name, shape in flux_param_shapes(small).items()}
+        h = latent
+        x = torch.randn(1, 16, h, h)
+        ctx = torch.randn(1, 256, cfg["context_in_dim"])
+        y = torch.randn(1, cfg["vec_in_dim"])
+        t1 = time.time()
+        flux_forward(sd, small, x, torch.tensor([0.7]), ctx, y, torch.tensor([3.5]))
+        dt = time.time() - t1
+        scale = (cfg["depth"] * 2 + cfg["depth_single_blocks"]) / (2 * 2 + 2)   # a double block is two streams' worth of a single block
+        return dt * scale, nthreads, (f"Flux-dev at 2 double + 2 single blocks of the {cfg['depth']} + {cfg['depth_single_blocks']} (full width 3072, 4096 + 256 tokens, "
+                                      f"B=1, fp32, torch CPU, {nthreads} threads) took {dt:.1f} s; scaled x{scale:.1f} by block count")
+    from oracle.unet import unet_forward
+    sd = {name: torch.empty(shape).normal_(0, 0.02, generator=g) for name, shape in unet_param_shapes(cfg).items()}
     x = torch.randn(1, cfg["in_channels"], latent, latent)
     ctx = torch.randn(1, 77, cfg["context_dim"])
     y = torch.randn(1, cfg["adm_in_channels"]) if cfg.get("adm_in_channels") else None
     t1 = time.time()
     unet_forward(sd, cfg, x, torch.tensor([500.0]), ctx, y)
     dt = time.time() - t1
-    return dt, nthreads, t_init
+    return dt, nthreads, (f"one {model.upper()} UNet sample-forward (B=1, {latent}x{latent} latent, fp32, torch CPU, {nthreads} threads) took {dt:.1f} s")
 
 
 def pmc_traffic_per_launch():
@@ -101,31 +153,110 @@ def pmc_traffic_per_launch():
         return None
 
 
+def stub_main(a, rank, world):
+    """Launcher self-test: the rank / barrier / max-over-ranks / JSON contract with a trivial CPU 'step' over gloo."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+        assert dist.get_world_size() == a.gpus, f"process group has {dist.get_world_size()} ranks, --gpus asked for {a.gpus}"
+    seen = torch.ones(1)
+    if world > 1:
+        dist.all_reduce(seen)
+
+    def step():
+        return float((torch.ones(64, 64) @ torch.ones(64, 64)).sum())
+    for _ in range(a.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0])
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "sampler it/s (UNet steps/sec)", "value": round(world * a.steps / float(el), 3), "unit": "it/s", "n_gpus": world,
+                          "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(float(el) / a.steps * 1e3, 4), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "stub", "ranks_in_collective": int(seen.item()),
+                          "launcher": "self" if os.environ.get("FMX_BENCH_SELF_LAUNCHED") else "external",
+                          "config": {"workload": "STUB (launcher self-test: no kernels ran, not a measurement)"}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        self_launch(a)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing to report a number for the wrong N")
+    if a.stub_engine:
+        return stub_main(a, rank, world)
+
+    import torch
+    import forge_amd  # noqa: F401
+    from forge_amd import distributed as fdist
+    from forge_amd import hipops, synth
+    from forge_amd.backend.diffusion_engine.base import build_engine, build_flux_engine
+    from forge_amd.backend.nn.layout import flux_param_shapes, unet_param_shapes, vae_decoder_param_shapes
+    from forge_amd.backend.nn.unet import IntegratedUNet2DConditionModel
+    from forge_amd.modules import processing, rng, sd_samplers, shared
+    from forge_amd.modules.prompt_parser import DictWithShape
+
+    if torch.cuda.device_count() <= local:
+        raise SystemExit(f"bench.py: rank {rank} (local {local}) has no GPU: {torch.cuda.device_count()} visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    ranks_seen = 1
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
-    model = a.model
-    res = a.res or (1024 if model == "sdxl" else 512)
-    bpg = a.batch or (8 if model == "sdxl" else 4)
-    ucfg = synth.SDXL_UNET_CONFIG if model == "sdxl" else synth.SD15_UNET_CONFIG
-    vcfg = synth.SDXL_VAE_CONFIG if model == "sdxl" else synth.SD15_VAE_CONFIG
+        dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        assert dist.get_world_size() == a.gpus, f"process group has {dist.get_world_size()} ranks, --gpus asked for {a.gpus}"
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)                              # a real RCCL collective: every rank must have contributed
+        ranks_seen = int(one.item())
+        if ranks_seen != a.gpus:
+            raise SystemExit(f"bench.py: all-reduce saw {ranks_seen} ranks, expected {a.gpus}")
+    wl = dict(CONFIGS[a.config])
+    model = a.model or wl["model"]
+    res = a.res or wl["res"]
+    bpg = a.batch or wl["batch"]
+    sampler_name = a.sampler or wl["sampler"]
+    cfg_scale = wl["cfg"] if a.cfg is None else a.cfg
+    nominal = wl["nominal_steps"]
+    is_flux = model == "flux"
+    dt16 = torch.bfloat16 if (wl["dtype"] == "bf16" and is_flux) else torch.float16
     latent = res // 8
 
     # ---- model: random-init weights drawn on the device ---------------------------------------------------------
     t0 = time.time()
-    usd = synth.synth_state_dict_device(unet_param_shapes(ucfg), 0, dev)
-    vsd = None if a.no_vae else synth.synth_state_dict_device(vae_decoder_param_shapes(vcfg), 1, dev)
-    IntegratedUNet2DConditionModel.RETAIN_TRUNK_WEIGHTS = False  # no Control-LoRA in this run: do not keep a second copy of the encoder weights
-    eng = build_engine(ucfg, usd, None if a.no_vae else vcfg, vsd, device=dev)
-    del usd, vsd
-    eng.forge_objects.unet.model.use_graph = not a.no_graph
+    if is_flux:
+        ucfg = synth.FLUX_DEV_CONFIG
+        vcfg = None
+        a.no_vae = True   # the 16-channel VAE decode is the same decoder kernels; this workload times the transformer
+        sd = synth.synth_state_dict_device(flux_param_shapes(ucfg), 2, dev, dtype=dt16)
+        eng = build_flux_engine(ucfg, sd, device=dev, dtype=dt16, seq_len=(latent // 2) ** 2)
+        del sd
+    else:
+        ucfg = synth.SDXL_UNET_CONFIG if model == "sdxl" else synth.SD15_UNET_CONFIG
+        vcfg = synth.SDXL_VAE_CONFIG if model == "sdxl" else synth.SD15_VAE_CONFIG
+        usd = synth.synth_state_dict_device(unet_param_shapes(ucfg), 0, dev)
+        vsd = None if a.no_vae else synth.synth_state_dict_device(vae_decoder_param_shapes(vcfg), 1, dev)
+        IntegratedUNet2DConditionModel.RETAIN_TRUNK_WEIGHTS = False  # no Control-LoRA in this run: do not keep a second copy of the encoder weights
+        eng = build_engine(ucfg, usd, None if a.no_vae else vcfg, vsd, device=dev)
+        del usd, vsd
+    km = eng.forge_objects.unet.model
+    if not is_flux:
+        km.use_graph = not a.no_graph
     torch.cuda.synchronize()
     t_build = time.time() - t0
 
@@ -133,10 +264,17 @@ def main():
     total = bpg * world
     t0 = time.time()
     if rank == 0:
-        c, uc = synth.synth_conditioning(total, ucfg["context_dim"], ucfg.get("adm_in_channels"), seed=1234)
-        to_dev = lambda t: t.to(dev).half()
-        c = {k: to_dev(v) for k, v in c.items()} if isinstance(c, dict) else to_dev(c)
-        uc = {k: to_dev(v) for k, v in uc.items()} if isinstance(uc, dict) else to_dev(uc)
+        if is_flux:
+            g = torch.Generator().manual_seed(1234)
+            c = {"crossattn": torch.randn(total, 256, ucfg["context_in_dim"], generator=g).to(dev, dt16),
+                 "vector": torch.randn(total, ucfg["vec_in_dim"], generator=g).to(dev, dt16),
+                 "guidance": torch.full((total,), 3.5, device=dev)}
+            uc = {k: v.clone() for k, v in c.items()}
+        else:
+            c, uc = synth.synth_conditioning(total, ucfg["context_dim"], ucfg.get("adm_in_channels"), seed=1234)
+            to_dev = lambda t: t.to(dev).half()
+            c = {k: to_dev(v) for k, v in c.items()} if isinstance(c, dict) else to_dev(c)
+            uc = {k: to_dev(v) for k, v in uc.items()} if isinstance(uc, dict) else to_dev(uc)
     else:
         c = uc = None
     c, uc = fdist.broadcast_conditioning(c, uc, dev)
@@ -149,18 +287,19 @@ def main():
 
     shared.opts.randn_source = "CPU"
     seeds = [1000 + i for i in range(lo, hi)]
+    lat_ch = 16 if is_flux else 4
 
     def make_p(steps):
-        p = processing.StableDiffusionProcessingTxt2Img(sd_model=eng, c=c, uc=uc, seed=seeds[0], sampler_name=a.sampler, batch_size=bpg,
-                                                        steps=steps, cfg_scale=a.cfg, width=res, height=res)
+        p = processing.StableDiffusionProcessingTxt2Img(sd_model=eng, c=c, uc=uc, seed=seeds[0], sampler_name=sampler_name, scheduler=wl["scheduler"],
+                                                        batch_size=bpg, steps=steps, cfg_scale=cfg_scale, width=res, height=res)
         p.seeds = seeds
         p.all_seeds = seeds
-        p.rng = rng.ImageRNG((4, latent, latent), seeds, device=dev)
+        p.rng = rng.ImageRNG((lat_ch, latent, latent), seeds, device=dev)
         return p
 
     def run_sampler(steps):
         p = make_p(steps)
-        sampler = sd_samplers.create_sampler(a.sampler, eng)
+        sampler = sd_samplers.create_sampler(sampler_name, eng)
         p.sampler = sampler
         x = p.rng.next()
         return sampler.sample(p, x, c, uc, steps=steps, image_conditioning=p.txt2img_image_conditioning(x))
@@ -201,20 +340,27 @@ def main():
         gathered = fdist.gather_latents(lat, total)
         torch.cuda.synchronize()
         t_gather = time.perf_counter() - t0
+        del gathered
 
-        # ---- roofline of the dominant kernel: HIP events around every launch in one eager UNet forward ----------
-        roof = attn_roof = None
+        # ---- roofline of the dominant kernels: HIP events around every launch in one eager network forward ----------
+        roof = attn_roof = gn_roof = None
         if rank == 0 and not a.no_roofline:
-            km = eng.forge_objects.unet.model
-            km.use_graph = False
-            x = torch.randn(bpg, 4, latent, latent, device=dev)
-            sig = torch.full((bpg,), 5.0, device=dev)
-            uctx = (uc["crossattn"], uc["vector"]) if isinstance(uc, dict) else (uc, None)
-            cctx = (c["crossattn"], c["vector"]) if isinstance(c, dict) else (c, None)
-            km.denoise_cfg(x, sig, uctx, cctx, a.cfg)
+            if is_flux:
+                net = km.diffusion_model
+                x = torch.randn(bpg, 16, latent, latent, device=dev)
+                ts = torch.full((bpg,), 0.7, device=dev)
+                call = lambda: net.forward(x, ts, c["crossattn"], c["vector"], c["guidance"])
+            else:
+                km.use_graph = False
+                x = torch.randn(bpg, 4, latent, latent, device=dev)
+                sig = torch.full((bpg,), 5.0, device=dev)
+                uctx = (uc["crossattn"], uc["vector"]) if isinstance(uc, dict) else (uc, None)
+                cctx = (c["crossattn"], c["vector"]) if isinstance(c, dict) else (c, None)
+                call = lambda: km.denoise_cfg(x, sig, uctx, cctx, cfg_scale)
+            call()
             torch.cuda.synchronize()
             with hipops.KernelProfiler() as prof:
-                km.denoise_cfg(x, sig, uctx, cctx, a.cfg)
+                call()
                 torch.cuda.synchronize()
                 summ = prof.summary()
             if a.breakdown:
@@ -222,40 +368,57 @@ def main():
                 with open(a.breakdown, "w") as f:
                     for (kind, tag), d in rows:
                         f.write(json.dumps({"kind": kind, "shape": tag, "launches": d["launches"], "ms": round(d["seconds"] * 1e3, 3),
-                                            "tflops": round(d["flops"] / d["seconds"] / 1e12, 1)}) + "\n")
-            km.use_graph = not a.no_graph
+                                            "tflops": round(d["flops"] / d["seconds"] / 1e12, 1) if d["flops"] else None,
+                                            "GBps": round(d.get("bytes", 0.0) / d["seconds"] / 1e9, 1) if d.get("bytes") else None}) + "\n")
+            if not is_flux:
+                km.use_graph = not a.no_graph
             g = summ.get("gemm_conv")
             if g:
                 ach = g["flops"] / g["seconds"]
-                traffic = pmc_traffic_per_launch()
-                roof = {"kernel": "gemm256p_kernel<256x320 | 320x256 | 256x256> + gemm_kernel (fmx_gemm_conv_f16: MFMA implicit-GEMM conv3x3/1x1 + linear, fused epilogues)",
+                roof = {"kernel": "gemm256p_kernel<256x320 | 320x256 | 256x256> + gemm_kernel (fmx_gemm_conv: MFMA implicit-GEMM conv3x3/1x1 + linear, fused epilogues)",
                         "bound": "mfma", "achieved": round(ach / 1e12, 1), "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s",
-                        "frac": round(ach / MFMA_PEAK, 4), "traffic": traffic, "launches_per_forward": g["launches"],
+                        "frac": round(ach / MFMA_PEAK, 4), "traffic": pmc_traffic_per_launch(), "launches_per_forward": g["launches"],
                         "flop_per_launch_avg": round(g["flops"] / g["launches"] / 1e9, 2), "flop_unit": "GFLOP",
                         "us_per_launch_avg": round(g["seconds"] / g["launches"] * 1e6, 1),
                         "kernel_time_per_forward_ms": round(g["seconds"] * 1e3, 2)}
             at = summ.get("attention")
             if at:
                 ach = at["flops"] / at["seconds"]
-                attn_roof = {"kernel": "attn_q64_kernel (fmx_attention_f16: fused QK^T-softmax-PV)", "bound": "mfma",
+                attn_roof = {"kernel": "attn_q64_kernel / attn_kernel<d> (fmx_attention: fused QK^T-softmax-PV)", "bound": "mfma",
                              "achieved": round(ach / 1e12, 1), "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK, 4),
                              "launches_per_forward": at["launches"], "kernel_time_per_forward_ms": round(at["seconds"] * 1e3, 2)}
+            gn = summ.get("groupnorm")
+            if gn and gn.get("bytes"):
+                ach = gn["bytes"] / gn["seconds"]
+                gn_roof = {"kernel": "gn_apply (+ gn_stats where the producer GEMM did not emit the statistics) (fmx_groupnorm: GroupNorm + SiLU, NHWC fp16)",
+                           "bound": "hbm", "achieved": round(ach / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(ach / HBM_PEAK, 4),
+                           "algorithmic_bytes": "1 read + 1 write of the tensor per GroupNorm", "launches_per_forward": gn["launches"],
+                           "kernel_time_per_forward_ms": round(gn["seconds"] * 1e3, 2)}
 
     ms_per_step = elapsed / a.steps * 1e3
     value = world * a.steps / elapsed
-    fl = FLOPS_PER_SAMPLE_FWD[model] * 2 * bpg  # per GPU per step (CFG: 2 sample-forwards per image)
+    fwd_per_image = 1 if (is_flux or cfg_scale == 1.0) else 2
+    fl = FLOPS_PER_SAMPLE_FWD[model] * fwd_per_image * bpg  # per GPU per step (CFG: 2 sample-forwards per image)
+    if res != wl["res"]:
+        fl = None
+    names = {"sdxl": "SDXL UNet", "sd15": "SD1.5 UNet", "flux": "Flux-dev DiT (4096 + 256 tokens)"}
     out = {
         "metric": "sampler it/s (UNet steps/sec)", "value": round(value, 4), "unit": "it/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16", "data": "synthetic (random-init weights, N(0,1) conditioning, per-image seeded CPU noise)",
-        "config": {"workload": f"{'SDXL' if model == 'sdxl' else 'SD1.5'} UNet {res}x{res} batch={bpg}/GPU fp16, {a.sampler} sampler, CFG {a.cfg} "
-                               f"(UNet batch {2 * bpg}), HIP-graph replay={'on' if not a.no_graph else 'off'}",
-                   "global_batch": total, "latent": [latent, latent], "parallelism": f"batch-shard x{world} (RCCL broadcast cond + gather latents)"},
-        "step_tflops_per_gpu": round(fl / 1e12, 2),
-        "achieved_tflops_per_gpu": round(fl / (ms_per_step * 1e-3) / 1e12, 1),
-        "step_frac_of_mfma_peak": round(fl / (ms_per_step * 1e-3) / MFMA_PEAK, 4),
+        "dtype": "bf16" if dt16 == torch.bfloat16 else "f16",
+        "data": "synthetic (random-init weights, N(0,1) conditioning, per-image seeded CPU noise)",
+        "config": {"workload": f"{names[model]} {res}x{res} batch={bpg}/GPU {'bf16' if dt16 == torch.bfloat16 else 'fp16'}, {sampler_name} sampler, CFG {cfg_scale} "
+                               f"(network batch {fwd_per_image * bpg}), HIP-graph replay={'on' if not a.no_graph else 'off'}",
+                   "name": a.config, "baseline_config": wl["baseline"], "global_batch": total, "latent": [latent, latent],
+                   "parallelism": f"batch-shard x{world} (RCCL broadcast cond + gather latents)"},
+        "ranks_in_collective": ranks_seen,
+        "launcher": "self (bench.py re-executed under torch.distributed.run)" if os.environ.get("FMX_BENCH_SELF_LAUNCHED") else
+                    ("external (torch.distributed.run)" if world > 1 else "single process"),
+        "step_tflops_per_gpu": None if fl is None else round(fl / 1e12, 2),
+        "achieved_tflops_per_gpu": None if fl is None else round(fl / (ms_per_step * 1e-3) / 1e12, 1),
+        "step_frac_of_mfma_peak": None if fl is None else round(fl / (ms_per_step * 1e-3) / MFMA_PEAK, 4),
         "vae_decode_ms_per_batch": None if vae_ms is None else round(vae_ms, 1),
-        "ms_per_image_20_steps_plus_vae": None if vae_ms is None else round((20 * ms_per_step + vae_ms) / bpg, 1),
+        f"ms_per_image_{nominal}_steps_plus_vae": None if vae_ms is None else round((nominal * ms_per_step + vae_ms) / bpg, 1),
         "comm_ms": {"broadcast_cond": round(t_bcast * 1e3, 2), "gather_latents": round(t_gather * 1e3, 2)},
         "build_s": round(t_build, 1),
     }
@@ -263,12 +426,15 @@ def main():
         out["roofline"] = roof
     if attn_roof:
         out["roofline_attention"] = attn_roof
+    if gn_roof:
+        out["roofline_groupnorm"] = gn_roof
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
-            dt, nthreads, t_init = cpu_baseline(model, ucfg, latent)
-            out["cpu_baseline"] = {"value": round(1.0 / (2 * bpg * dt), 6), "unit": "it/s", "cores": nthreads, "kind": "port",
-                                   "sample": f"one {model.upper()} UNet sample-forward (B=1, {latent}x{latent} latent, fp32, torch CPU, {nthreads} threads) took "
-                                             f"{dt:.1f} s; a step of this workload is {2 * bpg} such forwards"}
+            dt, nthreads, note = cpu_baseline(model, ucfg, latent)
+            out["cpu_baseline"] = {"value": round(1.0 / (fwd_per_image * bpg * dt), 6), "unit": "it/s", "cores": nthreads, "kind": "port",
+                                   "sample": note + f"; a step of this workload is {fwd_per_image * bpg} such forwards"}
+            if model in REFERENCE_CPU_AUTHORING_BOX:
+                out["cpu_baseline"]["reference_on_authoring_box"] = REFERENCE_CPU_AUTHORING_BOX[model]
         except Exception as e:  # the baseline must never take the bench line down
             out["cpu_baseline"] = {"value": None, "error": repr(e)}
     if rank == 0:

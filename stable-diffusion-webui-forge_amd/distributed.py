@@ -29,25 +29,36 @@ def _flatten(cond):
     return None, [cond]
 
 
-def broadcast_conditioning(cond, uncond, device, src=0, spec=None):
-    """Rank `src` holds (cond, uncond) for the GLOBAL batch; every rank returns them (same structure).  `spec` (needed on
-    non-src ranks) = {"keys": [...] or None, "shapes": [[...], ...], "dtype": torch.dtype} for cond; uncond mirrors it."""
+def _describe(cond):
+    """Picklable description of one conditioning (tensor, dict of tensors, or None): per-tensor shape AND dtype -- cond and uncond
+    differ in token count when only one of the prompts is longer than 75 tokens ([B,154,D] vs [B,77,D]; the reference does not pad
+    them, backend/sampling/condition.py pads per step by lcm), and dict conds mix dtypes."""
+    if cond is None:
+        return None
+    keys, tensors = _flatten(cond)
+    return {"keys": keys, "shapes": [list(t.shape) for t in tensors], "dtypes": [t.dtype for t in tensors]}
+
+
+def broadcast_conditioning(cond, uncond, device, src=0):
+    """Rank `src` holds (cond, uncond) for the GLOBAL batch; every rank returns them with the same structure (a tensor, a dict of
+    tensors, or None for an absent uncond at cfg_scale 1).  Each of the two carries its own metadata."""
     rank, ws = world()
     if ws == 1:
         return cond, uncond
     meta = [None]
     if rank == src:
-        keys, tensors = _flatten(cond)
-        meta = [{"keys": keys, "shapes": [list(t.shape) for t in tensors], "dtype": tensors[0].dtype}]
+        meta = [(_describe(cond), _describe(uncond))]
     dist.broadcast_object_list(meta, src=src)
-    m = meta[0]
     out = []
-    for which in (cond, uncond):
+    for which, m in zip((cond, uncond), meta[0]):
+        if m is None:
+            out.append(None)
+            continue
         if rank == src:
             _, tensors = _flatten(which)
             tensors = [t.to(device).contiguous() for t in tensors]
         else:
-            tensors = [torch.empty(s, dtype=m["dtype"], device=device) for s in m["shapes"]]
+            tensors = [torch.empty(s, dtype=d, device=device) for s, d in zip(m["shapes"], m["dtypes"])]
         for t in tensors:
             dist.broadcast(t, src=src)
         out.append(dict(zip(m["keys"], tensors)) if m["keys"] is not None else tensors[0])
@@ -55,6 +66,8 @@ def broadcast_conditioning(cond, uncond, device, src=0, spec=None):
 
 
 def slice_conditioning(cond, lo, hi):
+    if cond is None:
+        return None
     if isinstance(cond, dict):
         return type(cond)({k: v[lo:hi].contiguous() for k, v in cond.items()})
     return cond[lo:hi].contiguous()

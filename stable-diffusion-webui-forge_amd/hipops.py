@@ -44,31 +44,30 @@ class KernelProfiler:
         _lib.check(_lib.lib().fmx_event_create(C.byref(ev)), "fmx_event_create")
         return ev
 
-    def launch(self, kind, flops, fn, tag=None):
+    def launch(self, kind, flops, fn, tag=None, nbytes=0.0):
+        """nbytes: ALGORITHMIC HBM bytes of the bracketed launches (HBM-bound kernels: GroupNorm = 1 read + 1 write of the tensor)."""
         L = _lib.lib()
         a, b = self._event(), self._event()
         sp = stream_ptr()
         _lib.check(L.fmx_event_record(a, sp), "fmx_event_record")
         fn()
         _lib.check(L.fmx_event_record(b, sp), "fmx_event_record")
-        self.records.append((kind, flops, a, b))
+        self.records.append((kind, flops, a, b, nbytes))
         self.tags.append(tag)
 
     def summary(self):
         """-> {kind: {"launches", "flops", "seconds"}} ; synchronises."""
         L = _lib.lib()
         out = {}
-        for (kind, flops, a, b), tag in zip(self.records, self.tags):
+        for (kind, flops, a, b, nbytes), tag in zip(self.records, self.tags):
             ms = C.c_float()
             _lib.check(L.fmx_event_elapsed_ms(a, b, C.byref(ms)), "fmx_event_elapsed_ms")
-            d = out.setdefault(kind, {"launches": 0, "flops": 0.0, "seconds": 0.0})
-            d["launches"] += 1
-            d["flops"] += flops
-            d["seconds"] += ms.value * 1e-3
-            t = self.by_tag.setdefault((kind, tag), {"launches": 0, "flops": 0.0, "seconds": 0.0})
-            t["launches"] += 1
-            t["flops"] += flops
-            t["seconds"] += ms.value * 1e-3
+            for d in (out.setdefault(kind, {"launches": 0, "flops": 0.0, "seconds": 0.0, "bytes": 0.0}),
+                      self.by_tag.setdefault((kind, tag), {"launches": 0, "flops": 0.0, "seconds": 0.0, "bytes": 0.0})):
+                d["launches"] += 1
+                d["flops"] += flops
+                d["bytes"] += nbytes
+                d["seconds"] += ms.value * 1e-3
             L.fmx_event_destroy(a)
             L.fmx_event_destroy(b)
         self.records, self.tags = [], []

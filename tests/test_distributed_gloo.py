@@ -74,6 +74,45 @@ def test_broadcast_shard_gather_world2(total, with_dict):
     assert all(a and b for a, b in res), res
 
 
+def _worker_ragged(rank, world, port, q):
+    """cond and uncond of different token counts and dtypes (a >75-token prompt with a short negative: [B,154,D] vs [B,77,D]; an SDXL dict
+    cond with an fp32 vector next to fp16 cross-attention), and an absent uncond (cfg_scale 1)."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import forge_amd  # noqa: F401
+    from forge_amd import distributed as fd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(3)
+        c_full = {"crossattn": torch.randn(4, 154, 8, generator=g).half(), "vector": torch.randn(4, 6, generator=g)}
+        u_full = {"crossattn": torch.randn(4, 77, 8, generator=g).half(), "vector": torch.zeros(4, 6)}
+        c, uc = fd.broadcast_conditioning(c_full if rank == 0 else None, u_full if rank == 0 else None, torch.device("cpu"))
+        ok = all(torch.equal(c[k], c_full[k]) and c[k].dtype == c_full[k].dtype for k in c_full)
+        ok = ok and all(torch.equal(uc[k], u_full[k]) and uc[k].dtype == u_full[k].dtype for k in u_full)
+        c2, uc2 = fd.broadcast_conditioning(c_full["crossattn"] if rank == 0 else None, None, torch.device("cpu"))
+        ok = ok and torch.equal(c2, c_full["crossattn"]) and uc2 is None and fd.slice_conditioning(uc2, 0, 2) is None
+        q.put(bool(ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_broadcast_of_conds_that_differ_in_length_dtype_or_presence_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ragged, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(res), res
+
+
 def test_shard_range_partitions():
     for total in (0, 1, 7, 8, 64, 65):
         for ws in (1, 2, 3, 8):
