@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define FMX_ABI_VERSION 2
+#define FMX_ABI_VERSION 3
 
 #define FMX_OK 0
 #define FMX_E_BADARG 10001   /* shape / alignment / null-pointer contract violated */
@@ -148,17 +148,29 @@ int fmx_attention_f16(const fmx_attn_args* args /* host */, void* stream);
 int fmx_softmax_rows_f16(void* x, int64_t nrows, int32_t ncols, int64_t ld, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * GroupNorm over NHWC fp16 (optionally the channel-concat of two tensors), fp32 statistics.
- *   stats : partial[n][chunk][c][2] fp32 workspace, nchunks chosen by the caller (<= 256); CONSUMED by apply
- *           (apply first folds the chunks into per-channel scale/shift in place, deterministically)
- *   apply : y = (x - mean_g) * rstd_g * gamma[c] + beta[c], optional SiLU, fp16 out [n][hw][c0+c1]
- * (c0+c1) % groups == 0, c0 % 8 == 0, c1 % 8 == 0.
+ * GroupNorm over NHWC fp16 (optionally the channel-concat of two tensors), fp32 statistics, 1 read + 1 write.
+ *   statistics : partial[n][chunk][c][2] fp32 = {sum x, sum x^2} of channel c over the chunk's pixels of image n.  Produced EITHER by the
+ *                convolution / linear that wrote the tensor -- fmx_gemm_conv_stats_f16 below emits one chunk per 256-row output tile from
+ *                its epilogue, so the tensor is never re-read for statistics -- OR by fmx_groupnorm_stats_f16 (any nchunks <= 1024; one
+ *                source tensor [n][hw][c] with pixel stride ld).  A partial buffer is read-only for apply: a tensor that feeds two
+ *                GroupNorms (a UNet skip connection) keeps its statistics.
+ *   apply      : folds the chunks of both sources into per-channel {scale, shift} (scale_shift: fp32 workspace [n][c0+c1][2], fixed
+ *                summation order -> deterministic), then y = x * scale[c] + shift[c] = (x - mean_g) * rstd_g * gamma[c] + beta[c],
+ *                optional SiLU, fp16 out [n][hw][c0+c1] (the concatenation is materialised only here).
+ * (c0+c1) % groups == 0, c0 % 8 == 0, c1 % 8 == 0; ld0 / ld1 = pixel strides of the sources (elements, % 8 == 0).
  * ---------------------------------------------------------------------------------------------- */
-int fmx_groupnorm_stats_f16(const void* x0, const void* x1, int32_t c0, int32_t c1, int32_t n, int32_t hw,
-                            float* partial, int32_t nchunks, void* stream);
-int fmx_groupnorm_apply_f16(const void* x0, const void* x1, int32_t c0, int32_t c1, int32_t n, int32_t hw,
-                            float* partial, int32_t nchunks, int32_t groups, float eps,
-                            const void* gamma, const void* beta, int32_t silu, void* y, void* stream);
+int fmx_groupnorm_stats_f16(const void* x, int32_t c, int64_t ld, int32_t n, int32_t hw, float* partial, int32_t nchunks, void* stream);
+int fmx_groupnorm_apply_f16(const void* x0, const void* x1, int32_t c0, int32_t c1, int64_t ld0, int64_t ld1, int32_t n, int32_t hw,
+                            const float* partial0, int32_t nchunks0, const float* partial1, int32_t nchunks1, int32_t groups, float eps,
+                            const void* gamma, const void* beta, int32_t silu, float* scale_shift, void* y, void* stream);
+
+/* fmx_gemm_conv_f16 that ALSO leaves the GroupNorm statistics of its fp16 output [M = n*oh*ow][nout] (ld_out == nout, no GEGLU) in
+ * partial[n][chunks][nout][2]: from the epilogue of the 256-row tiles when an image is a whole number of them (oh*ow % 256 == 0) and the
+ * tile choice is a 256-row kernel, else by a statistics pass launched behind the GEMM -- the caller cannot tell the difference except by
+ * *chunks_out (host): the chunk count it must hand to fmx_groupnorm_apply_f16.  partial must hold n * max_chunks * nout * 2 floats,
+ * max_chunks >= max(oh*ow / 256, fallback_chunks); fallback_chunks (1..1024) is the chunk count of the separate pass. */
+int fmx_gemm_conv_stats_f16(const fmx_gemm_args* args /* host */, float* partial, int32_t max_chunks, int32_t fallback_chunks,
+                            int32_t* chunks_out /* host */, void* stream);
 
 /* LayerNorm over the last dim of fp16 [rows][c] (c % 8 == 0, c <= 4096), fp32 two-pass statistics. */
 int fmx_layernorm_f16(const void* x, const void* gamma, const void* beta, void* y, int64_t rows, int32_t c,
@@ -275,16 +287,12 @@ int fmx_philox_randn(uint64_t seed, uint32_t offset, float* out, uint32_t* raw_u
  * bfloat16 build of the Flux path.  The reference computes Flux in bf16 (backend/loader.py picks the storage dtype of the checkpoint,
  * bf16 for Flux.1; fp16 overflows in the late single-stream blocks of trained weights).  These entry points are the SAME kernels as
  * their _f16 counterparts compiled with bfloat16 elements (storage, MFMA operands; fp32 accumulation, softmax and epilogue math as
- * before): identical argument contracts, every "fp16" in the descriptions above reads "bf16".  fmx_groupnorm_* / fmx_layernorm_padded /
- * fmx_softmax_rows come along with their files; the Flux executor uses the other seven.
+ * before): identical argument contracts, every "fp16" in the descriptions above reads "bf16".  fmx_layernorm_padded / fmx_softmax_rows come
+ * along with their files; the Flux executor uses the other seven.
  * ---------------------------------------------------------------------------------------------- */
 int fmx_gemm_conv_bf16(const fmx_gemm_args* args /* host */, void* stream);
 int fmx_attention_bf16(const fmx_attn_args* args /* host */, void* stream);
 int fmx_softmax_rows_bf16(void* x, int64_t nrows, int32_t ncols, int64_t ld, void* stream);
-int fmx_groupnorm_stats_bf16(const void* x0, const void* x1, int32_t c0, int32_t c1, int32_t n, int32_t hw, float* partial, int32_t nchunks,
-                             void* stream);
-int fmx_groupnorm_apply_bf16(const void* x0, const void* x1, int32_t c0, int32_t c1, int32_t n, int32_t hw, float* partial, int32_t nchunks,
-                             int32_t groups, float eps, const void* gamma, const void* beta, int32_t silu, void* y, void* stream);
 int fmx_layernorm_bf16(const void* x, const void* gamma, const void* beta, void* y, int64_t rows, int32_t c, float eps, void* stream);
 int fmx_layernorm_padded_bf16(const void* x, const void* gamma, const void* beta, void* y, int64_t rows, int32_t c, float eps,
                               int64_t rows_per_image, int64_t out_rows_per_image, void* stream);

@@ -18,7 +18,7 @@ tests/parity.py turns that into the tolerances of the native path (max(1e-3, fac
     python -m oracle.make_floor                 # tiny families + SD1.5 full forward / config 0        (~3 min)
     python -m oracle.make_floor --only config2  # + fixture sd15_config2.pt: SD1.5 512^2, B=4, 20-step Euler a (~10 min)
     python -m oracle.make_floor --only sdxl     # SDXL full-size forward floor                                (~8 min)
-    python -m oracle.make_floor --only config3  # + fixture sdxl_config3.pt: SDXL 1024^2, B=1, 5 DPM++ 2M steps + 1024^2 VAE decode (~1 h)
+    python -m oracle.make_floor --only config3  # + fixture sdxl_config3.pt: SDXL 1024^2, one image, 30-step DPM++ 2M + 1024^2 VAE decode (~30 min)
     python -m oracle.make_floor --only vae1024  # 1024^2 decode only (fixture + floor)
 """
 import argparse
@@ -305,9 +305,9 @@ def floors_sdxl_full():
     update({"sdxl_full_fwd.pt:eps": metrics(call16(net16, x, t, ctx, y), g["eps"])})
 
 
-def gen_config3(steps=5):
-    """BASELINE config 3 at a CPU-affordable size: SDXL 1024x1024 (latent 128x128), ONE image, `steps` DPM++ 2M steps on the Karras schedule,
-    CFG 7, then the 1024^2 VAE decode of the result -- reference fp32 (fixture) and reference fp16 (floor)."""
+def gen_config3(steps=30):
+    """BASELINE config 3 for ONE image of the batch (images are independent): SDXL 1024x1024 (latent 128x128), `steps` DPM++ 2M steps on the
+    Karras schedule, CFG 7, then the 1024^2 VAE decode of the result -- reference fp32 (fixture) and reference fp16 (floor)."""
     cfg = synth.SDXL_UNET_CONFIG
     sd = synth.synth_unet_state_dict(cfg, seed=0)
     c, uc = synth.synth_conditioning(1, cfg["context_dim"], cfg["adm_in_channels"], seed=1234)
@@ -334,6 +334,7 @@ def gen_config3(steps=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
+    ap.add_argument("--steps", type=int, default=30, help="config3: sampler steps (30 = BASELINE config 3; ~26 s per step and precision on this box)")
     a = ap.parse_args()
     torch.manual_seed(0)
     if a.only in ("", "tiny"):
@@ -349,7 +350,7 @@ def main():
     if a.only == "vae1024":
         gen_vae1024()
     if a.only == "config3":
-        gen_config3()
+        gen_config3(a.steps)
 
 
 if __name__ == "__main__":

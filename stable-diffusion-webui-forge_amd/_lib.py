@@ -59,8 +59,9 @@ SIGNATURES = {
     "fmx_geglu_interleave_rows": [_vp, _vp, _vp, _vp, _i32, _i32, _vp],
     "fmx_attention_f16": [C.POINTER(AttnArgs), _vp],
     "fmx_softmax_rows_f16": [_vp, _i64, _i32, _i64, _vp],
-    "fmx_groupnorm_stats_f16": [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
-    "fmx_groupnorm_apply_f16": [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _f32, _vp, _vp, _i32, _vp, _vp],
+    "fmx_groupnorm_stats_f16": [_vp, _i32, _i64, _i32, _i32, _vp, _i32, _vp],
+    "fmx_groupnorm_apply_f16": [_vp, _vp, _i32, _i32, _i64, _i64, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _f32, _vp, _vp, _i32, _vp, _vp, _vp],
+    "fmx_gemm_conv_stats_f16": [C.POINTER(GemmArgs), _vp, _i32, _i32, C.POINTER(C.c_int32), _vp],
     "fmx_layernorm_f16": [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp],
     "fmx_layernorm_padded_f16": [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _i64, _i64, _vp],
     "fmx_layernorm_mod_f16": [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i32, _f32, _vp],
@@ -99,7 +100,7 @@ SIGNATURES = {
 
 
 # bfloat16 build of the Flux path's kernels: same signatures as the _f16 entries (include/fmx.h, last section)
-for _n in ("fmx_gemm_conv", "fmx_attention", "fmx_softmax_rows", "fmx_groupnorm_stats", "fmx_groupnorm_apply", "fmx_layernorm", "fmx_layernorm_padded",
+for _n in ("fmx_gemm_conv", "fmx_attention", "fmx_softmax_rows", "fmx_layernorm", "fmx_layernorm_padded",
            "fmx_layernorm_mod", "fmx_flux_qk_norm_rope", "fmx_silu"):
     SIGNATURES[_n + "_bf16"] = SIGNATURES[_n + "_f16"]
 SIGNATURES["fmx_timestep_embedding_bf16"] = SIGNATURES["fmx_timestep_embedding"]
@@ -141,7 +142,7 @@ def lib():
             fn.restype = C.c_int
         handle.fmx_last_error.argtypes = []
         handle.fmx_last_error.restype = C.c_char_p
-        if handle.fmx_abi_version() != 2:
+        if handle.fmx_abi_version() != 3:
             raise FmxError("libfmx ABI version mismatch")
         _lib = handle
     return _lib

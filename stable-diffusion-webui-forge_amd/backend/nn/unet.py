@@ -242,23 +242,26 @@ class IntegratedUNet2DConditionModel:
     # layers (NHWC fp16 [Bu, H, W, C])
     # ------------------------------------------------------------------------------------------------------------
     def _res(self, L, x, skip, emb_all, arena):
+        """ResBlock (unet.py:433-478).  The GroupNorm statistics of every tensor a convolution writes here come out of that GEMM's
+        epilogue (ops.conv_gemm(stats=True)) and travel with the tensor object (ops.attach_stats): no GroupNorm re-reads its input for them."""
         k = L.key
         bu, hh, ww, _ = x.shape
         out = ops.empty((bu, hh, ww, L.cout))
+        out_part = ops.stats_buffer(bu, hh * ww, L.cout)
         m = arena.mark()
         g1 = ops.groupnorm(x, *self.w[k + ".gn1"], 1e-5, x1=skip, silu=True)
         off, cout = self._emb_off[k]
-        h = ops.conv_gemm(g1, self.w[k + ".conv1"][0], cout, kh=3, pad=1, bias=self.w[k + ".conv1"][1],
-                          rowvec=emb_all[:, off:off + cout]).view(bu, hh, ww, cout)
-        g2 = ops.groupnorm(h, *self.w[k + ".gn2"], 1e-5, silu=True)
+        h, h_st = ops.conv_gemm(g1, self.w[k + ".conv1"][0], cout, kh=3, pad=1, bias=self.w[k + ".conv1"][1],
+                                rowvec=emb_all[:, off:off + cout], stats=True)
+        g2 = ops.groupnorm(h.view(bu, hh, ww, cout), *self.w[k + ".gn2"], 1e-5, silu=True, stats=h_st)
         if L.has_skip_conv:
             sk = ops.conv_gemm(x, self.w[k + ".skip"][0], cout, x1=skip, bias=self.w[k + ".skip"][1])
         else:
             sk = x.view(-1, cout)
-        ops.conv_gemm(g2, self.w[k + ".conv2"][0], cout, kh=3, pad=1, bias=self.w[k + ".conv2"][1], residual=sk,
-                      out=out.view(-1, cout), ld_out=cout)
+        _, st = ops.conv_gemm(g2, self.w[k + ".conv2"][0], cout, kh=3, pad=1, bias=self.w[k + ".conv2"][1], residual=sk,
+                              out=out.view(-1, cout), ld_out=cout, stats=True, stats_partial=out_part)
         arena.release(m)
-        return out
+        return ops.attach_stats(out, st)
 
     def _attn_block(self, b, L, h, bu, n, ctxc, arena):
         H, d = L.heads, L.dim_head
@@ -402,6 +405,7 @@ class IntegratedUNet2DConditionModel:
         """Run a UNet-level hook that expects NCHW on an NHWC fp16 activation: it gets a permuted VIEW (in-place edits land in h);
         a new tensor coming back is converted to NHWC fp16."""
         v = h.permute(0, 3, 1, 2)
+        ops.clear_stats(h)  # the hook may edit the view in place
         r = fn(v, *args)
         if r is v or (r.data_ptr() == h.data_ptr() and r.shape == v.shape and r.stride() == v.stride()):
             return h
@@ -413,6 +417,7 @@ class IntegratedUNet2DConditionModel:
         n = hh * ww
         inner = L.heads * L.dim_head
         out = ops.empty((bu, hh, ww, c))
+        out_part = ops.stats_buffer(bu, n, c)
         mk = arena.mark()
         g = ops.groupnorm(x, *self.w[k + ".norm"], 1e-6)
         h = ops.linear(g.view(-1, c), *self.w[k + ".proj_in"])  # 1x1 conv == Linear in NHWC
@@ -423,9 +428,10 @@ class IntegratedUNet2DConditionModel:
                 self._attn_block_hooked(f"{k}.transformer_blocks.{di}", L, h, bu, n, ctxc, arena, to)
             else:
                 self._attn_block(f"{k}.transformer_blocks.{di}", L, h, bu, n, ctxc, arena)
-        ops.linear(h, *self.w[k + ".proj_out"], residual=x.view(-1, c), out=out.view(-1, c), ld_out=c)
+        _, st = ops.linear(h, *self.w[k + ".proj_out"], residual=x.view(-1, c), out=out.view(-1, c), ld_out=c, n=bu, h=hh, w=ww, stats=True,
+                           stats_partial=out_part)
         arena.release(mk)
-        return out
+        return ops.attach_stats(out, st)
 
     def _run_block(self, blk, h, skip, emb_all, ctxc, arena, up_to=None, to=None):
         for L in blk:
@@ -438,12 +444,13 @@ class IntegratedUNet2DConditionModel:
                     to["transformer_index"] += 1  # unet.py:82-84
             elif isinstance(L, Down):
                 bu, hh, ww, c = h.shape
-                h = ops.conv_gemm(h, self.w[L.key][0], c, kh=3, stride=2, pad=1, bias=self.w[L.key][1])
-                h = h.view(bu, (hh + 2 - 3) // 2 + 1, (ww + 2 - 3) // 2 + 1, c)
+                h, st = ops.conv_gemm(h, self.w[L.key][0], c, kh=3, stride=2, pad=1, bias=self.w[L.key][1], stats=True)
+                h = ops.attach_stats(h.view(bu, (hh + 2 - 3) // 2 + 1, (ww + 2 - 3) // 2 + 1, c), st)
             elif isinstance(L, Up):
                 bu, hh, ww, c = h.shape
                 uh, uw = up_to if up_to is not None else (hh * 2, ww * 2)
-                h = ops.conv_gemm(h, self.w[L.key][0], c, kh=3, pad=1, up=(uh, uw), bias=self.w[L.key][1]).view(bu, uh, uw, c)
+                h, st = ops.conv_gemm(h, self.w[L.key][0], c, kh=3, pad=1, up=(uh, uw), bias=self.w[L.key][1], stats=True)
+                h = ops.attach_stats(h.view(bu, uh, uw, c), st)
             else:
                 raise TypeError(L)
         return h
@@ -514,7 +521,8 @@ class IntegratedUNet2DConditionModel:
                 cw, cb = self.w[blk[0].key]
                 if (concat_term is None) != (self.concat_channels == 0):
                     raise ValueError("an inpainting / edit UNet needs c_concat (and only such a UNet takes one)")
-                h = ops.linear(xcol, cw, cb, residual=concat_term).view(bu, hh, ww, lay.model_channels)
+                h, st = ops.linear(xcol, cw, cb, residual=concat_term, n=bu, h=hh, w=ww, stats=True)
+                h = ops.attach_stats(h.view(bu, hh, ww, lay.model_channels), st)
             else:
                 h = modify(h, "before")
                 h = self._run_block(blk, h, None, emb_all, ctxc, arena, to=to)
@@ -537,6 +545,8 @@ class IntegratedUNet2DConditionModel:
             skip = self._apply_control(hs.pop(), control, "output")
             for p in patches.get("output_block_patch", []):
                 hv, sv = h.permute(0, 3, 1, 2), skip.permute(0, 3, 1, 2)
+                ops.clear_stats(h)
+                ops.clear_stats(skip)
                 rh, rs = p(hv, sv, to)
                 h = h if rh is hv else rh.permute(0, 2, 3, 1).to(torch.float16).contiguous()
                 skip = skip if rs is sv else rs.permute(0, 2, 3, 1).to(torch.float16).contiguous()

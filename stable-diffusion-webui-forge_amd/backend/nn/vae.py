@@ -135,19 +135,22 @@ class IntegratedAutoencoderKL:
     def _res(self, k, x, cin, cout, arena):
         b, hh, ww, _ = x.shape
         out = ops.empty((b, hh, ww, cout))
+        out_part = ops.stats_buffer(b, hh * ww, cout)
         m = arena.mark()
-        g1 = ops.groupnorm(x, *self.w[k + ".n1"], 1e-6, silu=True)
-        h = ops.conv_gemm(g1, self.w[k + ".c1"][0], cout, kh=3, pad=1, bias=self.w[k + ".c1"][1]).view(b, hh, ww, cout)
-        g2 = ops.groupnorm(h, *self.w[k + ".n2"], 1e-6, silu=True)
+        g1 = ops.groupnorm(x, *self.w[k + ".n1"], 1e-6, silu=True)          # statistics: left on x by the GEMM that produced it
+        h, h_st = ops.conv_gemm(g1, self.w[k + ".c1"][0], cout, kh=3, pad=1, bias=self.w[k + ".c1"][1], stats=True)
+        g2 = ops.groupnorm(h.view(b, hh, ww, cout), *self.w[k + ".n2"], 1e-6, silu=True, stats=h_st)
         sk = ops.conv_gemm(x, self.w[k + ".sc"][0], cout, bias=self.w[k + ".sc"][1]) if cin != cout else x.view(-1, cout)
-        ops.conv_gemm(g2, self.w[k + ".c2"][0], cout, kh=3, pad=1, bias=self.w[k + ".c2"][1], residual=sk, out=out.view(-1, cout), ld_out=cout)
+        _, st = ops.conv_gemm(g2, self.w[k + ".c2"][0], cout, kh=3, pad=1, bias=self.w[k + ".c2"][1], residual=sk, out=out.view(-1, cout), ld_out=cout,
+                              stats=True, stats_partial=out_part)
         arena.release(m)
-        return out
+        return ops.attach_stats(out, st)
 
     def _attn(self, x, arena, a="decoder.mid.attn_1"):
         b, hh, ww, c = x.shape
         n = hh * ww
         out = ops.empty((b, hh, ww, c))
+        out_part = ops.stats_buffer(b, n, c)
         m = arena.mark()
         g = ops.groupnorm(x, *self.w[a + ".norm"], 1e-6).view(-1, c)
         qk = ops.linear(g, *self.w[a + ".qk"])                                  # [B*N, 2C]
@@ -172,9 +175,10 @@ class IntegratedAutoencoderKL:
             ops.conv_gemm(self.w[a + ".v"][0], gb, n, out=vt, ld_out=npad)        # V^T (bias deferred)
             ops.conv_gemm(s, vt, c, bias=self.w[a + ".v"][1], out=o[bi * n:(bi + 1) * n], ld_out=c)  # P V + b_v
             arena.release(mk)
-        ops.linear(o, *self.w[a + ".proj_out"], residual=x.view(-1, c), out=out.view(-1, c), ld_out=c)
+        _, st = ops.linear(o, *self.w[a + ".proj_out"], residual=x.view(-1, c), out=out.view(-1, c), ld_out=c, n=b, h=hh, w=ww, stats=True,
+                           stats_partial=out_part)
         arena.release(m)
-        return out
+        return ops.attach_stats(out, st)
 
     def _decode_impl(self, z, arena):
         """z fp32 NCHW [B, lc, h, w] (already process_out'ed) -> fp16 [B*8h*8w, 4] (first out_channels valid)"""
@@ -186,9 +190,10 @@ class IntegratedAutoencoderKL:
         else:
             zq = zl
         if lc * 9 <= 64:
-            h = ops.linear(ops.im2col3x3_smallc(zq, lc), *self.w["conv_in"]).view(b, hh, ww, lay.block_in)
+            h, st = ops.linear(ops.im2col3x3_smallc(zq, lc), *self.w["conv_in"], n=b, h=hh, w=ww, stats=True)
         else:
-            h = ops.conv_gemm(zq, self.w["conv_in"][0], lay.block_in, kh=3, pad=1, bias=self.w["conv_in"][1]).view(b, hh, ww, lay.block_in)
+            h, st = ops.conv_gemm(zq, self.w["conv_in"][0], lay.block_in, kh=3, pad=1, bias=self.w["conv_in"][1], stats=True)
+        h = ops.attach_stats(h.view(b, hh, ww, lay.block_in), st)
         bi = lay.block_in
         h = self._res("decoder.mid.block_1", h, bi, bi, arena)
         h = self._attn(h, arena)
@@ -198,7 +203,8 @@ class IntegratedAutoencoderKL:
                 h = self._res(key, h, cin, cout, arena)
             if up is not None:
                 bb, h2, w2, c = h.shape
-                h = ops.conv_gemm(h, self.w[up][0], c, kh=3, pad=1, up=(2 * h2, 2 * w2), bias=self.w[up][1]).view(bb, 2 * h2, 2 * w2, c)
+                h, st = ops.conv_gemm(h, self.w[up][0], c, kh=3, pad=1, up=(2 * h2, 2 * w2), bias=self.w[up][1], stats=True)
+                h = ops.attach_stats(h.view(bb, 2 * h2, 2 * w2, c), st)
         g = ops.groupnorm(h, *self.w["norm_out"], 1e-6, silu=True)
         y = ops.conv_gemm(g, self.w["conv_out"][0], lay.out_channels, kh=3, pad=1, bias=self.w["conv_out"][1],
                           out=ops.empty((g.shape[0] * g.shape[1] * g.shape[2], 4)), ld_out=4)
@@ -229,14 +235,16 @@ class IntegratedAutoencoderKL:
         b, c, hh, ww = x.shape
         xl = ops.vae_pack_latent(x, 1.0, 0.0, ld=8)                               # NHWC fp16, zero padded to 8 channels
         col = ops.im2col3x3_smallc(xl, c)
-        h = ops.linear(col, *self.w["e.conv_in"]).view(b, hh, ww, el.ch)
+        h, st = ops.linear(col, *self.w["e.conv_in"], n=b, h=hh, w=ww, stats=True)
+        h = ops.attach_stats(h.view(b, hh, ww, el.ch), st)
         for _, blocks, down in el.levels:
             for key, cin, cout in blocks:
                 h = self._res(key, h, cin, cout, arena)
             if down is not None:
                 bb, h2, w2, cc = h.shape
                 oh, ow = (h2 + 1 - 3) // 2 + 1, (w2 + 1 - 3) // 2 + 1            # F.pad (0,1,0,1) then 3x3 stride 2 (vae.py:67-70)
-                h = ops.conv_gemm(h, self.w[down][0], cc, kh=3, stride=2, pad=0, out_hw=(oh, ow), bias=self.w[down][1]).view(bb, oh, ow, cc)
+                h, st = ops.conv_gemm(h, self.w[down][0], cc, kh=3, stride=2, pad=0, out_hw=(oh, ow), bias=self.w[down][1], stats=True)
+                h = ops.attach_stats(h.view(bb, oh, ow, cc), st)
         ebi = el.block_in
         h = self._res("encoder.mid.block_1", h, ebi, ebi, arena)
         h = self._attn(h, arena, "encoder.mid.attn_1")

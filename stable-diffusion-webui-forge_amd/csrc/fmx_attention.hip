@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 // Same algorithm and LDS image as attn_kernel<64>, but a wave owns TWO 32-query fragments: every K / V^T fragment read
 // from LDS feeds 2 MFMAs and a workgroup (4 waves) covers 256 queries per K/V tile, which halves the LDS reads and the
 // LDS-DMA instructions per MFMA -- on MI355X both cost matrix-pipe time (a DMA instruction does not issue while the
-// SIMD's other wave streams MFMAs, see fmx_gemm256.hip).  ~215 VGPRs -> 2 waves per SIMD, softmax VALU of one wave
+// SIMD's other wave streams MFMAs, tools/ubench/dma_rate.hip).  ~215 VGPRs -> 2 waves per SIMD, softmax VALU of one wave
 // under the MFMAs of the other.
 template <int PRIO>
 __global__ __launch_bounds__(256, 2) void attn_q64_kernel(const AttnParams p) {

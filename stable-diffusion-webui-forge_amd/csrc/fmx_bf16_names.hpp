@@ -5,14 +5,11 @@
 #define fmx_gemm_conv_f16 fmx_gemm_conv_bf16
 #define fmx_attention_f16 fmx_attention_bf16
 #define fmx_softmax_rows_f16 fmx_softmax_rows_bf16
-#define fmx_groupnorm_stats_f16 fmx_groupnorm_stats_bf16
-#define fmx_groupnorm_apply_f16 fmx_groupnorm_apply_bf16
 #define fmx_layernorm_f16 fmx_layernorm_bf16
 #define fmx_layernorm_padded_f16 fmx_layernorm_padded_bf16
 #define fmx_layernorm_mod_f16 fmx_layernorm_mod_bf16
 #define fmx_flux_qk_norm_rope_f16 fmx_flux_qk_norm_rope_bf16
 // host-side C++ symbols shared between the GEMM files
-#define fmx_launch_gemm256 fmx_launch_gemm256_bf16
 #define fmx_launch_gemm256p fmx_launch_gemm256p_bf16
 #define GemmParams GemmParamsBf16
 #define GemmEpilogue GemmEpilogueBf16

@@ -309,7 +309,10 @@ __global__ void geglu_interleave_kernel(const f16* __restrict__ w_in, const f16*
 
 }  // namespace
 
-extern "C" int fmx_gemm_conv_f16(const fmx_gemm_args* a, void* stream) {
+int fmx_launch_gn_stats(const void* x, int32_t c, int64_t ld, int32_t n, int32_t hw, float* partial, int32_t nchunks, hipStream_t st);  // fmx_norm.hip
+
+// stats != null: also leave the GroupNorm statistics of the output in stats[n][chunks][nout][2] (see fmx_gemm_conv_stats_f16 in fmx.h)
+static int gemm_conv_impl(const fmx_gemm_args* a, float* stats, int max_chunks, int fallback_chunks, int* chunks_out, void* stream) {
   FMX_REQUIRE(a && a->a0 && a->wgt && a->out && a->zero_page, "gemm: null pointer");
   const int ctot = a->c0 + a->c1;
   FMX_REQUIRE(a->c0 > 0 && a->c1 >= 0 && (a->c0 % 64) == 0 && (ctot % 64) == 0, "gemm: channels (%d,%d) must be multiples of 64", a->c0, a->c1);
@@ -338,6 +341,8 @@ extern "C" int fmx_gemm_conv_f16(const fmx_gemm_args* a, void* stream) {
   p.cpt = ctot / 64;
   p.kt = a->kh * a->kh * p.cpt;
   p.tiles_m = p.tiles_n = 0;
+  p.stats = nullptr;
+  p.stats_nch = 0;
   FMX_REQUIRE(fmx_aligned16(p.a0) && fmx_aligned16(p.wgt) && fmx_aligned16(p.zp) && (!p.a1 || fmx_aligned16(p.a1)), "gemm: operands must be 16-byte aligned");
   FMX_REQUIRE((p.s0 % 8) == 0 && (p.s1 % 8) == 0 && (p.ldw % 8) == 0, "gemm: strides must be multiples of 8 elements");
   FMX_REQUIRE((long)p.M * 1 > 0 && (long)a->n * a->oh * a->ow < (1L << 31), "gemm: M overflow");
@@ -361,7 +366,7 @@ extern "C" int fmx_gemm_conv_f16(const fmx_gemm_args* a, void* stream) {
   // element in K-tiles (it scales with the tile area), F = per-tile fixed latency (prologue + first loads, ~1.5 K-tiles of a
   // 256x256 tile; half of it hides behind the CU's other workgroup for the 4-wave kernels).  Padding rows / columns are
   // counted through the tile area.
-  // sel: 0 = 128x128, 1 = 128x64, 2 = 64x64, 4 = 128x160, 5 / 6 / 7 = 256x256 / 256x320 / 320x256 pipelined (3 = ping-pong, test hook)
+  // sel: 0 = 128x128, 1 = 128x64, 2 = 64x64, 4 = 128x160, 5 / 6 / 7 = 256x256 / 256x320 / 320x256 pipelined
   auto tiles = [&](int bm, int bn) { return (double)((p.M + bm - 1) / bm) * (double)((p.nout + bn - 1) / bn); };
   const double kt = p.kt;
   const bool geglu = a->act == FMX_ACT_GEGLU;
@@ -381,24 +386,50 @@ extern "C" int fmx_gemm_conv_f16(const fmx_gemm_args* a, void* stream) {
   if (big_ok && (!geglu || (p.nout % 32) == 0)) consider(6, cost(256, 320, 1, 1.0, e8, F8));
   if (big_ok && !geglu) consider(7, cost(320, 256, 1, 0.97, e8, F8));  // only where its row quantisation wins (M = 320 k: the V^T GEMM)
   if (a->out_f32 < 0) sel = (-a->out_f32 - 1) % 8;  // test hook: force a tile shape (out_f32 = -1..-8 -> fp16 out)
+  FMX_REQUIRE(sel != 3, "gemm: tile id 4 (the first-generation ping-pong kernel) is no longer part of the library");
   FMX_REQUIRE(sel != 4 || a->act != FMX_ACT_GEGLU, "gemm: the 128x160 tile does not support GEGLU");
   if (a->out_f32 < 0) p.out_f32 = 0;
-  if (sel == 3 || sel >= 5) {
-    FMX_REQUIRE(FastEpilogue::eligible8(p) && fits32, "gemm: 256x256 kernel needs fp16 output, 16-byte aligned epilogue operands, leading dimensions / nout multiples of 8, operands < 2^32 elements");
+  // output statistics: from the epilogue of a 256-row tile when every image is a whole number of tiles, else a pass behind the GEMM
+  const int per_img = a->oh * a->ow;
+  bool stats_after = false;
+  if (stats) {
+    FMX_REQUIRE(!geglu && !p.out_f32 && p.ld_out == p.nout && (p.nout % 8) == 0 && !p.gate && a->act == FMX_ACT_NONE,
+                "gemm: output statistics need a dense fp16 [M][nout] output without activation / gate");
+    FMX_REQUIRE(fallback_chunks >= 1 && fallback_chunks <= 1024 && max_chunks >= fallback_chunks, "gemm: bad statistics chunk counts");
+    if ((sel == 5 || sel == 6) && (per_img % 256) == 0 && per_img / 256 <= max_chunks) {
+      p.stats = stats;
+      p.stats_nch = per_img / 256;
+      *chunks_out = p.stats_nch;
+    } else {
+      stats_after = true;
+      *chunks_out = fallback_chunks;
+    }
+  }
+  int rc;
+  if (sel >= 5) {
+    FMX_REQUIRE(FastEpilogue::eligible8(p) && fits32, "gemm: the 256-row kernels need fp16 output, 16-byte aligned epilogue operands, leading dimensions / nout multiples of 8, operands < 2^32 elements");
     if (sel == 6) FMX_REQUIRE(a->act != FMX_ACT_GEGLU || (p.nout % 32) == 0, "gemm: GEGLU needs nout % 32 == 0");
-    return sel == 3 ? fmx_launch_gemm256(p, conv, st) : fmx_launch_gemm256p(p, conv, sel == 7 ? 320 : 256, sel == 6 ? 320 : 256, st);
-  }
-  if (sel == 4) return conv ? launch<128, 160, true>(p, st) : launch<128, 160, false>(p, st);
-  if (conv) {
-    if (sel == 0) return launch<128, 128, true>(p, st);
-    if (sel == 1) return launch<128, 64, true>(p, st);
-    return launch<64, 64, true>(p, st);
+    rc = fmx_launch_gemm256p(p, conv, sel == 7 ? 320 : 256, sel == 6 ? 320 : 256, st);
+  } else if (sel == 4) {
+    rc = conv ? launch<128, 160, true>(p, st) : launch<128, 160, false>(p, st);
+  } else if (conv) {
+    rc = sel == 0 ? launch<128, 128, true>(p, st) : sel == 1 ? launch<128, 64, true>(p, st) : launch<64, 64, true>(p, st);
   } else {
-    if (sel == 0) return launch<128, 128, false>(p, st);
-    if (sel == 1) return launch<128, 64, false>(p, st);
-    return launch<64, 64, false>(p, st);
+    rc = sel == 0 ? launch<128, 128, false>(p, st) : sel == 1 ? launch<128, 64, false>(p, st) : launch<64, 64, false>(p, st);
   }
+  if (rc != FMX_OK || !stats_after) return rc;
+  return fmx_launch_gn_stats(p.out, p.nout, p.ld_out, a->n, per_img, stats, fallback_chunks, st);
 }
+
+extern "C" int fmx_gemm_conv_f16(const fmx_gemm_args* a, void* stream) { return gemm_conv_impl(a, nullptr, 0, 0, nullptr, stream); }
+
+#ifndef FMX_ELEM_BF16  // GroupNorm exists on the fp16 (UNet / VAE) path only
+extern "C" int fmx_gemm_conv_stats_f16(const fmx_gemm_args* a, float* partial, int32_t max_chunks, int32_t fallback_chunks, int32_t* chunks_out,
+                                       void* stream) {
+  FMX_REQUIRE(partial && chunks_out, "gemm_conv_stats: null pointer");
+  return gemm_conv_impl(a, partial, max_chunks, fallback_chunks, chunks_out, stream);
+}
+#endif
 
 #ifndef FMX_ELEM_BF16  // a 16-bit row shuffle: one copy serves both element types
 extern "C" int fmx_geglu_interleave_rows(const void* w_in, const void* b_in, void* w_out, void* b_out, int32_t inner,

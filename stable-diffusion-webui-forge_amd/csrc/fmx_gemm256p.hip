@@ -1,9 +1,9 @@
 // 256 x BN-tile implicit-GEMM convolution / linear for gfx950, software-pipelined ("gemm256p"), BN = 256 or 320.
 //
-// Same LDS image, swizzle and LDS-DMA pieces as fmx_gemm256.hip; what differs is the schedule.  fmx_gemm256.hip alternates
-// two wave groups through 8 barrier-separated slots per K-tile (one group loads while the other owns the matrix pipe);
-// its s_memtime stamps (profiles/r02d_*) show every slot costing max(load, 8 MFMA) + barrier skew, 3000+ cycles per
-// K-tile against 2048 cycles of MFMA.  Here every wave runs ONE in-order stream with ONE barrier per K-tile:
+// The first-generation 8-wave kernel (tools/legacy/fmx_gemm256_pingpong.hip, no longer part of the library) alternated two wave
+// groups through 8 barrier-separated slots per K-tile (one group loads while the other owns the matrix pipe); its s_memtime
+// stamps (profiles/r02d_*) show every slot costing max(load, 8 MFMA) + barrier skew, 3000+ cycles per K-tile against 2048 cycles
+// of MFMA.  Here every wave runs ONE in-order stream with ONE barrier per K-tile:
 //
 //   BN = 256: waves 2 (M) x 4 (N), wave tile 128 x 64  = 4 x 2 accumulator blocks of 32 x 32,  8 MFMA / 6 ds_read per k-step
 //   BN = 320: waves 4 (M) x 2 (N), wave tile  64 x 160 = 2 x 5 blocks,                        10 MFMA / 7 ds_read per k-step
@@ -62,11 +62,14 @@ struct Geo {
 // makes every later global load wait (s_waitcnt vmcnt(0)) for every earlier store to COMPLETE -- one full store round trip
 // per iteration, 9-15 us of epilogue per tile (tools/clock_gemm.py).  The promise is safe here: an element is read and
 // written by the same lane only, and its store depends on its load through registers.
-// MODE 0: bias + rowvec + gate + residual;  1: bias + residual;  2: bias only (the absent operands cost a load each otherwise)
-template <int RB, int LPR, int ROWS, int SWZ, bool TANH, int MODE>
+// MODE 0: bias + rowvec + gate + residual;  1: bias + residual;  2: bias only (the absent operands cost a load each otherwise);
+// 3: bias + rowvec + residual, no gate (the statistics-emitting kernels: 8 registers fewer than MODE 0)
+// STATS: the lane also accumulates sum / sum of squares of the 8 columns it stores (of the ROUNDED fp16 values: what a statistics pass
+// over the stored tensor would read) into st[0..7] / st[8..15] -- the GroupNorm statistics of the output, see the kernel's epilogue.
+template <int RB, int LPR, int ROWS, int SWZ, bool TANH, int MODE, bool STATS = false>
 __device__ __forceinline__ void epi_rows(const char* my, int lane, int mbase, int M, int /*col*/, bool nok, int per_img, float alpha, float has_gate,
                                          const f16* __restrict__ bias, const f16* __restrict__ rowvec, long ld_rv, const f16* __restrict__ gate, long ld_gt,
-                                         const f16* __restrict__ res, long ld_res, f16* __restrict__ out, long ld_out) {
+                                         const f16* __restrict__ res, long ld_res, f16* __restrict__ out, long ld_out, float* st = nullptr) {
   constexpr int RPI = 64 / LPR;  // rows per wave instruction
   constexpr int ITERS = (ROWS + RPI - 1) / RPI;
   // opaque copy: keeps the compiler from hoisting the ITERS x 2 LDS offsets of EVERY call of this function above the whole
@@ -82,9 +85,9 @@ __device__ __forceinline__ void epi_rows(const char* my, int lane, int mbase, in
     const int m = mbase + row;
     const int mc = m < M ? m : M - 1;
     const int img = mc / per_img;
-    if (MODE == 0) rv[slot] = *reinterpret_cast<const f16x8*>(rowvec + img * ld_rv);
+    if (MODE == 0 || MODE == 3) rv[slot] = *reinterpret_cast<const f16x8*>(rowvec + img * ld_rv);
     if (MODE == 0) gt[slot] = *reinterpret_cast<const f16x8*>(gate + img * ld_gt);
-    if (MODE <= 1) rs[slot] = *reinterpret_cast<const f16x8*>(res + mc * ld_res);
+    if (MODE <= 1 || MODE == 3) rs[slot] = *reinterpret_cast<const f16x8*>(res + mc * ld_res);
   };
   fetch(0, 0);
 #pragma unroll
@@ -100,17 +103,30 @@ __device__ __forceinline__ void epi_rows(const char* my, int lane, int mbase, in
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       float v = (r < 4 ? lo[r & 3] : hi4[r & 3]) * alpha + (float)bb[r];
-      if (MODE == 0) v += (float)rv[cur][r];
+      if (MODE == 0 || MODE == 3) v += (float)rv[cur][r];
       if (TANH) v = gelu_tanh_f(v);
       if (MODE == 0) v *= fmaf(has_gate, (float)gt[cur][r] - 1.0f, 1.0f);
-      if (MODE <= 1) v += (float)rs[cur][r];
+      if (MODE <= 1 || MODE == 3) v += (float)rs[cur][r];
       hv[r] = (f16)v;
     }
     if (ok) *reinterpret_cast<f16x8*>(out + m * ld_out) = hv;
+    if (STATS) {
+      // every row of the tile is a valid output row here (the host only asks for statistics when M % 256 == 0), lanes with an
+      // out-of-range column or a row-lane >= RPI are dropped by the reduction that follows; only the last iteration can revisit a row
+      const bool fresh = (it + 1) * RPI <= ROWS || it * RPI + rsub < ROWS;
+      if (fresh) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const float f = (float)hv[r];
+          st[r] += f;
+          st[8 + r] = fmaf(f, f, st[8 + r]);
+        }
+      }
+    }
   }
 }
 
-template <bool CONV, int BM, int BN>
+template <bool CONV, int BM, int BN, bool STATS = false>
 __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   using G = Geo<BM, BN>;
   constexpr int MI = G::MI, NJ = G::NJ, NPA = G::NPA, NPB = G::NPB, NP = G::NP;
@@ -147,7 +163,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   const int r8 = lane >> 3;
   const int kc = (lane & 7) ^ ((((wave & 1) << 2) + (lane >> 4)) & 7);  // logical chunk (source side of the swizzle)
   const unsigned kcb = (unsigned)kc * 16u;
-  // buffer_load_dwordx4 ... lds: uniform descriptor + 32-bit byte offset; offsets >= OOB read as zeros (see fmx_gemm256.hip)
+  // buffer_load_dwordx4 ... lds: uniform descriptor + 32-bit byte offset; offsets >= OOB read as zeros (tools/ubench/oob_probe.hip)
   constexpr unsigned OOB = 0xC0000000u;
   const __amdgpu_buffer_rsrc_t rs_a0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(p.a0), 0, p.a0_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(p.a1 ? p.a1 : p.a0), 0, p.a1_bytes, 0x00020000);
@@ -327,7 +343,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
 #endif
 
   // ---- epilogue: through LDS, so that every global access is row-contiguous.  The MFMA leaves a lane with 4-channel runs of
-  //      ONE pixel; stored as they are (even widened to 16 B by a half-wave swap, as fmx_gemm256.hip does) every store
+  //      ONE pixel; stored as they are (even widened to 16 B by a half-wave swap) every store
   //      instruction scatters 32-byte pieces over 32 cache lines (transaction-bound, not bandwidth-bound).  Here each wave
   //      transposes its sub-tile through a private slice of the (now idle) LDS in fp32, one 32-row block row at a time
   //      (GEGLU: the whole sub-tile at once, it is half as wide), and NJ*4 (GEGLU: NJ*2) lanes then own one output row:
@@ -336,7 +352,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   __builtin_amdgcn_s_barrier();  // every wave is done reading the last stage: the LDS is free
   char* my = smem + wave * G::WAVE_EPI_BYTES;
   const FastEpilogue ep(p);
-  const bool geglu = p.act == FMX_ACT_GEGLU;
+  const bool geglu = !STATS && p.act == FMX_ACT_GEGLU;   // (no GEGLU code in the statistics-emitting kernels: registers)
   if (!geglu) {
     constexpr int RB = NJ * 128;       // staged row: NJ*32 fp32
     constexpr int LPR = NJ * 4;        // lanes per output row (8 columns each)
@@ -344,6 +360,9 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
     const int nb = n0 + wn * (NJ * 32) + cg * 8;
     const bool nok = nb < ep.nout;
     const int nbc = nok ? nb : 0;
+    float st[STATS ? 16 : 1];
+#pragma unroll
+    for (int r = 0; r < (STATS ? 16 : 1); ++r) st[r] = 0.f;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -357,12 +376,59 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
       // same wave wrote and reads: LDS operations of one wave execute in order, no barrier needed
       const int mbase = m0 + wm * (MI * 32) + i * 32;
 #define FMX_EPI_ARGS my, lane, mbase, p.M, nbc, nok, ep.per_img, ep.alpha, (float)ep.mgt, ep.bias + nbc * ep.mb, ep.rowvec + nbc * ep.mrv, ep.ld_rv, \
-                     ep.gate + nbc * ep.mgt, ep.ld_gt, ep.res + nbc * ep.mres, ep.ld_res, ep.out + nbc, ep.ld_out
-      if (ep.gelu_tanh) epi_rows<RB, LPR, 32, 7, true, 0>(FMX_EPI_ARGS);       // uniform branches
+                     ep.gate + nbc * ep.mgt, ep.ld_gt, ep.res + nbc * ep.mres, ep.ld_res, ep.out + nbc, ep.ld_out, st
+      if (STATS) {  // (the host refuses GELU-tanh / gate together with statistics)
+        if (ep.mrv) epi_rows<RB, LPR, 32, 7, false, 3, true>(FMX_EPI_ARGS);
+        else if (ep.mres) epi_rows<RB, LPR, 32, 7, false, 1, true>(FMX_EPI_ARGS);
+        else epi_rows<RB, LPR, 32, 7, false, 2, true>(FMX_EPI_ARGS);
+      } else if (ep.gelu_tanh) epi_rows<RB, LPR, 32, 7, true, 0>(FMX_EPI_ARGS);       // uniform branches
       else if (ep.mrv | ep.mgt) epi_rows<RB, LPR, 32, 7, false, 0>(FMX_EPI_ARGS);
       else if (ep.mres) epi_rows<RB, LPR, 32, 7, false, 1>(FMX_EPI_ARGS);
       else epi_rows<RB, LPR, 32, 7, false, 2>(FMX_EPI_ARGS);
 #undef FMX_EPI_ARGS
+    }
+    if (STATS) {
+      // GroupNorm statistics of this 256-row tile (= chunk `m0 % per_img / 256` of image `m0 / per_img`; the host guarantees
+      // per_img % 256 == 0 and M % 256 == 0).  A lane holds the sums of its 8 columns over the rows it stored.  Fold
+      //   (1) the RPI row-lanes of each column group inside the wave: through the wave's own LDS slice (idle now; LDS operations of
+      //       one wave execute in order, so no barrier is needed to reuse it),
+      //   (2) the WM waves that share the tile's columns: every wave leaves its sums at a fixed place of its slice, one barrier,
+      //       the wm == 0 wave adds them in wave order,
+      // and write {sum, sum of squares} per column: partial[(img * nch + chunk) * nout + col][2].  Fixed order -> deterministic.
+      constexpr int RPI = 64 / LPR;
+      float* sl = reinterpret_cast<float*>(my);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) *reinterpret_cast<f32x4*>(sl + lane * 16 + v * 4) = f32x4{st[v * 4], st[v * 4 + 1], st[v * 4 + 2], st[v * 4 + 3]};
+      if (lane < LPR) {
+        f32x4 a4[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) a4[v] = *reinterpret_cast<const f32x4*>(sl + lane * 16 + v * 4);
+#pragma unroll
+        for (int rs = 1; rs < RPI; ++rs)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) a4[v] += *reinterpret_cast<const f32x4*>(sl + (rs * LPR + lane) * 16 + v * 4);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) *reinterpret_cast<f32x4*>(sl + 1024 + lane * 16 + v * 4) = a4[v];
+      }
+      __syncthreads();
+      if (wm == 0 && lane < LPR && nok) {
+        f32x4 a4[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) a4[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w2 = 0; w2 < G::WM; ++w2) {
+          const float* o = reinterpret_cast<const float*>(smem + (w2 * G::WN + wn) * G::WAVE_EPI_BYTES) + 1024 + lane * 16;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) a4[v] += *reinterpret_cast<const f32x4*>(o + v * 4);
+        }
+        const int img = m0 / ep.per_img;
+        const int chunk = (m0 - img * ep.per_img) >> 8;
+        float* dst = p.stats + ((long)(img * p.stats_nch + chunk) * ep.nout + nb) * 2;   // a4[0..1] = sums, a4[2..3] = sums of squares
+        *reinterpret_cast<f32x4*>(dst) = f32x4{a4[0][0], a4[2][0], a4[0][1], a4[2][1]};
+        *reinterpret_cast<f32x4*>(dst + 4) = f32x4{a4[0][2], a4[2][2], a4[0][3], a4[2][3]};
+        *reinterpret_cast<f32x4*>(dst + 8) = f32x4{a4[1][0], a4[3][0], a4[1][1], a4[3][1]};
+        *reinterpret_cast<f32x4*>(dst + 12) = f32x4{a4[1][2], a4[3][2], a4[1][3], a4[3][3]};
+      }
     }
   } else {
     // weight rows are interleaved [16 value | 16 gate] per 32-row block: registers q4 = 0,1 of a block are the values of
@@ -423,21 +489,21 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
 #endif
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool STATS>
 int launch_bn(const GemmParams& p, bool conv, hipStream_t st) {
   using G = Geo<BM, BN>;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<true, BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<false, BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<true, BM, BN, STATS>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<false, BM, BN, STATS>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     attr_set = true;
   }
   GemmParams q = p;
   q.tiles_m = (p.M + BM - 1) / BM;
   q.tiles_n = (p.nout + BN - 1) / BN;
   const int grid = q.tiles_m * q.tiles_n;
-  if (conv) hipLaunchKernelGGL((gemm256p_kernel<true, BM, BN>), dim3(grid), dim3(512), G::LDS_BYTES, st, q);
-  else hipLaunchKernelGGL((gemm256p_kernel<false, BM, BN>), dim3(grid), dim3(512), G::LDS_BYTES, st, q);
+  if (conv) hipLaunchKernelGGL((gemm256p_kernel<true, BM, BN, STATS>), dim3(grid), dim3(512), G::LDS_BYTES, st, q);
+  else hipLaunchKernelGGL((gemm256p_kernel<false, BM, BN, STATS>), dim3(grid), dim3(512), G::LDS_BYTES, st, q);
   FMX_LAUNCH_CHECK("fmx_gemm_conv_f16 (256-row pipelined)");
   return FMX_OK;
 }
@@ -445,6 +511,7 @@ int launch_bn(const GemmParams& p, bool conv, hipStream_t st) {
 }  // namespace
 
 int fmx_launch_gemm256p(const GemmParams& p, bool conv, int bm, int bn, hipStream_t st) {
-  if (bm == 320) return launch_bn<320, 256>(p, conv, st);
-  return bn == 320 ? launch_bn<256, 320>(p, conv, st) : launch_bn<256, 256>(p, conv, st);
+  if (bm == 320) return launch_bn<320, 256, false>(p, conv, st);
+  if (p.stats) return bn == 320 ? launch_bn<256, 320, true>(p, conv, st) : launch_bn<256, 256, true>(p, conv, st);   // output statistics: 256-row tiles only
+  return bn == 320 ? launch_bn<256, 320, false>(p, conv, st) : launch_bn<256, 256, false>(p, conv, st);
 }

@@ -1,5 +1,5 @@
-// Shared pieces of the MFMA implicit-GEMM kernels (fmx_gemm.hip: 128x128 / 128x64 / 64x64 tiles, 4 waves;
-// fmx_gemm256.hip: 256x256 tile, 8 waves, ping-pong schedule): launch parameters and the fused epilogue.
+// Shared pieces of the MFMA implicit-GEMM kernels (fmx_gemm.hip: 128x128 / 128x160 / 128x64 / 64x64 tiles, 4 waves;
+// fmx_gemm256p.hip: 256x256 / 256x320 / 320x256 tiles, 8 waves, software-pipelined): launch parameters and the fused epilogue.
 #pragma once
 #include "fmx_common.hpp"
 
@@ -31,6 +31,8 @@ struct GemmParams {
   int cpt;          // K tiles per tap = (c0+c1)/64
   int tiles_m, tiles_n;
   unsigned a0_bytes, a1_bytes, w_bytes;  // operand extents for the buffer descriptors of the 256x256 kernel
+  float* stats;     // GroupNorm statistics of the output, partial[image][chunk][nout][2] (256-row tiles only; null = none)
+  int stats_nch;    // chunks per image = oh*ow / 256
 };
 
 // K-tile depth of every GEMM kernel: 64 halfs = one 128-byte LDS row.
@@ -203,7 +205,5 @@ __device__ __forceinline__ void swap_halfwaves(float& a, float& b) {
   b = __uint_as_float(r[1]);
 }
 
-// 256x256-tile kernel (fmx_gemm256.hip)
-int fmx_launch_gemm256(const GemmParams& p, bool conv, hipStream_t st);
 // same tile, software-pipelined single-barrier schedule (fmx_gemm256p.hip)
 int fmx_launch_gemm256p(const GemmParams& p, bool conv, int bm, int bn, hipStream_t st);  // (bm, bn) = (256,256) (256,320) (320,256)

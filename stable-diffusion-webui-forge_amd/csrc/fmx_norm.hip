@@ -7,21 +7,24 @@
 
 namespace {
 
-// ---- pass 1: per-(image, chunk, channel) partial sum / sum of squares ---------------------------------------
-// grid (nchunks, n); block 256 threads; thread t owns channel octet (t % oct) and walks pixels t / oct + k*ppb.
-__global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ x0, const f16* __restrict__ x1, int c0, int c1,
-                                                        int hw, float* __restrict__ partial, int nchunks) {
+#ifndef FMX_ELEM_BF16  // GroupNorm: fp16 (UNet / VAE) build only
+// ---- statistics: per-(image, chunk, channel) partial sum / sum of squares ------------------------------------------------
+// partial[img][chunk][c] = {sum x, sum x^2} over the chunk's pixels (fp32).  This kernel is the FALLBACK producer: the 256-row GEMM
+// tiles emit the same records from their epilogue (fmx_gemm256p.hip, one chunk = one 256-row tile), so that a GroupNorm whose input
+// was just written by a convolution never re-reads it for statistics.
+// grid (nchunks, n); block 256 threads; thread t owns channel octet (t % oct) and walks pixels t / oct + k*lanes, four independent
+// 16-byte loads in flight per thread (the kernel is latency-, not bandwidth-bound at 8 waves per CU otherwise).
+__global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ x, int c, long ld, int hw, float* __restrict__ partial,
+                                                        int nchunks) {
   extern __shared__ float sred[];  // [256][16] only when several pixel-lanes share an octet
-  const int C = c0 + c1;
-  const int oct = C >> 3;
+  const int oct = c >> 3;
   const int img = blockIdx.y, chunk = blockIdx.x;
   const int per = (hw + nchunks - 1) / nchunks;
   const int p_begin = chunk * per;
   const int p_end = min(hw, p_begin + per);
   const int tid = threadIdx.x;
-  float* out = partial + ((long)(img * nchunks + chunk) * C) * 2;
+  float* out = partial + ((long)(img * nchunks + chunk) * c) * 2;
 
-  // each "round" covers all octets with as many pixel lanes as fit in the block
   const int lanes = max(1, 256 / oct);          // pixel lanes per octet (when oct <= 256)
   for (int ob = 0; ob < oct; ob += 256) {       // octet blocks (oct > 256 only for C > 2048)
     const int my_oct = ob + (oct >= 256 ? tid : tid % oct);
@@ -32,14 +35,23 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ x
     for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
     const bool active = my_oct < oct && my_lane < nl;
     if (active) {
-      const int ch = my_oct * 8;
-      const f16* src;
-      int cs, co;
-      if (ch < c0) { src = x0; cs = c0; co = ch; } else { src = x1; cs = c1; co = ch - c0; }
-      src += (long)img * hw * cs + co;
-#pragma unroll 4
-      for (int px = p_begin + my_lane; px < p_end; px += nl) {
-        const f16x8 v = *reinterpret_cast<const f16x8*>(src + (long)px * cs);
+      const f16* src = x + (long)img * hw * ld + my_oct * 8;
+      int px = p_begin + my_lane;
+      for (; px + 3 * nl < p_end; px += 4 * nl) {
+        f16x8 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f16x8*>(src + (long)(px + u * nl) * ld);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float f = (float)v[u][e];
+            s[e] += f;
+            q[e] += f * f;
+          }
+      }
+      for (; px < p_end; px += nl) {
+        const f16x8 v = *reinterpret_cast<const f16x8*>(src + (long)px * ld);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float f = (float)v[e];
@@ -84,74 +96,55 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ x
   }
 }
 
-// ---- pass 1b: fold the chunk partials of one image into per-channel (scale, shift), ONCE (every apply block used to
-// redo this reduction -- ~20 us of dependent L2 loads in front of ~10 us of streaming on the small UNet tensors).
-// grid (n); fixed summation order (chunks, then the channels of a group) -> deterministic.  The result overwrites
-// chunk 0 of the image's partials: partial[img][0][c] = {scale, shift}.
-__global__ __launch_bounds__(1024) void gn_finalize_kernel(float* __restrict__ partial, int C, int nchunks, int groups, int hw, float eps,
-                                                           const f16* __restrict__ gamma, const f16* __restrict__ beta) {
-  extern __shared__ float fs[];  // [C][2] per-channel sums, then [groups][2] mean / rstd
-  float* csum = fs;
-  float* gstat = fs + 2 * C;
-  const int img = blockIdx.x, tid = threadIdx.x;
-  float* pimg = partial + (long)img * nchunks * C * 2;
-  for (int c = tid; c < C; c += 1024) {
-    // 4 independent accumulators (chunk index mod 4), combined in a fixed order: deterministic, and the loads of a
-    // channel are all in flight at once instead of one L2 round trip per chunk
-    float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
-    int ch = 0;
-    for (; ch + 4 <= nchunks; ch += 4) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const f32x2 v = *reinterpret_cast<const f32x2*>(pimg + ((long)(ch + u) * C + c) * 2);
-        s4[u] += v[0];
-        q4[u] += v[1];
-      }
-    }
-    for (int u = 0; ch < nchunks; ++ch, ++u) {
-      const f32x2 v = *reinterpret_cast<const f32x2*>(pimg + ((long)ch * C + c) * 2);
-      s4[u] += v[0];
-      q4[u] += v[1];
-    }
-    csum[c * 2] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-    csum[c * 2 + 1] = (q4[0] + q4[1]) + (q4[2] + q4[3]);
-  }
-  __syncthreads();
+// ---- finalize: fold the chunk partials of one (image, group) into per-channel (scale, shift) ---------------------------------------
+// grid (groups, n), one wave per block.  The channels of the (virtually concatenated) input come from up to two partial buffers with
+// their own chunk counts (the two producers may have tiled differently).  Item i of a group = (channel i / nch, chunk i % nch); lane l
+// takes items l, l + 64, ...; the wave sum is a fixed butterfly -> deterministic.  ss[img][c] = {rstd * gamma, beta - mean * rstd * gamma}.
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ p0, int nch0, int c0, const float* __restrict__ p1, int nch1, int c1,
+                                                          int groups, int hw, float eps, const f16* __restrict__ gamma, const f16* __restrict__ beta,
+                                                          float* __restrict__ ss) {
+  const int C = c0 + c1;
   const int cpg = C / groups;
-  for (int g = tid; g < groups; g += 1024) {
-    float s = 0.f, q = 0.f;
-    for (int c = 0; c < cpg; ++c) {
-      s += csum[(g * cpg + c) * 2];
-      q += csum[(g * cpg + c) * 2 + 1];
+  const int g = blockIdx.x, img = blockIdx.y, lane = threadIdx.x;
+  float s = 0.f, q = 0.f;
+  for (int ci = 0; ci < cpg; ++ci) {
+    const int c = g * cpg + ci;
+    const float* base;
+    int nch, cs, cc;
+    if (c < c0) { base = p0; nch = nch0; cs = c0; cc = c; } else { base = p1; nch = nch1; cs = c1; cc = c - c0; }
+    base += ((long)img * nch * cs + cc) * 2;
+    for (int ch = lane; ch < nch; ch += 64) {
+      const f32x2 v = *reinterpret_cast<const f32x2*>(base + (long)ch * cs * 2);
+      s += v[0];
+      q += v[1];
     }
-    const float cnt = (float)cpg * (float)hw;
-    const float mean = s / cnt;
-    const float var = fmaxf(q / cnt - mean * mean, 0.f);
-    gstat[g * 2] = mean;
-    gstat[g * 2 + 1] = rsqrtf(var + eps);
   }
-  __syncthreads();
-  for (int c = tid; c < C; c += 1024) {
-    const int g = c / cpg;
-    const float sc = gstat[g * 2 + 1] * (float)gamma[c];
-    *reinterpret_cast<f32x2*>(pimg + (long)c * 2) = f32x2{sc, (float)beta[c] - gstat[g * 2] * sc};
+  s = wave_sum(s);
+  q = wave_sum(q);
+  const float cnt = (float)cpg * (float)hw;
+  const float mean = s / cnt;
+  const float rstd = rsqrtf(fmaxf(q / cnt - mean * mean, 0.f) + eps);
+  for (int ci = lane; ci < cpg; ci += 64) {
+    const int c = g * cpg + ci;
+    const float sc = rstd * (float)gamma[c];
+    *reinterpret_cast<f32x2*>(ss + ((long)img * C + c) * 2) = f32x2{sc, (float)beta[c] - mean * sc};
   }
 }
 
-// ---- pass 2: normalise + affine (+ SiLU), writing the (concatenated) fp16 NHWC tensor -------------------------
-// grid (pixel tiles, n); per-channel scale/shift (from gn_finalize_kernel) are staged once per block in LDS.
-__global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x0, const f16* __restrict__ x1, int c0, int c1,
-                                                        int hw, const float* __restrict__ partial, int nchunks,
-                                                        int silu, f16* __restrict__ y, int pix_per_block) {
+// ---- apply: normalise + affine (+ SiLU), writing the (concatenated) fp16 NHWC tensor: 1 read + 1 write ---------------------------
+// grid (pixel tiles, n); the image's per-channel scale / shift are staged once per block in LDS; element i = tid + k*256 over the
+// (pixel, octet) grid, four independent 16-byte loads in flight per thread.
+__global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x0, const f16* __restrict__ x1, int c0, int c1, long ld0, long ld1,
+                                                        int hw, const float* __restrict__ ss_g, int silu, f16* __restrict__ y, int pix_per_block) {
   extern __shared__ float ss[];  // [C] scale, [C] shift
   const int C = c0 + c1;
   const int img = blockIdx.y;
   float* scale = ss;
   float* shift = ss + C;
   const int tid = threadIdx.x;
-  const float* pimg = partial + (long)img * nchunks * C * 2;
+  const float* simg = ss_g + (long)img * C * 2;
   for (int c = tid; c < C; c += 256) {
-    const f32x2 v = *reinterpret_cast<const f32x2*>(pimg + (long)c * 2);
+    const f32x2 v = *reinterpret_cast<const f32x2*>(simg + (long)c * 2);
     scale[c] = v[0];
     shift[c] = v[1];
   }
@@ -159,29 +152,44 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
   const int oct = C >> 3;
   const int p0 = blockIdx.x * pix_per_block;
   const int p1 = min(hw, p0 + pix_per_block);
-  // element i = tid + k*256 over the (pixel, octet) grid; walk (px, o) incrementally instead of dividing
+  // walk (px, o) incrementally instead of dividing
   int px = p0 + tid / oct;
   int o = tid - (tid / oct) * oct;
   const int dpx = 256 / oct, dov = 256 - dpx * oct;
+  const long ibase = (long)img * hw;
   while (px < p1) {
-    const int ch = o * 8;
-    const f16* src;
-    if (ch < c0) src = x0 + ((long)img * hw + px) * c0 + ch;
-    else src = x1 + ((long)img * hw + px) * c1 + (ch - c0);
-    const f16x8 v = *reinterpret_cast<const f16x8*>(src);
-    f16x8 r;
+    int pxs[4], chs[4];
+    f16x8 v[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float f = (float)v[e] * scale[ch + e] + shift[ch + e];
-      if (silu) f = silu_f(f);
-      r[e] = (f16)f;
+    for (int u = 0; u < 4; ++u) {
+      pxs[u] = px;
+      chs[u] = o * 8;
+      if (px < p1) {
+        const f16* src = (chs[u] < c0) ? x0 + (ibase + px) * ld0 + chs[u] : x1 + (ibase + px) * ld1 + (chs[u] - c0);
+        v[u] = *reinterpret_cast<const f16x8*>(src);
+      }
+      px += dpx;
+      o += dov;
+      if (o >= oct) { o -= oct; ++px; }
     }
-    *reinterpret_cast<f16x8*>(y + ((long)img * hw + px) * C + ch) = r;
-    px += dpx;
-    o += dov;
-    if (o >= oct) { o -= oct; ++px; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (pxs[u] < p1) {
+        const int ch = chs[u];
+        f16x8 r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float f = (float)v[u][e] * scale[ch + e] + shift[ch + e];
+          if (silu) f = silu_f(f);
+          r[e] = (f16)f;
+        }
+        *reinterpret_cast<f16x8*>(y + (ibase + pxs[u]) * C + ch) = r;
+      }
+    }
   }
 }
+
+#endif  // !FMX_ELEM_BF16
 
 // ---- LayerNorm: one wave per row, row kept in registers, exact two-pass mean/variance in fp32 -----------------
 // MOD = false: y = LN(x) * gamma + beta, row r written to output row (r / rows_per_b) * ld_mod + r % rows_per_b (token rows re-spaced
@@ -239,37 +247,49 @@ __global__ __launch_bounds__(256) void ln_kernel(const f16* __restrict__ x, cons
 
 }  // namespace
 
-extern "C" int fmx_groupnorm_stats_f16(const void* x0, const void* x1, int32_t c0, int32_t c1, int32_t n, int32_t hw,
-                                       float* partial, int32_t nchunks, void* stream) {
-  FMX_REQUIRE(x0 && partial && c0 > 0 && c1 >= 0 && (c0 % 8) == 0 && (c1 % 8) == 0 && n > 0 && hw > 0, "groupnorm_stats: bad args");
-  FMX_REQUIRE(c1 == 0 || x1, "groupnorm_stats: x1 missing");
-  FMX_REQUIRE(nchunks >= 1 && nchunks <= 256, "groupnorm_stats: nchunks out of range");
-  FMX_REQUIRE(fmx_aligned16(x0) && (!x1 || fmx_aligned16(x1)), "groupnorm_stats: alignment");
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, n), dim3(256), 256 * 16 * sizeof(float), (hipStream_t)stream,
-                     (const f16*)x0, (const f16*)x1, c0, c1, hw, partial, nchunks);
+#ifndef FMX_ELEM_BF16
+int fmx_launch_gn_stats(const void* x, int32_t c, int64_t ld, int32_t n, int32_t hw, float* partial, int32_t nchunks, hipStream_t st) {
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, n), dim3(256), 256 * 16 * sizeof(float), st, (const f16*)x, c, (long)ld, hw, partial, nchunks);
   FMX_LAUNCH_CHECK("fmx_groupnorm_stats_f16");
   return FMX_OK;
 }
 
-extern "C" int fmx_groupnorm_apply_f16(const void* x0, const void* x1, int32_t c0, int32_t c1, int32_t n, int32_t hw,
-                                       float* partial, int32_t nchunks, int32_t groups, float eps, const void* gamma,
-                                       const void* beta, int32_t silu, void* y, void* stream) {
-  FMX_REQUIRE(x0 && partial && gamma && beta && y, "groupnorm_apply: null pointer");
+extern "C" int fmx_groupnorm_stats_f16(const void* x, int32_t c, int64_t ld, int32_t n, int32_t hw, float* partial, int32_t nchunks, void* stream) {
+  FMX_REQUIRE(x && partial && c > 0 && (c % 8) == 0 && ld >= c && (ld % 8) == 0 && n > 0 && hw > 0, "groupnorm_stats: bad args");
+  FMX_REQUIRE(nchunks >= 1 && nchunks <= 1024, "groupnorm_stats: nchunks out of range");
+  FMX_REQUIRE(fmx_aligned16(x), "groupnorm_stats: alignment");
+  return fmx_launch_gn_stats(x, c, ld, n, hw, partial, nchunks, (hipStream_t)stream);
+}
+
+extern "C" int fmx_groupnorm_apply_f16(const void* x0, const void* x1, int32_t c0, int32_t c1, int64_t ld0, int64_t ld1, int32_t n, int32_t hw,
+                                       const float* partial0, int32_t nchunks0, const float* partial1, int32_t nchunks1, int32_t groups, float eps,
+                                       const void* gamma, const void* beta, int32_t silu, float* scale_shift, void* y, void* stream) {
+  FMX_REQUIRE(x0 && partial0 && gamma && beta && y && scale_shift, "groupnorm_apply: null pointer");
   const int C = c0 + c1;
   FMX_REQUIRE(c0 > 0 && c1 >= 0 && (c0 % 8) == 0 && (c1 % 8) == 0 && groups > 0 && (C % groups) == 0, "groupnorm_apply: bad channels");
-  FMX_REQUIRE(c1 == 0 || x1, "groupnorm_apply: x1 missing");
+  FMX_REQUIRE(c1 == 0 || (x1 && partial1 && nchunks1 >= 1), "groupnorm_apply: second source incomplete");
+  FMX_REQUIRE(nchunks0 >= 1 && n > 0 && hw > 0 && ld0 >= c0 && (ld0 % 8) == 0 && (c1 == 0 || (ld1 >= c1 && (ld1 % 8) == 0)), "groupnorm_apply: bad geometry");
   FMX_REQUIRE(fmx_aligned16(x0) && fmx_aligned16(y) && (!x1 || fmx_aligned16(x1)), "groupnorm_apply: alignment");
-  // ~64 KB of activations per block keeps >= 2k blocks in flight on the big tensors
+  FMX_REQUIRE((size_t)(2 * C) * sizeof(float) <= 160 * 1024, "groupnorm_apply: too many channels for the LDS scale/shift table");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, n), dim3(64), 0, st, partial0, nchunks0, c0, partial1, c1 ? nchunks1 : 1, c1, groups, hw, eps,
+                     (const f16*)gamma, (const f16*)beta, scale_shift);
+  // ~64 KB of activations per block (4 rounds of 4 x 16 bytes per thread) keeps >= 2k blocks in flight on the big tensors
   int ppb = (32768 + C - 1) / C;
   if (ppb < 1) ppb = 1;
   const int tiles = (hw + ppb - 1) / ppb;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(n), dim3(1024), (size_t)(2 * C + 2 * groups) * sizeof(float), (hipStream_t)stream,
-                     partial, C, nchunks, groups, hw, eps, (const f16*)gamma, (const f16*)beta);
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(tiles, n), dim3(256), (size_t)(2 * C) * sizeof(float), (hipStream_t)stream, (const f16*)x0,
-                     (const f16*)x1, c0, c1, hw, partial, nchunks, silu, (f16*)y, ppb);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_apply_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(tiles, n), dim3(256), (size_t)(2 * C) * sizeof(float), st, (const f16*)x0, (const f16*)x1, c0, c1,
+                     (long)ld0, (long)ld1, hw, scale_shift, silu, (f16*)y, ppb);
   FMX_LAUNCH_CHECK("fmx_groupnorm_apply_f16");
   return FMX_OK;
 }
+
+#endif  // !FMX_ELEM_BF16
 
 template <bool MOD>
 static int launch_ln(const void* x, const void* gamma, const void* beta, void* y, int64_t rows, int32_t c, float eps, long rows_per_b,

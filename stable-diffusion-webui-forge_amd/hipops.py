@@ -7,6 +7,7 @@ Temporary / output buffers come from the active `Arena` (runtime.py) when one is
 forward allocates nothing from HIP and can be captured into a HIP graph.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -126,11 +127,27 @@ def _elem(*ts):
     return ("_bf16", torch.bfloat16) if dt == torch.bfloat16 else ("_f16", torch.float16)
 
 
+class GnStats:
+    """GroupNorm statistics of one NHWC fp16 tensor: partial[n][nchunks][c][2] fp32 = {sum, sum of squares} per chunk of pixels."""
+    __slots__ = ("partial", "nchunks")
+
+    def __init__(self, partial, nchunks):
+        self.partial, self.nchunks = partial, nchunks
+
+
+# A/B knob (tools/bench_kernels.py, bench.py --breakdown): FMX_GN_FUSED_STATS=0 makes conv_gemm(stats=True) return no statistics, so that
+# every GroupNorm runs its own statistics pass as in round 1
+_FUSED_STATS = os.environ.get("FMX_GN_FUSED_STATS", "1") != "0"
+
+
 def conv_gemm(x, wgt, nout, *, x1=None, n=None, h=None, w=None, kh=1, stride=1, pad=0, up=None, bias=None,
               rowvec=None, residual=None, act=ACT_NONE, alpha=1.0, out=None, ld_out=None, out_dtype=None,
-              ldw=0, force_tile=0, gate=None, out_hw=None):
+              ldw=0, force_tile=0, gate=None, out_hw=None, stats=False, stats_partial=None):
     """OUT[M, ncols] = epilogue(A (*) W^T).  x: [N,H,W,C0] (or [M,C0] with kh == 1); x1: optional second source
-    concatenated along channels; wgt: [nout, kh*kh*(C0+C1)]; up=(UH, UW): nearest-resize before the conv."""
+    concatenated along channels; wgt: [nout, kh*kh*(C0+C1)]; up=(UH, UW): nearest-resize before the conv.
+    stats=True: returns (out, GnStats of out) -- the GroupNorm statistics of the output come out of the GEMM's epilogue (256-row tiles)
+    or of a pass behind it, fmx_gemm_conv_stats_f16; (out, None) when the knob above disables it.  stats_partial: a buffer from
+    `stats_buffer` when the statistics have to outlive the current arena scope (they live exactly as long as `out` must)."""
     sfx, elem = _elem(x, x1, wgt, bias, rowvec, residual, gate)
     fn_name = "fmx_gemm_conv" + sfx
     if out_dtype is None:
@@ -172,13 +189,29 @@ def conv_gemm(x, wgt, nout, *, x1=None, n=None, h=None, w=None, kh=1, stride=1, 
     a.zero_page = _p(zero_page(x.device))
     a.gate = _p(gate)
     a.ld_gate = gate.stride(0) if gate is not None else 0
+    st = None
+    if stats and _FUSED_STATS and sfx == "_f16":
+        hw = oh * ow
+        fb, cap = _stats_geometry(n_, hw)
+        partial = stats_partial if stats_partial is not None else empty((n_, cap, ncols, 2), torch.float32, x.device)
+        assert partial.dtype == torch.float32 and partial.numel() >= n_ * cap * ncols * 2
+        nch = C.c_int32(0)
+        st = GnStats(partial, 0)
+
+        def launch():
+            _lib.check(_lib.lib().fmx_gemm_conv_stats_f16(C.byref(a), _p(partial), cap, fb, C.byref(nch), stream_ptr()), "fmx_gemm_conv_stats_f16")
+            st.nchunks = nch.value
+    else:
+        def launch():
+            _lib.check(getattr(_lib.lib(), fn_name)(C.byref(a), stream_ptr()), fn_name)
     if _profiler is not None:
         flops = 2.0 * m * nout * kh * kh * (c0 + c1)
-        _profiler.launch("gemm_conv", flops, lambda: _lib.check(getattr(_lib.lib(), fn_name)(C.byref(a), stream_ptr()), fn_name),
-                         tag=f"M={m} N={nout} K={kh * kh * (c0 + c1)} kh={kh} s={stride}{' up' if up else ''}{' geglu' if act == ACT_GEGLU else ''}")
-        return out
-    _lib.check(getattr(_lib.lib(), fn_name)(C.byref(a), stream_ptr()), fn_name)
-    return out
+        _profiler.launch("gemm_conv", flops, launch,
+                         tag=f"M={m} N={nout} K={kh * kh * (c0 + c1)} kh={kh} s={stride}{' up' if up else ''}{' geglu' if act == ACT_GEGLU else ''}"
+                             f"{' +gnstats' if st is not None else ''}")
+    else:
+        launch()
+    return (out, st) if stats else out
 
 
 def linear(x, wgt, bias=None, **kw):
@@ -227,25 +260,75 @@ def softmax_rows_(x):
 
 
 def _gn_chunks(n, hw):
-    want = max(1, -(-512 // n))
-    return int(max(1, min(64, want, max(1, hw // 64))))
+    """chunks per image of the stand-alone statistics pass: >= 2048 blocks on the big tensors, >= 32 pixels per chunk"""
+    want = max(1, -(-2048 // n))
+    return int(max(1, min(1024, want, max(1, hw // 32))))
 
 
-def groupnorm(x, gamma, beta, eps, *, x1=None, silu=False, groups=32, out=None):
-    """x: [N, H, W, C0] (x1: [N, H, W, C1] concatenated after it) -> [N, H, W, C0+C1]"""
+def _stats_geometry(n, hw):
+    fb = _gn_chunks(n, hw)
+    return fb, max(fb, hw // 256 if hw % 256 == 0 else 0)
+
+
+def stats_buffer(n, hw, c, device=None):
+    """Workspace for the statistics of an [n, hw, c] tensor about to be produced by conv_gemm(stats=True, stats_partial=...)."""
+    return empty((n, _stats_geometry(n, hw)[1], c, 2), torch.float32, device)
+
+
+def attach_stats(t, st):
+    """Remember the producer's statistics on the tensor OBJECT (views and copies do not inherit them; whoever writes into the tensor in
+    place afterwards -- ControlNet residuals, Python hooks -- must call clear_stats)."""
+    t._fmx_gn_stats = st
+    return t
+
+
+def clear_stats(t):
+    if t is not None and getattr(t, "_fmx_gn_stats", None) is not None:
+        t._fmx_gn_stats = None
+    return t
+
+
+def groupnorm_stats(x):
+    """x: fp16 [N, H, W, C] / [N, HW, C] (pixel stride = x.stride(-2), channels contiguous) -> GnStats (stand-alone pass over the tensor)."""
+    _check_f16(x)
+    n, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (n * c)
+    nch = _gn_chunks(n, hw)
+    partial = empty((n, nch, c, 2), torch.float32, x.device)
+    _lib.check(_lib.lib().fmx_groupnorm_stats_f16(_p(x), c, x.stride(-2), n, hw, _p(partial), nch, stream_ptr()), "fmx_groupnorm_stats_f16")
+    return GnStats(partial, nch)
+
+
+def groupnorm(x, gamma, beta, eps, *, x1=None, silu=False, groups=32, out=None, stats=None, stats1=None):
+    """x: [N, H, W, C0] (x1: [N, H, W, C1] concatenated after it) -> [N, H, W, C0+C1].  stats / stats1: GnStats of x / x1 when their
+    producer left them (conv_gemm(stats=True)); a source without statistics gets its own pass here."""
     _check_f16(x, x1, gamma, beta)
     n = x.shape[0]
     hw = x.numel() // (n * x.shape[-1])
     c0 = x.shape[-1]
     c1 = x1.shape[-1] if x1 is not None else 0
-    nch = _gn_chunks(n, hw)
-    partial = empty((n, nch, c0 + c1, 2), torch.float32, x.device)
     if out is None:
         out = empty(tuple(x.shape[:-1]) + (c0 + c1,), torch.float16, x.device)
-    L = _lib.lib()
-    _lib.check(L.fmx_groupnorm_stats_f16(_p(x), _p(x1), c0, c1, n, hw, _p(partial), nch, stream_ptr()), "fmx_groupnorm_stats_f16")
-    _lib.check(L.fmx_groupnorm_apply_f16(_p(x), _p(x1), c0, c1, n, hw, _p(partial), nch, groups, float(eps), _p(gamma), _p(beta),
-                                         1 if silu else 0, _p(out), stream_ptr()), "fmx_groupnorm_apply_f16")
+
+    if stats is None:
+        stats = getattr(x, "_fmx_gn_stats", None)
+    if stats1 is None and x1 is not None:
+        stats1 = getattr(x1, "_fmx_gn_stats", None)
+
+    def run():
+        s0 = stats if stats is not None else groupnorm_stats(x)
+        s1 = (stats1 if stats1 is not None else groupnorm_stats(x1)) if x1 is not None else None
+        ss = empty((n, c0 + c1, 2), torch.float32, x.device)
+        _lib.check(_lib.lib().fmx_groupnorm_apply_f16(_p(x), _p(x1), c0, c1, x.stride(-2), x1.stride(-2) if x1 is not None else 0, n, hw,
+                                                      _p(s0.partial), s0.nchunks, _p(s1.partial) if s1 is not None else None,
+                                                      s1.nchunks if s1 is not None else 0, groups, float(eps), _p(gamma), _p(beta),
+                                                      1 if silu else 0, _p(ss), _p(out), stream_ptr()), "fmx_groupnorm_apply_f16")
+    if _profiler is not None:
+        have = (stats is not None) + (x1 is not None and stats1 is not None)
+        _profiler.launch("groupnorm", 0.0, run, tag=f"N={n} HW={hw} C={c0}+{c1} stats_from_producer={have}/{1 + (x1 is not None)}",
+                         nbytes=2.0 * 2 * n * hw * (c0 + c1))
+    else:
+        run()
     return out
 
 
@@ -314,6 +397,7 @@ def add_control_(h, ctrl, alpha=1.0):
     channels-last (the native ControlNet hands out NCHW views of NHWC buffers) is added elementwise; an NCHW-contiguous one goes through
     the transposing kernel."""
     b, hh, ww, c = h.shape
+    clear_stats(h)  # h changes in place: statistics its producer left are stale
     if tuple(ctrl.shape) != (b, c, hh, ww):
         raise ValueError(f"control residual {tuple(ctrl.shape)} does not match activation {(b, c, hh, ww)}")
     nhwc = ctrl.permute(0, 2, 3, 1)

@@ -84,6 +84,19 @@ def test_other_contract_violations(lib):
     assert lib.fmx_sampler_lincomb(p, p, 9, p, 16, None) == BADARG and "1..8" in err()
     assert lib.fmx_avgpool2x2_nhwc_f16(p, p, 1, 5, 4, 64, None) == BADARG and "even" in err()
     assert lib.fmx_act_f16(p, p, 16, 7, None) == BADARG                                          # unknown activation kind
+    # GroupNorm: a second source needs its own statistics; channel / group / stride geometry
+    f = C.c_void_p(FAKE)
+    assert lib.fmx_groupnorm_apply_f16(p, p, 64, 64, 64, 64, 1, 16, f, 1, None, 0, 32, 1e-5, p, p, 0, f, p, None) == BADARG and "second source" in err()
+    assert lib.fmx_groupnorm_apply_f16(p, None, 72, 0, 72, 0, 1, 16, f, 1, None, 0, 32, 1e-5, p, p, 0, f, p, None) == BADARG and "bad channels" in err()
+    assert lib.fmx_groupnorm_apply_f16(p, None, 64, 0, 60, 0, 1, 16, f, 1, None, 0, 32, 1e-5, p, p, 0, f, p, None) == BADARG and "geometry" in err()
+    assert lib.fmx_groupnorm_stats_f16(p, 64, 64, 1, 16, f, 2000, None) == BADARG and "nchunks" in err()
+    # statistics out of the GEMM: dense fp16 [M][nout] output without activation, sane chunk counts
+    nch = C.c_int32(0)
+    assert lib.fmx_gemm_conv_stats_f16(C.byref(_gemm(ld_out=128)), f, 4, 2, C.byref(nch), None) == BADARG and "statistics" in err()
+    assert lib.fmx_gemm_conv_stats_f16(C.byref(_gemm(ld_out=64, act=2)), f, 4, 2, C.byref(nch), None) == BADARG and "statistics" in err()
+    assert lib.fmx_gemm_conv_stats_f16(C.byref(_gemm(ld_out=64)), f, 1, 2, C.byref(nch), None) == BADARG and "chunk counts" in err()
+    assert lib.fmx_gemm_conv_stats_f16(C.byref(_gemm(ld_out=64)), None, 4, 2, C.byref(nch), None) == BADARG
+    assert lib.fmx_gemm_conv_f16(C.byref(_gemm(ld_out=64, out_f32=-4)), None) == BADARG and "no longer part" in err()   # the retired ping-pong tile id
     a = AttnArgs()
     a.q = a.k = a.vt = a.o = a.zero_page = FAKE
     a.batch, a.heads, a.nq, a.nk, a.nk_pad, a.dpad, a.scale = 1, 1, 64, 64, 64, 200, 0.1
