@@ -68,6 +68,35 @@ def bench_gn(n, h, w, c):
                       "GBps_touched(2R+1W)": round(3 * by / t / 1e9, 0)}), flush=True)
 
 
+def bench_gn_paths(n, h, w, c):
+    """GroupNorm + SiLU three ways: own statistics pass (stats + finalize + apply), on statistics the producer left (finalize + apply),
+    and the producer side: the same conv / linear with and without statistics in its epilogue."""
+    x, g, bb = rnd(n, h, w, c), rnd(c), rnd(c)
+    out = torch.empty_like(x)
+    by = x.numel() * 2
+    t_own = timeit(lambda: ops.groupnorm(x, g, bb, 1e-5, silu=True, out=out))
+    st = ops.groupnorm_stats(x)
+    t_st = timeit(lambda: ops.groupnorm_stats(x))
+    t_app = timeit(lambda: ops.groupnorm(x, g, bb, 1e-5, silu=True, out=out, stats=st))
+    print(json.dumps({"op": "groupnorm_silu", "n": n, "hw": [h, w], "c": c, "own_stats_us": round(t_own * 1e6, 1), "stats_pass_us": round(t_st * 1e6, 1),
+                      "apply_only_us": round(t_app * 1e6, 1), "apply_GBps(1R+1W)": round(2 * by / t_app / 1e9, 0),
+                      "own_GBps_alg(1R+1W)": round(2 * by / t_own / 1e9, 0), "stats_GBps(1R)": round(by / t_st / 1e9, 0)}), flush=True)
+
+
+def bench_gemm_stats(n, h, w, cin, co, kh):
+    x, wk, b = rnd(n, h, w, cin), rnd(co, kh * kh * cin, scale=(kh * kh * cin) ** -0.5), rnd(co)
+    res = rnd(n * h * w, co)
+    out = torch.empty(n * h * w, co, dtype=torch.float16, device=DEV)
+    part = ops.stats_buffer(n, h * w, co, device=DEV)
+    t0 = timeit(lambda: ops.conv_gemm(x, wk, co, kh=kh, pad=kh // 2, bias=b, residual=res, out=out, ld_out=co))
+    t1 = timeit(lambda: ops.conv_gemm(x, wk, co, kh=kh, pad=kh // 2, bias=b, residual=res, out=out, ld_out=co, stats=True, stats_partial=part))
+    _, st = ops.conv_gemm(x, wk, co, kh=kh, pad=kh // 2, bias=b, residual=res, out=out, ld_out=co, stats=True, stats_partial=part)
+    fl = 2.0 * n * h * w * co * kh * kh * cin
+    print(json.dumps({"op": "gemm_with_gn_stats", "n": n, "hw": [h, w], "cin": cin, "co": co, "kh": kh, "plain_us": round(t0 * 1e6, 1), "with_stats_us": round(t1 * 1e6, 1),
+                      "delta_us": round((t1 - t0) * 1e6, 1), "plain_tflops": round(fl / t0 / 1e12, 1), "with_stats_tflops": round(fl / t1 / 1e12, 1),
+                      "chunks": None if st is None else st.nchunks, "fused": st is not None and st.nchunks == (h * w) // 256}), flush=True)
+
+
 def bench_ln(rows, c):
     x, g, bb = rnd(rows, c), rnd(c), rnd(c)
     out = torch.empty_like(x)
@@ -93,6 +122,14 @@ def gemm_sweep():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "gn":
+        for shp in ((16, 128, 128, 320), (16, 128, 128, 640), (16, 64, 64, 640), (16, 64, 64, 1280), (16, 32, 32, 1280), (16, 32, 32, 2560), (8, 1024, 1024, 128),
+                    (8, 512, 512, 256), (8, 256, 256, 512), (2, 64, 64, 320)):
+            bench_gn_paths(*shp)
+        for shp in ((16, 32, 32, 1280, 1280, 1), (16, 64, 64, 640, 640, 1), (16, 128, 128, 320, 320, 1), (16, 32, 32, 1280, 1280, 3), (16, 64, 64, 640, 640, 3),
+                    (16, 128, 128, 320, 320, 3), (8, 512, 512, 256, 256, 3), (8, 1024, 1024, 128, 128, 3)):
+            bench_gemm_stats(*shp)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "attn":
         for f32 in (True, False):
             bench_attn(16, 10, 4096, 4096, 64, 64, f32)

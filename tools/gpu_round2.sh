@@ -1,0 +1,36 @@
+#!/bin/bash
+# Round-2 GPU-box visits.  usage (from repo root, through gpurun): bash tools/gpu_round2.sh <tag> <step> [<step> ...]
+TAG=${1:-r4}; shift
+R=${GRAFT_REPO_ROOT:-$PWD}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd $R
+pmc_pass() {  # $1 = pass name, $2.. = counters ; workload: tools/pmc_kernels.py
+  local name=$1; shift
+  (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --pmc "$@" -f csv -d $O/pmc_$name -o pmc -- python $R/tools/pmc_kernels.py 3 > $O/pmc_$name.log 2>&1)
+  tail -2 $O/pmc_$name.log
+  find $O/pmc_$name -name '*kernel_trace.csv' -delete
+  find $O/pmc_$name -name '*counter_collection.csv' -size +20M -delete
+}
+for w in "$@"; do
+  case $w in
+    tests) FMX_PARITY_LOG=$O/parity.jsonl timeout 1500 python -m pytest tests -m gpu -q -s 2>&1 | grep -v "^\[parity\]" | tail -60 > $O/pytest_gpu.log; tail -8 $O/pytest_gpu.log;;
+    testsx) FMX_PARITY_LOG=$O/parity.jsonl timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -40 > $O/pytest_gpu.log; tail -8 $O/pytest_gpu.log;;
+    ktests) timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q 2>&1 | tail -40 > $O/ktests.log; tail -12 $O/ktests.log;;
+    smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -3 $O/smoke.log;;
+    bench) timeout 1200 python bench.py --breakdown $O/breakdown.jsonl > $O/bench.json 2> $O/bench.err; cat $O/bench.json; tail -3 $O/bench.err;;
+    bench_nofuse) FMX_GN_FUSED_STATS=0 timeout 900 python bench.py --no-cpu-baseline --breakdown $O/breakdown_nofuse.jsonl > $O/bench_nofuse.json 2> $O/bench_nofuse.err; cat $O/bench_nofuse.json; tail -3 $O/bench_nofuse.err;;
+    bench_cfgs) for c in sd15-b4-eulera sdxl-b8-dpmpp2m30-vae flux-b2-bf16; do timeout 900 python bench.py --config $c --steps 8 > $O/bench_$c.json 2> $O/bench_$c.err; cat $O/bench_$c.json; tail -2 $O/bench_$c.err; done;;
+    gnbench) timeout 600 python tools/bench_kernels.py gn > $O/gnbench.log 2>&1; cat $O/gnbench.log | tail -30;;
+    attnbench) timeout 600 python tools/bench_kernels.py attn > $O/attnbench.log 2>&1; tail -20 $O/attnbench.log;;
+    prof) (cd /tmp && export TMPDIR=/tmp && timeout 1200 rocprofv3 --kernel-trace --stats -f csv -d $O/prof -o kt -- \
+            python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/prof_bench.log 2>&1); tail -2 $O/prof_bench.log;
+          find $O/prof -name '*kernel_trace.csv' -size +20M -delete; ls -la $O/prof/* | head;;
+    counters) (cd /tmp && export TMPDIR=/tmp && timeout 120 rocprofv3 -L > $O/counters_all.txt 2>&1); grep -i -o -E "\b(SQ_[A-Z0-9_]*(MFMA|BUSY|WAVE_CYCLES|INSTS_VALU|ACTIVE_INST|WAIT)[A-Z0-9_]*|GRBM_GUI_ACTIVE|GRBM_COUNT)\b" $O/counters_all.txt | sort -u > $O/counters_sq.txt; wc -l $O/counters_sq.txt; head -80 $O/counters_sq.txt;;
+    pmc_mfma) pmc_pass mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE;
+              pmc_pass waves SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA;;
+    pmc_hbm) for C in FETCH_SIZE WRITE_SIZE; do (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --pmc $C -f csv -d $O/pmc_$C -o pmc -- \
+            python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vae --no-roofline --no-graph > $O/pmc_$C.log 2>&1); tail -1 $O/pmc_$C.log; done;
+          python $R/tools/pmc_summary.py $O > $O/pmc_summary.json; cat $O/pmc_summary.json; find $O -name '*counter_collection.csv' -size +30M -delete; find $O -name '*kernel_trace.csv' -delete;;
+  esac
+done
