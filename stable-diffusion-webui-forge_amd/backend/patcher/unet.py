@@ -22,10 +22,21 @@ class UnetPatcher:
         from ..modules.k_model import KModel
         return cls(KModel(model, k_predictor), load_device=model.device, offload_device=model.device)
 
+    @staticmethod
+    def _copy_containers(o):
+        """Copy of the dict / list STRUCTURE of model_options; the leaves (hook callables, tensors, modules) stay shared.  The reference
+        deep-copies model_options in ModelPatcher.clone (backend/patcher/base.py:83); a copy of the containers is what that buys on this
+        path: `set_model_patch` / `append_transformer_option` on a clone append to the clone's own lists, never to its parent's."""
+        if isinstance(o, dict):
+            return {k: UnetPatcher._copy_containers(v) for k, v in o.items()}
+        if isinstance(o, list):
+            return [UnetPatcher._copy_containers(v) for v in o]
+        return o
+
     def clone(self):
         n = UnetPatcher(self.model, self.load_device, self.offload_device)
-        n.model_options = copy.copy(self.model_options)  # shallow, like ModelPatcher.clone (base.py:64-66): hooks are shared objects
-        n.model_options["transformer_options"] = dict(self.model_options.get("transformer_options", {}))
+        n.model_options = self._copy_containers(self.model_options)
+        n.model_options.setdefault("transformer_options", {})
         n.controlnet_linked_list = self.controlnet_linked_list
         n.extra_concat_condition = self.extra_concat_condition
         return n

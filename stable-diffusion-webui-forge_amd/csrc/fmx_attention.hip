@@ -32,9 +32,13 @@ struct AttnParams {
   float scale_log2e;
   int causal;
   const f16* zp;
+  unsigned k_span, vt_span;   // bytes addressable from a (batch, head)'s K / V^T base (q64v2: buffer descriptors), 0 = do not use
 };
 
 constexpr int KVB = 64;  // keys per tile
+
+template <int V>
+struct IC { static constexpr int value = V; };
 
 template <int CPR>
 __device__ __forceinline__ int k_phys_chunk(int row, int c) {
@@ -400,21 +404,294 @@ __global__ __launch_bounds__(256, 2) void attn_q64_kernel(const AttnParams p) {
   }
 }
 
+// ---- d_head 64, 64 queries per wave, second generation ("q64v2") ------------------------------------------------------
+// Same tiling and LDS image as attn_q64_kernel.  What changed is the VALU work per score, because the counters say the loop is
+// ISSUE-bound, not matrix-pipe- or exp-bound (profiles/r04a_pmc_*: 9.7 VALU instructions per MFMA -- a 32-cycle MFMA leaves ~7 issue
+// slots -- matrix pipe 39 % busy at N = 4096):
+//   * Q is pre-multiplied by scale * log2(e) once per workgroup, and each score chain gets one extra rank-2 MFMA k-step that adds
+//     minus the running maximum of its query (see `mfrag` below): the matrix pipe hands back  s*c - m  directly -- no
+//     multiply-subtract per score (64 v_fma per tile gone, for 4 more MFMAs on a pipe that is 39 % busy).
+//   * the running maximum moves only when a tile's scores exceed it by more than THR (log2 units; P stays below 2^THR, fp16 / bf16
+//     have the exponent range and the same relative precision there; sums and O are fp32): the O / l rescale, the refresh of the -m operand and
+//     the 64 subtractions that re-base an already computed tile run in that rare branch only.  The first tile always takes it
+//     (exact maximum, which may be negative: a row whose scores are all far below zero must not underflow).
+//   * the two LDS stages are unrolled (compile-time stage -> immediate LDS offsets, no per-tile address arithmetic), K / V^T tiles
+//     arrive by buffer_load ... lds with a uniform scalar offset per tile (no per-lane 64-bit addresses), the cross-half maximum
+//     exchange is one v_permlane32_swap instead of an LDS bpermute, and the epilogue stores 16 bytes per lane (half-wave swap).
+template <int THR>
+__global__ __launch_bounds__(256, 2) void attn_q64v2_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int DP = 64, DSTEPS = 4, DVT = 2;
+  constexpr int KBYTES = KVB * DP * 2;
+  constexpr int STAGE = KBYTES + DVT * 32 * 128;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, li = lane & 31;
+
+  const int nwg = p.qtiles * p.heads * p.batch;
+  const int wg = xcd_remap(blockIdx.x, nwg);
+  const int qt = wg % p.qtiles;
+  const int bh = wg / p.qtiles;
+  const int h = bh % p.heads, b = bh / p.heads;
+
+  const f16* kbase = p.k + (long)b * p.k_bs + (long)h * DP;
+  const f16* vbase = p.vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
+  // uniform descriptors; lanes past the extents read zeros (launch_attn_q64 guarantees the spans fit 32 bits)
+  const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(kbase), 0, p.k_span, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(vbase), 0, p.vt_span, 0x00020000);
+
+  const int q0 = qt * 256 + wave * 64;
+  const float c2 = p.scale_log2e;
+  f16x8 qf[2][DSTEPS];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int qrow = min(q0 + a * 32 + li, p.nq - 1);
+    const f16* qp = p.q + (long)b * p.q_bs + (long)qrow * p.q_rs + (long)h * DP + hi * 8;
+#pragma unroll
+    for (int ds = 0; ds < DSTEPS; ++ds) {
+      const f16x8 raw = *reinterpret_cast<const f16x8*>(qp + ds * 16);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qf[a][ds][e] = (f16)((float)raw[e] * c2);
+    }
+  }
+
+  // staging: K tile 64 rows x 8 chunks and V^T tile 64 rows x 8 chunks = 2 x 8 KiB, 2 + 2 DMA instructions per wave and tile;
+  // per-lane byte offsets are tile-invariant, the tile's key offset rides in the scalar offset operand
+  const int srow = lane >> 3, spc = lane & 7;
+  unsigned k_voff[2], v_voff[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int row = (e * 4 + wave) * 8 + srow;
+    const int c = spc ^ ((row >> 1) & 7);
+    k_voff[e] = (unsigned)row * (unsigned)p.k_rs * 2u + (unsigned)c * 16u;
+    v_voff[e] = (unsigned)row * (unsigned)p.vt_ds * 2u + (unsigned)c * 16u;
+  }
+  const unsigned k_tile = (unsigned)KVB * (unsigned)p.k_rs * 2u;
+  auto stage = [&](auto SI, int kt) {
+    constexpr int S = decltype(SI)::value;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      auto* dk = (__attribute__((address_space(3))) void*)(smem + S * STAGE + (e * 4 + wave) * 1024);
+      auto* dv = (__attribute__((address_space(3))) void*)(smem + S * STAGE + KBYTES + (e * 4 + wave) * 1024);
+      const unsigned kv = k_voff[e], vv = v_voff[e];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, dk, 16, kv, (unsigned)kt * k_tile, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, dv, 16, vv, (unsigned)kt * (KVB * 2u), 0, 0);
+    }
+  };
+
+  f32x16 oacc[DVT][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+      for (int i = 0; i < DVT; ++i) oacc[i][a][r] = 0.f;
+  float m_run[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};   // m_run in the log2 domain (scores arrive scaled)
+  // "- m" through the matrix pipe: one extra k-step per score chain whose A operand is 1 in k-slots 0 and 1 (every key row alike) and
+  // whose B operand carries -m split into an fp16 high and low part in those two slots (residual 2^-22 |m|; products with 1 are exact,
+  // the accumulation is fp32).  12 registers instead of a 32-register accumulator-shaped copy of the maxima.
+  f16x8 ones, mfrag[2];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    ones[e] = (f16)((hi == 0 && e < 2) ? 1.0f : 0.0f);
+    mfrag[0][e] = mfrag[1][e] = (f16)0.0f;
+  }
+
+  const int ntiles = (p.nk + KVB - 1) / KVB;
+  stage(IC<0>{}, 0);
+  wait_vmcnt0();
+  __syncthreads();
+
+  const int krow = key_perm(li);
+  auto tile = [&](auto SI, int kt) {
+    constexpr int S = decltype(SI)::value;
+    if (kt + 1 < ntiles) stage(IC<S ^ 1>{}, kt + 1);
+    const char* sk = smem + S * STAGE;
+    const char* sv = sk + KBYTES;
+
+    f32x16 sacc[2][2];  // [32-key sub-tile][query fragment] = score * c - running max
+    // Issue order of the score phase, pinned: the four K fragments of sub-tile 0, the two "- maximum" MFMAs, then two MFMAs per fragment
+    // with one fragment read of sub-tile 1 behind each pair (its register quad was just released), then sub-tile 1's eight MFMAs.  Left
+    // alone the compiler recycles ONE register quad and waits for every read in turn (16 exposed LDS round trips per tile).
+    __builtin_amdgcn_sched_barrier(0);
+    f16x8 kf[2][DSTEPS];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int ds = 0; ds < DSTEPS; ++ds) {
+        const int row = s * 32 + krow;
+        kf[s][ds] = *reinterpret_cast<const f16x8*>(sk + row * 128 + (k_phys_chunk<8>(row, ds * 2 + hi) << 4));
+      }
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      f32x16 z;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) z[r] = 0.f;
+      sacc[0][a] = FMX_MFMA_32x32x16(ones, mfrag[a], z);
+      sacc[1][a] = sacc[0][a];
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int ds = 0; ds < DSTEPS; ++ds)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) sacc[s][a] = FMX_MFMA_32x32x16(kf[s][ds], qf[a][ds], sacc[s][a]);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // DS read x4
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // MFMA x2 (- maximum)
+#pragma unroll
+    for (int ds = 0; ds < DSTEPS; ++ds) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if ((kt + 1) * KVB > p.nk) {  // ragged tail: mask keys >= nk (wave-uniform branch)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (kt * KVB + s * 32 + hi * 16 + r >= p.nk) sacc[s][a][r] = -INFINITY;
+    }
+    // how far does this tile stick out above the running maxima?
+    float mx[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      float m0 = fmaxf(sacc[0][a][0], sacc[1][a][0]);
+#pragma unroll
+      for (int r = 1; r < 16; ++r) m0 = fmaxf(fmaxf(m0, sacc[0][a][r]), sacc[1][a][r]);
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m0), __float_as_uint(m0), false, false);
+      mx[a] = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));   // {own, other half-wave's} in some order
+    }
+    const bool first = kt == 0;
+    if (first || __any(fmaxf(mx[0], mx[1]) > (float)THR)) {   // wave-uniform; rare after the first few tiles
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        // the first tile sets the maximum exactly (it may be negative); later ones only raise it
+        const float delta = first ? mx[a] : fmaxf(mx[a], 0.f);
+        const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);
+        m_run[a] += delta;
+        l_run[a] *= alpha;
+        const f16 mh = (f16)(-m_run[a]);
+        const f16 ml = (f16)(-m_run[a] - (float)mh);
+        mfrag[a][0] = hi == 0 ? mh : (f16)0.0f;
+        mfrag[a][1] = hi == 0 ? ml : (f16)0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#pragma unroll
+          for (int i = 0; i < DVT; ++i) oacc[i][a][r] *= alpha;
+#pragma unroll
+          for (int s = 0; s < 2; ++s) sacc[s][a][r] -= delta;
+        }
+      }
+    }
+    f16x8 pf[2][2][2];  // [query fragment][sub-tile][8-key half]
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = __builtin_amdgcn_exp2f(sacc[s][a][r]);
+          if (s == 0) ps0 += e; else ps1 += e;
+          pf[a][s][r >> 3][r & 7] = (f16)e;
+        }
+      l_run[a] += ps0 + ps1;
+    }
+
+    // ---- O^T += V^T P^T, same discipline: four V^T fragments up front, the other four behind the first eight MFMAs ----
+    __builtin_amdgcn_sched_barrier(0);
+    f16x8 vf[DVT][2][2];
+#pragma unroll
+    for (int dt = 0; dt < DVT; ++dt) {
+      const int row = dt * 32 + li;
+      const char* rp = sv + row * 128;
+      const int sw = (row >> 1) & 7;
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) vf[dt][s][j] = *reinterpret_cast<const f16x8*>(rp + (((s * 4 + hi * 2 + j) ^ sw) << 4));
+    }
+#pragma unroll
+    for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int a = 0; a < 2; ++a) oacc[dt][a] = FMX_MFMA_32x32x16(vf[dt][s][j], pf[a][s][j], oacc[dt][a]);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    wait_vmcnt0();
+    __syncthreads();
+  };
+  for (int kt = 0; kt < ntiles; kt += 2) {
+    tile(IC<0>{}, kt);
+    if (kt + 1 < ntiles) tile(IC<1>{}, kt + 1);
+  }
+
+  // ---- finish: 1/l, O[b][q][h*64 + d]; lane = query.  A lane holds 4-wide runs of d (registers g*4.., d = dt*32 + g*8 + hi*4); one
+  //      half-wave swap per register pair turns two 8-byte pieces into one 16-byte store per lane ------------------------------------
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const u32x2 lw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run[a]), __float_as_uint(l_run[a]), false, false);
+    const float inv = 1.0f / (__uint_as_float(lw[0]) + __uint_as_float(lw[1]));
+    const int qg = q0 + a * 32 + li;
+    f16* op = p.o + (long)b * p.o_bs + (long)qg * p.o_rs + (long)h * DP;
+#pragma unroll
+    for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; g += 2) {
+        union { f16x4 h4; unsigned u[2]; } lo, up;   // groups g and g + 1 of this lane
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          lo.h4[e] = (f16)(oacc[dt][a][g * 4 + e] * inv);
+          up.h4[e] = (f16)(oacc[dt][a][(g + 1) * 4 + e] * inv);
+        }
+        // lanes 0-31 end up with [own group g | upper half's group g] = columns g*8 .. g*8+7; lanes 32-63 with
+        // [lower half's group g+1 | own group g+1] = columns (g+1)*8 .. (g+1)*8+7
+        const u32x2 x = __builtin_amdgcn_permlane32_swap(lo.u[0], up.u[0], false, false);
+        const u32x2 y = __builtin_amdgcn_permlane32_swap(lo.u[1], up.u[1], false, false);
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = {x[0], y[0], x[1], y[1]};
+        if (qg < p.nq) *reinterpret_cast<u32x4*>(op + dt * 32 + (g + hi) * 8) = v;
+      }
+  }
+}
+
 int launch_attn_q64(AttnParams p, hipStream_t st) {
   const int smem = 2 * (KVB * 64 * 2 + 2 * 32 * 128);
-  static int prio = -1;
-  if (prio < 0) {
-    // A/B knob (tools/bench_kernels.py attn): s_setprio flips around the MFMA bursts.  Measured on MI355X: without them
-    // 811 vs 793 TF/s at N = 4096 -- the partner wave's softmax VALU starves behind a prioritised MFMA stream -- so default off.
-    const char* e = getenv("FMX_ATTN_PRIO");
-    prio = e ? atoi(e) : 0;
+  static int variant = -1;
+  if (variant < 0) {
+    // A/B knob (tools/bench_kernels.py attn): FMX_ATTN_VARIANT=1 selects the first-generation kernel (round 1: 823 / 729 TFLOP/s at
+    // N = 4096 / 1024), 0 (default) the second-generation one.
+    const char* e = getenv("FMX_ATTN_VARIANT");
+    variant = e ? atoi(e) : 0;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_q64_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_q64_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_q64v2_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   }
   p.qtiles = (p.nq + 255) / 256;
   const int grid = p.qtiles * p.heads * p.batch;
-  if (prio == 1) hipLaunchKernelGGL(attn_q64_kernel<1>, dim3(grid), dim3(256), smem, st, p);
-  else hipLaunchKernelGGL(attn_q64_kernel<0>, dim3(grid), dim3(256), smem, st, p);
+  // 32-bit byte offsets from the (batch, head) bases: K rows 0 .. nk_pad-1, V^T rows 0 .. 63 with nk_pad keys each
+  const double k_span = ((double)(p.nk_pad - 1) * p.k_rs + 64) * 2.0, v_span = (63.0 * p.vt_ds + p.nk_pad) * 2.0;
+  if (variant == 0 && k_span < 2.0e9 && v_span < 2.0e9 && p.k_rs > 0 && p.vt_ds > 0) {
+    p.k_span = (unsigned)k_span;
+    p.vt_span = (unsigned)v_span;
+    hipLaunchKernelGGL(attn_q64v2_kernel<6>, dim3(grid), dim3(256), smem, st, p);
+  } else {
+    hipLaunchKernelGGL(attn_q64_kernel<0>, dim3(grid), dim3(256), smem, st, p);
+  }
   FMX_LAUNCH_CHECK("fmx_attention_f16 (q64)");
   return FMX_OK;
 }
@@ -476,6 +753,7 @@ extern "C" int fmx_attention_f16(const fmx_attn_args* a, void* stream) {
   p.scale_log2e = fabsf(a->scale) * 1.44269504088896340736f;
   p.zp = (const f16*)a->zero_page;
   p.causal = a->causal ? 1 : 0;
+  p.k_span = p.vt_span = 0;
   FMX_REQUIRE(!p.causal || a->nq == a->nk, "attention: the causal mask is defined for self-attention (nq == nk)");
   hipStream_t st = (hipStream_t)stream;
   switch (a->dpad) {

@@ -75,6 +75,21 @@ class KernelProfiler:
         return out
 
 
+# developer hook: FMX_DEBUG_NAN=1 synchronises after every GEMM / norm / attention launch (outside graph capture) and raises at the first
+# non-finite output -- pinpoints the producing kernel; never set in production (it serialises the stream)
+_DEBUG_NAN = os.environ.get("FMX_DEBUG_NAN") == "1"
+
+
+def _dbg(what, **tensors):
+    if not _DEBUG_NAN or torch.cuda.is_current_stream_capturing():
+        return
+    torch.cuda.synchronize()
+    for k, t in tensors.items():
+        if t is not None and not bool(torch.isfinite(t.float()).all()):
+            bad = (~torch.isfinite(t.float())).nonzero()
+            raise FloatingPointError(f"{what}: {k} {tuple(t.shape)} has {bad.shape[0]} non-finite values, first at {bad[0].tolist()}")
+
+
 def set_allocator(fn):
     global _alloc
     prev = _alloc
@@ -211,6 +226,8 @@ def conv_gemm(x, wgt, nout, *, x1=None, n=None, h=None, w=None, kh=1, stride=1, 
                              f"{' +gnstats' if st is not None else ''}")
     else:
         launch()
+    _dbg(f"conv_gemm M={m} N={nout} K={kh * kh * (c0 + c1)} stats={st is not None and st.nchunks}", out=out,
+         partial=None if st is None else st.partial.reshape(-1)[:n_ * st.nchunks * ncols * 2])
     return (out, st) if stats else out
 
 
@@ -329,6 +346,7 @@ def groupnorm(x, gamma, beta, eps, *, x1=None, silu=False, groups=32, out=None, 
                          nbytes=2.0 * 2 * n * hw * (c0 + c1))
     else:
         run()
+    _dbg(f"groupnorm N={n} HW={hw} C={c0}+{c1} stats={'producer' if stats is not None else 'own'}/{'producer' if stats1 is not None else 'own'}", out=out)
     return out
 
 

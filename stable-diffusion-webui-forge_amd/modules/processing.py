@@ -267,6 +267,8 @@ class StableDiffusionProcessingImg2Img(StableDiffusionProcessingTxt2Img):
 
 def _slice_cond(c, a, b):
     from .prompt_parser import MulticondLearnedConditioning
+    if c is None:   # no unconditional batch: setup_conds leaves uc = None at cfg_scale 1 (modules/processing.py:480-483 of the reference)
+        return None
     if isinstance(c, dict):
         return type(c)({k: v[a:b] for k, v in c.items()})
     if isinstance(c, MulticondLearnedConditioning):
