@@ -66,7 +66,9 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
   return base + (orig >> 3);
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) with the hardware reciprocal (1 ulp): the IEEE division of `x / (1 + e^-x)` is a 10-instruction sequence per element, which made
+// the HBM-bound GroupNorm+SiLU pass VALU-bound (profiles/r04a_pmc_*: VALU issue 50 % of the kernel's cycles)
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // exact-erf GELU (backend/nn/unet.py:111 F.gelu default).  erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far
 // below the fp16 rounding of the result): branch-free, one rcp + one exp -- libm's erff is ~60 instructions with
 // divergent branches, which made the GEGLU epilogue a measurable fraction of the ff1 GEMM.

@@ -134,9 +134,10 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
 // ---- apply: normalise + affine (+ SiLU), writing the (concatenated) fp16 NHWC tensor: 1 read + 1 write ---------------------------
 // grid (pixel tiles, n); the image's per-channel scale / shift are staged once per block in LDS; element i = tid + k*256 over the
 // (pixel, octet) grid, four independent 16-byte loads in flight per thread.
+template <bool SILU>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x0, const f16* __restrict__ x1, int c0, int c1, long ld0, long ld1,
-                                                        int hw, const float* __restrict__ ss_g, int silu, f16* __restrict__ y, int pix_per_block) {
-  extern __shared__ float ss[];  // [C] scale, [C] shift
+                                                        int hw, const float* __restrict__ ss_g, f16* __restrict__ y, int pix_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float ss[];  // [C] scale, [C] shift
   const int C = c0 + c1;
   const int img = blockIdx.y;
   float* scale = ss;
@@ -176,11 +177,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
     for (int u = 0; u < 4; ++u) {
       if (pxs[u] < p1) {
         const int ch = chs[u];
+        const f32x4 sc0 = *reinterpret_cast<const f32x4*>(scale + ch), sc1 = *reinterpret_cast<const f32x4*>(scale + ch + 4);
+        const f32x4 sh0 = *reinterpret_cast<const f32x4*>(shift + ch), sh1 = *reinterpret_cast<const f32x4*>(shift + ch + 4);
         f16x8 r;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          float f = (float)v[u][e] * scale[ch + e] + shift[ch + e];
-          if (silu) f = silu_f(f);
+          float f = fmaf((float)v[u][e], e < 4 ? sc0[e & 3] : sc1[e & 3], e < 4 ? sh0[e & 3] : sh1[e & 3]);
+          if (SILU) f = silu_f(f);
           r[e] = (f16)f;
         }
         *reinterpret_cast<f16x8*>(y + (ibase + pxs[u]) * C + ch) = r;
@@ -280,11 +283,16 @@ extern "C" int fmx_groupnorm_apply_f16(const void* x0, const void* x1, int32_t c
   const int tiles = (hw + ppb - 1) / ppb;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_apply_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_apply_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_apply_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(tiles, n), dim3(256), (size_t)(2 * C) * sizeof(float), st, (const f16*)x0, (const f16*)x1, c0, c1,
-                     (long)ld0, (long)ld1, hw, scale_shift, silu, (f16*)y, ppb);
+  if (silu)
+    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(tiles, n), dim3(256), (size_t)(2 * C) * sizeof(float), st, (const f16*)x0, (const f16*)x1, c0, c1,
+                       (long)ld0, (long)ld1, hw, scale_shift, (f16*)y, ppb);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(tiles, n), dim3(256), (size_t)(2 * C) * sizeof(float), st, (const f16*)x0, (const f16*)x1, c0, c1,
+                       (long)ld0, (long)ld1, hw, scale_shift, (f16*)y, ppb);
   FMX_LAUNCH_CHECK("fmx_groupnorm_apply_f16");
   return FMX_OK;
 }

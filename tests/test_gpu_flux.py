@@ -156,7 +156,7 @@ def test_bf16_gemm_epilogues_all_tile_families():
     lin = x.float() @ w.float().t() + bias.float()
     ref_gate = lin.view(bsz, l, n) * gate.float()[:, None] + res.float().view(bsz, l, n)
     # 0 = the dispatcher's choice; forced: 4-wave 128x128 / 128x64 / 64x64, ping-pong 256x256, 128x160, pipelined 256x256 / 256x320 / 320x256
-    for tile in (0, 1, 2, 3, 4, 5, 6, 7, 8):
+    for tile in (0, 1, 2, 3, 5, 6, 7, 8):
         out = ops.conv_gemm(x, w, n, n=bsz, h=1, w=l, bias=bias, gate=gate, residual=res, force_tile=tile)
         assert out.dtype == BF
         close(out.view(bsz, l, n), ref_gate, 1e-2, 1e-2, f"bf16 gate epilogue, tile {tile}")
