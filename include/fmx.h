@@ -11,7 +11,8 @@
  *                          nearest Upsample+conv backend/nn/unet.py:340-355, backend/nn/vae.py:35-57 ;
  *                          torch.cat([h, hsp]) backend/nn/unet.py:741 (two-source A operand) ;
  *                          GEGLU backend/nn/unet.py:104-111 ; ResBlock emb add / skip add :469-478
- *   fmx_attention_f16      attention_function  backend/attention.py:324-339 (and :37-93)
+ *   fmx_attention_f16      attention_function  backend/attention.py:324-339 (and :37-93, incl. its additive / bool `mask`)
+ *   fmx_strided_copy4      the reshape / permute / .to(dtype) around it: backend/attention.py:51-60,90-93,330-338,415-418
  *   fmx_softmax_rows_f16   sim.softmax(dim=-1) backend/attention.py:85 (materialised-score variant)
  *   fmx_groupnorm_*        F.group_norm backend/operations.py:308 (+ SiLU backend/nn/unet.py:394-398)
  *   fmx_layernorm_f16      F.layer_norm backend/operations.py:327
@@ -140,6 +141,11 @@ typedef struct fmx_attn_args {
   float scale;
   int32_t causal; /* 1: key j attends only for j <= query i (CLIP text encoder, transformers causal mask); occupies former padding */
   const void* zero_page;
+  /* optional additive mask (attention_function's `mask`, backend/attention.py:74-88 / SDPA attn_mask): fp16, added to the score before the
+   * softmax, element (b, h, i, j) at mask[b*mask_bs + h*mask_hs + i*mask_qs + j]; a stride of 0 broadcasts that dimension; every addressed row
+   * holds nk_pad keys; 16-byte aligned, strides % 8 == 0.  -inf entries mask a key out (a bool mask is converted by fmx_strided_copy4). */
+  const void* mask;
+  int64_t mask_bs, mask_hs, mask_qs;
 } fmx_attn_args;
 
 int fmx_attention_f16(const fmx_attn_args* args /* host */, void* stream);
@@ -210,6 +216,13 @@ int fmx_add_scaled_f16(void* h, const void* c, int32_t c_is_f32, float alpha, in
 /* 2x2 / stride-2 average pooling on fp16 NHWC [n][h][w][c] (h, w even): the conv-less Downsample of backend/nn/cnets/t2i_adapter.py:42-62 */
 int fmx_avgpool2x2_nhwc_f16(const void* x, void* y, int32_t n, int32_t h, int32_t w, int32_t c, void* stream);
 int fmx_cast_f32_to_f16(const float* x, void* y, int64_t n, void* stream);
+
+/* Strided 4-D copy with element conversion -- the layout adapter of the attention- and op-level drop-ins (backend/attention.py:324-339 takes
+ * [B, N, heads*d] or [B, heads, N, d] in any float type; the ForgeOperations modules take NCHW): dst[i0][i1][i2][i3] = convert(src[...]) for
+ * i < dims, element strides per tensor (host arrays of 4).  kinds: 0 fp16, 1 fp32, 2 bf16; source kind 3 = bool "attend" mask (1 byte per
+ * element) -> 0 / -inf.  Padding of the destination is the caller's (zero it first). */
+int fmx_strided_copy4(const void* src, int32_t src_kind, const int64_t* src_strides /* host[4] */, void* dst, int32_t dst_kind,
+                      const int64_t* dst_strides /* host[4] */, const int32_t* dims /* host[4] */, void* stream);
 /* y = act(x), fp16, kind 0 = quick_gelu x*sigmoid(1.702x) (CLIP-L), 1 = exact erf GELU (CLIP-G), 2 = ReLU (T2I-Adapter ResnetBlock) */
 int fmx_act_f16(const void* x, void* y, int64_t n, int32_t kind, void* stream);
 /* CLIP text embeddings (transformers CLIPTextEmbeddings): out[b*T + t][:] = tok_emb[ids[b*T + t]][:] + pos_emb[t][:], fp16, c % 8 == 0 */

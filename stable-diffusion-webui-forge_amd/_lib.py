@@ -45,6 +45,7 @@ class AttnArgs(C.Structure):
         ("vt_bs", C.c_int64), ("vt_hs", C.c_int64), ("vt_ds", C.c_int64), ("o_bs", C.c_int64), ("o_rs", C.c_int64),
         ("batch", C.c_int32), ("heads", C.c_int32), ("nq", C.c_int32), ("nk", C.c_int32), ("nk_pad", C.c_int32),
         ("dpad", C.c_int32), ("scale", C.c_float), ("causal", C.c_int32), ("zero_page", C.c_void_p),
+        ("mask", C.c_void_p), ("mask_bs", C.c_int64), ("mask_hs", C.c_int64), ("mask_qs", C.c_int64),
     ]
 
 
@@ -72,6 +73,7 @@ SIGNATURES = {
     "fmx_embed_tokens": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "fmx_add_control_nchw": [_vp, _vp, _i32, _i32, _i64, _vp],
     "fmx_cast_f32_to_f16": [_vp, _vp, _i64, _vp],
+    "fmx_strided_copy4": [_vp, _i32, C.POINTER(C.c_int64), _vp, _i32, C.POINTER(C.c_int64), C.POINTER(C.c_int32), _vp],
     "fmx_unet_pack_input": [_vp, _vp, _f32, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "fmx_cfg_combine": [_vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _i32, _f32, _vp],
     "fmx_sampler_euler_step": [_vp, _vp, _f32, _f32, _vp, _f32, _vp, _i64, _vp],

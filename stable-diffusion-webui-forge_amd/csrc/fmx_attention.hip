@@ -33,6 +33,9 @@ struct AttnParams {
   int causal;
   const f16* zp;
   unsigned k_span, vt_span;   // bytes addressable from a (batch, head)'s K / V^T base (q64v2: buffer descriptors), 0 = do not use
+  const f16* mask;            // optional additive mask, element (b, h, i, j) at mask[b*mask_bs + h*mask_hs + i*mask_qs + j] (strides may be 0)
+  long mask_bs, mask_hs, mask_qs;
+  float inv_scale;            // 1 / scale: the mask is added to the UNSCALED score
 };
 
 constexpr int KVB = 64;  // keys per tile
@@ -151,6 +154,15 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           if (kt * KVB + s * 32 + hi * 16 + r >= p.nk) sacc[s][r] = -INFINITY;
+    }
+    if (p.mask) {  // additive mask (attention_function's `mask`: 0 / -inf from a bool mask, or arbitrary biases), 16 consecutive keys per lane
+      const f16* mp = p.mask + (long)b * p.mask_bs + (long)h * p.mask_hs + (long)min(q0 + li, p.nq - 1) * p.mask_qs + kt * KVB + hi * 16;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const f16x8 m0 = *reinterpret_cast<const f16x8*>(mp + s * 32), m1 = *reinterpret_cast<const f16x8*>(mp + s * 32 + 8);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[s][r] += (float)(r < 8 ? m0[r & 7] : m1[r & 7]) * p.inv_scale;
+      }
     }
     if (p.causal && (kt + 1) * KVB - 1 > q0) {  // causal mask (CLIP text encoder): key j > query i never attends; the first key
       const int qi = q0 + li;                   // tile always holds key 0 <= i, so the running max is finite from tile 0 on
@@ -754,6 +766,10 @@ extern "C" int fmx_attention_f16(const fmx_attn_args* a, void* stream) {
   p.zp = (const f16*)a->zero_page;
   p.causal = a->causal ? 1 : 0;
   p.k_span = p.vt_span = 0;
+  p.mask = (const f16*)a->mask; p.mask_bs = a->mask_bs; p.mask_hs = a->mask_hs; p.mask_qs = a->mask_qs;
+  p.inv_scale = 1.0f / fabsf(a->scale);
+  FMX_REQUIRE(!p.mask || (fmx_aligned16(p.mask) && (p.mask_bs % 8) == 0 && (p.mask_hs % 8) == 0 && (p.mask_qs % 8) == 0),
+              "attention: mask must be 16-byte aligned with strides that are multiples of 8 elements (rows padded to nk_pad keys)");
   FMX_REQUIRE(!p.causal || a->nq == a->nk, "attention: the causal mask is defined for self-attention (nq == nk)");
   hipStream_t st = (hipStream_t)stream;
   switch (a->dpad) {
@@ -761,7 +777,7 @@ extern "C" int fmx_attention_f16(const fmx_attn_args* a, void* stream) {
     case 64:
       // 64-query-per-wave variant when there are enough queries to fill 256-query workgroups (test hook: scale < 0 forces
       // the 32-query kernel)
-      if (a->nq >= 256 && !force32 && !p.causal) return launch_attn_q64(p, st);
+      if (a->nq >= 256 && !force32 && !p.causal && !p.mask) return launch_attn_q64(p, st);
       return launch_attn<64>(p, st);
     case 80: return launch_attn<80>(p, st);
     case 128: return launch_attn<128>(p, st);

@@ -385,6 +385,40 @@ __global__ void philox_randn_kernel(uint32_t seed_lo, uint32_t seed_hi, uint32_t
   }
 }
 
+// ---- strided 4-D copy with element conversion: the layout adapter of the attention- and op-level entry points --------------------------
+// (NCHW <-> NHWC, [B, N, H*d] -> zero-padded heads, V -> V^T, bool mask -> additive mask).  One thread per element, innermost
+// destination index fastest; not a hot-path kernel.
+struct Copy4Params {
+  const void* src;
+  void* dst;
+  long ss[4], ds[4];
+  int d[4];
+  int src_kind, dst_kind;
+};
+__device__ __forceinline__ float load_kind(const void* p, long i, int kind) {
+  switch (kind) {
+    case 0: return (float)reinterpret_cast<const _Float16*>(p)[i];
+    case 1: return reinterpret_cast<const float*>(p)[i];
+    case 2: return (float)reinterpret_cast<const __bf16*>(p)[i];
+    default: return reinterpret_cast<const unsigned char*>(p)[i] ? 0.0f : -INFINITY;   // bool "attend" mask -> additive mask
+  }
+}
+__global__ void strided_copy4_kernel(const Copy4Params p) {
+  const long total = (long)p.d[0] * p.d[1] * p.d[2] * p.d[3];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long r = i;
+    const int i3 = (int)(r % p.d[3]); r /= p.d[3];
+    const int i2 = (int)(r % p.d[2]); r /= p.d[2];
+    const int i1 = (int)(r % p.d[1]);
+    const int i0 = (int)(r / p.d[1]);
+    const float v = load_kind(p.src, i0 * p.ss[0] + i1 * p.ss[1] + i2 * p.ss[2] + i3 * p.ss[3], p.src_kind);
+    const long o = i0 * p.ds[0] + i1 * p.ds[1] + i2 * p.ds[2] + i3 * p.ds[3];
+    if (p.dst_kind == 0) reinterpret_cast<_Float16*>(p.dst)[o] = (_Float16)v;
+    else if (p.dst_kind == 1) reinterpret_cast<float*>(p.dst)[o] = v;
+    else reinterpret_cast<__bf16*>(p.dst)[o] = (__bf16)v;
+  }
+}
+
 }  // namespace
 
 extern "C" int fmx_timestep_embedding(const float* t, void* emb, int32_t b, int32_t dim, float max_period, void* stream) {
@@ -424,6 +458,23 @@ extern "C" int fmx_embed_tokens(const int32_t* ids, const void* tok_emb, const v
   hipLaunchKernelGGL(embed_tokens_kernel, dim3(batch * tokens), dim3(128), 0, (hipStream_t)stream, ids, (const f16*)tok_emb, (const f16*)pos_emb,
                      (f16*)out, tokens, c, vocab);
   FMX_LAUNCH_CHECK("fmx_embed_tokens");
+  return FMX_OK;
+}
+
+extern "C" int fmx_strided_copy4(const void* src, int32_t src_kind, const int64_t* src_strides, void* dst, int32_t dst_kind,
+                                 const int64_t* dst_strides, const int32_t* dims, void* stream) {
+  FMX_REQUIRE(src && dst && src_strides && dst_strides && dims, "strided_copy4: null pointer");
+  FMX_REQUIRE(src_kind >= 0 && src_kind <= 3 && dst_kind >= 0 && dst_kind <= 2, "strided_copy4: element kinds are 0 f16, 1 f32, 2 bf16 (source also 3 = bool mask)");
+  Copy4Params p;
+  p.src = src; p.dst = dst; p.src_kind = src_kind; p.dst_kind = dst_kind;
+  long total = 1;
+  for (int i = 0; i < 4; ++i) {
+    FMX_REQUIRE(dims[i] > 0, "strided_copy4: dims must be positive");
+    p.d[i] = dims[i]; p.ss[i] = src_strides[i]; p.ds[i] = dst_strides[i];
+    total *= dims[i];
+  }
+  hipLaunchKernelGGL(strided_copy4_kernel, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream, p);
+  FMX_LAUNCH_CHECK("fmx_strided_copy4");
   return FMX_OK;
 }
 

@@ -244,9 +244,27 @@ def geglu_interleave(w, b):
     return wo, bo
 
 
+_KINDS = {torch.float16: 0, torch.float32: 1, torch.bfloat16: 2, torch.bool: 3, torch.uint8: 3}
+
+
+def strided_copy4(src, dst, dims, src_strides, dst_strides):
+    """dst[i0, i1, i2, i3] = convert(src[i0, i1, i2, i3]) for i < dims (element strides; base = data_ptr of each tensor): the layout /
+    dtype adapter of the attention- and op-level entry points (fmx_strided_copy4).  A bool source becomes an additive mask (0 / -inf)."""
+    if not (src.is_cuda and dst.is_cuda):
+        raise TypeError("strided_copy4 expects device tensors")
+    if src.dtype not in _KINDS or dst.dtype not in (torch.float16, torch.float32, torch.bfloat16):
+        raise TypeError(f"strided_copy4: unsupported element types {src.dtype} -> {dst.dtype}")
+    ss = (C.c_int64 * 4)(*[int(v) for v in src_strides])
+    ds = (C.c_int64 * 4)(*[int(v) for v in dst_strides])
+    dm = (C.c_int32 * 4)(*[int(v) for v in dims])
+    _lib.check(_lib.lib().fmx_strided_copy4(_p(src), _KINDS[src.dtype], ss, _p(dst), _KINDS[dst.dtype], ds, dm, stream_ptr()), "fmx_strided_copy4")
+    return dst
+
+
 def attention(q, k, vt, *, batch, heads, nq, nk, nk_pad, dpad, scale, q_bs, q_rs, k_bs, k_rs, vt_bs, vt_hs, vt_ds,
-              out=None, force32=False, causal=False):
-    """q/k/vt are base tensors (views allowed: the data_ptr is the element (0,0,0,0)); strides in elements."""
+              out=None, force32=False, causal=False, mask=None, mask_strides=(0, 0, 0)):
+    """q/k/vt are base tensors (views allowed: the data_ptr is the element (0,0,0,0)); strides in elements.
+    mask: optional fp16 additive mask, element (b, h, i, j) at mask_strides = (batch, head, query) element strides, rows of nk_pad keys."""
     sfx, elem = _elem(q, k, vt, out)
     fn_name = "fmx_attention" + sfx
     if out is None:
@@ -260,6 +278,8 @@ def attention(q, k, vt, *, batch, heads, nq, nk, nk_pad, dpad, scale, q_bs, q_rs
     a.scale = -float(scale) if force32 else float(scale)  # test hook: negative scale selects the 32-query-per-wave kernel
     a.zero_page = _p(zero_page(q.device))
     a.causal = 1 if causal else 0
+    a.mask = _p(mask)
+    a.mask_bs, a.mask_hs, a.mask_qs = (int(v) for v in mask_strides)
     if _profiler is not None:
         d_true = int(round(float(scale) ** -2))
         flops = 4.0 * batch * heads * nq * nk * d_true
