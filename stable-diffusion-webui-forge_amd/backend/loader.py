@@ -178,8 +178,17 @@ def split_state_dict(sd):
     # the prediction type is not in the tensor shapes: checkpoints mark it with a 'v_pred' key (and 'ztsnr' for a zero-terminal-SNR schedule,
     # loader.py:462); a yaml next to the file or the caller decides otherwise (loader.py:543-567) -> forge_loader(prediction_type=...)
     pred = "v_prediction" if "v_pred" in sd else "epsilon"
-    guess = {"unet_config": unet_config, "vae_config": vae_config, "is_sdxl": is_sdxl, "prediction_type": pred, "ztsnr": "ztsnr" in sd,
-             "ignored": sorted({k.split(".")[0] for k in sd if not k.startswith((UNET_PREFIX, VAE_PREFIX))})}
+    # SD2.x-768 v-prediction checkpoints carry NO marker key.  huggingface_guess (the package the reference's loader.py:567 takes
+    # model_type from; absent here, restated) tells them from SD2.x-base (epsilon) by a statistic of one trained tensor: the standard
+    # deviation of output_blocks.11.1.transformer_blocks.0.norm1.bias exceeds 0.09 for the v-prediction models (SD2.x: context_dim
+    # 1024, 4 input channels).  Loading such a file as epsilon produces garbage images silently, so the heuristic is applied and reported.
+    pred_source = "marker key" if "v_pred" in sd else "default"
+    probe = UNET_PREFIX + "output_blocks.11.1.transformer_blocks.0.norm1.bias"
+    if pred == "epsilon" and unet_config.get("context_dim") == 1024 and unet_config.get("in_channels") == 4 and not is_sdxl and probe in sd:
+        if float(sd[probe].float().std()) > 0.09:
+            pred, pred_source = "v_prediction", "SD2.x norm1.bias statistic (std > 0.09)"
+    guess = {"unet_config": unet_config, "vae_config": vae_config, "is_sdxl": is_sdxl, "prediction_type": pred, "prediction_type_source": pred_source,
+             "ztsnr": "ztsnr" in sd, "ignored": sorted({k.split(".")[0] for k in sd if not k.startswith((UNET_PREFIX, VAE_PREFIX))})}
     return {"unet": unet, "vae": vae}, guess
 
 

@@ -125,11 +125,18 @@ def merge_lora_to_weight(patches, weight, key="online_lora", computation_dtype=t
     Mirrors backend/patcher/lora.py:85-323 for the supported patch types (offset / function hooks are not used by LoRA files)."""
     w = weight.to(device=device, dtype=torch.float16).contiguous()
     shape = w.shape
+    # Several patches on one key (stacked LoRAs): the reference casts the weight to fp32 once, applies every patch and rounds once at the
+    # end (patcher/lora.py:85-92, :322).  So does this: with more than one patch the running weight stays fp32 between patches (`fin` is the
+    # identity) and is rounded after the loop; a single patch keeps the fused fp16-residual GEMM (one rounding either way).
+    multi = len(patches) > 1
+    fin = (lambda t: t) if multi else (lambda t: t.half())
+    if multi:
+        w = w.float()
     for strength, v, strength_model, offset, function in patches:
         if offset is not None or function is not None:
             raise NotImplementedError("weight offset / function hooks are not supported by the native merge")
         if strength_model != 1.0:
-            w = ops.scale_f16(w, strength_model) if hasattr(ops, "scale_f16") else (w.float() * strength_model).half()
+            w = fin(w.float() * strength_model)
         if len(v) == 1:
             ptype, v = "diff", v
         else:
@@ -139,9 +146,9 @@ def merge_lora_to_weight(patches, weight, key="online_lora", computation_dtype=t
                 d = v[0].to(device=device, dtype=torch.float32)
                 if d.shape != w.shape:
                     raise ValueError(f"{key}: diff shape {tuple(d.shape)} != weight shape {tuple(w.shape)}")
-                w = (w.float() + strength * d).half()  # elementwise, load time only
+                w = fin(w.float() + strength * d)  # elementwise, load time only
         elif ptype == "set":
-            w = v[0].to(device=device, dtype=torch.float16).reshape(shape).contiguous()
+            w = v[0].to(device=device, dtype=torch.float32 if multi else torch.float16).reshape(shape).contiguous()
         elif ptype == "lora":
             up, down, alpha, mid, dora = v
             if dora is not None:  # the decomposition needs the delta itself, not only W + delta: fp32 on the device, as the reference
@@ -150,7 +157,7 @@ def merge_lora_to_weight(patches, weight, key="online_lora", computation_dtype=t
                     m = mid.to(device=device, dtype=torch.float32)
                     dn = torch.mm(dn.transpose(0, 1).flatten(1), m.transpose(0, 1).flatten(1)).reshape(dn.shape[1], dn.shape[0], m.shape[2], m.shape[3]).transpose(0, 1)
                 diff = torch.mm(up.to(device=device, dtype=torch.float32).flatten(1), dn.flatten(1)).reshape(shape)
-                w = _weight_decompose(dora, w, diff, (alpha / down.shape[0]) if alpha is not None else 1.0, strength, device)
+                w = fin(_weight_decompose(dora, w, diff, (alpha / down.shape[0]) if alpha is not None else 1.0, strength, device))
                 continue
             rank = down.shape[0]
             scale = strength * ((alpha / rank) if alpha is not None else 1.0)
@@ -167,9 +174,14 @@ def merge_lora_to_weight(patches, weight, key="online_lora", computation_dtype=t
                 raise ValueError(f"{key}: LoRA shapes {tuple(up.shape)} x {tuple(down.shape)} do not match weight {tuple(shape)}")
             a = _pad_k(up2)                                   # GEMM "activations": rows = output channels
             b = _pad_k(down2.t().contiguous())                # GEMM "weights":     rows = input features
-            out = torch.empty_like(w2)
-            ops.conv_gemm(a, b, w2.shape[1], alpha=scale, residual=w2, out=out, ld_out=w2.shape[1])
-            w = out.reshape(shape)
+            if multi:   # delta alone, fp32 out of the GEMM, added to the fp32 running weight
+                delta = torch.empty(w2.shape, dtype=torch.float32, device=device)
+                ops.conv_gemm(a, b, w2.shape[1], alpha=scale, out=delta, ld_out=w2.shape[1])
+                w = (w2 + delta).reshape(shape)
+            else:
+                out = torch.empty_like(w2)
+                ops.conv_gemm(a, b, w2.shape[1], alpha=scale, residual=w2, out=out, ld_out=w2.shape[1])
+                w = out.reshape(shape)
         elif ptype in ("loha", "lokr", "glora"):
             f32 = lambda t: t.to(device=device, dtype=torch.float32)
             if ptype == "loha":  # patcher/lora.py:230-266: (w1a w1b) * (w2a w2b), optionally through Tucker cores t1 / t2
@@ -216,17 +228,17 @@ def merge_lora_to_weight(patches, weight, key="online_lora", computation_dtype=t
                         diff = torch.mm(torch.mm(wf, A1), A2).reshape(shape)
                     diff = diff + torch.mm(B1, B2).reshape(shape)
             if dora is not None:
-                w = _weight_decompose(dora, w, diff, scale, strength, device)
+                w = fin(_weight_decompose(dora, w, diff, scale, strength, device))
             else:
-                w = (w.float() + (strength * scale) * diff).half()
+                w = fin(w.float() + (strength * scale) * diff)
         else:
             raise NotImplementedError(f"patch type {ptype}")
-    return w
+    return w.half() if w.dtype != torch.float16 else w
 
 
 def _weight_decompose(dora_scale, weight, lora_diff, alpha, strength, device):
     """DoRA (patcher/lora.py:35-78): re-normalise every output (or input) slice of W + alpha * delta to the learned magnitude `dora_scale`,
-    then blend towards it by `strength`.  fp32 on the device; returns fp16."""
+    then blend towards it by `strength`.  fp32 on the device, fp32 result."""
     ds = dora_scale.to(device=device, dtype=torch.float32)
     wf = weight.float()
     calc = wf + alpha * lora_diff
@@ -238,7 +250,7 @@ def _weight_decompose(dora_scale, weight, lora_diff, alpha, strength, device):
     norm = norm + torch.finfo(torch.float32).eps  # eps of the computation dtype the weight was cast to (:74)
     calc = calc * (ds / norm)
     out = calc if strength == 1.0 else wf + strength * (calc - wf)
-    return out.half()
+    return out   # fp32; merge_lora_to_weight rounds once per key
 
 
 def merge_loras_into_state_dict(unet_sd, unet_config, loras, device="cuda"):

@@ -98,8 +98,8 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ x
 
 // ---- finalize: fold the chunk partials of one (image, group) into per-channel (scale, shift) ---------------------------------------
 // grid (groups, n), one wave per block.  The channels of the (virtually concatenated) input come from up to two partial buffers with
-// their own chunk counts (the two producers may have tiled differently).  Item i of a group = (channel i / nch, chunk i % nch); lane l
-// takes items l, l + 64, ...; the wave sum is a fixed butterfly -> deterministic.  ss[img][c] = {rstd * gamma, beta - mean * rstd * gamma}.
+// their own chunk counts (the two producers may have tiled differently).  Item i of a group and source = (channel i / nch, chunk i % nch);
+// lane l takes items l, l + 64, ...; the wave sum is a fixed butterfly -> deterministic.  ss[img][c] = {rstd * gamma, beta - mean * rstd * gamma}.
 __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ p0, int nch0, int c0, const float* __restrict__ p1, int nch1, int c1,
                                                           int groups, int hw, float eps, const f16* __restrict__ gamma, const f16* __restrict__ beta,
                                                           float* __restrict__ ss) {
@@ -107,18 +107,21 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
   const int cpg = C / groups;
   const int g = blockIdx.x, img = blockIdx.y, lane = threadIdx.x;
   float s = 0.f, q = 0.f;
-  for (int ci = 0; ci < cpg; ++ci) {
-    const int c = g * cpg + ci;
-    const float* base;
-    int nch, cs, cc;
-    if (c < c0) { base = p0; nch = nch0; cs = c0; cc = c; } else { base = p1; nch = nch1; cs = c1; cc = c - c0; }
-    base += ((long)img * nch * cs + cc) * 2;
-    for (int ch = lane; ch < nch; ch += 64) {
-      const f32x2 v = *reinterpret_cast<const f32x2*>(base + (long)ch * cs * 2);
+  // the group's (channel, chunk) records of each source, flattened over the lanes: all loads of a lane are independent (a loop over
+  // channels with a few chunks each leaves most lanes idle behind one L2 round trip per channel)
+  auto accumulate = [&](const float* base, int nch, int cs, int lo, int hi) {   // source-local channels [lo, hi)
+    const int items = (hi - lo) * nch;
+    const float* b0 = base + ((long)img * nch * cs + lo) * 2;
+    for (int i = lane; i < items; i += 64) {
+      const int ci = i / nch, ch = i - ci * nch;
+      const f32x2 v = *reinterpret_cast<const f32x2*>(b0 + ((long)ch * cs + ci) * 2);
       s += v[0];
       q += v[1];
     }
-  }
+  };
+  const int g_lo = g * cpg, g_hi = g_lo + cpg;
+  if (g_lo < c0) accumulate(p0, nch0, c0, g_lo, min(g_hi, c0));
+  if (g_hi > c0) accumulate(p1, nch1, c1, max(g_lo, c0) - c0, g_hi - c0);
   s = wave_sum(s);
   q = wave_sum(q);
   const float cnt = (float)cpg * (float)hw;

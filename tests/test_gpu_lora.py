@@ -38,6 +38,31 @@ def test_lora_merge_on_device_vs_reference():
     assert merged["time_embed.0.weight"] is sd["time_embed.0.weight"]
 
 
+def test_stacked_loras_on_one_key_round_once():
+    """Three patches on the same weight (two LoRAs and a full diff): the reference casts the weight to fp32, applies all of them and rounds
+    once (backend/patcher/lora.py:85-92, :322).  The native merge keeps an fp32 running weight between patches; against that arithmetic in
+    torch fp32 the result is within HALF an fp16 ulp of the exact value, i.e. at most one ulp from the rounded reference -- rounding after
+    every patch (round 1's behaviour) drifts by up to the number of patches."""
+    torch.manual_seed(3)
+    out_f, in_f, r1, r2 = 320, 192, 8, 16
+    w = (torch.randn(out_f, in_f) * 0.05).half()
+    up1, dn1 = torch.randn(out_f, r1) * 0.1, torch.randn(r1, in_f) * 0.1
+    up2, dn2 = torch.randn(out_f, r2) * 0.1, torch.randn(r2, in_f) * 0.1
+    diff = torch.randn(out_f, in_f) * 0.01
+    patches = [(0.8, ("lora", (up1, dn1, 4.0, None, None)), 1.0, None, None),
+               (-0.5, ("lora", (up2, dn2, None, None, None)), 1.0, None, None),
+               (1.0, ("diff", (diff,)), 1.0, None, None)]
+    got = nlora.merge_lora_to_weight(patches, w, key="stacked", device=DEV).float().cpu()
+    f16 = lambda t: t.half().double()   # the LoRA factors enter the device GEMM as fp16
+    exact = w.double() + 0.8 * (4.0 / r1) * (f16(up1) @ f16(dn1)) - 0.5 * (f16(up2) @ f16(dn2)) + diff.double()
+    ulp = torch.maximum(exact.abs(), torch.tensor(2.0 ** -14, dtype=torch.float64)).log2().floor().exp2() * 2.0 ** -10
+    err = (got.double() - exact).abs()
+    assert bool((err <= 0.5 * ulp * 1.01 + 1e-7).all()), f"max error {float((err / ulp).max()):.3f} ulp (0.5 = one correct rounding)"
+    single = nlora.merge_lora_to_weight(patches[:1], w, key="single", device=DEV).float().cpu()
+    e1 = (single.double() - (w.double() + 0.8 * (4.0 / r1) * (f16(up1) @ f16(dn1)))).abs()
+    assert bool((e1 <= 0.5 * ulp * 1.05 + 1e-7).all())
+
+
 def test_forge_loader_with_lora_end_to_end():
     """single-file checkpoint layout (model.diffusion_model.* + first_stage_model.*) -> engine with a merged LoRA; the UNet
     forward must match the CPU oracle evaluated on the reference-merged weights."""

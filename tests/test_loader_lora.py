@@ -61,6 +61,25 @@ def test_split_state_dict_single_file_layout():
     assert all(k.startswith(loader.UNET_PREFIX) for k in bare)
 
 
+def test_sd2_v_prediction_is_recognised_without_a_marker_key():
+    """SD2.x-768 (v-prediction) and SD2.x-base (epsilon) share every tensor shape and carry no marker: the trained bias of
+    output_blocks.11.1.transformer_blocks.0.norm1 decides (std > 0.09 -> v-prediction), as huggingface_guess does for the reference."""
+    shapes = unet_param_shapes(SD21_UNET_CONFIG)
+    probe = loader.UNET_PREFIX + "output_blocks.11.1.transformer_blocks.0.norm1.bias"
+    assert probe[len(loader.UNET_PREFIX):] in shapes
+    g = torch.Generator().manual_seed(0)
+    for std, want in ((0.02, "epsilon"), (0.15, "v_prediction")):
+        sd = _meta_sd(shapes, loader.UNET_PREFIX)
+        sd[probe] = torch.randn(shapes[probe[len(loader.UNET_PREFIX):]], generator=g) * std
+        _, guess = loader.split_state_dict(sd)
+        assert guess["prediction_type"] == want, (std, guess["prediction_type"], guess["prediction_type_source"])
+    # the statistic is an SD2.x rule: an SD1.5 UNet (context 768) with a wild bias stays epsilon
+    s15 = unet_param_shapes(synth.SD15_UNET_CONFIG)
+    sd = _meta_sd(s15, loader.UNET_PREFIX)
+    sd[probe] = torch.randn(s15[probe[len(loader.UNET_PREFIX):]], generator=g)
+    assert loader.split_state_dict(sd)[1]["prediction_type"] == "epsilon"
+
+
 def _key_map(cfg):
     return nlora.model_lora_keys_unet(list(unet_param_shapes(cfg)), cfg)
 
