@@ -13,7 +13,8 @@
  *                          GEGLU backend/nn/unet.py:104-111 ; ResBlock emb add / skip add :469-478
  *   fmx_attention_f16      attention_function  backend/attention.py:324-339 (and :37-93, incl. its additive / bool `mask`)
  *   fmx_strided_copy4      the reshape / permute / .to(dtype) around it: backend/attention.py:51-60,90-93,330-338,415-418
- *   fmx_softmax_rows_f16   sim.softmax(dim=-1) backend/attention.py:85 (materialised-score variant)
+ *   fmx_attention_single_head512_f16  attention_function_single_head_spatial backend/attention.py:412-422 at the VAE's 512 channels
+ *   fmx_softmax_rows_f16   sim.softmax(dim=-1) backend/attention.py:85 (materialised-score variant: single heads wider than 160 other than 512)
  *   fmx_groupnorm_*        F.group_norm backend/operations.py:308 (+ SiLU backend/nn/unet.py:394-398)
  *   fmx_layernorm_f16      F.layer_norm backend/operations.py:327
  *   fmx_timestep_embedding timestep_embedding backend/nn/unet.py:55-67 (and backend/nn/flux.py:52-73 with t*1000)
@@ -149,6 +150,15 @@ typedef struct fmx_attn_args {
 } fmx_attn_args;
 
 int fmx_attention_f16(const fmx_attn_args* args /* host */, void* stream);
+
+/* Fused attention of ONE head of width 512 (the VAE mid-block attention: backend/nn/vae.py:118-137 -> attention.py:412-422), N up to 16 384
+ * tokens, without materialising the scores: O = softmax(Q K^T * scale) V, the head dimension split across the waves of a workgroup.
+ *   q, k : fp16 token-major, token i of image b at q[b*q_bs + i*q_rs + c], c < 512 (q and k may be the two halves of one [B*N][1024] buffer)
+ *   vt   : fp16 V TRANSPOSED, (b, c, j) at vt[b*vt_bs + c*vt_ds + j]; every row holds nk_pad keys (multiple of 32), keys >= nk must be finite (zeros)
+ *   o    : fp16 token-major like q.   16-byte aligned bases, strides % 8 == 0, an image's K / V^T spans < 2 GB. */
+int fmx_attention_single_head512_f16(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs, const void* vt,
+                                     int64_t vt_bs, int64_t vt_ds, void* o, int64_t o_bs, int64_t o_rs, int32_t batch, int32_t nq, int32_t nk,
+                                     int32_t nk_pad, float scale, void* stream);
 
 /* In-place row softmax over fp16 scores: x[r*ld + j], j < ncols, r < nrows (fp32 math). */
 int fmx_softmax_rows_f16(void* x, int64_t nrows, int32_t ncols, int64_t ld, void* stream);

@@ -60,6 +60,7 @@ SIGNATURES = {
     "fmx_geglu_interleave_rows": [_vp, _vp, _vp, _vp, _i32, _i32, _vp],
     "fmx_attention_f16": [C.POINTER(AttnArgs), _vp],
     "fmx_softmax_rows_f16": [_vp, _i64, _i32, _i64, _vp],
+    "fmx_attention_single_head512_f16": [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _f32, _vp],
     "fmx_groupnorm_stats_f16": [_vp, _i32, _i64, _i32, _i32, _vp, _i32, _vp],
     "fmx_groupnorm_apply_f16": [_vp, _vp, _i32, _i32, _i64, _i64, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _f32, _vp, _vp, _i32, _vp, _vp, _vp],
     "fmx_gemm_conv_stats_f16": [C.POINTER(GemmArgs), _vp, _i32, _i32, C.POINTER(C.c_int32), _vp],

@@ -109,6 +109,18 @@ def _single_head_tokens(q, k, v):
     dev = q.device
     npad = -(-nk // 64) * 64
     out = torch.empty(b, nq, c, dtype=q.dtype, device=dev)
+    if c == 512:   # the VAE's width: fused kernel, whole batch in one launch (csrc/fmx_attention512.hip)
+        q2 = torch.empty(b * nq, c, dtype=torch.float16, device=dev)
+        k2 = torch.empty(b * nk, c, dtype=torch.float16, device=dev)
+        vt = torch.zeros(c, b * npad, dtype=torch.float16, device=dev)
+        ops.strided_copy4(q, q2, (1, b, nq, c), (0, q.stride(0), q.stride(1), q.stride(2)), (0, nq * c, c, 1))
+        ops.strided_copy4(k, k2, (1, b, nk, c), (0, k.stride(0), k.stride(1), k.stride(2)), (0, nk * c, c, 1))
+        ops.strided_copy4(v, vt, (1, b, nk, c), (0, v.stride(0), v.stride(1), v.stride(2)), (0, npad, 1, b * npad))
+        o2 = torch.empty(b * nq, c, dtype=torch.float16, device=dev)
+        ops.attention_single_head512(q2, k2, vt, o2, batch=b, nq=nq, nk=nk, nk_pad=npad, q_bs=nq * c, q_rs=c, k_bs=nk * c, k_rs=c, vt_bs=npad,
+                                     vt_ds=b * npad, scale=c ** -0.5)
+        ops.strided_copy4(o2, out, (1, b, nq, c), (0, nq * c, c, 1), (0, nq * c, c, 1))
+        return out
     qi = torch.empty(nq, c, dtype=torch.float16, device=dev)
     ki = torch.empty(nk, c, dtype=torch.float16, device=dev)
     vt = torch.zeros(c, npad, dtype=torch.float16, device=dev)

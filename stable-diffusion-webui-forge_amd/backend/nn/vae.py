@@ -91,6 +91,7 @@ class IntegratedAutoencoderKL:
         w[a + ".qk"] = (torch.cat([qw, kw], 0).contiguous(), torch.cat([qb, kb], 0).contiguous())
         w[a + ".v"] = conv(a + ".v")
         w[a + ".proj_out"] = conv(a + ".proj_out")
+        w[a + ".proj_out_vbias"] = self._fold_v_bias(w[a + ".proj_out"], w[a + ".v"][1])
         for _, blocks, up in lay.levels:
             for key, cin, cout in blocks:
                 res(key, cin, cout)
@@ -121,6 +122,7 @@ class IntegratedAutoencoderKL:
             w[a + ".qk"] = (torch.cat([qw, kw], 0).contiguous(), torch.cat([qb, kb], 0).contiguous())
             w[a + ".v"] = conv(a + ".v")
             w[a + ".proj_out"] = conv(a + ".proj_out")
+            w[a + ".proj_out_vbias"] = self._fold_v_bias(w[a + ".proj_out"], w[a + ".v"][1])
             w["e.norm_out"] = norm("encoder.norm_out")
             w["e.conv_out"] = conv("encoder.conv_out")
             if el.use_quant_conv:
@@ -130,6 +132,13 @@ class IntegratedAutoencoderKL:
                 w["e.quant"] = (qp.contiguous(), T("quant_conv.bias"))
         self.w = w
         torch.cuda.synchronize(dev)
+
+    @staticmethod
+    def _fold_v_bias(proj_out, b_v):
+        """proj_out(P V + b_v) = W_o (P V) + (W_o b_v + b_o): the value bias of the mid-block attention (vae.py:118-137; softmax rows sum to 1, so it
+        is the same vector for every token) folded into proj_out's bias once at load time, in fp32."""
+        w_o, b_o = proj_out
+        return (b_o.float() + w_o.float() @ b_v.float()).half().contiguous()
 
     # ------------------------------------------------------------------------------------------------------------
     def _res(self, k, x, cin, cout, arena):
@@ -157,6 +166,23 @@ class IntegratedAutoencoderKL:
         o = ops.empty((b * n, c))
         npad = -(-n // 64) * 64
         scale = c ** -0.5
+        if c == 512:
+            # fused: one launch for the whole batch, scores never leave the chip (csrc/fmx_attention512.hip).  V^T for all images comes from
+            # ONE operand-swapped GEMM when the token count needs no padding; V's bias rides in proj_out's (softmax rows sum to 1)
+            vt = ops.empty((c, b * npad))
+            if npad == n:
+                ops.conv_gemm(self.w[a + ".v"][0], g, b * n, out=vt, ld_out=b * n)
+            else:
+                vt.zero_()  # padded key columns must hold finite values (their probabilities are exactly zero)
+                for bi in range(b):
+                    ops.conv_gemm(self.w[a + ".v"][0], g[bi * n:(bi + 1) * n], n, out=vt[:, bi * npad:], ld_out=b * npad)
+            ops.attention_single_head512(qk, qk[:, c:], vt, o, batch=b, nq=n, nk=n, nk_pad=npad, q_bs=n * 2 * c, q_rs=2 * c, k_bs=n * 2 * c, k_rs=2 * c,
+                                         vt_bs=npad, vt_ds=b * npad, scale=scale)
+            _, st = ops.linear(o, self.w[a + ".proj_out"][0], self.w[a + ".proj_out_vbias"], residual=x.view(-1, c), out=out.view(-1, c), ld_out=c,
+                               n=b, h=hh, w=ww, stats=True, stats_partial=out_part)
+            arena.release(m)
+            return ops.attach_stats(out, st)
+        # other widths: S = scale * Q K^T (GEMM) -> row softmax -> P V (GEMM) per image
         for bi in range(b):
             mk = arena.mark()
             gb = g[bi * n:(bi + 1) * n]

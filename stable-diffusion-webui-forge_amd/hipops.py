@@ -290,6 +290,22 @@ def attention(q, k, vt, *, batch, heads, nq, nk, nk_pad, dpad, scale, q_bs, q_rs
     return out
 
 
+def attention_single_head512(q, k, vt, out, *, batch, nq, nk, nk_pad, q_bs, q_rs, k_bs, k_rs, vt_bs, vt_ds, scale):
+    """One 512-wide head, fused (fmx_attention_single_head512_f16): q / k token-major views, vt = V^T [512 rows][batch * nk_pad keys]."""
+    _check_f16(q, k, vt, out)
+
+    def launch():
+        _lib.check(_lib.lib().fmx_attention_single_head512_f16(_p(q), q_bs, q_rs, _p(k), k_bs, k_rs, _p(vt), vt_bs, vt_ds, _p(out), nq * out.stride(0),
+                                                               out.stride(0), batch, nq, nk, nk_pad, float(scale), stream_ptr()),
+                   "fmx_attention_single_head512_f16")
+    if _profiler is not None:
+        _profiler.launch("attention", 4.0 * batch * nq * nk * 512, launch, tag=f"B={batch} H=1 Nq={nq} Nk={nk} d=512")
+    else:
+        launch()
+    _dbg(f"attention512 B={batch} N={nq}", out=out)
+    return out
+
+
 def softmax_rows_(x):
     _check_f16(x)
     _lib.check(_lib.lib().fmx_softmax_rows_f16(_p(x), x.shape[0], x.shape[1], x.stride(0), stream_ptr()), "fmx_softmax_rows_f16")

@@ -59,6 +59,26 @@ def bench_attn(b, h, nq, nk, d, dpad, force32=False):
                       "tflops": round(4 * b * h * nq * nk * d / t / 1e12, 1)}), flush=True)
 
 
+def bench_attn512(b, n):
+    """the VAE mid-block attention: one 512-wide head over n tokens, fused kernel vs the materialised-score path of round 1"""
+    c = 512
+    qk, vt = rnd(b * n, 2 * c), rnd(c, b * n)
+    o = torch.empty(b * n, c, dtype=torch.float16, device=DEV)
+    t = timeit(lambda: ops.attention_single_head512(qk, qk[:, c:], vt, o, batch=b, nq=n, nk=n, nk_pad=n, q_bs=n * 2 * c, q_rs=2 * c, k_bs=n * 2 * c,
+                                                    k_rs=2 * c, vt_bs=n, vt_ds=b * n, scale=c ** -0.5), iters=5, warm=2)
+    s = torch.empty(n, n, dtype=torch.float16, device=DEV)
+
+    def materialised():
+        for bi in range(b):
+            ops.conv_gemm(qk[bi * n:(bi + 1) * n, :c], qk[bi * n:(bi + 1) * n, c:], n, alpha=c ** -0.5, out=s, ld_out=n)
+            ops.softmax_rows_(s)
+            ops.conv_gemm(s, vt[:, bi * n:(bi + 1) * n], c, out=o[bi * n:(bi + 1) * n], ld_out=c)
+    t2 = timeit(materialised, iters=3, warm=1)
+    fl = 4.0 * b * n * n * c
+    print(json.dumps({"op": "attention_single_head_512", "b": b, "n": n, "fused_us": round(t * 1e6, 1), "fused_tflops": round(fl / t / 1e12, 1),
+                      "materialised_us": round(t2 * 1e6, 1), "materialised_tflops": round(fl / t2 / 1e12, 1)}), flush=True)
+
+
 def bench_gn(n, h, w, c):
     x, g, bb = rnd(n, h, w, c), rnd(c), rnd(c)
     out = torch.empty_like(x)
@@ -129,6 +149,10 @@ if __name__ == "__main__":
         for shp in ((16, 32, 32, 1280, 1280, 1), (16, 64, 64, 640, 640, 1), (16, 128, 128, 320, 320, 1), (16, 32, 32, 1280, 1280, 3), (16, 64, 64, 640, 640, 3),
                     (16, 128, 128, 320, 320, 3), (8, 512, 512, 256, 256, 3), (8, 1024, 1024, 128, 128, 3)):
             bench_gemm_stats(*shp)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "attn512":
+        for b, n in ((8, 16384), (8, 4096), (1, 16384), (2, 1024)):
+            bench_attn512(b, n)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "attn":
         for f32 in (True, False):
