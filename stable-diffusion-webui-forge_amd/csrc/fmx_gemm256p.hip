@@ -23,6 +23,8 @@
 //   were read during k-step 2 and lgkmcnt(0) has retired them), so the stage may be overwritten (WAR); and every wave has
 //   waited for its own pieces of tile t+1 (issued during k-steps (t-1,3), (t,0), (t,1)), so after the barrier all of tile
 //   t+1 is visible in LDS (RAW).
+#include <stdlib.h>
+
 #include "fmx_gemm_common.hpp"
 
 namespace {
@@ -126,7 +128,11 @@ __device__ __forceinline__ void epi_rows(const char* my, int lane, int mbase, in
   }
 }
 
-template <bool CONV, int BM, int BN, bool STATS = false>
+// SCHED: where the NP LDS-DMA pieces of a K-tile are issued (A/B knob FMX_GEMM_SCHED, tools/bench_kernels.py gemmsched):
+//   0: 3 behind the barrier (k-step 3 of the tile before), 3 in k-step 0, the rest in k-step 1 -- spread thin beside the MFMAs
+//   1: 5 / 4 / 0 -- everything a k-step earlier, 2 k-steps (~1.5 k cycles) between the last issue and the wait
+//   2: all NP behind the barrier
+template <bool CONV, int BM, int BN, bool STATS = false, int SCHED = 0>
 __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   using G = Geo<BM, BN>;
   constexpr int MI = G::MI, NJ = G::NJ, NPA = G::NPA, NPB = G::NPB, NP = G::NP;
@@ -290,14 +296,29 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
     _Pragma("unroll") for (int q = MI * NJ - MI - NJ; q < (NV); ++q) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0); \
   }
 
-  // ---- prologue: tile 0 complete, pieces 0-2 of tile 1 in flight ----------------------------------------------------------
+  constexpr int P0 = SCHED == 0 ? 3 : SCHED == 1 ? 5 : NP;          // pieces issued behind the barrier (k-step 3 of the tile before)
+  constexpr int P1 = SCHED == 0 ? 3 : SCHED == 1 ? NP - 5 : 0;      // in k-step 0; the rest in k-step 1
+  auto issue_range = [&](auto LO, auto HI, const Cursor& c, int buf) {
+    constexpr int lo = decltype(LO)::value, hi = decltype(HI)::value;
+    if constexpr (lo + 0 < hi) issue_piece(IC<lo + 0>{}, c, buf);
+    if constexpr (lo + 1 < hi) issue_piece(IC<lo + 1>{}, c, buf);
+    if constexpr (lo + 2 < hi) issue_piece(IC<lo + 2>{}, c, buf);
+    if constexpr (lo + 3 < hi) issue_piece(IC<lo + 3>{}, c, buf);
+    if constexpr (lo + 4 < hi) issue_piece(IC<lo + 4>{}, c, buf);
+    if constexpr (lo + 5 < hi) issue_piece(IC<lo + 5>{}, c, buf);
+    if constexpr (lo + 6 < hi) issue_piece(IC<lo + 6>{}, c, buf);
+    if constexpr (lo + 7 < hi) issue_piece(IC<lo + 7>{}, c, buf);
+    if constexpr (lo + 8 < hi) issue_piece(IC<lo + 8>{}, c, buf);
+  };
+  // ---- prologue: tile 0 complete, the first P0 pieces of tile 1 in flight ------------------------------------------------------
   Cursor c1{0, 0, 0, 0};
-  issue_piece(IC<0>{}, c1, 0); issue_piece(IC<1>{}, c1, 0); issue_piece(IC<2>{}, c1, 0); issue_piece(IC<3>{}, c1, 0);
-  issue_piece(IC<4>{}, c1, 0); issue_piece(IC<5>{}, c1, 0); issue_piece(IC<6>{}, c1, 0); issue_piece(IC<7>{}, c1, 0);
-  issue_piece(IC<8>{}, c1, 0);
+  issue_range(IC<0>{}, IC<NP>{}, c1, 0);
   advance(c1);  // c1 = tile 1
-  issue_piece(IC<0>{}, c1, 1); issue_piece(IC<1>{}, c1, 1); issue_piece(IC<2>{}, c1, 1);
-  asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  issue_range(IC<0>{}, IC<P0>{}, c1, 1);
+  if constexpr (P0 == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (P0 == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (P0 == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   read_frags(0, 0, 0);
 
@@ -313,13 +334,13 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
     __builtin_amdgcn_sched_barrier(0);
     read_frags(buf, 1, 1);
     mma(0);
-    issue_piece(IC<3>{}, c1, buf ^ 1); issue_piece(IC<4>{}, c1, buf ^ 1); issue_piece(IC<5>{}, c1, buf ^ 1);
-    FMX_INTERLEAVE(3)
+    issue_range(IC<P0>{}, IC<P0 + P1>{}, c1, buf ^ 1);
+    FMX_INTERLEAVE(P1)
     __builtin_amdgcn_sched_barrier(0);
     read_frags(buf, 2, 0);
     mma(1);
-    issue_piece(IC<6>{}, c1, buf ^ 1); issue_piece(IC<7>{}, c1, buf ^ 1); issue_piece(IC<8>{}, c1, buf ^ 1);
-    FMX_INTERLEAVE(NP - 6)
+    issue_range(IC<P0 + P1>{}, IC<NP>{}, c1, buf ^ 1);
+    FMX_INTERLEAVE(NP - P0 - P1)
     __builtin_amdgcn_sched_barrier(0);
     read_frags(buf, 3, 1);
     mma(0);
@@ -331,8 +352,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
     __builtin_amdgcn_sched_barrier(0);
     read_frags(buf ^ 1, 0, 0);
     mma(1);
-    issue_piece(IC<0>{}, c2, buf); issue_piece(IC<1>{}, c2, buf); issue_piece(IC<2>{}, c2, buf);
-    FMX_INTERLEAVE(3)
+    issue_range(IC<0>{}, IC<P0>{}, c2, buf);
+    FMX_INTERLEAVE(P0)
     __builtin_amdgcn_sched_barrier(0);
     c1 = c2;
   }
@@ -489,21 +510,24 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
 #endif
 }
 
-template <int BM, int BN, bool STATS>
+// SC / SL: DMA issue schedule of the convolution / linear instantiation.  Measured (profiles/r04j_gemm_dma_schedule_ab.jsonl, 256x320 tile, two
+// runs each): the linear GEMMs of the SDXL forward gain 2-3 % from schedule 1 (993 -> 1014, 847 -> 870 GEGLU, 1186 -> 1225 at K = 5120, 1042 ->
+// 1065 TFLOP/s), the implicit-GEMM convolutions (longer address arithmetic per piece) are level or 1 % slower -> linear 1, convolution 0.
+template <int BM, int BN, bool STATS, int SC = 0, int SL = 1>
 int launch_bn(const GemmParams& p, bool conv, hipStream_t st) {
   using G = Geo<BM, BN>;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<true, BM, BN, STATS>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<false, BM, BN, STATS>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<true, BM, BN, STATS, SC>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<false, BM, BN, STATS, SL>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     attr_set = true;
   }
   GemmParams q = p;
   q.tiles_m = (p.M + BM - 1) / BM;
   q.tiles_n = (p.nout + BN - 1) / BN;
   const int grid = q.tiles_m * q.tiles_n;
-  if (conv) hipLaunchKernelGGL((gemm256p_kernel<true, BM, BN, STATS>), dim3(grid), dim3(512), G::LDS_BYTES, st, q);
-  else hipLaunchKernelGGL((gemm256p_kernel<false, BM, BN, STATS>), dim3(grid), dim3(512), G::LDS_BYTES, st, q);
+  if (conv) hipLaunchKernelGGL((gemm256p_kernel<true, BM, BN, STATS, SC>), dim3(grid), dim3(512), G::LDS_BYTES, st, q);
+  else hipLaunchKernelGGL((gemm256p_kernel<false, BM, BN, STATS, SL>), dim3(grid), dim3(512), G::LDS_BYTES, st, q);
   FMX_LAUNCH_CHECK("fmx_gemm_conv_f16 (256-row pipelined)");
   return FMX_OK;
 }
@@ -511,6 +535,14 @@ int launch_bn(const GemmParams& p, bool conv, hipStream_t st) {
 }  // namespace
 
 int fmx_launch_gemm256p(const GemmParams& p, bool conv, int bm, int bn, hipStream_t st) {
+  static int sched = -1;
+  if (sched < 0) {
+    const char* e = getenv("FMX_GEMM_SCHED");   // A/B knob (tools/bench_kernels.py gemmsched): force one DMA issue schedule on the 256x320 tile
+    sched = e ? atoi(e) + 1 : 0;
+  }
+  if (sched && bm == 256 && bn == 320 && !p.stats)
+    return sched == 1 ? launch_bn<256, 320, false, 0, 0>(p, conv, st) : sched == 2 ? launch_bn<256, 320, false, 1, 1>(p, conv, st)
+                                                                                    : launch_bn<256, 320, false, 2, 2>(p, conv, st);
   if (bm == 320) return launch_bn<320, 256, false>(p, conv, st);
   if (p.stats) return bn == 320 ? launch_bn<256, 320, true>(p, conv, st) : launch_bn<256, 256, true>(p, conv, st);   // output statistics: 256-row tiles only
   return bn == 320 ? launch_bn<256, 320, false>(p, conv, st) : launch_bn<256, 256, false>(p, conv, st);

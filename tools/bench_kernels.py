@@ -150,6 +150,16 @@ if __name__ == "__main__":
                     (16, 128, 128, 320, 320, 3), (8, 512, 512, 256, 256, 3), (8, 1024, 1024, 128, 128, 3)):
             bench_gemm_stats(*shp)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "gemmsched":
+        # the shapes that carry the SDXL forward, on the 256x320 tile (run under FMX_GEMM_SCHED=0/1/2 to compare DMA issue schedules)
+        Bu = 16
+        for m, n, k, act in ((Bu * 1024, 1280, 1280, 0), (Bu * 1024, 10240, 1280, 1), (Bu * 1024, 1280, 5120, 0), (Bu * 1024, 2560, 1280, 0),
+                             (Bu * 4096, 640, 640, 0), (Bu * 4096, 5120, 640, 1), (Bu * 4096, 640, 2560, 0)):
+            bench_linear(m, n, k, 7, act=act)
+        bench_conv(Bu, 32, 32, 1280, 1280, 7)
+        bench_conv(Bu, 64, 64, 640, 640, 7)
+        bench_conv(Bu, 128, 128, 320, 320, 7)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "attn512":
         for b, n in ((8, 16384), (8, 4096), (1, 16384), (2, 1024)):
             bench_attn512(b, n)
