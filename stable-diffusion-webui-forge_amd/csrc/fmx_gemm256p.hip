@@ -464,27 +464,35 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
       mcs[i] = mrow < p.M ? mrow : p.M - 1;
       imgs[i] = mcs[i] / ep.per_img;
     }
+    // the per-image row vector (a ResBlock's embedding add) is absent from every GEGLU call of the UNet / Flux executors: its loads
+    // (two 8-byte loads and their wait per 4 outputs, from the zero page when absent) are compiled out of the common instantiation
+    auto stage_geglu = [&](auto HAS_RV) {
+      constexpr bool RV = decltype(HAS_RV)::value != 0;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
-      for (int q4 = 0; q4 < 2; ++q4) {
-        const int nb = n0 + wn * (NJ * 32) + j * 32 + q4 * 8 + hi * 4;
-        const int nbc = nb < ep.nout ? nb : 0;
-        const f16x4 bv = ep.bias4(nbc), bg = ep.bias4(nbc + 16);  // few live registers: the 160-accumulator tile has none to spare
+        for (int q4 = 0; q4 < 2; ++q4) {
+          const int nb = n0 + wn * (NJ * 32) + j * 32 + q4 * 8 + hi * 4;
+          const int nbc = nb < ep.nout ? nb : 0;
+          const f16x4 bv = ep.bias4(nbc), bg = ep.bias4(nbc + 16);  // few live registers: the 160-accumulator tile has none to spare
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-          const f16x4 rvv = ep.rv4(imgs[i], nbc), rvg = ep.rv4(imgs[i], nbc + 16);
-          f32x4 o;
+          for (int i = 0; i < MI; ++i) {
+            f16x4 rvv, rvg;
+            if (RV) { rvv = ep.rv4(imgs[i], nbc); rvg = ep.rv4(imgs[i], nbc + 16); }
+            f32x4 o;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float val = acc[i][j][q4 * 4 + r] * ep.alpha + (float)bv[r] + (float)rvv[r];
-            const float gate = acc[i][j][8 + q4 * 4 + r] * ep.alpha + (float)bg[r] + (float)rvg[r];
-            o[r] = val * gelu_erf_f(gate);
+            for (int r = 0; r < 4; ++r) {
+              float val = acc[i][j][q4 * 4 + r] * ep.alpha + (float)bv[r];
+              float gate = acc[i][j][8 + q4 * 4 + r] * ep.alpha + (float)bg[r];
+              if (RV) { val += (float)rvv[r]; gate += (float)rvg[r]; }
+              o[r] = val * gelu_erf_f(gate);
+            }
+            const int row = i * 32 + li, chunk = j * 4 + q4 * 2 + hi;
+            *reinterpret_cast<f32x4*>(my + row * RB + ((chunk ^ (row & 3)) << 4)) = o;  // NJ*4 chunks per row: XOR of the low 2 bits stays inside
           }
-          const int row = i * 32 + li, chunk = j * 4 + q4 * 2 + hi;
-          *reinterpret_cast<f32x4*>(my + row * RB + ((chunk ^ (row & 3)) << 4)) = o;  // NJ*4 chunks per row: XOR of the low 2 bits stays inside
         }
-      }
+    };
+    if (ep.mrv) stage_geglu(IC<1>{}); else stage_geglu(IC<0>{});
     const int cg = lane % LPR;
     const int col = ((n0 + wn * (NJ * 32)) >> 1) + cg * 8;
     const bool nok = col < ep.ncols;

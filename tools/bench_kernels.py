@@ -159,6 +159,7 @@ if __name__ == "__main__":
         bench_conv(Bu, 32, 32, 1280, 1280, 7)
         bench_conv(Bu, 64, 64, 640, 640, 7)
         bench_conv(Bu, 128, 128, 320, 320, 7)
+        bench_linear(Bu * 1024, 10240, 1280, 7, act=0)   # the GEGLU projection's shape without GEGLU: what the activation epilogue costs
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "attn512":
         for b, n in ((8, 16384), (8, 4096), (1, 16384), (2, 1024)):
