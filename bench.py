@@ -79,6 +79,7 @@ def parse(argv=None):
     ap.add_argument("--no-vae", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--breakdown", default="", help="write the per-shape kernel-time table of one network forward to this file")
+    ap.add_argument("--vae-breakdown", default="", help="write the per-shape kernel-time table of one VAE decode to this file")
     ap.add_argument("--stub-engine", action="store_true", help="launcher self-test without a GPU (gloo, no kernels); not a measurement")
     return ap.parse_args(argv)
 
@@ -89,6 +90,16 @@ def _free_port():
     p = s.getsockname()[1]
     s.close()
     return p
+
+
+def write_breakdown(path, prof):
+    """Per-(kind, shape) kernel-time table of the launches a hipops.KernelProfiler saw, slowest first, one JSON object per line."""
+    rows = sorted(prof.by_tag.items(), key=lambda kv: -kv[1]["seconds"])
+    with open(path, "w") as f:
+        for (kind, tag), d in rows:
+            f.write(json.dumps({"kind": kind, "shape": tag, "launches": d["launches"], "ms": round(d["seconds"] * 1e3, 3),
+                                "tflops": round(d["flops"] / d["seconds"] / 1e12, 1) if d["flops"] else None,
+                                "GBps": round(d.get("bytes", 0.0) / d["seconds"] / 1e9, 1) if d.get("bytes") else None}) + "\n")
 
 
 def self_launch(a):
@@ -336,6 +347,12 @@ def main():
             torch.cuda.synchronize()
             vae_ms = (time.perf_counter() - t0) * 1e3
             del img
+            if a.vae_breakdown and rank == 0:
+                with hipops.KernelProfiler() as vprof:
+                    eng.decode_first_stage(lat)
+                    torch.cuda.synchronize()
+                    vprof.summary()
+                write_breakdown(a.vae_breakdown, vprof)
         t0 = time.perf_counter()
         gathered = fdist.gather_latents(lat, total)
         torch.cuda.synchronize()
@@ -364,12 +381,7 @@ def main():
                 torch.cuda.synchronize()
                 summ = prof.summary()
             if a.breakdown:
-                rows = sorted(prof.by_tag.items(), key=lambda kv: -kv[1]["seconds"])
-                with open(a.breakdown, "w") as f:
-                    for (kind, tag), d in rows:
-                        f.write(json.dumps({"kind": kind, "shape": tag, "launches": d["launches"], "ms": round(d["seconds"] * 1e3, 3),
-                                            "tflops": round(d["flops"] / d["seconds"] / 1e12, 1) if d["flops"] else None,
-                                            "GBps": round(d.get("bytes", 0.0) / d["seconds"] / 1e9, 1) if d.get("bytes") else None}) + "\n")
+                write_breakdown(a.breakdown, prof)
             if not is_flux:
                 km.use_graph = not a.no_graph
             g = summ.get("gemm_conv")

@@ -2,7 +2,8 @@
 `compute_controlnet_weighting` (:79-146), `broadcast_image_to` (:149-168), `ControlBase` (:175-272: strength, start / end percent ->
 sigma range, linked list of previous ControlNets, `control_merge`), `ControlNet.get_control` (:275-338).  The control model underneath is
 the native backend/nn/cnets/cldm.ControlNet; `T2IAdapter` / `load_t2i_adapter` (:477-586) over the native backend/nn/cnets/t2i_adapter.Adapter.
-ControlLoRA (:341-474) is not built.
+`ControlLora` (:341-474): the control model is assembled in `pre_run` from the UNet's own trunk tensors plus the file's direct tensors and
+`up @ down` pairs (summed once in fp32), and is an ordinary native ControlNet from there until `cleanup`.
 
 Residuals stay fp16 and channels-last from the ControlNet's zero convs to the UNet's `h += ctrl` (the reference casts them to the
 latent's fp32, :238-239; the native UNet consumes fp16, so the cast would only be undone)."""

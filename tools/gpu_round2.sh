@@ -18,7 +18,7 @@ for w in "$@"; do
     testsx) FMX_PARITY_LOG=$O/parity.jsonl timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -40 > $O/pytest_gpu.log; tail -8 $O/pytest_gpu.log;;
     ktests) timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q 2>&1 | tail -40 > $O/ktests.log; tail -12 $O/ktests.log;;
     smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -3 $O/smoke.log;;
-    bench) timeout 1200 python bench.py --breakdown $O/breakdown.jsonl > $O/bench.json 2> $O/bench.err; cat $O/bench.json; tail -3 $O/bench.err;;
+    bench) timeout 1200 python bench.py --breakdown $O/breakdown.jsonl --vae-breakdown $O/vae_breakdown.jsonl > $O/bench.json 2> $O/bench.err; cat $O/bench.json; tail -3 $O/bench.err;;
     bench_nofuse) FMX_GN_FUSED_STATS=0 timeout 900 python bench.py --no-cpu-baseline --breakdown $O/breakdown_nofuse.jsonl > $O/bench_nofuse.json 2> $O/bench_nofuse.err; cat $O/bench_nofuse.json; tail -3 $O/bench_nofuse.err;;
     bench_cfgs) for c in sd15-b4-eulera sdxl-b8-dpmpp2m30-vae flux-b2-bf16; do timeout 900 python bench.py --config $c --steps 8 > $O/bench_$c.json 2> $O/bench_$c.err; cat $O/bench_$c.json; tail -2 $O/bench_$c.err; done;;
     gnbench) timeout 600 python tools/bench_kernels.py gn > $O/gnbench.log 2>&1; cat $O/gnbench.log | tail -30;;
