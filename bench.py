@@ -360,7 +360,7 @@ def main():
         del gathered
 
         # ---- roofline of the dominant kernels: HIP events around every launch in one eager network forward ----------
-        roof = attn_roof = gn_roof = None
+        roof = attn_roof = xattn_roof = gn_roof = None
         if rank == 0 and not a.no_roofline:
             if is_flux:
                 net = km.diffusion_model
@@ -396,9 +396,16 @@ def main():
             at = summ.get("attention")
             if at:
                 ach = at["flops"] / at["seconds"]
-                attn_roof = {"kernel": "attn_q64_kernel / attn_kernel<d> (fmx_attention: fused QK^T-softmax-PV)", "bound": "mfma",
+                attn_roof = {"kernel": "attn_q64v2_kernel / attn_kernel<d> (fmx_attention: fused QK^T-softmax-PV), launches with more than 128 keys", "bound": "mfma",
                              "achieved": round(ach / 1e12, 1), "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK, 4),
                              "launches_per_forward": at["launches"], "kernel_time_per_forward_ms": round(at["seconds"] * 1e3, 2)}
+            xa = summ.get("attention_short_keys")
+            if xa and xa.get("bytes"):
+                ach = xa["bytes"] / xa["seconds"]
+                xattn_roof = {"kernel": "the same kernels on the 77-token text context (one or two key tiles: no key loop to pipeline)", "bound": "hbm",
+                              "achieved": round(ach / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(ach / HBM_PEAK, 4),
+                              "algorithmic_bytes": "1 read of Q, K, V + 1 write of O", "launches_per_forward": xa["launches"],
+                              "kernel_time_per_forward_ms": round(xa["seconds"] * 1e3, 2)}
             gn = summ.get("groupnorm")
             if gn and gn.get("bytes"):
                 ach = gn["bytes"] / gn["seconds"]
@@ -438,6 +445,8 @@ def main():
         out["roofline"] = roof
     if attn_roof:
         out["roofline_attention"] = attn_roof
+    if xattn_roof:
+        out["roofline_attention_short_keys"] = xattn_roof
     if gn_roof:
         out["roofline_groupnorm"] = gn_roof
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

@@ -36,6 +36,7 @@ struct AttnParams {
   const f16* mask;            // optional additive mask, element (b, h, i, j) at mask[b*mask_bs + h*mask_hs + i*mask_qs + j] (strides may be 0)
   long mask_bs, mask_hs, mask_qs;
   float inv_scale;            // 1 / scale: the mask is added to the UNSCALED score
+  int nfull, nsplit;          // q64v2: workgroups [0, nfull) own 256 queries x all keys; [nfull, nfull + nsplit) are key-split (see the kernel)
 };
 
 constexpr int KVB = 64;  // keys per tile
@@ -430,6 +431,10 @@ __global__ __launch_bounds__(256, 2) void attn_q64_kernel(const AttnParams p) {
 //   * the two LDS stages are unrolled (compile-time stage -> immediate LDS offsets, no per-tile address arithmetic), K / V^T tiles
 //     arrive by buffer_load ... lds with a uniform scalar offset per tile (no per-lane 64-bit addresses), the cross-half maximum
 //     exchange is one v_permlane32_swap instead of an LDS bpermute, and the epilogue stores 16 bytes per lane (half-wave swap).
+//   * KEY-SPLIT workgroups for the last, partial round of a launch.  A workgroup holds its CU slot for the whole key loop; when the tiles
+//     beyond the last full round of S slots (2 per CU) are fewer than the CUs, the launcher turns them into twice as many workgroups of 128
+//     queries whose wave PAIRS each walk one half of the keys (own LDS stages per pair) and merge (m, l, O) through LDS at the end: half the
+//     duration each, on CUs that would otherwise idle.  Small launches (batch 1) are all key-split.
 template <int THR>
 __global__ __launch_bounds__(256, 2) void attn_q64v2_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -441,8 +446,20 @@ __global__ __launch_bounds__(256, 2) void attn_q64v2_kernel(const AttnParams p) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, li = lane & 31;
 
-  const int nwg = p.qtiles * p.heads * p.batch;
-  const int wg = xcd_remap(blockIdx.x, nwg);
+  const int bid = blockIdx.x;
+  const bool split = bid >= p.nfull;   // workgroup-uniform
+  int wg, q_in_tile;
+  if (!split) {
+    wg = xcd_remap(bid, p.nfull);
+    q_in_tile = wave * 64;
+  } else {
+    const int sidx = xcd_remap(bid - p.nfull, p.nsplit);
+    wg = p.nfull + (sidx >> 1);
+    q_in_tile = (sidx & 1) * 128 + (wave & 1) * 64;
+  }
+  const int pair = split ? (wave >> 1) : 0;        // which half of the keys (key-split workgroups)
+  const int swave = split ? (wave & 1) : wave;     // position among the waves that share a K / V^T tile
+  const int sways = split ? 2 : 4;                 // how many waves share one
   const int qt = wg % p.qtiles;
   const int bh = wg / p.qtiles;
   const int h = bh % p.heads, b = bh / p.heads;
@@ -453,28 +470,16 @@ __global__ __launch_bounds__(256, 2) void attn_q64v2_kernel(const AttnParams p) 
   const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(kbase), 0, p.k_span, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(vbase), 0, p.vt_span, 0x00020000);
 
-  const int q0 = qt * 256 + wave * 64;
-  const float c2 = p.scale_log2e;
-  f16x8 qf[2][DSTEPS];
-#pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    const int qrow = min(q0 + a * 32 + li, p.nq - 1);
-    const f16* qp = p.q + (long)b * p.q_bs + (long)qrow * p.q_rs + (long)h * DP + hi * 8;
-#pragma unroll
-    for (int ds = 0; ds < DSTEPS; ++ds) {
-      const f16x8 raw = *reinterpret_cast<const f16x8*>(qp + ds * 16);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) qf[a][ds][e] = (f16)((float)raw[e] * c2);
-    }
-  }
-
-  // staging: K tile 64 rows x 8 chunks and V^T tile 64 rows x 8 chunks = 2 x 8 KiB, 2 + 2 DMA instructions per wave and tile;
-  // per-lane byte offsets are tile-invariant, the tile's key offset rides in the scalar offset operand
+  const int q0 = qt * 256 + q_in_tile;
+  // staging: K tile 64 rows x 8 chunks and V^T tile 64 rows x 8 chunks = 2 x 8 KiB, 2 + 2 DMA instructions per wave and tile (4 + 4 in a
+  // key-split workgroup, where two waves share a tile); per-lane byte offsets are tile-invariant, the tile's key offset rides in the
+  // scalar offset operand
   const int srow = lane >> 3, spc = lane & 7;
-  unsigned k_voff[2], v_voff[2];
+  char* const sbase = smem + pair * (2 * STAGE);   // a wave pair of a key-split workgroup has its own two stages
+  unsigned k_voff[4], v_voff[4];
 #pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const int row = (e * 4 + wave) * 8 + srow;
+  for (int e = 0; e < 4; ++e) {
+    const int row = ((e * sways + swave) * 8 + srow) & 63;
     const int c = spc ^ ((row >> 1) & 7);
     k_voff[e] = (unsigned)row * (unsigned)p.k_rs * 2u + (unsigned)c * 16u;
     v_voff[e] = (unsigned)row * (unsigned)p.vt_ds * 2u + (unsigned)c * 16u;
@@ -482,13 +487,18 @@ __global__ __launch_bounds__(256, 2) void attn_q64v2_kernel(const AttnParams p) 
   const unsigned k_tile = (unsigned)KVB * (unsigned)p.k_rs * 2u;
   auto stage = [&](auto SI, int kt) {
     constexpr int S = decltype(SI)::value;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      auto* dk = (__attribute__((address_space(3))) void*)(smem + S * STAGE + (e * 4 + wave) * 1024);
-      auto* dv = (__attribute__((address_space(3))) void*)(smem + S * STAGE + KBYTES + (e * 4 + wave) * 1024);
+    auto piece = [&](int e) {
+      auto* dk = (__attribute__((address_space(3))) void*)(sbase + S * STAGE + (e * sways + swave) * 1024);
+      auto* dv = (__attribute__((address_space(3))) void*)(sbase + S * STAGE + KBYTES + (e * sways + swave) * 1024);
       const unsigned kv = k_voff[e], vv = v_voff[e];
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, dk, 16, kv, (unsigned)kt * k_tile, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, dv, 16, vv, (unsigned)kt * (KVB * 2u), 0, 0);
+    };
+    piece(0);
+    piece(1);
+    if (split) {
+      piece(2);
+      piece(3);
     }
   };
 
@@ -510,16 +520,33 @@ __global__ __launch_bounds__(256, 2) void attn_q64v2_kernel(const AttnParams p) 
     mfrag[0][e] = mfrag[1][e] = (f16)0.0f;
   }
 
-  const int ntiles = (p.nk + KVB - 1) / KVB;
-  stage(IC<0>{}, 0);
+  const int ntiles_all = (p.nk + KVB - 1) / KVB;
+  const int ntiles = split ? ntiles_all >> 1 : ntiles_all;   // the launcher splits only an even number of key tiles
+  const int kt0 = pair * ntiles;
+  stage(IC<0>{}, kt0);   // first: its round trip to HBM overlaps the Q loads below
+
+  const float c2 = p.scale_log2e;
+  f16x8 qf[2][DSTEPS];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int qrow = min(q0 + a * 32 + li, p.nq - 1);
+    const f16* qp = p.q + (long)b * p.q_bs + (long)qrow * p.q_rs + (long)h * DP + hi * 8;
+#pragma unroll
+    for (int ds = 0; ds < DSTEPS; ++ds) {
+      const f16x8 raw = *reinterpret_cast<const f16x8*>(qp + ds * 16);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qf[a][ds][e] = (f16)((float)raw[e] * c2);
+    }
+  }
   wait_vmcnt0();
   __syncthreads();
 
   const int krow = key_perm(li);
-  auto tile = [&](auto SI, int kt) {
+  auto tile = [&](auto SI, int j) {   // j: position in this wave's key range
     constexpr int S = decltype(SI)::value;
-    if (kt + 1 < ntiles) stage(IC<S ^ 1>{}, kt + 1);
-    const char* sk = smem + S * STAGE;
+    const int kt = kt0 + j;
+    if (j + 1 < ntiles) stage(IC<S ^ 1>{}, kt + 1);
+    const char* sk = sbase + S * STAGE;
     const char* sv = sk + KBYTES;
 
     f32x16 sacc[2][2];  // [32-key sub-tile][query fragment] = score * c - running max
@@ -578,7 +605,7 @@ __global__ __launch_bounds__(256, 2) void attn_q64v2_kernel(const AttnParams p) 
       const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m0), __float_as_uint(m0), false, false);
       mx[a] = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));   // {own, other half-wave's} in some order
     }
-    const bool first = kt == 0;
+    const bool first = j == 0;
     if (first || __any(fmaxf(mx[0], mx[1]) > (float)THR)) {   // wave-uniform; rare after the first few tiles
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
@@ -647,9 +674,41 @@ __global__ __launch_bounds__(256, 2) void attn_q64v2_kernel(const AttnParams p) 
     wait_vmcnt0();
     __syncthreads();
   };
-  for (int kt = 0; kt < ntiles; kt += 2) {
-    tile(IC<0>{}, kt);
-    if (kt + 1 < ntiles) tile(IC<1>{}, kt + 1);
+  for (int j = 0; j < ntiles; j += 2) {
+    tile(IC<0>{}, j);
+    if (j + 1 < ntiles) tile(IC<1>{}, j + 1);
+  }
+
+  // ---- key-split workgroups: the pair that walked the upper half of the keys hands (O, m, l) to its partner through LDS (the stages are
+  //      idle: the last tile ended with a barrier); same code, so lane i holds the same (query, channel) elements in both waves ----------
+  if (split) {
+    float* ex = reinterpret_cast<float*>(smem) + (wave & 1) * (68 * 64) + lane;
+    if (pair == 1) {
+#pragma unroll
+      for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ex[((dt * 2 + a) * 16 + r) * 64] = oacc[dt][a][r];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        ex[(64 + a) * 64] = m_run[a];
+        ex[(66 + a) * 64] = l_run[a];
+      }
+    }
+    __syncthreads();
+    if (pair == 1) return;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const float m1 = ex[(64 + a) * 64], l1 = ex[(66 + a) * 64];
+      const float m = fmaxf(m_run[a], m1);
+      const float f0 = __builtin_amdgcn_exp2f(m_run[a] - m), f1 = __builtin_amdgcn_exp2f(m1 - m);
+      l_run[a] = l_run[a] * f0 + l1 * f1;
+#pragma unroll
+      for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][a][r] = oacc[dt][a][r] * f0 + ex[((dt * 2 + a) * 16 + r) * 64] * f1;
+    }
   }
 
   // ---- finish: 1/l, O[b][q][h*64 + d]; lane = query.  A lane holds 4-wide runs of d (registers g*4.., d = dt*32 + g*8 + hi*4); one
@@ -684,14 +743,19 @@ __global__ __launch_bounds__(256, 2) void attn_q64v2_kernel(const AttnParams p) 
 
 int launch_attn_q64(AttnParams p, hipStream_t st) {
   const int smem = 2 * (KVB * 64 * 2 + 2 * 32 * 128);
-  static int variant = -1;
+  static int variant = -1, slots = 512, allow_split = 1;
   if (variant < 0) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+      slots = 2 * cus;   // two 4-wave workgroups per CU at this kernel's register count
+    const char* sp = getenv("FMX_ATTN_SPLIT");   // A/B knob: 0 disables the key-split workgroups
+    allow_split = sp ? atoi(sp) : 1;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_q64v2_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * smem);
     // A/B knob (tools/bench_kernels.py attn): FMX_ATTN_VARIANT=1 selects the first-generation kernel (round 1: 823 / 729 TFLOP/s at
     // N = 4096 / 1024), 0 (default) the second-generation one.
     const char* e = getenv("FMX_ATTN_VARIANT");
     variant = e ? atoi(e) : 0;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_q64_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_q64v2_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   }
   p.qtiles = (p.nq + 255) / 256;
   const int grid = p.qtiles * p.heads * p.batch;
@@ -700,7 +764,16 @@ int launch_attn_q64(AttnParams p, hipStream_t st) {
   if (variant == 0 && k_span < 2.0e9 && v_span < 2.0e9 && p.k_rs > 0 && p.vt_ds > 0) {
     p.k_span = (unsigned)k_span;
     p.vt_span = (unsigned)v_span;
-    hipLaunchKernelGGL(attn_q64v2_kernel<6>, dim3(grid), dim3(256), smem, st, p);
+    // tiles beyond the last full round of `slots` workgroups: as key-split workgroups (2 per tile, half as long each) when they would leave
+    // CUs idle (fewer tiles than 3/4 of the CUs).  Measured (tools/bench_kernels.py attn, FMX_ATTN_SPLIT A/B): 640
+    // tiles (SDXL 1024-token level at batch 8) 58.7 -> 52.5 us; with one tile per CU left (1280 tiles = 2.5 rounds) splitting gains nothing --
+    // a workgroup alone on its CU already runs ~1.6x faster than one of two.  Needs an even number of key tiles to halve.
+    const int ntiles = (p.nk + KVB - 1) / KVB;
+    const int rem = grid % slots;
+    const bool do_split = allow_split && rem > 0 && 8 * rem <= 3 * slots && ntiles >= 4 && (ntiles & 1) == 0;
+    p.nfull = do_split ? grid - rem : grid;
+    p.nsplit = do_split ? 2 * rem : 0;
+    hipLaunchKernelGGL(attn_q64v2_kernel<6>, dim3(p.nfull + p.nsplit), dim3(256), do_split ? 2 * smem : smem, st, p);
   } else {
     hipLaunchKernelGGL(attn_q64_kernel<0>, dim3(grid), dim3(256), smem, st, p);
   }

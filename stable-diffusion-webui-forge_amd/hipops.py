@@ -283,8 +283,13 @@ def attention(q, k, vt, *, batch, heads, nq, nk, nk_pad, dpad, scale, q_bs, q_rs
     if _profiler is not None:
         d_true = int(round(float(scale) ** -2))
         flops = 4.0 * batch * heads * nq * nk * d_true
-        _profiler.launch("attention", flops, lambda: _lib.check(getattr(_lib.lib(), fn_name)(C.byref(a), stream_ptr()), fn_name),
-                         tag=f"B={batch} H={heads} Nq={nq} Nk={nk} d={dpad}")
+        # one key tile or two (the 77-token text context): no loop over keys, the launch is one read of Q + one write of O -> its own
+        # family with an HBM roofline (bench.py)
+        short = nk <= 128
+        _profiler.launch("attention_short_keys" if short else "attention", flops,
+                         lambda: _lib.check(getattr(_lib.lib(), fn_name)(C.byref(a), stream_ptr()), fn_name),
+                         tag=f"B={batch} H={heads} Nq={nq} Nk={nk} d={dpad}",
+                         nbytes=2.0 * batch * heads * dpad * (2 * nq + 2 * nk) if short else 0.0)
         return out
     _lib.check(getattr(_lib.lib(), fn_name)(C.byref(a), stream_ptr()), fn_name)
     return out

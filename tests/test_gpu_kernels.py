@@ -293,6 +293,24 @@ def test_attention_d64_generations_agree(monkeypatch):
     close(a, c.float(), 2e-3, 1e-3, "q64v2 vs 32-query kernel")
 
 
+@pytest.mark.parametrize("b,h,nq,nk", [(3, 25, 1024, 1024), (9, 16, 1000, 1024), (2, 3, 1000, 1000), (1, 2, 200, 512), (9, 16, 1024, 320)])
+def test_attention_d64_partial_round_key_split(b, h, nq, nk):
+    """The d_head-64 kernel turns the 256-query tiles beyond the last full round of workgroup slots (2 per CU) into key-split workgroups: two
+    per tile, 128 queries each, wave pairs walking one half of the keys and merging (m, l, O) through LDS (csrc/fmx_attention.hip).  On a
+    256-CU part: 300 tiles -> none split (the remainder would not fit one round); 576 tiles -> 512 whole + 128 key-split workgroups in ONE
+    launch, with a ragged last query tile; small launches -> all key-split, incl. ragged queries and a ragged last key tile in the upper half;
+    an odd number of key tiles (320 keys = 5) -> never split."""
+    d = 64
+    nkp = -(-nk // 64) * 64
+    q, k, v = rnd(b, nq, h, d, seed=61), torch.zeros(b, nkp, h, d, dtype=torch.float16, device=DEV), torch.zeros(b, nkp, h, d, dtype=torch.float16, device=DEV)
+    k[:, :nk], v[:, :nk] = rnd(b, nk, h, d, scale=1.3, seed=62), rnd(b, nk, h, d, seed=63)
+    k[:, nk:], v[:, nk:] = 6.0, -4.0
+    k[0, nk - 3, 0] = q[0, nq - 1, 0] * 5          # a dominant key at the very end of the upper half, for the last query
+    k[b - 1, 2, h - 1] = q[b - 1, 0, h - 1] * 5    # and one at the start of the lower half, for the first
+    ref = _attn_ref(q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3)[:, :, :nk], v.permute(0, 2, 1, 3)[:, :, :nk], d ** -0.5)
+    close(_attn_d64(q, k, v, nk=nk), ref, 2e-3, 2e-3, f"attention d64 b{b} h{h} nq{nq} nk{nk}")
+
+
 def test_softmax_rows():
     x = rnd(300, 1000, scale=3, seed=60)
     ref = x.float().softmax(-1)

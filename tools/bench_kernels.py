@@ -172,6 +172,9 @@ if __name__ == "__main__":
             bench_attn(16, 20, 1024, 77, 64, 64, f32)
             bench_attn(16, 10, 4096, 77, 64, 64, f32)
             bench_attn(2, 10, 4096, 4096, 64, 64, f32)
+            bench_attn(8, 10, 4096, 4096, 64, 64, f32)   # batch 4 under CFG: 1280 tiles = 2.5 rounds
+            bench_attn(8, 20, 1024, 1024, 64, 64, f32)   # 640 tiles = 1.25 rounds
+            bench_attn(2, 20, 1024, 1024, 64, 64, f32)   # batch 1 under CFG: 160 tiles
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "smallm":
         # batch-1 shapes (UNet batch 2): which tile is fastest, and what does the dispatcher (tile 0) pick?
