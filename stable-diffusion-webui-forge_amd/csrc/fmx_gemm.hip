@@ -311,8 +311,55 @@ __global__ void geglu_interleave_kernel(const f16* __restrict__ w_in, const f16*
 
 int fmx_launch_gn_stats(const void* x, int32_t c, int64_t ld, int32_t n, int32_t hw, float* partial, int32_t nchunks, hipStream_t st);  // fmx_norm.hip
 
+static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, int fallback_chunks, int* chunks_out, void* stream);
+
 // stats != null: also leave the GroupNorm statistics of the output in stats[n][chunks][nout][2] (see fmx_gemm_conv_stats_f16 in fmx.h)
+//
+// The 8-wave kernels address an operand with 32-bit byte offsets from its base.  An activation tensor beyond that range (the VAE decoder's
+// 8 x 1024 x 1024 x 256 input of its last level is 4.3 GB) is processed as equal groups of whole images -- images are independent rows of the
+// implicit GEMM -- each a launch of its own with the bases moved; the groups are identical in shape, so they pick the same tile and the same
+// statistics chunking.
 static int gemm_conv_impl(const fmx_gemm_args* a, float* stats, int max_chunks, int fallback_chunks, int* chunks_out, void* stream) {
+  FMX_REQUIRE(a && a->a0 && a->wgt && a->out && a->zero_page, "gemm: null pointer");
+  if (a->n > 1 && a->h > 0 && a->w > 0 && a->c0 > 0) {
+    const double s0 = a->a0_stride ? a->a0_stride : a->c0, s1 = a->a1_stride ? a->a1_stride : a->c1;
+    const double per_img = (double)a->h * a->w;
+    auto fits = [&](int imgs) { return imgs * per_img * s0 * 2.0 < 3.0e9 && (a->c1 == 0 || imgs * per_img * s1 * 2.0 < 3.0e9); };
+    if (!fits(a->n)) {
+      int groups = 0;
+      for (int d = 2; d <= a->n; ++d)
+        if (a->n % d == 0 && fits(a->n / d)) { groups = d; break; }
+      if (groups) {
+        const int gi = a->n / groups;
+        const long in_pix = (long)gi * a->h * a->w, out_pix = (long)gi * a->oh * a->ow;
+        int chunks = 0;
+        for (int g = 0; g < groups; ++g) {
+          fmx_gemm_args b = *a;
+          b.n = gi;
+          b.a0 = (const char*)a->a0 + g * in_pix * (long)s0 * 2;
+          if (a->a1) b.a1 = (const char*)a->a1 + g * in_pix * (long)s1 * 2;
+          b.out = (char*)a->out + g * out_pix * a->ld_out * (a->out_f32 > 0 ? 4 : 2);
+          if (a->residual) b.residual = (const char*)a->residual + g * out_pix * a->ld_res * 2;
+          if (a->rowvec) b.rowvec = (const char*)a->rowvec + (long)g * gi * a->ld_rowvec * 2;
+          if (a->gate) b.gate = (const char*)a->gate + (long)g * gi * a->ld_gate * 2;
+          int got = 0;
+          float* st = stats ? stats + (long)g * gi * chunks * a->nout * 2 : nullptr;
+          const int rc = gemm_conv_one(&b, st, max_chunks, fallback_chunks, stats ? &got : nullptr, stream);
+          if (rc != FMX_OK) return rc;
+          if (stats) {
+            FMX_REQUIRE(g == 0 || got == chunks, "gemm: image groups disagree on the statistics chunking");
+            chunks = got;
+          }
+        }
+        if (stats) *chunks_out = chunks;
+        return FMX_OK;
+      }
+    }
+  }
+  return gemm_conv_one(a, stats, max_chunks, fallback_chunks, chunks_out, stream);
+}
+
+static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, int fallback_chunks, int* chunks_out, void* stream) {
   FMX_REQUIRE(a && a->a0 && a->wgt && a->out && a->zero_page, "gemm: null pointer");
   const int ctot = a->c0 + a->c1;
   FMX_REQUIRE(a->c0 > 0 && a->c1 >= 0 && (a->c0 % 64) == 0 && (ctot % 64) == 0, "gemm: channels (%d,%d) must be multiples of 64", a->c0, a->c1);
@@ -366,7 +413,7 @@ static int gemm_conv_impl(const fmx_gemm_args* a, float* stats, int max_chunks, 
   // element in K-tiles (it scales with the tile area), F = per-tile fixed latency (prologue + first loads, ~1.5 K-tiles of a
   // 256x256 tile; half of it hides behind the CU's other workgroup for the 4-wave kernels).  Padding rows / columns are
   // counted through the tile area.
-  // sel: 0 = 128x128, 1 = 128x64, 2 = 64x64, 4 = 128x160, 5 / 6 / 7 = 256x256 / 256x320 / 320x256 pipelined
+  // sel: 0 = 128x128, 1 = 128x64, 2 = 64x64, 4 = 128x160, 5 / 6 / 7 / 8 = 256x256 / 256x320 / 320x256 / 512x128 pipelined
   auto tiles = [&](int bm, int bn) { return (double)((p.M + bm - 1) / bm) * (double)((p.nout + bn - 1) / bn); };
   const double kt = p.kt;
   const bool geglu = a->act == FMX_ACT_GEGLU;
@@ -385,7 +432,12 @@ static int gemm_conv_impl(const fmx_gemm_args* a, float* stats, int max_chunks, 
   if (big_ok) consider(5, cost(256, 256, 1, 0.97, e8, F8));
   if (big_ok && (!geglu || (p.nout % 32) == 0)) consider(6, cost(256, 320, 1, 1.0, e8, F8));
   if (big_ok && !geglu) consider(7, cost(320, 256, 1, 0.97, e8, F8));  // only where its row quantisation wins (M = 320 k: the V^T GEMM)
-  if (a->out_f32 < 0) sel = (-a->out_f32 - 1) % 8;  // test hook: force a tile shape (out_f32 = -1..-8 -> fp16 out)
+  // 512x128: narrow outputs (the VAE decoder's 128-channel level); its address path takes single-source convolutions without upsample-on-load
+  const bool narrow_ok = big_ok && !geglu && (!conv || (p.c1 == 0 && a->up_h == 0));
+  if (narrow_ok) consider(8, cost(512, 128, 1, 0.86, e8, F8));
+  if (a->out_f32 < 0) sel = (-a->out_f32 - 1) % 16;  // test hook: force a tile shape (out_f32 = -1..-9 -> fp16 out)
+  FMX_REQUIRE(sel <= 8, "gemm: unknown tile id");
+  FMX_REQUIRE(sel != 8 || (!geglu && (!conv || (p.c1 == 0 && a->up_h == 0))), "gemm: the 512x128 tile takes no GEGLU, second source or upsample-on-load");
   FMX_REQUIRE(sel != 3, "gemm: tile id 4 (the first-generation ping-pong kernel) is no longer part of the library");
   FMX_REQUIRE(sel != 4 || a->act != FMX_ACT_GEGLU, "gemm: the 128x160 tile does not support GEGLU");
   if (a->out_f32 < 0) p.out_f32 = 0;
@@ -396,9 +448,10 @@ static int gemm_conv_impl(const fmx_gemm_args* a, float* stats, int max_chunks, 
     FMX_REQUIRE(!geglu && !p.out_f32 && p.ld_out == p.nout && (p.nout % 8) == 0 && !p.gate && a->act == FMX_ACT_NONE,
                 "gemm: output statistics need a dense fp16 [M][nout] output without activation / gate");
     FMX_REQUIRE(fallback_chunks >= 1 && fallback_chunks <= 1024 && max_chunks >= fallback_chunks, "gemm: bad statistics chunk counts");
-    if ((sel == 5 || sel == 6) && (per_img % 256) == 0 && per_img / 256 <= max_chunks) {
+    const int rows = sel == 8 ? 512 : 256;
+    if ((sel == 5 || sel == 6 || sel == 8) && (per_img % rows) == 0 && per_img / rows <= max_chunks) {
       p.stats = stats;
-      p.stats_nch = per_img / 256;
+      p.stats_nch = per_img / rows;
       *chunks_out = p.stats_nch;
     } else {
       stats_after = true;
@@ -409,7 +462,7 @@ static int gemm_conv_impl(const fmx_gemm_args* a, float* stats, int max_chunks, 
   if (sel >= 5) {
     FMX_REQUIRE(FastEpilogue::eligible8(p) && fits32, "gemm: the 256-row kernels need fp16 output, 16-byte aligned epilogue operands, leading dimensions / nout multiples of 8, operands < 2^32 elements");
     if (sel == 6) FMX_REQUIRE(a->act != FMX_ACT_GEGLU || (p.nout % 32) == 0, "gemm: GEGLU needs nout % 32 == 0");
-    rc = fmx_launch_gemm256p(p, conv, sel == 7 ? 320 : 256, sel == 6 ? 320 : 256, st);
+    rc = fmx_launch_gemm256p(p, conv, sel == 8 ? 512 : sel == 7 ? 320 : 256, sel == 8 ? 128 : sel == 6 ? 320 : 256, st);
   } else if (sel == 4) {
     rc = conv ? launch<128, 160, true>(p, st) : launch<128, 160, false>(p, st);
   } else if (conv) {

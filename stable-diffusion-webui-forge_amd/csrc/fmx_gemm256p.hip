@@ -1,4 +1,4 @@
-// 256 x BN-tile implicit-GEMM convolution / linear for gfx950, software-pipelined ("gemm256p"), BN = 256 or 320.
+// 256 x BN-tile (BN = 256 or 320), 320 x 256 and 512 x 128 implicit-GEMM convolution / linear for gfx950, software-pipelined ("gemm256p").
 //
 // The first-generation 8-wave kernel (tools/legacy/fmx_gemm256_pingpong.hip, no longer part of the library) alternated two wave
 // groups through 8 barrier-separated slots per K-tile (one group loads while the other owns the matrix pipe); its s_memtime
@@ -8,6 +8,9 @@
 //   BN = 256: waves 2 (M) x 4 (N), wave tile 128 x 64  = 4 x 2 accumulator blocks of 32 x 32,  8 MFMA / 6 ds_read per k-step
 //   BN = 320: waves 4 (M) x 2 (N), wave tile  64 x 160 = 2 x 5 blocks,                        10 MFMA / 7 ds_read per k-step
 //   BM = 320 (x 256): waves 2 x 4, wave tile 160 x 64 = 5 x 2 blocks -- the same thing for the operand-swapped V^T GEMM
+//   512 x 128: waves 4 (M) x 2 (N), wave tile 128 x 64 = 4 x 2 blocks (the 256 x 256 kernel's inner loop) -- for layers with 128 output
+//   channels (the VAE decoder's 1024^2 level), where a 256-wide tile would compute 50 % padding; 8 + 2 LDS-DMA pieces per wave and K-tile,
+//   so the implicit-GEMM address arithmetic is the per-tap bit mask form (see FASTADDR below)
 //   (v_mfma_f32_32x32x16_f16, weights as MFMA-A, activations as MFMA-B).  320 is the native width of the SD family: every
 //   channel count is 320 k, so N = 320 / 640 / 1280 tile with no padding columns and (M, N) = (16384, 1280) is exactly
 //   256 tiles = one round of the 256 CUs (256-wide tiles: 320 tiles = 1.25 rounds), with 10 % fewer LDS-DMA bytes per FLOP.
@@ -47,14 +50,15 @@ struct Piece {  // one DMA instruction: per-lane byte offset, uniform byte offse
 
 template <int BM, int BN>
 struct Geo {
-  static constexpr int WN = BN == 320 ? 2 : 4;          // waves along N
+  static constexpr int WN = (BN == 320 || BN == 128) ? 2 : 4;   // waves along N
   static constexpr int WM = 8 / WN;                     // waves along M
   static constexpr int MI = BM / (WM * 32);             // 32-row blocks per wave along M
   static constexpr int NJ = BN / (WN * 32);             // 32-col blocks per wave along N
   static constexpr int NPA = BM / 64, NPB = BN / 64;    // LDS-DMA pieces per wave per K-tile (8 rows x 128 B each)
   static constexpr int NP = NPA + NPB;
   static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
-  static constexpr int WAVE_EPI_BYTES = (BM == 256 && BN == 256) ? 16384 : 20480;  // per-wave transpose buffer of the epilogue
+  // per-wave transpose buffer of the epilogue: one 32-row block row of NJ*32 fp32, or (GEGLU) the wave's whole MI*32 x NJ*16 sub-tile
+  static constexpr int WAVE_EPI_BYTES = 32 * NJ * 128 > MI * 32 * NJ * 64 ? 32 * NJ * 128 : MI * 32 * NJ * 64;
   static constexpr int LDS_BYTES = 2 * STAGE_BYTES > 8 * WAVE_EPI_BYTES ? 2 * STAGE_BYTES : 8 * WAVE_EPI_BYTES;  // 128 / 160 KiB
 };
 
@@ -174,12 +178,34 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   const __amdgpu_buffer_rsrc_t rs_a0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(p.a0), 0, p.a0_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(p.a1 ? p.a1 : p.a0), 0, p.a1_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(p.wgt), 0, p.w_bytes, 0x00020000);
+  // FASTADDR (the 512-row tile: 8 activation pieces per wave and K-tile): the host sends only single-source convolutions without
+  // upsample-on-load here, for which a piece's pixel offset is  base(lane) + (ky * w + kx) * stride  with a UNIFORM second term, and its
+  // validity one bit of a per-lane 9-bit mask computed once: 3 VALU instructions per piece instead of ~15.
+  constexpr bool FASTADDR = CONV && BM == 512;
   int a_pix[NPA], a_yx[NPA];
   unsigned b_off[NPB];
 #pragma unroll
   for (int s = 0; s < NPA; ++s) {
     const int m = m0 + s * 64 + wave * 8 + r8;
-    if (CONV) {
+    if (FASTADDR) {
+      const int per = p.oh * p.ow;
+      const int mm = min(m, p.M - 1);
+      const int img = mm / per;
+      const int rem = mm - img * per;
+      const int oy = rem / p.ow;
+      const int ox = rem - oy * p.ow;
+      const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+      unsigned mask = 0;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const bool ok = m < p.M && ky < p.kh && kx < p.kh && iy0 + ky >= 0 && iy0 + ky < p.h && ix0 + kx >= 0 && ix0 + kx < p.w;
+          mask |= (ok ? 1u : 0u) << (ky * 3 + kx);
+        }
+      a_pix[s] = (int)((unsigned)(img * p.h * p.w + iy0 * p.w + ix0) * (unsigned)p.s0 * 2u + kcb);   // modular: exact whenever the tap is valid
+      a_yx[s] = (int)mask;
+    } else if (CONV) {
       const int per = p.oh * p.ow;
       const int mm = min(m, p.M - 1);
       const int img = mm / per;
@@ -202,6 +228,11 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   }
 
   auto a_piece = [&](int s, const Cursor& c) -> Piece {
+    if (FASTADDR) {
+      const unsigned delta = (unsigned)(c.ky * p.w + c.kx) * (unsigned)p.s0 * 2u;   // uniform (scalar ALU)
+      const bool ok = ((unsigned)a_yx[s] >> (c.ky * 3 + c.kx)) & 1u;
+      return Piece{ok ? (unsigned)a_pix[s] + delta : OOB, (unsigned)c.cc * 2u, false};
+    }
     const bool second = c.cc >= p.c0;  // uniform
     const unsigned sstride = second ? (unsigned)p.s1 : (unsigned)p.s0;
     const unsigned coff = second ? (unsigned)(c.cc - p.c0) : (unsigned)c.cc;
@@ -309,6 +340,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
     if constexpr (lo + 6 < hi) issue_piece(IC<lo + 6>{}, c, buf);
     if constexpr (lo + 7 < hi) issue_piece(IC<lo + 7>{}, c, buf);
     if constexpr (lo + 8 < hi) issue_piece(IC<lo + 8>{}, c, buf);
+    if constexpr (lo + 9 < hi) issue_piece(IC<lo + 9>{}, c, buf);
   };
   // ---- prologue: tile 0 complete, the first P0 pieces of tile 1 in flight ------------------------------------------------------
   Cursor c1{0, 0, 0, 0};
@@ -409,8 +441,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
 #undef FMX_EPI_ARGS
     }
     if (STATS) {
-      // GroupNorm statistics of this 256-row tile (= chunk `m0 % per_img / 256` of image `m0 / per_img`; the host guarantees
-      // per_img % 256 == 0 and M % 256 == 0).  A lane holds the sums of its 8 columns over the rows it stored.  Fold
+      // GroupNorm statistics of this BM-row tile (= chunk `m0 % per_img / BM` of image `m0 / per_img`; the host guarantees
+      // per_img % BM == 0, hence M % BM == 0).  A lane holds the sums of its 8 columns over the rows it stored.  Fold
       //   (1) the RPI row-lanes of each column group inside the wave: through the wave's own LDS slice (idle now; LDS operations of
       //       one wave execute in order, so no barrier is needed to reuse it),
       //   (2) the WM waves that share the tile's columns: every wave leaves its sums at a fixed place of its slice, one barrier,
@@ -443,7 +475,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
           for (int v = 0; v < 4; ++v) a4[v] += *reinterpret_cast<const f32x4*>(o + v * 4);
         }
         const int img = m0 / ep.per_img;
-        const int chunk = (m0 - img * ep.per_img) >> 8;
+        const int chunk = (m0 - img * ep.per_img) / BM;
         float* dst = p.stats + ((long)(img * p.stats_nch + chunk) * ep.nout + nb) * 2;   // a4[0..1] = sums, a4[2..3] = sums of squares
         *reinterpret_cast<f32x4*>(dst) = f32x4{a4[0][0], a4[2][0], a4[0][1], a4[2][1]};
         *reinterpret_cast<f32x4*>(dst + 4) = f32x4{a4[0][2], a4[2][2], a4[0][3], a4[2][3]};
@@ -552,6 +584,7 @@ int fmx_launch_gemm256p(const GemmParams& p, bool conv, int bm, int bn, hipStrea
     return sched == 1 ? launch_bn<256, 320, false, 0, 0>(p, conv, st) : sched == 2 ? launch_bn<256, 320, false, 1, 1>(p, conv, st)
                                                                                     : launch_bn<256, 320, false, 2, 2>(p, conv, st);
   if (bm == 320) return launch_bn<320, 256, false>(p, conv, st);
+  if (bm == 512) return p.stats ? launch_bn<512, 128, true>(p, conv, st) : launch_bn<512, 128, false>(p, conv, st);
   if (p.stats) return bn == 320 ? launch_bn<256, 320, true>(p, conv, st) : launch_bn<256, 256, true>(p, conv, st);   // output statistics: 256-row tiles only
   return bn == 320 ? launch_bn<256, 320, false>(p, conv, st) : launch_bn<256, 256, false>(p, conv, st);
 }

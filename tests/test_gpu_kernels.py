@@ -31,9 +31,9 @@ def close(got, want, rtol, atol, what=""):
 
 # ----------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("m,n,k", [(256, 256, 128), (384, 320, 320), (77 * 2, 640, 768), (1000, 132, 64), (4096, 1280, 1280), (130, 4, 2880)])
-@pytest.mark.parametrize("tile", [1, 2, 3, 5, 6, 7, 8])
+@pytest.mark.parametrize("tile", [1, 2, 3, 5, 6, 7, 8, 9])
 def test_linear_plain(m, n, k, tile):
-    if tile in (4, 6, 7, 8) and n % 8:
+    if tile in (4, 6, 7, 8, 9) and n % 8:
         pytest.skip("256x256 kernel needs nout % 8 == 0 (dispatcher never selects it otherwise)")
     x = rnd(m, k, seed=1)
     w = rnd(n, k, scale=1 / math.sqrt(k), seed=2)
@@ -41,6 +41,47 @@ def test_linear_plain(m, n, k, tile):
     out = ops.linear(x, w, b, force_tile=tile)
     ref = x.float() @ w.float().t() + b.float()
     close(out, ref, 2e-3, 2e-3, "linear")
+
+
+def test_narrow_tile_refuses_what_its_address_path_cannot_do():
+    x = rnd(2, 8, 8, 128, seed=8)
+    wk = rnd(64, 128 * 9, scale=0.03, seed=9)
+    with pytest.raises(Exception, match="512x128"):
+        ops.conv_gemm(x, wk, 64, kh=3, pad=1, up=(16, 16), force_tile=9)
+
+
+@pytest.mark.parametrize("n,hh,ww,c,co", [(2, 64, 64, 128, 128), (1, 96, 80, 256, 128), (2, 40, 24, 128, 384)])
+def test_narrow_outputs_pick_a_correct_kernel(n, hh, ww, c, co):
+    """Layers with 128 output channels at large pixel counts (the VAE decoder's last level): whatever tile the dispatcher picks (the 512x128
+    one on a 256-CU part) must agree with conv2d, borders and ragged last tiles included."""
+    x = rnd(n, hh, ww, c, seed=25)
+    wt = rnd(co, c, 3, 3, scale=1 / math.sqrt(c * 9), seed=26)
+    b = rnd(co, seed=27)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).float(), wt.float(), b.float(), padding=1).permute(0, 2, 3, 1)
+    out = ops.conv_gemm(x, wt.permute(0, 2, 3, 1).reshape(co, -1).contiguous(), co, kh=3, pad=1, bias=b)
+    close(out.reshape(ref.shape), ref, 3e-3, 3e-3, "narrow conv")
+
+
+def test_conv_input_beyond_32bit_offsets_runs_as_image_groups():
+    """An activation tensor of more than 3e9 bytes (the VAE decoder's 8 x 1024 x 1024 x 256 level) cannot be addressed with the 8-wave kernels'
+    32-bit offsets: fmx_gemm_conv(_stats)_f16 runs it as groups of whole images (csrc/fmx_gemm.hip).  4 x 1024 x 768 x 512 input (3.2 GB), 3x3
+    to 64 channels with a per-image row vector and a residual, statistics requested; reference: conv2d per image on the same fp16 data."""
+    n, hh, ww, c, co = 4, 1024, 768, 512, 64
+    g = torch.Generator(DEV).manual_seed(77)
+    x = torch.randn(n, hh, ww, c, generator=g, device=DEV, dtype=torch.float16)
+    wt = (torch.randn(co, c, 3, 3, generator=g, device=DEV) / math.sqrt(c * 9)).half()
+    b, emb = rnd(co, seed=78), rnd(n, co, seed=79)
+    res = torch.randn(n * hh * ww, co, generator=g, device=DEV, dtype=torch.float16)
+    out, st = ops.conv_gemm(x, wt.permute(0, 2, 3, 1).reshape(co, -1).contiguous(), co, kh=3, pad=1, bias=b, rowvec=emb, residual=res, stats=True)
+    out = out.view(n, hh, ww, co)
+    for i in range(n):
+        ref = F.conv2d(x[i:i + 1].permute(0, 3, 1, 2).float(), wt.float(), b.float(), padding=1) + emb[i].float()[None, :, None, None]
+        ref = ref.permute(0, 2, 3, 1)[0] + res.view(n, hh, ww, co)[i].float()
+        close(out[i], ref, 3e-3, 3e-3, f"image {i} of an input beyond 32-bit offsets")
+        del ref
+    o = out.reshape(n, hh * ww, co).double()
+    want = torch.stack([o.sum(1), (o * o).sum(1)], -1)
+    torch.testing.assert_close(_partial_to_sums(st, n, co), want, rtol=2e-5, atol=2e-2)
 
 
 def test_linear_asymmetric_identity():
@@ -100,10 +141,12 @@ def test_linear_two_source_and_vt():
     dict(n=2, h=16, w=16, c=128, co=4, kh=3, stride=1, pad=1),
     dict(n=2, h=12, w=12, c=64, co=128, kh=1, stride=1, pad=0),
 ])
-@pytest.mark.parametrize("tile", [0, 3, 5, 6, 7, 8])
+@pytest.mark.parametrize("tile", [0, 3, 5, 6, 7, 8, 9])
 def test_conv(cfg, tile):
-    if tile in (4, 6, 7, 8) and cfg["co"] % 8:
+    if tile in (4, 6, 7, 8, 9) and cfg["co"] % 8:
         pytest.skip("256x256 kernel needs nout % 8 == 0")
+    if tile == 9 and cfg.get("up"):
+        pytest.skip("the 512x128 tile's address path takes no upsample-on-load (the dispatcher never sends one there)")
     n, h, w, c, co, kh = cfg["n"], cfg["h"], cfg["w"], cfg["c"], cfg["co"], cfg["kh"]
     x = rnd(n, h, w, c, seed=20)
     wt = rnd(co, c, kh, kh, scale=1 / math.sqrt(c * kh * kh), seed=21)  # torch layout [Cout,Cin,kh,kw]
@@ -340,7 +383,8 @@ def _partial_to_sums(st, n, c):
 
 
 @pytest.mark.parametrize("n,hh,ww,cin,cout,kh,tile", [(2, 32, 32, 64, 320, 3, 7), (2, 16, 32, 128, 640, 1, 7), (3, 16, 16, 64, 256, 3, 6), (2, 32, 32, 64, 320, 1, 0),
-                                                        (1, 48, 16, 64, 1280, 3, 7), (2, 10, 10, 64, 320, 3, 7), (2, 8, 8, 128, 320, 3, 0)])
+                                                        (1, 48, 16, 64, 1280, 3, 7), (2, 10, 10, 64, 320, 3, 7), (2, 8, 8, 128, 320, 3, 0),
+                                                        (2, 32, 32, 64, 128, 3, 9), (1, 64, 64, 128, 136, 3, 9), (3, 32, 16, 64, 128, 1, 9), (2, 24, 16, 64, 128, 3, 9)])
 def test_gemm_output_statistics(n, hh, ww, cin, cout, kh, tile):
     """fmx_gemm_conv_stats_f16: the per-(image, channel) sum / sum of squares of the fp16 OUTPUT, from the epilogue of the 256-row tiles when
     an image is a whole number of them (32x32, 16x32, 48x16, 16x16 pixels), by the pass behind the GEMM otherwise (10x10, 8x8, or a 4-wave
@@ -362,6 +406,8 @@ def test_gemm_output_statistics(n, hh, ww, cin, cout, kh, tile):
                 f"kw={sorted(kw)}: {int((d > 0).sum())} of {d.numel()} differ, max {float(d.max()):.4g}"
         if tile in (6, 7) and (hh * ww) % 256 == 0:
             assert st.nchunks == hh * ww // 256, "expected the fused (epilogue) statistics path"
+        if tile == 9 and (hh * ww) % 512 == 0:
+            assert st.nchunks == hh * ww // 512, "expected the fused (epilogue) statistics path of the 512-row tile"
         o = out.view(n, hh * ww, cout).double()
         want = torch.stack([o.sum(1), (o * o).sum(1)], -1)
         got = _partial_to_sums(st, n, cout)

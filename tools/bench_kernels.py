@@ -161,6 +161,15 @@ if __name__ == "__main__":
         bench_conv(Bu, 128, 128, 320, 320, 7)
         bench_linear(Bu * 1024, 10240, 1280, 7, act=0)   # the GEGLU projection's shape without GEGLU: what the activation epilogue costs
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "narrow":
+        # the VAE decoder's 128-output-channel level: 4-wave 128x128 tile (1), 256x256 (6, half of it padding), 512x128 (9), dispatcher (0)
+        for c in (128, 256):
+            for tile in (1, 6, 9, 0):
+                bench_conv(4, 1024, 1024, c, 128, tile)
+        for tile in (6, 7, 9, 0):
+            bench_conv(8, 512, 512, 256, 256, tile)
+            bench_conv(8, 256, 256, 512, 384, tile)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "attn512":
         for b, n in ((8, 16384), (8, 4096), (1, 16384), (2, 1024)):
             bench_attn512(b, n)
