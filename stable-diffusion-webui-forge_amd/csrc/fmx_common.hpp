@@ -69,25 +69,29 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
 // x * sigmoid(x) with the hardware reciprocal (1 ulp): the IEEE division of `x / (1 + e^-x)` is a 10-instruction sequence per element, which made
 // the HBM-bound GroupNorm+SiLU pass VALU-bound (profiles/r04a_pmc_*: VALU issue 50 % of the kernel's cycles)
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-// exact-erf GELU (backend/nn/unet.py:111 F.gelu default).  erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far
-// below the fp16 rounding of the result): branch-free, one rcp + one exp -- libm's erff is ~60 instructions with
-// divergent branches, which made the GEGLU epilogue a measurable fraction of the ff1 GEMM.
-__device__ __forceinline__ float erf_as(float x) {
-  const float ax = fabsf(x);
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+// exact-erf GELU (backend/nn/unet.py:111 F.gelu default):  0.5 x (1 + erf(x / sqrt 2)) = x/2 + |x/2| (1 - p(t) t e^{-z^2}),  z = |x| / sqrt 2,
+// erf by Abramowitz-Stegun 7.1.26 (t = 1 / (1 + 0.3275911 z); |abs err| of the GELU <= 5e-7, far below the fp16 rounding of the result).
+// 13 VALU instructions, two of them transcendental: z is carried pre-multiplied by sqrt(log2 e) so that e^{-z^2} is one v_exp_f32 of -u^2,
+// the reciprocal is the 1-ulp v_rcp_f32 (`__frcp_rn` is the correctly rounded one: a 10-instruction IEEE division sequence), and the sign
+// is folded into the last FMA instead of a copysign.  The GEGLU epilogue of the ff1 GEMM evaluates this 80 times per lane with both waves
+// of a SIMD in the epilogue at the same time: it was VALU-bound at ~27 instructions per value (profiles/r04k_gemm_microbench.jsonl: the
+// same GEMM without the activation ran 16 % faster).
+__device__ __forceinline__ float gelu_erf_f(float x) {
+  const float u = fabsf(x) * 0.8493218f;                                      // |x| / sqrt 2 * sqrt(log2 e)
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.27273747f, u, 1.0f));          // 0.3275911 / sqrt(log2 e)
   float pl = fmaf(1.061405429f, t, -1.453152027f);
   pl = fmaf(pl, t, 1.421413741f);
   pl = fmaf(pl, t, -0.284496736f);
   pl = fmaf(pl, t, 0.254829592f);
-  const float y = 1.0f - pl * t * __expf(-ax * ax);
-  return copysignf(y, x);
+  const float y = fmaf(-(pl * t), __builtin_amdgcn_exp2f(-(u * u)), 1.0f);    // erf(|x| / sqrt 2)
+  const float hx = 0.5f * x;
+  return fmaf(fabsf(hx), y, hx);
 }
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
 
 // nn.GELU(approximate="tanh"): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))), tanh(u) = 1 - 2 / (1 + e^{2u})
 __device__ __forceinline__ float gelu_tanh_f(float x) {
   const float u = 0.7978845608028654f * fmaf(0.044715f * x * x, x, x);
-  const float t = 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * u));
+  const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * u));
   return 0.5f * x * (1.0f + t);
 }
 
