@@ -331,6 +331,98 @@ def gen_config3(steps=30):
     gen_vae1024(lat, tag="sdxl_config3_decode.pt")
 
 
+def _worst(ms):
+    return {k: max(m[k] for m in ms) for k in ("max_rel", "pp_rel", "rms_rel")}
+
+
+def floors_aux():
+    """Floors of the fixtures whose network is not the UNet (the rows next to the hot path): cldm.ControlNet residuals, T2I-Adapter /
+    Adapter_light features, the CLIP text encoders (transformers), the Flux transformer (forward and a 4-step flow-sampling run) in fp16 and
+    in bfloat16 (the reference's own Flux compute type).  Lists of tensors (residuals, features) get ONE entry: the worst of each measure
+    over the list, which the test holds every element against."""
+    import contextlib
+    import importlib
+    import io
+    from transformers import CLIPTextConfig, CLIPTextModel   # before the reference's import stubs (a spec-less torchvision) are installed
+    ref = ref_import.load_reference()
+    out = {}
+    # --- ControlNet forward --------------------------------------------------------------------------------------------------------
+    cldm = importlib.import_module("backend.nn.cnets.cldm")
+    for name, cfg in (("tiny_sd15", synth.TINY_SD15_UNET_CONFIG), ("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG)):
+        g, fx = _load(f"{name}_controlnet.pt"), _load(f"{name}_unet_fwd.pt")
+        case = mg.controlnet_case(cfg, 2, g["hw"])
+        kw = {k: v for k, v in cfg.items() if k not in ("out_channels", "transformer_depth_output")}
+        kw["transformer_depth"] = list(kw["transformer_depth"])
+        m = cldm.ControlNet(hint_channels=3, dtype=torch.float32, **kw)
+        m.load_state_dict(synth.synth_controlnet_state_dict(cfg, seed=6), strict=True)
+        m = m.eval().half()
+        m.dtype = torch.float16
+        with torch.no_grad():
+            outs = m(x=fx["x"].half(), hint=case["hint_a"].half(), timesteps=fx["t"], context=fx["ctx"].half(),
+                     y=None if fx["y"] is None else fx["y"].half())
+        out[f"{name}_controlnet.pt:outs_worst"] = _worst([metrics(o[:, ::4].float(), w) for o, w in zip(outs, g["outs_every_4th_channel"])])
+    # --- T2I-Adapter / Adapter_light features ----------------------------------------------------------------------------------------
+    t2i = importlib.import_module("backend.nn.cnets.t2i_adapter")
+    g = _load("mini_sd15_t2i_adapter.pt")
+    for vname, kw in mg.ADAPTER_VARIANTS.items():
+        m = t2i.Adapter(**kw)
+        m.load_state_dict(synth.synth_t2i_adapter_state_dict(**kw))
+        m = m.eval().half()
+        with torch.no_grad():
+            feats = [f for f in m(mg.adapter_hint(vname, 2, g["hw"]).half()) if f is not None]
+        out[f"mini_sd15_t2i_adapter.pt:features/{vname}_worst"] = _worst(
+            [metrics(f[:, ::4].float(), w) for f, w in zip(feats, g["features"][vname]["values_every_4th_channel"])])
+    g = _load("mini_adapter_light.pt")
+    m = t2i.Adapter_light(**mg.ADAPTER_LIGHT_KW)
+    m.load_state_dict(synth.synth_t2i_adapter_light_state_dict(**mg.ADAPTER_LIGHT_KW))
+    m = m.eval().half()
+    with torch.no_grad():
+        feats = [f for f in m(mg.adapter_light_hint().half()) if f is not None]
+    out["mini_adapter_light.pt:features_worst"] = _worst([metrics(f[:, ::4].float(), w) for f, w in zip(feats, g["values_every_4th_channel"])])
+    # --- CLIP text encoders --------------------------------------------------------------------------------------------------------------
+    for name, cfg in (("tiny_clip_l", synth.TINY_CLIP_L_CONFIG), ("tiny_clip_g", synth.TINY_CLIP_G_CONFIG)):
+        g = _load(name + ".pt")
+        sd = synth.synth_clip_state_dict(cfg)
+        hc = CLIPTextConfig(vocab_size=cfg["vocab_size"], hidden_size=cfg["hidden_size"], intermediate_size=cfg["intermediate_size"],
+                            num_hidden_layers=cfg["num_hidden_layers"], num_attention_heads=cfg["num_attention_heads"], max_position_embeddings=77,
+                            hidden_act=cfg["hidden_act"], eos_token_id=2, bos_token_id=0, pad_token_id=1, projection_dim=cfg["hidden_size"])
+        m = CLIPTextModel(hc).eval()
+        pref = "text_model." if any(k.startswith("text_model.") for k in m.state_dict()) else ""
+        m.load_state_dict({pref + k[len("transformer.text_model."):]: v for k, v in sd.items() if k.startswith("transformer.text_model.")}, strict=True)
+        m = m.half()
+        with torch.no_grad():
+            o = m(g["ids"], output_hidden_states=True)
+            fin = m.text_model.final_layer_norm if hasattr(m, "text_model") else m.final_layer_norm
+            got = {"hidden_last": o.hidden_states[-1], "hidden_penultimate": o.hidden_states[-2], "last_hidden_state": o.last_hidden_state,
+                   "penultimate_final_ln": fin(o.hidden_states[-2]), "pooled": o.pooler_output}
+            if "pooled_projected" in g:
+                got["pooled_projected"] = torch.nn.functional.linear(o.pooler_output, sd["transformer.text_projection.weight"].half())
+        for k, v in got.items():
+            out[f"{name}.pt:{k}"] = metrics(v.float(), g[k])
+    # --- Flux ------------------------------------------------------------------------------------------------------------------------------
+    cfg = synth.TINY_FLUX_CONFIG
+    g = _load("tiny_flux_fwd.pt")
+    sd = synth.synth_flux_state_dict(cfg, seed=2)
+    for tag, dt in (("f16", torch.float16), ("bf16", torch.bfloat16)):
+        net = ref_import.build_ref_flux(cfg, sd).to(dt)
+        net.storage_dtype = net.computation_dtype = dt
+        with torch.no_grad():
+            o = net(g["x"].to(dt), g["t"], context=g["ctx"].to(dt), y=g["y"].to(dt), guidance=g["guidance"]).float()
+        out[f"tiny_flux_fwd.pt:out@{tag}"] = metrics(o, g["out"])
+        h, w = g["hw"]
+        pred = ref.k_prediction.PredictionFlux(seq_len=(h // 2) * (w // 2))
+        with contextlib.redirect_stdout(io.StringIO()):
+            km = ref.k_model.KModel(net, None, k_predictor=pred)
+        xs = pred.noise_scaling(g["sigmas"][0], g["noise"].clone(), torch.zeros_like(g["noise"]))
+
+        def model_fn(xx, sigma, **kw):
+            return km.apply_model(xx, sigma, c_crossattn=g["ctx"], y=g["y"], guidance=g["guidance"])
+        with torch.no_grad():
+            lat = ref.kd_sampling.sample_euler(model_fn, xs, g["sigmas"], disable=True)
+        out[f"tiny_flux_fwd.pt:latent@{tag}"] = metrics(lat.float(), g["latent"])
+    update(out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -341,6 +433,8 @@ def main():
         floors_tiny()
     if a.only == "pipeline":
         floors_pipeline()
+    if a.only in ("", "aux"):
+        floors_aux()
     if a.only in ("", "sd15"):
         floors_sd15_full()
     if a.only == "config2":

@@ -18,6 +18,7 @@ from forge_amd.modules import processing, shared  # noqa: E402
 from forge_amd.modules.prompt_parser import DictWithShape  # noqa: E402
 
 from conftest import load_golden  # noqa: E402
+from parity import check  # noqa: E402
 from test_gpu_kernels import close, rnd  # noqa: E402
 
 DEV = "cuda"
@@ -110,9 +111,7 @@ def flux_net():
 def test_flux_forward_vs_reference_fixture(flux_net):
     g = load_golden("tiny_flux_fwd.pt")
     out = flux_net.forward(g["x"].to(DEV), g["t"].to(DEV), g["ctx"].to(DEV), g["y"].to(DEV), g["guidance"].to(DEV))
-    v = max_rel(out, g["out"])
-    print(f"[parity] tiny flux forward vs reference: max_rel={v:.3e} (tol 3e-03)")
-    assert v < 3e-3
+    check("tiny flux forward vs reference", out, g["out"], floor="tiny_flux_fwd.pt:out@f16")
 
 
 def test_flux_euler_sampling_vs_reference_fixture():
@@ -137,9 +136,7 @@ def test_flux_euler_sampling_vs_reference_fixture():
         res = processing.process_images(p)
     finally:
         rng_mod.ImageRNG = orig
-    v = max_rel(res.latents, g["latent"])
-    print(f"[parity] tiny flux 4-step Euler (simple sigmas) vs reference: max_rel={v:.3e} (tol 1e-02)")
-    assert v < 1e-2
+    check("tiny flux 4-step Euler (simple sigmas) vs reference", res.latents, g["latent"], floor="tiny_flux_fwd.pt:latent@f16")
 
 
 # ---- bfloat16 build of the Flux path (the reference's Flux compute type): the same kernels compiled with bf16 elements ---------------------------
@@ -224,9 +221,8 @@ def test_bf16_flux_forward_and_sampling_vs_reference_fixture():
     net = IntegratedFluxTransformer2DModel(cfg, synth.synth_flux_state_dict(cfg, seed=2), device=DEV, dtype=BF)
     assert net.w["img_in"][0].dtype == BF and net.computation_dtype == BF
     out = net.forward(g["x"].to(DEV), g["t"].to(DEV), g["ctx"].to(DEV), g["y"].to(DEV), g["guidance"].to(DEV))
-    v = max_rel(out, g["out"])
-    print(f"[parity] tiny flux forward, bf16 build vs reference (fp32): max_rel={v:.3e} (tol 2e-02)")
-    assert v < 2e-2
+    # floor: the reference's own bfloat16 run (its Flux compute type) against its fp32 run
+    check("tiny flux forward, bf16 build vs reference (fp32)", out, g["out"], floor="tiny_flux_fwd.pt:out@bf16")
     h, w = g["hw"]
     eng = build_flux_engine(cfg, synth.synth_flux_state_dict(cfg, seed=2), device=DEV, dtype=BF, seq_len=(h // 2) * (w // 2))
     cond = DictWithShape({"crossattn": g["ctx"].to(DEV), "vector": g["y"].to(DEV), "guidance": g["guidance"].to(DEV)})
@@ -243,9 +239,7 @@ def test_bf16_flux_forward_and_sampling_vs_reference_fixture():
         res = processing.process_images(p)
     finally:
         rng_mod.ImageRNG = orig
-    v = max_rel(res.latents, g["latent"])
-    print(f"[parity] tiny flux 4-step Euler, bf16 build vs reference (fp32): max_rel={v:.3e} (tol 2e-02)")
-    assert v < 2e-2
+    check("tiny flux 4-step Euler, bf16 build vs reference (fp32)", res.latents, g["latent"], floor="tiny_flux_fwd.pt:latent@bf16")
 
 
 def test_forge_loader_builds_a_flux_engine_from_a_checkpoint():

@@ -524,8 +524,6 @@ def test_vae_pack_unpack_and_im2col():
     torch.testing.assert_close(out.reshape(-1, 3), torch.clamp((y[:, :3].float() + 1) / 2, 0, 1))
 
 
-@pytest.mark.xfail(strict=False, reason="written after the round-1 GPU budget was spent: not yet run on hardware (DESIGN.md, end of section 8); "
-                                       "an XPASS here means it can lose this marker")
 def test_image_rng_variations_on_device():
     """modules/rng.py ImageRNG with variation seeds / seed resize on the device against the reference's values (made on the CPU): the CPU source's
     draws are bit-identical but the slerp (norm, acos, sin, a division by sin(omega)) then runs in the device's libm; the Philox source adds the
