@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define FMX_ABI_VERSION 3
+#define FMX_ABI_VERSION 4
 
 #define FMX_OK 0
 #define FMX_E_BADARG 10001   /* shape / alignment / null-pointer contract violated */
@@ -109,6 +109,11 @@ typedef struct fmx_gemm_args {
   const void* zero_page; /* >= 256 bytes of zeros (device), used for padding taps / tails */
   const void* gate;      /* optional fp16 [n][ld_gate] per-image column scale applied after act (fp16-output fast epilogue only) */
   int32_t ld_gate;
+  /* Optional split-K workspace (ABI 4): device memory the library may use when the problem has fewer output tiles than the chip has
+   * workgroup slots (small batches).  The first 64 KiB are arrival counters: ZERO them once after allocation, the library leaves them zero
+   * after every call.  One workspace serves one stream at a time.  NULL / 0 = never split.  64 MiB covers every shape that profits. */
+  void* workspace;
+  int64_t workspace_bytes;
 } fmx_gemm_args;
 
 int fmx_gemm_conv_f16(const fmx_gemm_args* args /* host */, void* stream);

@@ -35,6 +35,7 @@ class GemmArgs(C.Structure):
         ("alpha", C.c_float), ("act", C.c_int32),
         ("out", C.c_void_p), ("ld_out", C.c_int32), ("out_f32", C.c_int32),
         ("zero_page", C.c_void_p), ("gate", C.c_void_p), ("ld_gate", C.c_int32),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
 
 
@@ -145,7 +146,7 @@ def lib():
             fn.restype = C.c_int
         handle.fmx_last_error.argtypes = []
         handle.fmx_last_error.restype = C.c_char_p
-        if handle.fmx_abi_version() != 3:
+        if handle.fmx_abi_version() != 4:
             raise FmxError("libfmx ABI version mismatch")
         _lib = handle
     return _lib

@@ -16,7 +16,13 @@
 //    side and on the ds_read_b128 side (same involution), which makes the fragment reads conflict-free.
 //  * double-buffered K loop (BK = 64): issue tile t+1, compute tile t, one vmcnt(0)+barrier per tile.
 //  * 1-D grid remapped so that consecutive tiles (same A rows, neighbouring W rows) share an XCD's L2.
+//  * split-K for problems with fewer tiles than the chip has workgroup slots (UNet batch 2 = interactive batch 1: M = 2048 rows is 160 tiles
+//    of 128 x 128 for 256 CUs): S workgroups share a tile, each over a contiguous range of K-tiles; each leaves its fp32 accumulators in
+//    its own slot of a workspace and takes a ticket; the last to arrive adds the slots IN SLOT ORDER (its own from registers), so the sum
+//    does not depend on who was last -- deterministic, no floating-point atomics -- and runs the ordinary fused epilogue.
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include "fmx_gemm_common.hpp"
 
@@ -30,7 +36,7 @@ __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + 
 
 // BUF: LDS-DMA through buffer descriptors (32-bit byte offsets, hardware zero fill for out-of-range lanes) -- needs every
 // operand to span < 0xC0000000 bytes (dispatcher: fits32); BUF = false keeps 64-bit global addresses + the zero page.
-template <int BM, int BN, bool CONV, bool BUF>
+template <int BM, int BN, bool CONV, bool BUF, bool SPLITK = false>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int MI = BM / 32;  // 16-row fragments per wave along M
@@ -45,7 +51,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   const int wm = wave >> 1, wn = wave & 1;
 
   const int nwg = p.tiles_m * p.tiles_n;
-  const int wg = xcd_remap(blockIdx.x, nwg);
+  int wg, ks = 0;
+  if (SPLITK) {  // the splits of a tile are neighbours in the remapped order: same XCD, resident together
+    const int lin = xcd_remap(blockIdx.x, nwg * p.splits);
+    wg = lin / p.splits;
+    ks = lin - wg * p.splits;
+  } else {
+    wg = xcd_remap(blockIdx.x, nwg);
+  }
   const int tm = wg / p.tiles_n;
   const int tn = wg - tm * p.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
@@ -156,15 +169,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  stage(0, 0);
+  const int t_begin = SPLITK ? (int)((long)p.kt * ks / p.splits) : 0;
+  const int t_end = SPLITK ? (int)((long)p.kt * (ks + 1) / p.splits) : p.kt;
+  stage(0, t_begin);
   wait_vmcnt0();
   __syncthreads();
 
   const int frow = lane & 15;
   const int fk = lane >> 4;
-  for (int t = 0; t < p.kt; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < p.kt) stage(cur ^ 1, t + 1);
+  for (int t = t_begin; t < t_end; ++t) {
+    const int cur = (t - t_begin) & 1;
+    if (t + 1 < t_end) stage(cur ^ 1, t + 1);
     const char* sa = smem + cur * STAGE_BYTES;
     const char* sb = sa + BM * 128;
 #pragma unroll
@@ -184,6 +199,70 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     }
     wait_vmcnt0();
     __syncthreads();
+  }
+
+  if (SPLITK) {
+    // ---- split-K hand-over.  The workgroups of a tile may sit on different XCDs, whose L2s are not coherent with each other.  A
+    //      device-scope FENCE writes back / invalidates the whole L2 (measured: 80 -> 330 us per launch).  Instead every access that
+    //      carries the partials is itself device-scope (the `sc1` bit, what a relaxed agent-scope atomic load / store compiles to on
+    //      gfx942 / gfx950): such stores are performed at the memory side before vmcnt retires them, such loads do not hit a stale line.
+    //      Order: own stores, s_waitcnt vmcnt(0), barrier, ticket (agent-scope atomic); the last arrival loads the other slots. ------------
+    float* const slots = p.ws + (long)wg * p.splits * (BM * BN);
+    float* const mine = slots + (long)ks * (BM * BN);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        float* dst = mine + ((i * NI + j) * 256 + tid) * 4;
+        // (s_nop: a VMEM store of more than 64 bits must not be followed at once by a VALU write of its data registers -- the compiler
+        //  keeps that hazard distance for its own stores, but does not look inside inline asm and re-fills v[4:7] from the AGPRs right away)
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(acc[i][j]) : "memory");
+      }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // (also: every wave is past its last LDS read, the first word can carry the ticket)
+    int* const s_ticket = reinterpret_cast<int*>(smem);
+    if (tid == 0) *s_ticket = __hip_atomic_fetch_add(p.tickets + wg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*s_ticket != p.splits - 1) return;
+    if (tid == 0) __hip_atomic_store(p.tickets + wg, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero again for the next launch
+    // sum in SLOT order, own slot from registers: the result does not depend on which workgroup arrived last.  All loads of a slot are
+    // in flight together (one wait per slot, not per load).
+    f32x4 total[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) total[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};   // 0 + x is exact
+    for (int s2 = 0; s2 < p.splits; ++s2) {
+      if (s2 == ks) {   // workgroup-uniform
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) total[i][j] += acc[i][j];
+      } else {
+        const float* src = slots + (long)s2 * (BM * BN) + tid * 4;
+        f32x4 part[MI][NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            // relaxed agent-scope atomic loads = `global_load_dwordx2 ... sc1`, tracked by the compiler's own waitcnt insertion (an
+            // inline-asm load's result may be copied before a separate asm waitcnt: the first version of this code read garbage that way)
+            const unsigned long long* q = reinterpret_cast<const unsigned long long*>(src + (i * NI + j) * 1024);
+            const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long hi2 = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            part[i][j] = f32x4{__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)), __uint_as_float((unsigned)hi2),
+                               __uint_as_float((unsigned)(hi2 >> 32))};
+          }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) total[i][j] += part[i][j];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = total[i][j];
   }
 
   // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + (lane>>4)*4 + r], r = 0..3 ---------------------
@@ -274,22 +353,28 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   }
 }
 
-template <int BM, int BN, bool CONV, bool BUF>
+template <int BM, int BN, bool CONV, bool BUF, bool SPLITK = false>
 int launch_impl(const GemmParams& p, hipStream_t st) {
   const int smem = 2 * (BM + BN) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, CONV, BUF>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, CONV, BUF, SPLITK>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   GemmParams q = p;
   q.tiles_m = (p.M + BM - 1) / BM;
   q.tiles_n = (p.nout + BN - 1) / BN;
-  const int grid = q.tiles_m * q.tiles_n;
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, CONV, BUF>), dim3(grid), dim3(256), smem, st, q);
+  const int grid = q.tiles_m * q.tiles_n * (SPLITK ? p.splits : 1);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, CONV, BUF, SPLITK>), dim3(grid), dim3(256), smem, st, q);
   FMX_LAUNCH_CHECK("fmx_gemm_conv_f16");
   return FMX_OK;
+}
+
+// split-K instantiations exist for the 128 x 128 and 128 x 64 tiles on the buffer-descriptor path
+template <int BM, int BN>
+int launch_split(const GemmParams& p, bool conv, hipStream_t st) {
+  return conv ? launch_impl<BM, BN, true, true, true>(p, st) : launch_impl<BM, BN, false, true, true>(p, st);
 }
 
 template <int BM, int BN, bool CONV>
@@ -390,6 +475,9 @@ static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, i
   p.tiles_m = p.tiles_n = 0;
   p.stats = nullptr;
   p.stats_nch = 0;
+  p.splits = 1;
+  p.ws = nullptr;
+  p.tickets = nullptr;
   FMX_REQUIRE(fmx_aligned16(p.a0) && fmx_aligned16(p.wgt) && fmx_aligned16(p.zp) && (!p.a1 || fmx_aligned16(p.a1)), "gemm: operands must be 16-byte aligned");
   FMX_REQUIRE((p.s0 % 8) == 0 && (p.s1 % 8) == 0 && (p.ldw % 8) == 0, "gemm: strides must be multiples of 8 elements");
   FMX_REQUIRE((long)p.M * 1 > 0 && (long)a->n * a->oh * a->ow < (1L << 31), "gemm: M overflow");
@@ -423,9 +511,9 @@ static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, i
   };
   const bool big_ok = FastEpilogue::eligible8(p) && fits32;
   const double e4 = geglu ? 5.0 : 2.0, F4 = 49152.0, e8 = 4.0, F8 = 98304.0;
-  int sel = 2;
+  int sel = 2, best_s = 1;
   double best = cost(64, 64, 5, 0.42, e4, F4);
-  auto consider = [&](int id, double c) { if (c < best) { best = c; sel = id; } };
+  auto consider = [&](int id, double c, int s = 1) { if (c < best) { best = c; sel = id; best_s = s; } };
   consider(1, cost(128, 64, 3, 0.58, e4, F4));
   consider(0, cost(128, 128, 2, 0.70, e4, F4));
   if (!geglu && (p.nout % 160) == 0) consider(4, cost(128, 160, 2, 0.80, e4, F4));
@@ -435,7 +523,38 @@ static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, i
   // 512x128: narrow outputs (the VAE decoder's 128-channel level); its address path takes single-source convolutions without upsample-on-load
   const bool narrow_ok = big_ok && !geglu && (!conv || (p.c1 == 0 && a->up_h == 0));
   if (narrow_ok) consider(8, cost(512, 128, 1, 0.86, e8, F8));
-  if (a->out_f32 < 0) sel = (-a->out_f32 - 1) % 16;  // test hook: force a tile shape (out_f32 = -1..-9 -> fp16 out)
+  // split-K over S workgroups per tile (128x128 / 128x64 tiles) when the problem leaves workgroup slots empty: K-loop / S, plus the
+  // partial-accumulator exchange (one fp32 tile written per workgroup, S - 1 read by the last: ES K-tile equivalents, fitted to
+  // tools/bench_kernels.py splitk sweeps).  Needs the caller's workspace (fmx_gemm_args.workspace) and the buffer-descriptor path.
+  constexpr long TICKET_BYTES = 65536;
+  const long ws_floats = (a->workspace && a->workspace_bytes > TICKET_BYTES) ? (a->workspace_bytes - TICKET_BYTES) / 4 : 0;
+  const char* force_split_env = getenv("FMX_GEMM_SPLITK");   // A/B / test knob, read per call: 0 = never split, S >= 2 = always S (where possible)
+  const int force_split = force_split_env ? atoi(force_split_env) : -1;
+  const bool split_ok = ws_floats > 0 && fits32 && a->out_f32 <= 0 && force_split != 0;
+  auto split_fits = [&](int bm, int bn, int S) {
+    const double t = tiles(bm, bn);
+    return S >= 2 && p.kt / S >= 2 && t <= TICKET_BYTES / 4 && t * S * bm * bn <= (double)ws_floats;
+  };
+  if (split_ok && force_split < 0) {
+    auto cost_split = [&](int bm, int bn, int wpc, double eff, int S) {
+      const double rounds = ceil(tiles(bm, bn) * S / (256.0 * wpc));
+      // measured (profiles/r05c_split_k_sweep.jsonl, in-graph, cold weights): the hand-over costs 12 us at S = 2 and 18 us at S = 3 for a
+      // 128 x 128 tile (~0.93 us per K-tile there), half again as much per K-tile for 128 x 64 -- it pays from ~50 K-tiles per workgroup on
+      const double es = (bn == 128 ? 6.5 : 9.0) * S;
+      return rounds * wpc * ((double)bm * bn * (kt / S + e4 + es) / eff + F4);
+    };
+    for (int S = 2; S <= 8; ++S) {
+      if (p.kt / S < 4) break;
+      if (split_fits(128, 128, S)) consider(0, cost_split(128, 128, 2, 0.70, S), S);
+      if (split_fits(128, 64, S)) consider(1, cost_split(128, 64, 3, 0.58, S), S);
+    }
+  }
+  if (a->out_f32 < 0) { sel = (-a->out_f32 - 1) % 16; best_s = 1; }  // test hook: force a tile shape (out_f32 = -1..-9 -> fp16 out)
+  if (split_ok && force_split >= 2 && (sel == 0 || sel == 1) && split_fits(128, sel == 0 ? 128 : 64, force_split)) best_s = force_split;
+  if (best_s > 1 && sel != 0 && sel != 1) best_s = 1;
+  if (getenv("FMX_GEMM_DEBUG"))
+    fprintf(stderr, "fmx_gemm: M=%d N=%d K=%d conv=%d -> tile id %d, split-K %d (workspace %ld floats, fits32 %d)\n", p.M, p.nout, p.kt * 64, (int)conv,
+            sel + 1, best_s, ws_floats, (int)fits32);
   FMX_REQUIRE(sel <= 8, "gemm: unknown tile id");
   FMX_REQUIRE(sel != 8 || (!geglu && (!conv || (p.c1 == 0 && a->up_h == 0))), "gemm: the 512x128 tile takes no GEGLU, second source or upsample-on-load");
   FMX_REQUIRE(sel != 3, "gemm: tile id 4 (the first-generation ping-pong kernel) is no longer part of the library");
@@ -463,6 +582,11 @@ static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, i
     FMX_REQUIRE(FastEpilogue::eligible8(p) && fits32, "gemm: the 256-row kernels need fp16 output, 16-byte aligned epilogue operands, leading dimensions / nout multiples of 8, operands < 2^32 elements");
     if (sel == 6) FMX_REQUIRE(a->act != FMX_ACT_GEGLU || (p.nout % 32) == 0, "gemm: GEGLU needs nout % 32 == 0");
     rc = fmx_launch_gemm256p(p, conv, sel == 8 ? 512 : sel == 7 ? 320 : 256, sel == 8 ? 128 : sel == 6 ? 320 : 256, st);
+  } else if (best_s > 1) {
+    p.splits = best_s;
+    p.tickets = reinterpret_cast<int*>(a->workspace);
+    p.ws = reinterpret_cast<float*>(reinterpret_cast<char*>(a->workspace) + TICKET_BYTES);
+    rc = sel == 0 ? launch_split<128, 128>(p, conv, st) : launch_split<128, 64>(p, conv, st);
   } else if (sel == 4) {
     rc = conv ? launch<128, 160, true>(p, st) : launch<128, 160, false>(p, st);
   } else if (conv) {

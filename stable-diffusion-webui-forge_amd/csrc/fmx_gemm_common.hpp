@@ -33,6 +33,10 @@ struct GemmParams {
   unsigned a0_bytes, a1_bytes, w_bytes;  // operand extents for the buffer descriptors of the 256x256 kernel
   float* stats;     // GroupNorm statistics of the output, partial[image][chunk][nout][2] (256-row tiles only; null = none)
   int stats_nch;    // chunks per image = oh*ow / 256
+  // split-K (4-wave kernels, small problems): `splits` workgroups share an output tile, each over a contiguous range of K-tiles
+  int splits;       // 1 = off
+  float* ws;        // partial accumulators, [tile][split][BM*BN] fp32 in the kernel's register layout
+  int* tickets;     // one arrival counter per tile, zero between launches
 };
 
 // K-tile depth of every GEMM kernel: 64 halfs = one 128-byte LDS row.

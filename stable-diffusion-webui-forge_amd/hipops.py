@@ -116,6 +116,21 @@ def zero_page(device):
     return zp
 
 
+SPLITK_WORKSPACE_BYTES = 64 << 20
+_splitk_ws = {}
+
+
+def splitk_workspace(device):
+    """The split-K workspace of fmx_gemm_args (include/fmx.h): one per device, arrival counters zeroed once, alive for the process -- a
+    captured graph keeps its address.  All launches go to ONE stream at a time (the executors' discipline), as the ABI asks."""
+    key = (device.type, device.index)
+    ws = _splitk_ws.get(key)
+    if ws is None:
+        ws = torch.zeros(SPLITK_WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+        _splitk_ws[key] = ws
+    return ws
+
+
 def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
@@ -204,6 +219,7 @@ def conv_gemm(x, wgt, nout, *, x1=None, n=None, h=None, w=None, kh=1, stride=1, 
     a.zero_page = _p(zero_page(x.device))
     a.gate = _p(gate)
     a.ld_gate = gate.stride(0) if gate is not None else 0
+    a.workspace, a.workspace_bytes = _p(splitk_workspace(x.device)), SPLITK_WORKSPACE_BYTES
     st = None
     if stats and _FUSED_STATS and sfx == "_f16":
         hw = oh * ow

@@ -84,6 +84,53 @@ def test_conv_input_beyond_32bit_offsets_runs_as_image_groups():
     torch.testing.assert_close(_partial_to_sums(st, n, co), want, rtol=2e-5, atol=2e-2)
 
 
+@pytest.mark.parametrize("splits", [2, 3, 5])
+@pytest.mark.parametrize("tile", [1, 2])
+def test_split_k_matches_and_is_deterministic(splits, tile, monkeypatch):
+    """Split-K of the 4-wave kernels (csrc/fmx_gemm.hip; used for small batches): S workgroups per output tile over contiguous K ranges, partial
+    accumulators through the workspace, the last arrival sums them in slot order and runs the fused epilogue.  Forced through the A/B knob on
+    both tile shapes: linear with bias + in-place residual and ragged M / N, GEGLU, a 3x3 convolution with a per-image row vector; equal to the
+    fp32 reference within the usual tolerance, bit-identical run to run (no floating-point atomics), and the arrival counters are left zero
+    (a second launch works)."""
+    monkeypatch.setenv("FMX_GEMM_SPLITK", str(splits))
+    m, n, k = 1000, 328, 1280
+    x, w, b = rnd(m, k, seed=30), rnd(n, k, scale=1 / math.sqrt(k), seed=31), rnd(n, seed=32)
+    res = rnd(m, n, seed=33)
+    ref = x.float() @ w.float().t() + b.float() + res.float()
+    outs = []
+    for _ in range(3):
+        r2 = res.clone()
+        ops.linear(x, w, b, residual=r2, out=r2, ld_out=n, force_tile=tile)
+        outs.append(r2)
+    close(outs[0], ref, 2e-3, 2e-3, f"split-K x{splits} linear")
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    inner = 320
+    wi, bi = rnd(2 * inner, k, scale=1 / math.sqrt(k), seed=34), rnd(2 * inner, seed=35)
+    wint, bint = ops.geglu_interleave(wi, bi)
+    out = ops.conv_gemm(x, wint, 2 * inner, bias=bint, act=ops.ACT_GEGLU, force_tile=tile)
+    hcat = x.float() @ wi.float().t() + bi.float()
+    close(out, hcat[:, :inner] * F.gelu(hcat[:, inner:]), 3e-3, 3e-3, f"split-K x{splits} GEGLU")
+    nb, hh, ww, c, co = 2, 12, 20, 128, 192
+    xc = rnd(nb, hh, ww, c, seed=36)
+    wt = rnd(co, c, 3, 3, scale=1 / math.sqrt(c * 9), seed=37)
+    bc, emb = rnd(co, seed=38), rnd(nb, co, seed=39)
+    refc = (F.conv2d(xc.permute(0, 3, 1, 2).float(), wt.float(), bc.float(), padding=1) + emb.float()[:, :, None, None]).permute(0, 2, 3, 1)
+    oc = ops.conv_gemm(xc, wt.permute(0, 2, 3, 1).reshape(co, -1).contiguous(), co, kh=3, pad=1, bias=bc, rowvec=emb, force_tile=tile)
+    close(oc.reshape(refc.shape), refc, 3e-3, 3e-3, f"split-K x{splits} conv")
+    monkeypatch.setenv("FMX_GEMM_SPLITK", "0")
+    plain = res.clone()
+    ops.linear(x, w, b, residual=plain, out=plain, ld_out=n, force_tile=tile)
+    close(outs[0], plain.float(), 1e-3, 1e-3, "split-K vs one workgroup per tile")
+
+
+def test_small_batch_shapes_pick_a_correct_kernel():
+    """The interactive-batch shapes of the SDXL forward (UNet batch 2: M = 2048 rows), through the dispatcher's own choice (split-K where its cost
+    model says so) against the fp32 reference."""
+    for m, n, k in ((2048, 1280, 1280), (2048, 1280, 5120), (2048, 2560, 1280), (1280, 2048, 1280), (8192, 640, 640)):
+        x, w, b = rnd(m, k, seed=40), rnd(n, k, scale=1 / math.sqrt(k), seed=41), rnd(n, seed=42)
+        close(ops.linear(x, w, b), x.float() @ w.float().t() + b.float(), 2e-3, 2e-3, f"linear {m}x{n}x{k}")
+
+
 def test_linear_asymmetric_identity():
     # A = I, asymmetric B: catches swapped row/col in the MFMA C layout
     m = n = k = 128

@@ -27,6 +27,42 @@ def timeit(fn, iters=20, warm=3):
     return s.elapsed_time(e) / iters * 1e-3
 
 
+def timeit_graph(fns, reps=5):
+    """Launch-overhead-free time per call: the calls of `fns` captured into ONE HIP graph (back to back on the device, as in the
+    graph-replayed UNet forward), replayed `reps` times.  Give every call its own weights when cold operands matter."""
+    from forge_amd.runtime import HipGraph
+    for f in fns[:2]:
+        f()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = HipGraph()
+    with torch.cuda.stream(side):
+        g.capture(side, lambda: [f() for f in fns])
+        g.launch(side)
+        side.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(side)
+        for _ in range(reps):
+            g.launch(side)
+        e.record(side)
+        side.synchronize()
+    g.destroy()
+    return s.elapsed_time(e) / (reps * len(fns)) * 1e-3
+
+
+def bench_linear_cold(m, n, k, tile=0, act=0, copies=None):
+    """as bench_linear, but inside a graph and with enough distinct weight matrices that none is cache-resident when its turn comes (> 256 MB
+    in total: the forward reads every weight once per step, from HBM)"""
+    copies = copies or max(8, int(300e6 / (n * k * 2)) + 1)
+    x, b = rnd(m, k), rnd(n)
+    ws = [rnd(n, k, scale=k ** -0.5) for _ in range(copies)]
+    out = torch.empty(m, n // 2 if act else n, dtype=torch.float16, device=DEV)
+    t = timeit_graph([(lambda w=w: ops.conv_gemm(x, w, n, bias=b, out=out, ld_out=out.shape[1], act=act, force_tile=tile)) for w in ws])
+    print(json.dumps({"op": "linear (in graph, cold weights)", "m": m, "n": n, "k": k, "tile": tile, "act": act, "us": round(t * 1e6, 1),
+                      "tflops": round(2 * m * n * k / t / 1e12, 1)}), flush=True)
+
+
 def rnd(*shape, scale=1.0):
     return (torch.randn(*shape, device=DEV) * scale).half()
 
@@ -160,6 +196,33 @@ if __name__ == "__main__":
         bench_conv(Bu, 64, 64, 640, 640, 7)
         bench_conv(Bu, 128, 128, 320, 320, 7)
         bench_linear(Bu * 1024, 10240, 1280, 7, act=0)   # the GEGLU projection's shape without GEGLU: what the activation epilogue costs
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "splitk":
+        # interactive-batch shapes (UNet batch 2 and 4): split-K factor sweep on the two 4-wave tiles (FMX_GEMM_SPLITK), and the dispatcher's choice
+        import os
+        shapes = [(2048, 1280, 1280), (2048, 1280, 5120), (2048, 2560, 1280), (1280, 2048, 1280), (8192, 640, 640), (8192, 640, 2560),
+                  (4096, 1280, 1280), (4096, 1280, 5120)]
+        for m, n, k in shapes:
+            for tile in (1, 2):
+                for s in (0, 2, 3, 4, 6, 8):
+                    os.environ["FMX_GEMM_SPLITK"] = str(s)
+                    print(json.dumps({"splitk": s}), end=" ")
+                    bench_linear_cold(m, n, k, tile)
+            for s in ("0", None):
+                if s is None:
+                    os.environ.pop("FMX_GEMM_SPLITK", None)
+                else:
+                    os.environ["FMX_GEMM_SPLITK"] = s
+                print(json.dumps({"splitk": "auto" if s is None else "off", "dispatcher": True}), end=" ")
+                bench_linear_cold(m, n, k, 0)
+        for co, c, hw in ((1280, 1280, 32), (1280, 2560, 32), (640, 640, 64)):
+            for s in ("0", None):
+                if s is None:
+                    os.environ.pop("FMX_GEMM_SPLITK", None)
+                else:
+                    os.environ["FMX_GEMM_SPLITK"] = s
+                print(json.dumps({"splitk": "auto" if s is None else "off", "dispatcher": True}), end=" ")
+                bench_conv(2, hw, hw, c, co, 0)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "narrow":
         # the VAE decoder's 128-output-channel level: 4-wave 128x128 tile (1), 256x256 (6, half of it padding), 512x128 (9), dispatcher (0)
