@@ -224,6 +224,14 @@ if __name__ == "__main__":
                 print(json.dumps({"splitk": "auto" if s is None else "off", "dispatcher": True}), end=" ")
                 bench_conv(2, hw, hw, c, co, 0)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "coldhot":
+        # the big linear shapes of the batch-8 forward: eager back-to-back on ONE weight matrix (hot in L2 / MALL) vs in a graph with a
+        # different weight matrix per call (cold, as in the forward)
+        for m, n, k, act in ((16384, 1280, 1280, 0), (16384, 10240, 1280, 1), (16384, 1280, 5120, 0), (16384, 2560, 1280, 0), (65536, 640, 640, 0)):
+            bench_linear(m, n, k, 7, act)
+            bench_linear_cold(m, n, k, 7, act)
+            bench_linear_cold(m, n, k, 7, act, copies=1 if False else 2)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "narrow":
         # the VAE decoder's 128-output-channel level: 4-wave 128x128 tile (1), 256x256 (6, half of it padding), 512x128 (9), dispatcher (0)
         for c in (128, 256):
