@@ -387,7 +387,7 @@ def main():
             g = summ.get("gemm_conv")
             if g:
                 ach = g["flops"] / g["seconds"]
-                roof = {"kernel": "gemm256p_kernel<256x320 | 320x256 | 256x256> + gemm_kernel (fmx_gemm_conv: MFMA implicit-GEMM conv3x3/1x1 + linear, fused epilogues)",
+                roof = {"kernel": "gemm256p_kernel<256x320 | 320x256 | 256x256 | 512x128> + gemm_kernel (fmx_gemm_conv: MFMA implicit-GEMM conv3x3/1x1 + linear, fused epilogues)",
                         "bound": "mfma", "achieved": round(ach / 1e12, 1), "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s",
                         "frac": round(ach / MFMA_PEAK, 4), "traffic": pmc_traffic_per_launch(), "launches_per_forward": g["launches"],
                         "flop_per_launch_avg": round(g["flops"] / g["launches"] / 1e9, 2), "flop_unit": "GFLOP",

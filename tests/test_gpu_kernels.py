@@ -123,6 +123,31 @@ def test_split_k_matches_and_is_deterministic(splits, tile, monkeypatch):
     close(outs[0], plain.float(), 1e-3, 1e-3, "split-K vs one workgroup per tile")
 
 
+def test_split_k_hand_over_under_load_is_stable(monkeypatch):
+    """The hand-over reuses ONE workspace and its arrival counters launch after launch.  Forty launches back to back with changing split
+    factors, tile shapes and problem sizes (so slot addresses are re-used by other tiles, other XCDs, other split counts while earlier kernels
+    are still draining), every output word compared with the first time that configuration ran, and with the unsplit kernel at the end."""
+    cases = []
+    for i, (m, n, k) in enumerate(((1000, 328, 1280), (2048, 1280, 2560), (640, 640, 5120), (3000, 136, 1920))):
+        x, w, b = rnd(m, k, seed=50 + i), rnd(n, k, scale=1 / math.sqrt(k), seed=60 + i), rnd(n, seed=70 + i)
+        cases.append((x, w, b))
+    first = {}
+    for it in range(40):
+        ci, splits, tile = it % 4, (2, 3, 4, 7)[(it // 4) % 4], 1 + (it // 2) % 2
+        monkeypatch.setenv("FMX_GEMM_SPLITK", str(splits))
+        x, w, b = cases[ci]
+        out = ops.linear(x, w, b, force_tile=tile)
+        key = (ci, splits, tile)
+        if key in first:
+            assert torch.equal(out, first[key]), f"case {key} changed on launch {it}"
+        else:
+            first[key] = out.clone()
+    monkeypatch.setenv("FMX_GEMM_SPLITK", "0")
+    for (ci, splits, tile), got in first.items():
+        x, w, b = cases[ci]
+        close(got, ops.linear(x, w, b, force_tile=tile).float(), 1e-3, 1e-3, f"split-K x{splits} tile {tile} case {ci} vs unsplit")
+
+
 def test_small_batch_shapes_pick_a_correct_kernel():
     """The interactive-batch shapes of the SDXL forward (UNet batch 2: M = 2048 rows), through the dispatcher's own choice (split-K where its cost
     model says so) against the fp32 reference."""
