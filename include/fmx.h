@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define FMX_ABI_VERSION 4
+#define FMX_ABI_VERSION 5
 
 #define FMX_OK 0
 #define FMX_E_BADARG 10001   /* shape / alignment / null-pointer contract violated */
@@ -114,9 +114,24 @@ typedef struct fmx_gemm_args {
    * after every call.  One workspace serves one stream at a time.  NULL / 0 = never split.  64 MiB covers every shape that profits. */
   void* workspace;
   int64_t workspace_bytes;
+  /* LayerNorm folded into its consumer (ABI 5; backend/nn/unet.py:262-279, norm2 / norm3 of a BasicTransformerBlock).  With ln_partial set,
+   * this GEMM computes  LN(x) W^T + b  from the UN-normalised x:  wgt = W * gamma (per input channel), ln_colsum[n] = sum_k wgt[n][k] in fp32
+   * (of the fp16 values), bias = W beta + b;  ln_partial = the row statistics fmx_gemm_linear_rowstats_f16 left for x, ln_parts entries per
+   * row.  Linear only (kh 1), act NONE or GEGLU, no residual / rowvec / gate, fp16 output; always the 256x320 tile. */
+  const void* ln_partial;
+  int32_t ln_parts;
+  const void* ln_colsum;
+  float ln_eps;
 } fmx_gemm_args;
 
 int fmx_gemm_conv_f16(const fmx_gemm_args* args /* host */, void* stream);
+
+/* The same GEMM (linear with bias + residual: the projections that close attention / feed-forward, unet.py:268,272,277), additionally
+ * leaving per-row partial sums of its fp16 OUTPUT for a LayerNorm that follows: row_partial[m][parts][{sum, sum of squares}] fp32, where
+ * parts = 2 * ceil(nout / 320) <= parts_cap is returned in *parts_out.  *parts_out = 0 means the dispatcher chose another tile shape for
+ * this problem (small M): the GEMM ran as usual, nothing was written, and the caller applies its LayerNorm with fmx_layernorm_f16. */
+int fmx_gemm_linear_rowstats_f16(const fmx_gemm_args* args /* host */, float* row_partial, int32_t parts_cap, int32_t* parts_out /* host */,
+                                 void* stream);
 
 /* Reorders the rows of a GEGLU projection weight [2*inner][k] (and bias [2*inner]) on the DEVICE into
  * the [16 value rows | 16 gate rows] interleave FMX_ACT_GEGLU expects.  inner % 16 == 0. */

@@ -36,6 +36,7 @@ class GemmArgs(C.Structure):
         ("out", C.c_void_p), ("ld_out", C.c_int32), ("out_f32", C.c_int32),
         ("zero_page", C.c_void_p), ("gate", C.c_void_p), ("ld_gate", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+        ("ln_partial", C.c_void_p), ("ln_parts", C.c_int32), ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float),
     ]
 
 
@@ -58,6 +59,7 @@ SIGNATURES = {
     "fmx_abi_version": [],
     "fmx_device_info": [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int],
     "fmx_gemm_conv_f16": [C.POINTER(GemmArgs), _vp],
+    "fmx_gemm_linear_rowstats_f16": [C.POINTER(GemmArgs), _vp, _i32, C.POINTER(C.c_int32), _vp],
     "fmx_geglu_interleave_rows": [_vp, _vp, _vp, _vp, _i32, _i32, _vp],
     "fmx_attention_f16": [C.POINTER(AttnArgs), _vp],
     "fmx_softmax_rows_f16": [_vp, _i64, _i32, _i64, _vp],
@@ -146,7 +148,7 @@ def lib():
             fn.restype = C.c_int
         handle.fmx_last_error.argtypes = []
         handle.fmx_last_error.restype = C.c_char_p
-        if handle.fmx_abi_version() != 4:
+        if handle.fmx_abi_version() != 5:
             raise FmxError("libfmx ABI version mismatch")
         _lib = handle
     return _lib

@@ -21,6 +21,8 @@ the captured graph, since the residuals change every step.  Hooks that need per-
 (`patches`, `patches_replace`, `block_modifiers`) are called eagerly on [B, N, C] / NCHW views; module-typed hooks are rejected.
 """
 
+import os
+
 import torch
 
 from ... import hipops as ops
@@ -29,6 +31,20 @@ from .layout import ConvIn, Down, Res, SpatialT, Up, unet_layout
 
 SUPPORTED_DPAD = (48, 64, 80, 160)
 CTX_PAD = 64  # text tokens are padded to a multiple of the attention key tile
+
+
+_LN_FOLD = os.environ.get("FMX_LN_FOLD", "1") != "0"   # A/B knob: 0 keeps the LayerNorm kernels in front of attn2.to_q / ff.net.0
+
+
+def _fold_layernorm(wt, bias, gamma, beta):
+    """LN(x) W^T + b = rstd (x W'^T - mean colsum(W')) + (W beta + b)  with  W' = W * gamma  (per input channel).  -> (W' fp16, colsum fp32 of
+    the fp16 values of W' -- it has to cancel exactly what the MFMAs accumulate -- and the folded bias fp16).  unet.py:262-279."""
+    wf = (wt.float() * gamma.float()[None, :]).to(torch.float16).contiguous()
+    colsum = wf.float().sum(1).contiguous()
+    b2 = wt.float() @ beta.float()
+    if bias is not None:
+        b2 = b2 + bias.float()
+    return wf, colsum, b2.to(torch.float16).contiguous()
 
 
 def _dpad(d):
@@ -178,6 +194,12 @@ class IntegratedUNet2DConditionModel:
                     w[b + ".attn2.out"] = (_pad_head_cols(T(b + ".attn2.to_out.0.weight"), H, d, dp).contiguous(), T(b + ".attn2.to_out.0.bias"))
                     w[b + ".ff1"] = ops.geglu_interleave(T(b + ".ff.net.0.proj.weight"), T(b + ".ff.net.0.proj.bias"))
                     w[b + ".ff2"] = lin(b + ".ff.net.2")
+                    if _LN_FOLD and L.ch % 320 == 0:
+                        # norm2 / norm3 folded into the projection behind them (ops.conv_gemm(ln=...)): weights scaled by gamma, their fp32
+                        # column sums, beta pushed through the weight into the bias.  Kept beside the plain weights: small problems (where
+                        # the producing GEMM runs on another tile shape and emits no row statistics) and hooked runs use the LayerNorm kernel.
+                        w[b + ".attn2.q.ln"] = _fold_layernorm(w[b + ".attn2.q"], None, *w[b + ".norm2"])
+                        w[b + ".ff1.ln"] = _fold_layernorm(*w[b + ".ff1"], *w[b + ".norm3"])
             elif isinstance(L, Down):
                 w[k] = (_conv_w(sd[k + ".op.weight"].to(dev, torch.float16)), T(k + ".op.bias"))
             elif isinstance(L, Up):
@@ -268,6 +290,10 @@ class IntegratedUNet2DConditionModel:
         dp = _dpad(d)
         hd = H * dp
         m_tok = bu * n
+        # LayerNorm folding (norm2 -> attn2.to_q, norm3 -> ff.net.0): the projection that writes h also leaves per-row sums of what it wrote
+        fold = (b + ".ff1.ln") in self.w
+        rs2 = ops.RowStats(m_tok, h.shape[1]) if fold else None
+        rs3 = ops.RowStats(m_tok, h.shape[1]) if fold else None
         mk = arena.mark()
         # self attention
         if n % 64 == 0:
@@ -296,21 +322,29 @@ class IntegratedUNet2DConditionModel:
             o = ops.attention(qk, qk[:, hd:], vt, batch=bu, heads=H, nq=n, nk=n, nk_pad=npad, dpad=dp, scale=d ** -0.5,
                               q_bs=npad * 2 * hd, q_rs=2 * hd, k_bs=npad * 2 * hd, k_rs=2 * hd, vt_bs=npad,
                               vt_hs=dp * bu * npad, vt_ds=bu * npad)
-        ops.linear(o, *self.w[b + ".attn1.out"], residual=h, out=h, ld_out=h.shape[1])
+        ops.linear(o, *self.w[b + ".attn1.out"], residual=h, out=h, ld_out=h.shape[1], row_stats=rs2)
         arena.release(mk)
         # cross attention against the cached text K / V^T
-        n2 = ops.layernorm(h, *self.w[b + ".norm2"])
-        q2 = ops.linear(n2, self.w[b + ".attn2.q"])
+        if fold and rs2.parts:
+            wq, csq, bq = self.w[b + ".attn2.q.ln"]
+            q2 = ops.conv_gemm(h, wq, wq.shape[0], bias=bq, ln=(rs2, csq, 1e-5))
+        else:
+            n2 = ops.layernorm(h, *self.w[b + ".norm2"])
+            q2 = ops.linear(n2, self.w[b + ".attn2.q"])
         kc, vtc = ctxc.kv[b]
         tp = ctxc.tpad
         o2 = ops.attention(q2, kc, vtc, batch=bu, heads=H, nq=n, nk=ctxc.tokens, nk_pad=tp, dpad=dp, scale=d ** -0.5,
                            q_bs=n * hd, q_rs=hd, k_bs=tp * hd, k_rs=hd, vt_bs=tp, vt_hs=dp * bu * tp, vt_ds=bu * tp)
-        ops.linear(o2, *self.w[b + ".attn2.out"], residual=h, out=h, ld_out=h.shape[1])
+        ops.linear(o2, *self.w[b + ".attn2.out"], residual=h, out=h, ld_out=h.shape[1], row_stats=rs3)
         arena.release(mk)
         # GEGLU feed-forward
-        n3 = ops.layernorm(h, *self.w[b + ".norm3"])
-        fw, fb = self.w[b + ".ff1"]
-        g = ops.conv_gemm(n3, fw, fw.shape[0], bias=fb, act=ops.ACT_GEGLU)
+        if fold and rs3.parts:
+            fw, csf, fb = self.w[b + ".ff1.ln"]
+            g = ops.conv_gemm(h, fw, fw.shape[0], bias=fb, act=ops.ACT_GEGLU, ln=(rs3, csf, 1e-5))
+        else:
+            n3 = ops.layernorm(h, *self.w[b + ".norm3"])
+            fw, fb = self.w[b + ".ff1"]
+            g = ops.conv_gemm(n3, fw, fw.shape[0], bias=fb, act=ops.ACT_GEGLU)
         ops.linear(g, *self.w[b + ".ff2"], residual=h, out=h, ld_out=h.shape[1])
         arena.release(mk)
 

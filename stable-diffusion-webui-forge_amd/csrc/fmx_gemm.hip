@@ -396,7 +396,8 @@ __global__ void geglu_interleave_kernel(const f16* __restrict__ w_in, const f16*
 
 int fmx_launch_gn_stats(const void* x, int32_t c, int64_t ld, int32_t n, int32_t hw, float* partial, int32_t nchunks, hipStream_t st);  // fmx_norm.hip
 
-static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, int fallback_chunks, int* chunks_out, void* stream);
+static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, int fallback_chunks, int* chunks_out, void* stream,
+                         float* row_stats = nullptr, int row_parts_cap = 0, int* row_parts_out = nullptr);
 
 // stats != null: also leave the GroupNorm statistics of the output in stats[n][chunks][nout][2] (see fmx_gemm_conv_stats_f16 in fmx.h)
 //
@@ -444,7 +445,8 @@ static int gemm_conv_impl(const fmx_gemm_args* a, float* stats, int max_chunks, 
   return gemm_conv_one(a, stats, max_chunks, fallback_chunks, chunks_out, stream);
 }
 
-static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, int fallback_chunks, int* chunks_out, void* stream) {
+static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, int fallback_chunks, int* chunks_out, void* stream, float* row_stats,
+                         int row_parts_cap, int* row_parts_out) {
   FMX_REQUIRE(a && a->a0 && a->wgt && a->out && a->zero_page, "gemm: null pointer");
   const int ctot = a->c0 + a->c1;
   FMX_REQUIRE(a->c0 > 0 && a->c1 >= 0 && (a->c0 % 64) == 0 && (ctot % 64) == 0, "gemm: channels (%d,%d) must be multiples of 64", a->c0, a->c1);
@@ -478,6 +480,11 @@ static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, i
   p.splits = 1;
   p.ws = nullptr;
   p.tickets = nullptr;
+  p.row_stats = nullptr;
+  p.ln_partial = nullptr;
+  p.ln_parts = 0;
+  p.ln_colsum = nullptr;
+  p.ln_eps = p.ln_inv_c = 0.f;
   FMX_REQUIRE(fmx_aligned16(p.a0) && fmx_aligned16(p.wgt) && fmx_aligned16(p.zp) && (!p.a1 || fmx_aligned16(p.a1)), "gemm: operands must be 16-byte aligned");
   FMX_REQUIRE((p.s0 % 8) == 0 && (p.s1 % 8) == 0 && (p.ldw % 8) == 0, "gemm: strides must be multiples of 8 elements");
   FMX_REQUIRE((long)p.M * 1 > 0 && (long)a->n * a->oh * a->ow < (1L << 31), "gemm: M overflow");
@@ -577,6 +584,29 @@ static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, i
       *chunks_out = fallback_chunks;
     }
   }
+  // LayerNorm folded into the GEMMs around it (fmx.h: fmx_gemm_linear_rowstats_f16 / the ln_* fields): 256x320 tile, linear only
+  const bool ln_shape_ok = !conv && big_ok && p.c1 == 0 && !p.gate && !p.rowvec;
+  if (row_parts_out) {
+    const int parts = 2 * ((p.nout + 319) / 320);
+    if (sel == 6 && ln_shape_ok && a->act == FMX_ACT_NONE && p.residual && parts <= row_parts_cap && !stats) {
+      p.row_stats = row_stats;
+      *row_parts_out = parts;
+    } else {
+      *row_parts_out = 0;   // another tile shape suits this problem better: plain GEMM, the caller runs its LayerNorm kernel
+    }
+  }
+  if (a->ln_partial) {
+    FMX_REQUIRE(ln_shape_ok && !p.residual && !stats && (a->act == FMX_ACT_NONE || (geglu && (p.nout % 32) == 0)) && a->ln_colsum && a->ln_parts >= 2 &&
+                    (a->ln_parts % 2) == 0 && a->ln_parts <= 64 && fmx_aligned16(a->ln_partial) && fmx_aligned16(a->ln_colsum),
+                "gemm: a LayerNorm-folded GEMM is a plain linear (bias, optional GEGLU) with fp16 output on the 256x320 tile");
+    p.ln_partial = (const float*)a->ln_partial;
+    p.ln_parts = a->ln_parts;
+    p.ln_colsum = (const float*)a->ln_colsum;
+    p.ln_eps = a->ln_eps;
+    p.ln_inv_c = 1.0f / (float)p.c0;
+    sel = 6;
+    best_s = 1;
+  }
   int rc;
   if (sel >= 5) {
     FMX_REQUIRE(FastEpilogue::eligible8(p) && fits32, "gemm: the 256-row kernels need fp16 output, 16-byte aligned epilogue operands, leading dimensions / nout multiples of 8, operands < 2^32 elements");
@@ -599,6 +629,14 @@ static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, i
 }
 
 extern "C" int fmx_gemm_conv_f16(const fmx_gemm_args* a, void* stream) { return gemm_conv_impl(a, nullptr, 0, 0, nullptr, stream); }
+
+#ifndef FMX_ELEM_BF16  // the LDM transformer blocks run in fp16
+extern "C" int fmx_gemm_linear_rowstats_f16(const fmx_gemm_args* a, float* row_partial, int32_t parts_cap, int32_t* parts_out, void* stream) {
+  FMX_REQUIRE(a && row_partial && parts_out && parts_cap >= 2, "gemm_linear_rowstats: bad arguments");
+  FMX_REQUIRE(!a->ln_partial, "gemm_linear_rowstats: a GEMM is either the producer or the consumer of a folded LayerNorm");
+  return gemm_conv_one(a, nullptr, 0, 0, nullptr, stream, row_partial, parts_cap, parts_out);
+}
+#endif
 
 #ifndef FMX_ELEM_BF16  // GroupNorm exists on the fp16 (UNet / VAE) path only
 extern "C" int fmx_gemm_conv_stats_f16(const fmx_gemm_args* a, float* partial, int32_t max_chunks, int32_t fallback_chunks, int32_t* chunks_out,

@@ -72,10 +72,19 @@ struct Geo {
 // 3: bias + rowvec + residual, no gate (the statistics-emitting kernels: 8 registers fewer than MODE 0)
 // STATS: the lane also accumulates sum / sum of squares of the 8 columns it stores (of the ROUNDED fp16 values: what a statistics pass
 // over the stored tensor would read) into st[0..7] / st[8..15] -- the GroupNorm statistics of the output, see the kernel's epilogue.
-template <int RB, int LPR, int ROWS, int SWZ, bool TANH, int MODE, bool STATS = false>
+// LN (LayerNorm folded into the GEMMs on both sides of it, backend/nn/unet.py:262-279 `norm2` / `norm3` of a BasicTransformerBlock):
+//   LN = 1, the PRODUCER of the tensor the LayerNorm reads (the residual-adding projection): also emits, per output row and per wave column
+//        range, {sum, sum of squares} of the fp16 values it stores -> row_stats[m][part][2].  The LPR lanes of a row leave their pairs in the
+//        LDS bytes of the staged row they have just consumed (dead from then on); 32 lanes add them up after the pass.
+//   LN = 2, the CONSUMER (the projection that follows the LayerNorm), run on the UN-normalised tensor with weights pre-multiplied by gamma:
+//        LN(x) W = rstd (x W' - mean colsum(W')) + (beta W + b)  -- `lnm` / `lnr` hold mean / rstd of row `lane` of this wave's rows
+//        (computed once per tile from the producer's partials), fetched per row with a lane shuffle; `cs` = colsum of this lane's 8 columns.
+template <int RB, int LPR, int ROWS, int SWZ, bool TANH, int MODE, bool STATS = false, int LN = 0>
 __device__ __forceinline__ void epi_rows(const char* my, int lane, int mbase, int M, int /*col*/, bool nok, int per_img, float alpha, float has_gate,
                                          const f16* __restrict__ bias, const f16* __restrict__ rowvec, long ld_rv, const f16* __restrict__ gate, long ld_gt,
-                                         const f16* __restrict__ res, long ld_res, f16* __restrict__ out, long ld_out, float* st = nullptr) {
+                                         const f16* __restrict__ res, long ld_res, f16* __restrict__ out, long ld_out, float* st = nullptr,
+                                         float* __restrict__ rowst = nullptr, int rowst_ld = 0, float lnm = 0.f, float lnr = 0.f, int lnbase = 0,
+                                         const float* __restrict__ cs = nullptr) {
   constexpr int RPI = 64 / LPR;  // rows per wave instruction
   constexpr int ITERS = (ROWS + RPI - 1) / RPI;
   // opaque copy: keeps the compiler from hoisting the ITERS x 2 LDS offsets of EVERY call of this function above the whole
@@ -83,6 +92,11 @@ __device__ __forceinline__ void epi_rows(const char* my, int lane, int mbase, in
   asm volatile("" : "+v"(lane));
   const int cg = lane % LPR, rsub = lane / LPR;
   const f16x8 bb = *reinterpret_cast<const f16x8*>(bias);
+  f32x4 cs0 = f32x4{0.f, 0.f, 0.f, 0.f}, cs1 = cs0;
+  if (LN == 2) {
+    cs0 = *reinterpret_cast<const f32x4*>(cs);
+    cs1 = *reinterpret_cast<const f32x4*>(cs + 4);
+  }
   // vmcnt retires in order, loads and stores alike: an iteration that loads its operands AFTER the previous iteration's
   // store waits for that store to complete.  So the operands of iteration it+1 are requested before iteration it stores.
   f16x8 rv[2], gt[2], rs[2];
@@ -105,10 +119,17 @@ __device__ __forceinline__ void epi_rows(const char* my, int lane, int mbase, in
     const f32x4 hi4 = *reinterpret_cast<const f32x4*>(my + row * RB + (((2 * cg + 1) ^ (row & SWZ)) << 4));
     const int m = mbase + row;
     const bool ok = nok && m < M && rsub < RPI && it * RPI + rsub < ROWS;
+    float mean_r = 0.f, rstd_r = 1.f;
+    if (LN == 2) {
+      mean_r = __shfl(lnm, lnbase + row);
+      rstd_r = __shfl(lnr, lnbase + row);
+    }
     f16x8 hv;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      float v = (r < 4 ? lo[r & 3] : hi4[r & 3]) * alpha + (float)bb[r];
+      float v = (r < 4 ? lo[r & 3] : hi4[r & 3]) * alpha;
+      if (LN == 2) v = (v - mean_r * (r < 4 ? cs0[r & 3] : cs1[r & 3])) * rstd_r;
+      v += (float)bb[r];
       if (MODE == 0 || MODE == 3) v += (float)rv[cur][r];
       if (TANH) v = gelu_tanh_f(v);
       if (MODE == 0) v *= fmaf(has_gate, (float)gt[cur][r] - 1.0f, 1.0f);
@@ -116,6 +137,18 @@ __device__ __forceinline__ void epi_rows(const char* my, int lane, int mbase, in
       hv[r] = (f16)v;
     }
     if (ok) *reinterpret_cast<f16x8*>(out + m * ld_out) = hv;
+    if (LN == 1) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const float f = (float)hv[r];
+        s1 += f;
+        s2 = fmaf(f, f, s2);
+      }
+      if (!nok) s1 = s2 = 0.f;   // columns beyond nout
+      // this row's staged accumulators were consumed by the two reads above (all of its lanes, same instructions): its bytes are free
+      if (rsub < RPI && it * RPI + rsub < ROWS) *reinterpret_cast<float2*>(const_cast<char*>(my) + row * RB + cg * 8) = float2{s1, s2};
+    }
     if (STATS) {
       // every row of the tile is a valid output row here (the host only asks for statistics when M % 256 == 0), lanes with an
       // out-of-range column or a row-lane >= RPI are dropped by the reduction that follows; only the last iteration can revisit a row
@@ -130,13 +163,26 @@ __device__ __forceinline__ void epi_rows(const char* my, int lane, int mbase, in
       }
     }
   }
+  if (LN == 1) {
+    if (lane < ROWS) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int c = 0; c < LPR; ++c) {
+        const float2 v = *reinterpret_cast<const float2*>(my + lane * RB + c * 8);
+        a += v.x;
+        b += v.y;
+      }
+      const int m = mbase + lane;
+      if (m < M) *reinterpret_cast<float2*>(rowst + (long)m * rowst_ld) = float2{a, b};
+    }
+  }
 }
 
 // SCHED: where the NP LDS-DMA pieces of a K-tile are issued (A/B knob FMX_GEMM_SCHED, tools/bench_kernels.py gemmsched):
 //   0: 3 behind the barrier (k-step 3 of the tile before), 3 in k-step 0, the rest in k-step 1 -- spread thin beside the MFMAs
 //   1: 5 / 4 / 0 -- everything a k-step earlier, 2 k-steps (~1.5 k cycles) between the last issue and the wait
 //   2: all NP behind the barrier
-template <bool CONV, int BM, int BN, bool STATS = false, int SCHED = 0>
+template <bool CONV, int BM, int BN, bool STATS = false, int SCHED = 0, int LN = 0>
 __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   using G = Geo<BM, BN>;
   constexpr int MI = G::MI, NJ = G::NJ, NPA = G::NPA, NPB = G::NPB, NP = G::NP;
@@ -405,7 +451,21 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   __builtin_amdgcn_s_barrier();  // every wave is done reading the last stage: the LDS is free
   char* my = smem + wave * G::WAVE_EPI_BYTES;
   const FastEpilogue ep(p);
-  const bool geglu = !STATS && p.act == FMX_ACT_GEGLU;   // (no GEGLU code in the statistics-emitting kernels: registers)
+  const bool geglu = !STATS && LN != 1 && p.act == FMX_ACT_GEGLU;   // (no GEGLU code in the statistics-emitting kernels: registers)
+  // LN consumer: mean / rstd of row `lane` of this wave's MI*32 rows, from the producer's per-row partial sums (fixed order)
+  float lnm = 0.f, lnr = 1.f;
+  if (LN == 2) {
+    const int mrow = min(m0 + wm * (MI * 32) + lane, p.M - 1);
+    const float* q = p.ln_partial + (long)mrow * (p.ln_parts * 2);
+    float s1 = 0.f, s2 = 0.f;
+    for (int k2 = 0; k2 < p.ln_parts; k2 += 2) {   // (an even number of parts: two waves per 320-column tile)
+      const f32x4 v = *reinterpret_cast<const f32x4*>(q + k2 * 2);
+      s1 += v[0] + v[2];
+      s2 += v[1] + v[3];
+    }
+    lnm = s1 * p.ln_inv_c;
+    lnr = rsqrtf(fmaxf(s2 * p.ln_inv_c - lnm * lnm, 0.f) + p.ln_eps);
+  }
   if (!geglu) {
     constexpr int RB = NJ * 128;       // staged row: NJ*32 fp32
     constexpr int LPR = NJ * 4;        // lanes per output row (8 columns each)
@@ -434,6 +494,10 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
         if (ep.mrv) epi_rows<RB, LPR, 32, 7, false, 3, true>(FMX_EPI_ARGS);
         else if (ep.mres) epi_rows<RB, LPR, 32, 7, false, 1, true>(FMX_EPI_ARGS);
         else epi_rows<RB, LPR, 32, 7, false, 2, true>(FMX_EPI_ARGS);
+      } else if (LN == 1) {   // producer: bias + residual (the host sends nothing else here)
+        epi_rows<RB, LPR, 32, 7, false, 1, false, 1>(FMX_EPI_ARGS, p.row_stats + (long)(tn * G::WN + wn) * 2, G::WN * p.tiles_n * 2);
+      } else if (LN == 2) {   // consumer: bias only
+        epi_rows<RB, LPR, 32, 7, false, 2, false, 2>(FMX_EPI_ARGS, nullptr, 0, lnm, lnr, i * 32, p.ln_colsum + nbc);
       } else if (ep.gelu_tanh) epi_rows<RB, LPR, 32, 7, true, 0>(FMX_EPI_ARGS);       // uniform branches
       else if (ep.mrv | ep.mgt) epi_rows<RB, LPR, 32, 7, false, 0>(FMX_EPI_ARGS);
       else if (ep.mres) epi_rows<RB, LPR, 32, 7, false, 1>(FMX_EPI_ARGS);
@@ -498,6 +562,12 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
     }
     // the per-image row vector (a ResBlock's embedding add) is absent from every GEGLU call of the UNet / Flux executors: its loads
     // (two 8-byte loads and their wait per 4 outputs, from the zero page when absent) are compiled out of the common instantiation
+    float gm[MI], gr[MI];   // LN consumer: mean / rstd of this lane's pixel row in each block row
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      gm[i] = LN == 2 ? __shfl(lnm, i * 32 + li) : 0.f;
+      gr[i] = LN == 2 ? __shfl(lnr, i * 32 + li) : 1.f;
+    }
     auto stage_geglu = [&](auto HAS_RV) {
       constexpr bool RV = decltype(HAS_RV)::value != 0;
 #pragma unroll
@@ -507,6 +577,11 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
           const int nb = n0 + wn * (NJ * 32) + j * 32 + q4 * 8 + hi * 4;
           const int nbc = nb < ep.nout ? nb : 0;
           const f16x4 bv = ep.bias4(nbc), bg = ep.bias4(nbc + 16);  // few live registers: the 160-accumulator tile has none to spare
+          f32x4 sv = f32x4{0.f, 0.f, 0.f, 0.f}, sg = sv;
+          if (LN == 2) {
+            sv = *reinterpret_cast<const f32x4*>(p.ln_colsum + nbc);
+            sg = *reinterpret_cast<const f32x4*>(p.ln_colsum + nbc + 16);
+          }
 #pragma unroll
           for (int i = 0; i < MI; ++i) {
             f16x4 rvv, rvg;
@@ -514,8 +589,14 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
             f32x4 o;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              float val = acc[i][j][q4 * 4 + r] * ep.alpha + (float)bv[r];
-              float gate = acc[i][j][8 + q4 * 4 + r] * ep.alpha + (float)bg[r];
+              float val = acc[i][j][q4 * 4 + r] * ep.alpha;
+              float gate = acc[i][j][8 + q4 * 4 + r] * ep.alpha;
+              if (LN == 2) {
+                val = (val - gm[i] * sv[r]) * gr[i];
+                gate = (gate - gm[i] * sg[r]) * gr[i];
+              }
+              val += (float)bv[r];
+              gate += (float)bg[r];
               if (RV) { val += (float)rvv[r]; gate += (float)rvg[r]; }
               o[r] = val * gelu_erf_f(gate);
             }
@@ -553,6 +634,23 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
 // SC / SL: DMA issue schedule of the convolution / linear instantiation.  Measured (profiles/r04j_gemm_dma_schedule_ab.jsonl, 256x320 tile, two
 // runs each): the linear GEMMs of the SDXL forward gain 2-3 % from schedule 1 (993 -> 1014, 847 -> 870 GEGLU, 1186 -> 1225 at K = 5120, 1042 ->
 // 1065 TFLOP/s), the implicit-GEMM convolutions (longer address arithmetic per piece) are level or 1 % slower -> linear 1, convolution 0.
+// the two LayerNorm-folding instantiations: linear GEMMs on the 256 x 320 tile only
+template <int LN>
+int launch_ln(const GemmParams& p, hipStream_t st) {
+  using G = Geo<256, 320>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<false, 256, 320, false, 1, LN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    attr_set = true;
+  }
+  GemmParams q = p;
+  q.tiles_m = (p.M + 255) / 256;
+  q.tiles_n = (p.nout + 319) / 320;
+  hipLaunchKernelGGL((gemm256p_kernel<false, 256, 320, false, 1, LN>), dim3(q.tiles_m * q.tiles_n), dim3(512), G::LDS_BYTES, st, q);
+  FMX_LAUNCH_CHECK("fmx_gemm_conv_f16 (256x320, LayerNorm folded)");
+  return FMX_OK;
+}
+
 template <int BM, int BN, bool STATS, int SC = 0, int SL = 1>
 int launch_bn(const GemmParams& p, bool conv, hipStream_t st) {
   using G = Geo<BM, BN>;
@@ -575,6 +673,8 @@ int launch_bn(const GemmParams& p, bool conv, hipStream_t st) {
 }  // namespace
 
 int fmx_launch_gemm256p(const GemmParams& p, bool conv, int bm, int bn, hipStream_t st) {
+  if (p.row_stats) return launch_ln<1>(p, st);
+  if (p.ln_partial) return launch_ln<2>(p, st);
   static int sched = -1;
   if (sched < 0) {
     const char* e = getenv("FMX_GEMM_SCHED");   // A/B knob (tools/bench_kernels.py gemmsched): force one DMA issue schedule on the 256x320 tile

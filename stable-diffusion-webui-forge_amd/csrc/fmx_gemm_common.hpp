@@ -37,6 +37,12 @@ struct GemmParams {
   int splits;       // 1 = off
   float* ws;        // partial accumulators, [tile][split][BM*BN] fp32 in the kernel's register layout
   int* tickets;     // one arrival counter per tile, zero between launches
+  // LayerNorm folded into the GEMMs around it (256x320 tile, see fmx_gemm256p.hip "LN"):
+  float* row_stats;          // producer: per-row {sum, sum of squares} of the stored fp16 output, [M][2 * tiles_n][2]
+  const float* ln_partial;   // consumer: the producer's array for this GEMM's INPUT rows, ln_parts entries per row
+  int ln_parts;
+  const float* ln_colsum;    // consumer: fp32 column sums of the (gamma-scaled) weight, [nout]
+  float ln_eps, ln_inv_c;    // consumer: LayerNorm epsilon, 1 / normalised width
 };
 
 // K-tile depth of every GEMM kernel: 64 halfs = one 128-byte LDS row.

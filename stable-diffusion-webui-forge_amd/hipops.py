@@ -172,12 +172,15 @@ _FUSED_STATS = os.environ.get("FMX_GN_FUSED_STATS", "1") != "0"
 
 def conv_gemm(x, wgt, nout, *, x1=None, n=None, h=None, w=None, kh=1, stride=1, pad=0, up=None, bias=None,
               rowvec=None, residual=None, act=ACT_NONE, alpha=1.0, out=None, ld_out=None, out_dtype=None,
-              ldw=0, force_tile=0, gate=None, out_hw=None, stats=False, stats_partial=None):
+              ldw=0, force_tile=0, gate=None, out_hw=None, stats=False, stats_partial=None, row_stats=None, ln=None):
     """OUT[M, ncols] = epilogue(A (*) W^T).  x: [N,H,W,C0] (or [M,C0] with kh == 1); x1: optional second source
     concatenated along channels; wgt: [nout, kh*kh*(C0+C1)]; up=(UH, UW): nearest-resize before the conv.
     stats=True: returns (out, GnStats of out) -- the GroupNorm statistics of the output come out of the GEMM's epilogue (256-row tiles)
     or of a pass behind it, fmx_gemm_conv_stats_f16; (out, None) when the knob above disables it.  stats_partial: a buffer from
-    `stats_buffer` when the statistics have to outlive the current arena scope (they live exactly as long as `out` must)."""
+    `stats_buffer` when the statistics have to outlive the current arena scope (they live exactly as long as `out` must).
+    LayerNorm folding (fmx.h, fmx_gemm_linear_rowstats_f16 / ln_* fields): row_stats = a RowStats whose buffer takes the per-row sums of the
+    output (its `.parts` is 0 afterwards if the dispatcher did not use the 256x320 tile); ln = (RowStats of the INPUT, colsum fp32 [nout],
+    eps) runs the GEMM as `LN(x) W^T + b` on the un-normalised x (wgt / bias pre-folded by the caller)."""
     sfx, elem = _elem(x, x1, wgt, bias, rowvec, residual, gate)
     fn_name = "fmx_gemm_conv" + sfx
     if out_dtype is None:
@@ -220,8 +223,23 @@ def conv_gemm(x, wgt, nout, *, x1=None, n=None, h=None, w=None, kh=1, stride=1, 
     a.gate = _p(gate)
     a.ld_gate = gate.stride(0) if gate is not None else 0
     a.workspace, a.workspace_bytes = _p(splitk_workspace(x.device)), SPLITK_WORKSPACE_BYTES
+    if ln is not None:
+        global LN_FOLDED_LAUNCHES
+        LN_FOLDED_LAUNCHES += 1
+        rs, colsum, eps = ln
+        assert rs.parts >= 2 and colsum.dtype == torch.float32 and colsum.numel() == nout and rs.partial.dtype == torch.float32
+        a.ln_partial, a.ln_parts, a.ln_colsum, a.ln_eps = _p(rs.partial), rs.parts, _p(colsum), float(eps)
     st = None
-    if stats and _FUSED_STATS and sfx == "_f16":
+    if row_stats is not None:
+        assert sfx == "_f16" and not stats and ln is None
+        cap = row_stats.partial.numel() // (2 * m)
+        got = C.c_int32(0)
+
+        def launch():
+            _lib.check(_lib.lib().fmx_gemm_linear_rowstats_f16(C.byref(a), _p(row_stats.partial), cap, C.byref(got), stream_ptr()),
+                       "fmx_gemm_linear_rowstats_f16")
+            row_stats.parts = got.value
+    elif stats and _FUSED_STATS and sfx == "_f16":
         hw = oh * ow
         fb, cap = _stats_geometry(n_, hw)
         partial = stats_partial if stats_partial is not None else empty((n_, cap, ncols, 2), torch.float32, x.device)
@@ -245,6 +263,18 @@ def conv_gemm(x, wgt, nout, *, x1=None, n=None, h=None, w=None, kh=1, stride=1, 
     _dbg(f"conv_gemm M={m} N={nout} K={kh * kh * (c0 + c1)} stats={st is not None and st.nchunks}", out=out,
          partial=None if st is None else st.partial.reshape(-1)[:n_ * st.nchunks * ncols * 2])
     return (out, st) if stats else out
+
+
+LN_FOLDED_LAUNCHES = 0   # GEMMs launched with a LayerNorm folded in (tests assert the executor took that path at the sizes it should)
+
+
+class RowStats:
+    """Per-row {sum, sum of squares} partials of an [M, N] tensor, written by the GEMM that produced it (conv_gemm(row_stats=...)) for the
+    LayerNorm-folded GEMM that reads it (conv_gemm(ln=...)).  parts == 0: not available (the producer used another tile shape)."""
+
+    def __init__(self, m, n, device=None):
+        self.partial = empty((m, 2 * (-(-n // 320)), 2), torch.float32, device)
+        self.parts = 0
 
 
 def linear(x, wgt, bias=None, **kw):

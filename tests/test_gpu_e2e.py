@@ -635,6 +635,29 @@ def test_sdxl_full_size_forward_vs_reference_fixture(sdxl_engine):
     check("SDXL unet forward at full size (128x128 latent) vs reference", eps, g["eps"], floor="sdxl_full_fwd.pt:eps")
 
 
+@pytest.mark.skipif(not _have("sdxl_full_fwd.pt"), reason="full fixture not generated")
+def test_sdxl_full_size_forward_at_the_bench_batch_vs_reference_fixture(sdxl_engine):
+    """The same fixture at the BENCH's UNet batch (16): the reference's input repeated 16 times, every image of the result against the
+    reference's output.  At this size the executor takes the paths a batch of 1 does not reach: 256x320 tiles everywhere, GroupNorm statistics
+    from the GEMM epilogues, norm2 / norm3 folded into the projections behind them (counted), key-split attention off -- the configuration the
+    throughput numbers are measured on."""
+    from forge_amd import hipops
+    from oracle.make_golden import _inputs
+    g = load_golden("sdxl_full_fwd.pt")
+    cfg = synth.SDXL_UNET_CONFIG
+    x, t, ctx, y = _inputs(cfg, 1, 128, seed=g["inputs_seed"])
+    net = sdxl_engine.forge_objects.unet.model.diffusion_model
+    n = 16
+    before = hipops.LN_FOLDED_LAUNCHES
+    eps = net.forward(x.repeat(n, 1, 1, 1).to(DEV), t.repeat(n).to(DEV), context=ctx.repeat(n, 1, 1).to(DEV), y=y.repeat(n, 1).to(DEV))
+    assert hipops.LN_FOLDED_LAUNCHES - before == 2 * 70, "norm2 and norm3 of all 70 transformer blocks are expected to run folded at this size"
+    worst = max(range(n), key=lambda i: float((eps[i].float().cpu() - g["eps"][0]).abs().max()))
+    for i in sorted({0, n - 1, worst}):
+        check(f"SDXL unet forward at full size, image {i} of a batch of {n} vs reference", eps[i:i + 1], g["eps"], floor="sdxl_full_fwd.pt:eps")
+    spread = float((eps.float() - eps[:1].float()).abs().max() / eps.float().abs().max())
+    assert spread < 2e-3, f"identical inputs, different batch positions: {spread}"
+
+
 @pytest.mark.skipif(not _have("sdxl_config3.pt"), reason="full fixture not generated")
 def test_sdxl_config3_dpmpp2m_vs_reference_fixture(sdxl_engine):
     """BASELINE config 3's sampler at full size: SDXL 1024x1024, DPM++ 2M on the Karras schedule, CFG 7, 5 steps of one image (10 sample-forwards

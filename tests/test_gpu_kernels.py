@@ -148,6 +148,56 @@ def test_split_k_hand_over_under_load_is_stable(monkeypatch):
         close(got, ops.linear(x, w, b, force_tile=tile).float(), 1e-3, 1e-3, f"split-K x{splits} tile {tile} case {ci} vs unsplit")
 
 
+@pytest.mark.parametrize("m,c,nq", [(16384, 1280, 1280), (16384 - 100, 1280, 640), (65536, 640, 640)])
+def test_layernorm_folded_into_the_gemms_around_it(m, c, nq):
+    """norm2 / norm3 of a transformer block without a LayerNorm kernel (csrc/fmx_gemm256p.hip `LN`): the residual-adding projection that
+    writes h also leaves per-row {sum, sum of squares} partials of the fp16 values it stored (fmx_gemm_linear_rowstats_f16); the projection
+    behind the LayerNorm runs on h itself with gamma-scaled weights and applies mean / rstd in its epilogue (plain and GEGLU).  Against
+    F.layer_norm + linear in fp32 on the same stored h; the partials against sums over the stored tensor; a ragged last row tile included."""
+    from forge_amd.backend.nn.unet import _fold_layernorm
+    k_in = c
+    o_in = rnd(m, k_in, seed=90)
+    w_out, b_out = rnd(c, k_in, scale=1 / math.sqrt(k_in), seed=91), rnd(c, seed=92)
+    h = (rnd(m, c, scale=2.0, seed=93) + 0.7).contiguous()          # the residual stream, with a non-zero mean
+    h0 = h.clone()
+    rs = ops.RowStats(m, c)
+    ops.linear(o_in, w_out, b_out, residual=h, out=h, ld_out=c, row_stats=rs)
+    close(h, o_in.float() @ w_out.float().t() + b_out.float() + h0.float(), 2e-3, 2e-3, "producer output")
+    assert rs.parts == 2 * (c // 320), "expected the 256x320 tile (and its row statistics) for this shape"
+    got = rs.partial.view(m, -1, 2)[:, :rs.parts].double().sum(1)
+    hf = h.double()
+    torch.testing.assert_close(got, torch.stack([hf.sum(1), (hf * hf).sum(1)], -1), rtol=1e-5, atol=1e-2)
+    gamma, beta = (1 + 0.2 * rnd(c, seed=94)), 0.1 * rnd(c, seed=95)
+    ln = F.layer_norm(h.float(), (c,), gamma.float(), beta.float(), 1e-5)
+    wq = rnd(nq, c, scale=1 / math.sqrt(c), seed=96)
+    wf, cs, bf = _fold_layernorm(wq, None, gamma, beta)
+    q = ops.conv_gemm(h, wf, nq, bias=bf, ln=(rs, cs, 1e-5))
+    close(q, ln @ wq.float().t(), 4e-3, 4e-3, "LayerNorm folded into a plain projection")
+    inner = nq
+    wg, bg = rnd(2 * inner, c, scale=1 / math.sqrt(c), seed=97), rnd(2 * inner, seed=98)
+    wgi, bgi = ops.geglu_interleave(wg, bg)
+    wf2, cs2, bf2 = _fold_layernorm(wgi, bgi, gamma, beta)
+    g = ops.conv_gemm(h, wf2, 2 * inner, bias=bf2, act=ops.ACT_GEGLU, ln=(rs, cs2, 1e-5))
+    hc = ln @ wg.float().t() + bg.float()
+    close(g, hc[:, :inner] * F.gelu(hc[:, inner:]), 5e-3, 5e-3, "LayerNorm folded into the GEGLU projection")
+    # the kernel it replaces, for scale: LayerNorm output rounded to fp16, then the same GEMM
+    n_kernel = ops.layernorm(h, gamma, beta)
+    q_old = ops.linear(n_kernel, wq)
+    err_new = float((q.float() - ln @ wq.float().t()).abs().max()), float((q_old.float() - ln @ wq.float().t()).abs().max())
+    assert err_new[0] <= 2.0 * err_new[1] + 1e-3, err_new
+
+
+def test_layernorm_fold_is_declined_for_small_problems():
+    """Below the sizes at which the dispatcher uses the 256x320 tile the producer emits nothing (parts == 0) and the caller keeps its LayerNorm."""
+    m, c = 512, 640
+    x, w, b, h = rnd(m, c, seed=99), rnd(c, c, scale=0.04, seed=100), rnd(c, seed=101), rnd(m, c, seed=102)
+    h0 = h.clone()
+    rs = ops.RowStats(m, c)
+    ops.linear(x, w, b, residual=h, out=h, ld_out=c, row_stats=rs)
+    assert rs.parts == 0
+    close(h, x.float() @ w.float().t() + b.float() + h0.float(), 2e-3, 2e-3, "producer output without statistics")
+
+
 def test_small_batch_shapes_pick_a_correct_kernel():
     """The interactive-batch shapes of the SDXL forward (UNet batch 2: M = 2048 rows), through the dispatcher's own choice (split-K where its cost
     model says so) against the fp32 reference."""
