@@ -597,7 +597,7 @@ static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, i
   }
   if (a->ln_partial) {
     FMX_REQUIRE(ln_shape_ok && !p.residual && !stats && (a->act == FMX_ACT_NONE || (geglu && (p.nout % 32) == 0)) && a->ln_colsum && a->ln_parts >= 2 &&
-                    (a->ln_parts % 2) == 0 && a->ln_parts <= 64 && fmx_aligned16(a->ln_partial) && fmx_aligned16(a->ln_colsum),
+                    (a->ln_parts % 2) == 0 && a->ln_parts <= 8 && fmx_aligned16(a->ln_partial) && fmx_aligned16(a->ln_colsum),
                 "gemm: a LayerNorm-folded GEMM is a plain linear (bias, optional GEGLU) with fp16 output on the 256x320 tile");
     p.ln_partial = (const float*)a->ln_partial;
     p.ln_parts = a->ln_parts;

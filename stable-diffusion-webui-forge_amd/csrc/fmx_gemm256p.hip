@@ -332,6 +332,16 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
     }
   };
 
+  // LN consumer: the producer's per-row partial sums of row `lane` of this wave's MI*32 rows are needed in the epilogue; a round trip to
+  // another XCD's output costs ~2 us there (15 us per ff1 launch).  One word of the row's 64-byte record is loaded here, ahead of the K loop:
+  // it pulls the line into this CU's cache, and ONE register rides through the loop (the 160-accumulator tile has no room for mean and rstd).
+  float ln_touch = 0.f;
+  const float* ln_row = nullptr;
+  if (LN == 2) {
+    const int mrow = min(m0 + wm * (MI * 32) + lane, p.M - 1);
+    ln_row = p.ln_partial + (long)mrow * (p.ln_parts * 2);
+    ln_touch = ln_row[0];
+  }
   f32x16 acc[MI][NJ];
 #pragma unroll
   for (int i = 0; i < MI; ++i)
@@ -399,7 +409,6 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   read_frags(0, 0, 0);
-
   // iteration t:  k-step 0: + pieces 3-5 of tile t+1   k-step 1: + pieces 6.. of tile t+1   k-step 2: nothing
   //               wait + barrier                          k-step 3: + pieces 0-2 of tile t+2 (into the stage just released)
 #ifdef FMX_ABLATE
@@ -452,16 +461,15 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   char* my = smem + wave * G::WAVE_EPI_BYTES;
   const FastEpilogue ep(p);
   const bool geglu = !STATS && LN != 1 && p.act == FMX_ACT_GEGLU;   // (no GEGLU code in the statistics-emitting kernels: registers)
-  // LN consumer: mean / rstd of row `lane` of this wave's MI*32 rows, from the producer's per-row partial sums (fixed order)
+  // LN consumer: mean / rstd of row `lane` of this wave's rows (fixed summation order); lane l serves row l through __shfl below
   float lnm = 0.f, lnr = 1.f;
   if (LN == 2) {
-    const int mrow = min(m0 + wm * (MI * 32) + lane, p.M - 1);
-    const float* q = p.ln_partial + (long)mrow * (p.ln_parts * 2);
-    float s1 = 0.f, s2 = 0.f;
-    for (int k2 = 0; k2 < p.ln_parts; k2 += 2) {   // (an even number of parts: two waves per 320-column tile)
-      const f32x4 v = *reinterpret_cast<const f32x4*>(q + k2 * 2);
-      s1 += v[0] + v[2];
-      s2 += v[1] + v[3];
+    float s1 = ln_touch, s2 = 0.f;   // (entry 0's sum is the word loaded before the K loop)
+    const float* q = ln_row;
+    s2 += q[1];
+    for (int k2 = 1; k2 < p.ln_parts; ++k2) {
+      s1 += q[2 * k2];
+      s2 += q[2 * k2 + 1];
     }
     lnm = s1 * p.ln_inv_c;
     lnr = rsqrtf(fmaxf(s2 * p.ln_inv_c - lnm * lnm, 0.f) + p.ln_eps);
