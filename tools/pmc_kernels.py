@@ -44,6 +44,29 @@ def gn(n, h, w, c):
         ops.groupnorm(x, g, bb, 1e-5, silu=True, out=out)
 
 
+def geglu(m, inner, k):
+    x, w, b = rnd(m, k), rnd(2 * inner, k, scale=k ** -0.5), rnd(2 * inner)
+    wi, bi = ops.geglu_interleave(w, b)
+    out = torch.empty(m, inner, dtype=torch.float16, device=DEV)
+    for _ in range(REPS):
+        ops.conv_gemm(x, wi, 2 * inner, bias=bi, act=ops.ACT_GEGLU, out=out, ld_out=inner)
+
+
+def ln_fold(m, c, inner):
+    """the LayerNorm-folding pair: producer (bias + in-place residual + row statistics), consumers (plain projection, GEGLU)"""
+    from forge_amd.backend.nn.unet import _fold_layernorm
+    o, w_out, b_out, h = rnd(m, c), rnd(c, c, scale=c ** -0.5), rnd(c), rnd(m, c)
+    gamma, beta = 1 + 0.1 * rnd(c), 0.1 * rnd(c)
+    wq = rnd(c, c, scale=c ** -0.5)
+    wg, bg = ops.geglu_interleave(rnd(2 * inner, c, scale=c ** -0.5), rnd(2 * inner))
+    fq, fg = _fold_layernorm(wq, None, gamma, beta), _fold_layernorm(wg, bg, gamma, beta)
+    rs = ops.RowStats(m, c)
+    for _ in range(REPS):
+        ops.linear(o, w_out, b_out, residual=h, out=h, ld_out=c, row_stats=rs)
+        ops.conv_gemm(h, fq[0], c, bias=fq[2], ln=(rs, fq[1], 1e-5))
+        ops.conv_gemm(h, fg[0], 2 * inner, bias=fg[2], act=ops.ACT_GEGLU, ln=(rs, fg[1], 1e-5))
+
+
 attn(16, 10, 4096, 4096)
 attn(16, 20, 1024, 1024)
 attn(16, 20, 1024, 77)
@@ -53,5 +76,8 @@ gemm(16384, 1280, 5120)
 conv(16, 32, 32, 1280, 1280)
 conv(16, 64, 64, 640, 640)
 gn(16, 128, 128, 320)
+geglu(16384, 5120, 1280)
+ln_fold(16384, 1280, 5120)
+conv(4, 1024, 1024, 128, 128)     # the VAE decoder's last level: 512x128 tile
 torch.cuda.synchronize()
 print("pmc_kernels done")
