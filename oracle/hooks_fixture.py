@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE ONLY.
 
-A deterministic set of transformer_options hooks (every hook point of backend/nn/unet.py:186-279 and :696-763 except the two whose
-arguments are torch.nn.Module objects), written with plain torch ops so the SAME functions run inside the reference UNet on CPU fp32
+A deterministic set of transformer_options hooks (every hook point of backend/nn/unet.py:186-279 and :696-763; the two whose arguments are
+torch.nn.Module objects -- block_inner_modifiers, group_norm_wrapper -- in build_module_hooks below), written with plain torch ops so the SAME functions run inside the reference UNet on CPU fp32
 (fixture generation, oracle/make_golden.py gen_unet_hooks) and inside the native executor on fp16 device tensors (tests/test_gpu_hooks.py).
 Each hook also records that it was called, and what `block` / `block_index` / `transformer_index` it saw."""
 import torch
@@ -93,3 +93,35 @@ def build_hooks(log=None, use_call_keys=False):
         "patches_replace": {"attn1": {("middle", 0, 0): attn1_replace}, "attn2": {("input", 3): attn2_replace}},
         "block_modifiers": [block_modifier],
     }, log
+
+
+def build_module_hooks(log=None):
+    """The two hooks that receive MODULES: `block_inner_modifiers` (unet.py:73-91: x, 'before' / 'after', layer, layer_index, block,
+    transformer_options) and `group_norm_wrapper` (unet.py:436-474, :755-757: norm, x, transformer_options).  They use what extensions use of
+    those objects -- the layer's class name, the block's length, the GroupNorm's parameters and the norm itself as a callable -- so the same
+    functions run on the reference's modules and on the native executor's stand-ins."""
+    log = log if log is not None else []
+
+    def inner(x, when, layer, layer_index, block, to):
+        name = type(layer).__name__
+        log.append(("inner_" + when, name, layer_index, len(block), to.get("block")))
+        if name == "SpatialTransformer" and when == "after":
+            return x * 1.03
+        if name == "ResBlock" and when == "before":
+            return x + 0.02
+        if name == "Upsample" and when == "after":
+            return x * 0.97
+        if name == "Downsample" and when == "before":
+            x *= 1.02   # in place
+            return x
+        if name == "Conv2d" and when == "after":
+            return x * 1.01
+        return x
+
+    def group_norm_wrapper(norm, x, to):
+        log.append(("group_norm_wrapper", int(norm.num_groups), int(norm.num_channels), int(x.shape[1]), to.get("block")))
+        y = norm(x)
+        y2 = torch.nn.functional.group_norm(x.float(), norm.num_groups, norm.weight.float(), norm.bias.float(), norm.eps).to(x.dtype)
+        return (0.5 * (y + y2)) * 0.98
+
+    return {"block_inner_modifiers": [inner], "group_norm_wrapper": group_norm_wrapper}, log

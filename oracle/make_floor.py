@@ -361,6 +361,15 @@ def floors_aux():
             outs = m(x=fx["x"].half(), hint=case["hint_a"].half(), timesteps=fx["t"], context=fx["ctx"].half(),
                      y=None if fx["y"] is None else fx["y"].half())
         out[f"{name}_controlnet.pt:outs_worst"] = _worst([metrics(o[:, ::4].float(), w) for o, w in zip(outs, g["outs_every_4th_channel"])])
+    # --- UNet forward with the two module-typed hooks ------------------------------------------------------------------------------------
+    from oracle.hooks_fixture import build_module_hooks
+    for name, cfg in (("tiny_sd15", synth.TINY_SD15_UNET_CONFIG), ("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG)):
+        g, fx = _load(f"{name}_unet_module_hooks.pt"), _load(f"{name}_unet_fwd.pt")
+        net16 = half_unet(cfg, synth.synth_unet_state_dict(cfg, seed=0))
+        to, _ = build_module_hooks()
+        with torch.no_grad():
+            e16 = net16(fx["x"].clone(), fx["t"], context=fx["ctx"], y=fx["y"], transformer_options=to)
+        out[f"{name}_unet_module_hooks.pt:eps"] = metrics(e16.float(), g["eps"])
     # --- T2I-Adapter / Adapter_light features ----------------------------------------------------------------------------------------
     t2i = importlib.import_module("backend.nn.cnets.t2i_adapter")
     g = _load("mini_sd15_t2i_adapter.pt")

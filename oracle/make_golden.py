@@ -896,6 +896,18 @@ def gen_unet_hooks(name, cfg, net, b=2, hw=16):
     print(name, "hooks:", len(log), "hook calls per forward; eps std", float(eps.std()), "euler3 std", float(lat.std()))
 
 
+def gen_unet_module_hooks(name, cfg, net):
+    """Reference UNet forward with the two module-typed hooks of oracle/hooks_fixture.py build_module_hooks (block_inner_modifiers,
+    group_norm_wrapper): output and the sequence of hook calls (class names, layer indices, block lengths, block ids)."""
+    from oracle.hooks_fixture import build_module_hooks
+    fx = torch.load(os.path.join(GOLD, f"{name}_unet_fwd.pt"))
+    to, log = build_module_hooks()
+    with torch.no_grad():
+        eps = net(fx["x"].clone(), fx["t"], context=fx["ctx"], y=fx["y"], transformer_options=to)
+    torch.save({"eps": eps, "log": list(log)}, os.path.join(GOLD, f"{name}_unet_module_hooks.pt"))
+    print(name, "module hooks:", len(log), "calls; eps std", float(eps.std()), "moved the output by", float((eps - fx["eps"]).abs().max() / fx["eps"].abs().max()))
+
+
 def controlnet_case(cfg, b=2, hw=16):
     """Deterministic ControlNet inputs shared by the generator and the tests: hint images (one at the exact 8x size, one that needs the
     nearest-exact resize + centre crop), a mask, per-frame weights."""
@@ -1689,6 +1701,9 @@ def main():
         for nm, cf in (("tiny_sd15", synth.TINY_SD15_UNET_CONFIG), ("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG)):
             net, _ = gen_unet(nm, cf)
             gen_unet_hooks(nm, cf, net)
+    if a.only in ("", "tiny", "module_hooks"):
+        for nm, cf in (("tiny_sd15", synth.TINY_SD15_UNET_CONFIG), ("tiny_sdxl", synth.TINY_SDXL_UNET_CONFIG)):
+            gen_unet_module_hooks(nm, cf, ref_import.build_ref_unet(cf, synth.synth_unet_state_dict(cf, seed=0)))
     if a.only == "unipc":
         net, _ = gen_unet("tiny_sd15", synth.TINY_SD15_UNET_CONFIG)
         gen_unipc("tiny_sd15", synth.TINY_SD15_UNET_CONFIG, net)

@@ -18,7 +18,8 @@ Differences from the reference that are design, not omissions:
 ControlNet residuals (`control={'input': [...], 'middle': [...], 'output': [...]}`, unet.py:44-52,714,732,739) are injected
 natively (fp32 NCHW residual -> fp16 NHWC activation, one transposing add kernel each); such forwards run eagerly, not from
 the captured graph, since the residuals change every step.  Hooks that need per-block Python callbacks on NCHW tensors
-(`patches`, `patches_replace`, `block_modifiers`) are called eagerly on [B, N, C] / NCHW views; module-typed hooks are rejected.
+(`patches`, `patches_replace`, `block_modifiers`) are called eagerly on [B, N, C] / NCHW views; the module-typed hooks
+(`block_inner_modifiers`, `group_norm_wrapper`) get stand-ins for the modules (below).
 """
 
 import os
@@ -31,6 +32,50 @@ from .layout import ConvIn, Down, Res, SpatialT, Up, unet_layout
 
 SUPPORTED_DPAD = (48, 64, 80, 160)
 CTX_PAD = 64  # text tokens are padded to a multiple of the attention key tile
+
+
+# ---- what the two module-typed hooks get to see (unet.py:73-91 `block_inner_modifiers`, :436-474 / :755-757 `group_norm_wrapper`) ----------------
+# The reference hands them torch.nn.Module objects.  The executor has no modules, so it hands over light stand-ins that carry the reference's
+# CLASS NAMES and the attributes extensions look at (type checks by isinstance against this module's classes or by type(layer).__name__, channel
+# counts, the GroupNorm's parameters), and -- for the GroupNorm -- are callable: norm(x) runs the native kernel.
+class _Layer:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class Conv2d(_Layer):
+    pass
+
+
+class ResBlock(_Layer):
+    pass
+
+
+class SpatialTransformer(_Layer):
+    pass
+
+
+class Upsample(_Layer):
+    pass
+
+
+class Downsample(_Layer):
+    pass
+
+
+class TimestepEmbedSequential(list):
+    """the block a layer belongs to, as `block_inner_modifiers` receive it: a sequence of the stand-ins above"""
+
+
+class GroupNorm(_Layer):
+    """stand-in for the ResBlock's / output head's GroupNorm32: num_groups, num_channels, eps, weight, bias; norm(x) -> group_norm(x)"""
+
+    def __call__(self, x):
+        xh = x.permute(0, 2, 3, 1).to(torch.float16).contiguous()
+        y = ops.groupnorm(xh, self.weight, self.bias, self.eps, silu=False, groups=self.num_groups)
+        return y.permute(0, 3, 1, 2).to(x.dtype)
+
+    forward = __call__
 
 
 _LN_FOLD = os.environ.get("FMX_LN_FOLD", "1") != "0"   # A/B knob: 0 keeps the LayerNorm kernels in front of attn2.to_q / ff.net.0
@@ -467,9 +512,36 @@ class IntegratedUNet2DConditionModel:
         arena.release(mk)
         return ops.attach_stats(out, st)
 
+    def _layer_standin(self, L):
+        if isinstance(L, Res):
+            return ResBlock(channels=L.cin, out_channels=L.cout, key=L.key)
+        if isinstance(L, SpatialT):
+            return SpatialTransformer(in_channels=L.ch, n_heads=L.heads, d_head=L.dim_head, depth=L.depth, key=L.key)
+        if isinstance(L, Down):
+            return Downsample(key=L.key)
+        if isinstance(L, Up):
+            return Upsample(key=L.key)
+        return Conv2d(key=L.key)
+
     def _run_block(self, blk, h, skip, emb_all, ctxc, arena, up_to=None, to=None):
-        for L in blk:
-            if isinstance(L, Res):
+        inner = to.get("block_inner_modifiers", []) if to is not None else []
+        wrapper = to.get("group_norm_wrapper") if to is not None else None
+        standins = TimestepEmbedSequential(self._layer_standin(L) for L in blk) if inner else None
+        for li, L in enumerate(blk):
+            if inner:
+                # unet.py:77-79.  The first layer of an output block sees the concatenated [h, skip] tensor, as the reference's does (:741)
+                if skip is not None:
+                    cat = torch.cat([h, skip], dim=-1)
+                    for m in inner:
+                        cat = self._call_nchw(m, cat, "before", standins[li], li, standins, to)
+                    h, skip = cat[..., :h.shape[-1]].contiguous(), cat[..., h.shape[-1]:].contiguous()
+                else:
+                    for m in inner:
+                        h = self._call_nchw(m, h, "before", standins[li], li, standins, to)
+            if isinstance(L, Res) and wrapper is not None:
+                h = self._res_wrapped(L, h, skip, emb_all, wrapper, to)
+                skip = None
+            elif isinstance(L, Res):
                 h = self._res(L, h, skip, emb_all, arena)
                 skip = None
             elif isinstance(L, SpatialT):
@@ -487,7 +559,31 @@ class IntegratedUNet2DConditionModel:
                 h = ops.attach_stats(h.view(bu, uh, uw, c), st)
             else:
                 raise TypeError(L)
+            for m in inner:
+                h = self._call_nchw(m, h, "after", standins[li], li, standins, to)   # unet.py:90-91
         return h
+
+    def _wrapped_norm(self, wrapper, key, x, eps, to):
+        """group_norm_wrapper(norm, x, transformer_options) -> h (unet.py:436-474): x as an NCHW view of the channels-last activation, the
+        GroupNorm as a callable stand-in; what comes back goes through SiLU (the rest of in_layers / out_layers) on the device."""
+        gamma, beta = self.w[key]
+        norm = GroupNorm(num_groups=32, num_channels=gamma.numel(), eps=eps, weight=gamma, bias=beta, affine=True)
+        r = wrapper(norm, x.permute(0, 3, 1, 2), to)
+        h = r.permute(0, 2, 3, 1).to(torch.float16).contiguous()
+        return ops.silu(h, out=h)
+
+    def _res_wrapped(self, L, x, skip, emb_all, wrapper, to):
+        """ResBlock with a group_norm_wrapper installed (eager, general path): both GroupNorms go through the wrapper."""
+        k = L.key
+        bu, hh, ww, _ = x.shape
+        xin = x if skip is None else torch.cat([x, skip], dim=-1)
+        g1 = self._wrapped_norm(wrapper, k + ".gn1", xin, 1e-5, to)
+        off, cout = self._emb_off[k]
+        h = ops.conv_gemm(g1, self.w[k + ".conv1"][0], cout, kh=3, pad=1, bias=self.w[k + ".conv1"][1], rowvec=emb_all[:, off:off + cout])
+        g2 = self._wrapped_norm(wrapper, k + ".gn2", h.view(bu, hh, ww, cout), 1e-5, to)
+        sk = ops.conv_gemm(xin, self.w[k + ".skip"][0], cout, bias=self.w[k + ".skip"][1]) if L.has_skip_conv else xin.reshape(-1, cout)
+        out = ops.conv_gemm(g2, self.w[k + ".conv2"][0], cout, kh=3, pad=1, bias=self.w[k + ".conv2"][1], residual=sk)
+        return out.view(bu, hh, ww, cout)
 
     # ------------------------------------------------------------------------------------------------------------
     @staticmethod
@@ -524,6 +620,7 @@ class IntegratedUNet2DConditionModel:
         lay = self.layout
         patches = to.get("patches", {}) if to is not None else {}
         modifiers = to.get("block_modifiers", []) if to is not None else []
+        inner = to.get("block_inner_modifiers", []) if to is not None else []
         if to is not None:
             to["original_shape"] = [bu, lay.in_channels, hh, ww]
             to["transformer_index"] = 0
@@ -544,12 +641,15 @@ class IntegratedUNet2DConditionModel:
             if to is not None:
                 to["block"] = ("input", bi)
             if bi == 0:
-                if modifiers:
+                if modifiers or inner:
                     # the 'before' hook of block 0 sees the network input: the centre tap of the im2col rows (already fp16); re-packed after
                     if self.concat_channels:
                         raise NotImplementedError("block modifiers on the input of an inpainting UNet")
                     ci = lay.in_channels
                     x_mod = modify(xcol.view(bu, hh, ww, -1)[..., 4 * ci:5 * ci].contiguous(), "before")
+                    conv_in = TimestepEmbedSequential([Conv2d(key=blk[0].key, in_channels=ci, out_channels=lay.model_channels)])
+                    for m in inner:
+                        x_mod = self._call_nchw(m, x_mod, "before", conv_in[0], 0, conv_in, to)
                     xcol = ops.unet_pack_input(x_mod.permute(0, 3, 1, 2).float().contiguous(), torch.zeros(bu, dtype=torch.float32, device=self.device),
                                                1, 1.0)
                 cw, cb = self.w[blk[0].key]
@@ -557,6 +657,8 @@ class IntegratedUNet2DConditionModel:
                     raise ValueError("an inpainting / edit UNet needs c_concat (and only such a UNet takes one)")
                 h, st = ops.linear(xcol, cw, cb, residual=concat_term, n=bu, h=hh, w=ww, stats=True)
                 h = ops.attach_stats(h.view(bu, hh, ww, lay.model_channels), st)
+                for m in inner:
+                    h = self._call_nchw(m, h, "after", conv_in[0], 0, conv_in, to)
             else:
                 h = modify(h, "before")
                 h = self._run_block(blk, h, None, emb_all, ctxc, arena, to=to)
@@ -595,7 +697,10 @@ class IntegratedUNet2DConditionModel:
         if to is not None:
             to["block"] = ("last", 0)
         h = modify(h, "before")
-        g = ops.groupnorm(h, *self.w["out.gn"], 1e-5, silu=True)
+        if to is not None and "group_norm_wrapper" in to:
+            g = self._wrapped_norm(to["group_norm_wrapper"], "out.gn", h, 1e-5, to)       # unet.py:755-758
+        else:
+            g = ops.groupnorm(h, *self.w["out.gn"], 1e-5, silu=True)
         oc = lay.out_channels
         out = ops.conv_gemm(g, self.w["out.conv"][0], oc, kh=3, pad=1, bias=self.w["out.conv"][1])
         if modifiers:
@@ -634,15 +739,13 @@ class IntegratedUNet2DConditionModel:
 
     @staticmethod
     def _hooks(transformer_options):
-        """-> the options dict if it carries Python hooks the executor has to call, else None (fast path).  Hooks whose contract is a
-        torch.nn.Module (block_inner_modifiers get `layer`, group_norm_wrapper gets the GroupNorm module) have no counterpart here."""
+        """-> the options dict if it carries Python hooks the executor has to call, else None (fast path).  The two hooks whose contract is a
+        torch.nn.Module (block_inner_modifiers get `layer` and the block, group_norm_wrapper gets the GroupNorm) receive the stand-ins
+        defined at the top of this file."""
         to = transformer_options
         if not to:
             return None
-        if to.get("block_inner_modifiers") or "group_norm_wrapper" in to:
-            raise NotImplementedError("block_inner_modifiers / group_norm_wrapper take torch.nn.Module arguments; the native executor has no "
-                                      "modules to hand them")
-        if to.get("patches") or to.get("patches_replace") or to.get("block_modifiers"):
+        if to.get("patches") or to.get("patches_replace") or to.get("block_modifiers") or to.get("block_inner_modifiers") or "group_norm_wrapper" in to:
             return to
         return None
 

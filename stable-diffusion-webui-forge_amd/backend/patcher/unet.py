@@ -114,6 +114,12 @@ class UnetPatcher:
     def add_block_modifier(self, modifier, ensure_uniqueness=False):
         self.append_transformer_option("block_modifiers", modifier, ensure_uniqueness)
 
+    def add_block_inner_modifier(self, modifier, ensure_uniqueness=False):
+        self.append_transformer_option("block_inner_modifiers", modifier, ensure_uniqueness)
+
+    def set_group_norm_wrapper(self, wrapper):
+        self.set_transformer_option("group_norm_wrapper", wrapper)
+
     def set_model_replace_all(self, patch, target="attn1"):
         for block_name in ["input", "middle", "output"]:
             for number in range(16):

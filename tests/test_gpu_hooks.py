@@ -45,6 +45,32 @@ def test_unet_forward_with_hooks_vs_reference(name, engines):
 
 
 @pytest.mark.parametrize("name", list(TINY))
+def test_module_typed_hooks_vs_reference(name, engines):
+    """`block_inner_modifiers` and `group_norm_wrapper` (unet.py:73-91, :436-474, :755-757) -- the hooks whose arguments are modules in the
+    reference.  The executor hands them stand-ins with the reference's class names and the GroupNorm's parameters (callable: norm(x) runs the
+    native kernel); the SAME hook functions ran inside the real reference for the fixture: equal call sequence (class name, layer index, block
+    length, block id; GroupNorm geometry), equal result; installed through the UnetPatcher API."""
+    from oracle.hooks_fixture import build_module_hooks
+    g, fx = load_golden(f"{name}_unet_module_hooks.pt"), load_golden(f"{name}_unet_fwd.pt")
+    to, log = build_module_hooks()
+    unet = engines[name].forge_objects.unet.clone()
+    unet.add_block_inner_modifier(to["block_inner_modifiers"][0])
+    unet.set_group_norm_wrapper(to["group_norm_wrapper"])
+    net = unet.model.diffusion_model
+    y = fx["y"].to(DEV) if fx["y"] is not None else None
+    eps = net.forward(fx["x"].to(DEV), fx["t"].to(DEV), context=fx["ctx"].to(DEV), y=y, transformer_options=unet.model_options["transformer_options"])
+    assert log == g["log"], [(a, b) for a, b in zip(log, g["log"]) if a != b][:5] + [len(log), len(g["log"])]
+    check(f"{name} unet forward with block_inner_modifiers + group_norm_wrapper ({len(log)} calls) vs reference", eps, g["eps"],
+          floor=f"{name}_unet_module_hooks.pt:eps")
+    assert max_rel(eps, fx["eps"]) > 0.03   # the hooks do change the result
+    from forge_amd.backend.nn import unet as native_unet
+    seen = []
+    net.forward(fx["x"].to(DEV), fx["t"].to(DEV), context=fx["ctx"].to(DEV), y=y,
+                transformer_options={"block_inner_modifiers": [lambda x, when, layer, li, block, to_: (seen.append(layer), x)[1]]})
+    assert any(isinstance(l, native_unet.SpatialTransformer) for l in seen) and any(isinstance(l, native_unet.ResBlock) for l in seen)
+
+
+@pytest.mark.parametrize("name", list(TINY))
 def test_sampling_with_hooks_installed_on_the_patcher(name, engines):
     """Hooks set through the UnetPatcher API (set_model_*), reaching the executor via sampling_function with the per-call keys
     (cond_or_uncond, sigmas, cond_mark, cond_indices, uncond_indices) the reference adds (sampling_function.py:253-257)."""

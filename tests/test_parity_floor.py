@@ -30,7 +30,8 @@ def expected_keys():
              "pipeline:txt2img_eulera4/latent", "pipeline:txt2img_eulera4/decoded", "pipeline:smoke_euler3/latent", "pipeline:smoke_euler3/decoded",
              "sd15_config0.pt:eps", "sd15_config0.pt:latent", "sd15_config0.pt:decoded", "sdxl_vae1024.pt:decoded"]
     # the rows next to the hot path (oracle/make_floor.py floors_aux): ControlNet residuals, adapters, text encoders, Flux in both compute types
-    keys += ["tiny_sd15_controlnet.pt:outs_worst", "tiny_sdxl_controlnet.pt:outs_worst", "mini_adapter_light.pt:features_worst"]
+    keys += ["tiny_sd15_controlnet.pt:outs_worst", "tiny_sdxl_controlnet.pt:outs_worst", "mini_adapter_light.pt:features_worst",
+             "tiny_sd15_unet_module_hooks.pt:eps", "tiny_sdxl_unet_module_hooks.pt:eps"]
     keys += [f"mini_sd15_t2i_adapter.pt:features/{v}_worst" for v in ("sd15_k1_pool", "sd15_k3_conv", "sdxl")]
     keys += [f"tiny_clip_{e}.pt:{k}" for e in "lg" for k in ("last_hidden_state", "hidden_penultimate", "penultimate_final_ln", "pooled")]
     keys += ["tiny_clip_g.pt:pooled_projected"] + [f"tiny_flux_fwd.pt:{k}@{t}" for k in ("out", "latent") for t in ("f16", "bf16")]
