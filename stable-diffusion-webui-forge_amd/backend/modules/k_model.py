@@ -116,11 +116,14 @@ class KModel:
                 g.launch(s)
             cur.wait_stream(s)
             self._graphs[key] = g
-            st["ctx_key"] = ctxc.key
+            st["ctx_key"] = (ctxc.key, ctxc.serial)
             st["arena_epoch"] = net.arena_epoch
             return st["eps"]
-        if st.get("ctx_key") != ctxc.key:
-            # new conditioning re-uses the same cached K/V buffers only if shapes match; simplest safe policy: recapture
+        if st.get("ctx_key") != (ctxc.key, ctxc.serial):
+            # the graph reads the cross-attention K / V^T buffers that existed when it was captured.  They are re-allocated whenever the
+            # conditioning changes (prepare_context), also when ANOTHER shape's job came in between and this job's conditioning tensor then
+            # re-used the address (hence the key) of the earlier one: the serial number tells, the key alone does not (that was a NaN:
+            # tools/soak.py, batch 8 -> batch 1 -> batch 8)
             g.destroy()
             del self._graphs[key]
             st["warm"] = 1

@@ -301,6 +301,9 @@ class IntegratedUNet2DConditionModel:
             h1 = ops.silu(h1, out=h1)
             c.label = ops.linear(h1, *self.w["le2"], out=torch.empty(bu, self.layout.time_embed_dim, dtype=torch.float16, device=self.device))
         c.key, c.bu, c.tokens, c.tpad = key, bu, t, tp
+        # the cached K / V^T / label tensors above are NEW allocations: a captured graph that still points at the previous ones must not be
+        # replayed even if `key` repeats (a later conditioning tensor can land on the address of an earlier, freed one) -- KModel compares this
+        c.serial = getattr(c, "serial", 0) + 1
         c.ctx = ctx[:, :t]  # fp16 [Bu, T, Dc]: the `context` a transformer hook sees
         self._ctx_keepalive = (context, y)
         return c

@@ -356,6 +356,32 @@ def test_unet_forward_ragged_token_counts_vs_oracle(name, hw, engines):
     check(f"{name} unet forward at latent {hw[0]}x{hw[1]} (ragged tokens) vs oracle", eps, unet_forward(sd, cfg, x, t, ctx, y), floor=f"{name}_unet_fwd.pt:eps")
 
 
+def test_graph_is_not_replayed_on_reallocated_text_caches():
+    """A captured UNet graph reads the cross-attention K / V^T caches that existed at capture time.  Job A (batch 2), job B (batch 1, other
+    conditioning: the caches are re-allocated, A's are freed), job A again with a NEW conditioning tensor of the same values that lands on the
+    freed address of the first one -- its cache key repeats.  The graph of A must be re-captured, not replayed on freed memory (this was a
+    NaN: tools/soak.py).  Same seeds => bit-identical latents."""
+    cfg = TINY["tiny_sd15"]
+    eng = build_engine(cfg, synth.synth_unet_state_dict(cfg, seed=0), None, None, device=DEV)
+    shared.opts.randn_source = "CPU"
+
+    def job(b, seed_c):
+        c, uc = synth.synth_conditioning(b, cfg["context_dim"], None, seed=seed_c)
+        c, uc = c.to(DEV), uc.to(DEV)     # fresh device tensors every time, the previous job's are garbage by then
+        p = processing.StableDiffusionProcessingTxt2Img(sd_model=eng, c=c, uc=uc, seed=77, sampler_name="Euler", batch_size=b, steps=4, cfg_scale=7.0,
+                                                        width=128, height=128, do_decode=False)
+        return processing.process_images(p).latents.clone()
+    first = job(2, 1234)
+    for _ in range(3):
+        other = job(1, 99)
+        # churn the caching allocator so that freed blocks get overwritten before they are handed out again
+        junk = [torch.full((1 << 16,), float("nan"), dtype=torch.float16, device=DEV) for _ in range(64)]
+        del junk
+        again = job(2, 1234)
+        assert bool(torch.isfinite(again).all()) and torch.equal(again, first)
+        assert bool(torch.isfinite(other).all())
+
+
 def test_graph_survives_arena_reallocation():
     """A captured UNet graph points into the executor's activation arena.  When a larger shape comes through later (hires second pass, a
     bigger batch) the arena is re-allocated; the old graph must be dropped and re-captured, not replayed on freed memory."""
