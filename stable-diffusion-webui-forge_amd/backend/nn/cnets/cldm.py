@@ -30,7 +30,7 @@ class ControlNet(IntegratedUNet2DConditionModel):
         if hint_channels * 9 > 64:
             raise NotImplementedError("hint_channels * 9 must be <= 64 (im2col'ed first conv)")
         super().__init__(config, state_dict, device=device, arena_bytes=arena_bytes)
-        self._hint_key, self._guided_hint = None, None
+        self._hint_key, self._guided_hint, self._hint_ref = None, None, None
 
     def _load_extra(self, sd, w):
         dev = self.device
@@ -64,8 +64,12 @@ class ControlNet(IntegratedUNet2DConditionModel):
     # ---- hint (once per hint image) -----------------------------------------------------------------------------------------------
     def guided_hint(self, hint):
         """hint [B, hint_channels, 8h, 8w] (any float dtype) -> fp16 NHWC [B, h, w, model_channels]; cached on tensor identity."""
-        key = (hint.data_ptr(), tuple(hint.shape), hint.dtype)
-        if self._hint_key == key:
+        try:
+            ver = hint._version
+        except RuntimeError:   # inference-mode tensors carry no version counter
+            ver = -1
+        key = (hint.data_ptr(), tuple(hint.shape), hint.dtype, ver)
+        if self._hint_key == key and self._hint_ref is hint:
             return self._guided_hint
         b, c, hh, ww = hint.shape
         x = hint.to(device=self.device, dtype=torch.float32).contiguous()
@@ -79,6 +83,7 @@ class ControlNet(IntegratedUNet2DConditionModel):
             oh, ow = (h2 + 2 - 3) // stride + 1, (w2 + 2 - 3) // stride + 1
             h = ops.conv_gemm(h, wp, cout, kh=3, stride=stride, pad=1, bias=bp).view(bb, oh, ow, cout)
         self._hint_key, self._guided_hint = key, h.clone()          # out of the arena: it lives across steps
+        self._hint_ref = hint   # keeps the image alive: a later hint cannot land on its address (and its key) while this entry is cached
         self._hint_keepalive = hint
         return self._guided_hint
 

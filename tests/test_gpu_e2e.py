@@ -382,6 +382,55 @@ def test_graph_is_not_replayed_on_reallocated_text_caches():
         assert bool(torch.isfinite(other).all())
 
 
+def test_interleaved_jobs_reproduce_their_first_run_bit_for_bit():
+    """Cache / graph / arena bookkeeping under churn: seven job configurations (batch 1-3, three resolutions incl. a ragged token count, CFG on and
+    off, Euler / Euler a / DPM++ 2M, one with a Python hook) run 5 times each in a seeded random order on ONE engine, fresh conditioning tensors
+    every time.  Each run must reproduce the first run of its configuration bit for bit (captured graphs are re-used, re-captured or evicted --
+    KModel.MAX_CACHED_SHAPES is lowered so that eviction happens -- but never replayed on stale buffers; all reductions are ordered)."""
+    import random
+    cfg = TINY["tiny_sd15"]
+    eng = build_engine(cfg, synth.synth_unet_state_dict(cfg, seed=0), None, None, device=DEV)
+    km = eng.forge_objects.unet.model
+    old_cap = type(km).MAX_CACHED_SHAPES
+    type(km).MAX_CACHED_SHAPES = 3
+    shared.opts.randn_source = "CPU"
+    configs = [dict(b=2, hw=(128, 128), sampler="Euler", cfg=7.0), dict(b=1, hw=(128, 128), sampler="Euler a", cfg=7.0),
+               dict(b=3, hw=(192, 128), sampler="DPM++ 2M", cfg=5.0), dict(b=2, hw=(128, 128), sampler="Euler", cfg=1.0),
+               dict(b=1, hw=(200, 136), sampler="Euler", cfg=7.0), dict(b=2, hw=(256, 256), sampler="Euler a", cfg=7.0),
+               dict(b=2, hw=(128, 128), sampler="Euler", cfg=7.0, hook=True)]
+
+    def run(c):
+        cond, uc = synth.synth_conditioning(c["b"], cfg["context_dim"], None, seed=300 + c["b"])
+        unet = eng.forge_objects.unet.clone()
+        if c.get("hook"):
+            unet.add_block_modifier(lambda h, when, to: h * 1.01 if (when == "after" and to["block"] == ("middle", 0)) else h)
+        saved = eng.forge_objects_after_applying_lora
+        eng.forge_objects_after_applying_lora = saved.shallow_copy()
+        eng.forge_objects_after_applying_lora.unet = unet
+        try:
+            p = processing.StableDiffusionProcessingTxt2Img(sd_model=eng, c=cond.to(DEV), uc=uc.to(DEV), seed=11, sampler_name=c["sampler"],
+                                                            batch_size=c["b"], steps=4, cfg_scale=c["cfg"], width=c["hw"][1], height=c["hw"][0],
+                                                            do_decode=False)
+            return processing.process_images(p).latents.clone()
+        finally:
+            eng.forge_objects_after_applying_lora = saved
+            eng.forge_objects = saved.shallow_copy()
+    try:
+        first = {}
+        order = [i for i in range(len(configs)) for _ in range(5)]
+        random.Random(7).shuffle(order)
+        for step, i in enumerate(order):
+            lat = run(configs[i])
+            assert bool(torch.isfinite(lat).all()), (step, configs[i])
+            if i in first:
+                assert torch.equal(lat, first[i]), f"job {step} (config {i}: {configs[i]}) differs from the first run of that configuration"
+            else:
+                first[i] = lat
+        assert not torch.equal(first[0], first[6]) and not torch.equal(first[0], first[3])   # the hook and the CFG switch do matter
+    finally:
+        type(km).MAX_CACHED_SHAPES = old_cap
+
+
 def test_graph_survives_arena_reallocation():
     """A captured UNet graph points into the executor's activation arena.  When a larger shape comes through later (hires second pass, a
     bigger batch) the arena is re-allocated; the old graph must be dropped and re-captured, not replayed on freed memory."""
