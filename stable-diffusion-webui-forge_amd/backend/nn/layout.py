@@ -7,7 +7,7 @@ expected state-dict keys and shapes (`unet_param_shapes`, `vae_decoder_param_sha
 """
 from collections import OrderedDict
 from dataclasses import dataclass, field
-from typing import List, Optional, Tuple
+from typing import List, Optional
 
 
 @dataclass(frozen=True)

@@ -1,7 +1,6 @@
 """Minimal `UnetPatcher` (reference: backend/patcher/unet.py, backend/patcher/base.py) -- the object protocol the call
 surface needs from `sd_model.forge_objects.unet`: `.model` (KModel), `.model_options`, clone(), and the
 ControlNet / concat / LoRA attributes, which are present but empty on the native path."""
-import copy
 
 
 class UnetPatcher:

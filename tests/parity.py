@@ -30,7 +30,6 @@ FMX_PARITY_REPORT_ONLY=1 prints without asserting (used once to collect the meas
 import json
 import os
 
-import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 NORTH_STAR = 1e-3

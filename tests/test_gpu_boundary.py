@@ -1,7 +1,6 @@
 """GPU parity of the attention-level and op-level drop-in boundaries: `forge_amd.backend.attention.attention_function`
 / `attention_function_single_head_spatial` with the reference's argument shapes (backend/attention.py:324-339, :37-93, :412-422) and the
 `ForgeOperations` modules (backend/operations.py:125-330) under `using_forge_operations`, against torch fp32 on the same inputs."""
-import math
 
 import pytest
 import torch

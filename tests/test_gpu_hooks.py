@@ -2,7 +2,6 @@
 called by the native executor, against the REAL reference UNet running the same hook functions (oracle/hooks_fixture.py) on CPU fp32
 (tests/golden/*_unet_hooks.pt): same call sequence (hook name, block, block_index, transformer_index), same result."""
 import pytest
-import torch
 
 pytestmark = pytest.mark.gpu
 

@@ -1,7 +1,6 @@
 """Micro-benchmarks of the individual HIP kernels at the SDXL / SD1.5 problem shapes.
 Prints one JSON line per case: achieved TFLOP/s or GB/s (algorithmic work / HIP-event time)."""
 import json
-import math
 import sys
 import os
 
