@@ -12,8 +12,9 @@
 //   * then O^T[slice] += V^T[slice] P^T: 8 MFMAs per wave on its 128 x 32 output slice (64 accumulator registers).
 // K / V^T tiles (32 keys: 32 KB + 32 KB) arrive by LDS-DMA, double buffered, 16-byte chunks XOR-swizzled on the source side and on the
 // ds_read_b128 side; LDS: 2 x 64 KB stages + 32 KB exchange = 160 KB, one workgroup per CU.
-// Rates: 16 MFMAs per wave and 64 KB of K / V per step -> the kernel is bound by the L2 -> LDS stream (64 queries amortise a tile), not
-// by the matrix pipe; what it buys is 1.5 GB of HBM traffic per 1024^2 image and the per-image host loop, see DESIGN.md section 4.2.
+// Rates: 16 MFMAs per wave against 16 fragment reads and a 20 KB partial-score exchange per step -> LDS-bound (PMC: matrix pipes 16-22 % busy,
+// 30 % of wave time waiting on LDS), not matrix-pipe-bound; 538 TFLOP/s after the bank-conflict fix below (407 before), against 397 for the
+// materialised path it replaces -- and no 512 MB score buffer or per-image host loop, see DESIGN.md section 4.2.
 #include "fmx_common.hpp"
 
 #ifndef FMX_ELEM_BF16  // fp16 (VAE) build only
@@ -41,6 +42,15 @@ template <int V>
 struct IC { static constexpr int value = V; };
 
 __device__ __forceinline__ int key_perm(int i) { return (i & 3) | (((i >> 3) & 3) << 2) | (((i >> 2) & 1) << 4); }
+// LDS swizzles.  A ds_read_b128 is served 8 lanes per cycle (8 x 16 B = the 32 banks); rows of the K tile are 1024 B apart and rows of the V^T
+// tile 64 B, so without a swizzle 8 consecutive lanes (= 8 rows) land on 1 or 2 sixteen-byte bank groups.  The XOR keys below give 8
+// consecutive lanes 8 distinct groups: for K the row a lane reads is key_perm(lane), whose bits 0, 1 and 4 are the lane's low three bits; for
+// V^T the rows are consecutive, two per 128 B, so bits 1-2 of the row spread the four rows that share a half.  (The first version keyed on
+// other bits: SQ_LDS_BANK_CONFLICT was 64 % of SQ_LDS_IDX_ACTIVE, profiles/r05z_pmc_attention512.json.)
+// (A variant that also gives the 8 even / odd lanes of a 16-lane pass distinct groups measured the same: 8.16 vs 8.18 ms, the same residual
+// SQ_LDS_BANK_CONFLICT count.)
+__device__ __forceinline__ int k_swz(int row) { return (row & 3) | (((row >> 4) & 1) << 2); }   // row = key_perm(lane)
+__device__ __forceinline__ int v_swz(int row) { return (row >> 1) & 3; }
 
 __global__ __launch_bounds__(512, 2) void attn512_kernel(const Attn512Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -69,15 +79,15 @@ __global__ __launch_bounds__(512, 2) void attn512_kernel(const Attn512Params p) 
     for (int e = 0; e < 8; ++e) qfr[s][e] = (f16)((float)raw[e] * p.scale_log2e);
   }
 
-  // ---- staging: 64 one-KiB pieces per stage, 8 per wave.  K piece r = key row r (64 chunks of 16 B, chunk ^= row & 15);
-  //      V^T piece r = channel rows 16 r .. 16 r + 15 (4 chunks of 16 B each, chunk ^= (row >> 2) & 3) --------------------------------------
+  // ---- staging: 64 one-KiB pieces per stage, 8 per wave.  K piece r = key row r (64 chunks of 16 B);
+  //      V^T piece r = channel rows 16 r .. 16 r + 15 (4 chunks of 16 B each); chunk positions XOR-ed with k_swz / v_swz of the row ---------
   unsigned k_voff[4], v_voff[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int row = e * 8 + wave;                                   // key row of this wave's e-th K piece
-    k_voff[e] = (unsigned)row * (unsigned)p.k_rs * 2u + (unsigned)(lane ^ (row & 15)) * 16u;
+    k_voff[e] = (unsigned)row * (unsigned)p.k_rs * 2u + (unsigned)(lane ^ k_swz(row)) * 16u;
     const int vrow = (e * 8 + wave) * 16 + (lane >> 2);             // channel row of this lane in the wave's e-th V^T piece
-    v_voff[e] = (unsigned)vrow * (unsigned)p.vt_ds * 2u + (unsigned)((lane & 3) ^ ((vrow >> 2) & 3)) * 16u;
+    v_voff[e] = (unsigned)vrow * (unsigned)p.vt_ds * 2u + (unsigned)((lane & 3) ^ v_swz(vrow)) * 16u;
   }
   const unsigned k_step = (unsigned)KV * (unsigned)p.k_rs * 2u;
   auto stage = [&](auto SI, int kt) {
@@ -105,8 +115,9 @@ __global__ __launch_bounds__(512, 2) void attn512_kernel(const Attn512Params p) 
   __syncthreads();
 
   const int krow = key_perm(li);
-  float* xw = reinterpret_cast<float*>(smem + XCH) + wave * 1024 + lane * 16;                     // this wave's record, this lane's 16 floats
-  const float* xr = reinterpret_cast<const float*>(smem + XCH) + (qf * 4) * 1024 + lane * 16;      // records of the fragment's 4 slices
+  // exchange records: 4 KB per wave, laid out [quarter v][lane] (16 B each): consecutive lanes write / read consecutive 16-byte groups
+  float* xw = reinterpret_cast<float*>(smem + XCH) + wave * 1024 + lane * 4;
+  const float* xr = reinterpret_cast<const float*>(smem + XCH) + (qf * 4) * 1024 + lane * 4;
   auto step = [&](auto SI, int kt) {
     constexpr int S = decltype(SI)::value;
     if (kt + 1 < nsteps) stage(IC<S ^ 1>{}, kt + 1);
@@ -119,11 +130,11 @@ __global__ __launch_bounds__(512, 2) void attn512_kernel(const Attn512Params p) 
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       const int chunk = ds * 16 + s * 2 + hi;
-      const f16x8 kf = *reinterpret_cast<const f16x8*>(sk + krow * 1024 + ((chunk ^ (krow & 15)) << 4));
+      const f16x8 kf = *reinterpret_cast<const f16x8*>(sk + krow * 1024 + ((chunk ^ k_swz(krow)) << 4));
       part = FMX_MFMA_32x32x16(kf, qfr[s], part);
     }
 #pragma unroll
-    for (int v = 0; v < 4; ++v) *reinterpret_cast<f32x4*>(xw + v * 4) = f32x4{part[v * 4], part[v * 4 + 1], part[v * 4 + 2], part[v * 4 + 3]};
+    for (int v = 0; v < 4; ++v) *reinterpret_cast<f32x4*>(xw + v * 256) = f32x4{part[v * 4], part[v * 4 + 1], part[v * 4 + 2], part[v * 4 + 3]};
     // raw barrier: the next stage's LDS-DMA stays in flight across it (a __syncthreads() would drain it: vmcnt(0)); only the exchange
     // records have to be visible
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -132,9 +143,9 @@ __global__ __launch_bounds__(512, 2) void attn512_kernel(const Attn512Params p) 
     f32x16 sc;
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      f32x4 a = *reinterpret_cast<const f32x4*>(xr + v * 4);
+      f32x4 a = *reinterpret_cast<const f32x4*>(xr + v * 256);
 #pragma unroll
-      for (int w2 = 1; w2 < 4; ++w2) a += *reinterpret_cast<const f32x4*>(xr + w2 * 1024 + v * 4);
+      for (int w2 = 1; w2 < 4; ++w2) a += *reinterpret_cast<const f32x4*>(xr + w2 * 1024 + v * 256);
 #pragma unroll
       for (int e = 0; e < 4; ++e) sc[v * 4 + e] = a[e];
     }
@@ -173,7 +184,7 @@ __global__ __launch_bounds__(512, 2) void attn512_kernel(const Attn512Params p) 
     for (int dt = 0; dt < 4; ++dt) {
       const int row = ds * 128 + dt * 32 + li;
       const char* rp = sv + row * 64;
-      const int swz = (row >> 2) & 3;
+      const int swz = v_swz(row);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const f16x8 vf = *reinterpret_cast<const f16x8*>(rp + (((hi * 2 + j) ^ swz) << 4));
