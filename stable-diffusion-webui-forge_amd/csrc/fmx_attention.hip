@@ -435,12 +435,20 @@ __global__ __launch_bounds__(256, 2) void attn_q64_kernel(const AttnParams p) {
 //     beyond the last full round of S slots (2 per CU) are fewer than the CUs, the launcher turns them into twice as many workgroups of 128
 //     queries whose wave PAIRS each walk one half of the keys (own LDS stages per pair) and merge (m, l, O) through LDS at the end: half the
 //     duration each, on CUs that would otherwise idle.  Small launches (batch 1) are all key-split.
-template <int THR>
-__global__ __launch_bounds__(256, 2) void attn_q64v2_kernel(const AttnParams p) {
+//   * DP = 128 (Flux: 24 heads of 128): the same kernel with 8 k-steps per score chain and four 32-channel output blocks.  64 queries per
+//     wave then need ~350 registers (128 accumulator + 64 Q-fragment + 64 score ...), so it runs ONE wave per SIMD on the unified 512-entry
+//     file (__launch_bounds__(256, 1)): nothing overlaps across waves, but a K / V^T fragment read still feeds two MFMAs, where the
+//     32-query generic kernel it replaces is LDS-read-bound (1 read per MFMA; 531 TFLOP/s in the Flux forward).
+template <int THR, int DP>
+__global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void attn_q64v2_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int DP = 64, DSTEPS = 4, DVT = 2;
+  constexpr int DSTEPS = DP / 16, DVT = DP / 32;
+  constexpr int CPR = DP / 8;                // 16-byte chunks per K row
   constexpr int KBYTES = KVB * DP * 2;
   constexpr int STAGE = KBYTES + DVT * 32 * 128;
+  constexpr int KROWS = 1024 / (DP * 2);     // K rows per 1-KiB LDS-DMA piece: 8 (DP 64) / 4 (DP 128)
+  constexpr int NPK = KVB / KROWS / 4;       // K pieces per wave and tile when four waves share it: 2 / 4
+  constexpr int NPV = DP / 8 / 4;            // V^T pieces (8 rows of 128 B) per wave: 2 / 4
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -474,32 +482,38 @@ __global__ __launch_bounds__(256, 2) void attn_q64v2_kernel(const AttnParams p) 
   // staging: K tile 64 rows x 8 chunks and V^T tile 64 rows x 8 chunks = 2 x 8 KiB, 2 + 2 DMA instructions per wave and tile (4 + 4 in a
   // key-split workgroup, where two waves share a tile); per-lane byte offsets are tile-invariant, the tile's key offset rides in the
   // scalar offset operand
-  const int srow = lane >> 3, spc = lane & 7;
   char* const sbase = smem + pair * (2 * STAGE);   // a wave pair of a key-split workgroup has its own two stages
-  unsigned k_voff[4], v_voff[4];
+  // piece e of this wave: K rows (e * sways + swave) * KROWS + lane / CPR, chunk lane % CPR; V^T rows (e * sways + swave) * 8 + lane / 8
+  constexpr int MAXP = 2 * (NPK > NPV ? NPK : NPV);   // (twice as many in a key-split workgroup, where two waves share a tile)
+  unsigned k_voff[2 * NPK], v_voff[2 * NPV];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int row = ((e * sways + swave) * 8 + srow) & 63;
-    const int c = spc ^ ((row >> 1) & 7);
-    k_voff[e] = (unsigned)row * (unsigned)p.k_rs * 2u + (unsigned)c * 16u;
-    v_voff[e] = (unsigned)row * (unsigned)p.vt_ds * 2u + (unsigned)c * 16u;
+  for (int e = 0; e < 2 * NPK; ++e) {
+    const int row = ((e * sways + swave) * KROWS + lane / CPR) & (KVB - 1);
+    k_voff[e] = (unsigned)row * (unsigned)p.k_rs * 2u + (unsigned)k_logical_chunk<CPR>(row, lane % CPR) * 16u;
   }
+#pragma unroll
+  for (int e = 0; e < 2 * NPV; ++e) {
+    const int row = ((e * sways + swave) * 8 + (lane >> 3)) & (DP - 1);
+    v_voff[e] = (unsigned)row * (unsigned)p.vt_ds * 2u + (unsigned)((lane & 7) ^ ((row >> 1) & 7)) * 16u;
+  }
+  (void)MAXP;
   const unsigned k_tile = (unsigned)KVB * (unsigned)p.k_rs * 2u;
   auto stage = [&](auto SI, int kt) {
     constexpr int S = decltype(SI)::value;
-    auto piece = [&](int e) {
-      auto* dk = (__attribute__((address_space(3))) void*)(sbase + S * STAGE + (e * sways + swave) * 1024);
-      auto* dv = (__attribute__((address_space(3))) void*)(sbase + S * STAGE + KBYTES + (e * sways + swave) * 1024);
-      const unsigned kv = k_voff[e], vv = v_voff[e];
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, dk, 16, kv, (unsigned)kt * k_tile, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, dv, 16, vv, (unsigned)kt * (KVB * 2u), 0, 0);
-    };
-    piece(0);
-    piece(1);
-    if (split) {
-      piece(2);
-      piece(3);
-    }
+#pragma unroll
+    for (int e = 0; e < 2 * NPK; ++e)
+      if (e < NPK || split) {
+        auto* dk = (__attribute__((address_space(3))) void*)(sbase + S * STAGE + (e * sways + swave) * 1024);
+        const unsigned kv = k_voff[e];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, dk, 16, kv, (unsigned)kt * k_tile, 0, 0);
+      }
+#pragma unroll
+    for (int e = 0; e < 2 * NPV; ++e)
+      if (e < NPV || split) {
+        auto* dv = (__attribute__((address_space(3))) void*)(sbase + S * STAGE + KBYTES + (e * sways + swave) * 1024);
+        const unsigned vv = v_voff[e];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, dv, 16, vv, (unsigned)kt * (KVB * 2u), 0, 0);
+      }
   };
 
   f32x16 oacc[DVT][2];
@@ -560,7 +574,7 @@ __global__ __launch_bounds__(256, 2) void attn_q64v2_kernel(const AttnParams p) 
 #pragma unroll
       for (int ds = 0; ds < DSTEPS; ++ds) {
         const int row = s * 32 + krow;
-        kf[s][ds] = *reinterpret_cast<const f16x8*>(sk + row * 128 + (k_phys_chunk<8>(row, ds * 2 + hi) << 4));
+        kf[s][ds] = *reinterpret_cast<const f16x8*>(sk + row * (DP * 2) + (k_phys_chunk<CPR>(row, ds * 2 + hi) << 4));
       }
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
@@ -576,14 +590,14 @@ __global__ __launch_bounds__(256, 2) void attn_q64v2_kernel(const AttnParams p) 
       for (int ds = 0; ds < DSTEPS; ++ds)
 #pragma unroll
         for (int a = 0; a < 2; ++a) sacc[s][a] = FMX_MFMA_32x32x16(kf[s][ds], qf[a][ds], sacc[s][a]);
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // DS read x4
-    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // MFMA x2 (- maximum)
+    __builtin_amdgcn_sched_group_barrier(0x100, DSTEPS, 0);   // DS read x DSTEPS
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);        // MFMA x2 (- maximum)
 #pragma unroll
     for (int ds = 0; ds < DSTEPS; ++ds) {
       __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 2 * DSTEPS, 0);
     __builtin_amdgcn_sched_barrier(0);
     if ((kt + 1) * KVB > p.nk) {  // ragged tail: mask keys >= nk (wave-uniform branch)
 #pragma unroll
@@ -665,7 +679,7 @@ __global__ __launch_bounds__(256, 2) void attn_q64v2_kernel(const AttnParams p) 
           for (int a = 0; a < 2; ++a) oacc[dt][a] = FMX_MFMA_32x32x16(vf[dt][s][j], pf[a][s][j], oacc[dt][a]);
     __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) {
+    for (int q4 = 0; q4 < DVT * 4 - 4; ++q4) {
       __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
@@ -682,7 +696,8 @@ __global__ __launch_bounds__(256, 2) void attn_q64v2_kernel(const AttnParams p) 
   // ---- key-split workgroups: the pair that walked the upper half of the keys hands (O, m, l) to its partner through LDS (the stages are
   //      idle: the last tile ended with a barrier); same code, so lane i holds the same (query, channel) elements in both waves ----------
   if (split) {
-    float* ex = reinterpret_cast<float*>(smem) + (wave & 1) * (68 * 64) + lane;
+    constexpr int NEX = DVT * 32 + 4;   // floats per lane: O, m, l
+    float* ex = reinterpret_cast<float*>(smem) + (wave & 1) * (NEX * 64) + lane;
     if (pair == 1) {
 #pragma unroll
       for (int dt = 0; dt < DVT; ++dt)
@@ -692,15 +707,15 @@ __global__ __launch_bounds__(256, 2) void attn_q64v2_kernel(const AttnParams p) 
           for (int r = 0; r < 16; ++r) ex[((dt * 2 + a) * 16 + r) * 64] = oacc[dt][a][r];
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
-        ex[(64 + a) * 64] = m_run[a];
-        ex[(66 + a) * 64] = l_run[a];
+        ex[(DVT * 32 + a) * 64] = m_run[a];
+        ex[(DVT * 32 + 2 + a) * 64] = l_run[a];
       }
     }
     __syncthreads();
     if (pair == 1) return;
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
-      const float m1 = ex[(64 + a) * 64], l1 = ex[(66 + a) * 64];
+      const float m1 = ex[(DVT * 32 + a) * 64], l1 = ex[(DVT * 32 + 2 + a) * 64];
       const float m = fmaxf(m_run[a], m1);
       const float f0 = __builtin_amdgcn_exp2f(m_run[a] - m), f1 = __builtin_amdgcn_exp2f(m1 - m);
       l_run[a] = l_run[a] * f0 + l1 * f1;
@@ -741,26 +756,28 @@ __global__ __launch_bounds__(256, 2) void attn_q64v2_kernel(const AttnParams p) 
   }
 }
 
-int launch_attn_q64(AttnParams p, hipStream_t st) {
-  const int smem = 2 * (KVB * 64 * 2 + 2 * 32 * 128);
+template <int DP>
+int launch_attn_v2(AttnParams p, hipStream_t st) {
+  constexpr int DVT = DP / 32;
+  const int smem = 2 * (KVB * DP * 2 + DVT * 32 * 128);
   static int variant = -1, slots = 512, allow_split = 1;
   if (variant < 0) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
-      slots = 2 * cus;   // two 4-wave workgroups per CU at this kernel's register count
+      slots = (DP == 64 ? 2 : 1) * cus;   // 4-wave workgroups per CU at this kernel's register count
     const char* sp = getenv("FMX_ATTN_SPLIT");   // A/B knob: 0 disables the key-split workgroups
     allow_split = sp ? atoi(sp) : 1;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_q64v2_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * smem);
-    // A/B knob (tools/bench_kernels.py attn): FMX_ATTN_VARIANT=1 selects the first-generation kernel (round 1: 823 / 729 TFLOP/s at
-    // N = 4096 / 1024), 0 (default) the second-generation one.
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_q64v2_kernel<6, DP>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * smem);
+    // A/B knob (tools/bench_kernels.py attn): FMX_ATTN_VARIANT=1 selects the first-generation kernels (d_head 64: round 1's 823 / 729 TFLOP/s at
+    // N = 4096 / 1024; d_head 128: the generic 32-query kernel), 0 (default) the second-generation one.
     const char* e = getenv("FMX_ATTN_VARIANT");
     variant = e ? atoi(e) : 0;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_q64_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (DP == 64) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_q64_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   }
   p.qtiles = (p.nq + 255) / 256;
   const int grid = p.qtiles * p.heads * p.batch;
-  // 32-bit byte offsets from the (batch, head) bases: K rows 0 .. nk_pad-1, V^T rows 0 .. 63 with nk_pad keys each
-  const double k_span = ((double)(p.nk_pad - 1) * p.k_rs + 64) * 2.0, v_span = (63.0 * p.vt_ds + p.nk_pad) * 2.0;
+  // 32-bit byte offsets from the (batch, head) bases: K rows 0 .. nk_pad-1, V^T rows 0 .. DP-1 with nk_pad keys each
+  const double k_span = ((double)(p.nk_pad - 1) * p.k_rs + DP) * 2.0, v_span = ((DP - 1.0) * p.vt_ds + p.nk_pad) * 2.0;
   if (variant == 0 && k_span < 2.0e9 && v_span < 2.0e9 && p.k_rs > 0 && p.vt_ds > 0) {
     p.k_span = (unsigned)k_span;
     p.vt_span = (unsigned)v_span;
@@ -773,11 +790,13 @@ int launch_attn_q64(AttnParams p, hipStream_t st) {
     const bool do_split = allow_split && rem > 0 && 8 * rem <= 3 * slots && ntiles >= 4 && (ntiles & 1) == 0;
     p.nfull = do_split ? grid - rem : grid;
     p.nsplit = do_split ? 2 * rem : 0;
-    hipLaunchKernelGGL(attn_q64v2_kernel<6>, dim3(p.nfull + p.nsplit), dim3(256), do_split ? 2 * smem : smem, st, p);
-  } else {
+    hipLaunchKernelGGL((attn_q64v2_kernel<6, DP>), dim3(p.nfull + p.nsplit), dim3(256), do_split ? 2 * smem : smem, st, p);
+  } else if (DP == 64) {
     hipLaunchKernelGGL(attn_q64_kernel<0>, dim3(grid), dim3(256), smem, st, p);
+  } else {
+    return -1;   // caller falls back to the generic kernel
   }
-  FMX_LAUNCH_CHECK("fmx_attention_f16 (q64)");
+  FMX_LAUNCH_CHECK("fmx_attention_f16 (64 queries per wave)");
   return FMX_OK;
 }
 
@@ -850,10 +869,15 @@ extern "C" int fmx_attention_f16(const fmx_attn_args* a, void* stream) {
     case 64:
       // 64-query-per-wave variant when there are enough queries to fill 256-query workgroups (test hook: scale < 0 forces
       // the 32-query kernel)
-      if (a->nq >= 256 && !force32 && !p.causal && !p.mask) return launch_attn_q64(p, st);
+      if (a->nq >= 256 && !force32 && !p.causal && !p.mask) return launch_attn_v2<64>(p, st);
       return launch_attn<64>(p, st);
     case 80: return launch_attn<80>(p, st);
-    case 128: return launch_attn<128>(p, st);
+    case 128:
+      if (a->nq >= 256 && !force32 && !p.causal && !p.mask) {
+        const int rc = launch_attn_v2<128>(p, st);
+        if (rc >= 0) return rc;
+      }
+      return launch_attn<128>(p, st);
     case 160: return launch_attn<160>(p, st);
     default: return fmx_set_error(FMX_E_UNSUPPORTED, "attention: dpad %d not in {48,64,80,128,160}", a->dpad);
   }

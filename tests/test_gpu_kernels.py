@@ -476,6 +476,22 @@ def test_attention_d64_partial_round_key_split(b, h, nq, nk):
     close(_attn_d64(q, k, v, nk=nk), ref, 2e-3, 2e-3, f"attention d64 b{b} h{h} nq{nq} nk{nk}")
 
 
+@pytest.mark.parametrize("b,h,nq,nk", [(1, 3, 1024, 1024), (2, 2, 4352, 4352), (1, 2, 300, 1000), (2, 3, 512, 77)])
+def test_attention_d128_64_queries_per_wave(b, h, nq, nk):
+    """d_head 128 (Flux) on the 64-query-per-wave kernel (one wave per SIMD, accumulators in the unified register file) against the fp32
+    reference and against the generic 32-query kernel (test hook): ragged query / key counts, a short context, a dominant late key."""
+    d = 128
+    nkp = -(-nk // 64) * 64
+    q, k, v = rnd(b, nq, h, d, seed=67), torch.zeros(b, nkp, h, d, dtype=torch.float16, device=DEV), torch.zeros(b, nkp, h, d, dtype=torch.float16, device=DEV)
+    k[:, :nk], v[:, :nk] = rnd(b, nk, h, d, scale=1.2, seed=68), rnd(b, nk, h, d, seed=69)
+    k[:, nk:], v[:, nk:] = 5.0, -3.0
+    k[0, nk - 2, 0] = q[0, nq - 1, 0] * 3
+    ref = _attn_ref(q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3)[:, :, :nk], v.permute(0, 2, 1, 3)[:, :, :nk], d ** -0.5)
+    got = _attn_d64(q, k, v, nk=nk)
+    close(got, ref, 2e-3, 2e-3, f"attention d128 b{b} h{h} nq{nq} nk{nk}")
+    close(got, _attn_d64(q, k, v, nk=nk, force32=True).float(), 2e-3, 1e-3, "64-query vs 32-query kernel, d128")
+
+
 def test_softmax_rows():
     x = rnd(300, 1000, scale=3, seed=60)
     ref = x.float().softmax(-1)

@@ -254,6 +254,7 @@ if __name__ == "__main__":
             bench_attn(8, 10, 4096, 4096, 64, 64, f32)   # batch 4 under CFG: 1280 tiles = 2.5 rounds
             bench_attn(8, 20, 1024, 1024, 64, 64, f32)   # 640 tiles = 1.25 rounds
             bench_attn(2, 20, 1024, 1024, 64, 64, f32)   # batch 1 under CFG: 160 tiles
+            bench_attn(2, 24, 4352, 4352, 128, 128, f32)  # Flux-dev at 1024^2: 4096 image + 256 text tokens, 24 heads of 128
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "smallm":
         # batch-1 shapes (UNet batch 2): which tile is fastest, and what does the dispatcher (tile 0) pick?
