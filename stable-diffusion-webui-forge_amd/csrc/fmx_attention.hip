@@ -37,6 +37,7 @@ struct AttnParams {
   long mask_bs, mask_hs, mask_qs;
   float inv_scale;            // 1 / scale: the mask is added to the UNSCALED score
   int nfull, nsplit;          // q64v2: workgroups [0, nfull) own 256 queries x all keys; [nfull, nfull + nsplit) are key-split (see the kernel)
+  int bid0;            // first workgroup index of this launch (0 except for a key-split tail launched on its own)
 };
 
 constexpr int KVB = 64;  // keys per tile
@@ -454,7 +455,7 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void attn_q64v2_kernel(const
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, li = lane & 31;
 
-  const int bid = blockIdx.x;
+  const int bid = blockIdx.x + p.bid0;   // bid0 > 0: only the key-split tail of a launch whose full rounds another kernel ran
   const bool split = bid >= p.nfull;   // workgroup-uniform
   int wg, q_in_tile;
   if (!split) {
@@ -756,6 +757,359 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void attn_q64v2_kernel(const
   }
 }
 
+// ---- wave-specialised form ("ws"): score / softmax waves and P V waves -------------------------------------------------------------------
+// A workgroup of 8 waves covers 256 queries; waves 0-3 ("S", 64 queries each) compute scores and the online softmax of key tile t and leave
+// P (fp16, as the MFMA operand fragments they already are: [fragment][lane], 8 KB) plus the rescale factor of a moved maximum in LDS; waves
+// 4-7 ("O", the same 64 queries) pick tile t up one interval later and accumulate O^T += V^T P^T.  A SIMD hosts one S and one O wave, and
+// neither carries the other's registers (S: Q fragments + scores; O: the output accumulators) -- which is what lets d_head 128 run two waves
+// per SIMD at 64 queries per wave at all (the symmetric kernel above needs ~350 registers per wave there: one wave per SIMD, nothing overlaps).
+// One barrier per key tile.  Intervals I_t = (B_{t-1}, B_t):
+//     I_t:  S waves: request K_{t+1}; scores + softmax of tile t -> P slot t & 1          O waves: request V_{t+1}; P V of tile t-1
+// K tiles live in a 2-slot ring, V^T tiles (read one interval later) in a 3-slot ring, P in 2 slots per query group.
+// Measured (Flux shape, 2 x 24 heads x 4352 tokens; profiles/r07_attention_ws_trace.md): 585 -> 497 us (795 -> 936 TFLOP/s).  The S wave is
+// the critical path: per tile ~1150 cycles for sub-tile 0's 18 MFMAs (two accumulator chains: one MFMA per 64 cycles, the O wave's MFMAs
+// take the slots between), ~1350 for sub-tile 1's MFMAs under sub-tile 0's exponentials, ~730 for sub-tile 1's exponentials (v_exp_f32 is
+// quarter rate: 16 cycles per wave instruction) and ~500 around the barrier; the O wave needs ~2300 of the ~3730.  Wave priorities, a third
+// accumulator chain in the first phase and delaying the O wave were measured and change nothing / lose.
+template <int THR, int DP>
+__global__ __launch_bounds__(512, 2) void attn_ws_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int DSTEPS = DP / 16, DVT = DP / 32, CPR = DP / 8;
+  constexpr int KBYTES = KVB * DP * 2, VBYTES = DVT * 32 * 128;
+  constexpr int KROWS = 1024 / (DP * 2);            // K rows per 1-KiB piece
+  constexpr int NPK = KVB / KROWS / 4, NPV = DP / 8 / 4;   // pieces per staging wave and tile
+  constexpr int PSLOT = 8 * 1024 + 1280;            // 8 operand fragments x 64 lanes x 16 B, then alpha[2][2][64] floats, flag[2], (pad)
+  constexpr int OFF_V = 2 * KBYTES, OFF_P = OFF_V + 3 * VBYTES, OFF_L = OFF_P + 2 * 4 * PSLOT;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool is_s = wave < 4;
+  const int grp = wave & 3;
+  const int hi = lane >> 5, li = lane & 31;
+  const int wg = xcd_remap(blockIdx.x, p.nfull);
+  const int qt = wg % p.qtiles, bh = wg / p.qtiles;
+  const int h = bh % p.heads, b = bh / p.heads;
+  const int q0 = qt * 256 + grp * 64;
+  const int ntiles = (p.nk + KVB - 1) / KVB;
+  char* const pbase = smem + OFF_P + grp * PSLOT;    // slot s of this group at pbase + s * 4 * PSLOT
+  float* const lbase = reinterpret_cast<float*>(smem + OFF_L) + grp * 128;
+
+  if (is_s) {
+    // =================================================== S waves ===================================================
+    const f16* kbase = p.k + (long)b * p.k_bs + (long)h * DP;
+    const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(kbase), 0, p.k_span, 0x00020000);
+    unsigned k_voff[NPK];
+#pragma unroll
+    for (int e = 0; e < NPK; ++e) {
+      const int row = (e * 4 + grp) * KROWS + lane / CPR;
+      k_voff[e] = (unsigned)row * (unsigned)p.k_rs * 2u + (unsigned)k_logical_chunk<CPR>(row, lane % CPR) * 16u;
+    }
+    const unsigned k_tile = (unsigned)KVB * (unsigned)p.k_rs * 2u;
+    auto stage_k = [&](int slot, int kt) __attribute__((always_inline)) {
+#pragma unroll
+      for (int e = 0; e < NPK; ++e) {
+        auto* dk = (__attribute__((address_space(3))) void*)(smem + slot * KBYTES + (e * 4 + grp) * 1024);
+        const unsigned kv = k_voff[e];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, dk, 16, kv, (unsigned)kt * k_tile, 0, 0);
+      }
+    };
+    stage_k(0, 0);
+    const float c2 = p.scale_log2e;
+    f16x8 qf[2][DSTEPS];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int qrow = min(q0 + a * 32 + li, p.nq - 1);
+      const f16* qp = p.q + (long)b * p.q_bs + (long)qrow * p.q_rs + (long)h * DP + hi * 8;
+#pragma unroll
+      for (int ds = 0; ds < DSTEPS; ++ds) {
+        const f16x8 raw = *reinterpret_cast<const f16x8*>(qp + ds * 16);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[a][ds][e] = (f16)((float)raw[e] * c2);
+      }
+    }
+    float m_run[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};
+    f16x8 ones, mfrag[2];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      ones[e] = (f16)((hi == 0 && e < 2) ? 1.0f : 0.0f);
+      mfrag[0][e] = mfrag[1][e] = (f16)0.0f;
+    }
+    const int krow = key_perm(li);
+    wait_vmcnt0();
+    __builtin_amdgcn_s_barrier();                                   // B_{-1}: K_0 (and V_0) visible
+    // One tile = two 32-key sub-tiles, each with its own maximum check and P / rescale record: the score MFMAs of sub-tile 1 are independent
+    // of sub-tile 0's softmax, so they are issued interleaved with its exp2 / sum / pack instructions (one MFMA, a handful of VALU, ...):
+    // this wave's matrix work runs under its own vector work, and what stays exposed (sub-tile 1's softmax) is covered by the O wave.
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    for (int t = 0; t <= ntiles; ++t) {
+      if (t < ntiles) {
+        if (t + 1 < ntiles) stage_k((t + 1) & 1, t + 1);
+        const char* sk = smem + (t & 1) * KBYTES;
+        char* const ps = pbase + (t & 1) * (4 * PSLOT);
+        float* const ctrl = reinterpret_cast<float*>(ps + 8 * 1024);   // [sub-tile][query fragment][lane] alpha, then [sub-tile] flag
+        const bool ragged = (t + 1) * KVB > p.nk;
+        f32x16 sacc[2][2];
+        // ---- scores of sub-tile 0; sub-tile 1's K fragments arrive behind its MFMAs ----
+        __builtin_amdgcn_sched_barrier(0);
+        f16x8 kf[2][DSTEPS];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int ds = 0; ds < DSTEPS; ++ds) {
+            const int row = s2 * 32 + krow;
+            kf[s2][ds] = *reinterpret_cast<const f16x8*>(sk + row * (DP * 2) + (k_phys_chunk<CPR>(row, ds * 2 + hi) << 4));
+          }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          f32x16 z;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) z[r] = 0.f;
+          sacc[0][a] = FMX_MFMA_32x32x16(ones, mfrag[a], z);
+        }
+#pragma unroll
+        for (int ds = 0; ds < DSTEPS; ++ds)
+#pragma unroll
+          for (int a = 0; a < 2; ++a) sacc[0][a] = FMX_MFMA_32x32x16(kf[0][ds], qf[a][ds], sacc[0][a]);
+        __builtin_amdgcn_sched_group_barrier(0x100, DSTEPS, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+#pragma unroll
+        for (int ds = 0; ds < DSTEPS; ++ds) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          if (ragged) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+              for (int r = 0; r < 16; ++r)
+                if (t * KVB + s2 * 32 + hi * 16 + r >= p.nk) sacc[s2][a][r] = -INFINITY;
+          }
+          float mx[2];
+#pragma unroll
+          for (int a = 0; a < 2; ++a) {
+            float m0 = fmaxf(sacc[s2][a][0], sacc[s2][a][1]);
+#pragma unroll
+            for (int r = 2; r < 16; r += 2) m0 = fmaxf(fmaxf(m0, sacc[s2][a][r]), sacc[s2][a][r + 1]);
+            const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m0), __float_as_uint(m0), false, false);
+            mx[a] = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+          }
+          const bool first = t == 0 && s2 == 0;
+          const bool moved = first || __any(fmaxf(mx[0], mx[1]) > (float)THR);
+          if (moved) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+              // a sub-tile that is masked out entirely (ragged tail) must not move the maximum to -inf
+              const float delta = first ? mx[a] : fmaxf(mx[a], 0.f);
+              const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);
+              m_run[a] += delta;
+              l_run[a] *= alpha;
+              const f16 mh = (f16)(-m_run[a]);
+              const f16 ml = (f16)(-m_run[a] - (float)mh);
+              mfrag[a][0] = hi == 0 ? mh : (f16)0.0f;
+              mfrag[a][1] = hi == 0 ? ml : (f16)0.0f;
+              ctrl[(s2 * 2 + a) * 64 + lane] = alpha;      // the O wave rescales its accumulators before it adds this sub-tile
+#pragma unroll
+              for (int r = 0; r < 16; ++r) sacc[s2][a][r] -= delta;
+            }
+          }
+          if (lane == 0) reinterpret_cast<int*>(ctrl)[256 + s2] = (moved && !first) ? 1 : 0;
+          __builtin_amdgcn_sched_barrier(0);
+          if (s2 == 0) {
+            // scores of sub-tile 1 (against the maximum as it stands now) ...
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+              f32x16 z;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) z[r] = 0.f;
+              sacc[1][a] = FMX_MFMA_32x32x16(ones, mfrag[a], z);
+            }
+#pragma unroll
+            for (int ds = 0; ds < DSTEPS; ++ds)
+#pragma unroll
+              for (int a = 0; a < 2; ++a) sacc[1][a] = FMX_MFMA_32x32x16(kf[1][ds], qf[a][ds], sacc[1][a]);
+          }
+          // ... under the exponentials of sub-tile 0
+#pragma unroll
+          for (int a = 0; a < 2; ++a) {
+            float ps0 = 0.f, ps1 = 0.f;
+            f16x8 pf[2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float e = __builtin_amdgcn_exp2f(sacc[s2][a][r]);
+              if (r & 1) ps1 += e; else ps0 += e;
+              pf[r >> 3][r & 7] = (f16)e;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) *reinterpret_cast<f16x8*>(ps + ((a * 2 + s2) * 2 + j) * 1024 + lane * 16) = pf[j];
+            l_run[a] += ps0 + ps1;
+          }
+          if (s2 == 0) {
+#pragma unroll
+            for (int i = 0; i < 2 * DSTEPS + 2; ++i) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x402, (80 + DSTEPS) / (2 * DSTEPS + 2), 0);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (t + 1 == ntiles) {
+          lbase[lane] = l_run[0];
+          lbase[64 + lane] = l_run[1];
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                                 // B_t
+    }
+    return;
+  }
+
+  // ===================================================== O waves =====================================================
+  const f16* vbase = p.vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
+  const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(vbase), 0, p.vt_span, 0x00020000);
+  unsigned v_voff[NPV];
+#pragma unroll
+  for (int e = 0; e < NPV; ++e) {
+    const int row = (e * 4 + grp) * 8 + (lane >> 3);
+    v_voff[e] = (unsigned)row * (unsigned)p.vt_ds * 2u + (unsigned)((lane & 7) ^ ((row >> 1) & 7)) * 16u;
+  }
+  auto stage_v = [&](int slot, int kt) __attribute__((always_inline)) {
+#pragma unroll
+    for (int e = 0; e < NPV; ++e) {
+      auto* dv = (__attribute__((address_space(3))) void*)(smem + OFF_V + slot * VBYTES + (e * 4 + grp) * 1024);
+      const unsigned vv = v_voff[e];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, dv, 16, vv, (unsigned)kt * (KVB * 2u), 0, 0);
+    }
+  };
+  stage_v(0, 0);
+  f32x16 oacc[DVT][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+      for (int i = 0; i < DVT; ++i) oacc[i][a][r] = 0.f;
+  wait_vmcnt0();
+  __builtin_amdgcn_s_barrier();                                     // B_{-1}
+  int vslot = 0;                                                    // slot of V_{t-1} while in interval t
+  for (int t = 0; t <= ntiles; ++t) {
+    // V_{t+1} goes to slot (t + 1) % 3: V_{t-2}, its previous tenant, was read in interval t - 1
+    const int vnext = t + 1 < ntiles ? (t + 1) % 3 : 0;
+    if (t + 1 < ntiles) stage_v(vnext, t + 1);
+    if (t >= 1) {
+      const int u = t - 1;                                          // the tile whose P the S wave left before B_{t-1}
+      const char* ps = pbase + (u & 1) * (4 * PSLOT);
+      const float* ctrl = reinterpret_cast<const float*>(ps + 8 * 1024);
+      const char* sv = smem + OFF_V + vslot * VBYTES;
+      // One LDS round trip per tile is exposed (the flags and the first operands, right behind the barrier); everything else is requested
+      // under MFMAs: sub-tile 0's V^T fragments 4 .. 7 and P / V^T 0 .. 3 of sub-tile 1 behind sub-tile 0's MFMAs, the rest behind sub-tile 1's.
+      typedef int i32x2 __attribute__((ext_vector_type(2)));
+      const i32x2 flags = *reinterpret_cast<const i32x2*>(ctrl + 256);
+      f16x8 pf[2][2][2], vf[2][DVT][2];                              // [sub-tile][query fragment | channel block][8-key half]
+      auto read_p = [&](int s2) __attribute__((always_inline)) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) pf[s2][a][j] = *reinterpret_cast<const f16x8*>(ps + ((a * 2 + s2) * 2 + j) * 1024 + lane * 16);
+      };
+      auto read_v = [&](int s2, int dt) __attribute__((always_inline)) {
+        const int row = dt * 32 + li;
+        const char* rp = sv + row * 128;
+        const int sw = (row >> 1) & 7;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) vf[s2][dt][j] = *reinterpret_cast<const f16x8*>(rp + (((s2 * 4 + hi * 2 + j) ^ sw) << 4));
+      };
+      auto rescale = [&](int s2) __attribute__((always_inline)) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const float alpha = ctrl[(s2 * 2 + a) * 64 + lane];
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int i = 0; i < DVT; ++i) oacc[i][a][r] *= alpha;
+        }
+      };
+      __builtin_amdgcn_sched_barrier(0);
+      read_p(0);
+#pragma unroll
+      for (int dt = 0; dt < DVT / 2; ++dt) read_v(0, dt);
+      __builtin_amdgcn_sched_barrier(0);
+      if (flags[0]) rescale(0);                                     // wave-uniform: the maximum moved at this sub-tile
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int dt = DVT / 2; dt < DVT; ++dt) read_v(0, dt);
+      read_p(1);
+#pragma unroll
+      for (int dt = 0; dt < DVT / 2; ++dt) read_v(1, dt);
+#pragma unroll
+      for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int a = 0; a < 2; ++a) oacc[dt][a] = FMX_MFMA_32x32x16(vf[0][dt][j], pf[0][a][j], oacc[dt][a]);
+      // DVT + 4 + DVT reads behind 4 * DVT MFMAs
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
+#pragma unroll
+      for (int i = 4; i < 2 * DVT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (flags[1]) rescale(1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int dt = DVT / 2; dt < DVT; ++dt) read_v(1, dt);
+#pragma unroll
+      for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int a = 0; a < 2; ++a) oacc[dt][a] = FMX_MFMA_32x32x16(vf[1][dt][j], pf[1][a][j], oacc[dt][a]);
+#pragma unroll
+      for (int i = 0; i < DVT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    vslot = t % 3;                                                  // in interval t + 1 the tile to consume is V_t
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                   // B_t
+  }
+  // ---- finish: 1 / l from the S wave (written before the last barrier), O[b][q][h*DP + d] -------------------------------------------------------
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const float lr = lbase[a * 64 + lane];
+    const u32x2 lw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lr), __float_as_uint(lr), false, false);
+    const float inv = 1.0f / (__uint_as_float(lw[0]) + __uint_as_float(lw[1]));
+    const int qg = q0 + a * 32 + li;
+    f16* op = p.o + (long)b * p.o_bs + (long)qg * p.o_rs + (long)h * DP;
+#pragma unroll
+    for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; g += 2) {
+        union { f16x4 h4; unsigned u[2]; } lo, up;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          lo.h4[e] = (f16)(oacc[dt][a][g * 4 + e] * inv);
+          up.h4[e] = (f16)(oacc[dt][a][(g + 1) * 4 + e] * inv);
+        }
+        const u32x2 x = __builtin_amdgcn_permlane32_swap(lo.u[0], up.u[0], false, false);
+        const u32x2 y = __builtin_amdgcn_permlane32_swap(lo.u[1], up.u[1], false, false);
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = {x[0], y[0], x[1], y[1]};
+        if (qg < p.nq) *reinterpret_cast<u32x4*>(op + dt * 32 + (g + hi) * 8) = v;
+      }
+  }
+}
+
 template <int DP>
 int launch_attn_v2(AttnParams p, hipStream_t st) {
   constexpr int DVT = DP / 32;
@@ -769,7 +1123,9 @@ int launch_attn_v2(AttnParams p, hipStream_t st) {
     allow_split = sp ? atoi(sp) : 1;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_q64v2_kernel<6, DP>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * smem);
     // A/B knob (tools/bench_kernels.py attn): FMX_ATTN_VARIANT=1 selects the first-generation kernels (d_head 64: round 1's 823 / 729 TFLOP/s at
-    // N = 4096 / 1024; d_head 128: the generic 32-query kernel), 0 (default) the second-generation one.
+    // N = 4096 / 1024; d_head 128: the generic 32-query kernel), 0 (default) the second-generation ones, 2 the wave-specialised kernel for
+    // d_head 64 as well (d_head 128 uses it by default; at 64 it is slower than the symmetric kernel: 832 vs 1025 TFLOP/s at N = 4096), 3 the
+    // symmetric 64-query kernel for d_head 128 too.
     const char* e = getenv("FMX_ATTN_VARIANT");
     variant = e ? atoi(e) : 0;
     if (DP == 64) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_q64_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -778,7 +1134,7 @@ int launch_attn_v2(AttnParams p, hipStream_t st) {
   const int grid = p.qtiles * p.heads * p.batch;
   // 32-bit byte offsets from the (batch, head) bases: K rows 0 .. nk_pad-1, V^T rows 0 .. DP-1 with nk_pad keys each
   const double k_span = ((double)(p.nk_pad - 1) * p.k_rs + DP) * 2.0, v_span = ((DP - 1.0) * p.vt_ds + p.nk_pad) * 2.0;
-  if (variant == 0 && k_span < 2.0e9 && v_span < 2.0e9 && p.k_rs > 0 && p.vt_ds > 0) {
+  if (variant != 1 && k_span < 2.0e9 && v_span < 2.0e9 && p.k_rs > 0 && p.vt_ds > 0) {
     p.k_span = (unsigned)k_span;
     p.vt_span = (unsigned)v_span;
     // tiles beyond the last full round of `slots` workgroups: as key-split workgroups (2 per tile, half as long each) when they would leave
@@ -788,6 +1144,28 @@ int launch_attn_v2(AttnParams p, hipStream_t st) {
     const int ntiles = (p.nk + KVB - 1) / KVB;
     const int rem = grid % slots;
     const bool do_split = allow_split && rem > 0 && 8 * rem <= 3 * slots && ntiles >= 4 && (ntiles & 1) == 0;
+    // d_head 128: the wave-specialised kernel (two waves per SIMD) unless this launch is one the key-split rule shortens (at most one round)
+    if (variant == 2 || (variant == 0 && DP == 128 && (!do_split || grid > slots))) {
+      constexpr int WS_SMEM = 2 * KVB * DP * 2 + 3 * DVT * 32 * 128 + 2 * 4 * (8 * 1024 + 1280) + 2048;
+      static bool ws_attr = false;
+      if (!ws_attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_ws_kernel<6, DP>), hipFuncAttributeMaxDynamicSharedMemorySize, WS_SMEM);
+        ws_attr = true;
+      }
+      // more than one round with a short tail: the full rounds here, the tail as key-split workgroups of the symmetric kernel behind it
+      const bool tail = variant == 0 && do_split && grid > slots;
+      p.nfull = tail ? grid - rem : grid;
+      p.nsplit = 0;
+      hipLaunchKernelGGL((attn_ws_kernel<6, DP>), dim3(p.nfull), dim3(512), WS_SMEM, st, p);
+      FMX_LAUNCH_CHECK("fmx_attention_f16 (wave-specialised)");
+      if (tail) {
+        p.bid0 = p.nfull;
+        p.nsplit = 2 * rem;
+        hipLaunchKernelGGL((attn_q64v2_kernel<6, DP>), dim3(p.nsplit), dim3(256), 2 * smem, st, p);
+        FMX_LAUNCH_CHECK("fmx_attention_f16 (key-split tail)");
+      }
+      return FMX_OK;
+    }
     p.nfull = do_split ? grid - rem : grid;
     p.nsplit = do_split ? 2 * rem : 0;
     hipLaunchKernelGGL((attn_q64v2_kernel<6, DP>), dim3(p.nfull + p.nsplit), dim3(256), do_split ? 2 * smem : smem, st, p);
@@ -858,6 +1236,7 @@ extern "C" int fmx_attention_f16(const fmx_attn_args* a, void* stream) {
   p.zp = (const f16*)a->zero_page;
   p.causal = a->causal ? 1 : 0;
   p.k_span = p.vt_span = 0;
+  p.nfull = p.nsplit = p.bid0 = 0;
   p.mask = (const f16*)a->mask; p.mask_bs = a->mask_bs; p.mask_hs = a->mask_hs; p.mask_qs = a->mask_qs;
   p.inv_scale = 1.0f / fabsf(a->scale);
   FMX_REQUIRE(!p.mask || (fmx_aligned16(p.mask) && (p.mask_bs % 8) == 0 && (p.mask_hs % 8) == 0 && (p.mask_qs % 8) == 0),

@@ -476,10 +476,13 @@ def test_attention_d64_partial_round_key_split(b, h, nq, nk):
     close(_attn_d64(q, k, v, nk=nk), ref, 2e-3, 2e-3, f"attention d64 b{b} h{h} nq{nq} nk{nk}")
 
 
-@pytest.mark.parametrize("b,h,nq,nk", [(1, 3, 1024, 1024), (2, 2, 4352, 4352), (1, 2, 300, 1000), (2, 3, 512, 77)])
+@pytest.mark.parametrize("b,h,nq,nk", [(1, 3, 1024, 1024), (2, 2, 4352, 4352), (1, 2, 300, 1000), (2, 3, 512, 77), (1, 3, 1024, 950), (2, 24, 1408, 1000),
+                                       (2, 24, 1500, 1024)])
 def test_attention_d128_64_queries_per_wave(b, h, nq, nk):
-    """d_head 128 (Flux) on the 64-query-per-wave kernel (one wave per SIMD, accumulators in the unified register file) against the fp32
-    reference and against the generic 32-query kernel (test hook): ragged query / key counts, a short context, a dominant late key."""
+    """d_head 128 (Flux) on the 64-query-per-wave kernels against the fp32 reference and against the generic 32-query kernel (test hook):
+    ragged query / key counts, a short context, a dominant late key.  Launches the key-split rule shortens (the first three) run the symmetric
+    kernel, the others the wave-specialised one: an odd number of key tiles, a short context, more than one round of workgroups (288; then
+    a key-split tail of the symmetric kernel behind the full round)."""
     d = 128
     nkp = -(-nk // 64) * 64
     q, k, v = rnd(b, nq, h, d, seed=67), torch.zeros(b, nkp, h, d, dtype=torch.float16, device=DEV), torch.zeros(b, nkp, h, d, dtype=torch.float16, device=DEV)
