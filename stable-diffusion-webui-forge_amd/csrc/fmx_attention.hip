@@ -757,6 +757,308 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void attn_q64v2_kernel(const
   }
 }
 
+// ---- third generation, d_head 64: the vector work of one 32-key sub-tile issued UNDER the MFMAs of the next one, inside each wave --------
+// tools/microbench_pipes.hip (profiles/r07f): one wave issues a 32x32x16 MFMA at most every ~47 cycles (the pipe takes one per 32 when two
+// waves feed it), a v_exp_f32 costs a wave ~16 cycles, and both run beside each other -- from two waves and from ONE wave (16 x (MFMA + 2
+// v_exp) take what 16 MFMAs take).  In attn_q64v2_kernel a wave's tile is a serial chain  scores (18 MFMA) -> maximum -> 64 exp2 -> P V (16
+// MFMA): ~3300 cycles of which the two halves overlap only across the SIMD's two waves.  Here the chain is re-cut at sub-tile granularity
+// (sub-tile = 32 keys; scores of 0 / 1 live in separate accumulators anyway, so no extra registers):
+//     phase A(t):  scores of sub-tile 0 of tile t          |  exponentials of sub-tile 1 of tile t-1
+//     phase B(t):  P V of sub-tile 1 of tile t-1           |  maximum check of sub-tile 0 of tile t
+//     phase C(t):  scores of sub-tile 1 of tile t          |  exponentials of sub-tile 0 of tile t
+//     phase D(t):  P V of sub-tile 0 of tile t             |  maximum check of sub-tile 1 of tile t
+// with the MFMA column and the VALU column of a phase interleaved instruction by instruction (sched_group_barrier).  The running maximum is
+// checked per sub-tile (same lazy rule and THR as above).  V^T of tile t-1 is read one tile late, so the LDS ring has three K / V^T stages
+// (48 KB; two workgroups per CU) and one barrier per tile as before.
+template <int THR>
+__global__ __launch_bounds__(256, 2) void attn_q64v3_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int DP = 64, DSTEPS = 4, DVT = 2, CPR = 8;
+  constexpr int KBYTES = KVB * DP * 2, STAGE = 2 * KBYTES, NSLOT = 3;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, li = lane & 31;
+  const int wg = xcd_remap(blockIdx.x, p.nfull);
+  const int qt = wg % p.qtiles, bh = wg / p.qtiles;
+  const int h = bh % p.heads, b = bh / p.heads;
+  const int q0 = qt * 256 + wave * 64;
+  const f16* kbase = p.k + (long)b * p.k_bs + (long)h * DP;
+  const f16* vbase = p.vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
+  const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(kbase), 0, p.k_span, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(vbase), 0, p.vt_span, 0x00020000);
+  unsigned k_voff[2], v_voff[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int row = (e * 4 + wave) * 8 + lane / CPR;
+    k_voff[e] = (unsigned)row * (unsigned)p.k_rs * 2u + (unsigned)k_logical_chunk<CPR>(row, lane % CPR) * 16u;
+    const int vrow = (e * 4 + wave) * 8 + (lane >> 3);
+    v_voff[e] = (unsigned)vrow * (unsigned)p.vt_ds * 2u + (unsigned)((lane & 7) ^ ((vrow >> 1) & 7)) * 16u;
+  }
+  const unsigned k_tile = (unsigned)KVB * (unsigned)p.k_rs * 2u;
+  auto stage = [&](int kt) __attribute__((always_inline)) {
+    char* const sb = smem + (kt % NSLOT) * STAGE;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      auto* dk = (__attribute__((address_space(3))) void*)(sb + (e * 4 + wave) * 1024);
+      const unsigned kv = k_voff[e];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, dk, 16, kv, (unsigned)kt * k_tile, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      auto* dv = (__attribute__((address_space(3))) void*)(sb + KBYTES + (e * 4 + wave) * 1024);
+      const unsigned vv = v_voff[e];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, dv, 16, vv, (unsigned)kt * (KVB * 2u), 0, 0);
+    }
+  };
+  const int ntiles = (p.nk + KVB - 1) / KVB;
+  stage(0);
+  if (ntiles > 1) stage(1);
+
+  const float c2 = p.scale_log2e;
+  f16x8 qf[2][DSTEPS];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int qrow = min(q0 + a * 32 + li, p.nq - 1);
+    const f16* qp = p.q + (long)b * p.q_bs + (long)qrow * p.q_rs + (long)h * DP + hi * 8;
+#pragma unroll
+    for (int ds = 0; ds < DSTEPS; ++ds) {
+      const f16x8 raw = *reinterpret_cast<const f16x8*>(qp + ds * 16);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qf[a][ds][e] = (f16)((float)raw[e] * c2);
+    }
+  }
+  f32x16 oacc[DVT][2], sacc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+      for (int i = 0; i < DVT; ++i) oacc[i][a][r] = 0.f;
+  float m_run[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};
+  f16x8 ones, mfrag[2];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    ones[e] = (f16)((hi == 0 && e < 2) ? 1.0f : 0.0f);
+    mfrag[0][e] = mfrag[1][e] = (f16)0.0f;
+  }
+  // per-lane LDS offsets inside a stage: K fragment (sub-tile, k-step), V^T fragment (channel block, sub-tile, 8-key half)
+  const int krow = key_perm(li);
+  int kofs[2][DSTEPS], vofs[DVT][2][2];
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+    for (int ds = 0; ds < DSTEPS; ++ds) {
+      const int row = s2 * 32 + krow;
+      kofs[s2][ds] = row * (DP * 2) + (k_phys_chunk<CPR>(row, ds * 2 + hi) << 4);
+    }
+#pragma unroll
+  for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = dt * 32 + li;
+        vofs[dt][s2][j] = KBYTES + row * 128 + (((s2 * 4 + hi * 2 + j) ^ ((row >> 1) & 7)) << 4);
+      }
+  f16x8 pf[2][2][2];   // [sub-tile][query fragment][8-key half]
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+  // ---- the four columns ----
+  auto scores = [&](int s2, const char* sb) __attribute__((always_inline)) {   // 4 reads, 2 + 8 MFMAs
+    f16x8 kf[DSTEPS];
+#pragma unroll
+    for (int ds = 0; ds < DSTEPS; ++ds) kf[ds] = *reinterpret_cast<const f16x8*>(sb + kofs[s2][ds]);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      f32x16 z;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) z[r] = 0.f;
+      sacc[s2][a] = FMX_MFMA_32x32x16(ones, mfrag[a], z);
+    }
+#pragma unroll
+    for (int ds = 0; ds < DSTEPS; ++ds)
+#pragma unroll
+      for (int a = 0; a < 2; ++a) sacc[s2][a] = FMX_MFMA_32x32x16(kf[ds], qf[a][ds], sacc[s2][a]);
+  };
+  auto exps = [&](int s2) __attribute__((always_inline)) {                     // 32 exp2, 32 adds, 16 packs
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(sacc[s2][a][r]);
+        if (r & 1) ps1 += e; else ps0 += e;
+        pf[s2][a][r >> 3][r & 7] = (f16)e;
+      }
+      l_run[a] += ps0 + ps1;
+    }
+  };
+  auto pv = [&](int s2, const char* sb) __attribute__((always_inline)) {       // 4 reads, 8 MFMAs
+    f16x8 vf[DVT][2];
+#pragma unroll
+    for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) vf[dt][j] = *reinterpret_cast<const f16x8*>(sb + vofs[dt][s2][j]);
+#pragma unroll
+    for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) oacc[dt][a] = FMX_MFMA_32x32x16(vf[dt][j], pf[s2][a][j], oacc[dt][a]);
+  };
+  float mx[2];
+  auto maxima = [&](int s2) __attribute__((always_inline)) {                   // ~34 VALU
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      float m0 = fmaxf(sacc[s2][a][0], sacc[s2][a][1]);
+#pragma unroll
+      for (int r = 2; r < 16; r += 2) m0 = fmaxf(fmaxf(m0, sacc[s2][a][r]), sacc[s2][a][r + 1]);
+      const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m0), __float_as_uint(m0), false, false);
+      mx[a] = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+  };
+  auto moved = [&](int s2, bool first) __attribute__((always_inline)) {        // rare after the first few tiles (wave-uniform branch)
+    if (first || __any(fmaxf(mx[0], mx[1]) > (float)THR)) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const float delta = first ? mx[a] : fmaxf(mx[a], 0.f);
+        const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);
+        m_run[a] += delta;
+        l_run[a] *= alpha;
+        const f16 mh = (f16)(-m_run[a]);
+        const f16 ml = (f16)(-m_run[a] - (float)mh);
+        mfrag[a][0] = hi == 0 ? mh : (f16)0.0f;
+        mfrag[a][1] = hi == 0 ? ml : (f16)0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#pragma unroll
+          for (int i = 0; i < DVT; ++i) oacc[i][a][r] *= alpha;
+          sacc[s2][a][r] -= delta;
+        }
+      }
+    }
+  };
+  auto mask_tail = [&](int s2, int kt) __attribute__((always_inline)) {
+    if ((kt + 1) * KVB > p.nk) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kt * KVB + s2 * 32 + hi * 16 + r >= p.nk) sacc[s2][a][r] = -INFINITY;
+    }
+  };
+  // phase shapes: `scores` beside `exps` (10 MFMAs, ~80 VALU) and `pv` beside `maxima` (8 MFMAs, ~34 VALU)
+#define FMX_V3_PHASE_SE()                                      \
+  __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);           \
+  __builtin_amdgcn_sched_group_barrier(0x402, 10, 0);          \
+  _Pragma("unroll") for (int i_ = 0; i_ < 10; ++i_) {          \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         \
+    __builtin_amdgcn_sched_group_barrier(0x402, 7, 0);         \
+  }
+#define FMX_V3_PHASE_PM()                                      \
+  __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);           \
+  __builtin_amdgcn_sched_group_barrier(0x402, 10, 0);          \
+  _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {           \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         \
+    __builtin_amdgcn_sched_group_barrier(0x402, 3, 0);         \
+  }
+
+  wait_vmcnt0();
+  __syncthreads();
+
+  // ---- tile 0: nothing of a previous tile beside phases A and B ----
+  {
+    const char* sb = smem;
+    __builtin_amdgcn_sched_barrier(0);
+    scores(0, sb);
+    __builtin_amdgcn_sched_barrier(0);
+    mask_tail(0, 0);
+    maxima(0);
+    moved(0, true);
+    __builtin_amdgcn_sched_barrier(0);
+    scores(1, sb);
+    exps(0);
+    FMX_V3_PHASE_SE()
+    __builtin_amdgcn_sched_barrier(0);
+    mask_tail(1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    pv(0, sb);
+    maxima(1);
+    FMX_V3_PHASE_PM()
+    __builtin_amdgcn_sched_barrier(0);
+    moved(1, false);
+    wait_vmcnt0();
+    __syncthreads();
+    if (2 < ntiles) stage(2);
+  }
+  // (the ragged-tail mask is a branch: LLVM sinks the exponentials of a phase below it, out of the MFMAs' block -- so only the last tile's
+  //  copy of the body has it)
+  auto body = [&](int t, auto MASK) __attribute__((always_inline)) {
+    const char* sb = smem + (t % NSLOT) * STAGE;
+    const char* sp = smem + ((t - 1) % NSLOT) * STAGE;
+    __builtin_amdgcn_sched_barrier(0);
+    scores(0, sb);                 // A
+    exps(1);
+    FMX_V3_PHASE_SE()
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (decltype(MASK)::value) mask_tail(0, t);
+    __builtin_amdgcn_sched_barrier(0);
+    pv(1, sp);                     // B
+    maxima(0);
+    FMX_V3_PHASE_PM()
+    __builtin_amdgcn_sched_barrier(0);
+    moved(0, false);
+    __builtin_amdgcn_sched_barrier(0);
+    scores(1, sb);                 // C
+    exps(0);
+    FMX_V3_PHASE_SE()
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (decltype(MASK)::value) mask_tail(1, t);
+    __builtin_amdgcn_sched_barrier(0);
+    pv(0, sb);                     // D
+    maxima(1);
+    FMX_V3_PHASE_PM()
+    __builtin_amdgcn_sched_barrier(0);
+    moved(1, false);
+    wait_vmcnt0();
+    __syncthreads();
+    if (t + 2 < ntiles) stage(t + 2);
+  };
+  for (int t = 1; t + 1 < ntiles; ++t) body(t, IC<0>{});
+  if (ntiles > 1) body(ntiles - 1, IC<1>{});
+  {  // the last sub-tile
+    const char* sp = smem + ((ntiles - 1) % NSLOT) * STAGE;
+    exps(1);
+    pv(1, sp);
+  }
+#undef FMX_V3_PHASE_SE
+#undef FMX_V3_PHASE_PM
+
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const u32x2 lw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run[a]), __float_as_uint(l_run[a]), false, false);
+    const float inv = 1.0f / (__uint_as_float(lw[0]) + __uint_as_float(lw[1]));
+    const int qg = q0 + a * 32 + li;
+    f16* op = p.o + (long)b * p.o_bs + (long)qg * p.o_rs + (long)h * DP;
+#pragma unroll
+    for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; g += 2) {
+        union { f16x4 h4; unsigned u[2]; } lo, up;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          lo.h4[e] = (f16)(oacc[dt][a][g * 4 + e] * inv);
+          up.h4[e] = (f16)(oacc[dt][a][(g + 1) * 4 + e] * inv);
+        }
+        const u32x2 x = __builtin_amdgcn_permlane32_swap(lo.u[0], up.u[0], false, false);
+        const u32x2 y = __builtin_amdgcn_permlane32_swap(lo.u[1], up.u[1], false, false);
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = {x[0], y[0], x[1], y[1]};
+        if (qg < p.nq) *reinterpret_cast<u32x4*>(op + dt * 32 + (g + hi) * 8) = v;
+      }
+  }
+}
+
 // ---- wave-specialised form ("ws"): score / softmax waves and P V waves -------------------------------------------------------------------
 // A workgroup of 8 waves covers 256 queries; waves 0-3 ("S", 64 queries each) compute scores and the online softmax of key tile t and leave
 // P (fp16, as the MFMA operand fragments they already are: [fragment][lane], 8 KB) plus the rescale factor of a moved maximum in LDS; waves
@@ -1165,6 +1467,25 @@ int launch_attn_v2(AttnParams p, hipStream_t st) {
         FMX_LAUNCH_CHECK("fmx_attention_f16 (key-split tail)");
       }
       return FMX_OK;
+    }
+    if (DP == 64 && !do_split) {
+      static int v3 = -1;
+      if (v3 < 0) {
+        // A/B knob: 0 never, 1 (default) for short contexts, 2 for every launch without key-split workgroups.  Measured (tools/bench_kernels.py
+        // attn, batch 16): 77 keys 31.1 -> 26.7 us (1024 queries, 20 heads) and 51.6 -> 43.4 us (4096 queries, 10 heads); 1024 keys 101.4 ->
+        // 99.0 us; 4096 keys 692.6 -> 717.0 us -- with many key tiles the SIMD's two waves already overlap each other and the vector pipe is
+        // the bound either way, with two tiles the per-wave chain is what counts.
+        const char* e6 = getenv("FMX_ATTN_V3");
+        v3 = e6 ? atoi(e6) : 1;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_q64v3_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * smem / 2);
+      }
+      if (v3 == 2 || (v3 == 1 && ntiles <= 4)) {
+        p.nfull = grid;
+        p.nsplit = 0;
+        hipLaunchKernelGGL(attn_q64v3_kernel<6>, dim3(grid), dim3(256), 3 * smem / 2, st, p);
+        FMX_LAUNCH_CHECK("fmx_attention_f16 (sub-tile pipelined)");
+        return FMX_OK;
+      }
     }
     p.nfull = do_split ? grid - rem : grid;
     p.nsplit = do_split ? 2 * rem : 0;

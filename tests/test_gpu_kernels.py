@@ -448,6 +448,32 @@ def test_attention_running_maximum_paths(case):
         close(_attn_d64(q, k, v, nk=nk, force32=f32), ref, 2e-3, 2e-3, f"attention {case} force32={f32}")
 
 
+@pytest.mark.parametrize("nk,spikes", [(77, ((40, 3, 4.0), (70, 300, 5.0))), (64, ((33, 5, 5.0),)), (130, ((5, 1, 3.0), (100, 2, 4.5), (129, 3, 6.0))),
+                                       (200, ()), (256, ((63, 7, 3.0), (64, 8, 4.5), (250, 9, 6.0)))])
+def test_attention_d64_short_context_pipelined(nk, spikes):
+    """Contexts of up to four key tiles (cross-attention: 77 tokens) run the sub-tile pipelined kernel (attn_q64v3_kernel: the exponentials of
+    one 32-key sub-tile under the MFMAs of the next, the running maximum checked per sub-tile).  Dominant keys placed in the second sub-tile of
+    the first tile, in the ragged last tile and right at a sub-tile edge force the rescale branch at every position of the pipeline; one case
+    has all-negative scores (the first sub-tile must set a negative maximum exactly).  Against torch fp32 and the 32-query kernel."""
+    b, h, n, d = 2, 3, 1000, 64
+    nkp = -(-nk // 64) * 64
+    q = rnd(b, n, h, d, seed=81)
+    k, v = torch.zeros(b, nkp, h, d, dtype=torch.float16, device=DEV), torch.zeros(b, nkp, h, d, dtype=torch.float16, device=DEV)
+    k[:, :nk], v[:, :nk] = rnd(b, nk, h, d, scale=1.2, seed=82), rnd(b, nk, h, d, seed=83)
+    if not spikes:
+        q, k = q.abs().contiguous(), (-(k.abs()) - 0.5).contiguous()
+    k[:, nk:], v[:, nk:] = 6.0, -4.0
+    for key, qi, f in spikes:
+        k[key % b, key, key % h] = q[key % b, qi, key % h] * f
+    ref = _attn_ref(q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3)[:, :, :nk], v.permute(0, 2, 1, 3)[:, :, :nk], d ** -0.5)
+    assert bool(torch.isfinite(ref).all())
+    got = _attn_d64(q, k, v, nk=nk)
+    # (3e-3: with a handful of keys the output is not an average -- it carries the fp16 rounding of P and of the pre-scaled Q of a
+    #  dominant key at full size; the 4096-key tests above hold 2e-3)
+    close(got, ref, 3e-3, 3e-3, f"attention d64, {nk} keys")
+    close(got, _attn_d64(q, k, v, nk=nk, force32=True).float(), 3e-3, 3e-3, "pipelined vs 32-query kernel")
+
+
 def test_attention_d64_generations_agree(monkeypatch):
     """Second-generation d_head-64 kernel (default) against the first-generation one (the 32-query kernel reached through the test hook):
     same inputs, results within fp16 rounding of each other on a 4096-token problem (Q pre-scaling and the deferred maximum change the
