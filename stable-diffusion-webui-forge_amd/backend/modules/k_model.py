@@ -46,8 +46,9 @@ class KModel:
         self.computation_dtype = model.computation_dtype
         self.device = model.device
         self.use_graph = use_graph
-        self._graphs = {}
-        self._static = {}
+        self._graphs = {}    # captured graphs, one per (shape key [, the active ControlNet executors])
+        self._gstate = {}    # per graph key: warm-up count, what the graph points at (`validity`), its result view
+        self._static = {}    # static input buffers (packed x, timesteps) per shape key
         self._stream = None
 
     def memory_required(self, input_shape):
@@ -58,8 +59,30 @@ class KModel:
         t = self.predictor.timestep(torch.tensor(sig_host, dtype=torch.float32)).float()
         return t.repeat(reps)
 
-    def _forward_static(self, key, x, sigma_dev, sig_host, reps, ctxc, control=None, transformer_options=None, c_concat=None):
-        """pack -> UNet -> (returns eps view); static buffers per shape so the UNet can be graph-replayed."""
+    def _drop_graphs(self):
+        torch.cuda.synchronize(self.device)
+        for g in self._graphs.values():
+            g.destroy()
+        self._graphs.clear()
+        self._gstate.clear()
+
+    def _control_plan(self, control_model, sig_host, bu, hh, ww, ctx, reps):
+        """The ControlNet chain as a list of capturable entries (outermost first), or None when any link needs Python per step (conditioning
+        modifiers, a model-function wrapper, advanced weighting, a T2I adapter, ...): patcher/controlnet.py `graph_entry`."""
+        if not self.use_graph or len(set(sig_host)) != 1:
+            return None
+        entries, seen, p = [], set(), control_model
+        while p is not None:
+            e = p.graph_entry(sig_host[0], bu, hh, ww, ctx[0], ctx[1], reps) if hasattr(p, "graph_entry") else None
+            if e is None or id(e["cm"]) in seen:   # one executor twice in a chain: its second forward would overwrite the first one's residuals
+                return None
+            seen.add(id(e["cm"]))
+            entries.append(e)
+            p = p.previous_controlnet
+        return entries
+
+    def _forward_static(self, key, x, sigma_dev, sig_host, reps, ctxc, control=None, transformer_options=None, c_concat=None, control_plan=None):
+        """pack -> [ControlNets ->] UNet -> (returns eps view); static buffers per shape so the chain can be graph-replayed."""
         b, c, hh, ww = x.shape
         bu = reps * b
         st = self._static.get(key)
@@ -67,13 +90,10 @@ class KModel:
             if len(self._static) >= self.MAX_CACHED_SHAPES:
                 # a long-lived server sees many (batch, resolution) shapes: drop every cached graph and its static buffers rather than
                 # grow without bound (the next call of each shape warms up and captures again)
-                torch.cuda.synchronize(self.device)
-                for g in self._graphs.values():
-                    g.destroy()
-                self._graphs.clear()
+                self._drop_graphs()
                 self._static.clear()
             st = {"xcol": torch.empty(bu * hh * ww, 64, dtype=torch.float16, device=self.device),
-                  "t": torch.empty(bu, dtype=torch.float32, device=self.device), "eps": None, "warm": 0}
+                  "t": torch.empty(bu, dtype=torch.float32, device=self.device)}
             self._static[key] = st
         ops.unet_pack_input(x, sigma_dev, reps, self.predictor.sigma_data, out=st["xcol"])
         tvals = self._timesteps(sig_host, reps)
@@ -85,26 +105,51 @@ class KModel:
         hooks = net._hooks(transformer_options)
         concat_term = net.prepare_concat(c_concat, bu) if c_concat is not None else None  # cached per c_concat tensor: once per job
         if not self.use_graph or control is not None or hooks is not None:
-            # ControlNet residuals change every step and Python hooks cannot be captured: eager, not graph replay
+            # Python hooks cannot be captured, and a ControlNet chain that needs Python per step arrives here with its residuals: eager
             return net.forward_packed(st["xcol"], st["t"], ctxc, bu, hh, ww, control, hooks, concat_term)
-        if st.get("concat_ptr") != (None if concat_term is None else concat_term.data_ptr()) and key in self._graphs:
-            self._graphs.pop(key).destroy()  # the captured graph reads the previous job's concat term
-            st["warm"] = 1
-        g = self._graphs.get(key)
-        if g is not None and st.get("arena_epoch") != net.arena_epoch:
-            # the executor re-allocated its arena since this graph was captured (a larger shape came through, e.g. the hires pass):
-            # the graph's kernels point into freed memory -- drop it and capture again on the current arena
-            g.destroy()
-            del self._graphs[key]
-            st["warm"] = 0
-            g = None
+        active = [e for e in control_plan if e["active"]] if control_plan else []
+        gkey = key if not active else key + ("control",) + tuple(id(e["cm"]) for e in active)
+
+        def run():
+            # The ControlNet trunks read the SAME packed input and timestep buffers as the UNet (both are `calculate_input` of x and the
+            # predictor's timestep of sigma: k_model.py:31-35, patcher/controlnet.py get_control), innermost link of the chain first,
+            # merged exactly as get_control / control_merge do in the eager path.
+            ctrl = None
+            for e in reversed(active):
+                outs = e["cm"].forward_static(st["xcol"], st["t"], e["ctxc"], bu, hh, ww, e["gh"])
+                ctrl = e["cn"].control_merge(None, outs, ctrl, torch.float32)
+            return net.forward_packed(st["xcol"], st["t"], ctxc, bu, hh, ww, control=ctrl, concat_term=concat_term)
+
+        def validity():
+            # What a captured graph points at: the executors' arenas (re-allocated when a larger shape comes through, e.g. the hires pass),
+            # the cross-attention K / V^T buffers (re-allocated whenever the conditioning changes -- also when ANOTHER shape's job came in
+            # between and this job's conditioning tensor then re-used the address, hence the key, of the earlier one: the serial number tells,
+            # the key alone does not; that was a NaN: tools/soak.py, batch 8 -> batch 1 -> batch 8), the concat term, the guided hints.
+            return ((net.arena_epoch,) + tuple(e["cm"].arena_epoch for e in active),
+                    (ctxc.key, ctxc.serial), None if concat_term is None else concat_term.data_ptr(), tuple(e["valid"]() for e in active))
+
+        gs = self._gstate.get(gkey)
+        if gs is None:
+            if len(self._graphs) >= 2 * self.MAX_CACHED_SHAPES:
+                self._drop_graphs()
+            gs = self._gstate[gkey] = {"warm": 0, "valid": None, "eps": None}
+        g = self._graphs.get(gkey)
+        if g is not None:
+            now = validity()
+            if now != gs["valid"]:
+                g.destroy()
+                del self._graphs[gkey]
+                g = None
+                # same arenas, other conditioning / hint (the usual case: a new job of a shape seen before): every buffer the chain needs
+                # exists, capture again right away; a new arena is sized by an eager run first
+                gs["warm"] = 2 if now[0] == gs["valid"][0] else 0
         if g is None:
-            # eager warm-up (sizes the arena, creates lazily-built buffers), then capture on a side stream
-            eps = net.forward_packed(st["xcol"], st["t"], ctxc, bu, hh, ww, concat_term=concat_term)
-            st["concat_ptr"] = None if concat_term is None else concat_term.data_ptr()
-            st["warm"] += 1
-            if st["warm"] < 2:
-                return eps
+            if gs["warm"] < 2:
+                # eager warm-up (sizes the arenas, creates lazily-built buffers), then capture on a side stream
+                eps = run()
+                gs["warm"] += 1
+                if gs["warm"] < 2:
+                    return eps
             cur = torch.cuda.current_stream(self.device)
             if self._stream is None:
                 self._stream = torch.cuda.Stream(self.device)
@@ -112,28 +157,18 @@ class KModel:
             s.wait_stream(cur)
             g = HipGraph()
             with torch.cuda.stream(s):
-                st["eps"] = g.capture(s, lambda: net.forward_packed(st["xcol"], st["t"], ctxc, bu, hh, ww, concat_term=concat_term))
+                gs["eps"] = g.capture(s, run)
                 g.launch(s)
             cur.wait_stream(s)
-            self._graphs[key] = g
-            st["ctx_key"] = (ctxc.key, ctxc.serial)
-            st["arena_epoch"] = net.arena_epoch
-            return st["eps"]
-        if st.get("ctx_key") != (ctxc.key, ctxc.serial):
-            # the graph reads the cross-attention K / V^T buffers that existed when it was captured.  They are re-allocated whenever the
-            # conditioning changes (prepare_context), also when ANOTHER shape's job came in between and this job's conditioning tensor then
-            # re-used the address (hence the key) of the earlier one: the serial number tells, the key alone does not (that was a NaN:
-            # tools/soak.py, batch 8 -> batch 1 -> batch 8)
-            g.destroy()
-            del self._graphs[key]
-            st["warm"] = 1
-            return self._forward_static(key, x, sigma_dev, sig_host, reps, ctxc, c_concat=c_concat)
+            self._graphs[gkey] = g
+            gs["valid"] = validity()
+            return gs["eps"]
         cur = torch.cuda.current_stream(self.device)
         s = self._stream
         s.wait_stream(cur)
         g.launch(s)
         cur.wait_stream(s)
-        return st["eps"]
+        return gs["eps"]
 
     def denoise_cfg(self, x, sigma, uncond_ctx, cond_ctx, cond_scale, want_parts=False, transformer_options=None, control_model=None,
                     c_concat=None):
@@ -161,17 +196,22 @@ class KModel:
             ctx = cond_ctx
         ctxc = self.diffusion_model.prepare_context(ctx[0], ctx[1])
         key = (b, c, hh, ww, reps)
-        control = None
+        control, plan = None, None
         if control_model is not None:
             # sampling_function.py:261-268: every ControlNet of the chain sees the per-call options, then one get_control on the stacked batch
             p = control_model
             while p is not None:
                 p.transformer_options = per_call_options
                 p = p.previous_controlnet
-            t_all = torch.cat([sigma] * reps)
-            t_all.fmx_sigma = SigmaInfo(list(sig_host) * reps)
-            control = control_model.get_control(torch.cat([x] * reps), t_all, {"c_crossattn": ctx[0], "y": ctx[1]}, reps)
-        eps = self._forward_static(key, x, sigma, sig_host, reps, ctxc, control=control, transformer_options=transformer_options, c_concat=c_concat)
+            # a chain that needs no Python per step runs inside the captured graph; otherwise its residuals are computed here, eagerly
+            if self.diffusion_model._hooks(transformer_options) is None:
+                plan = self._control_plan(control_model, sig_host, reps * b, hh, ww, ctx, reps)
+            if plan is None:
+                t_all = torch.cat([sigma] * reps)
+                t_all.fmx_sigma = SigmaInfo(list(sig_host) * reps)
+                control = control_model.get_control(torch.cat([x] * reps), t_all, {"c_crossattn": ctx[0], "y": ctx[1]}, reps)
+        eps = self._forward_static(key, x, sigma, sig_host, reps, ctxc, control=control, transformer_options=transformer_options, c_concat=c_concat,
+                                   control_plan=plan)
         cond_pred = torch.empty_like(x) if want_parts else None
         uncond_pred = torch.empty_like(x) if want_parts else None
         den = ops.cfg_combine(eps, eps.shape[-1], x, sigma, reps, cond_scale, None, cond_pred, uncond_pred,

@@ -95,10 +95,7 @@ class ControlNet(IntegratedUNet2DConditionModel):
         e1 = ops.silu(e1, out=e1)
         emb = ops.linear(e1, *self.w["te2"], residual=ctxc.label)
         emb_all = ops.linear(ops.silu(emb), *self.w["emb_all"])
-        if guided_hint.shape[0] != bu:
-            if bu % guided_hint.shape[0] != 0:
-                raise ValueError(f"hint batch {guided_hint.shape[0]} does not divide the UNet batch {bu}")
-            guided_hint = guided_hint.repeat(bu // guided_hint.shape[0], 1, 1, 1)
+        assert guided_hint.shape[0] == bu
         outs = []
         h = None
         for bi, blk in enumerate(lay.input_blocks):
@@ -114,18 +111,21 @@ class ControlNet(IntegratedUNet2DConditionModel):
         outs.append(ops.linear(h.view(-1, h.shape[-1]), *self.w["middle_block_out"]).view(h.shape))
         return outs
 
-    def forward(self, x, hint, timesteps, context, y=None, **kwargs):
-        """Reference signature (cldm.py:229): x [B, C, h, w] (already scaled by calculate_input), hint [B or 1, hc, 8h, 8w], timesteps [B],
-        context [B, T, Dc], y [B, adm] | None -> list of [B, C_i, h_i, w_i] fp16 residuals (channels-last memory), valid until the next call."""
-        assert (y is not None) == (self.num_classes is not None)
-        bu, c, hh, ww = x.shape
-        ctxc = self.prepare_context(context, y)
+    def hint_for_batch(self, hint, bu):
+        """The guided hint repeated to the network batch; cached with the guided hint itself (one tensor per hint image and batch)."""
         gh = self.guided_hint(hint)
-        if gh.shape[1] != hh or gh.shape[2] != ww:
-            raise ValueError(f"hint {tuple(hint.shape)} is not 8x the latent {tuple(x.shape)}")
-        zero = torch.zeros(bu, dtype=torch.float32, device=self.device)  # sigma = 0 -> the pack kernel's 1/sqrt(sigma^2 + 1) is 1
-        xcol = ops.unet_pack_input(x.to(device=self.device, dtype=torch.float32).contiguous(), zero, 1, 1.0)
-        t = timesteps.to(device=self.device, dtype=torch.float32).contiguous()
+        if gh.shape[0] == bu:
+            return gh
+        if bu % gh.shape[0] != 0:
+            raise ValueError(f"hint batch {gh.shape[0]} does not divide the UNet batch {bu}")
+        cached = getattr(self, "_gh_rep", None)
+        if cached is None or cached[0] is not gh or cached[1] != bu:
+            self._gh_rep = cached = (gh, bu, gh.repeat(bu // gh.shape[0], 1, 1, 1))
+        return cached[2]
+
+    def forward_static(self, xcol, t, ctxc, bu, hh, ww, gh):
+        """The trunk on inputs that are already packed (`fmx_unet_pack_input` columns, fp32 timesteps, cached conditioning, guided hint of the
+        network batch): kernels and arena allocations only, so `KModel` can capture it in its graph.  -> residuals as in `forward`."""
         from ....runtime import ArenaOverflow
         while True:
             arena = self._get_arena(bu, hh, ww)
@@ -139,5 +139,19 @@ class ControlNet(IntegratedUNet2DConditionModel):
                 self._arena_bytes = arena.capacity * 2
                 self._arena = None
         return [o.permute(0, 3, 1, 2) for o in outs]
+
+    def forward(self, x, hint, timesteps, context, y=None, **kwargs):
+        """Reference signature (cldm.py:229): x [B, C, h, w] (already scaled by calculate_input), hint [B or 1, hc, 8h, 8w], timesteps [B],
+        context [B, T, Dc], y [B, adm] | None -> list of [B, C_i, h_i, w_i] fp16 residuals (channels-last memory), valid until the next call."""
+        assert (y is not None) == (self.num_classes is not None)
+        bu, c, hh, ww = x.shape
+        ctxc = self.prepare_context(context, y)
+        gh = self.hint_for_batch(hint, bu)
+        if gh.shape[1] != hh or gh.shape[2] != ww:
+            raise ValueError(f"hint {tuple(hint.shape)} is not 8x the latent {tuple(x.shape)}")
+        zero = torch.zeros(bu, dtype=torch.float32, device=self.device)  # sigma = 0 -> the pack kernel's 1/sqrt(sigma^2 + 1) is 1
+        xcol = ops.unet_pack_input(x.to(device=self.device, dtype=torch.float32).contiguous(), zero, 1, 1.0)
+        t = timesteps.to(device=self.device, dtype=torch.float32).contiguous()
+        return self.forward_static(xcol, t, ctxc, bu, hh, ww, gh)
 
     __call__ = forward

@@ -186,11 +186,7 @@ class ControlNet(ControlBase):
         if self.timestep_range is not None:
             if t0 > self.timestep_range[0] or t0 < self.timestep_range[1]:
                 return control_prev
-        if self.cond_hint is None or x_noisy.shape[2] * 8 != self.cond_hint.shape[2] or x_noisy.shape[3] * 8 != self.cond_hint.shape[3]:
-            self.cond_hint = image_resize.adaptive_resize(self.cond_hint_original.to(x_noisy.device), x_noisy.shape[3] * 8, x_noisy.shape[2] * 8,
-                                                          "nearest-exact", "center")
-        if x_noisy.shape[0] != self.cond_hint.shape[0]:
-            self.cond_hint = broadcast_image_to(self.cond_hint, x_noisy.shape[0], batched_number)
+        self._prepare_hint(x_noisy.shape[0], x_noisy.shape[2], x_noisy.shape[3], x_noisy.device, batched_number)
         context, y = cond["c_crossattn"], cond.get("y", None)
         predictor = self.model_sampling_current
         sig = t.fmx_sigma.host if hasattr(t, "fmx_sigma") else t.detach().float().cpu().tolist()
@@ -204,6 +200,61 @@ class ControlNet(ControlBase):
         else:
             control = self.control_model(x=x_in, hint=self.cond_hint, timesteps=timestep, context=context, y=y)
         return self.control_merge(None, control, control_prev, x_noisy.dtype)
+
+    def _prepare_hint(self, bu, hh, ww, device, batched_number):
+        """The hint image at 8x the latent size, broadcast to the network batch (controlnet.py:get_control); kept across steps."""
+        if self.cond_hint is None or hh * 8 != self.cond_hint.shape[2] or ww * 8 != self.cond_hint.shape[3] or bu != self.cond_hint.shape[0]:
+            # `cleanup` drops cond_hint after every job; the executor keeps the last prepared image per source image, so that a second job
+            # with the same hint finds the same tensor -- and with it the cached guided hint and a still-valid captured graph
+            orig = self.cond_hint_original
+            try:
+                ver = orig._version
+            except RuntimeError:
+                ver = -1
+            key = (orig.data_ptr(), tuple(orig.shape), orig.dtype, ver, hh, ww, bu, batched_number)
+            holder = self.control_model if self.control_model is not None else self
+            cached = getattr(holder, "_prepared_hint", None)
+            if cached is not None and cached[0] == key and cached[1] is orig:
+                self.cond_hint = cached[2]
+                return self.cond_hint
+            if self.cond_hint is None or hh * 8 != self.cond_hint.shape[2] or ww * 8 != self.cond_hint.shape[3]:
+                self.cond_hint = image_resize.adaptive_resize(orig.to(device), ww * 8, hh * 8, "nearest-exact", "center")
+            if bu != self.cond_hint.shape[0]:
+                self.cond_hint = broadcast_image_to(self.cond_hint, bu, batched_number)
+            try:
+                holder._prepared_hint = (key, orig, self.cond_hint)
+            except AttributeError:
+                pass
+        return self.cond_hint
+
+    def graph_entry(self, sigma0, bu, hh, ww, context, y, batched_number):
+        """What `KModel` needs to run this link of the chain inside its captured graph: the executor, its cached conditioning and guided hint,
+        whether the link is active at this sigma (the timestep range is a host decision: the graph is keyed on the set of active links) and
+        a callable naming everything of this link a captured graph points at.  None when the link needs Python per step -- conditioning
+        modifiers, a model-function wrapper, advanced weighting, pooled residuals, a foreign control model -- and the chain runs eagerly."""
+        to = self.transformer_options or {}
+        cm = self.control_model
+        if type(self).get_control is not ControlNet.get_control or not hasattr(cm, "forward_static"):
+            return None
+        if to.get("controlnet_conditioning_modifiers") or to.get("controlnet_model_function_wrapper") is not None or self.global_average_pooling:
+            return None
+        if any(getattr(self, a, None) is not None for a in ("positive_advanced_weighting", "negative_advanced_weighting", "advanced_frame_weighting",
+                                                            "advanced_sigma_weighting", "advanced_mask_weighting")):
+            return None
+        if self.cond_hint_original is None or self.model_sampling_current is None:
+            return None
+        active = not (self.timestep_range is not None and (sigma0 > self.timestep_range[0] or sigma0 < self.timestep_range[1]))
+        entry = {"cn": self, "cm": cm, "active": active, "ctxc": None, "gh": None, "valid": None}
+        if active:
+            hint = self._prepare_hint(bu, hh, ww, context.device, batched_number)
+            ctxc = cm.prepare_context(context, y)
+            gh = cm.hint_for_batch(hint, bu)
+            if gh.shape[1] != hh or gh.shape[2] != ww:
+                raise ValueError(f"hint {tuple(hint.shape)} is not 8x the latent {(hh, ww)}")
+            entry.update(ctxc=ctxc, gh=gh)
+            strength = float(self.strength)
+            entry["valid"] = lambda: (ctxc.key, ctxc.serial, gh.data_ptr(), strength)
+        return entry
 
     def copy(self):
         c = ControlNet(self.control_model, global_average_pooling=self.global_average_pooling, load_device=self.load_device,

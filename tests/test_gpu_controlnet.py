@@ -85,6 +85,63 @@ def test_sampling_with_a_controlnet_chain_vs_reference(name, engines):
 
 
 @pytest.mark.parametrize("name", list(TINY))
+def test_controlnet_chain_inside_the_captured_graph_matches_eager(name, engines):
+    """A chain that needs no Python per step (plain strengths and timestep ranges) runs INSIDE KModel's captured graph: the trunks read the
+    UNet's own packed input / timestep buffers, the graph is keyed on the set of links active at the step's sigma.  10 Euler steps with ranges
+    (0 - 0.65) and (0.3 - 1.0) of the schedule: the active set goes {a} -> {a, b} -> {b}; three graphs are captured.  Against the same job run eagerly (`use_graph` off: residuals from `get_control` every step); the two differ only in
+    where 1 / sqrt(sigma^2 + 1) is rounded (pack kernel vs host), far below fp16 resolution.  A second job with another hint and another
+    conditioning on the same engine must not replay anything of the first (validity: conditioning serial, guided hint, arena)."""
+    cfg = TINY[name]
+    g = load_golden(f"{name}_controlnet.pt")
+    case = controlnet_case(cfg)
+    eng = engines[name]
+    km = eng.forge_objects.unet.model
+    cn_a = pc.ControlNet(cldm.ControlNet(cfg, synth.synth_controlnet_state_dict(cfg, seed=6), device=DEV))
+    cn_b = pc.ControlNet(cldm.ControlNet(cfg, synth.synth_controlnet_state_dict(cfg, seed=9), device=DEV))
+
+    def job(hint_a, hint_b, cond_seed, use_graph):
+        unet = pc.apply_controlnet_advanced(eng.forge_objects.unet, cn_a, hint_a, 0.8, 0.0, 0.65)
+        unet = pc.apply_controlnet_advanced(unet, cn_b, hint_b, 0.5, 0.3, 1.0)
+        saved = eng.forge_objects_after_applying_lora
+        eng.forge_objects_after_applying_lora = saved.shallow_copy()
+        eng.forge_objects_after_applying_lora.unet = unet
+        was = km.use_graph
+        km.use_graph = use_graph
+        try:
+            b = 2
+            c, uc = synth.synth_conditioning(b, cfg["context_dim"], cfg.get("adm_in_channels"), seed=cond_seed)
+            if isinstance(c, dict):
+                c, uc = DictWithShape({k: v.to(DEV) for k, v in c.items()}), DictWithShape({k: v.to(DEV) for k, v in uc.items()})
+            else:
+                c, uc = c.to(DEV), uc.to(DEV)
+            shared.opts.randn_source = "CPU"
+            p = processing.StableDiffusionProcessingTxt2Img(sd_model=eng, c=c, uc=uc, seed=77, sampler_name="Euler", batch_size=b, steps=10,
+                                                            cfg_scale=7.0, width=g["hw"] * 8, height=g["hw"] * 8, do_decode=False)
+            return processing.process_images(p).latents.clone()
+        finally:
+            km.use_graph = was
+            eng.forge_objects_after_applying_lora = saved
+            eng.forge_objects = saved.shallow_copy()
+
+    ha, hb = case["hint_a"].to(DEV), case["hint_b"].to(DEV)
+    eager = job(ha, hb, 1234, False)
+    n0 = len(km._graphs)
+    graphed = job(ha, hb, 1234, True)
+    captured = [k for k in km._graphs if "control" in k]
+    assert len(km._graphs) > n0 and len({k[k.index("control"):] for k in captured}) == 3, captured   # {a}, {a, b}, {b}
+    assert bool(torch.isfinite(graphed).all())
+    assert max_rel(graphed, eager) < 2e-3, max_rel(graphed, eager)
+    assert float((graphed - job(ha, hb, 1234, True)).abs().max()) == 0.0          # replays are deterministic
+    # another job on the same engine: swapped hints, another conditioning -> nothing of the first job may be replayed
+    eager2 = job(hb.clone(), ha.clone(), 99, False)
+    graphed2 = job(hb.clone(), ha.clone(), 99, True)
+    assert max_rel(graphed2, eager2) < 2e-3, max_rel(graphed2, eager2)
+    assert max_rel(graphed2, graphed) > 1e-2                                        # (and the two jobs do differ)
+    # and the first job again after the second
+    assert max_rel(job(ha, hb, 1234, True), eager) < 2e-3
+
+
+@pytest.mark.parametrize("name", list(TINY))
 def test_control_lora_vs_reference(name, engines):
     """Control-LoRA (patcher/controlnet.py:420-474): control model assembled in pre_run from the UNet's trunk + the file's low-rank pairs, against
     the reference's ControlLora -- residuals of one call and a 4-step Euler run."""

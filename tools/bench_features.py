@@ -91,7 +91,13 @@ def main():
         cn = cldm.ControlNet(cfg, synth.synth_state_dict_device(controlnet_param_shapes(cfg), 6, dev), device=dev)
         hint = torch.rand(1, 3, height, width, device=dev)
         unet = pc.apply_controlnet_advanced(eng.forge_objects.unet, pc.ControlNet(cn), hint, 0.8, 0.0, 1.0)
-        run("ControlNet (SDXL-size control model, strength 0.8)", unet=unet)
+        run("ControlNet (SDXL-size control model, strength 0.8), trunk inside the captured graph", unet=unet)
+        km = eng.forge_objects.unet.model
+        km.use_graph = False
+        try:
+            run("ControlNet (SDXL-size control model, strength 0.8), eager (residuals from get_control every step)", unet=unet)
+        finally:
+            km.use_graph = True
     if "hires" in what:
         run("hires fix 1024 -> 1536 (Latent bicubic), 6 + 4 steps", steps=6, enable_hr=True, hr_scale=1.5, hr_upscaler="Latent (bicubic)",
             hr_second_pass_steps=4, denoising_strength=0.6, hr_cfg=7.0)
