@@ -396,13 +396,13 @@ def main():
             at = summ.get("attention")
             if at:
                 ach = at["flops"] / at["seconds"]
-                attn_roof = {"kernel": "attn_q64v2_kernel / attn_kernel<d> (fmx_attention: fused QK^T-softmax-PV), launches with more than 128 keys", "bound": "mfma",
+                attn_roof = {"kernel": "attn_q64v2_kernel / attn_ws_kernel (d_head 128) / attn_kernel<d> (fmx_attention: fused QK^T-softmax-PV), launches with more than 128 keys", "bound": "mfma",
                              "achieved": round(ach / 1e12, 1), "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK, 4),
                              "launches_per_forward": at["launches"], "kernel_time_per_forward_ms": round(at["seconds"] * 1e3, 2)}
             xa = summ.get("attention_short_keys")
             if xa and xa.get("bytes"):
                 ach = xa["bytes"] / xa["seconds"]
-                xattn_roof = {"kernel": "the same kernels on the 77-token text context (one or two key tiles: no key loop to pipeline)", "bound": "hbm",
+                xattn_roof = {"kernel": "attn_q64v3_kernel / attn_kernel<d> on the 77-token text context (two key tiles)", "bound": "hbm",
                               "achieved": round(ach / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(ach / HBM_PEAK, 4),
                               "algorithmic_bytes": "1 read of Q, K, V + 1 write of O", "launches_per_forward": xa["launches"],
                               "kernel_time_per_forward_ms": round(xa["seconds"] * 1e3, 2)}
