@@ -1,6 +1,8 @@
 """Host-side contracts that need no GPU: a clone of the UNet patcher never leaks hooks into its parent (the reference
 deep-copies model_options, backend/patcher/base.py:83), and the per-iteration conditioning slice tolerates the absent unconditional
-batch of a cfg_scale 1 job (setup_conds leaves uc = None, as the reference does)."""
+batch of a cfg_scale 1 job (setup_conds leaves uc = None, as the reference does); which ControlNet chains may run inside the captured graph
+(round 2: a host decision per link, patcher/controlnet.py graph_entry)."""
+import pytest
 import torch
 
 import forge_amd  # noqa: F401
@@ -43,3 +45,83 @@ def test_slice_cond_handles_every_conditioning_shape_and_none():
     d = DictWithShape({"crossattn": torch.zeros(4, 77, 8), "vector": torch.ones(4, 6)})
     s = processing._slice_cond(d, 2, 4)
     assert isinstance(s, DictWithShape) and s["crossattn"].shape[0] == 2 and s["vector"].shape[0] == 2
+
+
+# ---- which ControlNet chains KModel may capture in its graph (patcher/controlnet.py graph_entry; host decision, no kernels) ------------------------
+class _FakeCtx:
+    key, serial = ("k",), 1
+
+
+class _FakeControlExecutor:
+    """Stands in for nn/cnets/cldm.ControlNet: the three things graph_entry asks of it."""
+    arena_epoch = 0
+
+    def __init__(self):
+        self.hints = 0
+
+    def forward_static(self, *a):
+        raise AssertionError("graph_entry must not run the trunk")
+
+    def prepare_context(self, context, y):
+        return _FakeCtx()
+
+    def hint_for_batch(self, hint, bu):
+        self.hints += 1
+        return torch.zeros(bu, hint.shape[2] // 8, hint.shape[3] // 8, 4)
+
+
+def _plain_link(strength=0.8, rng=(0.0, 1.0), pooling=False):
+    from forge_amd.backend.patcher import controlnet as pc
+
+    class P:   # predictor stand-in: percent -> sigma, linear from 10 down to 0
+        sigma_data = 1.0
+
+    cn = pc.ControlNet(_FakeControlExecutor(), global_average_pooling=pooling)
+    cn.set_cond_hint(torch.rand(1, 3, 64, 64), strength, rng)
+    cn.pre_run(type("M", (), {"predictor": P()})(), lambda pct: 10.0 * (1.0 - pct))
+    return cn
+
+
+def test_controlnet_graph_entry_accepts_plain_links_and_reports_activity():
+    ctx = torch.zeros(4, 77, 8)
+    cn = _plain_link(rng=(0.2, 0.7))                                   # active for sigma in [3, 8]
+    e = cn.graph_entry(5.0, 4, 8, 8, ctx, None, 2)
+    assert e is not None and e["active"] and e["cn"] is cn and e["gh"].shape[0] == 4
+    v = e["valid"]()
+    assert v[0] == ("k",) and v[1] == 1 and v[3] == 0.8
+    for sigma in (9.0, 2.0):                                           # before the start / after the end of the range: in the chain, inactive
+        e = cn.graph_entry(sigma, 4, 8, 8, ctx, None, 2)
+        assert e is not None and not e["active"] and e["gh"] is None
+    # the prepared hint survives cleanup() (per source image, on the executor): the next job finds the same tensor, hence the same guided hint
+    h1 = cn._prepare_hint(4, 8, 8, "cpu", 2)
+    cn.cleanup()
+    assert cn.cond_hint is None
+    cn.pre_run(type("M", (), {"predictor": type("P", (), {"sigma_data": 1.0})()})(), lambda pct: 10.0 * (1.0 - pct))
+    assert cn._prepare_hint(4, 8, 8, "cpu", 2) is h1
+    cn.cond_hint = None
+    cn.cond_hint_original = cn.cond_hint_original.clone()              # another image (even with equal content): prepared again
+    assert cn._prepare_hint(4, 8, 8, "cpu", 2) is not h1
+
+
+@pytest.mark.parametrize("why", ["modifier", "wrapper", "pooling", "weighting", "foreign_model", "subclass_get_control"])
+def test_controlnet_graph_entry_declines_links_that_need_python_per_step(why):
+    from forge_amd.backend.patcher import controlnet as pc
+    ctx = torch.zeros(4, 77, 8)
+    cn = _plain_link(pooling=(why == "pooling"))
+    if why == "modifier":
+        cn.transformer_options = {"controlnet_conditioning_modifiers": [lambda *a: a[1:]]}
+    elif why == "wrapper":
+        cn.transformer_options = {"controlnet_model_function_wrapper": lambda **kw: None}
+    elif why == "weighting":
+        cn.advanced_sigma_weighting = lambda s: s
+    elif why == "foreign_model":
+        cn.control_model = object()
+    elif why == "subclass_get_control":
+        class Custom(pc.ControlNet):
+            def get_control(self, *a):
+                return None
+        c2 = Custom(cn.control_model)
+        cn.copy_to(c2)
+        c2.timestep_range, c2.model_sampling_current = cn.timestep_range, cn.model_sampling_current
+        cn = c2
+    assert cn.graph_entry(5.0, 4, 8, 8, ctx, None, 2) is None
