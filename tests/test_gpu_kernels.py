@@ -474,6 +474,24 @@ def test_attention_d64_short_context_pipelined(nk, spikes):
     close(got, _attn_d64(q, k, v, nk=nk, force32=True).float(), 3e-3, 3e-3, "pipelined vs 32-query kernel")
 
 
+@pytest.mark.parametrize("d", [64, 128])
+@pytest.mark.parametrize("nk", [1, 20, 33, 63])
+def test_attention_fewer_keys_than_one_tile(d, nk):
+    """A context shorter than one 64-key tile on the 64-query kernels (d_head 64: the sub-tile pipelined kernel, whose second sub-tile is then
+    partly or wholly masked; d_head 128: the wave-specialised one): masked scores are -inf, a sub-tile without a valid key must not move the
+    running maximum, padded keys hold garbage.  One key: the output is that key's value row."""
+    b, h, n = 2, 2, 512
+    q = rnd(b, n, h, d, seed=91)
+    k, v = torch.full((b, 64, h, d), 9.0, dtype=torch.float16, device=DEV), torch.full((b, 64, h, d), -7.0, dtype=torch.float16, device=DEV)
+    k[:, :nk], v[:, :nk] = rnd(b, nk, h, d, seed=92), rnd(b, nk, h, d, seed=93)
+    ref = _attn_ref(q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3)[:, :, :nk], v.permute(0, 2, 1, 3)[:, :, :nk], d ** -0.5)
+    got = _attn_d64(q, k, v, nk=nk)
+    assert bool(torch.isfinite(got).all())
+    close(got, ref, 3e-3, 3e-3, f"attention d{d}, {nk} keys")
+    if nk == 1:
+        close(got, v[:, 0].float()[:, :, None, :].expand(b, h, n, d), 1e-3, 1e-3, "one key: its value row")
+
+
 def test_attention_d64_generations_agree(monkeypatch):
     """Second-generation d_head-64 kernel (default) against the first-generation one (the 32-query kernel reached through the test hook):
     same inputs, results within fp16 rounding of each other on a 4096-token problem (Q pre-scaling and the deferred maximum change the
