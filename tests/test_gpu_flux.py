@@ -164,7 +164,7 @@ def test_bf16_gemm_epilogues_all_tile_families():
         ops.linear(x, w.half(), bias)   # mixed element types are rejected, not converted
 
 
-@pytest.mark.parametrize("b,h,nq,nk", [(1, 2, 300, 300), (2, 3, 128, 77), (1, 24, 1280, 1280)])
+@pytest.mark.parametrize("b,h,nq,nk", [(1, 2, 300, 300), (2, 3, 128, 77), (1, 24, 1280, 1280), (2, 24, 1500, 1024)])   # last: 288 workgroups = a full round + a key-split tail
 def test_bf16_attention_d128(b, h, nq, nk):
     from test_gpu_kernels import _attn_ref
     d = 128
