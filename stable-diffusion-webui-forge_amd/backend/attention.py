@@ -15,7 +15,11 @@ these adapters: their projection GEMMs write the kernel's layouts directly (back
 
 `mask` (both forms the reference accepts): a bool mask whose True entries attend, `[B, Nk]` (attention_basic, :74-78) or anything
 broadcastable to `[B, heads, Nq, Nk]` (SDPA); an additive float mask `[Nq, Nk]`, `[bs, Nq, Nk]` (attention_basic :79-85) or broadcastable to
-`[B, heads, Nq, Nk]`.  `attn_precision` is accepted and ignored: scores, softmax statistics and the output accumulate in fp32 always.
+`[B, heads, Nq, Nk]`.  A 2-D bool mask is the `[B, Nk]` key mask when its shape says so; when B == Nq makes that ambiguous the call raises.
+`attn_precision` is accepted and ignored: scores, softmax statistics and the output accumulate in fp32 always -- but q, k, v (and the
+probabilities fed to P.V) are fp16 OPERANDS here, where the reference's fp32-upcast path (`attn_precision = torch.float32`, :45-47, :64-67) would
+carry them in fp32; bf16 / fp32 inputs are converted to fp16 by the adapter (values beyond 65504 overflow: the UNet / VAE activations the
+reference feeds this function are fp16 already).
 """
 import torch
 
@@ -40,7 +44,11 @@ def _need_cuda(*ts):
 def _additive_mask(mask, b, heads, nq, nk, nkp, device):
     """-> (fp16 tensor with rows of nkp keys, (batch, head, query) element strides) for the kernel."""
     m = mask
-    if m.dtype == torch.bool and m.dim() >= 2 and m.shape[0] == b and m.dim() != 4 and m[0].numel() == nk:
+    if m.dtype == torch.bool and m.dim() == 2 and m.shape == (b, nk) and nq == b and b > 1:
+        # [B, Nk] key mask (attention_basic :74-78) and [Nq, Nk] SDPA mask have the same shape here and mean different things
+        raise ValueError(f"a 2-D bool mask of shape {tuple(m.shape)} is ambiguous when B == Nq == {b}: pass it as [B, 1, 1, Nk] (key mask) or "
+                         f"[1, 1, Nq, Nk] (per-query mask)")
+    if m.dtype == torch.bool and m.dim() >= 2 and m.shape[0] == b and m.dim() != 4 and m[0].numel() == nk and not (m.dim() == 2 and nq == b == 1):
         m = m.reshape(b, 1, 1, nk)                                    # attention_basic's 'b ... -> b (...)' key mask
     elif m.dim() == 2:
         m = m.reshape(1, 1, m.shape[0], m.shape[1])
@@ -77,6 +85,8 @@ def attention_function(q, k, v, heads, mask=None, attn_precision=None, skip_resh
     if dp is None:
         if heads != 1:
             raise NotImplementedError(f"head dim {d} > 160 with {heads} heads: the fused kernel covers d_head <= 160, the single-head form any width")
+        if mask is not None:
+            raise NotImplementedError(f"attention mask with a {d}-wide single head: the wide single-head kernels take no mask (the VAE passes none)")
         o = _single_head_tokens(q.reshape(b, nq, d), k.reshape(b, nk, d), v.reshape(b, nk, d))
         return o if not skip_reshape else o
     dev = q.device

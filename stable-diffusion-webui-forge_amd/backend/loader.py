@@ -185,7 +185,7 @@ def split_state_dict(sd):
     pred_source = "marker key" if "v_pred" in sd else "default"
     probe = UNET_PREFIX + "output_blocks.11.1.transformer_blocks.0.norm1.bias"
     if pred == "epsilon" and unet_config.get("context_dim") == 1024 and unet_config.get("in_channels") == 4 and not is_sdxl and probe in sd:
-        if float(sd[probe].float().std()) > 0.09:
+        if float(sd[probe].float().std(unbiased=False)) > 0.09:   # the population form, as huggingface_guess computes it
             pred, pred_source = "v_prediction", "SD2.x norm1.bias statistic (std > 0.09)"
     guess = {"unet_config": unet_config, "vae_config": vae_config, "is_sdxl": is_sdxl, "prediction_type": pred, "prediction_type_source": pred_source,
              "ztsnr": "ztsnr" in sd, "ignored": sorted({k.split(".")[0] for k in sd if not k.startswith((UNET_PREFIX, VAE_PREFIX))})}

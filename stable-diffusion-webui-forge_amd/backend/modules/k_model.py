@@ -108,7 +108,7 @@ class KModel:
             # Python hooks cannot be captured, and a ControlNet chain that needs Python per step arrives here with its residuals: eager
             return net.forward_packed(st["xcol"], st["t"], ctxc, bu, hh, ww, control, hooks, concat_term)
         active = [e for e in control_plan if e["active"]] if control_plan else []
-        gkey = key if not active else key + ("control",) + tuple(id(e["cm"]) for e in active)
+        gkey = key if not active else key + ("control",) + tuple(e["cm"].exec_serial for e in active)
 
         def run():
             # The ControlNet trunks read the SAME packed input and timestep buffers as the UNet (both are `calculate_input` of x and the

@@ -24,6 +24,8 @@ the captured graph, since the residuals change every step.  Hooks that need per-
 
 import os
 
+import itertools
+
 import torch
 
 from ... import hipops as ops
@@ -139,6 +141,9 @@ class ContextCache:
         self.label = None  # [Bu, time_embed_dim] or None
 
 
+_EXEC_SERIAL = itertools.count(1)   # process-wide: an executor's serial is never handed out twice (id() of a freed one can be)
+
+
 class IntegratedUNet2DConditionModel:
     encoder_only = False  # cnets/cldm.py's ControlNet re-uses this executor for its trunk (input blocks + middle block)
     TRUNK_PREFIXES = ("input_blocks.", "middle_block.", "time_embed.", "label_emb.")
@@ -156,6 +161,7 @@ class IntegratedUNet2DConditionModel:
         self.num_classes = config.get("num_classes")
         self._pad_bufs = {}  # (Bu, n_pad, C) -> persistent zero-padded LayerNorm output for ragged token counts (see _attn_block)
         self._arena = None
+        self.exec_serial = next(_EXEC_SERIAL)  # identity of this executor in graph keys (k_model.py): unlike id(), never re-used
         self.arena_epoch = 0  # bumped whenever the arena is re-allocated: graphs captured on the old one hold dangling pointers
         self._arena_bytes = arena_bytes
         self._ctx = ContextCache()
@@ -577,7 +583,8 @@ class IntegratedUNet2DConditionModel:
         norm = GroupNorm(num_groups=32, num_channels=gamma.numel(), eps=eps, weight=gamma, bias=beta, affine=True)
         r = wrapper(norm, x.permute(0, 3, 1, 2), to)
         h = r.permute(0, 2, 3, 1).to(torch.float16).contiguous()
-        return ops.silu(h, out=h)
+        # a wrapper that bypasses the norm hands x itself back (no copy above): SiLU out of place, x is still the ResBlock's skip input
+        return ops.silu(h) if h.data_ptr() == x.data_ptr() else ops.silu(h, out=h)
 
     def _res_wrapped(self, L, x, skip, emb_all, wrapper, to):
         """ResBlock with a group_norm_wrapper installed (eager, general path): both GroupNorms go through the wrapper."""
@@ -704,7 +711,7 @@ class IntegratedUNet2DConditionModel:
         if to is not None:
             to["block"] = ("last", 0)
         h = modify(h, "before")
-        if to is not None and "group_norm_wrapper" in to:
+        if to is not None and to.get("group_norm_wrapper") is not None:
             g = self._wrapped_norm(to["group_norm_wrapper"], "out.gn", h, 1e-5, to)       # unet.py:755-758
         else:
             g = ops.groupnorm(h, *self.w["out.gn"], 1e-5, silu=True)
@@ -752,7 +759,7 @@ class IntegratedUNet2DConditionModel:
         to = transformer_options
         if not to:
             return None
-        if to.get("patches") or to.get("patches_replace") or to.get("block_modifiers") or to.get("block_inner_modifiers") or "group_norm_wrapper" in to:
+        if to.get("patches") or to.get("patches_replace") or to.get("block_modifiers") or to.get("block_inner_modifiers") or to.get("group_norm_wrapper") is not None:
             return to
         return None
 

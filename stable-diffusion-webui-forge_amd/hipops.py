@@ -381,9 +381,23 @@ def stats_buffer(n, hw, c, device=None):
 
 def attach_stats(t, st):
     """Remember the producer's statistics on the tensor OBJECT (views and copies do not inherit them; whoever writes into the tensor in
-    place afterwards -- ControlNet residuals, Python hooks -- must call clear_stats)."""
-    t._fmx_gn_stats = st
+    place afterwards -- ControlNet residuals, Python hooks -- must call clear_stats).  The record carries the tensor's torch version counter
+    and address: an in-place torch edit nobody announced (a hook holding the NCHW view: `h.add_(...)`) bumps the counter, and `_attached_stats`
+    then ignores the stale record instead of normalising with it (C-ABI launches write through raw pointers and do not bump it: they call
+    clear_stats themselves)."""
+    t._fmx_gn_stats = None if st is None else (st, t._version, t.data_ptr())
     return t
+
+
+def _attached_stats(t):
+    rec = getattr(t, "_fmx_gn_stats", None)
+    if rec is None:
+        return None
+    st, version, ptr = rec
+    if version != t._version or ptr != t.data_ptr():
+        t._fmx_gn_stats = None
+        return None
+    return st
 
 
 def clear_stats(t):
@@ -415,9 +429,9 @@ def groupnorm(x, gamma, beta, eps, *, x1=None, silu=False, groups=32, out=None, 
         out = empty(tuple(x.shape[:-1]) + (c0 + c1,), torch.float16, x.device)
 
     if stats is None:
-        stats = getattr(x, "_fmx_gn_stats", None)
+        stats = _attached_stats(x)
     if stats1 is None and x1 is not None:
-        stats1 = getattr(x1, "_fmx_gn_stats", None)
+        stats1 = _attached_stats(x1)
 
     def run():
         s0 = stats if stats is not None else groupnorm_stats(x)

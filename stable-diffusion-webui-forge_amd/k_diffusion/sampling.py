@@ -573,32 +573,27 @@ def sample_dpmpp_3m_sde(model, x, sigmas, extra_args=None, callback=None, disabl
 
 # ---- DPM-Solver (fast / adaptive) ----------------------------------------------------------------------------------------------------
 class PIDStepSizeController:
-    """PID controller for the adaptive step size (sampling.py:368-394)."""
+    """Step-size control of DPM-Solver adaptive (behaviour of sampling.py:368-394): the proposed factor is a product of powers of the last three
+    inverse error norms -- exponents from the P / I / D coefficients divided by the solver order -- squashed by 1 + atan(f - 1); a step is
+    accepted when the factor reaches `accept_safety`, and only accepted steps enter the history.  `h` is the running step (host float / 0-dim)."""
 
     def __init__(self, h, pcoeff, icoeff, dcoeff, order=1, accept_safety=0.81, eps=1e-8):
-        self.h = h
-        self.b1 = (pcoeff + icoeff + dcoeff) / order
-        self.b2 = -(pcoeff + 2 * dcoeff) / order
-        self.b3 = dcoeff / order
-        self.accept_safety = accept_safety
-        self.eps = eps
-        self.errs = []
-
-    def limiter(self, x):
-        return 1 + math.atan(x - 1)
+        self.h, self.accept_safety, self.eps = h, accept_safety, eps
+        self.exponents = ((pcoeff + icoeff + dcoeff) / order, -(pcoeff + 2 * dcoeff) / order, dcoeff / order)
+        self.history = None   # inverse errors of [this proposal, last accepted, the accepted one before]
 
     def propose_step(self, error):
-        inv_error = 1 / (float(error) + self.eps)
-        if not self.errs:
-            self.errs = [inv_error, inv_error, inv_error]
-        self.errs[0] = inv_error
-        factor = self.limiter(self.errs[0] ** self.b1 * self.errs[1] ** self.b2 * self.errs[2] ** self.b3)
-        accept = factor >= self.accept_safety
-        if accept:
-            self.errs[2] = self.errs[1]
-            self.errs[1] = self.errs[0]
-        self.h *= factor
-        return accept
+        inv = 1.0 / (float(error) + self.eps)
+        self.history = [inv, inv, inv] if self.history is None else [inv] + self.history[1:]
+        raw = 1.0
+        for e, w in zip(self.history, self.exponents):
+            raw *= e ** w
+        factor = 1.0 + math.atan(raw - 1.0)
+        accepted = factor >= self.accept_safety
+        if accepted:
+            self.history = [self.history[0], self.history[0], self.history[1]]
+        self.h = self.h * factor
+        return accepted
 
 
 class DPMSolver:
@@ -606,16 +601,16 @@ class DPMSolver:
     tensors (0-dim), exactly the arithmetic of the reference; each stage value is one fused linear combination of (x, eps, eps_r1, ...)."""
 
     def __init__(self, model, extra_args=None, eps_callback=None, info_callback=None):
-        self.model = model
-        self.extra_args = {} if extra_args is None else extra_args
-        self.eps_callback = eps_callback
-        self.info_callback = info_callback
+        self.model, self.extra_args = model, (extra_args or {})
+        self.eps_callback, self.info_callback = eps_callback, info_callback
 
-    def t(self, sigma):
-        return -sigma.log()
+    @staticmethod
+    def t(sigma):
+        return sigma.log().neg()
 
-    def sigma(self, t):
-        return t.neg().exp()
+    @staticmethod
+    def sigma(t):
+        return torch.exp(-t)
 
     def eps(self, eps_cache, key, x, t, *args, **kwargs):
         if key in eps_cache:

@@ -125,3 +125,36 @@ def test_controlnet_graph_entry_declines_links_that_need_python_per_step(why):
         c2.timestep_range, c2.model_sampling_current = cn.timestep_range, cn.model_sampling_current
         cn = c2
     assert cn.graph_entry(5.0, 4, 8, 8, ctx, None, 2) is None
+
+
+def test_attached_groupnorm_statistics_die_with_an_unannounced_in_place_edit():
+    """statistics a producer left on a tensor object are ignored once torch's version counter says the tensor was edited in place
+    (a hook holding the NCHW view), instead of silently normalising with stale sums."""
+    from forge_amd import hipops
+    t = torch.zeros(2, 4, 4, 8)
+    st = hipops.GnStats(torch.zeros(2, 1, 8, 2), 1)
+    hipops.attach_stats(t, st)
+    assert hipops._attached_stats(t) is st
+    t.permute(0, 3, 1, 2).add_(1.0)          # the NCHW view a Python hook would hold
+    assert hipops._attached_stats(t) is None and t._fmx_gn_stats is None
+    hipops.attach_stats(t, st)
+    hipops.clear_stats(t)
+    assert hipops._attached_stats(t) is None
+    hipops.attach_stats(t, None)
+    assert hipops._attached_stats(t) is None
+
+
+def test_executor_serials_are_never_reused():
+    """captured ControlNet graphs are keyed on the executors' serial numbers, which a later executor cannot inherit the
+    way it can inherit a freed object's id()."""
+    import itertools
+    from forge_amd.backend.nn import unet
+    a, b = next(unet._EXEC_SERIAL), next(unet._EXEC_SERIAL)
+    assert b == a + 1 and isinstance(unet._EXEC_SERIAL, itertools.count)
+
+
+def test_ambiguous_two_dimensional_bool_mask_is_refused():
+    from forge_amd.backend import attention
+    m = torch.ones(4, 4, dtype=torch.bool)
+    with pytest.raises(ValueError, match="ambiguous"):
+        attention._additive_mask(m, 4, 2, 4, 4, 64, torch.device("cpu"))
