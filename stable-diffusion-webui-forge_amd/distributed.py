@@ -2,7 +2,8 @@
 xGMI on ROCm; "gloo" in the CPU tests).  The reference is single-process single-GPU; images in a batch
 are independent (no cross-sample op anywhere on the path), so the only communication per JOB is
   1. broadcast of the conditioning from rank 0 (text-cond [B,77,Dc] (+ pooled vector) for cond and uncond), and
-  2. gather of the final latents (or decoded images) on rank 0;
+  2. gather of the final latents and of the decoded uint8 images on rank 0 (`modules.processing.process_images_sharded` is the product entry
+     that does 1 - 2 around the ordinary single-device job);
 nothing is exchanged inside the step loop.  Seeds are seed + global image index, so results do not depend on the sharding.
 """
 import torch
@@ -74,20 +75,29 @@ def slice_conditioning(cond, lo, hi):
 
 
 def gather_latents(local, total, dst=0):
-    """All ranks pass their [b_local, ...] tensor; rank `dst` gets the [total, ...] batch in global order (others None).
-    Uses all_gather on equal-size padded shards (RCCL has no native gatherv)."""
+    """All ranks pass their [b_local, ...] tensor (rank r holds images shard_range(total, r, world)); rank `dst` gets the [total, ...] batch in
+    global order, every other rank None.  A true gather -- only `dst` receives (RCCL / gloo `gather` of equal-size padded shards; there is no
+    native gatherv) -- not the all_gather of round 2, which delivered the whole batch to every rank."""
+    return gather_batch(local, total, 1, dst)
+
+
+def gather_batch(local, batch, n_iter=1, dst=0):
+    """Gather of a job of `n_iter` iterations of `batch` images: rank r holds, iteration-major, its share shard_range(batch, r, world) of every
+    iteration ([n_iter * b_r, ...]); rank `dst` returns [n_iter * batch, ...] in the order of the single-process job, other ranks None."""
     rank, ws = world()
     if ws == 1:
         return local
-    per = -(-total // ws)
+    per = -(-batch // ws) * n_iter
     pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[:local.shape[0]] = local
-    bufs = [torch.empty_like(pad) for _ in range(ws)]
-    dist.all_gather(bufs, pad)
+    bufs = [torch.empty_like(pad) for _ in range(ws)] if rank == dst else None
+    dist.gather(pad, bufs, dst=dst)
     if rank != dst:
         return None
     parts = []
-    for r in range(ws):
-        lo, hi = shard_range(total, r, ws)
-        parts.append(bufs[r][:hi - lo])
+    for n in range(n_iter):
+        for r in range(ws):
+            lo, hi = shard_range(batch, r, ws)
+            b_r = hi - lo
+            parts.append(bufs[r][n * b_r:(n + 1) * b_r])
     return torch.cat(parts)

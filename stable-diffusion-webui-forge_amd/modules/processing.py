@@ -283,13 +283,21 @@ def process_images(p) -> Processed:
     return process_images_inner(p)
 
 
-@torch.inference_mode()
-def process_images_inner(p) -> Processed:
+def _job_seeds(p, total):
+    """processing.py:889-899: (all_seeds, all_subseeds) of a job of `total` images; -1 draws a random base."""
     seed = int(p.seed) if p.seed is not None and int(p.seed) != -1 else int(np.random.randint(0, 2 ** 31 - 1))
-    total = p.batch_size * p.n_iter
-    p.all_seeds = [seed + (i if p.subseed_strength == 0 else 0) for i in range(total)]  # :894: a variation batch shares ONE seed ...
     subseed = int(p.subseed) if p.subseed is not None and int(p.subseed) != -1 else int(np.random.randint(0, 2 ** 31 - 1))
-    p.all_subseeds = [subseed + i for i in range(total)]                                 # ... and varies the subseed (:896-899)
+    return ([seed + (i if p.subseed_strength == 0 else 0) for i in range(total)],   # :894: a variation batch shares ONE seed ...
+            [subseed + i for i in range(total)])                                      # ... and varies the subseed (:896-899)
+
+
+@torch.inference_mode()
+def process_images_inner(p, seed_plan=None) -> Processed:
+    """seed_plan = (all_seeds, all_subseeds) fixes the per-image seeds from outside: a rank of a sharded job runs ITS images of the global
+    job with the seeds the single-process job would have given them (process_images_sharded)."""
+    total = p.batch_size * p.n_iter
+    p.all_seeds, p.all_subseeds = seed_plan if seed_plan is not None else _job_seeds(p, total)
+    assert len(p.all_seeds) == total and len(p.all_subseeds) == total
     dev = p.sd_model.device
     lc = p.sd_model.forge_objects.vae.latent_channels if p.sd_model.forge_objects.vae is not None else getattr(p.sd_model, "latent_channels", 4)
     images, lat_all, dec_all = [], [], []
@@ -319,3 +327,98 @@ def process_images_inner(p) -> Processed:
             images.append(arr.astype(np.uint8))  # truncation, as the reference (:1039-1040)
     return Processed(images=images, latents=torch.cat(lat_all), seeds=p.all_seeds,
                      decoded=torch.cat(dec_all) if dec_all else None)
+
+
+# ---- one job over the GPUs of a node ------------------------------------------------------------------------------------------------------
+def _to_u8(images, device):
+    """list of HxWx3 uint8 arrays -> [b, H, W, 3] uint8 tensor on `device` (empty list: a [0]-tensor the gather pads)"""
+    if not images:
+        return None
+    return torch.from_numpy(np.stack(images)).to(device)
+
+
+def process_images_sharded(p, gather_images=True, dst=0) -> Processed:
+    """`process_images` for a job whose images are spread over the ranks of the default process group (one process per GPU; backend "nccl" =
+    RCCL over xGMI, "gloo" in the CPU tests).  It splits the reference's batch loop (modules/processing.py:924-1012) ACROSS ranks instead of
+    walking it on one device: images are independent, so
+
+      1. rank `dst` owns the job: its conditioning (p.c / p.uc for all batch_size * n_iter images: tensors or {"crossattn", "vector"} dicts) and
+         its seed are broadcast -- the other ranks call this function with the same scalar parameters and c = uc = None;
+      2. of every iteration's `batch_size` images rank r samples (and decodes) the contiguous share `shard_range(batch_size, r, world)` with the
+         seeds / subseeds the single-process job gives those images (seed + global index), so the result does not depend on the sharding;
+      3. latents (fp32) and, with `gather_images`, the decoded uint8 images are gathered on rank `dst` in global order (`dist.gather` of equal,
+         padded shards: only `dst` receives).
+
+    Nothing is exchanged inside the step loop.  Returns, on rank `dst`, the `Processed` of the whole job (`decoded` fp32 tensors stay local
+    and are not gathered: 12 MB per 1024^2 image against 3 MB as uint8); on every other rank the `Processed` of its own share.  With one
+    rank (no process group) it is `process_images`."""
+    from .. import distributed as fdist
+    import torch.distributed as dist
+    rank, ws = fdist.world()
+    if ws == 1:
+        return process_images(p)
+    if isinstance(p, StableDiffusionProcessingImg2Img):
+        raise NotImplementedError("process_images_sharded splits txt2img jobs; shard an img2img job by its init images on the caller's side")
+    if p.prompt is not None and p.c is None:
+        if rank == dst:
+            p.setup_conds()      # prompts are encoded once, on the rank that owns the job
+    for name, cnd in (("c", p.c), ("uc", p.uc), ("hr_c", p.hr_c), ("hr_uc", p.hr_uc)):
+        if rank == dst and cnd is not None and not isinstance(cnd, (torch.Tensor, dict)):
+            raise NotImplementedError(f"p.{name} is a {type(cnd).__name__}: the sharded entry broadcasts ready conditioning tensors "
+                                      f"(prompt-editing schedules are host objects; reconstruct them per rank or pass tensors)")
+    dev = p.sd_model.device
+    B, total = p.batch_size, p.batch_size * p.n_iter
+    # ---- 1. job header + conditioning from the owner ----------------------------------------------------------------------------------
+    header = [(_job_seeds(p, total), type(p.c).__name__ if p.c is not None else None) if rank == dst else None]
+    dist.broadcast_object_list(header, src=dst)
+    (all_seeds, all_subseeds), c_kind = header[0]
+    c, uc = fdist.broadcast_conditioning(p.c if rank == dst else None, p.uc if rank == dst else None, dev, src=dst)
+    hr_c, hr_uc = fdist.broadcast_conditioning(p.hr_c if rank == dst else None, p.hr_uc if rank == dst else None, dev, src=dst)
+    lo, hi = fdist.shard_range(B, rank, ws)
+    mine = [n * B + i for n in range(p.n_iter) for i in range(lo, hi)]          # global indices of this rank's images, iteration-major
+
+    def take(cnd):
+        if cnd is None:
+            return None
+        idx = torch.as_tensor(mine, dtype=torch.long, device=dev)
+        if isinstance(cnd, dict):
+            out = {k: v.index_select(0, idx.to(v.device)).contiguous() for k, v in cnd.items()}
+            if c_kind == "DictWithShape":
+                from .prompt_parser import DictWithShape
+                return DictWithShape(out)
+            return out
+        return cnd.index_select(0, idx.to(cnd.device)).contiguous()
+
+    # ---- 2. this rank's share through the ordinary single-device job ------------------------------------------------------------------
+    local = None
+    if hi > lo:
+        import copy
+        q = copy.copy(p)
+        q.batch_size = hi - lo
+        q.c, q.uc, q.hr_c, q.hr_uc = take(c), take(uc), take(hr_c), take(hr_uc)
+        q.prompt = None
+        shared.sd_model = p.sd_model
+        local = process_images_inner(q, seed_plan=([all_seeds[i] for i in mine], [all_subseeds[i] for i in mine]))
+        p.sampler, p.rng = q.sampler, q.rng
+    p.all_seeds, p.all_subseeds = all_seeds, all_subseeds
+    # ---- 3. gather on the owner ---------------------------------------------------------------------------------------------------------
+    want_images = bool(gather_images and p.do_decode and p.sd_model.forge_objects.vae is not None)
+    lat_local = local.latents.to(dev).float().contiguous() if local is not None else None
+    u8_local = _to_u8(local.images, dev) if (local is not None and want_images) else None
+    # a rank with no image of this job (batch_size < world) still takes part in the gather: it learns the per-image shapes from the others
+    shapes = [None] * ws
+    dist.all_gather_object(shapes, None if local is None else (tuple(lat_local.shape[1:]), None if u8_local is None else tuple(u8_local.shape[1:])))
+    lat_shape, img_shape = next(sh for sh in shapes if sh is not None)
+    if lat_local is None:
+        lat_local = torch.zeros((0,) + lat_shape, device=dev)
+    lat = fdist.gather_batch(lat_local, B, p.n_iter, dst=dst)
+    images = None
+    if want_images:
+        if u8_local is None:
+            u8_local = torch.zeros((0,) + img_shape, dtype=torch.uint8, device=dev)
+        got = fdist.gather_batch(u8_local, B, p.n_iter, dst=dst)
+        if rank == dst:
+            images = [a for a in got.cpu().numpy()]
+    if rank != dst:
+        return local if local is not None else Processed(images=[], latents=lat_local, seeds=[])
+    return Processed(images=images if images is not None else [], latents=lat, seeds=all_seeds, decoded=None)

@@ -1,0 +1,129 @@
+"""CPU, world sizes 2 and 3 over gloo: `forge_amd.modules.processing.process_images_sharded` -- the product entry that splits the reference's
+batch loop (modules/processing.py:924-1012) across ranks -- against the single-process `process_images` of the same job, bit for bit.
+
+The job goes through the REAL processing code on every rank (seed plan, ImageRNG with the reference's CPU noise source, conditioning slicing,
+decode, clamp / *255 / uint8 truncation, the gathers); only the two things that need the GPU are stand-ins: the sampler (`sample` = a
+deterministic per-image function of the noise and the conditioning) and the VAE (`decode_first_stage` = a fixed upsample + channel mix).  On a
+GPU node the same function runs over RCCL (backend "nccl")."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make_job(batch, n_iter, with_dict, cfg1=False, give_conds=True):
+    import forge_amd  # noqa: F401
+    from forge_amd.modules import processing, shared
+    from forge_amd.modules.prompt_parser import DictWithShape
+
+    class _Vae:
+        latent_channels = 4
+
+    class _Objs:
+        vae = _Vae()
+
+        def shallow_copy(self):
+            return self
+
+    class _Engine:
+        device = torch.device("cpu")
+        forge_objects = _Objs()
+        forge_objects_after_applying_lora = _Objs()
+        is_sdxl = False
+
+        def decode_first_stage(self, x):
+            up = torch.nn.functional.interpolate(x, scale_factor=8, mode="nearest")
+            mix = torch.tensor([[0.3, -0.2, 0.1, 0.4], [0.1, 0.5, -0.3, 0.2], [-0.4, 0.2, 0.6, 0.1]])
+            return torch.einsum("oc,bchw->bohw", mix, up) * 0.5
+
+    class _Job(processing.StableDiffusionProcessingTxt2Img):
+        def sample(self, conditioning, unconditional_conditioning, seeds, subseeds=None, subseed_strength=0.0, prompts=None):
+            x = self.rng.next()                                   # the reference's per-image CPU noise: seed + global index
+            c = conditioning["crossattn"] if isinstance(conditioning, dict) else conditioning
+            s = c.float().mean(dim=(1, 2)).view(-1, 1, 1, 1)
+            if isinstance(conditioning, dict):
+                s = s + conditioning["vector"].float().sum(dim=1).view(-1, 1, 1, 1)
+            if unconditional_conditioning is not None:
+                u = unconditional_conditioning["crossattn"] if isinstance(unconditional_conditioning, dict) else unconditional_conditioning
+                s = s - 0.5 * u.float().std(dim=(1, 2)).view(-1, 1, 1, 1)
+            return torch.tanh(x * 0.7 + s) + 0.01 * torch.tensor([float(v % 97) for v in seeds]).view(-1, 1, 1, 1)
+
+    total = batch * n_iter
+    g = torch.Generator().manual_seed(11)
+    c = torch.randn(total, 154, 8, generator=g).half()
+    uc = torch.randn(total, 77, 8, generator=g).half()
+    if with_dict:
+        c = DictWithShape({"crossattn": c, "vector": torch.randn(total, 6, generator=g)})
+        uc = DictWithShape({"crossattn": uc, "vector": torch.zeros(total, 6)})
+    if cfg1:
+        uc = None
+    shared.opts.randn_source = "CPU"
+    return _Job(sd_model=_Engine(), c=c if give_conds else None, uc=uc if give_conds else None, seed=4242, batch_size=batch, n_iter=n_iter,
+                steps=4, cfg_scale=1.0 if cfg1 else 7.0, width=32, height=24)
+
+
+def _worker(rank, world, port, batch, n_iter, with_dict, cfg1, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from forge_amd.modules import processing
+        p = _make_job(batch, n_iter, with_dict, cfg1, give_conds=(rank == 0))      # only the owner has the conditioning
+        res = processing.process_images_sharded(p)
+        if rank == 0:
+            q.put((rank, res.latents.clone(), np.stack(res.images), list(res.seeds)))
+        else:
+            q.put((rank, int(res.latents.shape[0]), len(res.images), list(res.seeds)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,batch,n_iter,with_dict,cfg1", [(2, 5, 1, False, False), (3, 5, 2, True, False), (3, 2, 1, False, True),
+                                                               (2, 4, 2, True, True)])
+def test_sharded_job_equals_the_single_process_job_bit_for_bit(world, batch, n_iter, with_dict, cfg1):
+    from forge_amd import distributed as fdist
+    from forge_amd.modules import processing
+    want = processing.process_images(_make_job(batch, n_iter, with_dict, cfg1))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, batch, n_iter, with_dict, cfg1, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in procs:
+        r = q.get(timeout=180)
+        res[r[0]] = r[1:]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    lat, imgs, seeds = res[0]
+    assert seeds == want.seeds == [4242 + i for i in range(batch * n_iter)]
+    assert lat.shape == want.latents.shape and torch.equal(lat, want.latents), "gathered latents differ from the single-process job"
+    assert imgs.shape == np.stack(want.images).shape and np.array_equal(imgs, np.stack(want.images))
+    for r in range(1, world):                                   # the other ranks keep only their own share (a true gather, not all_gather)
+        lo, hi = fdist.shard_range(batch, r, world)
+        assert res[r][0] == (hi - lo) * n_iter and res[r][1] == (hi - lo) * n_iter
+
+
+def test_sharded_entry_is_process_images_without_a_process_group():
+    from forge_amd.modules import processing
+    a = processing.process_images_sharded(_make_job(3, 1, False))
+    b = processing.process_images(_make_job(3, 1, False))
+    assert torch.equal(a.latents, b.latents) and a.seeds == b.seeds
