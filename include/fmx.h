@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define FMX_ABI_VERSION 5
+#define FMX_ABI_VERSION 6
 
 #define FMX_OK 0
 #define FMX_E_BADARG 10001   /* shape / alignment / null-pointer contract violated */
@@ -315,6 +315,11 @@ int fmx_im2col3x3_smallc(const void* x, int32_t ldx, int32_t n, int32_t c, int32
 /* VAE output: y fp16 NHWC [b*h*w][ld] (first c channels) -> clamp((y+1)/2, 0, 1) fp32 NHWC [b][h][w][c] */
 int fmx_vae_unpack_image(const void* y, int32_t ld, int64_t npix, int32_t c, float* out, void* stream);
 
+/* *count (device int32) = how many of the n fp16 values at x (16-byte aligned) are inf or NaN.  The VAE's overflow guard: an fp16 decode whose
+ * output is not finite is repeated in bfloat16 (trained SDXL VAE weights leave fp16's range; the reference avoids fp16 there altogether,
+ * backend/memory_management.py:190-205). */
+int fmx_count_nonfinite_f16(const void* x, int64_t n, int32_t* count, void* stream);
+
 /* Posterior sample of the VAE encoder (backend/nn/vae.py:16-29 DiagonalGaussianDistribution.sample, :312-313 process_in):
  *   out[b][c][p] = (mean + exp(0.5 * clamp(logvar, -30, 20)) * noise[b][c][p] - shift) * scale
  * moments: fp16 [B*npix][ld], channels 0..lc-1 = mean, lc..2lc-1 = logvar (the quant_conv output, NHWC);
@@ -346,6 +351,26 @@ int fmx_flux_qk_norm_rope_bf16(const void* qkv, int64_t ld_qkv, const void* q_sc
                                int32_t row_off, int32_t l_pad, float eps, void* stream);
 int fmx_timestep_embedding_bf16(const float* t, void* emb, int32_t b, int32_t dim, float max_period, void* stream);
 int fmx_silu_bf16(const void* x, void* y, int64_t n, void* stream);
+
+/* bfloat16 build of the VAE (ABI 6).  The reference decodes in bf16 wherever the part supports it and in fp32 otherwise
+ * (backend/memory_management.py:190-205 VAE_DTYPES, :840-855 vae_dtype(); --vae-in-fp16 / --vae-in-bf16 select by hand): trained SDXL VAE
+ * weights overflow fp16 in the decoder's upper levels.  Same kernels, same contracts as the _f16 entry points of the same name ("fp16" reads
+ * "bf16": activations, weights, norm parameters; statistics, accumulation and softmax stay fp32); the 3x3 im2col of tiny channel counts
+ * (fmx_im2col3x3_smallc) moves 16-bit words and serves both types. */
+int fmx_gemm_conv_stats_bf16(const fmx_gemm_args* args /* host */, float* partial, int32_t max_chunks, int32_t fallback_chunks,
+                             int32_t* chunks_out /* host */, void* stream);
+int fmx_groupnorm_stats_bf16(const void* x, int32_t c, int64_t ld, int32_t n, int32_t hw, float* partial, int32_t nchunks, void* stream);
+int fmx_groupnorm_apply_bf16(const void* x0, const void* x1, int32_t c0, int32_t c1, int64_t ld0, int64_t ld1, int32_t n, int32_t hw,
+                             const float* partial0, int32_t nchunks0, const float* partial1, int32_t nchunks1, int32_t groups, float eps,
+                             const void* gamma, const void* beta, int32_t silu, float* scale_shift, void* y, void* stream);
+int fmx_attention_single_head512_bf16(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs, const void* vt,
+                                      int64_t vt_bs, int64_t vt_ds, void* o, int64_t o_bs, int64_t o_rs, int32_t batch, int32_t nq, int32_t nk,
+                                      int32_t nk_pad, float scale, void* stream);
+int fmx_vae_pack_latent_bf16(const float* z, float scaling_factor, float shift, int32_t b, int32_t c, int32_t h, int32_t w,
+                             void* out, int32_t ld, void* stream);
+int fmx_vae_unpack_image_bf16(const void* y, int32_t ld, int64_t npix, int32_t c, float* out, void* stream);
+int fmx_vae_sample_posterior_bf16(const void* moments, int32_t ld, const float* noise, int32_t b, int32_t lc, int64_t npix, float scale,
+                                  float shift, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * HIP-graph helpers: capture everything launched on `stream` between begin/end into an executable graph.

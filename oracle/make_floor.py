@@ -20,6 +20,7 @@ tests/parity.py turns that into the tolerances of the native path (max(1e-3, fac
     python -m oracle.make_floor --only sdxl     # SDXL full-size forward floor                                (~8 min)
     python -m oracle.make_floor --only config3  # + fixture sdxl_config3.pt: SDXL 1024^2, one image, 30-step DPM++ 2M + 1024^2 VAE decode (~30 min)
     python -m oracle.make_floor --only vae1024  # 1024^2 decode only (fixture + floor)
+    python -m oracle.make_floor --only vae_bf16 # bfloat16 floors of the VAE fixtures + the fp16-overflow fixture tiny_vae_overflow.pt
 """
 import argparse
 import json
@@ -297,6 +298,63 @@ def gen_vae1024(lat=None, tag="sdxl_vae1024.pt"):
     return d32
 
 
+OVERFLOW_KEY, OVERFLOW_SCALE = "decoder.mid.block_1.conv1.weight", 6.0e4
+
+
+def overflow_vae_state_dict(vcfg=None):
+    """The tiny VAE's synthetic decoder with ONE weight scaled so that a convolution output leaves fp16's range (|x| up to ~1e5 >> 65 504) on
+    its way to a GroupNorm -- what trained SDXL VAE weights do in the decoder's upper levels.  fp32 and bfloat16 (8 exponent bits) carry it and
+    the GroupNorm brings it back; an fp16 pipeline turns it into inf -> NaN."""
+    vcfg = vcfg or synth.TINY_VAE_CONFIG
+    sd = synth.synth_vae_decoder_state_dict(vcfg, seed=1)
+    sd[OVERFLOW_KEY] = sd[OVERFLOW_KEY] * OVERFLOW_SCALE
+    return sd
+
+
+def gen_vae_bf16():
+    """bfloat16 floors of the VAE fixtures (the reference's own VAE type on bf16-capable parts, backend/memory_management.py:190-205) and
+    the fp16-overflow fixture tests/golden/tiny_vae_overflow.pt: the REAL reference decoder in fp32 / bf16 / fp16 on CPU."""
+    out = {}
+    vcfg = synth.TINY_VAE_CONFIG
+
+    # 1. the existing tiny fixture in bf16
+    g = _load("tiny_vae_decode.pt")
+    vae = ref_import.build_ref_vae(vcfg)
+    vae.load_state_dict(synth.synth_vae_decoder_state_dict(vcfg, seed=1), strict=False)
+    with torch.no_grad():
+        out["tiny_vae_decode.pt:decode@bf16"] = metrics(vae.to(torch.bfloat16).decode(g["z"].to(torch.bfloat16)).float(), g["decode"])
+    # 2. the overflow fixture: 32x32 latents -> 64x64 images (every level's GroupNorm takes its statistics from a 256-row GEMM tile)
+    vae = ref_import.build_ref_vae(vcfg)
+    vae.load_state_dict(overflow_vae_state_dict(vcfg), strict=False)
+    z = torch.randn(2, 4, 32, 32, generator=torch.Generator("cpu").manual_seed(91)) * 0.9
+    with torch.no_grad():
+        d32 = vae.float().decode(z)
+        # how far outside fp16 the decoder goes: the scaled convolution's own output
+        seen = {}
+        hook = vae.decoder.mid.block_1.conv1.register_forward_hook(lambda m, i, o: seen.__setitem__("absmax", float(o.abs().max())))
+        vae.decode(z)
+        hook.remove()
+        d16 = vae.half().decode(z.half()).float()
+        dbf = vae.to(torch.bfloat16).decode(z.to(torch.bfloat16)).float()
+    assert seen["absmax"] > 65504, seen
+    assert not bool(torch.isfinite(d16).all()), "the fixture is supposed to overflow the reference's own fp16 run"
+    torch.save({"z": z, "decode": d32, "conv_absmax": seen["absmax"], "scaled_key": OVERFLOW_KEY, "scale": OVERFLOW_SCALE,
+                "reference_fp16_nonfinite_fraction": float((~torch.isfinite(d16)).float().mean())}, os.path.join(GOLD, "tiny_vae_overflow.pt"))
+    out["tiny_vae_overflow.pt:decode@bf16"] = metrics(dbf, d32)
+    print("overflow fixture: conv output absmax %.3g, reference fp16 non-finite fraction %.3f" % (seen["absmax"], float((~torch.isfinite(d16)).float().mean())))
+    # 3. the 1024^2 SDXL decode in bf16 (same samples as the fp16 floor: every 4th pixel + one crop)
+    g = _load("sdxl_vae1024.pt")
+    vae = _sdxl_vae().to(torch.bfloat16)
+    t0 = time.time()
+    with torch.no_grad():
+        d = vae.decode(vae.process_out(g["latent"].to(torch.bfloat16))).float()
+    print("vae 1024^2 decode: reference bf16 %.0f s" % (time.time() - t0))
+    got = torch.cat([d[:, :, ::4, ::4].reshape(-1), d[:, :, 448:576, 448:576].reshape(-1)])
+    want = torch.cat([g["decoded_s4"].reshape(-1), g["decoded_crop"].reshape(-1)])
+    out["sdxl_vae1024.pt:decoded@bf16"] = metrics(got, want)
+    update(out)
+
+
 def floors_sdxl_full():
     cfg = synth.SDXL_UNET_CONFIG
     g = _load("sdxl_full_fwd.pt")
@@ -452,6 +510,8 @@ def main():
         floors_sdxl_full()
     if a.only == "vae1024":
         gen_vae1024()
+    if a.only == "vae_bf16":
+        gen_vae_bf16()
     if a.only == "config3":
         gen_config3(a.steps)
 

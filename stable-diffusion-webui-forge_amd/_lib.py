@@ -92,6 +92,7 @@ SIGNATURES = {
     "fmx_im2col3x3_smallc": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "fmx_vae_unpack_image": [_vp, _i32, _i64, _i32, _vp, _vp],
     "fmx_blend_masked": [_vp, _vp, _vp, _vp, _vp, _i64, _vp],
+    "fmx_count_nonfinite_f16": [_vp, _i64, _vp, _vp],
     "fmx_vae_sample_posterior": [_vp, _i32, _vp, _i32, _i32, _i64, _f32, _f32, _vp, _vp],
     "fmx_philox_randn": [C.c_uint64, C.c_uint32, _vp, _vp, _i64, _vp],
     "fmx_graph_begin": [_vp],
@@ -110,6 +111,11 @@ for _n in ("fmx_gemm_conv", "fmx_attention", "fmx_softmax_rows", "fmx_layernorm"
            "fmx_layernorm_mod", "fmx_flux_qk_norm_rope", "fmx_silu"):
     SIGNATURES[_n + "_bf16"] = SIGNATURES[_n + "_f16"]
 SIGNATURES["fmx_timestep_embedding_bf16"] = SIGNATURES["fmx_timestep_embedding"]
+# bfloat16 build of the VAE (ABI 6)
+for _n in ("fmx_gemm_conv_stats", "fmx_groupnorm_stats", "fmx_groupnorm_apply", "fmx_attention_single_head512"):
+    SIGNATURES[_n + "_bf16"] = SIGNATURES[_n + "_f16"]
+for _n in ("fmx_vae_pack_latent", "fmx_vae_unpack_image", "fmx_vae_sample_posterior"):
+    SIGNATURES[_n + "_bf16"] = SIGNATURES[_n]
 
 
 def build(force=False, verbose=False):
@@ -148,7 +154,7 @@ def lib():
             fn.restype = C.c_int
         handle.fmx_last_error.argtypes = []
         handle.fmx_last_error.restype = C.c_char_p
-        if handle.fmx_abi_version() != 5:
+        if handle.fmx_abi_version() != 6:
             raise FmxError("libfmx ABI version mismatch")
         _lib = handle
     return _lib

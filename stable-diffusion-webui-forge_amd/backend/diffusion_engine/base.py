@@ -115,9 +115,11 @@ class TokenizedPrompts:
         self.is_negative_prompt, self.all_empty = is_negative_prompt, all_empty
 
 
-def build_engine(unet_config, unet_state_dict, vae_config=None, vae_state_dict=None, device="cuda", prediction_type="epsilon", ztsnr=False):
+def build_engine(unet_config, unet_state_dict, vae_config=None, vae_state_dict=None, device="cuda", prediction_type="epsilon", ztsnr=False,
+                 vae_dtype=torch.float16):
     unet = IntegratedUNet2DConditionModel(unet_config, unet_state_dict, device=device)
-    vae = IntegratedAutoencoderKL(vae_config, vae_state_dict, device=device) if vae_config is not None else None
+    # vae_dtype: float16 (guarded: falls back to bfloat16 on overflow) or bfloat16; `memory_management.vae_dtype()` answers the reference's question
+    vae = IntegratedAutoencoderKL(vae_config, vae_state_dict, device=device, dtype=vae_dtype) if vae_config is not None else None
     return ForgeDiffusionEngine(unet, vae, is_sdxl=unet_config.get("adm_in_channels") is not None, prediction_type=prediction_type, ztsnr=ztsnr)
 
 
@@ -152,8 +154,9 @@ class FluxEngine:
     encode_first_stage = ForgeDiffusionEngine.encode_first_stage
 
 
-def build_flux_engine(flux_config, state_dict, device="cuda", vae_config=None, vae_state_dict=None, dtype=torch.float16, seq_len=4096, schnell=None):
+def build_flux_engine(flux_config, state_dict, device="cuda", vae_config=None, vae_state_dict=None, dtype=torch.float16, seq_len=4096, schnell=None,
+                      vae_dtype=torch.float16):
     from ..nn.flux import IntegratedFluxTransformer2DModel
     net = IntegratedFluxTransformer2DModel(flux_config, state_dict, device=device, dtype=dtype)
-    vae = IntegratedAutoencoderKL(vae_config, vae_state_dict, device=device) if vae_config is not None else None
+    vae = IntegratedAutoencoderKL(vae_config, vae_state_dict, device=device, dtype=vae_dtype) if vae_config is not None else None
     return FluxEngine(net, seq_len=seq_len, vae=vae, schnell=schnell)

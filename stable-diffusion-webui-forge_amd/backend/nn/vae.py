@@ -7,8 +7,12 @@ loader, GroupNorm(eps 1e-6)+SiLU fused, residual adds in the conv epilogue.  The
 (C = 512, N up to 16 384; attention.py:412-422) runs as S = QK^T (GEMM) -> row softmax -> PV (GEMM): with 288 GB
 of HBM the N x N score matrix of one image (512 MB at 1024^2) is affordable and keeps the MFMA GEMM as the only
 heavy kernel; V's bias is added after PV (softmax rows sum to 1).
-The reference decodes in fp32 on AMD (backend/memory_management.py:190-205); this path is fp16 storage with fp32
-accumulation everywhere (GEMM, norm statistics, softmax).
+Element type (`dtype`): the reference decodes in bf16 wherever the part supports it and in fp32 otherwise, `--vae-in-fp16` / `--vae-in-bf16`
+select by hand (backend/memory_management.py:190-205 VAE_DTYPES, :840-855 vae_dtype(); forge_amd.backend.memory_management mirrors the
+chooser).  Here: fp16 (default: 8x finer than bf16, the type the parity fixtures and the bench run in) or bfloat16 -- the same kernels built for
+both (libfmx ABI 6) -- with fp32 accumulation everywhere (GEMM, norm statistics, softmax).  Trained SDXL VAE weights leave fp16's range in the
+decoder's upper levels; an fp16 decode whose output is not finite is therefore repeated in bfloat16 and the executor stays there
+(`auto_bf16_fallback`, one counting kernel over the output per decode; tests/golden/tiny_vae_overflow.pt is such a decoder).
 
 Encoder (`encode`, reference Encoder.forward vae.py:183-200, Downsample :60-74, quant_conv + DiagonalGaussianDistribution
 :16-29, :296-303): same kernels; the Downsample's right/bottom-only zero padding costs nothing -- the conv loader's bounds
@@ -24,7 +28,15 @@ from .unet import _conv_w
 
 
 class IntegratedAutoencoderKL:
-    def __init__(self, config, state_dict, device="cuda"):
+    def __init__(self, config, state_dict, device="cuda", dtype=torch.float16, auto_bf16_fallback=True):
+        if dtype not in (torch.float16, torch.bfloat16):
+            raise NotImplementedError(f"VAE element type {dtype}: the native decoder is built for float16 and bfloat16 (the reference's fp32 VAE has no "
+                                      f"MFMA form on gfx950; bfloat16 has fp32's range)")
+        self.dtype = dtype
+        self.auto_bf16_fallback = bool(auto_bf16_fallback)
+        self.fallbacks = 0          # decodes repeated in bfloat16 because the fp16 result was not finite
+        self._source = state_dict   # by reference: the bfloat16 weights are made from it if a fallback ever happens
+        self._weights = {}
         self.config = dict(config)
         self.layout = vae_decoder_layout(config)
         self.device = torch.device(device)
@@ -35,16 +47,24 @@ class IntegratedAutoencoderKL:
         self.up_factor = 2 ** (len(self.layout.levels) - 1)
         self.has_encoder = "encoder.conv_in.weight" in state_dict
         self.enc_layout = vae_encoder_layout(config) if self.has_encoder else None
-        self._load(state_dict)
+        self.w = self._weights[dtype] = self._load(state_dict, dtype)
 
-    def _load(self, sd):
+    def set_dtype(self, dtype):
+        """Switch the element type of every later decode / encode (weights of the new type are converted from the source state dict once)."""
+        if dtype not in (torch.float16, torch.bfloat16):
+            raise NotImplementedError(f"VAE element type {dtype}")
+        if dtype not in self._weights:
+            self._weights[dtype] = self._load(self._source, dtype)
+        self.dtype, self.w = dtype, self._weights[dtype]
+
+    def _load(self, sd, dt):
         dev = self.device
 
         def T(k):
-            return sd[k].to(device=dev, dtype=torch.float16).contiguous()
+            return sd[k].to(device=dev, dtype=dt).contiguous()
 
         def conv(k):
-            return (_conv_w(sd[k + ".weight"].to(dev, torch.float16)), T(k + ".bias"))
+            return (_conv_w(sd[k + ".weight"].to(dev, dt)), T(k + ".bias"))
 
         def norm(k):
             return (T(k + ".weight"), T(k + ".bias"))
@@ -55,13 +75,13 @@ class IntegratedAutoencoderKL:
         # post_quant_conv (1x1, lc->lc) folded into conv_in's im2col GEMM is not exact at the borders (zero padding
         # happens after the 1x1 conv + bias), so it runs as its own tiny GEMM on a 64-wide zero-padded latent.
         if lay.use_post_quant_conv:
-            pw = sd["post_quant_conv.weight"].to(dev, torch.float16).reshape(lc, lc)
+            pw = sd["post_quant_conv.weight"].to(dev, dt).reshape(lc, lc)
             wp = pw.new_zeros(8, 64)
             wp[:lc, :lc] = pw
             bp = pw.new_zeros(8)
             bp[:lc] = T("post_quant_conv.bias")
             w["pq"] = (wp.contiguous(), bp.contiguous())
-        full = sd["decoder.conv_in.weight"].to(dev, torch.float16)               # [block_in, lc, 3, 3]
+        full = sd["decoder.conv_in.weight"].to(dev, dt)               # [block_in, lc, 3, 3]
         if lc * 9 <= 64:
             cw = _conv_w(full)
             wp = cw.new_zeros(cw.shape[0], 64)
@@ -101,7 +121,7 @@ class IntegratedAutoencoderKL:
         w["conv_out"] = conv("decoder.conv_out")
         if self.has_encoder:
             el = self.enc_layout
-            cw = _conv_w(sd["encoder.conv_in.weight"].to(dev, torch.float16))   # [ch, 9*in_channels]
+            cw = _conv_w(sd["encoder.conv_in.weight"].to(dev, dt))   # [ch, 9*in_channels]
             if cw.shape[1] > 64:
                 raise NotImplementedError("encoder in_channels*9 must be <= 64 (im2col'ed first conv)")
             wp = cw.new_zeros(cw.shape[0], 64)
@@ -126,24 +146,24 @@ class IntegratedAutoencoderKL:
             w["e.norm_out"] = norm("encoder.norm_out")
             w["e.conv_out"] = conv("encoder.conv_out")
             if el.use_quant_conv:
-                qc = sd["quant_conv.weight"].to(dev, torch.float16).reshape(2 * lc, 2 * lc)
+                qc = sd["quant_conv.weight"].to(dev, dt).reshape(2 * lc, 2 * lc)
                 qp = qc.new_zeros(2 * lc, 64)  # the moments travel in a 64-wide zero-padded NHWC buffer (GEMM K tile)
                 qp[:, :2 * lc] = qc
                 w["e.quant"] = (qp.contiguous(), T("quant_conv.bias"))
-        self.w = w
         torch.cuda.synchronize(dev)
+        return w
 
     @staticmethod
     def _fold_v_bias(proj_out, b_v):
         """proj_out(P V + b_v) = W_o (P V) + (W_o b_v + b_o): the value bias of the mid-block attention (vae.py:118-137; softmax rows sum to 1, so it
         is the same vector for every token) folded into proj_out's bias once at load time, in fp32."""
         w_o, b_o = proj_out
-        return (b_o.float() + w_o.float() @ b_v.float()).half().contiguous()
+        return (b_o.float() + w_o.float() @ b_v.float()).to(b_o.dtype).contiguous()
 
     # ------------------------------------------------------------------------------------------------------------
     def _res(self, k, x, cin, cout, arena):
         b, hh, ww, _ = x.shape
-        out = ops.empty((b, hh, ww, cout))
+        out = ops.empty((b, hh, ww, cout), self.dtype)
         out_part = ops.stats_buffer(b, hh * ww, cout)
         m = arena.mark()
         g1 = ops.groupnorm(x, *self.w[k + ".n1"], 1e-6, silu=True)          # statistics: left on x by the GEMM that produced it
@@ -158,18 +178,18 @@ class IntegratedAutoencoderKL:
     def _attn(self, x, arena, a="decoder.mid.attn_1"):
         b, hh, ww, c = x.shape
         n = hh * ww
-        out = ops.empty((b, hh, ww, c))
+        out = ops.empty((b, hh, ww, c), self.dtype)
         out_part = ops.stats_buffer(b, n, c)
         m = arena.mark()
         g = ops.groupnorm(x, *self.w[a + ".norm"], 1e-6).view(-1, c)
         qk = ops.linear(g, *self.w[a + ".qk"])                                  # [B*N, 2C]
-        o = ops.empty((b * n, c))
+        o = ops.empty((b * n, c), self.dtype)
         npad = -(-n // 64) * 64
         scale = c ** -0.5
         if c == 512:
             # fused: one launch for the whole batch, scores never leave the chip (csrc/fmx_attention512.hip).  V^T for all images comes from
             # ONE operand-swapped GEMM when the token count needs no padding; V's bias rides in proj_out's (softmax rows sum to 1)
-            vt = ops.empty((c, b * npad))
+            vt = ops.empty((c, b * npad), self.dtype)
             if npad == n:
                 ops.conv_gemm(self.w[a + ".v"][0], g, b * n, out=vt, ld_out=b * n)
             else:
@@ -188,14 +208,14 @@ class IntegratedAutoencoderKL:
             gb = g[bi * n:(bi + 1) * n]
             q = qk[bi * n:(bi + 1) * n, :c]
             kk = qk[bi * n:(bi + 1) * n, c:]
-            s = ops.empty((n, npad))
+            s = ops.empty((n, npad), self.dtype)
             if npad != n:
                 s.zero_()  # padded key columns must hold finite values for the PV GEMM (their P is never produced)
             ops.conv_gemm(q, kk, n, alpha=scale, out=s, ld_out=npad)             # S = scale * Q K^T
             ops.softmax_rows_(s[:, :n])
             if npad != n:
                 s[:, n:].zero_()
-            vt = ops.empty((c, npad))
+            vt = ops.empty((c, npad), self.dtype)
             if npad != n:
                 vt.zero_()
             ops.conv_gemm(self.w[a + ".v"][0], gb, n, out=vt, ld_out=npad)        # V^T (bias deferred)
@@ -210,7 +230,7 @@ class IntegratedAutoencoderKL:
         """z fp32 NCHW [B, lc, h, w] (already process_out'ed) -> fp16 [B*8h*8w, 4] (first out_channels valid)"""
         lay = self.layout
         b, lc, hh, ww = z.shape
-        zl = ops.vae_pack_latent(z, 1.0, 0.0, ld=64)                              # [B,h,w,64] zero padded
+        zl = ops.vae_pack_latent(z, 1.0, 0.0, ld=64, dtype=self.dtype)                              # [B,h,w,64] zero padded
         if lay.use_post_quant_conv:
             zq = ops.conv_gemm(zl.view(-1, 64), self.w["pq"][0], 8, bias=self.w["pq"][1]).view(b, hh, ww, 8)
         else:
@@ -233,7 +253,7 @@ class IntegratedAutoencoderKL:
                 h = ops.attach_stats(h.view(bb, 2 * h2, 2 * w2, c), st)
         g = ops.groupnorm(h, *self.w["norm_out"], 1e-6, silu=True)
         y = ops.conv_gemm(g, self.w["conv_out"][0], lay.out_channels, kh=3, pad=1, bias=self.w["conv_out"][1],
-                          out=ops.empty((g.shape[0] * g.shape[1] * g.shape[2], 4)), ld_out=4)
+                          out=ops.empty((g.shape[0] * g.shape[1] * g.shape[2], 4), self.dtype), ld_out=4)
         return y
 
     def _run(self, z):
@@ -248,18 +268,29 @@ class IntegratedAutoencoderKL:
             arena.reset()
             try:
                 with arena:
-                    return self._decode_impl(z, arena)
+                    y = self._decode_impl(z, arena)
+                if self.dtype == torch.float16 and self.auto_bf16_fallback and ops.count_nonfinite(y) > 0:
+                    self._fall_back_to_bf16("decode")
+                    continue
+                return y
             except ArenaOverflow:
                 torch.cuda.synchronize(self.device)
                 need = arena.capacity * 2
                 self._arena = None
+
+    def _fall_back_to_bf16(self, what):
+        import warnings
+        self.fallbacks += 1
+        warnings.warn(f"VAE {what}: the float16 result is not finite (activations beyond 65504, as with trained SDXL VAE weights); repeating in "
+                      f"bfloat16 and keeping this VAE in bfloat16 from here on (construct it with dtype=torch.bfloat16 to start there)")
+        self.set_dtype(torch.bfloat16)
 
     # ---- encoder -----------------------------------------------------------------------------------------------------
     def _encode_impl(self, x, arena):
         """x fp32 NCHW [B, 3, H, W] in [-1, 1] -> moments fp16 [B*h*w, 64] (first 2*lc columns valid: mean | logvar)"""
         el = self.enc_layout
         b, c, hh, ww = x.shape
-        xl = ops.vae_pack_latent(x, 1.0, 0.0, ld=8)                               # NHWC fp16, zero padded to 8 channels
+        xl = ops.vae_pack_latent(x, 1.0, 0.0, ld=8, dtype=self.dtype)                               # NHWC fp16, zero padded to 8 channels
         col = ops.im2col3x3_smallc(xl, c)
         h, st = ops.linear(col, *self.w["e.conv_in"], n=b, h=hh, w=ww, stats=True)
         h = ops.attach_stats(h.view(b, hh, ww, el.ch), st)
@@ -278,11 +309,11 @@ class IntegratedAutoencoderKL:
         g = ops.groupnorm(h, *self.w["e.norm_out"], 1e-6, silu=True)
         npix = g.shape[0] * g.shape[1] * g.shape[2]
         lc2 = 2 * el.latent_channels
-        mo = ops.empty((npix, 64))
+        mo = ops.empty((npix, 64), self.dtype)
         mo.zero_()
         ops.conv_gemm(g, self.w["e.conv_out"][0], lc2, kh=3, pad=1, bias=self.w["e.conv_out"][1], out=mo, ld_out=64)
         if el.use_quant_conv:
-            mq = ops.empty((npix, 64))
+            mq = ops.empty((npix, 64), self.dtype)
             mq.zero_()
             ops.conv_gemm(mo, self.w["e.quant"][0], lc2, bias=self.w["e.quant"][1], out=mq, ld_out=64)
             mo = mq
@@ -299,7 +330,11 @@ class IntegratedAutoencoderKL:
             arena.reset()
             try:
                 with arena:
-                    return self._encode_impl(x, arena)
+                    mo = self._encode_impl(x, arena)
+                if self.dtype == torch.float16 and self.auto_bf16_fallback and ops.count_nonfinite(mo) > 0:
+                    self._fall_back_to_bf16("encode")
+                    continue
+                return mo
             except ArenaOverflow:
                 torch.cuda.synchronize(self.device)
                 need = arena.capacity * 2

@@ -17,7 +17,6 @@
 // materialised path it replaces -- and no 512 MB score buffer or per-image host loop, see DESIGN.md section 4.2.
 #include "fmx_common.hpp"
 
-#ifndef FMX_ELEM_BF16  // fp16 (VAE) build only
 
 namespace {
 
@@ -252,4 +251,3 @@ extern "C" int fmx_attention_single_head512_f16(const void* q, int64_t q_bs, int
   return FMX_OK;
 }
 
-#endif  // !FMX_ELEM_BF16

@@ -9,6 +9,13 @@
 #define fmx_layernorm_padded_f16 fmx_layernorm_padded_bf16
 #define fmx_layernorm_mod_f16 fmx_layernorm_mod_bf16
 #define fmx_flux_qk_norm_rope_f16 fmx_flux_qk_norm_rope_bf16
+// the VAE in bfloat16 (the reference's VAE type on bf16-capable parts, backend/memory_management.py:190-205, :840-855): GroupNorm, the GEMM
+// with output statistics, the 512-wide single-head attention
+#define fmx_gemm_conv_stats_f16 fmx_gemm_conv_stats_bf16
+#define fmx_groupnorm_stats_f16 fmx_groupnorm_stats_bf16
+#define fmx_groupnorm_apply_f16 fmx_groupnorm_apply_bf16
+#define fmx_attention_single_head512_f16 fmx_attention_single_head512_bf16
+#define fmx_launch_gn_stats fmx_launch_gn_stats_bf16
 // host-side C++ symbols shared between the GEMM files
 #define fmx_launch_gemm256p fmx_launch_gemm256p_bf16
 #define GemmParams GemmParamsBf16

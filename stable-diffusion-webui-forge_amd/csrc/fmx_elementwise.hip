@@ -314,19 +314,40 @@ __global__ void scale_kernel(const float* __restrict__ x, float s, float* __rest
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = x[i] * s;
 }
 
+// how many of n fp16 values are inf / NaN (exponent bits all ones): the VAE's overflow guard (backend/nn/vae.py auto_bf16_fallback)
+__global__ void count_nonfinite_kernel(const uint16_t* __restrict__ x, long n, int* __restrict__ count) {
+  int bad = 0;
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += (long)gridDim.x * blockDim.x * 8) {
+    if (i + 8 <= n) {
+      const uint4 v = *reinterpret_cast<const uint4*>(x + i);
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) bad += ((w[k] & 0x7C00u) == 0x7C00u) + ((w[k] & 0x7C000000u) == 0x7C000000u);
+    } else {
+      for (long j = i; j < n; ++j) bad += (x[j] & 0x7C00u) == 0x7C00u;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o);
+  if ((threadIdx.x & 63) == 0 && bad) atomicAdd(count, bad);
+}
+
+// the three VAE boundary kernels exist for both 16-bit element types (T = _Float16, or __bf16 for the bfloat16 decoder / encoder)
+template <typename T>
 __global__ void vae_pack_latent_kernel(const float* __restrict__ z, float inv_scale, float shift, int b, int c, int h, int w,
-                                       f16* __restrict__ out, int ld) {
+                                       T* __restrict__ out, int ld) {
   const long total = (long)b * h * w * ld;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int ch = (int)(i % ld);
     const long pix = i / ld;
     const long hw = (long)h * w;
     const long bi = pix / hw, p = pix % hw;
-    out[i] = ch < c ? (f16)(z[(bi * c + ch) * hw + p] / inv_scale + shift) : (f16)0.f;
+    out[i] = ch < c ? (T)(z[(bi * c + ch) * hw + p] / inv_scale + shift) : (T)0.f;
   }
 }
 
-__global__ void vae_unpack_image_kernel(const f16* __restrict__ y, int ld, long npix, int c, float* __restrict__ out) {
+template <typename T>
+__global__ void vae_unpack_image_kernel(const T* __restrict__ y, int ld, long npix, int c, float* __restrict__ out) {
   const long total = npix * c;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long pix = i / c;
@@ -340,7 +361,8 @@ __global__ void blend_masked_kernel(const float* a, const float* am, const float
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = a[i] * am[i] + b[i] * bm[i];
 }
 
-__global__ void vae_sample_posterior_kernel(const f16* __restrict__ mo, int ld, const float* __restrict__ noise, int b, int lc, long npix, float scale,
+template <typename T>
+__global__ void vae_sample_posterior_kernel(const T* __restrict__ mo, int ld, const float* __restrict__ noise, int b, int lc, long npix, float scale,
                                             float shift, float* __restrict__ out) {
   const long total = (long)b * lc * npix;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -348,7 +370,7 @@ __global__ void vae_sample_posterior_kernel(const f16* __restrict__ mo, int ld, 
     const long bc = i / npix;
     const int c = (int)(bc % lc);
     const long bi = bc / lc;
-    const f16* row = mo + (bi * npix + p) * ld;
+    const T* row = mo + (bi * npix + p) * ld;
     const float mean = (float)row[c];
     const float logvar = fminf(fmaxf((float)row[lc + c], -30.0f), 20.0f);
     out[i] = (mean + __expf(0.5f * logvar) * noise[i] - shift) * scale;
@@ -614,21 +636,46 @@ extern "C" int fmx_scale_f32(const float* x, float s, float* y, int64_t n, void*
   return FMX_OK;
 }
 
-extern "C" int fmx_vae_pack_latent(const float* z, float scaling_factor, float shift, int32_t b, int32_t c, int32_t h, int32_t w, void* out,
-                                   int32_t ld, void* stream) {
+template <typename T>
+static int vae_pack_latent_impl(const float* z, float scaling_factor, float shift, int32_t b, int32_t c, int32_t h, int32_t w, void* out, int32_t ld,
+                                void* stream) {
   FMX_REQUIRE(z && out && b > 0 && c > 0 && ld >= c && scaling_factor != 0.f, "vae_pack_latent: bad args");
   const long total = (long)b * h * w * ld;
-  hipLaunchKernelGGL(vae_pack_latent_kernel, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream, z, scaling_factor, shift, b, c, h, w,
-                     (f16*)out, ld);
+  hipLaunchKernelGGL(vae_pack_latent_kernel<T>, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream, z, scaling_factor, shift, b, c, h, w,
+                     (T*)out, ld);
   FMX_LAUNCH_CHECK("fmx_vae_pack_latent");
   return FMX_OK;
 }
+extern "C" int fmx_vae_pack_latent(const float* z, float scaling_factor, float shift, int32_t b, int32_t c, int32_t h, int32_t w, void* out,
+                                   int32_t ld, void* stream) {
+  return vae_pack_latent_impl<f16>(z, scaling_factor, shift, b, c, h, w, out, ld, stream);
+}
+extern "C" int fmx_vae_pack_latent_bf16(const float* z, float scaling_factor, float shift, int32_t b, int32_t c, int32_t h, int32_t w, void* out,
+                                        int32_t ld, void* stream) {
+  return vae_pack_latent_impl<__bf16>(z, scaling_factor, shift, b, c, h, w, out, ld, stream);
+}
 
-extern "C" int fmx_vae_unpack_image(const void* y, int32_t ld, int64_t npix, int32_t c, float* out, void* stream) {
+template <typename T>
+static int vae_unpack_image_impl(const void* y, int32_t ld, int64_t npix, int32_t c, float* out, void* stream) {
   FMX_REQUIRE(y && out && npix > 0 && c > 0 && ld >= c, "vae_unpack_image: bad args");
-  hipLaunchKernelGGL(vae_unpack_image_kernel, dim3(grid_for(npix * c, 2)), dim3(TPB), 0, (hipStream_t)stream, (const f16*)y, ld, (long)npix,
+  hipLaunchKernelGGL(vae_unpack_image_kernel<T>, dim3(grid_for(npix * c, 2)), dim3(TPB), 0, (hipStream_t)stream, (const T*)y, ld, (long)npix,
                      c, out);
   FMX_LAUNCH_CHECK("fmx_vae_unpack_image");
+  return FMX_OK;
+}
+extern "C" int fmx_vae_unpack_image(const void* y, int32_t ld, int64_t npix, int32_t c, float* out, void* stream) {
+  return vae_unpack_image_impl<f16>(y, ld, npix, c, out, stream);
+}
+extern "C" int fmx_vae_unpack_image_bf16(const void* y, int32_t ld, int64_t npix, int32_t c, float* out, void* stream) {
+  return vae_unpack_image_impl<__bf16>(y, ld, npix, c, out, stream);
+}
+
+extern "C" int fmx_count_nonfinite_f16(const void* x, int64_t n, int32_t* count, void* stream) {
+  FMX_REQUIRE(x && count && n > 0 && fmx_aligned16(x), "count_nonfinite: bad args (x must be 16-byte aligned)");
+  hipError_t e = hipMemsetAsync(count, 0, sizeof(int32_t), (hipStream_t)stream);
+  if (e != hipSuccess) return fmx_set_error((int)e, "fmx_count_nonfinite_f16: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(count_nonfinite_kernel, dim3(grid_for((n + 7) / 8)), dim3(TPB), 0, (hipStream_t)stream, (const uint16_t*)x, (long)n, count);
+  FMX_LAUNCH_CHECK("fmx_count_nonfinite_f16");
   return FMX_OK;
 }
 
@@ -639,13 +686,22 @@ extern "C" int fmx_blend_masked(const float* a, const float* a_mask, const float
   return FMX_OK;
 }
 
-extern "C" int fmx_vae_sample_posterior(const void* moments, int32_t ld, const float* noise, int32_t b, int32_t lc, int64_t npix, float scale, float shift,
-                                        float* out, void* stream) {
+template <typename T>
+static int vae_sample_posterior_impl(const void* moments, int32_t ld, const float* noise, int32_t b, int32_t lc, int64_t npix, float scale, float shift,
+                                     float* out, void* stream) {
   FMX_REQUIRE(moments && noise && out && b > 0 && lc > 0 && npix > 0 && ld >= 2 * lc, "vae_sample_posterior: bad args");
-  hipLaunchKernelGGL(vae_sample_posterior_kernel, dim3(grid_for((long)b * lc * npix)), dim3(TPB), 0, (hipStream_t)stream, (const f16*)moments, ld,
+  hipLaunchKernelGGL(vae_sample_posterior_kernel<T>, dim3(grid_for((long)b * lc * npix)), dim3(TPB), 0, (hipStream_t)stream, (const T*)moments, ld,
                      noise, b, lc, (long)npix, scale, shift, out);
   FMX_LAUNCH_CHECK("fmx_vae_sample_posterior");
   return FMX_OK;
+}
+extern "C" int fmx_vae_sample_posterior(const void* moments, int32_t ld, const float* noise, int32_t b, int32_t lc, int64_t npix, float scale, float shift,
+                                        float* out, void* stream) {
+  return vae_sample_posterior_impl<f16>(moments, ld, noise, b, lc, npix, scale, shift, out, stream);
+}
+extern "C" int fmx_vae_sample_posterior_bf16(const void* moments, int32_t ld, const float* noise, int32_t b, int32_t lc, int64_t npix, float scale,
+                                             float shift, float* out, void* stream) {
+  return vae_sample_posterior_impl<__bf16>(moments, ld, noise, b, lc, npix, scale, shift, out, stream);
 }
 
 extern "C" int fmx_philox_randn(uint64_t seed, uint32_t offset, float* out, uint32_t* raw_u32, int64_t n, void* stream) {

@@ -638,13 +638,11 @@ extern "C" int fmx_gemm_linear_rowstats_f16(const fmx_gemm_args* a, float* row_p
 }
 #endif
 
-#ifndef FMX_ELEM_BF16  // GroupNorm exists on the fp16 (UNet / VAE) path only
 extern "C" int fmx_gemm_conv_stats_f16(const fmx_gemm_args* a, float* partial, int32_t max_chunks, int32_t fallback_chunks, int32_t* chunks_out,
                                        void* stream) {
   FMX_REQUIRE(partial && chunks_out, "gemm_conv_stats: null pointer");
   return gemm_conv_impl(a, partial, max_chunks, fallback_chunks, chunks_out, stream);
 }
-#endif
 
 #ifndef FMX_ELEM_BF16  // a 16-bit row shuffle: one copy serves both element types
 extern "C" int fmx_geglu_interleave_rows(const void* w_in, const void* b_in, void* w_out, void* b_out, int32_t inner,

@@ -7,7 +7,6 @@
 
 namespace {
 
-#ifndef FMX_ELEM_BF16  // GroupNorm: fp16 (UNet / VAE) build only
 // ---- statistics: per-(image, chunk, channel) partial sum / sum of squares ------------------------------------------------
 // partial[img][chunk][c] = {sum x, sum x^2} over the chunk's pixels (fp32).  This kernel is the FALLBACK producer: the 256-row GEMM
 // tiles emit the same records from their epilogue (fmx_gemm256p.hip, one chunk = one 256-row tile), so that a GroupNorm whose input
@@ -195,7 +194,6 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
   }
 }
 
-#endif  // !FMX_ELEM_BF16
 
 // ---- LayerNorm: one wave per row, row kept in registers, exact two-pass mean/variance in fp32 -----------------
 // MOD = false: y = LN(x) * gamma + beta, row r written to output row (r / rows_per_b) * ld_mod + r % rows_per_b (token rows re-spaced
@@ -253,7 +251,6 @@ __global__ __launch_bounds__(256) void ln_kernel(const f16* __restrict__ x, cons
 
 }  // namespace
 
-#ifndef FMX_ELEM_BF16
 int fmx_launch_gn_stats(const void* x, int32_t c, int64_t ld, int32_t n, int32_t hw, float* partial, int32_t nchunks, hipStream_t st) {
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, n), dim3(256), 256 * 16 * sizeof(float), st, (const f16*)x, c, (long)ld, hw, partial, nchunks);
   FMX_LAUNCH_CHECK("fmx_groupnorm_stats_f16");
@@ -300,7 +297,6 @@ extern "C" int fmx_groupnorm_apply_f16(const void* x0, const void* x1, int32_t c
   return FMX_OK;
 }
 
-#endif  // !FMX_ELEM_BF16
 
 template <bool MOD>
 static int launch_ln(const void* x, const void* gamma, const void* beta, void* y, int64_t rows, int32_t c, float eps, long rows_per_b,

@@ -239,7 +239,7 @@ def conv_gemm(x, wgt, nout, *, x1=None, n=None, h=None, w=None, kh=1, stride=1, 
             _lib.check(_lib.lib().fmx_gemm_linear_rowstats_f16(C.byref(a), _p(row_stats.partial), cap, C.byref(got), stream_ptr()),
                        "fmx_gemm_linear_rowstats_f16")
             row_stats.parts = got.value
-    elif stats and _FUSED_STATS and sfx == "_f16":
+    elif stats and _FUSED_STATS:
         hw = oh * ow
         fb, cap = _stats_geometry(n_, hw)
         partial = stats_partial if stats_partial is not None else empty((n_, cap, ncols, 2), torch.float32, x.device)
@@ -248,7 +248,8 @@ def conv_gemm(x, wgt, nout, *, x1=None, n=None, h=None, w=None, kh=1, stride=1, 
         st = GnStats(partial, 0)
 
         def launch():
-            _lib.check(_lib.lib().fmx_gemm_conv_stats_f16(C.byref(a), _p(partial), cap, fb, C.byref(nch), stream_ptr()), "fmx_gemm_conv_stats_f16")
+            _lib.check(getattr(_lib.lib(), "fmx_gemm_conv_stats" + sfx)(C.byref(a), _p(partial), cap, fb, C.byref(nch), stream_ptr()),
+                       "fmx_gemm_conv_stats" + sfx)
             st.nchunks = nch.value
     else:
         def launch():
@@ -342,13 +343,13 @@ def attention(q, k, vt, *, batch, heads, nq, nk, nk_pad, dpad, scale, q_bs, q_rs
 
 
 def attention_single_head512(q, k, vt, out, *, batch, nq, nk, nk_pad, q_bs, q_rs, k_bs, k_rs, vt_bs, vt_ds, scale):
-    """One 512-wide head, fused (fmx_attention_single_head512_f16): q / k token-major views, vt = V^T [512 rows][batch * nk_pad keys]."""
-    _check_f16(q, k, vt, out)
+    """One 512-wide head, fused (fmx_attention_single_head512_f16 / _bf16): q / k token-major views, vt = V^T [512 rows][batch * nk_pad keys]."""
+    sfx, _ = _elem(q, k, vt, out)
 
     def launch():
-        _lib.check(_lib.lib().fmx_attention_single_head512_f16(_p(q), q_bs, q_rs, _p(k), k_bs, k_rs, _p(vt), vt_bs, vt_ds, _p(out), nq * out.stride(0),
-                                                               out.stride(0), batch, nq, nk, nk_pad, float(scale), stream_ptr()),
-                   "fmx_attention_single_head512_f16")
+        _lib.check(getattr(_lib.lib(), "fmx_attention_single_head512" + sfx)(_p(q), q_bs, q_rs, _p(k), k_bs, k_rs, _p(vt), vt_bs, vt_ds, _p(out),
+                                                                             nq * out.stride(0), out.stride(0), batch, nq, nk, nk_pad, float(scale),
+                                                                             stream_ptr()), "fmx_attention_single_head512" + sfx)
     if _profiler is not None:
         _profiler.launch("attention", 4.0 * batch * nq * nk * 512, launch, tag=f"B={batch} H=1 Nq={nq} Nk={nk} d=512")
     else:
@@ -358,8 +359,8 @@ def attention_single_head512(q, k, vt, out, *, batch, nq, nk, nk_pad, q_bs, q_rs
 
 
 def softmax_rows_(x):
-    _check_f16(x)
-    _lib.check(_lib.lib().fmx_softmax_rows_f16(_p(x), x.shape[0], x.shape[1], x.stride(0), stream_ptr()), "fmx_softmax_rows_f16")
+    sfx, _ = _elem(x)
+    _lib.check(getattr(_lib.lib(), "fmx_softmax_rows" + sfx)(_p(x), x.shape[0], x.shape[1], x.stride(0), stream_ptr()), "fmx_softmax_rows" + sfx)
     return x
 
 
@@ -407,26 +408,27 @@ def clear_stats(t):
 
 
 def groupnorm_stats(x):
-    """x: fp16 [N, H, W, C] / [N, HW, C] (pixel stride = x.stride(-2), channels contiguous) -> GnStats (stand-alone pass over the tensor)."""
-    _check_f16(x)
+    """x: fp16 / bf16 [N, H, W, C] / [N, HW, C] (pixel stride = x.stride(-2), channels contiguous) -> GnStats (stand-alone pass over the tensor)."""
+    sfx, _ = _elem(x)
     n, c = x.shape[0], x.shape[-1]
     hw = x.numel() // (n * c)
     nch = _gn_chunks(n, hw)
     partial = empty((n, nch, c, 2), torch.float32, x.device)
-    _lib.check(_lib.lib().fmx_groupnorm_stats_f16(_p(x), c, x.stride(-2), n, hw, _p(partial), nch, stream_ptr()), "fmx_groupnorm_stats_f16")
+    _lib.check(getattr(_lib.lib(), "fmx_groupnorm_stats" + sfx)(_p(x), c, x.stride(-2), n, hw, _p(partial), nch, stream_ptr()), "fmx_groupnorm_stats" + sfx)
     return GnStats(partial, nch)
 
 
 def groupnorm(x, gamma, beta, eps, *, x1=None, silu=False, groups=32, out=None, stats=None, stats1=None):
     """x: [N, H, W, C0] (x1: [N, H, W, C1] concatenated after it) -> [N, H, W, C0+C1].  stats / stats1: GnStats of x / x1 when their
-    producer left them (conv_gemm(stats=True)); a source without statistics gets its own pass here."""
-    _check_f16(x, x1, gamma, beta)
+    producer left them (conv_gemm(stats=True)); a source without statistics gets its own pass here.  fp16, or bf16 throughout (the VAE's
+    second element type)."""
+    sfx, elem = _elem(x, x1, gamma, beta, out)
     n = x.shape[0]
     hw = x.numel() // (n * x.shape[-1])
     c0 = x.shape[-1]
     c1 = x1.shape[-1] if x1 is not None else 0
     if out is None:
-        out = empty(tuple(x.shape[:-1]) + (c0 + c1,), torch.float16, x.device)
+        out = empty(tuple(x.shape[:-1]) + (c0 + c1,), elem, x.device)
 
     if stats is None:
         stats = _attached_stats(x)
@@ -437,10 +439,10 @@ def groupnorm(x, gamma, beta, eps, *, x1=None, silu=False, groups=32, out=None, 
         s0 = stats if stats is not None else groupnorm_stats(x)
         s1 = (stats1 if stats1 is not None else groupnorm_stats(x1)) if x1 is not None else None
         ss = empty((n, c0 + c1, 2), torch.float32, x.device)
-        _lib.check(_lib.lib().fmx_groupnorm_apply_f16(_p(x), _p(x1), c0, c1, x.stride(-2), x1.stride(-2) if x1 is not None else 0, n, hw,
-                                                      _p(s0.partial), s0.nchunks, _p(s1.partial) if s1 is not None else None,
-                                                      s1.nchunks if s1 is not None else 0, groups, float(eps), _p(gamma), _p(beta),
-                                                      1 if silu else 0, _p(ss), _p(out), stream_ptr()), "fmx_groupnorm_apply_f16")
+        _lib.check(getattr(_lib.lib(), "fmx_groupnorm_apply" + sfx)(_p(x), _p(x1), c0, c1, x.stride(-2), x1.stride(-2) if x1 is not None else 0, n, hw,
+                                                                    _p(s0.partial), s0.nchunks, _p(s1.partial) if s1 is not None else None,
+                                                                    s1.nchunks if s1 is not None else 0, groups, float(eps), _p(gamma), _p(beta),
+                                                                    1 if silu else 0, _p(ss), _p(out), stream_ptr()), "fmx_groupnorm_apply" + sfx)
     if _profiler is not None:
         have = (stats is not None) + (x1 is not None and stats1 is not None)
         _profiler.launch("groupnorm", 0.0, run, tag=f"N={n} HW={hw} C={c0}+{c1} stats_from_producer={have}/{1 + (x1 is not None)}",
@@ -578,7 +580,7 @@ def unet_pack_input(x, sigma, reps, sigma_data=1.0, out=None):
 def im2col3x3_smallc(x, c, out=None):
     n, h, w, ld = x.shape
     if out is None:
-        out = empty((n * h * w, 64), torch.float16, x.device)
+        out = empty((n * h * w, 64), x.dtype, x.device)    # a 16-bit word shuffle: fp16 and bf16 alike
     _lib.check(_lib.lib().fmx_im2col3x3_smallc(_p(x), ld, n, c, h, w, _p(out), stream_ptr()), "fmx_im2col3x3_smallc")
     return out
 
@@ -678,12 +680,16 @@ def blend_masked(a, a_mask, b, b_mask, out=None):
     return out
 
 
-def vae_pack_latent(z, scaling_factor, shift, ld=8, out=None):
+def _vae_sfx(dtype):
+    return "_bf16" if dtype == torch.bfloat16 else ""
+
+
+def vae_pack_latent(z, scaling_factor, shift, ld=8, out=None, dtype=torch.float16):
     b, c, h, w = z.shape
     if out is None:
-        out = empty((b, h, w, ld), torch.float16, z.device)
-    _lib.check(_lib.lib().fmx_vae_pack_latent(_p(z), float(scaling_factor), float(shift), b, c, h, w, _p(out), ld, stream_ptr()),
-               "fmx_vae_pack_latent")
+        out = empty((b, h, w, ld), dtype, z.device)
+    name = "fmx_vae_pack_latent" + _vae_sfx(out.dtype)
+    _lib.check(getattr(_lib.lib(), name)(_p(z), float(scaling_factor), float(shift), b, c, h, w, _p(out), ld, stream_ptr()), name)
     return out
 
 
@@ -692,13 +698,23 @@ def vae_sample_posterior(moments, ld, noise, lc, scale=1.0, shift=0.0, out=None)
     b, _, hh, ww = noise.shape
     if out is None:
         out = torch.empty_like(noise)
-    _lib.check(_lib.lib().fmx_vae_sample_posterior(_p(moments), ld, _p(noise), b, lc, hh * ww, float(scale), float(shift), _p(out), stream_ptr()),
-               "fmx_vae_sample_posterior")
+    name = "fmx_vae_sample_posterior" + _vae_sfx(moments.dtype)
+    _lib.check(getattr(_lib.lib(), name)(_p(moments), ld, _p(noise), b, lc, hh * ww, float(scale), float(shift), _p(out), stream_ptr()), name)
     return out
 
 
+def count_nonfinite(x):
+    """-> python int: inf / NaN values in the fp16 tensor x (contiguous).  One device sync -- the caller decides on the host (VAE overflow guard)."""
+    _check_f16(x)
+    assert x.is_contiguous()
+    cnt = torch.empty(1, dtype=torch.int32, device=x.device)
+    _lib.check(_lib.lib().fmx_count_nonfinite_f16(_p(x), x.numel(), _p(cnt), stream_ptr()), "fmx_count_nonfinite_f16")
+    return int(cnt.item())
+
+
 def vae_unpack_image(y, ld, npix, c, out):
-    _lib.check(_lib.lib().fmx_vae_unpack_image(_p(y), ld, npix, c, _p(out), stream_ptr()), "fmx_vae_unpack_image")
+    name = "fmx_vae_unpack_image" + _vae_sfx(y.dtype)
+    _lib.check(getattr(_lib.lib(), name)(_p(y), ld, npix, c, _p(out), stream_ptr()), name)
     return out
 
 

@@ -1,0 +1,109 @@
+"""GPU: the VAE in bfloat16 (libfmx ABI 6) -- the reference's VAE type on bf16-capable parts (backend/memory_management.py:190-205, :840-855;
+decoder backend/nn/vae.py:248-271) -- and the guard that keeps the float16 default safe: an fp16 decode that leaves fp16's range is repeated in
+bfloat16.  Floors: the REAL reference's own bfloat16 run against its fp32 run (oracle/make_floor.py gen_vae_bf16 -> fp16_floor.json `...@bf16`).
+"""
+import time
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import forge_amd  # noqa: E402,F401
+from forge_amd import synth  # noqa: E402
+from forge_amd.backend import memory_management  # noqa: E402
+from forge_amd.backend.nn.vae import IntegratedAutoencoderKL  # noqa: E402
+
+from conftest import load_golden  # noqa: E402
+from parity import check  # noqa: E402
+
+DEV = "cuda"
+
+
+def _u8(x):
+    """processing.py:1012-1040: clamp((x + 1) / 2) * 255, truncated"""
+    return (255.0 * torch.clamp((x.float().cpu() + 1.0) / 2.0, 0.0, 1.0)).numpy().astype(np.uint8).astype(np.int32)
+
+
+def test_tiny_vae_decode_and_encode_in_bfloat16_vs_reference_fixture():
+    g = load_golden("tiny_vae_decode.pt")
+    vae = IntegratedAutoencoderKL(synth.TINY_VAE_CONFIG, synth.synth_vae_state_dict(synth.TINY_VAE_CONFIG, seed=1), device=DEV, dtype=torch.bfloat16)
+    check("tiny vae decode, bfloat16 build, vs reference", vae.decode(g["z"].to(DEV)), g["decode"], floor="tiny_vae_decode.pt:decode@bf16")
+    assert vae.dtype == torch.bfloat16 and vae.fallbacks == 0
+    e = load_golden("tiny_vae_encode.pt")
+    # the encoder has no bfloat16 floor entry of its own: the decoder's bf16 floor family brackets it (same block grammar, same depth)
+    check("tiny vae encoder moments, bfloat16 build, vs reference", vae.encode_moments(e["x"].to(DEV)), e["moments"], floor="tiny_vae_decode.pt:decode@bf16")
+    check("tiny vae posterior sample, bfloat16 build, vs reference", vae.encode(e["x"].to(DEV), noise=e["noise"]), e["sample"],
+          floor="tiny_vae_decode.pt:decode@bf16")
+
+
+def test_fp16_overflow_is_caught_and_repeated_in_bfloat16():
+    """tests/golden/tiny_vae_overflow.pt: one convolution's weight scaled by 6e4, so its output (|x| up to 1.1e5) leaves fp16's range on the way
+    to a GroupNorm -- the reference's own fp16 run of this decoder is NaN everywhere (recorded in the fixture), its bf16 and fp32 runs are fine."""
+    from oracle.make_floor import overflow_vae_state_dict
+    g = load_golden("tiny_vae_overflow.pt")
+    assert g["conv_absmax"] > 65504 and g["reference_fp16_nonfinite_fraction"] > 0
+    sd = overflow_vae_state_dict()
+    z = g["z"].to(DEV)
+    # the unguarded fp16 executor overflows exactly like the reference's fp16 run
+    raw = IntegratedAutoencoderKL(synth.TINY_VAE_CONFIG, sd, device=DEV, auto_bf16_fallback=False)
+    assert not bool(torch.isfinite(raw.decode(z)).all())
+    # the default executor notices, repeats the decode in bfloat16 and stays there
+    vae = IntegratedAutoencoderKL(synth.TINY_VAE_CONFIG, sd, device=DEV)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out = vae.decode(z)
+    assert vae.fallbacks == 1 and vae.dtype == torch.bfloat16 and any("bfloat16" in str(x.message) for x in w)
+    check("overflowing decoder: guarded fp16 executor (fell back to bfloat16) vs reference fp32", out, g["decode"], floor="tiny_vae_overflow.pt:decode@bf16")
+    out2 = vae.decode(z)                     # second decode: already in bfloat16, no further fallback
+    assert vae.fallbacks == 1 and torch.equal(out, out2)
+    # and an executor started in bfloat16 (memory_management.vae_dtype()'s answer for "any checkpoint")
+    assert memory_management.vae_dtype() == torch.bfloat16
+    vb = IntegratedAutoencoderKL(synth.TINY_VAE_CONFIG, sd, device=DEV, dtype=memory_management.vae_dtype())
+    check("overflowing decoder: bfloat16 executor vs reference fp32", vb.decode(z), g["decode"], floor="tiny_vae_overflow.pt:decode@bf16")
+    # a healthy decoder is not disturbed by the guard
+    ok = IntegratedAutoencoderKL(synth.TINY_VAE_CONFIG, synth.synth_vae_decoder_state_dict(synth.TINY_VAE_CONFIG, seed=1), device=DEV)
+    ok.decode(load_golden("tiny_vae_decode.pt")["z"].to(DEV))
+    assert ok.fallbacks == 0 and ok.dtype == torch.float16
+
+
+def test_sdxl_vae_decode_1024_bfloat16_and_uint8_image_parity():
+    """SDXL decoder at 1024^2 (mid attention over 16 384 tokens): bfloat16 build within the reference's own bf16 floor; the uint8 IMAGE of the fp16
+    build within 2 levels of the reference's image (as asserted for SD1.5 512^2 in test_gpu_e2e.py); decode time of both builds side by side."""
+    g = load_golden("sdxl_vae1024.pt")
+    sd = synth.synth_vae_decoder_state_dict(synth.SDXL_VAE_CONFIG, seed=1)
+    z = g["latent"].to(DEV)
+    times = {}
+    dec = {}
+    for dt in (torch.float16, torch.bfloat16):
+        vae = IntegratedAutoencoderKL(synth.SDXL_VAE_CONFIG, sd, device=DEV, dtype=dt)
+        zz = vae.process_out(z)
+        vae.decode(zz)                                   # sizes the arena
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dec[dt] = vae.decode(zz)
+        torch.cuda.synchronize()
+        times[dt] = (time.perf_counter() - t0) * 1e3
+        assert vae.fallbacks == 0
+        del vae
+    print(f"[vae] SDXL 1024^2 decode of one image: fp16 {times[torch.float16]:.2f} ms, bf16 {times[torch.bfloat16]:.2f} ms")
+    d = dec[torch.bfloat16]
+    check("SDXL VAE decode 1024x1024, bfloat16 build, every 4th pixel vs reference", d[:, :, ::4, ::4], g["decoded_s4"], floor="sdxl_vae1024.pt:decoded@bf16")
+    check("SDXL VAE decode 1024x1024, bfloat16 build, centre crop vs reference", d[:, :, 448:576, 448:576], g["decoded_crop"],
+          floor="sdxl_vae1024.pt:decoded@bf16")
+    for name, fx in (("sdxl_vae1024.pt", g), ("sdxl_config3_decode.pt", load_golden("sdxl_config3_decode.pt"))):
+        zf = fx["latent"].to(DEV)
+        for dt, limit in ((torch.float16, 2), (torch.bfloat16, None)):
+            vae = IntegratedAutoencoderKL(synth.SDXL_VAE_CONFIG, sd, device=DEV, dtype=dt)
+            out = vae.decode(vae.process_out(zf))
+            diff = np.concatenate([np.abs(_u8(out[:, :, ::4, ::4]) - _u8(fx["decoded_s4"])).ravel(),
+                                   np.abs(_u8(out[:, :, 448:576, 448:576]) - _u8(fx["decoded_crop"])).ravel()])
+            print(f"[parity] SDXL 1024^2 image uint8 ({name}, {str(dt).split('.')[-1]}): max diff {diff.max()}, mean {diff.mean():.4f}, "
+                  f"frac>2: {(diff > 2).mean():.5f}")
+            if limit is not None:
+                assert diff.max() <= limit and diff.mean() < 0.25
+            else:
+                assert diff.mean() < 1.5, "bfloat16 image: mean level error"
+            del vae
