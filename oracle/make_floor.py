@@ -20,6 +20,7 @@ tests/parity.py turns that into the tolerances of the native path (max(1e-3, fac
     python -m oracle.make_floor --only sdxl     # SDXL full-size forward floor                                (~8 min)
     python -m oracle.make_floor --only config3  # + fixture sdxl_config3.pt: SDXL 1024^2, one image, 30-step DPM++ 2M + 1024^2 VAE decode (~30 min)
     python -m oracle.make_floor --only vae1024  # 1024^2 decode only (fixture + floor)
+    python -m oracle.make_floor --only flux_width # fixture flux_width3072_fwd.pt: Flux at hidden 3072 / 24 x 128 / 4096 + 256 tokens, 1 + 1 blocks, + its f16 / bf16 floors
     python -m oracle.make_floor --only vae_bf16 # bfloat16 floors of the VAE fixtures + the fp16-overflow fixture tiny_vae_overflow.pt
 """
 import argparse
@@ -355,6 +356,45 @@ def gen_vae_bf16():
     update(out)
 
 
+FLUX_WIDTH_CONFIG = dict(synth.FLUX_DEV_CONFIG, depth=1, depth_single_blocks=1)
+
+
+def flux_width_inputs(cfg=None, seed=33, lat=128, ltxt=256):
+    """Inputs of tests/golden/flux_width3072_fwd.pt, regenerated from the seed: one 1024^2 image (128x128 latent = 4096 image tokens) + 256 text
+    tokens of width 4096 -- BASELINE config 5's token counts."""
+    cfg = cfg or FLUX_WIDTH_CONFIG
+    g = torch.Generator("cpu").manual_seed(seed)
+    x = torch.randn(1, cfg["in_channels"], lat, lat, generator=g)
+    ctx = torch.randn(1, ltxt, cfg["context_in_dim"], generator=g)
+    y = torch.randn(1, cfg["vec_in_dim"], generator=g)
+    return x, torch.tensor([0.71]), ctx, y, torch.full((1,), 3.5)
+
+
+def gen_flux_width():
+    """Flux at ITS OWN WIDTH (round 3): hidden 3072, 24 heads x 128, MLP ratio 4, 4096 + 256 tokens -- Flux.1-dev's shapes with the depth cut to one
+    double-stream and one single-stream block (backend/nn/flux.py:206-307, :372-398), one forward of the REAL reference on CPU fp32 (~2 TFLOP), and
+    its own fp16 / bf16 runs as floors.  Fixture tests/golden/flux_width3072_fwd.pt (the 1 MB output; inputs and weights come back from seeds)."""
+    cfg = FLUX_WIDTH_CONFIG
+    sd = synth.synth_flux_state_dict(cfg, seed=2)
+    x, t, ctx, y, guid = flux_width_inputs(cfg)
+    net = ref_import.build_ref_flux(cfg, sd)
+    t0 = time.time()
+    with torch.no_grad():
+        out = net(x.clone(), t, context=ctx, y=y, guidance=guid)
+    secs = time.time() - t0
+    torch.save({"out": out, "inputs_seed": 33, "weights_seed": 2, "depth": 1, "depth_single_blocks": 1, "cpu_seconds": secs,
+                "params": sum(int(v.numel()) for v in sd.values())}, os.path.join(GOLD, "flux_width3072_fwd.pt"))
+    print("flux width-3072 forward: reference fp32 %.0f s, out std %.4f, params %.3f B" % (secs, float(out.std()), sum(int(v.numel()) for v in sd.values()) / 1e9))
+    floors = {}
+    for tag, dt in (("f16", torch.float16), ("bf16", torch.bfloat16)):
+        n2 = net.to(dt)
+        n2.storage_dtype = n2.computation_dtype = dt
+        with torch.no_grad():
+            o = n2(x.to(dt), t, context=ctx.to(dt), y=y.to(dt), guidance=guid).float()
+        floors[f"flux_width3072_fwd.pt:out@{tag}"] = metrics(o, out)
+    update(floors)
+
+
 def floors_sdxl_full():
     cfg = synth.SDXL_UNET_CONFIG
     g = _load("sdxl_full_fwd.pt")
@@ -512,6 +552,8 @@ def main():
         gen_vae1024()
     if a.only == "vae_bf16":
         gen_vae_bf16()
+    if a.only == "flux_width":
+        gen_flux_width()
     if a.only == "config3":
         gen_config3(a.steps)
 

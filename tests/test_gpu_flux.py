@@ -214,6 +214,27 @@ def test_bf16_layernorm_mod_and_qk_norm_rope():
     torch.testing.assert_close(vt.view(h, d, b, lpad)[:, :, :, row_off:ltot].permute(2, 3, 0, 1).float(), v, rtol=0, atol=0)
 
 
+@pytest.mark.parametrize("dt,tag", [(torch.float16, "f16"), (torch.bfloat16, "bf16")])
+def test_flux_forward_at_its_own_width_vs_reference_fixture(dt, tag):
+    """BASELINE config 5's shapes -- hidden 3072, 24 heads x 128, MLP 4x, 4096 image + 256 text tokens -- with the depth cut to one double-stream and
+    one single-stream block: one forward of the REAL reference (CPU fp32, oracle/make_floor.py gen_flux_width) against the native executor in both
+    builds.  At this width the executor runs what the tiny network never reaches: 256x320-class tiles on K = 3072 / 12288, the wave-specialised
+    d_head-128 attention kernel over 4352 keys, the fused qkv + MLP projection of the single-stream block (21 504 columns)."""
+    import os
+    from conftest import GOLDEN
+    if not os.path.exists(os.path.join(GOLDEN, "flux_width3072_fwd.pt")):
+        pytest.skip("full-width fixture not generated")
+    from oracle.make_floor import FLUX_WIDTH_CONFIG, flux_width_inputs
+    g = load_golden("flux_width3072_fwd.pt")
+    cfg = FLUX_WIDTH_CONFIG
+    net = IntegratedFluxTransformer2DModel(cfg, synth.synth_flux_state_dict(cfg, seed=g["weights_seed"]), device=DEV, dtype=dt)
+    x, t, ctx, y, guid = flux_width_inputs(cfg, seed=g["inputs_seed"])
+    out = net.forward(x.to(DEV), t.to(DEV), ctx.to(DEV, dt), y.to(DEV, dt), guid.to(DEV))
+    assert tuple(out.shape) == tuple(g["out"].shape)
+    check(f"flux forward at width 3072 (24 x 128, 4096 + 256 tokens, 1 + 1 blocks), {tag} build vs reference", out, g["out"],
+          floor=f"flux_width3072_fwd.pt:out@{tag}")
+
+
 def test_bf16_flux_forward_and_sampling_vs_reference_fixture():
     """The Flux executor with dtype=bfloat16 against the fp32 reference fixture (forward and the 4-step Euler run)."""
     g = load_golden("tiny_flux_fwd.pt")
