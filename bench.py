@@ -112,7 +112,7 @@ def self_launch(a):
     sys.exit(subprocess.call(cmd, env=env))
 
 
-def cpu_baseline(model, cfg, latent):
+def cpu_baseline(model, cfg, latent, sampler_name=None, cfg_scale=7.0):
     """Oracle timed on host cores (test-infrastructure import allowed for this leg only).  -> (seconds per sample-forward, threads, note)"""
     import torch
     from forge_amd.backend.nn.layout import unet_param_shapes
@@ -135,6 +135,19 @@ def cpu_baseline(model, cfg, latent):
                                       f"B=1, fp32, torch CPU, {nthreads} threads) took {dt:.1f} s; scaled x{scale:.1f} by block count")
     from oracle.unet import unet_forward
     sd = {name: torch.empty(shape).normal_(0, 0.02, generator=g) for name, shape in unet_param_shapes(cfg).items()}
+    if model == "sd15" and sampler_name is not None:
+        # a SAMPLER RUN, not one forward: the oracle's txt2img loop (CFGDenoiser -> UNet -> sampler update, same sampler as the GPU line) for
+        # one image over `cpu_steps` steps; seconds per step / 2 = seconds per sample-forward, so `value` below is a measured it/s scaled
+        # only by the batch (images are independent), not by an extrapolated step count
+        from oracle import pipeline
+        from forge_amd import synth
+        c1, u1 = synth.synth_conditioning(1, cfg["context_dim"], cfg.get("adm_in_channels"), seed=1234)
+        cpu_steps = 4
+        t1 = time.time()
+        pipeline.txt2img_latents(sd, cfg, c1, u1, [1000], latent * 8, latent * 8, cpu_steps, sampler_name=sampler_name, cfg_scale=cfg_scale)
+        dt = (time.time() - t1) / cpu_steps
+        return dt / 2, nthreads, (f"oracle sampler run: SD1.5 512^2, ONE image, {cpu_steps}-step {sampler_name} with CFG {cfg_scale} (2 sample-forwards per step), fp32, "
+                                  f"torch CPU, {nthreads} threads: {dt:.2f} s per step = {1.0 / dt:.3f} it/s at batch 1")
     x = torch.randn(1, cfg["in_channels"], latent, latent)
     ctx = torch.randn(1, 77, cfg["context_dim"])
     y = torch.randn(1, cfg["adm_in_channels"]) if cfg.get("adm_in_channels") else None
@@ -144,24 +157,91 @@ def cpu_baseline(model, cfg, latent):
     return dt, nthreads, (f"one {model.upper()} UNet sample-forward (B=1, {latent}x{latent} latent, fp32, torch CPU, {nthreads} threads) took {dt:.1f} s")
 
 
+def kernel_source_hash():
+    """sha256 (first 16 hex digits) over csrc/*.hip, *.hpp and include/fmx.h: identifies the kernel sources a binary / a PMC summary belongs to."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    pk = os.path.join(ROOT, "stable-diffusion-webui-forge_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(pk, "*.hip")) + glob.glob(os.path.join(pk, "*.hpp")) + [os.path.join(ROOT, "include", "fmx.h")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic_per_launch():
     """HBM bytes per launch of the GEMM kernels from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE
-    runs of this same workload, tools/gpu_round.sh pmc -> profiles/*_pmc_fetch_write_summary.json; FETCH_SIZE doubled per
-    MI355X_MICROARCH.md).  bench.py cannot run the profiler on itself, so this is the last committed measurement or None."""
+    runs of this same workload, tools/gpu_round2.sh pmc_hbm -> profiles/*_pmc_fetch_write_summary.json; FETCH_SIZE doubled per
+    MI355X_MICROARCH.md).  bench.py cannot run the profiler on itself, so this is the last committed measurement -- and ONLY if that
+    summary was taken on the kernel sources being timed now (`kernel_source_hash` recorded by tools/pmc_summary.py): a summary of an
+    older binary is refused (traffic null, the reason beside it) rather than quoted as this binary's traffic."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_fetch_write_summary.json")))
     if not files:
-        return None
+        return None, "no committed PMC summary"
     try:
         d = json.load(open(files[-1]))
+        src = d.get("kernel_source_hash")
+        if src != kernel_source_hash():
+            return None, f"{os.path.basename(files[-1])} was measured on kernel sources {src}, this binary is {kernel_source_hash()}: stale, refused"
         n = b = 0.0
         for fam in ("gemm", "gemm256"):
             if fam in d:
                 n += d[fam]["launches_FETCH_SIZE"]
                 b += d[fam]["hbm_bytes_per_launch"] * d[fam]["launches_FETCH_SIZE"]
-        return {"hbm_bytes_per_launch_avg": round(b / n), "source": os.path.basename(files[-1])} if n else None
-    except Exception:
-        return None
+        if not n:
+            return None, "summary holds no GEMM launches"
+        return {"hbm_bytes_per_launch_avg": round(b / n), "source": os.path.basename(files[-1]), "kernel_source_hash": src}, None
+    except Exception as e:
+        return None, repr(e)
+
+
+class ClockSampler:
+    """Shader / memory clocks of the timed region, read from the amdgpu sysfs DPM tables (the `*` line of pp_dpm_sclk / pp_dpm_mclk) every
+    20 ms on a host thread: puts the 'power-limited at ~1.8 GHz' statement into the driver-visible line.  Null fields when the files are absent."""
+
+    def __init__(self, local):
+        import glob
+        self.files = {}
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        if cards:
+            base = os.path.dirname(cards[min(local, len(cards) - 1)])
+            self.files = {"sclk": os.path.join(base, "pp_dpm_sclk"), "mclk": os.path.join(base, "pp_dpm_mclk")}
+        self.samples = {k: [] for k in self.files}
+        self._stop = False
+        self._t = None
+
+    def _read(self):
+        for k, f in self.files.items():
+            try:
+                for line in open(f):
+                    if "*" in line:
+                        self.samples[k].append(int("".join(ch for ch in line.split(":")[1] if ch.isdigit())))
+            except Exception:
+                pass
+
+    def __enter__(self):
+        import threading
+
+        def loop():
+            while not self._stop:
+                self._read()
+                time.sleep(0.02)
+        if self.files:
+            self._t = threading.Thread(target=loop, daemon=True)
+            self._t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        if self._t:
+            self._t.join()
+
+    def summary(self):
+        out = {}
+        for k, v in self.samples.items():
+            out[k + "_mhz"] = {"min": min(v), "mean": round(sum(v) / len(v)), "max": max(v), "samples": len(v)} if v else None
+        return out or None
 
 
 def stub_main(a, rank, world):
@@ -326,12 +406,14 @@ def main():
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        lat = run_sampler(a.steps)           # exactly K timed steps
-        torch.cuda.synchronize()
-        barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
+        clocks = ClockSampler(local)
+        with clocks:
+            t0 = time.perf_counter()
+            lat = run_sampler(a.steps)           # exactly K timed steps
+            torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
         if world > 1:
             tmax = torch.tensor([elapsed], device=dev)
             torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -387,9 +469,10 @@ def main():
             g = summ.get("gemm_conv")
             if g:
                 ach = g["flops"] / g["seconds"]
+                traffic, traffic_note = pmc_traffic_per_launch()
                 roof = {"kernel": "gemm256p_kernel<256x320 | 320x256 | 256x256 | 512x128> + gemm_kernel (fmx_gemm_conv: MFMA implicit-GEMM conv3x3/1x1 + linear, fused epilogues)",
                         "bound": "mfma", "achieved": round(ach / 1e12, 1), "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s",
-                        "frac": round(ach / MFMA_PEAK, 4), "traffic": pmc_traffic_per_launch(), "launches_per_forward": g["launches"],
+                        "frac": round(ach / MFMA_PEAK, 4), "traffic": traffic, "traffic_note": traffic_note, "launches_per_forward": g["launches"],
                         "flop_per_launch_avg": round(g["flops"] / g["launches"] / 1e9, 2), "flop_unit": "GFLOP",
                         "us_per_launch_avg": round(g["seconds"] / g["launches"] * 1e6, 1),
                         "kernel_time_per_forward_ms": round(g["seconds"] * 1e3, 2)}
@@ -440,6 +523,8 @@ def main():
         f"ms_per_image_{nominal}_steps_plus_vae": None if vae_ms is None else round((nominal * ms_per_step + vae_ms) / bpg, 1),
         "comm_ms": {"broadcast_cond": round(t_bcast * 1e3, 2), "gather_latents": round(t_gather * 1e3, 2)},
         "build_s": round(t_build, 1),
+        "clocks_during_timed_steps": clocks.summary(),
+        "kernel_source_hash": kernel_source_hash(),
     }
     if roof:
         out["roofline"] = roof
@@ -451,7 +536,7 @@ def main():
         out["roofline_groupnorm"] = gn_roof
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
-            dt, nthreads, note = cpu_baseline(model, ucfg, latent)
+            dt, nthreads, note = cpu_baseline(model, ucfg, latent, sampler_name, cfg_scale)
             out["cpu_baseline"] = {"value": round(1.0 / (fwd_per_image * bpg * dt), 6), "unit": "it/s", "cores": nthreads, "kind": "port",
                                    "sample": note + f"; a step of this workload is {fwd_per_image * bpg} such forwards"}
             if model in REFERENCE_CPU_AUTHORING_BOX:

@@ -99,7 +99,14 @@ __device__ __forceinline__ void epi_rows(const char* my, int lane, int mbase, in
   }
   // vmcnt retires in order, loads and stores alike: an iteration that loads its operands AFTER the previous iteration's
   // store waits for that store to complete.  So the operands of iteration it+1 are requested before iteration it stores.
-  f16x8 rv[2], gt[2], rs[2];
+  // One iteration of lead is ~200 cycles of work against 900 cycles of HBM latency (the residual was written a whole kernel ago):
+  // the pass was a chain of ITERS memory latencies.  PF-1 iterations of lead (ring of PF register slots; the accumulators' fragment
+  // double buffer is dead by now, so the registers exist) put PF-1 latencies in flight per wave.
+#ifndef FMX_EPI_PREFETCH
+#define FMX_EPI_PREFETCH 6
+#endif
+  constexpr int PF = MODE == 1 ? FMX_EPI_PREFETCH : (MODE == 3 ? (FMX_EPI_PREFETCH > 3 ? 3 : FMX_EPI_PREFETCH) : 2);
+  f16x8 rv[PF], gt[PF], rs[PF];
   auto fetch = [&](int it, int slot) {
     const int row = min(it * RPI + rsub, ROWS - 1);
     const int m = mbase + row;
@@ -109,11 +116,12 @@ __device__ __forceinline__ void epi_rows(const char* my, int lane, int mbase, in
     if (MODE == 0) gt[slot] = *reinterpret_cast<const f16x8*>(gate + img * ld_gt);
     if (MODE <= 1 || MODE == 3) rs[slot] = *reinterpret_cast<const f16x8*>(res + mc * ld_res);
   };
-  fetch(0, 0);
+#pragma unroll
+  for (int it = 0; it < PF - 1 && it < ITERS; ++it) fetch(it, it);
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
-    const int cur = it & 1;
-    if (it + 1 < ITERS) fetch(it + 1, cur ^ 1);
+    const int cur = it % PF;
+    if (it + PF - 1 < ITERS) fetch(it + PF - 1, (it + PF - 1) % PF);
     const int row = min(it * RPI + rsub, ROWS - 1);
     const f32x4 lo = *reinterpret_cast<const f32x4*>(my + row * RB + (((2 * cg) ^ (row & SWZ)) << 4));
     const f32x4 hi4 = *reinterpret_cast<const f32x4*>(my + row * RB + (((2 * cg + 1) ^ (row & SWZ)) << 4));

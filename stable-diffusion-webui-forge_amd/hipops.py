@@ -386,8 +386,14 @@ def attach_stats(t, st):
     and address: an in-place torch edit nobody announced (a hook holding the NCHW view: `h.add_(...)`) bumps the counter, and `_attached_stats`
     then ignores the stale record instead of normalising with it (C-ABI launches write through raw pointers and do not bump it: they call
     clear_stats themselves)."""
-    t._fmx_gn_stats = None if st is None else (st, t._version, t.data_ptr())
+    t._fmx_gn_stats = None if st is None else (st, _version_of(t), t.data_ptr())
     return t
+
+
+def _version_of(t):
+    """torch's in-place version counter; inference-mode tensors (processing runs under torch.inference_mode, as the reference does) do not
+    keep one -- there the address is the only tag and in-place writers have to announce themselves through clear_stats, as before."""
+    return None if t.is_inference() else t._version
 
 
 def _attached_stats(t):
@@ -395,7 +401,7 @@ def _attached_stats(t):
     if rec is None:
         return None
     st, version, ptr = rec
-    if version != t._version or ptr != t.data_ptr():
+    if version != _version_of(t) or ptr != t.data_ptr():
         t._fmx_gn_stats = None
         return None
     return st

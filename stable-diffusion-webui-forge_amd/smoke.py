@@ -25,15 +25,23 @@ def run():
                                                     steps=3, width=128, height=128)
     res = processing.process_images(p)
     lat, dec, img = pipeline.txt2img(sd, cfg, vsd, synth.TINY_VAE_CONFIG, c, uc, [3, 4], 128, 128, 3, sampler_name="Euler")
-    e1 = float((res.latents.cpu() - lat).abs().max() / lat.abs().max())
-    e2 = float((res.decoded.cpu() - dec).abs().max() / dec.abs().max())
+    def rel(a, ref):
+        d = (a.double().cpu() - ref.double())
+        return float(d.abs().max() / ref.abs().max()), float(d.pow(2).mean().sqrt() / ref.double().pow(2).mean().sqrt())
+    (m1, r1), (m2, r2) = rel(res.latents, lat), rel(res.decoded, dec)
     # the yard-stick: what the REAL reference loses when it runs this same job in its own fp16 mode instead of fp32
-    # (oracle/make_floor.py floors_pipeline -> tests/golden/fp16_floor.json); the north star's 1e-3 applies where that floor is below it
+    # (oracle/make_floor.py floors_pipeline -> tests/golden/fp16_floor.json); the north star's 1e-3 applies where that floor is below it.
+    # The gate is the RMS error (a stable statistic: 1.25 x the floor, as tests/parity.py); the maximum over a 2-image job is one draw of an
+    # extreme-value statistic -- round 2's smoke sat at 1.46 x the floor's maximum against a 1.5 x limit with the rms BELOW the floor -- so
+    # it only has to stay within 2 x (a wrong kernel is off by orders of magnitude in both).
     import json
     fl = json.load(open(os.path.join(root, "tests", "golden", "fp16_floor.json")))
-    f1, f2 = fl["pipeline:smoke_euler3/latent"]["max_rel"], fl["pipeline:smoke_euler3/decoded"]["max_rel"]
-    l1, l2 = max(1e-3, 1.5 * f1), max(1e-3, 1.5 * f2)
-    print(f"smoke: latents max_rel {e1:.3e} (reference fp16-vs-fp32 floor {f1:.3e}, limit {l1:.2e}), "
-          f"decoded max_rel {e2:.3e} (floor {f2:.3e}, limit {l2:.2e})")
-    assert e1 <= l1 and e2 <= l2, (e1, l1, e2, l2)
+    ok = True
+    for what, m, r in (("latent", m1, r1), ("decoded", m2, r2)):
+        f = fl["pipeline:smoke_euler3/" + what]
+        lm, lr = max(1e-3, 2.0 * f["max_rel"]), max(1e-3, 1.25 * f["rms_rel"])
+        print(f"smoke: {what} rms_rel {r:.3e} (reference fp16-vs-fp32 floor {f['rms_rel']:.3e}, limit {lr:.2e}), "
+              f"max_rel {m:.3e} (floor {f['max_rel']:.3e}, limit {lm:.2e})")
+        ok = ok and r <= lr and m <= lm
+    assert ok, "smoke parity outside the fp16 floor"
     print("smoke OK")

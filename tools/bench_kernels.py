@@ -62,6 +62,19 @@ def bench_linear_cold(m, n, k, tile=0, act=0, copies=None):
                       "tflops": round(2 * m * n * k / t / 1e12, 1)}), flush=True)
 
 
+def bench_linear_res(m, n, k, tile=0, copies=8, residual=True, inplace=True):
+    """Residual-adding projection (attn `to_out`, ff.net.2) as the forward runs it: in a graph, every call with its own weights AND its own
+    residual stream (written long ago: cold), x += f(x) in place or out of place.  Isolates the epilogue's row pass (round 3)."""
+    x, b = rnd(m, k), rnd(n)
+    ws = [rnd(n, k, scale=k ** -0.5) for _ in range(copies)]
+    rs = [rnd(m, n) for _ in range(copies)] if residual else [None] * copies
+    outs = rs if (inplace and residual) else [torch.empty(m, n, dtype=torch.float16, device=DEV) for _ in range(copies)]
+    t = timeit_graph([(lambda w=w, r=r, o=o: ops.conv_gemm(x, w, n, bias=b, residual=r, out=o, ld_out=n, force_tile=tile)) for w, r, o in zip(ws, rs, outs)])
+    print(json.dumps({"op": "linear + residual (in graph, cold)" if residual else "linear (in graph, cold, distinct outputs)", "m": m, "n": n, "k": k,
+                      "tile": tile, "inplace": bool(inplace and residual), "us": round(t * 1e6, 1), "tflops": round(2 * m * n * k / t / 1e12, 1),
+                      "lib": os.environ.get("FMX_LIB", "default")}), flush=True)
+
+
 def rnd(*shape, scale=1.0):
     return (torch.randn(*shape, device=DEV) * scale).half()
 
@@ -255,6 +268,12 @@ if __name__ == "__main__":
             bench_attn(8, 20, 1024, 1024, 64, 64, f32)   # 640 tiles = 1.25 rounds
             bench_attn(2, 20, 1024, 1024, 64, 64, f32)   # batch 1 under CFG: 160 tiles
             bench_attn(2, 24, 4352, 4352, 128, 128, f32)  # Flux-dev at 1024^2: 4096 image + 256 text tokens, 24 heads of 128
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "epi":
+        # round 3: what the epilogue costs.  Full chip (256 tiles), half chip (128 tiles: is the row pass contention-bound?), two rounds, long K
+        for m, n, k in ((16384, 1280, 1280), (8192, 1280, 1280), (16384, 2560, 1280), (16384, 1280, 5120), (65536, 640, 640), (65536, 640, 2560)):
+            bench_linear_res(m, n, k, residual=False)
+            bench_linear_res(m, n, k, residual=True)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "smallm":
         # batch-1 shapes (UNet batch 2): which tile is fastest, and what does the dispatcher (tile 0) pick?

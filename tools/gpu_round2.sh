@@ -14,7 +14,8 @@ pmc_pass() {  # $1 = pass name, $2.. = counters ; workload: tools/pmc_kernels.py
 }
 for w in "$@"; do
   case $w in
-    tests) FMX_PARITY_LOG=$O/parity.jsonl timeout 1500 python -m pytest tests -m gpu -q -s 2>&1 | grep -v "^\[parity\]" | tail -60 > $O/pytest_gpu.log; tail -8 $O/pytest_gpu.log;;
+    tests) FMX_PARITY_LOG=$O/parity.jsonl timeout 1500 python -m pytest tests -m gpu -q -s --tb=line 2>&1 | grep -v "^\[parity\]" | tail -120 > $O/pytest_gpu.log; tail -8 $O/pytest_gpu.log;;
+    epi) for L in "" tools/_build/libfmx_pf2.so tools/_build/libfmx_pf6.so; do FMX_LIB=$L timeout 300 python tools/bench_kernels.py epi >> $O/epi.jsonl 2>> $O/epi.err; done; cat $O/epi.jsonl;;
     testsx) FMX_PARITY_LOG=$O/parity.jsonl timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -40 > $O/pytest_gpu.log; tail -8 $O/pytest_gpu.log;;
     ktests) timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q 2>&1 | tail -40 > $O/ktests.log; tail -12 $O/ktests.log;;
     smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -3 $O/smoke.log;;

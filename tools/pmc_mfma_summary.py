@@ -63,6 +63,9 @@ def main(root):
                     o[n] = round(m[c] / m["SQ_WAVE_CYCLES"], 3)
         o["raw"] = {c: round(v) for c, v in m.items()}
         out[key] = o
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernel_source_hash
+    out["kernel_source_hash"] = kernel_source_hash()   # which kernel sources these counters were taken on
     print(json.dumps(out, indent=1))
 
 

@@ -30,4 +30,8 @@ for fam, d in out.items():
     d["fetch_bytes_per_launch_corrected"] = 2 * d["fetch_bytes_per_launch_raw"]
     d["write_bytes_per_launch_raw"] = d["WRITE_SIZE_KiB"] * 1024 / nw
     d["hbm_bytes_per_launch"] = d["fetch_bytes_per_launch_corrected"] + d["write_bytes_per_launch_raw"]
+# which kernel sources these counters belong to: bench.py quotes `roofline.traffic` from this file only when the hash matches the binary it times
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_hash  # noqa: E402
+out["kernel_source_hash"] = kernel_source_hash()
 print(json.dumps(out, indent=1))
