@@ -760,3 +760,10 @@ def test_sdxl_vae_decode_1024_vs_reference_fixture(fixture, sdxl_engine):
     fl = f"{fixture}:decoded"
     check(f"SDXL VAE decode 1024x1024 ({fixture}) every 4th pixel vs reference", dec[:, :, ::4, ::4], g["decoded_s4"], floor=fl)
     check(f"SDXL VAE decode 1024x1024 ({fixture}) centre crop vs reference", dec[:, :, 448:576, 448:576], g["decoded_crop"], floor=fl)
+    # the uint8 image as processing.py makes it (clamp((x + 1) / 2) * 255, truncated, :1012-1040) from both decodes: the bar of the SD1.5 image test
+    def u8(x):
+        return (255.0 * torch.clamp((x.float().cpu() + 1.0) / 2.0, min=0.0, max=1.0)).numpy().astype(np.uint8).astype(np.int32)
+    for what, got, ref in (("every 4th pixel", dec[:, :, ::4, ::4], g["decoded_s4"]), ("centre crop", dec[:, :, 448:576, 448:576], g["decoded_crop"])):
+        diff = np.abs(u8(got) - u8(ref))
+        print(f"[parity] SDXL 1024x1024 image uint8 ({fixture}, {what}): max diff {diff.max()}, mean {diff.mean():.4f}, frac>1: {(diff > 1).mean():.5f}")
+        assert diff.max() <= 2 and diff.mean() < 0.25
