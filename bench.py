@@ -203,10 +203,20 @@ class ClockSampler:
     def __init__(self, local):
         import glob
         self.files = {}
-        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
-        if cards:
-            base = os.path.dirname(cards[min(local, len(cards) - 1)])
-            self.files = {"sclk": os.path.join(base, "pp_dpm_sclk"), "mclk": os.path.join(base, "pp_dpm_mclk")}
+        self.note = None
+        try:   # the sysfs card of THIS HIP device: match the PCI address (the host may expose more cards than the container sees GPUs)
+            import torch
+            pr = torch.cuda.get_device_properties(local)
+            want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+            for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+                base = os.path.dirname(f)
+                if want in os.path.realpath(base).lower():
+                    self.files = {"sclk": os.path.join(base, "pp_dpm_sclk"), "mclk": os.path.join(base, "pp_dpm_mclk")}
+                    self.note = "sysfs " + base + " (PCI " + want + ")"
+            if not self.files:
+                self.note = "no sysfs card with PCI address " + want
+        except Exception as e:
+            self.note = repr(e)
         self.samples = {k: [] for k in self.files}
         self._stop = False
         self._t = None
@@ -238,10 +248,10 @@ class ClockSampler:
             self._t.join()
 
     def summary(self):
-        out = {}
+        out = {"source": self.note}
         for k, v in self.samples.items():
             out[k + "_mhz"] = {"min": min(v), "mean": round(sum(v) / len(v)), "max": max(v), "samples": len(v)} if v else None
-        return out or None
+        return out
 
 
 def stub_main(a, rank, world):

@@ -38,6 +38,7 @@ struct AttnParams {
   float inv_scale;            // 1 / scale: the mask is added to the UNSCALED score
   int nfull, nsplit;          // q64v2: workgroups [0, nfull) own 256 queries x all keys; [nfull, nfull + nsplit) are key-split (see the kernel)
   int bid0;            // first workgroup index of this launch (0 except for a key-split tail launched on its own)
+  int sk_tpw, sk_chunks;      // attn_short_kernel: 128-query tiles per persistent workgroup, workgroups per (batch, head)
 };
 
 constexpr int KVB = 64;  // keys per tile
@@ -1412,6 +1413,197 @@ __global__ __launch_bounds__(512, 2) void attn_ws_kernel(const AttnParams p) {
   }
 }
 
+
+// ---- d_head 64, contexts of at most 128 keys (the 77-token text context of every cross-attention, round 3) -------------------------------
+// The launch is a streaming kernel -- one read of Q, one write of O, ~90 FLOP per byte -- that the 64-query kernels above ran at a third of
+// the HBM rate (profiles/r07m: 2.6 ms per SDXL forward at 2.6 TB/s): a workgroup there lives for ONE query tile, and its life is a chain of
+// latencies (Q from HBM -> scores -> softmax -> P V -> store drain) with two workgroups per CU to overlap it.  Here
+//   * a workgroup is PERSISTENT over `sk_tpw` consecutive 128-query tiles of one (batch, head): the two K / V^T tiles (32 KB) are staged in
+//     LDS once, and the Q rows of tile t + 1 are requested before tile t is computed, so a load is in flight behind every tile's arithmetic;
+//   * 32 queries per wave (one query fragment), one key block's fragments live at a time: 114 registers -> four workgroups per CU instead of
+//     two, 32 KB of LDS each;
+//   * the softmax is ONE pass over all NB 32-key blocks (exact maximum, no running state, no rescale), and only the blocks that hold keys are
+//     computed (77 keys: 3 of the 4 blocks of the two 64-key tiles -- the looped kernels did 128 keys' worth of exponentials and MFMAs).
+// Same operand layouts as attn_q64v2_kernel (S^T = K Q^T with permuted key rows, O^T = V^T P^T, lane = query).
+template <int NB>
+__global__ __launch_bounds__(256, 4) void attn_short_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int DP = 64, DSTEPS = 4, CPR = 8;
+  constexpr int KBYTES = KVB * DP * 2;          // one 64-key K tile: 64 rows x 128 B
+  constexpr int STAGE = KBYTES + 2 * 32 * 128;   // + its V^T tile: 64 channel rows x 128 B (64 keys)
+  constexpr int NT = (NB + 1) / 2;               // 64-key tiles that hold keys
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, li = lane & 31;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int chunk = wg % p.sk_chunks;
+  const int bh = wg / p.sk_chunks;
+  const int h = bh % p.heads, b = bh / p.heads;
+  const int t0 = chunk * p.sk_tpw, t1 = min(t0 + p.sk_tpw, p.qtiles);   // 128-query tiles [t0, t1) of this (batch, head)
+
+  // K / V^T of this (batch, head): tiles 0 .. NT-1 by LDS-DMA, two + two 1-KiB pieces per wave and tile (layout and swizzles of q64v2)
+  const f16* kbase = p.k + (long)b * p.k_bs + (long)h * DP;
+  const f16* vbase = p.vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
+  const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(kbase), 0, p.k_span, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(vbase), 0, p.vt_span, 0x00020000);
+#pragma unroll
+  for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int krow = (e * 4 + wave) * 8 + lane / CPR;
+      const unsigned kv = (unsigned)krow * (unsigned)p.k_rs * 2u + (unsigned)k_logical_chunk<CPR>(krow, lane % CPR) * 16u;
+      auto* dk = (__attribute__((address_space(3))) void*)(smem + kt * STAGE + (e * 4 + wave) * 1024);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, dk, 16, kv, (unsigned)kt * ((unsigned)KVB * (unsigned)p.k_rs * 2u), 0, 0);
+      const int vrow = (e * 4 + wave) * 8 + (lane >> 3);
+      const unsigned vv = (unsigned)vrow * (unsigned)p.vt_ds * 2u + (unsigned)((lane & 7) ^ ((vrow >> 1) & 7)) * 16u;
+      auto* dv = (__attribute__((address_space(3))) void*)(smem + kt * STAGE + KBYTES + (e * 4 + wave) * 1024);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, dv, 16, vv, (unsigned)kt * (KVB * 2u), 0, 0);
+    }
+
+  const float c2 = p.scale_log2e;
+  const f16* qhead = p.q + (long)b * p.q_bs + (long)h * DP + hi * 8;
+  f16x8 raw[DSTEPS];   // Q rows of the NEXT tile, as loaded
+  auto load_q = [&](int t) {
+    const int qrow = min(t * 128 + wave * 32 + li, p.nq - 1);
+    const f16* qp = qhead + (long)qrow * p.q_rs;
+#pragma unroll
+    for (int ds = 0; ds < DSTEPS; ++ds) raw[ds] = *reinterpret_cast<const f16x8*>(qp + ds * 16);
+  };
+  if (t0 < t1) load_q(t0);
+  wait_vmcnt0();
+  __syncthreads();   // K / V^T visible to every wave; nothing below writes LDS, so this is the only barrier
+
+  const int krow = key_perm(li);
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  for (int t = t0; t < t1; ++t) {
+    f16x8 qf[DSTEPS];
+#pragma unroll
+    for (int ds = 0; ds < DSTEPS; ++ds)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qf[ds][e] = (f16)((float)raw[ds][e] * c2);
+    if (t + 1 < t1) load_q(t + 1);   // in flight behind this tile's arithmetic (its registers were just consumed)
+
+    // ---- scores of all NB blocks: S^T = K Q^T in exp2 units ----
+    f32x16 sacc[NB];
+#pragma unroll
+    for (int g = 0; g < NB; ++g) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[g][r] = 0.f;
+      const char* sk = smem + (g >> 1) * STAGE;
+      const int row = (g & 1) * 32 + krow;
+#pragma unroll
+      for (int ds = 0; ds < DSTEPS; ++ds) {
+        const f16x8 kf = *reinterpret_cast<const f16x8*>(sk + row * (DP * 2) + (k_phys_chunk<CPR>(row, ds * 2 + hi) << 4));
+        sacc[g] = FMX_MFMA_32x32x16(kf, qf[ds], sacc[g]);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // one block's fragments at a time: left alone the scheduler hoists all 4 NB fragment reads (48 registers)
+    }
+    if (NB * 32 > p.nk) {   // keys >= nk of the last block(s): out of the softmax (uniform branch)
+#pragma unroll
+      for (int g = 0; g < NB; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (g * 32 + hi * 16 + r >= p.nk) sacc[g][r] = -INFINITY;
+    }
+    // ---- one-pass softmax: exact maximum of the query (both half-waves hold 16 keys of each block), P = 2^(s - m) ----
+    float m0 = sacc[0][0];
+#pragma unroll
+    for (int g = 0; g < NB; ++g)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m0 = fmaxf(m0, sacc[g][r]);
+    const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m0), __float_as_uint(m0), false, false);
+    const float mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    float l = 0.f;
+    f16x8 pf[NB][2];
+#pragma unroll
+    for (int g = 0; g < NB; ++g)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(sacc[g][r] - mx);
+        l += e;
+        pf[g][r >> 3][r & 7] = (f16)e;
+      }
+    // ---- O^T = V^T P^T over the NB blocks ----
+    f32x16 oacc[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+      const int row = dt * 32 + li;
+      const int swz = (row >> 1) & 7;
+#pragma unroll
+      for (int g = 0; g < NB; ++g) {
+        const char* rp = smem + (g >> 1) * STAGE + KBYTES + row * 128;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const f16x8 vf = *reinterpret_cast<const f16x8*>(rp + ((((g & 1) * 4 + hi * 2 + j) ^ swz) << 4));
+          oacc[dt] = FMX_MFMA_32x32x16(vf, pf[g][j], oacc[dt]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- 1 / l and the store: 16 bytes per lane after a half-wave swap (as q64v2) ----
+    const u32x2 lw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l), __float_as_uint(l), false, false);
+    const float inv = 1.0f / (__uint_as_float(lw[0]) + __uint_as_float(lw[1]));
+    const int qg = t * 128 + wave * 32 + li;
+    f16* op = p.o + (long)b * p.o_bs + (long)qg * p.o_rs + (long)h * DP;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; g += 2) {
+        union { f16x4 h4; unsigned u[2]; } lo, up;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          lo.h4[e] = (f16)(oacc[dt][g * 4 + e] * inv);
+          up.h4[e] = (f16)(oacc[dt][(g + 1) * 4 + e] * inv);
+        }
+        const u32x2 x = __builtin_amdgcn_permlane32_swap(lo.u[0], up.u[0], false, false);
+        const u32x2 y = __builtin_amdgcn_permlane32_swap(lo.u[1], up.u[1], false, false);
+        const u32x4 v = {x[0], y[0], x[1], y[1]};
+        if (qg < p.nq) *reinterpret_cast<u32x4*>(op + dt * 32 + (g + hi) * 8) = v;
+      }
+  }
+}
+
+template <int NB>
+int launch_attn_short_nb(AttnParams& p, int grid, hipStream_t st) {
+  constexpr int SMEM = ((NB + 1) / 2) * (KVB * 64 * 2 + 2 * 32 * 128);
+  hipLaunchKernelGGL(attn_short_kernel<NB>, dim3(grid), dim3(256), SMEM, st, p);
+  FMX_LAUNCH_CHECK("fmx_attention_f16 (short context)");
+  return FMX_OK;
+}
+
+// nk <= 128, d_head 64, no mask: tiles of 128 queries, `sk_tpw` of them per persistent workgroup so that the launch is at most one round of
+// the 4-per-CU workgroup slots (every workgroup resident from the start: no tail round)
+int launch_attn_short(AttnParams p, hipStream_t st) {
+  static int slots = 0;
+  if (!slots) {
+    int dev = 0, cus = 256;
+    if (!(hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)) cus = 256;
+    const char* e = getenv("FMX_ATTN_SHORT_WGS");   // A/B knob: workgroups per CU the launch is sized for (the kernel allows 4)
+    const int per_cu = e ? atoi(e) : 4;
+    slots = (per_cu >= 1 && per_cu <= 4 ? per_cu : 4) * cus;
+  }
+  p.qtiles = (p.nq + 127) / 128;
+  const long bh = (long)p.batch * p.heads;
+  int chunks = (int)((slots + bh - 1) / bh);           // workgroups per (batch, head) the slots allow ...
+  if (chunks * bh > slots && chunks > 1) --chunks;     // ... rounded down to stay within one round
+  if (chunks > p.qtiles) chunks = p.qtiles;
+  if (chunks < 1) chunks = 1;
+  p.sk_tpw = (p.qtiles + chunks - 1) / chunks;
+  p.sk_chunks = (p.qtiles + p.sk_tpw - 1) / p.sk_tpw;
+  const int grid = (int)(bh * p.sk_chunks);
+  const int nb = (p.nk + 31) / 32;
+  switch (nb) {
+    case 1: return launch_attn_short_nb<1>(p, grid, st);
+    case 2: return launch_attn_short_nb<2>(p, grid, st);
+    case 3: return launch_attn_short_nb<3>(p, grid, st);
+    default: return launch_attn_short_nb<4>(p, grid, st);
+  }
+}
+
 template <int DP>
 int launch_attn_v2(AttnParams p, hipStream_t st) {
   constexpr int DVT = DP / 32;
@@ -1467,6 +1659,14 @@ int launch_attn_v2(AttnParams p, hipStream_t st) {
         FMX_LAUNCH_CHECK("fmx_attention_f16 (key-split tail)");
       }
       return FMX_OK;
+    }
+    if (DP == 64 && p.nk <= 128) {
+      static int sk = -1;
+      if (sk < 0) {
+        const char* e7 = getenv("FMX_ATTN_SHORT");   // A/B knob: 0 = the looped 64-query kernels for short contexts as well (round 2)
+        sk = e7 ? atoi(e7) : 1;
+      }
+      if (sk) return launch_attn_short(p, st);
     }
     if (DP == 64 && !do_split) {
       static int v3 = -1;
@@ -1558,6 +1758,7 @@ extern "C" int fmx_attention_f16(const fmx_attn_args* a, void* stream) {
   p.causal = a->causal ? 1 : 0;
   p.k_span = p.vt_span = 0;
   p.nfull = p.nsplit = p.bid0 = 0;
+  p.sk_tpw = p.sk_chunks = 0;
   p.mask = (const f16*)a->mask; p.mask_bs = a->mask_bs; p.mask_hs = a->mask_hs; p.mask_qs = a->mask_qs;
   p.inv_scale = 1.0f / fabsf(a->scale);
   FMX_REQUIRE(!p.mask || (fmx_aligned16(p.mask) && (p.mask_bs % 8) == 0 && (p.mask_hs % 8) == 0 && (p.mask_qs % 8) == 0),

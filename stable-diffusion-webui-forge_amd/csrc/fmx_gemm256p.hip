@@ -200,14 +200,24 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   const unsigned long long rt_entry = __builtin_amdgcn_s_memrealtime();
 #endif
   const int tid = threadIdx.x;
-  const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / G::WN, wn = wave % G::WN;
-  const int hi = lane >> 5, li = lane & 31;
 
   // ---- tile id: XCD remap, then 8-row groups of tiles so that an XCD's 32 concurrent tiles form an 8 x 4 patch ----
+  // PERSISTENT over the launch's tiles (round 3): workgroup b owns tiles b, b + grid, b + 2 grid, ... (grid = one workgroup per CU, a
+  // multiple of 8, so a workgroup's tiles stay on its XCD).  A workgroup dispatched per tile cannot start before its predecessor on the CU has
+  // drained its output stores and released the LDS; here the stores of tile t are still in flight while the LDS-DMA prologue of tile t + 1
+  // is issued (the first K-tile's vmcnt(0) then waits for both), and the dispatch / descriptor set-up of later rounds is gone.
   const int nwg = p.tiles_m * p.tiles_n;
-  const int wg = xcd_remap(blockIdx.x, nwg);
+  for (int lid = blockIdx.x; lid < nwg; lid += gridDim.x) {
+  // the lane id passes through an opaque copy once per tile: every per-lane address below (LDS-DMA offsets, fragment and epilogue LDS offsets)
+  // is the same for all tiles, and hoisted out of this loop they would ride through the K loop in ~45 registers the 160-accumulator tile
+  // does not have (spilled to scratch when first tried)
+  int lane_it = tid & 63;
+  asm volatile("" : "+v"(lane_it));
+  const int lane = lane_it;
+  const int hi = lane >> 5, li = lane & 31;
+  const int wg = xcd_remap(lid, nwg);
   int tm, tn;
   {
     constexpr int GM = 8;
@@ -645,12 +655,27 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
     dbg[5] = (unsigned)(__builtin_amdgcn_s_memrealtime() - rt0) - dbg_rt;  // epilogue incl. store drain up to here
   }
 #endif
+  // every wave is done with its epilogue slice of the LDS before the next tile's LDS-DMA pieces (any wave's) land in it
+  if (lid + (int)gridDim.x < nwg) __syncthreads();
+  }  // tile loop
 }
 
 // SC / SL: DMA issue schedule of the convolution / linear instantiation.  Measured (profiles/r04j_gemm_dma_schedule_ab.jsonl, 256x320 tile, two
 // runs each): the linear GEMMs of the SDXL forward gain 2-3 % from schedule 1 (993 -> 1014, 847 -> 870 GEGLU, 1186 -> 1225 at K = 5120, 1042 ->
 // 1065 TFLOP/s), the implicit-GEMM convolutions (longer address arithmetic per piece) are level or 1 % slower -> linear 1, convolution 0.
 // the two LayerNorm-folding instantiations: linear GEMMs on the 256 x 320 tile only
+// grid of a launch: one persistent workgroup per CU (FMX_GEMM_PERSIST=0: one workgroup per tile, the round-2 launch shape, for A/B)
+static int persistent_grid(int tiles) {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0, n = 256;
+    if (!(hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n >= 8)) n = 256;
+    const char* e = getenv("FMX_GEMM_PERSIST");
+    cus = (e && atoi(e) == 0) ? (1 << 30) : (n & ~7);
+  }
+  return tiles < cus ? tiles : cus;
+}
+
 template <int LN>
 int launch_ln(const GemmParams& p, hipStream_t st) {
   using G = Geo<256, 320>;
@@ -662,7 +687,7 @@ int launch_ln(const GemmParams& p, hipStream_t st) {
   GemmParams q = p;
   q.tiles_m = (p.M + 255) / 256;
   q.tiles_n = (p.nout + 319) / 320;
-  hipLaunchKernelGGL((gemm256p_kernel<false, 256, 320, false, 1, LN>), dim3(q.tiles_m * q.tiles_n), dim3(512), G::LDS_BYTES, st, q);
+  hipLaunchKernelGGL((gemm256p_kernel<false, 256, 320, false, 1, LN>), dim3(persistent_grid(q.tiles_m * q.tiles_n)), dim3(512), G::LDS_BYTES, st, q);
   FMX_LAUNCH_CHECK("fmx_gemm_conv_f16 (256x320, LayerNorm folded)");
   return FMX_OK;
 }
@@ -679,7 +704,7 @@ int launch_bn(const GemmParams& p, bool conv, hipStream_t st) {
   GemmParams q = p;
   q.tiles_m = (p.M + BM - 1) / BM;
   q.tiles_n = (p.nout + BN - 1) / BN;
-  const int grid = q.tiles_m * q.tiles_n;
+  const int grid = persistent_grid(q.tiles_m * q.tiles_n);
   if (conv) hipLaunchKernelGGL((gemm256p_kernel<true, BM, BN, STATS, SC>), dim3(grid), dim3(512), G::LDS_BYTES, st, q);
   else hipLaunchKernelGGL((gemm256p_kernel<false, BM, BN, STATS, SL>), dim3(grid), dim3(512), G::LDS_BYTES, st, q);
   FMX_LAUNCH_CHECK("fmx_gemm_conv_f16 (256-row pipelined)");

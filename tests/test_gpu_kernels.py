@@ -474,6 +474,31 @@ def test_attention_d64_short_context_pipelined(nk, spikes):
     close(got, _attn_d64(q, k, v, nk=nk, force32=True).float(), 3e-3, 3e-3, "pipelined vs 32-query kernel")
 
 
+@pytest.mark.parametrize("b,h,nq,nk", [(16, 20, 1024, 77), (16, 10, 4096, 77), (1, 1, 4096, 77), (2, 3, 1000, 96), (2, 2, 300, 97), (1, 2, 2000, 128),
+                                       (3, 5, 640, 32), (2, 2, 257, 65), (1, 7, 128 * 9 + 5, 31)])
+def test_attention_d64_short_context_persistent(b, h, nq, nk):
+    """Contexts of at most 128 keys on d_head 64 (every cross-attention against the 77-token text context) run attn_short_kernel (round 3): a
+    persistent workgroup walks several 128-query tiles of one (batch, head) with the K / V^T tiles staged once and the next tile's Q rows
+    requested ahead, a one-pass softmax over the 1-4 key blocks that hold keys.  Cases: the two bench shapes (3 and 6 tiles per workgroup, a
+    short last chunk), one (batch, head) split over the whole chip, key counts on and next to every 32-key block edge, ragged query counts
+    (a partial last tile, a partial last wave), padded keys holding garbage, a dominant key in the last valid position.  Against torch fp32
+    and the 32-query kernel."""
+    d = 64
+    nkp = -(-nk // 64) * 64
+    q = rnd(b, nq, h, d, seed=71)
+    k, v = torch.zeros(b, nkp, h, d, dtype=torch.float16, device=DEV), torch.zeros(b, nkp, h, d, dtype=torch.float16, device=DEV)
+    k[:, :nk], v[:, :nk] = rnd(b, nk, h, d, scale=1.2, seed=72), rnd(b, nk, h, d, seed=73)
+    k[:, nk:], v[:, nk:] = 6.0, -4.0
+    k[b - 1, nk - 1, h - 1] = q[b - 1, nq - 1, h - 1] * 5     # the last query's dominant key is the last valid one
+    k[0, 0, 0] = q[0, 0, 0] * 4
+    ref = _attn_ref(q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3)[:, :, :nk], v.permute(0, 2, 1, 3)[:, :, :nk], d ** -0.5)
+    got = _attn_d64(q, k, v, nk=nk)
+    assert bool(torch.isfinite(got).all())
+    close(got, ref, 3e-3, 3e-3, f"short-context attention b{b} h{h} nq{nq} nk{nk}")
+    if b * h * nq <= 400000:
+        close(got, _attn_d64(q, k, v, nk=nk, force32=True).float(), 3e-3, 3e-3, "short-context kernel vs 32-query kernel")
+
+
 @pytest.mark.parametrize("d", [64, 128])
 @pytest.mark.parametrize("nk", [1, 20, 33, 63])
 def test_attention_fewer_keys_than_one_tile(d, nk):

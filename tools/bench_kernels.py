@@ -75,6 +75,140 @@ def bench_linear_res(m, n, k, tile=0, copies=8, residual=True, inplace=True):
                       "lib": os.environ.get("FMX_LIB", "default")}), flush=True)
 
 
+def _graph_of(stream, fns):
+    from forge_amd.runtime import HipGraph
+    g = HipGraph()
+    with torch.cuda.stream(stream):
+        for f in fns[:2]:
+            f()
+        stream.synchronize()
+        g.capture(stream, lambda: [f() for f in fns])
+        g.launch(stream)
+        stream.synchronize()
+    return g
+
+
+def _wall(graphs_streams, reps):
+    import time
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for g, st in graphs_streams:
+            g.launch(st)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def bench_dual(name, make_chain, flops, reps=20):
+    """Round 3: ONE chain of kernels over the whole UNet batch on one stream, against TWO chains over half the batch each on two streams
+    (the uncond and cond halves of a CFG step are independent).  A half-batch launch fills half the CUs; the two chains drift out of phase, so
+    one chain's epilogue / launch ramp overlaps the other's K loop -- the overlap a 160-accumulator tile cannot get inside a CU.
+    make_chain(part, parts) -> list of callables for part `part` of `parts` (parts = 1: the whole batch)."""
+    s0, s1, s2 = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    full = _graph_of(s0, make_chain(0, 1))
+    h1, h2 = _graph_of(s1, make_chain(0, 2)), _graph_of(s2, make_chain(1, 2))
+    out = {"op": "one full-batch chain vs two half-batch chains on two streams", "case": name}
+    for rnd in range(2):
+        out[f"full_us_{rnd}"] = round(_wall([(full, s0)], reps) * 1e6, 1)
+        out[f"dual_us_{rnd}"] = round(_wall([(h1, s1), (h2, s2)], reps) * 1e6, 1)
+        out[f"half_alone_us_{rnd}"] = round(_wall([(h1, s1)], reps) * 1e6, 1)
+    # the same without graphs: eager launches, the two chains interleaved call by call from one host thread on two streams
+    import time
+    ffull, f1, f2 = make_chain(0, 1), make_chain(0, 2), make_chain(1, 2)
+
+    def eager_full():
+        with torch.cuda.stream(s0):
+            for f in ffull:
+                f()
+
+    def eager_dual():
+        for a, b in zip(f1, f2):
+            with torch.cuda.stream(s1):
+                a()
+            with torch.cuda.stream(s2):
+                b()
+    for nm, fn in (("eager_full_us", eager_full), ("eager_dual_us", eager_dual)):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        out[nm] = round((time.perf_counter() - t0) / reps * 1e6, 1)
+    out["full_tflops"] = round(flops / (out["full_us_1"] * 1e-6) / 1e12, 1)
+    out["dual_tflops"] = round(flops / (out["dual_us_1"] * 1e-6) / 1e12, 1)
+    print(json.dumps(out), flush=True)
+    for g in (full, h1, h2):
+        g.destroy()
+
+
+def dual_cases():
+    Bu = 16
+
+    def transformer_like(m_img, c, heads, nblk=4):
+        """per block: q+k projection (N = 2c), V^T projection, self-attention, to_out (+residual), to_q, (77-key attention skipped), to_out (+residual),
+        GEGLU ff1, ff2 (+residual) -- the GEMM / attention sequence of a BasicTransformerBlock at the SDXL sizes, cold weights per block"""
+        m = Bu * m_img
+        d = c // heads
+        x = rnd(m, c)
+        w_qk = [rnd(2 * c, c, scale=c ** -0.5) for _ in range(nblk)]
+        w_v = [rnd(c, c, scale=c ** -0.5) for _ in range(nblk)]
+        w_o = [rnd(c, c, scale=c ** -0.5) for _ in range(2 * nblk)]
+        w_q2 = [rnd(c, c, scale=c ** -0.5) for _ in range(nblk)]
+        w_f1 = [rnd(8 * c, c, scale=c ** -0.5) for _ in range(nblk)]
+        w_f2 = [rnd(c, 4 * c, scale=(4 * c) ** -0.5) for _ in range(nblk)]
+        bias = {n: rnd(n) for n in (c, 2 * c, 8 * c)}
+        stream_x = rnd(m, c)
+        qk = torch.empty(m, 2 * c, dtype=torch.float16, device=DEV)
+        vt = rnd(heads, c // heads, Bu, m_img)    # V^T as its projection GEMM leaves it: [head][channel][image][key]
+        ao = torch.empty(m, c, dtype=torch.float16, device=DEV)
+        q2 = torch.empty(m, c, dtype=torch.float16, device=DEV)
+        hid = torch.empty(m, 4 * c, dtype=torch.float16, device=DEV)
+        flops = nblk * (2 * m * c * (2 * c + c + c + c + c + 8 * c + 4 * c) + 4 * Bu * heads * m_img * m_img * d)
+
+        def chain(part, parts):
+            lo, hi = part * m // parts, (part + 1) * m // parts
+            blo, bhi = part * Bu // parts, (part + 1) * Bu // parts
+            fns = []
+            for i in range(nblk):
+                fns.append(lambda i=i: ops.conv_gemm(x[lo:hi], w_qk[i], 2 * c, bias=bias[2 * c], out=qk[lo:hi], ld_out=2 * c))
+                fns.append(lambda i=i: ops.conv_gemm(x[lo:hi], w_v[i], c, bias=bias[c], out=q2[lo:hi], ld_out=c))   # (V projection; the transposed form has the same cost)
+                fns.append(lambda: ops.attention(qk[lo:hi], qk[lo:hi, c:], vt[:, :, blo:bhi], batch=bhi - blo, heads=heads, nq=m_img, nk=m_img, nk_pad=m_img, dpad=d,
+                                                 scale=d ** -0.5, q_bs=m_img * 2 * c, q_rs=2 * c, k_bs=m_img * 2 * c, k_rs=2 * c, vt_bs=m_img, vt_hs=d * Bu * m_img,
+                                                 vt_ds=Bu * m_img, out=ao[lo:hi]))
+                fns.append(lambda i=i: ops.conv_gemm(ao[lo:hi], w_o[2 * i], c, bias=bias[c], residual=stream_x[lo:hi], out=stream_x[lo:hi], ld_out=c))
+                fns.append(lambda i=i: ops.conv_gemm(stream_x[lo:hi], w_q2[i], c, bias=bias[c], out=q2[lo:hi], ld_out=c))
+                fns.append(lambda i=i: ops.conv_gemm(q2[lo:hi], w_o[2 * i + 1], c, bias=bias[c], residual=stream_x[lo:hi], out=stream_x[lo:hi], ld_out=c))
+                fns.append(lambda i=i: ops.conv_gemm(stream_x[lo:hi], w_f1[i], 8 * c, bias=bias[8 * c], out=hid[lo:hi], ld_out=4 * c, act=1))
+                fns.append(lambda i=i: ops.conv_gemm(hid[lo:hi], w_f2[i], c, bias=bias[c], residual=stream_x[lo:hi], out=stream_x[lo:hi], ld_out=c))
+            return fns
+        return chain, flops
+
+    chain, fl = transformer_like(1024, 1280, 20)
+    bench_dual("4 transformer blocks at 32x32 (1280 wide, 20 heads), UNet batch 16", chain, fl)
+    chain, fl = transformer_like(4096, 640, 10, nblk=2)
+    bench_dual("2 transformer blocks at 64x64 (640 wide, 10 heads), UNet batch 16", chain, fl)
+
+    def conv_like(h, c, nconv=4):
+        x = torch.randn(Bu, h, h, c, device=DEV).half()
+        ws = [rnd(c, 9 * c, scale=(9 * c) ** -0.5) for _ in range(nconv)]
+        b = rnd(c)
+        ys = [torch.empty(Bu, h, h, c, dtype=torch.float16, device=DEV) for _ in range(2)]
+        flops = nconv * 2 * Bu * h * h * c * 9 * c
+
+        def chain(part, parts):
+            blo, bhi = part * Bu // parts, (part + 1) * Bu // parts
+            fns = []
+            for i in range(nconv):
+                src = x if i == 0 else ys[(i - 1) & 1]
+                fns.append(lambda i=i, src=src: ops.conv_gemm(src[blo:bhi], ws[i], c, kh=3, pad=1, bias=b, out=ys[i & 1][blo:bhi].view(-1, c), ld_out=c))
+            return fns
+        return chain, flops
+    for h, c in ((32, 1280), (64, 640), (128, 320)):
+        chain, fl = conv_like(h, c)
+        bench_dual(f"4 convolutions 3x3 {c}->{c} at {h}x{h}, UNet batch 16", chain, fl)
+
+
 def rnd(*shape, scale=1.0):
     return (torch.randn(*shape, device=DEV) * scale).half()
 
@@ -104,7 +238,8 @@ def bench_attn(b, h, nq, nk, d, dpad, force32=False):
     t = timeit(lambda: ops.attention(q, k, vt, batch=b, heads=h, nq=nq, nk=nk, nk_pad=nkp, dpad=dpad, scale=d ** -0.5, q_bs=nq * h * dpad,
                                      q_rs=h * dpad, k_bs=nkp * h * dpad, k_rs=h * dpad, vt_bs=nkp, vt_hs=dpad * b * nkp, vt_ds=b * nkp, out=out, force32=force32))
     print(json.dumps({"op": "attention", "b": b, "h": h, "nq": nq, "nk": nk, "d": d, "force32": force32, "us": round(t * 1e6, 1),
-                      "tflops": round(4 * b * h * nq * nk * d / t / 1e12, 1)}), flush=True)
+                      "tflops": round(4 * b * h * nq * nk * d / t / 1e12, 1), "q_plus_o_GBps": round(4 * b * h * nq * dpad / t / 1e9, 1),
+                      "env": {k: v for k, v in os.environ.items() if k.startswith("FMX_ATTN")}}), flush=True)
 
 
 def bench_attn512(b, n):
@@ -268,6 +403,16 @@ if __name__ == "__main__":
             bench_attn(8, 20, 1024, 1024, 64, 64, f32)   # 640 tiles = 1.25 rounds
             bench_attn(2, 20, 1024, 1024, 64, 64, f32)   # batch 1 under CFG: 160 tiles
             bench_attn(2, 24, 4352, 4352, 128, 128, f32)  # Flux-dev at 1024^2: 4096 image + 256 text tokens, 24 heads of 128
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "dual":
+        dual_cases()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "attnshort":
+        # the 77-token cross-attention launches of the SDXL forward at UNet batch 16 (A/B through FMX_ATTN_SHORT / FMX_ATTN_SHORT_WGS)
+        for _ in range(2):
+            bench_attn(16, 20, 1024, 77, 64, 64)
+            bench_attn(16, 10, 4096, 77, 64, 64)
+        bench_attn(2, 20, 1024, 77, 64, 64)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "epi":
         # round 3: what the epilogue costs.  Full chip (256 tiles), half chip (128 tiles: is the row pass contention-bound?), two rounds, long K
