@@ -32,6 +32,7 @@ struct AttnParams {
   float scale_log2e;
   int causal;
   const f16* zp;
+  unsigned q_span;            // attn_short2_kernel: bytes addressable from a (batch, head)'s Q base
   unsigned k_span, vt_span;   // bytes addressable from a (batch, head)'s K / V^T base (q64v2: buffer descriptors), 0 = do not use
   const f16* mask;            // optional additive mask, element (b, h, i, j) at mask[b*mask_bs + h*mask_hs + i*mask_qs + j] (strides may be 0)
   long mask_bs, mask_hs, mask_qs;
@@ -1604,6 +1605,237 @@ int launch_attn_short(AttnParams p, hipStream_t st) {
   }
 }
 
+
+// ---- the same, with Q and O moved in FULL CACHE LINES through LDS (round 3, second form) -------------------------------------------------
+// In attn_short_kernel a lane owns a query, so every 16-byte Q load / O store instruction of a wave touches 32 rows x 32 bytes: each 128-byte
+// line of a (query, head) is requested in four pieces by four instructions.  Here a wave's 32 x 64 Q tile arrives by LDS-DMA (4 pieces of 8
+// rows x 128 B: whole lines, bounds-checked by the descriptor, one tile AHEAD of the arithmetic) into one of two 4-KiB slots, the fragments
+// are read from there (chunk-swizzled like the K tile), and O goes back through the slot the tile's Q has just left: lanes write their
+// 16-byte pieces, then 8 lanes per row store whole lines.  A workgroup walks a contiguous range of the launch's (batch, head, tile) list and
+// restages K / V^T when the (batch, head) changes, so any grid size balances: 2 workgroups per CU (64 KB of LDS each), all resident.
+template <int NB>
+__global__ __launch_bounds__(256, 2) void attn_short2_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int DP = 64, DSTEPS = 4, CPR = 8;
+  constexpr int KBYTES = KVB * DP * 2;
+  constexpr int STAGE = KBYTES + 2 * 32 * 128;
+  constexpr int NT = (NB + 1) / 2;
+  constexpr int KV_BYTES = 2 * STAGE;            // (two tiles reserved whatever NB is: the slots' base does not depend on it)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, li = lane & 31;
+  char* const slots = smem + KV_BYTES + wave * 8192;   // this wave's two Q / O slots
+  // tiles [g0, g1) of the flattened (batch * heads, 128-query tile) list
+  const int total = p.batch * p.heads * p.qtiles;
+  const int per = (total + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int g0 = wg * per, g1 = min(total, g0 + per);
+  if (g0 >= g1) return;
+
+  const float c2 = p.scale_log2e;
+  const int krow = key_perm(li);
+  const int r8 = lane >> 3, pc = lane & 7;       // DMA / line pass: row within an 8-row piece, physical 16-byte chunk
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+  int bh_cur = -1;
+  __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(p.q), 0, 0, 0x00020000);
+  auto q_desc = [&](int bh) {
+    const int h = bh % p.heads, b = bh / p.heads;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(p.q + (long)b * p.q_bs + (long)h * DP), 0, p.q_span, 0x00020000);
+  };
+  // Q tile `tile` of the current (batch, head) -> slot: 4 pieces, rows >= nq read as zeros (descriptor bounds)
+  auto dma_q = [&](const __amdgpu_buffer_rsrc_t& rs, int tile, int slot) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = e * 8 + r8;
+      const unsigned off = (unsigned)(tile * 128 + wave * 32 + row) * (unsigned)p.q_rs * 2u + (unsigned)k_logical_chunk<CPR>(row, pc) * 16u;
+      auto* dst = (__attribute__((address_space(3))) void*)(slots + slot * 4096 + e * 1024);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, off, 0, 0, 0);
+    }
+  };
+
+  int slot = 0;
+  for (int g = g0; g < g1; ++g) {
+    const int bh = g / p.qtiles, tile = g - bh * p.qtiles;
+    const int h = bh % p.heads, b = bh / p.heads;
+    if (bh != bh_cur) {
+      // new (batch, head): every wave is done with the old K / V^T; stage the new ones and this tile's Q (nothing was prefetched across
+      // the change: the descriptor differs)
+      if (bh_cur >= 0) {
+        wait_vmcnt0();
+        __syncthreads();
+      }
+      bh_cur = bh;
+      rs_q = q_desc(bh);
+      const f16* kbase = p.k + (long)b * p.k_bs + (long)h * DP;
+      const f16* vbase = p.vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
+      const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(kbase), 0, p.k_span, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(vbase), 0, p.vt_span, 0x00020000);
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int kr = (e * 4 + wave) * 8 + lane / CPR;
+          const unsigned kv = (unsigned)kr * (unsigned)p.k_rs * 2u + (unsigned)k_logical_chunk<CPR>(kr, lane % CPR) * 16u;
+          auto* dk = (__attribute__((address_space(3))) void*)(smem + kt * STAGE + (e * 4 + wave) * 1024);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, dk, 16, kv, (unsigned)kt * ((unsigned)KVB * (unsigned)p.k_rs * 2u), 0, 0);
+          const int vr = (e * 4 + wave) * 8 + (lane >> 3);
+          const unsigned vv = (unsigned)vr * (unsigned)p.vt_ds * 2u + (unsigned)((lane & 7) ^ ((vr >> 1) & 7)) * 16u;
+          auto* dv = (__attribute__((address_space(3))) void*)(smem + kt * STAGE + KBYTES + (e * 4 + wave) * 1024);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, dv, 16, vv, (unsigned)kt * (KVB * 2u), 0, 0);
+        }
+      dma_q(rs_q, tile, slot);
+      wait_vmcnt0();
+      __syncthreads();
+    } else {
+      // this tile's Q was requested a tile ago; behind it in the (in-order) counter are only the 4 line stores of the previous tile's O
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
+    // ---- Q fragments out of the slot (pre-scaled), then the NEXT tile's Q into the other slot ----
+    f16x8 qf[DSTEPS];
+    {
+      const char* qs = slots + slot * 4096 + li * 128;
+#pragma unroll
+      for (int ds = 0; ds < DSTEPS; ++ds) {
+        const f16x8 raw = *reinterpret_cast<const f16x8*>(qs + (k_phys_chunk<CPR>(li, ds * 2 + hi) << 4));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[ds][e] = (f16)((float)raw[e] * c2);
+      }
+    }
+    const bool more = g + 1 < g1 && (g + 1) / p.qtiles == bh;   // uniform
+    // pinned in program order: the vmcnt(4) above counts on exactly this tile's four O stores being the only memory operations behind it
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) dma_q(rs_q, tile + 1, slot ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+
+    f32x16 sacc[NB];
+#pragma unroll
+    for (int gk = 0; gk < NB; ++gk) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[gk][r] = 0.f;
+      const char* sk = smem + (gk >> 1) * STAGE;
+      const int row = (gk & 1) * 32 + krow;
+#pragma unroll
+      for (int ds = 0; ds < DSTEPS; ++ds) {
+        const f16x8 kf = *reinterpret_cast<const f16x8*>(sk + row * (DP * 2) + (k_phys_chunk<CPR>(row, ds * 2 + hi) << 4));
+        sacc[gk] = FMX_MFMA_32x32x16(kf, qf[ds], sacc[gk]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (NB * 32 > p.nk) {
+#pragma unroll
+      for (int gk = 0; gk < NB; ++gk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (gk * 32 + hi * 16 + r >= p.nk) sacc[gk][r] = -INFINITY;
+    }
+    float m0 = sacc[0][0];
+#pragma unroll
+    for (int gk = 0; gk < NB; ++gk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m0 = fmaxf(m0, sacc[gk][r]);
+    const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m0), __float_as_uint(m0), false, false);
+    const float mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    float l = 0.f;
+    f16x8 pf[NB][2];
+#pragma unroll
+    for (int gk = 0; gk < NB; ++gk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(sacc[gk][r] - mx);
+        l += e;
+        pf[gk][r >> 3][r & 7] = (f16)e;
+      }
+    f32x16 oacc[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+      const int row = dt * 32 + li;
+      const int swz = (row >> 1) & 7;
+#pragma unroll
+      for (int gk = 0; gk < NB; ++gk) {
+        const char* rp = smem + (gk >> 1) * STAGE + KBYTES + row * 128;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const f16x8 vf = *reinterpret_cast<const f16x8*>(rp + ((((gk & 1) * 4 + hi * 2 + j) ^ swz) << 4));
+          oacc[dt] = FMX_MFMA_32x32x16(vf, pf[gk][j], oacc[dt]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- O: 16-byte pieces into the slot this tile's Q has left (row = query, chunk-swizzled), then whole lines out ----
+    const u32x2 lw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l), __float_as_uint(l), false, false);
+    const float inv = 1.0f / (__uint_as_float(lw[0]) + __uint_as_float(lw[1]));
+    char* os = slots + slot * 4096;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int gq = 0; gq < 4; gq += 2) {
+        union { f16x4 h4; unsigned u[2]; } lo, up;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          lo.h4[e] = (f16)(oacc[dt][gq * 4 + e] * inv);
+          up.h4[e] = (f16)(oacc[dt][(gq + 1) * 4 + e] * inv);
+        }
+        const u32x2 x = __builtin_amdgcn_permlane32_swap(lo.u[0], up.u[0], false, false);
+        const u32x2 y = __builtin_amdgcn_permlane32_swap(lo.u[1], up.u[1], false, false);
+        const u32x4 v = {x[0], y[0], x[1], y[1]};
+        const int chunk = dt * 4 + gq + hi;   // columns chunk * 8 .. + 7 of query li
+        *reinterpret_cast<u32x4*>(os + li * 128 + (k_phys_chunk<CPR>(li, chunk) << 4)) = v;
+      }
+    // (LDS operations of one wave execute in order: the reads below see the writes above)
+    f16* obase = p.o + (long)b * p.o_bs + (long)h * DP;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = e * 8 + r8;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(os + row * 128 + (pc << 4));
+      const int qg = tile * 128 + wave * 32 + row;
+      if (qg < p.nq) *reinterpret_cast<u32x4*>(obase + (long)qg * p.o_rs + k_logical_chunk<CPR>(row, pc) * 8) = v;
+    }
+    slot ^= 1;
+  }
+}
+
+template <int NB>
+int launch_attn_short2_nb(AttnParams& p, int grid, hipStream_t st) {
+  constexpr int SMEM = 2 * (KVB * 64 * 2 + 2 * 32 * 128) + 4 * 8192;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_short2_kernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    attr = true;
+  }
+  hipLaunchKernelGGL(attn_short2_kernel<NB>, dim3(grid), dim3(256), SMEM, st, p);
+  FMX_LAUNCH_CHECK("fmx_attention_f16 (short context, line-staged)");
+  return FMX_OK;
+}
+
+int launch_attn_short2(AttnParams p, hipStream_t st) {
+  static int slots = 0;
+  if (!slots) {
+    int dev = 0, cus = 256;
+    if (!(hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)) cus = 256;
+    slots = 2 * cus;
+  }
+  p.qtiles = (p.nq + 127) / 128;
+  const long total = (long)p.batch * p.heads * p.qtiles;
+  const double q_span = ((double)(p.nq - 1) * p.q_rs + 64) * 2.0;
+  if (q_span >= 2.0e9 || total >= (1L << 30)) return -1;
+  p.q_span = (unsigned)q_span;
+  const int grid = (int)(total < slots ? total : slots);
+  const int nb = (p.nk + 31) / 32;
+  switch (nb) {
+    case 1: return launch_attn_short2_nb<1>(p, grid, st);
+    case 2: return launch_attn_short2_nb<2>(p, grid, st);
+    case 3: return launch_attn_short2_nb<3>(p, grid, st);
+    default: return launch_attn_short2_nb<4>(p, grid, st);
+  }
+}
+
 template <int DP>
 int launch_attn_v2(AttnParams p, hipStream_t st) {
   constexpr int DVT = DP / 32;
@@ -1663,8 +1895,15 @@ int launch_attn_v2(AttnParams p, hipStream_t st) {
     if (DP == 64 && p.nk <= 128) {
       static int sk = -1;
       if (sk < 0) {
-        const char* e7 = getenv("FMX_ATTN_SHORT");   // A/B knob: 0 = the looped 64-query kernels for short contexts as well (round 2)
-        sk = e7 ? atoi(e7) : 1;
+        // A/B knob: 0 = the looped 64-query kernels for short contexts as well (round 2), 1 = attn_short_kernel (lane-owned Q loads / O stores),
+        // 2 (default) = attn_short2_kernel (Q and O in whole lines through LDS).  In a graph, every launch on its own Q / O tensors
+        // (profiles/r08e): batch 16 x 20 heads x 1024 queries 32.4 / 31.3 / 27.5 us, 16 x 10 x 4096 queries 53.7 / 60.1 / 46.0 us.
+        const char* e7 = getenv("FMX_ATTN_SHORT");
+        sk = e7 ? atoi(e7) : 2;
+      }
+      if (sk == 2) {
+        const int rc = launch_attn_short2(p, st);
+        if (rc >= 0) return rc;
       }
       if (sk) return launch_attn_short(p, st);
     }
@@ -1756,7 +1995,7 @@ extern "C" int fmx_attention_f16(const fmx_attn_args* a, void* stream) {
   p.scale_log2e = fabsf(a->scale) * 1.44269504088896340736f;
   p.zp = (const f16*)a->zero_page;
   p.causal = a->causal ? 1 : 0;
-  p.k_span = p.vt_span = 0;
+  p.k_span = p.vt_span = p.q_span = 0;
   p.nfull = p.nsplit = p.bid0 = 0;
   p.sk_tpw = p.sk_chunks = 0;
   p.mask = (const f16*)a->mask; p.mask_bs = a->mask_bs; p.mask_hs = a->mask_hs; p.mask_qs = a->mask_qs;

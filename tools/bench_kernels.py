@@ -242,6 +242,21 @@ def bench_attn(b, h, nq, nk, d, dpad, force32=False):
                       "env": {k: v for k, v in os.environ.items() if k.startswith("FMX_ATTN")}}), flush=True)
 
 
+def bench_attn_graph(b, h, nq, nk, d, copies=4):
+    """attention launches as the forward runs them: back to back inside ONE graph (no host launch gap), each on its own Q / O tensors"""
+    nkp = -(-nk // 64) * 64
+    k = rnd(b, nkp, h, d)
+    vt = rnd(h, d, b, nkp)
+    qs = [rnd(b, nq, h, d) for _ in range(copies)]
+    outs = [torch.empty(b * nq, h * d, dtype=torch.float16, device=DEV) for _ in range(copies)]
+    t = timeit_graph([(lambda q=q, o=o: ops.attention(q, k, vt, batch=b, heads=h, nq=nq, nk=nk, nk_pad=nkp, dpad=d, scale=d ** -0.5, q_bs=nq * h * d,
+                                                       q_rs=h * d, k_bs=nkp * h * d, k_rs=h * d, vt_bs=nkp, vt_hs=d * b * nkp, vt_ds=b * nkp, out=o))
+                      for q, o in zip(qs, outs)], reps=10)
+    print(json.dumps({"op": "attention (in graph)", "b": b, "h": h, "nq": nq, "nk": nk, "d": d, "us": round(t * 1e6, 1),
+                      "tflops": round(4 * b * h * nq * nk * d / t / 1e12, 1), "q_plus_o_GBps": round(4 * b * h * nq * d / t / 1e9, 1),
+                      "env": {k: v for k, v in os.environ.items() if k.startswith("FMX_ATTN")}}), flush=True)
+
+
 def bench_attn512(b, n):
     """the VAE mid-block attention: one 512-wide head over n tokens, fused kernel vs the materialised-score path of round 1"""
     c = 512
@@ -410,9 +425,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "attnshort":
         # the 77-token cross-attention launches of the SDXL forward at UNet batch 16 (A/B through FMX_ATTN_SHORT / FMX_ATTN_SHORT_WGS)
         for _ in range(2):
-            bench_attn(16, 20, 1024, 77, 64, 64)
-            bench_attn(16, 10, 4096, 77, 64, 64)
-        bench_attn(2, 20, 1024, 77, 64, 64)
+            bench_attn_graph(16, 20, 1024, 77, 64)
+            bench_attn_graph(16, 10, 4096, 77, 64)
+        bench_attn_graph(2, 20, 1024, 77, 64)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "epi":
         # round 3: what the epilogue costs.  Full chip (256 tiles), half chip (128 tiles: is the row pass contention-bound?), two rounds, long K

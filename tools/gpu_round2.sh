@@ -15,8 +15,9 @@ pmc_pass() {  # $1 = pass name, $2.. = counters ; workload: tools/pmc_kernels.py
 for w in "$@"; do
   case $w in
     tests) FMX_PARITY_LOG=$O/parity.jsonl timeout 1500 python -m pytest tests -m gpu -q -s --tb=line 2>&1 | grep -v "^\[parity\]" | tail -120 > $O/pytest_gpu.log; tail -8 $O/pytest_gpu.log;;
-    attnshort) for E in "FMX_ATTN_SHORT=0" "FMX_ATTN_SHORT_WGS=4" "FMX_ATTN_SHORT_WGS=3" "FMX_ATTN_SHORT_WGS=2"; do env $E timeout 300 python tools/bench_kernels.py attnshort >> $O/attnshort.jsonl 2>> $O/attnshort.err; done; cat $O/attnshort.jsonl; tail -3 $O/attnshort.err;;
+    attnshort) for E in "FMX_ATTN_SHORT=0" "FMX_ATTN_SHORT=1" "FMX_ATTN_SHORT=2"; do env $E timeout 300 python tools/bench_kernels.py attnshort >> $O/attnshort.jsonl 2>> $O/attnshort.err; done; cat $O/attnshort.jsonl; tail -3 $O/attnshort.err;;
     atests) timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q --tb=short -k "attention" 2>&1 | tail -40 > $O/atests.log; tail -15 $O/atests.log;;
+    atests2) FMX_ATTN_SHORT=2 timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q --tb=short -k "attention" 2>&1 | tail -40 > $O/atests2.log; tail -15 $O/atests2.log;;
     ab_persist) for E in "FMX_GEMM_PERSIST=0" "FMX_GEMM_PERSIST=1" "FMX_GEMM_PERSIST=0" "FMX_GEMM_PERSIST=1"; do env $E timeout 600 python bench.py --no-cpu-baseline --no-vae --steps 10 2>> $O/ab.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'env':'$E','ms_per_step':d['ms_per_step'],'gemm_tflops':d['roofline']['achieved'],'gemm_ms':d['roofline']['kernel_time_per_forward_ms'],'attn':d['roofline_attention']['achieved'],'xattn_ms':d['roofline_attention_short_keys']['kernel_time_per_forward_ms'],'clocks':d.get('clocks_during_timed_steps')}))" >> $O/ab.jsonl; done; cat $O/ab.jsonl; tail -3 $O/ab.err;;
     dual) timeout 600 python tools/bench_kernels.py dual > $O/dual.jsonl 2> $O/dual.err; cat $O/dual.jsonl; tail -3 $O/dual.err;;
     epi) for L in "" tools/_build/libfmx_pf2.so tools/_build/libfmx_pf6.so; do FMX_LIB=$L timeout 300 python tools/bench_kernels.py epi >> $O/epi.jsonl 2>> $O/epi.err; done; cat $O/epi.jsonl;;
