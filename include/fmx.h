@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define FMX_ABI_VERSION 6
+#define FMX_ABI_VERSION 7
 
 #define FMX_OK 0
 #define FMX_E_BADARG 10001   /* shape / alignment / null-pointer contract violated */
@@ -122,6 +122,14 @@ typedef struct fmx_gemm_args {
   int32_t ln_parts;
   const void* ln_colsum;
   float ln_eps;
+  /* The same fold for the OPERAND-SWAPPED GEMM (ABI 7; norm1 -> attn1.to_v, unet.py:262-266, whose projection runs as V^T = Wv x^T so that
+   * attention reads V^T without a transpose): here the LayerNorm rows are the COLUMNS of the output.  a0 = W * gamma [M = channels][K], wgt =
+   * the UN-normalised x [nout = tokens][K];  out[m][n] = acc * rstd[n] - mean[n] rstd[n] colsum[m] + (W beta)[m]:
+   *   ln_col_ab [nout][2] fp32 = {rstd, -mean * rstd} per token (fmx_layernorm_rowstats_finalize from the producer's row statistics),
+   *   ln_row_cb [M][2]    fp32 = {sum_k a0[m][k] (of the fp16 values), (W beta)[m]} per channel.
+   * Linear only, act NONE, no bias / residual / rowvec / gate, fp16 output, M % 320 == 0; always the 320x256 tile. */
+  const void* ln_col_ab;
+  const void* ln_row_cb;
 } fmx_gemm_args;
 
 int fmx_gemm_conv_f16(const fmx_gemm_args* args /* host */, void* stream);
@@ -129,9 +137,14 @@ int fmx_gemm_conv_f16(const fmx_gemm_args* args /* host */, void* stream);
 /* The same GEMM (linear with bias + residual: the projections that close attention / feed-forward, unet.py:268,272,277), additionally
  * leaving per-row partial sums of its fp16 OUTPUT for a LayerNorm that follows: row_partial[m][parts][{sum, sum of squares}] fp32, where
  * parts = 2 * ceil(nout / 320) <= parts_cap is returned in *parts_out.  *parts_out = 0 means the dispatcher chose another tile shape for
- * this problem (small M): the GEMM ran as usual, nothing was written, and the caller applies its LayerNorm with fmx_layernorm_f16. */
+ * this problem (small M): the GEMM ran as usual, nothing was written, and the caller applies its LayerNorm with fmx_layernorm_f16.
+ * The residual is optional since ABI 7 (proj_in of a SpatialTransformer, unet.py:311-316, feeds norm1 of its first block). */
 int fmx_gemm_linear_rowstats_f16(const fmx_gemm_args* args /* host */, float* row_partial, int32_t parts_cap, int32_t* parts_out /* host */,
                                  void* stream);
+
+/* Row statistics -> per-row LayerNorm terms:  ab[m] = {rstd, -mean * rstd}  with mean / rstd over the `c` elements of row m, from the
+ * `parts` partial {sum, sum of squares} pairs fmx_gemm_linear_rowstats_f16 left (fixed summation order).  Feeds ln_col_ab above. */
+int fmx_layernorm_rowstats_finalize(const float* row_partial, int32_t parts, int64_t rows, int32_t c, float eps, float* ab, void* stream);
 
 /* Reorders the rows of a GEGLU projection weight [2*inner][k] (and bias [2*inner]) on the DEVICE into
  * the [16 value rows | 16 gate rows] interleave FMX_ACT_GEGLU expects.  inner % 16 == 0. */

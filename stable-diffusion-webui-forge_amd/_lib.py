@@ -37,6 +37,7 @@ class GemmArgs(C.Structure):
         ("zero_page", C.c_void_p), ("gate", C.c_void_p), ("ld_gate", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("ln_partial", C.c_void_p), ("ln_parts", C.c_int32), ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float),
+        ("ln_col_ab", C.c_void_p), ("ln_row_cb", C.c_void_p),
     ]
 
 
@@ -60,6 +61,7 @@ SIGNATURES = {
     "fmx_device_info": [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int],
     "fmx_gemm_conv_f16": [C.POINTER(GemmArgs), _vp],
     "fmx_gemm_linear_rowstats_f16": [C.POINTER(GemmArgs), _vp, _i32, C.POINTER(C.c_int32), _vp],
+    "fmx_layernorm_rowstats_finalize": [_vp, _i32, _i64, _i32, _f32, _vp, _vp],
     "fmx_geglu_interleave_rows": [_vp, _vp, _vp, _vp, _i32, _i32, _vp],
     "fmx_attention_f16": [C.POINTER(AttnArgs), _vp],
     "fmx_softmax_rows_f16": [_vp, _i64, _i32, _i64, _vp],
@@ -154,7 +156,7 @@ def lib():
             fn.restype = C.c_int
         handle.fmx_last_error.argtypes = []
         handle.fmx_last_error.restype = C.c_char_p
-        if handle.fmx_abi_version() != 6:
+        if handle.fmx_abi_version() != 7:
             raise FmxError("libfmx ABI version mismatch")
         _lib = handle
     return _lib

@@ -81,6 +81,7 @@ class GroupNorm(_Layer):
 
 
 _LN_FOLD = os.environ.get("FMX_LN_FOLD", "1") != "0"   # A/B knob: 0 keeps the LayerNorm kernels in front of attn2.to_q / ff.net.0
+_LN_FOLD1 = os.environ.get("FMX_LN_FOLD1", "1") != "0"  # A/B knob: 0 keeps norm1 as a kernel (round 2) while norm2 / norm3 stay folded
 
 
 def _fold_layernorm(wt, bias, gamma, beta):
@@ -255,6 +256,14 @@ class IntegratedUNet2DConditionModel:
                         # the producing GEMM runs on another tile shape and emits no row statistics) and hooked runs use the LayerNorm kernel.
                         w[b + ".attn2.q.ln"] = _fold_layernorm(w[b + ".attn2.q"], None, *w[b + ".norm2"])
                         w[b + ".ff1.ln"] = _fold_layernorm(*w[b + ".ff1"], *w[b + ".norm3"])
+                        if (H * dp) % 320 == 0:
+                            # norm1 (round 3): into the q|k projection the same way, and into the operand-swapped V^T projection, where the
+                            # LayerNorm rows are the output's columns (fmx.h ln_col_ab / ln_row_cb): the weight is the row operand there
+                            g1, b1 = w[b + ".norm1"]
+                            w[b + ".attn1.qk.ln"] = _fold_layernorm(w[b + ".attn1.qk"], None, g1, b1)
+                            wv = w[b + ".attn1.v"]
+                            wvf = (wv.float() * g1.float()[None, :]).to(torch.float16).contiguous()
+                            w[b + ".attn1.v.ln"] = (wvf, torch.stack([wvf.float().sum(1), wv.float() @ b1.float()], 1).contiguous())
             elif isinstance(L, Down):
                 w[k] = (_conv_w(sd[k + ".op.weight"].to(dev, torch.float16)), T(k + ".op.bias"))
             elif isinstance(L, Up):
@@ -343,7 +352,10 @@ class IntegratedUNet2DConditionModel:
         arena.release(m)
         return ops.attach_stats(out, st)
 
-    def _attn_block(self, b, L, h, bu, n, ctxc, arena):
+    def _attn_block(self, b, L, h, bu, n, ctxc, arena, rs1=None, want_next=False):
+        """One BasicTransformerBlock on h [M, C] (updated in place).  rs1: the row statistics the projection that WROTE h left (proj_in or the
+        previous block's ff.net.2) -- norm1 then runs folded into the q|k and V^T projections; want_next: leave the statistics of this block's
+        output for the next block's norm1.  -> that RowStats (or None)."""
         H, d = L.heads, L.dim_head
         dp = _dpad(d)
         hd = H * dp
@@ -352,9 +364,17 @@ class IntegratedUNet2DConditionModel:
         fold = (b + ".ff1.ln") in self.w
         rs2 = ops.RowStats(m_tok, h.shape[1]) if fold else None
         rs3 = ops.RowStats(m_tok, h.shape[1]) if fold else None
+        rs_next = ops.RowStats(m_tok, h.shape[1]) if (want_next and fold) else None
         mk = arena.mark()
         # self attention
-        if n % 64 == 0:
+        if n % 64 == 0 and rs1 is not None and rs1.parts and (b + ".attn1.v.ln") in self.w:
+            wqk, csqk, bqk = self.w[b + ".attn1.qk.ln"]
+            qk = ops.conv_gemm(h, wqk, wqk.shape[0], bias=bqk, ln=(rs1, csqk, 1e-5))          # [M, 2*H*dp] = [Q | K] of LN(h)
+            wvf, vcb = self.w[b + ".attn1.v.ln"]
+            vt = ops.conv_gemm(wvf, h, m_tok, ln_swapped=(ops.ln_rowstats_finalize(rs1, h.shape[1], 1e-5), vcb))   # [H*dp, M] = V^T of LN(h)
+            o = ops.attention(qk, qk[:, hd:], vt, batch=bu, heads=H, nq=n, nk=n, nk_pad=n, dpad=dp, scale=d ** -0.5,
+                              q_bs=n * 2 * hd, q_rs=2 * hd, k_bs=n * 2 * hd, k_rs=2 * hd, vt_bs=n, vt_hs=dp * m_tok, vt_ds=m_tok)
+        elif n % 64 == 0:
             n1 = ops.layernorm(h, *self.w[b + ".norm1"])
             qk = ops.linear(n1, self.w[b + ".attn1.qk"])                   # [M, 2*H*dp] = [Q | K]
             vt = ops.conv_gemm(self.w[b + ".attn1.v"], n1, m_tok)          # [H*dp, M] = V^T (operand swap)
@@ -403,8 +423,9 @@ class IntegratedUNet2DConditionModel:
             n3 = ops.layernorm(h, *self.w[b + ".norm3"])
             fw, fb = self.w[b + ".ff1"]
             g = ops.conv_gemm(n3, fw, fw.shape[0], bias=fb, act=ops.ACT_GEGLU)
-        ops.linear(g, *self.w[b + ".ff2"], residual=h, out=h, ld_out=h.shape[1])
+        ops.linear(g, *self.w[b + ".ff2"], residual=h, out=h, ld_out=h.shape[1], row_stats=rs_next)
         arena.release(mk)
+        return rs_next
 
     # ---- per-block Python hooks (unet.py:186-279 `patches` / `patches_replace`): eager, general-shape path ----------------------------
     def _attend(self, wq, wk, wv, H, d, xq, xk, xv):
@@ -512,14 +533,17 @@ class IntegratedUNet2DConditionModel:
         out_part = ops.stats_buffer(bu, n, c)
         mk = arena.mark()
         g = ops.groupnorm(x, *self.w[k + ".norm"], 1e-6)
-        h = ops.linear(g.view(-1, c), *self.w[k + ".proj_in"])  # 1x1 conv == Linear in NHWC
         hooked = to is not None and (to.get("patches") or to.get("patches_replace"))
+        # norm1 of every block folded into its q|k / V^T projections: the GEMM that writes h (proj_in, then each block's ff.net.2) leaves the row sums
+        fold1 = _LN_FOLD and _LN_FOLD1 and not hooked and n % 64 == 0 and (f"{k}.transformer_blocks.0.attn1.v.ln") in self.w
+        rs1 = ops.RowStats(bu * n, inner) if fold1 else None
+        h = ops.linear(g.view(-1, c), *self.w[k + ".proj_in"], row_stats=rs1)  # 1x1 conv == Linear in NHWC
         for di in range(L.depth):
             if hooked:
                 to["block_index"] = di
                 self._attn_block_hooked(f"{k}.transformer_blocks.{di}", L, h, bu, n, ctxc, arena, to)
             else:
-                self._attn_block(f"{k}.transformer_blocks.{di}", L, h, bu, n, ctxc, arena)
+                rs1 = self._attn_block(f"{k}.transformer_blocks.{di}", L, h, bu, n, ctxc, arena, rs1=rs1, want_next=fold1 and di + 1 < L.depth)
         _, st = ops.linear(h, *self.w[k + ".proj_out"], residual=x.view(-1, c), out=out.view(-1, c), ld_out=c, n=bu, h=hh, w=ww, stats=True,
                            stats_partial=out_part)
         arena.release(mk)

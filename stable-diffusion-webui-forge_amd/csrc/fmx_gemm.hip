@@ -485,6 +485,7 @@ static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, i
   p.ln_parts = 0;
   p.ln_colsum = nullptr;
   p.ln_eps = p.ln_inv_c = 0.f;
+  p.ln_col_ab = p.ln_row_cb = nullptr;
   FMX_REQUIRE(fmx_aligned16(p.a0) && fmx_aligned16(p.wgt) && fmx_aligned16(p.zp) && (!p.a1 || fmx_aligned16(p.a1)), "gemm: operands must be 16-byte aligned");
   FMX_REQUIRE((p.s0 % 8) == 0 && (p.s1 % 8) == 0 && (p.ldw % 8) == 0, "gemm: strides must be multiples of 8 elements");
   FMX_REQUIRE((long)p.M * 1 > 0 && (long)a->n * a->oh * a->ow < (1L << 31), "gemm: M overflow");
@@ -588,7 +589,7 @@ static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, i
   const bool ln_shape_ok = !conv && big_ok && p.c1 == 0 && !p.gate && !p.rowvec;
   if (row_parts_out) {
     const int parts = 2 * ((p.nout + 319) / 320);
-    if (sel == 6 && ln_shape_ok && a->act == FMX_ACT_NONE && p.residual && parts <= row_parts_cap && !stats) {
+    if (sel == 6 && ln_shape_ok && a->act == FMX_ACT_NONE && parts <= row_parts_cap && !stats) {   // (residual optional: absent reads the zero page)
       p.row_stats = row_stats;
       *row_parts_out = parts;
     } else {
@@ -605,6 +606,15 @@ static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, i
     p.ln_eps = a->ln_eps;
     p.ln_inv_c = 1.0f / (float)p.c0;
     sel = 6;
+    best_s = 1;
+  }
+  if (a->ln_col_ab) {
+    FMX_REQUIRE(!a->ln_partial && !row_parts_out && ln_shape_ok && !p.residual && !p.bias && !stats && a->act == FMX_ACT_NONE && a->ln_row_cb &&
+                    (p.M % 320) == 0 && fmx_aligned16(a->ln_col_ab) && fmx_aligned16(a->ln_row_cb),
+                "gemm: the operand-swapped LayerNorm-folded GEMM is a plain linear (no bias / residual) with fp16 output, M a multiple of 320, on the 320x256 tile");
+    p.ln_col_ab = (const float*)a->ln_col_ab;
+    p.ln_row_cb = (const float*)a->ln_row_cb;
+    sel = 7;
     best_s = 1;
   }
   int rc;

@@ -79,12 +79,15 @@ struct Geo {
 //   LN = 2, the CONSUMER (the projection that follows the LayerNorm), run on the UN-normalised tensor with weights pre-multiplied by gamma:
 //        LN(x) W = rstd (x W' - mean colsum(W')) + (beta W + b)  -- `lnm` / `lnr` hold mean / rstd of row `lane` of this wave's rows
 //        (computed once per tile from the producer's partials), fetched per row with a lane shuffle; `cs` = colsum of this lane's 8 columns.
+//   LN = 3, the consumer in the OPERAND-SWAPPED GEMM (V^T = Wv x^T, 320 x 256 tile): the LayerNorm rows are this GEMM's output COLUMNS, so a lane's
+//        8 columns carry 8 (rstd, -mean rstd) pairs for the whole tile (`cs` = ln_col_ab at its first column) and each output row m one
+//        (colsum, folded bias) pair (`rowcb`):  v = acc rstd[n] + (-mean rstd)[n] colsum[m] + bias'[m].
 template <int RB, int LPR, int ROWS, int SWZ, bool TANH, int MODE, bool STATS = false, int LN = 0>
 __device__ __forceinline__ void epi_rows(const char* my, int lane, int mbase, int M, int /*col*/, bool nok, int per_img, float alpha, float has_gate,
                                          const f16* __restrict__ bias, const f16* __restrict__ rowvec, long ld_rv, const f16* __restrict__ gate, long ld_gt,
                                          const f16* __restrict__ res, long ld_res, f16* __restrict__ out, long ld_out, float* st = nullptr,
                                          float* __restrict__ rowst = nullptr, int rowst_ld = 0, float lnm = 0.f, float lnr = 0.f, int lnbase = 0,
-                                         const float* __restrict__ cs = nullptr) {
+                                         const float* __restrict__ cs = nullptr, const float* __restrict__ rowcb = nullptr) {
   constexpr int RPI = 64 / LPR;  // rows per wave instruction
   constexpr int ITERS = (ROWS + RPI - 1) / RPI;
   // opaque copy: keeps the compiler from hoisting the ITERS x 2 LDS offsets of EVERY call of this function above the whole
@@ -96,6 +99,15 @@ __device__ __forceinline__ void epi_rows(const char* my, int lane, int mbase, in
   if (LN == 2) {
     cs0 = *reinterpret_cast<const f32x4*>(cs);
     cs1 = *reinterpret_cast<const f32x4*>(cs + 4);
+  }
+  f32x4 ca0 = cs0, ca1 = cs0, cb0 = cs0, cb1 = cs0;   // LN 3: rstd / -mean rstd of this lane's 8 columns
+  if (LN == 3) {
+    const f32x4 t0 = *reinterpret_cast<const f32x4*>(cs), t1 = *reinterpret_cast<const f32x4*>(cs + 4);
+    const f32x4 t2 = *reinterpret_cast<const f32x4*>(cs + 8), t3 = *reinterpret_cast<const f32x4*>(cs + 12);
+    ca0 = f32x4{t0[0], t0[2], t1[0], t1[2]};
+    cb0 = f32x4{t0[1], t0[3], t1[1], t1[3]};
+    ca1 = f32x4{t2[0], t2[2], t3[0], t3[2]};
+    cb1 = f32x4{t2[1], t2[3], t3[1], t3[3]};
   }
   // vmcnt retires in order, loads and stores alike: an iteration that loads its operands AFTER the previous iteration's
   // store waits for that store to complete.  So the operands of iteration it+1 are requested before iteration it stores.
@@ -132,11 +144,14 @@ __device__ __forceinline__ void epi_rows(const char* my, int lane, int mbase, in
       mean_r = __shfl(lnm, lnbase + row);
       rstd_r = __shfl(lnr, lnbase + row);
     }
+    f32x2 rcb = f32x2{0.f, 0.f};
+    if (LN == 3) rcb = *reinterpret_cast<const f32x2*>(rowcb + (long)(m < M ? m : M - 1) * 2);
     f16x8 hv;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       float v = (r < 4 ? lo[r & 3] : hi4[r & 3]) * alpha;
       if (LN == 2) v = (v - mean_r * (r < 4 ? cs0[r & 3] : cs1[r & 3])) * rstd_r;
+      if (LN == 3) v = fmaf(v, r < 4 ? ca0[r & 3] : ca1[r & 3], fmaf(r < 4 ? cb0[r & 3] : cb1[r & 3], rcb[0], rcb[1]));
       v += (float)bb[r];
       if (MODE == 0 || MODE == 3) v += (float)rv[cur][r];
       if (TANH) v = gelu_tanh_f(v);
@@ -144,7 +159,18 @@ __device__ __forceinline__ void epi_rows(const char* my, int lane, int mbase, in
       if (MODE <= 1 || MODE == 3) v += (float)rs[cur][r];
       hv[r] = (f16)v;
     }
+#ifndef FMX_EPI_PLAIN_STORES
+    // streaming (nt) stores: the tile is not read again by this kernel and the launch ends with ~42 MB of dirty output to write back
+    // (tools/ubench/launch_floor.hip: 160 KB per CU from all 256 CUs, 7.99 us plain, 7.16 us nt; SDXL step 114.2 -> 113.8 ms, profiles/r08i)
+    if (ok) {
+      typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+      union { f16x8 h; u32x4_ u; } cv;
+      cv.h = hv;
+      __builtin_nontemporal_store(cv.u, reinterpret_cast<u32x4_*>(out + m * ld_out));
+    }
+#else   // A/B build (tools/build_variant.sh)
     if (ok) *reinterpret_cast<f16x8*>(out + m * ld_out) = hv;
+#endif
     if (LN == 1) {
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -524,6 +550,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
         epi_rows<RB, LPR, 32, 7, false, 1, false, 1>(FMX_EPI_ARGS, p.row_stats + (long)(tn * G::WN + wn) * 2, G::WN * p.tiles_n * 2);
       } else if (LN == 2) {   // consumer: bias only
         epi_rows<RB, LPR, 32, 7, false, 2, false, 2>(FMX_EPI_ARGS, nullptr, 0, lnm, lnr, i * 32, p.ln_colsum + nbc);
+      } else if (LN == 3) {   // consumer, operand-swapped: the host sends no bias / residual here
+        epi_rows<RB, LPR, 32, 7, false, 2, false, 3>(FMX_EPI_ARGS, nullptr, 0, 0.f, 0.f, 0, p.ln_col_ab + (long)nbc * 2, p.ln_row_cb);
       } else if (ep.gelu_tanh) epi_rows<RB, LPR, 32, 7, true, 0>(FMX_EPI_ARGS);       // uniform branches
       else if (ep.mrv | ep.mgt) epi_rows<RB, LPR, 32, 7, false, 0>(FMX_EPI_ARGS);
       else if (ep.mres) epi_rows<RB, LPR, 32, 7, false, 1>(FMX_EPI_ARGS);
@@ -608,22 +636,26 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
             sv = *reinterpret_cast<const f32x4*>(p.ln_colsum + nbc);
             sg = *reinterpret_cast<const f32x4*>(p.ln_colsum + nbc + 16);
           }
+          f32x4 bvf, bgf;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { bvf[r] = (float)bv[r]; bgf[r] = (float)bg[r]; }
 #pragma unroll
           for (int i = 0; i < MI; ++i) {
             f16x4 rvv, rvg;
             if (RV) { rvv = ep.rv4(imgs[i], nbc); rvg = ep.rv4(imgs[i], nbc + 16); }
+            // (acc alpha - mean colsum) rstd + bias  =  acc (alpha rstd) + (bias - mean rstd colsum): one FMA per element and one per column
+            const float sc = LN == 2 ? ep.alpha * gr[i] : ep.alpha;
+            const float mr = gm[i] * gr[i];
             f32x4 o;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              float val = acc[i][j][q4 * 4 + r] * ep.alpha;
-              float gate = acc[i][j][8 + q4 * 4 + r] * ep.alpha;
-              if (LN == 2) {
-                val = (val - gm[i] * sv[r]) * gr[i];
-                gate = (gate - gm[i] * sg[r]) * gr[i];
-              }
-              val += (float)bv[r];
-              gate += (float)bg[r];
-              if (RV) { val += (float)rvv[r]; gate += (float)rvg[r]; }
+              float cv = bvf[r], cg = bgf[r];
+              if (LN == 2) { cv = fmaf(-mr, sv[r], cv); cg = fmaf(-mr, sg[r], cg); }
+              if (RV) { cv += (float)rvv[r]; cg += (float)rvg[r]; }
+              const float val = fmaf(acc[i][j][q4 * 4 + r], sc, cv);
+              const float gate = fmaf(acc[i][j][8 + q4 * 4 + r], sc, cg);
+              // (a transcendental-free erf -- odd polynomial of degree 19, 12 packable operations -- was measured in round 3: 117.1 vs 117.1 ms
+              //  per step, profiles/r08j; the epilogue is not bound by v_rcp / v_exp issue, and the exact form is 30x more accurate)
               o[r] = val * gelu_erf_f(gate);
             }
             const int row = i * 32 + li, chunk = j * 4 + q4 * 2 + hi;
@@ -692,6 +724,22 @@ int launch_ln(const GemmParams& p, hipStream_t st) {
   return FMX_OK;
 }
 
+// LayerNorm folded into the operand-swapped V^T GEMM: 320 x 256 tile
+int launch_ln_swapped(const GemmParams& p, hipStream_t st) {
+  using G = Geo<320, 256>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<false, 320, 256, false, 1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    attr_set = true;
+  }
+  GemmParams q = p;
+  q.tiles_m = (p.M + 319) / 320;
+  q.tiles_n = (p.nout + 255) / 256;
+  hipLaunchKernelGGL((gemm256p_kernel<false, 320, 256, false, 1, 3>), dim3(persistent_grid(q.tiles_m * q.tiles_n)), dim3(512), G::LDS_BYTES, st, q);
+  FMX_LAUNCH_CHECK("fmx_gemm_conv_f16 (320x256, LayerNorm folded, operand-swapped)");
+  return FMX_OK;
+}
+
 template <int BM, int BN, bool STATS, int SC = 0, int SL = 1>
 int launch_bn(const GemmParams& p, bool conv, hipStream_t st) {
   using G = Geo<BM, BN>;
@@ -716,6 +764,7 @@ int launch_bn(const GemmParams& p, bool conv, hipStream_t st) {
 int fmx_launch_gemm256p(const GemmParams& p, bool conv, int bm, int bn, hipStream_t st) {
   if (p.row_stats) return launch_ln<1>(p, st);
   if (p.ln_partial) return launch_ln<2>(p, st);
+  if (p.ln_col_ab) return launch_ln_swapped(p, st);
   static int sched = -1;
   if (sched < 0) {
     const char* e = getenv("FMX_GEMM_SCHED");   // A/B knob (tools/bench_kernels.py gemmsched): force one DMA issue schedule on the 256x320 tile

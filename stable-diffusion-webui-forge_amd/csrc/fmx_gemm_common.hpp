@@ -43,6 +43,9 @@ struct GemmParams {
   int ln_parts;
   const float* ln_colsum;    // consumer: fp32 column sums of the (gamma-scaled) weight, [nout]
   float ln_eps, ln_inv_c;    // consumer: LayerNorm epsilon, 1 / normalised width
+  // the operand-swapped consumer (320 x 256 tile, fmx.h ln_col_ab / ln_row_cb): LayerNorm rows = output columns
+  const float* ln_col_ab;    // [nout][2] {rstd, -mean rstd}
+  const float* ln_row_cb;    // [M][2] {colsum, folded bias}
 };
 
 // K-tile depth of every GEMM kernel: 64 halfs = one 128-byte LDS row.

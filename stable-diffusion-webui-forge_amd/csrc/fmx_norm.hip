@@ -249,7 +249,33 @@ __global__ __launch_bounds__(256) void ln_kernel(const f16* __restrict__ x, cons
   }
 }
 
+// row statistics of a LayerNorm-folded GEMM's producer -> {rstd, -mean rstd} per row (the operand-swapped consumer reads them per output column)
+__global__ __launch_bounds__(256) void ln_rowstats_finalize_kernel(const float* __restrict__ partial, int parts, long rows, float inv_c, float eps,
+                                                                    float* __restrict__ ab) {
+  const long m = (long)blockIdx.x * 256 + threadIdx.x;
+  if (m >= rows) return;
+  const float* q = partial + m * (parts * 2);
+  float s1 = 0.f, s2 = 0.f;
+  for (int k = 0; k < parts; ++k) {   // same order as the in-kernel form of the 256 x 320 consumer (fmx_gemm256p.hip, LN == 2)
+    s1 += q[2 * k];
+    s2 += q[2 * k + 1];
+  }
+  const float mean = s1 * inv_c;
+  const float rstd = rsqrtf(fmaxf(s2 * inv_c - mean * mean, 0.f) + eps);
+  *reinterpret_cast<f32x2*>(ab + m * 2) = f32x2{rstd, -mean * rstd};
+}
+
 }  // namespace
+
+#ifndef FMX_ELEM_BF16   // fp32 in, fp32 out: one copy serves both element types
+extern "C" int fmx_layernorm_rowstats_finalize(const float* row_partial, int32_t parts, int64_t rows, int32_t c, float eps, float* ab, void* stream) {
+  FMX_REQUIRE(row_partial && ab && parts >= 1 && parts <= 64 && rows > 0 && c > 0, "layernorm_rowstats_finalize: bad args");
+  hipLaunchKernelGGL(ln_rowstats_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, row_partial, parts, (long)rows,
+                     1.0f / (float)c, eps, ab);
+  FMX_LAUNCH_CHECK("fmx_layernorm_rowstats_finalize");
+  return FMX_OK;
+}
+#endif
 
 int fmx_launch_gn_stats(const void* x, int32_t c, int64_t ld, int32_t n, int32_t hw, float* partial, int32_t nchunks, hipStream_t st) {
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, n), dim3(256), 256 * 16 * sizeof(float), st, (const f16*)x, c, (long)ld, hw, partial, nchunks);

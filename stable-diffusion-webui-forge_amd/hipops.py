@@ -172,7 +172,7 @@ _FUSED_STATS = os.environ.get("FMX_GN_FUSED_STATS", "1") != "0"
 
 def conv_gemm(x, wgt, nout, *, x1=None, n=None, h=None, w=None, kh=1, stride=1, pad=0, up=None, bias=None,
               rowvec=None, residual=None, act=ACT_NONE, alpha=1.0, out=None, ld_out=None, out_dtype=None,
-              ldw=0, force_tile=0, gate=None, out_hw=None, stats=False, stats_partial=None, row_stats=None, ln=None):
+              ldw=0, force_tile=0, gate=None, out_hw=None, stats=False, stats_partial=None, row_stats=None, ln=None, ln_swapped=None):
     """OUT[M, ncols] = epilogue(A (*) W^T).  x: [N,H,W,C0] (or [M,C0] with kh == 1); x1: optional second source
     concatenated along channels; wgt: [nout, kh*kh*(C0+C1)]; up=(UH, UW): nearest-resize before the conv.
     stats=True: returns (out, GnStats of out) -- the GroupNorm statistics of the output come out of the GEMM's epilogue (256-row tiles)
@@ -180,7 +180,9 @@ def conv_gemm(x, wgt, nout, *, x1=None, n=None, h=None, w=None, kh=1, stride=1, 
     `stats_buffer` when the statistics have to outlive the current arena scope (they live exactly as long as `out` must).
     LayerNorm folding (fmx.h, fmx_gemm_linear_rowstats_f16 / ln_* fields): row_stats = a RowStats whose buffer takes the per-row sums of the
     output (its `.parts` is 0 afterwards if the dispatcher did not use the 256x320 tile); ln = (RowStats of the INPUT, colsum fp32 [nout],
-    eps) runs the GEMM as `LN(x) W^T + b` on the un-normalised x (wgt / bias pre-folded by the caller)."""
+    eps) runs the GEMM as `LN(x) W^T + b` on the un-normalised x (wgt / bias pre-folded by the caller);  ln_swapped = (col_ab fp32 [nout, 2] from
+    `ln_rowstats_finalize`, row_cb fp32 [M, 2]) is the same fold for the operand-swapped form `W' x^T` (x = the gamma-scaled weight, wgt = the
+    un-normalised activations: V^T of self-attention), fmx.h ln_col_ab / ln_row_cb."""
     sfx, elem = _elem(x, x1, wgt, bias, rowvec, residual, gate)
     fn_name = "fmx_gemm_conv" + sfx
     if out_dtype is None:
@@ -223,15 +225,20 @@ def conv_gemm(x, wgt, nout, *, x1=None, n=None, h=None, w=None, kh=1, stride=1, 
     a.gate = _p(gate)
     a.ld_gate = gate.stride(0) if gate is not None else 0
     a.workspace, a.workspace_bytes = _p(splitk_workspace(x.device)), SPLITK_WORKSPACE_BYTES
+    global LN_FOLDED_LAUNCHES
     if ln is not None:
-        global LN_FOLDED_LAUNCHES
         LN_FOLDED_LAUNCHES += 1
         rs, colsum, eps = ln
         assert rs.parts >= 2 and colsum.dtype == torch.float32 and colsum.numel() == nout and rs.partial.dtype == torch.float32
         a.ln_partial, a.ln_parts, a.ln_colsum, a.ln_eps = _p(rs.partial), rs.parts, _p(colsum), float(eps)
+    if ln_swapped is not None:
+        LN_FOLDED_LAUNCHES += 1
+        col_ab, row_cb = ln_swapped
+        assert col_ab.dtype == torch.float32 and col_ab.numel() == 2 * nout and row_cb.dtype == torch.float32 and row_cb.numel() == 2 * m and ln is None
+        a.ln_col_ab, a.ln_row_cb = _p(col_ab), _p(row_cb)
     st = None
     if row_stats is not None:
-        assert sfx == "_f16" and not stats and ln is None
+        assert sfx == "_f16" and not stats and ln is None and ln_swapped is None
         cap = row_stats.partial.numel() // (2 * m)
         got = C.c_int32(0)
 
@@ -276,6 +283,16 @@ class RowStats:
     def __init__(self, m, n, device=None):
         self.partial = empty((m, 2 * (-(-n // 320)), 2), torch.float32, device)
         self.parts = 0
+
+
+def ln_rowstats_finalize(rs, c, eps):
+    """RowStats (parts > 0) of an [M, c] tensor -> fp32 [M, 2] = {rstd, -mean * rstd} per row (fmx_layernorm_rowstats_finalize): the per-column
+    operand of the operand-swapped LayerNorm-folded GEMM (conv_gemm(ln_swapped=...))."""
+    m = rs.partial.shape[0]
+    ab = empty((m, 2), torch.float32, rs.partial.device)
+    _lib.check(_lib.lib().fmx_layernorm_rowstats_finalize(_p(rs.partial), rs.parts, m, c, float(eps), _p(ab), stream_ptr()),
+               "fmx_layernorm_rowstats_finalize")
+    return ab
 
 
 def linear(x, wgt, bias=None, **kw):

@@ -107,6 +107,13 @@ def test_other_contract_violations(lib):
         kw = dict(ld_out=64, ln_partial=FAKE, ln_parts=2, ln_colsum=FAKE, ln_eps=1e-5)
         kw.update(bad)
         assert lib.fmx_gemm_conv_f16(C.byref(_gemm(**kw)), None) == BADARG and "LayerNorm-folded" in err(), bad
+    # the operand-swapped fold (ABI 7): no bias / residual, both operand arrays, M a multiple of 320, not together with the ordinary fold
+    for bad in (dict(ln_row_cb=0), dict(bias=FAKE), dict(residual=FAKE, ld_res=64), dict(ln_partial=FAKE, ln_parts=2, ln_colsum=FAKE), dict(act=1)):
+        kw = dict(ld_out=64, ln_col_ab=FAKE, ln_row_cb=FAKE)
+        kw.update(bad)
+        assert lib.fmx_gemm_conv_f16(C.byref(_gemm(**kw)), None) == BADARG, bad
+    assert lib.fmx_layernorm_rowstats_finalize(None, 8, 64, 1280, 1e-5, f, None) == BADARG
+    assert lib.fmx_layernorm_rowstats_finalize(f, 0, 64, 1280, 1e-5, f, None) == BADARG
     a = AttnArgs()
     a.q = a.k = a.vt = a.o = a.zero_page = FAKE
     a.batch, a.heads, a.nq, a.nk, a.nk_pad, a.dpad, a.scale = 1, 1, 64, 64, 64, 200, 0.1

@@ -49,7 +49,7 @@ def test_ctypes_binding_matches_header(built):
     bound = set(_lib.SIGNATURES) | {"fmx_last_error"}
     assert declared == bound, (sorted(declared - bound), sorted(bound - declared))
     L = _lib.lib()
-    assert L.fmx_abi_version() == 6
+    assert L.fmx_abi_version() == 7
 
 
 def test_struct_layouts_match_header():

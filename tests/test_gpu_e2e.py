@@ -714,7 +714,7 @@ def test_sdxl_full_size_forward_vs_reference_fixture(sdxl_engine):
 def test_sdxl_full_size_forward_at_the_bench_batch_vs_reference_fixture(sdxl_engine):
     """The same fixture at the BENCH's UNet batch (16): the reference's input repeated 16 times, every image of the result against the
     reference's output.  At this size the executor takes the paths a batch of 1 does not reach: 256x320 tiles everywhere, GroupNorm statistics
-    from the GEMM epilogues, norm2 / norm3 folded into the projections behind them (counted), key-split attention off -- the configuration the
+    from the GEMM epilogues, norm1 / norm2 / norm3 folded into the projections behind them (counted), key-split attention off -- the configuration the
     throughput numbers are measured on."""
     from forge_amd import hipops
     from oracle.make_golden import _inputs
@@ -725,7 +725,7 @@ def test_sdxl_full_size_forward_at_the_bench_batch_vs_reference_fixture(sdxl_eng
     n = 16
     before = hipops.LN_FOLDED_LAUNCHES
     eps = net.forward(x.repeat(n, 1, 1, 1).to(DEV), t.repeat(n).to(DEV), context=ctx.repeat(n, 1, 1).to(DEV), y=y.repeat(n, 1).to(DEV))
-    assert hipops.LN_FOLDED_LAUNCHES - before == 2 * 70, "norm2 and norm3 of all 70 transformer blocks are expected to run folded at this size"
+    assert hipops.LN_FOLDED_LAUNCHES - before == 4 * 70, "norm1 (q|k and V^T), norm2 and norm3 of all 70 transformer blocks are expected to run folded at this size"
     worst = max(range(n), key=lambda i: float((eps[i].float().cpu() - g["eps"][0]).abs().max()))
     for i in sorted({0, n - 1, worst}):
         check(f"SDXL unet forward at full size, image {i} of a batch of {n} vs reference", eps[i:i + 1], g["eps"], floor="sdxl_full_fwd.pt:eps")

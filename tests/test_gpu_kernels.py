@@ -187,6 +187,43 @@ def test_layernorm_folded_into_the_gemms_around_it(m, c, nq):
     assert err_new[0] <= 2.0 * err_new[1] + 1e-3, err_new
 
 
+@pytest.mark.parametrize("m,c,hd", [(16384, 1280, 1280), (65536, 640, 640), (16384 - 64, 1280, 1280)])
+def test_layernorm_folded_into_the_operand_swapped_vt_projection(m, c, hd):
+    """norm1 without a LayerNorm kernel (round 3): the projection that writes h WITHOUT a residual (proj_in) leaves the row statistics too; the
+    V^T projection runs as W' h^T on the un-normalised h (320x256 tile, `LN = 3`): the LayerNorm rows are its output COLUMNS, so the epilogue
+    takes {rstd, -mean rstd} per column (fmx_layernorm_rowstats_finalize) and {colsum, W beta} per row.  Against F.layer_norm + linear in fp32 on
+    the stored h, transposed; the q|k projection of the same block through the ordinary fold from the same statistics."""
+    from forge_amd.backend.nn.unet import _fold_layernorm
+    x_in = rnd(m, c, seed=110)
+    w_in, b_in = rnd(c, c, scale=1 / math.sqrt(c), seed=111), (rnd(c, seed=112) + 0.5).contiguous()
+    rs = ops.RowStats(m, c)
+    h = ops.linear(x_in, w_in, b_in, row_stats=rs)                      # producer without a residual
+    close(h, x_in.float() @ w_in.float().t() + b_in.float(), 2e-3, 2e-3, "producer output (no residual)")
+    assert rs.parts == 2 * (c // 320)
+    hf = h.double()
+    torch.testing.assert_close(rs.partial.view(m, -1, 2)[:, :rs.parts].double().sum(1), torch.stack([hf.sum(1), (hf * hf).sum(1)], -1), rtol=1e-5, atol=1e-2)
+    gamma, beta = (1 + 0.2 * rnd(c, seed=113)), 0.1 * rnd(c, seed=114)
+    ln = F.layer_norm(h.float(), (c,), gamma.float(), beta.float(), 1e-5)
+    ab = ops.ln_rowstats_finalize(rs, c, 1e-5)
+    mean, var = h.float().mean(1), h.float().var(1, unbiased=False)
+    torch.testing.assert_close(ab[:, 0], torch.rsqrt(var + 1e-5), rtol=2e-4, atol=1e-6)
+    torch.testing.assert_close(ab[:, 1], -mean * torch.rsqrt(var + 1e-5), rtol=2e-4, atol=2e-4)
+    wv = rnd(hd, c, scale=1 / math.sqrt(c), seed=115)
+    wvf = (wv.float() * gamma.float()[None, :]).half().contiguous()
+    cb = torch.stack([wvf.float().sum(1), wv.float() @ beta.float()], 1).contiguous()
+    vt = ops.conv_gemm(wvf, h, m, ln_swapped=(ab, cb))
+    assert tuple(vt.shape) == (hd, m)
+    close(vt, (ln @ wv.float().t()).t(), 4e-3, 4e-3, "LayerNorm folded into the operand-swapped V^T projection")
+    # the kernels it replaces, for scale
+    vt_old = ops.conv_gemm(wv, ops.layernorm(h, gamma, beta), m)
+    ref = (ln @ wv.float().t()).t()
+    e_new, e_old = float((vt.float() - ref).abs().max()), float((vt_old.float() - ref).abs().max())
+    assert e_new <= 2.0 * e_old + 1e-3, (e_new, e_old)
+    wqk = rnd(2 * hd, c, scale=1 / math.sqrt(c), seed=116)
+    wf, cs, bf = _fold_layernorm(wqk, None, gamma, beta)
+    close(ops.conv_gemm(h, wf, 2 * hd, bias=bf, ln=(rs, cs, 1e-5)), ln @ wqk.float().t(), 4e-3, 4e-3, "q|k projection from the same statistics")
+
+
 def test_layernorm_fold_is_declined_for_small_problems():
     """Below the sizes at which the dispatcher uses the 256x320 tile the producer emits nothing (parts == 0) and the caller keeps its LayerNorm."""
     m, c = 512, 640

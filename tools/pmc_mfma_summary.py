@@ -19,7 +19,7 @@ import sys
 
 
 def short(name):
-    for key in ("attn_q64v2_kernel", "attn_q64_kernel", "attn_kernel", "gemm256p_kernel", "gemm_kernel", "gn_apply_kernel", "gn_stats_kernel", "gn_finalize_kernel"):
+    for key in ("attn_short2_kernel", "attn_short_kernel", "attn_q64v3_kernel", "attn_q64v2_kernel", "attn_q64_kernel", "attn_kernel", "gemm256p_kernel", "gemm_kernel", "gn_apply_kernel", "gn_stats_kernel", "gn_finalize_kernel"):
         if key in name:
             i = name.index(key)
             j = name.find("(", i)
@@ -32,13 +32,21 @@ def main(root):
     dur = collections.defaultdict(dict)
     for sub in sorted(os.listdir(root)):
         f = os.path.join(root, sub, "pmc_counter_collection.csv")
-        if not sub.startswith("pmc_") or not os.path.exists(f):
+        if sub not in ("pmc_mfma", "pmc_waves") or not os.path.exists(f):   # (the FETCH / WRITE passes profile another workload: bench.py)
             continue
-        for r in csv.DictReader(open(f)):
+        rows = list(csv.DictReader(open(f)))
+        # the 8-wave GEMM kernels are persistent since round 3 (grid = one workgroup per CU whatever the problem), so the grid no longer tells
+        # the shapes of tools/pmc_kernels.py apart: the workload launches each shape REPS times in a row -> number the runs of equal kernel names
+        run_of, last, run = {}, None, -1
+        for r in sorted({(int(x["Dispatch_Id"]), x["Kernel_Name"]) for x in rows}):
+            if r[1] != last:
+                run, last = run + 1, r[1]
+            run_of[r[0]] = run
+        for r in rows:
             k = short(r["Kernel_Name"])
             if k is None:
                 continue
-            key = f"{k} grid={int(r['Grid_Size']) // int(r['Workgroup_Size'])}x{r['Workgroup_Size']} lds={r['LDS_Block_Size']} vgpr={r['VGPR_Count']}"
+            key = f"{k} grid={int(r['Grid_Size']) // int(r['Workgroup_Size'])}x{r['Workgroup_Size']} vgpr={r['VGPR_Count']} launch-group={run_of[int(r['Dispatch_Id'])]}"
             agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
             dur[key][r["Dispatch_Id"] + sub] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
     out = {}

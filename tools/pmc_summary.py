@@ -16,7 +16,7 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             if row.get("Counter_Name") != counter:
                 continue
             name = row["Kernel_Name"]
-            fam = "gemm256" if "gemm256" in name else "gemm" if "gemm_kernel" in name else "attn_q64v2" if "attn_q64v2" in name else \
+            fam = "gemm256" if "gemm256" in name else "gemm" if "gemm_kernel" in name else "attn_short" if "attn_short" in name else "attn_q64v2" if "attn_q64v2" in name else \
                 "attn_q64" if "attn_q64" in name else "attn" if "attn_kernel" in name else "gn_apply" if "gn_apply" in name else \
                 "gn_stats" if "gn_stats" in name else "gn_finalize" if "gn_finalize" in name else "layernorm" if "ln_kernel" in name else None
             if fam is None:
