@@ -536,6 +536,9 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
         for (int q4 = 0; q4 < 4; ++q4) {
           const int chunk = j * 8 + q4 * 2 + hi;
           const f32x16& a = acc[i][j];
+#ifdef FMX_ABLATE_EPI_LDS   // timing-only build (WRONG results): half of the transpose's LDS writes -- what do they cost?
+          if (q4 & 1) continue;
+#endif
           *reinterpret_cast<f32x4*>(my + li * RB + ((chunk ^ (li & 7)) << 4)) = f32x4{a[q4 * 4], a[q4 * 4 + 1], a[q4 * 4 + 2], a[q4 * 4 + 3]};
         }
       // same wave wrote and reads: LDS operations of one wave execute in order, no barrier needed

@@ -3,6 +3,8 @@
 // Replaces F.group_norm (backend/operations.py:308; eps 1e-5 ResBlock/out, 1e-6 SpatialTransformer/VAE) fused
 // with the SiLU that follows it in ResBlock.in_layers/out_layers (backend/nn/unet.py:394-398,417-421) and the
 // torch.cat of the skip tensor in front of it (:741); and F.layer_norm (backend/operations.py:327).
+#include <stdlib.h>
+
 #include "fmx_common.hpp"
 
 namespace {
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
 // ---- apply: normalise + affine (+ SiLU), writing the (concatenated) fp16 NHWC tensor: 1 read + 1 write ---------------------------
 // grid (pixel tiles, n); the image's per-channel scale / shift are staged once per block in LDS; element i = tid + k*256 over the
 // (pixel, octet) grid, four independent 16-byte loads in flight per thread.
-template <bool SILU>
+template <bool SILU, int UNR = 4, bool NT = false>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x0, const f16* __restrict__ x1, int c0, int c1, long ld0, long ld1,
                                                         int hw, const float* __restrict__ ss_g, f16* __restrict__ y, int pix_per_block) {
   extern __shared__ __attribute__((aligned(16))) float ss[];  // [C] scale, [C] shift
@@ -161,22 +163,29 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
   const int dpx = 256 / oct, dov = 256 - dpx * oct;
   const long ibase = (long)img * hw;
   while (px < p1) {
-    int pxs[4], chs[4];
-    f16x8 v[4];
+    int pxs[UNR], chs[UNR];
+    f16x8 v[UNR];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < UNR; ++u) {
       pxs[u] = px;
       chs[u] = o * 8;
       if (px < p1) {
         const f16* src = (chs[u] < c0) ? x0 + (ibase + px) * ld0 + chs[u] : x1 + (ibase + px) * ld1 + (chs[u] - c0);
-        v[u] = *reinterpret_cast<const f16x8*>(src);
+        if (NT) {
+          typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+          union { u32x4_ u4; f16x8 h; } cv;
+          cv.u4 = __builtin_nontemporal_load(reinterpret_cast<const u32x4_*>(src));
+          v[u] = cv.h;
+        } else {
+          v[u] = *reinterpret_cast<const f16x8*>(src);
+        }
       }
       px += dpx;
       o += dov;
       if (o >= oct) { o -= oct; ++px; }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < UNR; ++u) {
       if (pxs[u] < p1) {
         const int ch = chs[u];
         const f32x4 sc0 = *reinterpret_cast<const f32x4*>(scale + ch), sc1 = *reinterpret_cast<const f32x4*>(scale + ch + 4);
@@ -303,22 +312,41 @@ extern "C" int fmx_groupnorm_apply_f16(const void* x0, const void* x1, int32_t c
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, n), dim3(64), 0, st, partial0, nchunks0, c0, partial1, c1 ? nchunks1 : 1, c1, groups, hw, eps,
                      (const f16*)gamma, (const f16*)beta, scale_shift);
-  // ~64 KB of activations per block (4 rounds of 4 x 16 bytes per thread) keeps >= 2k blocks in flight on the big tensors
-  int ppb = (32768 + C - 1) / C;
+  static int ppb_bytes = 0;
+  if (!ppb_bytes) {
+    // A/B knob: activation bytes per block.  16 KB = one round of 4 x 16 bytes per thread: many short blocks beat few long ones on every
+    // shape of the SDXL UNet and VAE (in a graph, each launch on its own tensors, profiles/r08l: 128^2 x 320 91 -> 76 us, 32^2 x 1280 34 -> 28 us,
+    // 1024^2 x 128 818 -> 745 us against round 2's 64 KB; 8 / 12 KB and streaming loads are level or mixed)
+    const char* e = getenv("FMX_GN_BLOCK_KB");
+    ppb_bytes = (e ? atoi(e) : 16) * 512;        // (elements: 2 bytes each)
+  }
+  int ppb = (ppb_bytes + C - 1) / C;
   if (ppb < 1) ppb = 1;
   const int tiles = (hw + ppb - 1) / ppb;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_apply_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_apply_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_apply_kernel<true, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_apply_kernel<true, 8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_apply_kernel<true, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_apply_kernel<true, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_apply_kernel<false, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  if (silu)
-    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(tiles, n), dim3(256), (size_t)(2 * C) * sizeof(float), st, (const f16*)x0, (const f16*)x1, c0, c1,
-                       (long)ld0, (long)ld1, hw, scale_shift, (f16*)y, ppb);
-  else
-    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(tiles, n), dim3(256), (size_t)(2 * C) * sizeof(float), st, (const f16*)x0, (const f16*)x1, c0, c1,
-                       (long)ld0, (long)ld1, hw, scale_shift, (f16*)y, ppb);
+  static int variant = -1;
+  if (variant < 0) {
+    const char* e = getenv("FMX_GN_VARIANT");   // A/B knob (tools/bench_kernels.py gnapply): 0 = 4 loads in flight per thread, 1 = 8, 2 = 4 streaming (nt) loads, 3 = 8 nt
+    variant = e ? atoi(e) : 0;
+  }
+#define FMX_GN_LAUNCH(S, U, N)                                                                                                                   \
+  hipLaunchKernelGGL((gn_apply_kernel<S, U, N>), dim3(tiles, n), dim3(256), (size_t)(2 * C) * sizeof(float), st, (const f16*)x0, (const f16*)x1, c0, c1, \
+                     (long)ld0, (long)ld1, hw, scale_shift, (f16*)y, ppb)
+  if (silu) {
+    if (variant == 1) FMX_GN_LAUNCH(true, 8, false); else if (variant == 2) FMX_GN_LAUNCH(true, 4, true); else if (variant == 3) FMX_GN_LAUNCH(true, 8, true);
+    else FMX_GN_LAUNCH(true, 4, false);
+  } else {
+    FMX_GN_LAUNCH(false, 4, false);
+  }
+#undef FMX_GN_LAUNCH
   FMX_LAUNCH_CHECK("fmx_groupnorm_apply_f16");
   return FMX_OK;
 }

@@ -286,6 +286,18 @@ def bench_gn(n, h, w, c):
                       "GBps_touched(2R+1W)": round(3 * by / t / 1e9, 0)}), flush=True)
 
 
+def bench_gn_apply_graph(n, h, w, c, copies=3):
+    """GroupNorm apply (+SiLU) on statistics the producer left, as the forward runs it: in a graph, every launch on its own tensors"""
+    g, bb = rnd(c), rnd(c)
+    xs = [rnd(n, h, w, c) for _ in range(copies)]
+    outs = [torch.empty_like(x) for x in xs]
+    sts = [ops.groupnorm_stats(x) for x in xs]
+    t = timeit_graph([(lambda x=x, o=o, st=st: ops.groupnorm(x, g, bb, 1e-5, silu=True, out=o, stats=st)) for x, o, st in zip(xs, outs, sts)], reps=10)
+    by = xs[0].numel() * 2
+    print(json.dumps({"op": "groupnorm finalize + apply + SiLU (in graph)", "n": n, "hw": [h, w], "c": c, "us": round(t * 1e6, 1), "GBps(1R+1W)": round(2 * by / t / 1e9, 0),
+                      "env": {k: v for k, v in os.environ.items() if k.startswith("FMX_GN")}}), flush=True)
+
+
 def bench_gn_paths(n, h, w, c):
     """GroupNorm + SiLU three ways: own statistics pass (stats + finalize + apply), on statistics the producer left (finalize + apply),
     and the producer side: the same conv / linear with and without statistics in its epilogue."""
@@ -428,6 +440,10 @@ if __name__ == "__main__":
             bench_attn_graph(16, 20, 1024, 77, 64)
             bench_attn_graph(16, 10, 4096, 77, 64)
         bench_attn_graph(2, 20, 1024, 77, 64)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "gnapply":
+        for shp in ((16, 128, 128, 320), (16, 64, 64, 640), (16, 32, 32, 1280), (16, 32, 32, 2560), (8, 1024, 1024, 128), (8, 512, 512, 256)):
+            bench_gn_apply_graph(*shp)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "epi":
         # round 3: what the epilogue costs.  Full chip (256 tiles), half chip (128 tiles: is the row pass contention-bound?), two rounds, long K
