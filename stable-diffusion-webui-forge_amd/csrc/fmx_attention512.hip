@@ -15,8 +15,9 @@
 // Rates: 16 MFMAs per wave against 16 fragment reads and a 20 KB partial-score exchange per step -> LDS-bound (PMC: matrix pipes 16-22 % busy,
 // 30 % of wave time waiting on LDS), not matrix-pipe-bound; 538 TFLOP/s after the bank-conflict fix below (407 before), against 397 for the
 // materialised path it replaces -- and no 512 MB score buffer or per-image host loop, see DESIGN.md section 4.2.
-#include "fmx_common.hpp"
+#include <stdlib.h>
 
+#include "fmx_common.hpp"
 
 namespace {
 
@@ -51,11 +52,21 @@ __device__ __forceinline__ int key_perm(int i) { return (i & 3) | (((i >> 3) & 3
 __device__ __forceinline__ int k_swz(int row) { return (row & 3) | (((row >> 4) & 1) << 2); }   // row = key_perm(lane)
 __device__ __forceinline__ int v_swz(int row) { return (row >> 1) & 3; }
 
-__global__ __launch_bounds__(512, 2) void attn512_kernel(const Attn512Params p) {
+// NS = channel slices per query fragment: 4 (128 channels per wave, 8 waves = two per SIMD: the round-2 form) or 2 (256 channels per wave, 4 waves = ONE
+// per SIMD on the whole 512-entry register file; round 3, slower: see the launcher).  With 4 slices a 32-key step costs a CU 256 KB of fragment reads + the exchange of 8 x 4 KB of
+// fp32 partial scores, each partial read by 4 waves (LDS ~1 500 cycles against 1 024 of MFMA: LDS-bound, profiles/r05z); with 2 slices every fragment read
+// feeds a wave that owns twice the channels: the same MFMAs, 160 KB of reads, half the exchange, two partials per sum.
+template <int NS>
+__global__ __launch_bounds__(NS * 128, 1) void attn512_kernel(const Attn512Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NW = 2 * NS;              // waves
+  constexpr int SC = C / NS;              // channels per slice
+  constexpr int QS = SC / 16;             // 16-channel MFMA k-steps per slice
+  constexpr int OD = SC / 32;             // 32-channel output blocks per slice
+  constexpr int PW = 32 / NW;             // 1-KiB staging pieces per wave and operand (a stage is 32 K pieces + 32 V^T pieces)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int qf = wave >> 2, ds = wave & 3;   // query fragment, channel slice
+  const int qf = wave / NS, ds = wave % NS;   // query fragment, channel slice
   const int hi = lane >> 5, li = lane & 31;
 
   const int nwg = p.qtiles * p.batch;
@@ -69,10 +80,10 @@ __global__ __launch_bounds__(512, 2) void attn512_kernel(const Attn512Params p) 
   // ---- Q slice of this wave, pre-scaled by scale * log2(e): B operand, lane = query li, k-slots hi*8.. of each 16-channel step ----
   const int q0 = qt * QT + qf * 32;
   const int qrow = min(q0 + li, p.nq - 1);
-  const f16* qp = p.q + (long)b * p.q_bs + (long)qrow * p.q_rs + ds * 128 + hi * 8;
-  f16x8 qfr[8];
+  const f16* qp = p.q + (long)b * p.q_bs + (long)qrow * p.q_rs + ds * SC + hi * 8;
+  f16x8 qfr[QS];
 #pragma unroll
-  for (int s = 0; s < 8; ++s) {
+  for (int s = 0; s < QS; ++s) {
     const f16x8 raw = *reinterpret_cast<const f16x8*>(qp + s * 16);
 #pragma unroll
     for (int e = 0; e < 8; ++e) qfr[s][e] = (f16)((float)raw[e] * p.scale_log2e);
@@ -80,30 +91,30 @@ __global__ __launch_bounds__(512, 2) void attn512_kernel(const Attn512Params p) 
 
   // ---- staging: 64 one-KiB pieces per stage, 8 per wave.  K piece r = key row r (64 chunks of 16 B);
   //      V^T piece r = channel rows 16 r .. 16 r + 15 (4 chunks of 16 B each); chunk positions XOR-ed with k_swz / v_swz of the row ---------
-  unsigned k_voff[4], v_voff[4];
+  unsigned k_voff[PW], v_voff[PW];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int row = e * 8 + wave;                                   // key row of this wave's e-th K piece
+  for (int e = 0; e < PW; ++e) {
+    const int row = e * NW + wave;                                  // key row of this wave's e-th K piece
     k_voff[e] = (unsigned)row * (unsigned)p.k_rs * 2u + (unsigned)(lane ^ k_swz(row)) * 16u;
-    const int vrow = (e * 8 + wave) * 16 + (lane >> 2);             // channel row of this lane in the wave's e-th V^T piece
+    const int vrow = (e * NW + wave) * 16 + (lane >> 2);            // channel row of this lane in the wave's e-th V^T piece
     v_voff[e] = (unsigned)vrow * (unsigned)p.vt_ds * 2u + (unsigned)((lane & 3) ^ v_swz(vrow)) * 16u;
   }
   const unsigned k_step = (unsigned)KV * (unsigned)p.k_rs * 2u;
   auto stage = [&](auto SI, int kt) {
     constexpr int S = decltype(SI)::value;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      auto* dk = (__attribute__((address_space(3))) void*)(smem + S * STAGE + (e * 8 + wave) * 1024);
-      auto* dv = (__attribute__((address_space(3))) void*)(smem + S * STAGE + K_BYTES + (e * 8 + wave) * 1024);
+    for (int e = 0; e < PW; ++e) {
+      auto* dk = (__attribute__((address_space(3))) void*)(smem + S * STAGE + (e * NW + wave) * 1024);
+      auto* dv = (__attribute__((address_space(3))) void*)(smem + S * STAGE + K_BYTES + (e * NW + wave) * 1024);
       const unsigned kv = k_voff[e], vv = v_voff[e];
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, dk, 16, kv, (unsigned)kt * k_step, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, dv, 16, vv, (unsigned)kt * (KV * 2u), 0, 0);
     }
   };
 
-  f32x16 oacc[4];
+  f32x16 oacc[OD];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < OD; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;   // log2 domain
@@ -116,19 +127,19 @@ __global__ __launch_bounds__(512, 2) void attn512_kernel(const Attn512Params p) 
   const int krow = key_perm(li);
   // exchange records: 4 KB per wave, laid out [quarter v][lane] (16 B each): consecutive lanes write / read consecutive 16-byte groups
   float* xw = reinterpret_cast<float*>(smem + XCH) + wave * 1024 + lane * 4;
-  const float* xr = reinterpret_cast<const float*>(smem + XCH) + (qf * 4) * 1024 + lane * 4;
+  const float* xr = reinterpret_cast<const float*>(smem + XCH) + (qf * NS) * 1024 + lane * 4;
   auto step = [&](auto SI, int kt) {
     constexpr int S = decltype(SI)::value;
     if (kt + 1 < nsteps) stage(IC<S ^ 1>{}, kt + 1);
     const char* sk = smem + S * STAGE;
     const char* sv = sk + K_BYTES;
-    // partial scores over this wave's 128 channels: S^T[key][query]
+    // partial scores over this wave's SC channels: S^T[key][query]
     f32x16 part;
 #pragma unroll
     for (int r = 0; r < 16; ++r) part[r] = 0.f;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const int chunk = ds * 16 + s * 2 + hi;
+    for (int s = 0; s < QS; ++s) {
+      const int chunk = ds * (2 * QS) + s * 2 + hi;
       const f16x8 kf = *reinterpret_cast<const f16x8*>(sk + krow * 1024 + ((chunk ^ k_swz(krow)) << 4));
       part = FMX_MFMA_32x32x16(kf, qfr[s], part);
     }
@@ -144,7 +155,7 @@ __global__ __launch_bounds__(512, 2) void attn512_kernel(const Attn512Params p) 
     for (int v = 0; v < 4; ++v) {
       f32x4 a = *reinterpret_cast<const f32x4*>(xr + v * 256);
 #pragma unroll
-      for (int w2 = 1; w2 < 4; ++w2) a += *reinterpret_cast<const f32x4*>(xr + w2 * 1024 + v * 256);
+      for (int w2 = 1; w2 < NS; ++w2) a += *reinterpret_cast<const f32x4*>(xr + w2 * 1024 + v * 256);
 #pragma unroll
       for (int e = 0; e < 4; ++e) sc[v * 4 + e] = a[e];
     }
@@ -173,15 +184,15 @@ __global__ __launch_bounds__(512, 2) void attn512_kernel(const Attn512Params p) 
     l_run = l_run * alpha + psum;
     if (__any(m_new > m_run)) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < OD; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
     }
     m_run = m_new;
     // O^T[slice] += V^T[slice rows][32 keys] P^T : A = V^T rows (channel), B = P^T (k-slot hi*8+e <-> key hi*16 + j*8 + e)
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      const int row = ds * 128 + dt * 32 + li;
+    for (int dt = 0; dt < OD; ++dt) {
+      const int row = ds * SC + dt * 32 + li;
       const char* rp = sv + row * 64;
       const int swz = v_swz(row);
 #pragma unroll
@@ -204,9 +215,9 @@ __global__ __launch_bounds__(512, 2) void attn512_kernel(const Attn512Params p) 
   const u32x2 lw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
   const float inv = 1.0f / (__uint_as_float(lw[0]) + __uint_as_float(lw[1]));
   const int qg = q0 + li;
-  f16* op = p.o + (long)b * p.o_bs + (long)qg * p.o_rs + ds * 128;
+  f16* op = p.o + (long)b * p.o_bs + (long)qg * p.o_rs + ds * SC;
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt)
+  for (int dt = 0; dt < OD; ++dt)
 #pragma unroll
     for (int g = 0; g < 4; g += 2) {
       union { f16x4 h4; unsigned u[2]; } lo, up;
@@ -241,12 +252,18 @@ extern "C" int fmx_attention_single_head512_f16(const void* q, int64_t q_bs, int
   p.scale_log2e = scale * 1.44269504088896340736f;
   p.k_span = (unsigned)k_span; p.vt_span = (unsigned)v_span;
   const int smem = 2 * STAGE + 8 * 4096;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn512_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
+  static int slices = 0;
+  if (!slices) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn512_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn512_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    // A/B knob: 4 (default) = eight waves of 128 channels, 2 = four waves of 256 channels.  Measured (8 x 16 384 tokens, tools/bench_kernels.py attn512,
+    // profiles/r08p): 8.12 ms vs 9.67 ms -- with one wave per SIMD nothing covers the fragment-read and exchange latencies around the two barriers of a
+    // step; the LDS traffic saved (-40 %) does not pay for it.
+    const char* e = getenv("FMX_ATTN512_SLICES");
+    slices = (e && atoi(e) == 2) ? 2 : 4;
   }
-  hipLaunchKernelGGL(attn512_kernel, dim3(p.qtiles * batch), dim3(512), smem, (hipStream_t)stream, p);
+  if (slices == 4) hipLaunchKernelGGL(attn512_kernel<4>, dim3(p.qtiles * batch), dim3(512), smem, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(attn512_kernel<2>, dim3(p.qtiles * batch), dim3(256), smem, (hipStream_t)stream, p);
   FMX_LAUNCH_CHECK("fmx_attention_single_head512_f16");
   return FMX_OK;
 }

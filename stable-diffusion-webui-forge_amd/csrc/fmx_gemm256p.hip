@@ -402,6 +402,13 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
     const char* sb = sa + A_BYTES;
 #pragma unroll
     for (int i = 0; i < MI; ++i) af[fb][i] = *reinterpret_cast<const f16x8*>(sa + lds_off(wm * (MI * 32) + i * 32 + li, ks * 2 + hi));
+#ifdef FMX_ABLATE_LDS_READS   // timing-only build (WRONG results): weight fragments read for k-step 0 only -- what do the K loop's LDS reads cost?
+    if (ks != 0) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) wf[fb][j] = wf[fb ^ 1][j];
+      return;
+    }
+#endif
 #pragma unroll
     for (int j = 0; j < NJ; ++j) wf[fb][j] = *reinterpret_cast<const f16x8*>(sb + lds_off(wn * (NJ * 32) + j * 32 + li, ks * 2 + hi));
   };

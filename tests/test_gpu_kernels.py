@@ -536,6 +536,30 @@ def test_attention_d64_short_context_persistent(b, h, nq, nk):
         close(got, _attn_d64(q, k, v, nk=nk, force32=True).float(), 3e-3, 3e-3, "short-context kernel vs 32-query kernel")
 
 
+@pytest.mark.parametrize("b,n,nk", [(2, 1024, 1024), (1, 4096, 4096), (2, 1000, 1000), (3, 200, 77)])
+def test_attention_single_head_512_wide(b, n, nk):
+    """The VAE mid-block attention (one 512-wide head, backend/nn/vae.py:118-137) on its fused kernel (two query fragments x four channel
+    slices whose partial scores meet in LDS; FMX_ATTN512_SLICES=2 selects the four-wave form), online softmax over 32-key steps.  Ragged query and key counts
+    (rows beyond nk in the last step are masked, padded V^T columns hold garbage), a dominant late key.  Against torch fp32 on the same fp16 inputs."""
+    c = 512
+    nkp = -(-nk // 32) * 32
+    q = rnd(b * n, c, seed=121)
+    k = torch.full((b * nkp, c), 7.0, dtype=torch.float16, device=DEV)
+    v = torch.full((b, nkp, c), -5.0, dtype=torch.float16, device=DEV)
+    kv, vv = rnd(b, nk, c, seed=122), rnd(b, nk, c, seed=123)
+    k.view(b, nkp, c)[:, :nk] = kv
+    v[:, :nk] = vv
+    k.view(b, nkp, c)[b - 1, nk - 1] = q.view(b, n, c)[b - 1, n - 1] * 0.5      # a dominant key in the last valid row, for the last query
+    vt = v.permute(2, 0, 1).reshape(c, b * nkp).contiguous()                     # V^T [512][image * nk_pad + key]
+    o = torch.empty(b * n, c, dtype=torch.float16, device=DEV)
+    ops.attention_single_head512(q, k, vt, o, batch=b, nq=n, nk=nk, nk_pad=nkp, q_bs=n * c, q_rs=c, k_bs=nkp * c, k_rs=c, vt_bs=nkp, vt_ds=b * nkp,
+                                 scale=c ** -0.5)
+    kk = k.view(b, nkp, c)[:, :nk].float()
+    ref = torch.softmax(q.view(b, n, c).float() @ kk.transpose(1, 2) * c ** -0.5, -1) @ v[:, :nk].float()
+    assert bool(torch.isfinite(o).all())
+    close(o.view(b, n, c), ref, 3e-3, 3e-3, f"512-wide single-head attention b{b} n{n} nk{nk}")
+
+
 @pytest.mark.parametrize("d", [64, 128])
 @pytest.mark.parametrize("nk", [1, 20, 33, 63])
 def test_attention_fewer_keys_than_one_tile(d, nk):

@@ -26,8 +26,10 @@ for w in "$@"; do
     gnapply) for E in "FMX_GN_BLOCK_KB=64" "FMX_GN_BLOCK_KB=16" "FMX_GN_BLOCK_KB=8" "FMX_GN_BLOCK_KB=12" "FMX_GN_BLOCK_KB=16 FMX_GN_VARIANT=2" "FMX_GN_BLOCK_KB=8 FMX_GN_VARIANT=2" "FMX_GN_BLOCK_KB=16"; do env $E timeout 300 python tools/bench_kernels.py gnapply >> $O/gnapply.jsonl 2>> $O/gnapply.err; done; cat $O/gnapply.jsonl; tail -3 $O/gnapply.err;;
     soak) timeout 600 python tools/soak.py 3 8 > $O/soak.jsonl 2> $O/soak.err; tail -8 $O/soak.jsonl; tail -2 $O/soak.err;;
     ab_sd15) for E in "FMX_X=0" "FMX_GEMM_PERSIST=0" "FMX_ATTN_SHORT=0" "FMX_GN_BLOCK_KB=64" "FMX_X=0" "FMX_GEMM_PERSIST=0 FMX_ATTN_SHORT=0 FMX_GN_BLOCK_KB=64"; do env $E timeout 600 python bench.py --config ${ABCFG:-sd15-b4-eulera} --no-cpu-baseline --no-vae --steps 20 2>> $O/ab_sd15.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'env':'$E','cfg':d['config']['name'],'ms_per_step':d['ms_per_step'],'gemm_ms':d['roofline']['kernel_time_per_forward_ms'],'attn_ms':d['roofline_attention']['kernel_time_per_forward_ms'],'xattn_ms':(d.get('roofline_attention_short_keys') or {}).get('kernel_time_per_forward_ms'),'gn_ms':d['roofline_groupnorm']['kernel_time_per_forward_ms'],'sclk':(d.get('clocks_during_timed_steps') or {}).get('sclk_mhz',{}).get('mean')}))" >> $O/ab_sd15.jsonl; done; cat $O/ab_sd15.jsonl; tail -3 $O/ab_sd15.err;;
+    attn512) for E in FMX_ATTN512_SLICES=4 FMX_ATTN512_SLICES=2 FMX_ATTN512_SLICES=4 FMX_ATTN512_SLICES=2; do env $E timeout 300 python tools/bench_kernels.py attn512 >> $O/attn512.jsonl 2>> $O/attn512.err; done; cat $O/attn512.jsonl; tail -2 $O/attn512.err;;
+    vtests) timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_vae_bf16.py tests/test_gpu_boundary.py -m gpu -q --tb=short -k "512 or vae or single_head or spatial or decode" 2>&1 | tail -15 > $O/vtests.log; tail -8 $O/vtests.log;;
     dual) timeout 600 python tools/bench_kernels.py dual > $O/dual.jsonl 2> $O/dual.err; cat $O/dual.jsonl; tail -3 $O/dual.err;;
-    epi) for L in "" $EPILIBS; do FMX_LIB=$L timeout 300 python tools/bench_kernels.py epi >> $O/epi.jsonl 2>> $O/epi.err; done; cat $O/epi.jsonl;;
+    epi) for L in $EPILIBS; do FMX_LIB=$L timeout 300 python tools/bench_kernels.py epi >> $O/epi.jsonl 2>> $O/epi.err; done; cat $O/epi.jsonl;;
     testsx) FMX_PARITY_LOG=$O/parity.jsonl timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -40 > $O/pytest_gpu.log; tail -8 $O/pytest_gpu.log;;
     ktests) timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q 2>&1 | tail -40 > $O/ktests.log; tail -12 $O/ktests.log;;
     smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -3 $O/smoke.log;;
