@@ -28,6 +28,8 @@
 //   t+1 is visible in LDS (RAW).
 #include <stdlib.h>
 
+#include <utility>
+
 #include "fmx_gemm_common.hpp"
 
 namespace {
@@ -42,6 +44,11 @@ struct Cursor {  // K-tile being staged
 
 template <int V>
 struct IC { static constexpr int value = V; };
+
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(IC<Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 struct Piece {  // one DMA instruction: per-lane byte offset, uniform byte offset, second source (a1) or not
   unsigned voff, soff;
@@ -216,10 +223,19 @@ __device__ __forceinline__ void epi_rows(const char* my, int lane, int mbase, in
 //   0: 3 behind the barrier (k-step 3 of the tile before), 3 in k-step 0, the rest in k-step 1 -- spread thin beside the MFMAs
 //   1: 5 / 4 / 0 -- everything a k-step earlier, 2 k-steps (~1.5 k cycles) between the last issue and the wait
 //   2: all NP behind the barrier
-template <bool CONV, int BM, int BN, bool STATS = false, int SCHED = 0, int LN = 0>
+// MF: the MFMA shape of the K loop.  32 = v_mfma_f32_32x32x16 (rounds 1-2).  16 = v_mfma_f32_16x16x32 (round 3): the same FLOPs per k from four
+//   times as many accumulator blocks a quarter the size.  Why: the K loop is power-bound, and on this part a stream of 16x16x32
+//   MFMAs on random operands sustains 11 % more FLOP/s at the power limit than the same tile as 32x32x16 (tools/ubench/mfma_power.hip,
+//   profiles/r08q: the GEMM's own 64 x 160 wave-tile sequence from registers, 1 913 vs 1 714 TFLOP/s).  A k-step is then 32 of K (two per
+//   K-tile) and 40 MFMAs per wave; the weight fragments are SINGLE-buffered -- fragment j is re-read for the next k-step right behind its four
+//   MFMAs, 36 MFMAs before its next use -- and only the four activation fragments are double-buffered, so the register count stays where it was.
+template <bool CONV, int BM, int BN, bool STATS = false, int SCHED = 0, int LN = 0, int MF = 32>
 __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   using G = Geo<BM, BN>;
   constexpr int MI = G::MI, NJ = G::NJ, NPA = G::NPA, NPB = G::NPB, NP = G::NP;
+  constexpr int BR = MF;                                   // rows / columns of one accumulator block
+  constexpr int MIB = MI * 32 / BR, NJB = NJ * 32 / BR;    // accumulator blocks per wave along M / N
+  constexpr int WROWS = MI * 32;                           // output rows of a wave
   constexpr int STAGE_BYTES = G::STAGE_BYTES, A_BYTES = G::A_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef FMX_ABLATE
@@ -382,17 +398,19 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   float ln_touch = 0.f;
   const float* ln_row = nullptr;
   if (LN == 2) {
-    const int mrow = min(m0 + wm * (MI * 32) + lane, p.M - 1);
+    const int mrow = min(m0 + wm * WROWS + lane, p.M - 1);
     ln_row = p.ln_partial + (long)mrow * (p.ln_parts * 2);
     ln_touch = ln_row[0];
   }
-  f32x16 acc[MI][NJ];
+  typedef float accv __attribute__((ext_vector_type(MF == 32 ? 16 : 4)));
+  accv acc[MIB][NJB];
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+  for (int i = 0; i < MIB; ++i)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+    for (int j = 0; j < NJB; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < (MF == 32 ? 16 : 4); ++r) acc[i][j][r] = 0.f;
+  const int l16 = lane & 15, kg = lane >> 4;   // MF 16: block row / column of this lane, its 8-wide k group
 
   f16x8 af[2][MI];  // [buffer][mi]  activation fragments (MFMA "B" operand)
   f16x8 wf[2][NJ];  // [buffer][nj]  weight fragments     (MFMA "A" operand)
@@ -413,10 +431,12 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
     for (int j = 0; j < NJ; ++j) wf[fb][j] = *reinterpret_cast<const f16x8*>(sb + lds_off(wn * (NJ * 32) + j * 32 + li, ks * 2 + hi));
   };
   auto mma = [&](int fb) {
+    if constexpr (MF == 32) {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
-      for (int i = 0; i < MI; ++i) acc[i][j] = FMX_MFMA_32x32x16(wf[fb][j], af[fb][i], acc[i][j]);
+        for (int i = 0; i < MI; ++i) acc[i][j] = FMX_MFMA_32x32x16(wf[fb][j], af[fb][i], acc[i][j]);
+    }
   };
 
   // MFMA / DS-read / VMEM interleave of one k-step: (MFMA, ds_read) x (MI + NJ), then the remaining MFMAs each preceded by
@@ -434,7 +454,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
     _Pragma("unroll") for (int q = MI * NJ - MI - NJ; q < (NV); ++q) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0); \
   }
 
-  constexpr int P0 = SCHED == 0 ? 3 : SCHED == 1 ? 5 : NP;          // pieces issued behind the barrier (k-step 3 of the tile before)
+  constexpr int P0 = MF == 16 ? (NP > 5 ? 5 : NP) : SCHED == 0 ? 3 : SCHED == 1 ? 5 : NP;   // pieces issued behind the barrier (k-step 3 of the tile before)
   constexpr int P1 = SCHED == 0 ? 3 : SCHED == 1 ? NP - 5 : 0;      // in k-step 0; the rest in k-step 1
   auto issue_range = [&](auto LO, auto HI, const Cursor& c, int buf) {
     constexpr int lo = decltype(LO)::value, hi = decltype(HI)::value;
@@ -459,12 +479,88 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   else if constexpr (P0 == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  read_frags(0, 0, 0);
+  if constexpr (MF == 32) read_frags(0, 0, 0);
   // iteration t:  k-step 0: + pieces 3-5 of tile t+1   k-step 1: + pieces 6.. of tile t+1   k-step 2: nothing
   //               wait + barrier                          k-step 3: + pieces 0-2 of tile t+2 (into the stage just released)
 #ifdef FMX_ABLATE
   const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
+  if constexpr (MF == 16) {
+    // ---- 16x16x32 K loop: two k-steps of 32 per K-tile, MIB x NJB = 40 MFMAs each, every fragment SINGLE-buffered (216 registers with the
+    //      accumulators, as the 32x32x16 loop).  A k-step runs activation-major in two halves of the weight fragments:
+    //        half A:  for i: for j <  NJB/2: acc[i][j] += w[j] a[i]      half B:  for i: for j >= NJB/2: acc[i][j] += w[j] a[i]
+    //      A fragment is re-read for the NEXT k-step right behind its last MFMA of this one: w[j < NJB/2] behind the last activation row of half A,
+    //      a[i] behind its group of half B, w[j >= NJB/2] behind the last row of half B -- each 15 to 25 MFMAs (> 240 cycles) before its next use.
+    //      The one barrier per K-tile sits INSIDE k-step 1, in front of its first re-read (MFMA 15 of 40): k-step 1's own fragments were read during
+    //      k-step 0, whose last reads complete under the 15 MFMAs in front of the barrier (waiting for them at the k-step boundary cost 460 cycles per
+    //      K-tile when first tried: 3 330 against 2 860 of the 32x32x16 loop); behind it k-step 1 re-reads from stage buf^1 and stages tile t+2 into buf.
+    constexpr int HJ = NJB / 2, HM = MIB * HJ, NM = 2 * HM;   // weight fragments per half, MFMAs per half / per k-step
+    static_assert(NJB % 2 == 0, "two halves of the weight fragments");
+    f16x8 a4[MIB], w1[NJB];
+    unsigned abase[MIB], wbase[NJB];   // byte offsets of this lane's fragments in a stage (k-step 0); k-step 1 = ^ 64 (chunk bit 2 survives the XOR swizzle)
+#pragma unroll
+    for (int i = 0; i < MIB; ++i) abase[i] = (unsigned)lds_off(wm * WROWS + i * 16 + l16, kg);
+#pragma unroll
+    for (int j = 0; j < NJB; ++j) wbase[j] = (unsigned)(A_BYTES + lds_off(wn * (NJ * 32) + j * 16 + l16, kg));
+    auto rd = [&](unsigned base, unsigned kxor, unsigned stage_off) { return *reinterpret_cast<const f16x8*>(smem + ((base ^ kxor) + stage_off)); };
+#pragma unroll
+    for (int i = 0; i < MIB; ++i) a4[i] = rd(abase[i], 0u, 0u);
+#pragma unroll
+    for (int j = 0; j < NJB; ++j) w1[j] = rd(wbase[j], 0u, 0u);
+    constexpr int Q0 = NP > 5 ? 5 : NP;   // pieces of tile t+2 issued in k-step 1 (behind the barrier); the rest in k-step 0 of the next iteration
+    // MFMAs [LO, HI) of a k-step with what rides behind them: the fragment re-reads, and one LDS-DMA piece behind every second MFMA from PM0 on
+    auto kpart = [&](auto LOC, auto HIC, unsigned kxor, unsigned stage_off, auto&& piece, auto NPIECES, auto PM0C) {
+      constexpr int LO = decltype(LOC)::value, HI = decltype(HIC)::value, npieces = decltype(NPIECES)::value, PM0 = decltype(PM0C)::value;
+      static_for<HI - LO>([&](auto MC) {
+        constexpr int m = LO + decltype(MC)::value;
+        constexpr bool hb = m >= HM;
+        constexpr int mm = hb ? m - HM : m;
+        constexpr int i = mm / HJ, j = (hb ? HJ : 0) + mm % HJ;
+        acc[i][j] = FMX_MFMA_16x16x32(w1[j], a4[i], acc[i][j]);
+        if constexpr (i == MIB - 1) w1[j] = rd(wbase[j], kxor, stage_off);
+        if constexpr (hb && mm % HJ == HJ - 1) a4[i] = rd(abase[i], kxor, stage_off);
+        if constexpr (m >= PM0 && ((m - PM0) & 1) == 0 && (m - PM0) / 2 < npieces) piece(IC<(m - PM0) / 2>{});
+      });
+      static_for<HI - LO>([&](auto MC) {
+        constexpr int m = LO + decltype(MC)::value;
+        constexpr bool hb = m >= HM;
+        constexpr int mm = hb ? m - HM : m;
+        constexpr int i = mm / HJ;
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if constexpr (i == MIB - 1 && hb && mm % HJ == HJ - 1) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        else if constexpr (i == MIB - 1 || (hb && mm % HJ == HJ - 1)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if constexpr (m >= PM0 && ((m - PM0) & 1) == 0 && (m - PM0) / 2 < npieces) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      });
+    };
+    constexpr int MB = HM - HJ;   // the first MFMA of a k-step with a re-read behind it: the barrier of the K-tile sits in front of it in k-step 1
+    static_assert(MB + 1 + 2 * Q0 <= NM, "the pieces of tile t+2 follow the barrier inside k-step 1");
+    for (int t = 0; t < p.kt; ++t) {
+      const int buf = t & 1;
+      Cursor c2 = c1;
+      advance(c2);  // tile t+2
+      // (opaque per iteration: loop-invariant otherwise, and hoisted the 2 x 14 fragment addresses of both k-steps would ride through the loop)
+      unsigned k64 = 64u, k0 = 0u;
+      asm volatile("" : "+s"(k64), "+s"(k0));
+      const unsigned off_cur = (unsigned)buf * STAGE_BYTES, off_nxt = (unsigned)(buf ^ 1) * STAGE_BYTES;
+      auto piece1 = [&](auto IDX) { issue_piece(IC<Q0 + decltype(IDX)::value>{}, c1, buf ^ 1); };
+      auto piece2 = [&](auto IDX) { issue_piece(IC<decltype(IDX)::value>{}, c2, buf); };
+      // k-step 0: re-reads k-step 1's fragments from this tile's stage; the rest of tile t+1's pieces
+      __builtin_amdgcn_sched_barrier(0);
+      kpart(IC<0>{}, IC<NM>{}, k64, off_cur, piece1, IC<NP - Q0>{}, IC<1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      // k-step 1, MFMAs in front of its first re-read: nothing rides behind them -- the reads k-step 0 issued last complete under them
+      kpart(IC<0>{}, IC<MB>{}, k0, off_nxt, piece2, IC<0>{}, IC<0>{});
+      __builtin_amdgcn_sched_barrier(0);
+      // every wave: its reads of stage `buf` are complete, its pieces of tile t+1 have landed -> the K-tile's one barrier; behind it stage buf^1
+      // is readable and stage buf may be overwritten with tile t+2
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      kpart(IC<MB>{}, IC<NM>{}, k0, off_nxt, piece2, IC<Q0>{}, IC<MB + 1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      c1 = c2;
+    }
+  } else
   for (int t = 0; t < p.kt; ++t) {
     const int buf = t & 1;
     Cursor c2 = c1;
@@ -536,36 +632,45 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
 #pragma unroll
     for (int r = 0; r < (STATS ? 16 : 1); ++r) st[r] = 0.f;
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
+    for (int i = 0; i < MIB; ++i) {
+      if constexpr (MF == 32) {
 #pragma unroll
-      for (int j = 0; j < NJ; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-          const int chunk = j * 8 + q4 * 2 + hi;
-          const f32x16& a = acc[i][j];
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const int chunk = j * 8 + q4 * 2 + hi;
+            const accv& a = acc[i][j];
 #ifdef FMX_ABLATE_EPI_LDS   // timing-only build (WRONG results): half of the transpose's LDS writes -- what do they cost?
-          if (q4 & 1) continue;
+            if (q4 & 1) continue;
 #endif
-          *reinterpret_cast<f32x4*>(my + li * RB + ((chunk ^ (li & 7)) << 4)) = f32x4{a[q4 * 4], a[q4 * 4 + 1], a[q4 * 4 + 2], a[q4 * 4 + 3]};
+            *reinterpret_cast<f32x4*>(my + li * RB + ((chunk ^ (li & 7)) << 4)) = f32x4{a[q4 * 4], a[q4 * 4 + 1], a[q4 * 4 + 2], a[q4 * 4 + 3]};
+          }
+      } else {   // 16 x 16 blocks: lane = pixel l16, its 4 registers = channels j*16 + kg*4 + [0, 4) -> one 16-byte chunk per block
+#pragma unroll
+        for (int j = 0; j < NJB; ++j) {
+          const int chunk = j * 4 + kg;
+          const accv& a = acc[i][j];
+          *reinterpret_cast<f32x4*>(my + l16 * RB + ((chunk ^ (l16 & 7)) << 4)) = f32x4{a[0], a[1], a[2], a[3]};
         }
+      }
       // same wave wrote and reads: LDS operations of one wave execute in order, no barrier needed
-      const int mbase = m0 + wm * (MI * 32) + i * 32;
+      const int mbase = m0 + wm * WROWS + i * BR;
 #define FMX_EPI_ARGS my, lane, mbase, p.M, nbc, nok, ep.per_img, ep.alpha, (float)ep.mgt, ep.bias + nbc * ep.mb, ep.rowvec + nbc * ep.mrv, ep.ld_rv, \
                      ep.gate + nbc * ep.mgt, ep.ld_gt, ep.res + nbc * ep.mres, ep.ld_res, ep.out + nbc, ep.ld_out, st
       if (STATS) {  // (the host refuses GELU-tanh / gate together with statistics)
-        if (ep.mrv) epi_rows<RB, LPR, 32, 7, false, 3, true>(FMX_EPI_ARGS);
-        else if (ep.mres) epi_rows<RB, LPR, 32, 7, false, 1, true>(FMX_EPI_ARGS);
-        else epi_rows<RB, LPR, 32, 7, false, 2, true>(FMX_EPI_ARGS);
+        if (ep.mrv) epi_rows<RB, LPR, BR, 7, false, 3, true>(FMX_EPI_ARGS);
+        else if (ep.mres) epi_rows<RB, LPR, BR, 7, false, 1, true>(FMX_EPI_ARGS);
+        else epi_rows<RB, LPR, BR, 7, false, 2, true>(FMX_EPI_ARGS);
       } else if (LN == 1) {   // producer: bias + residual (the host sends nothing else here)
-        epi_rows<RB, LPR, 32, 7, false, 1, false, 1>(FMX_EPI_ARGS, p.row_stats + (long)(tn * G::WN + wn) * 2, G::WN * p.tiles_n * 2);
+        epi_rows<RB, LPR, BR, 7, false, 1, false, 1>(FMX_EPI_ARGS, p.row_stats + (long)(tn * G::WN + wn) * 2, G::WN * p.tiles_n * 2);
       } else if (LN == 2) {   // consumer: bias only
-        epi_rows<RB, LPR, 32, 7, false, 2, false, 2>(FMX_EPI_ARGS, nullptr, 0, lnm, lnr, i * 32, p.ln_colsum + nbc);
+        epi_rows<RB, LPR, BR, 7, false, 2, false, 2>(FMX_EPI_ARGS, nullptr, 0, lnm, lnr, i * BR, p.ln_colsum + nbc);
       } else if (LN == 3) {   // consumer, operand-swapped: the host sends no bias / residual here
-        epi_rows<RB, LPR, 32, 7, false, 2, false, 3>(FMX_EPI_ARGS, nullptr, 0, 0.f, 0.f, 0, p.ln_col_ab + (long)nbc * 2, p.ln_row_cb);
-      } else if (ep.gelu_tanh) epi_rows<RB, LPR, 32, 7, true, 0>(FMX_EPI_ARGS);       // uniform branches
-      else if (ep.mrv | ep.mgt) epi_rows<RB, LPR, 32, 7, false, 0>(FMX_EPI_ARGS);
-      else if (ep.mres) epi_rows<RB, LPR, 32, 7, false, 1>(FMX_EPI_ARGS);
-      else epi_rows<RB, LPR, 32, 7, false, 2>(FMX_EPI_ARGS);
+        epi_rows<RB, LPR, BR, 7, false, 2, false, 3>(FMX_EPI_ARGS, nullptr, 0, 0.f, 0.f, 0, p.ln_col_ab + (long)nbc * 2, p.ln_row_cb);
+      } else if (ep.gelu_tanh) epi_rows<RB, LPR, BR, 7, true, 0>(FMX_EPI_ARGS);       // uniform branches
+      else if (ep.mrv | ep.mgt) epi_rows<RB, LPR, BR, 7, false, 0>(FMX_EPI_ARGS);
+      else if (ep.mres) epi_rows<RB, LPR, BR, 7, false, 1>(FMX_EPI_ARGS);
+      else epi_rows<RB, LPR, BR, 7, false, 2>(FMX_EPI_ARGS);
 #undef FMX_EPI_ARGS
     }
     if (STATS) {
@@ -617,28 +722,32 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
     constexpr int RB = NJ * 64;
     constexpr int LPR = NJ * 2;
     constexpr int ROWS = MI * 32;
-    int mcs[MI], imgs[MI];
+    const int lrow = MF == 32 ? li : l16;   // this lane's pixel row inside a block row
+    int mcs[MIB], imgs[MIB];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int mrow = m0 + wm * (MI * 32) + i * 32 + li;
+    for (int i = 0; i < MIB; ++i) {
+      const int mrow = m0 + wm * WROWS + i * BR + lrow;
       mcs[i] = mrow < p.M ? mrow : p.M - 1;
       imgs[i] = mcs[i] / ep.per_img;
     }
     // the per-image row vector (a ResBlock's embedding add) is absent from every GEGLU call of the UNet / Flux executors: its loads
     // (two 8-byte loads and their wait per 4 outputs, from the zero page when absent) are compiled out of the common instantiation
-    float gm[MI], gr[MI];   // LN consumer: mean / rstd of this lane's pixel row in each block row
+    float gm[MIB], gr[MIB];   // LN consumer: mean / rstd of this lane's pixel row in each block row
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      gm[i] = LN == 2 ? __shfl(lnm, i * 32 + li) : 0.f;
-      gr[i] = LN == 2 ? __shfl(lnr, i * 32 + li) : 1.f;
+    for (int i = 0; i < MIB; ++i) {
+      gm[i] = LN == 2 ? __shfl(lnm, i * BR + lrow) : 0.f;
+      gr[i] = LN == 2 ? __shfl(lnr, i * BR + lrow) : 1.f;
     }
+    // MF 32: registers q4 = 0, 1 of block j are values of columns q4*8 + hi*4 + [0, 4), registers q4 = 2, 3 their gates.
+    // MF 16: block 2 jj holds the 16 values of weight-row group jj, block 2 jj + 1 their gates (same lane: columns kg*4 + [0, 4)); the loop
+    //        below runs q4 over ONE value run per (jj, lane): q4 = kg.
     auto stage_geglu = [&](auto HAS_RV) {
       constexpr bool RV = decltype(HAS_RV)::value != 0;
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int q4 = 0; q4 < 2; ++q4) {
-          const int nb = n0 + wn * (NJ * 32) + j * 32 + q4 * 8 + hi * 4;
+        for (int q4 = 0; q4 < (MF == 32 ? 2 : 1); ++q4) {
+          const int nb = n0 + wn * (NJ * 32) + j * 32 + (MF == 32 ? q4 * 8 + hi * 4 : kg * 4);
           const int nbc = nb < ep.nout ? nb : 0;
           const f16x4 bv = ep.bias4(nbc), bg = ep.bias4(nbc + 16);  // few live registers: the 160-accumulator tile has none to spare
           f32x4 sv = f32x4{0.f, 0.f, 0.f, 0.f}, sg = sv;
@@ -650,7 +759,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) { bvf[r] = (float)bv[r]; bgf[r] = (float)bg[r]; }
 #pragma unroll
-          for (int i = 0; i < MI; ++i) {
+          for (int i = 0; i < MIB; ++i) {
             f16x4 rvv, rvg;
             if (RV) { rvv = ep.rv4(imgs[i], nbc); rvg = ep.rv4(imgs[i], nbc + 16); }
             // (acc alpha - mean colsum) rstd + bias  =  acc (alpha rstd) + (bias - mean rstd colsum): one FMA per element and one per column
@@ -662,13 +771,13 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
               float cv = bvf[r], cg = bgf[r];
               if (LN == 2) { cv = fmaf(-mr, sv[r], cv); cg = fmaf(-mr, sg[r], cg); }
               if (RV) { cv += (float)rvv[r]; cg += (float)rvg[r]; }
-              const float val = fmaf(acc[i][j][q4 * 4 + r], sc, cv);
-              const float gate = fmaf(acc[i][j][8 + q4 * 4 + r], sc, cg);
+              const float val = fmaf(MF == 32 ? acc[i][j][(q4 * 4 + r) % (MF == 32 ? 16 : 4)] : acc[i][(2 * j) % NJB][r], sc, cv);
+              const float gate = fmaf(MF == 32 ? acc[i][j][(8 + q4 * 4 + r) % (MF == 32 ? 16 : 4)] : acc[i][(2 * j + 1) % NJB][r], sc, cg);
               // (a transcendental-free erf -- odd polynomial of degree 19, 12 packable operations -- was measured in round 3: 117.1 vs 117.1 ms
               //  per step, profiles/r08j; the epilogue is not bound by v_rcp / v_exp issue, and the exact form is 30x more accurate)
               o[r] = val * gelu_erf_f(gate);
             }
-            const int row = i * 32 + li, chunk = j * 4 + q4 * 2 + hi;
+            const int row = i * BR + lrow, chunk = j * 4 + (MF == 32 ? q4 * 2 + hi : kg);
             *reinterpret_cast<f32x4*>(my + row * RB + ((chunk ^ (row & 3)) << 4)) = o;  // NJ*4 chunks per row: XOR of the low 2 bits stays inside
           }
         }
@@ -679,9 +788,9 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
     const bool nok = col < ep.ncols;
     const int colc = nok ? col : 0;
     // bias / rowvec / act were applied above: the row pass only adds the residual (alpha = 1, every other operand -> zero page)
-    if (ep.mres) epi_rows<RB, LPR, ROWS, 3, false, 1>(my, lane, m0 + wm * (MI * 32), p.M, colc, nok, ep.per_img, 1.0f, 0.0f, p.zp, p.zp, 0L, p.zp, 0L,
+    if (ep.mres) epi_rows<RB, LPR, ROWS, 3, false, 1>(my, lane, m0 + wm * WROWS, p.M, colc, nok, ep.per_img, 1.0f, 0.0f, p.zp, p.zp, 0L, p.zp, 0L,
                                                        ep.res + colc, ep.ld_res, ep.out + colc, ep.ld_out);
-    else epi_rows<RB, LPR, ROWS, 3, false, 2>(my, lane, m0 + wm * (MI * 32), p.M, colc, nok, ep.per_img, 1.0f, 0.0f, p.zp, p.zp, 0L, p.zp, 0L, p.zp, 0L,
+    else epi_rows<RB, LPR, ROWS, 3, false, 2>(my, lane, m0 + wm * WROWS, p.M, colc, nok, ep.per_img, 1.0f, 0.0f, p.zp, p.zp, 0L, p.zp, 0L, p.zp, 0L,
                                                ep.out + colc, ep.ld_out);
   }
 #ifdef FMX_ABLATE
@@ -718,19 +827,36 @@ static int persistent_grid(int tiles) {
   return tiles < cus ? tiles : cus;
 }
 
-template <int LN>
+template <int LN, int MF = 32>
 int launch_ln(const GemmParams& p, hipStream_t st) {
   using G = Geo<256, 320>;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<false, 256, 320, false, 1, LN>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<false, 256, 320, false, 1, LN, MF>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     attr_set = true;
   }
   GemmParams q = p;
   q.tiles_m = (p.M + 255) / 256;
   q.tiles_n = (p.nout + 319) / 320;
-  hipLaunchKernelGGL((gemm256p_kernel<false, 256, 320, false, 1, LN>), dim3(persistent_grid(q.tiles_m * q.tiles_n)), dim3(512), G::LDS_BYTES, st, q);
+  hipLaunchKernelGGL((gemm256p_kernel<false, 256, 320, false, 1, LN, MF>), dim3(persistent_grid(q.tiles_m * q.tiles_n)), dim3(512), G::LDS_BYTES, st, q);
   FMX_LAUNCH_CHECK("fmx_gemm_conv_f16 (256x320, LayerNorm folded)");
+  return FMX_OK;
+}
+
+// plain / statistics-emitting LINEAR GEMM on the 256 x 320 tile with the 16x16x32 K loop
+template <bool STATS>
+int launch_lin16(const GemmParams& p, hipStream_t st) {
+  using G = Geo<256, 320>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<false, 256, 320, STATS, 1, 0, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    attr_set = true;
+  }
+  GemmParams q = p;
+  q.tiles_m = (p.M + 255) / 256;
+  q.tiles_n = (p.nout + 319) / 320;
+  hipLaunchKernelGGL((gemm256p_kernel<false, 256, 320, STATS, 1, 0, 16>), dim3(persistent_grid(q.tiles_m * q.tiles_n)), dim3(512), G::LDS_BYTES, st, q);
+  FMX_LAUNCH_CHECK("fmx_gemm_conv_f16 (256x320, 16x16x32 K loop)");
   return FMX_OK;
 }
 
@@ -772,6 +898,19 @@ int launch_bn(const GemmParams& p, bool conv, hipStream_t st) {
 }  // namespace
 
 int fmx_launch_gemm256p(const GemmParams& p, bool conv, int bm, int bn, hipStream_t st) {
+  static int mf = 0;
+  if (!mf) {
+    // A/B knob: 32 = v_mfma_f32_32x32x16 K loops everywhere (rounds 1-2); 16 (default) = v_mfma_f32_16x16x32 for the LINEAR GEMMs of the 256 x 320 tile.
+    // Same box, SDXL 1024^2 batch 8 (profiles/r08r): 110.76 -> 107.27 ms per step, chip clock of the timed steps 1.91 -> 1.99 GHz.
+    const char* e = getenv("FMX_GEMM_MFMA");
+    mf = (e && atoi(e) == 32) ? 32 : 16;
+  }
+  if (mf == 16) {
+    if (p.row_stats) return launch_ln<1, 16>(p, st);
+    if (p.ln_partial) return launch_ln<2, 16>(p, st);
+    // (linear only: the implicit-GEMM convolutions carry 13 more address registers through the K loop and spill inside it in this form)
+    if (!conv && !p.ln_col_ab && bm == 256 && bn == 320) return p.stats ? launch_lin16<true>(p, st) : launch_lin16<false>(p, st);
+  }
   if (p.row_stats) return launch_ln<1>(p, st);
   if (p.ln_partial) return launch_ln<2>(p, st);
   if (p.ln_col_ab) return launch_ln_swapped(p, st);

@@ -72,7 +72,7 @@ def bench_linear_res(m, n, k, tile=0, copies=8, residual=True, inplace=True):
     t = timeit_graph([(lambda w=w, r=r, o=o: ops.conv_gemm(x, w, n, bias=b, residual=r, out=o, ld_out=n, force_tile=tile)) for w, r, o in zip(ws, rs, outs)])
     print(json.dumps({"op": "linear + residual (in graph, cold)" if residual else "linear (in graph, cold, distinct outputs)", "m": m, "n": n, "k": k,
                       "tile": tile, "inplace": bool(inplace and residual), "us": round(t * 1e6, 1), "tflops": round(2 * m * n * k / t / 1e12, 1),
-                      "lib": os.environ.get("FMX_LIB", "default")}), flush=True)
+                      "lib": os.environ.get("FMX_LIB", "default"), "mfma": os.environ.get("FMX_GEMM_MFMA", "32")}), flush=True)
 
 
 def _graph_of(stream, fns):

@@ -20,6 +20,7 @@ for w in "$@"; do
     atests2) FMX_ATTN_SHORT=2 timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q --tb=short -k "attention" 2>&1 | tail -40 > $O/atests2.log; tail -15 $O/atests2.log;;
     ab_persist) for E in "FMX_GEMM_PERSIST=0" "FMX_GEMM_PERSIST=1" "FMX_GEMM_PERSIST=0" "FMX_GEMM_PERSIST=1"; do env $E timeout 600 python bench.py --no-cpu-baseline --no-vae --steps 10 2>> $O/ab.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'env':'$E','ms_per_step':d['ms_per_step'],'gemm_tflops':d['roofline']['achieved'],'gemm_ms':d['roofline']['kernel_time_per_forward_ms'],'attn':d['roofline_attention']['achieved'],'xattn_ms':d['roofline_attention_short_keys']['kernel_time_per_forward_ms'],'clocks':d.get('clocks_during_timed_steps')}))" >> $O/ab.jsonl; done; cat $O/ab.jsonl; tail -3 $O/ab.err;;
     clock) for R in 0 1; do FMX_LIB=tools/_build/libfmx_ablate.so FMX_TILE=7 FMX_CLOCK_RESIDUAL=$R timeout 300 python tools/clock_gemm.py >> $O/clock.txt 2>> $O/clock.err; done; cat $O/clock.txt; tail -2 $O/clock.err;;
+    clock16) for MFV in 16 32 16 32; do echo "== FMX_GEMM_MFMA=$MFV" >> $O/clock16.txt; FMX_GEMM_MFMA=$MFV FMX_LIB=tools/_build/libfmx_ablate.so FMX_TILE=7 timeout 300 python tools/clock_gemm.py >> $O/clock16.txt 2>> $O/clock16.err; done; cat $O/clock16.txt; tail -2 $O/clock16.err;;
     ab_lib) for L in "" $ABLIB "" $ABLIB; do FMX_LIB=$L timeout 600 python bench.py --no-cpu-baseline --no-vae --steps 10 2>> $O/ab.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'lib':'$L','ms_per_step':d['ms_per_step'],'gemm_tflops':d['roofline']['achieved'],'gemm_ms':d['roofline']['kernel_time_per_forward_ms'],'attn':d['roofline_attention']['achieved'],'xattn_ms':d['roofline_attention_short_keys']['kernel_time_per_forward_ms'],'sclk':(d.get('clocks_during_timed_steps') or {}).get('sclk_mhz')}))" >> $O/ab.jsonl; done; cat $O/ab.jsonl; tail -3 $O/ab.err;;
     ab_env) for E in $ABENV0 $ABENV1 $ABENV0 $ABENV1; do env ${E//,/ } timeout 600 python bench.py --no-cpu-baseline --no-vae --steps 10 2>> $O/ab.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'env':'$E','ms_per_step':d['ms_per_step'],'gemm_tflops':d['roofline']['achieved'],'gemm_ms':d['roofline']['kernel_time_per_forward_ms'],'attn':d['roofline_attention']['achieved'],'xattn_ms':d['roofline_attention_short_keys']['kernel_time_per_forward_ms'],'sclk':(d.get('clocks_during_timed_steps') or {}).get('sclk_mhz')}))" >> $O/ab.jsonl; done; cat $O/ab.jsonl; tail -3 $O/ab.err;;
     e2etests) timeout 1200 python -m pytest tests/test_gpu_e2e.py tests/test_gpu_controlnet.py tests/test_gpu_hooks.py -m gpu -q --tb=short 2>&1 | tail -30 > $O/e2e.log; tail -12 $O/e2e.log;;
@@ -28,6 +29,8 @@ for w in "$@"; do
     ab_sd15) for E in "FMX_X=0" "FMX_GEMM_PERSIST=0" "FMX_ATTN_SHORT=0" "FMX_GN_BLOCK_KB=64" "FMX_X=0" "FMX_GEMM_PERSIST=0 FMX_ATTN_SHORT=0 FMX_GN_BLOCK_KB=64"; do env $E timeout 600 python bench.py --config ${ABCFG:-sd15-b4-eulera} --no-cpu-baseline --no-vae --steps 20 2>> $O/ab_sd15.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'env':'$E','cfg':d['config']['name'],'ms_per_step':d['ms_per_step'],'gemm_ms':d['roofline']['kernel_time_per_forward_ms'],'attn_ms':d['roofline_attention']['kernel_time_per_forward_ms'],'xattn_ms':(d.get('roofline_attention_short_keys') or {}).get('kernel_time_per_forward_ms'),'gn_ms':d['roofline_groupnorm']['kernel_time_per_forward_ms'],'sclk':(d.get('clocks_during_timed_steps') or {}).get('sclk_mhz',{}).get('mean')}))" >> $O/ab_sd15.jsonl; done; cat $O/ab_sd15.jsonl; tail -3 $O/ab_sd15.err;;
     attn512) for E in FMX_ATTN512_SLICES=4 FMX_ATTN512_SLICES=2 FMX_ATTN512_SLICES=4 FMX_ATTN512_SLICES=2; do env $E timeout 300 python tools/bench_kernels.py attn512 >> $O/attn512.jsonl 2>> $O/attn512.err; done; cat $O/attn512.jsonl; tail -2 $O/attn512.err;;
     vtests) timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_vae_bf16.py tests/test_gpu_boundary.py -m gpu -q --tb=short -k "512 or vae or single_head or spatial or decode" 2>&1 | tail -15 > $O/vtests.log; tail -8 $O/vtests.log;;
+    ktests16) FMX_GEMM_MFMA=16 timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_boundary.py -m gpu -q --tb=short 2>&1 | tail -40 > $O/ktests16.log; tail -15 $O/ktests16.log;;
+    epi16) for E in FMX_GEMM_MFMA=16 FMX_GEMM_MFMA=32 FMX_GEMM_MFMA=16 FMX_GEMM_MFMA=32; do env $E timeout 300 python tools/bench_kernels.py epi >> $O/epi16.jsonl 2>> $O/epi16.err; done; tail -2 $O/epi16.err;;
     dual) timeout 600 python tools/bench_kernels.py dual > $O/dual.jsonl 2> $O/dual.err; cat $O/dual.jsonl; tail -3 $O/dual.err;;
     epi) for L in $EPILIBS; do FMX_LIB=$L timeout 300 python tools/bench_kernels.py epi >> $O/epi.jsonl 2>> $O/epi.err; done; cat $O/epi.jsonl;;
     testsx) FMX_PARITY_LOG=$O/parity.jsonl timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -40 > $O/pytest_gpu.log; tail -8 $O/pytest_gpu.log;;
