@@ -497,28 +497,29 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
     constexpr int HJ = NJB / 2, HM = MIB * HJ, NM = 2 * HM;   // weight fragments per half, MFMAs per half / per k-step
     static_assert(NJB % 2 == 0, "two halves of the weight fragments");
     f16x8 a4[MIB], w1[NJB];
-    unsigned abase[MIB], wbase[NJB];   // byte offsets of this lane's fragments in a stage (k-step 0); k-step 1 = ^ 64 (chunk bit 2 survives the XOR swizzle)
+    // byte offset of this lane's fragment 0 of either operand in a stage, k-step 0.  Fragment i is 16 rows further: + i * 2048 exactly (the XOR swizzle
+    // keys on (row >> 1) & 7, which 16 rows do not change) -- an immediate of the ds_read; k-step 1 = ^ 64 (chunk bit 2 survives the swizzle).
+    static_assert((WROWS % 16) == 0 && ((NJ * 32) % 16) == 0, "fragment rows in steps of 16");
+    const unsigned abase = (unsigned)lds_off(wm * WROWS + l16, kg);
+    const unsigned wbase = (unsigned)(A_BYTES + lds_off(wn * (NJ * 32) + l16, kg));
+    auto rd = [&](unsigned addr, int frag) { return *reinterpret_cast<const f16x8*>(smem + addr + frag * 2048); };
 #pragma unroll
-    for (int i = 0; i < MIB; ++i) abase[i] = (unsigned)lds_off(wm * WROWS + i * 16 + l16, kg);
+    for (int i = 0; i < MIB; ++i) a4[i] = rd(abase, i);
 #pragma unroll
-    for (int j = 0; j < NJB; ++j) wbase[j] = (unsigned)(A_BYTES + lds_off(wn * (NJ * 32) + j * 16 + l16, kg));
-    auto rd = [&](unsigned base, unsigned kxor, unsigned stage_off) { return *reinterpret_cast<const f16x8*>(smem + ((base ^ kxor) + stage_off)); };
-#pragma unroll
-    for (int i = 0; i < MIB; ++i) a4[i] = rd(abase[i], 0u, 0u);
-#pragma unroll
-    for (int j = 0; j < NJB; ++j) w1[j] = rd(wbase[j], 0u, 0u);
+    for (int j = 0; j < NJB; ++j) w1[j] = rd(wbase, j);
     constexpr int Q0 = NP > 5 ? 5 : NP;   // pieces of tile t+2 issued in k-step 1 (behind the barrier); the rest in k-step 0 of the next iteration
     // MFMAs [LO, HI) of a k-step with what rides behind them: the fragment re-reads, and one LDS-DMA piece behind every second MFMA from PM0 on
     auto kpart = [&](auto LOC, auto HIC, unsigned kxor, unsigned stage_off, auto&& piece, auto NPIECES, auto PM0C) {
       constexpr int LO = decltype(LOC)::value, HI = decltype(HIC)::value, npieces = decltype(NPIECES)::value, PM0 = decltype(PM0C)::value;
+      const unsigned aaddr = (abase ^ kxor) + stage_off, waddr = (wbase ^ kxor) + stage_off;   // the only per-k-step address arithmetic
       static_for<HI - LO>([&](auto MC) {
         constexpr int m = LO + decltype(MC)::value;
         constexpr bool hb = m >= HM;
         constexpr int mm = hb ? m - HM : m;
         constexpr int i = mm / HJ, j = (hb ? HJ : 0) + mm % HJ;
         acc[i][j] = FMX_MFMA_16x16x32(w1[j], a4[i], acc[i][j]);
-        if constexpr (i == MIB - 1) w1[j] = rd(wbase[j], kxor, stage_off);
-        if constexpr (hb && mm % HJ == HJ - 1) a4[i] = rd(abase[i], kxor, stage_off);
+        if constexpr (i == MIB - 1) w1[j] = rd(waddr, j);
+        if constexpr (hb && mm % HJ == HJ - 1) a4[i] = rd(aaddr, i);
         if constexpr (m >= PM0 && ((m - PM0) & 1) == 0 && (m - PM0) / 2 < npieces) piece(IC<(m - PM0) / 2>{});
       });
       static_for<HI - LO>([&](auto MC) {
@@ -538,7 +539,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
       const int buf = t & 1;
       Cursor c2 = c1;
       advance(c2);  // tile t+2
-      // (opaque per iteration: loop-invariant otherwise, and hoisted the 2 x 14 fragment addresses of both k-steps would ride through the loop)
+      // (opaque per iteration: loop-invariant otherwise, and the fragment addresses of both k-steps and stages would ride through the loop)
       unsigned k64 = 64u, k0 = 0u;
       asm volatile("" : "+s"(k64), "+s"(k0));
       const unsigned off_cur = (unsigned)buf * STAGE_BYTES, off_nxt = (unsigned)(buf ^ 1) * STAGE_BYTES;
@@ -843,54 +844,38 @@ int launch_ln(const GemmParams& p, hipStream_t st) {
   return FMX_OK;
 }
 
-// plain / statistics-emitting LINEAR GEMM on the 256 x 320 tile with the 16x16x32 K loop
-template <bool STATS>
-int launch_lin16(const GemmParams& p, hipStream_t st) {
-  using G = Geo<256, 320>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<false, 256, 320, STATS, 1, 0, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-    attr_set = true;
-  }
-  GemmParams q = p;
-  q.tiles_m = (p.M + 255) / 256;
-  q.tiles_n = (p.nout + 319) / 320;
-  hipLaunchKernelGGL((gemm256p_kernel<false, 256, 320, STATS, 1, 0, 16>), dim3(persistent_grid(q.tiles_m * q.tiles_n)), dim3(512), G::LDS_BYTES, st, q);
-  FMX_LAUNCH_CHECK("fmx_gemm_conv_f16 (256x320, 16x16x32 K loop)");
-  return FMX_OK;
-}
-
 // LayerNorm folded into the operand-swapped V^T GEMM: 320 x 256 tile
+template <int MF>
 int launch_ln_swapped(const GemmParams& p, hipStream_t st) {
   using G = Geo<320, 256>;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<false, 320, 256, false, 1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<false, 320, 256, false, 1, 3, MF>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     attr_set = true;
   }
   GemmParams q = p;
   q.tiles_m = (p.M + 319) / 320;
   q.tiles_n = (p.nout + 255) / 256;
-  hipLaunchKernelGGL((gemm256p_kernel<false, 320, 256, false, 1, 3>), dim3(persistent_grid(q.tiles_m * q.tiles_n)), dim3(512), G::LDS_BYTES, st, q);
+  hipLaunchKernelGGL((gemm256p_kernel<false, 320, 256, false, 1, 3, MF>), dim3(persistent_grid(q.tiles_m * q.tiles_n)), dim3(512), G::LDS_BYTES, st, q);
   FMX_LAUNCH_CHECK("fmx_gemm_conv_f16 (320x256, LayerNorm folded, operand-swapped)");
   return FMX_OK;
 }
 
-template <int BM, int BN, bool STATS, int SC = 0, int SL = 1>
+template <int BM, int BN, bool STATS, int SC = 0, int SL = 1, int MF = 32>
 int launch_bn(const GemmParams& p, bool conv, hipStream_t st) {
   using G = Geo<BM, BN>;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<true, BM, BN, STATS, SC>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<false, BM, BN, STATS, SL>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<true, BM, BN, STATS, SC, 0, MF>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<false, BM, BN, STATS, SL, 0, MF>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     attr_set = true;
   }
   GemmParams q = p;
   q.tiles_m = (p.M + BM - 1) / BM;
   q.tiles_n = (p.nout + BN - 1) / BN;
   const int grid = persistent_grid(q.tiles_m * q.tiles_n);
-  if (conv) hipLaunchKernelGGL((gemm256p_kernel<true, BM, BN, STATS, SC>), dim3(grid), dim3(512), G::LDS_BYTES, st, q);
-  else hipLaunchKernelGGL((gemm256p_kernel<false, BM, BN, STATS, SL>), dim3(grid), dim3(512), G::LDS_BYTES, st, q);
+  if (conv) hipLaunchKernelGGL((gemm256p_kernel<true, BM, BN, STATS, SC, 0, MF>), dim3(grid), dim3(512), G::LDS_BYTES, st, q);
+  else hipLaunchKernelGGL((gemm256p_kernel<false, BM, BN, STATS, SL, 0, MF>), dim3(grid), dim3(512), G::LDS_BYTES, st, q);
   FMX_LAUNCH_CHECK("fmx_gemm_conv_f16 (256-row pipelined)");
   return FMX_OK;
 }
@@ -908,12 +893,13 @@ int fmx_launch_gemm256p(const GemmParams& p, bool conv, int bm, int bn, hipStrea
   if (mf == 16) {
     if (p.row_stats) return launch_ln<1, 16>(p, st);
     if (p.ln_partial) return launch_ln<2, 16>(p, st);
-    // (linear only: the implicit-GEMM convolutions carry 13 more address registers through the K loop and spill inside it in this form)
-    if (!conv && !p.ln_col_ab && bm == 256 && bn == 320) return p.stats ? launch_lin16<true>(p, st) : launch_lin16<false>(p, st);
+    if (p.ln_col_ab) return launch_ln_swapped<16>(p, st);
+    if (bm == 256 && bn == 320) return p.stats ? launch_bn<256, 320, true, 0, 1, 16>(p, conv, st) : launch_bn<256, 320, false, 0, 1, 16>(p, conv, st);
+    if (bm == 320 && !p.stats) return launch_bn<320, 256, false, 0, 1, 16>(p, conv, st);
   }
   if (p.row_stats) return launch_ln<1>(p, st);
   if (p.ln_partial) return launch_ln<2>(p, st);
-  if (p.ln_col_ab) return launch_ln_swapped(p, st);
+  if (p.ln_col_ab) return launch_ln_swapped<32>(p, st);
   static int sched = -1;
   if (sched < 0) {
     const char* e = getenv("FMX_GEMM_SCHED");   // A/B knob (tools/bench_kernels.py gemmsched): force one DMA issue schedule on the 256x320 tile
