@@ -896,6 +896,8 @@ int fmx_launch_gemm256p(const GemmParams& p, bool conv, int bm, int bn, hipStrea
     if (p.ln_col_ab) return launch_ln_swapped<16>(p, st);
     if (bm == 256 && bn == 320) return p.stats ? launch_bn<256, 320, true, 0, 1, 16>(p, conv, st) : launch_bn<256, 320, false, 0, 1, 16>(p, conv, st);
     if (bm == 320 && !p.stats) return launch_bn<320, 256, false, 0, 1, 16>(p, conv, st);
+    if (bm == 512) return p.stats ? launch_bn<512, 128, true, 0, 1, 16>(p, conv, st) : launch_bn<512, 128, false, 0, 1, 16>(p, conv, st);
+    if (bm == 256 && bn == 256) return p.stats ? launch_bn<256, 256, true, 0, 1, 16>(p, conv, st) : launch_bn<256, 256, false, 0, 1, 16>(p, conv, st);
   }
   if (p.row_stats) return launch_ln<1>(p, st);
   if (p.ln_partial) return launch_ln<2>(p, st);
