@@ -507,7 +507,14 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
     for (int i = 0; i < MIB; ++i) a4[i] = rd(abase, i);
 #pragma unroll
     for (int j = 0; j < NJB; ++j) w1[j] = rd(wbase, j);
-    constexpr int Q0 = NP > 5 ? 5 : NP;   // pieces of tile t+2 issued in k-step 1 (behind the barrier); the rest in k-step 0 of the next iteration
+#ifndef FMX_MF16_Q0
+#define FMX_MF16_Q0 5
+#endif
+#ifndef FMX_MF16_GAP
+#define FMX_MF16_GAP 4
+#endif
+    constexpr int Q0 = NP > FMX_MF16_Q0 ? FMX_MF16_Q0 : NP;   // pieces of tile t+2 issued in k-step 1 (behind the barrier); the rest in k-step 0 of the next iteration
+    constexpr int GAP = FMX_MF16_GAP;                          // one LDS-DMA piece behind every GAP-th MFMA
     // MFMAs [LO, HI) of a k-step with what rides behind them: the fragment re-reads, and one LDS-DMA piece behind every second MFMA from PM0 on
     auto kpart = [&](auto LOC, auto HIC, unsigned kxor, unsigned stage_off, auto&& piece, auto NPIECES, auto PM0C) {
       constexpr int LO = decltype(LOC)::value, HI = decltype(HIC)::value, npieces = decltype(NPIECES)::value, PM0 = decltype(PM0C)::value;
@@ -520,7 +527,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
         acc[i][j] = FMX_MFMA_16x16x32(w1[j], a4[i], acc[i][j]);
         if constexpr (i == MIB - 1) w1[j] = rd(waddr, j);
         if constexpr (hb && mm % HJ == HJ - 1) a4[i] = rd(aaddr, i);
-        if constexpr (m >= PM0 && ((m - PM0) & 1) == 0 && (m - PM0) / 2 < npieces) piece(IC<(m - PM0) / 2>{});
+        if constexpr (m >= PM0 && ((m - PM0) % GAP) == 0 && (m - PM0) / GAP < npieces) piece(IC<(m - PM0) / GAP>{});
       });
       static_for<HI - LO>([&](auto MC) {
         constexpr int m = LO + decltype(MC)::value;
@@ -530,11 +537,11 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         if constexpr (i == MIB - 1 && hb && mm % HJ == HJ - 1) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         else if constexpr (i == MIB - 1 || (hb && mm % HJ == HJ - 1)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        if constexpr (m >= PM0 && ((m - PM0) & 1) == 0 && (m - PM0) / 2 < npieces) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        if constexpr (m >= PM0 && ((m - PM0) % GAP) == 0 && (m - PM0) / GAP < npieces) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
       });
     };
     constexpr int MB = HM - HJ;   // the first MFMA of a k-step with a re-read behind it: the barrier of the K-tile sits in front of it in k-step 1
-    static_assert(MB + 1 + 2 * Q0 <= NM, "the pieces of tile t+2 follow the barrier inside k-step 1");
+    static_assert(MB + 1 + GAP * (Q0 - 1) < NM && 1 + GAP * (NP - Q0 - 1) < NM, "the pieces fit their k-step");
     for (int t = 0; t < p.kt; ++t) {
       const int buf = t & 1;
       Cursor c2 = c1;

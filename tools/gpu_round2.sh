@@ -32,6 +32,7 @@ for w in "$@"; do
     ktests16) FMX_GEMM_MFMA=16 timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_boundary.py -m gpu -q --tb=short 2>&1 | tail -40 > $O/ktests16.log; tail -15 $O/ktests16.log;;
     epi16) for E in FMX_GEMM_MFMA=16 FMX_GEMM_MFMA=32 FMX_GEMM_MFMA=16 FMX_GEMM_MFMA=32; do env $E timeout 300 python tools/bench_kernels.py epi >> $O/epi16.jsonl 2>> $O/epi16.err; done; tail -2 $O/epi16.err;;
     ab_vae) for E in FMX_GEMM_MFMA=32 FMX_GEMM_MFMA=16 FMX_GEMM_MFMA=32 FMX_GEMM_MFMA=16; do env $E timeout 600 python bench.py --no-cpu-baseline --no-roofline --steps 4 --warmup 1 2>> $O/ab_vae.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'env':'$E','ms_per_step':d['ms_per_step'],'vae_ms':d['vae_decode_ms_per_batch']}))" >> $O/ab_vae.jsonl; done; cat $O/ab_vae.jsonl; tail -2 $O/ab_vae.err;;
+    clocksweep) for L in $SWEEPLIBS; do echo "== $L" >> $O/clocksweep.txt; FMX_LIB=tools/_build/libfmx_$L.so FMX_TILE=7 timeout 300 python tools/clock_gemm.py 2>> $O/clocksweep.err | grep "TF/s" >> $O/clocksweep.txt; done; cat $O/clocksweep.txt; tail -2 $O/clocksweep.err;;
     dual) timeout 600 python tools/bench_kernels.py dual > $O/dual.jsonl 2> $O/dual.err; cat $O/dual.jsonl; tail -3 $O/dual.err;;
     epi) for L in $EPILIBS; do FMX_LIB=$L timeout 300 python tools/bench_kernels.py epi >> $O/epi.jsonl 2>> $O/epi.err; done; cat $O/epi.jsonl;;
     testsx) FMX_PARITY_LOG=$O/parity.jsonl timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -40 > $O/pytest_gpu.log; tail -8 $O/pytest_gpu.log;;
