@@ -42,4 +42,5 @@ for (m, n, k, reps, act) in [(16384, 1280, 1280, 200, 0), (16384, 10240, 1280, 6
         print(f"   per workgroup: prologue {pro * 10} ns, K loop {rt * 10} ns, epilogue+store drain {epi * 10} ns; kernel wall {t * 1e6:.1f} us over {rounds} round(s) "
               f"-> {t * 1e6 / rounds:.1f} us per round vs {(pro + rt + epi) * 0.01:.1f} us inside the workgroup")
         print(f"{m}x{n}x{k} act={act} residual={int(RES)} {data}: {2*m*n*k/t/1e12:.0f} TF/s wall; K loop {cyc} cycles / {rt} ticks -> {cyc/kt:.0f} cycles per K-tile, "
-              f"clock {cyc/rt*0.1:.3f} GHz, MFMA-pipe busy {2048*kt/cyc*100:.0f}%", flush=True)
+              f"clock {cyc/rt*0.1:.3f} GHz, MFMA-pipe busy {8 * BN * kt / cyc * 100:.0f}% "
+              f"(ideal {8 * BN} cycles per K-tile: 256 x {BN} x 64 x 2 FLOP / 4096 per cycle and CU)", flush=True)
