@@ -130,6 +130,9 @@ typedef struct fmx_gemm_args {
    * Linear only, act NONE, no bias / residual / rowvec / gate, fp16 output, M % 320 == 0; always the 320x256 tile. */
   const void* ln_col_ab;
   const void* ln_row_cb;
+  /* optional output of an ln_partial (consumer) GEMM: the {rstd, -mean * rstd} pairs it derived for its input rows, [M][2] fp32 -- what
+   * fmx_layernorm_rowstats_finalize computes, for the operand-swapped GEMM that follows on the same rows (q|k projection -> V^T projection) */
+  void* ln_ab_out;
 } fmx_gemm_args;
 
 int fmx_gemm_conv_f16(const fmx_gemm_args* args /* host */, void* stream);

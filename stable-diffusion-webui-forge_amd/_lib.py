@@ -37,7 +37,7 @@ class GemmArgs(C.Structure):
         ("zero_page", C.c_void_p), ("gate", C.c_void_p), ("ld_gate", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("ln_partial", C.c_void_p), ("ln_parts", C.c_int32), ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float),
-        ("ln_col_ab", C.c_void_p), ("ln_row_cb", C.c_void_p),
+        ("ln_col_ab", C.c_void_p), ("ln_row_cb", C.c_void_p), ("ln_ab_out", C.c_void_p),
     ]
 
 

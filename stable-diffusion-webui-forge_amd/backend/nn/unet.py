@@ -369,9 +369,10 @@ class IntegratedUNet2DConditionModel:
         # self attention
         if n % 64 == 0 and rs1 is not None and rs1.parts and (b + ".attn1.v.ln") in self.w:
             wqk, csqk, bqk = self.w[b + ".attn1.qk.ln"]
-            qk = ops.conv_gemm(h, wqk, wqk.shape[0], bias=bqk, ln=(rs1, csqk, 1e-5))          # [M, 2*H*dp] = [Q | K] of LN(h)
+            ab = ops.empty((m_tok, 2), torch.float32)     # {rstd, -mean rstd} per token: the q|k GEMM derives them anyway and leaves them for V^T
+            qk = ops.conv_gemm(h, wqk, wqk.shape[0], bias=bqk, ln=(rs1, csqk, 1e-5), ln_ab_out=ab)   # [M, 2*H*dp] = [Q | K] of LN(h)
             wvf, vcb = self.w[b + ".attn1.v.ln"]
-            vt = ops.conv_gemm(wvf, h, m_tok, ln_swapped=(ops.ln_rowstats_finalize(rs1, h.shape[1], 1e-5), vcb))   # [H*dp, M] = V^T of LN(h)
+            vt = ops.conv_gemm(wvf, h, m_tok, ln_swapped=(ab, vcb))                                   # [H*dp, M] = V^T of LN(h)
             o = ops.attention(qk, qk[:, hd:], vt, batch=bu, heads=H, nq=n, nk=n, nk_pad=n, dpad=dp, scale=d ** -0.5,
                               q_bs=n * 2 * hd, q_rs=2 * hd, k_bs=n * 2 * hd, k_rs=2 * hd, vt_bs=n, vt_hs=dp * m_tok, vt_ds=m_tok)
         elif n % 64 == 0:

@@ -486,6 +486,7 @@ static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, i
   p.ln_colsum = nullptr;
   p.ln_eps = p.ln_inv_c = 0.f;
   p.ln_col_ab = p.ln_row_cb = nullptr;
+  p.ln_ab_out = nullptr;
   FMX_REQUIRE(fmx_aligned16(p.a0) && fmx_aligned16(p.wgt) && fmx_aligned16(p.zp) && (!p.a1 || fmx_aligned16(p.a1)), "gemm: operands must be 16-byte aligned");
   FMX_REQUIRE((p.s0 % 8) == 0 && (p.s1 % 8) == 0 && (p.ldw % 8) == 0, "gemm: strides must be multiples of 8 elements");
   FMX_REQUIRE((long)p.M * 1 > 0 && (long)a->n * a->oh * a->ow < (1L << 31), "gemm: M overflow");
@@ -605,6 +606,7 @@ static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, i
     p.ln_colsum = (const float*)a->ln_colsum;
     p.ln_eps = a->ln_eps;
     p.ln_inv_c = 1.0f / (float)p.c0;
+    p.ln_ab_out = (float*)a->ln_ab_out;
     sel = 6;
     best_s = 1;
   }

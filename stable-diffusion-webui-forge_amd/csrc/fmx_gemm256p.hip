@@ -628,6 +628,11 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
     }
     lnm = s1 * p.ln_inv_c;
     lnr = rsqrtf(fmaxf(s2 * p.ln_inv_c - lnm * lnm, 0.f) + p.ln_eps);
+    // the same pairs for the operand-swapped GEMM that follows on these rows (fmx.h ln_ab_out): one tile column writes them
+    if (p.ln_ab_out && tn == 0 && wn == 0) {
+      const int mrow = m0 + wm * WROWS + lane;
+      if (mrow < p.M) *reinterpret_cast<f32x2*>(p.ln_ab_out + (long)mrow * 2) = f32x2{lnr, -lnm * lnr};
+    }
   }
   if (!geglu) {
     constexpr int RB = NJ * 128;       // staged row: NJ*32 fp32

@@ -46,6 +46,7 @@ struct GemmParams {
   // the operand-swapped consumer (320 x 256 tile, fmx.h ln_col_ab / ln_row_cb): LayerNorm rows = output columns
   const float* ln_col_ab;    // [nout][2] {rstd, -mean rstd}
   const float* ln_row_cb;    // [M][2] {colsum, folded bias}
+  float* ln_ab_out;          // LN consumer: also write {rstd, -mean rstd} of its input rows (tiles of the first tile column), or null
 };
 
 // K-tile depth of every GEMM kernel: 64 halfs = one 128-byte LDS row.

@@ -172,7 +172,7 @@ _FUSED_STATS = os.environ.get("FMX_GN_FUSED_STATS", "1") != "0"
 
 def conv_gemm(x, wgt, nout, *, x1=None, n=None, h=None, w=None, kh=1, stride=1, pad=0, up=None, bias=None,
               rowvec=None, residual=None, act=ACT_NONE, alpha=1.0, out=None, ld_out=None, out_dtype=None,
-              ldw=0, force_tile=0, gate=None, out_hw=None, stats=False, stats_partial=None, row_stats=None, ln=None, ln_swapped=None):
+              ldw=0, force_tile=0, gate=None, out_hw=None, stats=False, stats_partial=None, row_stats=None, ln=None, ln_swapped=None, ln_ab_out=None):
     """OUT[M, ncols] = epilogue(A (*) W^T).  x: [N,H,W,C0] (or [M,C0] with kh == 1); x1: optional second source
     concatenated along channels; wgt: [nout, kh*kh*(C0+C1)]; up=(UH, UW): nearest-resize before the conv.
     stats=True: returns (out, GnStats of out) -- the GroupNorm statistics of the output come out of the GEMM's epilogue (256-row tiles)
@@ -231,6 +231,9 @@ def conv_gemm(x, wgt, nout, *, x1=None, n=None, h=None, w=None, kh=1, stride=1, 
         rs, colsum, eps = ln
         assert rs.parts >= 2 and colsum.dtype == torch.float32 and colsum.numel() == nout and rs.partial.dtype == torch.float32
         a.ln_partial, a.ln_parts, a.ln_colsum, a.ln_eps = _p(rs.partial), rs.parts, _p(colsum), float(eps)
+        if ln_ab_out is not None:   # the {rstd, -mean rstd} pairs of the input rows, for an operand-swapped fold on the same rows (fmx.h ln_ab_out)
+            assert ln_ab_out.dtype == torch.float32 and ln_ab_out.numel() == 2 * m
+            a.ln_ab_out = _p(ln_ab_out)
     if ln_swapped is not None:
         LN_FOLDED_LAUNCHES += 1
         col_ab, row_cb = ln_swapped

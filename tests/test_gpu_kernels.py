@@ -221,7 +221,9 @@ def test_layernorm_folded_into_the_operand_swapped_vt_projection(m, c, hd):
     assert e_new <= 2.0 * e_old + 1e-3, (e_new, e_old)
     wqk = rnd(2 * hd, c, scale=1 / math.sqrt(c), seed=116)
     wf, cs, bf = _fold_layernorm(wqk, None, gamma, beta)
-    close(ops.conv_gemm(h, wf, 2 * hd, bias=bf, ln=(rs, cs, 1e-5)), ln @ wqk.float().t(), 4e-3, 4e-3, "q|k projection from the same statistics")
+    ab2 = torch.zeros(m, 2, dtype=torch.float32, device=DEV)
+    close(ops.conv_gemm(h, wf, 2 * hd, bias=bf, ln=(rs, cs, 1e-5), ln_ab_out=ab2), ln @ wqk.float().t(), 4e-3, 4e-3, "q|k projection from the same statistics")
+    torch.testing.assert_close(ab2, ab, rtol=2e-6, atol=1e-6)   # the pairs the q|k GEMM leaves for the V^T GEMM = the finalize kernel's
 
 
 def test_layernorm_fold_is_declined_for_small_problems():
