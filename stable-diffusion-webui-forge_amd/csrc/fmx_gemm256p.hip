@@ -375,6 +375,9 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
     constexpr int idx = decltype(IDX)::value;
     if constexpr (idx < NP) {
       char* sbase = smem + buf * STAGE_BYTES + wave * 1024;
+#ifdef FMX_ABLATE_DMA   // timing-only build (WRONG results): only the first two K-tiles are fetched, later pieces are not issued at all (the stages keep
+      if (c.t >= 2) return;   // their random data: a zero fill would change the operands' power) -- what does the L2 -> LDS stream of the K loop cost?
+#endif
       const bool live = c.t < p.kt;  // uniform
       if constexpr (idx < NPA) {
         constexpr int s = idx;
