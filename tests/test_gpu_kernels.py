@@ -2,6 +2,7 @@
 on the same fp16-rounded inputs.  Tolerances are written per test; fp16 outputs carry 2^-11 relative
 rounding, accumulation is fp32 in both."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -224,6 +225,46 @@ def test_layernorm_folded_into_the_operand_swapped_vt_projection(m, c, hd):
     ab2 = torch.zeros(m, 2, dtype=torch.float32, device=DEV)
     close(ops.conv_gemm(h, wf, 2 * hd, bias=bf, ln=(rs, cs, 1e-5), ln_ab_out=ab2), ln @ wqk.float().t(), 4e-3, 4e-3, "q|k projection from the same statistics")
     torch.testing.assert_close(ab2, ab, rtol=2e-6, atol=1e-6)   # the pairs the q|k GEMM leaves for the V^T GEMM = the finalize kernel's
+
+
+def test_gemm_32x32x16_loop_behind_its_knob():
+    """The K loops run on v_mfma_f32_16x16x32 since round 3; the 32x32x16 loop stays in the library behind FMX_GEMM_MFMA=32 (the A/B of
+    profiles/r08r).  The knob is read once per process, so the old loop is exercised in a child process: plain, residual, GEGLU and a 3x3
+    convolution with GroupNorm statistics at shapes that take the 256x320 tile, against torch fp32 -- and against this process's 16x16x32
+    results (same fp32 accumulation in another order: equal within fp16 rounding of the output)."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, math, torch, torch.nn.functional as F
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import forge_amd
+from forge_amd import hipops as ops
+g = torch.Generator('cuda').manual_seed(5)
+r = lambda *s, scale=1.0: (torch.randn(*s, device='cuda', generator=g) * scale).half()
+x, w, b, res = r(4096, 1280), r(1280, 1280, scale=1280 ** -0.5), r(1280), r(4096, 1280)
+out = {}
+out['plain'] = ops.linear(x, w, b).float().cpu()
+out['res'] = ops.linear(x, w, b, residual=res).float().cpu()
+wg, bg = r(2560, 1280, scale=1280 ** -0.5), r(2560)
+wgi, bgi = ops.geglu_interleave(wg, bg)
+out['geglu'] = ops.conv_gemm(x, wgi, 2560, bias=bgi, act=ops.ACT_GEGLU).float().cpu()
+xc, wc = r(4, 32, 32, 640), r(640, 9 * 640, scale=(9 * 640) ** -0.5)
+y, st = ops.conv_gemm(xc, wc, 640, kh=3, pad=1, bias=r(640), stats=True)
+out['conv'] = y.float().cpu()
+ref = {'plain': x.float() @ w.float().t() + b.float(), 'res': x.float() @ w.float().t() + b.float() + res.float()}
+for k, v in ref.items():
+    assert float((out[k] - v.cpu()).abs().max()) < 2e-2, k
+torch.save(out, sys.argv[1])
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    outs = {}
+    for mf in ("32", "16"):
+        with tempfile.NamedTemporaryFile(suffix=".pt") as f:
+            env = dict(os.environ, FMX_GEMM_MFMA=mf)
+            subprocess.run([sys.executable, "-c", code, f.name], check=True, env=env, timeout=300)
+            outs[mf] = torch.load(f.name)
+    for k in outs["32"]:
+        close(outs["32"][k], outs["16"][k], 2e-3, 2e-3, f"32x32x16 loop vs 16x16x32 loop: {k}")
 
 
 def test_layernorm_fold_is_declined_for_small_problems():
