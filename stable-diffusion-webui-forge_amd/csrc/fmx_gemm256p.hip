@@ -229,7 +229,10 @@ __device__ __forceinline__ void epi_rows(const char* my, int lane, int mbase, in
 //   profiles/r08q: the GEMM's own 64 x 160 wave-tile sequence from registers, 1 913 vs 1 714 TFLOP/s).  A k-step is then 32 of K (two per
 //   K-tile) and 40 MFMAs per wave; the weight fragments are SINGLE-buffered -- fragment j is re-read for the next k-step right behind its four
 //   MFMAs, 36 MFMAs before its next use -- and only the four activation fragments are double-buffered, so the register count stays where it was.
-template <bool CONV, int BM, int BN, bool STATS = false, int SCHED = 0, int LN = 0, int MF = 32>
+// FA: the per-tap bit-mask form of the implicit-GEMM addresses (FASTADDR below) on tiles other than 512 x 128 -- single-source convolutions without
+//   upsample-on-load (every 3x3 convolution of the UNet except the decoder's upsamplers): the general form's ~15 vector instructions per
+//   activation piece (two sources, nearest-resize, bounds) become 3, in a K loop that otherwise issues ~10 instructions per MFMA (round 3).
+template <bool CONV, int BM, int BN, bool STATS = false, int SCHED = 0, int LN = 0, int MF = 32, bool FA = false>
 __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   using G = Geo<BM, BN>;
   constexpr int MI = G::MI, NJ = G::NJ, NPA = G::NPA, NPB = G::NPB, NP = G::NP;
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   // FASTADDR (the 512-row tile: 8 activation pieces per wave and K-tile): the host sends only single-source convolutions without
   // upsample-on-load here, for which a piece's pixel offset is  base(lane) + (ky * w + kx) * stride  with a UNIFORM second term, and its
   // validity one bit of a per-lane 9-bit mask computed once: 3 VALU instructions per piece instead of ~15.
-  constexpr bool FASTADDR = CONV && BM == 512;
+  constexpr bool FASTADDR = CONV && (BM == 512 || FA);
   int a_pix[NPA], a_yx[NPA];
   unsigned b_off[NPB];
 #pragma unroll
@@ -876,12 +879,12 @@ int launch_ln_swapped(const GemmParams& p, hipStream_t st) {
   return FMX_OK;
 }
 
-template <int BM, int BN, bool STATS, int SC = 0, int SL = 1, int MF = 32>
+template <int BM, int BN, bool STATS, int SC = 0, int SL = 1, int MF = 32, bool FA = false>
 int launch_bn(const GemmParams& p, bool conv, hipStream_t st) {
   using G = Geo<BM, BN>;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<true, BM, BN, STATS, SC, 0, MF>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<true, BM, BN, STATS, SC, 0, MF, FA>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<false, BM, BN, STATS, SL, 0, MF>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     attr_set = true;
   }
@@ -889,7 +892,7 @@ int launch_bn(const GemmParams& p, bool conv, hipStream_t st) {
   q.tiles_m = (p.M + BM - 1) / BM;
   q.tiles_n = (p.nout + BN - 1) / BN;
   const int grid = persistent_grid(q.tiles_m * q.tiles_n);
-  if (conv) hipLaunchKernelGGL((gemm256p_kernel<true, BM, BN, STATS, SC, 0, MF>), dim3(grid), dim3(512), G::LDS_BYTES, st, q);
+  if (conv) hipLaunchKernelGGL((gemm256p_kernel<true, BM, BN, STATS, SC, 0, MF, FA>), dim3(grid), dim3(512), G::LDS_BYTES, st, q);
   else hipLaunchKernelGGL((gemm256p_kernel<false, BM, BN, STATS, SL, 0, MF>), dim3(grid), dim3(512), G::LDS_BYTES, st, q);
   FMX_LAUNCH_CHECK("fmx_gemm_conv_f16 (256-row pipelined)");
   return FMX_OK;
@@ -909,6 +912,15 @@ int fmx_launch_gemm256p(const GemmParams& p, bool conv, int bm, int bn, hipStrea
     if (p.row_stats) return launch_ln<1, 16>(p, st);
     if (p.ln_partial) return launch_ln<2, 16>(p, st);
     if (p.ln_col_ab) return launch_ln_swapped<16>(p, st);
+    static int fa = -1;
+    if (fa < 0) {
+      const char* e2 = getenv("FMX_CONV_FASTADDR");   // A/B knob: 0 = the general address form for every convolution of the 256-row tiles (round 2)
+      fa = e2 ? atoi(e2) : 1;
+    }
+    if (fa && conv && p.c1 == 0 && p.up_h == 0 && p.kh <= 3) {   // single source, no resize-on-load: the bit-mask address form
+      if (bm == 256 && bn == 320) return p.stats ? launch_bn<256, 320, true, 0, 1, 16, true>(p, conv, st) : launch_bn<256, 320, false, 0, 1, 16, true>(p, conv, st);
+      if (bm == 256 && bn == 256) return p.stats ? launch_bn<256, 256, true, 0, 1, 16, true>(p, conv, st) : launch_bn<256, 256, false, 0, 1, 16, true>(p, conv, st);
+    }
     if (bm == 256 && bn == 320) return p.stats ? launch_bn<256, 320, true, 0, 1, 16>(p, conv, st) : launch_bn<256, 320, false, 0, 1, 16>(p, conv, st);
     if (bm == 320 && !p.stats) return launch_bn<320, 256, false, 0, 1, 16>(p, conv, st);
     if (bm == 512) return p.stats ? launch_bn<512, 128, true, 0, 1, 16>(p, conv, st) : launch_bn<512, 128, false, 0, 1, 16>(p, conv, st);
