@@ -725,7 +725,9 @@ def test_sdxl_full_size_forward_at_the_bench_batch_vs_reference_fixture(sdxl_eng
     n = 16
     before = hipops.LN_FOLDED_LAUNCHES
     eps = net.forward(x.repeat(n, 1, 1, 1).to(DEV), t.repeat(n).to(DEV), context=ctx.repeat(n, 1, 1).to(DEV), y=y.repeat(n, 1).to(DEV))
-    assert hipops.LN_FOLDED_LAUNCHES - before == 4 * 70, "norm1 (q|k and V^T), norm2 and norm3 of all 70 transformer blocks are expected to run folded at this size"
+    from forge_amd.backend.nn import unet as _unet
+    folds = (4 if _unet._LN_FOLD1 else 2) if _unet._LN_FOLD else 0     # (the A/B knobs FMX_LN_FOLD / FMX_LN_FOLD1 switch the folds off)
+    assert hipops.LN_FOLDED_LAUNCHES - before == folds * 70, "norm1 (q|k and V^T), norm2 and norm3 of all 70 transformer blocks are expected to run folded at this size"
     worst = max(range(n), key=lambda i: float((eps[i].float().cpu() - g["eps"][0]).abs().max()))
     for i in sorted({0, n - 1, worst}):
         check(f"SDXL unet forward at full size, image {i} of a batch of {n} vs reference", eps[i:i + 1], g["eps"], floor="sdxl_full_fwd.pt:eps")
