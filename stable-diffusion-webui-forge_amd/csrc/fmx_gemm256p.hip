@@ -253,8 +253,35 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   // multiple of 8, so a workgroup's tiles stay on its XCD).  A workgroup dispatched per tile cannot start before its predecessor on the CU has
   // drained its output stores and released the LDS; here the stores of tile t are still in flight while the LDS-DMA prologue of tile t + 1
   // is issued (the first K-tile's vmcnt(0) then waits for both), and the dispatch / descriptor set-up of later rounds is gone.
+  // XT (round 3, linear GEMMs on the 256 x 320 tile with the 16x16x32 loop): the K loop's LDS-DMA pipeline runs ACROSS output tiles.  The pieces a
+  // K loop issues for "K-tile kt" and beyond were zero fills; with a next tile in this workgroup's walk, K-tile kt IS that tile's K-tile 0 (its
+  // addresses swapped in two K-tiles before the end), so it lands under the last K-tile's MFMAs and is complete at that K-tile's barrier: the next
+  // tile's prologue (issue 14 pieces, wait for the first 9: ~3 us with the matrix pipes idle) shrinks to issuing the first pieces
+  // of its K-tile 1.  The stage that holds the prefetched K-tile is whichever is next in the alternation ((kt + s0) & 1, so a tile starts on
+  // stage s0 = 0 or 1), and the epilogue's transpose slices (16 rows x NJ*32 fp32 = XSL bytes per wave with this loop; GEGLU in two halves of 32
+  // rows) are laid around it: above stage 0, or below stage 1 with the eighth slice above it.
+  constexpr bool XT = !CONV && !STATS && MF == 16 && BM == 256 && BN == 320;
+  constexpr int XSL = NJ * 2048;
+  static_assert(!XT || (G::LDS_BYTES - 8 * XSL >= STAGE_BYTES && 7 * XSL <= STAGE_BYTES && 2 * STAGE_BYTES + XSL <= G::LDS_BYTES), "slices fit around one stage");
+  int xs0 = 0;          // stage of this tile's K-tile 0
+  bool xpre = false;    // ... which is already there (fetched under the previous tile's K loop)
   const int nwg = p.tiles_m * p.tiles_n;
+  auto tile_origin = [&](int l, int& tm_, int& tn_) {
+    const int wg_ = xcd_remap(l, nwg);
+    constexpr int GM = 8;
+    const int per_group = GM * p.tiles_n;
+    const int grp = wg_ / per_group;
+    const int first_m = grp * GM;
+    const int gsz = min(GM, p.tiles_m - first_m);
+    const int in_g = wg_ - grp * per_group;
+    tn_ = in_g / gsz;
+    tm_ = first_m + (in_g - tn_ * gsz);
+  };
   for (int lid = blockIdx.x; lid < nwg; lid += gridDim.x) {
+  const bool has_next = XT && p.xtile && p.kt >= 2 && lid + (int)gridDim.x < nwg;   // uniform
+  const int s0 = XT ? xs0 : 0;
+  const bool pre = XT && xpre;
+  const int kt_live = p.kt + (has_next ? 1 : 0);
   // the lane id passes through an opaque copy once per tile: every per-lane address below (LDS-DMA offsets, fragment and epilogue LDS offsets)
   // is the same for all tiles, and hoisted out of this loop they would ride through the K loop in ~45 registers the 160-accumulator tile
   // does not have (spilled to scratch when first tried)
@@ -264,16 +291,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   const int hi = lane >> 5, li = lane & 31;
   const int wg = xcd_remap(lid, nwg);
   int tm, tn;
-  {
-    constexpr int GM = 8;
-    const int per_group = GM * p.tiles_n;
-    const int grp = wg / per_group;
-    const int first_m = grp * GM;
-    const int gsz = min(GM, p.tiles_m - first_m);
-    const int in_g = wg - grp * per_group;
-    tn = in_g / gsz;
-    tm = first_m + (in_g - tn * gsz);
-  }
+  tile_origin(lid, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   const int Ctot = p.c0 + p.c1;
 
@@ -367,6 +385,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   auto advance = [&](Cursor& c) {
     c.t++;
     c.cc += BK;
+    if (XT && c.t == p.kt) c.cc = 0;   // (XT) "K-tile kt" is the next output tile's K-tile 0
     if (CONV && c.cc == Ctot) {
       c.cc = 0;
       if (++c.kx == p.kh) { c.kx = 0; ++c.ky; }
@@ -381,7 +400,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
 #ifdef FMX_ABLATE_DMA   // timing-only build (WRONG results): only the first two K-tiles are fetched, later pieces are not issued at all (the stages keep
       if (c.t >= 2) return;   // their random data: a zero fill would change the operands' power) -- what does the L2 -> LDS stream of the K loop cost?
 #endif
-      const bool live = c.t < p.kt;  // uniform
+      const bool live = c.t < kt_live;  // uniform
       if constexpr (idx < NPA) {
         constexpr int s = idx;
         const Piece pc = a_piece(s, c);
@@ -393,7 +412,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
         auto* dst = (__attribute__((address_space(3))) void*)(sbase + A_BYTES + s * 8192);
         const unsigned bo = b_off[s];  // (local copy: hipcc's host pass silently drops the kernel stub when a captured array
         const unsigned voff = live ? bo : OOB;  //  element is handed straight to the buffer builtin)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, dst, 16, voff, (unsigned)c.t * (BK * 2u), 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, dst, 16, voff, CONV ? (unsigned)c.t * (BK * 2u) : (unsigned)c.cc * 2u, 0, 0);
       }
     }
   };
@@ -477,14 +496,16 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   };
   // ---- prologue: tile 0 complete, the first P0 pieces of tile 1 in flight ------------------------------------------------------
   Cursor c1{0, 0, 0, 0};
-  issue_range(IC<0>{}, IC<NP>{}, c1, 0);
+  if (!pre) issue_range(IC<0>{}, IC<NP>{}, c1, s0);
   advance(c1);  // c1 = tile 1
-  issue_range(IC<0>{}, IC<P0>{}, c1, 1);
-  if constexpr (P0 == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  else if constexpr (P0 == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-  else if constexpr (P0 == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+  issue_range(IC<0>{}, IC<P0>{}, c1, s0 ^ 1);
+  if (!pre) {   // (XT, pre: K-tile 0 was complete at the previous tile's last K-tile barrier, and that tile ended on a barrier)
+    if constexpr (P0 == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (P0 == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if constexpr (P0 == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
   if constexpr (MF == 32) read_frags(0, 0, 0);
   // iteration t:  k-step 0: + pieces 3-5 of tile t+1   k-step 1: + pieces 6.. of tile t+1   k-step 2: nothing
   //               wait + barrier                          k-step 3: + pieces 0-2 of tile t+2 (into the stage just released)
@@ -509,10 +530,13 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
     const unsigned abase = (unsigned)lds_off(wm * WROWS + l16, kg);
     const unsigned wbase = (unsigned)(A_BYTES + lds_off(wn * (NJ * 32) + l16, kg));
     auto rd = [&](unsigned addr, int frag) { return *reinterpret_cast<const f16x8*>(smem + addr + frag * 2048); };
+    {
+      const unsigned st0 = (unsigned)s0 * STAGE_BYTES;
 #pragma unroll
-    for (int i = 0; i < MIB; ++i) a4[i] = rd(abase, i);
+      for (int i = 0; i < MIB; ++i) a4[i] = rd(abase + st0, i);
 #pragma unroll
-    for (int j = 0; j < NJB; ++j) w1[j] = rd(wbase, j);
+      for (int j = 0; j < NJB; ++j) w1[j] = rd(wbase + st0, j);
+    }
 #ifndef FMX_MF16_Q0
 #define FMX_MF16_Q0 5
 #endif
@@ -549,7 +573,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
     constexpr int MB = HM - HJ;   // the first MFMA of a k-step with a re-read behind it: the barrier of the K-tile sits in front of it in k-step 1
     static_assert(MB + 1 + GAP * (Q0 - 1) < NM && 1 + GAP * (NP - Q0 - 1) < NM, "the pieces fit their k-step");
     for (int t = 0; t < p.kt; ++t) {
-      const int buf = t & 1;
+      const int buf = (t + s0) & 1;
       Cursor c2 = c1;
       advance(c2);  // tile t+2
       // (opaque per iteration: loop-invariant otherwise, and the fragment addresses of both k-steps and stages would ride through the loop)
@@ -569,6 +593,23 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
       // is readable and stage buf may be overwritten with tile t+2
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+      if constexpr (XT) {
+        // two K-tiles before the end: every piece issued from here on belongs to the NEXT output tile's K-tile 0 (or is a no-op) -> its addresses
+        if (has_next && t == p.kt - 2) {
+          int tmn, tnn;
+          tile_origin(lid + (int)gridDim.x, tmn, tnn);
+#pragma unroll
+          for (int s = 0; s < NPA; ++s) {
+            const int m = tmn * BM + s * 64 + wave * 8 + r8;
+            a_pix[s] = (m < p.M) ? m : -1;
+          }
+#pragma unroll
+          for (int s = 0; s < NPB; ++s) {
+            const int nn = tnn * BN + s * 64 + wave * 8 + r8;
+            b_off[s] = (nn < p.nout) ? (unsigned)nn * (unsigned)p.ldw * 2u + kcb : OOB;
+          }
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
       kpart(IC<MB>{}, IC<NM>{}, k0, off_nxt, piece2, IC<Q0>{}, IC<MB + 1>{});
       __builtin_amdgcn_sched_barrier(0);
@@ -619,9 +660,12 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   //      residual loads and stores are contiguous runs of NJ*64 (NJ*32) bytes.  16-byte chunks are XOR-swizzled by row on
   //      both sides; the arithmetic (fp32, one rounding) is unchanged.  The row pass itself lives in epi_rows() below.
   __builtin_amdgcn_s_barrier();  // every wave is done reading the last stage: the LDS is free
-  char* my = smem + wave * G::WAVE_EPI_BYTES;
+  // XT: the slices stay clear of the stage that holds the next tile's K-tile 0
+  const int sN = (p.kt + s0) & 1;
+  char* my = !XT ? smem + wave * G::WAVE_EPI_BYTES
+                 : smem + ((has_next && sN == 1) ? (wave < 7 ? wave * XSL : 2 * STAGE_BYTES) : G::LDS_BYTES - 8 * XSL + wave * XSL);
   const FastEpilogue ep(p);
-  const bool geglu = !STATS && LN != 1 && p.act == FMX_ACT_GEGLU;   // (no GEGLU code in the statistics-emitting kernels: registers)
+  const bool geglu = !STATS && LN != 1 && LN != 3 && p.act == FMX_ACT_GEGLU;   // (no GEGLU code in the statistics-emitting / operand-swapped kernels: registers; the host refuses)
   // LN consumer: mean / rstd of row `lane` of this wave's rows (fixed summation order); lane l serves row l through __shfl below
   float lnm = 0.f, lnr = 1.f;
   if (LN == 2) {
@@ -740,7 +784,11 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
     // output columns q4*8 + hi*4 + [0,4), registers q4 = 2,3 their gates (same lane).  Staged row = NJ*16 outputs.
     constexpr int RB = NJ * 64;
     constexpr int LPR = NJ * 2;
-    constexpr int ROWS = MI * 32;
+    // GH passes over the wave's rows: one (the whole MI*32 x NJ*16 sub-tile staged at once), or (XT: XSL-byte slices) two halves of MIB/2 block rows
+    constexpr int GH = XT ? 2 : 1;
+    constexpr int ROWS = MI * 32 / GH;
+    constexpr int IH = MIB / GH;
+    static_assert(!XT || ROWS * RB <= XSL, "a GEGLU half fits the slice");
     const int lrow = MF == 32 ? li : l16;   // this lane's pixel row inside a block row
     int mcs[MIB], imgs[MIB];
 #pragma unroll
@@ -760,8 +808,9 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
     // MF 32: registers q4 = 0, 1 of block j are values of columns q4*8 + hi*4 + [0, 4), registers q4 = 2, 3 their gates.
     // MF 16: block 2 jj holds the 16 values of weight-row group jj, block 2 jj + 1 their gates (same lane: columns kg*4 + [0, 4)); the loop
     //        below runs q4 over ONE value run per (jj, lane): q4 = kg.
-    auto stage_geglu = [&](auto HAS_RV) {
+    auto stage_geglu = [&](auto HAS_RV, auto HALF) {
       constexpr bool RV = decltype(HAS_RV)::value != 0;
+      constexpr int I0 = decltype(HALF)::value * IH;
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -778,7 +827,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) { bvf[r] = (float)bv[r]; bgf[r] = (float)bg[r]; }
 #pragma unroll
-          for (int i = 0; i < MIB; ++i) {
+          for (int i = I0; i < I0 + IH; ++i) {
             f16x4 rvv, rvg;
             if (RV) { rvv = ep.rv4(imgs[i], nbc); rvg = ep.rv4(imgs[i], nbc + 16); }
             // (acc alpha - mean colsum) rstd + bias  =  acc (alpha rstd) + (bias - mean rstd colsum): one FMA per element and one per column
@@ -796,21 +845,25 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
               //  per step, profiles/r08j; the epilogue is not bound by v_rcp / v_exp issue, and the exact form is 30x more accurate)
               o[r] = val * gelu_erf_f(gate);
             }
-            const int row = i * BR + lrow, chunk = j * 4 + (MF == 32 ? q4 * 2 + hi : kg);
+            const int row = (i - I0) * BR + lrow, chunk = j * 4 + (MF == 32 ? q4 * 2 + hi : kg);
             *reinterpret_cast<f32x4*>(my + row * RB + ((chunk ^ (row & 3)) << 4)) = o;  // NJ*4 chunks per row: XOR of the low 2 bits stays inside
           }
         }
     };
-    if (ep.mrv) stage_geglu(IC<1>{}); else stage_geglu(IC<0>{});
-    const int cg = lane % LPR;
-    const int col = ((n0 + wn * (NJ * 32)) >> 1) + cg * 8;
-    const bool nok = col < ep.ncols;
-    const int colc = nok ? col : 0;
-    // bias / rowvec / act were applied above: the row pass only adds the residual (alpha = 1, every other operand -> zero page)
-    if (ep.mres) epi_rows<RB, LPR, ROWS, 3, false, 1>(my, lane, m0 + wm * WROWS, p.M, colc, nok, ep.per_img, 1.0f, 0.0f, p.zp, p.zp, 0L, p.zp, 0L,
-                                                       ep.res + colc, ep.ld_res, ep.out + colc, ep.ld_out);
-    else epi_rows<RB, LPR, ROWS, 3, false, 2>(my, lane, m0 + wm * WROWS, p.M, colc, nok, ep.per_img, 1.0f, 0.0f, p.zp, p.zp, 0L, p.zp, 0L, p.zp, 0L,
-                                               ep.out + colc, ep.ld_out);
+    static_for<GH>([&](auto HALF) {
+      constexpr int h = decltype(HALF)::value;
+      if (ep.mrv) stage_geglu(IC<1>{}, HALF); else stage_geglu(IC<0>{}, HALF);
+      const int cg = lane % LPR;
+      const int col = ((n0 + wn * (NJ * 32)) >> 1) + cg * 8;
+      const bool nok = col < ep.ncols;
+      const int colc = nok ? col : 0;
+      // bias / rowvec / act were applied above: the row pass only adds the residual (alpha = 1, every other operand -> zero page)
+      const int mb = m0 + wm * WROWS + h * ROWS;
+      if (ep.mres) epi_rows<RB, LPR, ROWS, 3, false, 1>(my, lane, mb, p.M, colc, nok, ep.per_img, 1.0f, 0.0f, p.zp, p.zp, 0L, p.zp, 0L,
+                                                         ep.res + colc, ep.ld_res, ep.out + colc, ep.ld_out);
+      else epi_rows<RB, LPR, ROWS, 3, false, 2>(my, lane, mb, p.M, colc, nok, ep.per_img, 1.0f, 0.0f, p.zp, p.zp, 0L, p.zp, 0L, p.zp, 0L,
+                                                 ep.out + colc, ep.ld_out);
+    });
   }
 #ifdef FMX_ABLATE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -827,6 +880,10 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
 #endif
   // every wave is done with its epilogue slice of the LDS before the next tile's LDS-DMA pieces (any wave's) land in it
   if (lid + (int)gridDim.x < nwg) __syncthreads();
+  if constexpr (XT) {
+    xpre = has_next;
+    xs0 = has_next ? sN : 0;
+  }
   }  // tile loop
 }
 
@@ -846,6 +903,16 @@ static int persistent_grid(int tiles) {
   return tiles < cus ? tiles : cus;
 }
 
+// FMX_GEMM_XTILE=0: the persistent linear kernels fetch every tile's first K-tile in its own prologue again (A/B of the cross-tile prefetch)
+static int xtile_on() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("FMX_GEMM_XTILE");
+    v = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  return v;
+}
+
 template <int LN, int MF = 32>
 int launch_ln(const GemmParams& p, hipStream_t st) {
   using G = Geo<256, 320>;
@@ -855,6 +922,7 @@ int launch_ln(const GemmParams& p, hipStream_t st) {
     attr_set = true;
   }
   GemmParams q = p;
+  q.xtile = xtile_on();
   q.tiles_m = (p.M + 255) / 256;
   q.tiles_n = (p.nout + 319) / 320;
   hipLaunchKernelGGL((gemm256p_kernel<false, 256, 320, false, 1, LN, MF>), dim3(persistent_grid(q.tiles_m * q.tiles_n)), dim3(512), G::LDS_BYTES, st, q);
@@ -872,6 +940,7 @@ int launch_ln_swapped(const GemmParams& p, hipStream_t st) {
     attr_set = true;
   }
   GemmParams q = p;
+  q.xtile = xtile_on();
   q.tiles_m = (p.M + 319) / 320;
   q.tiles_n = (p.nout + 255) / 256;
   hipLaunchKernelGGL((gemm256p_kernel<false, 320, 256, false, 1, 3, MF>), dim3(persistent_grid(q.tiles_m * q.tiles_n)), dim3(512), G::LDS_BYTES, st, q);
@@ -889,6 +958,7 @@ int launch_bn(const GemmParams& p, bool conv, hipStream_t st) {
     attr_set = true;
   }
   GemmParams q = p;
+  q.xtile = xtile_on();
   q.tiles_m = (p.M + BM - 1) / BM;
   q.tiles_n = (p.nout + BN - 1) / BN;
   const int grid = persistent_grid(q.tiles_m * q.tiles_n);

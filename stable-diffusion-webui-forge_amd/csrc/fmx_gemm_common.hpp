@@ -47,6 +47,7 @@ struct GemmParams {
   const float* ln_col_ab;    // [nout][2] {rstd, -mean rstd}
   const float* ln_row_cb;    // [M][2] {colsum, folded bias}
   float* ln_ab_out;          // LN consumer: also write {rstd, -mean rstd} of its input rows (tiles of the first tile column), or null
+  int xtile;                 // persistent 256 x 320 linear kernels: fetch the next output tile's first K-tile under the last K-tile of this one (set by the launcher)
 };
 
 // K-tile depth of every GEMM kernel: 64 halfs = one 128-byte LDS row.

@@ -267,6 +267,76 @@ torch.save(out, sys.argv[1])
         close(outs["32"][k], outs["16"][k], 2e-3, 2e-3, f"32x32x16 loop vs 16x16x32 loop: {k}")
 
 
+def test_cross_tile_prefetch_matches_the_per_tile_prologue_bit_for_bit():
+    """Round 3: a persistent workgroup of the linear 256x320 kernels fetches its NEXT output tile's first K-tile under the last K-tile of the
+    current one (csrc/fmx_gemm256p.hip `XT`); FMX_GEMM_XTILE=0 (read once per process) restores the per-tile prologue.  Same arithmetic in the
+    same order, so every output word must be identical: launches with 2 - 4 tiles per workgroup, odd and even K-tile counts (the stage a tile
+    starts on alternates when the count is odd), the two- and three-K-tile minimum, one K-tile (prefetch off by construction), ragged last row
+    and column tiles; plain, in-place residual, GEGLU with and without residual, and the LayerNorm producer / consumer / consumer-GEGLU chain."""
+    import subprocess
+    import sys
+    import tempfile
+    code = r"""
+import sys, math, torch, torch.nn.functional as F
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import forge_amd
+from forge_amd import hipops as ops
+from forge_amd.backend.nn.unet import _fold_layernorm
+g = torch.Generator('cuda').manual_seed(11)
+r = lambda *s, scale=1.0: (torch.randn(*s, device='cuda', generator=g) * scale).half()
+out = {}
+def check(name, got, ref, tol):
+    err = float((got.float() - ref).abs().max())
+    assert err < tol, (name, err)
+    out[name] = got.cpu()
+for (m, n, k) in ((33000, 1920, 960), (20000, 2560, 128), (20000, 2560, 192), (20000, 2560, 64), (30000, 1288, 1280)):
+    x, w, b = r(m, k), r(n, k, scale=k ** -0.5), r(n)
+    ref = x.float() @ w.float().t() + b.float()
+    check(f'plain {m}x{n}x{k}', ops.linear(x, w, b, force_tile=7), ref, 2e-2)
+    h = r(m, n)
+    h0 = h.clone()
+    ops.linear(x, w, b, residual=h, out=h, ld_out=n, force_tile=7)
+    check(f'residual in place {m}x{n}x{k}', h, ref + h0.float(), 2e-2)
+    if n %% 64 == 0:
+        wgi, bgi = ops.geglu_interleave(w, b)
+        gref = ref[:, :n // 2] * F.gelu(ref[:, n // 2:])
+        check(f'geglu {m}x{n}x{k}', ops.conv_gemm(x, wgi, n, bias=bgi, act=ops.ACT_GEGLU, force_tile=7), gref, 3e-2)
+        res = r(m, n // 2)
+        check(f'geglu + residual {m}x{n}x{k}', ops.conv_gemm(x, wgi, n, bias=bgi, act=ops.ACT_GEGLU, residual=res, force_tile=7), gref + res.float(), 3e-2)
+for (m, c) in ((40000 - 60, 1280), (70000, 640)):
+    o_in, w_out, b_out = r(m, c), r(c, c, scale=c ** -0.5), r(c)
+    h = (r(m, c, scale=2.0) + 0.7).contiguous()
+    h0 = h.clone()
+    rs = ops.RowStats(m, c)
+    ops.linear(o_in, w_out, b_out, residual=h, out=h, ld_out=c, row_stats=rs, force_tile=7)
+    assert rs.parts == 2 * (c // 320)
+    check(f'LN producer {m}x{c}', h, o_in.float() @ w_out.float().t() + b_out.float() + h0.float(), 2e-2)
+    out[f'LN producer partials {m}x{c}'] = rs.partial.view(m, -1, 2)[:, :rs.parts].clone().cpu()
+    gamma, beta = (1 + 0.2 * r(c)), 0.1 * r(c)
+    ln = F.layer_norm(h.float(), (c,), gamma.float(), beta.float(), 1e-5)
+    wq = r(2 * c, c, scale=c ** -0.5)
+    wf, cs, bf = _fold_layernorm(wq, None, gamma, beta)
+    ab = torch.zeros(m, 2, dtype=torch.float32, device='cuda')
+    check(f'LN consumer {m}x{c}', ops.conv_gemm(h, wf, 2 * c, bias=bf, ln=(rs, cs, 1e-5), ln_ab_out=ab), ln @ wq.float().t(), 3e-2)
+    out[f'LN consumer pairs {m}x{c}'] = ab.cpu()
+    wg, bg = r(4 * c, c, scale=c ** -0.5), r(4 * c)
+    wgi, bgi = ops.geglu_interleave(wg, bg)
+    wf2, cs2, bf2 = _fold_layernorm(wgi, bgi, gamma, beta)
+    hc = ln @ wg.float().t() + bg.float()
+    check(f'LN consumer GEGLU {m}x{c}', ops.conv_gemm(h, wf2, 4 * c, bias=bf2, act=ops.ACT_GEGLU, ln=(rs, cs2, 1e-5)), hc[:, :2 * c] * F.gelu(hc[:, 2 * c:]), 4e-2)
+    del ln, hc
+torch.save(out, sys.argv[1])
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for knob in ("0", "1"):
+        with tempfile.NamedTemporaryFile(suffix=".pt") as f:
+            subprocess.run([sys.executable, "-c", code, f.name], check=True, env=dict(os.environ, FMX_GEMM_XTILE=knob), timeout=600)
+            outs[knob] = torch.load(f.name)
+    assert outs["0"].keys() == outs["1"].keys() and len(outs["0"]) == 28
+    for k in outs["0"]:
+        assert torch.equal(outs["0"][k], outs["1"][k]), f"cross-tile prefetch changed the result of: {k}"
+
+
 def test_layernorm_fold_is_declined_for_small_problems():
     """Below the sizes at which the dispatcher uses the 256x320 tile the producer emits nothing (parts == 0) and the caller keeps its LayerNorm."""
     m, c = 512, 640
