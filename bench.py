@@ -479,7 +479,11 @@ def main():
             g = summ.get("gemm_conv")
             if g:
                 ach = g["flops"] / g["seconds"]
-                traffic, traffic_note = pmc_traffic_per_launch()
+                # the committed counters were taken on the default workload's GEMM launches (tools/gpu_round2.sh pmc_hbm): quoted for that workload only
+                if a.config == "sdxl-b8-euler20" and not (a.model or a.res or a.batch):
+                    traffic, traffic_note = pmc_traffic_per_launch()
+                else:
+                    traffic, traffic_note = None, "the committed PMC passes profile the default workload (sdxl-b8-euler20), not this one"
                 roof = {"kernel": "gemm256p_kernel<256x320 | 320x256 | 256x256 | 512x128> + gemm_kernel (fmx_gemm_conv: MFMA implicit-GEMM conv3x3/1x1 + linear, fused epilogues)",
                         "bound": "mfma", "achieved": round(ach / 1e12, 1), "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s",
                         "frac": round(ach / MFMA_PEAK, 4), "traffic": traffic, "traffic_note": traffic_note, "launches_per_forward": g["launches"],
