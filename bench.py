@@ -198,12 +198,14 @@ def pmc_traffic_per_launch():
 
 class ClockSampler:
     """Shader / memory clocks of the timed region, read from the amdgpu sysfs DPM tables (the `*` line of pp_dpm_sclk / pp_dpm_mclk) every
-    20 ms on a host thread: puts the 'power-limited at ~1.8 GHz' statement into the driver-visible line.  Null fields when the files are absent."""
+    20 ms on a host thread, and the socket power beside them (hwmon power1_average / power1_input against power1_cap, microwatts): puts the
+    'power-limited at ~1.8 GHz' statement into the driver-visible line.  Null fields when the files are absent."""
 
     def __init__(self, local):
         import glob
         self.files = {}
         self.note = None
+        self.power_cap_w = None
         try:   # the sysfs card of THIS HIP device: match the PCI address (the host may expose more cards than the container sees GPUs)
             import torch
             pr = torch.cuda.get_device_properties(local)
@@ -213,6 +215,14 @@ class ClockSampler:
                 if want in os.path.realpath(base).lower():
                     self.files = {"sclk": os.path.join(base, "pp_dpm_sclk"), "mclk": os.path.join(base, "pp_dpm_mclk")}
                     self.note = "sysfs " + base + " (PCI " + want + ")"
+                    for hw in sorted(glob.glob(os.path.join(base, "hwmon", "hwmon*"))):
+                        for name in ("power1_average", "power1_input"):
+                            if os.path.exists(os.path.join(hw, name)) and "power" not in self.files:
+                                self.files["power"] = os.path.join(hw, name)
+                                try:
+                                    self.power_cap_w = int(open(os.path.join(hw, "power1_cap")).read()) / 1e6
+                                except Exception:
+                                    pass
             if not self.files:
                 self.note = "no sysfs card with PCI address " + want
         except Exception as e:
@@ -224,6 +234,9 @@ class ClockSampler:
     def _read(self):
         for k, f in self.files.items():
             try:
+                if k == "power":
+                    self.samples[k].append(int(open(f).read()) / 1e6)
+                    continue
                 for line in open(f):
                     if "*" in line:
                         self.samples[k].append(int("".join(ch for ch in line.split(":")[1] if ch.isdigit())))
@@ -250,6 +263,9 @@ class ClockSampler:
     def summary(self):
         out = {"source": self.note}
         for k, v in self.samples.items():
+            if k == "power":
+                out["power_w"] = {"min": round(min(v)), "mean": round(sum(v) / len(v)), "max": round(max(v)), "samples": len(v), "cap": self.power_cap_w} if v else None
+                continue
             out[k + "_mhz"] = {"min": min(v), "mean": round(sum(v) / len(v)), "max": max(v), "samples": len(v)} if v else None
         return out
 
