@@ -80,6 +80,8 @@ def parse(argv=None):
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--breakdown", default="", help="write the per-shape kernel-time table of one network forward to this file")
     ap.add_argument("--vae-breakdown", default="", help="write the per-shape kernel-time table of one VAE decode to this file")
+    ap.add_argument("--rccl-selfcheck", action="store_true", help="(child process of the 1-GPU run) RCCL at world size 1: init, all-reduce, the job's broadcast + gathers on the device")
+    ap.add_argument("--no-rccl-selfcheck", action="store_true", help="1-GPU run: skip the RCCL world-1 leg")
     ap.add_argument("--stub-engine", action="store_true", help="launcher self-test without a GPU (gloo, no kernels); not a measurement")
     return ap.parse_args(argv)
 
@@ -158,15 +160,24 @@ def cpu_baseline(model, cfg, latent, sampler_name=None, cfg_scale=7.0):
 
 
 def kernel_source_hash():
-    """sha256 (first 16 hex digits) over csrc/*.hip, *.hpp and include/fmx.h: identifies the kernel sources a binary / a PMC summary belongs to."""
-    import glob
-    import hashlib
-    h = hashlib.sha256()
-    pk = os.path.join(ROOT, "stable-diffusion-webui-forge_amd", "csrc")
-    for f in sorted(glob.glob(os.path.join(pk, "*.hip")) + glob.glob(os.path.join(pk, "*.hpp")) + [os.path.join(ROOT, "include", "fmx.h")]):
-        h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
-    return h.hexdigest()[:16]
+    """Identity of the kernel sources THE LOADED BINARY was built from (fmx_build_info(): the Makefile bakes csrc/src_hash.py's sha256 over csrc/*.hip,
+    *.hpp and include/fmx.h into libfmx_gfx950.so) -- not of whatever sources lie next to it: a stale .so beside newer sources is not credited with
+    measurements taken on them.  `source_tree_hash()` is the hash of the sources on disk; the bench line carries both."""
+    from forge_amd import _lib
+    return _lib.build_info().get("src", "unknown")
+
+
+def source_tree_hash():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fmx_src_hash", os.path.join(ROOT, "stable-diffusion-webui-forge_amd", "csrc", "src_hash.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.kernel_source_hash()
+
+
+def _knobs(ignored):
+    from forge_amd import _lib
+    return _lib.active_knobs(ignored)
 
 
 def pmc_traffic_per_launch():
@@ -305,8 +316,77 @@ def stub_main(a, rank, world):
         dist.destroy_process_group()
 
 
+def rccl_selfcheck():
+    """RCCL on ONE GPU (a process group of one rank is a real RCCL communicator: init, kernels, streams): the collectives a sharded job issues --
+    the all-reduce of the rank check, `broadcast_conditioning` of an SDXL batch-8 conditioning pair, the `gather_batch` of fp32 latents and of uint8
+    1024^2 images -- run on the device and are compared with their inputs.  Printed as ONE JSON line; the 1-GPU bench run embeds it as `rccl_world1`
+    so that the driver's own record shows the RCCL code path executing (a scaling curve needs the 8-GPU node; this shows the path is not dead code)."""
+    import torch
+    import torch.distributed as dist
+    import forge_amd  # noqa: F401
+    from forge_amd import distributed as fdist, synth
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(_free_port()))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    t0 = time.perf_counter()
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    out = {"backend": dist.get_backend(), "world": dist.get_world_size()}
+    one = torch.ones(1, device=dev)
+    dist.all_reduce(one)
+    torch.cuda.synchronize()
+    out["init_plus_first_allreduce_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+    out["ranks_in_collective"] = int(one.item())
+    cfg = synth.SDXL_UNET_CONFIG
+    c, uc = synth.synth_conditioning(8, cfg["context_dim"], cfg["adm_in_channels"], seed=1234)
+    c = {k: v.half() for k, v in c.items()}
+    uc = {k: v.half() for k, v in uc.items()}
+    t0 = time.perf_counter()
+    c2, uc2 = fdist.broadcast_conditioning(c, uc, dev)
+    torch.cuda.synchronize()
+    out["broadcast_cond_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+    ok = all(torch.equal(c2[k].cpu(), c[k]) and torch.equal(uc2[k].cpu(), uc[k]) and c2[k].is_cuda for k in c)
+    lat = torch.randn(8, 4, 128, 128, device=dev)
+    img = torch.randint(0, 255, (8, 1024, 1024, 3), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    lat2 = fdist.gather_batch(lat, 8)
+    img2 = fdist.gather_batch(img, 8)
+    torch.cuda.synchronize()
+    out["gather_latents_and_images_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+    ok = ok and torch.equal(lat2, lat) and torch.equal(img2, img) and lat2.data_ptr() != lat.data_ptr()
+    out["results_equal_inputs"] = bool(ok)
+    try:
+        out["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:  # noqa: BLE001
+        out["rccl_version"] = None
+    dist.barrier()
+    dist.destroy_process_group()
+    print("RCCL_SELFCHECK " + json.dumps(out), flush=True)
+
+
+def rccl_world1_leg(timeout=120):
+    """Run rccl_selfcheck() in a CHILD process with a timeout (an RCCL init that hangs must not take the bench line down) -> dict for the line."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        res = subprocess.run([sys.executable, os.path.abspath(__file__), "--rccl-selfcheck"], capture_output=True, text=True, timeout=timeout, env=env)
+        for ln in res.stdout.splitlines():
+            if ln.startswith("RCCL_SELFCHECK "):
+                return dict(json.loads(ln[len("RCCL_SELFCHECK "):]), ok=True)
+        return {"ok": False, "returncode": res.returncode, "stderr_tail": res.stderr[-400:]}
+    except subprocess.TimeoutExpired:
+        return {"ok": False, "error": f"timed out after {timeout} s"}
+    except Exception as e:  # noqa: BLE001
+        return {"ok": False, "error": repr(e)}
+
+
 def main():
     a = parse()
+    if a.rccl_selfcheck:
+        return rccl_selfcheck()
     if a.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -554,7 +634,9 @@ def main():
         "comm_ms": {"broadcast_cond": round(t_bcast * 1e3, 2), "gather_latents": round(t_gather * 1e3, 2)},
         "build_s": round(t_build, 1),
         "clocks_during_timed_steps": clocks.summary(),
-        "kernel_source_hash": kernel_source_hash(),
+        "kernel_source_hash": kernel_source_hash(),          # of the loaded binary (fmx_build_info)
+        "source_tree_hash": source_tree_hash(),              # of csrc/ on disk: differs from the line above when the .so is stale
+        "knobs": {"active": _knobs(False), "set_but_ignored": _knobs(True)},   # development A/B knobs (need FMX_ALLOW_KNOBS=1); {} = the default kernels
     }
     if roof:
         out["roofline"] = roof
@@ -573,6 +655,8 @@ def main():
                 out["cpu_baseline"]["reference_on_authoring_box"] = REFERENCE_CPU_AUTHORING_BOX[model]
         except Exception as e:  # the baseline must never take the bench line down
             out["cpu_baseline"] = {"value": None, "error": repr(e)}
+    if rank == 0 and world == 1 and not a.no_rccl_selfcheck:
+        out["rccl_world1"] = rccl_world1_leg()     # after the timed region, in a child process
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

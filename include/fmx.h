@@ -65,6 +65,12 @@ extern "C" {
 
 int fmx_abi_version(void);
 const char* fmx_last_error(void);
+/* identity of the loaded binary: "src=<16 hex digits: sha256 over csrc sources + this header at build time> abi=<n> arch=gfx950" -- what a
+ * measurement (bench.py's `roofline.traffic`, a committed PMC summary) is keyed on, instead of whatever sources lie next to the .so */
+const char* fmx_build_info(void);
+/* development A/B knobs (environment variables FMX_GEMM_*, FMX_ATTN_*, FMX_GN_*, ... that select another kernel for the same call) are read ONLY in a
+ * process that carries FMX_ALLOW_KNOBS=1; this lists "NAME=value,..." of the knobs that took effect (ignored = 0) or were set but ignored (ignored = 1) */
+int fmx_active_knobs(char* buf, int buf_len, int ignored);
 /* host out-params: number of CUs, wave size, gcn arch name (e.g. "gfx950:sramecc+:xnack-") */
 int fmx_device_info(int* cu_count, int* wave_size, char* arch, int arch_len);
 

@@ -19,6 +19,7 @@ tests/parity.py turns that into the tolerances of the native path (max(1e-3, fac
     python -m oracle.make_floor --only config2  # + fixture sd15_config2.pt: SD1.5 512^2, B=4, 20-step Euler a (~10 min)
     python -m oracle.make_floor --only sdxl     # SDXL full-size forward floor                                (~8 min)
     python -m oracle.make_floor --only config3  # + fixture sdxl_config3.pt: SDXL 1024^2, one image, 30-step DPM++ 2M + 1024^2 VAE decode (~30 min)
+    python -m oracle.make_floor --only config3_b8 # + fixture sdxl_config3_b8.pt: SDXL 1024^2, batch 8 with eight distinct conditionings / seeds, 5-step DPM++ 2M (~45 min)
     python -m oracle.make_floor --only vae1024  # 1024^2 decode only (fixture + floor)
     python -m oracle.make_floor --only flux_width # fixture flux_width3072_fwd.pt: Flux at hidden 3072 / 24 x 128 / 4096 + 256 tokens, 1 + 1 blocks, + its f16 / bf16 floors
     python -m oracle.make_floor --only vae_bf16 # bfloat16 floors of the VAE fixtures + the fp16-overflow fixture tiny_vae_overflow.pt
@@ -429,6 +430,37 @@ def gen_config3(steps=30):
     gen_vae1024(lat, tag="sdxl_config3_decode.pt")
 
 
+def gen_config3_b8(steps=5, batch=8):
+    """BASELINE config 3 at its own BATCH (round 4): SDXL 1024x1024, batch 8 with EIGHT DISTINCT conditionings and seeds (the first `batch` rows of
+    synth_conditioning(batch, ...): different prompts, pooled vectors and noise per image), `steps` DPM++ 2M steps on the Karras schedule, CFG 7, through
+    the reference's own sampling_function (cond and uncond of all eight images in the reference's model calls) -- reference fp32 (fixture
+    tests/golden/sdxl_config3_b8.pt: all eight final latents + the first denoised prediction) and reference fp16 (floor, per image and overall)."""
+    cfg = synth.SDXL_UNET_CONFIG
+    sd = synth.synth_unet_state_dict(cfg, seed=0)
+    c, uc = synth.synth_conditioning(batch, cfg["context_dim"], cfg["adm_in_channels"], seed=1234)
+    c, uc = ref_import.SdxlCond(c), ref_import.SdxlCond(uc)
+    seeds = [3100 + i for i in range(batch)]
+    t0 = time.time()
+    net = ref_import.build_ref_unet(cfg, sd)
+    trace = []
+    lat, sigmas = mg.ref_sample(net, cfg, c, uc, seeds, 128, steps, "DPM++ 2M", trace=trace)
+    t32 = time.time() - t0
+    del net
+    print("config 3 at batch %d: reference fp32 %d steps in %.0f s" % (batch, steps, t32), flush=True)
+    torch.save({"seeds": seeds, "steps": steps, "sampler": "DPM++ 2M", "batch": batch, "cond_seed": 1234, "latent": lat, "sigmas": sigmas,
+                "denoised0": trace[0], "cpu_seconds": {"sample": t32, "threads": torch.get_num_threads()}}, os.path.join(GOLD, "sdxl_config3_b8.pt"))
+    net16 = half_unet(cfg, sd)
+    del sd
+    tr16 = []
+    lat16, _ = mg.ref_sample(net16, cfg, c, uc, seeds, 128, steps, "DPM++ 2M", trace=tr16)
+    del net16
+    fl = {"sdxl_config3_b8.pt:latent": metrics(lat16, lat), "sdxl_config3_b8.pt:denoised0": metrics(tr16[0], trace[0])}
+    # one entry per image as well: the test holds every image against the WORST per-image floor (images are independent realisations)
+    per = [metrics(lat16[i:i + 1], lat[i:i + 1]) for i in range(batch)]
+    fl["sdxl_config3_b8.pt:latent_per_image_worst"] = _worst(per)
+    update(fl)
+
+
 def _worst(ms):
     return {k: max(m[k] for m in ms) for k in ("max_rel", "pp_rel", "rms_rel")}
 
@@ -556,6 +588,8 @@ def main():
         gen_flux_width()
     if a.only == "config3":
         gen_config3(a.steps)
+    if a.only == "config3_b8":
+        gen_config3_b8(min(a.steps, 8) if a.steps != 30 else 5)
 
 
 if __name__ == "__main__":

@@ -11,8 +11,25 @@ import subprocess
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# FMX_LIB: developer hook for tools/ (timing-ablation builds of the same library); the product path never sets it
-LIB_PATH = os.environ.get("FMX_LIB") or os.path.join(_HERE, "libfmx_gfx950.so")
+
+
+def knob(name, default=None):
+    """Development A/B knob: the value of environment variable `name` ONLY in a process that also carries FMX_ALLOW_KNOBS=1 (the same rule as
+    fmx_knob() inside the library) -- a stray FMX_* variable must not change what a production process runs.  Knobs that took effect are recorded
+    in ACTIVE_KNOBS (bench.py prints them, together with the library's own list, into its line)."""
+    v = os.environ.get(name)
+    if v is None:
+        return default
+    if os.environ.get("FMX_ALLOW_KNOBS") != "1":
+        IGNORED_KNOBS[name] = v
+        return default
+    ACTIVE_KNOBS[name] = v
+    return v
+
+
+ACTIVE_KNOBS, IGNORED_KNOBS = {}, {}
+# FMX_LIB: developer hook for tools/ (timing builds of the same library, tools/build_patched*.sh); a knob like the others
+LIB_PATH = knob("FMX_LIB") or os.path.join(_HERE, "libfmx_gfx950.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 _lock = threading.Lock()
@@ -59,6 +76,7 @@ _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SIGNATURES = {
     "fmx_abi_version": [],
     "fmx_device_info": [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int],
+    "fmx_active_knobs": [C.c_char_p, C.c_int, C.c_int],
     "fmx_gemm_conv_f16": [C.POINTER(GemmArgs), _vp],
     "fmx_gemm_linear_rowstats_f16": [C.POINTER(GemmArgs), _vp, _i32, C.POINTER(C.c_int32), _vp],
     "fmx_layernorm_rowstats_finalize": [_vp, _i32, _i64, _i32, _f32, _vp, _vp],
@@ -156,10 +174,29 @@ def lib():
             fn.restype = C.c_int
         handle.fmx_last_error.argtypes = []
         handle.fmx_last_error.restype = C.c_char_p
+        try:
+            handle.fmx_build_info.argtypes = []
+            handle.fmx_build_info.restype = C.c_char_p
+        except AttributeError as e:
+            raise FmxError(f"symbol fmx_build_info missing from {LIB_PATH}") from e
         if handle.fmx_abi_version() != 7:
             raise FmxError("libfmx ABI version mismatch")
         _lib = handle
     return _lib
+
+
+def build_info():
+    """{'src': hash of the kernel sources the LOADED binary was built from, 'abi': ..., 'arch': ...} (fmx_build_info)."""
+    return dict(kv.split("=", 1) for kv in lib().fmx_build_info().decode().split())
+
+
+def active_knobs(ignored=False):
+    """Development knobs that took effect in this process (library side + Python side), or -- ignored=True -- that were set without FMX_ALLOW_KNOBS=1."""
+    buf = C.create_string_buffer(2048)
+    check(lib().fmx_active_knobs(buf, len(buf), 1 if ignored else 0), "fmx_active_knobs")
+    out = dict(kv.split("=", 1) for kv in buf.value.decode().split(",") if "=" in kv)
+    out.update(IGNORED_KNOBS if ignored else ACTIVE_KNOBS)
+    return out
 
 
 def check(code, what=""):

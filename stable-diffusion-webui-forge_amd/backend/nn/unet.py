@@ -29,6 +29,7 @@ import itertools
 import torch
 
 from ... import hipops as ops
+from ..._lib import knob as _knob
 from ...runtime import Arena, ArenaOverflow
 from .layout import ConvIn, Down, Res, SpatialT, Up, unet_layout
 
@@ -80,8 +81,8 @@ class GroupNorm(_Layer):
     forward = __call__
 
 
-_LN_FOLD = os.environ.get("FMX_LN_FOLD", "1") != "0"   # A/B knob: 0 keeps the LayerNorm kernels in front of attn2.to_q / ff.net.0
-_LN_FOLD1 = os.environ.get("FMX_LN_FOLD1", "1") != "0"  # A/B knob: 0 keeps norm1 as a kernel (round 2) while norm2 / norm3 stay folded
+_LN_FOLD = _knob("FMX_LN_FOLD", "1") != "0"   # A/B knob: 0 keeps the LayerNorm kernels in front of attn2.to_q / ff.net.0
+_LN_FOLD1 = _knob("FMX_LN_FOLD1", "1") != "0"  # A/B knob: 0 keeps norm1 as a kernel (round 2) while norm2 / norm3 stay folded
 
 
 def _fold_layernorm(wt, bias, gamma, beta):

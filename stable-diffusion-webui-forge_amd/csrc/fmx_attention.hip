@@ -1583,7 +1583,7 @@ int launch_attn_short(AttnParams p, hipStream_t st) {
   if (!slots) {
     int dev = 0, cus = 256;
     if (!(hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)) cus = 256;
-    const char* e = getenv("FMX_ATTN_SHORT_WGS");   // A/B knob: workgroups per CU the launch is sized for (the kernel allows 4)
+    const char* e = fmx_knob("FMX_ATTN_SHORT_WGS");   // A/B knob: workgroups per CU the launch is sized for (the kernel allows 4)
     const int per_cu = e ? atoi(e) : 4;
     slots = (per_cu >= 1 && per_cu <= 4 ? per_cu : 4) * cus;
   }
@@ -1845,14 +1845,14 @@ int launch_attn_v2(AttnParams p, hipStream_t st) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
       slots = (DP == 64 ? 2 : 1) * cus;   // 4-wave workgroups per CU at this kernel's register count
-    const char* sp = getenv("FMX_ATTN_SPLIT");   // A/B knob: 0 disables the key-split workgroups
+    const char* sp = fmx_knob("FMX_ATTN_SPLIT");   // A/B knob: 0 disables the key-split workgroups
     allow_split = sp ? atoi(sp) : 1;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_q64v2_kernel<6, DP>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * smem);
     // A/B knob (tools/bench_kernels.py attn): FMX_ATTN_VARIANT=1 selects the first-generation kernels (d_head 64: round 1's 823 / 729 TFLOP/s at
     // N = 4096 / 1024; d_head 128: the generic 32-query kernel), 0 (default) the second-generation ones, 2 the wave-specialised kernel for
     // d_head 64 as well (d_head 128 uses it by default; at 64 it is slower than the symmetric kernel: 832 vs 1025 TFLOP/s at N = 4096), 3 the
     // symmetric 64-query kernel for d_head 128 too.
-    const char* e = getenv("FMX_ATTN_VARIANT");
+    const char* e = fmx_knob("FMX_ATTN_VARIANT");
     variant = e ? atoi(e) : 0;
     if (DP == 64) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_q64_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   }
@@ -1898,7 +1898,7 @@ int launch_attn_v2(AttnParams p, hipStream_t st) {
         // A/B knob: 0 = the looped 64-query kernels for short contexts as well (round 2), 1 = attn_short_kernel (lane-owned Q loads / O stores),
         // 2 (default) = attn_short2_kernel (Q and O in whole lines through LDS).  In a graph, every launch on its own Q / O tensors
         // (profiles/r08e): batch 16 x 20 heads x 1024 queries 32.4 / 31.3 / 27.5 us, 16 x 10 x 4096 queries 53.7 / 60.1 / 46.0 us.
-        const char* e7 = getenv("FMX_ATTN_SHORT");
+        const char* e7 = fmx_knob("FMX_ATTN_SHORT");
         sk = e7 ? atoi(e7) : 2;
       }
       if (sk == 2) {
@@ -1914,7 +1914,7 @@ int launch_attn_v2(AttnParams p, hipStream_t st) {
         // attn, batch 16): 77 keys 31.1 -> 26.7 us (1024 queries, 20 heads) and 51.6 -> 43.4 us (4096 queries, 10 heads); 1024 keys 101.4 ->
         // 99.0 us; 4096 keys 692.6 -> 717.0 us -- with many key tiles the SIMD's two waves already overlap each other and the vector pipe is
         // the bound either way, with two tiles the per-wave chain is what counts.
-        const char* e6 = getenv("FMX_ATTN_V3");
+        const char* e6 = fmx_knob("FMX_ATTN_V3");
         v3 = e6 ? atoi(e6) : 1;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_q64v3_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * smem / 2);
       }

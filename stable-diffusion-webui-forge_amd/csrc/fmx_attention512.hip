@@ -259,7 +259,7 @@ extern "C" int fmx_attention_single_head512_f16(const void* q, int64_t q_bs, int
     // A/B knob: 4 (default) = eight waves of 128 channels, 2 = four waves of 256 channels.  Measured (8 x 16 384 tokens, tools/bench_kernels.py attn512,
     // profiles/r08p): 8.12 ms vs 9.67 ms -- with one wave per SIMD nothing covers the fragment-read and exchange latencies around the two barriers of a
     // step; the LDS traffic saved (-40 %) does not pay for it.
-    const char* e = getenv("FMX_ATTN512_SLICES");
+    const char* e = fmx_knob("FMX_ATTN512_SLICES");
     slices = (e && atoi(e) == 2) ? 2 : 4;
   }
   if (slices == 4) hipLaunchKernelGGL(attn512_kernel<4>, dim3(p.qtiles * batch), dim3(512), smem, (hipStream_t)stream, p);

@@ -36,6 +36,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 int fmx_set_error(int code, const char* fmt, ...);
 
+// Development A/B knobs (FMX_GEMM_MFMA, FMX_ATTN_SPLIT, ...): an environment variable changes which kernel a launch takes ONLY when the process
+// also carries FMX_ALLOW_KNOBS=1 -- a stray variable must not change what a production process runs.  Returns the value of `name` when knobs are
+// allowed and the variable is set, else nullptr; every knob that took effect is listed by fmx_active_knobs() (bench.py prints them into its line).
+const char* fmx_knob(const char* name);
+
 #define FMX_REQUIRE(cond, ...)                         \
   do {                                                 \
     if (!(cond)) return fmx_set_error(FMX_E_BADARG, __VA_ARGS__); \

@@ -537,7 +537,7 @@ static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, i
   // tools/bench_kernels.py splitk sweeps).  Needs the caller's workspace (fmx_gemm_args.workspace) and the buffer-descriptor path.
   constexpr long TICKET_BYTES = 65536;
   const long ws_floats = (a->workspace && a->workspace_bytes > TICKET_BYTES) ? (a->workspace_bytes - TICKET_BYTES) / 4 : 0;
-  const char* force_split_env = getenv("FMX_GEMM_SPLITK");   // A/B / test knob, read per call: 0 = never split, S >= 2 = always S (where possible)
+  const char* force_split_env = fmx_knob("FMX_GEMM_SPLITK");   // A/B / test knob, read per call: 0 = never split, S >= 2 = always S (where possible)
   const int force_split = force_split_env ? atoi(force_split_env) : -1;
   const bool split_ok = ws_floats > 0 && fits32 && a->out_f32 <= 0 && force_split != 0;
   auto split_fits = [&](int bm, int bn, int S) {
@@ -561,7 +561,7 @@ static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, i
   if (a->out_f32 < 0) { sel = (-a->out_f32 - 1) % 16; best_s = 1; }  // test hook: force a tile shape (out_f32 = -1..-9 -> fp16 out)
   if (split_ok && force_split >= 2 && (sel == 0 || sel == 1) && split_fits(128, sel == 0 ? 128 : 64, force_split)) best_s = force_split;
   if (best_s > 1 && sel != 0 && sel != 1) best_s = 1;
-  if (getenv("FMX_GEMM_DEBUG"))
+  if (fmx_knob("FMX_GEMM_DEBUG"))
     fprintf(stderr, "fmx_gemm: M=%d N=%d K=%d conv=%d -> tile id %d, split-K %d (workspace %ld floats, fits32 %d)\n", p.M, p.nout, p.kt * 64, (int)conv,
             sel + 1, best_s, ws_floats, (int)fits32);
   FMX_REQUIRE(sel <= 8, "gemm: unknown tile id");

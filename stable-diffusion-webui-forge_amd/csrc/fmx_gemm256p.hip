@@ -241,9 +241,6 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   constexpr int WROWS = MI * 32;                           // output rows of a wave
   constexpr int STAGE_BYTES = G::STAGE_BYTES, A_BYTES = G::A_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-#ifdef FMX_ABLATE
-  const unsigned long long rt_entry = __builtin_amdgcn_s_memrealtime();
-#endif
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / G::WN, wn = wave % G::WN;
@@ -397,9 +394,6 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
     constexpr int idx = decltype(IDX)::value;
     if constexpr (idx < NP) {
       char* sbase = smem + buf * STAGE_BYTES + wave * 1024;
-#ifdef FMX_ABLATE_DMA   // timing-only build (WRONG results): only the first two K-tiles are fetched, later pieces are not issued at all (the stages keep
-      if (c.t >= 2) return;   // their random data: a zero fill would change the operands' power) -- what does the L2 -> LDS stream of the K loop cost?
-#endif
       const bool live = c.t < kt_live;  // uniform
       if constexpr (idx < NPA) {
         constexpr int s = idx;
@@ -445,13 +439,6 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
     const char* sb = sa + A_BYTES;
 #pragma unroll
     for (int i = 0; i < MI; ++i) af[fb][i] = *reinterpret_cast<const f16x8*>(sa + lds_off(wm * (MI * 32) + i * 32 + li, ks * 2 + hi));
-#ifdef FMX_ABLATE_LDS_READS   // timing-only build (WRONG results): weight fragments read for k-step 0 only -- what do the K loop's LDS reads cost?
-    if (ks != 0) {
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) wf[fb][j] = wf[fb ^ 1][j];
-      return;
-    }
-#endif
 #pragma unroll
     for (int j = 0; j < NJ; ++j) wf[fb][j] = *reinterpret_cast<const f16x8*>(sb + lds_off(wn * (NJ * 32) + j * 32 + li, ks * 2 + hi));
   };
@@ -509,9 +496,6 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   if constexpr (MF == 32) read_frags(0, 0, 0);
   // iteration t:  k-step 0: + pieces 3-5 of tile t+1   k-step 1: + pieces 6.. of tile t+1   k-step 2: nothing
   //               wait + barrier                          k-step 3: + pieces 0-2 of tile t+2 (into the stage just released)
-#ifdef FMX_ABLATE
-  const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
-#endif
   if constexpr (MF == 16) {
     // ---- 16x16x32 K loop: two k-steps of 32 per K-tile, MIB x NJB = 40 MFMAs each, every fragment SINGLE-buffered (216 registers with the
     //      accumulators, as the 32x32x16 loop).  A k-step runs activation-major in two halves of the weight fragments:
@@ -648,9 +632,6 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   }
 #undef FMX_INTERLEAVE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail's zero-fill pieces must land before the LDS is released
-#ifdef FMX_ABLATE  // timing build only (tools/clock_gemm.py): K-loop shader cycles / 100 MHz ticks of workgroup 8
-  const unsigned dbg_cyc = (unsigned)(__builtin_amdgcn_s_memtime() - clk0), dbg_rt = (unsigned)(__builtin_amdgcn_s_memrealtime() - rt0);
-#endif
 
   // ---- epilogue: through LDS, so that every global access is row-contiguous.  The MFMA leaves a lane with 4-channel runs of
   //      ONE pixel; stored as they are (even widened to 16 B by a half-wave swap) every store
@@ -703,9 +684,6 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
           for (int q4 = 0; q4 < 4; ++q4) {
             const int chunk = j * 8 + q4 * 2 + hi;
             const accv& a = acc[i][j];
-#ifdef FMX_ABLATE_EPI_LDS   // timing-only build (WRONG results): half of the transpose's LDS writes -- what do they cost?
-            if (q4 & 1) continue;
-#endif
             *reinterpret_cast<f32x4*>(my + li * RB + ((chunk ^ (li & 7)) << 4)) = f32x4{a[q4 * 4], a[q4 * 4 + 1], a[q4 * 4 + 2], a[q4 * 4 + 3]};
           }
       } else {   // 16 x 16 blocks: lane = pixel l16, its 4 registers = channels j*16 + kg*4 + [0, 4) -> one 16-byte chunk per block
@@ -865,19 +843,6 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
                                                  ep.out + colc, ep.ld_out);
     });
   }
-#ifdef FMX_ABLATE
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (wg == 8 && tid == 0) {  // overwrite the first words of this tile's output
-    unsigned* dbg = reinterpret_cast<unsigned*>(reinterpret_cast<f16*>(p.out) + (size_t)m0 * p.ld_out + (p.act == FMX_ACT_GEGLU ? n0 >> 1 : n0));
-    dbg[0] = dbg_cyc;
-    dbg[1] = dbg_rt;
-    dbg[2] = (unsigned)p.kt;
-    dbg[3] = 0x5eed5eedu;
-    dbg[4] = (unsigned)(rt0 - rt_entry);                                  // prologue, 10 ns ticks
-    dbg[5] = (unsigned)(__builtin_amdgcn_s_memrealtime() - rt0) - dbg_rt;  // epilogue incl. store drain up to here
-  }
-#endif
   // every wave is done with its epilogue slice of the LDS before the next tile's LDS-DMA pieces (any wave's) land in it
   if (lid + (int)gridDim.x < nwg) __syncthreads();
   if constexpr (XT) {
@@ -897,7 +862,7 @@ static int persistent_grid(int tiles) {
   if (!cus) {
     int dev = 0, n = 256;
     if (!(hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n >= 8)) n = 256;
-    const char* e = getenv("FMX_GEMM_PERSIST");
+    const char* e = fmx_knob("FMX_GEMM_PERSIST");
     cus = (e && atoi(e) == 0) ? (1 << 30) : (n & ~7);
   }
   return tiles < cus ? tiles : cus;
@@ -907,7 +872,7 @@ static int persistent_grid(int tiles) {
 static int xtile_on() {
   static int v = -1;
   if (v < 0) {
-    const char* e = getenv("FMX_GEMM_XTILE");
+    const char* e = fmx_knob("FMX_GEMM_XTILE");
     v = (e && atoi(e) == 0) ? 0 : 1;
   }
   return v;
@@ -975,7 +940,7 @@ int fmx_launch_gemm256p(const GemmParams& p, bool conv, int bm, int bn, hipStrea
   if (!mf) {
     // A/B knob: 32 = v_mfma_f32_32x32x16 K loops everywhere (rounds 1-2); 16 (default) = v_mfma_f32_16x16x32 for the LINEAR GEMMs of the 256 x 320 tile.
     // Same box, SDXL 1024^2 batch 8 (profiles/r08r): 110.76 -> 107.27 ms per step, chip clock of the timed steps 1.91 -> 1.99 GHz.
-    const char* e = getenv("FMX_GEMM_MFMA");
+    const char* e = fmx_knob("FMX_GEMM_MFMA");
     mf = (e && atoi(e) == 32) ? 32 : 16;
   }
   if (mf == 16) {
@@ -984,7 +949,7 @@ int fmx_launch_gemm256p(const GemmParams& p, bool conv, int bm, int bn, hipStrea
     if (p.ln_col_ab) return launch_ln_swapped<16>(p, st);
     static int fa = -1;
     if (fa < 0) {
-      const char* e2 = getenv("FMX_CONV_FASTADDR");   // A/B knob: 0 = the general address form for every convolution of the 256-row tiles (round 2)
+      const char* e2 = fmx_knob("FMX_CONV_FASTADDR");   // A/B knob: 0 = the general address form for every convolution of the 256-row tiles (round 2)
       fa = e2 ? atoi(e2) : 1;
     }
     if (fa && conv && p.c1 == 0 && p.up_h == 0 && p.kh <= 3) {   // single source, no resize-on-load: the bit-mask address form
@@ -1001,7 +966,7 @@ int fmx_launch_gemm256p(const GemmParams& p, bool conv, int bm, int bn, hipStrea
   if (p.ln_col_ab) return launch_ln_swapped<32>(p, st);
   static int sched = -1;
   if (sched < 0) {
-    const char* e = getenv("FMX_GEMM_SCHED");   // A/B knob (tools/bench_kernels.py gemmsched): force one DMA issue schedule on the 256x320 tile
+    const char* e = fmx_knob("FMX_GEMM_SCHED");   // A/B knob (tools/bench_kernels.py gemmsched): force one DMA issue schedule on the 256x320 tile
     sched = e ? atoi(e) + 1 : 0;
   }
   if (sched && bm == 256 && bn == 320 && !p.stats)

@@ -317,7 +317,7 @@ extern "C" int fmx_groupnorm_apply_f16(const void* x0, const void* x1, int32_t c
     // A/B knob: activation bytes per block.  16 KB = one round of 4 x 16 bytes per thread: many short blocks beat few long ones on every
     // shape of the SDXL UNet and VAE (in a graph, each launch on its own tensors, profiles/r08l: 128^2 x 320 91 -> 76 us, 32^2 x 1280 34 -> 28 us,
     // 1024^2 x 128 818 -> 745 us against round 2's 64 KB; 8 / 12 KB and streaming loads are level or mixed)
-    const char* e = getenv("FMX_GN_BLOCK_KB");
+    const char* e = fmx_knob("FMX_GN_BLOCK_KB");
     ppb_bytes = (e ? atoi(e) : 16) * 512;        // (elements: 2 bytes each)
   }
   int ppb = (ppb_bytes + C - 1) / C;
@@ -334,7 +334,7 @@ extern "C" int fmx_groupnorm_apply_f16(const void* x0, const void* x1, int32_t c
   }
   static int variant = -1;
   if (variant < 0) {
-    const char* e = getenv("FMX_GN_VARIANT");   // A/B knob (tools/bench_kernels.py gnapply): 0 = 4 loads in flight per thread, 1 = 8, 2 = 4 streaming (nt) loads, 3 = 8 nt
+    const char* e = fmx_knob("FMX_GN_VARIANT");   // A/B knob (tools/bench_kernels.py gnapply): 0 = 4 loads in flight per thread, 1 = 8, 2 = 4 streaming (nt) loads, 3 = 8 nt
     variant = e ? atoi(e) : 0;
   }
 #define FMX_GN_LAUNCH(S, U, N)                                                                                                                   \

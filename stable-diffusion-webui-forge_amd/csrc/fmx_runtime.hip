@@ -21,6 +21,50 @@ int fmx_set_error(int code, const char* fmt, ...) {
     if (_e != hipSuccess) return fmx_set_error((int)_e, "%s: %s", what, hipGetErrorString(_e)); \
   } while (0)
 
+// ---- development knobs: honoured only under FMX_ALLOW_KNOBS=1, and recorded -------------------------------------------------------------------
+#include <stdlib.h>
+
+#include <mutex>
+#include <string>
+
+static std::mutex g_knob_mu;
+static std::string g_knobs_active, g_knobs_ignored;
+
+static void knob_note(std::string& list, const char* name, const char* value) {
+  const std::string item = std::string(name) + "=" + value;
+  if (("," + list + ",").find("," + item + ",") != std::string::npos) return;
+  if (!list.empty()) list += ",";
+  list += item;
+}
+
+const char* fmx_knob(const char* name) {
+  const char* v = getenv(name);
+  if (!v) return nullptr;
+  const char* a = getenv("FMX_ALLOW_KNOBS");
+  const bool allow = a && atoi(a) == 1;
+  std::lock_guard<std::mutex> lk(g_knob_mu);
+  knob_note(allow ? g_knobs_active : g_knobs_ignored, name, v);
+  return allow ? v : nullptr;
+}
+
+extern "C" int fmx_active_knobs(char* buf, int buf_len, int ignored) {
+  FMX_REQUIRE(buf && buf_len > 0, "active_knobs: null buffer");
+  std::lock_guard<std::mutex> lk(g_knob_mu);
+  const std::string& s = ignored ? g_knobs_ignored : g_knobs_active;
+  strncpy(buf, s.c_str(), (size_t)buf_len - 1);
+  buf[buf_len - 1] = 0;
+  return FMX_OK;
+}
+
+// FMX_SRC_HASH: csrc/src_hash.py over the kernel sources at build time (csrc/Makefile); bench.py compares it with the hash a committed PMC summary
+// was taken on, so a stale .so beside newer sources is not credited with their measurements
+#ifndef FMX_SRC_HASH
+#define FMX_SRC_HASH "unknown"
+#endif
+#define FMX_STR2(x) #x
+#define FMX_STR(x) FMX_STR2(x)
+extern "C" const char* fmx_build_info(void) { return "src=" FMX_SRC_HASH " abi=" FMX_STR(FMX_ABI_VERSION) " arch=gfx950"; }
+
 extern "C" int fmx_abi_version(void) { return FMX_ABI_VERSION; }
 extern "C" const char* fmx_last_error(void) { return g_err; }
 

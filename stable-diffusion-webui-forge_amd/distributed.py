@@ -16,6 +16,13 @@ def world():
     return 0, 1
 
 
+def group_active():
+    """True when a default process group exists -- also one of a single rank: the collectives below then RUN (a world-1 broadcast / gather is a
+    valid collective), which is how the RCCL code path is exercised on a one-GPU box (bench.py's `rccl_world1` leg, tests/test_gpu_rccl.py).  Without a
+    process group they are the identity."""
+    return dist.is_available() and dist.is_initialized()
+
+
 def shard_range(total, rank, world_size):
     """Contiguous shard [lo, hi) of `total` images for `rank`; earlier ranks take the remainder."""
     base, rem = divmod(total, world_size)
@@ -44,7 +51,7 @@ def broadcast_conditioning(cond, uncond, device, src=0):
     """Rank `src` holds (cond, uncond) for the GLOBAL batch; every rank returns them with the same structure (a tensor, a dict of
     tensors, or None for an absent uncond at cfg_scale 1).  Each of the two carries its own metadata."""
     rank, ws = world()
-    if ws == 1:
+    if not group_active():
         return cond, uncond
     meta = [None]
     if rank == src:
@@ -85,7 +92,7 @@ def gather_batch(local, batch, n_iter=1, dst=0):
     """Gather of a job of `n_iter` iterations of `batch` images: rank r holds, iteration-major, its share shard_range(batch, r, world) of every
     iteration ([n_iter * b_r, ...]); rank `dst` returns [n_iter * batch, ...] in the order of the single-process job, other ranks None."""
     rank, ws = world()
-    if ws == 1:
+    if not group_active():
         return local
     per = -(-batch // ws) * n_iter
     pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)

@@ -77,7 +77,7 @@ class KernelProfiler:
 
 # developer hook: FMX_DEBUG_NAN=1 synchronises after every GEMM / norm / attention launch (outside graph capture) and raises at the first
 # non-finite output -- pinpoints the producing kernel; never set in production (it serialises the stream)
-_DEBUG_NAN = os.environ.get("FMX_DEBUG_NAN") == "1"
+_DEBUG_NAN = _lib.knob("FMX_DEBUG_NAN") == "1"
 
 
 def _dbg(what, **tensors):
@@ -167,7 +167,7 @@ class GnStats:
 
 # A/B knob (tools/bench_kernels.py, bench.py --breakdown): FMX_GN_FUSED_STATS=0 makes conv_gemm(stats=True) return no statistics, so that
 # every GroupNorm runs its own statistics pass as in round 1
-_FUSED_STATS = os.environ.get("FMX_GN_FUSED_STATS", "1") != "0"
+_FUSED_STATS = _lib.knob("FMX_GN_FUSED_STATS", "1") != "0"
 
 
 def conv_gemm(x, wgt, nout, *, x1=None, n=None, h=None, w=None, kh=1, stride=1, pad=0, up=None, bias=None,

@@ -355,23 +355,32 @@ def process_images_sharded(p, gather_images=True, dst=0) -> Processed:
     from .. import distributed as fdist
     import torch.distributed as dist
     rank, ws = fdist.world()
-    if ws == 1:
+    if not fdist.group_active():
         return process_images(p)
-    if isinstance(p, StableDiffusionProcessingImg2Img):
-        raise NotImplementedError("process_images_sharded splits txt2img jobs; shard an img2img job by its init images on the caller's side")
-    if p.prompt is not None and p.c is None:
-        if rank == dst:
-            p.setup_conds()      # prompts are encoded once, on the rank that owns the job
-    for name, cnd in (("c", p.c), ("uc", p.uc), ("hr_c", p.hr_c), ("hr_uc", p.hr_uc)):
-        if rank == dst and cnd is not None and not isinstance(cnd, (torch.Tensor, dict)):
-            raise NotImplementedError(f"p.{name} is a {type(cnd).__name__}: the sharded entry broadcasts ready conditioning tensors "
-                                      f"(prompt-editing schedules are host objects; reconstruct them per rank or pass tensors)")
     dev = p.sd_model.device
     B, total = p.batch_size, p.batch_size * p.n_iter
-    # ---- 1. job header + conditioning from the owner ----------------------------------------------------------------------------------
-    header = [(_job_seeds(p, total), type(p.c).__name__ if p.c is not None else None) if rank == dst else None]
+    # ---- 1. job header + conditioning from the owner.  Everything that can fail on the owner BEFORE the first collective (prompt encoding, the
+    #      argument checks) runs inside the try: the header then carries the error and EVERY rank raises it -- an owner that raised on its own
+    #      would leave the other ranks blocked in the broadcast for ever. --------------------------------------------------------------------------
+    header = [None]
+    if rank == dst:
+        try:
+            if isinstance(p, StableDiffusionProcessingImg2Img):
+                raise NotImplementedError("process_images_sharded splits txt2img jobs; shard an img2img job by its init images on the caller's side")
+            if p.prompt is not None and p.c is None:
+                p.setup_conds()      # prompts are encoded once, on the rank that owns the job
+            for name, cnd in (("c", p.c), ("uc", p.uc), ("hr_c", p.hr_c), ("hr_uc", p.hr_uc)):
+                if cnd is not None and not isinstance(cnd, (torch.Tensor, dict)):
+                    raise NotImplementedError(f"p.{name} is a {type(cnd).__name__}: the sharded entry broadcasts ready conditioning tensors "
+                                              f"(prompt-editing schedules are host objects; reconstruct them per rank or pass tensors)")
+            header = [("ok", _job_seeds(p, total), type(p.c).__name__ if p.c is not None else None)]
+        except Exception as e:   # noqa: BLE001 -- re-raised on every rank below
+            header = [("error", type(e).__name__, str(e))]
     dist.broadcast_object_list(header, src=dst)
-    (all_seeds, all_subseeds), c_kind = header[0]
+    if header[0][0] == "error":
+        _, ename, emsg = header[0]
+        raise (NotImplementedError if ename == "NotImplementedError" else RuntimeError)(f"process_images_sharded, owner rank {dst}: {ename}: {emsg}")
+    _, (all_seeds, all_subseeds), c_kind = header[0]
     c, uc = fdist.broadcast_conditioning(p.c if rank == dst else None, p.uc if rank == dst else None, dev, src=dst)
     hr_c, hr_uc = fdist.broadcast_conditioning(p.hr_c if rank == dst else None, p.hr_uc if rank == dst else None, dev, src=dst)
     lo, hi = fdist.shard_range(B, rank, ws)
@@ -389,17 +398,22 @@ def process_images_sharded(p, gather_images=True, dst=0) -> Processed:
             return out
         return cnd.index_select(0, idx.to(cnd.device)).contiguous()
 
-    # ---- 2. this rank's share through the ordinary single-device job ------------------------------------------------------------------
+    # ---- 2. this rank's share through the ordinary single-device job.  A rank whose job fails (out of memory, a kernel error) still takes part in
+    #      the next collective and reports the failure there, so that every rank raises instead of the healthy ones waiting for ever ----------------
     local = None
+    failure = None
     if hi > lo:
         import copy
-        q = copy.copy(p)
-        q.batch_size = hi - lo
-        q.c, q.uc, q.hr_c, q.hr_uc = take(c), take(uc), take(hr_c), take(hr_uc)
-        q.prompt = None
-        shared.sd_model = p.sd_model
-        local = process_images_inner(q, seed_plan=([all_seeds[i] for i in mine], [all_subseeds[i] for i in mine]))
-        p.sampler, p.rng = q.sampler, q.rng
+        try:
+            q = copy.copy(p)
+            q.batch_size = hi - lo
+            q.c, q.uc, q.hr_c, q.hr_uc = take(c), take(uc), take(hr_c), take(hr_uc)
+            q.prompt = None
+            shared.sd_model = p.sd_model
+            local = process_images_inner(q, seed_plan=([all_seeds[i] for i in mine], [all_subseeds[i] for i in mine]))
+            p.sampler, p.rng = q.sampler, q.rng
+        except Exception as e:   # noqa: BLE001
+            failure = f"rank {rank}: {type(e).__name__}: {e}"
     p.all_seeds, p.all_subseeds = all_seeds, all_subseeds
     # ---- 3. gather on the owner ---------------------------------------------------------------------------------------------------------
     want_images = bool(gather_images and p.do_decode and p.sd_model.forge_objects.vae is not None)
@@ -407,7 +421,11 @@ def process_images_sharded(p, gather_images=True, dst=0) -> Processed:
     u8_local = _to_u8(local.images, dev) if (local is not None and want_images) else None
     # a rank with no image of this job (batch_size < world) still takes part in the gather: it learns the per-image shapes from the others
     shapes = [None] * ws
-    dist.all_gather_object(shapes, None if local is None else (tuple(lat_local.shape[1:]), None if u8_local is None else tuple(u8_local.shape[1:])))
+    mine_msg = ("error", failure) if failure else (None if local is None else (tuple(lat_local.shape[1:]), None if u8_local is None else tuple(u8_local.shape[1:])))
+    dist.all_gather_object(shapes, mine_msg)
+    errors = [sh[1] for sh in shapes if sh is not None and sh[0] == "error"]
+    if errors:
+        raise RuntimeError("process_images_sharded: " + "; ".join(errors))
     lat_shape, img_shape = next(sh for sh in shapes if sh is not None)
     if lat_local is None:
         lat_local = torch.zeros((0,) + lat_shape, device=dev)

@@ -46,7 +46,7 @@ def test_no_undeclared_fmx_exports(built):
 
 def test_ctypes_binding_matches_header(built):
     declared = set(declared_symbols())
-    bound = set(_lib.SIGNATURES) | {"fmx_last_error"}
+    bound = set(_lib.SIGNATURES) | {"fmx_last_error", "fmx_build_info"}
     assert declared == bound, (sorted(declared - bound), sorted(bound - declared))
     L = _lib.lib()
     assert L.fmx_abi_version() == 7
@@ -74,3 +74,26 @@ def test_missing_library_fails_loudly(tmp_path, monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.FmxError):
         _lib.lib()
+
+
+def test_build_info_carries_the_hash_of_the_sources_on_disk(built):
+    """fmx_build_info(): the .so knows which kernel sources it was built from (csrc/Makefile bakes csrc/src_hash.py's value in); after build() it
+    equals the hash of the tree -- bench.py credits a committed PMC summary to THE BINARY's hash, so a stale .so cannot borrow newer measurements."""
+    import importlib.util
+    info = _lib.build_info()
+    spec = importlib.util.spec_from_file_location("fmx_src_hash", os.path.join(ROOT, "stable-diffusion-webui-forge_amd", "csrc", "src_hash.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert info["abi"] == "7" and info["arch"] == "gfx950"
+    assert re.fullmatch(r"[0-9a-f]{16}", info["src"]) and info["src"] == mod.kernel_source_hash()
+
+
+def test_python_side_knobs_need_the_allow_flag(monkeypatch):
+    monkeypatch.delenv("FMX_ALLOW_KNOBS", raising=False)
+    monkeypatch.setenv("FMX_LN_FOLD", "0")
+    assert _lib.knob("FMX_LN_FOLD", "1") == "1" and _lib.IGNORED_KNOBS.get("FMX_LN_FOLD") == "0"
+    monkeypatch.setenv("FMX_ALLOW_KNOBS", "1")
+    assert _lib.knob("FMX_LN_FOLD", "1") == "0" and _lib.ACTIVE_KNOBS.get("FMX_LN_FOLD") == "0"
+    _lib.ACTIVE_KNOBS.clear(); _lib.IGNORED_KNOBS.clear()
+    buf = ctypes.create_string_buffer(64)
+    assert _lib.lib().fmx_active_knobs(buf, 64, 0) == 0 and _lib.lib().fmx_active_knobs(None, 0, 0) != 0

@@ -93,6 +93,7 @@ def test_split_k_matches_and_is_deterministic(splits, tile, monkeypatch):
     both tile shapes: linear with bias + in-place residual and ragged M / N, GEGLU, a 3x3 convolution with a per-image row vector; equal to the
     fp32 reference within the usual tolerance, bit-identical run to run (no floating-point atomics), and the arrival counters are left zero
     (a second launch works)."""
+    monkeypatch.setenv("FMX_ALLOW_KNOBS", "1")
     monkeypatch.setenv("FMX_GEMM_SPLITK", str(splits))
     m, n, k = 1000, 328, 1280
     x, w, b = rnd(m, k, seed=30), rnd(n, k, scale=1 / math.sqrt(k), seed=31), rnd(n, seed=32)
@@ -118,6 +119,7 @@ def test_split_k_matches_and_is_deterministic(splits, tile, monkeypatch):
     refc = (F.conv2d(xc.permute(0, 3, 1, 2).float(), wt.float(), bc.float(), padding=1) + emb.float()[:, :, None, None]).permute(0, 2, 3, 1)
     oc = ops.conv_gemm(xc, wt.permute(0, 2, 3, 1).reshape(co, -1).contiguous(), co, kh=3, pad=1, bias=bc, rowvec=emb, force_tile=tile)
     close(oc.reshape(refc.shape), refc, 3e-3, 3e-3, f"split-K x{splits} conv")
+    monkeypatch.setenv("FMX_ALLOW_KNOBS", "1")
     monkeypatch.setenv("FMX_GEMM_SPLITK", "0")
     plain = res.clone()
     ops.linear(x, w, b, residual=plain, out=plain, ld_out=n, force_tile=tile)
@@ -135,6 +137,7 @@ def test_split_k_hand_over_under_load_is_stable(monkeypatch):
     first = {}
     for it in range(40):
         ci, splits, tile = it % 4, (2, 3, 4, 7)[(it // 4) % 4], 1 + (it // 2) % 2
+        monkeypatch.setenv("FMX_ALLOW_KNOBS", "1")
         monkeypatch.setenv("FMX_GEMM_SPLITK", str(splits))
         x, w, b = cases[ci]
         out = ops.linear(x, w, b, force_tile=tile)
@@ -143,6 +146,7 @@ def test_split_k_hand_over_under_load_is_stable(monkeypatch):
             assert torch.equal(out, first[key]), f"case {key} changed on launch {it}"
         else:
             first[key] = out.clone()
+    monkeypatch.setenv("FMX_ALLOW_KNOBS", "1")
     monkeypatch.setenv("FMX_GEMM_SPLITK", "0")
     for (ci, splits, tile), got in first.items():
         x, w, b = cases[ci]
@@ -238,7 +242,7 @@ def test_gemm_32x32x16_loop_behind_its_knob():
 import sys, math, torch, torch.nn.functional as F
 sys.path.insert(0, %r); sys.path.insert(0, %r)
 import forge_amd
-from forge_amd import hipops as ops
+from forge_amd import hipops as ops, _lib
 g = torch.Generator('cuda').manual_seed(5)
 r = lambda *s, scale=1.0: (torch.randn(*s, device='cuda', generator=g) * scale).half()
 x, w, b, res = r(4096, 1280), r(1280, 1280, scale=1280 ** -0.5), r(1280), r(4096, 1280)
@@ -254,17 +258,25 @@ out['conv'] = y.float().cpu()
 ref = {'plain': x.float() @ w.float().t() + b.float(), 'res': x.float() @ w.float().t() + b.float() + res.float()}
 for k, v in ref.items():
     assert float((out[k] - v.cpu()).abs().max()) < 2e-2, k
+out['knobs_active'], out['knobs_ignored'] = _lib.active_knobs(False), _lib.active_knobs(True)
 torch.save(out, sys.argv[1])
 """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
     import tempfile
     outs = {}
-    for mf in ("32", "16"):
+    # "stray": the knob set WITHOUT FMX_ALLOW_KNOBS=1 -- a production process must keep its default kernels (VERDICT r3 item 6)
+    for mf in ("32", "16", "stray"):
         with tempfile.NamedTemporaryFile(suffix=".pt") as f:
-            env = dict(os.environ, FMX_GEMM_MFMA=mf)
+            env = {k: v for k, v in os.environ.items() if not k.startswith("FMX_")}
+            env.update({"FMX_GEMM_MFMA": "32"} if mf == "stray" else {"FMX_GEMM_MFMA": mf, "FMX_ALLOW_KNOBS": "1"})
             subprocess.run([sys.executable, "-c", code, f.name], check=True, env=env, timeout=300)
             outs[mf] = torch.load(f.name)
+    kn = {mf: (outs[mf].pop("knobs_active"), outs[mf].pop("knobs_ignored")) for mf in outs}
+    assert kn["32"][0].get("FMX_GEMM_MFMA") == "32" and not kn["32"][1]
+    assert not kn["stray"][0] and kn["stray"][1].get("FMX_GEMM_MFMA") == "32", kn["stray"]
     for k in outs["32"]:
         close(outs["32"][k], outs["16"][k], 2e-3, 2e-3, f"32x32x16 loop vs 16x16x32 loop: {k}")
+        assert torch.equal(outs["stray"][k], outs["16"][k]), f"a knob without FMX_ALLOW_KNOBS=1 changed the kernel: {k}"
+    assert any(not torch.equal(outs["32"][k], outs["16"][k]) for k in outs["32"]), "the allowed knob selected no other kernel"
 
 
 def test_cross_tile_prefetch_matches_the_per_tile_prologue_bit_for_bit():
@@ -330,7 +342,7 @@ torch.save(out, sys.argv[1])
     outs = {}
     for knob in ("0", "1"):
         with tempfile.NamedTemporaryFile(suffix=".pt") as f:
-            subprocess.run([sys.executable, "-c", code, f.name], check=True, env=dict(os.environ, FMX_GEMM_XTILE=knob), timeout=600)
+            subprocess.run([sys.executable, "-c", code, f.name], check=True, env=dict(os.environ, FMX_GEMM_XTILE=knob, FMX_ALLOW_KNOBS="1"), timeout=600)
             outs[knob] = torch.load(f.name)
     assert outs["0"].keys() == outs["1"].keys() and len(outs["0"]) == 28
     for k in outs["0"]:

@@ -94,8 +94,10 @@ def _worker(rank, world, port, batch, n_iter, with_dict, cfg1, q):
         dist.destroy_process_group()
 
 
+# (1, ...): a process group of ONE rank still runs every collective (what tests/test_gpu_rccl.py does over RCCL on a one-GPU box);
+# (8, 64, ...): BASELINE config 4's shape -- 64 images over 8 ranks, 8 per rank
 @pytest.mark.parametrize("world,batch,n_iter,with_dict,cfg1", [(2, 5, 1, False, False), (3, 5, 2, True, False), (3, 2, 1, False, True),
-                                                               (2, 4, 2, True, True)])
+                                                               (2, 4, 2, True, True), (1, 3, 2, True, False), (8, 64, 1, True, False)])
 def test_sharded_job_equals_the_single_process_job_bit_for_bit(world, batch, n_iter, with_dict, cfg1):
     from forge_amd import distributed as fdist
     from forge_amd.modules import processing
@@ -127,3 +129,52 @@ def test_sharded_entry_is_process_images_without_a_process_group():
     a = processing.process_images_sharded(_make_job(3, 1, False))
     b = processing.process_images(_make_job(3, 1, False))
     assert torch.equal(a.latents, b.latents) and a.seeds == b.seeds
+
+
+def _failing_worker(rank, world, port, mode, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from forge_amd.modules import processing
+        p = _make_job(4, 1, False, give_conds=(rank == 0))
+        if mode == "owner" and rank == 0:
+            p.c = ["a host-side prompt-editing schedule is not a tensor"]      # refused by the owner BEFORE the first collective
+        if mode == "worker" and rank == 1:
+            def boom(*a, **k):
+                raise MemoryError("simulated out-of-memory on one rank")
+            p.sample = boom                                                       # fails INSIDE this rank's share of the job
+        try:
+            processing.process_images_sharded(p)
+            q.put((rank, "returned", ""))
+        except Exception as e:  # noqa: BLE001
+            q.put((rank, type(e).__name__, str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["owner", "worker"])
+def test_a_failure_on_one_rank_raises_on_every_rank_instead_of_hanging(mode):
+    """the owner raising before the first collective (a conditioning the sharded entry does not broadcast) or one rank failing inside its
+    share left the other ranks blocked in broadcast_object_list / all_gather_object.  Now the error travels in the header / the shape exchange."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, world, port, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in procs:
+        r = q.get(timeout=120)      # a hang shows up here
+        got[r[0]] = r[1:]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        kind, msg = got[r]
+        assert kind in ("NotImplementedError", "RuntimeError"), got
+        assert ("prompt-editing" in msg) if mode == "owner" else ("simulated out-of-memory" in msg and "rank 1" in msg), got

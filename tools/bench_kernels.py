@@ -3,6 +3,7 @@ Prints one JSON line per case: achieved TFLOP/s or GB/s (algorithmic work / HIP-
 import json
 import sys
 import os
+os.environ.setdefault("FMX_ALLOW_KNOBS", "1")   # this tool A/Bs the library's development knobs
 
 import torch
 

@@ -1,4 +1,5 @@
 #!/bin/bash
+export FMX_ALLOW_KNOBS=1   # the A/B knobs below are development switches: the library ignores them without this
 # A/B builds that need a SOURCE edit of a kernel file without touching csrc/ (bench.py keys the committed PMC traffic on the hash of the
 # library sources): sed the file into tools/_build/src/<name>/, compile both element-type builds, link with the main build's other objects.
 #   usage: tools/build_patched.sh <name> '<sed expression>' [file.hip, default fmx_gemm256p.hip]        -> tools/_build/libfmx_<name>.so

@@ -1,4 +1,5 @@
 #!/bin/bash
+export FMX_ALLOW_KNOBS=1   # the A/B knobs below are development switches: the library ignores them without this
 # tools/_build/libfmx_timeline.so: the library with the tile-timeline stamps of tools/patch_tile_timeline.py in the 8-wave GEMM kernels
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)

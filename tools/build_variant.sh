@@ -1,4 +1,5 @@
 #!/bin/bash
+export FMX_ALLOW_KNOBS=1   # the A/B knobs below are development switches: the library ignores them without this
 # A/B builds of libfmx_gfx950.so: recompile the named csrc files (both element-type builds) with extra flags, link them with the
 # main build's other objects into tools/_build/libfmx_<name>.so.  Select with FMX_LIB=tools/_build/libfmx_<name>.so (forge_amd/_lib.py).
 #   usage: tools/build_variant.sh <name> "<extra hipcc flags>" <file.hip> [...]

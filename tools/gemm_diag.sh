@@ -1,4 +1,5 @@
 #!/bin/bash
+export FMX_ALLOW_KNOBS=1   # the A/B knobs below are development switches: the library ignores them without this
 # s_memtime stamps + timing ablations of the 256x256 GEMM (needs the -DFMX_ABLATE build: libfmx_ablate_gfx950.so)
 TAG=${1:-diag}
 R=${GRAFT_REPO_ROOT:-$PWD}

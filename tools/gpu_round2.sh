@@ -1,4 +1,5 @@
 #!/bin/bash
+export FMX_ALLOW_KNOBS=1   # the A/B knobs below are development switches: the library ignores them without this
 # Round-2 GPU-box visits.  usage (from repo root, through gpurun): bash tools/gpu_round2.sh <tag> <step> [<step> ...]
 TAG=${1:-r4}; shift
 R=${GRAFT_REPO_ROOT:-$PWD}
