@@ -41,13 +41,16 @@ def _need_cuda(*ts):
             raise TypeError("forge_amd.backend.attention runs on the MI355X only: got a tensor on %s (there is no CPU path)" % t.device)
 
 
-def _additive_mask(mask, b, heads, nq, nk, nkp, device):
-    """-> (fp16 tensor with rows of nkp keys, (batch, head, query) element strides) for the kernel."""
+def _mask_view(mask, b, heads, nq, nk):
+    """The mask as a 4-D [B | 1, heads | 1, Nq | 1, Nk] view, by the reference's reading of each rank (host logic only: no kernel)."""
     m = mask
     if m.dtype == torch.bool and m.dim() == 2 and m.shape == (b, nk) and nq == b and b > 1:
-        # [B, Nk] key mask (attention_basic :74-78) and [Nq, Nk] SDPA mask have the same shape here and mean different things
-        raise ValueError(f"a 2-D bool mask of shape {tuple(m.shape)} is ambiguous when B == Nq == {b}: pass it as [B, 1, 1, Nk] (key mask) or "
-                         f"[1, 1, Nq, Nk] (per-query mask)")
+        # [B, Nk] key mask (attention_basic :74-78) and [Nq, Nk] SDPA mask have the same shape here and mean different things.  The reference's
+        # explicit form ALWAYS reads a 2-D bool mask as the per-batch key mask ('b ... -> b (...)'), so that is what it means here too; a caller
+        # who means the per-query reading passes [1, 1, Nq, Nk] (ADVICE r3: round 3 raised here, which broke callers following the reference contract)
+        import warnings
+        warnings.warn(f"2-D bool attention mask of shape {tuple(m.shape)} with B == Nq == {b}: read as the reference's [B, Nk] key mask "
+                      f"(attention_basic); pass [1, 1, Nq, Nk] for a per-query mask", stacklevel=3)
     if m.dtype == torch.bool and m.dim() >= 2 and m.shape[0] == b and m.dim() != 4 and m[0].numel() == nk and not (m.dim() == 2 and nq == b == 1):
         m = m.reshape(b, 1, 1, nk)                                    # attention_basic's 'b ... -> b (...)' key mask
     elif m.dim() == 2:
@@ -61,6 +64,13 @@ def _additive_mask(mask, b, heads, nq, nk, nkp, device):
         raise ValueError(f"attention mask {tuple(mask.shape)} does not broadcast to [{b}, {heads}, {nq}, {nk}]")
     if m.dtype not in (torch.bool, torch.float16, torch.float32, torch.bfloat16):
         raise TypeError(f"attention mask dtype {m.dtype}")
+    return m
+
+
+def _additive_mask(mask, b, heads, nq, nk, nkp, device):
+    """-> (fp16 tensor with rows of nkp keys, (batch, head, query) element strides) for the kernel."""
+    m = _mask_view(mask, b, heads, nq, nk)
+    mb, mh, mq, mk = m.shape
     out = torch.zeros(mb, mh, mq, nkp, dtype=torch.float16, device=device)
     ops.strided_copy4(m, out, (mb, mh, mq, nk), m.stride(), out.stride())
     strides = (out.stride(0) if mb > 1 else 0, out.stride(1) if mh > 1 else 0, out.stride(2) if mq > 1 else 0)

@@ -35,7 +35,10 @@ class IntegratedAutoencoderKL:
         self.dtype = dtype
         self.auto_bf16_fallback = bool(auto_bf16_fallback)
         self.fallbacks = 0          # decodes repeated in bfloat16 because the fp16 result was not finite
-        self._source = state_dict   # by reference: the bfloat16 weights are made from it if a fallback ever happens
+        # by reference, and only while a fallback can still happen (an fp16 executor with the guard on): the bfloat16 weights are made from it then, and
+        # it is released -- together with the fp16 copy, which no later decode uses -- as soon as they exist (the caller's full state dict,
+        # often fp32 and already on the device, used to stay alive for the executor's lifetime)
+        self._source = state_dict if (dtype == torch.float16 and self.auto_bf16_fallback) else None
         self._weights = {}
         self.config = dict(config)
         self.layout = vae_decoder_layout(config)
@@ -54,7 +57,11 @@ class IntegratedAutoencoderKL:
         if dtype not in (torch.float16, torch.bfloat16):
             raise NotImplementedError(f"VAE element type {dtype}")
         if dtype not in self._weights:
-            self._weights[dtype] = self._load(self._source, dtype)
+            if self._source is not None:
+                self._weights[dtype] = self._load(self._source, dtype)
+            else:   # the source was released: re-round the resident copy (fp16 -> bf16 keeps every exponent; bf16 -> fp16 may overflow like any fp16 load)
+                src = next(iter(self._weights.values()))
+                self._weights[dtype] = {k: (tuple(t.to(dtype) for t in v) if isinstance(v, tuple) else v.to(dtype) if torch.is_tensor(v) else v) for k, v in src.items()}
         self.dtype, self.w = dtype, self._weights[dtype]
 
     def _load(self, sd, dt):
@@ -252,8 +259,11 @@ class IntegratedAutoencoderKL:
                 h, st = ops.conv_gemm(h, self.w[up][0], c, kh=3, pad=1, up=(2 * h2, 2 * w2), bias=self.w[up][1], stats=True)
                 h = ops.attach_stats(h.view(bb, 2 * h2, 2 * w2, c), st)
         g = ops.groupnorm(h, *self.w["norm_out"], 1e-6, silu=True)
-        y = ops.conv_gemm(g, self.w["conv_out"][0], lay.out_channels, kh=3, pad=1, bias=self.w["conv_out"][1],
-                          out=ops.empty((g.shape[0] * g.shape[1] * g.shape[2], 4), self.dtype), ld_out=4)
+        # [npix, 4] with 3 valid columns: the GEMM epilogue never writes column 3, and the arena hands out recycled bytes -- zeroed, so that the
+        # overflow guard's scan of the whole buffer (ops.count_nonfinite) cannot trip over a stale inf / NaN half-word there
+        y = ops.empty((g.shape[0] * g.shape[1] * g.shape[2], 4), self.dtype)
+        y.zero_()
+        y = ops.conv_gemm(g, self.w["conv_out"][0], lay.out_channels, kh=3, pad=1, bias=self.w["conv_out"][1], out=y, ld_out=4)
         return y
 
     def _run(self, z):
@@ -284,6 +294,9 @@ class IntegratedAutoencoderKL:
         warnings.warn(f"VAE {what}: the float16 result is not finite (activations beyond 65504, as with trained SDXL VAE weights); repeating in "
                       f"bfloat16 and keeping this VAE in bfloat16 from here on (construct it with dtype=torch.bfloat16 to start there)")
         self.set_dtype(torch.bfloat16)
+        # this VAE stays in bfloat16: neither the fp16 weights nor the caller's state dict are needed again
+        self._weights.pop(torch.float16, None)
+        self._source = None
 
     # ---- encoder -----------------------------------------------------------------------------------------------------
     def _encode_impl(self, x, arena):

@@ -18,6 +18,7 @@
 #define fmx_launch_gn_stats fmx_launch_gn_stats_bf16
 // host-side C++ symbols shared between the GEMM files
 #define fmx_launch_gemm256p fmx_launch_gemm256p_bf16
+#define fmx_launch_gemm4w fmx_launch_gemm4w_bf16
 #define GemmParams GemmParamsBf16
 #define GemmEpilogue GemmEpilogueBf16
 #define FastEpilogue FastEpilogueBf16

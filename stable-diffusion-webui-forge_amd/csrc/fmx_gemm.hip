@@ -399,6 +399,12 @@ int fmx_launch_gn_stats(const void* x, int32_t c, int64_t ld, int32_t n, int32_t
 static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, int fallback_chunks, int* chunks_out, void* stream,
                          float* row_stats = nullptr, int row_parts_cap = 0, int* row_parts_out = nullptr);
 
+// Where the 256x160 two-workgroups-per-CU kernel replaces the 256x320 one by default: set from the same-box A/B of profiles/r10_gemm4w_ab.jsonl.
+static bool fmx_gemm4w_preferred(int M, int nout, int kt, bool geglu) {
+  (void)M; (void)nout; (void)kt; (void)geglu;
+  return false;
+}
+
 // stats != null: also leave the GroupNorm statistics of the output in stats[n][chunks][nout][2] (see fmx_gemm_conv_stats_f16 in fmx.h)
 //
 // The 8-wave kernels address an operand with 32-bit byte offsets from its base.  An activation tensor beyond that range (the VAE decoder's
@@ -510,7 +516,8 @@ static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, i
   // element in K-tiles (it scales with the tile area), F = per-tile fixed latency (prologue + first loads, ~1.5 K-tiles of a
   // 256x256 tile; half of it hides behind the CU's other workgroup for the 4-wave kernels).  Padding rows / columns are
   // counted through the tile area.
-  // sel: 0 = 128x128, 1 = 128x64, 2 = 64x64, 4 = 128x160, 5 / 6 / 7 / 8 = 256x256 / 256x320 / 320x256 / 512x128 pipelined
+  // sel: 0 = 128x128, 1 = 128x64, 2 = 64x64, 4 = 128x160, 5 / 6 / 7 / 8 = 256x256 / 256x320 / 320x256 / 512x128 pipelined,
+  //      9 = 256x160 with two 4-wave workgroups per CU (fmx_gemm4w.hip; linear GEMMs)
   auto tiles = [&](int bm, int bn) { return (double)((p.M + bm - 1) / bm) * (double)((p.nout + bn - 1) / bn); };
   const double kt = p.kt;
   const bool geglu = a->act == FMX_ACT_GEGLU;
@@ -558,13 +565,22 @@ static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, i
       if (split_fits(128, 64, S)) consider(1, cost_split(128, 64, 3, 0.58, S), S);
     }
   }
-  if (a->out_f32 < 0) { sel = (-a->out_f32 - 1) % 16; best_s = 1; }  // test hook: force a tile shape (out_f32 = -1..-9 -> fp16 out)
+  // 256x160 x 2 workgroups per CU: a plain linear GEMM (single source, 1x1, no output statistics) with the 8-wave kernels' epilogue contract
+  const bool w4_ok = big_ok && !conv && p.c1 == 0 && !stats && !a->ln_col_ab && (!geglu || (p.nout % 32) == 0);
+  {
+    // where the dispatcher takes it by itself: FMX_GEMM_4W = 0 never, 1 (default) by the rule below, 2 wherever it is eligible (A/B knob, development only)
+    const char* e4 = fmx_knob("FMX_GEMM_4W");
+    const int mode4 = e4 ? atoi(e4) : 1;
+    if (w4_ok && sel == 6 && (mode4 == 2 || (mode4 == 1 && fmx_gemm4w_preferred(p.M, p.nout, p.kt, geglu)))) sel = 9;
+  }
+  if (a->out_f32 < 0) { sel = (-a->out_f32 - 1) % 16; best_s = 1; }  // test hook: force a tile shape (out_f32 = -1..-10 -> fp16 out)
   if (split_ok && force_split >= 2 && (sel == 0 || sel == 1) && split_fits(128, sel == 0 ? 128 : 64, force_split)) best_s = force_split;
   if (best_s > 1 && sel != 0 && sel != 1) best_s = 1;
   if (fmx_knob("FMX_GEMM_DEBUG"))
     fprintf(stderr, "fmx_gemm: M=%d N=%d K=%d conv=%d -> tile id %d, split-K %d (workspace %ld floats, fits32 %d)\n", p.M, p.nout, p.kt * 64, (int)conv,
             sel + 1, best_s, ws_floats, (int)fits32);
-  FMX_REQUIRE(sel <= 8, "gemm: unknown tile id");
+  FMX_REQUIRE(sel <= 9, "gemm: unknown tile id");
+  FMX_REQUIRE(sel != 9 || w4_ok, "gemm: the 256x160 two-workgroup tile takes plain linear GEMMs (one source, no output statistics, fp16 out, 16-byte aligned operands)");
   FMX_REQUIRE(sel != 8 || (!geglu && (!conv || (p.c1 == 0 && a->up_h == 0))), "gemm: the 512x128 tile takes no GEGLU, second source or upsample-on-load");
   FMX_REQUIRE(sel != 3, "gemm: tile id 4 (the first-generation ping-pong kernel) is no longer part of the library");
   FMX_REQUIRE(sel != 4 || a->act != FMX_ACT_GEGLU, "gemm: the 128x160 tile does not support GEGLU");
@@ -589,8 +605,8 @@ static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, i
   // LayerNorm folded into the GEMMs around it (fmx.h: fmx_gemm_linear_rowstats_f16 / the ln_* fields): 256x320 tile, linear only
   const bool ln_shape_ok = !conv && big_ok && p.c1 == 0 && !p.gate && !p.rowvec;
   if (row_parts_out) {
-    const int parts = 2 * ((p.nout + 319) / 320);
-    if (sel == 6 && ln_shape_ok && a->act == FMX_ACT_NONE && parts <= row_parts_cap && !stats) {   // (residual optional: absent reads the zero page)
+    const int parts = sel == 9 ? (p.nout + 159) / 160 : 2 * ((p.nout + 319) / 320);   // one entry per 160 output columns either way
+    if ((sel == 6 || sel == 9) && ln_shape_ok && a->act == FMX_ACT_NONE && parts <= row_parts_cap && !stats) {   // (residual optional: absent reads the zero page)
       p.row_stats = row_stats;
       *row_parts_out = parts;
     } else {
@@ -598,8 +614,8 @@ static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, i
     }
   }
   if (a->ln_partial) {
-    FMX_REQUIRE(ln_shape_ok && !p.residual && !stats && (a->act == FMX_ACT_NONE || (geglu && (p.nout % 32) == 0)) && a->ln_colsum && a->ln_parts >= 2 &&
-                    (a->ln_parts % 2) == 0 && a->ln_parts <= 8 && fmx_aligned16(a->ln_partial) && fmx_aligned16(a->ln_colsum),
+    FMX_REQUIRE(ln_shape_ok && !p.residual && !stats && (a->act == FMX_ACT_NONE || (geglu && (p.nout % 32) == 0)) && a->ln_colsum && a->ln_parts >= 1 &&
+                    a->ln_parts <= 8 && fmx_aligned16(a->ln_partial) && fmx_aligned16(a->ln_colsum),
                 "gemm: a LayerNorm-folded GEMM is a plain linear (bias, optional GEGLU) with fp16 output on the 256x320 tile");
     p.ln_partial = (const float*)a->ln_partial;
     p.ln_parts = a->ln_parts;
@@ -607,7 +623,7 @@ static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, i
     p.ln_eps = a->ln_eps;
     p.ln_inv_c = 1.0f / (float)p.c0;
     p.ln_ab_out = (float*)a->ln_ab_out;
-    sel = 6;
+    if (sel != 9) sel = 6;
     best_s = 1;
   }
   if (a->ln_col_ab) {
@@ -620,7 +636,9 @@ static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, i
     best_s = 1;
   }
   int rc;
-  if (sel >= 5) {
+  if (sel == 9) {
+    rc = fmx_launch_gemm4w(p, st);
+  } else if (sel >= 5) {
     FMX_REQUIRE(FastEpilogue::eligible8(p) && fits32, "gemm: the 256-row kernels need fp16 output, 16-byte aligned epilogue operands, leading dimensions / nout multiples of 8, operands < 2^32 elements");
     if (sel == 6) FMX_REQUIRE(a->act != FMX_ACT_GEGLU || (p.nout % 32) == 0, "gemm: GEGLU needs nout % 32 == 0");
     rc = fmx_launch_gemm256p(p, conv, sel == 8 ? 512 : sel == 7 ? 320 : 256, sel == 8 ? 128 : sel == 6 ? 320 : 256, st);

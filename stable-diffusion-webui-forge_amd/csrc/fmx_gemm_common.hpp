@@ -222,3 +222,5 @@ __device__ __forceinline__ void swap_halfwaves(float& a, float& b) {
 
 // same tile, software-pipelined single-barrier schedule (fmx_gemm256p.hip)
 int fmx_launch_gemm256p(const GemmParams& p, bool conv, int bm, int bn, hipStream_t st);  // (bm, bn) = (256,256) (256,320) (320,256)
+// 256 x 160 tile, two 4-wave workgroups per CU (fmx_gemm4w.hip): linear GEMMs, optional LayerNorm producer / consumer / GEGLU
+int fmx_launch_gemm4w(const GemmParams& p, hipStream_t st);

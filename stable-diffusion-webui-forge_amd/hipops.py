@@ -405,7 +405,13 @@ def attach_stats(t, st):
     place afterwards -- ControlNet residuals, Python hooks -- must call clear_stats).  The record carries the tensor's torch version counter
     and address: an in-place torch edit nobody announced (a hook holding the NCHW view: `h.add_(...)`) bumps the counter, and `_attached_stats`
     then ignores the stale record instead of normalising with it (C-ABI launches write through raw pointers and do not bump it: they call
-    clear_stats themselves)."""
+    clear_stats themselves).
+
+    The guard is BEST-EFFORT and says so: torch keeps ONE version counter per storage, and every arena tensor is a view of the
+    arena's single uint8 buffer -- there the counter says nothing about THIS tensor (any `zero_()` / `copy_()` on any other arena tensor bumps it,
+    which used to drop the statistics of every live tensor and silently add a statistics pass), so for views of a larger buffer, and under
+    torch.inference_mode (no counters at all; the product path), the tag is the address alone and the contract is the explicit one: whoever writes
+    into a tensor in place calls clear_stats.  Only tensors that own their storage (what a Python hook's own buffers are) get the version check."""
     t._fmx_gn_stats = None if st is None else (st, _version_of(t), t.data_ptr())
     return t
 
@@ -413,7 +419,11 @@ def attach_stats(t, st):
 def _version_of(t):
     """torch's in-place version counter; inference-mode tensors (processing runs under torch.inference_mode, as the reference does) do not
     keep one -- there the address is the only tag and in-place writers have to announce themselves through clear_stats, as before."""
-    return None if t.is_inference() else t._version
+    if t.is_inference():
+        return None
+    if t.untyped_storage().nbytes() != t.numel() * t.element_size():
+        return None          # a window of a larger buffer (the arena): the storage's shared counter is not about this tensor
+    return t._version
 
 
 def _attached_stats(t):

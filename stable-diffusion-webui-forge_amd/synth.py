@@ -21,7 +21,7 @@ import torch
 from .backend.nn.layout import clip_param_shapes, flux_param_shapes, unet_param_shapes, vae_decoder_param_shapes, vae_encoder_param_shapes
 
 # LDM-style unet_config dicts (parameter counts 859.52 M / 2567.46 M verified against
-# the reference module in tests/test_oracle_vs_reference.py).
+# the reference module's own parameter shapes, tests/golden/param_shapes.json, in tests/test_oracle_golden.py).
 SD15_UNET_CONFIG = dict(
     in_channels=4, model_channels=320, out_channels=4, num_res_blocks=[2, 2, 2, 2], channel_mult=(1, 2, 4, 4),
     num_heads=8, use_spatial_transformer=True, transformer_depth=[1, 1, 1, 1, 1, 1, 0, 0],

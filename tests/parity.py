@@ -24,6 +24,13 @@ the reference's own fp16 run of tiny_clip_g's pooled output has max_rel 0.95 sig
 tensors of at most SMALL (1024) elements the two max norms are therefore also allowed up to SMALL_SIGMAS x the rms limit derived from the floor
 (max|d| / max|ref| <= k sigma_d / max|ref| <= k rms_rel, since rms(ref) <= max|ref|).
 
+Round 4: (i) the FULL-SIZE hot-path fixtures (the configurations BASELINE.json names: SD1.5 512^2, SDXL 1024^2 forward / sampler / decode, Flux at
+width 3072) are held to RMS_FACTOR_FULL = 1.15 -- what the path achieves there (worst measured 1.12; the tiny networks keep 1.25: their floors are
+single draws of a few thousand values); (ii) every comparison also reports the UNCLAMPED per-pixel error |d| / |ref| -- `pp_rel` divides by
+max(|ref|, rms(ref)), i.e. it is a clamped measure -- as two order statistics that have a size: `frac_gt_1e-3` (fraction of elements whose
+unclamped relative error exceeds the north star's 1e-3) and `pp_unclamped_p999` (its 99.9th percentile).  They are logged, not gated: an fp16
+pipeline cannot hold 1e-3 relative on elements near zero (profiles/r08a_error_budget_fp16_sites.jsonl), the numbers say by how much it misses.
+
 FMX_PARITY_LOG=<file> appends one JSON line per comparison (that file is what gets committed under profiles/);
 FMX_PARITY_REPORT_ONLY=1 prints without asserting (used once to collect the measurements the explicit tolerances come from).
 """
@@ -35,6 +42,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 NORTH_STAR = 1e-3
 MAX_FACTOR = 1.5
 RMS_FACTOR = 1.25
+RMS_FACTOR_FULL = 1.15
+FULL_SIZE_FIXTURES = ("sd15_config0.pt", "sd15_config2.pt", "sdxl_full_fwd.pt", "sdxl_config3.pt", "sdxl_config3_b8.pt", "sdxl_vae1024.pt",
+                      "sdxl_config3_decode.pt", "flux_width3072_fwd.pt", "flux_depth4x8_fwd.pt")
 SMALL = 1024
 SMALL_SIGMAS = 3.0
 
@@ -53,6 +63,21 @@ def metrics(a, ref):
             "rms_rel": float(d.pow(2).mean().sqrt() / rms)}
 
 
+def unclamped(a, ref):
+    """Order statistics of the UNCLAMPED per-element relative error |d| / |ref| (elements with ref == 0 excluded)."""
+    import torch
+    a, ref = a.detach().double().cpu().reshape(-1), ref.detach().double().cpu().reshape(-1)
+    nz = ref != 0
+    rel = ((a - ref).abs()[nz] / ref.abs()[nz])
+    if rel.numel() == 0:
+        return {"frac_gt_1e-3": 0.0, "pp_unclamped_p999": 0.0}
+    if rel.numel() > 4_000_000:      # torch.quantile's input limit; a strided sample of a large tensor is an unbiased estimate of an order statistic
+        rel_q = rel[:: rel.numel() // 4_000_000 + 1]
+    else:
+        rel_q = rel
+    return {"frac_gt_1e-3": float((rel > NORTH_STAR).double().mean()), "pp_unclamped_p999": float(torch.quantile(rel_q, 0.999))}
+
+
 def max_rel(a, ref):
     return metrics(a, ref)["max_rel"]
 
@@ -64,14 +89,15 @@ def limits(floor_key, both_fp16=False):
     the error process, sqrt(2) x the floor."""
     keys = [floor_key] if isinstance(floor_key, str) else list(floor_key)
     fl = {m: max(FLOORS[k][m] for k in keys) * (2.0 ** 0.5 if both_fp16 else 1.0) for m in ("max_rel", "pp_rel", "rms_rel")}
+    rf = RMS_FACTOR_FULL if all(k.split(":")[0] in FULL_SIZE_FIXTURES for k in keys) else RMS_FACTOR
     return fl, {"max_rel": max(NORTH_STAR, MAX_FACTOR * fl["max_rel"]), "pp_rel": max(NORTH_STAR, MAX_FACTOR * fl["pp_rel"]),
-                "rms_rel": max(NORTH_STAR, RMS_FACTOR * fl["rms_rel"])}
+                "rms_rel": max(NORTH_STAR, rf * fl["rms_rel"])}
 
 
 def check(name, got, ref, floor=None, tol=None, both_fp16=False):
     """Compare `got` with `ref`; `floor` = key(s) into fp16_floor.json, or `tol` = explicit bound on max_rel."""
     m = metrics(got, ref)
-    rec = {"name": name, **{k: round(v, 7) for k, v in m.items()}}
+    rec = {"name": name, **{k: round(v, 7) for k, v in m.items()}, **{k: round(v, 6) for k, v in unclamped(got, ref).items()}}
     if floor is not None:
         fl, lim = limits(floor, both_fp16)
         if got.numel() <= SMALL:

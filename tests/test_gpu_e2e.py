@@ -737,8 +737,9 @@ def test_sdxl_full_size_forward_at_the_bench_batch_vs_reference_fixture(sdxl_eng
 
 @pytest.mark.skipif(not _have("sdxl_config3.pt"), reason="full fixture not generated")
 def test_sdxl_config3_dpmpp2m_vs_reference_fixture(sdxl_engine):
-    """BASELINE config 3's sampler at full size: SDXL 1024x1024, DPM++ 2M on the Karras schedule, CFG 7, 5 steps of one image (10 sample-forwards
-    of the real reference on CPU fp32 take 25 minutes; oracle/make_floor.py gen_config3)."""
+    """BASELINE config 3's sampler at full size and full length: SDXL 1024x1024, DPM++ 2M on the Karras schedule, CFG 7, the fixture's 30 steps for
+    one image of the batch (60 sample-forwards of the real reference on CPU fp32, 11 minutes; oracle/make_floor.py gen_config3).  The batch of
+    eight distinct images is the next test."""
     g = load_golden("sdxl_config3.pt")
     cfg = synth.SDXL_UNET_CONFIG
     c, uc = _conds(cfg, 1)
@@ -747,6 +748,31 @@ def test_sdxl_config3_dpmpp2m_vs_reference_fixture(sdxl_engine):
                                                     steps=g["steps"], cfg_scale=7.0, width=1024, height=1024, do_decode=False)
     res = processing.process_images(p)
     check(f"SDXL 1024x1024 {g['steps']}-step DPM++ 2M latents vs reference", res.latents, g["latent"], floor="sdxl_config3.pt:latent")
+
+
+@pytest.mark.skipif(not _have("sdxl_config3_b8.pt"), reason="full fixture not generated")
+def test_sdxl_config3_batch8_distinct_conditionings_vs_reference_fixture(sdxl_engine):
+    """BASELINE config 3 at ITS batch: SDXL 1024x1024, batch 8 with EIGHT DISTINCT conditionings (prompt context, pooled vector) and
+    seeds through `process_images` -- UNet batch 16 per step, the shapes the bench is timed on -- DPM++ 2M on the Karras schedule, CFG 7, the fixture's
+    5 steps, every image against the real reference's CPU fp32 run of the same job (oracle/make_floor.py gen_config3_b8: 80 sample-forwards).  Each
+    image is held against the worst per-image floor (the reference's own fp16 run of the same eight images), the batch as a whole against its own."""
+    g = load_golden("sdxl_config3_b8.pt")
+    cfg = synth.SDXL_UNET_CONFIG
+    b = g["batch"]
+    c, uc = _conds(cfg, b)                                     # synth_conditioning(8, ..., seed=1234): the fixture's conditionings
+    shared.opts.randn_source = "CPU"
+    p = processing.StableDiffusionProcessingTxt2Img(sd_model=sdxl_engine, c=c, uc=uc, seed=g["seeds"][0], sampler_name=g["sampler"], batch_size=b,
+                                                    steps=g["steps"], cfg_scale=7.0, width=1024, height=1024, do_decode=False)
+    res = processing.process_images(p)
+    assert res.seeds == g["seeds"]
+    check(f"SDXL 1024x1024 batch {b}, eight distinct conditionings, {g['steps']}-step DPM++ 2M latents vs reference", res.latents, g["latent"],
+          floor="sdxl_config3_b8.pt:latent")
+    for i in range(b):
+        check(f"SDXL 1024x1024 batch {b} distinct conditionings: image {i} vs reference", res.latents[i:i + 1], g["latent"][i:i + 1],
+              floor="sdxl_config3_b8.pt:latent_per_image_worst")
+    # the images differ from each other (distinct conditionings reached the network: a broadcast of image 0's would pass a repeated-input test)
+    lat = res.latents.float().cpu()
+    assert float((lat[1:] - lat[:1]).abs().mean()) > 0.1 * float(lat.abs().mean())
 
 
 @pytest.mark.parametrize("fixture", ["sdxl_vae1024.pt", "sdxl_config3_decode.pt"])

@@ -32,9 +32,9 @@ def close(got, want, rtol, atol, what=""):
 
 # ----------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("m,n,k", [(256, 256, 128), (384, 320, 320), (77 * 2, 640, 768), (1000, 132, 64), (4096, 1280, 1280), (130, 4, 2880)])
-@pytest.mark.parametrize("tile", [1, 2, 3, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("tile", [1, 2, 3, 5, 6, 7, 8, 9, 10])
 def test_linear_plain(m, n, k, tile):
-    if tile in (4, 6, 7, 8, 9) and n % 8:
+    if tile in (4, 6, 7, 8, 9, 10) and n % 8:
         pytest.skip("256x256 kernel needs nout % 8 == 0 (dispatcher never selects it otherwise)")
     x = rnd(m, k, seed=1)
     w = rnd(n, k, scale=1 / math.sqrt(k), seed=2)
@@ -451,7 +451,7 @@ def test_conv(cfg, tile):
 
 # ---- 256-row kernels (force_tile = 6 / 7 / 8: 256x256, 256x320, 320x256 tiles of the software-pipelined single-barrier kernel): epilogues, GEGLU, two sources, ragged M / N, long K, tail handling ----
 @pytest.mark.parametrize("m,n,k", [(256, 256, 64), (512, 512, 128), (300, 264, 192), (1000, 1280, 1280), (4096, 640, 2560), (2048, 320, 320)])
-@pytest.mark.parametrize("t256", [6, 7, 8])
+@pytest.mark.parametrize("t256", [6, 7, 8, 10])
 def test_gemm256_epilogues(m, n, k, t256):
     x, w, b = rnd(m, k, seed=100), rnd(n, k, scale=1 / math.sqrt(k), seed=101), rnd(n, seed=102)
     res = rnd(m, n, seed=103)
@@ -462,7 +462,7 @@ def test_gemm256_epilogues(m, n, k, t256):
     close(r2, x.float() @ w.float().t() + res.float(), 2e-3, 2e-3, "gemm256 in-place residual")
 
 
-@pytest.mark.parametrize("t256", [6, 7, 8])
+@pytest.mark.parametrize("t256", [6, 7, 8, 10])
 def test_gemm256_identity_asymmetric(t256):
     m = n = k = 512
     x = torch.eye(m, dtype=torch.float16, device=DEV)
@@ -472,7 +472,7 @@ def test_gemm256_identity_asymmetric(t256):
 
 
 @pytest.mark.parametrize("m,k,inner", [(512, 320, 1280), (300, 640, 2560 + 16)])
-@pytest.mark.parametrize("t256", [6, 7, 8])
+@pytest.mark.parametrize("t256", [6, 7, 8, 10])
 def test_gemm256_geglu(m, k, inner, t256):
     x = rnd(m, k, seed=110)
     w = rnd(2 * inner, k, scale=1 / math.sqrt(k), seed=111)
@@ -482,6 +482,67 @@ def test_gemm256_geglu(m, k, inner, t256):
     h = x.float() @ w.float().t() + b.float()
     a, g = h.chunk(2, dim=-1)
     close(out, a * F.gelu(g), 3e-3, 3e-3, "gemm256 geglu")
+
+
+def test_two_workgroup_tile_refuses_what_it_does_not_do():
+    """force_tile 10 = the 256x160 tile with two 4-wave workgroups per CU (csrc/fmx_gemm4w.hip): plain linear GEMMs only."""
+    x = rnd(2, 16, 16, 128, seed=8)
+    wk = rnd(160, 128 * 9, scale=0.03, seed=9)
+    with pytest.raises(Exception, match="256x160"):
+        ops.conv_gemm(x, wk, 160, kh=3, pad=1, force_tile=10)
+
+
+@pytest.mark.parametrize("m,c,nq", [(16384, 1280, 1280), (16384 - 100, 1280, 640), (8192, 640, 640), (4096, 320, 960)])
+def test_two_workgroup_tile_layernorm_folds_and_interoperates_with_the_256x320_kernel(m, c, nq):
+    """The 256x160 two-workgroups-per-CU kernel as LayerNorm PRODUCER (per-row sums of the stored output, one entry per 160 columns) and CONSUMER (plain
+    and GEGLU), and mixed with the 256x320 kernel on the same statistics array -- either kernel may produce what the other consumes (the dispatcher
+    picks per shape)."""
+    from forge_amd.backend.nn.unet import _fold_layernorm
+    o_in = rnd(m, c, seed=190)
+    w_out, b_out = rnd(c, c, scale=1 / math.sqrt(c), seed=191), rnd(c, seed=192)
+    h0 = (rnd(m, c, scale=2.0, seed=193) + 0.7).contiguous()
+    gamma, beta = (1 + 0.2 * rnd(c, seed=194)), 0.1 * rnd(c, seed=195)
+    wq = rnd(nq, c, scale=1 / math.sqrt(c), seed=196)
+    wf, cs, bf = _fold_layernorm(wq, None, gamma, beta)
+    wg, bg = rnd(2 * nq, c, scale=1 / math.sqrt(c), seed=197), rnd(2 * nq, seed=198)
+    wgi, bgi = ops.geglu_interleave(wg, bg)
+    wf2, cs2, bf2 = _fold_layernorm(wgi, bgi, gamma, beta)
+    outs = {}
+    for prod in (10, 7):
+        h = h0.clone()
+        rs = ops.RowStats(m, c)
+        ops.linear(o_in, w_out, b_out, residual=h, out=h, ld_out=c, row_stats=rs, force_tile=prod)
+        close(h, o_in.float() @ w_out.float().t() + b_out.float() + h0.float(), 2e-3, 2e-3, f"producer output (tile {prod})")
+        assert rs.parts == c // 160, (prod, rs.parts)
+        hf = h.double()
+        torch.testing.assert_close(rs.partial.view(m, -1, 2)[:, :rs.parts].double().sum(1), torch.stack([hf.sum(1), (hf * hf).sum(1)], -1), rtol=1e-5, atol=1e-2)
+        ln = F.layer_norm(h.float(), (c,), gamma.float(), beta.float(), 1e-5)
+        hc = ln @ wg.float().t() + bg.float()
+        for cons in (10, 7):
+            q = ops.conv_gemm(h, wf, nq, bias=bf, ln=(rs, cs, 1e-5), force_tile=cons)
+            close(q, ln @ wq.float().t(), 4e-3, 4e-3, f"LayerNorm consumer (producer tile {prod}, consumer tile {cons})")
+            g = ops.conv_gemm(h, wf2, 2 * nq, bias=bf2, act=ops.ACT_GEGLU, ln=(rs, cs2, 1e-5), force_tile=cons)
+            close(g, hc[:, :nq] * F.gelu(hc[:, nq:]), 5e-3, 5e-3, f"LayerNorm GEGLU consumer (producer tile {prod}, consumer tile {cons})")
+            outs[(prod, cons)] = (q, g)
+        outs[prod] = h
+    assert torch.equal(outs[10], outs[7]), "the two kernels accumulate every output element in the same order (K ascending, fp32): bit-identical stores"
+
+
+@pytest.mark.parametrize("m,n,k", [(16384, 1280, 1280), (65536, 640, 640), (16384, 2560, 1280), (16384, 1280, 5120), (1000, 328, 192)])
+def test_two_workgroup_tile_is_bit_identical_to_the_256x320_kernel(m, n, k):
+    """Both kernels run the same 16x16x32 MFMA sequence per output block over K ascending in fp32 and the same epilogue arithmetic, so the stored fp16
+    values must agree bit for bit -- plain, residual, GEGLU; many tiles per workgroup (the persistent walk and the three-stage ring across tiles)."""
+    x, w, b = rnd(m, k, seed=200), rnd(n, k, scale=1 / math.sqrt(k), seed=201), rnd(n, seed=202)
+    res = rnd(m, n, seed=203)
+    for kw in ({}, {"residual": res}):
+        a10, a7 = ops.linear(x, w, b, force_tile=10, **kw), ops.linear(x, w, b, force_tile=7, **kw)
+        assert torch.equal(a10, a7), f"{kw.keys()}: max diff {float((a10.float() - a7.float()).abs().max())}"
+    close(a10, x.float() @ w.float().t() + b.float() + res.float(), 3e-3, 3e-3, "against fp32")
+    if n % 32 == 0:
+        wi, bi = ops.geglu_interleave(w, b)
+        g10 = ops.conv_gemm(x, wi, n, bias=bi, act=ops.ACT_GEGLU, force_tile=10)
+        g7 = ops.conv_gemm(x, wi, n, bias=bi, act=ops.ACT_GEGLU, force_tile=7)
+        assert torch.equal(g10, g7)
 
 
 @pytest.mark.parametrize("t256", [6, 7, 8])

@@ -67,6 +67,15 @@ def test_fp16_overflow_is_caught_and_repeated_in_bfloat16():
     ok = IntegratedAutoencoderKL(synth.TINY_VAE_CONFIG, synth.synth_vae_decoder_state_dict(synth.TINY_VAE_CONFIG, seed=1), device=DEV)
     ok.decode(load_golden("tiny_vae_decode.pt")["z"].to(DEV))
     assert ok.fallbacks == 0 and ok.dtype == torch.float16
+    # ... nor by what a recycled arena holds in the output's pad column (conv_out writes 3 of the 4 columns of [npix, 4]): fill the arena with fp16
+    # infinities (0x7C00) and NaNs and decode again -- the guard scans the whole buffer (a stale inf there made the fallback sticky)
+    ok._arena.buf.view(torch.int16).fill_(0x7C00)
+    a = ok.decode(load_golden("tiny_vae_decode.pt")["z"].to(DEV))
+    ok._arena.buf.view(torch.int16).fill_(0x7E00)
+    b = ok.decode(load_golden("tiny_vae_decode.pt")["z"].to(DEV))
+    assert ok.fallbacks == 0 and ok.dtype == torch.float16 and torch.equal(a, b) and bool(torch.isfinite(a).all())
+    # after a fallback neither the fp16 weights nor the caller's state dict stay alive
+    assert torch.float16 not in vae._weights and vae._source is None and raw._source is None
 
 
 def test_sdxl_vae_decode_1024_bfloat16_and_uint8_image_parity():

@@ -144,6 +144,22 @@ def test_attached_groupnorm_statistics_die_with_an_unannounced_in_place_edit():
     assert hipops._attached_stats(t) is None
 
 
+def test_arena_neighbours_do_not_invalidate_each_others_statistics():
+    """all arena tensors are views of one uint8 buffer and share torch's version counter; an in-place op on one of them must not
+    drop the GroupNorm statistics attached to another (it silently added a statistics pass); an announced write (clear_stats) still does."""
+    from forge_amd import hipops
+    buf = torch.zeros(4096, dtype=torch.uint8)
+    a = buf[:1024].view(torch.float16).view(2, 4, 4, 16)
+    b = buf[2048:3072].view(torch.float16).view(2, 4, 4, 16)
+    st = hipops.GnStats(torch.zeros(2, 1, 16, 2), 1)
+    hipops.attach_stats(a, st)
+    b.zero_()
+    buf[3072:].fill_(1)
+    assert hipops._attached_stats(a) is st
+    hipops.clear_stats(a)
+    assert hipops._attached_stats(a) is None
+
+
 def test_executor_serials_are_never_reused():
     """captured ControlNet graphs are keyed on the executors' serial numbers, which a later executor cannot inherit the
     way it can inherit a freed object's id()."""
@@ -153,8 +169,15 @@ def test_executor_serials_are_never_reused():
     assert b == a + 1 and isinstance(unet._EXEC_SERIAL, itertools.count)
 
 
-def test_ambiguous_two_dimensional_bool_mask_is_refused():
+def test_two_dimensional_bool_mask_keeps_the_reference_reading():
+    """a 2-D bool mask is ALWAYS the per-batch key mask in the reference's attention_basic ('b ... -> b (...)',
+    /root/reference/backend/attention.py:74-78), also when B == Nq makes it look like an SDPA [Nq, Nk] mask: warned about, not refused."""
     from forge_amd.backend import attention
     m = torch.ones(4, 4, dtype=torch.bool)
-    with pytest.raises(ValueError, match="ambiguous"):
-        attention._additive_mask(m, 4, 2, 4, 4, 64, torch.device("cpu"))
+    with pytest.warns(UserWarning, match="key mask"):
+        v = attention._mask_view(m, 4, 2, 4, 4)
+    assert tuple(v.shape) == (4, 1, 1, 4)
+    assert tuple(attention._mask_view(torch.ones(3, 5, dtype=torch.bool), 3, 2, 7, 5).shape) == (3, 1, 1, 5)      # [B, Nk], B != Nq: key mask
+    assert tuple(attention._mask_view(torch.zeros(7, 5), 3, 2, 7, 5).shape) == (1, 1, 7, 5)                        # float [Nq, Nk]: additive per-query
+    with pytest.raises(ValueError):
+        attention._mask_view(torch.zeros(6, 5), 3, 2, 7, 5)

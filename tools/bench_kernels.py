@@ -353,6 +353,18 @@ def gemm_sweep():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "gemm4w":
+        # round 4: the 256x160 tile with two 4-wave workgroups per CU (force_tile 10) against the 256x320 kernel (7), same process,
+        # interleaved twice, in a graph on cold weights -- the K <= 1280 linear shapes of the SDXL forward, the long-K one for reference
+        for rep in range(2):
+            for (m, n, k, act) in [(16384, 1280, 1280, 0), (16384, 2560, 1280, 0), (16384, 10240, 1280, 1), (65536, 640, 640, 0), (65536, 5120, 640, 1),
+                                   (16384, 1280, 5120, 0), (65536, 640, 2560, 0)]:
+                for tile in (7, 10):
+                    bench_linear_cold(m, n, k, tile=tile, act=act)
+            for (m, n, k) in [(16384, 1280, 1280), (65536, 640, 640)]:
+                for tile in (7, 10):
+                    bench_linear_res(m, n, k, tile=tile)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "gn":
         for shp in ((16, 128, 128, 320), (16, 128, 128, 640), (16, 64, 64, 640), (16, 64, 64, 1280), (16, 32, 32, 1280), (16, 32, 32, 2560), (8, 1024, 1024, 128),
                     (8, 512, 512, 256), (8, 256, 256, 512), (2, 64, 64, 320)):

@@ -15,6 +15,9 @@ pmc_pass() {  # $1 = pass name, $2.. = counters ; workload: tools/pmc_kernels.py
 }
 for w in "$@"; do
   case $w in
+    gemm4w) timeout 900 python tools/bench_kernels.py gemm4w > $O/gemm4w.jsonl 2> $O/gemm4w.err; cat $O/gemm4w.jsonl; tail -3 $O/gemm4w.err;;
+    ktests4w) timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_rccl.py tests/test_gpu_vae_bf16.py -m gpu -q --tb=short -k "two_workgroup or linear_plain or gemm256 or knob or rccl or overflow or layernorm_folded" 2>&1 | tail -40 > $O/ktests4w.log; tail -25 $O/ktests4w.log;;
+    ab_4w) for E in FMX_GEMM_4W=0 FMX_GEMM_4W=2 FMX_GEMM_4W=0 FMX_GEMM_4W=2; do env $E timeout 600 python bench.py --no-cpu-baseline --no-vae --no-rccl-selfcheck --steps 10 --breakdown $O/breakdown_$E.jsonl 2>> $O/ab4w.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'env':'$E','ms_per_step':d['ms_per_step'],'gemm_tflops':d['roofline']['achieved'],'gemm_ms':d['roofline']['kernel_time_per_forward_ms'],'attn':d['roofline_attention']['achieved'],'sclk':(d.get('clocks_during_timed_steps') or {}).get('sclk_mhz'),'power':(d.get('clocks_during_timed_steps') or {}).get('power_w'),'knobs':d.get('knobs')}))" >> $O/ab4w.jsonl; done; cat $O/ab4w.jsonl; tail -3 $O/ab4w.err;;
     tests) FMX_PARITY_LOG=$O/parity.jsonl timeout 1500 python -m pytest tests -m gpu -q -s --tb=line 2>&1 | grep -v "^\[parity\]" | tail -120 > $O/pytest_gpu.log; tail -8 $O/pytest_gpu.log;;
     attnshort) for E in "FMX_ATTN_SHORT=0" "FMX_ATTN_SHORT=1" "FMX_ATTN_SHORT=2"; do env $E timeout 300 python tools/bench_kernels.py attnshort >> $O/attnshort.jsonl 2>> $O/attnshort.err; done; cat $O/attnshort.jsonl; tail -3 $O/attnshort.err;;
     atests) timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q --tb=short -k "attention" 2>&1 | tail -40 > $O/atests.log; tail -15 $O/atests.log;;
