@@ -22,6 +22,7 @@ tests/parity.py turns that into the tolerances of the native path (max(1e-3, fac
     python -m oracle.make_floor --only config3_b8 # + fixture sdxl_config3_b8.pt: SDXL 1024^2, batch 8 with eight distinct conditionings / seeds, 5-step DPM++ 2M (~45 min)
     python -m oracle.make_floor --only vae1024  # 1024^2 decode only (fixture + floor)
     python -m oracle.make_floor --only flux_width # fixture flux_width3072_fwd.pt: Flux at hidden 3072 / 24 x 128 / 4096 + 256 tokens, 1 + 1 blocks, + its f16 / bf16 floors
+    python -m oracle.make_floor --only flux_depth # fixture flux_depth4x8_fwd.pt: the same width with 4 double + 8 single blocks (2.5 B parameters), + its f16 / bf16 floors
     python -m oracle.make_floor --only vae_bf16 # bfloat16 floors of the VAE fixtures + the fp16-overflow fixture tiny_vae_overflow.pt
 """
 import argparse
@@ -396,6 +397,38 @@ def gen_flux_width():
     update(floors)
 
 
+FLUX_DEPTH_CONFIG = dict(synth.FLUX_DEV_CONFIG, depth=4, depth_single_blocks=8)
+
+
+def gen_flux_depth():
+    """Flux at its own width AND with depth (round 4): hidden 3072, 24 x 128, 4096 + 256 tokens, FOUR double-stream and EIGHT
+    single-stream blocks (backend/nn/flux.py:181-307, :372-398; 2.5 B parameters) -- how the error of a bf16 / fp16 executor grows over a stack of blocks,
+    which the 1 + 1 fixture cannot show.  One forward of the REAL reference on CPU fp32 (~25 TFLOP) and its own fp16 / bf16 runs as floors.  Fixture
+    tests/golden/flux_depth4x8_fwd.pt (the 1 MB output; inputs and weights come back from seeds)."""
+    cfg = FLUX_DEPTH_CONFIG
+    sd = synth.synth_flux_state_dict(cfg, seed=2)
+    x, t, ctx, y, guid = flux_width_inputs(cfg)
+    net = ref_import.build_ref_flux(cfg, sd)
+    nparams = sum(int(v.numel()) for v in sd.values())
+    del sd
+    t0 = time.time()
+    with torch.no_grad():
+        out = net(x.clone(), t, context=ctx, y=y, guidance=guid)
+    secs = time.time() - t0
+    torch.save({"out": out, "inputs_seed": 33, "weights_seed": 2, "depth": cfg["depth"], "depth_single_blocks": cfg["depth_single_blocks"], "cpu_seconds": secs,
+                "params": nparams}, os.path.join(GOLD, "flux_depth4x8_fwd.pt"))
+    print("flux 4 + 8 blocks at width 3072: reference fp32 %.0f s, out std %.4f, params %.3f B" % (secs, float(out.std()), nparams / 1e9), flush=True)
+    floors = {}
+    for tag, dt in (("f16", torch.float16), ("bf16", torch.bfloat16)):
+        n2 = net.to(dt)
+        n2.storage_dtype = n2.computation_dtype = dt
+        with torch.no_grad():
+            o = n2(x.to(dt), t, context=ctx.to(dt), y=y.to(dt), guidance=guid).float()
+        floors[f"flux_depth4x8_fwd.pt:out@{tag}"] = metrics(o, out)
+        print("  %s run done" % tag, flush=True)
+    update(floors)
+
+
 def floors_sdxl_full():
     cfg = synth.SDXL_UNET_CONFIG
     g = _load("sdxl_full_fwd.pt")
@@ -586,6 +619,8 @@ def main():
         gen_vae_bf16()
     if a.only == "flux_width":
         gen_flux_width()
+    if a.only == "flux_depth":
+        gen_flux_depth()
     if a.only == "config3":
         gen_config3(a.steps)
     if a.only == "config3_b8":

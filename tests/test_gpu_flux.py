@@ -235,6 +235,28 @@ def test_flux_forward_at_its_own_width_vs_reference_fixture(dt, tag):
           floor=f"flux_width3072_fwd.pt:out@{tag}")
 
 
+@pytest.mark.parametrize("dt,tag", [(torch.bfloat16, "bf16"), (torch.float16, "f16")])
+def test_flux_forward_at_its_own_width_with_depth_vs_reference_fixture(dt, tag):
+    """Error growth over a STACK of blocks at Flux's own width: 4 double-stream + 8 single-stream blocks (2.5 B parameters, 4096 + 256
+    tokens), one forward of the REAL reference (CPU fp32, oracle/make_floor.py gen_flux_depth) against the native executor in the reference's compute type
+    (bf16) and in fp16, each held against the reference's own run in that type."""
+    import os
+    from conftest import GOLDEN
+    if not os.path.exists(os.path.join(GOLDEN, "flux_depth4x8_fwd.pt")):
+        pytest.skip("depth fixture not generated")
+    from oracle.make_floor import FLUX_DEPTH_CONFIG, flux_width_inputs
+    g = load_golden("flux_depth4x8_fwd.pt")
+    cfg = FLUX_DEPTH_CONFIG
+    assert (cfg["depth"], cfg["depth_single_blocks"]) == (g["depth"], g["depth_single_blocks"])
+    net = IntegratedFluxTransformer2DModel(cfg, synth.synth_flux_state_dict(cfg, seed=g["weights_seed"]), device=DEV, dtype=dt)
+    x, t, ctx, y, guid = flux_width_inputs(cfg, seed=g["inputs_seed"])
+    out = net.forward(x.to(DEV), t.to(DEV), ctx.to(DEV, dt), y.to(DEV, dt), guid.to(DEV))
+    check(f"flux forward at width 3072 with depth ({g['depth']} double + {g['depth_single_blocks']} single blocks), {tag} build vs reference", out, g["out"],
+          floor=f"flux_depth4x8_fwd.pt:out@{tag}")
+    del net
+    torch.cuda.empty_cache()
+
+
 def test_bf16_flux_forward_and_sampling_vs_reference_fixture():
     """The Flux executor with dtype=bfloat16 against the fp32 reference fixture (forward and the 4-step Euler run)."""
     g = load_golden("tiny_flux_fwd.pt")

@@ -276,7 +276,8 @@ torch.save(out, sys.argv[1])
     for k in outs["32"]:
         close(outs["32"][k], outs["16"][k], 2e-3, 2e-3, f"32x32x16 loop vs 16x16x32 loop: {k}")
         assert torch.equal(outs["stray"][k], outs["16"][k]), f"a knob without FMX_ALLOW_KNOBS=1 changed the kernel: {k}"
-    assert any(not torch.equal(outs["32"][k], outs["16"][k]) for k in outs["32"]), "the allowed knob selected no other kernel"
+    # (the 32x32x16 and 16x16x32 loops accumulate each output over K in the same order in fp32 and may well agree bit for bit: that the allowed knob
+    #  took effect is what fmx_active_knobs() says above, not a difference in the results)
 
 
 def test_cross_tile_prefetch_matches_the_per_tile_prologue_bit_for_bit():

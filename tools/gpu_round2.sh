@@ -15,6 +15,14 @@ pmc_pass() {  # $1 = pass name, $2.. = counters ; workload: tools/pmc_kernels.py
 }
 for w in "$@"; do
   case $w in
+    pmc_4w) for PASS in "mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" "waves SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA" \
+                        "lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_WAVE_CYCLES" "l2 TCP_TCC_READ_REQ_sum TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum" \
+                        "lat TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum" "fetch FETCH_SIZE SQ_INSTS_VMEM_RD SQ_INSTS_SALU"; do
+              set -- $PASS; name=$1; shift
+              (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --pmc "$@" -f csv -d $O/pmc4w_$name -o pmc -- python $R/tools/pmc_gemm4w.py 3 > $O/pmc4w_$name.log 2>&1); tail -1 $O/pmc4w_$name.log
+              find $O/pmc4w_$name -name '*kernel_trace.csv' -delete; done
+            python tools/pmc_gemm4w_summary.py $O > $O/pmc_gemm4w_summary.json; cat $O/pmc_gemm4w_summary.json;;
+    retest) timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_e2e.py -m gpu -q --tb=short -k "knob or batch8" -s 2>&1 | grep -v "^\[parity\] SDXL 1024x1024 batch 8 distinct" | tail -15 > $O/retest.log; cat $O/retest.log;;
     gemm4w) timeout 900 python tools/bench_kernels.py gemm4w > $O/gemm4w.jsonl 2> $O/gemm4w.err; cat $O/gemm4w.jsonl; tail -3 $O/gemm4w.err;;
     ktests4w) timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_rccl.py tests/test_gpu_vae_bf16.py -m gpu -q --tb=short -k "two_workgroup or linear_plain or gemm256 or knob or rccl or overflow or layernorm_folded" 2>&1 | tail -40 > $O/ktests4w.log; tail -25 $O/ktests4w.log;;
     ab_4w) for E in FMX_GEMM_4W=0 FMX_GEMM_4W=2 FMX_GEMM_4W=0 FMX_GEMM_4W=2; do env $E timeout 600 python bench.py --no-cpu-baseline --no-vae --no-rccl-selfcheck --steps 10 --breakdown $O/breakdown_$E.jsonl 2>> $O/ab4w.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'env':'$E','ms_per_step':d['ms_per_step'],'gemm_tflops':d['roofline']['achieved'],'gemm_ms':d['roofline']['kernel_time_per_forward_ms'],'attn':d['roofline_attention']['achieved'],'sclk':(d.get('clocks_during_timed_steps') or {}).get('sclk_mhz'),'power':(d.get('clocks_during_timed_steps') or {}).get('power_w'),'knobs':d.get('knobs')}))" >> $O/ab4w.jsonl; done; cat $O/ab4w.jsonl; tail -3 $O/ab4w.err;;
