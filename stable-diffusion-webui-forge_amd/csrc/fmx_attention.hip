@@ -653,28 +653,12 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void attn_q64v2_kernel(const
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float e = __builtin_amdgcn_exp2f(sacc[s][a][r]);
-#ifdef FMX_ATTN_SUM_F32   // A/B build (tools/build_variant.sh): rounds 2-3 summed the fp32 exponentials, one v_add each
+          // (row sums from the PACKED P through v_dot2c_f32_f16 -- 32 instead of 64 vector instructions per tile, and a denominator made of exactly the
+          //  fp16 values the P.V MFMA multiplies -- were measured in round 4 and LOSE: 4096 keys 665 -> 692 us, 1024 keys level, batch 2 114 -> 128 us
+          //  (profiles/r10c_attention_dot2_row_sums_negative_result.jsonl); fewer instructions, a longer dependent chain behind the packing.  Not kept.)
           if (s == 0) ps0 += e; else ps1 += e;
-#endif
           pf[a][s][r >> 3][r & 7] = (f16)e;
         }
-#ifndef FMX_ATTN_SUM_F32
-      // row sums from the PACKED P (round 4): v_dot2c adds the two halves of a register of P to an fp32 sum in ONE instruction -- 32 instead of 64
-      // vector instructions per 64 x 64 tile in a loop that is vector-issue-bound -- and the denominator is then the sum of exactly
-      // the fp16 values the P.V MFMA multiplies with (numerator and denominator round alike; denormal P: tools/ubench/dot2_denorm.hip)
-      {
-        const f16x2 one2 = {(f16)1.0f, (f16)1.0f};
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int q2 = 0; q2 < 4; ++q2) {
-              const f16x2 pr = {pf[a][s][j][2 * q2], pf[a][s][j][2 * q2 + 1]};
-              if (s == 0) ps0 = FMX_DOT2(pr, one2, ps0); else ps1 = FMX_DOT2(pr, one2, ps1);
-            }
-      }
-#endif
       l_run[a] += ps0 + ps1;
     }
 

@@ -20,7 +20,6 @@ typedef __bf16 f16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 f16x8 __attribute__((ext_vector_type(8)));
 #define FMX_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 #define FMX_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
-#define FMX_DOT2(a, b, c) __builtin_amdgcn_fdot2_f32_bf16(a, b, c, false)      // v_dot2c_f32_bf16: c + a.x b.x + a.y b.y in fp32
 #else
 typedef _Float16 f16;
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -28,7 +27,6 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define FMX_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
 #define FMX_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
-#define FMX_DOT2(a, b, c) __builtin_amdgcn_fdot2(a, b, c, false)               // v_dot2c_f32_f16
 #endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -14,8 +14,7 @@
 //   LDS: a workgroup may use 80 KB.  Two stages of a 64-deep K-tile are (256 + 160) x 128 B x 2 = 104 KB -- too much; so the K-tile is 32 deep (one
 //   k-step of the 16x16x32 loop, 64-byte LDS rows) and the ring has THREE stages of 26 KB = 78 KB: the LDS-DMA pieces of K-tile t + 3 are issued
 //   behind the barrier of K-tile t into the stage that barrier released and have two K-tiles (~1.3 us with both workgroups on the pipes) to land.
-//   64-byte rows: 16-byte chunk c of row r lives at chunk c ^ ((r >> 2) & 3) (source side of the DMA and ds_read side): the 16 rows x 4 chunks a
-//   fragment read touches fall into 16 distinct bank groups.  Fragment i of an operand is 1 KiB behind fragment 0 (16 rows do not change the key).
+//   64-byte rows: 16-byte chunk c of row r lives at chunk c ^ ((r >> 1) & 3) (source side of the DMA and ds_read side; see lds_off64).  Fragment i of an operand is 1 KiB behind fragment 0 (16 rows do not change the key).
 //
 //   K-tile t:   MFMAs 0..14 (nothing rides behind them: the fragment re-reads issued last complete under them)
 //               s_waitcnt vmcnt(pieces of one K-tile) lgkmcnt(0) | s_barrier      -> K-tile t + 1 has landed for every wave, stage t % 3 is free
@@ -41,7 +40,9 @@ constexpr int NPA = 4, NPB = 3;         // LDS-DMA pieces (16 rows x 64 B) per w
 constexpr int XSL = NJ * 2048;          // a wave's transpose slice of the epilogue: 16 rows x 160 fp32
 static_assert(4 * XSL <= LDS_BYTES, "epilogue slices fit the stages");
 
-__device__ __forceinline__ int lds_off64(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+// key (row >> 1) & 3: the one of the candidate keys that tools/ubench/lds_b128_patterns.hip times as conflict-free for a 16-row fragment read; the first
+// version of this file keyed on (row >> 2) & 3 and ran with SQ_LDS_BANK_CONFLICT = 0.46 of SQ_LDS_IDX_ACTIVE (profiles/r10b_pmc_gemm4w_vs_256x320.json)
+__device__ __forceinline__ int lds_off64(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 3)) << 4); }
 
 // LN: 0 plain, 1 LayerNorm producer (per-row statistics of the stored output), 2 LayerNorm consumer (incl. GEGLU) -- fmx_gemm_epi.hpp
 template <int LN>
@@ -72,9 +73,9 @@ __global__ __launch_bounds__(256, 2) void gemm4w_kernel(const GemmParams p) {
     tile_origin(lid, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
-    // ---- staging: a piece = 16 rows x 64 B; lane -> row lane / 4, physical chunk lane & 3, logical chunk = physical ^ ((row >> 2) & 3) -----------
+    // ---- staging: a piece = 16 rows x 64 B; lane -> row lane / 4, physical chunk lane & 3, logical chunk = physical ^ ((row >> 1) & 3) -----------
     const int r16 = lane >> 2;
-    const unsigned kcb = (unsigned)((lane & 3) ^ ((lane >> 4) & 3)) * 16u;
+    const unsigned kcb = (unsigned)((lane & 3) ^ ((lane >> 3) & 3)) * 16u;   // (row >> 1) & 3 with row = 16 k + lane / 4
     constexpr unsigned OOB = 0xC0000000u;   // beyond num_records: the hardware writes zeros into LDS (tools/ubench/oob_probe.hip)
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(p.a0), 0, p.a0_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(p.wgt), 0, p.w_bytes, 0x00020000);
