@@ -63,6 +63,21 @@ CONFIGS = {
 REFERENCE_CPU_AUTHORING_BOX = {"sd15": {"it_per_s_b1_cfg": 0.468, "cores": 8, "source": "BASELINE.md section 2 (reference modules, SD1.5 512^2 B=1 20-step Euler)"}}
 
 
+def reference_on_authoring_box(model):
+    """The REAL reference's own CPU path for this workload's network, timed where /root/reference exists (the authoring container; the GPU box has only
+    the oracle port): profiles/cpu_reference_sdxl_b1.json is written by oracle/time_reference.py (a sampler run: Euler, CFG 7, batch 1); the batch-8 figure
+    is the reference's 5-step DPM++ 2M run that produced tests/golden/sdxl_config3_b8.pt (oracle/make_floor.py gen_config3_b8, 874 s incl. the model build)."""
+    if model == "sdxl":
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", "cpu_reference_sdxl_b1.json")))
+            return {"it_per_s_b1_cfg": d["it_per_s_b1_cfg"], "seconds_per_step_b1": d["seconds_per_step"], "cores": d["cores"], "cpu": d["cpu"],
+                    "it_per_s_b8_cfg_measured": round(5 / 874.0, 5), "source": "profiles/cpu_reference_sdxl_b1.json (oracle/time_reference.py: the real reference, "
+                    "SDXL 1024^2 B=1 Euler CFG 7, fp32) + the batch-8 fixture run of oracle/make_floor.py gen_config3_b8"}
+        except Exception:  # noqa: BLE001
+            return None
+    return REFERENCE_CPU_AUTHORING_BOX.get(model)
+
+
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -651,8 +666,9 @@ def main():
             dt, nthreads, note = cpu_baseline(model, ucfg, latent, sampler_name, cfg_scale)
             out["cpu_baseline"] = {"value": round(1.0 / (fwd_per_image * bpg * dt), 6), "unit": "it/s", "cores": nthreads, "kind": "port",
                                    "sample": note + f"; a step of this workload is {fwd_per_image * bpg} such forwards"}
-            if model in REFERENCE_CPU_AUTHORING_BOX:
-                out["cpu_baseline"]["reference_on_authoring_box"] = REFERENCE_CPU_AUTHORING_BOX[model]
+            ref_box = reference_on_authoring_box(model)
+            if ref_box:
+                out["cpu_baseline"]["reference_on_authoring_box"] = ref_box
         except Exception as e:  # the baseline must never take the bench line down
             out["cpu_baseline"] = {"value": None, "error": repr(e)}
     if rank == 0 and world == 1 and not a.no_rccl_selfcheck:

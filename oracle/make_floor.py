@@ -236,6 +236,27 @@ def floors_pipeline():
     update(out)
 
 
+def floors_schedulers(steps=4):
+    """One floor PER SCHEDULE for tests/test_gpu_e2e.py::test_scheduler_choice_reaches_the_sampler (round 4): until round 3 those 14 comparisons borrowed
+    the floor of the 6-step Euler fixture on the default schedule -- other seeds, other sigmas -- and 6 of the 9 parity rows whose rms sat ABOVE their
+    floor were exactly these (profiles/r09_parity_vs_fp16_floor.jsonl).  Same job as the test: tiny SD1.5, seeds 5 / 6, 4 Euler steps on the fixture's
+    sigmas of each scheduler, reference fp16 against reference fp32."""
+    cfg = synth.TINY_SD15_UNET_CONFIG
+    sd = synth.synth_unet_state_dict(cfg, seed=0)
+    net32, net16 = _real_build_ref_unet(cfg, sd), half_unet(cfg, sd)
+    g = _load("schedulers.pt")
+    c, uc = synth.synth_conditioning(2, cfg["context_dim"], None, seed=1234)
+    out = {}
+    for key, label in g["labels"].items():
+        if (key, steps, False) not in g:
+            continue
+        sig = g[(key, steps, False)]
+        l32, _ = mg.ref_sample(net32, cfg, c, uc, [5, 6], 16, steps, "Euler", sigmas_override=sig)
+        l16, _ = mg.ref_sample(net16, cfg, c, uc, [5, 6], 16, steps, "Euler", sigmas_override=sig)
+        out[f"schedulers.pt:{label}/latent"] = metrics(l16, l32)
+    update(out)
+
+
 def floors_sd15_full():
     """BASELINE config 0 (tests/golden/sd15_config0.pt): full-size forward, 20-step Euler latents, decoded image."""
     cfg = synth.SD15_UNET_CONFIG
@@ -605,6 +626,8 @@ def main():
         floors_tiny()
     if a.only == "pipeline":
         floors_pipeline()
+    if a.only in ("", "schedulers"):
+        floors_schedulers()
     if a.only in ("", "aux"):
         floors_aux()
     if a.only in ("", "sd15"):

@@ -180,8 +180,9 @@ class _Hijack:
         return getattr(torch, item)
 
 
-def ref_sample(net, cfg, cond, uncond, seeds, hw, steps, sampler, cfg_scale=7.0, source="CPU", trace=None):
-    """Reference k-diffusion loop + reference sampling_function + reference UNet (CPU fp32)."""
+def ref_sample(net, cfg, cond, uncond, seeds, hw, steps, sampler, cfg_scale=7.0, source="CPU", trace=None, sigmas_override=None):
+    """Reference k-diffusion loop + reference sampling_function + reference UNet (CPU fp32).  sigmas_override: run the sampler on this schedule
+    (the scheduler fixtures) instead of the sampler's default one."""
     ref = ref_import.load_reference()
     pred = ref_import.build_ref_predictor()
     den = ref_import.RefDenoiser(net, pred, seeds)
@@ -195,6 +196,8 @@ def ref_sample(net, cfg, cond, uncond, seeds, hw, steps, sampler, cfg_scale=7.0,
     else:
         sigmas = linker.get_sigmas(steps)
         fn = ref.kd_sampling.sample_euler if sampler == "Euler" else ref.kd_sampling.sample_euler_ancestral
+    if sigmas_override is not None:
+        sigmas = sigmas_override
     x = pred.noise_scaling(sigmas[0], x, torch.zeros_like(x), max_denoise=False)
     ref.kd_sampling.torch = _Hijack(rng)
     ref.sampling_function.sampling_prepare(den.patcher, x=x)
