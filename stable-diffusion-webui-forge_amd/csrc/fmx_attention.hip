@@ -1616,6 +1616,9 @@ int launch_attn_short(AttnParams p, hipStream_t st) {
 // are read from there (chunk-swizzled like the K tile), and O goes back through the slot the tile's Q has just left: lanes write their
 // 16-byte pieces, then 8 lanes per row store whole lines.  A workgroup walks a contiguous range of the launch's (batch, head, tile) list and
 // restages K / V^T when the (batch, head) changes, so any grid size balances: 2 workgroups per CU (64 KB of LDS each), all resident.
+// (Round 4: Q requested TWO tiles ahead -- three slots per wave, one descriptor over the whole Q tensor so that the prefetch also crosses (batch, head)
+// changes -- was built and measured: 27.6 / 46.4-47.6 us against 27.5 / 46.0 us per launch, profiles/r10e_short_context_attention_two_tiles_ahead.jsonl.
+// The lead time of the Q request is not what holds the launch at 0.4 of the HBM rate; the one-tile form stays.)
 template <int NB>
 __global__ __launch_bounds__(256, 2) void attn_short2_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1628,8 +1631,7 @@ __global__ __launch_bounds__(256, 2) void attn_short2_kernel(const AttnParams p)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, li = lane & 31;
-  constexpr int NSLOT = 3;                                   // Q / O slots per wave: Q is requested TWO tiles ahead (round 4)
-  char* const slots = smem + KV_BYTES + wave * (NSLOT * 4096);
+  char* const slots = smem + KV_BYTES + wave * 8192;   // this wave's two Q / O slots
   // tiles [g0, g1) of the flattened (batch * heads, 128-query tile) list
   const int total = p.batch * p.heads * p.qtiles;
   const int per = (total + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -1644,31 +1646,22 @@ __global__ __launch_bounds__(256, 2) void attn_short2_kernel(const AttnParams p)
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
   int bh_cur = -1;
-  // ONE descriptor over the whole Q tensor (the launcher checks that it spans < 2^32 bytes): the Q tile of ANY entry of the (batch, head, tile) list can be
-  // requested ahead of time, also across a change of (batch, head) -- until round 3 the descriptor was per (batch, head) and the prefetch stopped there.
-  // Rows >= nq of a head's last tile read the next rows of the tensor (finite values of another query: computed, never stored -- a lane is a query) or,
-  // past the end of the tensor, zeros.
-  const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(p.q), 0, p.q_span, 0x00020000);
-  // Q tile of list entry g -> slot: 4 pieces of 8 rows x 128 B (whole lines)
-  auto dma_q = [&](int g, int slot) {
-    const int bh_ = g / p.qtiles, tile_ = g - bh_ * p.qtiles;
-    const int h_ = bh_ % p.heads, b_ = bh_ / p.heads;
-    // (the (batch, head) base rides in the per-lane offset, not in the scalar offset operand: the descriptor's bounds check looks at the former only)
-    const unsigned base = (unsigned)((long)b_ * p.q_bs + (long)h_ * DP) * 2u;   // uniform
+  __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(p.q), 0, 0, 0x00020000);
+  auto q_desc = [&](int bh) {
+    const int h = bh % p.heads, b = bh / p.heads;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(p.q + (long)b * p.q_bs + (long)h * DP), 0, p.q_span, 0x00020000);
+  };
+  // Q tile `tile` of the current (batch, head) -> slot: 4 pieces, rows >= nq read as zeros (descriptor bounds)
+  auto dma_q = [&](const __amdgpu_buffer_rsrc_t& rs, int tile, int slot) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int row = e * 8 + r8;
-      const unsigned off = base + (unsigned)(tile_ * 128 + wave * 32 + row) * (unsigned)p.q_rs * 2u + (unsigned)k_logical_chunk<CPR>(row, pc) * 16u;
+      const unsigned off = (unsigned)(tile * 128 + wave * 32 + row) * (unsigned)p.q_rs * 2u + (unsigned)k_logical_chunk<CPR>(row, pc) * 16u;
       auto* dst = (__attribute__((address_space(3))) void*)(slots + slot * 4096 + e * 1024);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_q, dst, 16, off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, off, 0, 0, 0);
     }
   };
 
-  // Q two tiles ahead, three slots.  Memory operations of a wave in program order:  Q(t+2) x4, O(t) x4, Q(t+3) x4, O(t+1) x4, ...  -> when tile t+2 starts,
-  // 12 operations were issued behind its Q: s_waitcnt vmcnt(12) (the counter retires in order).  A tile period of ~1 us against 2-3 us of loaded
-  // memory latency left the waves waiting on a ONE-tile lead (0.41 of the HBM rate, profiles/r09); two tiles of lead keep 64 KB per CU in flight.
-  dma_q(g0, 0);
-  if (g0 + 1 < g1) dma_q(g0 + 1, 1);
   int slot = 0;
   for (int g = g0; g < g1; ++g) {
     const int bh = g / p.qtiles, tile = g - bh * p.qtiles;
@@ -1681,6 +1674,7 @@ __global__ __launch_bounds__(256, 2) void attn_short2_kernel(const AttnParams p)
         __syncthreads();
       }
       bh_cur = bh;
+      rs_q = q_desc(bh);
       const f16* kbase = p.k + (long)b * p.k_bs + (long)h * DP;
       const f16* vbase = p.vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
       const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(kbase), 0, p.k_span, 0x00020000);
@@ -1698,11 +1692,12 @@ __global__ __launch_bounds__(256, 2) void attn_short2_kernel(const AttnParams p)
           auto* dv = (__attribute__((address_space(3))) void*)(smem + kt * STAGE + KBYTES + (e * 4 + wave) * 1024);
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, dv, 16, vv, (unsigned)kt * (KVB * 2u), 0, 0);
         }
-      wait_vmcnt0();      // (also drains the Q requests in flight: they are this tile's and the next one's)
+      dma_q(rs_q, tile, slot);
+      wait_vmcnt0();
       __syncthreads();
     } else {
-      // this tile's Q was requested two tiles ago: behind it in the (in-order) counter are O(t-2), Q(t+1), O(t-1) = 12 operations
-      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      // this tile's Q was requested a tile ago; behind it in the (in-order) counter are only the 4 line stores of the previous tile's O
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     }
     // ---- Q fragments out of the slot (pre-scaled), then the NEXT tile's Q into the other slot ----
     f16x8 qf[DSTEPS];
@@ -1715,11 +1710,11 @@ __global__ __launch_bounds__(256, 2) void attn_short2_kernel(const AttnParams p)
         for (int e = 0; e < 8; ++e) qf[ds][e] = (f16)((float)raw[e] * c2);
       }
     }
-    const bool more = g + 2 < g1;   // uniform
-    // pinned in program order: the vmcnt(12) above counts the operations between a Q request and its use
+    const bool more = g + 1 < g1 && (g + 1) / p.qtiles == bh;   // uniform
+    // pinned in program order: the vmcnt(4) above counts on exactly this tile's four O stores being the only memory operations behind it
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    if (more) dma_q(g + 2, slot >= 1 ? slot - 1 : NSLOT - 1);   // (slot + 2) % 3: the slot tile t-1's O has left (its line reads completed before its stores issued)
+    if (more) dma_q(rs_q, tile + 1, slot ^ 1);
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("" ::: "memory");
 
@@ -1808,13 +1803,13 @@ __global__ __launch_bounds__(256, 2) void attn_short2_kernel(const AttnParams p)
       const int qg = tile * 128 + wave * 32 + row;
       if (qg < p.nq) *reinterpret_cast<u32x4*>(obase + (long)qg * p.o_rs + k_logical_chunk<CPR>(row, pc) * 8) = v;
     }
-    slot = slot == NSLOT - 1 ? 0 : slot + 1;
+    slot ^= 1;
   }
 }
 
 template <int NB>
 int launch_attn_short2_nb(AttnParams& p, int grid, hipStream_t st) {
-  constexpr int SMEM = 2 * (KVB * 64 * 2 + 2 * 32 * 128) + 4 * 3 * 4096;   // K / V^T of one (batch, head) + three 4-KiB Q / O slots per wave = 80 KB: two workgroups per CU
+  constexpr int SMEM = 2 * (KVB * 64 * 2 + 2 * 32 * 128) + 4 * 8192;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_short2_kernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
@@ -1834,8 +1829,8 @@ int launch_attn_short2(AttnParams p, hipStream_t st) {
   }
   p.qtiles = (p.nq + 127) / 128;
   const long total = (long)p.batch * p.heads * p.qtiles;
-  const double q_span = ((double)(p.batch - 1) * p.q_bs + (double)(p.nq - 1) * p.q_rs + (double)p.heads * 64) * 2.0;   // the whole Q tensor
-  if (q_span >= 3.0e9 || total >= (1L << 30)) return -1;
+  const double q_span = ((double)(p.nq - 1) * p.q_rs + 64) * 2.0;
+  if (q_span >= 2.0e9 || total >= (1L << 30)) return -1;
   p.q_span = (unsigned)q_span;
   const int grid = (int)(total < slots ? total : slots);
   const int nb = (p.nk + 31) / 32;
