@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define FMX_ABI_VERSION 7
+#define FMX_ABI_VERSION 8
 
 #define FMX_OK 0
 #define FMX_E_BADARG 10001   /* shape / alignment / null-pointer contract violated */
@@ -123,7 +123,8 @@ typedef struct fmx_gemm_args {
   /* LayerNorm folded into its consumer (ABI 5; backend/nn/unet.py:262-279, norm2 / norm3 of a BasicTransformerBlock).  With ln_partial set,
    * this GEMM computes  LN(x) W^T + b  from the UN-normalised x:  wgt = W * gamma (per input channel), ln_colsum[n] = sum_k wgt[n][k] in fp32
    * (of the fp16 values), bias = W beta + b;  ln_partial = the row statistics fmx_gemm_linear_rowstats_f16 left for x, ln_parts entries per
-   * row.  Linear only (kh 1), act NONE or GEGLU, no residual / rowvec / gate, fp16 output; always the 256x320 tile. */
+   * row (1..8: one per 160 output columns of the producer).  Linear only (kh 1), act NONE or GEGLU, no residual / rowvec / gate, fp16 output; the
+   * 256x320 tile (or, under the development knob FMX_GEMM_4W, the 256x160 two-workgroups-per-CU tile of csrc/fmx_gemm4w.hip: same arrays). */
   const void* ln_partial;
   int32_t ln_parts;
   const void* ln_colsum;
@@ -334,6 +335,12 @@ int fmx_vae_pack_latent(const float* z, float scaling_factor, float shift, int32
 /* generic 3x3 im2col for tiny channel counts: x fp16 NHWC [n][h][w][ldx] (first c channels) -> out fp16
  * [n*h*w][64] with column (ky*3+kx)*c + ch, c*9 <= 64 */
 int fmx_im2col3x3_smallc(const void* x, int32_t ldx, int32_t n, int32_t c, int32_t h, int32_t w, void* out, void* stream);
+/* 3x3 convolution (stride 1, zero padding 1) with at most 4 output channels: the VAE decoder's conv_out (/root/reference/backend/nn/vae.py:248-271, the
+ * last layer: 128 -> 3 channels at the full image size).  x NHWC [n][h][w][c] 16-bit, c = 32 / 64 / 128; wgt [nout][ky][kx][c] (the GEMM entry's
+ * weight layout); bias [nout] or null; out [n*h*w][ld_out], columns >= nout of an ld_out = 4 output are written as zeros.  A direct kernel (the input
+ * patch of a 4 x 32 pixel tile staged once in LDS) instead of the implicit GEMM's nine-fold im2col gather; HBM-bound (ABI 8). */
+int fmx_conv3x3_narrow_f16(const void* x, int32_t n, int32_t h, int32_t w, int32_t c, const void* wgt, const void* bias, int32_t nout, void* out,
+                           int32_t ld_out, void* stream);
 /* VAE output: y fp16 NHWC [b*h*w][ld] (first c channels) -> clamp((y+1)/2, 0, 1) fp32 NHWC [b][h][w][c] */
 int fmx_vae_unpack_image(const void* y, int32_t ld, int64_t npix, int32_t c, float* out, void* stream);
 
@@ -391,6 +398,8 @@ int fmx_attention_single_head512_bf16(const void* q, int64_t q_bs, int64_t q_rs,
 int fmx_vae_pack_latent_bf16(const float* z, float scaling_factor, float shift, int32_t b, int32_t c, int32_t h, int32_t w,
                              void* out, int32_t ld, void* stream);
 int fmx_vae_unpack_image_bf16(const void* y, int32_t ld, int64_t npix, int32_t c, float* out, void* stream);
+int fmx_conv3x3_narrow_bf16(const void* x, int32_t n, int32_t h, int32_t w, int32_t c, const void* wgt, const void* bias, int32_t nout, void* out,
+                            int32_t ld_out, void* stream);
 int fmx_vae_sample_posterior_bf16(const void* moments, int32_t ld, const float* noise, int32_t b, int32_t lc, int64_t npix, float scale,
                                   float shift, float* out, void* stream);
 

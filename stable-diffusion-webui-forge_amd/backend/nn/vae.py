@@ -259,11 +259,17 @@ class IntegratedAutoencoderKL:
                 h, st = ops.conv_gemm(h, self.w[up][0], c, kh=3, pad=1, up=(2 * h2, 2 * w2), bias=self.w[up][1], stats=True)
                 h = ops.attach_stats(h.view(bb, 2 * h2, 2 * w2, c), st)
         g = ops.groupnorm(h, *self.w["norm_out"], 1e-6, silu=True)
-        # [npix, 4] with 3 valid columns: the GEMM epilogue never writes column 3, and the arena hands out recycled bytes -- zeroed, so that the
-        # overflow guard's scan of the whole buffer (ops.count_nonfinite) cannot trip over a stale inf / NaN half-word there
-        y = ops.empty((g.shape[0] * g.shape[1] * g.shape[2], 4), self.dtype)
-        y.zero_()
-        y = ops.conv_gemm(g, self.w["conv_out"][0], lay.out_channels, kh=3, pad=1, bias=self.w["conv_out"][1], out=y, ld_out=4)
+        co, cin = lay.out_channels, g.shape[-1]
+        if co <= 4 and cin in (32, 64, 128) and g.numel() * 2 < 3.0e9:
+            # conv_out as a DIRECT 3x3 kernel (round 4): the implicit GEMM spends 2.2 ms per 8 x 1024^2 on a 3-column output (nine-fold im2col gather,
+            # 97 % padding columns); this one stages each input patch once and writes all four columns of [npix, 4] (the pad column as zeros)
+            y = ops.conv3x3_narrow(g, self.w["conv_out"][0], self.w["conv_out"][1], co)
+        else:
+            # [npix, 4] with 3 valid columns: the GEMM epilogue never writes column 3, and the arena hands out recycled bytes -- zeroed, so that the
+            # overflow guard's scan of the whole buffer (ops.count_nonfinite) cannot trip over a stale inf / NaN half-word there
+            y = ops.empty((g.shape[0] * g.shape[1] * g.shape[2], 4), self.dtype)
+            y.zero_()
+            y = ops.conv_gemm(g, self.w["conv_out"][0], co, kh=3, pad=1, bias=self.w["conv_out"][1], out=y, ld_out=4)
         return y
 
     def _run(self, z):

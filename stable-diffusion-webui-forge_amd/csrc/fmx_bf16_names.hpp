@@ -15,6 +15,7 @@
 #define fmx_groupnorm_stats_f16 fmx_groupnorm_stats_bf16
 #define fmx_groupnorm_apply_f16 fmx_groupnorm_apply_bf16
 #define fmx_attention_single_head512_f16 fmx_attention_single_head512_bf16
+#define fmx_conv3x3_narrow_f16 fmx_conv3x3_narrow_bf16
 #define fmx_launch_gn_stats fmx_launch_gn_stats_bf16
 // host-side C++ symbols shared between the GEMM files
 #define fmx_launch_gemm256p fmx_launch_gemm256p_bf16

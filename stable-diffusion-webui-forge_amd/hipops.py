@@ -748,6 +748,18 @@ def count_nonfinite(x):
     return int(cnt.item())
 
 
+def conv3x3_narrow(x, wgt, bias, nout, out=None, ld_out=4):
+    """3x3 convolution (stride 1, padding 1) with at most 4 output channels, direct kernel (fmx_conv3x3_narrow): x NHWC [n, h, w, c] with c in
+    (32, 64, 128), wgt [nout, 9 * c] in the GEMM's tap-major layout -> [n * h * w, ld_out] (columns >= nout zero when ld_out == 4)."""
+    sfx, elem = _elem(x, wgt, bias)
+    n, h, w, c = x.shape
+    if out is None:
+        out = empty((n * h * w, ld_out), elem, x.device)
+    name = "fmx_conv3x3_narrow" + sfx
+    _lib.check(getattr(_lib.lib(), name)(_p(x), n, h, w, c, _p(wgt), _p(bias), nout, _p(out), ld_out, stream_ptr()), name)
+    return out
+
+
 def vae_unpack_image(y, ld, npix, c, out):
     name = "fmx_vae_unpack_image" + _vae_sfx(y.dtype)
     _lib.check(getattr(_lib.lib(), name)(_p(y), ld, npix, c, _p(out), stream_ptr()), name)

@@ -97,13 +97,13 @@ def test_other_contract_violations(lib):
     assert lib.fmx_gemm_conv_stats_f16(C.byref(_gemm(ld_out=64)), f, 1, 2, C.byref(nch), None) == BADARG and "chunk counts" in err()
     assert lib.fmx_gemm_conv_stats_f16(C.byref(_gemm(ld_out=64)), None, 4, 2, C.byref(nch), None) == BADARG
     assert lib.fmx_gemm_conv_f16(C.byref(_gemm(ld_out=64, out_f32=-4)), None) == BADARG and "no longer part" in err()   # the retired ping-pong tile id
-    # LayerNorm folding: a GEMM is the producer OR the consumer; the consumer is a plain linear with column sums and an even part count <= 8
+    # LayerNorm folding: a GEMM is the producer OR the consumer; the consumer is a plain linear with column sums and 1..8 parts (one per 160 output columns of the producer)
     parts = C.c_int32(0)
     assert lib.fmx_gemm_linear_rowstats_f16(C.byref(_gemm(ld_out=64)), None, 8, C.byref(parts), None) == BADARG
     assert lib.fmx_gemm_linear_rowstats_f16(C.byref(_gemm(ld_out=64)), f, 1, C.byref(parts), None) == BADARG
     assert lib.fmx_gemm_linear_rowstats_f16(C.byref(_gemm(ld_out=64, ln_partial=FAKE, ln_parts=2, ln_colsum=FAKE)), f, 8, C.byref(parts), None) == BADARG \
         and "producer or the consumer" in err()
-    for bad in (dict(ln_parts=3), dict(ln_parts=10), dict(ln_colsum=0), dict(residual=FAKE, ld_res=64), dict(kh=3, pad=1), dict(act=2)):
+    for bad in (dict(ln_parts=0), dict(ln_parts=10), dict(ln_colsum=0), dict(residual=FAKE, ld_res=64), dict(kh=3, pad=1), dict(act=2)):
         kw = dict(ld_out=64, ln_partial=FAKE, ln_parts=2, ln_colsum=FAKE, ln_eps=1e-5)
         kw.update(bad)
         assert lib.fmx_gemm_conv_f16(C.byref(_gemm(**kw)), None) == BADARG and "LayerNorm-folded" in err(), bad

@@ -1013,3 +1013,34 @@ def test_philox_bit_exact():
     want = np.stack(philox4x32_10(np.full(n, 3, np.uint32), z, idx, z, np.full(n, 12345, np.uint32), z), 1)
     np.testing.assert_array_equal(raw.cpu().numpy().view(np.uint32), want)  # integer path: bit exact
     np.testing.assert_allclose(out.cpu().numpy(), philox_randn(12345, 3, n), rtol=0, atol=2e-6)  # Box-Muller: device libm
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("n,hh,ww,c,co", [(2, 64, 64, 128, 3), (1, 37, 50, 128, 3), (3, 5, 7, 64, 4), (1, 130, 33, 32, 1), (1, 256, 256, 128, 3)])
+def test_narrow_output_conv3x3_direct_kernel(n, hh, ww, c, co, dtype):
+    """fmx_conv3x3_narrow (csrc/fmx_conv_narrow.hip, round 4): the VAE decoder's conv_out (128 -> 3 channels, /root/reference/backend/nn/vae.py:248-271) as a
+    direct kernel -- the input patch of a 4 x 32 pixel tile staged once, zero padding through the descriptor's bounds check, the pad column of the
+    [npix, 4] output written as zeros.  Against F.conv2d in fp32 and against the implicit-GEMM path; image sizes that are no multiple of the tile, images
+    narrower than a tile, every supported channel count, both element types."""
+    x = rnd(n, hh, ww, c, seed=300).to(dtype)
+    wt = rnd(co, c, 3, 3, scale=1 / math.sqrt(9 * c), seed=301).to(dtype)
+    b = rnd(co, seed=302).to(dtype)
+    wk = wt.permute(0, 2, 3, 1).reshape(co, -1).contiguous()
+    out = torch.full((n * hh * ww, 4), float("nan"), dtype=dtype, device=DEV)      # a recycled buffer: every column must be written
+    got = ops.conv3x3_narrow(x, wk, b, co, out=out)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).float(), wt.float(), b.float(), padding=1).permute(0, 2, 3, 1).reshape(-1, co)
+    tol = 2e-3 if dtype == torch.float16 else 1.6e-2
+    close(got[:, :co], ref, tol, tol, f"direct 3x3 conv {c} -> {co}")
+    assert bool((got[:, co:] == 0).all()), "pad columns must be zero (the VAE's overflow guard scans the whole buffer)"
+    if dtype == torch.float16:
+        y = torch.zeros(n * hh * ww, 4, dtype=dtype, device=DEV)
+        ops.conv_gemm(x, wk, co, kh=3, pad=1, bias=b, out=y, ld_out=4)
+        close(got[:, :co], y[:, :co].float(), 1e-3, 1e-3, "direct kernel vs the implicit-GEMM path")
+
+
+def test_narrow_output_conv3x3_contract():
+    x = rnd(1, 8, 8, 96, seed=1)
+    with pytest.raises(Exception, match="32, 64 or 128"):
+        ops.conv3x3_narrow(x, rnd(3, 9 * 96, seed=2), None, 3)
+    with pytest.raises(Exception, match="1..4 output"):
+        ops.conv3x3_narrow(rnd(1, 8, 8, 64, seed=1), rnd(5, 9 * 64, seed=2), None, 5, out=torch.zeros(64, 8, dtype=torch.float16, device=DEV), ld_out=8)
