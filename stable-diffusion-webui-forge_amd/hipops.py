@@ -756,7 +756,13 @@ def conv3x3_narrow(x, wgt, bias, nout, out=None, ld_out=4):
     if out is None:
         out = empty((n * h * w, ld_out), elem, x.device)
     name = "fmx_conv3x3_narrow" + sfx
-    _lib.check(getattr(_lib.lib(), name)(_p(x), n, h, w, c, _p(wgt), _p(bias), nout, _p(out), ld_out, stream_ptr()), name)
+
+    def run():
+        _lib.check(getattr(_lib.lib(), name)(_p(x), n, h, w, c, _p(wgt), _p(bias), nout, _p(out), ld_out, stream_ptr()), name)
+    if _profiler is not None:   # HBM-bound: one read of the input, one write of the [npix, ld_out] output
+        _profiler.launch("conv3x3_narrow", 2.0 * n * h * w * 9 * c * nout, run, tag=f"N={n} H={h} W={w} C={c} nout={nout}", nbytes=2.0 * n * h * w * (c + ld_out))
+    else:
+        run()
     return out
 
 

@@ -1032,7 +1032,7 @@ def test_narrow_output_conv3x3_direct_kernel(n, hh, ww, c, co, dtype):
     tol = 2e-3 if dtype == torch.float16 else 1.6e-2
     close(got[:, :co], ref, tol, tol, f"direct 3x3 conv {c} -> {co}")
     assert bool((got[:, co:] == 0).all()), "pad columns must be zero (the VAE's overflow guard scans the whole buffer)"
-    if dtype == torch.float16:
+    if dtype == torch.float16 and c % 64 == 0:     # (the implicit GEMM takes channel counts in multiples of 64)
         y = torch.zeros(n * hh * ww, 4, dtype=dtype, device=DEV)
         ops.conv_gemm(x, wk, co, kh=3, pad=1, bias=b, out=y, ld_out=4)
         close(got[:, :co], y[:, :co].float(), 1e-3, 1e-3, "direct kernel vs the implicit-GEMM path")
