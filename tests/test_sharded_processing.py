@@ -87,7 +87,7 @@ def _worker(rank, world, port, batch, n_iter, with_dict, cfg1, q):
         p = _make_job(batch, n_iter, with_dict, cfg1, give_conds=(rank == 0))      # only the owner has the conditioning
         res = processing.process_images_sharded(p)
         if rank == 0:
-            q.put((rank, res.latents.clone(), np.stack(res.images), list(res.seeds)))
+            q.put((rank, res.latents.cpu().numpy().copy(), np.stack(res.images), list(res.seeds)))   # by value: a tensor would travel as an fd of a process that may be gone
         else:
             q.put((rank, int(res.latents.shape[0]), len(res.images), list(res.seeds)))
     finally:
@@ -116,6 +116,7 @@ def test_sharded_job_equals_the_single_process_job_bit_for_bit(world, batch, n_i
         p.join(timeout=60)
         assert p.exitcode == 0
     lat, imgs, seeds = res[0]
+    lat = torch.from_numpy(lat)
     assert seeds == want.seeds == [4242 + i for i in range(batch * n_iter)]
     assert lat.shape == want.latents.shape and torch.equal(lat, want.latents), "gathered latents differ from the single-process job"
     assert imgs.shape == np.stack(want.images).shape and np.array_equal(imgs, np.stack(want.images))
