@@ -793,6 +793,27 @@ def test_attention_d64_partial_round_key_split(b, h, nq, nk):
     close(_attn_d64(q, k, v, nk=nk), ref, 2e-3, 2e-3, f"attention d64 b{b} h{h} nq{nq} nk{nk}")
 
 
+@pytest.mark.parametrize("b,h,nq,nk", [(16, 20, 1024, 1024), (9, 20, 1000, 896), (9, 20, 1000, 1000), (9, 20, 1000, 960), (3, 10, 4096, 2048)])
+def test_attention_d64_persistent_walk(b, h, nq, nk):
+    """Launches of more 256-query entries than workgroup slots (2 per CU) without a key-split tail and with an even number of key tiles run the PERSISTENT
+    form of attn_q64v2_kernel (round 4): a workgroup walks entries b, b + 512, ..., the last key tile of an entry stages the first K / V^T tile of the next
+    (another batch / head / query tile) and the next Q rows are requested before the O stores.  The bench shape (1280 entries: 3 or 2 per workgroup),
+    ragged query counts, a ragged last key tile, dominant keys at the tile that is prefetched across entries -- and an ODD tile count, which must stay on the
+    one-entry-per-workgroup form.  Against torch fp32, every element."""
+    d = 64
+    nkp = -(-nk // 64) * 64
+    q, k, v = rnd(b, nq, h, d, seed=161), torch.zeros(b, nkp, h, d, dtype=torch.float16, device=DEV), torch.zeros(b, nkp, h, d, dtype=torch.float16, device=DEV)
+    k[:, :nk], v[:, :nk] = rnd(b, nk, h, d, scale=1.3, seed=162), rnd(b, nk, h, d, seed=163)
+    k[:, nk:], v[:, nk:] = 6.0, -4.0
+    for bb in range(b):                                   # a dominant key in the FIRST tile of every (batch, head): the tile the previous entry prefetched
+        k[bb, 3 + bb, bb % h] = q[bb, (17 * bb) % nq, bb % h] * 5
+    k[b - 1, nk - 2, h - 1] = q[b - 1, nq - 1, h - 1] * 5  # and one in the last (partial) tile of the last entry
+    ref = _attn_ref(q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3)[:, :, :nk], v.permute(0, 2, 1, 3)[:, :, :nk], d ** -0.5)
+    got = _attn_d64(q, k, v, nk=nk)
+    assert bool(torch.isfinite(got).all())
+    close(got, ref, 2e-3, 2e-3, f"persistent attention d64 b{b} h{h} nq{nq} nk{nk}")
+
+
 @pytest.mark.parametrize("b,h,nq,nk", [(1, 3, 1024, 1024), (2, 2, 4352, 4352), (1, 2, 300, 1000), (2, 3, 512, 77), (1, 3, 1024, 950), (2, 24, 1408, 1000),
                                        (2, 24, 1500, 1024)])
 def test_attention_d128_64_queries_per_wave(b, h, nq, nk):
