@@ -39,7 +39,6 @@ struct AttnParams {
   float inv_scale;            // 1 / scale: the mask is added to the UNSCALED score
   int nfull, nsplit;          // q64v2: workgroups [0, nfull) own 256 queries x all keys; [nfull, nfull + nsplit) are key-split (see the kernel)
   int bid0;            // first workgroup index of this launch (0 except for a key-split tail launched on its own)
-  int persist;         // q64v2: the launch's workgroups walk the entry list (grid = slots); needs nsplit == 0 and an even number of key tiles
   int sk_tpw, sk_chunks;      // attn_short_kernel: 128-query tiles per persistent workgroup, workgroups per (batch, head)
 };
 
@@ -439,11 +438,16 @@ __global__ __launch_bounds__(256, 2) void attn_q64_kernel(const AttnParams p) {
 //     beyond the last full round of S slots (2 per CU) are fewer than the CUs, the launcher turns them into twice as many workgroups of 128
 //     queries whose wave PAIRS each walk one half of the keys (own LDS stages per pair) and merge (m, l, O) through LDS at the end: half the
 //     duration each, on CUs that would otherwise idle.  Small launches (batch 1) are all key-split.
+//   * (round 4) a PERSISTENT form -- workgroups walking the (batch, head, query tile) list, the last key tile of an entry staging the first K / V^T tile of the
+//     next one, the next Q rows requested ahead of the O stores -- was built and measured (commit "attn_q64v2: persistent walk ...", profiles/
+//     r12a_attention_persistent_walk_negative_result.jsonl): 1024 keys 98.4 -> 99.4 us, 4096 keys 667 -> 723 us.  The walk's loop-carried state took the kernel
+//     from 127 + 32 to 249 registers, i.e. from THREE resident workgroups per CU to two, and a static entry assignment replaces the dispatcher's dynamic one;
+//     what it saves (one K / V^T + Q round trip per entry, ~2 us of 38) is less than what those cost.  Not kept.
 //   * DP = 128 (Flux: 24 heads of 128): the same kernel with 8 k-steps per score chain and four 32-channel output blocks.  64 queries per
 //     wave then need ~350 registers (128 accumulator + 64 Q-fragment + 64 score ...), so it runs ONE wave per SIMD on the unified 512-entry
 //     file (__launch_bounds__(256, 1)): nothing overlaps across waves, but a K / V^T fragment read still feeds two MFMAs, where the
 //     32-query generic kernel it replaces is LDS-read-bound (1 read per MFMA; 531 TFLOP/s in the Flux forward).
-template <int THR, int DP, bool PERSIST = false>
+template <int THR, int DP>
 __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void attn_q64v2_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int DSTEPS = DP / 16, DVT = DP / 32;
@@ -458,39 +462,31 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void attn_q64v2_kernel(const
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, li = lane & 31;
 
-  const int bid_first = blockIdx.x + p.bid0;   // bid0 > 0: only the key-split tail of a launch whose full rounds another kernel ran
-  const bool split = bid_first >= p.nfull;   // workgroup-uniform
-  // PERSISTENT over the launch's (batch, head, 256-query tile) list (round 4, p.persist: launches without key-split workgroups and an even number of key
-  // tiles): workgroup b walks entries b, b + grid, ...; the LAST key tile of an entry stages the FIRST K / V^T tile of the next one into the stage it
-  // would have used for "tile ntiles" (even count: stage 0 again), the next entry's Q rows are requested before this entry's O stores go out (the
-  // memory counter retires in order: behind the stores they would wait a store round trip), so an entry after the first starts its key loop with
-  // no HBM round trip in front of it.  What this removes per entry is the fixed cost DESIGN.md 4.2 puts at ~4 us of a 1024-key entry's 38.
-  const int estride = (PERSIST && !split) ? (int)gridDim.x : 0;   // (a template parameter: the one-entry instantiations keep the register allocation of rounds 2-3)
+  const int bid = blockIdx.x + p.bid0;   // bid0 > 0: only the key-split tail of a launch whose full rounds another kernel ran
+  const bool split = bid >= p.nfull;   // workgroup-uniform
+  int wg, q_in_tile;
+  if (!split) {
+    wg = xcd_remap(bid, p.nfull);
+    q_in_tile = wave * 64;
+  } else {
+    const int sidx = xcd_remap(bid - p.nfull, p.nsplit);
+    wg = p.nfull + (sidx >> 1);
+    q_in_tile = (sidx & 1) * 128 + (wave & 1) * 64;
+  }
   const int pair = split ? (wave >> 1) : 0;        // which half of the keys (key-split workgroups)
   const int swave = split ? (wave & 1) : wave;     // position among the waves that share a K / V^T tile
   const int sways = split ? 2 : 4;                 // how many waves share one
-  struct Entry { int q0, b, h; };
-  auto entry_of = [&](int bid) -> Entry {
-    int wg, q_in_tile;
-    if (!split) {
-      wg = xcd_remap(bid, p.nfull);
-      q_in_tile = wave * 64;
-    } else {
-      const int sidx = xcd_remap(bid - p.nfull, p.nsplit);
-      wg = p.nfull + (sidx >> 1);
-      q_in_tile = (sidx & 1) * 128 + (wave & 1) * 64;
-    }
-    const int qt = wg % p.qtiles;
-    const int bh = wg / p.qtiles;
-    return Entry{qt * 256 + q_in_tile, bh / p.heads, bh % p.heads};
-  };
-  // uniform descriptors per (batch, head); lanes past the extents read zeros (launch_attn_v2 guarantees the spans fit 32 bits)
-  auto k_desc = [&](const Entry& e) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(p.k + (long)e.b * p.k_bs + (long)e.h * DP), 0, p.k_span, 0x00020000);
-  };
-  auto v_desc = [&](const Entry& e) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(p.vt + (long)e.b * p.vt_bs + (long)e.h * p.vt_hs), 0, p.vt_span, 0x00020000);
-  };
+  const int qt = wg % p.qtiles;
+  const int bh = wg / p.qtiles;
+  const int h = bh % p.heads, b = bh / p.heads;
+
+  const f16* kbase = p.k + (long)b * p.k_bs + (long)h * DP;
+  const f16* vbase = p.vt + (long)b * p.vt_bs + (long)h * p.vt_hs;
+  // uniform descriptors; lanes past the extents read zeros (launch_attn_q64 guarantees the spans fit 32 bits)
+  const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(kbase), 0, p.k_span, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(vbase), 0, p.vt_span, 0x00020000);
+
+  const int q0 = qt * 256 + q_in_tile;
   // staging: K tile 64 rows x 8 chunks and V^T tile 64 rows x 8 chunks = 2 x 8 KiB, 2 + 2 DMA instructions per wave and tile (4 + 4 in a
   // key-split workgroup, where two waves share a tile); per-lane byte offsets are tile-invariant, the tile's key offset rides in the
   // scalar offset operand
@@ -510,7 +506,7 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void attn_q64v2_kernel(const
   }
   (void)MAXP;
   const unsigned k_tile = (unsigned)KVB * (unsigned)p.k_rs * 2u;
-  auto stage = [&](auto SI, int kt, const __amdgpu_buffer_rsrc_t& rs_k, const __amdgpu_buffer_rsrc_t& rs_v) {
+  auto stage = [&](auto SI, int kt) {
     constexpr int S = decltype(SI)::value;
 #pragma unroll
     for (int e = 0; e < 2 * NPK; ++e)
@@ -528,42 +524,6 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void attn_q64v2_kernel(const
       }
   };
 
-  f16x8 ones;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) ones[e] = (f16)((hi == 0 && e < 2) ? 1.0f : 0.0f);
-  const int ntiles_all = (p.nk + KVB - 1) / KVB;
-  const int ntiles = split ? ntiles_all >> 1 : ntiles_all;   // the launcher splits only an even number of key tiles
-  const int kt0 = pair * ntiles;
-  const float c2 = p.scale_log2e;
-  const int krow = key_perm(li);
-  // this lane's Q rows of an entry, raw (fp16 as stored); scaled by scale * log2(e) into the MFMA operand form by `scale_q`
-  auto load_q = [&](const Entry& e, f16x8 (&raw)[2][DSTEPS]) {
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const int qrow = min(e.q0 + a * 32 + li, p.nq - 1);
-      const f16* qp = p.q + (long)e.b * p.q_bs + (long)qrow * p.q_rs + (long)e.h * DP + hi * 8;
-#pragma unroll
-      for (int ds = 0; ds < DSTEPS; ++ds) raw[a][ds] = *reinterpret_cast<const f16x8*>(qp + ds * 16);
-    }
-  };
-  f16x8 qf[2][DSTEPS];
-  auto scale_q = [&](const f16x8 (&raw)[2][DSTEPS]) {
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int ds = 0; ds < DSTEPS; ++ds)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) qf[a][ds][e] = (f16)((float)raw[a][ds][e] * c2);
-  };
-  bool pre = false;   // this entry's first K / V^T tile and its Q fragments are already there (persistent walk)
-  for (int bid = bid_first;;) {
-  const Entry ent = entry_of(bid);
-  const int q0 = ent.q0, b = ent.b, h = ent.h;
-  const __amdgpu_buffer_rsrc_t rs_k = k_desc(ent), rs_v = v_desc(ent);
-  const int nbid = bid + estride;
-  const bool has_next = PERSIST && estride > 0 && nbid < p.nfull;   // uniform
-  const Entry nxt = entry_of(has_next ? nbid : bid);
-
   f32x16 oacc[DVT][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -575,24 +535,39 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void attn_q64v2_kernel(const
   // "- m" through the matrix pipe: one extra k-step per score chain whose A operand is 1 in k-slots 0 and 1 (every key row alike) and
   // whose B operand carries -m split into an fp16 high and low part in those two slots (residual 2^-22 |m|; products with 1 are exact,
   // the accumulation is fp32).  12 registers instead of a 32-register accumulator-shaped copy of the maxima.
-  f16x8 mfrag[2];
+  f16x8 ones, mfrag[2];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) mfrag[0][e] = mfrag[1][e] = (f16)0.0f;
-
-  if (!pre) {
-    stage(IC<0>{}, kt0, rs_k, rs_v);   // first: its round trip to HBM overlaps the Q loads below
-    f16x8 raw[2][DSTEPS];
-    load_q(ent, raw);
-    scale_q(raw);
-    wait_vmcnt0();
-    __syncthreads();
+  for (int e = 0; e < 8; ++e) {
+    ones[e] = (f16)((hi == 0 && e < 2) ? 1.0f : 0.0f);
+    mfrag[0][e] = mfrag[1][e] = (f16)0.0f;
   }
 
+  const int ntiles_all = (p.nk + KVB - 1) / KVB;
+  const int ntiles = split ? ntiles_all >> 1 : ntiles_all;   // the launcher splits only an even number of key tiles
+  const int kt0 = pair * ntiles;
+  stage(IC<0>{}, kt0);   // first: its round trip to HBM overlaps the Q loads below
+
+  const float c2 = p.scale_log2e;
+  f16x8 qf[2][DSTEPS];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int qrow = min(q0 + a * 32 + li, p.nq - 1);
+    const f16* qp = p.q + (long)b * p.q_bs + (long)qrow * p.q_rs + (long)h * DP + hi * 8;
+#pragma unroll
+    for (int ds = 0; ds < DSTEPS; ++ds) {
+      const f16x8 raw = *reinterpret_cast<const f16x8*>(qp + ds * 16);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qf[a][ds][e] = (f16)((float)raw[e] * c2);
+    }
+  }
+  wait_vmcnt0();
+  __syncthreads();
+
+  const int krow = key_perm(li);
   auto tile = [&](auto SI, int j) {   // j: position in this wave's key range
     constexpr int S = decltype(SI)::value;
     const int kt = kt0 + j;
-    if (j + 1 < ntiles) stage(IC<S ^ 1>{}, kt + 1, rs_k, rs_v);
-    else if (PERSIST && has_next) stage(IC<S ^ 1>{}, 0, k_desc(nxt), v_desc(nxt));   // (persistent walk, even tile count: S ^ 1 = 0) the next entry's first tile
+    if (j + 1 < ntiles) stage(IC<S ^ 1>{}, kt + 1);
     const char* sk = sbase + S * STAGE;
     const char* sv = sk + KBYTES;
 
@@ -762,11 +737,6 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void attn_q64v2_kernel(const
     }
   }
 
-  // the next entry's Q rows are requested BEFORE this entry's stores (see the head of the kernel)
-  f16x8 qnext[PERSIST ? 2 : 1][PERSIST ? DSTEPS : 1];
-  if constexpr (PERSIST) {
-    if (has_next) load_q(nxt, qnext);
-  }
   // ---- finish: 1/l, O[b][q][h*64 + d]; lane = query.  A lane holds 4-wide runs of d (registers g*4.., d = dt*32 + g*8 + hi*4); one
   //      half-wave swap per register pair turns two 8-byte pieces into one 16-byte store per lane ------------------------------------
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -795,17 +765,7 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void attn_q64v2_kernel(const
         if (qg < p.nq) *reinterpret_cast<u32x4*>(op + dt * 32 + (g + hi) * 8) = v;
       }
   }
-  if constexpr (!PERSIST) {
-    break;
-  } else {
-    if (!has_next) break;
-    scale_q(qnext);
-    pre = true;
-    bid = nbid;
-  }
-  }   // entries
 }
-
 
 // ---- third generation, d_head 64: the vector work of one 32-key sub-tile issued UNDER the MFMAs of the next one, inside each wave --------
 // tools/microbench_pipes.hip (profiles/r07f): one wave issues a 32x32x16 MFMA at most every ~47 cycles (the pipe takes one per 32 when two
@@ -1979,25 +1939,7 @@ int launch_attn_v2(AttnParams p, hipStream_t st) {
     }
     p.nfull = do_split ? grid - rem : grid;
     p.nsplit = do_split ? 2 * rem : 0;
-    // persistent walk (round 4): more entries than workgroup slots, no key-split tail, an even number of key tiles (the next entry's first tile lands in stage 0)
-    static int persist_ok = -1;
-    if (persist_ok < 0) {
-      const char* ep = fmx_knob("FMX_ATTN_PERSIST");   // A/B knob: 0 = one workgroup per entry (rounds 2-3)
-      persist_ok = ep ? atoi(ep) : 1;
-    }
-    p.persist = (persist_ok && DP == 64 && !do_split && grid > slots && (ntiles & 1) == 0) ? 1 : 0;
-    if (p.persist) {
-      if constexpr (DP == 64) {
-        static bool pattr = false;
-        if (!pattr) {
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_q64v2_kernel<6, 64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * smem);
-          pattr = true;
-        }
-        hipLaunchKernelGGL((attn_q64v2_kernel<6, 64, true>), dim3(slots), dim3(256), smem, st, p);
-      }
-    } else {
-      hipLaunchKernelGGL((attn_q64v2_kernel<6, DP>), dim3(p.nfull + p.nsplit), dim3(256), do_split ? 2 * smem : smem, st, p);
-    }
+    hipLaunchKernelGGL((attn_q64v2_kernel<6, DP>), dim3(p.nfull + p.nsplit), dim3(256), do_split ? 2 * smem : smem, st, p);
   } else if (DP == 64) {
     hipLaunchKernelGGL(attn_q64_kernel<0>, dim3(grid), dim3(256), smem, st, p);
   } else {
@@ -2065,7 +2007,7 @@ extern "C" int fmx_attention_f16(const fmx_attn_args* a, void* stream) {
   p.zp = (const f16*)a->zero_page;
   p.causal = a->causal ? 1 : 0;
   p.k_span = p.vt_span = p.q_span = 0;
-  p.nfull = p.nsplit = p.bid0 = p.persist = 0;
+  p.nfull = p.nsplit = p.bid0 = 0;
   p.sk_tpw = p.sk_chunks = 0;
   p.mask = (const f16*)a->mask; p.mask_bs = a->mask_bs; p.mask_hs = a->mask_hs; p.mask_qs = a->mask_qs;
   p.inv_scale = 1.0f / fabsf(a->scale);

@@ -794,12 +794,11 @@ def test_attention_d64_partial_round_key_split(b, h, nq, nk):
 
 
 @pytest.mark.parametrize("b,h,nq,nk", [(16, 20, 1024, 1024), (9, 20, 1000, 896), (9, 20, 1000, 1000), (9, 20, 1000, 960), (3, 10, 4096, 2048)])
-def test_attention_d64_persistent_walk(b, h, nq, nk):
-    """Launches of more 256-query entries than workgroup slots (2 per CU) without a key-split tail and with an even number of key tiles run the PERSISTENT
-    form of attn_q64v2_kernel (round 4): a workgroup walks entries b, b + 512, ..., the last key tile of an entry stages the first K / V^T tile of the next
-    (another batch / head / query tile) and the next Q rows are requested before the O stores.  The bench shape (1280 entries: 3 or 2 per workgroup),
-    ragged query counts, a ragged last key tile, dominant keys at the tile that is prefetched across entries -- and an ODD tile count, which must stay on the
-    one-entry-per-workgroup form.  Against torch fp32, every element."""
+def test_attention_d64_launches_of_many_entries(b, h, nq, nk):
+    """Launches of more 256-query entries than the chip holds at once, without a key-split tail (the bench shapes: 1280 and 2560 entries): several rounds of
+    workgroups, ragged query counts, a ragged last key tile, an odd tile count, dominant keys in the first and the last key tile.  (Written for the persistent
+    form of attn_q64v2_kernel that round 4 measured and did not keep -- profiles/r12a_* -- and kept as coverage of the many-round launches.)  Against torch
+    fp32, every element."""
     d = 64
     nkp = -(-nk // 64) * 64
     q, k, v = rnd(b, nq, h, d, seed=161), torch.zeros(b, nkp, h, d, dtype=torch.float16, device=DEV), torch.zeros(b, nkp, h, d, dtype=torch.float16, device=DEV)
