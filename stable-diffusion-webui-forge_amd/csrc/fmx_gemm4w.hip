@@ -318,7 +318,17 @@ int launch4w(const GemmParams& p, hipStream_t st) {
   q.tiles_m = (p.M + BM - 1) / BM;
   q.tiles_n = (p.nout + BN - 1) / BN;
   const int tiles = q.tiles_m * q.tiles_n;
-  hipLaunchKernelGGL((gemm4w_kernel<LN>), dim3(tiles < slots ? tiles : slots), dim3(256), LDS_BYTES, st, q);
+  // development knob FMX_GEMM_4W_SOLO=1: ask for more LDS than half a CU's, so that ONE workgroup -- one wave per SIMD -- is resident per CU: how busy can a
+  // single 4-wave group keep the matrix pipes (the number any scheme with one MFMA wave per SIMD depends on)
+  static int solo = -1;
+  if (solo < 0) {
+    const char* e = fmx_knob("FMX_GEMM_4W_SOLO");
+    solo = e ? atoi(e) : 0;
+    if (solo) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4w_kernel<LN>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+  }
+  const int lds = solo ? 100 * 1024 : LDS_BYTES;
+  const int cap = solo ? slots / 2 : slots;
+  hipLaunchKernelGGL((gemm4w_kernel<LN>), dim3(tiles < cap ? tiles : cap), dim3(256), lds, st, q);
   FMX_LAUNCH_CHECK("fmx_gemm_conv_f16 (256x160, two workgroups per CU)");
   return FMX_OK;
 }
