@@ -133,9 +133,10 @@ def cpu_baseline(model, cfg, latent, sampler_name=None, cfg_scale=7.0):
     """Oracle timed on host cores (test-infrastructure import allowed for this leg only).  -> (seconds per sample-forward, threads, note)"""
     import torch
     from forge_amd.backend.nn.layout import unet_param_shapes
-    # the port is bandwidth- and synchronisation-bound long before 128 threads: on the GPU box's 128 cores one SDXL forward took 31.5 s with torch's default
-    # (all cores) against 24.8 s per forward of the REAL reference on 8 cores of the authoring container; a quarter of the cores (at most 32) is the sample
-    want = max(1, min(32, (os.cpu_count() or 8) // 4 if (os.cpu_count() or 8) > 32 else (os.cpu_count() or 8)))
+    # the port is synchronisation-bound long before 128 threads: on the GPU box (128 cores) one SDXL forward takes 9.6 s on 16 threads, 11.5 s on 32, 17.4 s
+    # on 64 and 31.3 s on torch's default of all 128 (profiles/r14b_cpu_baseline_thread_count.jsonl; the REAL reference on the authoring container's 8 cores:
+    # 24.8 s per forward) -- the baseline is quoted at the count that is fastest, and `cores` says which
+    want = min(16, os.cpu_count() or 8)
     if os.environ.get("FMX_BENCH_CPU_THREADS"):
         want = int(os.environ["FMX_BENCH_CPU_THREADS"])
     torch.set_num_threads(want)
