@@ -1,6 +1,6 @@
 // 256 x BN-tile (BN = 256 or 320), 320 x 256 and 512 x 128 implicit-GEMM convolution / linear for gfx950, software-pipelined ("gemm256p").
 //
-// The first-generation 8-wave kernel (tools/legacy/fmx_gemm256_pingpong.hip, no longer part of the library) alternated two wave
+// The first-generation 8-wave kernel (in the history up to round 3; no longer part of the library) alternated two wave
 // groups through 8 barrier-separated slots per K-tile (one group loads while the other owns the matrix pipe); its s_memtime
 // stamps (profiles/r02d_*) show every slot costing max(load, 8 MFMA) + barrier skew, 3000+ cycles per K-tile against 2048 cycles
 // of MFMA.  Here every wave runs ONE in-order stream with ONE barrier per K-tile:

@@ -1,5 +1,6 @@
 """Effective shader clock and cycles per K-tile of the pipelined 256x256 GEMM under SUSTAINED load
-(library built with -DFMX_ABLATE: workgroup 8 writes its K-loop s_memtime / s_memrealtime deltas into its output tile)."""
+(stamping build made OUTSIDE csrc/: `python tools/patch_clock_stamps.py clock && tools/build_patched_file.sh clock tools/_build/src/clock_clock/fmx_gemm256p.hip`,
+selected with FMX_ALLOW_KNOBS=1 FMX_LIB=tools/_build/libfmx_clock.so: workgroup 8 writes its K-loop s_memtime / s_memrealtime deltas into its output tile)."""
 import os
 import sys
 

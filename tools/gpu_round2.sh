@@ -37,8 +37,8 @@ for w in "$@"; do
     atests) timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q --tb=short -k "attention" 2>&1 | tail -40 > $O/atests.log; tail -15 $O/atests.log;;
     atests2) FMX_ATTN_SHORT=2 timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q --tb=short -k "attention" 2>&1 | tail -40 > $O/atests2.log; tail -15 $O/atests2.log;;
     ab_persist) for E in "FMX_GEMM_PERSIST=0" "FMX_GEMM_PERSIST=1" "FMX_GEMM_PERSIST=0" "FMX_GEMM_PERSIST=1"; do env $E timeout 600 python bench.py --no-cpu-baseline --no-vae --steps 10 2>> $O/ab.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'env':'$E','ms_per_step':d['ms_per_step'],'gemm_tflops':d['roofline']['achieved'],'gemm_ms':d['roofline']['kernel_time_per_forward_ms'],'attn':d['roofline_attention']['achieved'],'xattn_ms':d['roofline_attention_short_keys']['kernel_time_per_forward_ms'],'clocks':d.get('clocks_during_timed_steps')}))" >> $O/ab.jsonl; done; cat $O/ab.jsonl; tail -3 $O/ab.err;;
-    clock) for R in 0 1; do FMX_LIB=tools/_build/libfmx_ablate.so FMX_TILE=7 FMX_CLOCK_RESIDUAL=$R timeout 300 python tools/clock_gemm.py >> $O/clock.txt 2>> $O/clock.err; done; cat $O/clock.txt; tail -2 $O/clock.err;;
-    clock16) for MFV in 16 32 16 32; do echo "== FMX_GEMM_MFMA=$MFV" >> $O/clock16.txt; FMX_GEMM_MFMA=$MFV FMX_LIB=tools/_build/libfmx_ablate.so FMX_TILE=7 timeout 300 python tools/clock_gemm.py >> $O/clock16.txt 2>> $O/clock16.err; done; cat $O/clock16.txt; tail -2 $O/clock16.err;;
+    clock) for R in 0 1; do FMX_LIB=tools/_build/libfmx_clock.so FMX_TILE=7 FMX_CLOCK_RESIDUAL=$R timeout 300 python tools/clock_gemm.py >> $O/clock.txt 2>> $O/clock.err; done; cat $O/clock.txt; tail -2 $O/clock.err;;
+    clock16) for MFV in 16 32 16 32; do echo "== FMX_GEMM_MFMA=$MFV" >> $O/clock16.txt; FMX_GEMM_MFMA=$MFV FMX_LIB=tools/_build/libfmx_clock.so FMX_TILE=7 timeout 300 python tools/clock_gemm.py >> $O/clock16.txt 2>> $O/clock16.err; done; cat $O/clock16.txt; tail -2 $O/clock16.err;;
     ab_lib) for L in "" $ABLIB "" $ABLIB; do FMX_LIB=$L timeout 600 python bench.py --no-cpu-baseline --no-vae --steps 10 2>> $O/ab.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'lib':'$L','ms_per_step':d['ms_per_step'],'gemm_tflops':d['roofline']['achieved'],'gemm_ms':d['roofline']['kernel_time_per_forward_ms'],'attn':d['roofline_attention']['achieved'],'xattn_ms':d['roofline_attention_short_keys']['kernel_time_per_forward_ms'],'sclk':(d.get('clocks_during_timed_steps') or {}).get('sclk_mhz')}))" >> $O/ab.jsonl; done; cat $O/ab.jsonl; tail -3 $O/ab.err;;
     timeline) for X in 1 0; do FMX_GEMM_XTILE=$X FMX_LIB=tools/_build/libfmx_timeline.so timeout 300 python tools/tile_timeline.py >> $O/timeline.txt 2>> $O/timeline.err; done; cat $O/timeline.txt | cut -c1-250; tail -3 $O/timeline.err;;
     ab_env) for E in $ABENV0 $ABENV1 $ABENV0 $ABENV1; do env ${E//,/ } timeout 600 python bench.py --no-cpu-baseline --no-vae --steps 10 2>> $O/ab.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'env':'$E','ms_per_step':d['ms_per_step'],'gemm_tflops':d['roofline']['achieved'],'gemm_ms':d['roofline']['kernel_time_per_forward_ms'],'attn':d['roofline_attention']['achieved'],'xattn_ms':d['roofline_attention_short_keys']['kernel_time_per_forward_ms'],'sclk':(d.get('clocks_during_timed_steps') or {}).get('sclk_mhz')}))" >> $O/ab.jsonl; done; cat $O/ab.jsonl; tail -3 $O/ab.err;;
