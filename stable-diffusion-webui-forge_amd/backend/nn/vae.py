@@ -394,22 +394,43 @@ class IntegratedAutoencoderKL:
     def process_out(self, latent):
         return (latent / self.scaling_factor) + self.shift_factor  # vae.py:315
 
+    def _image_groups(self, b, hh, ww):
+        """Images are independent: a batch whose decode arena (14 full-resolution fp16 tensors of `final_ch` channels per image) would not fit beside
+        what is already resident is decoded in equal groups of whole images, each through the same arena (round 4: 64 x 1024^2 -- BASELINE config 4's
+        global batch on ONE device -- asked for a 225 GiB arena).  The reference decodes one image at a time (modules/processing.py decode_latent_batch)."""
+        f = self.up_factor
+        per = hh * ww * f * f * self.layout.final_ch * 2 * 14
+        try:
+            free, total = torch.cuda.mem_get_info(self.device)
+            budget = max(1 << 30, min(int(0.45 * total), int(0.8 * (free + (self._arena.capacity if self._arena is not None else 0)))))
+        except Exception:  # noqa: BLE001
+            budget = 64 << 30
+        g = max(1, min(b, budget // max(per, 1)))
+        while b % g:
+            g -= 1
+        return g
+
     def decode(self, z):
         """vae.py:305-311: z [B, lc, h, w] -> [B, 3, 8h, 8w] (same dtype as z)."""
         zf = z.to(device=self.device, dtype=torch.float32).contiguous()
-        y = self._run(zf)
         b, _, hh, ww = z.shape
         oc = self.layout.out_channels
         f = self.up_factor
-        return y.view(b, f * hh, f * ww, 4)[..., :oc].permute(0, 3, 1, 2).to(z.dtype)
+        g = self._image_groups(b, hh, ww)
+        if g == b:
+            y = self._run(zf)
+            return y.view(b, f * hh, f * ww, 4)[..., :oc].permute(0, 3, 1, 2).to(z.dtype)
+        return torch.cat([self._run(zf[i:i + g]).view(g, f * hh, f * ww, 4)[..., :oc].permute(0, 3, 1, 2).to(z.dtype) for i in range(0, b, g)])
 
     def decode_inner(self, samples_in):
         """patcher/vae.py:128-148: -> fp32 [B, 8h, 8w, 3] in [0, 1] (clamp((y+1)/2) fused into the unpack kernel)."""
         zf = samples_in.to(device=self.device, dtype=torch.float32).contiguous()
-        y = self._run(zf)
         b, _, hh, ww = samples_in.shape
         oc = self.layout.out_channels
         f = self.up_factor
         out = torch.empty(b, f * hh, f * ww, oc, dtype=torch.float32, device=self.device)
-        ops.vae_unpack_image(y, 4, b * f * f * hh * ww, oc, out)
+        g = self._image_groups(b, hh, ww)
+        for i in range(0, b, g):          # (one group = the whole batch unless its arena would not fit: see _image_groups)
+            y = self._run(zf[i:i + g])
+            ops.vae_unpack_image(y, 4, g * f * f * hh * ww, oc, out[i:i + g])
         return out

@@ -116,3 +116,22 @@ def test_sdxl_vae_decode_1024_bfloat16_and_uint8_image_parity():
             else:
                 assert diff.mean() < 1.5, "bfloat16 image: mean level error"
             del vae
+
+
+def test_a_batch_too_large_for_one_arena_is_decoded_in_groups_of_whole_images(monkeypatch):
+    """Round 4: 64 x 1024^2 (BASELINE config 4's global batch on one device) asked for a 225 GiB decode arena.  Images are independent, so a batch whose
+    arena would not fit is decoded in equal groups of whole images (the reference decodes image by image, modules/processing.py decode_latent_batch):
+    same bits as the one-arena decode, for `decode` and `decode_inner`."""
+    vae = IntegratedAutoencoderKL(synth.TINY_VAE_CONFIG, synth.synth_vae_decoder_state_dict(synth.TINY_VAE_CONFIG, seed=1), device=DEV)
+    z = (torch.randn(6, 4, 16, 16, generator=torch.Generator().manual_seed(5)) * 0.9).to(DEV)
+    whole, whole_inner = vae.decode(z).clone(), vae.decode_inner(z).clone()
+    assert vae._image_groups(6, 16, 16) == 6
+    per = 16 * 16 * vae.up_factor ** 2 * vae.layout.final_ch * 2 * 14
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (int(2.2 * per / 0.8), 1 << 40))    # room for two images
+    vae._arena = None
+    assert vae._image_groups(6, 16, 16) == 2
+    assert torch.equal(vae.decode(z), whole) and torch.equal(vae.decode_inner(z), whole_inner)
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (int(4.5 * per / 0.8), 1 << 40))    # room for four: 6 is split as 3 + 3
+    vae._arena = None
+    assert vae._image_groups(6, 16, 16) == 3
+    assert torch.equal(vae.decode(z), whole)
