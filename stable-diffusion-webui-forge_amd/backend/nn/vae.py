@@ -402,7 +402,7 @@ class IntegratedAutoencoderKL:
         per = hh * ww * f * f * self.layout.final_ch * 2 * 14
         try:
             free, total = torch.cuda.mem_get_info(self.device)
-            budget = max(1 << 30, min(int(0.45 * total), int(0.8 * (free + (self._arena.capacity if self._arena is not None else 0)))))
+            budget = max(per, min(int(0.45 * total), int(0.8 * (free + (self._arena.capacity if self._arena is not None else 0)))))
         except Exception:  # noqa: BLE001
             budget = 64 << 30
         g = max(1, min(b, budget // max(per, 1)))
