@@ -74,7 +74,10 @@ struct Geo {
 // FA: the per-tap bit-mask form of the implicit-GEMM addresses (FASTADDR below) on tiles other than 512 x 128 -- single-source convolutions without
 //   upsample-on-load (every 3x3 convolution of the UNet except the decoder's upsamplers): the general form's ~15 vector instructions per
 //   activation piece (two sources, nearest-resize, bounds) become 3, in a K loop that otherwise issues ~10 instructions per MFMA (round 3).
-template <bool CONV, int BM, int BN, bool STATS = false, int SCHED = 0, int LN = 0, int MF = 32, bool FA = false>
+//   FA = 2 (round 4): the same for the x2 NEAREST UPSAMPLE ON LOAD of the UNet's / VAE decoder's Upsample convolutions (3x3, stride 1, pad 1 on the
+//   upsampled grid): source row of tap ky is  (iy0 >> 1) + {0, iy0 & 1, 1}[ky]  (iy0 = oy - 1 on the upsampled grid), likewise for columns, so the two
+//   parity bits ride in the mask word (bits 9, 10) and a piece costs 7 vector instructions instead of ~15.
+template <bool CONV, int BM, int BN, bool STATS = false, int SCHED = 0, int LN = 0, int MF = 32, int FA = 0>
 __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   using G = Geo<BM, BN>;
   constexpr int MI = G::MI, NJ = G::NJ, NPA = G::NPA, NPB = G::NPB, NP = G::NP;
@@ -147,7 +150,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   // FASTADDR (the 512-row tile: 8 activation pieces per wave and K-tile): the host sends only single-source convolutions without
   // upsample-on-load here, for which a piece's pixel offset is  base(lane) + (ky * w + kx) * stride  with a UNIFORM second term, and its
   // validity one bit of a per-lane 9-bit mask computed once: 3 VALU instructions per piece instead of ~15.
-  constexpr bool FASTADDR = CONV && (BM == 512 || FA);
+  constexpr bool FASTADDR = CONV && (BM == 512 || FA != 0);
+  constexpr bool UP2 = CONV && FA == 2;
   int a_pix[NPA], a_yx[NPA];
   unsigned b_off[NPB];
 #pragma unroll
@@ -161,15 +165,21 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
       const int oy = rem / p.ow;
       const int ox = rem - oy * p.ow;
       const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+      const int lim_h = UP2 ? p.up_h : p.h, lim_w = UP2 ? p.up_w : p.w;   // (UP2: output pixel and taps live on the upsampled grid)
       unsigned mask = 0;
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-          const bool ok = m < p.M && ky < p.kh && kx < p.kh && iy0 + ky >= 0 && iy0 + ky < p.h && ix0 + kx >= 0 && ix0 + kx < p.w;
+          const bool ok = m < p.M && ky < p.kh && kx < p.kh && iy0 + ky >= 0 && iy0 + ky < lim_h && ix0 + kx >= 0 && ix0 + kx < lim_w;
           mask |= (ok ? 1u : 0u) << (ky * 3 + kx);
         }
-      a_pix[s] = (int)((unsigned)(img * p.h * p.w + iy0 * p.w + ix0) * (unsigned)p.s0 * 2u + kcb);   // modular: exact whenever the tap is valid
+      if (UP2) {
+        mask |= ((unsigned)iy0 & 1u) << 9 | ((unsigned)ix0 & 1u) << 10;   // parities of the first tap's row / column
+        a_pix[s] = (int)((unsigned)(img * p.h * p.w + (iy0 >> 1) * p.w + (ix0 >> 1)) * (unsigned)p.s0 * 2u + kcb);   // (arithmetic shifts: -1 >> 1 = -1)
+      } else {
+        a_pix[s] = (int)((unsigned)(img * p.h * p.w + iy0 * p.w + ix0) * (unsigned)p.s0 * 2u + kcb);   // modular: exact whenever the tap is valid
+      }
       a_yx[s] = (int)mask;
     } else if (CONV) {
       const int per = p.oh * p.ow;
@@ -194,6 +204,15 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   }
 
   auto a_piece = [&](int s, const Cursor& c) -> Piece {
+    if (UP2) {
+      // source row / column of tap k: base + {0, parity, 1}[k]: the uniform part (k == 2) and the per-lane part (k == 1: the parity bit) -- no branch
+      const unsigned ps2 = (unsigned)p.s0 * 2u;
+      const unsigned uni = ((c.ky == 2 ? (unsigned)p.w : 0u) + (c.kx == 2 ? 1u : 0u)) * ps2;          // scalar ALU
+      const unsigned my = c.ky == 1 ? (unsigned)p.w * ps2 : 0u, mx = c.kx == 1 ? ps2 : 0u;            // scalar ALU
+      const unsigned py = ((unsigned)a_yx[s] >> 9) & 1u, px = ((unsigned)a_yx[s] >> 10) & 1u;
+      const bool ok = ((unsigned)a_yx[s] >> (c.ky * 3 + c.kx)) & 1u;
+      return Piece{ok ? (unsigned)a_pix[s] + uni + py * my + px * mx : OOB, (unsigned)c.cc * 2u, false};
+    }
     if (FASTADDR) {
       const unsigned delta = (unsigned)(c.ky * p.w + c.kx) * (unsigned)p.s0 * 2u;   // uniform (scalar ALU)
       const bool ok = ((unsigned)a_yx[s] >> (c.ky * 3 + c.kx)) & 1u;
@@ -755,7 +774,7 @@ int launch_ln_swapped(const GemmParams& p, hipStream_t st) {
   return FMX_OK;
 }
 
-template <int BM, int BN, bool STATS, int SC = 0, int SL = 1, int MF = 32, bool FA = false>
+template <int BM, int BN, bool STATS, int SC = 0, int SL = 1, int MF = 32, int FA = 0>
 int launch_bn(const GemmParams& p, bool conv, hipStream_t st) {
   using G = Geo<BM, BN>;
   static bool attr_set = false;
@@ -795,8 +814,13 @@ int fmx_launch_gemm256p(const GemmParams& p, bool conv, int bm, int bn, hipStrea
       fa = e2 ? atoi(e2) : 1;
     }
     if (fa && conv && p.c1 == 0 && p.up_h == 0 && p.kh <= 3) {   // single source, no resize-on-load: the bit-mask address form
-      if (bm == 256 && bn == 320) return p.stats ? launch_bn<256, 320, true, 0, 1, 16, true>(p, conv, st) : launch_bn<256, 320, false, 0, 1, 16, true>(p, conv, st);
-      if (bm == 256 && bn == 256) return p.stats ? launch_bn<256, 256, true, 0, 1, 16, true>(p, conv, st) : launch_bn<256, 256, false, 0, 1, 16, true>(p, conv, st);
+      if (bm == 256 && bn == 320) return p.stats ? launch_bn<256, 320, true, 0, 1, 16, 1>(p, conv, st) : launch_bn<256, 320, false, 0, 1, 16, 1>(p, conv, st);
+      if (bm == 256 && bn == 256) return p.stats ? launch_bn<256, 256, true, 0, 1, 16, 1>(p, conv, st) : launch_bn<256, 256, false, 0, 1, 16, 1>(p, conv, st);
+    }
+    // single source, x2 nearest upsample on load, 3x3 / stride 1 / pad 1 (the Upsample convolutions of the UNet decoder and the VAE decoder): FA = 2
+    if (fa && conv && p.c1 == 0 && p.up_h == 2 * p.h && p.up_w == 2 * p.w && p.kh == 3 && p.stride == 1 && p.pad == 1 && p.oh == p.up_h && p.ow == p.up_w) {
+      if (bm == 256 && bn == 320) return p.stats ? launch_bn<256, 320, true, 0, 1, 16, 2>(p, conv, st) : launch_bn<256, 320, false, 0, 1, 16, 2>(p, conv, st);
+      if (bm == 256 && bn == 256) return p.stats ? launch_bn<256, 256, true, 0, 1, 16, 2>(p, conv, st) : launch_bn<256, 256, false, 0, 1, 16, 2>(p, conv, st);
     }
     if (bm == 256 && bn == 320) return p.stats ? launch_bn<256, 320, true, 0, 1, 16>(p, conv, st) : launch_bn<256, 320, false, 0, 1, 16>(p, conv, st);
     if (bm == 320 && !p.stats) return launch_bn<320, 256, false, 0, 1, 16>(p, conv, st);

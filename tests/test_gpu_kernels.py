@@ -1064,3 +1064,28 @@ def test_narrow_output_conv3x3_contract():
         ops.conv3x3_narrow(x, rnd(3, 9 * 96, seed=2), None, 3)
     with pytest.raises(Exception, match="1..4 output"):
         ops.conv3x3_narrow(rnd(1, 8, 8, 64, seed=1), rnd(5, 9 * 64, seed=2), None, 5, out=torch.zeros(64, 8, dtype=torch.float16, device=DEV), ld_out=8)
+
+
+@pytest.mark.parametrize("tile", [0, 6, 7])
+@pytest.mark.parametrize("n,hh,ww,c,co,stats", [(2, 16, 16, 128, 320, True), (1, 13, 9, 64, 64, False), (2, 32, 32, 256, 256, True), (1, 7, 40, 128, 640, False)])
+def test_conv_x2_nearest_upsample_on_load_fast_address_form(n, hh, ww, c, co, stats, tile):
+    """The Upsample convolutions (backend/nn/unet.py:340-355 / backend/nn/vae.py:35-57: F.interpolate(scale 2, nearest) then a 3x3 convolution) on the per-tap
+    bit-mask address form (csrc/fmx_gemm256p.hip FA = 2, round 4): source row of tap ky = (iy0 >> 1) + {0, iy0 & 1, 1}[ky].  Odd source sizes, sources narrower
+    than a tile row, borders on all four sides, with and without the GroupNorm statistics of the output; against conv2d of the upsampled input in fp32 and
+    against the small-tile kernel (general address form)."""
+    x = rnd(n, hh, ww, c, seed=310)
+    wt = rnd(co, c, 3, 3, scale=1 / math.sqrt(9 * c), seed=311)
+    b = rnd(co, seed=312)
+    wk = wt.permute(0, 2, 3, 1).reshape(co, -1).contiguous()
+    ref = F.conv2d(F.interpolate(x.permute(0, 3, 1, 2).float(), scale_factor=2.0, mode="nearest"), wt.float(), b.float(), padding=1).permute(0, 2, 3, 1)
+    if stats and (4 * hh * ww) % 256 == 0 and tile in (0, 6, 7):
+        out, st = ops.conv_gemm(x, wk, co, kh=3, pad=1, up=(2 * hh, 2 * ww), bias=b, stats=True, force_tile=tile)
+        o = out.view(n, -1, co).double()
+        got = st.partial.double().sum(1)                       # [n, co, 2]
+        torch.testing.assert_close(got[..., 0], o.sum(1), rtol=1e-4, atol=5e-2)
+        torch.testing.assert_close(got[..., 1], (o * o).sum(1), rtol=1e-4, atol=5e-2)
+    else:
+        out = ops.conv_gemm(x, wk, co, kh=3, pad=1, up=(2 * hh, 2 * ww), bias=b, force_tile=tile)
+    close(out.reshape(ref.shape), ref, 3e-3, 3e-3, f"x2 upsample-on-load conv, tile {tile}")
+    small = ops.conv_gemm(x, wk, co, kh=3, pad=1, up=(2 * hh, 2 * ww), bias=b, force_tile=1)
+    close(out.reshape(ref.shape), small.reshape(ref.shape).float(), 1e-3, 1e-3, "fast address form vs the general one (128x128 tile)")
