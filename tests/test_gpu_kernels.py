@@ -1081,7 +1081,7 @@ def test_conv_x2_nearest_upsample_on_load_fast_address_form(n, hh, ww, c, co, st
     if stats and (4 * hh * ww) % 256 == 0 and tile in (0, 6, 7):
         out, st = ops.conv_gemm(x, wk, co, kh=3, pad=1, up=(2 * hh, 2 * ww), bias=b, stats=True, force_tile=tile)
         o = out.view(n, -1, co).double()
-        got = st.partial[:, :st.nchunks].double().sum(1)        # [n, co, 2]: the chunks the producer filled
+        got = st.partial.reshape(-1)[:n * st.nchunks * co * 2].view(n, st.nchunks, co, 2).double().sum(1)   # dense [n][nchunks][co][2] at the buffer's head
         torch.testing.assert_close(got[..., 0], o.sum(1), rtol=1e-4, atol=5e-2)
         torch.testing.assert_close(got[..., 1], (o * o).sum(1), rtol=1e-4, atol=5e-2)
     else:
