@@ -810,7 +810,7 @@ int fmx_launch_gemm256p(const GemmParams& p, bool conv, int bm, int bn, hipStrea
     if (p.ln_col_ab) return launch_ln_swapped<16>(p, st);
     static int fa = -1;
     if (fa < 0) {
-      const char* e2 = fmx_knob("FMX_CONV_FASTADDR");   // A/B knob: 0 = the general address form for every convolution of the 256-row tiles (round 2)
+      const char* e2 = fmx_knob("FMX_CONV_FASTADDR");   // A/B knob: 0 = the general address form for every convolution of the 256-row tiles (round 2); 3 = not for the x2-upsample convolutions (round 3)
       fa = e2 ? atoi(e2) : 1;
     }
     if (fa && conv && p.c1 == 0 && p.up_h == 0 && p.kh <= 3) {   // single source, no resize-on-load: the bit-mask address form
@@ -818,7 +818,7 @@ int fmx_launch_gemm256p(const GemmParams& p, bool conv, int bm, int bn, hipStrea
       if (bm == 256 && bn == 256) return p.stats ? launch_bn<256, 256, true, 0, 1, 16, 1>(p, conv, st) : launch_bn<256, 256, false, 0, 1, 16, 1>(p, conv, st);
     }
     // single source, x2 nearest upsample on load, 3x3 / stride 1 / pad 1 (the Upsample convolutions of the UNet decoder and the VAE decoder): FA = 2
-    if (fa && conv && p.c1 == 0 && p.up_h == 2 * p.h && p.up_w == 2 * p.w && p.kh == 3 && p.stride == 1 && p.pad == 1 && p.oh == p.up_h && p.ow == p.up_w) {
+    if (fa && fa != 3 && conv && p.c1 == 0 && p.up_h == 2 * p.h && p.up_w == 2 * p.w && p.kh == 3 && p.stride == 1 && p.pad == 1 && p.oh == p.up_h && p.ow == p.up_w) {
       if (bm == 256 && bn == 320) return p.stats ? launch_bn<256, 320, true, 0, 1, 16, 2>(p, conv, st) : launch_bn<256, 320, false, 0, 1, 16, 2>(p, conv, st);
       if (bm == 256 && bn == 256) return p.stats ? launch_bn<256, 256, true, 0, 1, 16, 2>(p, conv, st) : launch_bn<256, 256, false, 0, 1, 16, 2>(p, conv, st);
     }
