@@ -77,9 +77,8 @@ struct Geo {
 //   FA = 2 (round 4): the same for the x2 NEAREST UPSAMPLE ON LOAD of the UNet's / VAE decoder's Upsample convolutions (3x3, stride 1, pad 1 on the
 //   upsampled grid): source row of tap ky is  (iy0 >> 1) + {0, iy0 & 1, 1}[ky]  (iy0 = oy - 1 on the upsampled grid), likewise for columns, so the two
 //   parity bits ride in the mask word (bits 9, 10) and a piece costs 7 vector instructions instead of ~15.
-//   FA = 3 (round 4): TWO-SOURCE convolutions (the decoder ResBlocks' first convolution reads [h | skip] without a torch.cat, backend/nn/unet.py:741): both
-//   sources share the pixel grid, so the lane keeps the PIXEL INDEX (not yet multiplied by a source's pixel stride) and a piece is
-//   (index + uniform tap offset) x uniform stride of the K-tile's source (v_mul_u32_u24: indices and strides are below 2^24, the host checks) -- 5 instead of ~15.
+//   (The same form for the TWO-SOURCE convolutions of the decoder -- pixel index x the K-tile's source stride -- was measured in round 4 and changes nothing:
+//   102.82 vs 102.83 ms per step, every two-source shape within 1 %: those launches have K >= 5760 and hide the address arithmetic.  Not kept.)
 template <bool CONV, int BM, int BN, bool STATS = false, int SCHED = 0, int LN = 0, int MF = 32, int FA = 0>
 __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   using G = Geo<BM, BN>;
@@ -177,9 +176,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
           const bool ok = m < p.M && ky < p.kh && kx < p.kh && iy0 + ky >= 0 && iy0 + ky < lim_h && ix0 + kx >= 0 && ix0 + kx < lim_w;
           mask |= (ok ? 1u : 0u) << (ky * 3 + kx);
         }
-      if (FA == 3) {
-        a_pix[s] = img * p.h * p.w + iy0 * p.w + ix0;   // pixel index of tap (0, 0); may be negative where that tap is invalid
-      } else if (UP2) {
+      if (UP2) {
         mask |= ((unsigned)iy0 & 1u) << 9 | ((unsigned)ix0 & 1u) << 10;   // parities of the first tap's row / column
         a_pix[s] = (int)((unsigned)(img * p.h * p.w + (iy0 >> 1) * p.w + (ix0 >> 1)) * (unsigned)p.s0 * 2u + kcb);   // (arithmetic shifts: -1 >> 1 = -1)
       } else {
@@ -209,14 +206,6 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   }
 
   auto a_piece = [&](int s, const Cursor& c) -> Piece {
-    if (CONV && FA == 3) {
-      const bool second = c.cc >= p.c0;                                                           // uniform
-      const unsigned st2 = (second ? (unsigned)p.s1 : (unsigned)p.s0) * 2u;                        // scalar ALU: byte stride of this K-tile's source
-      const unsigned coff = second ? (unsigned)(c.cc - p.c0) : (unsigned)c.cc;
-      const int dpix = c.ky * p.w + c.kx;                                                         // scalar ALU
-      const bool ok = ((unsigned)a_yx[s] >> (c.ky * 3 + c.kx)) & 1u;
-      return Piece{ok ? __umul24((unsigned)(a_pix[s] + dpix), st2) + kcb : OOB, coff * 2u, second};
-    }
     if (UP2) {
       // source row / column of tap k: base + {0, parity, 1}[k]: the uniform part (k == 2) and the per-lane part (k == 1: the parity bit) -- no branch
       const unsigned ps2 = (unsigned)p.s0 * 2u;
@@ -823,17 +812,12 @@ int fmx_launch_gemm256p(const GemmParams& p, bool conv, int bm, int bn, hipStrea
     if (p.ln_col_ab) return launch_ln_swapped<16>(p, st);
     static int fa = -1;
     if (fa < 0) {
-      const char* e2 = fmx_knob("FMX_CONV_FASTADDR");   // A/B knob: 0 = the general address form for every convolution of the 256-row tiles (round 2); 3 = not for the x2-upsample convolutions, 4 = not for the two-source ones (round 4 A/Bs)
+      const char* e2 = fmx_knob("FMX_CONV_FASTADDR");   // A/B knob: 0 = the general address form for every convolution of the 256-row tiles (round 2); 3 = not for the x2-upsample convolutions (round 4 A/B)
       fa = e2 ? atoi(e2) : 1;
     }
     if (fa && conv && p.c1 == 0 && p.up_h == 0 && p.kh <= 3) {   // single source, no resize-on-load: the bit-mask address form
       if (bm == 256 && bn == 320) return p.stats ? launch_bn<256, 320, true, 0, 1, 16, 1>(p, conv, st) : launch_bn<256, 320, false, 0, 1, 16, 1>(p, conv, st);
       if (bm == 256 && bn == 256) return p.stats ? launch_bn<256, 256, true, 0, 1, 16, 1>(p, conv, st) : launch_bn<256, 256, false, 0, 1, 16, 1>(p, conv, st);
-    }
-    // two sources (the skip concatenation), no resize-on-load: FA = 3 (24-bit pixel indices and byte strides)
-    if (fa && fa != 4 && conv && p.c1 > 0 && p.a1 && p.up_h == 0 && p.kh <= 3 && (long)p.n * p.h * p.w < (1L << 24) && p.s0 * 2 < (1 << 24) && p.s1 * 2 < (1 << 24)) {
-      if (bm == 256 && bn == 320) return p.stats ? launch_bn<256, 320, true, 0, 1, 16, 3>(p, conv, st) : launch_bn<256, 320, false, 0, 1, 16, 3>(p, conv, st);
-      if (bm == 256 && bn == 256) return p.stats ? launch_bn<256, 256, true, 0, 1, 16, 3>(p, conv, st) : launch_bn<256, 256, false, 0, 1, 16, 3>(p, conv, st);
     }
     // single source, x2 nearest upsample on load, 3x3 / stride 1 / pad 1 (the Upsample convolutions of the UNet decoder and the VAE decoder): FA = 2
     if (fa && fa != 3 && conv && p.c1 == 0 && p.up_h == 2 * p.h && p.up_w == 2 * p.w && p.kh == 3 && p.stride == 1 && p.pad == 1 && p.oh == p.up_h && p.ow == p.up_w) {

@@ -31,7 +31,6 @@ for w in "$@"; do
     cputhreads) for T in 16 32 64 128; do FMX_BENCH_CPU_THREADS=$T timeout 600 python bench.py --steps 2 --warmup 1 --no-vae --no-roofline --no-rccl-selfcheck 2>> $O/cputhreads.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'threads': $T, 'cpu_baseline': d['cpu_baseline']}))" >> $O/cputhreads.jsonl; done; cat $O/cputhreads.jsonl;;
     batch64) timeout 900 python bench.py --batch 64 --steps 3 --warmup 1 --no-cpu-baseline --no-rccl-selfcheck > $O/bench_b64.json 2> $O/bench_b64.err; cat $O/bench_b64.json | cut -c1-900; tail -3 $O/bench_b64.err;;
     ab_fa2) for E in FMX_CONV_FASTADDR=3 FMX_CONV_FASTADDR=1 FMX_CONV_FASTADDR=3 FMX_CONV_FASTADDR=1; do env $E timeout 600 python bench.py --no-cpu-baseline --no-rccl-selfcheck --steps 10 --breakdown $O/bd_$E.jsonl --vae-breakdown $O/vbd_$E.jsonl 2>> $O/abfa2.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'env':'$E','ms_per_step':d['ms_per_step'],'vae_ms':d['vae_decode_ms_per_batch'],'gemm_tflops':d['roofline']['achieved'],'sclk':(d.get('clocks_during_timed_steps') or {}).get('sclk_mhz',{}).get('mean')}))" >> $O/abfa2.jsonl; done; cat $O/abfa2.jsonl; tail -2 $O/abfa2.err; grep -h " up" $O/bd_*.jsonl $O/vbd_*.jsonl | cut -c1-200;;
-    ab_fa3) for E in FMX_CONV_FASTADDR=4 FMX_CONV_FASTADDR=1 FMX_CONV_FASTADDR=4 FMX_CONV_FASTADDR=1; do env $E timeout 600 python bench.py --no-cpu-baseline --no-rccl-selfcheck --no-vae --steps 10 --breakdown $O/bd_$E.jsonl 2>> $O/abfa3.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'env':'$E','ms_per_step':d['ms_per_step'],'gemm_tflops':d['roofline']['achieved'],'gemm_ms':d['roofline']['kernel_time_per_forward_ms'],'sclk':(d.get('clocks_during_timed_steps') or {}).get('sclk_mhz',{}).get('mean')}))" >> $O/abfa3.jsonl; done; cat $O/abfa3.jsonl; tail -2 $O/abfa3.err;;
     gemm4w) timeout 900 python tools/bench_kernels.py gemm4w > $O/gemm4w.jsonl 2> $O/gemm4w.err; cat $O/gemm4w.jsonl; tail -3 $O/gemm4w.err;;
     ktests4w) timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_rccl.py tests/test_gpu_vae_bf16.py -m gpu -q --tb=short -k "two_workgroup or linear_plain or gemm256 or knob or rccl or overflow or layernorm_folded" 2>&1 | tail -40 > $O/ktests4w.log; tail -25 $O/ktests4w.log;;
     ab_4w) for E in FMX_GEMM_4W=0 FMX_GEMM_4W=2 FMX_GEMM_4W=0 FMX_GEMM_4W=2; do env $E timeout 600 python bench.py --no-cpu-baseline --no-vae --no-rccl-selfcheck --steps 10 --breakdown $O/breakdown_$E.jsonl 2>> $O/ab4w.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'env':'$E','ms_per_step':d['ms_per_step'],'gemm_tflops':d['roofline']['achieved'],'gemm_ms':d['roofline']['kernel_time_per_forward_ms'],'attn':d['roofline_attention']['achieved'],'sclk':(d.get('clocks_during_timed_steps') or {}).get('sclk_mhz'),'power':(d.get('clocks_during_timed_steps') or {}).get('power_w'),'knobs':d.get('knobs')}))" >> $O/ab4w.jsonl; done; cat $O/ab4w.jsonl; tail -3 $O/ab4w.err;;
