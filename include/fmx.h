@@ -336,7 +336,8 @@ int fmx_vae_pack_latent(const float* z, float scaling_factor, float shift, int32
  * [n*h*w][64] with column (ky*3+kx)*c + ch, c*9 <= 64 */
 int fmx_im2col3x3_smallc(const void* x, int32_t ldx, int32_t n, int32_t c, int32_t h, int32_t w, void* out, void* stream);
 /* 3x3 convolution (stride 1, zero padding 1) with at most 4 output channels: the VAE decoder's conv_out (/root/reference/backend/nn/vae.py:248-271, the
- * last layer: 128 -> 3 channels at the full image size).  x NHWC [n][h][w][c] 16-bit, c = 32 / 64 / 128; wgt [nout][ky][kx][c] (the GEMM entry's
+ * last layer: 128 -> 3 channels at the full image size) and the UNet's `out` convolution (backend/nn/unet.py:760-764: 320 -> 4).  x NHWC [n][h][w][c] 16-bit,
+ * c a multiple of 32 (walked in channel chunks of 128 / 64 / 32); wgt [nout][ky][kx][c] (the GEMM entry's
  * weight layout); bias [nout] or null; out [n*h*w][ld_out], columns >= nout of an ld_out = 4 output are written as zeros.  A direct kernel (the input
  * patch of a 4 x 32 pixel tile staged once in LDS) instead of the implicit GEMM's nine-fold im2col gather; HBM-bound (ABI 8). */
 int fmx_conv3x3_narrow_f16(const void* x, int32_t n, int32_t h, int32_t w, int32_t c, const void* wgt, const void* bias, int32_t nout, void* out,

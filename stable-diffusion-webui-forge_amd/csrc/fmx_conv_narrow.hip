@@ -11,7 +11,8 @@
 //     of a row as the MFMA-B operand of v_mfma_f32_16x16x32; a wave owns one row of 32 pixels = 2 accumulator blocks, 9 taps x C / 32 k-steps;
 //   * 16-byte chunk c of patch pixel q lives at chunk c ^ (q & 15): 16 neighbouring pixels of one fragment read hit 16 different bank groups;
 //   * the accumulator block hands lanes 0-15 the 4 output channels of one pixel each: bias, one 8-byte store per pixel, 128 contiguous bytes per block.
-// Bound: HBM (the input read once, the 1.6x halo from L2).  C must be a multiple of 32 and at most 128 (one pixel <= 256 B of a DMA piece).
+// Bound: HBM (the input read once, the 1.6x halo from L2).  Wider inputs (the UNet's own `out` convolution: 320 -> 4 channels, backend/nn/unet.py:760-764) are
+// walked in channel chunks of C = 128 / 64 / 32 (the widest that divides the channel count): patch and weights of a chunk staged, 9 taps accumulated, next chunk.
 #include "fmx_common.hpp"
 
 namespace {
@@ -21,11 +22,12 @@ constexpr int PH = TH + 2;
 // staged pixels per patch row: TW + 2 halo, rounded up to whole DMA pieces (4 pixels of 128 channels, 8 of 64, 16 of 32)
 constexpr int patch_width(int c) { return (TW + 2 + 1024 / (c * 2) - 1) / (1024 / (c * 2)) * (1024 / (c * 2)); }
 
+// C: channels per chunk (staged at once); ctot: channels of the input (a multiple of C)
 template <int C>
 __global__ __launch_bounds__(256, 3) void conv3x3_narrow_kernel(const f16* __restrict__ x, long x_bytes, const f16* __restrict__ wgt, const f16* __restrict__ bias,
-                                                                f16* __restrict__ out, int n, int h, int w, int nout, int ld_out, int tiles_x, int tiles_y) {
+                                                                f16* __restrict__ out, int n, int h, int w, int ctot, int nout, int ld_out, int tiles_x, int tiles_y) {
   constexpr int PW = patch_width(C);
-  constexpr int PIXB = C * 2;                       // bytes per pixel
+  constexpr int PIXB = C * 2;                       // bytes per pixel OF A CHUNK (LDS); a pixel of the input is ctot * 2 bytes
   constexpr int PPP = 1024 / PIXB;                  // pixels per 1-KiB DMA piece: 4 (C = 128), 8 (64), 16 (32)
   constexpr int CHUNKS = PIXB / 16;                 // 16-byte chunks per pixel
   constexpr int PIECES_ROW = PW / PPP;              // pieces per patch row
@@ -45,54 +47,58 @@ __global__ __launch_bounds__(256, 3) void conv3x3_narrow_kernel(const f16* __res
   const int img = t / tiles_y;
   const int x0 = tx * TW, y0 = ty * TH;
 
-  // ---- weights -> LDS (4 rows of 9 C halfs; rows >= nout zero) -------------------------------------------------------------------------------
-  for (int i = tid; i < 4 * 9 * C / 8; i += 256) {
-    const int row = i / (9 * C / 8), c8 = i - row * (9 * C / 8);
-    f16x8 v;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (f16)0.0f;
-    if (row < nout) v = *reinterpret_cast<const f16x8*>(wgt + (long)row * 9 * C + c8 * 8);
-    *reinterpret_cast<f16x8*>(wl + (long)row * 9 * C + c8 * 8) = v;
-  }
-  // ---- input patch -> LDS: piece p = (patch row pr, pixels pc * PPP .. + PPP); lane -> pixel lane / CHUNKS, physical chunk lane % CHUNKS ---------
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(x), 0, (unsigned)x_bytes, 0x00020000);
   constexpr unsigned OOB = 0xC0000000u;
   const long img_base = (long)img * h * w;
-  for (int p = wave; p < PH * PIECES_ROW; p += 4) {       // uniform trip count per wave
-    const int pr = p / PIECES_ROW, pc = p - pr * PIECES_ROW;
-    const int q = pc * PPP + lane / CHUNKS;               // patch-local pixel index in its row
-    const int gy = y0 - 1 + pr, gx = x0 - 1 + q;
-    const int chunk = (lane % CHUNKS) ^ (q & (CHUNKS - 1));   // logical chunk this lane fetches (source side of the swizzle)
-    const bool ok = gy >= 0 && gy < h && gx >= 0 && gx < w;
-    const unsigned off = ok ? (unsigned)((img_base + (long)gy * w + gx) * PIXB + chunk * 16) : OOB;
-    auto* dst = (__attribute__((address_space(3))) void*)(patch + (pr * PW + pc * PPP) * PIXB);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, off, 0, 0, 0);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  // ---- wave `wave` = output row y0 + wave, two blocks of 16 pixels ---------------------------------------------------------------------------------
   f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-  const f16* wrow = wl + (long)(l16 < 4 ? l16 : 3) * 9 * C;   // output rows >= 4 of the 16-row operand: masked below
+  for (int c0 = 0; c0 < ctot; c0 += C) {
+    if (c0) __syncthreads();   // every wave is done with the previous chunk's patch and weights
+    // ---- weights of this chunk -> LDS (4 rows of 9 x C halfs; rows >= nout zero) ---------------------------------------------------------------------
+    for (int i = tid; i < 4 * 9 * C / 8; i += 256) {
+      const int row = i / (9 * C / 8), r8 = i - row * (9 * C / 8);
+      const int tap = r8 / (C / 8), c8 = r8 - tap * (C / 8);
+      f16x8 v;
 #pragma unroll
-  for (int ky = 0; ky < 3; ++ky)
+      for (int e = 0; e < 8; ++e) v[e] = (f16)0.0f;
+      if (row < nout) v = *reinterpret_cast<const f16x8*>(wgt + ((long)row * 9 + tap) * ctot + c0 + c8 * 8);
+      *reinterpret_cast<f16x8*>(wl + ((long)row * 9 + tap) * C + c8 * 8) = v;
+    }
+    // ---- input patch -> LDS: piece p = (patch row pr, pixels pc * PPP .. + PPP); lane -> pixel lane / CHUNKS, physical chunk lane % CHUNKS ---------
+    for (int p = wave; p < PH * PIECES_ROW; p += 4) {       // uniform trip count per wave
+      const int pr = p / PIECES_ROW, pc = p - pr * PIECES_ROW;
+      const int q = pc * PPP + lane / CHUNKS;               // patch-local pixel index in its row
+      const int gy = y0 - 1 + pr, gx = x0 - 1 + q;
+      const int chunk = (lane % CHUNKS) ^ (q & (CHUNKS - 1));   // logical chunk this lane fetches (source side of the swizzle)
+      const bool ok = gy >= 0 && gy < h && gx >= 0 && gx < w;
+      const unsigned off = ok ? (unsigned)((img_base + (long)gy * w + gx) * ((long)ctot * 2) + c0 * 2 + chunk * 16) : OOB;
+      auto* dst = (__attribute__((address_space(3))) void*)(patch + (pr * PW + pc * PPP) * PIXB);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, off, 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- wave `wave` = output row y0 + wave, two blocks of 16 pixels -------------------------------------------------------------------------------
+    const f16* wrow = wl + (long)(l16 < 4 ? l16 : 3) * 9 * C;   // output rows >= 4 of the 16-row operand: masked below
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx)
+    for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks) {
-        f16x8 wf = *reinterpret_cast<const f16x8*>(wrow + (ky * 3 + kx) * C + ks * 32 + kg * 8);
-        if (l16 >= 4) {
+      for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) wf[e] = (f16)0.0f;
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+          f16x8 wf = *reinterpret_cast<const f16x8*>(wrow + (ky * 3 + kx) * C + ks * 32 + kg * 8);
+          if (l16 >= 4) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) wf[e] = (f16)0.0f;
+          }
+#pragma unroll
+          for (int bl = 0; bl < 2; ++bl) {
+            const int q = bl * 16 + l16 + kx;                  // patch pixel of this lane's output pixel under tap kx
+            const int chunk = (ks * 4 + kg) ^ (q & (CHUNKS - 1));
+            const f16x8 af = *reinterpret_cast<const f16x8*>(patch + ((wave + ky) * PW + q) * PIXB + chunk * 16);
+            acc[bl] = FMX_MFMA_16x16x32(wf, af, acc[bl]);
+          }
         }
-#pragma unroll
-        for (int bl = 0; bl < 2; ++bl) {
-          const int q = bl * 16 + l16 + kx;                  // patch pixel of this lane's output pixel under tap kx (patch x = output x + 1 - 1 + kx)
-          const int chunk = (ks * 4 + kg) ^ (q & (CHUNKS - 1));
-          const f16x8 af = *reinterpret_cast<const f16x8*>(patch + ((wave + ky) * PW + q) * PIXB + chunk * 16);
-          acc[bl] = FMX_MFMA_16x16x32(wf, af, acc[bl]);
-        }
-      }
+  }
   // ---- lanes 0-15 (kg = 0) hold output channels 0-3 of pixel l16 of each block ----------------------------------------------------------------------
   const int oy = y0 + wave;
   if (kg == 0 && oy < h) {
@@ -120,7 +126,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_narrow_kernel(const f16* __res
 }
 
 template <int C>
-int launch_narrow(const void* x, long x_bytes, const void* wgt, const void* bias, void* out, int n, int h, int w, int nout, int ld_out, hipStream_t st) {
+int launch_narrow(const void* x, long x_bytes, const void* wgt, const void* bias, void* out, int n, int h, int w, int ctot, int nout, int ld_out, hipStream_t st) {
   constexpr int SMEM = PH * patch_width(C) * C * 2 + 4 * 9 * C * 2;
   static bool attr = false;
   if (!attr) {
@@ -129,7 +135,7 @@ int launch_narrow(const void* x, long x_bytes, const void* wgt, const void* bias
   }
   const int tiles_x = (w + TW - 1) / TW, tiles_y = (h + TH - 1) / TH;
   hipLaunchKernelGGL(conv3x3_narrow_kernel<C>, dim3((unsigned)(n * tiles_x * tiles_y)), dim3(256), SMEM, st, (const f16*)x, x_bytes, (const f16*)wgt, (const f16*)bias,
-                     (f16*)out, n, h, w, nout, ld_out, tiles_x, tiles_y);
+                     (f16*)out, n, h, w, ctot, nout, ld_out, tiles_x, tiles_y);
   FMX_LAUNCH_CHECK("fmx_conv3x3_narrow_f16");
   return FMX_OK;
 }
@@ -140,12 +146,12 @@ extern "C" int fmx_conv3x3_narrow_f16(const void* x, int32_t n, int32_t h, int32
                                       int32_t ld_out, void* stream) {
   FMX_REQUIRE(x && wgt && out && n > 0 && h > 0 && w > 0, "conv3x3_narrow: bad arguments");
   FMX_REQUIRE(nout >= 1 && nout <= 4 && ld_out >= nout, "conv3x3_narrow: 1..4 output channels, ld_out >= nout (got %d, %d)", nout, ld_out);
-  FMX_REQUIRE(c == 32 || c == 64 || c == 128, "conv3x3_narrow: 32, 64 or 128 input channels (got %d)", c);
+  FMX_REQUIRE(c >= 32 && (c % 32) == 0 && c <= 2048, "conv3x3_narrow: input channels must be a multiple of 32, 32..2048 (got %d)", c);
   FMX_REQUIRE(fmx_aligned16(x) && fmx_aligned16(wgt) && (ld_out != 4 || (reinterpret_cast<uintptr_t>(out) & 7u) == 0), "conv3x3_narrow: operands must be 16-byte aligned");
   const double bytes = (double)n * h * w * c * 2.0;
   FMX_REQUIRE(bytes < 3.0e9 && (long)n * ((w + TW - 1) / TW) * ((h + TH - 1) / TH) < (1L << 31), "conv3x3_narrow: input beyond the 32-bit offset range of one launch (split the batch)");
   hipStream_t st = (hipStream_t)stream;
-  if (c == 128) return launch_narrow<128>(x, (long)bytes, wgt, bias, out, n, h, w, nout, ld_out, st);
-  if (c == 64) return launch_narrow<64>(x, (long)bytes, wgt, bias, out, n, h, w, nout, ld_out, st);
-  return launch_narrow<32>(x, (long)bytes, wgt, bias, out, n, h, w, nout, ld_out, st);
+  if ((c % 128) == 0) return launch_narrow<128>(x, (long)bytes, wgt, bias, out, n, h, w, c, nout, ld_out, st);
+  if ((c % 64) == 0) return launch_narrow<64>(x, (long)bytes, wgt, bias, out, n, h, w, c, nout, ld_out, st);
+  return launch_narrow<32>(x, (long)bytes, wgt, bias, out, n, h, w, c, nout, ld_out, st);
 }

@@ -749,8 +749,8 @@ def count_nonfinite(x):
 
 
 def conv3x3_narrow(x, wgt, bias, nout, out=None, ld_out=4):
-    """3x3 convolution (stride 1, padding 1) with at most 4 output channels, direct kernel (fmx_conv3x3_narrow): x NHWC [n, h, w, c] with c in
-    (32, 64, 128), wgt [nout, 9 * c] in the GEMM's tap-major layout -> [n * h * w, ld_out] (columns >= nout zero when ld_out == 4)."""
+    """3x3 convolution (stride 1, padding 1) with at most 4 output channels, direct kernel (fmx_conv3x3_narrow): x NHWC [n, h, w, c] with c a
+    multiple of 32, wgt [nout, 9 * c] in the GEMM's tap-major layout -> [n * h * w, ld_out] (columns >= nout zero when ld_out == 4)."""
     sfx, elem = _elem(x, wgt, bias)
     n, h, w, c = x.shape
     if out is None:

@@ -86,7 +86,7 @@ def test_other_contract_violations(lib):
     assert lib.fmx_act_f16(p, p, 16, 7, None) == BADARG                                          # unknown activation kind
     # the direct narrow-output 3x3 convolution (ABI 8): 1..4 output channels, 32 / 64 / 128 input channels, one launch's 32-bit offset range
     assert lib.fmx_conv3x3_narrow_f16(p, 1, 8, 8, 128, p, None, 5, p, 8, None) == BADARG and "1..4 output" in err()
-    assert lib.fmx_conv3x3_narrow_f16(p, 1, 8, 8, 96, p, None, 3, p, 4, None) == BADARG and "32, 64 or 128" in err()
+    assert lib.fmx_conv3x3_narrow_f16(p, 1, 8, 8, 80, p, None, 3, p, 4, None) == BADARG and "multiple of 32" in err()
     assert lib.fmx_conv3x3_narrow_bf16(p, 1, 8, 8, 128, p, None, 3, p, 2, None) == BADARG                              # ld_out < nout
     assert lib.fmx_conv3x3_narrow_f16(p, 16, 1024, 1024, 128, p, None, 3, p, 4, None) == BADARG and "split the batch" in err()
     assert lib.fmx_conv3x3_narrow_f16(None, 1, 8, 8, 128, p, None, 3, p, 4, None) == BADARG

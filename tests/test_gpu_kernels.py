@@ -1036,7 +1036,8 @@ def test_philox_bit_exact():
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("n,hh,ww,c,co", [(2, 64, 64, 128, 3), (1, 37, 50, 128, 3), (3, 5, 7, 64, 4), (1, 130, 33, 32, 1), (1, 256, 256, 128, 3)])
+@pytest.mark.parametrize("n,hh,ww,c,co", [(2, 64, 64, 128, 3), (1, 37, 50, 128, 3), (3, 5, 7, 64, 4), (1, 130, 33, 32, 1), (1, 256, 256, 128, 3),
+                                          (2, 64, 64, 320, 4), (1, 19, 45, 96, 4), (1, 32, 32, 640, 2)])
 def test_narrow_output_conv3x3_direct_kernel(n, hh, ww, c, co, dtype):
     """fmx_conv3x3_narrow (csrc/fmx_conv_narrow.hip, round 4): the VAE decoder's conv_out (128 -> 3 channels, /root/reference/backend/nn/vae.py:248-271) as a
     direct kernel -- the input patch of a 4 x 32 pixel tile staged once, zero padding through the descriptor's bounds check, the pad column of the
@@ -1059,9 +1060,9 @@ def test_narrow_output_conv3x3_direct_kernel(n, hh, ww, c, co, dtype):
 
 
 def test_narrow_output_conv3x3_contract():
-    x = rnd(1, 8, 8, 96, seed=1)
-    with pytest.raises(Exception, match="32, 64 or 128"):
-        ops.conv3x3_narrow(x, rnd(3, 9 * 96, seed=2), None, 3)
+    x = rnd(1, 8, 8, 80, seed=1)
+    with pytest.raises(Exception, match="multiple of 32"):
+        ops.conv3x3_narrow(x, rnd(3, 9 * 80, seed=2), None, 3)
     with pytest.raises(Exception, match="1..4 output"):
         ops.conv3x3_narrow(rnd(1, 8, 8, 64, seed=1), rnd(5, 9 * 64, seed=2), None, 5, out=torch.zeros(64, 8, dtype=torch.float16, device=DEV), ld_out=8)
 
