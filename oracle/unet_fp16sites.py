@@ -1,0 +1,333 @@
+"""TEST INFRASTRUCTURE ONLY (CPU oracle) -- never imported by the product package.
+
+The pinned fp32 restatement of the reference's UNet forward (oracle/unet.py, backend/nn/unet.py:696-763) with fp16 ROUNDING inserted at
+exactly the places where the native executor STORES fp16 (stable-diffusion-webui-forge_amd/backend/nn/unet.py), and nothing else changed:
+every sum is still an fp32 (statistics: fp64) sum on the CPU.  It answers the question the fp16-floor gate (tests/parity.py) cannot: "is the
+native output the reference's ARITHMETIC evaluated at the executor's storage precision?"  Two runs that round at the same sites differ only
+by fp32 summation order (and the rare fp16 rounding flip that order causes), so a wrong constant or a wrong wire anywhere in the executor
+shows up far below the floor (VERDICT r4 "Next round" item 2; the planted-bug tests in tests/test_oracle_fp16sites.py / test_gpu_sharp_parity.py).
+
+Rounding sites (R = x.half().float(); each cites the executor line that stores fp16 and the reference line whose arithmetic it is):
+
+  parameters        every weight, bias, gamma, beta resident in fp16                     unet.py(native):184-277   -- reference: fp16 storage_dtype
+  input             x -> fp16 im2col rows (`fmx_unet_pack_input`)                        native:808                 unet.py:696
+  time / label MLP  fp16 after the sinusoid, after each Linear, after each SiLU          native:672-677, 319-322    unet.py:55-67, 703-707
+  ResBlock          fp16( SiLU(GN(x)) ), fp16( conv1 + b + emb ), fp16( SiLU(GN(h)) ),   native:342-352             unet.py:433-478
+                    fp16( skip 1x1 + b ), fp16( conv2 + b + skip )
+  SpatialTransf.    fp16( GN(x, 1e-6) ), fp16( proj_in ), fp16( proj_out + b + x_in )    native:537-550             unet.py:308-327
+  attention         fp16 q | k | v;  q' = fp16(q * scale * log2e);  P = fp16(exp2(s-m))  native:374-417,            attention.py:324-339
+                    with the row sum taken over the UNROUNDED P;  fp16( O )              csrc/fmx_attention.hip:550-561
+  transformer blk   fp16( to_out + b + x ) twice, fp16( a * gelu(gate) ) from fp32 a and native:405-428             unet.py:183-279, :104-111
+                    gate, fp16( ff.net.2 + b + x )
+  LayerNorm         NOT folded: fp16( LN(x) ) feeds the projection (`ln_kernel`).        native:380, 412, 425
+                    FOLDED (per block and norm, as the executor decided -- `fold`):      native:88-96, 254-267
+                    no rounding of LN(x); instead W' = fp16(W16 * gamma16), bias' =      csrc/fmx_gemm256p.hip:513-524,
+                    fp16(W16 beta16 + b16) (q|k, to_q, ff.net.0) resp. fp32 W16 beta16   csrc/fmx_gemm_epi.hpp:33-37
+                    (V^T), result = rstd (x W'^T - mean colsum(W')) + bias'
+  Down / Up / conv_in / out   fp16( conv + b );  out.2 reads fp16( SiLU(GN(h)) )         native:592-598, 698, 743-750
+
+`rounding=False` switches every R off and must then reproduce oracle/unet.py BIT FOR BIT (tests/test_oracle_fp16sites.py) -- that is the pin:
+the walk below IS the pinned restatement's (oracle.unet.unet_forward / _run_block run unchanged; only the leaf functions are swapped for the
+duration of the call).
+
+`plant` deliberately breaks ONE constant so that the sharp test can be shown to fail on it:
+    {"gn_eps": (resblock_key, "in_layers.0" | "out_layers.0", eps)}     e.g. 1e-6 where the reference has 1e-5 (unet.py:395 vs :292)
+    {"gelu_tanh": transformer_block_key}                                 tanh-approximated GELU in one GEGLU (unet.py:111 is exact erf)
+"""
+import contextlib
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import unet as ou
+
+LOG2E = 1.44269504088896340736
+
+
+def _r16(x):
+    return x.half().float()
+
+
+def _ident(x):
+    return x
+
+
+class _State:
+    def __init__(self, rounding, fold, plant, teacher=None, layer_out=None, acc64=False):
+        self.acc64 = acc64
+        self.R = _r16 if rounding else _ident
+        self.rounding = rounding
+        self.fold = fold or {}
+        self.plant = plant or {}
+        self.used_folds = 0
+        self.teacher = teacher
+        self.native_view = {}
+        self.layer_out = layer_out if layer_out is not None else {}
+
+
+_ST = None
+
+
+def _c2d(x, w, b=None, stride=1, padding=0):
+    if _ST.acc64:
+        return F.conv2d(x.double(), w.double(), None if b is None else b.double(), stride=stride, padding=padding).float()
+    return F.conv2d(x, w, b, stride=stride, padding=padding)
+
+
+def _lnr(x, w, b=None):
+    if _ST.acc64:
+        return F.linear(x.double(), w.double(), None if b is None else b.double()).float()
+    return F.linear(x, w, b)
+
+
+def _teach(key, computed, heads=None):
+    """Teacher forcing (layer-wise parity): `computed` is this oracle's output of layer `key` evaluated on the NATIVE executor's stored inputs; it
+    is recorded for the comparison and the native tensor (`teacher[key]`: channels-last fp16 as the executor holds it) is handed on instead, so
+    that the next layer is again evaluated on exactly what the executor's next layer read.  Without a teacher: identity."""
+    st = _ST
+    st.layer_out[key] = computed
+    if st.teacher is None:
+        return computed
+    t = st.teacher[key].float()
+    if computed.dim() == 4:
+        t = t.permute(0, 3, 1, 2)
+    if heads is not None and t.shape[-1] != computed.shape[-1]:
+        # attention outputs: the executor keeps heads zero-padded to the width of its attention kernel (SD1.5: 40 -> 64)
+        d, dp = computed.shape[-1] // heads, t.shape[-1] // heads
+        t = t.reshape(*t.shape[:-1], heads, dp)[..., :d].reshape(*t.shape[:-1], heads * d)
+    assert t.shape == computed.shape, (key, tuple(t.shape), tuple(computed.shape))
+    t = t.contiguous()
+    st.native_view[key] = t
+    return t
+
+
+def _stats64(x, dims):
+    """mean / biased variance over `dims` in fp64 (the kernels take fp32 sums of the stored fp16 values; fp64 here is the exact value of those sums)"""
+    xd = x.double()
+    mean = xd.mean(dim=dims, keepdim=True)
+    var = (xd * xd).mean(dim=dims, keepdim=True) - mean * mean
+    return mean, var.clamp_min(0.0)
+
+
+def _gn(sd, key, x, eps):
+    st = _ST
+    if not st.rounding:
+        return ou_gn(sd, key, x, eps)
+    pl = st.plant.get("gn_eps")
+    if pl is not None and key == f"{pl[0]}.{pl[1]}":
+        eps = pl[2]
+    b, c, h, w = x.shape
+    xg = x.reshape(b, 32, c // 32, h, w)
+    mean, var = _stats64(xg, (2, 3, 4))
+    rstd = 1.0 / torch.sqrt(var + eps)
+    y = ((xg.double() - mean) * rstd).reshape(b, c, h, w)
+    return (y * sd[key + ".weight"].double()[None, :, None, None] + sd[key + ".bias"].double()[None, :, None, None]).float()
+
+
+def _ln_stats(x, eps=1e-5):
+    mean, var = _stats64(x, (-1,))
+    return mean, 1.0 / torch.sqrt(var + eps)
+
+
+def _ln(sd, key, x):
+    st = _ST
+    if not st.rounding:
+        return ou_ln(sd, key, x)
+    mean, rstd = _ln_stats(x)
+    return st.R((((x.double() - mean) * rstd) * sd[key + ".weight"].double() + sd[key + ".bias"].double()).float())
+
+
+def _conv(sd, key, x, stride=1, padding=1):
+    # conv_in, Down, Up, out.2: one rounding of (accumulator + bias); out.2 reads the stored fp16( SiLU(GN(h)) ) (the walk hands it over unrounded)
+    if key == "out.2":
+        x = _ST.R(x)
+    out = _ST.R(_c2d(x, sd[key + ".weight"], sd[key + ".bias"], stride=stride, padding=padding))
+    for suffix in (".op", ".conv"):            # the executor names a Down / Up layer by its block key
+        if key.endswith(suffix):
+            key = key[:-len(suffix)]
+    return _teach(key, out)
+
+
+def _lin_raw(sd, key, x):
+    return _lnr(x, sd[key + ".weight"], sd.get(key + ".bias"))
+
+
+def _lin(sd, key, x):
+    # time_embed.{0,2}, label_emb.0.{0,2}: fp16 after each Linear; the SiLU between them is its own kernel writing fp16
+    st = _ST
+    if st.rounding and (key.startswith("time_embed.") or key.startswith("label_emb.")):
+        out = _lin_raw(sd, key, st.R(x))            # st.R(x): the SiLU output (or y, or the sinusoid) as stored
+        # time_embed.2 is stored as fp16( accumulator + bias + label_emb(y) ) -- ONE rounding of the sum (native unet.py:675): its own output
+        # stays unrounded here, the walk adds the (rounded) label term, and resblock() rounds the sum where it reads it
+        return out if key == "time_embed.2" else st.R(out)
+    return _lin_raw(sd, key, x)
+
+
+def _folded_linear(sd, wkey, bkey, nkey, x, bias_fp16=True):
+    """LN(x) W^T + b through the executor's fold: rstd (x W'^T - mean colsum(W')) + bias'  (native unet.py:88-96, fmx_gemm_epi.hpp:33-37)"""
+    st = _ST
+    w, gamma, beta = sd[wkey], sd[nkey + ".weight"], sd[nkey + ".bias"]
+    wf = st.R(w * gamma[None, :])
+    colsum = wf.double().sum(1)
+    b2 = w.double() @ beta.double()
+    if bkey is not None and bkey in sd:
+        b2 = b2 + sd[bkey].double()
+    b2 = st.R(b2.float()).double() if bias_fp16 else b2.float().double()
+    mean, rstd = _ln_stats(x)
+    acc = _lnr(x, wf).double()
+    st.used_folds += 1
+    return ((acc - mean * colsum) * rstd + b2).float()
+
+
+def _attention(q, k, v, heads):
+    """backend/attention.py:324-339 at the kernel's precision: q, k, v arrive fp16-valued; q' = fp16(q scale log2e); scores and the running
+    sums in fp32; P rounded to fp16 for the P.V product, the denominator summed over the unrounded P (csrc/fmx_attention.hip)."""
+    st = _ST
+    b, nq, c = q.shape
+    d = c // heads
+    q = q.reshape(b, nq, heads, d).permute(0, 2, 1, 3)
+    k = k.reshape(b, -1, heads, d).permute(0, 2, 1, 3)
+    v = v.reshape(b, -1, heads, d).permute(0, 2, 1, 3)
+    if not st.rounding:
+        sim = torch.matmul(q, k.transpose(-1, -2)) * (d ** -0.5)
+        return torch.matmul(sim.softmax(dim=-1), v).permute(0, 2, 1, 3).reshape(b, nq, c)
+    c2 = torch.tensor(d ** -0.5, dtype=torch.float32) * torch.tensor(LOG2E, dtype=torch.float32)
+    qs = st.R(q * c2)
+    out = torch.empty_like(q)
+    step = max(1, (1 << 26) // max(1, k.shape[2] * heads))     # query rows per chunk: bounds the score matrix at ~256 MB
+    for i in range(0, nq, step):
+        s = torch.matmul(qs[:, :, i:i + step], k.transpose(-1, -2))
+        p = torch.exp2(s - s.amax(dim=-1, keepdim=True))
+        l = p.sum(dim=-1, keepdim=True)
+        out[:, :, i:i + step] = torch.matmul(st.R(p), v) / l
+    return out.permute(0, 2, 1, 3).reshape(b, nq, c)
+
+
+def resblock(sd, key, x, emb):
+    st, R = _ST, _ST.R
+    emb = R(emb)
+    st.layer_out.setdefault("time_embed", emb)
+    if st.teacher is not None and "time_embed" in st.teacher:
+        emb = st.teacher["time_embed"].float()
+    g1 = R(F.silu(_gn(sd, key + ".in_layers.0", x, 1e-5)))
+    e = R(_lin_raw(sd, key + ".emb_layers.1", R(F.silu(emb))))
+    h = _teach(key + ".h", R(_c2d(g1, sd[key + ".in_layers.2.weight"], sd[key + ".in_layers.2.bias"], padding=1) + e[:, :, None, None]))
+    g2 = R(F.silu(_gn(sd, key + ".out_layers.0", h, 1e-5)))
+    h = _c2d(g2, sd[key + ".out_layers.3.weight"], sd[key + ".out_layers.3.bias"], padding=1)
+    if key + ".skip_connection.weight" in sd:
+        x = R(_c2d(x, sd[key + ".skip_connection.weight"], sd[key + ".skip_connection.bias"]))
+    return _teach(key, R(x + h))
+
+
+def _gelu(gate, tanh):
+    return F.gelu(gate, approximate="tanh") if tanh else F.gelu(gate)
+
+
+def transformer_block(sd, key, x, context, heads, to=None):
+    st, R = _ST, _ST.R
+    f1, f2, f3 = st.fold.get(key, (False, False, False)) if st.rounding else (False, False, False)
+    # attn1 (self): q | k | v of LN1(x)
+    a = key + ".attn1"
+    if f1:
+        q = R(_folded_linear(sd, a + ".to_q.weight", None, key + ".norm1", x))
+        k = R(_folded_linear(sd, a + ".to_k.weight", None, key + ".norm1", x))
+        v = R(_folded_linear(sd, a + ".to_v.weight", None, key + ".norm1", x, bias_fp16=False))
+    else:
+        n1 = _ln(sd, key + ".norm1", x)
+        q, k, v = R(_lin_raw(sd, a + ".to_q", n1)), R(_lin_raw(sd, a + ".to_k", n1)), R(_lin_raw(sd, a + ".to_v", n1))
+    x = _teach(a, R(x + _lin_raw(sd, a + ".to_out.0", _teach(a + ".o", R(_attention(q, k, v, heads)), heads))))
+    # attn2 (cross): q of LN2(x), k | v of the fp16 text context
+    a = key + ".attn2"
+    if f2:
+        q = R(_folded_linear(sd, a + ".to_q.weight", None, key + ".norm2", x))
+    else:
+        q = R(_lin_raw(sd, a + ".to_q", _ln(sd, key + ".norm2", x)))
+    ctx = R(context)
+    k, v = R(_lin_raw(sd, a + ".to_k", ctx)), R(_lin_raw(sd, a + ".to_v", ctx))
+    x = _teach(a, R(x + _lin_raw(sd, a + ".to_out.0", _teach(a + ".o", R(_attention(q, k, v, heads)), heads))))
+    # GEGLU feed-forward: value * gelu(gate) from the fp32 accumulators, one rounding
+    if f3:
+        h = _folded_linear(sd, key + ".ff.net.0.proj.weight", key + ".ff.net.0.proj.bias", key + ".norm3", x)
+    else:
+        h = _lin_raw(sd, key + ".ff.net.0.proj", _ln(sd, key + ".norm3", x))
+    val, gate = h.chunk(2, dim=-1)
+    g = _teach(key + ".ff.g", R(val * _gelu(gate, st.plant.get("gelu_tanh") == key)))
+    return _teach(key, R(x + _lin_raw(sd, key + ".ff.net.2", g)))
+
+
+def spatial_transformer(sd, key, x, context, heads, to=None):
+    st, R = _ST, _ST.R
+    b, c, hh, ww = x.shape
+    x_in = x
+    x = R(_gn(sd, key + ".norm", x, 1e-6))
+    use_linear = sd[key + ".proj_in.weight"].ndim == 2
+    if not use_linear:
+        x = R(_c2d(x, sd[key + ".proj_in.weight"], sd[key + ".proj_in.bias"]))
+    x = x.permute(0, 2, 3, 1).reshape(b, hh * ww, -1)
+    if use_linear:
+        x = R(_lin_raw(sd, key + ".proj_in", x))
+    x = _teach(key + ".proj_in", x)
+    d = 0
+    while f"{key}.transformer_blocks.{d}.norm1.weight" in sd:
+        x = transformer_block(sd, f"{key}.transformer_blocks.{d}", x, context, heads, to)
+        d += 1
+    if use_linear:
+        x = _lin_raw(sd, key + ".proj_out", x)
+    x = x.reshape(b, hh, ww, -1).permute(0, 3, 1, 2)
+    if not use_linear:
+        x = _c2d(x, sd[key + ".proj_out.weight"], sd[key + ".proj_out.bias"])
+    return _teach(key, R(x + x_in))
+
+
+def _timestep_embedding(t, dim, max_period=10000):
+    return _ST.R(ou_timestep_embedding(t, dim, max_period))
+
+
+ou_gn, ou_ln, ou_timestep_embedding = ou._gn, ou._ln, ou.timestep_embedding
+_SWAPPED = ("_gn", "_ln", "_conv", "_lin", "resblock", "transformer_block", "spatial_transformer", "timestep_embedding")
+
+
+@contextlib.contextmanager
+def _installed(state):
+    """route the pinned walk's leaf functions through the rounding ones for the duration of one forward (restored on exit, also on error)"""
+    global _ST
+    saved = {n: getattr(ou, n) for n in _SWAPPED}
+    prev = _ST
+    _ST = state
+    try:
+        ou._gn, ou._ln, ou._conv, ou._lin = _gn, _ln, _conv, _lin
+        ou.resblock, ou.transformer_block, ou.spatial_transformer = resblock, transformer_block, spatial_transformer
+        ou.timestep_embedding = _timestep_embedding
+        yield
+    finally:
+        for n, f in saved.items():
+            setattr(ou, n, f)
+        _ST = prev
+
+
+@torch.no_grad()
+def unet_forward(sd, cfg, x, timesteps, context, y=None, fold=None, plant=None, rounding=True, teacher=None, layer_out=None, acc64=False, native_view=None):
+    """Same contract as oracle.unet.unet_forward (hooks / ControlNet not supported here).
+    fold: {transformer_block_key: (norm1_folded, norm2_folded, norm3_folded)} -- what the executor did (`IntegratedUNet2DConditionModel.fold_trace`);
+    absent keys = not folded.  -> eps fp32 (fp16-valued when rounding).
+    teacher / layer_out: layer-wise mode.  teacher = {layer key: the executor's stored output of that layer} (`IntegratedUNet2DConditionModel.tap`);
+    every layer is then evaluated on the executor's own inputs and its result lands in layer_out[key] (the return value is the teacher's eps);
+    native_view[key] receives the teacher's tensor in the oracle's layout (NCHW, heads unpadded) for the comparison.
+    acc64: convolutions and Linears accumulate in fp64 instead of fp32 -- a SECOND implementation of the same rounding network that differs from
+    the first by summation error only (~1e-7); the CPU tests use it as a stand-in for "another correct executor" to show what two of them can and
+    cannot agree on (whole network: decorrelated rounding realisations; layer by layer on shared inputs: ~1e-5)."""
+    state = _State(rounding, fold, plant, teacher, layer_out, acc64)
+    if rounding:
+        sd = {k: _r16(v) if v.is_floating_point() else v for k, v in sd.items()}
+        x = _r16(x.float())
+        y = None if y is None else y.float()
+        context = context.float()
+    with _installed(state):
+        eps = ou.unet_forward(sd, cfg, x, timesteps, context, y)
+    if native_view is not None:
+        native_view.update(state.native_view)
+    if fold and rounding:
+        want = sum(int(bool(f)) for v in fold.values() for f in v) + sum(2 for v in fold.values() if v[0])   # norm1 folds three projections
+        assert state.used_folds == want, (state.used_folds, want)
+    return eps

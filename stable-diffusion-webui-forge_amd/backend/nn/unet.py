@@ -167,6 +167,15 @@ class IntegratedUNet2DConditionModel:
         self.arena_epoch = 0  # bumped whenever the arena is re-allocated: graphs captured on the old one hold dangling pointers
         self._arena_bytes = arena_bytes
         self._ctx = ContextCache()
+        # {transformer block key: (norm1, norm2, norm3 ran folded into the projections behind them)} of the LAST forward that walked the layers
+        # (eager or graph capture) -- which rounding sites exist depends on it, so the executor-faithful oracle (oracle/unet_fp16sites.py, tests
+        # only) is told what happened instead of guessing the dispatcher's tile choices
+        self.fold_trace = {}
+        # tap(name, tensor): when set, called on the eager path with every layer's stored output (name = the layer's LDM key; `<SpatialTransformer
+        # key>.proj_in`, every `...transformer_blocks.N` and its `.attn1` / `.attn2` (the stream after those sub-layers), `.attn1.o` / `.attn2.o`
+        # (attention outputs, heads at their padded width), `.ff.g` (GEGLU output), a ResBlock's `.h` (conv1 + emb), "time_embed", "out.2") -- a VIEW of the kernel's own buffer, to be copied by the callee.
+        # The layer-wise parity tests feed these tensors to the rounding oracle layer by layer (tests/test_gpu_sharp_parity.py).
+        self.tap = None
         # Control-LoRA builds its control model from the UNet's own trunk weights (patcher/controlnet.py:445-453 reads
         # `diffusion_model.state_dict()`); the kernel layouts below are not invertible in general (fused / padded / transposed), so the source
         # tensors of the trunk are kept by reference (no copy) under their LDM keys
@@ -343,6 +352,7 @@ class IntegratedUNet2DConditionModel:
         off, cout = self._emb_off[k]
         h, h_st = ops.conv_gemm(g1, self.w[k + ".conv1"][0], cout, kh=3, pad=1, bias=self.w[k + ".conv1"][1],
                                 rowvec=emb_all[:, off:off + cout], stats=True)
+        self._tap(k + ".h", h.view(bu, hh, ww, cout))
         g2 = ops.groupnorm(h.view(bu, hh, ww, cout), *self.w[k + ".gn2"], 1e-5, silu=True, stats=h_st)
         if L.has_skip_conv:
             sk = ops.conv_gemm(x, self.w[k + ".skip"][0], cout, x1=skip, bias=self.w[k + ".skip"][1])
@@ -368,7 +378,8 @@ class IntegratedUNet2DConditionModel:
         rs_next = ops.RowStats(m_tok, h.shape[1]) if (want_next and fold) else None
         mk = arena.mark()
         # self attention
-        if n % 64 == 0 and rs1 is not None and rs1.parts and (b + ".attn1.v.ln") in self.w:
+        folded1 = n % 64 == 0 and rs1 is not None and bool(rs1.parts) and (b + ".attn1.v.ln") in self.w
+        if folded1:
             wqk, csqk, bqk = self.w[b + ".attn1.qk.ln"]
             ab = ops.empty((m_tok, 2), torch.float32)     # {rstd, -mean rstd} per token: the q|k GEMM derives them anyway and leaves them for V^T
             qk = ops.conv_gemm(h, wqk, wqk.shape[0], bias=bqk, ln=(rs1, csqk, 1e-5), ln_ab_out=ab)   # [M, 2*H*dp] = [Q | K] of LN(h)
@@ -402,8 +413,11 @@ class IntegratedUNet2DConditionModel:
             o = ops.attention(qk, qk[:, hd:], vt, batch=bu, heads=H, nq=n, nk=n, nk_pad=npad, dpad=dp, scale=d ** -0.5,
                               q_bs=npad * 2 * hd, q_rs=2 * hd, k_bs=npad * 2 * hd, k_rs=2 * hd, vt_bs=npad,
                               vt_hs=dp * bu * npad, vt_ds=bu * npad)
+        self._tap(b + ".attn1.o", o.view(bu, n, -1))
         ops.linear(o, *self.w[b + ".attn1.out"], residual=h, out=h, ld_out=h.shape[1], row_stats=rs2)
         arena.release(mk)
+        self._tap(b + ".attn1", h.view(bu, n, -1))
+        self.fold_trace[b] = (folded1, bool(fold and rs2.parts), False)
         # cross attention against the cached text K / V^T
         if fold and rs2.parts:
             wq, csq, bq = self.w[b + ".attn2.q.ln"]
@@ -415,9 +429,12 @@ class IntegratedUNet2DConditionModel:
         tp = ctxc.tpad
         o2 = ops.attention(q2, kc, vtc, batch=bu, heads=H, nq=n, nk=ctxc.tokens, nk_pad=tp, dpad=dp, scale=d ** -0.5,
                            q_bs=n * hd, q_rs=hd, k_bs=tp * hd, k_rs=hd, vt_bs=tp, vt_hs=dp * bu * tp, vt_ds=bu * tp)
+        self._tap(b + ".attn2.o", o2.view(bu, n, -1))
         ops.linear(o2, *self.w[b + ".attn2.out"], residual=h, out=h, ld_out=h.shape[1], row_stats=rs3)
         arena.release(mk)
+        self._tap(b + ".attn2", h.view(bu, n, -1))
         # GEGLU feed-forward
+        self.fold_trace[b] = self.fold_trace[b][:2] + (bool(fold and rs3.parts),)
         if fold and rs3.parts:
             fw, csf, fb = self.w[b + ".ff1.ln"]
             g = ops.conv_gemm(h, fw, fw.shape[0], bias=fb, act=ops.ACT_GEGLU, ln=(rs3, csf, 1e-5))
@@ -425,6 +442,7 @@ class IntegratedUNet2DConditionModel:
             n3 = ops.layernorm(h, *self.w[b + ".norm3"])
             fw, fb = self.w[b + ".ff1"]
             g = ops.conv_gemm(n3, fw, fw.shape[0], bias=fb, act=ops.ACT_GEGLU)
+        self._tap(b + ".ff.g", g.view(bu, n, -1))
         ops.linear(g, *self.w[b + ".ff2"], residual=h, out=h, ld_out=h.shape[1], row_stats=rs_next)
         arena.release(mk)
         return rs_next
@@ -540,16 +558,22 @@ class IntegratedUNet2DConditionModel:
         fold1 = _LN_FOLD and _LN_FOLD1 and not hooked and n % 64 == 0 and (f"{k}.transformer_blocks.0.attn1.v.ln") in self.w
         rs1 = ops.RowStats(bu * n, inner) if fold1 else None
         h = ops.linear(g.view(-1, c), *self.w[k + ".proj_in"], row_stats=rs1)  # 1x1 conv == Linear in NHWC
+        self._tap(k + ".proj_in", h.view(bu, n, -1))
         for di in range(L.depth):
             if hooked:
                 to["block_index"] = di
                 self._attn_block_hooked(f"{k}.transformer_blocks.{di}", L, h, bu, n, ctxc, arena, to)
             else:
                 rs1 = self._attn_block(f"{k}.transformer_blocks.{di}", L, h, bu, n, ctxc, arena, rs1=rs1, want_next=fold1 and di + 1 < L.depth)
+            self._tap(f"{k}.transformer_blocks.{di}", h.view(bu, n, -1))
         _, st = ops.linear(h, *self.w[k + ".proj_out"], residual=x.view(-1, c), out=out.view(-1, c), ld_out=c, n=bu, h=hh, w=ww, stats=True,
                            stats_partial=out_part)
         arena.release(mk)
         return ops.attach_stats(out, st)
+
+    def _tap(self, name, t):
+        if self.tap is not None:
+            self.tap(name, t)
 
     def _layer_standin(self, L):
         if isinstance(L, Res):
@@ -600,6 +624,7 @@ class IntegratedUNet2DConditionModel:
                 raise TypeError(L)
             for m in inner:
                 h = self._call_nchw(m, h, "after", standins[li], li, standins, to)   # unet.py:90-91
+            self._tap(L.key, h)
         return h
 
     def _wrapped_norm(self, wrapper, key, x, eps, to):
@@ -673,6 +698,7 @@ class IntegratedUNet2DConditionModel:
         e1 = ops.linear(t_emb, *self.w["te0"])
         e1 = ops.silu(e1, out=e1)
         emb = ops.linear(e1, *self.w["te2"], residual=ctxc.label)        # + label_emb(y) (unet.py:707)
+        self._tap("time_embed", emb)
         se = ops.silu(emb)
         emb_all = ops.linear(se, *self.w["emb_all"])                      # every ResBlock's emb_layers at once
         hs = []
@@ -697,6 +723,7 @@ class IntegratedUNet2DConditionModel:
                     raise ValueError("an inpainting / edit UNet needs c_concat (and only such a UNet takes one)")
                 h, st = ops.linear(xcol, cw, cb, residual=concat_term, n=bu, h=hh, w=ww, stats=True)
                 h = ops.attach_stats(h.view(bu, hh, ww, lay.model_channels), st)
+                self._tap(blk[0].key, h)
                 for m in inner:
                     h = self._call_nchw(m, h, "after", conv_in[0], 0, conv_in, to)
             else:
@@ -748,6 +775,7 @@ class IntegratedUNet2DConditionModel:
             out = ops.conv3x3_narrow(g, self.w["out.conv"][0], self.w["out.conv"][1], oc, ld_out=oc)
         else:
             out = ops.conv_gemm(g, self.w["out.conv"][0], oc, kh=3, pad=1, bias=self.w["out.conv"][1])
+        self._tap("out.2", out.view(bu, hh, ww, -1)[..., :oc])
         if modifiers:
             out = modify(out.view(bu, hh, ww, -1)[..., :oc].contiguous(), "after").reshape(bu * hh * ww, oc)
         return out

@@ -59,8 +59,15 @@ class IntegratedAutoencoderKL:
         if dtype not in self._weights:
             if self._source is not None:
                 self._weights[dtype] = self._load(self._source, dtype)
-            else:   # the source was released: re-round the resident copy (fp16 -> bf16 keeps every exponent; bf16 -> fp16 may overflow like any fp16 load)
-                src = next(iter(self._weights.values()))
+            else:
+                # the source was released: re-round the resident copy.  fp16 -> bf16 keeps every exponent and drops 3 mantissa bits (what a load
+                # from an fp16 checkpoint gives).  bf16 -> fp16 would start from 8-bit mantissas AND re-round the folded attention bias instead of
+                # recomputing it in fp32 -- silently less accurate than `_load(sd, fp16)` -- so it is refused: build the VAE in fp16 (with the bf16
+                # guard, which keeps the source while it may be needed) or hand the state dict again.
+                src_dt, src = next(iter(self._weights.items()))
+                if src_dt == torch.bfloat16 and dtype == torch.float16:
+                    raise RuntimeError("set_dtype(float16) on a VAE whose only resident weights are bfloat16: the fp32 source was released; "
+                                       "construct IntegratedAutoencoderKL(..., dtype=torch.float16) from the state dict instead")
                 self._weights[dtype] = {k: (tuple(t.to(dtype) for t in v) if isinstance(v, tuple) else v.to(dtype) if torch.is_tensor(v) else v) for k, v in src.items()}
         self.dtype, self.w = dtype, self._weights[dtype]
 
@@ -420,7 +427,12 @@ class IntegratedAutoencoderKL:
         if g == b:
             y = self._run(zf)
             return y.view(b, f * hh, f * ww, 4)[..., :oc].permute(0, 3, 1, 2).to(z.dtype)
-        return torch.cat([self._run(zf[i:i + g]).view(g, f * hh, f * ww, 4)[..., :oc].permute(0, 3, 1, 2).to(z.dtype) for i in range(0, b, g)])
+        # every group runs through the SAME arena: its result must be copied out before the next group overwrites it (`.to(z.dtype)` makes no copy
+        # when z already has the VAE's element type -- ADVICE r4: fp16 latents on an fp16 VAE came back as B/g views of the last group's arena)
+        out = torch.empty(b, oc, f * hh, f * ww, dtype=z.dtype, device=self.device)
+        for i in range(0, b, g):
+            out[i:i + g].copy_(self._run(zf[i:i + g]).view(g, f * hh, f * ww, 4)[..., :oc].permute(0, 3, 1, 2))
+        return out
 
     def decode_inner(self, samples_in):
         """patcher/vae.py:128-148: -> fp32 [B, 8h, 8w, 3] in [0, 1] (clamp((y+1)/2) fused into the unpack kernel)."""

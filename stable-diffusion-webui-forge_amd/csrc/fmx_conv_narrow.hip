@@ -6,7 +6,7 @@
 // input, 67 MB of output.  So:
 //   * a workgroup (4 waves) owns 4 rows x 32 pixels of the output; the input patch it needs -- 6 rows x 34 (staged: 36) pixels x C channels -- is staged ONCE in LDS by
 //     LDS-DMA (buffer_load ... lds, 1 KiB = 4 pixels x 256 B per instruction for C = 128; pixels outside the image read as zeros through the
-//     descriptor's bounds check), 52 KB, three workgroups per CU;
+//     descriptor's bounds check), 63 KB at C = 128 (6 x 36 pixels x 256 B of patch + 4 x 9 x 128 fp16 weights), two workgroups per CU;
 //   * every tap reads its shifted pixels from that patch: weights (padded to 16 output rows: 3 real + zeros) as the MFMA-A operand, 16 consecutive pixels
 //     of a row as the MFMA-B operand of v_mfma_f32_16x16x32; a wave owns one row of 32 pixels = 2 accumulator blocks, 9 taps x C / 32 k-steps;
 //   * 16-byte chunk c of patch pixel q lives at chunk c ^ (q & 15): 16 neighbouring pixels of one fragment read hit 16 different bank groups;
@@ -24,7 +24,7 @@ constexpr int patch_width(int c) { return (TW + 2 + 1024 / (c * 2) - 1) / (1024 
 
 // C: channels per chunk (staged at once); ctot: channels of the input (a multiple of C)
 template <int C>
-__global__ __launch_bounds__(256, 3) void conv3x3_narrow_kernel(const f16* __restrict__ x, long x_bytes, const f16* __restrict__ wgt, const f16* __restrict__ bias,
+__global__ __launch_bounds__(256, 2) void conv3x3_narrow_kernel(const f16* __restrict__ x, long x_bytes, const f16* __restrict__ wgt, const f16* __restrict__ bias,
                                                                 f16* __restrict__ out, int n, int h, int w, int ctot, int nout, int ld_out, int tiles_x, int tiles_y) {
   constexpr int PW = patch_width(C);
   constexpr int PIXB = C * 2;                       // bytes per pixel OF A CHUNK (LDS); a pixel of the input is ctot * 2 bytes

@@ -41,7 +41,7 @@ const char* fmx_knob(const char* name) {
   const char* v = getenv(name);
   if (!v) return nullptr;
   const char* a = getenv("FMX_ALLOW_KNOBS");
-  const bool allow = a && atoi(a) == 1;
+  const bool allow = a && strcmp(a, "1") == 0;   // exactly "1", the predicate forge_amd/_lib.py knob() uses
   std::lock_guard<std::mutex> lk(g_knob_mu);
   knob_note(allow ? g_knobs_active : g_knobs_ignored, name, v);
   return allow ? v : nullptr;

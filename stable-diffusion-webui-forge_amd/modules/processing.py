@@ -402,6 +402,8 @@ def process_images_sharded(p, gather_images=True, dst=0) -> Processed:
     #      the next collective and reports the failure there, so that every rank raises instead of the healthy ones waiting for ever ----------------
     local = None
     failure = None
+    lat_local = u8_local = None
+    want_images = bool(gather_images and p.do_decode and p.sd_model.forge_objects.vae is not None)
     if hi > lo:
         import copy
         try:
@@ -412,13 +414,15 @@ def process_images_sharded(p, gather_images=True, dst=0) -> Processed:
             shared.sd_model = p.sd_model
             local = process_images_inner(q, seed_plan=([all_seeds[i] for i in mine], [all_subseeds[i] for i in mine]))
             p.sampler, p.rng = q.sampler, q.rng
+            # what this rank contributes to the gathers is prepared INSIDE the try as well (an out-of-memory on the 8 x 1024^2 image
+            # copy after the try would have left the other ranks in the collective)
+            lat_local = local.latents.to(dev).float().contiguous()
+            u8_local = _to_u8(local.images, dev) if want_images else None
         except Exception as e:   # noqa: BLE001
             failure = f"rank {rank}: {type(e).__name__}: {e}"
+            local = lat_local = u8_local = None
     p.all_seeds, p.all_subseeds = all_seeds, all_subseeds
     # ---- 3. gather on the owner ---------------------------------------------------------------------------------------------------------
-    want_images = bool(gather_images and p.do_decode and p.sd_model.forge_objects.vae is not None)
-    lat_local = local.latents.to(dev).float().contiguous() if local is not None else None
-    u8_local = _to_u8(local.images, dev) if (local is not None and want_images) else None
     # a rank with no image of this job (batch_size < world) still takes part in the gather: it learns the per-image shapes from the others
     shapes = [None] * ws
     mine_msg = ("error", failure) if failure else (None if local is None else (tuple(lat_local.shape[1:]), None if u8_local is None else tuple(u8_local.shape[1:])))

@@ -1,0 +1,193 @@
+"""SHARP parity (VERDICT r4 "Next round" item 2): the native UNet against the executor-faithful rounding oracle (oracle/unet_fp16sites.py: the
+pinned fp32 restatement of backend/nn/unet.py:696-763 with fp16 rounding at exactly the executor's storage sites).
+
+Two granularities:
+
+* LAYER-WISE, teacher-forced (the gate).  The executor hands out every layer's stored output (`IntegratedUNet2DConditionModel.tap`); the oracle
+  evaluates each layer -- conv_in, the time-embedding MLP, every ResBlock, proj_in, the three sub-layers of every BasicTransformerBlock (stream
+  after attn1, after attn2, after the GEGLU feed-forward), every SpatialTransformer's proj_out + residual, Down, Up, the output head -- on the
+  executor's OWN stored inputs and the two outputs are compared.  Both sides round at the same places from the same inputs, so what is left is
+  fp32 summation order plus the rare fp16 rounding flip it causes (one element off by 1 ulp <= 9.8e-4): two CPU implementations that differ
+  only in accumulation precision agree to 1e-6 .. 8e-5 rms and <= 1.1e-3 per pixel this way (tests/test_oracle_fp16sites.py).  The gate is
+  rms <= SHARP_RMS (2e-4 = 0.12..0.14 x the fp16 floor; the verdict asked for 0.35 x) and pp_rel <= SHARP_PP (1.5e-3, the verdict's figure) for
+  EVERY layer.  A wrong constant or wire in any layer of the
+  executor is then visible at 1e-4 instead of hiding under the floor gate's ~1e-3 of slack (planted-bug tests below).
+
+* WHOLE NETWORK, free-running (reported; gated at 1.0 x floor).  An fp16 pipeline of this depth is a chaotic map at the rounding level: a
+  perturbation of 1e-7 (fp32 vs fp64 accumulation, nothing else changed) decorrelates the rounding realisation completely within a few layers,
+  and two runs of the SAME rounding oracle then differ by 0.75..0.8 x floor (tests/test_oracle_fp16sites.py shows exactly that on the CPU).  So
+  "whole-network rms <= 0.35 x floor" cannot be met by ANY two implementations that do not share their summation order bit for bit; the native
+  path lands where the oracle lands against itself.  That is why the gate is layer-wise.
+"""
+import json
+import os
+import time
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import forge_amd  # noqa: E402,F401
+from forge_amd import synth  # noqa: E402
+
+from conftest import GOLDEN, load_golden  # noqa: E402
+import parity  # noqa: E402
+
+DEV = "cuda"
+SHARP_RMS = 2.0e-4           # per layer, rms(native - oracle) / rms(oracle)
+SHARP_PP = 1.5e-3            # per layer, max |d| / max(|oracle|, rms(oracle))
+SHARP_RMS_FACTOR = 0.35      # the verdict's whole-network figure, kept for the planted-bug arithmetic: 0.35 x the fp16 floor's rms
+WHOLE_NET_FACTOR = 1.0       # free-running whole network: two realisations of one rounding process (see the module docstring)
+
+# one wrong constant each, planted in the ORACLE (the native path is right; the test has to FAIL against these)
+PLANTS = {
+    "GroupNorm eps 1e-6 instead of 1e-5 in one ResBlock norm (unet.py:395 vs :292)": {"gn_eps": ("input_blocks.1.0", "in_layers.0", 1e-6)},
+    "tanh GELU instead of erf in one GEGLU (unet.py:111)": {"gelu_tanh": "input_blocks.1.1.transformer_blocks.0"},
+}
+
+
+def planted_layer(plant):
+    """the tap at which a plant must show: the first stored tensor behind the wrong constant"""
+    if "gn_eps" in plant:
+        key, which, _ = plant["gn_eps"]
+        return key + ".h" if which == "in_layers.0" else key
+    return plant["gelu_tanh"] + ".ff.g"
+
+
+def small_variance_state_dict(cfg, scale=0.1):
+    """the tiny network with conv_in scaled down so that the first ResBlock's GroupNorm sees a variance (~3e-3) at which eps matters (the planted layer moves by ~1.4e-3: the size of the floor gate's slack): the
+    only regime in which 1e-5 vs 1e-6 is more than an fp32 rounding error (rstd changes by 0.5 (1e-5 - 1e-6) / var)"""
+    sd = synth.synth_unet_state_dict(cfg, seed=0)
+    sd = dict(sd)
+    sd["input_blocks.0.0.weight"] = sd["input_blocks.0.0.weight"] * scale
+    sd["input_blocks.0.0.bias"] = sd["input_blocks.0.0.bias"] * scale
+    return sd
+
+
+def _log(rec):
+    path = os.environ.get("FMX_PARITY_LOG")
+    if path:
+        with open(path, "a") as f:
+            f.write(json.dumps(rec) + "\n")
+
+
+def native_forward_with_taps(net, x, t, ctx, y):
+    taps = {}
+    net.tap = lambda name, tens: taps.__setitem__(name, tens.detach().to("cpu", copy=True))
+    try:
+        eps = net.forward(x.to(DEV), t.to(DEV), context=ctx.to(DEV), y=None if y is None else y.to(DEV))
+    finally:
+        net.tap = None
+    return eps.float().cpu(), taps, dict(net.fold_trace)
+
+
+def layerwise(sd, cfg, x, t, ctx, y, taps, fold, plant=None):
+    """-> {layer: metrics of native vs oracle on the native layer's own inputs}"""
+    from oracle import unet_fp16sites as o16
+    outs, nat = {}, {}
+    o16.unet_forward(sd, cfg, x, t, ctx, y, fold=fold, plant=plant, teacher=taps, layer_out=outs, native_view=nat)
+    res = {key: parity.metrics(nat[key], ref) for key, ref in outs.items()}
+    missing = set(taps) - set(outs)
+    assert not missing, f"executor layers the oracle did not visit: {sorted(missing)}"
+    return res
+
+
+def _worst(res):
+    kr = max(res, key=lambda k: res[k]["rms_rel"])
+    kp = max(res, key=lambda k: res[k]["pp_rel"])
+    return kr, res[kr]["rms_rel"], kp, res[kp]["pp_rel"]
+
+
+def _run_case(name, cfg, sd, x, t, ctx, y, floor_key, whole_network=True):
+    from forge_amd.backend.nn.unet import IntegratedUNet2DConditionModel
+    from oracle import unet_fp16sites as o16
+    net = IntegratedUNet2DConditionModel(cfg, sd, device=DEV)
+    eps, taps, fold = native_forward_with_taps(net, x, t, ctx, y)
+    t0 = time.time()
+    res = layerwise(sd, cfg, x, t, ctx, y, taps, fold)
+    kr, rms, kp, pp = _worst(res)
+    nf = sum(int(f) for v in fold.values() for f in v)
+    fl = parity.FLOORS[floor_key]
+    rec = {"name": f"sharp layer-wise: {name}", "layers": len(res), "folded_norms": nf, "worst_rms_rel": round(rms, 8), "worst_rms_layer": kr,
+           "worst_pp_rel": round(pp, 8), "worst_pp_layer": kp, "median_rms_rel": round(sorted(v["rms_rel"] for v in res.values())[len(res) // 2], 8),
+           "floor_rms_rel": fl["rms_rel"], "worst_rms_over_floor": round(rms / fl["rms_rel"], 4), "gate": {"rms_rel": SHARP_RMS, "pp_rel": SHARP_PP},
+           "oracle_seconds": round(time.time() - t0, 1)}
+    if whole_network:
+        t0 = time.time()
+        free = o16.unet_forward(sd, cfg, x, t, ctx, y, fold=fold)
+        m = parity.metrics(eps, free)
+        rec["whole_network_free_running"] = {**{k: round(v, 7) for k, v in m.items()}, "rms_over_floor": round(m["rms_rel"] / fl["rms_rel"], 4),
+                                            "oracle_seconds": round(time.time() - t0, 1)}
+    print("[sharp]", json.dumps(rec))
+    _log(rec)
+    assert rms <= SHARP_RMS, (name, kr, rms)
+    assert pp <= SHARP_PP, (name, kp, pp)
+    if whole_network:
+        assert rec["whole_network_free_running"]["rms_rel"] <= WHOLE_NET_FACTOR * fl["rms_rel"], rec
+    return net, taps, fold, res
+
+
+@pytest.mark.parametrize("name", ["tiny_sd15", "tiny_sdxl"])
+def test_tiny_networks_layer_by_layer(name):
+    cfg = {"tiny_sd15": synth.TINY_SD15_UNET_CONFIG, "tiny_sdxl": synth.TINY_SDXL_UNET_CONFIG}[name]
+    g = load_golden(f"{name}_unet_fwd.pt")
+    sd = synth.synth_unet_state_dict(cfg, seed=0)
+    _run_case(name, cfg, sd, g["x"], g["t"], g["ctx"], g["y"], f"{name}_unet_fwd.pt:eps")
+
+
+def test_sd15_full_size_forward_layer_by_layer():
+    """BASELINE config 0 / 2's network at full size (860 M parameters, 64x64 latent), batch 2: the LayerNorm folds that the 256 x 320 tiles
+    carry are live here (reported as `folded_norms`)."""
+    from oracle.make_golden import _inputs
+    cfg = synth.SD15_UNET_CONFIG
+    sd = synth.synth_unet_state_dict(cfg, seed=0)
+    x, t, ctx, y = _inputs(cfg, 2, 64, seed=11)
+    _run_case("SD1.5 full size, batch 2", cfg, sd, x, t, ctx, y, "sd15_config0.pt:latent", whole_network=False)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(GOLDEN, "sdxl_full_fwd.pt")), reason="full fixture not generated")
+def test_sdxl_full_size_forward_layer_by_layer():
+    """The bench workload's network (2.57 B parameters, 128x128 latent), the reference fixture's own input: every one of its 70 transformer blocks,
+    17 ResBlocks ... against the rounding oracle, layer by layer, on the executor's own inputs."""
+    from oracle.make_golden import _inputs
+    g = load_golden("sdxl_full_fwd.pt")
+    cfg = synth.SDXL_UNET_CONFIG
+    sd = synth.synth_unet_state_dict(cfg, seed=0)
+    x, t, ctx, y = _inputs(cfg, 1, 128, seed=g["inputs_seed"])
+    _run_case("SDXL full size (128x128 latent)", cfg, sd, x, t, ctx, y, "sdxl_full_fwd.pt:eps", whole_network=False)
+
+
+@pytest.mark.parametrize("pname", list(PLANTS))
+def test_planted_bug_fails_the_sharp_gate_and_passes_the_floor_gate(pname):
+    """A wrong constant planted in the ORACLE's copy of ONE layer: the layer-wise gate must fail AT that layer (and nowhere else), while the gate the
+    suite used until round 4 -- whole network against the reference fixture at 1.25 x floor -- is recorded for the same wrong constant planted
+    the other way round (a native path with that bug would have produced the planted oracle's output up to the sharp gate)."""
+    from oracle import unet_fp16sites as o16
+    from forge_amd.backend.nn.unet import IntegratedUNet2DConditionModel
+    plant = PLANTS[pname]
+    cfg = synth.TINY_SD15_UNET_CONFIG
+    g = load_golden("tiny_sd15_unet_fwd.pt")
+    sd = small_variance_state_dict(cfg) if "gn_eps" in plant else synth.synth_unet_state_dict(cfg, seed=0)
+    net = IntegratedUNet2DConditionModel(cfg, sd, device=DEV)
+    eps, taps, fold = native_forward_with_taps(net, g["x"], g["t"], g["ctx"], g["y"])
+    good = layerwise(sd, cfg, g["x"], g["t"], g["ctx"], g["y"], taps, fold)
+    bad = layerwise(sd, cfg, g["x"], g["t"], g["ctx"], g["y"], taps, fold, plant=plant)
+    layer = planted_layer(plant)
+    assert max(v["rms_rel"] for v in good.values()) <= SHARP_RMS and max(v["pp_rel"] for v in good.values()) <= SHARP_PP
+    failing = sorted(k for k, v in bad.items() if v["rms_rel"] > SHARP_RMS or v["pp_rel"] > SHARP_PP)
+    # would the floor gate have seen it?  the planted network, free-running, against the unplanted fp32 restatement, held to what check() allows
+    from oracle import unet as ou
+    ref32 = ou.unet_forward(sd, cfg, g["x"], g["t"], g["ctx"], g["y"])
+    planted_free = o16.unet_forward(sd, cfg, g["x"], g["t"], g["ctx"], g["y"], fold=fold, plant=plant)
+    unplanted_free = o16.unet_forward(sd, cfg, g["x"], g["t"], g["ctx"], g["y"], fold=fold)
+    mp, mu = parity.metrics(planted_free, ref32), parity.metrics(unplanted_free, ref32)
+    _, lim = parity.limits("tiny_sd15_unet_fwd.pt:eps")
+    floor_gate_catches = any(mp[k] > lim[k] for k in lim)
+    rec = {"name": f"planted bug: {pname}", "layer": layer, "sharp_gate_fails_at": failing, "planted_layer_rms_rel": round(bad[layer]["rms_rel"], 7),
+           "planted_layer_pp_rel": round(bad[layer]["pp_rel"], 7), "unplanted_layer_rms_rel": round(good[layer]["rms_rel"], 8),
+           "floor_gate_would_catch_it": floor_gate_catches, "planted_vs_fp32": {k: round(v, 6) for k, v in mp.items()},
+           "unplanted_vs_fp32": {k: round(v, 6) for k, v in mu.items()}, "floor_gate_limit": {k: round(v, 6) for k, v in lim.items()}}
+    print("[sharp]", json.dumps(rec))
+    _log(rec)
+    assert failing == [layer], rec

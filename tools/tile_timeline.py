@@ -1,8 +1,8 @@
 """Timeline of ONE persistent workgroup (blockIdx 8) of the 8-wave GEMM kernel over the output tiles it walks, under sustained load: for every tile the
 100 MHz real-time counter at the tile's top, in front of the K loop, behind the first K-tile's barrier, behind the K loop, behind the epilogue
-(library built by tools/build_timeline.sh; select it with FMX_LIB=tools/_build/libfmx_timeline.so).  What is left between two tiles, and where.
+(library built by tools/build_timeline.sh; select it with FMX_ALLOW_KNOBS=1 FMX_LIB=tools/_build/libfmx_timeline.so).  What is left between two tiles, and where.
 
-    FMX_LIB=tools/_build/libfmx_timeline.so [FMX_GEMM_XTILE=0] python tools/tile_timeline.py
+    FMX_ALLOW_KNOBS=1 FMX_LIB=tools/_build/libfmx_timeline.so [FMX_GEMM_XTILE=0] python tools/tile_timeline.py
 """
 import json
 import os
