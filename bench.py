@@ -97,6 +97,7 @@ def parse(argv=None):
     ap.add_argument("--vae-breakdown", default="", help="write the per-shape kernel-time table of one VAE decode to this file")
     ap.add_argument("--rccl-selfcheck", action="store_true", help="(child process of the 1-GPU run) RCCL at world size 1: init, all-reduce, the job's broadcast + gathers on the device")
     ap.add_argument("--no-rccl-selfcheck", action="store_true", help="1-GPU run: skip the RCCL world-1 leg")
+    ap.add_argument("--no-other-configs", action="store_true", help="default 1-GPU run: skip the two small-batch legs (BASELINE config 2 and SDXL batch 1) run after the timed region")
     ap.add_argument("--stub-engine", action="store_true", help="launcher self-test without a GPU (gloo, no kernels); not a measurement")
     return ap.parse_args(argv)
 
@@ -405,6 +406,41 @@ def rccl_world1_leg(timeout=120):
         return {"ok": False, "error": repr(e)}
 
 
+def other_configs_leg(timeout=90):
+    """The small-batch regime in the driver's own record: after the timed region of the default workload, BASELINE config 2
+    (SD1.5 512^2, batch 4, Euler a) and SDXL 1024^2 at batch 1 (how the reference is used: modules/processing.py:139 `batch_size: int = 1`) are each
+    measured by a child process running THIS file with that workload (10 timed steps after 2 warm-up steps, same contract, graph replay on) -- the
+    default line's own numbers are untouched by them.  -> {name: {it_per_s, ms_per_step, step_frac_of_mfma_peak, gemm_frac_of_mfma_peak, ...}}"""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    legs = {"sd15-512-b4-eulera (BASELINE configs[1])": ["--config", "sd15-b4-eulera"],
+            "sdxl-1024-b1-euler (the reference's default batch size)": ["--config", "sdxl-b8-euler20", "--batch", "1"]}
+    out = {}
+    for name, flags in legs.items():
+        t0 = time.time()
+        try:
+            res = subprocess.run([sys.executable, os.path.abspath(__file__), *flags, "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--no-vae",
+                                  "--no-rccl-selfcheck", "--no-other-configs"], capture_output=True, text=True, timeout=timeout, env=env)
+            line = next((ln for ln in reversed(res.stdout.splitlines()) if ln.startswith("{")), None)
+            if line is None:
+                out[name] = {"ok": False, "returncode": res.returncode, "stderr_tail": res.stderr[-300:]}
+                continue
+            d = json.loads(line)
+            out[name] = {"it_per_s": d["value"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "workload": d["config"]["workload"],
+                         "step_tflops_per_gpu": d.get("step_tflops_per_gpu"), "step_frac_of_mfma_peak": d.get("step_frac_of_mfma_peak"),
+                         "gemm_frac_of_mfma_peak": (d.get("roofline") or {}).get("frac"), "gemm_launches_per_forward": (d.get("roofline") or {}).get("launches_per_forward"),
+                         "attention_frac_of_mfma_peak": (d.get("roofline_attention") or {}).get("frac"),
+                         "groupnorm_ms_per_forward": (d.get("roofline_groupnorm") or {}).get("kernel_time_per_forward_ms"),
+                         "sclk_mhz_mean": ((d.get("clocks_during_timed_steps") or {}).get("sclk_mhz") or {}).get("mean"),
+                         "wall_s_of_this_leg": round(time.time() - t0, 1)}
+        except subprocess.TimeoutExpired:
+            out[name] = {"ok": False, "error": f"timed out after {timeout} s"}
+        except Exception as e:  # noqa: BLE001 -- an extra leg must never take the bench line down
+            out[name] = {"ok": False, "error": repr(e)}
+    return out
+
+
 def main():
     a = parse()
     if a.rccl_selfcheck:
@@ -481,7 +517,6 @@ def main():
 
     # ---- conditioning: rank 0 owns the global batch, RCCL broadcast, each rank keeps its shard -------------------
     total = bpg * world
-    t0 = time.time()
     if rank == 0:
         if is_flux:
             g = torch.Generator().manual_seed(1234)
@@ -496,13 +531,17 @@ def main():
             uc = {k: to_dev(v) for k, v in uc.items()} if isinstance(uc, dict) else to_dev(uc)
     else:
         c = uc = None
+    # (until round 4 this interval also held the host-side synthesis of the conditioning and its upload: 22-28 ms "broadcast" at world 1)
+    torch.cuda.synchronize()
+    t0 = time.time()
     c, uc = fdist.broadcast_conditioning(c, uc, dev)
+    torch.cuda.synchronize()
+    t_bcast = time.time() - t0
     lo, hi = fdist.shard_range(total, rank, world)
     c, uc = fdist.slice_conditioning(c, lo, hi), fdist.slice_conditioning(uc, lo, hi)
     if isinstance(c, dict):
         c, uc = DictWithShape(c), DictWithShape(uc)
     torch.cuda.synchronize()
-    t_bcast = time.time() - t0
 
     shared.opts.randn_source = "CPU"
     seeds = [1000 + i for i in range(lo, hi)]
@@ -680,6 +719,8 @@ def main():
             out["cpu_baseline"] = {"value": None, "error": repr(e)}
     if rank == 0 and world == 1 and not a.no_rccl_selfcheck:
         out["rccl_world1"] = rccl_world1_leg()     # after the timed region, in a child process
+    if rank == 0 and world == 1 and not a.no_other_configs and a.config == "sdxl-b8-euler20" and not (a.model or a.res or a.batch or a.sampler):
+        out["other_configs"] = other_configs_leg()  # after the timed region, child processes
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

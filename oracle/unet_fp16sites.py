@@ -87,7 +87,7 @@ def _teach(key, computed, heads=None):
     that the next layer is again evaluated on exactly what the executor's next layer read.  Without a teacher: identity."""
     st = _ST
     st.layer_out[key] = computed
-    if st.teacher is None:
+    if st.teacher is None or key not in st.teacher:    # (a tensor the executor did not hand out on the path it took: left free-running)
         return computed
     t = st.teacher[key].float()
     if computed.dim() == 4:
@@ -210,6 +210,7 @@ def resblock(sd, key, x, emb):
     st.layer_out.setdefault("time_embed", emb)
     if st.teacher is not None and "time_embed" in st.teacher:
         emb = st.teacher["time_embed"].float()
+        st.native_view["time_embed"] = emb
     g1 = R(F.silu(_gn(sd, key + ".in_layers.0", x, 1e-5)))
     e = R(_lin_raw(sd, key + ".emb_layers.1", R(F.silu(emb))))
     h = _teach(key + ".h", R(_c2d(g1, sd[key + ".in_layers.2.weight"], sd[key + ".in_layers.2.bias"], padding=1) + e[:, :, None, None]))
@@ -236,6 +237,7 @@ def transformer_block(sd, key, x, context, heads, to=None):
     else:
         n1 = _ln(sd, key + ".norm1", x)
         q, k, v = R(_lin_raw(sd, a + ".to_q", n1)), R(_lin_raw(sd, a + ".to_k", n1)), R(_lin_raw(sd, a + ".to_v", n1))
+    q, k, v = _teach(a + ".q", q, heads), _teach(a + ".k", k, heads), _teach(a + ".v", v, heads)
     x = _teach(a, R(x + _lin_raw(sd, a + ".to_out.0", _teach(a + ".o", R(_attention(q, k, v, heads)), heads))))
     # attn2 (cross): q of LN2(x), k | v of the fp16 text context
     a = key + ".attn2"
@@ -245,6 +247,7 @@ def transformer_block(sd, key, x, context, heads, to=None):
         q = R(_lin_raw(sd, a + ".to_q", _ln(sd, key + ".norm2", x)))
     ctx = R(context)
     k, v = R(_lin_raw(sd, a + ".to_k", ctx)), R(_lin_raw(sd, a + ".to_v", ctx))
+    q, k, v = _teach(a + ".q", q, heads), _teach(a + ".k", k, heads), _teach(a + ".v", v, heads)
     x = _teach(a, R(x + _lin_raw(sd, a + ".to_out.0", _teach(a + ".o", R(_attention(q, k, v, heads)), heads))))
     # GEGLU feed-forward: value * gelu(gate) from the fp32 accumulators, one rounding
     if f3:

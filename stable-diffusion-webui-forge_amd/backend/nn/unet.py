@@ -173,7 +173,7 @@ class IntegratedUNet2DConditionModel:
         self.fold_trace = {}
         # tap(name, tensor): when set, called on the eager path with every layer's stored output (name = the layer's LDM key; `<SpatialTransformer
         # key>.proj_in`, every `...transformer_blocks.N` and its `.attn1` / `.attn2` (the stream after those sub-layers), `.attn1.o` / `.attn2.o`
-        # (attention outputs, heads at their padded width), `.ff.g` (GEGLU output), a ResBlock's `.h` (conv1 + emb), "time_embed", "out.2") -- a VIEW of the kernel's own buffer, to be copied by the callee.
+        # (attention outputs, heads at their padded width), `.attn{1,2}.{q,k,v}` (the attention kernel's operands), `.ff.g` (GEGLU output), a ResBlock's `.h` (conv1 + emb), "time_embed", "out.2") -- a VIEW of the kernel's own buffer, to be copied by the callee.
         # The layer-wise parity tests feed these tensors to the rounding oracle layer by layer (tests/test_gpu_sharp_parity.py).
         self.tap = None
         # Control-LoRA builds its control model from the UNet's own trunk weights (patcher/controlnet.py:445-453 reads
@@ -385,12 +385,14 @@ class IntegratedUNet2DConditionModel:
             qk = ops.conv_gemm(h, wqk, wqk.shape[0], bias=bqk, ln=(rs1, csqk, 1e-5), ln_ab_out=ab)   # [M, 2*H*dp] = [Q | K] of LN(h)
             wvf, vcb = self.w[b + ".attn1.v.ln"]
             vt = ops.conv_gemm(wvf, h, m_tok, ln_swapped=(ab, vcb))                                   # [H*dp, M] = V^T of LN(h)
+            self._tap_qkv(b + ".attn1", qk[:, :hd].view(bu, n, hd), qk[:, hd:].view(bu, n, hd), vt.view(hd, bu, n))
             o = ops.attention(qk, qk[:, hd:], vt, batch=bu, heads=H, nq=n, nk=n, nk_pad=n, dpad=dp, scale=d ** -0.5,
                               q_bs=n * 2 * hd, q_rs=2 * hd, k_bs=n * 2 * hd, k_rs=2 * hd, vt_bs=n, vt_hs=dp * m_tok, vt_ds=m_tok)
         elif n % 64 == 0:
             n1 = ops.layernorm(h, *self.w[b + ".norm1"])
             qk = ops.linear(n1, self.w[b + ".attn1.qk"])                   # [M, 2*H*dp] = [Q | K]
             vt = ops.conv_gemm(self.w[b + ".attn1.v"], n1, m_tok)          # [H*dp, M] = V^T (operand swap)
+            self._tap_qkv(b + ".attn1", qk[:, :hd].view(bu, n, hd), qk[:, hd:].view(bu, n, hd), vt.view(hd, bu, n))
             o = ops.attention(qk, qk[:, hd:], vt, batch=bu, heads=H, nq=n, nk=n, nk_pad=n, dpad=dp, scale=d ** -0.5,
                               q_bs=n * 2 * hd, q_rs=2 * hd, k_bs=n * 2 * hd, k_rs=2 * hd, vt_bs=n, vt_hs=dp * m_tok, vt_ds=m_tok)
         else:
@@ -427,6 +429,7 @@ class IntegratedUNet2DConditionModel:
             q2 = ops.linear(n2, self.w[b + ".attn2.q"])
         kc, vtc = ctxc.kv[b]
         tp = ctxc.tpad
+        self._tap_qkv(b + ".attn2", q2.view(bu, n, hd), kc.view(bu, tp, hd)[:, :ctxc.tokens], vtc.view(hd, bu, tp)[:, :, :ctxc.tokens])
         o2 = ops.attention(q2, kc, vtc, batch=bu, heads=H, nq=n, nk=ctxc.tokens, nk_pad=tp, dpad=dp, scale=d ** -0.5,
                            q_bs=n * hd, q_rs=hd, k_bs=tp * hd, k_rs=hd, vt_bs=tp, vt_hs=dp * bu * tp, vt_ds=bu * tp)
         self._tap(b + ".attn2.o", o2.view(bu, n, -1))
@@ -574,6 +577,13 @@ class IntegratedUNet2DConditionModel:
     def _tap(self, name, t):
         if self.tap is not None:
             self.tap(name, t)
+
+    def _tap_qkv(self, name, q, k, vt):
+        """attention operands as the kernel reads them: q / k [B, N, H*dp], V^T [H*dp, B, Nk] (handed on as [B, Nk, H*dp] views)"""
+        if self.tap is not None:
+            self.tap(name + ".q", q)
+            self.tap(name + ".k", k)
+            self.tap(name + ".v", vt.permute(1, 2, 0))
 
     def _layer_standin(self, L):
         if isinstance(L, Res):

@@ -36,7 +36,14 @@ __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + 
 
 // BUF: LDS-DMA through buffer descriptors (32-bit byte offsets, hardware zero fill for out-of-range lanes) -- needs every
 // operand to span < 0xC0000000 bytes (dispatcher: fits32); BUF = false keeps 64-bit global addresses + the zero page.
-template <int BM, int BN, bool CONV, bool BUF, bool SPLITK = false>
+// NST: stages of the LDS ring.  2 (rounds 1-4): issue K-tile t+1, compute K-tile t, vmcnt(0) + barrier -- ONE K-tile in flight, so with one or two
+// workgroups on a CU a K-tile costs a full trip to L2 / HBM (~0.8 us measured, profiles/r05c: (2048,1280,5120) - (2048,1280,1280) = 47 us for 60
+// K-tiles) against ~0.25 us of MFMA work: the small-M regime (UNet batch 2..8 at the inner levels, where a launch has fewer tiles than the chip has
+// CUs and nothing else covers the latency) ran at 250-550 TFLOP/s.  NST >= 3 (round 5): a ring with NST - 1 K-tiles in flight, counted
+// s_waitcnt vmcnt(N) and a raw s_barrier (a __syncthreads() would drain the ring: an LDS-DMA is a pending LDS write on the VM counter), one
+// barrier per K-tile:  wait for tile i's own pieces -> barrier (every wave's pieces of tile i are in LDS; every wave is done reading tile i-1) ->
+// issue tile i+NST-1 into the stage tile i-1 has left -> compute tile i.
+template <int BM, int BN, bool CONV, bool BUF, bool SPLITK = false, int NST = 2>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int MI = BM / 32;  // 16-row fragments per wave along M
@@ -171,12 +178,55 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 
   const int t_begin = SPLITK ? (int)((long)p.kt * ks / p.splits) : 0;
   const int t_end = SPLITK ? (int)((long)p.kt * (ks + 1) / p.splits) : p.kt;
+  const int frow = lane & 15;
+  const int fk = lane >> 4;
+  auto compute = [&](int cur) {
+    const char* sa = smem + cur * STAGE_BYTES;
+    const char* sb = sa + BM * 128;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      f16x8 af[MI], bf[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+        af[i] = *reinterpret_cast<const f16x8*>(sa + lds_off(wm * (BM / 2) + i * 16 + frow, kk * 4 + fk));
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+        bf[j] = *reinterpret_cast<const f16x8*>(sb + lds_off(wn * (BN / 2) + j * 16 + frow, kk * 4 + fk));
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = FMX_MFMA_16x16x32(bf[j], af[i], acc[i][j]);
+    }
+  };
+  if constexpr (NST > 2) {
+    static_assert(BUF, "the ring runs on the buffer-descriptor path");
+    constexpr int PPT = LA + LB;   // LDS-DMA instructions a wave issues per K-tile: what one tile in flight adds to its VM counter
+    static_assert((NST - 2) * PPT <= 63 && NST <= 6, "vmcnt is a 6-bit counter; the wait ladder below covers four tiles in flight behind the current one");
+    const int nt = t_end - t_begin;
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+      if (s < nt) stage(s, t_begin + s);
+    int cur = 0, nxt = NST - 1;    // stage of tile i; stage tile i + NST - 1 goes to (= the one tile i - 1 has left)
+    for (int i = 0; i < nt; ++i) {
+      const int ahead = min(NST - 2, nt - 1 - i);   // tiles issued behind tile i that may still be in flight (uniform)
+      if (ahead >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((4 * PPT) & 63) : "memory");
+      else if (ahead == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((3 * PPT) & 63) : "memory");
+      else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPT) : "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPT) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (i + NST - 1 < nt) stage(nxt, t_begin + i + NST - 1);
+      compute(cur);
+      cur = cur + 1 == NST ? 0 : cur + 1;
+      nxt = nxt + 1 == NST ? 0 : nxt + 1;
+    }
+    __builtin_amdgcn_s_barrier();   // (split-K: every wave is past its last LDS read before the first word carries the ticket)
+  } else {
   stage(0, t_begin);
   wait_vmcnt0();
   __syncthreads();
 
-  const int frow = lane & 15;
-  const int fk = lane >> 4;
   for (int t = t_begin; t < t_end; ++t) {
     const int cur = (t - t_begin) & 1;
     if (t + 1 < t_end) stage(cur ^ 1, t + 1);
@@ -199,6 +249,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     }
     wait_vmcnt0();
     __syncthreads();
+  }
   }
 
   if (SPLITK) {
@@ -279,6 +330,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
       nbs[j] = nok[j] ? nb : 0;
       bb[j] = fe.bias4(nbs[j]);
     }
+    float cs[NI][4], cq[NI][4];   // column sums / sums of squares of this lane's rows (output statistics, below)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cs[j][r] = cq[j][r] = 0.f;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int m = m0 + wm * (BM / 2) + i * 16 + frow;
@@ -300,6 +356,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
           for (int r = 0; r < 4; ++r)
             v[r] = fe.act_gate(acc[i][j][r] * fe.alpha + (float)bb[j][r] + (float)rv[j][r], (float)gt[j][r]) + (float)rs[j][r];
           if (mok && nok[j]) fe.store4(m, nbs[j], v);
+          if (BM == 128 && p.stats) {   // (uniform) GroupNorm statistics of the fp16 values just stored
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float h = (mok && nok[j]) ? (float)(f16)v[r] : 0.f;
+              cs[j][r] += h;
+              cq[j][r] = fmaf(h, h, cq[j][r]);
+            }
+          }
         }
       } else {
         // fragments come in [value | gate] pairs along j: odd j holds the gate of fragment j-1
@@ -317,6 +381,43 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
           }
           if (mok && nok[j]) fe.store4(m, col, v);
         }
+      }
+    }
+    if (BM == 128 && p.stats) {
+      // ---- round 5: the output's GroupNorm statistics from this tile (128 rows of ONE image: the dispatcher sets p.stats only then), so that a
+      //      small-batch ResBlock needs no gn_stats pass over what was just written.  A lane holds, per column block j, 4 columns of MI rows summed;
+      //      the 16 lanes of a column quad add up by a fixed butterfly, the two row halves of the workgroup through LDS in a fixed order:
+      //      partial[image][128-row chunk][column][{sum, sum of squares}], plain stores into this tile's own slots -- deterministic.
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float s1 = cs[j][r], q1 = cq[j][r];
+#pragma unroll
+          for (int d = 1; d < 16; d <<= 1) {
+            s1 += __shfl_xor(s1, d);
+            q1 += __shfl_xor(q1, d);
+          }
+          cs[j][r] = s1;
+          cq[j][r] = q1;
+        }
+      float* red = reinterpret_cast<float*>(smem);   // [2 (wm)][BN][2]; every wave is past the K loop's last barrier
+      if (frow == 0) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int col = wn * (BN / 2) + j * 16 + fk * 4 + r;
+            red[(wm * BN + col) * 2 + 0] = cs[j][r];
+            red[(wm * BN + col) * 2 + 1] = cq[j][r];
+          }
+      }
+      __syncthreads();
+      if (tid < BN && n0 + tid < p.nout) {
+        const int per = p.oh * p.ow;
+        const int img = m0 / per, chunk = (m0 - img * per) / BM;
+        float* dst = p.stats + ((long)(img * p.stats_nch + chunk) * p.nout + n0 + tid) * 2;
+        *reinterpret_cast<f32x2*>(dst) = f32x2{red[tid * 2] + red[(BN + tid) * 2], red[tid * 2 + 1] + red[(BN + tid) * 2 + 1]};
       }
     }
     return;
@@ -353,12 +454,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   }
 }
 
-template <int BM, int BN, bool CONV, bool BUF, bool SPLITK = false>
+template <int BM, int BN, bool CONV, bool BUF, bool SPLITK = false, int NST = 2>
 int launch_impl(const GemmParams& p, hipStream_t st) {
-  const int smem = 2 * (BM + BN) * 128;
+  const int smem = NST * (BM + BN) * 128;
+  static_assert(NST * (BM + BN) * 128 <= 160 * 1024, "LDS ring beyond 160 KB");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, CONV, BUF, SPLITK>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, CONV, BUF, SPLITK, NST>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
@@ -366,9 +468,21 @@ int launch_impl(const GemmParams& p, hipStream_t st) {
   q.tiles_m = (p.M + BM - 1) / BM;
   q.tiles_n = (p.nout + BN - 1) / BN;
   const int grid = q.tiles_m * q.tiles_n * (SPLITK ? p.splits : 1);
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, CONV, BUF, SPLITK>), dim3(grid), dim3(256), smem, st, q);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, CONV, BUF, SPLITK, NST>), dim3(grid), dim3(256), smem, st, q);
   FMX_LAUNCH_CHECK("fmx_gemm_conv_f16");
   return FMX_OK;
+}
+
+// the LDS ring (round 5; buffer-descriptor path only): one workgroup per CU, four stages (96 / 128 / 144 KB).  As many stages as 160 KB hold (5 on
+// the 128x128 tile, 6 on 128x64) were measured level or slower (profiles/r20_ring_vs_two_stage_microbench.jsonl): three tiles in flight already cover
+// the memory latency, the K-tile is LDS-bound
+template <int BM, int BN>
+constexpr int ring_depth() { return 4; }
+template <int BM, int BN>
+int launch_ring(const GemmParams& p, bool conv, bool split, hipStream_t st) {
+  constexpr int R = ring_depth<BM, BN>();
+  if (split) return conv ? launch_impl<BM, BN, true, true, true, R>(p, st) : launch_impl<BM, BN, false, true, true, R>(p, st);
+  return conv ? launch_impl<BM, BN, true, true, false, R>(p, st) : launch_impl<BM, BN, false, true, false, R>(p, st);
 }
 
 // split-K instantiations exist for the 128 x 128 and 128 x 64 tiles on the buffer-descriptor path
@@ -565,6 +679,38 @@ static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, i
       if (split_fits(128, 64, S)) consider(1, cost_split(128, 64, 3, 0.58, S), S);
     }
   }
+  // ---- round 5: the 4-wave tiles on a 4-stage LDS ring (ids 10 / 11 / 12 = 128x128 / 128x160 / 128x64), ONE workgroup per CU with three K-tiles in
+  //      flight.  What it is for: launches with fewer tiles than CUs (UNet batch 2..8 at the 8^2..32^2 levels), where the 2-stage kernels above pay a
+  //      full memory round trip per K-tile (~0.8-0.9 us; the model's "wpc x area / eff" happens to price that correctly) and the ring pays
+  //      ~0.4 us.  Same epilogue, same split-K hand-over (ids 10 and 12).  FMX_GEMM_RING: 0 = never, 1 (default) = by the cost model,
+  //      2 = wherever eligible (A/B).
+  const char* ering = fmx_knob("FMX_GEMM_RING");
+  const int ring_mode = ering ? atoi(ering) : 1;
+  const bool ring_ok = fits32 && ring_mode != 0;
+  if (ring_ok) {
+    // fitted to tools/bench_kernels.py ring (profiles/r20_ring_vs_two_stage_microbench.jsonl; in a graph, cold weights): a K-tile costs the ring
+    // 0.60 / 0.72 / 0.43 us on the 128x128 / 128x160 / 128x64 tile (2-stage forms: 0.9-1.0 / - / 0.8) -- LDS-bound from here on: a 64 x 64 wave tile
+    // with one wave per SIMD needs the LDS's whole 128 B / clk at the MFMA rate -- and a launch 12-14 K-tiles' worth of fixed time (dispatch, first
+    // tile's round trip, epilogue); a 3x3 convolution's address arithmetic slows the K-tile by a quarter.  Neither more stages (5 / 6: level or
+    // worse) nor hot weights (19.7 vs 21.0 us) move it.
+    if (ring_mode == 2) best = 1e300;
+    auto cost_ring = [&](int bm, int bn, int S) {
+      const double effr = (bn == 128 ? 0.606 : bn == 160 ? 0.63 : 0.416) * (conv ? 0.80 : 1.0);
+      const double E = bn == 128 ? 14.3 : 12.5;
+      const double rounds = ceil(tiles(bm, bn) * S / 256.0);
+      const double es = S > 1 ? 2.7 * S + 1.1 : 0.0;
+      return rounds * (double)bm * bn * (kt / S + E + es) / effr;
+    };
+    consider(10, cost_ring(128, 128, 1));
+    consider(12, cost_ring(128, 64, 1));
+    if (!geglu && (p.nout % 160) == 0) consider(11, cost_ring(128, 160, 1));
+    if (split_ok && force_split < 0)
+      for (int S = 2; S <= 8; ++S) {
+        if (p.kt / S < 6) break;
+        if (split_fits(128, 128, S)) consider(10, cost_ring(128, 128, S), S);
+        if (split_fits(128, 64, S)) consider(12, cost_ring(128, 64, S), S);
+      }
+  }
   // 256x160 x 2 workgroups per CU: a plain linear GEMM (single source, 1x1, no output statistics) with the 8-wave kernels' epilogue contract
   const bool w4_ok = big_ok && !conv && p.c1 == 0 && !stats && !a->ln_col_ab && (!geglu || (p.nout % 32) == 0);
   {
@@ -574,12 +720,15 @@ static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, i
     if (w4_ok && sel == 6 && (mode4 == 2 || (mode4 == 1 && fmx_gemm4w_preferred(p.M, p.nout, p.kt, geglu)))) sel = 9;
   }
   if (a->out_f32 < 0) { sel = (-a->out_f32 - 1) % 16; best_s = 1; }  // test hook: force a tile shape (out_f32 = -1..-10 -> fp16 out)
-  if (split_ok && force_split >= 2 && (sel == 0 || sel == 1) && split_fits(128, sel == 0 ? 128 : 64, force_split)) best_s = force_split;
-  if (best_s > 1 && sel != 0 && sel != 1) best_s = 1;
+  if (split_ok && force_split >= 2 && (sel == 0 || sel == 1 || sel == 10 || sel == 12) && split_fits(128, (sel == 0 || sel == 10) ? 128 : 64, force_split))
+    best_s = force_split;
+  if (best_s > 1 && sel != 0 && sel != 1 && sel != 10 && sel != 12) best_s = 1;
   if (fmx_knob("FMX_GEMM_DEBUG"))
     fprintf(stderr, "fmx_gemm: M=%d N=%d K=%d conv=%d -> tile id %d, split-K %d (workspace %ld floats, fits32 %d)\n", p.M, p.nout, p.kt * 64, (int)conv,
             sel + 1, best_s, ws_floats, (int)fits32);
-  FMX_REQUIRE(sel <= 9, "gemm: unknown tile id");
+  FMX_REQUIRE(sel <= 12, "gemm: unknown tile id");
+  FMX_REQUIRE(sel < 10 || fits32, "gemm: the ring tiles (ids 11-13) address their operands through buffer descriptors (operands < 3 GB)");
+  FMX_REQUIRE(sel != 11 || (a->act != FMX_ACT_GEGLU), "gemm: the 128x160 ring tile does not support GEGLU");
   FMX_REQUIRE(sel != 9 || w4_ok, "gemm: the 256x160 two-workgroup tile takes plain linear GEMMs (one source, no output statistics, fp16 out, 16-byte aligned operands)");
   FMX_REQUIRE(sel != 8 || (!geglu && (!conv || (p.c1 == 0 && a->up_h == 0))), "gemm: the 512x128 tile takes no GEGLU, second source or upsample-on-load");
   FMX_REQUIRE(sel != 3, "gemm: tile id 4 (the first-generation ping-pong kernel) is no longer part of the library");
@@ -592,8 +741,10 @@ static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, i
     FMX_REQUIRE(!geglu && !p.out_f32 && p.ld_out == p.nout && (p.nout % 8) == 0 && !p.gate && a->act == FMX_ACT_NONE,
                 "gemm: output statistics need a dense fp16 [M][nout] output without activation / gate");
     FMX_REQUIRE(fallback_chunks >= 1 && fallback_chunks <= 1024 && max_chunks >= fallback_chunks, "gemm: bad statistics chunk counts");
-    const int rows = sel == 8 ? 512 : 256;
-    if ((sel == 5 || sel == 6 || sel == 8) && (per_img % rows) == 0 && per_img / rows <= max_chunks) {
+    // (round 5) the 128-row 4-wave tiles emit them too -- the small-batch launches, whose tensors used to get a gn_stats pass of their own
+    const bool rows128 = (sel == 0 || sel == 1 || sel == 4 || sel >= 10) && FastEpilogue::eligible(p);
+    const int rows = sel == 8 ? 512 : rows128 ? 128 : 256;
+    if ((sel == 5 || sel == 6 || sel == 8 || rows128) && (per_img % rows) == 0 && per_img / rows <= max_chunks) {
       p.stats = stats;
       p.stats_nch = per_img / rows;
       *chunks_out = p.stats_nch;
@@ -638,6 +789,14 @@ static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, i
   int rc;
   if (sel == 9) {
     rc = fmx_launch_gemm4w(p, st);
+  } else if (sel >= 10) {
+    if (best_s > 1) {
+      p.splits = best_s;
+      p.tickets = reinterpret_cast<int*>(a->workspace);
+      p.ws = reinterpret_cast<float*>(reinterpret_cast<char*>(a->workspace) + TICKET_BYTES);
+    }
+    rc = sel == 10 ? launch_ring<128, 128>(p, conv, best_s > 1, st) : sel == 12 ? launch_ring<128, 64>(p, conv, best_s > 1, st)
+                   : (conv ? launch_impl<128, 160, true, true, false, ring_depth<128, 160>()>(p, st) : launch_impl<128, 160, false, true, false, ring_depth<128, 160>()>(p, st));
   } else if (sel >= 5) {
     FMX_REQUIRE(FastEpilogue::eligible8(p) && fits32, "gemm: the 256-row kernels need fp16 output, 16-byte aligned epilogue operands, leading dimensions / nout multiples of 8, operands < 2^32 elements");
     if (sel == 6) FMX_REQUIRE(a->act != FMX_ACT_GEGLU || (p.nout % 32) == 0, "gemm: GEGLU needs nout % 32 == 0");

@@ -138,20 +138,81 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
 // ---- apply: normalise + affine (+ SiLU), writing the (concatenated) fp16 NHWC tensor: 1 read + 1 write ---------------------------
 // grid (pixel tiles, n); the image's per-channel scale / shift are staged once per block in LDS; element i = tid + k*256 over the
 // (pixel, octet) grid, four independent 16-byte loads in flight per thread.
-template <bool SILU, int UNR = 4, bool NT = false>
+// FUSE (round 5): no gn_finalize launch in front -- every block folds its image's chunk partials into the scale / shift table itself (32 groups,
+// fixed summation order: every block of an image computes the same bits).  The partials of one image are (channels x chunks) 8-byte records out
+// of L2; the launcher fuses up to 12 288 of them (96 KB per block), which covers the UNet's tensors up to 32^2 x 2560 / 64^2 x 640 (batch 1-8: the
+// tensors whose apply launch is 15-20 us and whose finalize launch was another 7-12 us of pure latency, 46-61 launches per forward); larger
+// tensors keep the separate finalize (8 us against a 45-90 us apply).
+struct GnFuse {
+  const float* p0; const float* p1;   // chunk partials of the two sources [n][nch][c][2]
+  int nch0, nch1;
+  const f16* gamma; const f16* beta;
+  float eps;
+};
+
+template <bool SILU, int UNR = 4, bool NT = false, bool FUSE = false>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x0, const f16* __restrict__ x1, int c0, int c1, long ld0, long ld1,
-                                                        int hw, const float* __restrict__ ss_g, f16* __restrict__ y, int pix_per_block) {
-  extern __shared__ __attribute__((aligned(16))) float ss[];  // [C] scale, [C] shift
+                                                        int hw, const float* __restrict__ ss_g, f16* __restrict__ y, int pix_per_block, GnFuse fu) {
+  extern __shared__ __attribute__((aligned(16))) float ss[];  // [C] scale, [C] shift (FUSE: + 64 floats of group sums)
   const int C = c0 + c1;
   const int img = blockIdx.y;
   float* scale = ss;
   float* shift = ss + C;
   const int tid = threadIdx.x;
-  const float* simg = ss_g + (long)img * C * 2;
-  for (int c = tid; c < C; c += 256) {
-    const f32x2 v = *reinterpret_cast<const f32x2*>(simg + (long)c * 2);
-    scale[c] = v[0];
-    shift[c] = v[1];
+  if (FUSE) {
+    // 1. per channel: sum of its chunk records, in chunk order
+    for (int c = tid; c < C; c += 256) {
+      const bool second = c >= c0;
+      const int cl = second ? c - c0 : c, cs = second ? c1 : c0, nch = second ? fu.nch1 : fu.nch0;
+      const float* b = (second ? fu.p1 : fu.p0) + ((long)img * nch * cs + cl) * 2;
+      float s = 0.f, q = 0.f;
+      for (int ch = 0; ch < nch; ++ch) {
+        const f32x2 v = *reinterpret_cast<const f32x2*>(b + (long)ch * cs * 2);
+        s += v[0];
+        q += v[1];
+      }
+      scale[c] = s;
+      shift[c] = q;
+    }
+    __syncthreads();
+    // 2. per group (32 of them, 8 threads each): channels j, j + 8, ... of the group, then a fixed 8-lane butterfly
+    const int cpg = C >> 5;
+    {
+      const int g = tid >> 3, j = tid & 7;
+      float s = 0.f, q = 0.f;
+      for (int ci = j; ci < cpg; ci += 8) {
+        s += scale[g * cpg + ci];
+        q += shift[g * cpg + ci];
+      }
+#pragma unroll
+      for (int d = 1; d < 8; d <<= 1) {
+        s += __shfl_xor(s, d);
+        q += __shfl_xor(q, d);
+      }
+      __syncthreads();   // every read of the per-channel sums is done before step 3 overwrites them
+      if (j == 0) {
+        ss[2 * C + g] = s;
+        ss[2 * C + 32 + g] = q;
+      }
+    }
+    __syncthreads();
+    // 3. per channel: scale = rstd gamma, shift = beta - mean rstd gamma
+    const float cnt = (float)cpg * (float)hw;
+    for (int c = tid; c < C; c += 256) {
+      const int g = c / cpg;
+      const float mean = ss[2 * C + g] / cnt;
+      const float rstd = rsqrtf(fmaxf(ss[2 * C + 32 + g] / cnt - mean * mean, 0.f) + fu.eps);
+      const float sc = rstd * (float)fu.gamma[c];
+      scale[c] = sc;
+      shift[c] = (float)fu.beta[c] - mean * sc;
+    }
+  } else {
+    const float* simg = ss_g + (long)img * C * 2;
+    for (int c = tid; c < C; c += 256) {
+      const f32x2 v = *reinterpret_cast<const f32x2*>(simg + (long)c * 2);
+      scale[c] = v[0];
+      shift[c] = v[1];
+    }
   }
   __syncthreads();
   const int oct = C >> 3;
@@ -310,8 +371,17 @@ extern "C" int fmx_groupnorm_apply_f16(const void* x0, const void* x1, int32_t c
   FMX_REQUIRE(fmx_aligned16(x0) && fmx_aligned16(y) && (!x1 || fmx_aligned16(x1)), "groupnorm_apply: alignment");
   FMX_REQUIRE((size_t)(2 * C) * sizeof(float) <= 160 * 1024, "groupnorm_apply: too many channels for the LDS scale/shift table");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, n), dim3(64), 0, st, partial0, nchunks0, c0, partial1, c1 ? nchunks1 : 1, c1, groups, hw, eps,
-                     (const f16*)gamma, (const f16*)beta, scale_shift);
+  static int fuse_mode = -1;
+  if (fuse_mode < 0) {
+    const char* e = fmx_knob("FMX_GN_FUSE");   // A/B knob: 0 = always the separate finalize launch (rounds 2-4), 1 (default) = folded into the apply blocks where small
+    fuse_mode = e ? atoi(e) : 1;
+  }
+  const long records = (long)c0 * nchunks0 + (long)c1 * (c1 ? nchunks1 : 0);
+  const bool fuse = fuse_mode != 0 && groups == 32 && records <= 12288;
+  if (!fuse)
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, n), dim3(64), 0, st, partial0, nchunks0, c0, partial1, c1 ? nchunks1 : 1, c1, groups, hw, eps,
+                       (const f16*)gamma, (const f16*)beta, scale_shift);
+  const GnFuse fu{partial0, partial1, nchunks0, c1 ? nchunks1 : 1, (const f16*)gamma, (const f16*)beta, eps};
   static int ppb_bytes = 0;
   if (!ppb_bytes) {
     // A/B knob: activation bytes per block.  16 KB = one round of 4 x 16 bytes per thread: many short blocks beat few long ones on every
@@ -330,6 +400,8 @@ extern "C" int fmx_groupnorm_apply_f16(const void* x0, const void* x1, int32_t c
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_apply_kernel<true, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_apply_kernel<true, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_apply_kernel<false, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_apply_kernel<true, 4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_apply_kernel<false, 4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   static int variant = -1;
@@ -339,14 +411,20 @@ extern "C" int fmx_groupnorm_apply_f16(const void* x0, const void* x1, int32_t c
   }
 #define FMX_GN_LAUNCH(S, U, N)                                                                                                                   \
   hipLaunchKernelGGL((gn_apply_kernel<S, U, N>), dim3(tiles, n), dim3(256), (size_t)(2 * C) * sizeof(float), st, (const f16*)x0, (const f16*)x1, c0, c1, \
-                     (long)ld0, (long)ld1, hw, scale_shift, (f16*)y, ppb)
-  if (silu) {
+                     (long)ld0, (long)ld1, hw, scale_shift, (f16*)y, ppb, fu)
+#define FMX_GN_LAUNCH_FUSED(S)                                                                                                                    \
+  hipLaunchKernelGGL((gn_apply_kernel<S, 4, false, true>), dim3(tiles, n), dim3(256), (size_t)(2 * C + 64) * sizeof(float), st, (const f16*)x0,    \
+                     (const f16*)x1, c0, c1, (long)ld0, (long)ld1, hw, scale_shift, (f16*)y, ppb, fu)
+  if (fuse) {
+    if (silu) FMX_GN_LAUNCH_FUSED(true); else FMX_GN_LAUNCH_FUSED(false);
+  } else if (silu) {
     if (variant == 1) FMX_GN_LAUNCH(true, 8, false); else if (variant == 2) FMX_GN_LAUNCH(true, 4, true); else if (variant == 3) FMX_GN_LAUNCH(true, 8, true);
     else FMX_GN_LAUNCH(true, 4, false);
   } else {
     FMX_GN_LAUNCH(false, 4, false);
   }
 #undef FMX_GN_LAUNCH
+#undef FMX_GN_LAUNCH_FUSED
   FMX_LAUNCH_CHECK("fmx_groupnorm_apply_f16");
   return FMX_OK;
 }

@@ -391,8 +391,10 @@ def _gn_chunks(n, hw):
 
 
 def _stats_geometry(n, hw):
+    """(chunks of the stand-alone pass, capacity of the partial buffer): the GEMM's own statistics come per 256-row tile (8-wave kernels), per 128-row
+    tile (4-wave kernels, round 5) or per 512-row tile"""
     fb = _gn_chunks(n, hw)
-    return fb, max(fb, hw // 256 if hw % 256 == 0 else 0)
+    return fb, max(fb, hw // 128 if hw % 128 == 0 else (hw // 256 if hw % 256 == 0 else 0))
 
 
 def stats_buffer(n, hw, c, device=None):

@@ -32,7 +32,7 @@ def close(got, want, rtol, atol, what=""):
 
 # ----------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("m,n,k", [(256, 256, 128), (384, 320, 320), (77 * 2, 640, 768), (1000, 132, 64), (4096, 1280, 1280), (130, 4, 2880)])
-@pytest.mark.parametrize("tile", [1, 2, 3, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("tile", [1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13])
 def test_linear_plain(m, n, k, tile):
     if tile in (4, 6, 7, 8, 9, 10) and n % 8:
         pytest.skip("256x256 kernel needs nout % 8 == 0 (dispatcher never selects it otherwise)")
@@ -85,8 +85,28 @@ def test_conv_input_beyond_32bit_offsets_runs_as_image_groups():
     torch.testing.assert_close(_partial_to_sums(st, n, co), want, rtol=2e-5, atol=2e-2)
 
 
+@pytest.mark.parametrize("k", [64 * kt for kt in (1, 2, 3, 4, 5, 6, 7, 9, 20, 37)])
+@pytest.mark.parametrize("tile", [11, 12, 13])
+def test_ring_tiles_every_pipeline_depth(k, tile):
+    """Round 5: the 4-wave tiles on a 4-stage LDS ring (force_tile 11 / 12 / 13 = 128x128 / 128x160 / 128x64; csrc/fmx_gemm.hip `NST`): three K-tiles
+    in flight, counted vmcnt waits.  K-tile counts below, at and above the ring depth (the prologue issues min(3, kt) tiles, the tail waits with
+    vmcnt(16) -> (8) -> (0)), ragged M / N, residual in place; against fp32 and BIT-IDENTICAL to the 2-stage kernel of the same tile shape (same
+    MFMA sequence per output block, same epilogue)."""
+    m, n = 300, 328
+    x, w, b = rnd(m, k, seed=40), rnd(n, k, scale=1 / math.sqrt(k), seed=41), rnd(n, seed=42)
+    res = rnd(m, n, seed=43)
+    ref = x.float() @ w.float().t() + b.float() + res.float()
+    got = res.clone()
+    ops.linear(x, w, b, residual=got, out=got, ld_out=n, force_tile=tile)
+    close(got, ref, 2e-3, 2e-3, f"ring tile {tile}, {k // 64} K-tiles")
+    old = {11: 1, 12: 5, 13: 2}[tile]
+    same = res.clone()
+    ops.linear(x, w, b, residual=same, out=same, ld_out=n, force_tile=old)
+    assert torch.equal(got, same), f"ring tile {tile} differs from the 2-stage tile {old}"
+
+
 @pytest.mark.parametrize("splits", [2, 3, 5])
-@pytest.mark.parametrize("tile", [1, 2])
+@pytest.mark.parametrize("tile", [1, 2, 11, 13])
 def test_split_k_matches_and_is_deterministic(splits, tile, monkeypatch):
     """Split-K of the 4-wave kernels (csrc/fmx_gemm.hip; used for small batches): S workgroups per output tile over contiguous K ranges, partial
     accumulators through the workspace, the last arrival sums them in slot order and runs the fused epilogue.  Forced through the A/B knob on
@@ -426,7 +446,7 @@ def test_linear_two_source_and_vt():
     dict(n=2, h=16, w=16, c=128, co=4, kh=3, stride=1, pad=1),
     dict(n=2, h=12, w=12, c=64, co=128, kh=1, stride=1, pad=0),
 ])
-@pytest.mark.parametrize("tile", [0, 3, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("tile", [0, 3, 5, 6, 7, 8, 9, 11, 12, 13])
 def test_conv(cfg, tile):
     if tile in (4, 6, 7, 8, 9) and cfg["co"] % 8:
         pytest.skip("256x256 kernel needs nout % 8 == 0")

@@ -57,9 +57,11 @@ def bench_linear_cold(m, n, k, tile=0, act=0, copies=None):
     copies = copies or max(8, int(300e6 / (n * k * 2)) + 1)
     x, b = rnd(m, k), rnd(n)
     ws = [rnd(n, k, scale=k ** -0.5) for _ in range(copies)]
+    if copies == 1:
+        ws = ws * 40     # one matrix, forty launches in the graph: hot weights
     out = torch.empty(m, n // 2 if act else n, dtype=torch.float16, device=DEV)
     t = timeit_graph([(lambda w=w: ops.conv_gemm(x, w, n, bias=b, out=out, ld_out=out.shape[1], act=act, force_tile=tile)) for w in ws])
-    print(json.dumps({"op": "linear (in graph, cold weights)", "m": m, "n": n, "k": k, "tile": tile, "act": act, "us": round(t * 1e6, 1),
+    print(json.dumps({"op": "linear (in graph, cold weights)" if copies > 1 else "linear (in graph, ONE weight matrix)", "m": m, "n": n, "k": k, "tile": tile, "act": act, "us": round(t * 1e6, 1),
                       "tflops": round(2 * m * n * k / t / 1e12, 1)}), flush=True)
 
 
@@ -410,6 +412,44 @@ if __name__ == "__main__":
                     os.environ["FMX_GEMM_SPLITK"] = s
                 print(json.dumps({"splitk": "auto" if s is None else "off", "dispatcher": True}), end=" ")
                 bench_conv(2, hw, hw, c, co, 0)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "ring":
+        # round 5: the 4-wave tiles on the 4-stage LDS ring (force_tile 11 / 12 / 13 = 128x128 / 128x160 / 128x64) against their 2-stage forms (1 / 5 / 2)
+        # and the dispatcher's choice with the ring allowed / forbidden, at the small-M shapes of SD1.5 batch 4 and SDXL batch 1; in a graph, cold weights
+        import os
+        shapes = [(2048, 1280, 1280), (2048, 1280, 5120), (2048, 2560, 1280), (1280, 2048, 1280), (2048, 1280, 2560), (512, 1280, 1280), (512, 1280, 5120),
+                  (8192, 640, 640), (8192, 640, 2560), (8192, 1280, 640), (4096, 1280, 1280), (32768, 320, 320)]
+        for m, n, k in shapes:
+            os.environ["FMX_GEMM_SPLITK"] = "0"
+            for tile in (1, 11, 2, 13) + ((5, 12) if n % 160 == 0 else ()):
+                bench_linear_cold(m, n, k, tile)
+            os.environ.pop("FMX_GEMM_SPLITK", None)
+            for ring in ("0", "1"):
+                os.environ["FMX_GEMM_RING"] = ring
+                print(json.dumps({"dispatcher": True, "ring": ring}), end=" ")
+                bench_linear_cold(m, n, k, 0)
+            os.environ.pop("FMX_GEMM_RING", None)
+        # the same launches on ONE weight matrix (hot in L2 / the memory-side cache): what a prefetch of the next layer's weights could buy
+        os.environ["FMX_GEMM_SPLITK"] = "0"
+        for m, n, k in ((2048, 1280, 1280), (2048, 1280, 5120), (2048, 2560, 1280)):
+            for tile in (1, 11, 12):
+                print(json.dumps({"weights": "hot (one matrix)"}), end=" ")
+                bench_linear_cold(m, n, k, tile, copies=1)
+        os.environ.pop("FMX_GEMM_SPLITK", None)
+        for s in (2, 3, 4):
+            os.environ["FMX_GEMM_SPLITK"] = str(s)
+            for m, n, k in ((2048, 1280, 5120), (512, 1280, 5120)):
+                for tile in (1, 11):
+                    print(json.dumps({"splitk": s}), end=" ")
+                    bench_linear_cold(m, n, k, tile)
+        os.environ.pop("FMX_GEMM_SPLITK", None)
+        for co, c, hw, nb in ((1280, 1280, 32, 2), (1280, 2560, 32, 2), (640, 640, 64, 2), (1280, 1280, 16, 8), (1280, 2560, 16, 8), (1280, 1280, 8, 8), (1280, 2560, 8, 8),
+                              (640, 640, 32, 8), (640, 1280, 32, 8)):
+            for ring in ("0", "1"):
+                os.environ["FMX_GEMM_RING"] = ring
+                print(json.dumps({"dispatcher": True, "ring": ring}), end=" ")
+                bench_conv(nb, hw, hw, c, co, 0)
+            os.environ.pop("FMX_GEMM_RING", None)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "coldhot":
         # the big linear shapes of the batch-8 forward: eager back-to-back on ONE weight matrix (hot in L2 / MALL) vs in a graph with a
