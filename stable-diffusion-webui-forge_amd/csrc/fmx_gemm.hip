@@ -330,7 +330,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
       nbs[j] = nok[j] ? nb : 0;
       bb[j] = fe.bias4(nbs[j]);
     }
-    float cs[NI][4], cq[NI][4];   // column sums / sums of squares of this lane's rows (output statistics, below)
+    // output statistics (below): every 128-row tile but the 2-stage 128 x 160 one, whose 236 registers are what lets two workgroups share a CU (with the
+    // 32 sums it ran one per CU and 40 % slower: profiles/r21 -> r23 breakdowns); that tile keeps the gn_stats pass behind it
+    constexpr bool STATS_OK = BM == 128 && !(BN == 160 && NST == 2);
+    float cs[NI][4], cq[NI][4];   // column sums / sums of squares of this lane's rows
 #pragma unroll
     for (int j = 0; j < NI; ++j)
 #pragma unroll
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
           for (int r = 0; r < 4; ++r)
             v[r] = fe.act_gate(acc[i][j][r] * fe.alpha + (float)bb[j][r] + (float)rv[j][r], (float)gt[j][r]) + (float)rs[j][r];
           if (mok && nok[j]) fe.store4(m, nbs[j], v);
-          if (BM == 128 && p.stats) {   // (uniform) GroupNorm statistics of the fp16 values just stored
+          if (STATS_OK && p.stats) {   // (uniform) GroupNorm statistics of the fp16 values just stored
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const float h = (mok && nok[j]) ? (float)(f16)v[r] : 0.f;
@@ -383,7 +386,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
         }
       }
     }
-    if (BM == 128 && p.stats) {
+    if (STATS_OK && p.stats) {
       // ---- round 5: the output's GroupNorm statistics from this tile (128 rows of ONE image: the dispatcher sets p.stats only then), so that a
       //      small-batch ResBlock needs no gn_stats pass over what was just written.  A lane holds, per column block j, 4 columns of MI rows summed;
       //      the 16 lanes of a column quad add up by a fixed butterfly, the two row halves of the workgroup through LDS in a fixed order:
@@ -639,14 +642,26 @@ static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, i
     const double rounds = ceil(tiles(bm, bn) / (256.0 * wpc));
     return rounds * wpc * ((double)bm * bn * (kt + e) / eff + fixed);
   };
+  const double e4v = geglu ? 5.0 : 2.0, F4v = 49152.0;
+  // (round 5) the 2-stage 4-wave tiles in a launch of ONE round: the constants above were fitted to multi-round launches, where a CU's workgroups
+  // start staggered and cover each other's prologue / epilogue; in one round they start and end together.  Measured (tools/bench_kernels.py
+  // smallconv / ring, profiles/r23_small_batch_conv_tiles.jsonl): twice the fixed cost, the 128 x 160 tile at 0.62 (3x3 convolutions: 0.55) instead
+  // of 0.80, convolutions on the other two at 0.83 of their linear rate.  The 8-wave tiles' prices were right as they are (73.8 us predicted 75).
+  const char* er5 = fmx_knob("FMX_GEMM_R5COST");   // A/B knob: 0 = round 4's prices for these launches
+  const bool r5cost = !(er5 && atoi(er5) == 0);
+  auto cost4 = [&](int bm, int bn, int wpc, double eff) {
+    if (!r5cost || tiles(bm, bn) > 256.0 * wpc) return cost(bm, bn, wpc, eff, e4v, F4v);
+    const double e1 = bn == 160 ? (conv ? 0.55 : 0.62) : eff * (conv ? 0.83 : 1.0);
+    return cost(bm, bn, wpc, e1, e4v, 100000.0);
+  };
   const bool big_ok = FastEpilogue::eligible8(p) && fits32;
   const double e4 = geglu ? 5.0 : 2.0, F4 = 49152.0, e8 = 4.0, F8 = 98304.0;
   int sel = 2, best_s = 1;
   double best = cost(64, 64, 5, 0.42, e4, F4);
   auto consider = [&](int id, double c, int s = 1) { if (c < best) { best = c; sel = id; best_s = s; } };
-  consider(1, cost(128, 64, 3, 0.58, e4, F4));
-  consider(0, cost(128, 128, 2, 0.70, e4, F4));
-  if (!geglu && (p.nout % 160) == 0) consider(4, cost(128, 160, 2, 0.80, e4, F4));
+  consider(1, cost4(128, 64, 3, 0.58));
+  consider(0, cost4(128, 128, 2, 0.70));
+  if (!geglu && (p.nout % 160) == 0) consider(4, cost4(128, 160, 2, 0.80));
   if (big_ok) consider(5, cost(256, 256, 1, 0.97, e8, F8));
   if (big_ok && (!geglu || (p.nout % 32) == 0)) consider(6, cost(256, 320, 1, 1.0, e8, F8));
   if (big_ok && !geglu) consider(7, cost(320, 256, 1, 0.97, e8, F8));  // only where its row quantisation wins (M = 320 k: the V^T GEMM)
@@ -679,7 +694,7 @@ static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, i
       if (split_fits(128, 64, S)) consider(1, cost_split(128, 64, 3, 0.58, S), S);
     }
   }
-  // ---- round 5: the 4-wave tiles on a 4-stage LDS ring (ids 10 / 11 / 12 = 128x128 / 128x160 / 128x64), ONE workgroup per CU with three K-tiles in
+  // ---- round 5: the 4-wave tiles on a 4-stage LDS ring (ids 10 / 11 / 12 / 13 = 128x128 / 128x160 / 128x64 / 64x160; force_tile = id + 1), ONE workgroup per CU with three K-tiles in
   //      flight.  What it is for: launches with fewer tiles than CUs (UNet batch 2..8 at the 8^2..32^2 levels), where the 2-stage kernels above pay a
   //      full memory round trip per K-tile (~0.8-0.9 us; the model's "wpc x area / eff" happens to price that correctly) and the ring pays
   //      ~0.4 us.  Same epilogue, same split-K hand-over (ids 10 and 12).  FMX_GEMM_RING: 0 = never, 1 (default) = by the cost model,
@@ -695,8 +710,10 @@ static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, i
     // worse) nor hot weights (19.7 vs 21.0 us) move it.
     if (ring_mode == 2) best = 1e300;
     auto cost_ring = [&](int bm, int bn, int S) {
-      const double effr = (bn == 128 ? 0.606 : bn == 160 ? 0.63 : 0.416) * (conv ? 0.80 : 1.0);
-      const double E = bn == 128 ? 14.3 : 12.5;
+      // (64 x 160, id 14: a K-tile 0.51 us, 13 K-tiles fixed -- N = 1280 at M = 2048 is 256 tiles of it, one per CU, where 128 x 128 leaves 96 CUs idle:
+      //  16.8 against 20.3 us at K = 1280, 47.3 against 55.5 at K = 5120; convolutions 0.77 of that)
+      const double effr = (bm == 64 || bm == 160) ? (conv ? 0.34 : 0.44) : (bn == 128 ? 0.606 : bn == 160 ? 0.63 : 0.416) * (conv ? 0.80 : 1.0);
+      const double E = (bm == 64 || bm == 160) ? 13.0 : bn == 128 ? 14.3 : 12.5;
       const double rounds = ceil(tiles(bm, bn) * S / 256.0);
       const double es = S > 1 ? 2.7 * S + 1.1 : 0.0;
       return rounds * (double)bm * bn * (kt / S + E + es) / effr;
@@ -704,6 +721,8 @@ static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, i
     consider(10, cost_ring(128, 128, 1));
     consider(12, cost_ring(128, 64, 1));
     if (!geglu && (p.nout % 160) == 0) consider(11, cost_ring(128, 160, 1));
+    if (!geglu && (p.nout % 160) == 0) consider(13, cost_ring(64, 160, 1));
+    if (!geglu && (p.M % 160) == 0) consider(14, cost_ring(160, 64, 1));   // the same tile lying down: the operand-swapped V^T projection (M = 1280 weight rows)
     if (split_ok && force_split < 0)
       for (int S = 2; S <= 8; ++S) {
         if (p.kt / S < 6) break;
@@ -722,13 +741,13 @@ static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, i
   if (a->out_f32 < 0) { sel = (-a->out_f32 - 1) % 16; best_s = 1; }  // test hook: force a tile shape (out_f32 = -1..-10 -> fp16 out)
   if (split_ok && force_split >= 2 && (sel == 0 || sel == 1 || sel == 10 || sel == 12) && split_fits(128, (sel == 0 || sel == 10) ? 128 : 64, force_split))
     best_s = force_split;
-  if (best_s > 1 && sel != 0 && sel != 1 && sel != 10 && sel != 12) best_s = 1;
+  if (best_s > 1 && sel != 0 && sel != 1 && sel != 10 && sel != 12) best_s = 1;   // (ids 12 / 14, the 160-wide ring tiles, have no split-K form)
   if (fmx_knob("FMX_GEMM_DEBUG"))
     fprintf(stderr, "fmx_gemm: M=%d N=%d K=%d conv=%d -> tile id %d, split-K %d (workspace %ld floats, fits32 %d)\n", p.M, p.nout, p.kt * 64, (int)conv,
             sel + 1, best_s, ws_floats, (int)fits32);
-  FMX_REQUIRE(sel <= 12, "gemm: unknown tile id");
+  FMX_REQUIRE(sel <= 14, "gemm: unknown tile id");
   FMX_REQUIRE(sel < 10 || fits32, "gemm: the ring tiles (ids 11-13) address their operands through buffer descriptors (operands < 3 GB)");
-  FMX_REQUIRE(sel != 11 || (a->act != FMX_ACT_GEGLU), "gemm: the 128x160 ring tile does not support GEGLU");
+  FMX_REQUIRE((sel != 11 && sel != 13 && sel != 14) || (a->act != FMX_ACT_GEGLU), "gemm: the 128x160 / 64x160 / 160x64 ring tiles do not support GEGLU");
   FMX_REQUIRE(sel != 9 || w4_ok, "gemm: the 256x160 two-workgroup tile takes plain linear GEMMs (one source, no output statistics, fp16 out, 16-byte aligned operands)");
   FMX_REQUIRE(sel != 8 || (!geglu && (!conv || (p.c1 == 0 && a->up_h == 0))), "gemm: the 512x128 tile takes no GEGLU, second source or upsample-on-load");
   FMX_REQUIRE(sel != 3, "gemm: tile id 4 (the first-generation ping-pong kernel) is no longer part of the library");
@@ -742,7 +761,7 @@ static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, i
                 "gemm: output statistics need a dense fp16 [M][nout] output without activation / gate");
     FMX_REQUIRE(fallback_chunks >= 1 && fallback_chunks <= 1024 && max_chunks >= fallback_chunks, "gemm: bad statistics chunk counts");
     // (round 5) the 128-row 4-wave tiles emit them too -- the small-batch launches, whose tensors used to get a gn_stats pass of their own
-    const bool rows128 = (sel == 0 || sel == 1 || sel == 4 || sel >= 10) && FastEpilogue::eligible(p);
+    const bool rows128 = (sel == 0 || sel == 1 || sel >= 10) && FastEpilogue::eligible(p);
     const int rows = sel == 8 ? 512 : rows128 ? 128 : 256;
     if ((sel == 5 || sel == 6 || sel == 8 || rows128) && (per_img % rows) == 0 && per_img / rows <= max_chunks) {
       p.stats = stats;
@@ -796,6 +815,8 @@ static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, i
       p.ws = reinterpret_cast<float*>(reinterpret_cast<char*>(a->workspace) + TICKET_BYTES);
     }
     rc = sel == 10 ? launch_ring<128, 128>(p, conv, best_s > 1, st) : sel == 12 ? launch_ring<128, 64>(p, conv, best_s > 1, st)
+       : sel == 13 ? (conv ? launch_impl<64, 160, true, true, false, ring_depth<64, 160>()>(p, st) : launch_impl<64, 160, false, true, false, ring_depth<64, 160>()>(p, st))
+       : sel == 14 ? (conv ? launch_impl<160, 64, true, true, false, ring_depth<160, 64>()>(p, st) : launch_impl<160, 64, false, true, false, ring_depth<160, 64>()>(p, st))
                    : (conv ? launch_impl<128, 160, true, true, false, ring_depth<128, 160>()>(p, st) : launch_impl<128, 160, false, true, false, ring_depth<128, 160>()>(p, st));
   } else if (sel >= 5) {
     FMX_REQUIRE(FastEpilogue::eligible8(p) && fits32, "gemm: the 256-row kernels need fp16 output, 16-byte aligned epilogue operands, leading dimensions / nout multiples of 8, operands < 2^32 elements");

@@ -90,14 +90,21 @@ def test_sdxl_vae_decode_1024_bfloat16_and_uint8_image_parity():
         vae = IntegratedAutoencoderKL(synth.SDXL_VAE_CONFIG, sd, device=DEV, dtype=dt)
         zz = vae.process_out(z)
         vae.decode(zz)                                   # sizes the arena
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        dec[dt] = vae.decode(zz)
-        torch.cuda.synchronize()
-        times[dt] = (time.perf_counter() - t0) * 1e3
+        best = 1e9
+        for _ in range(3):                               # best of three: one log of round 4 showed a single 61.7 ms bf16 decode beside 14.7 ms fp16
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            dec[dt] = vae.decode(zz)
+            torch.cuda.synchronize()
+            best = min(best, (time.perf_counter() - t0) * 1e3)
+        times[dt] = best
         assert vae.fallbacks == 0
         del vae
     print(f"[vae] SDXL 1024^2 decode of one image: fp16 {times[torch.float16]:.2f} ms, bf16 {times[torch.bfloat16]:.2f} ms")
+    # bf16 is the overflow fallback and the reference's own VAE type on bf16 parts: it must not be a slow path.  tools/vae_dtype_check.py (both
+    # construction orders, five decodes each, per-kernel tables: profiles/r20_vae_fp16_vs_bf16_decode.jsonl) has the two level -- 13.1-13.5 ms bf16
+    # against 13.7-13.8 ms fp16, kernel time 12.9 / 13.4 ms; the only slow decode of a process is the very first (60 ms: module load)
+    assert times[torch.bfloat16] <= 1.3 * times[torch.float16], times
     d = dec[torch.bfloat16]
     check("SDXL VAE decode 1024x1024, bfloat16 build, every 4th pixel vs reference", d[:, :, ::4, ::4], g["decoded_s4"], floor="sdxl_vae1024.pt:decoded@bf16")
     check("SDXL VAE decode 1024x1024, bfloat16 build, centre crop vs reference", d[:, :, 448:576, 448:576], g["decoded_crop"],

@@ -233,6 +233,19 @@ def bench_conv(n, h, w, c, co, tile=0, stride=1, up=None):
                       "tflops": round(2 * n * oh * ow * co * 9 * c / t / 1e12, 1)}), flush=True)
 
 
+def bench_conv_cold(n, h, w, c, co, tile=0, stride=1, up=None, copies=None, stats=False):
+    """3x3 convolution in a graph, every launch on its own weights (cold), optionally with the output statistics"""
+    copies = copies or max(4, int(300e6 / (co * 9 * c * 2)) + 1)
+    x, b = rnd(n, h, w, c), rnd(co)
+    ws = [rnd(co, 9 * c, scale=(9 * c) ** -0.5) for _ in range(copies)]
+    oh, ow = (up or (h, w))
+    oh, ow = oh // stride, ow // stride
+    out = torch.empty(n * oh * ow, co, dtype=torch.float16, device=DEV)
+    t = timeit_graph([(lambda wk=wk: ops.conv_gemm(x, wk, co, kh=3, pad=1, stride=stride, up=up, bias=b, out=out, ld_out=co, force_tile=tile, stats=stats)) for wk in ws])
+    print(json.dumps({"op": "conv3x3 (in graph, cold weights)", "n": n, "hw": [h, w], "c": c, "co": co, "stride": stride, "up": up, "stats": stats, "tile": tile,
+                      "M": n * oh * ow, "K": 9 * c, "us": round(t * 1e6, 1), "tflops": round(2 * n * oh * ow * co * 9 * c / t / 1e12, 1)}), flush=True)
+
+
 def bench_attn(b, h, nq, nk, d, dpad, force32=False):
     nkp = -(-nk // 64) * 64
     q, k = rnd(b, nq, h, dpad), rnd(b, nkp, h, dpad)
@@ -450,6 +463,38 @@ if __name__ == "__main__":
                 print(json.dumps({"dispatcher": True, "ring": ring}), end=" ")
                 bench_conv(nb, hw, hw, c, co, 0)
             os.environ.pop("FMX_GEMM_RING", None)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "tile14":
+        import os
+        os.environ["FMX_GEMM_SPLITK"] = "0"
+        for m, n, k in ((2048, 1280, 1280), (2048, 1280, 5120), (2048, 1280, 2560), (2048, 2560, 1280), (8192, 640, 640), (8192, 640, 2560), (512, 1280, 1280), (4096, 1280, 1280)):
+            for tile in (11, 12, 14):
+                bench_linear_cold(m, n, k, tile)
+        for (n, hw, c, co) in ((2, 32, 1280, 1280), (2, 64, 640, 640), (8, 8, 1280, 1280)):
+            for tile in (11, 12, 14):
+                bench_conv_cold(n, hw, hw, c, co, tile)
+        for m, n, k in ((1280, 2048, 1280), (640, 8192, 640), (1280, 512, 1280)):
+            for tile in (11, 13, 15, 0):
+                bench_linear_cold(m, n, k, tile)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "smallconv":
+        # round 5: the convolutions of SD1.5 batch 4 / SDXL batch 1 that leave CUs idle, tile by tile (0 = dispatcher)
+        import os
+        os.environ["FMX_GEMM_SPLITK"] = "0"
+        for (n, hw, c, co, up) in ((2, 32, 1280, 1280, (64, 64)), (2, 128, 320, 320, None), (2, 128, 640, 320, None), (2, 64, 640, 640, None), (2, 64, 1280, 640, None)):
+            for tile in (5, 12, 7, 6, 1, 11):
+                try:
+                    bench_conv_cold(n, hw, hw, c, co, tile, up=up, stats=True)
+                except Exception as e:
+                    print(json.dumps({"hw": hw, "c": c, "co": co, "tile": tile, "error": str(e)[:100]}), flush=True)
+        os.environ.pop("FMX_GEMM_SPLITK", None)
+        for (n, hw, c, co, up) in ((2, 32, 1280, 1280, (64, 64)), (2, 128, 320, 320, None), (2, 128, 640, 320, None), (2, 64, 640, 640, None), (2, 64, 1280, 640, None),
+                                   (2, 32, 1280, 1280, None), (8, 8, 1280, 1280, None)):
+            print(json.dumps({"dispatcher": True}), end=" ")
+            bench_conv_cold(n, hw, hw, c, co, 0, up=up, stats=True)
+        for m, n, k in ((32768, 320, 512), (32768, 320, 1280), (32768, 320, 320), (8192, 640, 640), (8192, 1280, 640)):
+            for tile in (5, 12, 7, 6, 2, 13, 0):
+                bench_linear_cold(m, n, k, tile)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "coldhot":
         # the big linear shapes of the batch-8 forward: eager back-to-back on ONE weight matrix (hot in L2 / MALL) vs in a graph with a
