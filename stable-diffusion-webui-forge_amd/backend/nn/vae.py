@@ -27,6 +27,26 @@ from .layout import vae_decoder_layout, vae_encoder_layout
 from .unet import _conv_w
 
 
+class DiagonalGaussianDistribution:
+    """nn/vae.py:14-30: what a `model_vae_regulation` hook is handed (mean | logvar moments, NCHW fp32) -- same attributes and methods."""
+
+    def __init__(self, parameters, deterministic=False):
+        self.parameters = parameters
+        self.mean, self.logvar = torch.chunk(parameters, 2, dim=1)
+        self.logvar = torch.clamp(self.logvar, -30.0, 20.0)
+        self.deterministic = deterministic
+        self.std = torch.exp(0.5 * self.logvar)
+        self.var = torch.exp(self.logvar)
+        if self.deterministic:
+            self.var = self.std = torch.zeros_like(self.mean)
+
+    def sample(self):
+        return self.mean + self.std * torch.randn(self.mean.shape).to(device=self.parameters.device)   # CPU default generator, as the reference (:27)
+
+    def mode(self):
+        return self.mean
+
+
 class IntegratedAutoencoderKL:
     def __init__(self, config, state_dict, device="cuda", dtype=torch.float16, auto_bf16_fallback=True):
         if dtype not in (torch.float16, torch.bfloat16):
@@ -381,7 +401,9 @@ class IntegratedAutoencoderKL:
         """vae.py:296-303: posterior sample = mean + std * noise.  The reference draws torch.randn(shape) on the CPU default
         generator (vae.py:28); same here unless `noise` is given, so a seeded torch.manual_seed reproduces it."""
         if regulation is not None:
-            raise NotImplementedError("model_vae_regulation hooks are not supported by the native MI355X executor")
+            # patcher/vae.py:166-178 `model_vae_regulation` (set by UnetPatcher.set_model_vae_regulation, patcher/base.py:155): the hook receives the
+            # posterior and returns the latent.  The encoder runs natively; the posterior is the reference's value object over its moments.
+            return regulation(DiagonalGaussianDistribution(self.encode_moments(x))).to(x.dtype)
         if not self.has_encoder:
             raise RuntimeError("this AutoencoderKL was built without encoder weights")
         xf = x.to(device=self.device, dtype=torch.float32).contiguous()

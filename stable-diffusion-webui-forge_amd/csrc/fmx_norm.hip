@@ -371,17 +371,6 @@ extern "C" int fmx_groupnorm_apply_f16(const void* x0, const void* x1, int32_t c
   FMX_REQUIRE(fmx_aligned16(x0) && fmx_aligned16(y) && (!x1 || fmx_aligned16(x1)), "groupnorm_apply: alignment");
   FMX_REQUIRE((size_t)(2 * C) * sizeof(float) <= 160 * 1024, "groupnorm_apply: too many channels for the LDS scale/shift table");
   hipStream_t st = (hipStream_t)stream;
-  static int fuse_mode = -1;
-  if (fuse_mode < 0) {
-    const char* e = fmx_knob("FMX_GN_FUSE");   // A/B knob: 0 = always the separate finalize launch (rounds 2-4), 1 (default) = folded into the apply blocks where small
-    fuse_mode = e ? atoi(e) : 1;
-  }
-  const long records = (long)c0 * nchunks0 + (long)c1 * (c1 ? nchunks1 : 0);
-  const bool fuse = fuse_mode != 0 && groups == 32 && records <= 12288;
-  if (!fuse)
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, n), dim3(64), 0, st, partial0, nchunks0, c0, partial1, c1 ? nchunks1 : 1, c1, groups, hw, eps,
-                       (const f16*)gamma, (const f16*)beta, scale_shift);
-  const GnFuse fu{partial0, partial1, nchunks0, c1 ? nchunks1 : 1, (const f16*)gamma, (const f16*)beta, eps};
   static int ppb_bytes = 0;
   if (!ppb_bytes) {
     // A/B knob: activation bytes per block.  16 KB = one round of 4 x 16 bytes per thread: many short blocks beat few long ones on every
@@ -390,6 +379,21 @@ extern "C" int fmx_groupnorm_apply_f16(const void* x0, const void* x1, int32_t c
     const char* e = fmx_knob("FMX_GN_BLOCK_KB");
     ppb_bytes = (e ? atoi(e) : 16) * 512;        // (elements: 2 bytes each)
   }
+  auto ppb_for = [&](int c) { const int v = (ppb_bytes + c - 1) / c; return v < 1 ? 1 : v; };
+  static int fuse_mode = -1;
+  if (fuse_mode < 0) {
+    const char* e = fmx_knob("FMX_GN_FUSE");   // A/B knob: 0 = always the separate finalize launch (rounds 2-4), 1 (default) = folded into the apply blocks where small
+    fuse_mode = e ? atoi(e) : 1;
+  }
+  const long records = (long)c0 * nchunks0 + (long)c1 * (c1 ? nchunks1 : 0);
+  // ... and only where the launch is a few blocks per CU: every block repeats the fold, so on the batch-8 tensors (2 560 blocks each) the fused form
+  // cost 0.68 ms per forward more than the 46 finalize launches it removed (profiles/r26: 103.85 -> 104.33 ms per step); at batch 1-4 (320-640 blocks) it wins
+  const long blocks_total = (long)n * ((hw + (ppb_for(C) - 1)) / ppb_for(C));
+  const bool fuse = fuse_mode != 0 && groups == 32 && records <= 12288 && blocks_total <= 1024;
+  if (!fuse)
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, n), dim3(64), 0, st, partial0, nchunks0, c0, partial1, c1 ? nchunks1 : 1, c1, groups, hw, eps,
+                       (const f16*)gamma, (const f16*)beta, scale_shift);
+  const GnFuse fu{partial0, partial1, nchunks0, c1 ? nchunks1 : 1, (const f16*)gamma, (const f16*)beta, eps};
   int ppb = (ppb_bytes + C - 1) / C;
   if (ppb < 1) ppb = 1;
   const int tiles = (hw + ppb - 1) / ppb;

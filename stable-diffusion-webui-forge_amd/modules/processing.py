@@ -210,7 +210,7 @@ class StableDiffusionProcessingImg2Img(StableDiffusionProcessingTxt2Img):
     init_latent: Any = None            # or an already encoded latent [B, lc, H/8, W/8]
     denoising_strength: float = 0.75
     latent_mask: Any = None            # [B or 1, 1 or lc, H/8, W/8] in [0, 1]: 1 = repaint (the reference's `latmask`, :1823-1831)
-    inpainting_fill: int = 1           # 1 = original (:1834-1841); latent noise / nothing are UI conveniences not mirrored
+    inpainting_fill: int = 1           # "masked content" (:1781-1840): 0 = fill, 1 = original, 2 = latent noise, 3 = latent nothing
     initial_noise_multiplier: float = 1.0
     mask: Any = None
     nmask: Any = None
@@ -222,10 +222,20 @@ class StableDiffusionProcessingImg2Img(StableDiffusionProcessingTxt2Img):
         """:1684-1842 for tensor inputs: VAE-encode the init images, build mask / nmask at latent resolution."""
         from .sd_samplers_common import images_tensor_to_samples
         dev = self.sd_model.device
+        if self.inpainting_fill not in (0, 1, 2, 3):
+            raise ValueError(f"inpainting_fill {self.inpainting_fill}: 0 = fill, 1 = original, 2 = latent noise, 3 = latent nothing (processing.py:1781-1840)")
+        masked = self.latent_mask is not None
         if self.init_latent is None:
             if self.init_images is None:
                 raise ValueError("img2img needs init_images or init_latent")
+            if masked and self.inpainting_fill != 1:
+                # :1781-1785 -- every "masked content" mode but `original` first bleeds the surroundings into the masked region of the IMAGE
+                from . import masking
+                pm = getattr(self, "image_mask", None)
+                self.init_images = masking.fill_tensor(self.init_images, pm if pm is not None else self.latent_mask)
             self.init_latent = images_tensor_to_samples(self.init_images, None, self.sd_model)
+        elif masked and self.inpainting_fill == 0:
+            raise ValueError("inpainting_fill = 0 ('fill') works on the init IMAGE (masking.fill); this job handed over a ready init_latent")
         self.init_latent = self.init_latent.to(device=dev, dtype=torch.float32).contiguous()
         if self.latent_mask is not None:
             latmask = self.latent_mask.to(device=dev, dtype=torch.float32)
@@ -234,8 +244,14 @@ class StableDiffusionProcessingImg2Img(StableDiffusionProcessingTxt2Img):
             latmask = latmask.expand(self.init_latent.shape[0], self.init_latent.shape[1], -1, -1).contiguous()
             self.mask = 1.0 - latmask       # :1830
             self.nmask = latmask            # :1831
-            if self.inpainting_fill != 1:
-                raise NotImplementedError("only inpainting_fill == 1 (original) is mirrored")
+            if self.inpainting_fill == 2:   # :1834-1836 'latent noise': the masked latent starts from the job's own seeded noise
+                if all_seeds is None:
+                    raise ValueError("inpainting_fill = 2 ('latent noise') draws create_random_tensors(shape, all_seeds[:B]): init() needs all_seeds")
+                nb = self.init_latent.shape[0]
+                noise = rng.ImageRNG(tuple(self.init_latent.shape[1:]), list(all_seeds[0:nb]), device=dev).next().to(device=dev, dtype=torch.float32)
+                self.init_latent = (self.init_latent * self.mask + noise * self.nmask).contiguous()
+            elif self.inpainting_fill == 3:  # :1838-1840 'latent nothing'
+                self.init_latent = (self.init_latent * self.mask).contiguous()
         if getattr(self.sd_model, "is_inpaint", False):  # :1842: conditioning from the (pixel-space) source image and mask
             if self.init_images is None:
                 raise ValueError("an inpainting model needs init_images (the masked image is VAE-encoded for its conditioning)")

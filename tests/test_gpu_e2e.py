@@ -599,6 +599,78 @@ def test_img2img_from_images(engines):
     check("img2img from images vs oracle", res.latents, lat, floor="tiny_sd15_img2img.pt:Euler/latent")
 
 
+@pytest.mark.parametrize("fill", [0, 2, 3])
+def test_inpainting_masked_content_modes(engines, fill):
+    """processing.py:1781-1840 `inpainting_fill`: 0 'fill' / 2 'latent noise' / 3 'latent nothing' (1 'original' is the masked test above).  Every mode but
+    'original' first bleeds the surroundings into the masked region of the IMAGE (masking.fill, before the VAE encoder); 2 then replaces the masked LATENT by
+    create_random_tensors(shape, all_seeds[:B]) -- the job's own seeded noise -- and 3 by zeros.  Checked on what init() leaves in `p.init_latent`, against the
+    same formulas evaluated here on the native encoder's output of the filled image (the encoder itself is pinned by test_img2img_from_images)."""
+    from forge_amd.modules import masking, rng
+    from forge_amd.modules.sd_samplers_common import images_tensor_to_samples
+    cfg = TINY["tiny_sd15"]
+    eng = engines["tiny_sd15"]
+    c, uc = _conds(cfg, 2)
+    img = torch.rand(2, 3, 32, 32, generator=torch.Generator("cpu").manual_seed(78))
+    img = (img * 255).round() / 255
+    # the tiny VAE downsamples by 2: a 32 x 32 image has a 16 x 16 latent; the job calls that a 128 x 128 image
+    nmask = torch.zeros(1, 1, 16, 16)
+    nmask[..., 4:12, 3:9] = 1.0
+    seeds = [41, 42]
+
+    def job():
+        return processing.StableDiffusionProcessingImg2Img(sd_model=eng, c=c, uc=uc, seed=seeds[0], sampler_name="Euler", batch_size=2, steps=4, cfg_scale=7.0,
+                                                           width=128, height=128, init_images=img.clone(), denoising_strength=0.6, do_decode=False,
+                                                           latent_mask=nmask.clone(), inpainting_fill=fill,
+                                                           mask_noise_source=lambda step, like: torch.zeros_like(like))
+    torch.manual_seed(9)
+    p = job()
+    p.init(seeds)
+    filled = masking.fill_tensor(img, nmask)
+    assert torch.equal(p.init_images.cpu(), filled), "the image handed to the encoder is the filled one"
+    inside = torch.nn.functional.interpolate(nmask, size=(32, 32), mode="nearest").bool().expand_as(img)
+    assert not torch.equal(filled[inside], img[inside]) and torch.equal(filled[~inside], img[~inside])
+    torch.manual_seed(9)
+    enc = images_tensor_to_samples(filled, None, eng).float()
+    m = nmask.to(enc.device).expand_as(enc)
+    if fill == 0:
+        want = enc
+    elif fill == 2:
+        noise = rng.ImageRNG(tuple(enc.shape[1:]), seeds, device=enc.device).next().to(enc.device).float()
+        want = enc * (1 - m) + noise * m
+    else:
+        want = enc * (1 - m)
+    assert torch.equal(p.init_latent, want.contiguous())
+    # and the job runs: the unmasked region comes back as the (filled image's) latent exactly
+    torch.manual_seed(9)
+    res = processing.process_images(job())
+    keep = (1 - m).bool().cpu()
+    assert torch.equal(res.latents.cpu()[keep], want.cpu()[keep])
+    assert torch.isfinite(res.latents).all()
+
+
+def test_vae_regulation_hook_receives_the_posterior(engines):
+    """patcher/vae.py:166-178 `model_vae_regulation`: the hook gets the DiagonalGaussianDistribution of the encoder's moments and returns the latent (nn/vae.py:293-303);
+    `mode()` must be the mean half of encode_moments, a sampling hook must see mean / std / logvar consistent with the reference's clamp."""
+    eng = engines["tiny_sd15"]
+    vae = eng.forge_objects.vae
+    img = torch.rand(2, 32, 32, 3, generator=torch.Generator("cpu").manual_seed(79)).to(DEV)
+    seen = {}
+
+    def regulation(posterior):
+        seen["mean"], seen["logvar"], seen["std"] = posterior.mean, posterior.logvar, posterior.std
+        assert type(posterior).__name__ == "DiagonalGaussianDistribution"
+        return posterior.mode()
+    vae.patcher.model_options["model_vae_regulation"] = regulation
+    try:
+        z = vae.encode(img)
+    finally:
+        vae.patcher.model_options.pop("model_vae_regulation")
+    mo = vae.first_stage_model.encode_moments(2.0 * img.movedim(-1, 1) - 1.0)
+    lc = vae.latent_channels
+    assert torch.equal(z, mo[:, :lc].float())
+    assert torch.equal(seen["logvar"], mo[:, lc:].clamp(-30.0, 20.0)) and torch.allclose(seen["std"], torch.exp(0.5 * seen["logvar"]))
+
+
 def test_cfg_scale_one_shortcut(engines):
     g = load_golden("tiny_sd15_samples.pt")
     cfg = TINY["tiny_sd15"]
