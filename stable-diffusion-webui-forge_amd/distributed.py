@@ -73,6 +73,99 @@ def broadcast_conditioning(cond, uncond, device, src=0):
     return out[0], out[1]
 
 
+# ---- conditioning OBJECTS (round 5): what `p.c` / `p.uc` normally are in the reference -- a MulticondLearnedConditioning (AND parts with weights, each a
+#      prompt-editing schedule) and a list of per-image schedules (modules/prompt_parser.py:129-147, 233-242, 294-365) -- travel as a picklable skeleton plus
+#      the distinct tensors they hold; a tensor that many images share (the same prompt repeated over a batch: get_learned_conditioning caches per prompt
+#      text) is broadcast ONCE.  Tensors and dicts of tensors are the degenerate trees.
+def _tree_flatten(obj, tensors, seen):
+    from .modules.prompt_parser import ComposableScheduledPromptConditioning, DictWithShape, MulticondLearnedConditioning, ScheduledPromptConditioning
+    if obj is None or isinstance(obj, (bool, int, float)):
+        return ("v", obj)
+    if torch.is_tensor(obj):
+        if id(obj) not in seen:
+            seen[id(obj)] = len(tensors)
+            tensors.append(obj)
+        return ("t", seen[id(obj)])
+    if isinstance(obj, ScheduledPromptConditioning):
+        return ("sched", obj.end_at_step, _tree_flatten(obj.cond, tensors, seen))
+    if isinstance(obj, ComposableScheduledPromptConditioning):
+        return ("comp", _tree_flatten(obj.schedules, tensors, seen), float(obj.weight))
+    if isinstance(obj, MulticondLearnedConditioning):
+        return ("multi", tuple(obj.shape), _tree_flatten(obj.batch, tensors, seen))
+    if isinstance(obj, dict):
+        return ("dws" if isinstance(obj, DictWithShape) else "dict", {k: _tree_flatten(v, tensors, seen) for k, v in obj.items()})
+    if isinstance(obj, (list, tuple)):
+        return ("list" if isinstance(obj, list) else "tuple", [_tree_flatten(v, tensors, seen) for v in obj])
+    raise NotImplementedError(f"a {type(obj).__name__} inside a conditioning: the sharded entry broadcasts tensors, dicts of tensors and prompt-editing "
+                              f"schedules (ScheduledPromptConditioning / MulticondLearnedConditioning)")
+
+
+def _tree_build(node, tensors):
+    from .modules.prompt_parser import ComposableScheduledPromptConditioning, DictWithShape, MulticondLearnedConditioning, ScheduledPromptConditioning
+    kind = node[0]
+    if kind == "v":
+        return node[1]
+    if kind == "t":
+        return tensors[node[1]]
+    if kind == "sched":
+        return ScheduledPromptConditioning(node[1], _tree_build(node[2], tensors))
+    if kind == "comp":
+        return ComposableScheduledPromptConditioning(_tree_build(node[1], tensors), node[2])
+    if kind == "multi":
+        return MulticondLearnedConditioning(node[1], _tree_build(node[2], tensors))
+    if kind in ("dict", "dws"):
+        d = {k: _tree_build(v, tensors) for k, v in node[1].items()}
+        return DictWithShape(d) if kind == "dws" else d
+    seq = [_tree_build(v, tensors) for v in node[1]]
+    return seq if kind == "list" else tuple(seq)
+
+
+def flatten_tree(obj):
+    """-> (skeleton, [distinct tensors]) ; raises NotImplementedError for a leaf that is none of the conditioning types (before any collective)"""
+    tensors = []
+    return _tree_flatten(obj, tensors, {}), tensors
+
+
+def broadcast_tree(obj, device, src=0, flat=None):
+    """Rank `src` holds `obj` (any nesting of the conditioning types above, or None); every rank returns an equal object whose tensors live on
+    `device`.  flat: the owner's flatten_tree(obj), when it has already been taken (to validate before the first collective)."""
+    rank, ws = world()
+    if not group_active():
+        return obj
+    meta = [None]
+    tensors = []
+    if rank == src:
+        skel, tensors = flat if flat is not None else flatten_tree(obj)
+        meta = [(skel, [(list(t.shape), t.dtype) for t in tensors])]
+    dist.broadcast_object_list(meta, src=src)
+    skel, descr = meta[0]
+    if rank == src:
+        tensors = [t.to(device).contiguous() for t in tensors]
+    else:
+        tensors = [torch.empty(shape, dtype=dtype, device=device) for shape, dtype in descr]
+    for t in tensors:
+        if t.numel():
+            dist.broadcast(t, src=src)
+    return _tree_build(skel, tensors)
+
+
+def take_images(cond, indices, device=None):
+    """The per-image entries `indices` (global image numbers) of a conditioning for a whole job: rows of a tensor / of every tensor of a dict, the
+    listed images' schedules of a schedule list or a MulticondLearnedConditioning."""
+    from .modules.prompt_parser import MulticondLearnedConditioning
+    if cond is None:
+        return None
+    if torch.is_tensor(cond):
+        return cond.index_select(0, torch.as_tensor(indices, dtype=torch.long, device=cond.device)).contiguous()
+    if isinstance(cond, dict):
+        return type(cond)({k: take_images(v, indices) for k, v in cond.items()})
+    if isinstance(cond, MulticondLearnedConditioning):
+        return MulticondLearnedConditioning((len(indices),), [cond.batch[i] for i in indices])
+    if isinstance(cond, (list, tuple)):
+        return [cond[i] for i in indices]
+    raise NotImplementedError(type(cond).__name__)
+
+
 def slice_conditioning(cond, lo, hi):
     if cond is None:
         return None

@@ -353,13 +353,37 @@ def _to_u8(images, device):
     return torch.from_numpy(np.stack(images)).to(device)
 
 
+_I2I_FIELDS = ("init_images", "init_latent", "latent_mask", "image_mask")
+
+
+def _check_per_image(name, cnd, total):
+    from .prompt_parser import MulticondLearnedConditioning
+    if cnd is None:
+        return
+    if torch.is_tensor(cnd):
+        n = cnd.shape[0]
+    elif isinstance(cnd, dict):
+        n = next(iter(cnd.values())).shape[0]
+    elif isinstance(cnd, MulticondLearnedConditioning):
+        n = len(cnd.batch)
+    else:
+        n = len(cnd)
+        if any(isinstance(e, str) for e in cnd):
+            raise NotImplementedError(f"p.{name} holds strings: the sharded entry broadcasts ENCODED conditionings (tensors, dicts, prompt-editing schedules); "
+                                      f"hand prompts over as p.prompt and they are encoded on the owner")
+    if n != total:
+        raise ValueError(f"p.{name} describes {n} images, the job has {total}")
+
+
 def process_images_sharded(p, gather_images=True, dst=0) -> Processed:
     """`process_images` for a job whose images are spread over the ranks of the default process group (one process per GPU; backend "nccl" =
     RCCL over xGMI, "gloo" in the CPU tests).  It splits the reference's batch loop (modules/processing.py:924-1012) ACROSS ranks instead of
     walking it on one device: images are independent, so
 
-      1. rank `dst` owns the job: its conditioning (p.c / p.uc for all batch_size * n_iter images: tensors or {"crossattn", "vector"} dicts) and
-         its seed are broadcast -- the other ranks call this function with the same scalar parameters and c = uc = None;
+      1. rank `dst` owns the job: its conditioning (p.c / p.uc for all batch_size * n_iter images: tensors, {"crossattn", "vector"} dicts, or the
+         reference's schedule objects -- a MulticondLearnedConditioning / per-image ScheduledPromptConditioning lists, i.e. prompt editing and
+         AND-composition, modules/prompt_parser.py:294-365; a tensor shared by several images travels once), for an img2img job its init images /
+         init latents / masks, and its seed are broadcast -- the other ranks call this function with the same scalar parameters and those fields None;
       2. of every iteration's `batch_size` images rank r samples (and decodes) the contiguous share `shard_range(batch_size, r, world)` with the
          seeds / subseeds the single-process job gives those images (seed + global index), so the result does not depend on the sharding;
       3. latents (fp32) and, with `gather_images`, the decoded uint8 images are gathered on rank `dst` in global order (`dist.gather` of equal,
@@ -379,40 +403,53 @@ def process_images_sharded(p, gather_images=True, dst=0) -> Processed:
     #      argument checks) runs inside the try: the header then carries the error and EVERY rank raises it -- an owner that raised on its own
     #      would leave the other ranks blocked in the broadcast for ever. --------------------------------------------------------------------------
     header = [None]
+    is_i2i = isinstance(p, StableDiffusionProcessingImg2Img)
+    flats = {}
     if rank == dst:
         try:
-            if isinstance(p, StableDiffusionProcessingImg2Img):
-                raise NotImplementedError("process_images_sharded splits txt2img jobs; shard an img2img job by its init images on the caller's side")
             if p.prompt is not None and p.c is None:
                 p.setup_conds()      # prompts are encoded once, on the rank that owns the job
-            for name, cnd in (("c", p.c), ("uc", p.uc), ("hr_c", p.hr_c), ("hr_uc", p.hr_uc)):
-                if cnd is not None and not isinstance(cnd, (torch.Tensor, dict)):
-                    raise NotImplementedError(f"p.{name} is a {type(cnd).__name__}: the sharded entry broadcasts ready conditioning tensors "
-                                              f"(prompt-editing schedules are host objects; reconstruct them per rank or pass tensors)")
-            header = [("ok", _job_seeds(p, total), type(p.c).__name__ if p.c is not None else None)]
+            # what travels: the conditionings -- tensors, {"crossattn", "vector"} dicts, or the reference's schedule objects (a MulticondLearnedConditioning
+            # / per-image ScheduledPromptConditioning lists: prompt editing, AND-composition) -- and, for img2img, the per-image inputs of the job.
+            # Flattened HERE so that a leaf the entry cannot broadcast is refused before the first collective.
+            for name in ("c", "uc", "hr_c", "hr_uc"):
+                try:
+                    flats[name] = fdist.flatten_tree(getattr(p, name, None))
+                except NotImplementedError as e:
+                    raise NotImplementedError(f"p.{name}: {e}") from None
+                _check_per_image(name, getattr(p, name, None), total)
+            if is_i2i:
+                if p.init_images is None and p.init_latent is None:
+                    raise ValueError("img2img needs init_images or init_latent")
+                for name in _I2I_FIELDS:
+                    flats[name] = fdist.flatten_tree(getattr(p, name, None))
+            header = [("ok", _job_seeds(p, total))]
         except Exception as e:   # noqa: BLE001 -- re-raised on every rank below
             header = [("error", type(e).__name__, str(e))]
     dist.broadcast_object_list(header, src=dst)
     if header[0][0] == "error":
         _, ename, emsg = header[0]
         raise (NotImplementedError if ename == "NotImplementedError" else RuntimeError)(f"process_images_sharded, owner rank {dst}: {ename}: {emsg}")
-    _, (all_seeds, all_subseeds), c_kind = header[0]
-    c, uc = fdist.broadcast_conditioning(p.c if rank == dst else None, p.uc if rank == dst else None, dev, src=dst)
-    hr_c, hr_uc = fdist.broadcast_conditioning(p.hr_c if rank == dst else None, p.hr_uc if rank == dst else None, dev, src=dst)
+    _, (all_seeds, all_subseeds) = header[0]
+    got = {name: fdist.broadcast_tree(getattr(p, name, None) if rank == dst else None, dev, src=dst, flat=flats.get(name))
+           for name in (("c", "uc", "hr_c", "hr_uc") + (_I2I_FIELDS if is_i2i else ()))}
+    c, uc, hr_c, hr_uc = got["c"], got["uc"], got["hr_c"], got["hr_uc"]
     lo, hi = fdist.shard_range(B, rank, ws)
     mine = [n * B + i for n in range(p.n_iter) for i in range(lo, hi)]          # global indices of this rank's images, iteration-major
 
     def take(cnd):
-        if cnd is None:
-            return None
-        idx = torch.as_tensor(mine, dtype=torch.long, device=dev)
-        if isinstance(cnd, dict):
-            out = {k: v.index_select(0, idx.to(v.device)).contiguous() for k, v in cnd.items()}
-            if c_kind == "DictWithShape":
-                from .prompt_parser import DictWithShape
-                return DictWithShape(out)
-            return out
-        return cnd.index_select(0, idx.to(cnd.device)).contiguous()
+        return fdist.take_images(cnd, mine)
+
+    def take_i2i(t):
+        """a per-image input of an img2img job: one row per image of the job, one per image of an iteration (the same images every iteration), or one
+        shared row"""
+        if t is None or t.shape[0] == 1:
+            return t
+        if t.shape[0] == total:
+            return take(t)
+        if t.shape[0] == B:
+            return t[lo:hi].contiguous()
+        raise ValueError(f"an img2img input with {t.shape[0]} rows in a job of {p.n_iter} x {B} images")
 
     # ---- 2. this rank's share through the ordinary single-device job.  A rank whose job fails (out of memory, a kernel error) still takes part in
     #      the next collective and reports the failure there, so that every rank raises instead of the healthy ones waiting for ever ----------------
@@ -427,6 +464,9 @@ def process_images_sharded(p, gather_images=True, dst=0) -> Processed:
             q.batch_size = hi - lo
             q.c, q.uc, q.hr_c, q.hr_uc = take(c), take(uc), take(hr_c), take(hr_uc)
             q.prompt = None
+            if is_i2i:   # this rank's init images / latents / masks: an img2img job is sharded by init image like a txt2img job by noise seed
+                for name in _I2I_FIELDS:
+                    setattr(q, name, take_i2i(got[name]))
             shared.sd_model = p.sd_model
             local = process_images_inner(q, seed_plan=([all_seeds[i] for i in mine], [all_subseeds[i] for i in mine]))
             p.sampler, p.rng = q.sampler, q.rng

@@ -179,3 +179,120 @@ def test_a_failure_on_one_rank_raises_on_every_rank_instead_of_hanging(mode):
         kind, msg = got[r]
         assert kind in ("NotImplementedError", "RuntimeError"), got
         assert ("prompt-editing" in msg) if mode == "owner" else ("simulated out-of-memory" in msg and "rank 1" in msg), got
+
+
+# ---- round 5: the conditionings the reference normally has (schedule objects), and img2img jobs sharded by init image ---------------------------------
+def _make_schedule_job(batch, n_iter, give_conds=True):
+    """p.c = MulticondLearnedConditioning (two AND parts with weights, the first a prompt-editing schedule that switches at step 2; some images share ONE
+    tensor object, as a repeated prompt does), p.uc = per-image schedule lists -- what modules/prompt_parser.py:294-365 builds from prompt strings"""
+    import forge_amd  # noqa: F401
+    from forge_amd.modules import processing, prompt_parser as pp, shared
+    base = _make_job(batch, n_iter, False)
+    total = batch * n_iter
+    g = torch.Generator().manual_seed(23)
+    shared_t = torch.randn(77, 8, generator=g).half()
+
+    class _Job(type(base)):
+        def sample(self, conditioning, unconditional_conditioning, seeds, subseeds=None, subseed_strength=0.0, prompts=None):
+            x = self.rng.next()
+            acc = torch.zeros(len(seeds), 1, 1, 1)
+            for step in (0, 2, 3):                         # the schedule is read per step, as CFGDenoiser does (sd_samplers_cfg_denoiser.py:156-170)
+                conds_list, tensor = pp.reconstruct_multicond_batch(conditioning, step)
+                un = pp.reconstruct_cond_batch(unconditional_conditioning, step)
+                for i, parts in enumerate(conds_list):
+                    for idx, w in parts:
+                        acc[i] += w * tensor[idx].float().mean() * (step + 1)
+                acc -= 0.25 * un.float().std(dim=(1, 2)).view(-1, 1, 1, 1)
+            return torch.tanh(x * 0.7 + acc) + 0.01 * torch.tensor([float(v % 97) for v in seeds]).view(-1, 1, 1, 1)
+
+    def sched(i):
+        a = shared_t if i % 2 == 0 else torch.randn(77, 8, generator=g).half()
+        b = torch.randn(77, 8, generator=g).half()
+        return [pp.ScheduledPromptConditioning(2, a), pp.ScheduledPromptConditioning(4, b)]
+    c = pp.MulticondLearnedConditioning((total,), [[pp.ComposableScheduledPromptConditioning(sched(i), 1.0),
+                                                      pp.ComposableScheduledPromptConditioning([pp.ScheduledPromptConditioning(4, torch.randn(77, 8, generator=g).half())], 0.5 + 0.1 * i)]
+                                                     for i in range(total)])
+    uc = [[pp.ScheduledPromptConditioning(4, shared_t)] for _ in range(total)]
+    p = _Job(sd_model=base.sd_model, c=c if give_conds else None, uc=uc if give_conds else None, seed=4242, batch_size=batch, n_iter=n_iter, steps=4, cfg_scale=7.0,
+             width=32, height=24)
+    return p
+
+
+def _make_img2img_job(batch, n_iter, give=True):
+    import forge_amd  # noqa: F401
+    from forge_amd.modules import processing
+    base = _make_job(batch, n_iter, False)
+    total = batch * n_iter
+    g = torch.Generator().manual_seed(31)
+
+    class _Job(processing.StableDiffusionProcessingImg2Img):
+        def sample(self, conditioning, unconditional_conditioning, seeds, subseeds=None, subseed_strength=0.0, prompts=None):
+            x = self.rng.next()
+            lo = self.iteration * self.batch_size
+            init = self.init_latent[lo:lo + self.batch_size] if self.init_latent.shape[0] > self.batch_size else self.init_latent
+            out = torch.tanh(0.5 * init + 0.3 * x + conditioning.float().mean(dim=(1, 2)).view(-1, 1, 1, 1))
+            if self.mask is not None:
+                m = self.mask[lo:lo + self.batch_size] if self.mask.shape[0] > self.batch_size else self.mask
+                out = out * (1 - m) + init * m
+            return out
+    nmask = torch.zeros(1, 1, 3, 4)
+    nmask[..., 1:, :2] = 1.0
+    return _Job(sd_model=base.sd_model, c=base.c if give else None, uc=base.uc if give else None, seed=4242, batch_size=batch, n_iter=n_iter, steps=4, cfg_scale=7.0,
+                width=32, height=24, init_latent=torch.randn(total, 4, 3, 4, generator=g) if give else None, latent_mask=nmask if give else None,
+                denoising_strength=0.6, inpainting_fill=3)
+
+
+def _worker2(rank, world, port, kind, batch, n_iter, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from forge_amd.modules import processing
+        make = _make_schedule_job if kind == "schedules" else _make_img2img_job
+        res = processing.process_images_sharded(make(batch, n_iter, rank == 0))          # only the owner holds conditionings / init latents / masks
+        q.put((rank, res.latents.cpu().numpy().copy() if rank == 0 else int(res.latents.shape[0]), list(res.seeds)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,world,batch,n_iter", [("schedules", 2, 5, 1), ("schedules", 3, 4, 2), ("img2img", 2, 5, 1), ("img2img", 3, 4, 2)])
+def test_sharded_prompt_editing_and_img2img_jobs_equal_the_single_process_job(kind, world, batch, n_iter):
+    """`p.c` as the reference has it (MulticondLearnedConditioning with AND parts and a prompt-editing schedule, schedule lists for the
+    negative prompt; tensors shared between images travel once) and an img2img job (per-image init latents, a shared latent mask, 'latent nothing' fill)
+    split over 2 and 3 ranks: latents bit for bit those of the single-process job."""
+    from forge_amd.modules import processing
+    make = _make_schedule_job if kind == "schedules" else _make_img2img_job
+    want = processing.process_images(make(batch, n_iter))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker2, args=(r, world, port, kind, batch, n_iter, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = {}
+    for _ in procs:
+        r = q.get(timeout=180)
+        res[r[0]] = r[1:]
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    lat = torch.from_numpy(res[0][0])
+    assert res[0][1] == want.seeds
+    assert lat.shape == want.latents.shape and torch.equal(lat, want.latents)
+    rows = want.latents.reshape(want.latents.shape[0], -1)
+    assert len({tuple(r.tolist()) for r in rows}) == rows.shape[0], "every image of the job is its own"
+
+
+def test_shared_tensors_of_a_schedule_travel_once():
+    from forge_amd import distributed as fdist
+    p = _make_schedule_job(6, 1)
+    skel, tensors = fdist.flatten_tree(p.uc)
+    assert len(tensors) == 1                                   # six images, one negative-prompt tensor
+    skel, tensors = fdist.flatten_tree(p.c)
+    assert len(tensors) == 1 + 3 + 6 + 6                       # the shared first segment, three own ones, six second segments, six AND parts
+    sub = fdist.take_images(p.c, [4, 1])
+    assert sub.shape == (2,) and sub.batch[0] is p.c.batch[4] and sub.batch[1] is p.c.batch[1]
