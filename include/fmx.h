@@ -17,6 +17,7 @@
  *   fmx_softmax_rows_f16   sim.softmax(dim=-1) backend/attention.py:85 (materialised-score variant: single heads wider than 160 other than 512)
  *   fmx_groupnorm_*        F.group_norm backend/operations.py:308 (+ SiLU backend/nn/unet.py:394-398)
  *   fmx_layernorm_f16      F.layer_norm backend/operations.py:327
+ *   fmx_rmsnorm_f16        T5LayerNorm backend/nn/t5.py:15-25 (the T5-XXL text encoder of Flux, backend/diffusion_engine/flux.py:87-88)
  *   fmx_timestep_embedding timestep_embedding backend/nn/unet.py:55-67 (and backend/nn/flux.py:52-73 with t*1000)
  *   fmx_layernorm_mod_f16  LayerNorm(no affine) + adaLN modulate backend/nn/flux.py:209-210,228-229,255,260,286,326
  *   fmx_flux_qk_norm_rope_f16  QKNorm (RMSNorm) + apply_rope + [B,H,L,D] permute backend/nn/flux.py:43-49,115-139,217-247
@@ -52,7 +53,7 @@
 extern "C" {
 #endif
 
-#define FMX_ABI_VERSION 8
+#define FMX_ABI_VERSION 9
 
 #define FMX_OK 0
 #define FMX_E_BADARG 10001   /* shape / alignment / null-pointer contract violated */
@@ -235,6 +236,10 @@ int fmx_gemm_conv_stats_f16(const fmx_gemm_args* args /* host */, float* partial
 int fmx_layernorm_f16(const void* x, const void* gamma, const void* beta, void* y, int64_t rows, int32_t c,
                       float eps, void* stream);
 
+/* RMS LayerNorm (ABI 9; T5LayerNorm, backend/nn/t5.py:15-25): y = x * rsqrt(mean(x^2) + eps) * weight over the last dim of fp16 [rows][c]
+ * (c % 8 == 0, c <= 4096), fp32 sum of squares. */
+int fmx_rmsnorm_f16(const void* x, const void* weight, void* y, int64_t rows, int32_t c, float eps, void* stream);
+
 /* Same, with the output rows of every image re-spaced: input row i of image b (b = r / rows_per_image) goes to output row
  * b * out_rows_per_image + i.  Used when the token count per image is not a multiple of the attention key tile (64): the rows in between
  * stay whatever the caller left there (zeros), so ONE batched Q|K / V^T projection serves all images. */
@@ -372,6 +377,7 @@ int fmx_gemm_conv_bf16(const fmx_gemm_args* args /* host */, void* stream);
 int fmx_attention_bf16(const fmx_attn_args* args /* host */, void* stream);
 int fmx_softmax_rows_bf16(void* x, int64_t nrows, int32_t ncols, int64_t ld, void* stream);
 int fmx_layernorm_bf16(const void* x, const void* gamma, const void* beta, void* y, int64_t rows, int32_t c, float eps, void* stream);
+int fmx_rmsnorm_bf16(const void* x, const void* weight, void* y, int64_t rows, int32_t c, float eps, void* stream);
 int fmx_layernorm_padded_bf16(const void* x, const void* gamma, const void* beta, void* y, int64_t rows, int32_t c, float eps,
                               int64_t rows_per_image, int64_t out_rows_per_image, void* stream);
 int fmx_layernorm_mod_bf16(const void* x, const void* scale, const void* shift, int64_t ld_mod, int64_t rows_per_batch, void* y,

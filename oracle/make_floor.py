@@ -616,6 +616,25 @@ def floors_aux():
     update(out)
 
 
+def floors_t5():
+    """The T5 text encoder of Flux (backend/nn/t5.py) in fp16 and in bfloat16 against its own fp32 run (tests/golden/tiny_t5.pt)."""
+    import importlib
+    import transformers.activations  # noqa: F401 -- before the reference's import stubs
+    ref_import.load_reference()
+    t5 = importlib.import_module("backend.nn.t5")
+    cfg = synth.TINY_T5_CONFIG
+    g = _load("tiny_t5.pt")
+    out = {}
+    for tag, dt in (("f16", torch.float16), ("bf16", torch.bfloat16)):
+        m = t5.IntegratedT5(cfg).eval()
+        m.load_state_dict(synth.synth_t5_state_dict(cfg), strict=True)
+        m = m.to(dt)
+        with torch.no_grad():
+            z = m.transformer(input_ids=g["ids"])
+        out[f"tiny_t5.pt:z@{tag}"] = metrics(z.float(), g["z"])
+    update(out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -630,6 +649,8 @@ def main():
         floors_schedulers()
     if a.only in ("", "aux"):
         floors_aux()
+    if a.only in ("", "t5"):
+        floors_t5()
     if a.only in ("", "sd15"):
         floors_sd15_full()
     if a.only == "config2":

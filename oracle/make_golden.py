@@ -131,6 +131,33 @@ def gen_clip(name, cfg):
     print(name, tuple(out.last_hidden_state.shape), float(out.last_hidden_state.std()))
 
 
+def t5_test_tokens(cfg, b=2, t=256, seed=3):
+    """token ids shaped like T5TextProcessingEngine's chunks: words, EOS = 1, padding 0 up to min_length 256 (t5_engine.py:74-92)"""
+    g = torch.Generator("cpu").manual_seed(seed)
+    ids = torch.randint(2, cfg["vocab_size"], (b, t), generator=g)
+    for i, n in enumerate((12, 200)[:b]):
+        ids[i, n] = 1
+        ids[i, n + 1:] = 0
+    return ids
+
+
+def gen_t5(name="tiny_t5", cfg=None):
+    """the REAL reference class (backend/nn/t5.py IntegratedT5) on the synthetic weights: the encoder output the T5 text-processing engine feeds Flux"""
+    import importlib
+    import transformers.activations  # noqa: F401 -- before the reference's import stubs (a spec-less torchvision) are installed: t5.py imports NewGELUActivation
+    ref_import.load_reference()
+    t5 = importlib.import_module("backend.nn.t5")
+    cfg = cfg or synth.TINY_T5_CONFIG
+    sd = synth.synth_t5_state_dict(cfg)
+    m = t5.IntegratedT5(cfg).eval()
+    m.load_state_dict(sd, strict=True)
+    ids = t5_test_tokens(cfg)
+    with torch.no_grad():
+        z = m.transformer(input_ids=ids)
+    torch.save({"ids": ids, "z": z}, os.path.join(GOLD, f"{name}.pt"))
+    print(name, tuple(z.shape), float(z.std()))
+
+
 def gen_vae(name, cfg, b=2, hw=8):
     sd = synth.synth_vae_decoder_state_dict(cfg, seed=1)
     vae = ref_import.build_ref_vae(cfg)
@@ -1388,6 +1415,67 @@ class FakeEmbeddingDb:
         return None, None
 
 
+T5_PROMPTS = ["a photo of a cat", "a (very:1.3) detailed [painting] of a fox, BREAK with (((emphasis))) and a second chunk", "",
+              "plain text with , commas , and . punctuation " * 12]
+
+
+class ReplayT5Tokenizer:
+    """T5TokenizerFast stand-in from a recorded {text: ids} table; get_vocab() carries the recorded bracket tokens (t5_engine.py:36-53)"""
+
+    def __init__(self, rec):
+        self.table, self.vocab = rec["table"], rec["vocab"]
+
+    def get_vocab(self):
+        return dict(self.vocab)
+
+    def __call__(self, texts, truncation=False, add_special_tokens=False):
+        return {"input_ids": [list(self.table[t]) for t in texts]}
+
+
+def gen_t5_tokenize():
+    """The reference's T5TextProcessingEngine.tokenize_line (backend/text_processing/t5_engine.py:68-112) with the REAL T5 tokenizer
+    (backend/huggingface/black-forest-labs/FLUX.1-dev/tokenizer_2); every tokenizer call is recorded for replay."""
+    import importlib
+    import types
+    from transformers import T5TokenizerFast  # before the reference's stub modules are installed
+    tok = T5TokenizerFast.from_pretrained(os.path.join(ref_import.REFERENCE_ROOT, "backend", "huggingface", "black-forest-labs", "FLUX.1-dev", "tokenizer_2"))
+    ref_import.load_reference()
+    saved = {k: sys.modules.get(k) for k in ("modules", "modules.shared")}
+    try:
+        for n in ("modules", "modules.shared"):
+            sys.modules[n] = types.ModuleType(n)
+        sys.modules["modules"].__path__ = []
+        sys.modules["modules"].shared = sys.modules["modules.shared"]
+        sys.modules["modules.shared"].opts = SimpleNamespace(emphasis="Original")
+        te = importlib.import_module("backend.text_processing.t5_engine")
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    table = {}
+
+    class Recording:
+        def get_vocab(self):
+            return tok.get_vocab()
+
+        def __call__(self, texts, truncation=False, add_special_tokens=False):
+            out = tok(texts, truncation=truncation, add_special_tokens=add_special_tokens)
+            for t, ids in zip(texts, out["input_ids"]):
+                table[t] = list(ids)
+            return out
+    eng = te.T5TextProcessingEngine(SimpleNamespace(transformer=None), Recording())
+    lines = []
+    for prompt in T5_PROMPTS:
+        chunks, count = eng.tokenize_line(prompt)
+        lines.append({"count": count, "chunks": [{"tokens": list(c.tokens), "multipliers": list(c.multipliers)} for c in chunks]})
+    vocab = {k: v for k, v in tok.get_vocab().items() if any(ch in k for ch in "()[]") or k == ",</w>"}
+    res = {"prompts": T5_PROMPTS, "lines": lines, "tokenizer": {"table": table, "vocab": vocab}, "token_mults": dict(eng.token_mults), "comma_token": eng.comma_token}
+    torch.save(res, os.path.join(GOLD, "tokenize_t5.pt"))
+    print("tokenize_t5", [(l["count"], len(l["chunks"])) for l in lines], len(vocab))
+
+
 def gen_tokenize():
     """The reference's parse_prompt_attention / ClassicTextProcessingEngine.tokenize_line / get_multicond_prompt_list on a prompt set, with the
     real CLIP tokenizer (backend/huggingface/runwayml/stable-diffusion-v1-5/tokenizer); every tokenizer call is recorded for replay."""
@@ -1718,6 +1806,10 @@ def main():
     if a.only in ("", "samplers"):
         gen_samplers_toy()
         gen_schedulers()
+    if a.only in ("", "t5"):
+        gen_t5()
+    if a.only in ("", "t5tok"):
+        gen_t5_tokenize()
     if a.only in ("", "clip"):
         gen_clip("tiny_clip_l", synth.TINY_CLIP_L_CONFIG)
         gen_clip("tiny_clip_g", synth.TINY_CLIP_G_CONFIG)

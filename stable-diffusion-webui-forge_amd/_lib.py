@@ -92,6 +92,7 @@ SIGNATURES = {
     "fmx_gemm_conv_stats_f16": [C.POINTER(GemmArgs), _vp, _i32, _i32, C.POINTER(C.c_int32), _vp],
     "fmx_layernorm_f16": [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp],
     "fmx_layernorm_padded_f16": [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _i64, _i64, _vp],
+    "fmx_rmsnorm_f16": [_vp, _vp, _vp, _i64, _i32, _f32, _vp],
     "fmx_layernorm_mod_f16": [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i32, _f32, _vp],
     "fmx_flux_qk_norm_rope_f16": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
     "fmx_timestep_embedding": [_vp, _vp, _i32, _i32, _f32, _vp],
@@ -131,7 +132,7 @@ SIGNATURES = {
 
 
 # bfloat16 build of the Flux path's kernels: same signatures as the _f16 entries (include/fmx.h, last section)
-for _n in ("fmx_gemm_conv", "fmx_attention", "fmx_softmax_rows", "fmx_layernorm", "fmx_layernorm_padded",
+for _n in ("fmx_gemm_conv", "fmx_attention", "fmx_softmax_rows", "fmx_layernorm", "fmx_layernorm_padded", "fmx_rmsnorm",
            "fmx_layernorm_mod", "fmx_flux_qk_norm_rope", "fmx_silu"):
     SIGNATURES[_n + "_bf16"] = SIGNATURES[_n + "_f16"]
 SIGNATURES["fmx_timestep_embedding_bf16"] = SIGNATURES["fmx_timestep_embedding"]
@@ -220,7 +221,7 @@ def lib():
             handle.fmx_build_info.restype = C.c_char_p
         except AttributeError as e:
             raise FmxError(f"symbol fmx_build_info missing from {LIB_PATH}") from e
-        if handle.fmx_abi_version() != 8:
+        if handle.fmx_abi_version() != 9:
             raise FmxError("libfmx ABI version mismatch")
         _lib = handle
     return _lib

@@ -153,6 +153,39 @@ class FluxEngine:
     decode_first_stage = ForgeDiffusionEngine.decode_first_stage   # flux.py:113-117: same process_out -> decode -> [-1, 1] as sd15.py:80-84
     encode_first_stage = ForgeDiffusionEngine.encode_first_stage
 
+    # ---- text conditioning (flux.py:52-73, :84-100): CLIP-L pooled vector + T5-XXL sequence --------------------------------------------------
+    def attach_text_encoders(self, clip_l, t5xxl, tokenizer_l=None, tokenizer_t5=None, embeddings_l=None, emphasis_name="Original"):
+        """clip_l: forge_amd.backend.nn.clip.IntegratedCLIP, t5xxl: forge_amd.backend.nn.t5.IntegratedT5; the tokenizers are the user's install's
+        (CLIPTokenizer / T5TokenizerFast objects: their vocabularies are data files).  Options as flux.py:52-73 constructs the two engines."""
+        from ..text_processing.classic_engine import ClassicTextProcessingEngine
+        from ..text_processing.t5_engine import T5TextProcessingEngine
+        self.text_processing_engine_l = ClassicTextProcessingEngine(clip_l, embedding_key="clip_l", text_projection=False, minimal_clip_skip=1, clip_skip=1,
+                                                                    return_pooled=True, final_layer_norm=True, emphasis_name=emphasis_name,
+                                                                    tokenizer=tokenizer_l, embeddings=embeddings_l)
+        self.text_processing_engine_t5 = T5TextProcessingEngine(t5xxl, tokenizer_t5, emphasis_name=emphasis_name)
+
+    def set_clip_skip(self, clip_skip):
+        self.text_processing_engine_l.clip_skip = clip_skip          # flux.py:80-81
+
+    @torch.inference_mode()
+    def get_learned_conditioning(self, prompt):
+        """flux.py:84-100: prompt strings (an SdConditioning or a list) -> {'crossattn': T5 [B, 256 n, 4096], 'vector': CLIP-L pooled [B, 768],
+        'guidance': [B]} (the distilled guidance scale rides along only for the guidance-distilled model; schnell ignores it)."""
+        if not hasattr(self, "text_processing_engine_t5"):
+            raise RuntimeError("no text encoders attached: attach_text_encoders() or pass conditioning tensors to the processing object")
+        from ...modules.prompt_parser import DictWithShape
+        texts = list(prompt)
+        cond_l = self.text_processing_engine_l.encode_texts(texts)
+        cond = dict(crossattn=self.text_processing_engine_t5(texts), vector=cond_l.pooled)
+        if self.use_distilled_cfg_scale:
+            scale = getattr(prompt, "distilled_cfg_scale", 3.5) or 3.5
+            cond["guidance"] = torch.FloatTensor([scale] * len(texts)).to(self.device)
+        return DictWithShape(cond)
+
+    def get_prompt_lengths_on_ui(self, prompt):
+        n = len(self.text_processing_engine_t5.tokenize([prompt])[0])   # flux.py:102-105
+        return n, max(255, n)
+
 
 def build_flux_engine(flux_config, state_dict, device="cuda", vae_config=None, vae_state_dict=None, dtype=torch.float16, seq_len=4096, schnell=None,
                       vae_dtype=torch.float16):

@@ -248,7 +248,8 @@ class KModel:
 
 class KModelFlux:
     """`KModel` over the Flux executor (k_model.py:25-46 with prediction_type 'const': input = x, timestep = sigma, denoised =
-    x - out * sigma).  Flux-dev is guidance-distilled: cond_scale == 1, no uncond batch (diffusion_engine/flux.py:88-93)."""
+    x - out * sigma).  Flux-dev is guidance-distilled: normally cond_scale == 1 and no uncond batch (diffusion_engine/flux.py:88-93); with a negative
+    prompt and cond_scale != 1 the uncond batch is a second model call (denoise_cfg)."""
 
     def __init__(self, model, predictor):
         self.diffusion_model = model
@@ -276,8 +277,14 @@ class KModelFlux:
         to = transformer_options or {}
         if control_model is not None or to.get("patches") or to.get("patches_replace") or to.get("block_modifiers"):
             raise NotImplementedError("ControlNet / per-block hooks are built for the LDM UNet executor, not for the Flux transformer")
-        if uncond_ctx is not None:
-            raise NotImplementedError("Flux-dev runs at cfg scale 1 with distilled guidance (one model call per step)")
         ctx, y, guidance = cond_ctx
         den = self.apply_model(x, sigma, c_crossattn=ctx, y=y, guidance=guidance)
-        return (den, den, None) if want_parts else den
+        if uncond_ctx is None:          # cfg scale 1 (the guidance-distilled default, diffusion_engine/flux.py:88-93): one model call per step
+            return (den, den, None) if want_parts else den
+        # a negative prompt with cond_scale != 1: the reference's generic path (sampling_function.py:154-288, :292-312) runs the uncond batch through
+        # the model as well and combines  uncond + (cond - uncond) * scale.  Two model calls (the batch a Flux transformer is tuned for is the job's own;
+        # the uncond context may also differ in token count), one fused pass for the combination.
+        uctx, uy, ug = uncond_ctx
+        den_u = self.apply_model(x, sigma, c_crossattn=uctx, y=uy, guidance=ug if ug is not None else guidance)
+        out = ops.lincomb3(den_u, den, None, 1.0 - float(cond_scale), float(cond_scale), 0.0)
+        return (out, den, den_u) if want_parts else out

@@ -425,6 +425,32 @@ def clip_param_shapes(cfg):
     return s
 
 
+def t5_param_shapes(cfg):
+    """State-dict keys / shapes of IntegratedT5 (backend/nn/t5.py:196-214) for a config with the reference's keys: d_model, d_ff, num_layers, num_heads,
+    vocab_size, dense_act_fn, is_gated_act, model_type.  The reference builds the attention at inner_dim = d_model (:186); the relative-position bias
+    table (32 buckets x heads) sits in block 0 only unless model_type == 'umt5' (:179-181)."""
+    c, f, H = cfg["d_model"], cfg["d_ff"], cfg["num_heads"]
+    s = OrderedDict()
+    s["transformer.shared.weight"] = (cfg["vocab_size"], c)
+    for i in range(cfg["num_layers"]):
+        b = f"transformer.encoder.block.{i}.layer."
+        for n in ("q", "k", "v", "o"):
+            s[b + f"0.SelfAttention.{n}.weight"] = (c, c)
+        if i == 0 or cfg.get("model_type") == "umt5":
+            s[b + "0.SelfAttention.relative_attention_bias.weight"] = (32, H)
+        s[b + "0.layer_norm.weight"] = (c,)
+        if cfg.get("is_gated_act", True):
+            s[b + "1.DenseReluDense.wi_0.weight"] = (f, c)
+            s[b + "1.DenseReluDense.wi_1.weight"] = (f, c)
+        else:
+            s[b + "1.DenseReluDense.wi.weight"] = (f, c)
+        s[b + "1.DenseReluDense.wo.weight"] = (c, f)
+        s[b + "1.layer_norm.weight"] = (c,)
+    s["transformer.encoder.final_layer_norm.weight"] = (c,)
+    s["logit_scale"] = ()
+    return s
+
+
 # ---- Flux (MMDiT) ---------------------------------------------------------------------------------------------------
 def flux_param_shapes(cfg):
     """State-dict keys / shapes of IntegratedFluxTransformer2DModel (backend/nn/flux.py:310-367) for a config dict with the

@@ -8,6 +8,7 @@
 #define fmx_layernorm_f16 fmx_layernorm_bf16
 #define fmx_layernorm_padded_f16 fmx_layernorm_padded_bf16
 #define fmx_layernorm_mod_f16 fmx_layernorm_mod_bf16
+#define fmx_rmsnorm_f16 fmx_rmsnorm_bf16
 #define fmx_flux_qk_norm_rope_f16 fmx_flux_qk_norm_rope_bf16
 // the VAE in bfloat16 (the reference's VAE type on bf16-capable parts, backend/memory_management.py:190-205, :840-855): GroupNorm, the GEMM
 // with output statistics, the 512-wide single-head attention

@@ -434,6 +434,58 @@ extern "C" int fmx_groupnorm_apply_f16(const void* x0, const void* x1, int32_t c
 }
 
 
+// ---- RMS LayerNorm (T5LayerNorm, backend/nn/t5.py:15-25): y = x * rsqrt(mean(x^2) + eps) * weight -- no mean subtraction, no bias.  One wave per
+//      row, the row kept in registers, fp32 sum of squares (the reference takes it in x's own type: fp32 here is the closer-to-exact form).
+template <int MAXOCT>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const f16* __restrict__ x, const f16* __restrict__ weight, f16* __restrict__ y, long rows, int c, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int oct = c >> 3;
+  const f16* xr = x + row * c;
+  f16x8 v[MAXOCT];
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXOCT; ++j) {
+    const int o = lane + j * 64;
+    if (o < oct) {
+      v[j] = *reinterpret_cast<const f16x8*>(xr + o * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) q = fmaf((float)v[j][e], (float)v[j][e], q);
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)c + eps);
+  f16* yr = y + row * c;
+#pragma unroll
+  for (int j = 0; j < MAXOCT; ++j) {
+    const int o = lane + j * 64;
+    if (o < oct) {
+      const f16x8 g = *reinterpret_cast<const f16x8*>(weight + o * 8);
+      f16x8 r;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r[e] = (f16)((float)v[j][e] * rstd * (float)g[e]);
+      *reinterpret_cast<f16x8*>(yr + o * 8) = r;
+    }
+  }
+}
+
+extern "C" int fmx_rmsnorm_f16(const void* x, const void* weight, void* y, int64_t rows, int32_t c, float eps, void* stream) {
+  FMX_REQUIRE(x && weight && y && rows > 0 && c > 0 && (c % 8) == 0 && c <= 4096, "rmsnorm: bad args");
+  FMX_REQUIRE(fmx_aligned16(x) && fmx_aligned16(y) && fmx_aligned16(weight), "rmsnorm: alignment");
+  const long blocks = (rows + 3) / 4;
+  if (blocks >= (1L << 31)) return fmx_set_error(FMX_E_BADARG, "rmsnorm: too many rows");
+  hipStream_t st = (hipStream_t)stream;
+  const int oct = c >> 3;
+#define FMX_RMS(MO) hipLaunchKernelGGL((rmsnorm_kernel<MO>), dim3((unsigned)blocks), dim3(256), 0, st, (const f16*)x, (const f16*)weight, (f16*)y, (long)rows, c, eps)
+  if (oct <= 64) FMX_RMS(1);
+  else if (oct <= 128) FMX_RMS(2);
+  else if (oct <= 256) FMX_RMS(4);
+  else FMX_RMS(8);
+#undef FMX_RMS
+  FMX_LAUNCH_CHECK("fmx_rmsnorm_f16");
+  return FMX_OK;
+}
+
 template <bool MOD>
 static int launch_ln(const void* x, const void* gamma, const void* beta, void* y, int64_t rows, int32_t c, float eps, long rows_per_b,
                      long ld_mod, void* stream, const char* name) {

@@ -501,6 +501,17 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None):
     return out
 
 
+def rmsnorm(x, weight, eps=1e-6, out=None):
+    """T5LayerNorm (backend/nn/t5.py:15-25): x * rsqrt(mean(x^2) + eps) * weight over the last dim; fp16 or bf16 throughout"""
+    sfx, elem = _elem(x, weight, out)
+    c = x.shape[-1]
+    rows = x.numel() // c
+    if out is None:
+        out = empty(x.shape, elem, x.device)
+    _lib.check(getattr(_lib.lib(), "fmx_rmsnorm" + sfx)(_p(x), _p(weight), _p(out), rows, c, float(eps), stream_ptr()), "fmx_rmsnorm" + sfx)
+    return out
+
+
 def layernorm_padded(x, gamma, beta, out, rows_per_image, eps=1e-5):
     """LayerNorm of x [B*n, C] written into out [B, n_pad, C] (rows n..n_pad of every image are left untouched)."""
     _check_f16(x, gamma, beta, out)

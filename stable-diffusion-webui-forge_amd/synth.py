@@ -209,6 +209,31 @@ def synth_clip_state_dict(cfg, seed=4, **kw):
     return synth_state_dict(clip_param_shapes(cfg), seed=seed, **kw)
 
 
+# T5-XXL as Flux uses it (backend/huggingface/black-forest-labs/FLUX.1-dev/text_encoder_2/config.json): 24 layers, 64 heads of 64, gated tanh-GELU
+T5_XXL_CONFIG = dict(d_model=4096, d_ff=10240, num_layers=24, num_heads=64, vocab_size=32128, dense_act_fn="gelu_pytorch_tanh", is_gated_act=True, model_type="t5")
+TINY_T5_CONFIG = dict(d_model=128, d_ff=320, num_layers=3, num_heads=2, vocab_size=1000, dense_act_fn="gelu_pytorch_tanh", is_gated_act=True, model_type="t5")
+
+
+def synth_t5_state_dict(cfg, seed=9):
+    """random-init T5 encoder: N(0, 1) / sqrt(fan_in) projections, RMS-norm weights 1 + 0.1 N, token embeddings N(0, 1), bias table N(0, 0.5)"""
+    from .backend.nn.layout import t5_param_shapes
+    sd = OrderedDict()
+    for name, shape in t5_param_shapes(cfg).items():
+        rng = np.random.Generator(np.random.PCG64([seed, zlib.crc32(name.encode())]))
+        if name == "logit_scale":
+            sd[name] = torch.tensor(4.6055)
+            continue
+        z = torch.from_numpy(rng.standard_normal(shape, dtype=np.float32))
+        if name.endswith("layer_norm.weight"):
+            z = 1.0 + 0.1 * z
+        elif name.endswith("relative_attention_bias.weight"):
+            z = 0.5 * z
+        elif name != "transformer.shared.weight":
+            z = z / float(np.sqrt(shape[1]))
+        sd[name] = z
+    return sd
+
+
 def synth_conditioning(batch, context_dim, adm_in_channels=None, tokens=77, seed=1234):
     """cond / uncond tensors of the shapes the text encoders would produce."""
     rng = np.random.Generator(np.random.PCG64([seed, 7]))

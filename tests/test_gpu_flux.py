@@ -309,3 +309,113 @@ def test_forge_loader_builds_a_flux_engine_from_a_checkpoint():
     assert tuple(img.shape) == (1, 3, 8 * up, 8 * up) and torch.isfinite(img).all()
     schnell = loader.forge_loader({k: v for k, v in tr.items() if not k.startswith("guidance_in.")}, device=DEV)
     assert abs(schnell.forge_objects.unet.model.predictor.mu - 1.0) < 1e-12 and not schnell.use_distilled_cfg_scale and schnell.forge_objects.vae is None
+
+
+# ---- round 5: Flux from a prompt (T5-XXL + CLIP-L text encoders) and Flux with a negative prompt (cond_scale != 1) ----------------------------------------
+def test_rmsnorm_kernel():
+    for rows, c, dt in ((100, 128, torch.float16), (33, 4096, torch.float16), (64, 1024, torch.bfloat16), (7, 3072, torch.bfloat16)):
+        x = (rnd(rows, c, scale=3, seed=400) + 0.7).to(dt)
+        w = (1 + 0.1 * rnd(c, seed=401)).to(dt)
+        ref = w.float() * (x.float() * torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + 1e-6))
+        close(ops.rmsnorm(x, w, 1e-6), ref, 2e-3 if dt == torch.float16 else 1e-2, 2e-3 if dt == torch.float16 else 1e-2, f"rmsnorm {rows}x{c} {dt}")
+
+
+@pytest.mark.parametrize("dt,tag", [(torch.float16, "f16"), (torch.bfloat16, "bf16")])
+def test_t5_encoder_vs_reference_fixture(dt, tag):
+    """backend/nn/t5.py (RMS norms, relative-position bias through the attention kernel's additive-mask operand, gated tanh-GELU feed-forward as a
+    per-row gated GEMM epilogue) against the REAL reference class on CPU fp32 (tests/golden/tiny_t5.pt), held to the reference's own 16-bit run"""
+    from forge_amd.backend.nn.t5 import IntegratedT5
+    cfg = synth.TINY_T5_CONFIG
+    g = load_golden("tiny_t5.pt")
+    net = IntegratedT5(cfg, synth.synth_t5_state_dict(cfg), device=DEV, dtype=dt)
+    z = net.encode(g["ids"])
+    check(f"tiny T5 encoder ({tag}) vs reference", z, g["z"], floor=f"tiny_t5.pt:z@{tag}")
+    z2 = net.transformer(input_ids=g["ids"][:, :100])           # a length that is not a multiple of the key tile: padded keys, masked
+    from oracle import t5 as ot5
+    ref = ot5.t5_encode(synth.synth_t5_state_dict(cfg), cfg, g["ids"][:, :100])
+    check(f"tiny T5 encoder ({tag}), 100 tokens vs oracle", z2, ref, floor=f"tiny_t5.pt:z@{tag}")
+
+
+class _WordTokenizer:
+    """deterministic stand-in for the two tokenizers (their vocabularies are data files of the user's install): word -> id by crc32"""
+
+    def __init__(self, vocab, bos=None, eos=None, pad=None, lo=3):
+        self.vocab, self.lo = vocab, lo
+        self.bos_token_id, self.eos_token_id, self.pad_token_id = bos, eos, pad
+
+    def get_vocab(self):
+        return {}
+
+    def __call__(self, texts, truncation=False, add_special_tokens=False):
+        import zlib
+        return {"input_ids": [[self.lo + zlib.crc32(w.encode()) % (self.vocab - self.lo - 2) for w in t.replace(",", " , ").split()] for t in texts]}
+
+
+def test_flux_from_prompt_strings_with_a_negative_prompt():
+    """prompt STRINGS -> FluxEngine.get_learned_conditioning (CLIP-L pooled + T5 sequence + distilled guidance, diffusion_engine/flux.py:84-100) ->
+    sampling with a negative prompt at cond_scale 3 (two model calls per step, sampling_function.py:292-312) -> latents, against the CPU oracles
+    (oracle/clip.py, oracle/t5.py, oracle/flux.py: each pinned to the real reference) driven by the same token ids and the same CFG formula."""
+    from forge_amd.backend.nn.clip import IntegratedCLIP
+    from forge_amd.backend.nn.t5 import IntegratedT5
+    from forge_amd.modules.prompt_parser import SdConditioning
+    from oracle import clip as oclip, flux as oflux, t5 as ot5
+    lcfg, tcfg = synth.TINY_CLIP_L_CONFIG, synth.TINY_T5_CONFIG
+    fcfg = dict(synth.TINY_FLUX_CONFIG, vec_in_dim=lcfg["hidden_size"], context_in_dim=tcfg["d_model"])
+    assert fcfg["context_in_dim"] == tcfg["d_model"] and fcfg["vec_in_dim"] == lcfg["hidden_size"], (fcfg, "tiny Flux must take the tiny encoders' widths")
+    fsd, lsd, tsd = synth.synth_flux_state_dict(fcfg, seed=2), synth.synth_clip_state_dict(lcfg), synth.synth_t5_state_dict(tcfg)
+    h, w = 8, 8
+    eng = build_flux_engine(fcfg, fsd, device=DEV, seq_len=(h // 2) * (w // 2))
+    tok_l = _WordTokenizer(lcfg["vocab_size"], bos=lcfg["vocab_size"] - 2, eos=lcfg["vocab_size"] - 1, pad=lcfg["vocab_size"] - 1)
+    tok_t = _WordTokenizer(tcfg["vocab_size"], lo=2)
+    eng.attach_text_encoders(IntegratedCLIP(lcfg, lsd, device=DEV), IntegratedT5(tcfg, tsd, device=DEV, dtype=torch.float16), tokenizer_l=tok_l, tokenizer_t5=tok_t)
+    prompts, negs = ["a photo of a (red:1.2) fox, detailed", "two cats on a sofa"], ["blurry, low quality", "blurry, low quality"]
+    c = eng.get_learned_conditioning(SdConditioning(prompts, distilled_cfg_scale=3.5))
+    uc = eng.get_learned_conditioning(SdConditioning(negs, is_negative_prompt=True, distilled_cfg_scale=3.5))
+    assert c["crossattn"].shape == (2, 256, tcfg["d_model"]) and c["vector"].shape == (2, lcfg["hidden_size"]) and c["guidance"].tolist() == [3.5, 3.5]
+
+    # the same conditioning from the oracles, on the same token ids
+    def oracle_cond(texts):
+        eng_t, eng_l = eng.text_processing_engine_t5, eng.text_processing_engine_l
+        zs, pooled = [], []
+        for t in texts:
+            chunks, _ = eng_t.tokenize_line(t)
+            ids = torch.tensor([chunks[0].tokens])
+            z = ot5.t5_encode(tsd, tcfg, ids)
+            zs.append(oclip.apply_emphasis_original(z, torch.tensor([chunks[0].multipliers]))[0])
+            lchunks, _ = eng_l.tokenize_line(t)
+            _, p = oclip.encode_with_transformers(lsd, lcfg, torch.tensor([lchunks[0].tokens]), clip_skip=1, final_layer_norm=True, return_pooled=True, is_clip_l=True)
+            pooled.append(p[0])
+        return torch.stack(zs), torch.stack(pooled)
+    oc, ov = oracle_cond(prompts)
+    ouc, ouv = oracle_cond(negs)
+    check("Flux conditioning from a prompt: T5 sequence vs oracle", c["crossattn"], oc, floor="tiny_t5.pt:z@f16")
+    check("Flux conditioning from a prompt: CLIP-L pooled vs oracle", c["vector"], ov, floor="tiny_clip_l.pt:pooled")
+    scale = 3.0
+    noise = torch.randn(2, eng.latent_channels, h, w, generator=torch.Generator().manual_seed(5))
+    p = processing.StableDiffusionProcessingTxt2Img(sd_model=eng, c=c, uc=uc, seed=0, sampler_name="Euler", scheduler="simple", batch_size=2, steps=4,
+                                                    cfg_scale=scale, width=w * 8, height=h * 8, do_decode=False)
+
+    class FixedNoise:
+        def next(self_inner):
+            return noise.to(DEV)
+    import forge_amd.modules.rng as rng_mod
+    orig = rng_mod.ImageRNG
+    rng_mod.ImageRNG = lambda *a, **k: FixedNoise()
+    try:
+        res = processing.process_images(p)
+    finally:
+        rng_mod.ImageRNG = orig
+    # oracle: Euler on the simple flow sigmas, two model calls per step, uncond + (cond - uncond) * scale on the denoised (= on the model output: x - out * sigma)
+    sig = oflux.flux_sigmas_simple(4, oflux.flux_sigma_table(seq_len=(h // 2) * (w // 2)))
+    gd = torch.full((2,), 3.5)
+    x = noise.clone() * sig[0]           # noise_scaling of PredictionFlux at the first sigma on a zero latent (k_prediction.py: sigma * noise + (1 - sigma) * latent)
+    for i in range(len(sig) - 1):
+        s = sig[i].expand(2)
+        out_c = oflux.flux_forward(fsd, fcfg, x, s, oc, ov, gd)
+        out_u = oflux.flux_forward(fsd, fcfg, x, s, ouc, ouv, gd)
+        den = (x - out_u * sig[i]) + ((x - out_c * sig[i]) - (x - out_u * sig[i])) * scale
+        d = (x - den) / sig[i]
+        x = x + d * (sig[i + 1] - sig[i])
+    # no floor entry of its own: the conditioning itself comes out of two 16-bit text encoders (T5 at rms 4.7e-3 of its fp32 value, within its floor of
+    # 7.8e-3) and the CFG extrapolation at scale 3 amplifies what the two model calls disagree on; measured max_rel 7.6e-4, rms 8.0e-4 (r27)
+    check("tiny Flux from prompt strings, negative prompt at cfg 3, 4-step Euler vs oracle", res.latents, x, tol=1.2e-3)

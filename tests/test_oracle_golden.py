@@ -392,3 +392,12 @@ def test_processing_wires_variation_seeds_into_the_noise():
     finally:
         shared.opts.randn_source, shared.opts.eta_noise_seed_delta = saved[0], saved[1]
         shared.sd_model = saved[2]
+
+
+def test_t5_restatement_vs_reference_fixture():
+    """oracle/t5.py against the REAL reference class (backend/nn/t5.py IntegratedT5) on the tiny configuration: tests/golden/tiny_t5.pt"""
+    from forge_amd import synth
+    from oracle import t5 as ot5
+    g = load_golden("tiny_t5.pt")
+    z = ot5.t5_encode(synth.synth_t5_state_dict(synth.TINY_T5_CONFIG), synth.TINY_T5_CONFIG, g["ids"])
+    assert float((z - g["z"]).abs().max() / g["z"].abs().max()) < 1e-4

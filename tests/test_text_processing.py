@@ -117,3 +117,36 @@ def test_prompt_schedule_invariants():
             assert marks[-1] == total and marks == sorted(set(marks)) and all(1 <= m <= total for m in marks), (s, sched)
             if not any(ch in s for ch in "[|"):
                 assert sched == [[total, s]], (s, sched)
+
+
+def test_t5_engine_tokenize_line_vs_reference():
+    """T5TextProcessingEngine.tokenize_line (backend/text_processing/t5_engine.py:68-112) run by the reference with the real T5 tokenizer, replayed:
+    EOS = 1 appended, padding 0 to 256, BREAK opens a chunk, emphasis weights per token, the bracket-token multiplier table."""
+    from forge_amd.backend.text_processing.t5_engine import T5TextProcessingEngine
+    from oracle.make_golden import ReplayT5Tokenizer
+    from types import SimpleNamespace
+    g = load_golden("tokenize_t5.pt")
+    eng = T5TextProcessingEngine(SimpleNamespace(transformer=None), ReplayT5Tokenizer(g["tokenizer"]))
+    assert eng.token_mults == g["token_mults"] and eng.comma_token == g["comma_token"]
+    for prompt, want in zip(g["prompts"], g["lines"]):
+        chunks, count = eng.tokenize_line(prompt)
+        assert count == want["count"] and len(chunks) == len(want["chunks"]), prompt
+        for c, w in zip(chunks, want["chunks"]):
+            assert c.tokens == w["tokens"] and c.multipliers == w["multipliers"], prompt
+            assert len(c.tokens) >= 256 and c.tokens[-1] in (0, 1)
+
+    # __call__: one encoding per chunk, emphasis applied ("Original": multiply, restore the mean), lines cached
+    calls = []
+
+    def fake_encoder(input_ids):
+        calls.append(input_ids.shape)
+        return torch.ones(input_ids.shape[0], input_ids.shape[1], 4) * torch.arange(1, input_ids.shape[1] + 1).view(1, -1, 1).float()
+    eng = T5TextProcessingEngine(SimpleNamespace(transformer=fake_encoder), ReplayT5Tokenizer(g["tokenizer"]))
+    z = eng([g["prompts"][0], g["prompts"][1], g["prompts"][0]])
+    assert z.shape == (4, 256, 4) and len(calls) == 3          # 1 + 2 chunks + the cached repeat
+    assert torch.equal(z[0], z[3])
+    base = torch.arange(1, 257).view(-1, 1).float().expand(256, 4)
+    assert torch.allclose(z[0], base)                           # no emphasis in prompt 0: untouched
+    m = torch.tensor(g["lines"][1]["chunks"][0]["multipliers"]).view(-1, 1)
+    want = base * m
+    assert torch.allclose(z[1], want * (base.mean() / want.mean()), rtol=1e-5)
