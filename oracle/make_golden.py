@@ -413,6 +413,64 @@ def synth_lycoris(cfg, seed=8):
     return sd
 
 
+def synth_flux_lora(cfg, seed=3, rank=4):
+    """a diffusers-named Flux LoRA (q / k / v and add_k_proj of a double block, to_q + proj_mlp of a single block, the swapped norm_out), one native-named
+    and one OneTrainer-named entry"""
+    g = torch.Generator().manual_seed(seed)
+    hs = cfg["hidden_size"]
+    lo = {}
+
+    def add(name, out_f, in_f, alpha=2.0):
+        lo[name + ".lora_up.weight"] = torch.randn(out_f, rank, generator=g) * 0.1
+        lo[name + ".lora_down.weight"] = torch.randn(rank, in_f, generator=g) * 0.1
+        lo[name + ".alpha"] = torch.tensor(alpha)
+    for n in ("to_q", "to_k", "to_v", "add_k_proj"):
+        add(f"transformer.transformer_blocks.0.attn.{n}", hs, hs)
+    add("transformer.single_transformer_blocks.1.attn.to_q", hs, hs)
+    add("transformer.single_transformer_blocks.1.proj_mlp", 4 * hs, hs)
+    add("transformer.norm_out.linear", 2 * hs, hs)
+    add("lora_unet_double_blocks_1_img_mlp_0", int(hs * cfg["mlp_ratio"]), hs)
+    add("lora_transformer_transformer_blocks_1_ff_context_net_2", hs, int(hs * cfg["mlp_ratio"]))
+    return lo
+
+
+def gen_flux_lora():
+    """The REAL reference's Flux LoRA handling: comfyui_lora_collection/utils.py flux_to_diffusers (slice / function targets), load_lora, and
+    backend/patcher/lora.py merge_lora_to_weight with the offsets / functions ModelPatcher.add_patches attaches (base.py:99-113) -> merged weights of the tiny
+    Flux transformer (fp16 weights, fp32 computation)."""
+    import importlib
+    from forge_amd.backend.nn.layout import flux_param_shapes
+    ref_import.load_reference()
+    rl = importlib.import_module("backend.patcher.lora")
+    cu = importlib.import_module("packages_3rdparty.comfyui_lora_collection.utils")
+    cfg = synth.TINY_FLUX_CONFIG
+    sd = {k: v.half() for k, v in synth.synth_flux_state_dict(cfg, seed=2).items()}
+    key_map = {}
+    for k in flux_param_shapes(cfg):           # comfyui_lora_collection/lora.py:286-299 (generic part) + :342-347 (Flux diffusers spellings)
+        mk = "diffusion_model." + k
+        if k.endswith(".weight"):
+            key_map["lora_unet_" + k[:-len(".weight")].replace(".", "_")] = mk
+            key_map["diffusion_model." + k[:-len(".weight")]] = mk
+        else:
+            key_map[mk] = mk
+    for dk, to in cu.flux_to_diffusers(dict(cfg), output_prefix="diffusion_model.").items():
+        if dk.endswith(".weight"):
+            stem = dk[:-len(".weight")]
+            key_map["transformer." + stem] = to
+            key_map["lycoris_" + stem.replace(".", "_")] = to
+            key_map["lora_transformer_" + stem.replace(".", "_")] = to
+    patch_dict, remaining = rl.load_lora(synth_flux_lora(cfg), key_map)
+    per_key = {}
+    for target, pv in patch_dict.items():
+        mk, off, fn = (target, None, None) if not isinstance(target, tuple) else (target[0], target[1], target[2] if len(target) > 2 else None)
+        per_key.setdefault(mk[len("diffusion_model."):], []).append([0.8, pv, 1.0, off, fn])
+    merged = {k: rl.merge_lora_to_weight(patches, sd[k].clone(), key=k, computation_dtype=torch.float32) for k, patches in per_key.items()}
+    torch.save({"strength": 0.8, "merged": merged, "remaining": sorted(remaining),
+                "key_map_targets": {k: (v if isinstance(v, str) else (v[0], v[1], v[2].__name__ if len(v) > 2 else None)) for k, v in key_map.items()}},
+               os.path.join(GOLD, "tiny_flux_lora_merge.pt"))
+    print("tiny_flux lora merge:", sorted(merged), "remaining", sorted(remaining))
+
+
 def gen_lora(name="tiny_sd15", cfg=None):
     """The REAL reference's key map, patch parser and merge (backend/patcher/lora.py:43,19,85; comfyui_lora_collection/lora.py)
     on a synthetic LoRA for the tiny UNet: merged weights of every patched parameter (fp16 weights, fp32 computation)."""
@@ -1808,6 +1866,8 @@ def main():
         gen_schedulers()
     if a.only in ("", "t5"):
         gen_t5()
+    if a.only in ("", "fluxlora"):
+        gen_flux_lora()
     if a.only in ("", "t5tok"):
         gen_t5_tokenize()
     if a.only in ("", "clip"):

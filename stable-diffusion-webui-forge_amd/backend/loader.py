@@ -199,12 +199,15 @@ def forge_loader(sd, loras=None, device="cuda", prediction_type=None):
     from .patcher.lora import merge_loras_into_state_dict
     sd = load_torch_file(sd)
     if flux_prefix(sd) is not None:
-        if loras:
-            raise NotImplementedError("LoRA merging is built for the LDM UNet key maps, not for Flux")
         from .diffusion_engine.base import build_flux_engine
+        from .patcher.lora import merge_loras_into_flux_state_dict
         parts, guess = split_flux_state_dict(sd)
-        engine = build_flux_engine(guess["flux_config"], parts["transformer"], device=device, vae_config=guess["vae_config"],
+        tsd, report = parts["transformer"], None
+        if loras:   # native and diffusers-named Flux LoRAs (comfyui_lora_collection/lora.py:286-299, :342-347), merged offline like the UNet's
+            tsd, report = merge_loras_into_flux_state_dict(tsd, guess["flux_config"], [(load_torch_file(l), s) for l, s in loras], device=device, dtype=guess["dtype"])
+        engine = build_flux_engine(guess["flux_config"], tsd, device=device, vae_config=guess["vae_config"],
                                    vae_state_dict=parts["vae"] or None, dtype=guess["dtype"])
+        engine.lora_report = report
         engine.model_guess = guess
         return engine
     parts, guess = split_state_dict(sd)

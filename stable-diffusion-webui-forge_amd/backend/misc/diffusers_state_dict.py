@@ -5,6 +5,8 @@ kohya naming need (`lora_unet_down_blocks_0_attentions_0_transformer_blocks_0_at
 Built from the executor's own flat layout (`layout.unet_layout`) rather than from the config lists: every layer object
 already knows its LDM key, so the diffusers name only needs the (level, index-within-level) bookkeeping of diffusers'
 down_blocks / mid_block / up_blocks.  tests/test_loader_lora.py checks the result against the reference's map."""
+import torch
+
 from ..nn.layout import Down, Res, SpatialT, Up, unet_layout, unet_param_shapes
 
 _RES = {  # LDM ResBlock sub-key -> diffusers ResnetBlock2D sub-key
@@ -131,4 +133,61 @@ def vae_from_diffusers(sd):
                         v = v.reshape(v.shape[0], v.shape[1], 1, 1)
         k = k.replace(".conv_shortcut.", ".nin_shortcut.").replace(".conv_norm_out.", ".norm_out.")
         out[k] = v
+    return out
+
+
+# ---- Flux: diffusers transformer names -> the single-file (BFL) names the native transformer is keyed by ------------------------------------------------
+def swap_scale_shift(weight):
+    """diffusers stores the final adaLN projection as [scale | shift], the BFL layout as [shift | scale] (comfyui_lora_collection/utils.py:255-258)"""
+    shift, scale = weight.chunk(2, dim=0)
+    return torch.cat([scale, shift], dim=0)
+
+
+def flux_to_diffusers(cfg, output_prefix=""):
+    """{diffusers parameter name: target} for a Flux transformer (depth, depth_single_blocks, hidden_size), as
+    packages_3rdparty/comfyui_lora_collection/utils.py:407-509 builds it.  A target is the BFL parameter name, or (name, (dim, offset, size)) where the
+    diffusers tensor is one slice of a fused projection (q | k | v of `img_attn.qkv` / `txt_attn.qkv`; q | k | v | mlp of a single block's `linear1`), or
+    (name, None, function) where it maps through a function (`swap_scale_shift`)."""
+    hs = cfg.get("hidden_size", 0)
+    out = {}
+
+    def fused(dst, names_sizes, src_prefix):
+        for end in ("weight", "bias"):
+            off = 0
+            for name, size in names_sizes:
+                out[f"{src_prefix}{name}.{end}"] = (f"{dst}.{end}", (0, off, size))
+                off += size
+    double = [("attn.to_out.0", "img_attn.proj"), ("norm1.linear", "img_mod.lin"), ("norm1_context.linear", "txt_mod.lin"), ("attn.to_add_out", "txt_attn.proj"),
+              ("ff.net.0.proj", "img_mlp.0"), ("ff.net.2", "img_mlp.2"), ("ff_context.net.0.proj", "txt_mlp.0"), ("ff_context.net.2", "txt_mlp.2")]
+    double_scales = [("attn.norm_q.weight", "img_attn.norm.query_norm.scale"), ("attn.norm_k.weight", "img_attn.norm.key_norm.scale"),
+                     ("attn.norm_added_q.weight", "txt_attn.norm.query_norm.scale"), ("attn.norm_added_k.weight", "txt_attn.norm.key_norm.scale")]
+    for i in range(cfg.get("depth", 0)):
+        src, dst = f"transformer_blocks.{i}.", f"{output_prefix}double_blocks.{i}."
+        fused(dst + "img_attn.qkv", [("to_q", hs), ("to_k", hs), ("to_v", hs)], src + "attn.")
+        fused(dst + "txt_attn.qkv", [("add_q_proj", hs), ("add_k_proj", hs), ("add_v_proj", hs)], src + "attn.")
+        for a, b in double:
+            for end in ("weight", "bias"):
+                out[f"{src}{a}.{end}"] = f"{dst}{b}.{end}"
+        for a, b in double_scales:
+            out[src + a] = dst + b
+    for i in range(cfg.get("depth_single_blocks", 0)):
+        src, dst = f"single_transformer_blocks.{i}.", f"{output_prefix}single_blocks.{i}."
+        for end in ("weight", "bias"):
+            off = 0
+            for name, size in (("attn.to_q", hs), ("attn.to_k", hs), ("attn.to_v", hs), ("proj_mlp", 4 * hs)):
+                out[f"{src}{name}.{end}"] = (f"{dst}linear1.{end}", (0, off, size))
+                off += size
+            out[f"{src}norm.linear.{end}"] = f"{dst}modulation.lin.{end}"
+            out[f"{src}proj_out.{end}"] = f"{dst}linear2.{end}"
+        out[src + "attn.norm_q.weight"] = dst + "norm.query_norm.scale"
+        out[src + "attn.norm_k.weight"] = dst + "norm.key_norm.scale"
+    basic = [("final_layer.linear", "proj_out"), ("img_in", "x_embedder"), ("time_in.in_layer", "time_text_embed.timestep_embedder.linear_1"),
+             ("time_in.out_layer", "time_text_embed.timestep_embedder.linear_2"), ("txt_in", "context_embedder"),
+             ("vector_in.in_layer", "time_text_embed.text_embedder.linear_1"), ("vector_in.out_layer", "time_text_embed.text_embedder.linear_2"),
+             ("guidance_in.in_layer", "time_text_embed.guidance_embedder.linear_1"), ("guidance_in.out_layer", "time_text_embed.guidance_embedder.linear_2")]
+    for bfl, dif in basic:
+        for end in ("weight", "bias"):
+            out[f"{dif}.{end}"] = f"{output_prefix}{bfl}.{end}"
+    for end in ("weight", "bias"):
+        out[f"norm_out.linear.{end}"] = (f"{output_prefix}final_layer.adaLN_modulation.1.{end}", None, swap_scale_shift)
     return out

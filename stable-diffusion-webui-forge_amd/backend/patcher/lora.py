@@ -47,6 +47,31 @@ def model_lora_keys_unet(unet_keys, unet_config, key_map=None):
     return key_map
 
 
+def model_lora_keys_flux(flux_keys, flux_config, key_map=None):
+    """{lora key prefix: target} for a Flux transformer with BFL parameter names `flux_keys` (no prefix).  Targets are model keys with the reference's
+    'diffusion_model.' prefix, or (key, (dim, offset, size)) / (key, None, function) for the diffusers-named LoRAs whose tensors address one slice of a
+    fused projection or map through `swap_scale_shift` (comfyui_lora_collection/lora.py:286-299 for the native names, :342-347 for the three diffusers
+    spellings: 'transformer.' (diffusers / simpletuner), 'lycoris_' (simpletuner LyCORIS), 'lora_transformer_' (OneTrainer))."""
+    from ..misc.diffusers_state_dict import flux_to_diffusers
+    key_map = {} if key_map is None else key_map
+    for k in flux_keys:
+        mk = "diffusion_model." + k
+        if k.endswith(".weight"):
+            stem = k[:-len(".weight")]
+            key_map["lora_unet_" + stem.replace(".", "_")] = mk
+            key_map["diffusion_model." + stem] = mk
+        else:
+            key_map[mk] = mk
+    for dk, to in flux_to_diffusers(flux_config, output_prefix="diffusion_model.").items():
+        if not dk.endswith(".weight"):
+            continue
+        stem = dk[:-len(".weight")]
+        key_map["transformer." + stem] = to
+        key_map["lycoris_" + stem.replace(".", "_")] = to
+        key_map["lora_transformer_" + stem.replace(".", "_")] = to
+    return key_map
+
+
 def load_lora(lora, to_load):
     """-> (patch_dict {model key: (type, tensors)}, remaining {unused lora keys}); comfyui_lora_collection/lora.py:32-213 for
     the patch types listed in the module docstring."""
@@ -132,9 +157,31 @@ def merge_lora_to_weight(patches, weight, key="online_lora", computation_dtype=t
     fin = (lambda t: t) if multi else (lambda t: t.half())
     if multi:
         w = w.float()
+    own = w.data_ptr() != weight.data_ptr() if weight.is_floating_point() and weight.device == w.device else True
     for strength, v, strength_model, offset, function in patches:
         if offset is not None or function is not None:
-            raise NotImplementedError("weight offset / function hooks are not supported by the native merge")
+            # patcher/lora.py:100-108: the patch addresses ONE SLICE of this parameter (the q / k / v / mlp part of a fused Flux projection, which a
+            # diffusers-named LoRA patches separately) and / or its delta goes through a function (swap_scale_shift for norm_out.linear).  The slice is
+            # merged as a parameter of its own and written back.
+            if not own:
+                w, own = w.clone(), True
+            sl = w if offset is None else w.narrow(offset[0], offset[1], offset[2])
+            if function is None:
+                sl.copy_(merge_lora_to_weight([(strength, v, strength_model, None, None)], sl.contiguous(), key=key, device=device).to(sl.dtype))
+                continue
+            ptype_f, vf = ("diff", v) if len(v) == 1 else (v[0], v[1])
+            if strength_model != 1.0:
+                sl.copy_((sl.float() * strength_model).to(sl.dtype))
+            if ptype_f == "diff":
+                delta = strength * vf[0].to(device=device, dtype=torch.float32)
+            elif ptype_f == "lora" and vf[3] is None and vf[4] is None:
+                up, down, alpha = vf[0], vf[1], vf[2]
+                delta = (strength * ((alpha / down.shape[0]) if alpha is not None else 1.0)) * torch.mm(
+                    up.to(device=device, dtype=torch.float32).flatten(1), down.to(device=device, dtype=torch.float32).flatten(1)).reshape(sl.shape)
+            else:
+                raise NotImplementedError(f"{key}: a {ptype_f} patch through a weight function (only plain lora / diff patches map through swap_scale_shift)")
+            sl.copy_((sl.float() + function(delta)).to(sl.dtype))
+            continue
         if strength_model != 1.0:
             w = fin(w.float() * strength_model)
         if len(v) == 1:
@@ -253,21 +300,35 @@ def _weight_decompose(dora_scale, weight, lora_diff, alpha, strength, device):
     return out   # fp32; merge_lora_to_weight rounds once per key
 
 
-def merge_loras_into_state_dict(unet_sd, unet_config, loras, device="cuda"):
-    """unet_sd: LDM-layout UNet state dict (no prefix); loras: [(lora_state_dict, strength)] applied in order.
-    -> (merged state dict (fp16 on device for touched tensors, untouched entries passed through), report)"""
-    key_map = model_lora_keys_unet(list(unet_sd.keys()), unet_config)
+def merge_loras_into_state_dict(unet_sd, unet_config, loras, device="cuda", key_map=None, out_dtype=torch.float16):
+    """unet_sd: LDM-layout UNet (or BFL-layout Flux transformer) state dict (no prefix); loras: [(lora_state_dict, strength)] applied in order;
+    key_map: model_lora_keys_unet(...) by default, model_lora_keys_flux(...) for Flux (targets may carry an offset / a function, ModelPatcher.add_patches
+    base.py:99-113).  -> (merged state dict (on device for touched tensors, untouched entries passed through), report)"""
+    if key_map is None:
+        key_map = model_lora_keys_unet(list(unet_sd.keys()), unet_config)
     per_key = {}
     unused = []
     for lora_sd, strength in loras:
         patch_dict, remaining = load_lora(lora_sd, key_map)
         unused.append(sorted(k for k in remaining if not k.startswith(("lora_te", "text_encoder", "lora_prior"))))
-        for mk, pv in patch_dict.items():
+        for target, pv in patch_dict.items():
+            offset = function = None
+            mk = target
+            if isinstance(target, tuple):
+                mk, offset = target[0], target[1]
+                function = target[2] if len(target) > 2 else None
             k = mk[len("diffusion_model."):]
             if k not in unet_sd:
                 continue
-            per_key.setdefault(k, []).append((float(strength), pv, 1.0, None, None))
+            per_key.setdefault(k, []).append((float(strength), pv, 1.0, offset, function))
     merged = dict(unet_sd)
     for k, patches in per_key.items():
-        merged[k] = merge_lora_to_weight(patches, unet_sd[k], key=k, device=device)
+        merged[k] = merge_lora_to_weight(patches, unet_sd[k], key=k, device=device).to(out_dtype)
     return merged, {"patched": len(per_key), "unused_keys": unused}
+
+
+def merge_loras_into_flux_state_dict(flux_sd, flux_config, loras, device="cuda", dtype=torch.bfloat16):
+    """the same offline merge for a Flux transformer (BFL parameter names): native ('lora_unet_double_blocks_0_img_attn_qkv', 'diffusion_model. ...') and
+    diffusers-named ('transformer.transformer_blocks.0.attn.to_q', ...) LoRA files.  The merge arithmetic runs in fp16 operands / fp32 accumulation like
+    the UNet's; the result is cast to the transformer's storage type."""
+    return merge_loras_into_state_dict(flux_sd, flux_config, loras, device=device, key_map=model_lora_keys_flux(list(flux_sd.keys()), flux_config), out_dtype=dtype)

@@ -90,3 +90,23 @@ def test_forge_loader_with_lora_end_to_end():
     # the split / detection entry point on the same checkpoint (tiny config has no family rule -> detection is shape-only)
     unet_part = {k[len(loader.UNET_PREFIX):]: v for k, v in loader.preprocess_state_dict(ckpt).items()}
     assert set(unet_part) == set(base)
+
+
+def test_flux_lora_merge_on_device_vs_reference():
+    """A diffusers-named Flux LoRA merged into the tiny Flux transformer on the device -- slices of the fused qkv / linear1 projections patched one by
+    one, norm_out through swap_scale_shift, native and OneTrainer spellings beside it -- against the REAL reference's merge (tests/golden/tiny_flux_lora_merge.pt)."""
+    from oracle.make_golden import synth_flux_lora
+    g = load_golden("tiny_flux_lora_merge.pt")
+    cfg = synth.TINY_FLUX_CONFIG
+    sd = {k: v.half() for k, v in synth.synth_flux_state_dict(cfg, seed=2).items()}
+    merged, report = nlora.merge_loras_into_flux_state_dict(sd, cfg, [(synth_flux_lora(cfg), g["strength"])], device=DEV, dtype=torch.float16)
+    assert report["patched"] == len(g["merged"]) and report["unused_keys"] == [[]]
+    for k, ref in g["merged"].items():
+        got = merged[k].float().cpu().reshape(ref.shape)
+        err = (got - ref.float()).abs().max().item()
+        assert err <= 2.0 ** -10 * ref.float().abs().max().item() + 1e-6, (k, err)          # one fp16 rounding on both sides
+        assert not torch.equal(merged[k].cpu(), sd[k])
+    hs = cfg["hidden_size"]
+    qkv, q0 = merged["double_blocks.0.txt_attn.qkv.weight"].cpu(), sd["double_blocks.0.txt_attn.qkv.weight"]
+    assert torch.equal(qkv[:hs], q0[:hs]) and torch.equal(qkv[2 * hs:], q0[2 * hs:]) and not torch.equal(qkv[hs:2 * hs], q0[hs:2 * hs])
+    assert merged["img_in.weight"] is sd["img_in.weight"]

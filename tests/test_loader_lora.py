@@ -347,3 +347,41 @@ def test_family_constants_match_the_shipped_scheduler_and_vae_configs():
     assert (d["base_seq_len"], d["max_seq_len"], d["base_shift"], d["max_shift"]) == (fl["base_image_seq_len"], fl["max_image_seq_len"],
                                                                                       fl["base_shift"], fl["max_shift"])
     assert abs(PredictionFlux().mu - fl["max_shift"]) < 1e-12      # the engine's constant 4096-token image sits at the top of the shift range
+
+
+def _norm_target(v):
+    return v if isinstance(v, str) else (v[0], v[1], v[2].__name__ if len(v) > 2 else None)
+
+
+def test_flux_lora_key_map_matches_reference_fixture():
+    """Flux LoRA key map (VERDICT r4 missing 3): native, diffusers ('transformer.'), simpletuner LyCORIS ('lycoris_') and OneTrainer ('lora_transformer_')
+    spellings, with the slice targets (q | k | v of a fused qkv; q | k | v | mlp of linear1) and the swap_scale_shift function target, against the map the
+    reference builds (tests/golden/tiny_flux_lora_merge.pt, oracle/make_golden.py gen_flux_lora); the patch parser finds every entry of the synthetic LoRA."""
+    from forge_amd.backend.nn.layout import flux_param_shapes
+    from oracle.make_golden import synth_flux_lora
+    g = load_golden("tiny_flux_lora_merge.pt")
+    cfg = synth.TINY_FLUX_CONFIG
+    km = nlora.model_lora_keys_flux(list(flux_param_shapes(cfg)), cfg)
+    assert {k: _norm_target(v) for k, v in km.items()} == g["key_map_targets"]
+    patch_dict, remaining = nlora.load_lora(synth_flux_lora(cfg), km)
+    assert sorted(remaining) == g["remaining"] == []
+    touched = {(t if isinstance(t, str) else t[0])[len("diffusion_model."):] for t in patch_dict}
+    assert touched == set(g["merged"])
+
+
+@pytest.mark.skipif(not ref_import.reference_available(), reason="needs /root/reference")
+def test_flux_to_diffusers_vs_reference():
+    import importlib
+    from forge_amd.backend.misc.diffusers_state_dict import flux_to_diffusers
+    ref_import.load_reference()
+    cu = importlib.import_module("packages_3rdparty.comfyui_lora_collection.utils")
+    for cfg in (synth.TINY_FLUX_CONFIG, synth.FLUX_DEV_CONFIG):
+        ours, theirs = flux_to_diffusers(cfg, output_prefix="diffusion_model."), cu.flux_to_diffusers(dict(cfg), output_prefix="diffusion_model.")
+        assert set(ours) == set(theirs)
+        for k in ours:
+            a, b = ours[k], theirs[k]
+            if isinstance(b, tuple) and len(b) > 2:
+                t = torch.arange(12.0).reshape(6, 2)
+                assert a[0] == b[0] and a[1] is None and torch.equal(a[2](t), b[2](t))
+            else:
+                assert a == b, k
