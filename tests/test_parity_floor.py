@@ -57,6 +57,10 @@ def test_floors_are_fp16_sized():
     network, and far below a percent for one forward / one decode."""
     for k, v in parity.FLOORS.items():
         hi = 1e-1 if k.endswith("@bf16") else 2e-2   # bfloat16 (the reference's Flux compute type) has 8 significand bits
+        if k.startswith("tiny_t5.pt:"):
+            # the reference's T5 squares and averages its RMS-norm statistic IN the 16-bit type (backend/nn/t5.py:21-23) on an un-normalised residual
+            # stream: its own 16-bit run is 2.9e-2 (fp16) / 1.2e-1 (bf16) off its fp32 run -- the native encoder, with fp32 statistics, sits well inside
+            hi = 2e-1 if k.endswith("@bf16") else 5e-2
         assert 2e-4 < v["max_rel"] < hi and v["rms_rel"] <= v["pp_rel"] and v["max_rel"] <= v["pp_rel"] * 1.0001, (k, v)
     assert parity.FLOORS["tiny_sd15_unet_fwd.pt:eps"]["max_rel"] < 4e-3
     assert parity.FLOORS["sd15_config0.pt:latent"]["max_rel"] < 4e-3
