@@ -447,7 +447,33 @@ __global__ __launch_bounds__(256, 2) void attn_q64_kernel(const AttnParams p) {
 //     wave then need ~350 registers (128 accumulator + 64 Q-fragment + 64 score ...), so it runs ONE wave per SIMD on the unified 512-entry
 //     file (__launch_bounds__(256, 1)): nothing overlaps across waves, but a K / V^T fragment read still feeds two MFMAs, where the
 //     32-query generic kernel it replaces is LDS-read-bound (1 read per MFMA; 531 TFLOP/s in the Flux forward).
-template <int THR, int DP>
+// ---- round 5 experiment: a fraction of a tile's exponentials on the PACKED-fp16 vector path instead of the quarter-rate
+//      transcendental unit.  exp2 of two scores at once: x (<= THR, clamped at -15) -> t = x + 1536 (fp16 ulp 1 there: t - 1536 = round(x) = n, and the low
+//      mantissa bits of t ARE 512 + n) -> f = x - n in [-0.5, 0.5] -> degree-3 minimax 2^f (7.5e-5) in three v_pk_fma_f16 -> the exponent add as
+//      bits(poly) + (bits(t) << 10) (512 << 10 wraps to 0 in 16 bits, n << 10 is what is left) -> x a [0, 1] factor clamp(x + 15) that flushes what
+//      would have left fp16's normal range.  ~12 full-rate packed instructions per PAIR of scores against two v_exp_f32 (16.5 issue cycles each).
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+#ifndef FMX_ELEM_BF16
+__device__ __forceinline__ h16x2 pk_exp2(float x0, float x1) {
+  h16x2 x = {(_Float16)x0, (_Float16)x1};
+  const h16x2 lo = {(_Float16)-15.0f, (_Float16)-15.0f}, magic = {(_Float16)1536.0f, (_Float16)1536.0f};
+  const h16x2 zero = {(_Float16)0.0f, (_Float16)0.0f}, one = {(_Float16)1.0f, (_Float16)1.0f}, fifteen = {(_Float16)15.0f, (_Float16)15.0f};
+  const h16x2 xc = __builtin_elementwise_max(x, lo);
+  const h16x2 t = xc + magic;
+  const h16x2 f = xc - (t - magic);
+  const h16x2 c0 = {(_Float16)0.99992807f, (_Float16)0.99992807f}, c1 = {(_Float16)0.69326099f, (_Float16)0.69326099f},
+              c2 = {(_Float16)0.24261112f, (_Float16)0.24261112f}, c3 = {(_Float16)0.05517162f, (_Float16)0.05517162f};
+  h16x2 pl = c3 * f + c2;
+  pl = pl * f + c1;
+  pl = pl * f + c0;
+  const u16x2_t bits = __builtin_bit_cast(u16x2_t, pl) + (__builtin_bit_cast(u16x2_t, t) << (unsigned short)10);
+  const h16x2 keep = __builtin_elementwise_min(__builtin_elementwise_max(x + fifteen, zero), one);
+  return __builtin_bit_cast(h16x2, bits) * keep;
+}
+#endif
+
+template <int THR, int DP, int NPOLY = 0>
 __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void attn_q64v2_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int DSTEPS = DP / 16, DVT = DP / 32;
@@ -657,6 +683,18 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void attn_q64v2_kernel(const
       for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+#ifndef FMX_ELEM_BF16
+          if (NPOLY > 0 && (r >> 1) < NPOLY) {   // (compile time) the first NPOLY pairs of every 16-key group: packed-fp16 polynomial
+            if ((r & 1) == 0) {
+              const h16x2 e2 = pk_exp2(sacc[s][a][r], sacc[s][a][r + 1]);
+              pf[a][s][r >> 3][r & 7] = (f16)e2[0];
+              pf[a][s][r >> 3][(r & 7) + 1] = (f16)e2[1];
+              const float es = (float)e2[0] + (float)e2[1];
+              if (s == 0) ps0 += es; else ps1 += es;
+            }
+            continue;
+          }
+#endif
           const float e = __builtin_amdgcn_exp2f(sacc[s][a][r]);
           // (row sums from the PACKED P through v_dot2c_f32_f16 -- 32 instead of 64 vector instructions per tile, and a denominator made of exactly the
           //  fp16 values the P.V MFMA multiplies -- were measured in round 4 and LOSE: 4096 keys 665 -> 692 us, 1024 keys level, batch 2 114 -> 128 us
@@ -1939,6 +1977,32 @@ int launch_attn_v2(AttnParams p, hipStream_t st) {
     }
     p.nfull = do_split ? grid - rem : grid;
     p.nsplit = do_split ? 2 * rem : 0;
+#ifndef FMX_ELEM_BF16
+    if (DP == 64) {
+      static int npoly = -1;
+      if (npoly < 0) {
+        // A/B knob (development only): pairs per 16-key group whose exponentials run as the packed-fp16 polynomial (0 = none, the default; 2 = a
+        // quarter, 3, 4 = half).  Measured and NOT adopted: profiles/r29_attention_packed_polynomial_exp2.jsonl -- every share is SLOWER
+        // (4096 keys, hot: 671 us with v_exp_f32 only, 750 / 797 / 826 us with 2 / 3 / 4 pairs on the polynomial): the packed sequence costs
+        // 8 VALU issues per pair (range shift, 3 pk_fma, pk_add magic, pk_lshl, pk_mul, clamp) against 2 quarter-rate transcendentals that
+        // already overlap with the MFMA pipe, so the kernel's limiter is VALU issue slots, not the transcendental unit.
+        const char* e8 = fmx_knob("FMX_ATTN_POLY");
+        npoly = e8 ? atoi(e8) : 0;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_q64v2_kernel<6, 64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_q64v2_kernel<6, 64, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_q64v2_kernel<6, 64, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * smem);
+      }
+      if (npoly >= 2 && npoly <= 4) {
+        const dim3 g(p.nfull + p.nsplit);
+        const size_t sm = do_split ? 2 * smem : smem;
+        if (npoly == 2) hipLaunchKernelGGL((attn_q64v2_kernel<6, 64, 2>), g, dim3(256), sm, st, p);
+        else if (npoly == 3) hipLaunchKernelGGL((attn_q64v2_kernel<6, 64, 3>), g, dim3(256), sm, st, p);
+        else hipLaunchKernelGGL((attn_q64v2_kernel<6, 64, 4>), g, dim3(256), sm, st, p);
+        FMX_LAUNCH_CHECK("fmx_attention_f16 (packed-polynomial exp2)");
+        return FMX_OK;
+      }
+    }
+#endif
     hipLaunchKernelGGL((attn_q64v2_kernel<6, DP>), dim3(p.nfull + p.nsplit), dim3(256), do_split ? 2 * smem : smem, st, p);
   } else if (DP == 64) {
     hipLaunchKernelGGL(attn_q64_kernel<0>, dim3(grid), dim3(256), smem, st, p);

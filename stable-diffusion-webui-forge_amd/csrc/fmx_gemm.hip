@@ -761,7 +761,7 @@ static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, i
                 "gemm: output statistics need a dense fp16 [M][nout] output without activation / gate");
     FMX_REQUIRE(fallback_chunks >= 1 && fallback_chunks <= 1024 && max_chunks >= fallback_chunks, "gemm: bad statistics chunk counts");
     // (round 5) the 128-row 4-wave tiles emit them too -- the small-batch launches, whose tensors used to get a gn_stats pass of their own
-    const bool rows128 = (sel == 0 || sel == 1 || sel >= 10) && FastEpilogue::eligible(p);
+    const bool rows128 = (sel == 0 || sel == 1 || sel == 10 || sel == 11 || sel == 12) && FastEpilogue::eligible(p);   // the 128-ROW tiles (not 64 x 160 / 160 x 64)
     const int rows = sel == 8 ? 512 : rows128 ? 128 : 256;
     if ((sel == 5 || sel == 6 || sel == 8 || rows128) && (per_img % rows) == 0 && per_img / rows <= max_chunks) {
       p.stats = stats;

@@ -137,8 +137,20 @@ def test_a_batch_too_large_for_one_arena_is_decoded_in_groups_of_whole_images(mo
     monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (int(2.2 * per / 0.8), 1 << 40))    # room for two images
     vae._arena = None
     assert vae._image_groups(6, 16, 16) == 2
-    assert torch.equal(vae.decode(z), whole) and torch.equal(vae.decode_inner(z), whole_inner)
+
+    def same(a, b):
+        """Until round 4 the grouped decode was bit-identical to the one-arena decode.  Since round 5 the GEMM dispatcher prices small launches on their own
+        (another tile for 2 images than for 6) and the 4-wave tiles emit the GroupNorm statistics themselves in 128-row chunks: the same per-image sums in
+        another order, so a group may differ from the whole batch in the last bits -- as any two batch sizes of the UNet always could."""
+        return float((a.float() - b.float()).abs().max()) <= 2e-3 * float(b.float().abs().max())
+    assert same(vae.decode(z), whole) and same(vae.decode_inner(z), whole_inner)
     monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (int(4.5 * per / 0.8), 1 << 40))    # room for four: 6 is split as 3 + 3
     vae._arena = None
     assert vae._image_groups(6, 16, 16) == 3
-    assert torch.equal(vae.decode(z), whole)
+    assert same(vae.decode(z), whole)
+    # ADVICE r4: latents that already have the VAE's element type make `.to(z.dtype)` a no-copy -- every group's result used to be a view of the ONE arena
+    # the next group overwrites.  Groups of distinct images must come back distinct and equal to the one-arena decode.
+    zh = z.half()
+    got = vae.decode(zh)
+    assert got.dtype == torch.float16 and same(got, whole)
+    assert not same(got[:3], got[3:]), "the two groups hold different images"

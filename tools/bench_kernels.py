@@ -517,6 +517,28 @@ if __name__ == "__main__":
         for b, n in ((8, 16384), (8, 4096), (1, 16384), (2, 1024)):
             bench_attn512(b, n)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "attnpoly":
+        # round 5: attn_q64v2 with a fraction of its exponentials as a packed-fp16 polynomial (FMX_ATTN_POLY = pairs per 16-key group, read once per process):
+        # time at 4096 / 1024 keys and the error against fp32 softmax attention on peaked and flat score distributions
+        import os
+        bench_attn(16, 10, 4096, 4096, 64, 64)
+        bench_attn(16, 20, 1024, 1024, 64, 64)
+        bench_attn(16, 10, 4096, 4096, 64, 64)
+        bench_attn(16, 20, 1024, 1024, 64, 64)
+        for name, qs in (("peaked (|q| = 1)", 1.0), ("flat (|q| = 0.1)", 0.1)):
+            g = torch.Generator().manual_seed(1)
+            b, h, n, d = 2, 4, 1024, 64
+            q, k, v = (torch.randn(b, n, h * d, generator=g) for _ in range(3))
+            q = (q * qs).half().to(DEV); k = k.half().to(DEV); v = v.half().to(DEV)
+            vt = v.view(b * n, h, d).permute(1, 2, 0).reshape(h * d, b * n).contiguous()
+            o = ops.attention(q.view(b * n, h * d), k.view(b * n, h * d), vt, batch=b, heads=h, nq=n, nk=n, nk_pad=n, dpad=d, scale=d ** -0.5, q_bs=n * h * d, q_rs=h * d,
+                              k_bs=n * h * d, k_rs=h * d, vt_bs=n, vt_hs=d * b * n, vt_ds=b * n)
+            qf, kf, vf = (t.float().view(b, n, h, d).permute(0, 2, 1, 3) for t in (q, k, v))
+            ref = torch.softmax(qf @ kf.transpose(-1, -2) * d ** -0.5, -1) @ vf
+            got = o.view(b, n, h, d).permute(0, 2, 1, 3).float()
+            print(json.dumps({"poly": os.environ.get("FMX_ATTN_POLY", "0"), "scores": name, "rms_rel_vs_fp32": float(((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())),
+                              "max_rel_vs_fp32": float((got - ref).abs().max() / ref.abs().max())}), flush=True)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "attn":
         for f32 in (True, False):
             bench_attn(16, 10, 4096, 4096, 64, 64, f32)
