@@ -23,6 +23,7 @@ tests/parity.py turns that into the tolerances of the native path (max(1e-3, fac
     python -m oracle.make_floor --only vae1024  # 1024^2 decode only (fixture + floor)
     python -m oracle.make_floor --only flux_width # fixture flux_width3072_fwd.pt: Flux at hidden 3072 / 24 x 128 / 4096 + 256 tokens, 1 + 1 blocks, + its f16 / bf16 floors
     python -m oracle.make_floor --only flux_depth # fixture flux_depth4x8_fwd.pt: the same width with 4 double + 8 single blocks (2.5 B parameters), + its f16 / bf16 floors
+    python -m oracle.make_floor --only flux_full  # fixture flux_full_depth_fwd.pt: Flux.1-dev at full depth (19 + 38 blocks, 11.9 B parameters, needs ~55 GB of host memory), + its bf16 / f16 floors
     python -m oracle.make_floor --only vae_bf16 # bfloat16 floors of the VAE fixtures + the fp16-overflow fixture tiny_vae_overflow.pt
 """
 import argparse
@@ -450,6 +451,64 @@ def gen_flux_depth():
     update(floors)
 
 
+def gen_flux_full(only_floor=None):
+    """Flux.1-dev at FULL depth (round 5, VERDICT r4 missing 4): 19 double-stream + 38 single-stream blocks, hidden 3072, 24 x 128 -- 11.9 B parameters --
+    on BASELINE config 5's token counts (4096 image + 256 text), one forward of the REAL reference on CPU fp32 and its own bf16 / fp16 runs as
+    floors.  The 48 GB of fp32 weights never exist twice: the reference module is built on the meta device, materialised empty and filled tensor
+    by tensor from the seeded stream (`synth.LazySynthStateDict`); the native side loads from the same lazy mapping.  Fixture
+    tests/golden/flux_full_depth_fwd.pt (the 1 MB output; inputs and weights come back from seeds)."""
+    from forge_amd.backend.nn.layout import flux_param_shapes
+    cfg = dict(synth.FLUX_DEV_CONFIG)
+    shapes = flux_param_shapes(cfg)
+    ref = ref_import.load_reference()
+    t0 = time.time()
+    with torch.device("meta"):
+        net = ref.nn_flux.IntegratedFluxTransformer2DModel(**cfg)
+    net = net.to_empty(device="cpu")
+    lazy = synth.LazySynthStateDict(shapes, seed=2)
+    own = dict(net.named_parameters())
+    assert set(own) == set(shapes), (sorted(set(own) ^ set(shapes))[:8])
+    assert not [n for n, b in net.named_buffers()], "a buffer would stay uninitialised"
+
+    def fill():
+        with torch.no_grad():
+            for name, prm in own.items():
+                prm.copy_(lazy[name])
+
+    fill()
+    net.storage_dtype = net.computation_dtype = torch.float32
+    net.load_device = net.offload_device = net.initial_device = torch.device("cpu")
+    net.eval()
+    nparams = sum(int(v.numel()) for v in own.values())
+    print("flux full depth: %.3f B parameters filled in %.0f s" % (nparams / 1e9, time.time() - t0), flush=True)
+    x, t, ctx, y, guid = flux_width_inputs(cfg)
+    path = os.path.join(GOLD, "flux_full_depth_fwd.pt")
+    if only_floor is None:
+        t0 = time.time()
+        with torch.no_grad():
+            out = net(x.clone(), t, context=ctx, y=y, guidance=guid)
+        secs = time.time() - t0
+        torch.save({"out": out, "inputs_seed": 33, "weights_seed": 2, "depth": cfg["depth"], "depth_single_blocks": cfg["depth_single_blocks"],
+                    "cpu_seconds": secs, "params": nparams}, path)
+        print("flux %d + %d blocks: reference fp32 %.0f s, out std %.4f" % (cfg["depth"], cfg["depth_single_blocks"], secs, float(out.std())), flush=True)
+    else:
+        out = torch.load(path)["out"]
+    for tag, dt in (("bf16", torch.bfloat16), ("f16", torch.float16)):
+        if only_floor not in (None, tag):
+            continue
+        t0 = time.time()
+        if next(net.parameters()).dtype != torch.float32:      # rounded by the previous floor run: widen and draw the fp32 values again
+            net.to(torch.float32)
+            fill()
+        n2 = net.to(dt)
+        n2.storage_dtype = n2.computation_dtype = dt
+        with torch.no_grad():
+            o = n2(x.to(dt), t, context=ctx.to(dt), y=y.to(dt), guidance=guid).float()
+        m = metrics(o, out)
+        update({f"flux_full_depth_fwd.pt:out@{tag}": m})
+        print("  %s run done in %.0f s: %s" % (tag, time.time() - t0, m), flush=True)
+
+
 def floors_sdxl_full():
     cfg = synth.SDXL_UNET_CONFIG
     g = _load("sdxl_full_fwd.pt")
@@ -663,6 +722,10 @@ def main():
         gen_vae_bf16()
     if a.only == "flux_width":
         gen_flux_width()
+    if a.only == "flux_full":
+        gen_flux_full()
+    if a.only == "flux_full_f16":
+        gen_flux_full(only_floor="f16")
     if a.only == "flux_depth":
         gen_flux_depth()
     if a.only == "config3":

@@ -704,10 +704,15 @@ static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, i
   const bool ring_ok = fits32 && ring_mode != 0;
   if (ring_ok) {
     // fitted to tools/bench_kernels.py ring (profiles/r20_ring_vs_two_stage_microbench.jsonl; in a graph, cold weights): a K-tile costs the ring
-    // 0.60 / 0.72 / 0.43 us on the 128x128 / 128x160 / 128x64 tile (2-stage forms: 0.9-1.0 / - / 0.8) -- LDS-bound from here on: a 64 x 64 wave tile
-    // with one wave per SIMD needs the LDS's whole 128 B / clk at the MFMA rate -- and a launch 12-14 K-tiles' worth of fixed time (dispatch, first
-    // tile's round trip, epilogue); a 3x3 convolution's address arithmetic slows the K-tile by a quarter.  Neither more stages (5 / 6: level or
-    // worse) nor hot weights (19.7 vs 21.0 us) move it.
+    // 0.60 / 0.72 / 0.43 us on the 128x128 / 128x160 / 128x64 tile (2-stage forms: 0.9-1.0 / - / 0.8) and a launch 12-14 K-tiles' worth of fixed time
+    // (dispatch, first tile's round trip, epilogue); a 3x3 convolution's address arithmetic slows the K-tile by a quarter.  Neither more stages (5 / 6:
+    // level or worse) nor hot weights (19.7 vs 21.0 us) move it.  What bounds the K-tile is the CU's LDS-DMA INGEST, not the LDS reads or the MFMA
+    // pipe: a K-tile is (BM + BN) / 8 one-KiB pieces per CU (32 / 36 / 24 / 28 on 128x128 / 128x160 / 128x64 / 64x160), a CU takes a piece per ~13 ns
+    // beside MFMA waves (tools/ubench/dma_rate.hip, profiles/r02b: 10.4 ns alone) = 0.42 / 0.48 / 0.32 / 0.37 us, and every tile sits at 1.35-1.4 x
+    // that.  Hand-ordering the fragment reads (all of a k-step requested behind the barrier, the LDS-DMA issue under their latency, counted lgkmcnt
+    // waits, k-step 1 under k-step 0's MFMAs -- the compiler's own order exposes ~600 cycles of LDS latency per K-tile) was built and measured:
+    // linear launches 0-5 % SLOWER, convolutions -3 % .. +5 %, steps level (profiles/r30_ring_ordered_fragment_reads_negative_result.jsonl) -- the
+    // latency it hides was never on the critical path.  Fewer bytes per FLOP needs a bigger tile, which a small-M launch cannot fill the chip with.
     if (ring_mode == 2) best = 1e300;
     auto cost_ring = [&](int bm, int bn, int S) {
       // (64 x 160, id 14: a K-tile 0.51 us, 13 K-tiles fixed -- N = 1280 at M = 2048 is 256 tiles of it, one per CU, where 128 x 128 leaves 96 CUs idle:

@@ -18,6 +18,7 @@ from forge_amd.modules import processing, shared  # noqa: E402
 from forge_amd.modules.prompt_parser import DictWithShape  # noqa: E402
 
 from conftest import load_golden  # noqa: E402
+import parity  # noqa: E402
 from parity import check  # noqa: E402
 from test_gpu_kernels import close, rnd  # noqa: E402
 
@@ -255,6 +256,43 @@ def test_flux_forward_at_its_own_width_with_depth_vs_reference_fixture(dt, tag):
           floor=f"flux_depth4x8_fwd.pt:out@{tag}")
     del net
     torch.cuda.empty_cache()
+
+
+def test_flux_forward_at_full_depth_vs_reference_fixture():
+    """Flux.1-dev as BASELINE config 5 runs it: all 19 double-stream + 38 single-stream blocks (11.9 B parameters), 4096 image + 256 text tokens -- one forward
+    of the REAL reference (CPU fp32, oracle/make_floor.py gen_flux_full) against the native executor in bf16 (the reference's own type for Flux) and fp16, each
+    held against the reference's own run in that type.  Weights come from the seeded stream on both sides, cast per tensor (the 48 GB fp32 form never exists as a whole)."""
+    import os
+    import time
+    from conftest import GOLDEN
+    if not os.path.exists(os.path.join(GOLDEN, "flux_full_depth_fwd.pt")):
+        pytest.skip("full-depth fixture not generated")
+    from forge_amd.backend.nn.layout import flux_param_shapes
+    from oracle.make_floor import flux_width_inputs
+    g = load_golden("flux_full_depth_fwd.pt")
+    cfg = dict(synth.FLUX_DEV_CONFIG)
+    assert (cfg["depth"], cfg["depth_single_blocks"]) == (g["depth"], g["depth_single_blocks"]) == (19, 38)
+    shapes = flux_param_shapes(cfg)
+    x, t, ctx, y, guid = flux_width_inputs(cfg, seed=g["inputs_seed"])
+    ran = []
+    for dt, tag in ((torch.bfloat16, "bf16"), (torch.float16, "f16")):
+        if f"flux_full_depth_fwd.pt:out@{tag}" not in parity.FLOORS:
+            continue
+        t0 = time.time()
+        sd = synth.synth_state_dict_threaded(shapes, seed=g["weights_seed"], dtype=dt)       # 24 GB of host memory
+        net = IntegratedFluxTransformer2DModel(cfg, sd, device=DEV, dtype=dt)
+        del sd
+        t1 = time.time()
+        out = net.forward(x.to(DEV), t.to(DEV), ctx.to(DEV, dt), y.to(DEV, dt), guid.to(DEV))
+        torch.cuda.synchronize()
+        print(f"flux full depth {tag}: weights drawn and loaded in {t1 - t0:.0f} s, first forward {time.time() - t1:.1f} s")
+        assert tuple(out.shape) == tuple(g["out"].shape)
+        check(f"flux forward at full depth (19 + 38 blocks, 11.9 B parameters, 4096 + 256 tokens), {tag} build vs reference", out, g["out"],
+              floor=f"flux_full_depth_fwd.pt:out@{tag}")
+        ran.append(tag)
+        del net, out
+        torch.cuda.empty_cache()
+    assert "bf16" in ran
 
 
 def test_bf16_flux_forward_and_sampling_vs_reference_fixture():

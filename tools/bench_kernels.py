@@ -464,6 +464,23 @@ if __name__ == "__main__":
                 bench_conv(nb, hw, hw, c, co, 0)
             os.environ.pop("FMX_GEMM_RING", None)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "ringord":
+        # round 5: every ring tile (force_tile 11..15) on the small-M shapes, one process per FMX_RING_ORDERED setting (the knob is read once)
+        import os
+        os.environ["FMX_GEMM_SPLITK"] = "0"
+        tag = {"FMX_RING_ORDERED": os.environ.get("FMX_RING_ORDERED", "default")}
+        for m, n, k in ((2048, 1280, 1280), (2048, 1280, 5120), (2048, 2560, 1280), (1280, 2048, 1280), (8192, 640, 640), (8192, 640, 2560), (512, 1280, 1280),
+                        (4096, 1280, 1280), (32768, 320, 320), (32768, 320, 1280)):
+            for tile in (11, 12, 13, 14, 15, 0):
+                if tile == 12 and n % 160:
+                    continue
+                print(json.dumps(tag), end=" ")
+                bench_linear_cold(m, n, k, tile)
+        for (n, hw, c, co) in ((2, 32, 1280, 1280), (2, 64, 640, 640), (8, 8, 1280, 1280), (8, 16, 1280, 1280), (2, 128, 320, 320)):
+            for tile in (11, 12, 13, 14, 0):
+                print(json.dumps(tag), end=" ")
+                bench_conv_cold(n, hw, hw, c, co, tile, stats=True)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "tile14":
         import os
         os.environ["FMX_GEMM_SPLITK"] = "0"
