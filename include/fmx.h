@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define FMX_ABI_VERSION 9
+#define FMX_ABI_VERSION 10
 
 #define FMX_OK 0
 #define FMX_E_BADARG 10001   /* shape / alignment / null-pointer contract violated */
@@ -141,6 +141,25 @@ typedef struct fmx_gemm_args {
   /* optional output of an ln_partial (consumer) GEMM: the {rstd, -mean * rstd} pairs it derived for its input rows, [M][2] fp32 -- what
    * fmx_layernorm_rowstats_finalize computes, for the operand-swapped GEMM that follows on the same rows (q|k projection -> V^T projection) */
   void* ln_ab_out;
+  /* Cross-attention as the EPILOGUE of the query projection (ABI 10; backend/nn/unet.py:145-155 CrossAttention.forward + :254-267, the attn2 of a
+   * BasicTransformerBlock: q = to_q(norm2(x)), out = softmax(q k^T / sqrt(d)) v against the text context's cached K / V^T).  With xa_k set, an
+   * ln_partial (LayerNorm-consumer) GEMM does not store Q: a 256 x 320 tile of Q holds five whole 64-wide heads of 256 queries of ONE image; after
+   * the K loop the tile's K / V^T rows (xa_nk <= 80 keys x 320 columns) are staged in the idle LDS, S = K Q^T, a one-pass softmax and O = V^T P^T
+   * run per head out of the accumulators (Q rounded to fp16 and pre-scaled exactly as fmx_attention_f16 does), and `out` receives O [M][nout].
+   *   xa_k  [images * xa_k_bs rows][xa_k_rs] fp16: K of the context, row = key, head h at columns h*64 .. (rows >= xa_nk are never read beyond key 79)
+   *   xa_vt [nout rows][xa_vt_ds] fp16: V^T, row = head h * 64 + d, image i's keys at columns i * xa_vt_bs ..
+   * Linear only, act NONE, bias optional, no residual / rowvec / gate, fp16 output; d_head 64; nout % 320 == 0; xa_rows (queries per image) % 256
+   * == 0 and M % xa_rows == 0; always the 256 x 320 tile.  fp16 build only. */
+  const void* xa_k;
+  const void* xa_vt;
+  int32_t xa_k_rs;   /* elements between keys in xa_k (= heads * 64) */
+  int32_t xa_k_bs;   /* key ROWS per image in xa_k (the padded token count) */
+  int32_t xa_vt_ds;  /* elements between rows of xa_vt (= images * padded token count) */
+  int32_t xa_vt_bs;  /* elements (keys) between images in a row of xa_vt */
+  int32_t xa_nk;     /* keys per image, 1..80 */
+  int32_t xa_rows;   /* queries per image */
+  float xa_scale;    /* softmax scale (d_head^-0.5) */
+  int64_t xa_k_bytes, xa_vt_bytes;   /* extents of the two tensors (buffer descriptors) */
 } fmx_gemm_args;
 
 int fmx_gemm_conv_f16(const fmx_gemm_args* args /* host */, void* stream);

@@ -58,6 +58,8 @@ class GemmArgs(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("ln_partial", C.c_void_p), ("ln_parts", C.c_int32), ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float),
         ("ln_col_ab", C.c_void_p), ("ln_row_cb", C.c_void_p), ("ln_ab_out", C.c_void_p),
+        ("xa_k", C.c_void_p), ("xa_vt", C.c_void_p), ("xa_k_rs", C.c_int32), ("xa_k_bs", C.c_int32), ("xa_vt_ds", C.c_int32), ("xa_vt_bs", C.c_int32),
+        ("xa_nk", C.c_int32), ("xa_rows", C.c_int32), ("xa_scale", C.c_float), ("xa_k_bytes", C.c_int64), ("xa_vt_bytes", C.c_int64),
     ]
 
 
@@ -221,7 +223,7 @@ def lib():
             handle.fmx_build_info.restype = C.c_char_p
         except AttributeError as e:
             raise FmxError(f"symbol fmx_build_info missing from {LIB_PATH}") from e
-        if handle.fmx_abi_version() != 9:
+        if handle.fmx_abi_version() != 10:
             raise FmxError("libfmx ABI version mismatch")
         _lib = handle
     return _lib

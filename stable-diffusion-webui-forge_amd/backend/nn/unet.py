@@ -83,6 +83,10 @@ class GroupNorm(_Layer):
 
 _LN_FOLD = _knob("FMX_LN_FOLD", "1") != "0"   # A/B knob: 0 keeps the LayerNorm kernels in front of attn2.to_q / ff.net.0
 _LN_FOLD1 = _knob("FMX_LN_FOLD1", "1") != "0"  # A/B knob: 0 keeps norm1 as a kernel (round 2) while norm2 / norm3 stay folded
+# A/B knob (round 5): 1 runs attn2 as ONE launch where the fused epilogue is eligible (csrc/fmx_gemm256p.hip XA).  Default 0: built, correct, and measured
+# slower (SDXL batch 8: 102.4 -> 104.9 ms per step, profiles/r32_cross_attention_in_to_q_epilogue_ab.jsonl) -- the 77-key attention is vector-issue work,
+# not a memory pass the fusion deletes
+_XATTN_FUSE = _knob("FMX_XATTN_FUSE", "0") == "1"
 
 
 def _fold_layernorm(wt, bias, gamma, beta):
@@ -421,17 +425,24 @@ class IntegratedUNet2DConditionModel:
         self._tap(b + ".attn1", h.view(bu, n, -1))
         self.fold_trace[b] = (folded1, bool(fold and rs2.parts), False)
         # cross attention against the cached text K / V^T
-        if fold and rs2.parts:
-            wq, csq, bq = self.w[b + ".attn2.q.ln"]
-            q2 = ops.conv_gemm(h, wq, wq.shape[0], bias=bq, ln=(rs2, csq, 1e-5))
-        else:
-            n2 = ops.layernorm(h, *self.w[b + ".norm2"])
-            q2 = ops.linear(n2, self.w[b + ".attn2.q"])
         kc, vtc = ctxc.kv[b]
         tp = ctxc.tpad
-        self._tap_qkv(b + ".attn2", q2.view(bu, n, hd), kc.view(bu, tp, hd)[:, :ctxc.tokens], vtc.view(hd, bu, tp)[:, :, :ctxc.tokens])
-        o2 = ops.attention(q2, kc, vtc, batch=bu, heads=H, nq=n, nk=ctxc.tokens, nk_pad=tp, dpad=dp, scale=d ** -0.5,
-                           q_bs=n * hd, q_rs=hd, k_bs=tp * hd, k_rs=hd, vt_bs=tp, vt_hs=dp * bu * tp, vt_ds=bu * tp)
+        # (round 5, off by default -- see _XATTN_FUSE) the whole of attn2 in ONE launch: a 256 x 320 tile of the query projection holds five whole 64-wide heads
+        # of 256 queries of one image, so the attention against the cached K / V^T runs in that GEMM's epilogue out of the accumulators (fmx.h xa_*)
+        fused2 = (_XATTN_FUSE and fold and bool(rs2.parts) and self.tap is None and d == 64 and hd % 320 == 0 and n % 256 == 0 and ctxc.tokens <= 80 and tp >= 80)
+        if fused2:
+            wq, csq, bq = self.w[b + ".attn2.q.ln"]
+            o2 = ops.conv_gemm(h, wq, wq.shape[0], bias=bq, ln=(rs2, csq, 1e-5), xattn=(kc, vtc, ctxc.tokens, tp, n, d ** -0.5))
+        else:
+            if fold and rs2.parts:
+                wq, csq, bq = self.w[b + ".attn2.q.ln"]
+                q2 = ops.conv_gemm(h, wq, wq.shape[0], bias=bq, ln=(rs2, csq, 1e-5))
+            else:
+                n2 = ops.layernorm(h, *self.w[b + ".norm2"])
+                q2 = ops.linear(n2, self.w[b + ".attn2.q"])
+            self._tap_qkv(b + ".attn2", q2.view(bu, n, hd), kc.view(bu, tp, hd)[:, :ctxc.tokens], vtc.view(hd, bu, tp)[:, :, :ctxc.tokens])
+            o2 = ops.attention(q2, kc, vtc, batch=bu, heads=H, nq=n, nk=ctxc.tokens, nk_pad=tp, dpad=dp, scale=d ** -0.5,
+                               q_bs=n * hd, q_rs=hd, k_bs=tp * hd, k_rs=hd, vt_bs=tp, vt_hs=dp * bu * tp, vt_ds=bu * tp)
         self._tap(b + ".attn2.o", o2.view(bu, n, -1))
         ops.linear(o2, *self.w[b + ".attn2.out"], residual=h, out=h, ld_out=h.shape[1], row_stats=rs3)
         arena.release(mk)

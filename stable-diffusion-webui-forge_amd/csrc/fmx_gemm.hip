@@ -610,6 +610,10 @@ static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, i
   p.ln_eps = p.ln_inv_c = 0.f;
   p.ln_col_ab = p.ln_row_cb = nullptr;
   p.ln_ab_out = nullptr;
+  p.xa_k = p.xa_vt = nullptr;
+  p.xa_k_rs = p.xa_k_bs = p.xa_vt_ds = p.xa_vt_bs = p.xa_nk = p.xa_rows = 0;
+  p.xa_k_bytes = p.xa_vt_bytes = 0;
+  p.xa_c2 = 0.f;
   FMX_REQUIRE(fmx_aligned16(p.a0) && fmx_aligned16(p.wgt) && fmx_aligned16(p.zp) && (!p.a1 || fmx_aligned16(p.a1)), "gemm: operands must be 16-byte aligned");
   FMX_REQUIRE((p.s0 % 8) == 0 && (p.s1 % 8) == 0 && (p.ldw % 8) == 0, "gemm: strides must be multiples of 8 elements");
   FMX_REQUIRE((long)p.M * 1 > 0 && (long)a->n * a->oh * a->ow < (1L << 31), "gemm: M overflow");
@@ -800,6 +804,23 @@ static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, i
     p.ln_ab_out = (float*)a->ln_ab_out;
     if (sel != 9) sel = 6;
     best_s = 1;
+  }
+  if (a->xa_k) {   // cross-attention as the epilogue of this (query) projection
+#ifdef FMX_ELEM_BF16
+    FMX_REQUIRE(false, "gemm: the cross-attention epilogue exists in the fp16 build only");
+#endif
+    FMX_REQUIRE(a->ln_partial && a->act == FMX_ACT_NONE && !row_parts_out && a->xa_vt && (p.nout % 320) == 0 && a->xa_rows > 0 && (a->xa_rows % 256) == 0 &&
+                    (p.M % a->xa_rows) == 0 && a->xa_nk >= 1 && a->xa_nk <= 80 && a->xa_k_bs >= 80 && a->xa_vt_bs >= 80 && a->xa_k_rs >= p.nout && (a->xa_k_rs % 8) == 0 &&
+                    (a->xa_vt_ds % 8) == 0 && (a->xa_vt_bs % 8) == 0 && fmx_aligned16(a->xa_k) && fmx_aligned16(a->xa_vt) && a->xa_k_bytes > 0 &&
+                    a->xa_k_bytes < 0xC0000000ll && a->xa_vt_bytes > 0 && a->xa_vt_bytes < 0xC0000000ll && !a->ln_ab_out && a->alpha == 1.0f,
+                "gemm: the cross-attention epilogue takes a LayerNorm-consumer query projection (256x320 tile): nout %% 320 == 0, queries per image %% 256 == 0, 1..80 keys, "
+                "K rows / V^T columns padded to >= 80 keys per image, 16-byte aligned K / V^T with strides %% 8 == 0");
+    p.xa_k = (const f16*)a->xa_k;
+    p.xa_vt = (const f16*)a->xa_vt;
+    p.xa_k_rs = a->xa_k_rs; p.xa_k_bs = a->xa_k_bs; p.xa_vt_ds = a->xa_vt_ds; p.xa_vt_bs = a->xa_vt_bs; p.xa_nk = a->xa_nk; p.xa_rows = a->xa_rows;
+    p.xa_k_bytes = (unsigned)a->xa_k_bytes; p.xa_vt_bytes = (unsigned)a->xa_vt_bytes;
+    p.xa_c2 = a->xa_scale * 1.4426950408889634f;
+    sel = 6;
   }
   if (a->ln_col_ab) {
     FMX_REQUIRE(!a->ln_partial && !row_parts_out && ln_shape_ok && !p.residual && !p.bias && !stats && a->act == FMX_ACT_NONE && a->ln_row_cb &&

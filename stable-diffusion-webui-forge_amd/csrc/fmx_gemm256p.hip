@@ -79,7 +79,8 @@ struct Geo {
 //   parity bits ride in the mask word (bits 9, 10) and a piece costs 7 vector instructions instead of ~15.
 //   (The same form for the TWO-SOURCE convolutions of the decoder -- pixel index x the K-tile's source stride -- was measured in round 4 and changes nothing:
 //   102.82 vs 102.83 ms per step, every two-source shape within 1 %: those launches have K >= 5760 and hide the address arithmetic.  Not kept.)
-template <bool CONV, int BM, int BN, bool STATS = false, int SCHED = 0, int LN = 0, int MF = 32, int FA = 0>
+// XA (round 5): cross-attention against the text context as the EPILOGUE of the query projection (fmx.h xa_*), see the block behind the K loop.
+template <bool CONV, int BM, int BN, bool STATS = false, int SCHED = 0, int LN = 0, int MF = 32, int FA = 0, bool XA = false>
 __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   using G = Geo<BM, BN>;
   constexpr int MI = G::MI, NJ = G::NJ, NPA = G::NPA, NPB = G::NPB, NP = G::NP;
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   // of its K-tile 1.  The stage that holds the prefetched K-tile is whichever is next in the alternation ((kt + s0) & 1, so a tile starts on
   // stage s0 = 0 or 1), and the epilogue's transpose slices (16 rows x NJ*32 fp32 = XSL bytes per wave with this loop; GEGLU in two halves of 32
   // rows) are laid around it: above stage 0, or below stage 1 with the eighth slice above it.
-  constexpr bool XT = !CONV && !STATS && MF == 16 && BM == 256 && BN == 320;
+  constexpr bool XT = !XA && !CONV && !STATS && MF == 16 && BM == 256 && BN == 320;   // (XA: the epilogue needs the whole LDS)
   constexpr int XSL = NJ * 2048;
   static_assert(!XT || (G::LDS_BYTES - 8 * XSL >= STAGE_BYTES && 7 * XSL <= STAGE_BYTES && 2 * STAGE_BYTES + XSL <= G::LDS_BYTES), "slices fit around one stage");
   int xs0 = 0;          // stage of this tile's K-tile 0
@@ -528,6 +529,225 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
       if (mrow < p.M) *reinterpret_cast<f32x2*>(p.ln_ab_out + (long)mrow * 2) = f32x2{lnr, -lnm * lnr};
     }
   }
+#ifndef FMX_ELEM_BF16
+  if constexpr (XA) {
+    // ---- cross-attention out of the accumulators (reference backend/nn/unet.py:145-155, 254-267) -----------------------------------
+    // The tile is Q[256 queries of ONE image][320 columns = 5 heads of 64]; this wave holds 64 queries x 160 columns = 2.5 heads: lane (l16, kg) has, of
+    // every 16 x 16 accumulator block (i, j), query i*16 + l16 and columns j*16 + kg*4 + [0, 4).  That IS the B-operand layout of the next MFMA up to a
+    // permutation of its contraction index: two column blocks side by side give a lane 8 values at d = {4 kg + [0,4)} u {16 + 4 kg + [0,4)} of a 32-wide
+    // d step, and a contraction does not care about the order of its index as long as the other operand uses the same one -- so the K fragments are read
+    // from LDS in that order (two 8-byte reads instead of one 16-byte read) and Q never leaves the registers.  S^T = K Q^T comes out as lane = (query
+    // l16, keys 4 kg + [0,4) of key block kb): the same trick gives P^T as the B operand of O^T = V^T P^T (key blocks paired for 16x16x32, the fifth
+    // block through 16x16x16), and O^T lands with lane = (query l16, d = 4 kg + [0, 4) of d block db) -- the accumulator layout of the GEMM itself, so O
+    // is written back into the Q columns' registers and leaves through the ordinary transposing epilogue.
+    //   head 2 of the tile straddles the two wave columns (wn 0: d 0..31, wn 1: d 32..63): the partners exchange that Q half through LDS (4 KB per wave,
+    //   under the barrier the staging needs anyway), both compute the head's full S (5 redundant MFMAs per query block) and each its own half of O.
+    //   LDS: K image [d chunk c = 0..39][key 0..79] x 16 B (a wave's 16 keys of one chunk are 256 contiguous bytes: conflict-free 8-byte reads),
+    //   V^T image [key chunk 0..9][d 0..319] x 16 B, 100 LDS-DMA pieces of 1 KiB; the exchange buffer behind them.  Numerics = fmx_attention_f16's
+    //   short-context kernel: Q rounded to fp16, pre-scaled by scale log2(e) and rounded again, fp32 scores, exp2, row sum of the unrounded
+    //   exponentials, P rounded to fp16, fp32 O scaled by 1 / l.
+    // MEASURED (profiles/r32_cross_attention_in_to_q_epilogue_ab.jsonl, SDXL 1024^2 batch 8, same box, interleaved): correct (agrees with the two
+    // launches it replaces to fp32 summation order) and SLOWER -- the fused launch 102.8 us against 56.7 (projection) + 28.3 (fmx_attention_f16) = 85.0 us,
+    // step 102.4 -> 104.9 ms.  The 77-key attention is not a memory pass that a producer-side fusion deletes: per wave it is ~4 000 vector instructions
+    // (mask / max / exp2 / sum / two conversions per score on 16 x 16 blocks, the LayerNorm-consumer arithmetic and two roundings per Q element) around 260
+    // MFMAs, i.e. bound by vector issue; as its own launch that work runs four workgroups deep per CU under its memory traffic, as an epilogue it runs
+    // alone on a CU whose matrix pipes wait (one query block at a time; two at a time spill 143 registers next to the 160 accumulators: 149 us).  The
+    // executor therefore keeps the two launches (backend/nn/unet.py, FMX_XATTN_FUSE=1 selects this path for A/B); the kernel stays for the record and
+    // its test.
+    static_assert(!XA || (MF == 16 && BM == 256 && BN == 320 && LN == 2 && !STATS && !CONV), "cross-attention epilogue: the 256 x 320 LayerNorm-consumer linear kernel");
+    constexpr int XKEYS = 80, NKB = 5;
+    constexpr int K_BYTES = 40 * XKEYS * 16, V_BYTES = 10 * 320 * 16;
+    static_assert(K_BYTES + V_BYTES + 8 * 4096 <= G::LDS_BYTES, "K / V^T images and the exchange buffer fit the LDS");
+    char* const xk = smem;
+    char* const xv = smem + K_BYTES;
+    char* const xq = smem + K_BYTES + V_BYTES;
+    {
+      const int img = m0 / p.xa_rows;
+      const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(p.xa_k), 0, p.xa_k_bytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(p.xa_vt), 0, p.xa_vt_bytes, 0x00020000);
+      for (int pc = wave; pc < 100; pc += 8) {   // (uniform: `wave` is a scalar)
+        const bool isk = pc < 50;
+        const int pq = isk ? pc : pc - 50;
+        const int sl = pq * 64 + lane;
+        unsigned off;
+        if (isk) {
+          const int c = sl / XKEYS, key = sl - c * XKEYS;
+          off = (unsigned)((img * p.xa_k_bs + key) * p.xa_k_rs + n0 + c * 8) * 2u;
+        } else {
+          const int kc = sl / 320, d = sl - kc * 320;
+          off = (unsigned)((n0 + d) * p.xa_vt_ds + img * p.xa_vt_bs + kc * 8) * 2u;
+        }
+        auto* dst = (__attribute__((address_space(3))) void*)((isk ? xk : xv) + pq * 1024);
+        const __amdgpu_buffer_rsrc_t rs = isk ? rs_k : rs_v;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, off, 0, 0, 0);
+      }
+    }
+    const float c2 = p.xa_c2;
+    float mr[MIB], rr[MIB];
+#pragma unroll
+    for (int i = 0; i < MIB; ++i) {
+      mr[i] = __shfl(lnm, i * 16 + l16);
+      rr[i] = __shfl(lnr, i * 16 + l16);
+    }
+    const int colw = n0 + wn * (NJ * 32);
+    // column blocks JB, JB + 1 of this wave -> one pre-scaled fp16 B-operand fragment per query block I0, I0 + 1 (the LayerNorm-consumer arithmetic of
+    // epi_rows).  Two query blocks at a time: four (80 score registers per head) spill next to the 160 accumulators.
+#ifndef FMX_XA_QH
+#define FMX_XA_QH 1
+#endif
+    constexpr int QH = FMX_XA_QH;
+    auto qfrag_pair = [&](auto JB, auto I0, f16x8(&out)[QH]) {
+      constexpr int jb = decltype(JB)::value, i0 = decltype(I0)::value;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int col = colw + (jb + half) * 16 + kg * 4;
+        const f32x4 cs = *reinterpret_cast<const f32x4*>(p.ln_colsum + col);
+        const f16x4 bb = *reinterpret_cast<const f16x4*>(ep.bias + (long)col * ep.mb);
+#pragma unroll
+        for (int ii = 0; ii < QH; ++ii)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = acc[i0 + ii][jb + half][r];   // (alpha = 1: the host refuses anything else here)
+            v = (v - mr[i0 + ii] * cs[r]) * rr[i0 + ii];
+            v += (float)bb[r];
+            const f16 qh = (f16)v;                           // Q as fmx_attention_f16 would have read it from memory
+            out[ii][half * 4 + r] = (f16)((float)qh * c2);   // ... and pre-scaled as that kernel does
+          }
+      }
+    };
+    auto pack8 = [](f16x4 a, f16x4 b) { return f16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; };
+    // MODE 0: a whole head in column blocks J0 .. J0 + 3;  1: head 2's d 0..31 in J0, J0 + 1 (wn 0);  2: head 2's d 32..63 in J0, J0 + 1 (wn 1)
+    auto head = [&](auto HC, auto J0, auto MODE, auto I0) {
+      constexpr int hc = decltype(HC)::value, j0 = decltype(J0)::value, mode = decltype(MODE)::value, i0 = decltype(I0)::value;
+      f16x8 qf[QH][2];
+      if constexpr (mode == 0) {
+        f16x8 t0[QH], t1[QH];
+        qfrag_pair(IC<j0>{}, IC<i0>{}, t0);
+        qfrag_pair(IC<j0 + 2>{}, IC<i0>{}, t1);
+#pragma unroll
+        for (int ii = 0; ii < QH; ++ii) { qf[ii][0] = t0[ii]; qf[ii][1] = t1[ii]; }
+      } else {
+        f16x8 own[QH];
+        qfrag_pair(IC<j0>{}, IC<i0>{}, own);   // (recomputed: the copy that went to the partner is not kept)
+#pragma unroll
+        for (int ii = 0; ii < QH; ++ii) {
+          const f16x8 pq = *reinterpret_cast<const f16x8*>(xq + (wave ^ 1) * 4096 + (i0 + ii) * 1024 + lane * 16);
+          qf[ii][mode == 1 ? 0 : 1] = own[ii];
+          qf[ii][mode == 1 ? 1 : 0] = pq;
+        }
+      }
+      f32x4 S[QH][NKB];
+#pragma unroll
+      for (int ii = 0; ii < QH; ++ii)
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) S[ii][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int c = hc * 8 + ks * 4 + (kg >> 1);
+          const char* a = xk + (c * XKEYS + kb * 16 + l16) * 16 + (kg & 1) * 8;
+          const f16x8 kf = pack8(*reinterpret_cast<const f16x4*>(a), *reinterpret_cast<const f16x4*>(a + 2 * XKEYS * 16));
+#pragma unroll
+          for (int ii = 0; ii < QH; ++ii) S[ii][kb] = FMX_MFMA_16x16x32(kf, qf[ii][ks], S[ii][kb]);
+        }
+      f16x4 P[QH][NKB];
+      float inv[QH];
+#pragma unroll
+      for (int ii = 0; ii < QH; ++ii) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (kb * 16 + 16 > p.xa_nk) {   // (uniform: only the key block that holds the end of the context pays for the mask)
+              if (kb * 16 + kg * 4 + r >= p.xa_nk) S[ii][kb][r] = -INFINITY;
+            }
+            mx = fmaxf(mx, S[ii][kb][r]);
+          }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float l = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = __builtin_amdgcn_exp2f(S[ii][kb][r] - mx);
+            l += e;
+            P[ii][kb][r] = (f16)e;
+          }
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        inv[ii] = 1.0f / l;
+      }
+      constexpr int db0 = mode == 2 ? 2 : 0, ndb = mode == 0 ? 4 : 2;
+      static_for<ndb>([&](auto DBI) {
+        constexpr int dbi = decltype(DBI)::value, db = db0 + dbi;
+        f32x4 O[QH];
+#pragma unroll
+        for (int ii = 0; ii < QH; ++ii) O[ii] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int d = hc * 64 + db * 16 + l16;
+#pragma unroll
+        for (int kp = 0; kp < 2; ++kp) {
+          const int kc = kp * 4 + (kg >> 1);
+          const char* a = xv + (kc * 320 + d) * 16 + (kg & 1) * 8;
+          const f16x8 vf = pack8(*reinterpret_cast<const f16x4*>(a), *reinterpret_cast<const f16x4*>(a + 2 * 320 * 16));
+#pragma unroll
+          for (int ii = 0; ii < QH; ++ii) O[ii] = FMX_MFMA_16x16x32(vf, pack8(P[ii][2 * kp], P[ii][2 * kp + 1]), O[ii]);
+        }
+        {
+          const int kc = 8 + (kg >> 1);
+          const f16x4 vf4 = *reinterpret_cast<const f16x4*>(xv + (kc * 320 + d) * 16 + (kg & 1) * 8);
+#pragma unroll
+          for (int ii = 0; ii < QH; ++ii) {
+#ifdef FMX_XA_TAIL16
+            O[ii] = __builtin_amdgcn_mfma_f32_16x16x16f16(vf4, P[ii][4], O[ii], 0, 0, 0);
+#else
+            // (the fifth key block as a 16x16x32 step with a zero second half.  With a v_mfma_f32_16x16x16_f16 taking over the accumulator of the
+            //  v_mfma_f32_16x16x32_f16 straight in front of it, registers 0 and 1 of the result came back wrong in a fixed subset of the blocks -- every
+            //  launch, no spills involved, gone with this form; FMX_XA_TAIL16 rebuilds the failing sequence)
+            const f16x4 z4 = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+            O[ii] = FMX_MFMA_16x16x32(pack8(vf4, vf4), pack8(P[ii][4], z4), O[ii]);
+#endif
+          }
+        }
+#pragma unroll
+        for (int ii = 0; ii < QH; ++ii)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i0 + ii][j0 + dbi][r] = O[ii][r] * inv[ii];
+      });
+    };
+    // the straddling head's own half first: its fragments go to the partner through LDS, under the barrier that also publishes the staged K / V^T
+    static_for<MIB / QH>([&](auto IH) {
+      constexpr int i0 = decltype(IH)::value * QH;
+      f16x8 o0[QH];
+      if (wn == 0) qfrag_pair(IC<8>{}, IC<i0>{}, o0);
+      else qfrag_pair(IC<0>{}, IC<i0>{}, o0);
+#pragma unroll
+      for (int ii = 0; ii < QH; ++ii) *reinterpret_cast<f16x8*>(xq + wave * 4096 + (i0 + ii) * 1024 + lane * 16) = o0[ii];
+    });
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");   // (the raw barrier does not keep the compiler from hoisting the LDS reads below above it)
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<MIB / QH>([&](auto IH) {
+      constexpr int i0 = decltype(IH)::value * QH;
+      if (wn == 0) {
+        head(IC<2>{}, IC<8>{}, IC<1>{}, IC<i0>{});
+        head(IC<0>{}, IC<0>{}, IC<0>{}, IC<i0>{});
+        head(IC<1>{}, IC<4>{}, IC<0>{}, IC<i0>{});
+      } else {
+        head(IC<2>{}, IC<0>{}, IC<2>{}, IC<i0>{});
+        head(IC<3>{}, IC<2>{}, IC<0>{}, IC<i0>{});
+        head(IC<4>{}, IC<6>{}, IC<0>{}, IC<i0>{});
+      }
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // every wave is done reading K / V^T / the exchange buffer: the transposing epilogue may take the LDS
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#endif
   if (!geglu) {
     constexpr int RB = NJ * 128;       // staged row: NJ*32 fp32
     constexpr int LPR = NJ * 4;        // lanes per output row (8 columns each)
@@ -561,6 +781,9 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
       const int mbase = m0 + wm * WROWS + i * BR;
 #define FMX_EPI_ARGS my, lane, mbase, p.M, nbc, nok, ep.per_img, ep.alpha, (float)ep.mgt, ep.bias + nbc * ep.mb, ep.rowvec + nbc * ep.mrv, ep.ld_rv, \
                      ep.gate + nbc * ep.mgt, ep.ld_gt, ep.res + nbc * ep.mres, ep.ld_res, ep.out + nbc, ep.ld_out, st
+      if constexpr (XA) {   // O is final: plain fp16 store (no bias, no LayerNorm arithmetic -- that went into Q)
+        epi_rows<RB, LPR, BR, 7, false, 2>(my, lane, mbase, p.M, nbc, nok, ep.per_img, 1.0f, 0.0f, p.zp, p.zp, 0L, p.zp, 0L, p.zp, 0L, ep.out + nbc, ep.ld_out, st);
+      } else
       if (STATS) {  // (the host refuses GELU-tanh / gate together with statistics)
         if (ep.mrv) epi_rows<RB, LPR, BR, 7, false, 3, true>(FMX_EPI_ARGS);
         else if (ep.mres) epi_rows<RB, LPR, BR, 7, false, 1, true>(FMX_EPI_ARGS);
@@ -758,6 +981,28 @@ int launch_ln(const GemmParams& p, hipStream_t st) {
   return FMX_OK;
 }
 
+// the LayerNorm-consumer query projection with the cross-attention epilogue (fp16 build only)
+int launch_ln_xa(const GemmParams& p, hipStream_t st) {
+#ifndef FMX_ELEM_BF16
+  using G = Geo<256, 320>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<false, 256, 320, false, 1, 2, 16, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    attr_set = true;
+  }
+  GemmParams q = p;
+  q.xtile = 0;
+  q.tiles_m = (p.M + 255) / 256;
+  q.tiles_n = (p.nout + 319) / 320;
+  hipLaunchKernelGGL((gemm256p_kernel<false, 256, 320, false, 1, 2, 16, 0, true>), dim3(persistent_grid(q.tiles_m * q.tiles_n)), dim3(512), G::LDS_BYTES, st, q);
+  FMX_LAUNCH_CHECK("fmx_gemm_conv_f16 (256x320, LayerNorm folded, cross-attention epilogue)");
+  return FMX_OK;
+#else
+  (void)p; (void)st;
+  return -1;
+#endif
+}
+
 // LayerNorm folded into the operand-swapped V^T GEMM: 320 x 256 tile
 template <int MF>
 int launch_ln_swapped(const GemmParams& p, hipStream_t st) {
@@ -806,6 +1051,7 @@ int fmx_launch_gemm256p(const GemmParams& p, bool conv, int bm, int bn, hipStrea
     const char* e = fmx_knob("FMX_GEMM_MFMA");
     mf = (e && atoi(e) == 32) ? 32 : 16;
   }
+  if (p.xa_k) return launch_ln_xa(p, st);
   if (mf == 16) {
     if (p.row_stats) return launch_ln<1, 16>(p, st);
     if (p.ln_partial) return launch_ln<2, 16>(p, st);

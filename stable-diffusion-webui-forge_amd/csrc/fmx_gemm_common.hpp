@@ -47,6 +47,12 @@ struct GemmParams {
   const float* ln_col_ab;    // [nout][2] {rstd, -mean rstd}
   const float* ln_row_cb;    // [M][2] {colsum, folded bias}
   float* ln_ab_out;          // LN consumer: also write {rstd, -mean rstd} of its input rows (tiles of the first tile column), or null
+  // cross-attention epilogue of the query projection (fmx.h xa_*): K / V^T of the text context, element strides, scale * log2(e)
+  const f16* xa_k;
+  const f16* xa_vt;
+  int xa_k_rs, xa_k_bs, xa_vt_ds, xa_vt_bs, xa_nk, xa_rows;
+  unsigned xa_k_bytes, xa_vt_bytes;
+  float xa_c2;
   int xtile;                 // persistent 256 x 320 linear kernels: fetch the next output tile's first K-tile under the last K-tile of this one (set by the launcher)
 };
 

@@ -172,7 +172,8 @@ _FUSED_STATS = _lib.knob("FMX_GN_FUSED_STATS", "1") != "0"
 
 def conv_gemm(x, wgt, nout, *, x1=None, n=None, h=None, w=None, kh=1, stride=1, pad=0, up=None, bias=None,
               rowvec=None, residual=None, act=ACT_NONE, alpha=1.0, out=None, ld_out=None, out_dtype=None,
-              ldw=0, force_tile=0, gate=None, out_hw=None, stats=False, stats_partial=None, row_stats=None, ln=None, ln_swapped=None, ln_ab_out=None):
+              ldw=0, force_tile=0, gate=None, out_hw=None, stats=False, stats_partial=None, row_stats=None, ln=None, ln_swapped=None, ln_ab_out=None,
+              xattn=None):
     """OUT[M, ncols] = epilogue(A (*) W^T).  x: [N,H,W,C0] (or [M,C0] with kh == 1); x1: optional second source
     concatenated along channels; wgt: [nout, kh*kh*(C0+C1)]; up=(UH, UW): nearest-resize before the conv.
     stats=True: returns (out, GnStats of out) -- the GroupNorm statistics of the output come out of the GEMM's epilogue (256-row tiles)
@@ -182,7 +183,9 @@ def conv_gemm(x, wgt, nout, *, x1=None, n=None, h=None, w=None, kh=1, stride=1, 
     output (its `.parts` is 0 afterwards if the dispatcher did not use the 256x320 tile); ln = (RowStats of the INPUT, colsum fp32 [nout],
     eps) runs the GEMM as `LN(x) W^T + b` on the un-normalised x (wgt / bias pre-folded by the caller);  ln_swapped = (col_ab fp32 [nout, 2] from
     `ln_rowstats_finalize`, row_cb fp32 [M, 2]) is the same fold for the operand-swapped form `W' x^T` (x = the gamma-scaled weight, wgt = the
-    un-normalised activations: V^T of self-attention), fmx.h ln_col_ab / ln_row_cb."""
+    un-normalised activations: V^T of self-attention), fmx.h ln_col_ab / ln_row_cb.
+    xattn = (k [images * keys_pad, heads * 64], vt [heads * 64, images * keys_pad], nk, keys_pad, queries_per_image, scale) with `ln`: the query
+    projection of a cross-attention whose attention runs in the GEMM's epilogue (fmx.h xa_*): `out` receives the attention output, Q is never stored."""
     sfx, elem = _elem(x, x1, wgt, bias, rowvec, residual, gate)
     fn_name = "fmx_gemm_conv" + sfx
     if out_dtype is None:
@@ -234,6 +237,13 @@ def conv_gemm(x, wgt, nout, *, x1=None, n=None, h=None, w=None, kh=1, stride=1, 
         if ln_ab_out is not None:   # the {rstd, -mean rstd} pairs of the input rows, for an operand-swapped fold on the same rows (fmx.h ln_ab_out)
             assert ln_ab_out.dtype == torch.float32 and ln_ab_out.numel() == 2 * m
             a.ln_ab_out = _p(ln_ab_out)
+    if xattn is not None:
+        xk, xvt, xnk, xpad, xrows, xscale = xattn
+        assert ln is not None and sfx == "_f16" and xk.dtype == torch.float16 and xvt.dtype == torch.float16 and xk.is_contiguous() and xvt.is_contiguous()
+        a.xa_k, a.xa_vt = _p(xk), _p(xvt)
+        a.xa_k_rs, a.xa_k_bs, a.xa_vt_ds, a.xa_vt_bs = xk.shape[1], xpad, xvt.shape[1], xpad
+        a.xa_nk, a.xa_rows, a.xa_scale = int(xnk), int(xrows), float(xscale)
+        a.xa_k_bytes, a.xa_vt_bytes = xk.numel() * 2, xvt.numel() * 2
     if ln_swapped is not None:
         LN_FOLDED_LAUNCHES += 1
         col_ab, row_cb = ln_swapped
@@ -268,7 +278,7 @@ def conv_gemm(x, wgt, nout, *, x1=None, n=None, h=None, w=None, kh=1, stride=1, 
         flops = 2.0 * m * nout * kh * kh * (c0 + c1)
         _profiler.launch("gemm_conv", flops, launch,
                          tag=f"M={m} N={nout} K={kh * kh * (c0 + c1)} kh={kh} s={stride}{' up' if up else ''}{' geglu' if act == ACT_GEGLU else ''}"
-                             f"{' +gnstats' if st is not None else ''}")
+                             f"{' +gnstats' if st is not None else ''}{' +xattn' if xattn is not None else ''}")
     else:
         launch()
     _dbg(f"conv_gemm M={m} N={nout} K={kh * kh * (c0 + c1)} stats={st is not None and st.nchunks}", out=out,

@@ -28,6 +28,7 @@ DEV = "cuda"
 TINY = {"tiny_sd15": synth.TINY_SD15_UNET_CONFIG, "tiny_sdxl": synth.TINY_SDXL_UNET_CONFIG}
 
 
+import parity  # noqa: E402
 from parity import check, max_rel  # noqa: E402
 
 
@@ -808,6 +809,35 @@ def test_sdxl_full_size_forward_at_the_bench_batch_vs_reference_fixture(sdxl_eng
         check(f"SDXL unet forward at full size, image {i} of a batch of {n} vs reference", eps[i:i + 1], g["eps"], floor="sdxl_full_fwd.pt:eps")
     spread = float((eps.float() - eps[:1].float()).abs().max() / eps.float().abs().max())
     assert spread < 2e-3, f"identical inputs, different batch positions: {spread}"
+
+
+def test_sdxl_full_size_forward_with_cross_attention_in_the_query_projection_epilogue(sdxl_engine, monkeypatch):
+    """The executor with attn2 as ONE launch per block (csrc/fmx_gemm256p.hip `XA`, off by default: measured slower) at the bench's UNet batch: all 70 cross
+    attentions of the SDXL UNet run in their query projection's epilogue; against the reference fixture at the same floor gate as the two-launch executor,
+    and against that executor's own output: two correct fp16 executors differ from each other by most of a floor over 70 blocks (a flipped
+    rounding in one layer is a full-ulp input change for everything behind it; measured 0.66 x floor here), so that comparison is bounded by the floor
+    itself -- the sharp comparison of the fused op is the kernel test (agreement with the two launches to 1 fp16 ulp)."""
+    from forge_amd import hipops
+    from forge_amd.backend.nn import unet as _unet
+    from oracle.make_golden import _inputs
+    g = load_golden("sdxl_full_fwd.pt")
+    cfg = synth.SDXL_UNET_CONFIG
+    x, t, ctx, y = _inputs(cfg, 1, 128, seed=g["inputs_seed"])
+    net = sdxl_engine.forge_objects.unet.model.diffusion_model
+    n = 16
+    args = (x.repeat(n, 1, 1, 1).to(DEV), t.repeat(n).to(DEV))
+    kw = dict(context=ctx.repeat(n, 1, 1).to(DEV), y=y.repeat(n, 1).to(DEV))
+    plain = net.forward(*args, **kw).float().clone()
+    seen = []
+    real = hipops.conv_gemm
+    monkeypatch.setattr(hipops, "conv_gemm", lambda *a, **k: (seen.append(1) if k.get("xattn") is not None else None, real(*a, **k))[1])
+    monkeypatch.setattr(_unet, "_XATTN_FUSE", True)
+    fused = net.forward(*args, **kw).float()
+    assert len(seen) == 70, f"{len(seen)} of the 70 cross attentions ran in the projection's epilogue"
+    check("SDXL unet forward at full size with the fused cross-attention epilogue, image 0 of 16 vs reference", fused[:1], g["eps"], floor="sdxl_full_fwd.pt:eps")
+    m = parity.metrics(fused, plain)
+    print("fused vs two-launch executor:", m)
+    assert m["rms_rel"] < 1.0 * parity.FLOORS["sdxl_full_fwd.pt:eps"]["rms_rel"], m
 
 
 @pytest.mark.skipif(not _have("sdxl_config3.pt"), reason="full fixture not generated")

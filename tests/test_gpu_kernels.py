@@ -219,6 +219,50 @@ def test_layernorm_folded_into_the_gemms_around_it(m, c, nq):
     assert err_new[0] <= 2.0 * err_new[1] + 1e-3, err_new
 
 
+@pytest.mark.parametrize("bu,n,c,nk", [(4, 1024, 1280, 77), (2, 4096, 640, 77), (4, 256, 320, 80), (2, 512, 640, 33)])
+def test_cross_attention_as_the_epilogue_of_the_query_projection(bu, n, c, nk):
+    """attn2 of a BasicTransformerBlock without a query tensor (csrc/fmx_gemm256p.hip `XA`, fmx.h xa_*; reference backend/nn/unet.py:145-155, 254-267):
+    the LayerNorm-consumer projection `to_q(norm2(h))` keeps its 256 x 320 tile of Q in the accumulators and runs softmax(q k^T / 8) v against the
+    cached K / V^T of the text context in its own epilogue.  Against (a) the two launches it replaces -- the same projection storing Q, then
+    fmx_attention_f16 -- whose rounding sites it shares (Q rounded to fp16, pre-scaled, P rounded to fp16): agreement at the level of fp32 summation
+    order, and (b) LayerNorm + Linear + softmax attention in fp32 on the stored h."""
+    from forge_amd.backend.nn.unet import _fold_layernorm
+    m, heads, tp = bu * n, c // 64, 128
+    o_in = rnd(m, c, seed=190)
+    w_out, b_out = rnd(c, c, scale=1 / math.sqrt(c), seed=191), rnd(c, seed=192)
+    h = (rnd(m, c, scale=2.0, seed=193) + 0.7).contiguous()
+    rs = ops.RowStats(m, c)
+    ops.linear(o_in, w_out, b_out, residual=h, out=h, ld_out=c, row_stats=rs, force_tile=7)   # (the 256 x 320 tile whatever the dispatcher would pick at this M)
+    assert rs.parts == 2 * (c // 320)
+    gamma, beta = (1 + 0.2 * rnd(c, seed=194)), 0.1 * rnd(c, seed=195)
+    wq = rnd(c, c, scale=2.0 / math.sqrt(c), seed=196)          # (scores with a spread of a few units: a peaked softmax)
+    wf, cs, bf = _fold_layernorm(wq, None, gamma, beta)
+    kc = torch.zeros(bu * tp, c, dtype=torch.float16, device=DEV)
+    vt = torch.zeros(c, bu * tp, dtype=torch.float16, device=DEV)
+    kv = rnd(bu, nk, c, seed=197)
+    vv = rnd(bu, nk, c, seed=198)
+    kc.view(bu, tp, c)[:, :nk] = kv
+    vt.view(c, bu, tp)[:, :, :nk] = vv.permute(2, 0, 1)
+    scale = 64 ** -0.5
+    q = ops.conv_gemm(h, wf, c, bias=bf, ln=(rs, cs, 1e-5))
+    two = ops.attention(q, kc, vt, batch=bu, heads=heads, nq=n, nk=nk, nk_pad=tp, dpad=64, scale=scale,
+                        q_bs=n * c, q_rs=c, k_bs=tp * c, k_rs=c, vt_bs=tp, vt_hs=64 * bu * tp, vt_ds=bu * tp)
+    fused = ops.conv_gemm(h, wf, c, bias=bf, ln=(rs, cs, 1e-5), xattn=(kc, vt, nk, tp, n, scale))
+    assert fused.shape == two.shape == (m, c)
+    ln = F.layer_norm(h.float(), (c,), gamma.float(), beta.float(), 1e-5)
+    qr = (ln @ wq.float().t()).view(bu, n, heads, 64).permute(0, 2, 1, 3)
+    kr = kv.float().view(bu, nk, heads, 64).permute(0, 2, 1, 3)
+    vr = vv.float().view(bu, nk, heads, 64).permute(0, 2, 1, 3)
+    ref = (torch.softmax(qr @ kr.transpose(-1, -2) * scale, -1) @ vr).permute(0, 2, 1, 3).reshape(m, c)
+    e_two, e_fused = float((two.float() - ref).abs().max()), float((fused.float() - ref).abs().max())
+    d = float((fused.float() - two.float()).abs().max())
+    print(f"cross-attention epilogue bu={bu} n={n} c={c} nk={nk}: fused vs fp32 {e_fused:.2e}, two launches vs fp32 {e_two:.2e}, fused vs two launches {d:.2e} "
+          f"(|ref| max {float(ref.abs().max()):.2f})")
+    close(fused, ref, 4e-3, 4e-3, "fused cross-attention vs fp32")
+    close(fused, two.float(), 2e-3, 2e-3, "fused cross-attention vs projection + fmx_attention_f16")
+    assert e_fused <= 1.5 * e_two + 1e-3
+
+
 @pytest.mark.parametrize("m,c,hd", [(16384, 1280, 1280), (65536, 640, 640), (16384 - 64, 1280, 1280)])
 def test_layernorm_folded_into_the_operand_swapped_vt_projection(m, c, hd):
     """norm1 without a LayerNorm kernel (round 3): the projection that writes h WITHOUT a residual (proj_in) leaves the row statistics too; the
