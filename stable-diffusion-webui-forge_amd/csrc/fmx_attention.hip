@@ -1547,13 +1547,15 @@ __global__ __launch_bounds__(256, 4) void attn_short_kernel(const AttnParams p) 
       }
       __builtin_amdgcn_sched_barrier(0);   // one block's fragments at a time: left alone the scheduler hoists all 4 NB fragment reads (48 registers)
     }
-    if (NB * 32 > p.nk) {   // keys >= nk of the last block(s): out of the softmax (uniform branch)
+    // keys >= nk: out of the softmax.  Per key block and uniform: only the block(s) that reach past nk pay for the compare + select pairs (77 keys: one
+    // block of three -- the kernel is vector-issue-bound, profiles/r32: 16 instead of 48 pairs per lane)
 #pragma unroll
-      for (int g = 0; g < NB; ++g)
+    for (int g = 0; g < NB; ++g)
+      if ((g + 1) * 32 > p.nk) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           if (g * 32 + hi * 16 + r >= p.nk) sacc[g][r] = -INFINITY;
-    }
+      }
     // ---- one-pass softmax: exact maximum of the query (both half-waves hold 16 keys of each block), P = 2^(s - m) ----
     float m0 = sacc[0][0];
 #pragma unroll
@@ -1775,13 +1777,13 @@ __global__ __launch_bounds__(256, 2) void attn_short2_kernel(const AttnParams p)
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (NB * 32 > p.nk) {
 #pragma unroll
-      for (int gk = 0; gk < NB; ++gk)
+    for (int gk = 0; gk < NB; ++gk)
+      if ((gk + 1) * 32 > p.nk) {   // (uniform; see attn_short_kernel)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           if (gk * 32 + hi * 16 + r >= p.nk) sacc[gk][r] = -INFINITY;
-    }
+      }
     float m0 = sacc[0][0];
 #pragma unroll
     for (int gk = 0; gk < NB; ++gk)
