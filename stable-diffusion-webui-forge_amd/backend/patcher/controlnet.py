@@ -87,50 +87,56 @@ def broadcast_image_to(tensor, target_batch_size, batched_number):
 
 
 class ControlBase:
+    """What every control object carries and how a chain of them behaves -- the attribute names and methods are the reference's public surface
+    (backend/patcher/controlnet.py:11-45: extensions set `strength`, `timestep_percent_range`, `global_average_pooling`, chain with
+    `set_previous_controlnet`); the arithmetic underneath is native.  A chain is a singly linked list through `previous_controlnet`; the walkers
+    below visit it tail-first, as the reference's recursion does."""
+
+    # (name, initial value) of the per-object state; the first four are what `copy_to` hands to a copy
+    _COPIED = (("cond_hint_original", None), ("strength", 1.0), ("timestep_percent_range", (0.0, 1.0)), ("global_average_pooling", False))
+    _STATE = _COPIED + (("cond_hint", None), ("timestep_range", None), ("previous_controlnet", None))
+
     def __init__(self, device=None):
-        self.cond_hint_original = None
-        self.cond_hint = None
-        self.strength = 1.0
-        self.timestep_percent_range = (0.0, 1.0)
-        self.global_average_pooling = False
-        self.timestep_range = None
+        for name, initial in self._STATE:
+            setattr(self, name, initial)
         self.transformer_options = {}
         self.device = device
-        self.previous_controlnet = None
+
+    def _rest_of_chain(self):
+        return self.previous_controlnet
 
     def set_cond_hint(self, cond_hint, strength=1.0, timestep_percent_range=(0.0, 1.0)):
-        self.cond_hint_original = cond_hint
-        self.strength = strength
-        self.timestep_percent_range = timestep_percent_range
+        self.cond_hint_original, self.strength, self.timestep_percent_range = cond_hint, strength, timestep_percent_range
         return self
-
-    def pre_run(self, model, percent_to_timestep_function):
-        self.timestep_range = (percent_to_timestep_function(self.timestep_percent_range[0]),
-                               percent_to_timestep_function(self.timestep_percent_range[1]))
-        if self.previous_controlnet is not None:
-            self.previous_controlnet.pre_run(model, percent_to_timestep_function)
 
     def set_previous_controlnet(self, controlnet):
         self.previous_controlnet = controlnet
         return self
 
+    def pre_run(self, model, percent_to_timestep_function):
+        lo, hi = self.timestep_percent_range
+        self.timestep_range = (percent_to_timestep_function(lo), percent_to_timestep_function(hi))
+        rest = self._rest_of_chain()
+        if rest is not None:
+            rest.pre_run(model, percent_to_timestep_function)
+
     def cleanup(self):
-        if self.previous_controlnet is not None:
-            self.previous_controlnet.cleanup()
-        self.cond_hint = None
-        self.timestep_range = None
+        rest = self._rest_of_chain()
+        if rest is not None:
+            rest.cleanup()
+        self.cond_hint = self.timestep_range = None
 
     def get_models(self):
-        return self.previous_controlnet.get_models() if self.previous_controlnet is not None else []
-
-    def copy_to(self, c):
-        c.cond_hint_original = self.cond_hint_original
-        c.strength = self.strength
-        c.timestep_percent_range = self.timestep_percent_range
-        c.global_average_pooling = self.global_average_pooling
+        rest = self._rest_of_chain()
+        return [] if rest is None else rest.get_models()
 
     def inference_memory_requirements(self, dtype):
-        return self.previous_controlnet.inference_memory_requirements(dtype) if self.previous_controlnet is not None else 0
+        rest = self._rest_of_chain()
+        return 0 if rest is None else rest.inference_memory_requirements(dtype)
+
+    def copy_to(self, c):
+        for name, _ in self._COPIED:
+            setattr(c, name, getattr(self, name))
 
     def control_merge(self, control_input, control_output, control_prev, output_dtype):
         out = {"input": [], "middle": [], "output": []}
