@@ -55,6 +55,7 @@ class IntegratedAutoencoderKL:
         self.dtype = dtype
         self.auto_bf16_fallback = bool(auto_bf16_fallback)
         self.fallbacks = 0          # decodes repeated in bfloat16 because the fp16 result was not finite
+        self.tap = None             # test hook: a dict that receives every layer's stored output of the next decode (see _tap)
         # by reference, and only while a fallback can still happen (an fp16 executor with the guard on): the bfloat16 weights are made from it then, and
         # it is released -- together with the fp16 copy, which no later decode uses -- as soon as they exist (the caller's full state dict,
         # often fp32 and already on the device, used to stay alive for the executor's lifetime)
@@ -195,6 +196,11 @@ class IntegratedAutoencoderKL:
         return (b_o.float() + w_o.float() @ b_v.float()).to(b_o.dtype).contiguous()
 
     # ------------------------------------------------------------------------------------------------------------
+    def _tap(self, key, t, nchw=True):
+        """test hook (tests/test_gpu_vae_sharp_parity.py): with `self.tap` a dict, every layer's stored output is copied out as fp32 NCHW"""
+        if self.tap is not None:
+            self.tap[key] = (t.permute(0, 3, 1, 2) if nchw else t).float().cpu()
+
     def _res(self, k, x, cin, cout, arena):
         b, hh, ww, _ = x.shape
         out = ops.empty((b, hh, ww, cout), self.dtype)
@@ -203,10 +209,12 @@ class IntegratedAutoencoderKL:
         g1 = ops.groupnorm(x, *self.w[k + ".n1"], 1e-6, silu=True)          # statistics: left on x by the GEMM that produced it
         h, h_st = ops.conv_gemm(g1, self.w[k + ".c1"][0], cout, kh=3, pad=1, bias=self.w[k + ".c1"][1], stats=True)
         g2 = ops.groupnorm(h.view(b, hh, ww, cout), *self.w[k + ".n2"], 1e-6, silu=True, stats=h_st)
+        self._tap(k + ".h", h.view(b, hh, ww, cout))
         sk = ops.conv_gemm(x, self.w[k + ".sc"][0], cout, bias=self.w[k + ".sc"][1]) if cin != cout else x.view(-1, cout)
         _, st = ops.conv_gemm(g2, self.w[k + ".c2"][0], cout, kh=3, pad=1, bias=self.w[k + ".c2"][1], residual=sk, out=out.view(-1, cout), ld_out=cout,
                               stats=True, stats_partial=out_part)
         arena.release(m)
+        self._tap(k, out)
         return ops.attach_stats(out, st)
 
     def _attn(self, x, arena, a="decoder.mid.attn_1"):
@@ -232,9 +240,15 @@ class IntegratedAutoencoderKL:
                     ops.conv_gemm(self.w[a + ".v"][0], g[bi * n:(bi + 1) * n], n, out=vt[:, bi * npad:], ld_out=b * npad)
             ops.attention_single_head512(qk, qk[:, c:], vt, o, batch=b, nq=n, nk=n, nk_pad=npad, q_bs=n * 2 * c, q_rs=2 * c, k_bs=n * 2 * c, k_rs=2 * c,
                                          vt_bs=npad, vt_ds=b * npad, scale=scale)
+            if self.tap is not None:
+                self._tap(a + ".q", qk[:, :c].reshape(b, hh, ww, c))
+                self._tap(a + ".k", qk[:, c:].reshape(b, hh, ww, c))
+                self._tap(a + ".v", vt.view(c, b, npad)[:, :, :n].permute(1, 0, 2), nchw=False)    # V^T without its bias, [B, C, N]
+                self._tap(a + ".o", o.view(b, hh, ww, c))
             _, st = ops.linear(o, self.w[a + ".proj_out"][0], self.w[a + ".proj_out_vbias"], residual=x.view(-1, c), out=out.view(-1, c), ld_out=c,
                                n=b, h=hh, w=ww, stats=True, stats_partial=out_part)
             arena.release(m)
+            self._tap(a, out)
             return ops.attach_stats(out, st)
         # other widths: S = scale * Q K^T (GEMM) -> row softmax -> P V (GEMM) per image
         for bi in range(b):
@@ -255,9 +269,14 @@ class IntegratedAutoencoderKL:
             ops.conv_gemm(self.w[a + ".v"][0], gb, n, out=vt, ld_out=npad)        # V^T (bias deferred)
             ops.conv_gemm(s, vt, c, bias=self.w[a + ".v"][1], out=o[bi * n:(bi + 1) * n], ld_out=c)  # P V + b_v
             arena.release(mk)
+        if self.tap is not None:
+            self._tap(a + ".q", qk[:, :c].reshape(b, hh, ww, c))
+            self._tap(a + ".k", qk[:, c:].reshape(b, hh, ww, c))
+            self._tap(a + ".o", o.view(b, hh, ww, c))
         _, st = ops.linear(o, *self.w[a + ".proj_out"], residual=x.view(-1, c), out=out.view(-1, c), ld_out=c, n=b, h=hh, w=ww, stats=True,
                            stats_partial=out_part)
         arena.release(m)
+        self._tap(a, out)
         return ops.attach_stats(out, st)
 
     def _decode_impl(self, z, arena):
@@ -274,6 +293,7 @@ class IntegratedAutoencoderKL:
         else:
             h, st = ops.conv_gemm(zq, self.w["conv_in"][0], lay.block_in, kh=3, pad=1, bias=self.w["conv_in"][1], stats=True)
         h = ops.attach_stats(h.view(b, hh, ww, lay.block_in), st)
+        self._tap("conv_in", h)
         bi = lay.block_in
         h = self._res("decoder.mid.block_1", h, bi, bi, arena)
         h = self._attn(h, arena)
@@ -285,6 +305,7 @@ class IntegratedAutoencoderKL:
                 bb, h2, w2, c = h.shape
                 h, st = ops.conv_gemm(h, self.w[up][0], c, kh=3, pad=1, up=(2 * h2, 2 * w2), bias=self.w[up][1], stats=True)
                 h = ops.attach_stats(h.view(bb, 2 * h2, 2 * w2, c), st)
+                self._tap(up, h)
         g = ops.groupnorm(h, *self.w["norm_out"], 1e-6, silu=True)
         co, cin = lay.out_channels, g.shape[-1]
         if co <= 4 and cin % 32 == 0 and g.numel() * 2 < 3.0e9:
@@ -297,6 +318,8 @@ class IntegratedAutoencoderKL:
             y = ops.empty((g.shape[0] * g.shape[1] * g.shape[2], 4), self.dtype)
             y.zero_()
             y = ops.conv_gemm(g, self.w["conv_out"][0], co, kh=3, pad=1, bias=self.w["conv_out"][1], out=y, ld_out=4)
+        if self.tap is not None:
+            self._tap("conv_out", y.view(g.shape[0], g.shape[1], g.shape[2], 4)[..., :co])
         return y
 
     def _run(self, z):
