@@ -55,6 +55,7 @@ class IntegratedFluxTransformer2DModel:
         self.depth, self.depth_single = config["depth"], config["depth_single_blocks"]
         self.axes_dim, self.theta = list(config["axes_dim"]), config["theta"]
         self._pe_cache = {}
+        self.tap = None    # test hook (tests/test_gpu_flux_sharp_parity.py): a dict that receives every stored stage output of the next forward
         self._load(state_dict)
 
     # ------------------------------------------------------------------------------------------------------------
@@ -124,6 +125,16 @@ class IntegratedFluxTransformer2DModel:
         return pe
 
     # ------------------------------------------------------------------------------------------------------------
+    def _tap(self, key, t):
+        if self.tap is not None:
+            self.tap[key] = t.float().cpu()
+
+    def _tap_qkv(self, key, qj, kj, vtj, bsz, ltot, lpad):
+        if self.tap is not None:
+            self._tap(key + ".q", qj[:, :ltot])
+            self._tap(key + ".k", kj[:, :ltot])
+            self._tap(key + ".v", vtj.view(self.hidden, bsz, lpad)[:, :, :ltot].permute(1, 2, 0))
+
     def _mlp_embed(self, x, k):
         h = ops.linear(x, *self.w[k + ".in_layer"])
         h = ops.silu(h, out=h)
@@ -169,9 +180,12 @@ class IntegratedFluxTransformer2DModel:
         yv = y.to(device=dev, dtype=self.dtype).contiguous()
         vec = ops.linear(ops.silu(ops.linear(yv, *self.w["vector_in.in_layer"])), *self.w["vector_in.out_layer"], residual=vec)
         mods = ops.linear(ops.silu(vec), *self.w["mods"])                       # [B, total]
+        self._tap("vec", vec)
 
         img = ops.linear(img_tok, *self.w["img_in"])                            # [B*L, hs]
         txt = ops.linear(ctx.view(bsz * lt, -1), *self.w["txt_in"])             # [B*Lt, hs]
+        self._tap("img_in", img.view(bsz, L, hs))
+        self._tap("txt_in", txt.view(bsz, lt, hs))
         qj = torch.zeros(bsz, lpad, hs, dtype=self.dtype, device=dev)           # joint txt||img q, k (pad rows stay 0)
         kj = torch.zeros(bsz, lpad, hs, dtype=self.dtype, device=dev)
         vtj = torch.zeros(hs, bsz * lpad, dtype=self.dtype, device=dev)         # V^T
@@ -188,17 +202,22 @@ class IntegratedFluxTransformer2DModel:
                 qkv = ops.linear(xm, *self.w[f"{b}.{st}.qkv"])
                 ops.flux_qk_norm_rope(qkv, self.w[f"{b}.{st}.qs"], self.w[f"{b}.{st}.ks"], pe, qj, kj, vtj, batch=bsz, tokens=n_tok,
                                       heads=H, head_dim=D, row_off=row_off, l_pad=lpad)
+            self._tap_qkv(b, qj, kj, vtj, bsz, ltot, lpad)
             attn = self._attend(qj, kj, vtj, bsz, ltot, lpad).view(bsz, ltot, hs)
+            self._tap(b + ".attn", attn)
             for st, n_tok, row_off in streams:
                 xs = cur[st]
                 pw, pb = self.w[f"{b}.{st}.proj"]
                 for bi in range(bsz):   # the stream's rows of the joint attention output are contiguous per batch element
                     rows = xs[bi * n_tok:(bi + 1) * n_tok]
                     ops.conv_gemm(attn[bi, row_off:row_off + n_tok], pw, hs, bias=pb, gate=md[st][2][bi:bi + 1], residual=rows, out=rows, ld_out=hs)
+                self._tap(f"{b}.{st}.a", xs.view(bsz, n_tok, hs))
                 xm = ops.layernorm_mod(xs, md[st][4], md[st][3], n_tok)
                 hdn = ops.conv_gemm(xm, self.w[f"{b}.{st}.mlp0"][0], self.mlp, bias=self.w[f"{b}.{st}.mlp0"][1], act=ops.ACT_GELU_TANH)
+                self._tap(f"{b}.{st}.h", hdn.view(bsz, n_tok, self.mlp))
                 ops.conv_gemm(hdn, self.w[f"{b}.{st}.mlp2"][0], hs, n=bsz, h=1, w=n_tok, bias=self.w[f"{b}.{st}.mlp2"][1], gate=md[st][5],
                               residual=xs, out=xs, ld_out=hs)
+                self._tap(f"{b}.{st}", xs.view(bsz, n_tok, hs))
 
         # ---- single-stream blocks on the joint sequence (flux.py:283-307) ------------------------------------------
         xj = torch.cat((txt.view(bsz, lt, hs), img.view(bsz, L, hs)), 1).reshape(bsz * ltot, hs).contiguous()  # flux.py:392
@@ -210,15 +229,20 @@ class IntegratedFluxTransformer2DModel:
             mlp = ops.conv_gemm(xm, self.w[b + ".mlp"][0], self.mlp, bias=self.w[b + ".mlp"][1], act=ops.ACT_GELU_TANH)
             ops.flux_qk_norm_rope(qkv, self.w[b + ".qs"], self.w[b + ".ks"], pe, qj, kj, vtj, batch=bsz, tokens=ltot, heads=H, head_dim=D,
                                   row_off=0, l_pad=lpad)
+            self._tap_qkv(b, qj, kj, vtj, bsz, ltot, lpad)
+            self._tap(b + ".mlp", mlp.view(bsz, ltot, self.mlp))
             attn = self._attend(qj, kj, vtj, bsz, ltot, lpad)
+            self._tap(b + ".attn", attn.view(bsz, ltot, hs))
             ops.conv_gemm(attn, self.w[b + ".lin2"][0], hs, x1=mlp, n=bsz, h=1, w=ltot, bias=self.w[b + ".lin2"][1], gate=gate, residual=xj,
                           out=xj, ld_out=hs)
+            self._tap(b, xj.view(bsz, ltot, hs))
 
         # ---- final layer (flux.py:317-328) + unpatchify (:416) -------------------------------------------------------
         imgf = xj.view(bsz, ltot, hs)[:, lt:].reshape(bsz * L, hs).contiguous()
         shift, scale = self._mod(mods, "final", 2)
         out = ops.linear(ops.layernorm_mod(imgf, scale, shift, L), *self.w["final_layer.linear"])     # [B*L, 64]
         out = out.view(bsz, h_len, w_len, c, 2, 2).permute(0, 3, 1, 4, 2, 5).reshape(bsz, c, h_len * 2, w_len * 2)
+        self._tap("out", out[:, :, :h, :w])
         return out[:, :, :h, :w].to(x.dtype)
 
     __call__ = forward
