@@ -410,18 +410,21 @@ def other_configs_leg(timeout=90):
     """The small-batch regime in the driver's own record: after the timed region of the default workload, BASELINE config 2
     (SD1.5 512^2, batch 4, Euler a) and SDXL 1024^2 at batch 1 (how the reference is used: modules/processing.py:139 `batch_size: int = 1`) are each
     measured by a child process running THIS file with that workload (10 timed steps after 2 warm-up steps, same contract, graph replay on) -- the
-    default line's own numbers are untouched by them.  -> {name: {it_per_s, ms_per_step, step_frac_of_mfma_peak, gemm_frac_of_mfma_peak, ...}}"""
+    default line's own numbers are untouched by them; and Flux.1-dev at 1024^2, batch 2 in bfloat16 (BASELINE config 5's network; 5 timed steps).  -> {name: {it_per_s, ms_per_step, step_frac_of_mfma_peak, gemm_frac_of_mfma_peak, ...}}"""
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     legs = {"sd15-512-b4-eulera (BASELINE configs[1])": ["--config", "sd15-b4-eulera"],
-            "sdxl-1024-b1-euler (the reference's default batch size)": ["--config", "sdxl-b8-euler20", "--batch", "1"]}
+            "sdxl-1024-b1-euler (the reference's default batch size)": ["--config", "sdxl-b8-euler20", "--batch", "1"],
+            # BASELINE config 5's network in the reference's own compute type: Flux.1-dev (11.9 B parameters, random init drawn on the device), 1024^2, batch 2
+            "flux-dev-1024-b2-bf16 (BASELINE configs[4]'s network)": ["--config", "flux-b2-bf16"]}
     out = {}
     for name, flags in legs.items():
         t0 = time.time()
         try:
-            res = subprocess.run([sys.executable, os.path.abspath(__file__), *flags, "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--no-vae",
-                                  "--no-rccl-selfcheck", "--no-other-configs"], capture_output=True, text=True, timeout=timeout, env=env)
+            steps = "5" if "flux" in name else "10"
+            res = subprocess.run([sys.executable, os.path.abspath(__file__), *flags, "--steps", steps, "--warmup", "2", "--no-cpu-baseline", "--no-vae",
+                                  "--no-rccl-selfcheck", "--no-other-configs"], capture_output=True, text=True, timeout=2 * timeout if "flux" in name else timeout, env=env)
             line = next((ln for ln in reversed(res.stdout.splitlines()) if ln.startswith("{")), None)
             if line is None:
                 out[name] = {"ok": False, "returncode": res.returncode, "stderr_tail": res.stderr[-300:]}
