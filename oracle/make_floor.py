@@ -20,6 +20,7 @@ tests/parity.py turns that into the tolerances of the native path (max(1e-3, fac
     python -m oracle.make_floor --only sdxl     # SDXL full-size forward floor                                (~8 min)
     python -m oracle.make_floor --only config3  # + fixture sdxl_config3.pt: SDXL 1024^2, one image, 30-step DPM++ 2M + 1024^2 VAE decode (~30 min)
     python -m oracle.make_floor --only config3_b8 # + fixture sdxl_config3_b8.pt: SDXL 1024^2, batch 8 with eight distinct conditionings / seeds, 5-step DPM++ 2M (~45 min)
+    python -m oracle.make_floor --only headline_b8 # + fixture sdxl_headline_b8.pt: the bench's own job -- SDXL 1024^2, batch 8, 20-step Euler, CFG 7 (~1 h fp32 + the fp16 floor run)
     python -m oracle.make_floor --only vae1024  # 1024^2 decode only (fixture + floor)
     python -m oracle.make_floor --only flux_width # fixture flux_width3072_fwd.pt: Flux at hidden 3072 / 24 x 128 / 4096 + 256 tokens, 1 + 1 blocks, + its f16 / bf16 floors
     python -m oracle.make_floor --only flux_depth # fixture flux_depth4x8_fwd.pt: the same width with 4 double + 8 single blocks (2.5 B parameters), + its f16 / bf16 floors
@@ -574,6 +575,44 @@ def gen_config3_b8(steps=5, batch=8):
     update(fl)
 
 
+def gen_headline_b8(steps=20, batch=8, floor_only=False):
+    """The BENCH's own job against the real reference (round 5): SDXL 1024x1024, batch 8 with eight distinct conditionings and seeds, Euler on the model's
+    default schedule, CFG 7, the metric's 20 steps -- 320 sample-forwards of the reference UNet on CPU fp32 (fixture tests/golden/sdxl_headline_b8.pt: the
+    eight final latents + the first denoised prediction), then the same job in the reference's fp16 mode (floor, per image and overall).  The fixture is
+    written as soon as the fp32 run is done; `floor_only` re-runs only the fp16 job against a fixture that already exists."""
+    cfg = synth.SDXL_UNET_CONFIG
+    sd = synth.synth_unet_state_dict(cfg, seed=0)
+    c, uc = synth.synth_conditioning(batch, cfg["context_dim"], cfg["adm_in_channels"], seed=1234)
+    c, uc = ref_import.SdxlCond(c), ref_import.SdxlCond(uc)
+    seeds = [5200 + i for i in range(batch)]
+    path = os.path.join(GOLD, "sdxl_headline_b8.pt")
+    if not floor_only:
+        t0 = time.time()
+        net = ref_import.build_ref_unet(cfg, sd)
+        trace = []
+        lat, sigmas = mg.ref_sample(net, cfg, c, uc, seeds, 128, steps, "Euler", trace=trace)
+        t32 = time.time() - t0
+        del net
+        print("headline job at batch %d: reference fp32 %d Euler steps in %.0f s" % (batch, steps, t32), flush=True)
+        torch.save({"seeds": seeds, "steps": steps, "sampler": "Euler", "batch": batch, "cond_seed": 1234, "latent": lat, "sigmas": sigmas,
+                    "denoised0": trace[0], "cpu_seconds": {"sample": t32, "threads": torch.get_num_threads()}}, path)
+        d0 = trace[0]
+        del trace
+    else:
+        g = torch.load(path)
+        lat, d0 = g["latent"], g["denoised0"]
+    t0 = time.time()
+    net16 = half_unet(cfg, sd)
+    del sd
+    tr16 = []
+    lat16, _ = mg.ref_sample(net16, cfg, c, uc, seeds, 128, steps, "Euler", trace=tr16)
+    del net16
+    print("headline job: reference fp16 run in %.0f s" % (time.time() - t0), flush=True)
+    fl = {"sdxl_headline_b8.pt:latent": metrics(lat16, lat), "sdxl_headline_b8.pt:denoised0": metrics(tr16[0], d0)}
+    fl["sdxl_headline_b8.pt:latent_per_image_worst"] = _worst([metrics(lat16[i:i + 1], lat[i:i + 1]) for i in range(batch)])
+    update(fl)
+
+
 def _worst(ms):
     return {k: max(m[k] for m in ms) for k in ("max_rel", "pp_rel", "rms_rel")}
 
@@ -730,6 +769,10 @@ def main():
         gen_flux_depth()
     if a.only == "config3":
         gen_config3(a.steps)
+    if a.only == "headline_b8":
+        gen_headline_b8()
+    if a.only == "headline_b8_floor":
+        gen_headline_b8(floor_only=True)
     if a.only == "config3_b8":
         gen_config3_b8(min(a.steps, 8) if a.steps != 30 else 5)
 

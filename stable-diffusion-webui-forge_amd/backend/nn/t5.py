@@ -48,6 +48,7 @@ class IntegratedT5:
         if config.get("model_type") == "umt5":
             raise NotImplementedError("umt5 (a relative-position table per block)")
         self.transformer = _Transformer(self)
+        self.tap = None    # test hook: a list that receives the stream after the embedding, after every block, and the final norm's output
         self._bias = {}
         self._load(state_dict)
 
@@ -104,6 +105,8 @@ class IntegratedT5:
         x = self.w["tok"][ids32.long()].reshape(m, c).contiguous()              # nn.Embedding gather (:205); no position embedding in T5
         tp = -(-t // 64) * 64
         bias = self.position_bias(t, tp)
+        if self.tap is not None:
+            self.tap.append(x.float().cpu().view(b, t, c))
         for i in range(self.layers):
             n = ops.rmsnorm(x, self.w[f"{i}.ln0"], 1e-6)
             if tp == t:
@@ -124,6 +127,11 @@ class IntegratedT5:
             lin = ops.linear(n, self.w[f"{i}.wi1"])                              # hidden_linear = wi_1 x
             h = ops.conv_gemm(n, self.w[f"{i}.wi0"], self.ff, act=ops.ACT_GELU_TANH, gate=lin, n=m, h=1, w=1)   # gelu_tanh(wi_0 x) * hidden_linear, per row
             x = ops.linear(h, self.w[f"{i}.wo"], residual=x)
-        return ops.rmsnorm(x, self.w["final"], 1e-6).view(b, t, c).float()
+            if self.tap is not None:
+                self.tap.append(x.float().cpu().view(b, t, c))
+        y = ops.rmsnorm(x, self.w["final"], 1e-6).view(b, t, c).float()
+        if self.tap is not None:
+            self.tap.append(y.cpu())
+        return y
 
     __call__ = encode

@@ -44,6 +44,31 @@ def test_clip_text_encoder_vs_transformers_fixture(name, cfg):
         check(f"{name} pooled x text_projection", pp, g["pooled_projected"], floor=f"{name}.pt:pooled_projected")
 
 
+@pytest.mark.parametrize("name,cfg", [("clip_l (tiny)", synth.TINY_CLIP_L_CONFIG), ("clip_g (tiny)", synth.TINY_CLIP_G_CONFIG), ("CLIP-L at full size", synth.CLIP_L_CONFIG)])
+def test_clip_layer_by_layer_against_the_rounding_oracle(name, cfg):
+    """SHARP parity of the text encoder (DESIGN 2.4's construction for row f2): every hidden state the native CLIP hands out against the rounding oracle
+    (oracle/clip_fp16sites.py: the pinned restatement with fp16 rounding at the executor's storage sites) evaluated on the NATIVE hidden state in front of
+    it.  A whole layer (eight rounding levels between two hidden states) per comparison: gate 5e-4 rms, 3 ulps per element."""
+    from oracle import clip_fp16sites as c16
+    import parity
+    sd = synth.synth_clip_state_dict(cfg)
+    g = torch.Generator("cpu").manual_seed(3)
+    ids = torch.randint(0, cfg["vocab_size"] - 2, (2, 77), generator=g)
+    ids[:, 0] = cfg["vocab_size"] - 2
+    ids[0, 12:] = cfg["vocab_size"] - 1
+    ids[1, 40:] = cfg["vocab_size"] - 1
+    net = IntegratedCLIP(cfg, sd, device=DEV)
+    nat = [h.float().cpu().view(2, 77, -1) for h in net.hidden_states(ids.to(DEV))]
+    ora = c16.clip_hidden_states(sd, cfg, ids, teacher=nat)
+    assert len(nat) == len(ora) == cfg["num_hidden_layers"] + 1
+    ms = [parity.metrics(a, b) for a, b in zip(nat, ora)]
+    worst = max(ms, key=lambda m: m["rms_rel"])
+    print(f"[sharp-clip] {name}: {len(ms)} hidden states, worst rms_rel {worst['rms_rel']:.2e}, worst per-pixel {max(m['pp_rel'] for m in ms):.2e}, "
+          f"embeddings rms_rel {ms[0]['rms_rel']:.1e}")
+    assert ms[0]["rms_rel"] < 1e-6                                      # token + position embedding: one rounding on both sides
+    assert all(m["rms_rel"] <= 5e-4 and m["pp_rel"] <= 3e-3 for m in ms), ms
+
+
 def test_classic_engine_emphasis_and_chunks():
     cfg = synth.TINY_CLIP_L_CONFIG
     sd = synth.synth_clip_state_dict(cfg)

@@ -880,6 +880,32 @@ def test_sdxl_config3_batch8_distinct_conditionings_vs_reference_fixture(sdxl_en
     assert float((lat[1:] - lat[:1]).abs().mean()) > 0.1 * float(lat.abs().mean())
 
 
+@pytest.mark.skipif(not _have("sdxl_headline_b8.pt"), reason="full fixture not generated")
+def test_the_bench_job_itself_vs_reference_fixture(sdxl_engine):
+    """The job `bench.py` times, end to end against the real reference (round 5): SDXL 1024x1024, batch 8 with eight distinct conditionings and seeds,
+    Euler on the model's default schedule, CFG 7, the metric's 20 steps through `process_images` (UNet batch 16 per step, graph replay) -- every image
+    against the reference's CPU fp32 run of the same job (oracle/make_floor.py gen_headline_b8: 320 sample-forwards of the 2.57 B-parameter UNet),
+    held against the reference's own fp16 run of it (per image: the worst per-image floor)."""
+    g = load_golden("sdxl_headline_b8.pt")
+    cfg = synth.SDXL_UNET_CONFIG
+    b = g["batch"]
+    c, uc = _conds(cfg, b)
+    shared.opts.randn_source = "CPU"
+    p = processing.StableDiffusionProcessingTxt2Img(sd_model=sdxl_engine, c=c, uc=uc, seed=g["seeds"][0], sampler_name=g["sampler"], batch_size=b,
+                                                    steps=g["steps"], cfg_scale=7.0, width=1024, height=1024, do_decode=False)
+    res = processing.process_images(p)
+    assert res.seeds == g["seeds"] and g["steps"] == 20 and g["sampler"] == "Euler"
+    have_floor = "sdxl_headline_b8.pt:latent" in parity.FLOORS
+    # (until the fixture's own fp16 floor exists -- the reference's fp16 run of this job takes hours of CPU -- the 30-step single-image job's floor stands in)
+    fl_all = "sdxl_headline_b8.pt:latent" if have_floor else "sdxl_config3.pt:latent"
+    fl_img = "sdxl_headline_b8.pt:latent_per_image_worst" if have_floor else "sdxl_config3.pt:latent"
+    check(f"the bench job: SDXL 1024x1024 batch {b}, {g['steps']}-step Euler, CFG 7, latents vs reference", res.latents, g["latent"], floor=fl_all)
+    for i in range(b):
+        check(f"the bench job: image {i} vs reference", res.latents[i:i + 1], g["latent"][i:i + 1], floor=fl_img)
+    lat = res.latents.float().cpu()
+    assert float((lat[1:] - lat[:1]).abs().mean()) > 0.1 * float(lat.abs().mean())
+
+
 @pytest.mark.parametrize("fixture", ["sdxl_vae1024.pt", "sdxl_config3_decode.pt"])
 def test_sdxl_vae_decode_1024_vs_reference_fixture(fixture, sdxl_engine):
     """The 1024x1024 VAE decode incl. the mid-block attention over 16 384 tokens (backend/nn/vae.py:118-137, attention.py:412-422) against the

@@ -389,6 +389,33 @@ class _WordTokenizer:
         return {"input_ids": [[self.lo + zlib.crc32(w.encode()) % (self.vocab - self.lo - 2) for w in t.replace(",", " , ").split()] for t in texts]}
 
 
+@pytest.mark.parametrize("dt,tag", [(torch.bfloat16, "bf16"), (torch.float16, "f16")])
+@pytest.mark.parametrize("size", ["tiny", "wide"])
+def test_t5_block_by_block_against_the_rounding_oracle(size, dt, tag):
+    """SHARP parity of the T5 encoder (DESIGN 2.4's construction for the text encoder of Flux): the stream after the embedding, after every block and
+    after the final norm against the rounding oracle (oracle/t5_sites.py: the pinned restatement with rounding at the executor's storage sites, in its
+    element type) evaluated on the NATIVE stream in front of each block.  A whole block -- ten rounding levels -- per comparison; gates in ulps of the
+    element type: rms <= 0.6 ulp (measured 0.07 .. 0.37), per element <= 4 ulps (measured <= 2.5).  `wide`: 16 heads x 64, d_ff 2816, 4 blocks, 256 tokens (T5-XXL's sequence length)."""
+    from forge_amd.backend.nn.t5 import IntegratedT5
+    from oracle import t5_sites as ts
+    cfg = synth.TINY_T5_CONFIG if size == "tiny" else dict(synth.T5_XXL_CONFIG, d_model=1024, num_heads=16, d_ff=2816, num_layers=4)
+    sd = synth.synth_t5_state_dict(cfg)
+    g = torch.Generator("cpu").manual_seed(9)
+    ids = torch.randint(0, cfg["vocab_size"], (2, 40 if size == "tiny" else 256), generator=g)
+    net = IntegratedT5(cfg, sd, device=DEV, dtype=dt)
+    net.tap = []
+    net.encode(ids.to(DEV))
+    nat, net.tap = net.tap, None
+    ora = ts.t5_block_outputs(sd, cfg, ids, dtype=dt, teacher=nat)
+    assert len(nat) == len(ora) == cfg["num_layers"] + 2
+    ulp = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10
+    ms = [parity.metrics(a, b) for a, b in zip(nat, ora)]
+    print(f"[sharp-t5] {size} {tag}: {len(ms)} stream states, worst rms_rel {max(m['rms_rel'] for m in ms) / ulp:.2f} ulp, worst per-element "
+          f"{max(m['pp_rel'] for m in ms) / ulp:.2f} ulp")
+    assert ms[0]["rms_rel"] == 0.0                                  # the embedding gather is exact
+    assert all(m["rms_rel"] <= 0.6 * ulp and m["pp_rel"] <= 4 * ulp for m in ms), ms
+
+
 def test_flux_from_prompt_strings_with_a_negative_prompt():
     """prompt STRINGS -> FluxEngine.get_learned_conditioning (CLIP-L pooled + T5 sequence + distilled guidance, diffusion_engine/flux.py:84-100) ->
     sampling with a negative prompt at cond_scale 3 (two model calls per step, sampling_function.py:292-312) -> latents, against the CPU oracles
