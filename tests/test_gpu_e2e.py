@@ -895,10 +895,7 @@ def test_the_bench_job_itself_vs_reference_fixture(sdxl_engine):
                                                     steps=g["steps"], cfg_scale=7.0, width=1024, height=1024, do_decode=False)
     res = processing.process_images(p)
     assert res.seeds == g["seeds"] and g["steps"] == 20 and g["sampler"] == "Euler"
-    have_floor = "sdxl_headline_b8.pt:latent" in parity.FLOORS
-    # (until the fixture's own fp16 floor exists -- the reference's fp16 run of this job takes hours of CPU -- the 30-step single-image job's floor stands in)
-    fl_all = "sdxl_headline_b8.pt:latent" if have_floor else "sdxl_config3.pt:latent"
-    fl_img = "sdxl_headline_b8.pt:latent_per_image_worst" if have_floor else "sdxl_config3.pt:latent"
+    fl_all, fl_img = "sdxl_headline_b8.pt:latent", "sdxl_headline_b8.pt:latent_per_image_worst"
     check(f"the bench job: SDXL 1024x1024 batch {b}, {g['steps']}-step Euler, CFG 7, latents vs reference", res.latents, g["latent"], floor=fl_all)
     for i in range(b):
         check(f"the bench job: image {i} vs reference", res.latents[i:i + 1], g["latent"][i:i + 1], floor=fl_img)
