@@ -21,6 +21,7 @@ tests/parity.py turns that into the tolerances of the native path (max(1e-3, fac
     python -m oracle.make_floor --only config3  # + fixture sdxl_config3.pt: SDXL 1024^2, one image, 30-step DPM++ 2M + 1024^2 VAE decode (~30 min)
     python -m oracle.make_floor --only config3_b8 # + fixture sdxl_config3_b8.pt: SDXL 1024^2, batch 8 with eight distinct conditionings / seeds, 5-step DPM++ 2M (~45 min)
     python -m oracle.make_floor --only headline_b8 # + fixture sdxl_headline_b8.pt: the bench's own job -- SDXL 1024^2, batch 8, 20-step Euler, CFG 7 (~1 h fp32 + the fp16 floor run)
+    python -m oracle.make_floor --only flux_job  # + fixture flux_job_b2.pt: BASELINE config 5's job -- Flux.1-dev full depth, 1024^2, batch 2, 20 Euler steps (needs ~55 GB of host memory, ~2 h)
     python -m oracle.make_floor --only vae1024  # 1024^2 decode only (fixture + floor)
     python -m oracle.make_floor --only flux_width # fixture flux_width3072_fwd.pt: Flux at hidden 3072 / 24 x 128 / 4096 + 256 tokens, 1 + 1 blocks, + its f16 / bf16 floors
     python -m oracle.make_floor --only flux_depth # fixture flux_depth4x8_fwd.pt: the same width with 4 double + 8 single blocks (2.5 B parameters), + its f16 / bf16 floors
@@ -510,6 +511,79 @@ def gen_flux_full(only_floor=None):
         print("  %s run done in %.0f s: %s" % (tag, time.time() - t0, m), flush=True)
 
 
+def gen_flux_job(steps=20, batch=2, floor_only=False):
+    """BASELINE config 5's job against the real reference (round 5): Flux.1-dev at FULL depth (19 + 38 blocks, 11.9 B parameters), 1024x1024 (4096 image
+    tokens) + 256 text tokens, batch 2 (the per-GPU shard of 16 images on 8 GPUs), `steps` Euler steps on the 'simple' flow schedule through the reference's
+    KModel + PredictionFlux + k_diffusion.sample_euler, distilled guidance 3.5 -- on CPU fp32 (fixture tests/golden/flux_job_b2.pt: final latents, the noise,
+    the schedule), then the same job in bfloat16, the reference's own compute type for Flux (floor).  Weights: the seeded stream, filled tensor by tensor."""
+    import contextlib
+    import io
+    from forge_amd.backend.nn.layout import flux_param_shapes
+    cfg = dict(synth.FLUX_DEV_CONFIG)
+    shapes = flux_param_shapes(cfg)
+    ref = ref_import.load_reference()
+    with torch.device("meta"):
+        net = ref.nn_flux.IntegratedFluxTransformer2DModel(**cfg)
+    net = net.to_empty(device="cpu")
+    lazy = synth.LazySynthStateDict(shapes, seed=2)
+    own = dict(net.named_parameters())
+
+    def fill():
+        with torch.no_grad():
+            for name, prm in own.items():
+                prm.copy_(lazy[name])
+
+    fill()
+    net.storage_dtype = net.computation_dtype = torch.float32
+    net.load_device = net.offload_device = net.initial_device = torch.device("cpu")
+    net.eval()
+    lat_hw, ltxt = 128, 256
+    g = torch.Generator("cpu").manual_seed(77)
+    ctx = torch.randn(batch, ltxt, cfg["context_in_dim"], generator=g)
+    y = torch.randn(batch, cfg["vec_in_dim"], generator=g)
+    guid = torch.full((batch,), 3.5)
+    x0 = torch.randn(batch, cfg["in_channels"], lat_hw, lat_hw, generator=g)
+    pred = ref.k_prediction.PredictionFlux(seq_len=(lat_hw // 2) ** 2)
+    ss = len(pred.sigmas) / steps
+    sigmas = torch.FloatTensor([float(pred.sigmas[-(1 + int(i * ss))]) for i in range(steps)] + [0.0])
+    path = os.path.join(GOLD, "flux_job_b2.pt")
+
+    def run(dt):
+        with contextlib.redirect_stdout(io.StringIO()):
+            km = ref.k_model.KModel(net, None, k_predictor=pred)
+        xs = pred.noise_scaling(sigmas[0], x0.clone(), torch.zeros_like(x0))
+
+        def model_fn(xx, sigma, **kw):
+            return km.apply_model(xx, sigma, c_crossattn=ctx, y=y, guidance=guid)
+        with torch.no_grad():
+            return ref.kd_sampling.sample_euler(model_fn, xs, sigmas, disable=True).float()
+
+    if not floor_only:
+        t0 = time.time()
+        lat = run(torch.float32)
+        secs = time.time() - t0
+        torch.save({"latent": lat, "noise": x0, "ctx_seed": 77, "sigmas": sigmas, "sigma_table": pred.sigmas.clone(), "steps": steps, "batch": batch, "weights_seed": 2,
+                    "guidance": 3.5, "cpu_seconds": secs}, path)
+        print("flux job: reference fp32 %d steps x batch %d in %.0f s, latent std %.4f" % (steps, batch, secs, float(lat.std())), flush=True)
+    else:
+        lat = torch.load(path)["latent"]
+    t0 = time.time()
+    net.to(torch.bfloat16)
+    net.storage_dtype = net.computation_dtype = torch.bfloat16
+    lat16 = run(torch.bfloat16)
+    print("flux job: reference bf16 run in %.0f s" % (time.time() - t0), flush=True)
+    update({"flux_job_b2.pt:latent@bf16": metrics(lat16, lat)})
+
+
+def flux_job_conditioning(cfg, batch=2, seed=77, lat_hw=128, ltxt=256):
+    """the conditioning / noise of tests/golden/flux_job_b2.pt, regenerated from the seed (same draws, same order, as gen_flux_job)"""
+    g = torch.Generator("cpu").manual_seed(seed)
+    ctx = torch.randn(batch, ltxt, cfg["context_in_dim"], generator=g)
+    y = torch.randn(batch, cfg["vec_in_dim"], generator=g)
+    x0 = torch.randn(batch, cfg["in_channels"], lat_hw, lat_hw, generator=g)
+    return ctx, y, torch.full((batch,), 3.5), x0
+
+
 def floors_sdxl_full():
     cfg = synth.SDXL_UNET_CONFIG
     g = _load("sdxl_full_fwd.pt")
@@ -769,6 +843,10 @@ def main():
         gen_flux_depth()
     if a.only == "config3":
         gen_config3(a.steps)
+    if a.only == "flux_job":
+        gen_flux_job()
+    if a.only == "flux_job_floor":
+        gen_flux_job(floor_only=True)
     if a.only == "headline_b8":
         gen_headline_b8()
     if a.only == "headline_b8_floor":

@@ -295,6 +295,47 @@ def test_flux_forward_at_full_depth_vs_reference_fixture():
     assert "bf16" in ran
 
 
+def test_flux_dev_job_at_full_depth_vs_reference_fixture():
+    """BASELINE config 5's job end to end against the real reference (round 5): Flux.1-dev at full depth (11.9 B parameters) in bfloat16, 1024x1024, batch 2
+    (the per-GPU shard), 20 Euler steps on the 'simple' flow schedule, distilled guidance 3.5, through processing -> KDiffusionSampler -> CFGDenoiser ->
+    KModelFlux with graph replay -- against the reference's CPU fp32 run of the same job through its own KModel / PredictionFlux / sample_euler
+    (oracle/make_floor.py gen_flux_job: 40 forwards of the full network), held against the reference's own bfloat16 run of it."""
+    import os
+    from conftest import GOLDEN
+    if not os.path.exists(os.path.join(GOLDEN, "flux_job_b2.pt")) or "flux_job_b2.pt:latent@bf16" not in parity.FLOORS:
+        pytest.skip("full-depth job fixture (or its floor) not generated")
+    from forge_amd.backend.nn.layout import flux_param_shapes
+    from oracle.make_floor import flux_job_conditioning
+    g = load_golden("flux_job_b2.pt")
+    cfg = dict(synth.FLUX_DEV_CONFIG)
+    b = g["batch"]
+    ctx, y, guid, x0 = flux_job_conditioning(cfg, b, seed=g["ctx_seed"])
+    torch.testing.assert_close(x0, g["noise"], rtol=0, atol=0)
+    sd = synth.synth_state_dict_threaded(flux_param_shapes(cfg), seed=g["weights_seed"], dtype=BF)
+    eng = build_flux_engine(cfg, sd, device=DEV, dtype=BF, seq_len=4096)
+    del sd
+    pred = eng.forge_objects.unet.model.predictor
+    torch.testing.assert_close(pred.sigmas, g["sigma_table"], rtol=1e-6, atol=1e-7)
+    cond = DictWithShape({"crossattn": ctx.to(DEV), "vector": y.to(DEV), "guidance": guid.to(DEV)})
+    p = processing.StableDiffusionProcessingTxt2Img(sd_model=eng, c=cond, uc=cond, seed=0, sampler_name="Euler", scheduler="simple", batch_size=b,
+                                                    steps=g["steps"], cfg_scale=1.0, width=1024, height=1024, do_decode=False)
+
+    class FixedNoise:
+        def next(self_inner):
+            return g["noise"].to(DEV)
+    import forge_amd.modules.rng as rng_mod
+    orig = rng_mod.ImageRNG
+    rng_mod.ImageRNG = lambda *a, **k: FixedNoise()
+    try:
+        res = processing.process_images(p)
+    finally:
+        rng_mod.ImageRNG = orig
+    check(f"Flux.1-dev at full depth, 1024x1024 batch {b}, {g['steps']}-step Euler (simple sigmas), bf16 build vs reference (fp32)", res.latents, g["latent"],
+          floor="flux_job_b2.pt:latent@bf16")
+    del eng
+    torch.cuda.empty_cache()
+
+
 def test_bf16_flux_forward_and_sampling_vs_reference_fixture():
     """The Flux executor with dtype=bfloat16 against the fp32 reference fixture (forward and the 4-step Euler run)."""
     g = load_golden("tiny_flux_fwd.pt")
