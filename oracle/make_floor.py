@@ -618,7 +618,7 @@ def gen_config3(steps=30):
     gen_vae1024(lat, tag="sdxl_config3_decode.pt")
 
 
-def gen_config3_b8(steps=5, batch=8):
+def gen_config3_b8(steps=5, batch=8, name="sdxl_config3_b8.pt"):
     """BASELINE config 3 at its own BATCH (round 4): SDXL 1024x1024, batch 8 with EIGHT DISTINCT conditionings and seeds (the first `batch` rows of
     synth_conditioning(batch, ...): different prompts, pooled vectors and noise per image), `steps` DPM++ 2M steps on the Karras schedule, CFG 7, through
     the reference's own sampling_function (cond and uncond of all eight images in the reference's model calls) -- reference fp32 (fixture
@@ -636,16 +636,16 @@ def gen_config3_b8(steps=5, batch=8):
     del net
     print("config 3 at batch %d: reference fp32 %d steps in %.0f s" % (batch, steps, t32), flush=True)
     torch.save({"seeds": seeds, "steps": steps, "sampler": "DPM++ 2M", "batch": batch, "cond_seed": 1234, "latent": lat, "sigmas": sigmas,
-                "denoised0": trace[0], "cpu_seconds": {"sample": t32, "threads": torch.get_num_threads()}}, os.path.join(GOLD, "sdxl_config3_b8.pt"))
+                "denoised0": trace[0], "cpu_seconds": {"sample": t32, "threads": torch.get_num_threads()}}, os.path.join(GOLD, name))
     net16 = half_unet(cfg, sd)
     del sd
     tr16 = []
     lat16, _ = mg.ref_sample(net16, cfg, c, uc, seeds, 128, steps, "DPM++ 2M", trace=tr16)
     del net16
-    fl = {"sdxl_config3_b8.pt:latent": metrics(lat16, lat), "sdxl_config3_b8.pt:denoised0": metrics(tr16[0], trace[0])}
+    fl = {f"{name}:latent": metrics(lat16, lat), f"{name}:denoised0": metrics(tr16[0], trace[0])}
     # one entry per image as well: the test holds every image against the WORST per-image floor (images are independent realisations)
     per = [metrics(lat16[i:i + 1], lat[i:i + 1]) for i in range(batch)]
-    fl["sdxl_config3_b8.pt:latent_per_image_worst"] = _worst(per)
+    fl[f"{name}:latent_per_image_worst"] = _worst(per)
     update(fl)
 
 
@@ -851,6 +851,8 @@ def main():
         gen_headline_b8()
     if a.only == "headline_b8_floor":
         gen_headline_b8(floor_only=True)
+    if a.only == "config3_b8_full":     # BASELINE config 3 exactly: batch 8, the full 30 DPM++ 2M steps (~1.3 h fp32 + ~1.3 h fp16)
+        gen_config3_b8(30, name="sdxl_config3_b8_30.pt")
     if a.only == "config3_b8":
         gen_config3_b8(min(a.steps, 8) if a.steps != 30 else 5)
 

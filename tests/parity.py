@@ -43,7 +43,7 @@ NORTH_STAR = 1e-3
 MAX_FACTOR = 1.5
 RMS_FACTOR = 1.25
 RMS_FACTOR_FULL = 1.15
-FULL_SIZE_FIXTURES = ("sd15_config0.pt", "sd15_config2.pt", "sdxl_full_fwd.pt", "sdxl_config3.pt", "sdxl_config3_b8.pt", "sdxl_headline_b8.pt", "sdxl_vae1024.pt",
+FULL_SIZE_FIXTURES = ("sd15_config0.pt", "sd15_config2.pt", "sdxl_full_fwd.pt", "sdxl_config3.pt", "sdxl_config3_b8.pt", "sdxl_config3_b8_30.pt", "sdxl_headline_b8.pt", "sdxl_vae1024.pt",
                       "sdxl_config3_decode.pt", "flux_width3072_fwd.pt", "flux_depth4x8_fwd.pt")
 SMALL = 1024
 SMALL_SIGMAS = 3.0

@@ -855,13 +855,17 @@ def test_sdxl_config3_dpmpp2m_vs_reference_fixture(sdxl_engine):
     check(f"SDXL 1024x1024 {g['steps']}-step DPM++ 2M latents vs reference", res.latents, g["latent"], floor="sdxl_config3.pt:latent")
 
 
-@pytest.mark.skipif(not _have("sdxl_config3_b8.pt"), reason="full fixture not generated")
-def test_sdxl_config3_batch8_distinct_conditionings_vs_reference_fixture(sdxl_engine):
+@pytest.mark.parametrize("fixture", ["sdxl_config3_b8.pt", "sdxl_config3_b8_30.pt"])
+def test_sdxl_config3_batch8_distinct_conditionings_vs_reference_fixture(fixture, sdxl_engine):
     """BASELINE config 3 at ITS batch: SDXL 1024x1024, batch 8 with EIGHT DISTINCT conditionings (prompt context, pooled vector) and
     seeds through `process_images` -- UNet batch 16 per step, the shapes the bench is timed on -- DPM++ 2M on the Karras schedule, CFG 7, the fixture's
     5 steps, every image against the real reference's CPU fp32 run of the same job (oracle/make_floor.py gen_config3_b8: 80 sample-forwards).  Each
     image is held against the worst per-image floor (the reference's own fp16 run of the same eight images), the batch as a whole against its own."""
-    g = load_golden("sdxl_config3_b8.pt")
+    # (`sdxl_config3_b8_30.pt`, round 5: the same job at config 3's FULL 30 steps -- 480 sample-forwards of the reference, 1.3 h of CPU fp32 and as long again for
+    #  its fp16 floor; skipped while either half is missing)
+    if not _have(fixture) or f"{fixture}:latent_per_image_worst" not in parity.FLOORS:
+        pytest.skip("full fixture (or its floor) not generated")
+    g = load_golden(fixture)
     cfg = synth.SDXL_UNET_CONFIG
     b = g["batch"]
     c, uc = _conds(cfg, b)                                     # synth_conditioning(8, ..., seed=1234): the fixture's conditionings
@@ -871,10 +875,10 @@ def test_sdxl_config3_batch8_distinct_conditionings_vs_reference_fixture(sdxl_en
     res = processing.process_images(p)
     assert res.seeds == g["seeds"]
     check(f"SDXL 1024x1024 batch {b}, eight distinct conditionings, {g['steps']}-step DPM++ 2M latents vs reference", res.latents, g["latent"],
-          floor="sdxl_config3_b8.pt:latent")
+          floor=f"{fixture}:latent")
     for i in range(b):
-        check(f"SDXL 1024x1024 batch {b} distinct conditionings: image {i} vs reference", res.latents[i:i + 1], g["latent"][i:i + 1],
-              floor="sdxl_config3_b8.pt:latent_per_image_worst")
+        check(f"SDXL 1024x1024 batch {b} distinct conditionings ({g['steps']} steps): image {i} vs reference", res.latents[i:i + 1], g["latent"][i:i + 1],
+              floor=f"{fixture}:latent_per_image_worst")
     # the images differ from each other (distinct conditionings reached the network: a broadcast of image 0's would pass a repeated-input test)
     lat = res.latents.float().cpu()
     assert float((lat[1:] - lat[:1]).abs().mean()) > 0.1 * float(lat.abs().mean())
