@@ -25,6 +25,8 @@ Extra objects on the JSON line:
                 network forward / their summed HIP-event time (events recorded on the launch stream), vs the 2.5 PFLOP/s dense fp16/bf16
                 MFMA peak.  `roofline_attention` carries the same for the fused attention kernel, `roofline_groupnorm` the HBM-side one for
                 GroupNorm(+SiLU) (algorithmic bytes = 1 read + 1 write of the tensor, vs 8 TB/s).
+  torch_rocm_baseline  the reference's own op stack on the SAME GPU (stock PyTorch-ROCm fp16 kernels + F.scaled_dot_product_attention running the oracle's
+                walk of the SDXL UNet at batch 16): ms per forward, it/s-equivalent; `vs_baseline` = native / that (context, not the target).
   cpu_baseline  the CPU oracle (oracle/, a restatement of the reference's torch code pinned to the real reference; kind "port") timed on
                 this box's host cores on a bounded sample: ONE sample-forward of the workload's network (B = 1; Flux: 2 + 2 blocks of the
                 57, extrapolated by block count); a step is 2 * batch (CFG) such forwards.  `reference_on_authoring_box` repeats the figure
@@ -97,6 +99,8 @@ def parse(argv=None):
     ap.add_argument("--vae-breakdown", default="", help="write the per-shape kernel-time table of one VAE decode to this file")
     ap.add_argument("--rccl-selfcheck", action="store_true", help="(child process of the 1-GPU run) RCCL at world size 1: init, all-reduce, the job's broadcast + gathers on the device")
     ap.add_argument("--no-rccl-selfcheck", action="store_true", help="1-GPU run: skip the RCCL world-1 leg")
+    ap.add_argument("--torch-rocm-baseline", action="store_true", help="(child process of the 1-GPU run) the reference's op stack -- stock PyTorch-ROCm fp16 -- on the same workload and GPU")
+    ap.add_argument("--no-torch-rocm-baseline", action="store_true", help="1-GPU run: skip the PyTorch-ROCm leg")
     ap.add_argument("--no-other-configs", action="store_true", help="default 1-GPU run: skip the two small-batch legs (BASELINE config 2 and SDXL batch 1) run after the timed region")
     ap.add_argument("--stub-engine", action="store_true", help="launcher self-test without a GPU (gloo, no kernels); not a measurement")
     return ap.parse_args(argv)
@@ -406,6 +410,80 @@ def rccl_world1_leg(timeout=120):
         return {"ok": False, "error": repr(e)}
 
 
+def torch_rocm_baseline(batch=16, latent=128, warm=3, timed=5):
+    """The SAME-GPU other side of "matching or beating" (VERDICT r5 item 5): what the reference itself executes on this part -- stock PyTorch-ROCm
+    kernels (MIOpen / hipBLASLt / ATen), fp16 storage and compute as `memory_management` picks for a GPU -- on the default workload's network step:
+    the SDXL UNet at batch 16 (8 images x {cond, uncond}) on the 128 x 128 latent.  The network is the oracle's walk (oracle/unet.py: the pinned
+    restatement of backend/nn/unet.py:696-763 whose leaves are exactly the ATen calls ForgeOperations forwards to -- F.conv2d / F.linear /
+    F.group_norm / F.layer_norm, operations.py:153-176) moved to cuda in fp16, with attention through F.scaled_dot_product_attention as
+    `attention_pytorch` does (backend/attention.py:324-339).  A BASELINE leg like `cpu_baseline` (the only other place bench.py touches oracle/):
+    timed, reported beside the native figure, never the thing measured as `value`.  It times the network forward only (no sampler arithmetic, no
+    CFG combine: those are < 0.1 % of a step), `warm` untimed forwards (MIOpen's kernel search) then `timed` forwards between synchronisations.
+    Printed as ONE JSON line by a child process."""
+    import math
+    import torch
+    import torch.nn.functional as F
+    import forge_amd  # noqa: F401
+    from forge_amd import synth
+    from forge_amd.backend.nn.layout import unet_param_shapes
+    from oracle import unet as ou
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    cfg = synth.SDXL_UNET_CONFIG
+    sd = synth.synth_state_dict_device(unet_param_shapes(cfg), 0, dev)          # fp16 on the device, the weights the native leg used
+    sd = {k: v.half() for k, v in sd.items()}
+
+    def sdpa(q, k, v, heads):                                                    # attention.py:324-339 attention_pytorch
+        b, nq, c = q.shape
+        d = c // heads
+        q, k, v = (t.reshape(b, -1, heads, d).transpose(1, 2) for t in (q, k, v))
+        return F.scaled_dot_product_attention(q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False).transpose(1, 2).reshape(b, nq, c)
+
+    def temb(t, dim, max_period=10000):                                          # unet.py:55-67, on the timesteps' device
+        half = dim // 2
+        freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
+        args = t[:, None].float() * freqs[None]
+        return torch.cat([torch.cos(args), torch.sin(args)], dim=-1).half()
+    ou.attention, ou.timestep_embedding = sdpa, temb
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(batch, cfg["in_channels"], latent, latent, generator=g).to(dev).half()
+    ctx = torch.randn(batch, 77, cfg["context_dim"], generator=g).to(dev).half()
+    y = torch.randn(batch, cfg["adm_in_channels"], generator=g).to(dev).half()
+    t = torch.full((batch,), 500.0, device=dev)
+    out = {"torch": torch.__version__, "hip": torch.version.hip, "batch": batch, "latent": latent, "dtype": "f16"}
+    with torch.inference_mode():
+        t0 = time.perf_counter()
+        for _ in range(warm):
+            eps = ou.unet_forward(sd, cfg, x, t, ctx, y)
+        torch.cuda.synchronize()
+        out["warmup_s"] = round(time.perf_counter() - t0, 1)
+        t0 = time.perf_counter()
+        for _ in range(timed):
+            eps = ou.unet_forward(sd, cfg, x, t, ctx, y)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / timed
+    out.update({"ms_per_forward": round(dt * 1e3, 2), "it_per_s_equivalent": round(1.0 / dt, 4), "forwards_timed": timed, "finite": bool(torch.isfinite(eps.float()).all()),
+                "tflops": round(batch * FLOPS_PER_SAMPLE_FWD["sdxl"] / dt / 1e12, 1), "frac_of_mfma_peak": round(batch * FLOPS_PER_SAMPLE_FWD["sdxl"] / dt / MFMA_PEAK, 4)})
+    print("TORCH_ROCM_BASELINE " + json.dumps(out), flush=True)
+
+
+def torch_rocm_baseline_leg(timeout=240):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.time()
+    try:
+        res = subprocess.run([sys.executable, os.path.abspath(__file__), "--torch-rocm-baseline"], capture_output=True, text=True, timeout=timeout, env=env)
+        for ln in res.stdout.splitlines():
+            if ln.startswith("TORCH_ROCM_BASELINE "):
+                return dict(json.loads(ln[len("TORCH_ROCM_BASELINE "):]), ok=True, wall_s_of_this_leg=round(time.time() - t0, 1))
+        return {"ok": False, "returncode": res.returncode, "stderr_tail": res.stderr[-400:]}
+    except subprocess.TimeoutExpired:
+        return {"ok": False, "error": f"timed out after {timeout} s"}
+    except Exception as e:  # noqa: BLE001
+        return {"ok": False, "error": repr(e)}
+
+
 def other_configs_leg(timeout=90):
     """The small-batch regime in the driver's own record: after the timed region of the default workload, BASELINE config 2
     (SD1.5 512^2, batch 4, Euler a) and SDXL 1024^2 at batch 1 (how the reference is used: modules/processing.py:139 `batch_size: int = 1`) are each
@@ -424,7 +502,7 @@ def other_configs_leg(timeout=90):
         try:
             steps = "5" if "flux" in name else "10"
             res = subprocess.run([sys.executable, os.path.abspath(__file__), *flags, "--steps", steps, "--warmup", "2", "--no-cpu-baseline", "--no-vae",
-                                  "--no-rccl-selfcheck", "--no-other-configs"], capture_output=True, text=True, timeout=2 * timeout if "flux" in name else timeout, env=env)
+                                  "--no-rccl-selfcheck", "--no-other-configs", "--no-torch-rocm-baseline"], capture_output=True, text=True, timeout=2 * timeout if "flux" in name else timeout, env=env)
             line = next((ln for ln in reversed(res.stdout.splitlines()) if ln.startswith("{")), None)
             if line is None:
                 out[name] = {"ok": False, "returncode": res.returncode, "stderr_tail": res.stderr[-300:]}
@@ -448,6 +526,8 @@ def main():
     a = parse()
     if a.rccl_selfcheck:
         return rccl_selfcheck()
+    if a.torch_rocm_baseline:
+        return torch_rocm_baseline()
     if a.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -720,6 +800,16 @@ def main():
                 out["cpu_baseline"]["reference_on_authoring_box"] = ref_box
         except Exception as e:  # the baseline must never take the bench line down
             out["cpu_baseline"] = {"value": None, "error": repr(e)}
+    default_workload = a.config == "sdxl-b8-euler20" and not (a.model or a.res or a.batch or a.sampler)
+    if rank == 0 and world == 1 and not a.no_torch_rocm_baseline and default_workload:
+        # the reference's own op stack on THIS GPU, same network step (child process, after the timed region).  `vs_baseline` = native / that: context --
+        # BASELINE.md publishes no number for this metric, and the target is the kernel roofline, not this ratio
+        tb = torch_rocm_baseline_leg()
+        out["torch_rocm_baseline"] = dict(tb, kind="the reference's op stack (stock PyTorch-ROCm ATen / MIOpen / hipBLASLt kernels, fp16, F.scaled_dot_product_attention) "
+                                                   "on the same GPU: SDXL UNet forward at batch 16, 128 x 128 latent")
+        if tb.get("ok") and tb.get("it_per_s_equivalent"):
+            out["vs_baseline"] = round(value / tb["it_per_s_equivalent"], 3)
+            out["vs_baseline_note"] = "native it/s / same-GPU PyTorch-ROCm it/s-equivalent (torch_rocm_baseline); context only -- BASELINE.md holds no published number for this metric"
     if rank == 0 and world == 1 and not a.no_rccl_selfcheck:
         out["rccl_world1"] = rccl_world1_leg()     # after the timed region, in a child process
     if rank == 0 and world == 1 and not a.no_other_configs and a.config == "sdxl-b8-euler20" and not (a.model or a.res or a.batch or a.sampler):

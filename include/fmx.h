@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define FMX_ABI_VERSION 10
+#define FMX_ABI_VERSION 11
 
 #define FMX_OK 0
 #define FMX_E_BADARG 10001   /* shape / alignment / null-pointer contract violated */
@@ -366,6 +366,36 @@ int fmx_im2col3x3_smallc(const void* x, int32_t ldx, int32_t n, int32_t c, int32
  * patch of a 4 x 32 pixel tile staged once in LDS) instead of the implicit GEMM's nine-fold im2col gather; HBM-bound (ABI 8). */
 int fmx_conv3x3_narrow_f16(const void* x, int32_t n, int32_t h, int32_t w, int32_t c, const void* wgt, const void* bias, int32_t nout, void* out,
                            int32_t ld_out, void* stream);
+/* GroupNorm + SiLU + 3x3 convolution (stride 1, padding 1) in one kernel, 128 output channels: the `norm -> swish -> conv` halves of the VAE's
+ * ResnetBlock.forward (backend/nn/vae.py:98-114: norm1 / conv1, norm2 / conv2 + `x + h`) at the decoder's full-resolution level (ABI 11).
+ *   out[m][o] = bias[o] + residual[m][o] + sum_{ky,kx,c} wgt[o][ky][kx][c] * silu(x[pixel(m) + (ky-1, kx-1)][c] * scale[c] + shift[c])     (zero outside the image)
+ * with {scale, shift} = GroupNorm(groups, eps, gamma, beta) of x from its chunk statistics x_partial [n][x_nchunks][cin][2] ({sum, sum of squares} as the
+ * producing GEMM's epilogue / fmx_groupnorm_stats left them); the table is written to scale_shift [n][cin][2] (workspace, fp32).  x NHWC [n][h][w][cin],
+ * cin a multiple of 64; wgt in the GEMM entry's layout [128][ky][kx][cin]; bias [128] or null; residual [n*h*w][ld_res] or null; one rounding of the
+ * sum.  stats (optional): [n][stats_cap][128][2] receives the GroupNorm statistics of the OUTPUT as stored, one record per 8 x 32-pixel tile
+ * (*stats_nchunks = records per image, 0 without stats) -- the operand of the next fmx_groupnorm_apply / fmx_conv3x3_gn_silu.
+ * The normalised tensor the unfused pair (fmx_groupnorm_apply + fmx_gemm_conv) stores between its launches exists only as a tile's LDS patch here,
+ * holding the same values (same arithmetic, same rounding). */
+typedef struct fmx_conv_gn_args {
+  const void* x;
+  int32_t n, h, w, cin;
+  const float* x_partial;
+  int32_t x_nchunks, groups;
+  float eps;
+  const void* gamma;
+  const void* beta;
+  float* scale_shift;
+  const void* wgt;
+  int32_t cout;
+  const void* bias;
+  const void* residual;
+  int64_t ld_res;
+  void* out;
+  int64_t ld_out;
+  float* stats;
+  int32_t stats_cap;
+} fmx_conv_gn_args;
+int fmx_conv3x3_gn_silu_f16(const fmx_conv_gn_args* args /* host */, int32_t* stats_nchunks /* host, may be null */, void* stream);
 /* VAE output: y fp16 NHWC [b*h*w][ld] (first c channels) -> clamp((y+1)/2, 0, 1) fp32 NHWC [b][h][w][c] */
 int fmx_vae_unpack_image(const void* y, int32_t ld, int64_t npix, int32_t c, float* out, void* stream);
 
@@ -426,6 +456,7 @@ int fmx_vae_pack_latent_bf16(const float* z, float scaling_factor, float shift, 
 int fmx_vae_unpack_image_bf16(const void* y, int32_t ld, int64_t npix, int32_t c, float* out, void* stream);
 int fmx_conv3x3_narrow_bf16(const void* x, int32_t n, int32_t h, int32_t w, int32_t c, const void* wgt, const void* bias, int32_t nout, void* out,
                             int32_t ld_out, void* stream);
+int fmx_conv3x3_gn_silu_bf16(const fmx_conv_gn_args* args /* host */, int32_t* stats_nchunks /* host, may be null */, void* stream);
 int fmx_vae_sample_posterior_bf16(const void* moments, int32_t ld, const float* noise, int32_t b, int32_t lc, int64_t npix, float scale,
                                   float shift, float* out, void* stream);
 

@@ -575,6 +575,63 @@ def gen_flux_job(steps=20, batch=2, floor_only=False):
     update({"flux_job_b2.pt:latent@bf16": metrics(lat16, lat)})
 
 
+def _flux_job_guidance_fp32(net, pred, ctx, y, guid, dt):
+    """The reference's Flux sampler step with ONE line of `KModel.apply_model` left out: the cast of `guidance` to the compute type
+    (backend/modules/k_model.py:38-43 casts every floating-point extra conditioning).  In bfloat16 that cast is not harmless: `timestep_embedding`
+    (backend/nn/flux.py:52-53) multiplies by 1000 IN the tensor's type, and 3.5 * 1000 = 3500 needs 10 significant bits -- bfloat16 has 8, so the
+    distilled-guidance embedding becomes that of 3.504 (a 4-radian phase error at the top frequency).  That alone is a 3.9e-2 error of every model
+    output of the reference's bf16 run (tiny network, measured: 3.85e-2 with the cast, 6.3e-3 without), and it is why the reference's bf16 JOB sits
+    at 2.0e-2 / 3.7e-2 of its fp32 job while its bf16 single FORWARD (called with an fp32 guidance) sits at 6.3e-3 / 1.45e-2.  Everything else is
+    apply_model's: calculate_input, x / context / y in the compute type, fp32 timestep, .float() output, calculate_denoised."""
+    def model_fn(xx, sigma, **kw):
+        xc = pred.calculate_input(sigma, xx).to(dt)
+        out = net(xc, pred.timestep(sigma).float(), context=ctx.to(dt), y=y.to(dt), guidance=guid.float()).float()
+        return pred.calculate_denoised(sigma, out, xx)
+    return model_fn
+
+
+def floors_flux_guidance_fp32(full_job=False):
+    """Floors `...:latent@bf16_g32`: the reference's bfloat16 Flux JOBS with the distilled guidance kept in fp32 through its sinusoid (see
+    _flux_job_guidance_fp32) -- the arithmetic the native executor implements (it never rounds the guidance scalar), and the floor a bf16 Flux job can
+    meaningfully be held to.  The `@bf16` entries (the reference exactly as it runs, guidance 3.504) stay for the record."""
+    ref = ref_import.load_reference()
+    BF = torch.bfloat16
+    if not full_job:
+        cfg = synth.TINY_FLUX_CONFIG
+        g = _load("tiny_flux_fwd.pt")
+        net = ref_import.build_ref_flux(cfg, synth.synth_flux_state_dict(cfg, seed=2)).to(BF)
+        net.storage_dtype = net.computation_dtype = BF
+        h, w = g["hw"]
+        pred = ref.k_prediction.PredictionFlux(seq_len=(h // 2) * (w // 2))
+        xs = pred.noise_scaling(g["sigmas"][0], g["noise"].clone(), torch.zeros_like(g["noise"]))
+        with torch.no_grad():
+            lat = ref.kd_sampling.sample_euler(_flux_job_guidance_fp32(net, pred, g["ctx"], g["y"], g["guidance"], BF), xs, g["sigmas"], disable=True)
+        update({"tiny_flux_fwd.pt:latent@bf16_g32": metrics(lat.float(), g["latent"])})
+        return
+    from forge_amd.backend.nn.layout import flux_param_shapes
+    cfg = dict(synth.FLUX_DEV_CONFIG)
+    g = _load("flux_job_b2.pt")
+    with torch.device("meta"):
+        net = ref.nn_flux.IntegratedFluxTransformer2DModel(**cfg)
+    net = net.to_empty(device="cpu").to(BF)
+    lazy = synth.LazySynthStateDict(flux_param_shapes(cfg), seed=g["weights_seed"])
+    with torch.no_grad():
+        for name, prm in net.named_parameters():
+            prm.copy_(lazy[name])          # fp32 draw -> one rounding to bf16, as net.to(bfloat16) of the fp32 network does
+    net.storage_dtype = net.computation_dtype = BF
+    net.load_device = net.offload_device = net.initial_device = torch.device("cpu")
+    net.eval()
+    ctx, y, guid, x0 = flux_job_conditioning(cfg, g["batch"], seed=g["ctx_seed"])
+    assert torch.equal(x0, g["noise"])
+    pred = ref.k_prediction.PredictionFlux(seq_len=(128 // 2) ** 2)
+    xs = pred.noise_scaling(g["sigmas"][0], x0.clone(), torch.zeros_like(x0))
+    t0 = time.time()
+    with torch.no_grad():
+        lat = ref.kd_sampling.sample_euler(_flux_job_guidance_fp32(net, pred, ctx, y, guid, BF), xs, g["sigmas"], disable=True).float()
+    print("flux job: reference bf16 with fp32 guidance in %.0f s" % (time.time() - t0), flush=True)
+    update({"flux_job_b2.pt:latent@bf16_g32": metrics(lat, g["latent"])})
+
+
 def flux_job_conditioning(cfg, batch=2, seed=77, lat_hw=128, ltxt=256):
     """the conditioning / noise of tests/golden/flux_job_b2.pt, regenerated from the seed (same draws, same order, as gen_flux_job)"""
     g = torch.Generator("cpu").manual_seed(seed)
@@ -847,6 +904,10 @@ def main():
         gen_flux_job()
     if a.only == "flux_job_floor":
         gen_flux_job(floor_only=True)
+    if a.only == "flux_g32":            # seconds
+        floors_flux_guidance_fp32()
+    if a.only == "flux_job_g32":        # ~1 h: 40 forwards of the full network in bfloat16 on the CPU
+        floors_flux_guidance_fp32(full_job=True)
     if a.only == "headline_b8":
         gen_headline_b8()
     if a.only == "headline_b8_floor":

@@ -465,7 +465,11 @@ def gen_flux_lora():
         mk, off, fn = (target, None, None) if not isinstance(target, tuple) else (target[0], target[1], target[2] if len(target) > 2 else None)
         per_key.setdefault(mk[len("diffusion_model."):], []).append([0.8, pv, 1.0, off, fn])
     merged = {k: rl.merge_lora_to_weight(patches, sd[k].clone(), key=k, computation_dtype=torch.float32) for k, patches in per_key.items()}
-    torch.save({"strength": 0.8, "merged": merged, "remaining": sorted(remaining),
+    # the same merge on bfloat16 storage (Flux's own type; round 6): the reference casts to fp32, merges, casts once to the weight's type
+    sd_bf = {k: v.bfloat16() for k, v in synth.synth_flux_state_dict(cfg, seed=2).items()}
+    merged_bf16 = {k: rl.merge_lora_to_weight(patches, sd_bf[k].clone(), key=k, computation_dtype=torch.float32) for k, patches in per_key.items()}
+    assert all(v.dtype == torch.bfloat16 for v in merged_bf16.values())
+    torch.save({"strength": 0.8, "merged": merged, "merged_bf16": merged_bf16, "remaining": sorted(remaining),
                 "key_map_targets": {k: (v if isinstance(v, str) else (v[0], v[1], v[2].__name__ if len(v) > 2 else None)) for k, v in key_map.items()}},
                os.path.join(GOLD, "tiny_flux_lora_merge.pt"))
     print("tiny_flux lora merge:", sorted(merged), "remaining", sorted(remaining))

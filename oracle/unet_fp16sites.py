@@ -33,6 +33,10 @@ duration of the call).
 `plant` deliberately breaks ONE constant so that the sharp test can be shown to fail on it:
     {"gn_eps": (resblock_key, "in_layers.0" | "out_layers.0", eps)}     e.g. 1e-6 where the reference has 1e-5 (unet.py:395 vs :292)
     {"gelu_tanh": transformer_block_key}                                 tanh-approximated GELU in one GEGLU (unet.py:111 is exact erf)
+and two that live INSIDE the LayerNorm fold (round 6; they only exist where the executor folded, i.e. at the bench's sizes):
+    {"ln_eps": (transformer_block_key, "norm1" | "norm2" | "norm3", eps)}   e.g. 1e-6 where nn.LayerNorm has 1e-5 (unet.py:167-175)
+    {"colsum_unscaled": (transformer_block_key, "norm2" | "norm3")}          colsum taken over W instead of W' = W * gamma: the mean term no
+                                                                            longer cancels what the GEMM accumulated
 """
 import contextlib
 import math
@@ -125,7 +129,10 @@ def _gn(sd, key, x, eps):
     return (y * sd[key + ".weight"].double()[None, :, None, None] + sd[key + ".bias"].double()[None, :, None, None]).float()
 
 
-def _ln_stats(x, eps=1e-5):
+def _ln_stats(x, eps=1e-5, nkey=None):
+    pl = _ST.plant.get("ln_eps")
+    if pl is not None and nkey == f"{pl[0]}.{pl[1]}":
+        eps = pl[2]
     mean, var = _stats64(x, (-1,))
     return mean, 1.0 / torch.sqrt(var + eps)
 
@@ -134,7 +141,7 @@ def _ln(sd, key, x):
     st = _ST
     if not st.rounding:
         return ou_ln(sd, key, x)
-    mean, rstd = _ln_stats(x)
+    mean, rstd = _ln_stats(x, nkey=key)
     return st.R((((x.double() - mean) * rstd) * sd[key + ".weight"].double() + sd[key + ".bias"].double()).float())
 
 
@@ -170,11 +177,14 @@ def _folded_linear(sd, wkey, bkey, nkey, x, bias_fp16=True):
     w, gamma, beta = sd[wkey], sd[nkey + ".weight"], sd[nkey + ".bias"]
     wf = st.R(w * gamma[None, :])
     colsum = wf.double().sum(1)
+    pl = st.plant.get("colsum_unscaled")
+    if pl is not None and nkey == f"{pl[0]}.{pl[1]}":
+        colsum = w.double().sum(1)
     b2 = w.double() @ beta.double()
     if bkey is not None and bkey in sd:
         b2 = b2 + sd[bkey].double()
     b2 = st.R(b2.float()).double() if bias_fp16 else b2.float().double()
-    mean, rstd = _ln_stats(x)
+    mean, rstd = _ln_stats(x, nkey=nkey)
     acc = _lnr(x, wf).double()
     st.used_folds += 1
     return ((acc - mean * colsum) * rstd + b2).float()
@@ -334,3 +344,22 @@ def unet_forward(sd, cfg, x, timesteps, context, y=None, fold=None, plant=None, 
         want = sum(int(bool(f)) for v in fold.values() for f in v) + sum(2 for v in fold.values() if v[0])   # norm1 folds three projections
         assert state.used_folds == want, (state.used_folds, want)
     return eps
+
+
+@torch.no_grad()
+def transformer_block_only(sd, cfg, block_key, context, fold, teacher, plant=None, layer_out=None, native_view=None):
+    """ONE BasicTransformerBlock (unet.py:183-279) of the rounding network, teacher-forced: its input is the executor's stored stream in front of
+    it (`<SpatialTransformer>.proj_in` for block 0, the previous block's output otherwise), every sub-layer is evaluated on the executor's own
+    stored inputs as in unet_forward(teacher=...).  What a planted-bug check at full size needs, at a thousandth of the whole walk's cost.
+    -> layer_out (this block's layers only)."""
+    st_key, d = block_key.split(".transformer_blocks.")
+    d = int(d)
+    src = f"{st_key}.proj_in" if d == 0 else f"{st_key}.transformer_blocks.{d - 1}"
+    x = teacher[src].float()
+    state = _State(True, fold, plant, teacher, layer_out, False)
+    sd = {k: _r16(v) if v.is_floating_point() else v for k, v in sd.items() if k.startswith(block_key + ".")}
+    with _installed(state):
+        transformer_block(sd, block_key, x, context.float(), ou._heads_for(cfg, x.shape[-1]))
+    if native_view is not None:
+        native_view.update(state.native_view)
+    return state.layer_out

@@ -63,6 +63,17 @@ class GemmArgs(C.Structure):
     ]
 
 
+class ConvGnArgs(C.Structure):
+    """fmx_conv_gn_args (include/fmx.h): GroupNorm + SiLU + 3x3 convolution in one kernel"""
+    _fields_ = [
+        ("x", C.c_void_p), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("cin", C.c_int32),
+        ("x_partial", C.c_void_p), ("x_nchunks", C.c_int32), ("groups", C.c_int32), ("eps", C.c_float),
+        ("gamma", C.c_void_p), ("beta", C.c_void_p), ("scale_shift", C.c_void_p),
+        ("wgt", C.c_void_p), ("cout", C.c_int32), ("bias", C.c_void_p), ("residual", C.c_void_p), ("ld_res", C.c_int64),
+        ("out", C.c_void_p), ("ld_out", C.c_int64), ("stats", C.c_void_p), ("stats_cap", C.c_int32),
+    ]
+
+
 class AttnArgs(C.Structure):
     _fields_ = [
         ("q", C.c_void_p), ("k", C.c_void_p), ("vt", C.c_void_p), ("o", C.c_void_p),
@@ -118,6 +129,7 @@ SIGNATURES = {
     "fmx_im2col3x3_smallc": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "fmx_vae_unpack_image": [_vp, _i32, _i64, _i32, _vp, _vp],
     "fmx_conv3x3_narrow_f16": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp],
+    "fmx_conv3x3_gn_silu_f16": [C.POINTER(ConvGnArgs), C.POINTER(C.c_int32), _vp],
     "fmx_blend_masked": [_vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "fmx_count_nonfinite_f16": [_vp, _i64, _vp, _vp],
     "fmx_vae_sample_posterior": [_vp, _i32, _vp, _i32, _i32, _i64, _f32, _f32, _vp, _vp],
@@ -139,7 +151,7 @@ for _n in ("fmx_gemm_conv", "fmx_attention", "fmx_softmax_rows", "fmx_layernorm"
     SIGNATURES[_n + "_bf16"] = SIGNATURES[_n + "_f16"]
 SIGNATURES["fmx_timestep_embedding_bf16"] = SIGNATURES["fmx_timestep_embedding"]
 # bfloat16 build of the VAE (ABI 6)
-for _n in ("fmx_gemm_conv_stats", "fmx_groupnorm_stats", "fmx_groupnorm_apply", "fmx_attention_single_head512", "fmx_conv3x3_narrow"):
+for _n in ("fmx_gemm_conv_stats", "fmx_groupnorm_stats", "fmx_groupnorm_apply", "fmx_attention_single_head512", "fmx_conv3x3_narrow", "fmx_conv3x3_gn_silu"):
     SIGNATURES[_n + "_bf16"] = SIGNATURES[_n + "_f16"]
 for _n in ("fmx_vae_pack_latent", "fmx_vae_unpack_image", "fmx_vae_sample_posterior"):
     SIGNATURES[_n + "_bf16"] = SIGNATURES[_n]
@@ -223,7 +235,7 @@ def lib():
             handle.fmx_build_info.restype = C.c_char_p
         except AttributeError as e:
             raise FmxError(f"symbol fmx_build_info missing from {LIB_PATH}") from e
-        if handle.fmx_abi_version() != 10:
+        if handle.fmx_abi_version() != 11:
             raise FmxError("libfmx ABI version mismatch")
         _lib = handle
     return _lib

@@ -206,13 +206,23 @@ class IntegratedAutoencoderKL:
         out = ops.empty((b, hh, ww, cout), self.dtype)
         out_part = ops.stats_buffer(b, hh * ww, cout)
         m = arena.mark()
-        g1 = ops.groupnorm(x, *self.w[k + ".n1"], 1e-6, silu=True)          # statistics: left on x by the GEMM that produced it
-        h, h_st = ops.conv_gemm(g1, self.w[k + ".c1"][0], cout, kh=3, pad=1, bias=self.w[k + ".c1"][1], stats=True)
-        g2 = ops.groupnorm(h.view(b, hh, ww, cout), *self.w[k + ".n2"], 1e-6, silu=True, stats=h_st)
+        # the decoder's full-resolution level (128 output channels): norm -> swish -> conv as ONE launch each, the normalised tensor never stored
+        # (csrc/fmx_conv_patch.hip; same values, same rounding sites as the two launches below)
+        fused = ops.conv3x3_gn_silu_eligible(x, cout)
+        if fused:
+            h, h_st = ops.conv3x3_gn_silu(x, *self.w[k + ".n1"], 1e-6, *self.w[k + ".c1"])
+        else:
+            g1 = ops.groupnorm(x, *self.w[k + ".n1"], 1e-6, silu=True)          # statistics: left on x by the GEMM that produced it
+            h, h_st = ops.conv_gemm(g1, self.w[k + ".c1"][0], cout, kh=3, pad=1, bias=self.w[k + ".c1"][1], stats=True)
         self._tap(k + ".h", h.view(b, hh, ww, cout))
         sk = ops.conv_gemm(x, self.w[k + ".sc"][0], cout, bias=self.w[k + ".sc"][1]) if cin != cout else x.view(-1, cout)
-        _, st = ops.conv_gemm(g2, self.w[k + ".c2"][0], cout, kh=3, pad=1, bias=self.w[k + ".c2"][1], residual=sk, out=out.view(-1, cout), ld_out=cout,
-                              stats=True, stats_partial=out_part)
+        if fused and h_st is not None:
+            _, st = ops.conv3x3_gn_silu(h.view(b, hh, ww, cout), *self.w[k + ".n2"], 1e-6, *self.w[k + ".c2"], residual=sk, out=out.view(-1, cout),
+                                        stats=h_st, stats_partial=out_part)
+        else:
+            g2 = ops.groupnorm(h.view(b, hh, ww, cout), *self.w[k + ".n2"], 1e-6, silu=True, stats=h_st)
+            _, st = ops.conv_gemm(g2, self.w[k + ".c2"][0], cout, kh=3, pad=1, bias=self.w[k + ".c2"][1], residual=sk, out=out.view(-1, cout), ld_out=cout,
+                                  stats=True, stats_partial=out_part)
         arena.release(m)
         self._tap(k, out)
         return ops.attach_stats(out, st)

@@ -84,6 +84,10 @@ def load_lora(lora, to_load):
         dora_scale = lora.get(x + ".dora_scale")
         if dora_scale is not None:
             loaded.add(x + ".dora_scale")
+        # where a bias diff of this entry lands.  A slice target `(key, offset[, fn])` (the fused Flux projections) has none: the reference forms
+        # "{}.bias".format(to_load[x][:-len(".weight")]) on the TUPLE (lora.py:199-203) -- a key no parameter has -- so its bias diff patches
+        # nothing; here the entry is left in `remaining` (reported as unused) instead of raising on tuple + str
+        bias_target = target[:-len(".weight")] + ".bias" if isinstance(target, str) else None
 
         def take(*names):
             out = []
@@ -117,13 +121,13 @@ def load_lora(lora, to_load):
         if x + ".w_norm" in lora:  # :173-182
             w_norm, b_norm = take(".w_norm", ".b_norm")
             patch_dict[target] = ("diff", (w_norm,))
-            if b_norm is not None:
-                patch_dict[target[:-len(".weight")] + ".bias"] = ("diff", (b_norm,))
+            if b_norm is not None and bias_target is not None:
+                patch_dict[bias_target] = ("diff", (b_norm,))
         if x + ".diff" in lora:
             patch_dict[target] = ("diff", (lora[x + ".diff"],))
             loaded.add(x + ".diff")
-        if x + ".diff_b" in lora:
-            patch_dict[target[:-len(".weight")] + ".bias"] = ("diff", (lora[x + ".diff_b"],))
+        if x + ".diff_b" in lora and bias_target is not None:
+            patch_dict[bias_target] = ("diff", (lora[x + ".diff_b"],))
             loaded.add(x + ".diff_b")
         if x + ".set_weight" in lora:
             patch_dict[target] = ("set", (lora[x + ".set_weight"],))
@@ -144,16 +148,19 @@ def _pad_k(t):
 
 
 @torch.inference_mode()
-def merge_lora_to_weight(patches, weight, key="online_lora", computation_dtype=torch.float32, device="cuda"):
+def merge_lora_to_weight(patches, weight, key="online_lora", computation_dtype=torch.float32, device="cuda", out_dtype=torch.float16):
     """patches: [(strength_patch, (type, tensors) | (tensor,), strength_model, offset, function)] as ModelPatcher.add_patches
     stores them (backend/patcher/base.py); weight: the LDM-layout parameter.  Returns the merged weight, fp16 on `device`.
     Mirrors backend/patcher/lora.py:85-323 for the supported patch types (offset / function hooks are not used by LoRA files)."""
-    w = weight.to(device=device, dtype=torch.float16).contiguous()
+    # storage types other than fp16 (bfloat16 Flux, fp32): the reference casts the weight to fp32, merges, and casts ONCE to the weight's type
+    # (patcher/lora.py:85-92, :322) -- a detour through fp16 would flush what lies below 2^-14, overflow above 65504 and round twice
+    wide = out_dtype != torch.float16
+    w = weight.to(device=device, dtype=torch.float32 if wide else torch.float16).contiguous()
     shape = w.shape
     # Several patches on one key (stacked LoRAs): the reference casts the weight to fp32 once, applies every patch and rounds once at the
     # end (patcher/lora.py:85-92, :322).  So does this: with more than one patch the running weight stays fp32 between patches (`fin` is the
     # identity) and is rounded after the loop; a single patch keeps the fused fp16-residual GEMM (one rounding either way).
-    multi = len(patches) > 1
+    multi = len(patches) > 1 or wide
     fin = (lambda t: t) if multi else (lambda t: t.half())
     if multi:
         w = w.float()
@@ -167,7 +174,8 @@ def merge_lora_to_weight(patches, weight, key="online_lora", computation_dtype=t
                 w, own = w.clone(), True
             sl = w if offset is None else w.narrow(offset[0], offset[1], offset[2])
             if function is None:
-                sl.copy_(merge_lora_to_weight([(strength, v, strength_model, None, None)], sl.contiguous(), key=key, device=device).to(sl.dtype))
+                sl.copy_(merge_lora_to_weight([(strength, v, strength_model, None, None)], sl.contiguous(), key=key, device=device,
+                                              out_dtype=torch.float32 if wide else torch.float16).to(sl.dtype))
                 continue
             ptype_f, vf = ("diff", v) if len(v) == 1 else (v[0], v[1])
             if strength_model != 1.0:
@@ -280,7 +288,7 @@ def merge_lora_to_weight(patches, weight, key="online_lora", computation_dtype=t
                 w = fin(w.float() + (strength * scale) * diff)
         else:
             raise NotImplementedError(f"patch type {ptype}")
-    return w.half() if w.dtype != torch.float16 else w
+    return w if w.dtype == out_dtype else w.to(out_dtype)
 
 
 def _weight_decompose(dora_scale, weight, lora_diff, alpha, strength, device):
@@ -323,12 +331,12 @@ def merge_loras_into_state_dict(unet_sd, unet_config, loras, device="cuda", key_
             per_key.setdefault(k, []).append((float(strength), pv, 1.0, offset, function))
     merged = dict(unet_sd)
     for k, patches in per_key.items():
-        merged[k] = merge_lora_to_weight(patches, unet_sd[k], key=k, device=device).to(out_dtype)
+        merged[k] = merge_lora_to_weight(patches, unet_sd[k], key=k, device=device, out_dtype=out_dtype)
     return merged, {"patched": len(per_key), "unused_keys": unused}
 
 
 def merge_loras_into_flux_state_dict(flux_sd, flux_config, loras, device="cuda", dtype=torch.bfloat16):
     """the same offline merge for a Flux transformer (BFL parameter names): native ('lora_unet_double_blocks_0_img_attn_qkv', 'diffusion_model. ...') and
-    diffusers-named ('transformer.transformer_blocks.0.attn.to_q', ...) LoRA files.  The merge arithmetic runs in fp16 operands / fp32 accumulation like
-    the UNet's; the result is cast to the transformer's storage type."""
+    diffusers-named ('transformer.transformer_blocks.0.attn.to_q', ...) LoRA files.  fp16 storage merges like the UNet (fp16 operands, fp32 accumulation,
+    one rounding); bfloat16 storage keeps the running weight in fp32 and is cast once at the end, as the reference does."""
     return merge_loras_into_state_dict(flux_sd, flux_config, loras, device=device, key_map=model_lora_keys_flux(list(flux_sd.keys()), flux_config), out_dtype=dtype)

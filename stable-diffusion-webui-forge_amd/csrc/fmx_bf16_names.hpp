@@ -18,6 +18,8 @@
 #define fmx_attention_single_head512_f16 fmx_attention_single_head512_bf16
 #define fmx_conv3x3_narrow_f16 fmx_conv3x3_narrow_bf16
 #define fmx_launch_gn_stats fmx_launch_gn_stats_bf16
+#define fmx_launch_gn_finalize fmx_launch_gn_finalize_bf16
+#define fmx_conv3x3_gn_silu_f16 fmx_conv3x3_gn_silu_bf16
 // host-side C++ symbols shared between the GEMM files
 #define fmx_launch_gemm256p fmx_launch_gemm256p_bf16
 #define fmx_launch_gemm4w fmx_launch_gemm4w_bf16

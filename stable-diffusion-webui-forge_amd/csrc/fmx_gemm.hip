@@ -274,7 +274,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     int* const s_ticket = reinterpret_cast<int*>(smem);
     if (tid == 0) *s_ticket = __hip_atomic_fetch_add(p.tickets + wg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    if (*s_ticket != p.splits - 1) return;
+    const int ticket = *s_ticket;
+    __syncthreads();   // every wave holds the ticket in a register before anything (the statistics epilogue's `red[0]`) may write that LDS word again
+    if (ticket != p.splits - 1) return;
     if (tid == 0) __hip_atomic_store(p.tickets + wg, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero again for the next launch
     // sum in SLOT order, own slot from registers: the result does not depend on which workgroup arrived last.  All loads of a slot are
     // in flight together (one wait per slot, not per load).

@@ -353,6 +353,15 @@ int fmx_launch_gn_stats(const void* x, int32_t c, int64_t ld, int32_t n, int32_t
   return FMX_OK;
 }
 
+// scale / shift table [n][c][2] of a one-source GroupNorm from its chunk partials -- for kernels that apply the norm themselves (fmx_conv_patch.hip)
+int fmx_launch_gn_finalize(const float* partial, int32_t nchunks, int32_t c, int32_t n, int32_t groups, int32_t hw, float eps, const void* gamma,
+                           const void* beta, float* scale_shift, hipStream_t st) {
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, n), dim3(64), 0, st, partial, nchunks, c, (const float*)nullptr, 1, 0, groups, hw, eps,
+                     (const f16*)gamma, (const f16*)beta, scale_shift);
+  FMX_LAUNCH_CHECK("fmx_groupnorm_finalize");
+  return FMX_OK;
+}
+
 extern "C" int fmx_groupnorm_stats_f16(const void* x, int32_t c, int64_t ld, int32_t n, int32_t hw, float* partial, int32_t nchunks, void* stream) {
   FMX_REQUIRE(x && partial && c > 0 && (c % 8) == 0 && ld >= c && (ld % 8) == 0 && n > 0 && hw > 0, "groupnorm_stats: bad args");
   FMX_REQUIRE(nchunks >= 1 && nchunks <= 1024, "groupnorm_stats: nchunks out of range");

@@ -12,7 +12,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import AttnArgs, GemmArgs
+from ._lib import AttnArgs, ConvGnArgs, GemmArgs
 
 ACT_NONE, ACT_GEGLU, ACT_GELU_TANH = 0, 1, 2
 
@@ -787,6 +787,62 @@ def conv3x3_narrow(x, wgt, bias, nout, out=None, ld_out=4):
     else:
         run()
     return out
+
+
+# A/B knob: FMX_CONV_GN_FUSE=0 keeps GroupNorm apply + implicit-GEMM convolution as two launches where conv3x3_gn_silu is eligible (round 5's path)
+_CONV_GN_FUSE = _lib.knob("FMX_CONV_GN_FUSE", "1") != "0"
+
+
+def conv3x3_gn_silu_eligible(x, cout, stats=None):
+    """the fused GroupNorm + SiLU + 3x3 convolution kernel covers: 128 output channels, input channels a multiple of 64, statistics of x available from
+    its producer, a tensor large enough that the 8 x 32-pixel tiles fill the chip (the VAE decoder's last level); everything else takes
+    groupnorm() + conv_gemm()"""
+    if not _CONV_GN_FUSE or x.dim() != 4 or cout != 128 or x.shape[-1] % 64 or x.shape[-1] > 1024 or not x.is_contiguous():
+        return False
+    n, h, w, _ = x.shape
+    if (stats if stats is not None else _attached_stats(x)) is None or n * h * w < (1 << 19):
+        return False
+    tiles = -(-h // 8) * -(-w // 32)
+    return tiles <= _stats_geometry(n, h * w)[1] and x.numel() * 2 < 3.9e9
+
+
+def conv3x3_gn_silu(x, gamma, beta, eps, wgt, bias, *, residual=None, out=None, groups=32, stats=None, want_stats=True, stats_partial=None):
+    """silu(group_norm(x)) -> conv3x3(stride 1, pad 1) -> + bias (+ residual), ONE launch (fmx_conv3x3_gn_silu, csrc/fmx_conv_patch.hip;
+    backend/nn/vae.py:98-114).  x NHWC [n, h, w, cin] with its producer's GnStats (`stats`, or attached to x); wgt [128, 9 * cin];
+    -> (out [n*h*w, 128], GnStats of out | None).  Check conv3x3_gn_silu_eligible first."""
+    sfx, elem = _elem(x, gamma, beta, wgt, bias, residual)
+    n, h, w, cin = x.shape
+    cout = wgt.shape[0]
+    s0 = stats if stats is not None else _attached_stats(x)
+    assert s0 is not None and wgt.shape[1] == 9 * cin and wgt.is_contiguous()
+    if out is None:
+        out = empty((n * h * w, cout), elem, x.device)
+    ss = empty((n, cin, 2), torch.float32, x.device)
+    st = None
+    a = ConvGnArgs()
+    a.x, a.n, a.h, a.w, a.cin = _p(x), n, h, w, cin
+    a.x_partial, a.x_nchunks, a.groups, a.eps = _p(s0.partial), s0.nchunks, groups, float(eps)
+    a.gamma, a.beta, a.scale_shift = _p(gamma), _p(beta), _p(ss)
+    a.wgt, a.cout, a.bias = _p(wgt), cout, _p(bias)
+    a.residual, a.ld_res = _p(residual), (residual.stride(-2) if residual is not None else 0)
+    a.out, a.ld_out = _p(out), out.stride(-2)
+    nch = C.c_int32(0)
+    if want_stats and _FUSED_STATS:
+        cap = _stats_geometry(n, h * w)[1]
+        partial = stats_partial if stats_partial is not None else empty((n, cap, cout, 2), torch.float32, x.device)
+        a.stats, a.stats_cap = _p(partial), partial.numel() // (n * cout * 2)
+        st = GnStats(partial, 0)
+    name = "fmx_conv3x3_gn_silu" + sfx
+
+    def run():
+        _lib.check(getattr(_lib.lib(), name)(C.byref(a), C.byref(nch), stream_ptr()), name)
+        if st is not None:
+            st.nchunks = nch.value
+    if _profiler is not None:
+        _profiler.launch("gemm_conv", 2.0 * n * h * w * cout * 9 * cin, run, tag=f"M={n * h * w} N={cout} K={9 * cin} kh=3 s=1 gn+silu fused{' +gnstats' if st is not None else ''}")
+    else:
+        run()
+    return out, st
 
 
 def vae_unpack_image(y, ld, npix, c, out):

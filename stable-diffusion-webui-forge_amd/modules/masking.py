@@ -27,7 +27,11 @@ def fill_tensor(images, mask):
     `fill` on the PIL image before it becomes a float array)."""
     from PIL import Image
     b = images.shape[0]
-    m = mask.reshape(-1, mask.shape[-2], mask.shape[-1]).float().cpu()
+    # one channel per image: a latent mask may arrive as [B or 1, lc, h, w] (every channel the same), and flattening that to B * lc rows would
+    # hand image i channel i of image 0
+    m = (mask[:, 0] if mask.dim() == 4 else mask.reshape(-1, mask.shape[-2], mask.shape[-1])).float().cpu()
+    if m.shape[0] not in (1, b):
+        raise ValueError(f"fill_tensor: a mask of {m.shape[0]} rows for {b} images (1 or {b} expected)")
     out = []
     for i in range(b):
         arr = (images[i].detach().float().cpu().clamp(0, 1) * 255.0).round().to(torch.uint8).permute(1, 2, 0).numpy()

@@ -237,6 +237,11 @@ class StableDiffusionProcessingImg2Img(StableDiffusionProcessingTxt2Img):
         elif masked and self.inpainting_fill == 0:
             raise ValueError("inpainting_fill = 0 ('fill') works on the init IMAGE (masking.fill); this job handed over a ready init_latent")
         self.init_latent = self.init_latent.to(device=dev, dtype=torch.float32).contiguous()
+        if masked and self.inpainting_fill == 2 and self.init_latent.shape[0] == 1 and self.batch_size > 1:
+            # :1797-1799 -- the reference repeats a single init image to batch_size BEFORE the fill, so 'latent noise' draws one row per image from
+            # all_seeds[0:batch_size]; a 1-row latent would hand every image of the batch image 0's noise (and, in a sharded job, each rank the noise
+            # of ITS first image: a result that depends on the sharding)
+            self.init_latent = self.init_latent.expand(self.batch_size, -1, -1, -1).contiguous()
         if self.latent_mask is not None:
             latmask = self.latent_mask.to(device=dev, dtype=torch.float32)
             if latmask.dim() == 3:

@@ -90,6 +90,24 @@ def test_other_contract_violations(lib):
     assert lib.fmx_conv3x3_narrow_bf16(p, 1, 8, 8, 128, p, None, 3, p, 2, None) == BADARG                              # ld_out < nout
     assert lib.fmx_conv3x3_narrow_f16(p, 16, 1024, 1024, 128, p, None, 3, p, 4, None) == BADARG and "split the batch" in err()
     assert lib.fmx_conv3x3_narrow_f16(None, 1, 8, 8, 128, p, None, 3, p, 4, None) == BADARG
+    # GroupNorm + SiLU + 3x3 convolution in one kernel (ABI 11): 128 output channels, input channels in 64-channel chunks, a statistics buffer with one
+    # record per 8 x 32 tile
+    def cg(**kw):
+        a = _lib.ConvGnArgs()
+        a.x = a.x_partial = a.gamma = a.beta = a.scale_shift = a.wgt = a.out = FAKE
+        a.n, a.h, a.w, a.cin, a.x_nchunks, a.groups, a.eps, a.cout, a.ld_out = 1, 64, 64, 128, 4, 32, 1e-6, 128, 128
+        for k, v in kw.items():
+            setattr(a, k, v)
+        return C.byref(a)
+    for sfx in ("_f16", "_bf16"):
+        fn = getattr(lib, "fmx_conv3x3_gn_silu" + sfx)
+        assert fn(cg(cout=256), None, None) == BADARG and "128 output channels" in err()
+        assert fn(cg(cin=96), None, None) == BADARG and "multiple of 64" in err()
+        assert fn(cg(x_partial=None), None, None) == BADARG and "null pointer" in err()
+        assert fn(cg(groups=24), None, None) == BADARG and "groups" in err()
+        assert fn(cg(ld_out=64), None, None) == BADARG and "leading dimensions" in err()
+        assert fn(cg(out=FAKE + 2), None, None) == BADARG and "alignment" in err()
+        assert fn(cg(stats=FAKE, stats_cap=8), None, None) == BADARG and "16 tiles" in err()       # 64 x 64 pixels = 8 x 2 tiles
     # GroupNorm: a second source needs its own statistics; channel / group / stride geometry
     f = C.c_void_p(FAKE)
     assert lib.fmx_groupnorm_apply_f16(p, p, 64, 64, 64, 64, 1, 16, f, 1, None, 0, 32, 1e-5, p, p, 0, f, p, None) == BADARG and "second source" in err()

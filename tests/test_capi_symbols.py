@@ -49,7 +49,7 @@ def test_ctypes_binding_matches_header(built):
     bound = set(_lib.SIGNATURES) | {"fmx_last_error", "fmx_build_info"}
     assert declared == bound, (sorted(declared - bound), sorted(bound - declared))
     L = _lib.lib()
-    assert L.fmx_abi_version() == 10
+    assert L.fmx_abi_version() == 11
 
 
 def test_struct_layouts_match_header():
@@ -84,7 +84,7 @@ def test_build_info_carries_the_hash_of_the_sources_on_disk(built):
     spec = importlib.util.spec_from_file_location("fmx_src_hash", os.path.join(ROOT, "stable-diffusion-webui-forge_amd", "csrc", "src_hash.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    assert info["abi"] == "10" and info["arch"] == "gfx950"
+    assert info["abi"] == "11" and info["arch"] == "gfx950"
     assert re.fullmatch(r"[0-9a-f]{16}", info["src"]) and info["src"] == mod.kernel_source_hash()
 
 

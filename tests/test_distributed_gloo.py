@@ -74,6 +74,85 @@ def test_broadcast_shard_gather_world2(total, with_dict):
     assert all(a and b for a, b in res), res
 
 
+def _worker_flux_config5(rank, world, port, q):
+    """BASELINE config 5's job shape: Flux.1-dev, global batch 16 -- T5 context [16, 256, 4096] + pooled [16, 768] in bf16, guidance [16] fp32, no uncond
+    (distilled guidance, cfg scale 1), latents [16, 16, 128, 128] fp32 and decoded uint8 images [16, 1024, 1024, 3]"""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import forge_amd  # noqa: F401
+    from forge_amd import distributed as fd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        total = 16
+        g = torch.Generator().manual_seed(11)
+        full = {"crossattn": torch.randn(total, 256, 4096, generator=g).bfloat16(), "vector": torch.randn(total, 768, generator=g).bfloat16(),
+                "guidance": torch.full((total,), 3.5)}
+        c, uc = fd.broadcast_conditioning(full if rank == 0 else None, None, torch.device("cpu"))
+        assert uc is None
+        lo, hi = fd.shard_range(total, rank, world)
+        mine = fd.slice_conditioning(c, lo, hi)
+        del c
+        per = total // world
+        ok = all(mine[k].shape[0] == per and mine[k].dtype == full[k].dtype and torch.equal(mine[k], full[k][lo:hi]) for k in full)
+        # a rank keeps ITS images' conditioning only: the slices own their storage, the 16-image broadcast buffers are gone with `c`
+        ok = ok and mine["crossattn"].untyped_storage().nbytes() == per * 256 * 4096 * 2
+        lat = torch.stack([torch.full((16, 128, 128), float(lo + i)) + mine["crossattn"][i].float().mean() for i in range(per)])
+        img = torch.stack([torch.full((1024, 1024, 3), (lo + i) * 7 % 251, dtype=torch.uint8) for i in range(per)])
+
+        class Counting:          # what gather_batch allocates, in bytes (every tensor-creating call it makes goes through its module's `torch`)
+            def __init__(self):
+                self.bytes = 0
+
+            def __getattr__(self, name):
+                f = getattr(torch, name)
+                if name not in ("empty", "zeros", "empty_like", "zeros_like", "cat", "stack"):
+                    return f
+
+                def counted(*a, **k):
+                    r = f(*a, **k)
+                    self.bytes += r.numel() * r.element_size()
+                    return r
+                return counted
+        ct = Counting()
+        fd.torch = ct
+        try:
+            got_lat = fd.gather_batch(lat, total)
+            got_img = fd.gather_batch(img, total)
+        finally:
+            fd.torch = torch
+        if rank == 0:
+            want = torch.stack([torch.full((16, 128, 128), float(i)) + full["crossattn"][i].float().mean() for i in range(total)])
+            ok = ok and torch.equal(got_lat, want) and all(int(got_img[i, 0, 0, 0]) == i * 7 % 251 for i in range(total))
+            # the owner allocates the gathered batch and nothing else (no staging copy of its shard, no second copy for the reorder)
+            ok = ok and ct.bytes == got_lat.numel() * 4 + got_img.numel()
+        else:
+            ok = ok and got_lat is None and got_img is None and ct.bytes == 0        # a non-owner's memory stays at its own shard
+        q.put((rank, bool(ok), ct.bytes))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_flux_config5_job_shapes_shard_and_gather(world):
+    """BASELINE config 5 (Flux.1-dev, batch 16 over 8 GPUs = 2 images per rank beside a 23.8 GB bf16 replica) through the broadcast /
+    slice / gather helpers at world 2 and at the configuration's own world size 8 (gloo): every rank ends up with its own images' conditioning only,
+    the gather allocates the result on the owner and nothing anywhere else."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_flux_config5, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), sorted(res)
+
+
 def _worker_ragged(rank, world, port, q):
     """cond and uncond of different token counts and dtypes (a >75-token prompt with a short negative: [B,154,D] vs [B,77,D]; an SDXL dict
     cond with an fp32 vector next to fp16 cross-attention), and an absent uncond (cfg_scale 1)."""

@@ -304,6 +304,13 @@ def test_flux_dev_job_at_full_depth_vs_reference_fixture():
     from conftest import GOLDEN
     if not os.path.exists(os.path.join(GOLDEN, "flux_job_b2.pt")) or "flux_job_b2.pt:latent@bf16" not in parity.FLOORS:
         pytest.skip("full-depth job fixture (or its floor) not generated")
+    # Which floor (round 6).  `@bf16` is the reference's bfloat16 job exactly as it runs: 3.7e-2 -- fifteen times the native figure, because
+    # KModel.apply_model casts `guidance` to bfloat16 and timestep_embedding multiplies by 1000 in that type (3500 -> 3504: the guidance embedding of
+    # 3.504; oracle/make_floor.py _flux_job_guidance_fp32).  A gate that loose holds nothing, so the job is held to `@bf16_g32` -- the same reference job
+    # with that one cast left out, i.e. the arithmetic the native executor implements -- and, floor or no floor, to JOB_RMS_LIMIT = 2 x the 2.5e-3
+    # measured in round 5 (profiles/r36_flux_job_vs_reference.log).
+    JOB_RMS_LIMIT, JOB_PP_LIMIT = 5.0e-3, 2.5e-2
+    floor_key = "flux_job_b2.pt:latent@bf16_g32" if "flux_job_b2.pt:latent@bf16_g32" in parity.FLOORS else "flux_job_b2.pt:latent@bf16"
     from forge_amd.backend.nn.layout import flux_param_shapes
     from oracle.make_floor import flux_job_conditioning
     g = load_golden("flux_job_b2.pt")
@@ -330,8 +337,9 @@ def test_flux_dev_job_at_full_depth_vs_reference_fixture():
         res = processing.process_images(p)
     finally:
         rng_mod.ImageRNG = orig
-    check(f"Flux.1-dev at full depth, 1024x1024 batch {b}, {g['steps']}-step Euler (simple sigmas), bf16 build vs reference (fp32)", res.latents, g["latent"],
-          floor="flux_job_b2.pt:latent@bf16")
+    m = check(f"Flux.1-dev at full depth, 1024x1024 batch {b}, {g['steps']}-step Euler (simple sigmas), bf16 build vs reference (fp32)", res.latents, g["latent"],
+              floor=floor_key)
+    assert m["rms_rel"] <= JOB_RMS_LIMIT and m["pp_rel"] <= JOB_PP_LIMIT, (m, "the job gate: 2 x round 5's measurement, whatever the floor says")
     del eng
     torch.cuda.empty_cache()
 
@@ -361,7 +369,9 @@ def test_bf16_flux_forward_and_sampling_vs_reference_fixture():
         res = processing.process_images(p)
     finally:
         rng_mod.ImageRNG = orig
-    check("tiny flux 4-step Euler, bf16 build vs reference (fp32)", res.latents, g["latent"], floor="tiny_flux_fwd.pt:latent@bf16")
+    # floor: the reference's bf16 job with the guidance scalar kept in fp32 (1.98e-3); as the reference runs it -- guidance cast to bfloat16, 3500 -> 3504
+    # inside timestep_embedding -- it sits at 1.97e-2, ten times further out (see test_flux_dev_job_at_full_depth_vs_reference_fixture)
+    check("tiny flux 4-step Euler, bf16 build vs reference (fp32)", res.latents, g["latent"], floor="tiny_flux_fwd.pt:latent@bf16_g32")
 
 
 def test_forge_loader_builds_a_flux_engine_from_a_checkpoint():

@@ -1130,6 +1130,48 @@ def test_narrow_output_conv3x3_direct_kernel(n, hh, ww, c, co, dtype):
         close(got[:, :co], y[:, :co].float(), 1e-3, 1e-3, "direct kernel vs the implicit-GEMM path")
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("n,hh,ww,cin,with_res", [(2, 24, 40, 128, True), (1, 16, 64, 256, False), (1, 9, 33, 64, True), (3, 8, 32, 128, False), (1, 64, 96, 128, True),
+                                                  (1, 40, 31, 192, True)])
+def test_groupnorm_silu_conv3x3_in_one_kernel(n, hh, ww, cin, with_res, dtype):
+    """fmx_conv3x3_gn_silu (csrc/fmx_conv_patch.hip, round 6): norm -> swish -> conv of the VAE's ResnetBlock (/root/reference/backend/nn/vae.py:98-114) as ONE
+    launch -- the 8 x 32-pixel tile's input patch normalised while it is staged in LDS.  The staged values are the tensor groupnorm() stores (same
+    arithmetic), so against groupnorm() + conv_gemm() the result differs by fp32 summation order only; against F.conv2d of torch's own
+    silu(group_norm(x)) at the element type's tolerance; the output statistics against sums over the stored tensor.  Image sizes that are no multiple of
+    the tile, one to four channel chunks, with and without the residual, both element types."""
+    cout = 128
+    x = (rnd(n, hh, ww, cin, scale=1.5, seed=330) + 0.3).to(dtype)
+    g, b = (1 + 0.1 * rnd(cin, seed=331)).to(dtype), (0.1 * rnd(cin, seed=332)).to(dtype)
+    wt = rnd(cout, cin, 3, 3, scale=1 / math.sqrt(9 * cin), seed=333).to(dtype)
+    wk = wt.permute(0, 2, 3, 1).reshape(cout, -1).contiguous()
+    bias = rnd(cout, seed=334).to(dtype)
+    res = rnd(n * hh * ww, cout, seed=335).to(dtype) if with_res else None
+    st_x = ops.groupnorm_stats(x)
+    tiles = -(-hh // 8) * -(-ww // 32)
+    part = torch.full((n, tiles, cout, 2), float("nan"), dtype=torch.float32, device=DEV)
+    out = torch.full((n * hh * ww, cout), float("nan"), dtype=dtype, device=DEV)
+    got, st = ops.conv3x3_gn_silu(x, g, b, 1e-6, wk, bias, residual=res, out=out, stats=st_x, stats_partial=part)
+    assert st.nchunks == tiles and bool(torch.isfinite(got.float()).all())
+    # the unfused pair on the same statistics
+    gn = ops.groupnorm(x, g, b, 1e-6, silu=True, stats=st_x)
+    two = ops.conv_gemm(gn, wk, cout, kh=3, pad=1, bias=bias, residual=res)
+    d = (got.float() - two.float()).abs()
+    ulp = torch.maximum(two.float().abs(), torch.tensor(2.0 ** -14, device=DEV)).log2().floor().exp2() * (2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7)
+    assert bool((d <= ulp).all()), f"fused vs groupnorm + conv_gemm: max {float((d / ulp).max()):.2f} ulp"
+    assert float((d > 0).float().mean()) < 0.05, "summation order only: a rounding flips in a few per cent of the elements at most"
+    ref = F.conv2d(F.silu(F.group_norm(x.permute(0, 3, 1, 2).float(), 32, g.float(), b.float(), 1e-6)), wt.float(), bias.float(), padding=1)
+    ref = ref.permute(0, 2, 3, 1).reshape(-1, cout) + (res.float() if with_res else 0)
+    tol = 3e-3 if dtype == torch.float16 else 2e-2
+    close(got, ref, tol, tol, "fused groupnorm + silu + conv3x3 vs torch fp32")
+    o = got.view(n, hh * ww, cout).double()
+    want = torch.stack([o.sum(1), (o * o).sum(1)], -1)
+    torch.testing.assert_close(_partial_to_sums(st, n, cout), want, rtol=2e-5, atol=2e-3)
+    # and the statistics feed the next fused launch (norm2 -> conv2 of the same block)
+    nxt, _ = ops.conv3x3_gn_silu(got.view(n, hh, ww, cout), g[:cout], b[:cout], 1e-6, wk[:, :9 * cout].contiguous() if cin >= cout else
+                                 rnd(cout, 9 * cout, scale=0.03, seed=336).to(dtype), bias, stats=st, want_stats=False)
+    assert bool(torch.isfinite(nxt.float()).all())
+
+
 def test_narrow_output_conv3x3_contract():
     x = rnd(1, 8, 8, 80, seed=1)
     with pytest.raises(Exception, match="multiple of 32"):

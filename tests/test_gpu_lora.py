@@ -110,3 +110,30 @@ def test_flux_lora_merge_on_device_vs_reference():
     qkv, q0 = merged["double_blocks.0.txt_attn.qkv.weight"].cpu(), sd["double_blocks.0.txt_attn.qkv.weight"]
     assert torch.equal(qkv[:hs], q0[:hs]) and torch.equal(qkv[2 * hs:], q0[2 * hs:]) and not torch.equal(qkv[hs:2 * hs], q0[hs:2 * hs])
     assert merged["img_in.weight"] is sd["img_in.weight"]
+
+
+def test_flux_lora_merge_on_bfloat16_storage_vs_reference():
+    """The same LoRA on Flux's own storage type: the reference casts the bf16 weight to fp32, merges, casts ONCE to bf16 (patcher/lora.py:85-92,
+    :322) -- so does the native merge (no detour through fp16).  Fixture `merged_bf16` from the real reference."""
+    from oracle.make_golden import synth_flux_lora
+    g = load_golden("tiny_flux_lora_merge.pt")
+    cfg = synth.TINY_FLUX_CONFIG
+    sd = {k: v.bfloat16() for k, v in synth.synth_flux_state_dict(cfg, seed=2).items()}
+    merged, report = nlora.merge_loras_into_flux_state_dict(sd, cfg, [(synth_flux_lora(cfg), g["strength"])], device=DEV, dtype=torch.bfloat16)
+    assert report["patched"] == len(g["merged_bf16"])
+    for k, ref in g["merged_bf16"].items():
+        assert merged[k].dtype == torch.bfloat16
+        got, ref = merged[k].float().cpu().reshape(ref.shape), ref.float()
+        # the LoRA factors enter the device GEMM as fp16 (the reference multiplies them in fp32: the delta carries <= 2 x 2^-11 of itself), then ONE bf16
+        # rounding on both sides: one ulp of the result plus that share of the largest delta
+        delta = float((ref - sd[k].float().reshape(ref.shape)).abs().max())
+        assert bool(((got - ref).abs() <= 2.0 ** -7 * ref.abs() + 1.0e-3 * delta).all()), k
+        assert (got != ref).float().mean().item() < 0.05, (k, (got != ref).float().mean().item())
+    hs = cfg["hidden_size"]
+    q0 = sd["double_blocks.0.txt_attn.qkv.weight"]
+    assert torch.equal(merged["double_blocks.0.txt_attn.qkv.weight"].cpu()[:hs], q0[:hs])           # the un-patched slice: bit for bit
+    # what a detour through fp16 would lose: bf16 values below fp16's range survive a merge that does not touch them (a zero diff), above it they do not overflow
+    w = torch.full((64, 64), 2.0 ** -20, dtype=torch.bfloat16)
+    w[0, 0] = 1.0e5
+    out = nlora.merge_lora_to_weight([(1.0, ("diff", (torch.zeros(64, 64),)), 1.0, None, None)], w, device=DEV, out_dtype=torch.bfloat16)
+    assert out.dtype == torch.bfloat16 and torch.equal(out.cpu(), w)

@@ -176,8 +176,9 @@ def test_tiny_networks_layer_by_layer(name):
 
 
 def test_sd15_full_size_forward_layer_by_layer():
-    """BASELINE config 0 / 2's network at full size (860 M parameters, 64x64 latent), batch 2: the LayerNorm folds that the 256 x 320 tiles
-    carry are live here (reported as `folded_norms`)."""
+    """BASELINE config 0 / 2's network at full size (860 M parameters, 64x64 latent), batch 2.  At this batch the projections that write the
+    stream run on 4-wave tiles that emit no row statistics, so every LayerNorm runs as its own kernel (`folded_norms` = 0 in the record); the
+    folds are exercised by test_sdxl_bench_batch_with_the_layernorm_folds_live_layer_by_layer below."""
     from oracle.make_golden import _inputs
     cfg = synth.SD15_UNET_CONFIG
     sd = synth.synth_unet_state_dict(cfg, seed=0)
@@ -186,15 +187,148 @@ def test_sd15_full_size_forward_layer_by_layer():
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(GOLDEN, "sdxl_full_fwd.pt")), reason="full fixture not generated")
-def test_sdxl_full_size_forward_layer_by_layer():
+def test_sdxl_full_size_forward_layer_by_layer(sdxl_sd):
     """The bench workload's network (2.57 B parameters, 128x128 latent), the reference fixture's own input: every one of its 70 transformer blocks,
     17 ResBlocks ... against the rounding oracle, layer by layer, on the executor's own inputs."""
     from oracle.make_golden import _inputs
     g = load_golden("sdxl_full_fwd.pt")
     cfg = synth.SDXL_UNET_CONFIG
-    sd = synth.synth_unet_state_dict(cfg, seed=0)
     x, t, ctx, y = _inputs(cfg, 1, 128, seed=g["inputs_seed"])
-    _run_case("SDXL full size (128x128 latent)", cfg, sd, x, t, ctx, y, "sdxl_full_fwd.pt:eps", whole_network=False)
+    _run_case("SDXL full size (128x128 latent)", cfg, sdxl_sd, x, t, ctx, y, "sdxl_full_fwd.pt:eps", whole_network=False)
+
+
+# ---- the configuration the bench is timed on: UNet batch 16 on the 128 x 128 latent, every LayerNorm folded (VERDICT r5 item 1) ---------------------------
+BENCH_BATCH = 16
+BENCH_IMAGES = (5, 14)      # the images the oracle replays (teacher forcing makes images independent: every layer is evaluated on the executor's own
+                            # stored input of THAT image; LayerNorm / GroupNorm statistics are per row / per image)
+FOLD_PLANT_BLOCK = "input_blocks.4.1.transformer_blocks.0"     # 640 channels, 64 x 64 tokens: M = 65 536 rows at batch 16
+
+
+def fold_plants(block=FOLD_PLANT_BLOCK):
+    return {
+        "LayerNorm eps 1e-6 instead of 1e-5 inside one folded norm2 (unet.py:167-175; nn.LayerNorm's default)": {"ln_eps": (block, "norm2", 1e-6)},
+        "colsum(W) instead of colsum(W * gamma) in one folded ff.net.0 (the mean term of the fold)": {"colsum_unscaled": (block, "norm3")},
+    }
+
+
+def fold_planted_layer(plant):
+    """the first tensor stored behind the wrong constant"""
+    return plant["ln_eps"][0] + ".attn2.q" if "ln_eps" in plant else plant["colsum_unscaled"][0] + ".ff.g"
+
+
+def bench_batch_inputs(cfg, b=BENCH_BATCH, hw=128, seed=29):
+    """sixteen DIFFERENT images, conditionings and timesteps (a repeated input would let a batch-position bug through)"""
+    g = torch.Generator("cpu").manual_seed(seed)
+    x = torch.randn(b, cfg["in_channels"], hw, hw, generator=g)
+    ctx = torch.randn(b, 77, cfg["context_dim"], generator=g)
+    y = torch.randn(b, cfg["adm_in_channels"], generator=g)
+    t = torch.linspace(991.0, 7.0, b).round()
+    return x, t, ctx, y
+
+
+def small_stream_state_dict(sd, block=FOLD_PLANT_BLOCK, scale=0.04):
+    """the stream in front of `block`'s norm2 scaled down (proj_in and attn1.to_out x scale: variance ~2e-3), the only regime in which a LayerNorm
+    eps of 1e-6 vs 1e-5 is more than an fp32 rounding error (rstd moves by 0.5 * 9e-6 / var).  A shallow copy: four tensors replaced."""
+    st_key = block.split(".transformer_blocks.")[0]
+    out = dict(sd)
+    for k in (st_key + ".proj_in", block + ".attn1.to_out.0"):
+        out[k + ".weight"] = sd[k + ".weight"] * scale
+        out[k + ".bias"] = sd[k + ".bias"] * scale
+    return out
+
+
+@pytest.fixture(scope="module")
+def sdxl_sd():
+    return synth.synth_unet_state_dict(synth.SDXL_UNET_CONFIG, seed=0)
+
+
+def native_forward_with_taps_of(net, x, t, ctx, y, images, prefix=""):
+    """the forward at the full batch; of every stored tensor only `images` (and only layers under `prefix`) leave the device"""
+    from forge_amd import hipops
+    taps = {}
+    sel = torch.tensor(images, device=DEV)
+
+    def tap(name, tens):
+        if name.startswith(prefix) or name == "time_embed":
+            taps[name] = tens.index_select(0, sel).to("cpu")
+    net.tap = tap
+    before = hipops.LN_FOLDED_LAUNCHES
+    try:
+        eps = net.forward(x.to(DEV), t.to(DEV), context=ctx.to(DEV), y=y.to(DEV))
+    finally:
+        net.tap = None
+    return eps.float().cpu(), taps, dict(net.fold_trace), hipops.LN_FOLDED_LAUNCHES - before
+
+
+def test_sdxl_bench_batch_with_the_layernorm_folds_live_layer_by_layer(sdxl_sd):
+    """What bench.py times: the SDXL network at UNet batch 16 on the 128 x 128 latent -- 256 x 320 tiles everywhere, so norm1 / norm2 / norm3 of all
+    70 transformer blocks run FOLDED into the projections around them (`gemm256p_kernel<..., LN = 1 | 2 | 3>`: 48.6 % of the bench's GPU time), and the
+    GroupNorm statistics come from the GEMM epilogues.  The fold computes rstd (x W'^T - mean colsum(W')) + bias' -- a cancellation -- from row sums
+    the producing GEMM left; the oracle evaluates the same formula at the same rounding sites (oracle/unet_fp16sites.py _folded_linear) on the
+    executor's stored stream, layer by layer, for two of the sixteen images."""
+    from forge_amd.backend.nn import unet as _unet
+    from forge_amd.backend.nn.unet import IntegratedUNet2DConditionModel
+    cfg = synth.SDXL_UNET_CONFIG
+    x, t, ctx, y = bench_batch_inputs(cfg)
+    net = IntegratedUNet2DConditionModel(cfg, sdxl_sd, device=DEV)
+    eps, taps, fold, launches = native_forward_with_taps_of(net, x, t, ctx, y, BENCH_IMAGES)
+    del net
+    torch.cuda.empty_cache()
+    nf = sum(int(f) for v in fold.values() for f in v)
+    if _unet._LN_FOLD and _unet._LN_FOLD1:
+        assert nf == 3 * 70 and launches == 4 * 70, (nf, launches)     # q|k, V^T, attn2.to_q, ff.net.0 per block
+    sel = list(BENCH_IMAGES)
+    t0 = time.time()
+    res = layerwise(sdxl_sd, cfg, x[sel], t[sel], ctx[sel], y[sel], taps, fold)
+    kr, rms, kp, pp = _worst(res)
+    fl = parity.FLOORS["sdxl_full_fwd.pt:eps"]
+    rec = {"name": f"sharp layer-wise: SDXL full size at the bench's UNet batch {BENCH_BATCH}, images {sel} (LayerNorm folds live)", "layers": len(res),
+           "folded_norms": nf, "folded_gemm_launches": launches, "worst_rms_rel": round(rms, 8), "worst_rms_layer": kr, "worst_pp_rel": round(pp, 8),
+           "worst_pp_layer": kp, "median_rms_rel": round(sorted(v["rms_rel"] for v in res.values())[len(res) // 2], 8), "floor_rms_rel": fl["rms_rel"],
+           "worst_rms_over_floor": round(rms / fl["rms_rel"], 4), "gate": {"rms_rel": SHARP_RMS, "rms_rel_attention_outputs": SHARP_RMS_ATTN, "pp_rel": SHARP_PP},
+           "oracle_seconds": round(time.time() - t0, 1), "by_kind": by_kind(res)}
+    print("[sharp]", json.dumps(rec))
+    _log(rec)
+    assert nf > 0, "the folds are what this case exists for"
+    bad = over_gate(res)
+    assert not bad, {k: res[k] for k in bad[:5]}
+
+
+def test_planted_bugs_inside_the_layernorm_fold_fail_at_their_layer(sdxl_sd):
+    """Two wrong constants INSIDE the fold, planted in the oracle's copy of ONE block at the bench's sizes: a LayerNorm eps of 1e-6 in the folded norm2
+    (visible because that block's stream is scaled down to a variance where eps matters) and the mean term's column sums taken over W instead of
+    W * gamma in the folded ff.net.0.  The native executor must agree with the unplanted oracle on every layer of the block and disagree with each
+    planted one at exactly the first tensor stored behind the wrong constant."""
+    from oracle import unet_fp16sites as o16
+    from forge_amd.backend.nn.unet import IntegratedUNet2DConditionModel
+    cfg = synth.SDXL_UNET_CONFIG
+    sd = small_stream_state_dict(sdxl_sd)
+    x, t, ctx, y = bench_batch_inputs(cfg)
+    net = IntegratedUNet2DConditionModel(cfg, sd, device=DEV)
+    st_key = FOLD_PLANT_BLOCK.split(".transformer_blocks.")[0]
+    _, taps, fold, _ = native_forward_with_taps_of(net, x, t, ctx, y, BENCH_IMAGES, prefix=st_key)
+    del net
+    torch.cuda.empty_cache()
+    assert fold[FOLD_PLANT_BLOCK] == (True, True, True), fold[FOLD_PLANT_BLOCK]
+    sel = list(BENCH_IMAGES)
+
+    def block_metrics(plant):
+        outs, nat = {}, {}
+        o16.transformer_block_only(sd, cfg, FOLD_PLANT_BLOCK, ctx[sel], fold, taps, plant=plant, layer_out=outs, native_view=nat)
+        return {k: parity.metrics(nat[k], ref) for k, ref in outs.items() if k in nat}
+    good = block_metrics(None)
+    assert len(good) == 12 and not over_gate(good), good
+    var = float(taps[FOLD_PLANT_BLOCK + ".attn1"].float().var(dim=-1).mean())
+    for pname, plant in fold_plants().items():
+        bad = block_metrics(plant)
+        layer = fold_planted_layer(plant)
+        failing = over_gate(bad)
+        rec = {"name": f"planted bug in the fold: {pname}", "layer": layer, "sharp_gate_fails_at": failing, "planted_layer_rms_rel": round(bad[layer]["rms_rel"], 7),
+               "planted_layer_pp_rel": round(bad[layer]["pp_rel"], 7), "unplanted_layer_rms_rel": round(good[layer]["rms_rel"], 8),
+               "stream_variance_in_front_of_norm2": round(var, 6), "unet_batch": BENCH_BATCH, "images": sel}
+        print("[sharp]", json.dumps(rec))
+        _log(rec)
+        assert failing == [layer], rec
 
 
 @pytest.mark.parametrize("pname", list(PLANTS))

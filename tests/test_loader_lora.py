@@ -385,3 +385,27 @@ def test_flux_to_diffusers_vs_reference():
                 assert a[0] == b[0] and a[1] is None and torch.equal(a[2](t), b[2](t))
             else:
                 assert a == b, k
+
+
+def test_bias_diff_on_a_slice_target_is_reported_not_raised():
+    """a diffusers-named Flux LoRA carrying `.diff_b` on to_q / proj_mlp (slice targets `(key, offset)`): the reference's
+    `to_load[x][:-len(".weight")]` on the tuple yields a key no parameter has (lora.py:199-203), i.e. the bias diff patches nothing; the native parser must
+    not raise (tuple + str) and reports the entry as unused."""
+    import torch
+    from forge_amd import synth
+    from forge_amd.backend.patcher import lora as nlora
+    from forge_amd.backend.nn.layout import flux_param_shapes
+    cfg = synth.TINY_FLUX_CONFIG
+    km = nlora.model_lora_keys_flux(list(flux_param_shapes(cfg)), cfg)
+    hs = cfg["hidden_size"]
+    x = "transformer.transformer_blocks.0.attn.to_q"
+    assert isinstance(km[x], tuple)
+    lo = {x + ".lora_up.weight": torch.randn(hs, 4), x + ".lora_down.weight": torch.randn(4, hs), x + ".diff_b": torch.randn(hs),
+          "transformer.norm_out.linear.w_norm": torch.randn(2 * hs, hs), "transformer.norm_out.linear.b_norm": torch.randn(2 * hs)}
+    patch, remaining = nlora.load_lora(lo, km)
+    assert km[x] in patch and all(isinstance(k, (str, tuple)) for k in patch)
+    assert x + ".diff_b" in remaining
+    # a plain (string) target keeps its bias diff
+    y = "lora_unet_img_in"
+    patch2, rem2 = nlora.load_lora({y + ".diff": torch.randn(*flux_param_shapes(cfg)["img_in.weight"]), y + ".diff_b": torch.randn(hs)}, km)
+    assert "diffusion_model.img_in.bias" in patch2 and not rem2

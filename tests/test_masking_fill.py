@@ -61,6 +61,19 @@ def test_fill_tensor_matches_the_reference_fixture():
     assert out2.shape == img.shape
 
 
+def test_fill_tensor_takes_one_mask_channel_per_image():
+    """a latent mask may be [B or 1, lc, h, w] (processing.py's `latent_mask`): per IMAGE masks with several channels must not be read as B * lc rows"""
+    img, mask = _case()
+    per_image = torch.cat([mask, torch.zeros_like(mask)], 0)                       # image 0 masked, image 1 not
+    want = masking.fill_tensor(img, per_image)
+    assert torch.equal(want[1], img[1]) and not torch.equal(want[0], img[0])
+    assert torch.equal(masking.fill_tensor(img, per_image.expand(2, 4, -1, -1)), want)
+    assert torch.equal(masking.fill_tensor(img, mask.expand(1, 4, -1, -1)), masking.fill_tensor(img, mask))
+    assert torch.equal(masking.fill_tensor(img, per_image[:, 0]), want)            # [B, H, W]
+    with pytest.raises(ValueError):
+        masking.fill_tensor(img, torch.zeros(3, 1, 48, 64))
+
+
 if __name__ == "__main__":
     img, mask = _case()
     ref_fill = _ref_fill()

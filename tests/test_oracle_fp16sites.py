@@ -127,3 +127,32 @@ def test_planted_bugs_are_visible_layer_wise_and_mostly_invisible_to_the_floor_g
         layer = planted_layer(plant)
         print(pname, layer, m[layer], failing)
         assert failing == [layer], (pname, failing, m[layer])
+
+
+def test_planted_bugs_inside_the_layernorm_fold_are_visible_at_their_layer():
+    """The two fold plants of tests/test_gpu_sharp_parity.py (LayerNorm eps 1e-6 inside a folded norm2 of a small-variance stream; colsum(W) for
+    colsum(W * gamma) in a folded ff.net.0), with the rounding oracle itself as the "native" side and every norm folded, through the single-block
+    evaluator the GPU test uses at full size: the planted layer -- and only it -- exceeds the sharp gate; unplanted, the block agrees with the
+    whole-network walk's own layers."""
+    from test_gpu_sharp_parity import fold_planted_layer, fold_plants, over_gate, small_stream_state_dict
+    cfg, g, sd0 = _case("tiny_sdxl")
+    block = _blocks(sd0)[0]
+    sd = small_stream_state_dict(sd0, block)
+    fold = {b: (True, True, True) for b in _blocks(sd)}
+    outs = {}
+    o16.unet_forward(sd, cfg, g["x"], g["t"], g["ctx"], g["y"], fold=fold, layer_out=outs)
+    taps = _as_taps(outs)
+    same = {}
+    o16.transformer_block_only(sd, cfg, block, g["ctx"], fold, taps, layer_out=same)
+    assert len(same) == 12
+    for k, v in same.items():
+        m = parity.metrics(v, outs[k])
+        assert m["rms_rel"] < 2e-4 and m["pp_rel"] < 1.5e-3, (k, m)
+    for pname, plant in fold_plants(block).items():
+        bad = {}
+        o16.transformer_block_only(sd, cfg, block, g["ctx"], fold, taps, plant=plant, layer_out=bad)
+        m = {k: parity.metrics(outs[k], bad[k]) for k in bad}
+        failing = over_gate(m)
+        layer = fold_planted_layer(plant)
+        print(pname, layer, m[layer], failing)
+        assert failing == [layer], (pname, failing, m[layer])

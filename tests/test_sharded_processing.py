@@ -218,7 +218,7 @@ def _make_schedule_job(batch, n_iter, give_conds=True):
     return p
 
 
-def _make_img2img_job(batch, n_iter, give=True):
+def _make_img2img_job(batch, n_iter, give=True, shared_fill2=False):
     import forge_amd  # noqa: F401
     from forge_amd.modules import processing
     base = _make_job(batch, n_iter, False)
@@ -237,9 +237,14 @@ def _make_img2img_job(batch, n_iter, give=True):
             return out
     nmask = torch.zeros(1, 1, 3, 4)
     nmask[..., 1:, :2] = 1.0
+    rows = 1 if shared_fill2 else total     # shared_fill2: ONE init latent for the whole job + 'latent noise' fill -- every image draws its own fill noise
     return _Job(sd_model=base.sd_model, c=base.c if give else None, uc=base.uc if give else None, seed=4242, batch_size=batch, n_iter=n_iter, steps=4, cfg_scale=7.0,
-                width=32, height=24, init_latent=torch.randn(total, 4, 3, 4, generator=g) if give else None, latent_mask=nmask if give else None,
-                denoising_strength=0.6, inpainting_fill=3)
+                width=32, height=24, init_latent=torch.randn(rows, 4, 3, 4, generator=g) if give else None, latent_mask=nmask if give else None,
+                denoising_strength=0.6, inpainting_fill=2 if shared_fill2 else 3)
+
+
+def _make_img2img_fill2_job(batch, n_iter, give=True):
+    return _make_img2img_job(batch, n_iter, give, shared_fill2=True)
 
 
 def _worker2(rank, world, port, kind, batch, n_iter, q):
@@ -252,21 +257,26 @@ def _worker2(rank, world, port, kind, batch, n_iter, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from forge_amd.modules import processing
-        make = _make_schedule_job if kind == "schedules" else _make_img2img_job
+        make = {"schedules": _make_schedule_job, "img2img": _make_img2img_job, "img2img_fill2": _make_img2img_fill2_job}[kind]
         res = processing.process_images_sharded(make(batch, n_iter, rank == 0))          # only the owner holds conditionings / init latents / masks
         q.put((rank, res.latents.cpu().numpy().copy() if rank == 0 else int(res.latents.shape[0]), list(res.seeds)))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind,world,batch,n_iter", [("schedules", 2, 5, 1), ("schedules", 3, 4, 2), ("img2img", 2, 5, 1), ("img2img", 3, 4, 2)])
+@pytest.mark.parametrize("kind,world,batch,n_iter", [("schedules", 2, 5, 1), ("schedules", 3, 4, 2), ("img2img", 2, 5, 1), ("img2img", 3, 4, 2), ("img2img_fill2", 2, 5, 1),
+                                                      ("img2img_fill2", 3, 4, 2)])
 def test_sharded_prompt_editing_and_img2img_jobs_equal_the_single_process_job(kind, world, batch, n_iter):
     """`p.c` as the reference has it (MulticondLearnedConditioning with AND parts and a prompt-editing schedule, schedule lists for the
     negative prompt; tensors shared between images travel once) and an img2img job (per-image init latents, a shared latent mask, 'latent nothing' fill)
-    split over 2 and 3 ranks: latents bit for bit those of the single-process job."""
+    split over 2 and 3 ranks: latents bit for bit those of the single-process job.  `img2img_fill2`: ONE shared init latent with the 'latent
+    noise' fill -- the reference repeats the image to batch_size first (processing.py:1797-1799), so image i's fill comes from all_seeds[i], on whichever rank."""
     from forge_amd.modules import processing
-    make = _make_schedule_job if kind == "schedules" else _make_img2img_job
+    make = {"schedules": _make_schedule_job, "img2img": _make_img2img_job, "img2img_fill2": _make_img2img_fill2_job}[kind]
     want = processing.process_images(make(batch, n_iter))
+    if kind == "img2img_fill2":
+        first = want.latents[:batch].reshape(batch, -1)
+        assert len({tuple(r.tolist()) for r in first[:, :]}) == batch
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
