@@ -43,6 +43,12 @@ struct AttnParams {
 };
 
 constexpr int KVB = 64;  // keys per tile
+#ifndef FMX_ATTN_WS_ROT_DEFAULT
+#define FMX_ATTN_WS_ROT_DEFAULT 1   // the wave-specialised kernel's rotated sub-tile pipeline.  Measured (profiles/r44_*, r45_*): Flux shape 568 -> 562 us eager,
+                                    // PMC 811 k -> 784 k cycles (-3.4 %) at 1.87 -> 1.83 GHz: matrix pipes 54.7 -> 56.9 % busy, busy x GHz 1.02 -> 1.04 -- the kernel sits
+                                    // on the chip's power line, a denser schedule is answered with a lower clock; +1-3 % on every d = 128 shape, so it stays on
+                                    // (FMX_ATTN_WS_ROT=0 restores round 2's order)
+#endif
 
 template <int V>
 struct IC { static constexpr int value = V; };
@@ -1121,7 +1127,14 @@ __global__ __launch_bounds__(256, 2) void attn_q64v3_kernel(const AttnParams p) 
 // take the slots between), ~1350 for sub-tile 1's MFMAs under sub-tile 0's exponentials, ~730 for sub-tile 1's exponentials (v_exp_f32 is
 // quarter rate: 16 cycles per wave instruction) and ~500 around the barrier; the O wave needs ~2300 of the ~3730.  Wave priorities, a third
 // accumulator chain in the first phase and delaying the O wave were measured and change nothing / lose.
-template <int THR, int DP>
+//
+// ROT = 1 (round 6): the S wave's sub-tile pipeline ROTATED ACROSS the tile boundary.  In the form above sub-tile 0's score MFMAs have nothing to
+// run under (their softmax cannot start before they finish: ~1150 cycles per tile of matrix-only issue) and sub-tile 1's exponentials nothing to
+// cover them (~730 cycles of vector-only issue).  Rotated, every phase is "maximum check of sub-tile n -> issue the scores of sub-tile n + 1 ->
+// exponentials of sub-tile n under them": the scores of (t + 1, 0) run under the exponentials of (t, 1).  That needs K_{t+1} visible during
+// interval t, i.e. requested in interval t - 1: K moves to a THREE-slot ring, and V^T, which was requested two intervals before its use, to a
+// two-slot ring requested one interval before (same 80 KB).  Past the last tile the "next" scores read a stale slot and are never used.
+template <int THR, int DP, int ROT = 0>
 __global__ __launch_bounds__(512, 2) void attn_ws_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int DSTEPS = DP / 16, DVT = DP / 32, CPR = DP / 8;
@@ -1129,7 +1142,8 @@ __global__ __launch_bounds__(512, 2) void attn_ws_kernel(const AttnParams p) {
   constexpr int KROWS = 1024 / (DP * 2);            // K rows per 1-KiB piece
   constexpr int NPK = KVB / KROWS / 4, NPV = DP / 8 / 4;   // pieces per staging wave and tile
   constexpr int PSLOT = 8 * 1024 + 1280;            // 8 operand fragments x 64 lanes x 16 B, then alpha[2][2][64] floats, flag[2], (pad)
-  constexpr int OFF_V = 2 * KBYTES, OFF_P = OFF_V + 3 * VBYTES, OFF_L = OFF_P + 2 * 4 * PSLOT;
+  constexpr int KSLOTS = ROT ? 3 : 2, VSLOTS = ROT ? 2 : 3;
+  constexpr int OFF_V = KSLOTS * KBYTES, OFF_P = OFF_V + VSLOTS * VBYTES, OFF_L = OFF_P + 2 * 4 * PSLOT;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1164,6 +1178,7 @@ __global__ __launch_bounds__(512, 2) void attn_ws_kernel(const AttnParams p) {
       }
     };
     stage_k(0, 0);
+    if (ROT && ntiles > 1) stage_k(1, 1);
     const float c2 = p.scale_log2e;
     f16x8 qf[2][DSTEPS];
 #pragma unroll
@@ -1191,6 +1206,126 @@ __global__ __launch_bounds__(512, 2) void attn_ws_kernel(const AttnParams p) {
     // of sub-tile 0's softmax, so they are issued interleaved with its exp2 / sum / pack instructions (one MFMA, a handful of VALU, ...):
     // this wave's matrix work runs under its own vector work, and what stays exposed (sub-tile 1's softmax) is covered by the O wave.
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    if constexpr (ROT != 0) {
+      // ---- rotated pipeline: phase (t, s2) = maximum check of sub-tile (t, s2) | scores of the NEXT sub-tile issued | exponentials of (t, s2) under them ----
+      f32x16 sacc[2][2];
+      f16x8 kf[2][DSTEPS];
+      auto read_k = [&](int which, const char* sk, int half) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ds = 0; ds < DSTEPS; ++ds) {
+          const int row = half * 32 + krow;
+          kf[which][ds] = *reinterpret_cast<const f16x8*>(sk + row * (DP * 2) + (k_phys_chunk<CPR>(row, ds * 2 + hi) << 4));
+        }
+      };
+      auto scores = [&](int which) __attribute__((always_inline)) {     // sacc[which] = K (sub-tile in kf[which]) Q^T - running maximum
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          f32x16 z;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) z[r] = 0.f;
+          sacc[which][a] = FMX_MFMA_32x32x16(ones, mfrag[a], z);
+        }
+#pragma unroll
+        for (int ds = 0; ds < DSTEPS; ++ds)
+#pragma unroll
+          for (int a = 0; a < 2; ++a) sacc[which][a] = FMX_MFMA_32x32x16(kf[which][ds], qf[a][ds], sacc[which][a]);
+      };
+      // prologue: both halves of K_0, the scores of (0, 0) with nothing to run under
+      __builtin_amdgcn_sched_barrier(0);
+      read_k(0, smem, 0);
+      read_k(1, smem, 1);
+      scores(0);
+      __builtin_amdgcn_sched_barrier(0);
+      int kslot_next = ntiles > 1 ? 1 : 0;                            // slot of K_{t+1} while in interval t
+      for (int t = 0; t <= ntiles; ++t) {
+        if (t < ntiles) {
+          if (t + 2 < ntiles) stage_k(kslot_next == 2 ? 0 : kslot_next + 1, t + 2);
+          const char* skn = smem + kslot_next * KBYTES;
+          char* const ps = pbase + (t & 1) * (4 * PSLOT);
+          float* const ctrl = reinterpret_cast<float*>(ps + 8 * 1024);
+          const bool ragged = (t + 1) * KVB > p.nk;
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (ragged) {
+#pragma unroll
+              for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                  if (t * KVB + s2 * 32 + hi * 16 + r >= p.nk) sacc[s2][a][r] = -INFINITY;
+            }
+            float mx[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+              float m0 = fmaxf(sacc[s2][a][0], sacc[s2][a][1]);
+#pragma unroll
+              for (int r = 2; r < 16; r += 2) m0 = fmaxf(fmaxf(m0, sacc[s2][a][r]), sacc[s2][a][r + 1]);
+              const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m0), __float_as_uint(m0), false, false);
+              mx[a] = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            }
+            const bool first = t == 0 && s2 == 0;
+            const bool moved = first || __any(fmaxf(mx[0], mx[1]) > (float)THR);
+            if (moved) {
+#pragma unroll
+              for (int a = 0; a < 2; ++a) {
+                const float delta = first ? mx[a] : fmaxf(mx[a], 0.f);
+                const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);
+                m_run[a] += delta;
+                l_run[a] *= alpha;
+                const f16 mh = (f16)(-m_run[a]);
+                const f16 ml = (f16)(-m_run[a] - (float)mh);
+                mfrag[a][0] = hi == 0 ? mh : (f16)0.0f;
+                mfrag[a][1] = hi == 0 ? ml : (f16)0.0f;
+                ctrl[(s2 * 2 + a) * 64 + lane] = alpha;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[s2][a][r] -= delta;
+              }
+            }
+            if (lane == 0) reinterpret_cast<int*>(ctrl)[256 + s2] = (moved && !first) ? 1 : 0;
+            __builtin_amdgcn_sched_barrier(0);
+            // the next sub-tile's scores against the maximum as it stands now: (t, 1) from kf[1] behind (t, 0); (t + 1, 0) from kf[0] behind (t, 1);
+            // and the fragments of the sub-tile after that into the operand registers these scores' predecessor has left
+            if (s2 == 0) {
+              scores(1);
+              read_k(0, skn, 0);
+            } else {
+              scores(0);
+              read_k(1, skn, 1);
+            }
+            // ... under the exponentials of this one
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+              float ps0 = 0.f, ps1 = 0.f;
+              f16x8 pf[2];
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const float e = __builtin_amdgcn_exp2f(sacc[s2][a][r]);
+                if (r & 1) ps1 += e; else ps0 += e;
+                pf[r >> 3][r & 7] = (f16)e;
+              }
+#pragma unroll
+              for (int j = 0; j < 2; ++j) *reinterpret_cast<f16x8*>(ps + ((a * 2 + s2) * 2 + j) * 1024 + lane * 16) = pf[j];
+              l_run[a] += ps0 + ps1;
+            }
+#pragma unroll
+            for (int i = 0; i < 2 * DSTEPS + 2; ++i) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              if (i < DSTEPS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x402, (80 + DSTEPS) / (2 * DSTEPS + 2), 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (t + 1 == ntiles) {
+            lbase[lane] = l_run[0];
+            lbase[64 + lane] = l_run[1];
+          }
+          kslot_next = kslot_next == 2 ? 0 : kslot_next + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                 // B_t
+      }
+      return;
+    }
     for (int t = 0; t <= ntiles; ++t) {
       if (t < ntiles) {
         if (t + 1 < ntiles) stage_k((t + 1) & 1, t + 1);
@@ -1333,7 +1468,7 @@ __global__ __launch_bounds__(512, 2) void attn_ws_kernel(const AttnParams p) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, dv, 16, vv, (unsigned)kt * (KVB * 2u), 0, 0);
     }
   };
-  stage_v(0, 0);
+  if (!ROT) stage_v(0, 0);
   f32x16 oacc[DVT][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -1346,8 +1481,13 @@ __global__ __launch_bounds__(512, 2) void attn_ws_kernel(const AttnParams p) {
   int vslot = 0;                                                    // slot of V_{t-1} while in interval t
   for (int t = 0; t <= ntiles; ++t) {
     // V_{t+1} goes to slot (t + 1) % 3: V_{t-2}, its previous tenant, was read in interval t - 1
+    // (ROT: V_t itself, one interval before its use, into slot t & 1 -- V_{t-1}, read in this interval, sits in the other one)
     const int vnext = t + 1 < ntiles ? (t + 1) % 3 : 0;
-    if (t + 1 < ntiles) stage_v(vnext, t + 1);
+    if (ROT) {
+      if (t < ntiles) stage_v(t & 1, t);
+    } else if (t + 1 < ntiles) {
+      stage_v(vnext, t + 1);
+    }
     if (t >= 1) {
       const int u = t - 1;                                          // the tile whose P the S wave left before B_{t-1}
       const char* ps = pbase + (u & 1) * (4 * PSLOT);
@@ -1428,7 +1568,7 @@ __global__ __launch_bounds__(512, 2) void attn_ws_kernel(const AttnParams p) {
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    vslot = t % 3;                                                  // in interval t + 1 the tile to consume is V_t
+    vslot = ROT ? (t & 1) : t % 3;                                  // in interval t + 1 the tile to consume is V_t
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                   // B_t
   }
@@ -1925,15 +2065,21 @@ int launch_attn_v2(AttnParams p, hipStream_t st) {
     if (variant == 2 || (variant == 0 && DP == 128 && (!do_split || grid > slots))) {
       constexpr int WS_SMEM = 2 * KVB * DP * 2 + 3 * DVT * 32 * 128 + 2 * 4 * (8 * 1024 + 1280) + 2048;
       static bool ws_attr = false;
+      static int ws_rot = 0;
       if (!ws_attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_ws_kernel<6, DP>), hipFuncAttributeMaxDynamicSharedMemorySize, WS_SMEM);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_ws_kernel<6, DP, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, WS_SMEM);
+        // A/B knob (round 6): 1 = the S wave's sub-tile pipeline rotated across the tile boundary (K in a three-slot ring, see the kernel)
+        const char* er = fmx_knob("FMX_ATTN_WS_ROT");
+        ws_rot = er ? atoi(er) : FMX_ATTN_WS_ROT_DEFAULT;
         ws_attr = true;
       }
       // more than one round with a short tail: the full rounds here, the tail as key-split workgroups of the symmetric kernel behind it
       const bool tail = variant == 0 && do_split && grid > slots;
       p.nfull = tail ? grid - rem : grid;
       p.nsplit = 0;
-      hipLaunchKernelGGL((attn_ws_kernel<6, DP>), dim3(p.nfull), dim3(512), WS_SMEM, st, p);
+      if (ws_rot) hipLaunchKernelGGL((attn_ws_kernel<6, DP, 1>), dim3(p.nfull), dim3(512), WS_SMEM, st, p);
+      else hipLaunchKernelGGL((attn_ws_kernel<6, DP>), dim3(p.nfull), dim3(512), WS_SMEM, st, p);
       FMX_LAUNCH_CHECK("fmx_attention_f16 (wave-specialised)");
       if (tail) {
         p.bid0 = p.nfull;

@@ -116,7 +116,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gn_patch_kernel(const PatchCon
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const f32x4 s = sv[e >> 1];
+#ifdef FMX_CGN_ABLATE_SILU   // timing build: what the normalisation arithmetic costs (wrong results)
+          r[e] = v[it][e];
+#else
           r[e] = (f16)silu_f(fmaf((float)v[it][e], s[(e & 1) * 2], s[(e & 1) * 2 + 1]));   // gn_apply_kernel's arithmetic, bit for bit
+#endif
         }
       }
       *reinterpret_cast<f16x8*>(patch + (lds_off[it] & ((1 << 30) - 1))) = r;
@@ -161,13 +165,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gn_patch_kernel(const PatchCon
       kx = 0;
       if (++ky == 3) ky = 0;
     }
+#ifdef FMX_CGN_ABLATE_RESTAGE   // timing build: the first chunk's patch serves every chunk (wrong results): what restaging costs
+    if (false) {
+#else
     if (ti + 1 < ntaps && ky == 0 && kx == 0) {       // next tap opens a new channel chunk: every wave is done with this patch, then restage
+#endif
       __syncthreads();
       stage_patch(((ti + 1) / 9) * CC);
     }
+#ifdef FMX_CGN_ABLATE_WAIT    // timing build: the barrier without waiting for the next tap's weights (wrong results): what the DMA round trip costs
+    __builtin_amdgcn_s_barrier();
+#else
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
+#endif
   }
+#ifdef FMX_CGN_ABLATE_WAIT
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+#endif
 
   // ---- epilogue: lane (l16, kg) of block (pb, cb) holds output channels cb * 16 + kg * 4 + 0..3 of pixel (row 2 * wave + (pb >> 1), column (pb & 1) * 16 + l16) ----
   f32x4 bsum[8];
@@ -205,7 +221,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gn_patch_kernel(const PatchCon
         ssum[cb][r] += g;
         sqs[cb][r] += g * g;
       }
+#ifdef FMX_CGN_ABLATE_STORE   // timing build: no output traffic (wrong results)
+      if (ok && o[0] == (f16)12345.0f) *reinterpret_cast<f16x4*>(p.out + m * p.ld_out + cb * 16 + kg * 4) = o;
+#else
       if (ok) *reinterpret_cast<f16x4*>(p.out + m * p.ld_out + cb * 16 + kg * 4) = o;
+#endif
     }
   }
   if (p.stats) {

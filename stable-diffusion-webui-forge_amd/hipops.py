@@ -803,7 +803,7 @@ def conv3x3_gn_silu_eligible(x, cout, stats=None):
     if (stats if stats is not None else _attached_stats(x)) is None or n * h * w < (1 << 19):
         return False
     tiles = -(-h // 8) * -(-w // 32)
-    return tiles <= _stats_geometry(n, h * w)[1] and x.numel() * 2 < 3.9e9
+    return tiles <= _stats_geometry(n, h * w)[1]
 
 
 def conv3x3_gn_silu(x, gamma, beta, eps, wgt, bias, *, residual=None, out=None, groups=32, stats=None, want_stats=True, stats_partial=None):

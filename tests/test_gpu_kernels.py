@@ -1155,10 +1155,17 @@ def test_groupnorm_silu_conv3x3_in_one_kernel(n, hh, ww, cin, with_res, dtype):
     # the unfused pair on the same statistics
     gn = ops.groupnorm(x, g, b, 1e-6, silu=True, stats=st_x)
     two = ops.conv_gemm(gn, wk, cout, kh=3, pad=1, bias=bias, residual=res)
+    # two kernels: another fp32 summation order over the K = 9 * cin products, and -- at these small sizes -- another summation order of the
+    # statistics (groupnorm() folds its finalize into the apply blocks below 1 024 blocks, fmx_norm.hip GnFuse; the fused convolution runs the
+    # stand-alone finalize): scale / shift differ in their last bit, so one normalised activation in ~10^4 lands on the other neighbour, and an
+    # output moves by |w| x ulp(activation) <= ~5e-4 of the output's scale in fp16 (8 x that in bf16); at the VAE's sizes both paths use the same
+    # finalize and the staged patch IS the stored tensor (tests/test_gpu_vae_sharp_parity.py holds that level layer by layer at 2e-4 rms)
     d = (got.float() - two.float()).abs()
-    ulp = torch.maximum(two.float().abs(), torch.tensor(2.0 ** -14, device=DEV)).log2().floor().exp2() * (2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7)
-    assert bool((d <= ulp).all()), f"fused vs groupnorm + conv_gemm: max {float((d / ulp).max()):.2f} ulp"
-    assert float((d > 0).float().mean()) < 0.05, "summation order only: a rounding flips in a few per cent of the elements at most"
+    e = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    ulp = torch.maximum(two.float().abs(), torch.tensor(2.0 ** -14, device=DEV)).log2().floor().exp2() * e
+    scale = float(two.float().pow(2).mean().sqrt())
+    assert bool((d <= ulp + 0.5 * e * scale).all()), f"fused vs groupnorm + conv_gemm: max {float(((d - 0.5 * e * scale) / ulp).max()):.2f} ulp"
+    assert float((d > ulp).float().mean()) < 0.02, "more than a rounding apart in a few elements only"
     ref = F.conv2d(F.silu(F.group_norm(x.permute(0, 3, 1, 2).float(), 32, g.float(), b.float(), 1e-6)), wt.float(), bias.float(), padding=1)
     ref = ref.permute(0, 2, 3, 1).reshape(-1, cout) + (res.float() if with_res else 0)
     tol = 3e-3 if dtype == torch.float16 else 2e-2
@@ -1167,9 +1174,11 @@ def test_groupnorm_silu_conv3x3_in_one_kernel(n, hh, ww, cin, with_res, dtype):
     want = torch.stack([o.sum(1), (o * o).sum(1)], -1)
     torch.testing.assert_close(_partial_to_sums(st, n, cout), want, rtol=2e-5, atol=2e-3)
     # and the statistics feed the next fused launch (norm2 -> conv2 of the same block)
-    nxt, _ = ops.conv3x3_gn_silu(got.view(n, hh, ww, cout), g[:cout], b[:cout], 1e-6, wk[:, :9 * cout].contiguous() if cin >= cout else
-                                 rnd(cout, 9 * cout, scale=0.03, seed=336).to(dtype), bias, stats=st, want_stats=False)
-    assert bool(torch.isfinite(nxt.float()).all())
+    g2, b2 = (1 + 0.1 * rnd(cout, seed=337)).to(dtype), (0.1 * rnd(cout, seed=338)).to(dtype)
+    w2 = rnd(cout, 9 * cout, scale=0.03, seed=336).to(dtype)
+    nxt, _ = ops.conv3x3_gn_silu(got.view(n, hh, ww, cout), g2, b2, 1e-6, w2, bias, stats=st, want_stats=False)
+    nxt2 = ops.conv_gemm(ops.groupnorm(got.view(n, hh, ww, cout), g2, b2, 1e-6, silu=True, stats=st), w2, cout, kh=3, pad=1, bias=bias)
+    close(nxt, nxt2.float(), 4 * e, 4 * e, "second fused launch on the first one's statistics")
 
 
 def test_narrow_output_conv3x3_contract():

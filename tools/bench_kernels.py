@@ -530,6 +530,34 @@ if __name__ == "__main__":
             bench_conv(8, 512, 512, 256, 256, tile)
             bench_conv(8, 256, 256, 512, 384, tile)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "convgn":
+        # GroupNorm + SiLU + conv3x3 in one kernel (csrc/fmx_conv_patch.hip) against groupnorm + conv_gemm, the VAE decoder's full-resolution level
+        import math
+        for n, hh, ww, cin in ((8, 1024, 1024, 128), (4, 1024, 1024, 256), (8, 512, 512, 128)):
+            x = (rnd(n, hh, ww, cin) + 0.3)
+            g, b = 1 + 0.1 * rnd(cin), 0.1 * rnd(cin)
+            wk = rnd(128, 9 * cin, scale=1 / math.sqrt(9 * cin))
+            bias = rnd(128)
+            res = rnd(n * hh * ww, 128)
+            st = ops.groupnorm_stats(x)
+            flops = 2.0 * n * hh * ww * 128 * 9 * cin
+            for with_res in (False, True):
+                r = res if with_res else None
+                out = ops.empty((n * hh * ww, 128), torch.float16)
+                t_f = timeit(lambda: ops.conv3x3_gn_silu(x, g, b, 1e-6, wk, bias, residual=r, out=out, stats=st), iters=10)
+
+                def two():
+                    gn = ops.groupnorm(x, g, b, 1e-6, silu=True, stats=st)
+                    ops.conv_gemm(gn, wk, 128, kh=3, pad=1, bias=bias, residual=r, out=out, ld_out=128, stats=True)
+                t_2 = timeit(two, iters=10)
+                gn = ops.groupnorm(x, g, b, 1e-6, silu=True, stats=st)
+                t_c = timeit(lambda: ops.conv_gemm(gn, wk, 128, kh=3, pad=1, bias=bias, residual=r, out=out, ld_out=128, stats=True), iters=10)
+                print(json.dumps({"case": f"gn+silu+conv3x3 n={n} {hh}x{ww} cin={cin} cout=128 residual={with_res}", "fused_ms": round(t_f * 1e3, 3),
+                                  "fused_tflops": round(flops / t_f / 1e12, 1), "groupnorm_plus_conv_gemm_ms": round(t_2 * 1e3, 3),
+                                  "conv_gemm_alone_ms": round(t_c * 1e3, 3), "conv_gemm_alone_tflops": round(flops / t_c / 1e12, 1),
+                                  "lib": os.environ.get("FMX_LIB", "")}), flush=True)
+                del gn
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "attn512":
         for b, n in ((8, 16384), (8, 4096), (1, 16384), (2, 1024)):
             bench_attn512(b, n)
@@ -555,6 +583,11 @@ if __name__ == "__main__":
             got = o.view(b, n, h, d).permute(0, 2, 1, 3).float()
             print(json.dumps({"poly": os.environ.get("FMX_ATTN_POLY", "0"), "scores": name, "rms_rel_vs_fp32": float(((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())),
                               "max_rel_vs_fp32": float((got - ref).abs().max() / ref.abs().max())}), flush=True)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "attn128":
+        # d_head 128 (Flux-dev at 1024^2: 4096 image + 256 text tokens, 24 heads) and two neighbours, in a graph on their own tensors
+        for b, h, n in ((2, 24, 4352), (1, 24, 4352), (4, 24, 4352), (2, 24, 1280)):
+            bench_attn(b, h, n, n, 128, 128, False)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "attn":
         for f32 in (True, False):

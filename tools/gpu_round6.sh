@@ -21,7 +21,15 @@ for w in "$@"; do
     ab_env) for E in $ABENV0 $ABENV1 $ABENV0 $ABENV1; do env ${E//,/ } timeout 600 python bench.py ${ABFLAGS:---no-vae} --no-cpu-baseline --no-rccl-selfcheck --no-other-configs --no-torch-rocm-baseline --steps 10 2>> $O/ab.err | benchline "$E" >> $O/ab.jsonl; done; cat $O/ab.jsonl; tail -3 $O/ab.err;;
     ab_lib) for L in "" $ABLIB "" $ABLIB; do FMX_LIB=$L timeout 600 python bench.py ${ABFLAGS:---no-vae} --no-cpu-baseline --no-rccl-selfcheck --no-other-configs --no-torch-rocm-baseline --steps 10 2>> $O/ab.err | benchline "lib=$L" >> $O/ab.jsonl; done; cat $O/ab.jsonl; tail -3 $O/ab.err;;
     kb) timeout 900 python tools/bench_kernels.py $KB > $O/kb_$KB.jsonl 2> $O/kb_$KB.err; cat $O/kb_$KB.jsonl | cut -c1-400; tail -3 $O/kb_$KB.err;;
-    pyt) timeout 1200 python -m pytest $PYT -m gpu -q --tb=short -s 2>&1 | grep -v "^\[parity\]" | tail -40 > $O/pyt.log; tail -30 $O/pyt.log | cut -c1-600;;
+    attnrot) FMX_ATTN_WS_ROT=1 timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_flux.py tests/test_gpu_flux_sharp_parity.py -m gpu -q --tb=short -k "d128 or attention or flux_forward_at_its_own_width or tiny or sharp or stage" 2>&1 | tail -15 > $O/attnrot_tests.log; tail -6 $O/attnrot_tests.log | cut -c1-300;
+             for E in 0 1 0 1; do FMX_ATTN_WS_ROT=$E timeout 300 python tools/bench_kernels.py attn128 >> $O/attnrot.jsonl 2>> $O/attnrot.err; done; cat $O/attnrot.jsonl | cut -c1-300; tail -2 $O/attnrot.err;;
+    pmc_attnrot) for E in 0 1; do mkdir -p $O/rot$E; for PASS in "mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" "waves SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA"; do
+               set -- $PASS; name=$1; shift
+               (cd /tmp && export TMPDIR=/tmp && FMX_ATTN_WS_ROT=$E timeout 300 rocprofv3 --kernel-trace --pmc "$@" -f csv -d $O/rot$E/pmc_$name -o pmc -- python $R/tools/pmc_attn128.py > $O/rot$E/pmc_$name.log 2>&1); tail -1 $O/rot$E/pmc_$name.log | cut -c1-200
+               find $O/rot$E/pmc_$name -name '*kernel_trace.csv' -delete; done
+             python tools/pmc_mfma_summary.py $O/rot$E > $O/pmc_attn128_rot$E.json; cat $O/pmc_attn128_rot$E.json | head -40; done;;
+    kbvar) for L in "" $KBLIBS; do FMX_LIB=$L timeout 600 python tools/bench_kernels.py $KB >> $O/kbvar_$KB.jsonl 2>> $O/kbvar_$KB.err; done; cat $O/kbvar_$KB.jsonl | cut -c1-500; tail -3 $O/kbvar_$KB.err;;
+    pyt) eval timeout 1200 python -m pytest $PYT -m gpu -q --tb=short -s 2>&1 | grep -v "^\[parity\]" | tail -40 > $O/pyt.log; tail -30 $O/pyt.log | cut -c1-600;;
     prof) (cd /tmp && export TMPDIR=/tmp && timeout 1200 rocprofv3 --kernel-trace --stats -f csv -d $O/prof -o kt -- \
             python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs --no-torch-rocm-baseline --no-rccl-selfcheck > $O/prof_bench.log 2>&1); tail -2 $O/prof_bench.log | cut -c1-600;
           find $O/prof -name '*kernel_trace.csv' -size +20M -delete; ls -la $O/prof/* | head;;

@@ -19,7 +19,7 @@ import sys
 
 
 def short(name):
-    for key in ("attn_short2_kernel", "attn_short_kernel", "attn_q64v3_kernel", "attn_q64v2_kernel", "attn_q64_kernel", "attn_kernel", "gemm256p_kernel", "gemm_kernel", "gn_apply_kernel", "gn_stats_kernel", "gn_finalize_kernel"):
+    for key in ("attn_ws_kernel", "attn512_kernel", "conv3x3_gn_patch_kernel", "attn_short2_kernel", "attn_short_kernel", "attn_q64v3_kernel", "attn_q64v2_kernel", "attn_q64_kernel", "attn_kernel", "gemm256p_kernel", "gemm_kernel", "gn_apply_kernel", "gn_stats_kernel", "gn_finalize_kernel"):
         if key in name:
             i = name.index(key)
             j = name.find("(", i)
