@@ -396,6 +396,20 @@ typedef struct fmx_conv_gn_args {
   int32_t stats_cap;
 } fmx_conv_gn_args;
 int fmx_conv3x3_gn_silu_f16(const fmx_conv_gn_args* args /* host */, int32_t* stats_nchunks /* host, may be null */, void* stream);
+/* Upsample: 3x3 convolution (padding 1) of the x2 NEAREST-upsampled input -- backend/nn/unet.py:328-355 (Upsample.forward: F.interpolate(scale 2,
+ * "nearest") then conv) and backend/nn/vae.py:35-57 -- WITHOUT the nine-fold work on the upsampled grid (ABI 11).  Of the 3 x 3 taps of an output pixel
+ * only 2 x 2 DISTINCT input pixels are touched: output rows 2iy read input rows {iy-1, iy} with weights {w[0], w[1]+w[2]}, rows 2iy+1 read {iy, iy+1}
+ * with {w[0]+w[1], w[2]}; columns alike.  So the layer is FOUR 2 x 2 convolutions on the input grid, one per output parity (py, px), each writing every
+ * second pixel of every second output row: 4 / 9 of the multiply-adds, no upsampled tensor, no gather.
+ *   x    : fp16 NHWC [n][h][w][c], c a multiple of 64, w a multiple of 32
+ *   wgt4 : fp16 [4][nout][2][2][c] -- phase 2*py + px, taps (dy, dx) row-major -- the tap SUMS of the layer's [nout][3][3][c] weight, formed in fp32
+ *          and rounded once to the element type by the caller (forge_amd.hipops.fold_up2x_weights): one more rounding of the same size as the
+ *          weight's own, which the rounding oracles of tests/ model at exactly this site
+ *   out  : fp16 NHWC [n][2h][2w][nout] dense; bias [nout] or null
+ *   stats: optional GroupNorm statistics of the output, [n][stats_cap][nout][2], 4 * h*w/256 records per image (h*w a multiple of 256)
+ * Runs on the 256-row implicit-GEMM kernels (their bit-mask address form, K = 4 c) with scattered output rows. */
+int fmx_conv3x3_up2x_f16(const void* x, int32_t n, int32_t h, int32_t w, int32_t c, const void* wgt4, const void* bias, int32_t nout, void* out,
+                         float* stats, int32_t stats_cap, int32_t* stats_nchunks /* host, may be null */, const void* zero_page, void* stream);
 /* VAE output: y fp16 NHWC [b*h*w][ld] (first c channels) -> clamp((y+1)/2, 0, 1) fp32 NHWC [b][h][w][c] */
 int fmx_vae_unpack_image(const void* y, int32_t ld, int64_t npix, int32_t c, float* out, void* stream);
 
@@ -456,6 +470,8 @@ int fmx_vae_pack_latent_bf16(const float* z, float scaling_factor, float shift, 
 int fmx_vae_unpack_image_bf16(const void* y, int32_t ld, int64_t npix, int32_t c, float* out, void* stream);
 int fmx_conv3x3_narrow_bf16(const void* x, int32_t n, int32_t h, int32_t w, int32_t c, const void* wgt, const void* bias, int32_t nout, void* out,
                             int32_t ld_out, void* stream);
+int fmx_conv3x3_up2x_bf16(const void* x, int32_t n, int32_t h, int32_t w, int32_t c, const void* wgt4, const void* bias, int32_t nout, void* out,
+                          float* stats, int32_t stats_cap, int32_t* stats_nchunks, const void* zero_page, void* stream);
 int fmx_conv3x3_gn_silu_bf16(const fmx_conv_gn_args* args /* host */, int32_t* stats_nchunks /* host, may be null */, void* stream);
 int fmx_vae_sample_posterior_bf16(const void* moments, int32_t ld, const float* noise, int32_t b, int32_t lc, int64_t npix, float scale,
                                   float shift, float* out, void* stream);

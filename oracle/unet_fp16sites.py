@@ -25,6 +25,8 @@ Rounding sites (R = x.half().float(); each cites the executor line that stores f
                     fp16(W16 beta16 + b16) (q|k, to_q, ff.net.0) resp. fp32 W16 beta16   csrc/fmx_gemm_epi.hpp:33-37
                     (V^T), result = rstd (x W'^T - mean colsum(W')) + bias'
   Down / Up / conv_in / out   fp16( conv + b );  out.2 reads fp16( SiLU(GN(h)) )         native:592-598, 698, 743-750
+  Upsample conv     where the executor runs it as four phase convolutions (`up2x`):      native hipops.fold_up2x_weights,  unet.py:340-355
+                    weights = fp16( sums of the fp16 taps that meet in one input pixel )  include/fmx.h fmx_conv3x3_up2x
 
 `rounding=False` switches every R off and must then reproduce oracle/unet.py BIT FOR BIT (tests/test_oracle_fp16sites.py) -- that is the pin:
 the walk below IS the pinned restatement's (oracle.unet.unet_forward / _run_block run unchanged; only the leaf functions are swapped for the
@@ -58,8 +60,9 @@ def _ident(x):
 
 
 class _State:
-    def __init__(self, rounding, fold, plant, teacher=None, layer_out=None, acc64=False):
+    def __init__(self, rounding, fold, plant, teacher=None, layer_out=None, acc64=False, up2x=()):
         self.acc64 = acc64
+        self.up2x = set(up2x or ())
         self.R = _r16 if rounding else _ident
         self.rounding = rounding
         self.fold = fold or {}
@@ -145,11 +148,35 @@ def _ln(sd, key, x):
     return st.R((((x.double() - mean) * rstd) * sd[key + ".weight"].double() + sd[key + ".bias"].double()).float())
 
 
+def up2x_phase_conv(x_up, w, b, R, c2d=F.conv2d):
+    """conv3x3(pad 1) of a x2 NEAREST-upsampled tensor as the executor runs it where fmx_conv3x3_up2x is eligible (include/fmx.h): four 2 x 2
+    convolutions on the un-upsampled grid, one per output parity, on TAP SUMS of the (already rounded) weight that are rounded once more:
+    even output rows read input rows {iy - 1, iy} through {w[0], w[1] + w[2]}, odd ones {iy, iy + 1} through {w[0] + w[1], w[2]}; columns alike.
+    With R = identity this is the reference's interpolate + conv exactly (up to fp32 summation order).  x_up: [B, C, 2h, 2w] as F.interpolate made it."""
+    x = x_up[:, :, ::2, ::2]
+    n, _, h, wd = x.shape
+    out = x.new_empty(n, w.shape[0], 2 * h, 2 * wd)
+
+    def fold(t, dim, parity):
+        a, m, d = t.unbind(dim)
+        return torch.stack([a, m + d] if parity == 0 else [a + m, d], dim)
+    for py in (0, 1):
+        for px in (0, 1):
+            wp = R(fold(fold(w, 2, py), 3, px))                                   # [nout, C, 2, 2]
+            xp = F.pad(x, (1 - px, px, 1 - py, py))                               # even parity: {i - 1, i}; odd: {i, i + 1}
+            out[:, :, py::2, px::2] = c2d(xp, wp, None)
+    return out if b is None else out + b[None, :, None, None]
+
+
 def _conv(sd, key, x, stride=1, padding=1):
     # conv_in, Down, Up, out.2: one rounding of (accumulator + bias); out.2 reads the stored fp16( SiLU(GN(h)) ) (the walk hands it over unrounded)
     if key == "out.2":
         x = _ST.R(x)
-    out = _ST.R(_c2d(x, sd[key + ".weight"], sd[key + ".bias"], stride=stride, padding=padding))
+    if _ST.rounding and key.endswith(".conv") and key[:-len(".conv")] in _ST.up2x:
+        # an Upsample convolution the executor ran as four phase convolutions (IntegratedUNet2DConditionModel.up2x_trace): tap sums rounded to fp16
+        out = _ST.R(up2x_phase_conv(x, sd[key + ".weight"], sd[key + ".bias"], _ST.R, lambda a, w_, b_: _c2d(a, w_, b_)))
+    else:
+        out = _ST.R(_c2d(x, sd[key + ".weight"], sd[key + ".bias"], stride=stride, padding=padding))
     for suffix in (".op", ".conv"):            # the executor names a Down / Up layer by its block key
         if key.endswith(suffix):
             key = key[:-len(suffix)]
@@ -320,17 +347,20 @@ def _installed(state):
 
 
 @torch.no_grad()
-def unet_forward(sd, cfg, x, timesteps, context, y=None, fold=None, plant=None, rounding=True, teacher=None, layer_out=None, acc64=False, native_view=None):
+def unet_forward(sd, cfg, x, timesteps, context, y=None, fold=None, plant=None, rounding=True, teacher=None, layer_out=None, acc64=False, native_view=None,
+                 up2x=()):
     """Same contract as oracle.unet.unet_forward (hooks / ControlNet not supported here).
     fold: {transformer_block_key: (norm1_folded, norm2_folded, norm3_folded)} -- what the executor did (`IntegratedUNet2DConditionModel.fold_trace`);
     absent keys = not folded.  -> eps fp32 (fp16-valued when rounding).
     teacher / layer_out: layer-wise mode.  teacher = {layer key: the executor's stored output of that layer} (`IntegratedUNet2DConditionModel.tap`);
     every layer is then evaluated on the executor's own inputs and its result lands in layer_out[key] (the return value is the teacher's eps);
     native_view[key] receives the teacher's tensor in the oracle's layout (NCHW, heads unpadded) for the comparison.
+    up2x: keys of the Upsample layers whose convolution the executor ran as four phase convolutions on tap-summed weights
+    (`IntegratedUNet2DConditionModel.up2x_trace`; up2x_phase_conv above).
     acc64: convolutions and Linears accumulate in fp64 instead of fp32 -- a SECOND implementation of the same rounding network that differs from
     the first by summation error only (~1e-7); the CPU tests use it as a stand-in for "another correct executor" to show what two of them can and
     cannot agree on (whole network: decorrelated rounding realisations; layer by layer on shared inputs: ~1e-5)."""
-    state = _State(rounding, fold, plant, teacher, layer_out, acc64)
+    state = _State(rounding, fold, plant, teacher, layer_out, acc64, up2x)
     if rounding:
         sd = {k: _r16(v) if v.is_floating_point() else v for k, v in sd.items()}
         x = _r16(x.float())

@@ -28,8 +28,9 @@ LOG2E = 1.4426950408889634
 
 
 class _State:
-    def __init__(self, rounding, teacher, layer_out, plant):
+    def __init__(self, rounding, teacher, layer_out, plant, up2x=()):
         self.rounding, self.teacher, self.layer_out, self.plant = rounding, teacher, layer_out, plant or {}
+        self.up2x = set(up2x or ())
         self.R = (lambda t: t.half().float()) if rounding else (lambda t: t)
 
     def teach(self, key, computed):
@@ -101,9 +102,9 @@ def _attn(st, sd, key, x):
 
 
 @torch.no_grad()
-def vae_decode(sd, z, rounding=True, teacher=None, layer_out=None, plant=None):
+def vae_decode(sd, z, rounding=True, teacher=None, layer_out=None, plant=None, up2x=()):
     """IntegratedAutoencoderKL.decode on z [B, lc, h, w] (already process_out'ed) -> [B, 3, 8h, 8w] (vae.py:305-316 without the scaling)."""
-    st = _State(rounding, teacher, layer_out, plant)
+    st = _State(rounding, teacher, layer_out, plant, up2x)
     R = st.R
     h = R(z.float())
     if "post_quant_conv.weight" in sd:
@@ -122,7 +123,14 @@ def vae_decode(sd, z, rounding=True, teacher=None, layer_out=None, plant=None):
             i += 1
         if lev != 0:
             up = f"decoder.up.{lev}.upsample"
-            h = st.teach(up, R(_conv(st, sd, up + ".conv", F.interpolate(h, scale_factor=2.0, mode="nearest"))))
+            hu = F.interpolate(h, scale_factor=2.0, mode="nearest")
+            if rounding and up in st.up2x:
+                # the executor ran this Upsample convolution as four phase convolutions on tap-summed weights (IntegratedAutoencoderKL.up2x_trace;
+                # oracle/unet_fp16sites.py up2x_phase_conv): the sums of the rounded taps are rounded once more
+                from .unet_fp16sites import up2x_phase_conv
+                h = st.teach(up, R(up2x_phase_conv(hu, R(sd[up + ".conv.weight"]), R(sd[up + ".conv.bias"]), R)))
+            else:
+                h = st.teach(up, R(_conv(st, sd, up + ".conv", hu)))
     g = R(F.silu(_gn(st, sd, "decoder.norm_out", h)))
     return st.teach("conv_out", R(_conv(st, sd, "decoder.conv_out", g)))
 

@@ -175,6 +175,9 @@ class IntegratedUNet2DConditionModel:
         # (eager or graph capture) -- which rounding sites exist depends on it, so the executor-faithful oracle (oracle/unet_fp16sites.py, tests
         # only) is told what happened instead of guessing the dispatcher's tile choices
         self.fold_trace = {}
+        # Upsample layers whose convolution ran as four phase convolutions on tap-summed weights in the last forward (another rounding site of the
+        # weights: the rounding oracle is told, like fold_trace)
+        self.up2x_trace = set()
         # tap(name, tensor): when set, called on the eager path with every layer's stored output (name = the layer's LDM key; `<SpatialTransformer
         # key>.proj_in`, every `...transformer_blocks.N` and its `.attn1` / `.attn2` (the stream after those sub-layers), `.attn1.o` / `.attn2.o`
         # (attention outputs, heads at their padded width), `.attn{1,2}.{q,k,v}` (the attention kernel's operands), `.ff.g` (GEGLU output), a ResBlock's `.h` (conv1 + emb), "time_embed", "out.2") -- a VIEW of the kernel's own buffer, to be copied by the callee.
@@ -282,6 +285,9 @@ class IntegratedUNet2DConditionModel:
                 w[k] = (_conv_w(sd[k + ".op.weight"].to(dev, torch.float16)), T(k + ".op.bias"))
             elif isinstance(L, Up):
                 w[k] = (_conv_w(sd[k + ".conv.weight"].to(dev, torch.float16)), T(k + ".conv.bias"))
+                # the same layer as four 2 x 2 convolutions on the un-upsampled grid (4 / 9 of the multiply-adds, hipops.conv3x3_up2x); the 3 x 3 form
+                # stays for output sizes that are not an exact x2 (unet.py:349-351 `output_shape`) and for hooked runs
+                w[k + ".up2x"] = ops.fold_up2x_weights(w[k][0], w[k][0].shape[1] // 9)
         w["emb_all"] = (torch.cat(emb_w, 0).contiguous(), torch.cat(emb_b, 0).contiguous())
         self._emb_off = emb_off
         self._emb_total = off
@@ -639,7 +645,11 @@ class IntegratedUNet2DConditionModel:
             elif isinstance(L, Up):
                 bu, hh, ww, c = h.shape
                 uh, uw = up_to if up_to is not None else (hh * 2, ww * 2)
-                h, st = ops.conv_gemm(h, self.w[L.key][0], c, kh=3, pad=1, up=(uh, uw), bias=self.w[L.key][1], stats=True)
+                if ops.conv3x3_up2x_eligible(h, c, (uh, uw)):
+                    h, st = ops.conv3x3_up2x(h, self.w[L.key + ".up2x"], self.w[L.key][1], c)
+                    self.up2x_trace.add(L.key)
+                else:
+                    h, st = ops.conv_gemm(h, self.w[L.key][0], c, kh=3, pad=1, up=(uh, uw), bias=self.w[L.key][1], stats=True)
                 h = ops.attach_stats(h.view(bu, uh, uw, c), st)
             else:
                 raise TypeError(L)

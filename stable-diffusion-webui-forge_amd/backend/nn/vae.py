@@ -55,6 +55,7 @@ class IntegratedAutoencoderKL:
         self.dtype = dtype
         self.auto_bf16_fallback = bool(auto_bf16_fallback)
         self.fallbacks = 0          # decodes repeated in bfloat16 because the fp16 result was not finite
+        self.up2x_trace = set()     # Upsample layers that ran as four phase convolutions in the last decode (told to the rounding oracle, tests only)
         self.tap = None             # test hook: a dict that receives every layer's stored output of the next decode (see _tap)
         # by reference, and only while a fallback can still happen (an fp16 executor with the guard on): the bfloat16 weights are made from it then, and
         # it is released -- together with the fp16 copy, which no later decode uses -- as soon as they exist (the caller's full state dict,
@@ -90,6 +91,9 @@ class IntegratedAutoencoderKL:
                     raise RuntimeError("set_dtype(float16) on a VAE whose only resident weights are bfloat16: the fp32 source was released; "
                                        "construct IntegratedAutoencoderKL(..., dtype=torch.float16) from the state dict instead")
                 self._weights[dtype] = {k: (tuple(t.to(dtype) for t in v) if isinstance(v, tuple) else v.to(dtype) if torch.is_tensor(v) else v) for k, v in src.items()}
+                for k in [k for k in self._weights[dtype] if k.endswith(".up2x")]:   # tap sums: from the re-rounded taps, one rounding (not a second one of the fp16 sums)
+                    base = self._weights[dtype][k[:-len(".up2x")]][0]
+                    self._weights[dtype][k] = ops.fold_up2x_weights(base, base.shape[1] // 9)
         self.dtype, self.w = dtype, self._weights[dtype]
 
     def _load(self, sd, dt):
@@ -152,6 +156,7 @@ class IntegratedAutoencoderKL:
                 res(key, cin, cout)
             if up is not None:
                 w[up] = conv(up + ".conv")
+                w[up + ".up2x"] = ops.fold_up2x_weights(w[up][0], w[up][0].shape[1] // 9)   # the Upsample convolution as four phase convolutions (hipops.conv3x3_up2x)
         w["norm_out"] = norm("decoder.norm_out")
         w["conv_out"] = conv("decoder.conv_out")
         if self.has_encoder:
@@ -313,7 +318,11 @@ class IntegratedAutoencoderKL:
                 h = self._res(key, h, cin, cout, arena)
             if up is not None:
                 bb, h2, w2, c = h.shape
-                h, st = ops.conv_gemm(h, self.w[up][0], c, kh=3, pad=1, up=(2 * h2, 2 * w2), bias=self.w[up][1], stats=True)
+                if ops.conv3x3_up2x_eligible(h, c):
+                    h, st = ops.conv3x3_up2x(h, self.w[up + ".up2x"], self.w[up][1], c)
+                    self.up2x_trace.add(up)
+                else:
+                    h, st = ops.conv_gemm(h, self.w[up][0], c, kh=3, pad=1, up=(2 * h2, 2 * w2), bias=self.w[up][1], stats=True)
                 h = ops.attach_stats(h.view(bb, 2 * h2, 2 * w2, c), st)
                 self._tap(up, h)
         g = ops.groupnorm(h, *self.w["norm_out"], 1e-6, silu=True)

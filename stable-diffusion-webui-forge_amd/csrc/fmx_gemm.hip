@@ -23,6 +23,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "fmx_gemm_common.hpp"
 
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
       const int ox = rem - oy * p.ow;
       a_pix[j] = (long)img * p.h * p.w;
       a_iy0[j] = oy * p.stride - p.pad;
-      a_ix0[j] = ox * p.stride - p.pad;
+      a_ix0[j] = ox * p.stride - p.pad_x;
     } else {
       a_pix[j] = m;
       a_iy0[j] = a_ix0[j] = 0;
@@ -515,8 +516,15 @@ __global__ void geglu_interleave_kernel(const f16* __restrict__ w_in, const f16*
 
 int fmx_launch_gn_stats(const void* x, int32_t c, int64_t ld, int32_t n, int32_t hw, float* partial, int32_t nchunks, hipStream_t st);  // fmx_norm.hip
 
+// a phase convolution of fmx_conv3x3_up2x: horizontal padding of its own, scattered output rows, its slice of a statistics array shared by the four phases
+struct ScatterSpec {
+  int pad_x, ow;
+  long extra;
+  int stats_nch_total;
+};
+
 static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, int fallback_chunks, int* chunks_out, void* stream,
-                         float* row_stats = nullptr, int row_parts_cap = 0, int* row_parts_out = nullptr);
+                         float* row_stats = nullptr, int row_parts_cap = 0, int* row_parts_out = nullptr, const ScatterSpec* sc = nullptr);
 
 // Where the 256x160 two-workgroups-per-CU kernel replaces the 256x320 one by default: set from the same-box A/B of profiles/r10_gemm4w_ab.jsonl.
 static bool fmx_gemm4w_preferred(int M, int nout, int kt, bool geglu) {
@@ -571,12 +579,12 @@ static int gemm_conv_impl(const fmx_gemm_args* a, float* stats, int max_chunks, 
 }
 
 static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, int fallback_chunks, int* chunks_out, void* stream, float* row_stats,
-                         int row_parts_cap, int* row_parts_out) {
+                         int row_parts_cap, int* row_parts_out, const ScatterSpec* sc) {
   FMX_REQUIRE(a && a->a0 && a->wgt && a->out && a->zero_page, "gemm: null pointer");
   const int ctot = a->c0 + a->c1;
   FMX_REQUIRE(a->c0 > 0 && a->c1 >= 0 && (a->c0 % 64) == 0 && (ctot % 64) == 0, "gemm: channels (%d,%d) must be multiples of 64", a->c0, a->c1);
   FMX_REQUIRE(a->c1 == 0 || a->a1, "gemm: a1 missing");
-  FMX_REQUIRE(a->kh == 1 || a->kh == 3, "gemm: kh must be 1 or 3");
+  FMX_REQUIRE(a->kh == 1 || a->kh == 3 || (sc && a->kh == 2), "gemm: kh must be 1 or 3");
   FMX_REQUIRE(a->n > 0 && a->h > 0 && a->w > 0 && a->oh > 0 && a->ow > 0 && a->nout > 0, "gemm: bad dims");
   FMX_REQUIRE(a->act == FMX_ACT_NONE || a->act == FMX_ACT_GELU_TANH || (a->act == FMX_ACT_GEGLU && (a->nout % 32) == 0), "gemm: bad act/nout");
   GemmParams p;
@@ -586,6 +594,9 @@ static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, i
   p.s1 = a->a1_stride ? a->a1_stride : a->c1;
   p.n = a->n; p.h = a->h; p.w = a->w; p.oh = a->oh; p.ow = a->ow;
   p.kh = a->kh; p.stride = a->stride > 0 ? a->stride : 1; p.pad = a->pad;
+  p.pad_x = sc ? sc->pad_x : a->pad;
+  p.scat_ow = sc ? sc->ow : 0;
+  p.scat_extra = sc ? sc->extra : 0;
   p.up_h = a->up_h; p.up_w = a->up_w;
   p.wgt = (const f16*)a->wgt;
   p.ldw = a->ldw ? a->ldw : a->kh * a->kh * ctot;
@@ -750,6 +761,11 @@ static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, i
     if (w4_ok && sel == 6 && (mode4 == 2 || (mode4 == 1 && fmx_gemm4w_preferred(p.M, p.nout, p.kt, geglu)))) sel = 9;
   }
   if (a->out_f32 < 0) { sel = (-a->out_f32 - 1) % 16; best_s = 1; }  // test hook: force a tile shape (out_f32 = -1..-10 -> fp16 out)
+  if (sc) {   // scattered output rows exist in the 256 x 256 / 256 x 320 kernels only
+    FMX_REQUIRE(big_ok && !geglu && p.c1 == 0 && a->up_h == 0, "gemm: a phase convolution needs the 256-row kernels (fp16 output, aligned operands < 3 GB, one source)");
+    sel = cost(256, 320, 1, 1.0, e8, F8) <= cost(256, 256, 1, 0.97, e8, F8) ? 6 : 5;
+    best_s = 1;
+  }
   if (split_ok && force_split >= 2 && (sel == 0 || sel == 1 || sel == 10 || sel == 12) && split_fits(128, (sel == 0 || sel == 10) ? 128 : 64, force_split))
     best_s = force_split;
   if (best_s > 1 && sel != 0 && sel != 1 && sel != 10 && sel != 12) best_s = 1;   // (ids 12 / 14, the 160-wide ring tiles, have no split-K form)
@@ -767,7 +783,10 @@ static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, i
   // output statistics: from the epilogue of a 256-row tile when every image is a whole number of tiles, else a pass behind the GEMM
   const int per_img = a->oh * a->ow;
   bool stats_after = false;
-  if (stats) {
+  if (stats && sc) {   // the caller (fmx_conv3x3_up2x) checked that an image is a whole number of 256-row tiles and offset `stats` to this phase's records
+    p.stats = stats;
+    p.stats_nch = sc->stats_nch_total;
+  } else if (stats) {
     FMX_REQUIRE(!geglu && !p.out_f32 && p.ld_out == p.nout && (p.nout % 8) == 0 && !p.gate && a->act == FMX_ACT_NONE,
                 "gemm: output statistics need a dense fp16 [M][nout] output without activation / gate");
     FMX_REQUIRE(fallback_chunks >= 1 && fallback_chunks <= 1024 && max_chunks >= fallback_chunks, "gemm: bad statistics chunk counts");
@@ -867,6 +886,42 @@ static int gemm_conv_one(const fmx_gemm_args* a, float* stats, int max_chunks, i
 }
 
 extern "C" int fmx_gemm_conv_f16(const fmx_gemm_args* a, void* stream) { return gemm_conv_impl(a, nullptr, 0, 0, nullptr, stream); }
+
+// conv3x3(pad 1) of the x2 nearest-upsampled input = four 2 x 2 convolutions on the INPUT grid, one per output parity (see fmx.h)
+extern "C" int fmx_conv3x3_up2x_f16(const void* x, int32_t n, int32_t h, int32_t w, int32_t c, const void* wgt4, const void* bias, int32_t nout, void* out,
+                                    float* stats, int32_t stats_cap, int32_t* stats_nchunks, const void* zero_page, void* stream) {
+  FMX_REQUIRE(x && wgt4 && out && zero_page && n > 0 && h > 0 && w > 0, "conv3x3_up2x: bad arguments");
+  FMX_REQUIRE(c > 0 && (c % 64) == 0 && nout > 0 && (nout % 8) == 0, "conv3x3_up2x: input channels must be a multiple of 64, output channels of 8 (got %d, %d)", c, nout);
+  FMX_REQUIRE((w % 32) == 0, "conv3x3_up2x: the input width must be a multiple of 32 (got %d)", w);
+  const long per = (long)h * w;
+  FMX_REQUIRE((double)n * per * c * 2.0 < 3.0e9, "conv3x3_up2x: input beyond the 32-bit offset range of one launch (split the batch)");
+  int nch = 0;
+  if (stats) {
+    FMX_REQUIRE((per % 256) == 0, "conv3x3_up2x: output statistics need h * w to be a multiple of 256 (got %ld)", per);
+    nch = (int)(4 * (per / 256));
+    FMX_REQUIRE(stats_cap >= nch, "conv3x3_up2x: the statistics buffer holds %d records per image, the four phases write %d", stats_cap, nch);
+  }
+  for (int ph = 0; ph < 4; ++ph) {
+    const int py = ph >> 1, px = ph & 1;
+    fmx_gemm_args a;
+    memset(&a, 0, sizeof(a));
+    a.a0 = x; a.c0 = c; a.a0_stride = c;
+    a.n = n; a.h = h; a.w = w; a.oh = h; a.ow = w;
+    a.kh = 2; a.stride = 1; a.pad = 1 - py;                       // rows {iy - 1, iy} for the even output rows, {iy, iy + 1} for the odd ones
+    a.wgt = (const char*)wgt4 + (long)ph * nout * 4 * c * 2; a.ldw = 4 * c; a.nout = nout;
+    a.bias = bias;
+    a.alpha = 1.0f; a.act = FMX_ACT_NONE;
+    a.out = (char*)out + ((long)py * 2 * w + px) * nout * 2;      // pixel (py, px) of the [n][2h][2w][nout] output
+    a.ld_out = 2 * nout;                                          // the next pixel of this phase is two pixels on
+    a.zero_page = zero_page;
+    const ScatterSpec sc{1 - px, w, (long)2 * w * nout, nch};     // ... and its next row two rows down: 4 w nout - w * ld_out more per row
+    int got = 0;
+    const int rc = gemm_conv_one(&a, stats ? stats + (long)ph * (per / 256) * nout * 2 : nullptr, nch, 1, &got, stream, nullptr, 0, nullptr, &sc);
+    if (rc != FMX_OK) return rc;
+  }
+  if (stats_nchunks) *stats_nchunks = nch;
+  return FMX_OK;
+}
 
 #ifndef FMX_ELEM_BF16  // the LDM transformer blocks run in fp16
 extern "C" int fmx_gemm_linear_rowstats_f16(const fmx_gemm_args* a, float* row_partial, int32_t parts_cap, int32_t* parts_out, void* stream) {

@@ -74,6 +74,7 @@ struct Geo {
 // FA: the per-tap bit-mask form of the implicit-GEMM addresses (FASTADDR below) on tiles other than 512 x 128 -- single-source convolutions without
 //   upsample-on-load (every 3x3 convolution of the UNet except the decoder's upsamplers): the general form's ~15 vector instructions per
 //   activation piece (two sources, nearest-resize, bounds) become 3, in a K loop that otherwise issues ~10 instructions per MFMA (round 3).
+//   FA = 3 (round 6): FA = 1 with scattered output rows (GemmParams::scat_ow), the four phase convolutions of fmx_conv3x3_up2x.
 //   FA = 2 (round 4): the same for the x2 NEAREST UPSAMPLE ON LOAD of the UNet's / VAE decoder's Upsample convolutions (3x3, stride 1, pad 1 on the
 //   upsampled grid): source row of tap ky is  (iy0 >> 1) + {0, iy0 & 1, 1}[ky]  (iy0 = oy - 1 on the upsampled grid), likewise for columns, so the two
 //   parity bits ride in the mask word (bits 9, 10) and a piece costs 7 vector instructions instead of ~15.
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
       const int rem = mm - img * per;
       const int oy = rem / p.ow;
       const int ox = rem - oy * p.ow;
-      const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+      const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad_x;
       const int lim_h = UP2 ? p.up_h : p.h, lim_w = UP2 ? p.up_w : p.w;   // (UP2: output pixel and taps live on the upsampled grid)
       unsigned mask = 0;
 #pragma unroll
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
       const int ox = rem - oy * p.ow;
       a_pix[s] = img * p.h * p.w;
       const int iy0 = (m < p.M) ? oy * p.stride - p.pad : -20000;  // out-of-range rows fail every bounds check
-      const int ix0 = ox * p.stride - p.pad;
+      const int ix0 = ox * p.stride - p.pad_x;
       a_yx[s] = (iy0 << 16) | (ix0 & 0xffff);
     } else {
       a_pix[s] = (m < p.M) ? m : -1;
@@ -779,8 +780,12 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
       }
       // same wave wrote and reads: LDS operations of one wave execute in order, no barrier needed
       const int mbase = m0 + wm * WROWS + i * BR;
+      // FA = 3 (round 6, fmx_conv3x3_up2x): the BR rows of this block are neighbours in ONE row of the phase's pixel grid (scat_ow % 32 == 0), whose
+      // pixels sit every second pixel of every second row of the output: the row pass keeps `out + m * ld_out`, the block's base moves
+      long scat = 0;
+      if constexpr (FA == 3) scat = (long)(mbase / p.scat_ow) * p.scat_extra;
 #define FMX_EPI_ARGS my, lane, mbase, p.M, nbc, nok, ep.per_img, ep.alpha, (float)ep.mgt, ep.bias + nbc * ep.mb, ep.rowvec + nbc * ep.mrv, ep.ld_rv, \
-                     ep.gate + nbc * ep.mgt, ep.ld_gt, ep.res + nbc * ep.mres, ep.ld_res, ep.out + nbc, ep.ld_out, st
+                     ep.gate + nbc * ep.mgt, ep.ld_gt, ep.res + nbc * ep.mres, ep.ld_res, ep.out + nbc + scat, ep.ld_out, st
       if constexpr (XA) {   // O is final: plain fp16 store (no bias, no LayerNorm arithmetic -- that went into Q)
         epi_rows<RB, LPR, BR, 7, false, 2>(my, lane, mbase, p.M, nbc, nok, ep.per_img, 1.0f, 0.0f, p.zp, p.zp, 0L, p.zp, 0L, p.zp, 0L, ep.out + nbc, ep.ld_out, st);
       } else
@@ -1052,6 +1057,7 @@ int fmx_launch_gemm256p(const GemmParams& p, bool conv, int bm, int bn, hipStrea
     mf = (e && atoi(e) == 32) ? 32 : 16;
   }
   if (p.xa_k) return launch_ln_xa(p, st);
+  if (p.scat_ow && (mf != 16 || !conv)) return fmx_set_error(FMX_E_BADARG, "gemm: scattered output rows exist in the 16x16x32 convolution kernels only");
   if (mf == 16) {
     if (p.row_stats) return launch_ln<1, 16>(p, st);
     if (p.ln_partial) return launch_ln<2, 16>(p, st);
@@ -1060,6 +1066,11 @@ int fmx_launch_gemm256p(const GemmParams& p, bool conv, int bm, int bn, hipStrea
     if (fa < 0) {
       const char* e2 = fmx_knob("FMX_CONV_FASTADDR");   // A/B knob: 0 = the general address form for every convolution of the 256-row tiles (round 2); 3 = not for the x2-upsample convolutions (round 4 A/B)
       fa = e2 ? atoi(e2) : 1;
+    }
+    if (p.scat_ow) {   // a phase convolution of fmx_conv3x3_up2x: the bit-mask address form with scattered output rows (the host sends only eligible launches)
+      if (bm == 256 && bn == 320) return p.stats ? launch_bn<256, 320, true, 0, 1, 16, 3>(p, conv, st) : launch_bn<256, 320, false, 0, 1, 16, 3>(p, conv, st);
+      if (bm == 256 && bn == 256) return p.stats ? launch_bn<256, 256, true, 0, 1, 16, 3>(p, conv, st) : launch_bn<256, 256, false, 0, 1, 16, 3>(p, conv, st);
+      return -1;
     }
     if (fa && conv && p.c1 == 0 && p.up_h == 0 && p.kh <= 3) {   // single source, no resize-on-load: the bit-mask address form
       if (bm == 256 && bn == 320) return p.stats ? launch_bn<256, 320, true, 0, 1, 16, 1>(p, conv, st) : launch_bn<256, 320, false, 0, 1, 16, 1>(p, conv, st);

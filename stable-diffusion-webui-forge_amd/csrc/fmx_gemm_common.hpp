@@ -9,6 +9,7 @@ struct GemmParams {
   int c0, c1, s0, s1;  // channels and pixel strides (elements) of the two sources
   int n, h, w, oh, ow;
   int kh, stride, pad;
+  int pad_x;        // horizontal padding (= pad except for the phase convolutions of fmx_conv3x3_up2x, whose 2 x 2 windows start at -1 or 0 per axis)
   int up_h, up_w;
   const f16* wgt;
   int ldw;
@@ -53,6 +54,10 @@ struct GemmParams {
   int xa_k_rs, xa_k_bs, xa_vt_ds, xa_vt_bs, xa_nk, xa_rows;
   unsigned xa_k_bytes, xa_vt_bytes;
   float xa_c2;
+  // scattered output rows (fmx_conv3x3_up2x: a phase's pixels are every second pixel of every second row of the output): row m is stored at
+  // out + m * ld_out + (m / scat_ow) * scat_extra; 0 = off.  8-wave kernels with FA = 3 only, scat_ow a multiple of 32.
+  int scat_ow;
+  long scat_extra;
   int xtile;                 // persistent 256 x 320 linear kernels: fetch the next output tile's first K-tile under the last K-tile of this one (set by the launcher)
 };
 

@@ -789,6 +789,65 @@ def conv3x3_narrow(x, wgt, bias, nout, out=None, ld_out=4):
     return out
 
 
+# A/B knob: FMX_UP2X=0 keeps the Upsample convolutions on the implicit GEMM with nearest-upsample-on-load (9 taps per output pixel, round 4's path)
+_UP2X = _lib.knob("FMX_UP2X", "1") != "0"
+
+
+def fold_up2x_weights(wk, c):
+    """[nout, 9 * c] (the GEMM layout: taps (ky, kx) row-major, then channels) -> [4, nout, 4 * c]: the tap sums of the four parity phases of
+    conv3x3(nearest_upsample_x2(x)) -- phase 2 * py + px, its 2 x 2 taps (dy, dx) row-major (include/fmx.h fmx_conv3x3_up2x).  Even output rows
+    see input rows {iy - 1, iy} through {w[0], w[1] + w[2]}, odd ones {iy, iy + 1} through {w[0] + w[1], w[2]}; columns alike.  Summed in fp32,
+    rounded ONCE to the element type."""
+    nout = wk.shape[0]
+    w = wk.reshape(nout, 3, 3, c).float()
+
+    def fold(t, dim, parity):
+        a, b, d = t.unbind(dim)
+        return torch.stack([a, b + d] if parity == 0 else [a + b, d], dim)
+    phases = [fold(fold(w, 1, py), 2, px).reshape(nout, 4 * c) for py in (0, 1) for px in (0, 1)]
+    return torch.stack(phases).to(wk.dtype).contiguous()
+
+
+def conv3x3_up2x_eligible(x, nout, out_hw=None):
+    """the four-phase form of an Upsample convolution (fmx_conv3x3_up2x) takes: an exact x2 output, input channels in 64s, an input width in 32s,
+    a whole number of 256-pixel statistics chunks per image, an input within one launch's 32-bit offsets"""
+    if not _UP2X or x.dim() != 4 or not x.is_contiguous():
+        return False
+    n, h, w, c = x.shape
+    if out_hw is not None and tuple(out_hw) != (2 * h, 2 * w):
+        return False
+    return c % 64 == 0 and w % 32 == 0 and nout % 8 == 0 and (h * w) % 256 == 0 and x.numel() * 2 < 3.0e9
+
+
+def conv3x3_up2x(x, w4, bias, nout, *, stats=True, stats_partial=None):
+    """conv3x3(pad 1) of the x2 nearest-upsampled x as four 2 x 2 convolutions on x's own grid (backend/nn/unet.py:340-355, backend/nn/vae.py:42-57):
+    x NHWC [n, h, w, c], w4 from fold_up2x_weights -> (out [n * 2h * 2w, nout], GnStats of out | None)."""
+    sfx, elem = _elem(x, w4, bias)
+    n, h, w, c = x.shape
+    assert w4.shape == (4, nout, 4 * c) and w4.is_contiguous()
+    out = empty((n * 4 * h * w, nout), elem, x.device)
+    st = None
+    partial, cap = None, 0
+    if stats and _FUSED_STATS:
+        cap = _stats_geometry(n, 4 * h * w)[1]
+        partial = stats_partial if stats_partial is not None else empty((n, cap, nout, 2), torch.float32, x.device)
+        cap = partial.numel() // (n * nout * 2)
+        st = GnStats(partial, 0)
+    nch = C.c_int32(0)
+    name = "fmx_conv3x3_up2x" + sfx
+
+    def run():
+        _lib.check(getattr(_lib.lib(), name)(_p(x), n, h, w, c, _p(w4), _p(bias), nout, _p(out), _p(partial), cap, C.byref(nch), _p(zero_page(x.device)),
+                                            stream_ptr()), name)
+        if st is not None:
+            st.nchunks = nch.value
+    if _profiler is not None:   # the multiply-adds EXECUTED: 4 taps per output pixel (the reference's form of the layer has 9)
+        _profiler.launch("gemm_conv", 2.0 * n * 4 * h * w * nout * 4 * c, run, tag=f"M={n * 4 * h * w} N={nout} K={4 * c} kh=2 s=1 up2x-phases{' +gnstats' if st is not None else ''}")
+    else:
+        run()
+    return (out, st) if stats else out
+
+
 # A/B knob: FMX_CONV_GN_FUSE=0 keeps GroupNorm apply + implicit-GEMM convolution as two launches where conv3x3_gn_silu is eligible (round 5's path)
 _CONV_GN_FUSE = _lib.knob("FMX_CONV_GN_FUSE", "1") != "0"
 

@@ -59,7 +59,7 @@ def run():
     finally:
         net.tap = None
     outs, nat = {}, {}
-    o16.unet_forward(sd, cfg, x, t, ctx, None, fold=dict(net.fold_trace), teacher=taps, layer_out=outs, native_view=nat)
+    o16.unet_forward(sd, cfg, x, t, ctx, None, fold=dict(net.fold_trace), teacher=taps, layer_out=outs, native_view=nat, up2x=net.up2x_trace)
     worst_rms = worst_pp = 0.0
     bad = []
     for key, ref in outs.items():

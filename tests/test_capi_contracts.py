@@ -108,6 +108,16 @@ def test_other_contract_violations(lib):
         assert fn(cg(ld_out=64), None, None) == BADARG and "leading dimensions" in err()
         assert fn(cg(out=FAKE + 2), None, None) == BADARG and "alignment" in err()
         assert fn(cg(stats=FAKE, stats_cap=8), None, None) == BADARG and "16 tiles" in err()       # 64 x 64 pixels = 8 x 2 tiles
+    # the Upsample convolution as four phase convolutions (ABI 11): channel granules, an input width in 32s, whole statistics chunks
+    f = C.c_void_p(FAKE)
+    for sfx in ("_f16", "_bf16"):
+        fn = getattr(lib, "fmx_conv3x3_up2x" + sfx)
+        assert fn(p, 1, 16, 32, 96, p, None, 64, p, None, 0, None, p, None) == BADARG and "multiple of 64" in err()
+        assert fn(p, 1, 16, 40, 64, p, None, 64, p, None, 0, None, p, None) == BADARG and "multiple of 32" in err()
+        assert fn(p, 1, 5, 32, 64, p, None, 64, p, f, 64, None, p, None) == BADARG and "multiple of 256" in err()
+        assert fn(p, 1, 16, 32, 64, p, None, 64, p, f, 4, None, p, None) == BADARG and "four phases write 8" in err()
+        assert fn(p, 16, 1024, 1024, 128, p, None, 64, p, None, 0, None, p, None) == BADARG and "split the batch" in err()
+        assert fn(p, 1, 16, 32, 64, p, None, 64, p, None, 0, None, None, None) == BADARG
     # GroupNorm: a second source needs its own statistics; channel / group / stride geometry
     f = C.c_void_p(FAKE)
     assert lib.fmx_groupnorm_apply_f16(p, p, 64, 64, 64, 64, 1, 16, f, 1, None, 0, 32, 1e-5, p, p, 0, f, p, None) == BADARG and "second source" in err()

@@ -1181,6 +1181,45 @@ def test_groupnorm_silu_conv3x3_in_one_kernel(n, hh, ww, cin, with_res, dtype):
     close(nxt, nxt2.float(), 4 * e, 4 * e, "second fused launch on the first one's statistics")
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("n,hh,ww,c,nout", [(2, 32, 32, 64, 320), (1, 16, 64, 128, 256), (2, 8, 32, 64, 128), (1, 32, 96, 64, 640), (3, 16, 32, 192, 64), (1, 64, 64, 256, 256)])
+def test_upsample_conv_as_four_phase_convolutions(n, hh, ww, c, nout, dtype):
+    """fmx_conv3x3_up2x (round 6): conv3x3(pad 1) of the x2 nearest-upsampled input (/root/reference/backend/nn/unet.py:340-355, nn/vae.py:42-57) as four
+    2 x 2 convolutions on the input grid with tap-summed weights, each writing every second pixel of every second output row.  Against F.conv2d of
+    F.interpolate in fp32; against the same four convolutions evaluated in fp32 on the SAME rounded tap sums (what is left is accumulation order and
+    the output rounding); against the nine-tap implicit-GEMM path it replaces; the GroupNorm statistics of the scattered output against sums over it."""
+    x = rnd(n, hh, ww, c, seed=340).to(dtype)
+    wt = rnd(nout, c, 3, 3, scale=1 / math.sqrt(9 * c), seed=341).to(dtype)
+    wk = wt.permute(0, 2, 3, 1).reshape(nout, -1).contiguous()
+    bias = rnd(nout, seed=342).to(dtype)
+    w4 = ops.fold_up2x_weights(wk, c)
+    assert ops.conv3x3_up2x_eligible(x, nout)
+    out, st = ops.conv3x3_up2x(x, w4, bias, nout)
+    e = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    xu = F.interpolate(x.permute(0, 3, 1, 2).float(), scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xu, wt.float(), bias.float(), padding=1).permute(0, 2, 3, 1).reshape(-1, nout)
+    close(out, ref, 3 * e, 3 * e, "four phase convolutions vs conv3x3 of the upsampled input (fp32)")
+    # the arithmetic it implements, in fp32 on the rounded tap sums
+    same = torch.empty(n, nout, 2 * hh, 2 * ww, device=DEV)
+    xl = x.permute(0, 3, 1, 2).float()
+    for ph in range(4):
+        py, px = ph >> 1, ph & 1
+        wp = w4[ph].float().view(nout, 2, 2, c).permute(0, 3, 1, 2)
+        same[:, :, py::2, px::2] = F.conv2d(F.pad(xl, (1 - px, px, 1 - py, py)), wp, bias.float())
+    same = same.permute(0, 2, 3, 1).reshape(-1, nout)
+    d = (out.float() - same).abs()
+    ulp = torch.maximum(same.abs(), torch.tensor(2.0 ** -14, device=DEV)).log2().floor().exp2() * e
+    assert bool((d <= ulp + 1e-5 * float(same.pow(2).mean().sqrt())).all()), f"vs the same sums in fp32: max {float((d / ulp).max()):.2f} ulp"
+    # the path it replaces: nine taps on the upsample-on-load address form (another rounding of the weights: the sums)
+    old = ops.conv_gemm(x, wk, nout, kh=3, pad=1, up=(2 * hh, 2 * ww), bias=bias)
+    close(out, old.float(), 3 * e, 3 * e, "four phase convolutions vs the nine-tap upsample-on-load path")
+    assert st.nchunks == 4 * hh * ww // 256
+    o = out.view(n, 4 * hh * ww, nout).double()
+    want = torch.stack([o.sum(1), (o * o).sum(1)], -1)
+    torch.testing.assert_close(_partial_to_sums(st, n, nout), want, rtol=2e-5, atol=2e-3)
+    assert not ops.conv3x3_up2x_eligible(x[:, :, :24].contiguous(), nout) and not ops.conv3x3_up2x_eligible(x, nout, (2 * hh + 1, 2 * ww))
+
+
 def test_narrow_output_conv3x3_contract():
     x = rnd(1, 8, 8, 80, seed=1)
     with pytest.raises(Exception, match="multiple of 32"):

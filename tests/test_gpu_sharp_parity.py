@@ -80,6 +80,10 @@ def _log(rec):
             f.write(json.dumps(rec) + "\n")
 
 
+UP2X = set()      # the Upsample layers the LAST native forward ran as four phase convolutions (IntegratedUNet2DConditionModel.up2x_trace): a weight-rounding
+                  # site the oracle has to be told about, like `fold`
+
+
 def native_forward_with_taps(net, x, t, ctx, y):
     taps = {}
     net.tap = lambda name, tens: taps.__setitem__(name, tens.detach().to("cpu", copy=True))
@@ -87,6 +91,8 @@ def native_forward_with_taps(net, x, t, ctx, y):
         eps = net.forward(x.to(DEV), t.to(DEV), context=ctx.to(DEV), y=None if y is None else y.to(DEV))
     finally:
         net.tap = None
+    UP2X.clear()
+    UP2X.update(net.up2x_trace)
     return eps.float().cpu(), taps, dict(net.fold_trace)
 
 
@@ -94,7 +100,7 @@ def layerwise(sd, cfg, x, t, ctx, y, taps, fold, plant=None):
     """-> {layer: metrics of native vs oracle on the native layer's own inputs}"""
     from oracle import unet_fp16sites as o16
     outs, nat = {}, {}
-    o16.unet_forward(sd, cfg, x, t, ctx, y, fold=fold, plant=plant, teacher=taps, layer_out=outs, native_view=nat)
+    o16.unet_forward(sd, cfg, x, t, ctx, y, fold=fold, plant=plant, teacher=taps, layer_out=outs, native_view=nat, up2x=UP2X)
     res = {key: parity.metrics(nat[key], ref) for key, ref in outs.items() if key in nat}
     missing = set(taps) - set(outs)
     assert not missing, f"executor layers the oracle did not visit: {sorted(missing)}"
@@ -148,13 +154,13 @@ def _run_case(name, cfg, sd, x, t, ctx, y, floor_key, whole_network=True):
     kr, rms, kp, pp = _worst(res)
     nf = sum(int(f) for v in fold.values() for f in v)
     fl = parity.FLOORS[floor_key]
-    rec = {"name": f"sharp layer-wise: {name}", "layers": len(res), "folded_norms": nf, "worst_rms_rel": round(rms, 8), "worst_rms_layer": kr,
+    rec = {"name": f"sharp layer-wise: {name}", "layers": len(res), "folded_norms": nf, "upsample_convs_as_phase_convolutions": sorted(UP2X), "worst_rms_rel": round(rms, 8), "worst_rms_layer": kr,
            "worst_pp_rel": round(pp, 8), "worst_pp_layer": kp, "median_rms_rel": round(sorted(v["rms_rel"] for v in res.values())[len(res) // 2], 8),
            "floor_rms_rel": fl["rms_rel"], "worst_rms_over_floor": round(rms / fl["rms_rel"], 4), "gate": {"rms_rel": SHARP_RMS, "rms_rel_attention_outputs": SHARP_RMS_ATTN, "pp_rel": SHARP_PP},
            "oracle_seconds": round(time.time() - t0, 1), "by_kind": by_kind(res)}
     if whole_network:
         t0 = time.time()
-        free = o16.unet_forward(sd, cfg, x, t, ctx, y, fold=fold)
+        free = o16.unet_forward(sd, cfg, x, t, ctx, y, fold=fold, up2x=UP2X)
         m = parity.metrics(eps, free)
         rec["whole_network_free_running"] = {**{k: round(v, 7) for k, v in m.items()}, "rms_over_floor": round(m["rms_rel"] / fl["rms_rel"], 4),
                                             "oracle_seconds": round(time.time() - t0, 1)}
@@ -257,6 +263,8 @@ def native_forward_with_taps_of(net, x, t, ctx, y, images, prefix=""):
         eps = net.forward(x.to(DEV), t.to(DEV), context=ctx.to(DEV), y=y.to(DEV))
     finally:
         net.tap = None
+    UP2X.clear()
+    UP2X.update(net.up2x_trace)
     return eps.float().cpu(), taps, dict(net.fold_trace), hipops.LN_FOLDED_LAUNCHES - before
 
 
@@ -283,7 +291,7 @@ def test_sdxl_bench_batch_with_the_layernorm_folds_live_layer_by_layer(sdxl_sd):
     kr, rms, kp, pp = _worst(res)
     fl = parity.FLOORS["sdxl_full_fwd.pt:eps"]
     rec = {"name": f"sharp layer-wise: SDXL full size at the bench's UNet batch {BENCH_BATCH}, images {sel} (LayerNorm folds live)", "layers": len(res),
-           "folded_norms": nf, "folded_gemm_launches": launches, "worst_rms_rel": round(rms, 8), "worst_rms_layer": kr, "worst_pp_rel": round(pp, 8),
+           "folded_norms": nf, "folded_gemm_launches": launches, "upsample_convs_as_phase_convolutions": sorted(UP2X), "worst_rms_rel": round(rms, 8), "worst_rms_layer": kr, "worst_pp_rel": round(pp, 8),
            "worst_pp_layer": kp, "median_rms_rel": round(sorted(v["rms_rel"] for v in res.values())[len(res) // 2], 8), "floor_rms_rel": fl["rms_rel"],
            "worst_rms_over_floor": round(rms / fl["rms_rel"], 4), "gate": {"rms_rel": SHARP_RMS, "rms_rel_attention_outputs": SHARP_RMS_ATTN, "pp_rel": SHARP_PP},
            "oracle_seconds": round(time.time() - t0, 1), "by_kind": by_kind(res)}

@@ -51,7 +51,7 @@ def _layerwise(cfg, z, plant=None, seed=1, scale_conv_in=None):
     assert torch.isfinite(out).all()
     t0 = time.time()
     mine = {}
-    v16.vae_decode(sd, z, teacher=taps, layer_out=mine, plant=plant)
+    v16.vae_decode(sd, z, teacher=taps, layer_out=mine, plant=plant, up2x=vae.up2x_trace)   # (which Upsample convolutions ran as four phase convolutions)
     secs = time.time() - t0
     # (the materialised attention of widths other than 512 computes V^T image by image inside its loop: no tap for it)
     assert set(taps) <= set(mine) and set(mine) - set(taps) <= {"decoder.mid.attn_1.v"}, sorted(set(mine) ^ set(taps))
@@ -90,8 +90,11 @@ def test_sdxl_vae_layer_by_layer(lat):
     """the SDXL decoder at 512^2 and at 1024^2 (the bench's decode: fused 512-wide attention over 4 096 / 16 384 tokens, 512x128 tiles, the direct conv_out)"""
     g = torch.Generator("cpu").manual_seed(7)
     z = torch.randn(1, 4, lat, lat, generator=g) * 0.9
-    m, secs, _ = _layerwise(synth.SDXL_VAE_CONFIG, z)
-    _summary(f"sharp layer-wise VAE decode: SDXL VAE, {8 * lat}^2", m, secs)
+    m, secs, vae = _layerwise(synth.SDXL_VAE_CONFIG, z)
+    from forge_amd import hipops as _ops
+    if _ops._UP2X:
+        assert len(vae.up2x_trace) == 3, vae.up2x_trace      # every Upsample convolution of the decoder runs as four phase convolutions at these sizes
+    _summary(f"sharp layer-wise VAE decode: SDXL VAE, {8 * lat}^2 ({len(vae.up2x_trace)} Upsample convolutions as phase convolutions)", m, secs)
     assert not _over(m), {k: m[k] for k in _over(m)}
 
 

@@ -156,3 +156,34 @@ def test_planted_bugs_inside_the_layernorm_fold_are_visible_at_their_layer():
         layer = fold_planted_layer(plant)
         print(pname, layer, m[layer], failing)
         assert failing == [layer], (pname, failing, m[layer])
+
+
+def test_upsample_conv_as_four_phase_convolutions_is_the_same_function():
+    """The Upsample convolution on tap-summed weights (fmx_conv3x3_up2x; oracle site `up2x`): with rounding off it IS interpolate + conv3x3 (fp32
+    summation order apart); the native weight fold (forge_amd.hipops.fold_up2x_weights: [4][nout][2][2][c]) holds exactly the oracle's tap sums; with
+    rounding on, the extra rounding of the sums moves the network output by a fraction of the fp16 floor."""
+    import torch.nn.functional as F
+    from forge_amd import hipops
+    g = torch.Generator().manual_seed(3)
+    x, w, b = torch.randn(2, 6, 5, 7, generator=g), torch.randn(4, 6, 3, 3, generator=g), torch.randn(4, generator=g)
+    xu = F.interpolate(x, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xu, w, b, padding=1)
+    torch.testing.assert_close(o16.up2x_phase_conv(xu, w, b, lambda t: t), ref, rtol=1e-5, atol=2e-5)
+    w4 = hipops.fold_up2x_weights(w.permute(0, 2, 3, 1).reshape(4, -1).contiguous(), 6)
+    out = torch.empty_like(ref)
+    for ph in range(4):
+        py, px = ph >> 1, ph & 1
+        out[:, :, py::2, px::2] = F.conv2d(F.pad(x, (1 - px, px, 1 - py, py)), w4[ph].view(4, 2, 2, 6).permute(0, 3, 1, 2), b)
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=2e-5)
+    cfg, gg, sd = _case("tiny_sdxl")
+    ups = sorted({k[:-len(".conv.weight")] for k in sd if k.endswith(".conv.weight")})
+    assert ups
+    plain = o16.unet_forward(sd, cfg, gg["x"], gg["t"], gg["ctx"], gg["y"])
+    phased = o16.unet_forward(sd, cfg, gg["x"], gg["t"], gg["ctx"], gg["y"], up2x=ups)
+    m = parity.metrics(phased, plain)
+    fl = parity.FLOORS["tiny_sdxl_unet_fwd.pt:eps"]
+    print("up2x vs plain", m, "floor", fl["rms_rel"])
+    assert 0 < m["rms_rel"] <= 1.0 * fl["rms_rel"]
+    assert parity.metrics(phased, gg["eps"])["rms_rel"] <= 1.3 * fl["rms_rel"]
+    assert torch.equal(o16.unet_forward(sd, cfg, gg["x"], gg["t"], gg["ctx"], gg["y"], rounding=False, up2x=ups),
+                       o16.unet_forward(sd, cfg, gg["x"], gg["t"], gg["ctx"], gg["y"], rounding=False))
