@@ -46,7 +46,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# algorithmic FLOP per sample-forward (FlopCounterMode on the reference modules)
+# algorithmic FLOP per sample-forward (FlopCounterMode on the reference modules).  `step_tflops_per_gpu` / `step_frac_of_mfma_peak` are quoted on
+# THIS count (the work the reference's formulation of the network does per step); `roofline.achieved` counts the multiply-adds the kernels EXECUTE, which since round 6
+# are fewer: the Upsample convolutions run as four 2 x 2 phase convolutions = 4 / 9 of the reference form's (SDXL: -1.1 % of a forward's FLOP)
 FLOPS_PER_SAMPLE_FWD = {"sdxl": 6.7612e12, "sd15": 0.8033e12, "flux": 69.47e12}
 MFMA_PEAK = 2.5e15
 HBM_PEAK = 8.0e12

@@ -152,10 +152,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gn_patch_kernel(const PatchCon
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       f16x8 wf[8], af[4];
+      // (the block / pixel-block offsets are multiples of 128 and leave bit 6 alone: one base per k-step, every read an immediate offset)
+      const char* wks = smem + (wo ^ (ks * 64));
+      const char* pks = smem + (po ^ (ks * 64));
 #pragma unroll
-      for (int cb = 0; cb < 8; ++cb) wf[cb] = *reinterpret_cast<const f16x8*>(smem + ((wo + cb * 2048) ^ (ks * 64)));
+      for (int cb = 0; cb < 8; ++cb) wf[cb] = *reinterpret_cast<const f16x8*>(wks + cb * 2048);
 #pragma unroll
-      for (int pb = 0; pb < 4; ++pb) af[pb] = *reinterpret_cast<const f16x8*>(smem + ((po + ((pb >> 1) * PW + (pb & 1) * 16) * (CC * 2)) ^ (ks * 64)));
+      for (int pb = 0; pb < 4; ++pb) af[pb] = *reinterpret_cast<const f16x8*>(pks + ((pb >> 1) * PW + (pb & 1) * 16) * (CC * 2));
 #pragma unroll
       for (int pb = 0; pb < 4; ++pb)
 #pragma unroll

@@ -28,6 +28,11 @@ for w in "$@"; do
                (cd /tmp && export TMPDIR=/tmp && FMX_ATTN_WS_ROT=$E timeout 300 rocprofv3 --kernel-trace --pmc "$@" -f csv -d $O/rot$E/pmc_$name -o pmc -- python $R/tools/pmc_attn128.py > $O/rot$E/pmc_$name.log 2>&1); tail -1 $O/rot$E/pmc_$name.log | cut -c1-200
                find $O/rot$E/pmc_$name -name '*kernel_trace.csv' -delete; done
              python tools/pmc_mfma_summary.py $O/rot$E > $O/pmc_attn128_rot$E.json; cat $O/pmc_attn128_rot$E.json | head -40; done;;
+    pmc_py) mkdir -p $O/$PMCTAG; for PASS in "mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" "waves SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA" "lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_WAVE_CYCLES"; do
+               set -- $PASS; name=$1; shift
+               (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --pmc "$@" -f csv -d $O/$PMCTAG/pmc_$name -o pmc -- python $R/$PMCPY > $O/$PMCTAG/pmc_$name.log 2>&1); tail -1 $O/$PMCTAG/pmc_$name.log | cut -c1-200
+               find $O/$PMCTAG/pmc_$name -name '*kernel_trace.csv' -delete; done
+             python tools/pmc_mfma_summary.py $O/$PMCTAG > $O/pmc_$PMCTAG.json; cat $O/pmc_$PMCTAG.json | head -60;;
     kbvar) for L in "" $KBLIBS; do FMX_LIB=$L timeout 600 python tools/bench_kernels.py $KB >> $O/kbvar_$KB.jsonl 2>> $O/kbvar_$KB.err; done; cat $O/kbvar_$KB.jsonl | cut -c1-500; tail -3 $O/kbvar_$KB.err;;
     pyt) eval timeout 1200 python -m pytest $PYT -m gpu -q --tb=short -s 2>&1 | grep -v "^\[parity\]" | tail -40 > $O/pyt.log; tail -30 $O/pyt.log | cut -c1-600;;
     prof) (cd /tmp && export TMPDIR=/tmp && timeout 1200 rocprofv3 --kernel-trace --stats -f csv -d $O/prof -o kt -- \

@@ -32,7 +32,7 @@ def main(root):
     dur = collections.defaultdict(dict)
     for sub in sorted(os.listdir(root)):
         f = os.path.join(root, sub, "pmc_counter_collection.csv")
-        if sub not in ("pmc_mfma", "pmc_waves") or not os.path.exists(f):   # (the FETCH / WRITE passes profile another workload: bench.py)
+        if sub not in ("pmc_mfma", "pmc_waves", "pmc_lds") or not os.path.exists(f):   # (the FETCH / WRITE passes profile another workload: bench.py)
             continue
         rows = list(csv.DictReader(open(f)))
         # the 8-wave GEMM kernels are persistent since round 3 (grid = one workgroup per CU whatever the problem), so the grid no longer tells
@@ -69,6 +69,12 @@ def main(root):
             for c, n in (("SQ_ACTIVE_INST_ANY", "wave_time_issuing"), ("SQ_WAIT_INST_ANY", "wave_time_issue_stalled"), ("SQ_WAIT_ANY", "wave_time_waitcnt_or_barrier")):
                 if c in m:
                     o[n] = round(m[c] / m["SQ_WAVE_CYCLES"], 3)
+        if m.get("SQ_LDS_IDX_ACTIVE"):
+            o["lds_bank_conflict_over_active"] = round(m.get("SQ_LDS_BANK_CONFLICT", 0.0) / m["SQ_LDS_IDX_ACTIVE"], 4)
+            if "GRBM_GUI_ACTIVE" in m or "kernel_cycles" in o:
+                pass
+        if m.get("SQ_WAVE_CYCLES") and "SQ_WAIT_INST_LDS" in m:
+            o["wave_time_waiting_on_lds"] = round(m["SQ_WAIT_INST_LDS"] / m["SQ_WAVE_CYCLES"], 3)
         o["raw"] = {c: round(v) for c, v in m.items()}
         out[key] = o
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
