@@ -808,15 +808,26 @@ def fold_up2x_weights(wk, c):
     return torch.stack(phases).to(wk.dtype).contiguous()
 
 
-def conv3x3_up2x_eligible(x, nout, out_hw=None):
+def conv3x3_up2x_supported(x, nout, out_hw=None):
     """the four-phase form of an Upsample convolution (fmx_conv3x3_up2x) takes: an exact x2 output, input channels in 64s, an input width in 32s,
     a whole number of 256-pixel statistics chunks per image, an input within one launch's 32-bit offsets"""
-    if not _UP2X or x.dim() != 4 or not x.is_contiguous():
+    if x.dim() != 4 or not x.is_contiguous():
         return False
     n, h, w, c = x.shape
     if out_hw is not None and tuple(out_hw) != (2 * h, 2 * w):
         return False
     return c % 64 == 0 and w % 32 == 0 and nout % 8 == 0 and (h * w) % 256 == 0 and x.numel() * 2 < 3.0e9
+
+
+def conv3x3_up2x_eligible(x, nout, out_hw=None):
+    """... and where the executors USE it: launches that fill the chip.  A phase is a launch of its own on 256-row tiles (n h w / 256 x ceil(nout / 320) of
+    them); the nine-tap form is ONE launch with four times the rows.  Measured (profiles/r50_small_batch_breakdowns.jsonl): 32 tiles per phase (SDXL at
+    UNet batch 2) 0.51 ms = 210 TFLOP/s against ~0.40 ms for the nine taps; 64 tiles per phase (SD1.5 at UNet batch 8) level; 256 / 512 tiles
+    (SDXL at UNet batch 16) 0.65 + 0.70 ms against 1.48 + 1.39.  From 128 tiles per phase on."""
+    if not _UP2X or not conv3x3_up2x_supported(x, nout, out_hw):
+        return False
+    n, h, w, _ = x.shape
+    return (n * h * w // 256) * -(-nout // 320) >= 128
 
 
 def conv3x3_up2x(x, w4, bias, nout, *, stats=True, stats_partial=None):

@@ -93,7 +93,7 @@ def test_sdxl_vae_layer_by_layer(lat):
     m, secs, vae = _layerwise(synth.SDXL_VAE_CONFIG, z)
     from forge_amd import hipops as _ops
     if _ops._UP2X:
-        assert len(vae.up2x_trace) == 3, vae.up2x_trace      # every Upsample convolution of the decoder runs as four phase convolutions at these sizes
+        assert len(vae.up2x_trace) == (3 if lat == 128 else 2), vae.up2x_trace      # the Upsample convolutions whose phases fill the chip (>= 128 tiles each) run as phase convolutions
     _summary(f"sharp layer-wise VAE decode: SDXL VAE, {8 * lat}^2 ({len(vae.up2x_trace)} Upsample convolutions as phase convolutions)", m, secs)
     assert not _over(m), {k: m[k] for k in _over(m)}
 
