@@ -410,6 +410,13 @@ int fmx_conv3x3_gn_silu_f16(const fmx_conv_gn_args* args /* host */, int32_t* st
  * Runs on the 256-row implicit-GEMM kernels (their bit-mask address form, K = 4 c) with scattered output rows. */
 int fmx_conv3x3_up2x_f16(const void* x, int32_t n, int32_t h, int32_t w, int32_t c, const void* wgt4, const void* bias, int32_t nout, void* out,
                          float* stats, int32_t stats_cap, int32_t* stats_nchunks /* host, may be null */, const void* zero_page, void* stream);
+/* fmx_conv3x3_narrow_f16 on silu(group_norm(x)) without storing it (ABI 11): the `norm_out -> swish -> conv_out` tail of the VAE decoder (backend/nn/vae.py:266-271)
+ * and of the UNet (`out`, backend/nn/unet.py:760-764).  x is the UN-normalised tensor with its chunk statistics x_partial [n][x_nchunks][c][2]; the (image, channel)
+ * {scale, shift} table is written to scale_shift [n][c][2] (fp32 workspace) and applied while the tile's input patch is staged in LDS, with fmx_groupnorm_apply's
+ * arithmetic and rounding (the staged values are the tensor the two-launch form stores; zeros outside the image).  Other arguments as fmx_conv3x3_narrow_f16. */
+int fmx_conv3x3_narrow_gn_silu_f16(const void* x, int32_t n, int32_t h, int32_t w, int32_t c, const float* x_partial, int32_t x_nchunks, int32_t groups, float eps,
+                                   const void* gamma, const void* beta, float* scale_shift, const void* wgt, const void* bias, int32_t nout, void* out,
+                                   int32_t ld_out, void* stream);
 /* VAE output: y fp16 NHWC [b*h*w][ld] (first c channels) -> clamp((y+1)/2, 0, 1) fp32 NHWC [b][h][w][c] */
 int fmx_vae_unpack_image(const void* y, int32_t ld, int64_t npix, int32_t c, float* out, void* stream);
 
@@ -470,6 +477,9 @@ int fmx_vae_pack_latent_bf16(const float* z, float scaling_factor, float shift, 
 int fmx_vae_unpack_image_bf16(const void* y, int32_t ld, int64_t npix, int32_t c, float* out, void* stream);
 int fmx_conv3x3_narrow_bf16(const void* x, int32_t n, int32_t h, int32_t w, int32_t c, const void* wgt, const void* bias, int32_t nout, void* out,
                             int32_t ld_out, void* stream);
+int fmx_conv3x3_narrow_gn_silu_bf16(const void* x, int32_t n, int32_t h, int32_t w, int32_t c, const float* x_partial, int32_t x_nchunks, int32_t groups, float eps,
+                                    const void* gamma, const void* beta, float* scale_shift, const void* wgt, const void* bias, int32_t nout, void* out,
+                                    int32_t ld_out, void* stream);
 int fmx_conv3x3_up2x_bf16(const void* x, int32_t n, int32_t h, int32_t w, int32_t c, const void* wgt4, const void* bias, int32_t nout, void* out,
                           float* stats, int32_t stats_cap, int32_t* stats_nchunks, const void* zero_page, void* stream);
 int fmx_conv3x3_gn_silu_bf16(const fmx_conv_gn_args* args /* host */, int32_t* stats_nchunks /* host, may be null */, void* stream);

@@ -129,6 +129,7 @@ SIGNATURES = {
     "fmx_im2col3x3_smallc": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "fmx_vae_unpack_image": [_vp, _i32, _i64, _i32, _vp, _vp],
     "fmx_conv3x3_narrow_f16": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp],
+    "fmx_conv3x3_narrow_gn_silu_f16": [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp],
     "fmx_conv3x3_up2x_f16": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _i32, C.POINTER(C.c_int32), _vp, _vp],
     "fmx_conv3x3_gn_silu_f16": [C.POINTER(ConvGnArgs), C.POINTER(C.c_int32), _vp],
     "fmx_blend_masked": [_vp, _vp, _vp, _vp, _vp, _i64, _vp],
@@ -152,7 +153,7 @@ for _n in ("fmx_gemm_conv", "fmx_attention", "fmx_softmax_rows", "fmx_layernorm"
     SIGNATURES[_n + "_bf16"] = SIGNATURES[_n + "_f16"]
 SIGNATURES["fmx_timestep_embedding_bf16"] = SIGNATURES["fmx_timestep_embedding"]
 # bfloat16 build of the VAE (ABI 6)
-for _n in ("fmx_gemm_conv_stats", "fmx_groupnorm_stats", "fmx_groupnorm_apply", "fmx_attention_single_head512", "fmx_conv3x3_narrow", "fmx_conv3x3_gn_silu", "fmx_conv3x3_up2x"):
+for _n in ("fmx_gemm_conv_stats", "fmx_groupnorm_stats", "fmx_groupnorm_apply", "fmx_attention_single_head512", "fmx_conv3x3_narrow", "fmx_conv3x3_gn_silu", "fmx_conv3x3_up2x", "fmx_conv3x3_narrow_gn_silu"):
     SIGNATURES[_n + "_bf16"] = SIGNATURES[_n + "_f16"]
 for _n in ("fmx_vae_pack_latent", "fmx_vae_unpack_image", "fmx_vae_sample_posterior"):
     SIGNATURES[_n + "_bf16"] = SIGNATURES[_n]

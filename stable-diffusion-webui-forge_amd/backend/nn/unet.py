@@ -795,11 +795,20 @@ class IntegratedUNet2DConditionModel:
         if to is not None:
             to["block"] = ("last", 0)
         h = modify(h, "before")
-        if to is not None and to.get("group_norm_wrapper") is not None:
+        oc = lay.out_channels
+        wrapped = to is not None and to.get("group_norm_wrapper") is not None
+        if (not wrapped and oc <= 4 and h.dim() == 4 and h.is_contiguous() and h.shape[-1] % 32 == 0 and ops._CONV_GN_FUSE and ops._attached_stats(h) is not None
+                and h.shape[0] * h.shape[1] * h.shape[2] >= (1 << 16)):
+            # out.0 -> SiLU -> out.2 (unet.py:755-764) in one launch: the normalisation applied while the direct kernel stages its patch (round 6)
+            out = ops.conv3x3_narrow_gn_silu(h, *self.w["out.gn"], 1e-5, self.w["out.conv"][0], self.w["out.conv"][1], oc, ld_out=oc)
+            self._tap("out.2", out.view(bu, hh, ww, -1)[..., :oc])
+            if modifiers:
+                out = modify(out.view(bu, hh, ww, -1)[..., :oc].contiguous(), "after").reshape(bu * hh * ww, oc)
+            return out
+        if wrapped:
             g = self._wrapped_norm(to["group_norm_wrapper"], "out.gn", h, 1e-5, to)       # unet.py:755-758
         else:
             g = ops.groupnorm(h, *self.w["out.gn"], 1e-5, silu=True)
-        oc = lay.out_channels
         cg = g.shape[-1]
         if oc <= 4 and cg % 32 == 0 and g.dim() == 4 and g.is_contiguous() and g.numel() * 2 < 3.0e9:
             # the `out` convolution (320 -> 4 channels, unet.py:760-764) as the direct narrow-output kernel (round 4): the implicit GEMM spent 0.21 ms per step on it

@@ -325,20 +325,26 @@ class IntegratedAutoencoderKL:
                     h, st = ops.conv_gemm(h, self.w[up][0], c, kh=3, pad=1, up=(2 * h2, 2 * w2), bias=self.w[up][1], stats=True)
                 h = ops.attach_stats(h.view(bb, 2 * h2, 2 * w2, c), st)
                 self._tap(up, h)
-        g = ops.groupnorm(h, *self.w["norm_out"], 1e-6, silu=True)
-        co, cin = lay.out_channels, g.shape[-1]
-        if co <= 4 and cin % 32 == 0 and g.numel() * 2 < 3.0e9:
-            # conv_out as a DIRECT 3x3 kernel (round 4): the implicit GEMM spends 2.2 ms per 8 x 1024^2 on a 3-column output (nine-fold im2col gather,
-            # 97 % padding columns); this one stages each input patch once and writes all four columns of [npix, 4] (the pad column as zeros)
-            y = ops.conv3x3_narrow(g, self.w["conv_out"][0], self.w["conv_out"][1], co)
+        co, cin = lay.out_channels, h.shape[-1]
+        nb, oh, ow = h.shape[0], h.shape[1], h.shape[2]
+        if co <= 4 and cin % 32 == 0 and ops._CONV_GN_FUSE and ops._attached_stats(h) is not None and nb * oh * ow >= (1 << 16):
+            # norm_out -> swish -> conv_out in ONE launch (round 6): the normalisation applied while the direct kernel stages its input patch, the
+            # GroupNorm apply pass (one read + one write of the full-resolution tensor) gone; same values, same rounding sites
+            y = ops.conv3x3_narrow_gn_silu(h, *self.w["norm_out"], 1e-6, self.w["conv_out"][0], self.w["conv_out"][1], co)
         else:
-            # [npix, 4] with 3 valid columns: the GEMM epilogue never writes column 3, and the arena hands out recycled bytes -- zeroed, so that the
-            # overflow guard's scan of the whole buffer (ops.count_nonfinite) cannot trip over a stale inf / NaN half-word there
-            y = ops.empty((g.shape[0] * g.shape[1] * g.shape[2], 4), self.dtype)
-            y.zero_()
-            y = ops.conv_gemm(g, self.w["conv_out"][0], co, kh=3, pad=1, bias=self.w["conv_out"][1], out=y, ld_out=4)
+            g = ops.groupnorm(h, *self.w["norm_out"], 1e-6, silu=True)
+            if co <= 4 and cin % 32 == 0 and g.numel() * 2 < 3.0e9:
+                # conv_out as a DIRECT 3x3 kernel (round 4): the implicit GEMM spends 2.2 ms per 8 x 1024^2 on a 3-column output (nine-fold im2col gather,
+                # 97 % padding columns); this one stages each input patch once and writes all four columns of [npix, 4] (the pad column as zeros)
+                y = ops.conv3x3_narrow(g, self.w["conv_out"][0], self.w["conv_out"][1], co)
+            else:
+                # [npix, 4] with 3 valid columns: the GEMM epilogue never writes column 3, and the arena hands out recycled bytes -- zeroed, so that the
+                # overflow guard's scan of the whole buffer (ops.count_nonfinite) cannot trip over a stale inf / NaN half-word there
+                y = ops.empty((nb * oh * ow, 4), self.dtype)
+                y.zero_()
+                y = ops.conv_gemm(g, self.w["conv_out"][0], co, kh=3, pad=1, bias=self.w["conv_out"][1], out=y, ld_out=4)
         if self.tap is not None:
-            self._tap("conv_out", y.view(g.shape[0], g.shape[1], g.shape[2], 4)[..., :co])
+            self._tap("conv_out", y.view(nb, oh, ow, 4)[..., :co])
         return y
 
     def _run(self, z):

@@ -21,6 +21,7 @@
 #define fmx_launch_gn_finalize fmx_launch_gn_finalize_bf16
 #define fmx_conv3x3_gn_silu_f16 fmx_conv3x3_gn_silu_bf16
 #define fmx_conv3x3_up2x_f16 fmx_conv3x3_up2x_bf16
+#define fmx_conv3x3_narrow_gn_silu_f16 fmx_conv3x3_narrow_gn_silu_bf16
 // host-side C++ symbols shared between the GEMM files
 #define fmx_launch_gemm256p fmx_launch_gemm256p_bf16
 #define fmx_launch_gemm4w fmx_launch_gemm4w_bf16

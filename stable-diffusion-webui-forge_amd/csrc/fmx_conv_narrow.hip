@@ -23,9 +23,13 @@ constexpr int PH = TH + 2;
 constexpr int patch_width(int c) { return (TW + 2 + 1024 / (c * 2) - 1) / (1024 / (c * 2)) * (1024 / (c * 2)); }
 
 // C: channels per chunk (staged at once); ctot: channels of the input (a multiple of C)
-template <int C>
+// GN (round 6): the input is the UN-normalised tensor and `ss` its GroupNorm's (image, channel) {scale, shift} table (gn_finalize): the patch is staged
+// through registers -- silu(fma(x, scale, shift)) with gn_apply's own arithmetic and rounding, zeros outside the image -- instead of by LDS-DMA, and the
+// norm_out -> swish -> conv_out tail of the VAE decoder (backend/nn/vae.py:266-271) loses its GroupNorm apply pass (one read + one write of the full-size tensor)
+template <int C, bool GN = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_narrow_kernel(const f16* __restrict__ x, long x_bytes, const f16* __restrict__ wgt, const f16* __restrict__ bias,
-                                                                f16* __restrict__ out, int n, int h, int w, int ctot, int nout, int ld_out, int tiles_x, int tiles_y) {
+                                                                f16* __restrict__ out, int n, int h, int w, int ctot, int nout, int ld_out, int tiles_x, int tiles_y,
+                                                                const float* __restrict__ ss = nullptr) {
   constexpr int PW = patch_width(C);
   constexpr int PIXB = C * 2;                       // bytes per pixel OF A CHUNK (LDS); a pixel of the input is ctot * 2 bytes
   constexpr int PPP = 1024 / PIXB;                  // pixels per 1-KiB DMA piece: 4 (C = 128), 8 (64), 16 (32)
@@ -63,6 +67,43 @@ __global__ __launch_bounds__(256, 2) void conv3x3_narrow_kernel(const f16* __res
       if (row < nout) v = *reinterpret_cast<const f16x8*>(wgt + ((long)row * 9 + tap) * ctot + c0 + c8 * 8);
       *reinterpret_cast<f16x8*>(wl + ((long)row * 9 + tap) * C + c8 * 8) = v;
     }
+    if constexpr (GN) {
+      // ---- input patch through registers: item i = (patch pixel i / CHUNKS, logical chunk i % CHUNKS); 256 % CHUNKS == 0, so a thread keeps ONE chunk ----
+      constexpr int ITEMS = PH * PW * CHUNKS, ITERS = (ITEMS + 255) / 256;
+      const int cc = tid % CHUNKS;
+      const float* ssp = ss + ((long)img * ctot + c0 + cc * 8) * 2;
+      f32x4 sv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sv[i] = *reinterpret_cast<const f32x4*>(ssp + i * 4);   // {scale, shift} of channels 2i, 2i + 1
+      f16x8 v[ITERS];
+      int lo[ITERS];                                         // -1: no item; else LDS byte offset, bit 30 = outside the image
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        const int pi = tid / CHUNKS + it * (256 / CHUNKS);
+        const int pr = pi / PW, q = pi - pr * PW;
+        const int gy = y0 - 1 + pr, gx = x0 - 1 + q;
+        const bool in_patch = pi < PH * PW;
+        const bool ok = in_patch && gy >= 0 && gy < h && gx >= 0 && gx < w;
+        lo[it] = in_patch ? ((pi * PIXB + ((cc ^ (q & (CHUNKS - 1))) << 4)) | (ok ? 0 : (1 << 30))) : -1;
+        if (ok) v[it] = *reinterpret_cast<const f16x8*>(x + (img_base + (long)gy * w + gx) * ctot + c0 + cc * 8);
+      }
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        if (lo[it] < 0) continue;
+        f16x8 r;
+        if (lo[it] & (1 << 30)) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) r[e] = (f16)0.0f;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const f32x4 sq = sv[e >> 1];
+            r[e] = (f16)silu_f(fmaf((float)v[it][e], sq[(e & 1) * 2], sq[(e & 1) * 2 + 1]));   // gn_apply_kernel's arithmetic, bit for bit
+          }
+        }
+        *reinterpret_cast<f16x8*>(patch + (lo[it] & ((1 << 30) - 1))) = r;
+      }
+    } else
     // ---- input patch -> LDS: piece p = (patch row pr, pixels pc * PPP .. + PPP); lane -> pixel lane / CHUNKS, physical chunk lane % CHUNKS ---------
     for (int p = wave; p < PH * PIECES_ROW; p += 4) {       // uniform trip count per wave
       const int pr = p / PIECES_ROW, pc = p - pr * PIECES_ROW;
@@ -125,22 +166,44 @@ __global__ __launch_bounds__(256, 2) void conv3x3_narrow_kernel(const f16* __res
   }
 }
 
-template <int C>
-int launch_narrow(const void* x, long x_bytes, const void* wgt, const void* bias, void* out, int n, int h, int w, int ctot, int nout, int ld_out, hipStream_t st) {
+template <int C, bool GN = false>
+int launch_narrow(const void* x, long x_bytes, const void* wgt, const void* bias, void* out, int n, int h, int w, int ctot, int nout, int ld_out, hipStream_t st,
+                  const float* ss = nullptr) {
   constexpr int SMEM = PH * patch_width(C) * C * 2 + 4 * 9 * C * 2;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_narrow_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_narrow_kernel<C, GN>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     attr = true;
   }
   const int tiles_x = (w + TW - 1) / TW, tiles_y = (h + TH - 1) / TH;
-  hipLaunchKernelGGL(conv3x3_narrow_kernel<C>, dim3((unsigned)(n * tiles_x * tiles_y)), dim3(256), SMEM, st, (const f16*)x, x_bytes, (const f16*)wgt, (const f16*)bias,
-                     (f16*)out, n, h, w, ctot, nout, ld_out, tiles_x, tiles_y);
+  hipLaunchKernelGGL((conv3x3_narrow_kernel<C, GN>), dim3((unsigned)(n * tiles_x * tiles_y)), dim3(256), SMEM, st, (const f16*)x, x_bytes, (const f16*)wgt, (const f16*)bias,
+                     (f16*)out, n, h, w, ctot, nout, ld_out, tiles_x, tiles_y, ss);
   FMX_LAUNCH_CHECK("fmx_conv3x3_narrow_f16");
   return FMX_OK;
 }
 
 }  // namespace
+
+int fmx_launch_gn_finalize(const float* partial, int32_t nchunks, int32_t c, int32_t n, int32_t groups, int32_t hw, float eps, const void* gamma,
+                           const void* beta, float* scale_shift, hipStream_t st);   // fmx_norm.hip
+
+// silu(group_norm(x)) -> conv3x3 with at most 4 output channels, one launch (+ the statistics' finalize): see fmx.h
+extern "C" int fmx_conv3x3_narrow_gn_silu_f16(const void* x, int32_t n, int32_t h, int32_t w, int32_t c, const float* x_partial, int32_t x_nchunks, int32_t groups,
+                                              float eps, const void* gamma, const void* beta, float* scale_shift, const void* wgt, const void* bias, int32_t nout,
+                                              void* out, int32_t ld_out, void* stream) {
+  FMX_REQUIRE(x && wgt && out && x_partial && gamma && beta && scale_shift && n > 0 && h > 0 && w > 0 && x_nchunks >= 1, "conv3x3_narrow_gn_silu: bad arguments");
+  FMX_REQUIRE(nout >= 1 && nout <= 4 && ld_out >= nout, "conv3x3_narrow_gn_silu: 1..4 output channels, ld_out >= nout (got %d, %d)", nout, ld_out);
+  FMX_REQUIRE(c >= 32 && (c % 32) == 0 && c <= 2048 && groups > 0 && (c % groups) == 0, "conv3x3_narrow_gn_silu: input channels must be a multiple of 32 and of the group count (got %d, %d groups)", c, groups);
+  FMX_REQUIRE(fmx_aligned16(x) && fmx_aligned16(wgt) && fmx_aligned16(scale_shift) && (ld_out != 4 || (reinterpret_cast<uintptr_t>(out) & 7u) == 0), "conv3x3_narrow_gn_silu: operands must be 16-byte aligned");
+  FMX_REQUIRE((long)n * ((w + TW - 1) / TW) * ((h + TH - 1) / TH) < (1L << 31), "conv3x3_narrow_gn_silu: too many tiles for one launch (split the batch)");
+  hipStream_t st = (hipStream_t)stream;
+  const int rc = fmx_launch_gn_finalize(x_partial, x_nchunks, c, n, groups, h * w, eps, gamma, beta, scale_shift, st);
+  if (rc != FMX_OK) return rc;
+  const long bytes = (long)n * h * w * c * 2;
+  if ((c % 128) == 0) return launch_narrow<128, true>(x, bytes, wgt, bias, out, n, h, w, c, nout, ld_out, st, scale_shift);
+  if ((c % 64) == 0) return launch_narrow<64, true>(x, bytes, wgt, bias, out, n, h, w, c, nout, ld_out, st, scale_shift);
+  return launch_narrow<32, true>(x, bytes, wgt, bias, out, n, h, w, c, nout, ld_out, st, scale_shift);
+}
 
 extern "C" int fmx_conv3x3_narrow_f16(const void* x, int32_t n, int32_t h, int32_t w, int32_t c, const void* wgt, const void* bias, int32_t nout, void* out,
                                       int32_t ld_out, void* stream) {

@@ -915,6 +915,28 @@ def conv3x3_gn_silu(x, gamma, beta, eps, wgt, bias, *, residual=None, out=None, 
     return out, st
 
 
+def conv3x3_narrow_gn_silu(x, gamma, beta, eps, wgt, bias, nout, *, groups=32, out=None, ld_out=4, stats=None):
+    """conv3x3_narrow on silu(group_norm(x)) without storing it (fmx_conv3x3_narrow_gn_silu): the norm_out -> swish -> conv_out tail of the VAE decoder.  x NHWC with its
+    producer's GnStats (`stats`, or attached to x); FMX_CONV_GN_FUSE=0 (or no statistics) -> the caller keeps groupnorm() + conv3x3_narrow()."""
+    sfx, elem = _elem(x, gamma, beta, wgt, bias)
+    n, h, w, c = x.shape
+    s0 = stats if stats is not None else _attached_stats(x)
+    assert s0 is not None
+    if out is None:
+        out = empty((n * h * w, ld_out), elem, x.device)
+    ss = empty((n, c, 2), torch.float32, x.device)
+    name = "fmx_conv3x3_narrow_gn_silu" + sfx
+
+    def run():
+        _lib.check(getattr(_lib.lib(), name)(_p(x), n, h, w, c, _p(s0.partial), s0.nchunks, groups, float(eps), _p(gamma), _p(beta), _p(ss), _p(wgt), _p(bias), nout,
+                                            _p(out), ld_out, stream_ptr()), name)
+    if _profiler is not None:   # HBM-bound: one read of the input, one write of the [npix, ld_out] output
+        _profiler.launch("conv3x3_narrow", 2.0 * n * h * w * 9 * c * nout, run, tag=f"N={n} H={h} W={w} C={c} nout={nout} gn+silu fused", nbytes=2.0 * n * h * w * (c + ld_out))
+    else:
+        run()
+    return out
+
+
 def vae_unpack_image(y, ld, npix, c, out):
     name = "fmx_vae_unpack_image" + _vae_sfx(y.dtype)
     _lib.check(getattr(_lib.lib(), name)(_p(y), ld, npix, c, _p(out), stream_ptr()), name)

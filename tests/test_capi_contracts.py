@@ -108,6 +108,11 @@ def test_other_contract_violations(lib):
         assert fn(cg(ld_out=64), None, None) == BADARG and "leading dimensions" in err()
         assert fn(cg(out=FAKE + 2), None, None) == BADARG and "alignment" in err()
         assert fn(cg(stats=FAKE, stats_cap=8), None, None) == BADARG and "16 tiles" in err()       # 64 x 64 pixels = 8 x 2 tiles
+    # ... and with GroupNorm + SiLU in its staging (ABI 11)
+    f0 = C.c_void_p(FAKE)
+    assert lib.fmx_conv3x3_narrow_gn_silu_f16(p, 1, 8, 8, 128, f0, 1, 32, 1e-6, p, p, f0, p, None, 5, p, 8, None) == BADARG and "1..4 output" in err()
+    assert lib.fmx_conv3x3_narrow_gn_silu_bf16(p, 1, 8, 8, 96, f0, 1, 64, 1e-6, p, p, f0, p, None, 3, p, 4, None) == BADARG and "group count" in err()
+    assert lib.fmx_conv3x3_narrow_gn_silu_f16(p, 1, 8, 8, 128, None, 1, 32, 1e-6, p, p, f0, p, None, 3, p, 4, None) == BADARG
     # the Upsample convolution as four phase convolutions (ABI 11): channel granules, an input width in 32s, whole statistics chunks
     f = C.c_void_p(FAKE)
     for sfx in ("_f16", "_bf16"):

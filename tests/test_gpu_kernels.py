@@ -1220,6 +1220,28 @@ def test_upsample_conv_as_four_phase_convolutions(n, hh, ww, c, nout, dtype):
     assert not ops.conv3x3_up2x_supported(x[:, :, :24].contiguous(), nout) and not ops.conv3x3_up2x_supported(x, nout, (2 * hh + 1, 2 * ww))
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("n,hh,ww,c,co", [(2, 64, 64, 128, 3), (1, 37, 50, 128, 3), (1, 19, 45, 96, 4), (2, 64, 64, 320, 4), (1, 40, 33, 64, 2)])
+def test_narrow_output_conv3x3_with_groupnorm_silu_in_its_staging(n, hh, ww, c, co, dtype):
+    """fmx_conv3x3_narrow_gn_silu (round 6): the norm_out -> swish -> conv_out tail of the VAE decoder (/root/reference/backend/nn/vae.py:266-271) in one launch --
+    against groupnorm() + conv3x3_narrow() on the same statistics (the staged patch holds the tensor groupnorm() stores; at these sizes the two paths finalise
+    their statistics in different orders, see test_groupnorm_silu_conv3x3_in_one_kernel) and against torch fp32."""
+    x = (rnd(n, hh, ww, c, scale=1.5, seed=350) + 0.3).to(dtype)
+    g, b = (1 + 0.1 * rnd(c, seed=351)).to(dtype), (0.1 * rnd(c, seed=352)).to(dtype)
+    wt = rnd(co, c, 3, 3, scale=1 / math.sqrt(9 * c), seed=353).to(dtype)
+    wk = wt.permute(0, 2, 3, 1).reshape(co, -1).contiguous()
+    bias = rnd(co, seed=354).to(dtype)
+    st = ops.groupnorm_stats(x)
+    out = torch.full((n * hh * ww, 4), float("nan"), dtype=dtype, device=DEV)
+    got = ops.conv3x3_narrow_gn_silu(x, g, b, 1e-6, wk, bias, co, out=out, stats=st)
+    two = ops.conv3x3_narrow(ops.groupnorm(x, g, b, 1e-6, silu=True, stats=st), wk, bias, co)
+    e = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    close(got[:, :co], two[:, :co].float(), 2 * e, 2 * e, "fused vs groupnorm + conv3x3_narrow")
+    assert bool((got[:, co:] == 0).all()), "pad columns must be zero"
+    ref = F.conv2d(F.silu(F.group_norm(x.permute(0, 3, 1, 2).float(), 32, g.float(), b.float(), 1e-6)), wt.float(), bias.float(), padding=1)
+    close(got[:, :co], ref.permute(0, 2, 3, 1).reshape(-1, co), 3 * e, 3 * e, "fused groupnorm + silu + narrow conv3x3 vs torch fp32")
+
+
 def test_narrow_output_conv3x3_contract():
     x = rnd(1, 8, 8, 80, seed=1)
     with pytest.raises(Exception, match="multiple of 32"):
