@@ -7,7 +7,7 @@ rows = [json.loads(ln) for ln in open(sys.argv[1])]
 fl = [r for r in rows if "floor" in r]
 ratio = sorted(((r["rms_rel"] / r["floor"]["rms_rel"], r["name"]) for r in fl if r["floor"]["rms_rel"] > 0), reverse=True)
 med = ratio[len(ratio) // 2][0]
-print(json.dumps({"comparisons": len(rows), "against_a_floor": len(fl), "pp_rel_above_1e-3": sum(r["pp_rel"] > 1e-3 for r in rows),
+print(json.dumps({"comparisons": len(rows), "against_a_floor": len(fl), "pp_rel_above_1e-3": sum(r.get("pp_rel", 0.0) > 1e-3 for r in rows),
                   "rms_below_floor": sum(x < 1.0 for x, _ in ratio), "rms_ratio_median": round(med, 3), "rms_ratio_worst": round(ratio[0][0], 3),
                   "rows_above_floor_in_rms": [(round(x, 3), n) for x, n in ratio if x >= 1.0]}, indent=1))
 keys = ("SDXL 1024x1024 batch 8, eight", "SDXL 1024x1024 30-step", "SDXL unet forward at full size (128x128", "SD1.5 512x512 20-step", "SD1.5 512x512 batch 4",
