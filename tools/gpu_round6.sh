@@ -33,6 +33,9 @@ for w in "$@"; do
                (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --pmc "$@" -f csv -d $O/$PMCTAG/pmc_$name -o pmc -- python $R/$PMCPY > $O/$PMCTAG/pmc_$name.log 2>&1); tail -1 $O/$PMCTAG/pmc_$name.log | cut -c1-200
                find $O/$PMCTAG/pmc_$name -name '*kernel_trace.csv' -delete; done
              python tools/pmc_mfma_summary.py $O/$PMCTAG > $O/pmc_$PMCTAG.json; cat $O/pmc_$PMCTAG.json | head -60;;
+    prof_flux) (cd /tmp && export TMPDIR=/tmp && timeout 1200 rocprofv3 --kernel-trace --stats -f csv -d $O/prof_flux -o kt -- \
+            python $R/bench.py --config flux-b2-bf16 --steps 5 --warmup 2 --no-cpu-baseline --no-rccl-selfcheck --no-roofline > $O/prof_flux_bench.log 2>&1); tail -1 $O/prof_flux_bench.log | cut -c1-300;
+          find $O/prof_flux -name '*kernel_trace.csv' -delete; head -25 $O/prof_flux/kt_kernel_stats.csv | cut -c1-220;;
     kbvar) for L in "" $KBLIBS; do FMX_LIB=$L timeout 600 python tools/bench_kernels.py $KB >> $O/kbvar_$KB.jsonl 2>> $O/kbvar_$KB.err; done; cat $O/kbvar_$KB.jsonl | cut -c1-500; tail -3 $O/kbvar_$KB.err;;
     pyt) eval timeout 1200 python -m pytest $PYT -m gpu -q --tb=short -s 2>&1 | grep -v "^\[parity\]" | tail -40 > $O/pyt.log; tail -30 $O/pyt.log | cut -c1-600;;
     prof) (cd /tmp && export TMPDIR=/tmp && timeout 1200 rocprofv3 --kernel-trace --stats -f csv -d $O/prof -o kt -- \
